@@ -1,0 +1,476 @@
+"""CPU oracle for the Marlin FFT spectral hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement of the reference's algorithm for the hot path named in
+BASELINE.json (`north_star`).  Nothing in the product (`marlin_amd/`, `include/`) may
+import, call, link or execute it; only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` do, and there only as the checker / the reported CPU
+baseline.
+
+Why torch: the reference performs *all* arithmetic through libTorch/ATen calls
+(README.md:3,28 of the reference); it is a third-party dependency that the reference
+does not pin (it takes "all its dependencies provided by MOOSE", README.md:29).  This
+image ships libTorch 2.10.0 (CPU/MKL kernels); the Python API dispatches to the same
+ATen CPU kernels as the C++ API the reference calls, so calling the same ops in the same
+order *is* the reference's CPU path for these functions.  The reference itself cannot be
+compiled here (every TU needs MOOSE/libMesh headers and `moose/` is an empty submodule).
+
+Pinning (see tests/test_oracle_golden.py, runs with -m "not gpu"):
+  * cahnhilliard.h5 gold  (reference test/tests/cahnhilliard/tests:46-57, abs_tol 1e-13)
+  * cahnhilliard.rank0001.h5 gold (2-rank FFT_SLAB, tests:58-70)
+  * mech3d.h5 / mech.h5 gold (test/tests/mechanics/tests:2-21, abs_tol 1e-10)
+  * backandforth / gradient CSV gold, ConjugateGradientTest iteration counts.
+
+All file:line citations are relative to /root/reference.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+F64 = torch.float64
+C128 = torch.complex128
+
+
+# --------------------------------------------------------------------------------------
+# Domain: axes, reciprocal axes, k^2, k-grid, FFT service
+# --------------------------------------------------------------------------------------
+def _align(t: torch.Tensor, dim: int, ndim: int) -> torch.Tensor:
+    """DomainAction::align (src/actions/DomainAction.C:1406-1434): make a 1-D axis broadcastable."""
+    shape = [1] * ndim
+    shape[dim] = t.numel()
+    return t.reshape(shape)
+
+
+class Domain:
+    """Serial (`parallel_mode = NONE`) restatement of DomainAction's math service.
+
+    src/actions/DomainAction.C:226-338 (gridChanged), :853-867 (fftSerial), :1049-1063 (ifft),
+    :1479-1509 (k-grid, k-square).  `slab_c2c=True` reproduces the reciprocal axes of FFT_SLAB
+    mode (all axes `fftfreq`, full c2c transform, :279-281) for a *global* (all ranks
+    concatenated) field.
+    """
+
+    def __init__(self, dim: int, n: Sequence[int], mx: Sequence[float], mn: Sequence[float] = (0.0, 0.0, 0.0),
+                 slab_c2c: bool = False):
+        self.dim = dim
+        self.n = [int(n[d]) if d < dim else 1 for d in range(3)]
+        self.min = [float(mn[d]) for d in range(3)]
+        self.max = [float(mx[d]) if d < dim else 1.0 for d in range(3)]
+        self.slab_c2c = slab_c2c
+        self.dx = [(self.max[d] - self.min[d]) / self.n[d] for d in range(3)]      # :241
+        self.shape = self.n[:dim]
+        # real-space axes: linspace(min+dx/2, max-dx/2, n)  (:246-251)
+        self.axis = []
+        for d in range(3):
+            if d < dim:
+                a = torch.linspace(self.min[d] + self.dx[d] / 2.0, self.max[d] - self.dx[d] / 2.0, self.n[d], dtype=F64)
+                self.axis.append(_align(a, d, dim))
+            else:
+                self.axis.append(torch.tensor([0.0], dtype=F64))
+        # reciprocal axes (:259-293): rfftfreq on the last active axis in NONE mode
+        self.kaxis = []
+        for d in range(3):
+            if d < dim:
+                use_rfft = (d == dim - 1) and not slab_c2c
+                f = (torch.fft.rfftfreq if use_rfft else torch.fft.fftfreq)(self.n[d], self.dx[d], dtype=F64)
+                self.kaxis.append(_align(f * 2.0 * math.pi, d, dim))
+            else:
+                self.kaxis.append(torch.tensor([0.0], dtype=F64))
+        self.rshape = [self.kaxis[d].numel() for d in range(dim)]
+
+    # :1503-1509
+    def k_square(self) -> torch.Tensor:
+        return self.kaxis[0] * self.kaxis[0] + self.kaxis[1] * self.kaxis[1] + self.kaxis[2] * self.kaxis[2]
+
+    # :1479-1501
+    def k_grid(self) -> torch.Tensor:
+        if self.dim == 1:
+            return self.kaxis[0]
+        return torch.stack([self.kaxis[d].expand(self.rshape) for d in range(self.dim)], -1)
+
+    # :853-867 (and the c2c stages of :869-938 when slab_c2c)
+    def fft(self, t: torch.Tensor) -> torch.Tensor:
+        axes = list(range(self.dim))
+        if self.slab_c2c:
+            return torch.fft.fftn(t, dim=axes)
+        if self.dim == 1:
+            return torch.fft.rfft(t, dim=0)
+        if self.dim == 2:
+            return torch.fft.rfft2(t, dim=(0, 1))
+        return torch.fft.rfftn(t, dim=(0, 1, 2))
+
+    # :1049-1063 (and :940-1019 when slab_c2c: ifft + torch::real)
+    def ifft(self, t: torch.Tensor) -> torch.Tensor:
+        if self.slab_c2c:
+            return torch.real(torch.fft.ifftn(t, dim=list(range(self.dim))))
+        if self.dim == 1:
+            return torch.fft.irfft(t, self.shape[0], dim=0)
+        if self.dim == 2:
+            return torch.fft.irfft2(t, self.shape, dim=(0, 1))
+        return torch.fft.irfftn(t, self.shape, dim=(0, 1, 2))
+
+    def value_shape(self, extra: Sequence[int]) -> List[int]:
+        return list(self.shape) + list(extra)
+
+    # DomainAction::average (:1558-1574): mean over the spatial axes
+    def average(self, t: torch.Tensor) -> torch.Tensor:
+        return t.sum(dim=list(range(self.dim))) / float(torch.tensor(self.shape).prod().item())
+
+
+def partition_helper(total: int, weights: Sequence[int]) -> List[int]:
+    """DomainAction::partitionHepler (include/actions/DomainAction.h:247-280)."""
+    ns: List[int] = []
+    remaining = sum(weights)
+    for w in weights:
+        if remaining == 0:
+            raise RuntimeError("Internal partitioning error. remaining_total_weight == 0")
+        n = max((total * w) // remaining, 1)
+        ns.append(n)
+        remaining -= w
+        if total < n:
+            raise RuntimeError("Internal partitioning error.")
+        total -= n
+    ns[-1] += total
+    return ns
+
+
+# --------------------------------------------------------------------------------------
+# Cahn-Hilliard operators
+# --------------------------------------------------------------------------------------
+def reciprocal_laplacian_factor(dom: Domain, factor: float) -> torch.Tensor:
+    """src/tensor_computes/ReciprocalLaplacianFactor.C:28-31:  -k^2 * factor."""
+    return -dom.k_square() * factor
+
+
+def reciprocal_laplacian_square_factor(dom: Domain, factor: float) -> torch.Tensor:
+    """src/tensor_computes/ReciprocalLaplacianSquareFactor.C:28-32:  k^2 * k^2 * factor."""
+    k2 = dom.k_square()
+    return k2 * k2 * factor
+
+
+def mu_double_well(c: torch.Tensor, A: float = 0.1) -> torch.Tensor:
+    """d/dc [A*c^2*(c-1)^2] exactly as the reference's parser derives and evaluates it.
+
+    Grammar/derivative rules: include/utils/MarlinExpressionParser.h:400-412,
+    src/utils/MarlinExpressionParser.C:143-203 (differentiate), :50-141 (simplify);
+    evaluation by aten ops src/utils/ParsedJITTensor.C:114-156.  Resulting tree:
+        (A*(2*c)) * pow(c-1, 2)  +  (A*pow(c, 2)) * (2*(c-1))
+    """
+    cm1 = c - 1.0
+    return (A * (2.0 * c)) * torch.pow(cm1, 2.0) + (A * torch.pow(c, 2.0)) * (2.0 * cm1)
+
+
+def mu_pfhub(c: torch.Tensor, rho: float, ca: float, cb: float) -> torch.Tensor:
+    """d/dc [rho*(c-ca)^2*(cb-c)^2] by the same mechanical rules (benchmarks/01_spinodal_decomposition/1a_solver.i:62-70).
+
+    f = (rho * (c-ca)^2) * (cb-c)^2 (left-assoc product).  Product rule (f*g)' = f'*g + f*g':
+      d[(rho*(c-ca)^2)] = rho * (2*(c-ca))            (power rule g*f^(g-1)*f', f' = 1 dropped, ^1 dropped)
+      d[(cb-c)^2]       = 2*(cb-c) * (0-1) -> simplify folds (0-1) = -1:  (2*(cb-c))*-1
+    """
+    a = c - ca
+    b = cb - c
+    return (rho * (2.0 * a)) * torch.pow(b, 2.0) + (rho * torch.pow(a, 2.0)) * ((2.0 * b) * -1.0)
+
+
+AB_BETA = [
+    [1.0, 0.0, 0.0, 0.0, 0.0],
+    [3.0 / 2.0, -1.0 / 2.0, 0.0, 0.0, 0.0],
+    [23.0 / 12.0, -16.0 / 12.0, 5.0 / 12.0, 0.0, 0.0],
+    [55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -9.0 / 24.0, 0.0],
+    # AB5 row carries the reference's 190/720 (sic), src/tensor_solver/AdamsBashforthMoulton.C:72
+    [190.0 / 720.0, -2774.0 / 720.0, 2616.0 / 720.0, -1274.0 / 720.0, 251.0 / 720.0],
+]
+AM_ALPHA = [
+    [1.0, 0.0, 0.0, 0.0, 0.0],
+    [0.5, 0.5, 0.0, 0.0, 0.0],
+    [5.0 / 12.0, 8.0 / 12.0, -1.0 / 12.0, 0.0, 0.0],
+    [9.0 / 24.0, 19.0 / 24.0, -5.0 / 24.0, 1.0 / 24.0, 0.0],
+    [251.0 / 720.0, 646.0 / 720.0, -264.0 / 720.0, 106.0 / 720.0, -19.0 / 720.0],
+]
+
+
+@dataclass
+class History:
+    """TensorBuffer<T>::advanceState / getOldTensor (include/tensor_buffers/TensorBuffer.h:62-79,110-116)."""
+    max_states: int
+    old: List[torch.Tensor] = field(default_factory=list)
+
+    def advance(self, u: torch.Tensor) -> None:
+        if len(self.old) < self.max_states:
+            self.old.append(None)  # resize(+1)
+        if self.old:
+            for i in range(len(self.old) - 1, 0, -1):
+                self.old[i] = self.old[i - 1]
+            self.old[0] = u
+
+
+class CahnHilliardABM:
+    """TensorSolver::computeBuffer + AdamsBashforthMoulton::substep for the single-variable CH system.
+
+    src/tensor_solver/TensorSolver.C:93-109, src/tensor_solver/AdamsBashforthMoulton.C:60-101,
+    compute group order src/tensor_computes/ComputeGroup.C:61-84 (mu, mubar, Mbarmubar, cbar),
+    history rule src/problems/TensorProblem.C:451-472 (advanceState is a no-op while timeStep()<=1).
+    `mu_fn` is the parsed chemical potential (see mu_double_well / mu_pfhub).
+    """
+
+    def __init__(self, dom: Domain, c0: torch.Tensor, M: float, kappa_factor: float,
+                 mu_fn: Callable[[torch.Tensor], torch.Tensor], substeps: int, predictor_order: int = 2):
+        self.dom = dom
+        self.c = c0.clone()
+        self.mu = torch.zeros_like(c0)
+        self.Mbar = reciprocal_laplacian_factor(dom, M)
+        self.Lbar = reciprocal_laplacian_square_factor(dom, kappa_factor)
+        self.mu_fn = mu_fn
+        self.substeps = substeps
+        self.pred = predictor_order - 1                     # AdamsBashforthMoulton.C:48
+        self.hist = History(max_states=self.pred)           # :55-56 (corrector_steps = 0 here)
+        self.Nhat: Optional[torch.Tensor] = None
+        self.cbar: Optional[torch.Tensor] = None
+        self.time_step = 0
+        self.order_log: List[int] = []
+
+    def _advance_state(self) -> None:
+        if self.time_step <= 1:                             # TensorProblem.C:455
+            return
+        if self.Nhat is not None:
+            self.hist.advance(self.Nhat)
+
+    def substep(self, sub_dt: float) -> None:
+        # root compute group (ComputeGroup.C:61-84)
+        self.mu = self.mu_fn(self.c)                        # ParsedCompute.C:216
+        mubar = self.dom.fft(self.mu)                       # PerformFFT.C:37
+        self.Nhat = self.Mbar * mubar                       # Mbarmubar = Mbar*mubar
+        self.cbar = self.dom.fft(self.c)
+        n_old = len(self.hist.old)
+        order = min(n_old, self.pred)                       # AdamsBashforthMoulton.C:90-91 (dt constant)
+        self.order_log.append(order)
+        ubar = self.cbar + (sub_dt * AB_BETA[order][0]) * self.Nhat            # :94
+        for i in range(order):
+            ubar += (sub_dt * AB_BETA[order][i + 1]) * self.hist.old[i]        # :95-96
+        ubar /= (1.0 - sub_dt * self.Lbar)                                     # :99
+        self.c = self.dom.ifft(ubar)                                           # :101
+
+    def step(self, dt: float) -> None:
+        """One MOOSE time step: incrementStepOrReject -> advanceState, then TensorSolver::computeBuffer."""
+        self.time_step += 1
+        self._advance_state()
+        sub_dt = dt / self.substeps                         # TensorSolver.C:96
+        for s in range(self.substeps):
+            self.substep(sub_dt)
+            if s < self.substeps - 1:                       # :104-105
+                self._advance_state()
+
+
+def ch_substep_ops(c, Mbar, Lbar, Nhat_old, sub_dt, order, mu_fn, dom):
+    """One bare substep (used for the CPU baseline timing and operator-level parity)."""
+    mu = mu_fn(c)
+    mubar = dom.fft(mu)
+    Nhat = Mbar * mubar
+    cbar = dom.fft(c)
+    ubar = cbar + (sub_dt * AB_BETA[order][0]) * Nhat
+    for i in range(order):
+        ubar += (sub_dt * AB_BETA[order][i + 1]) * Nhat_old[i]
+    ubar /= (1.0 - sub_dt * Lbar)
+    return dom.ifft(ubar), Nhat, cbar, mu
+
+
+# --------------------------------------------------------------------------------------
+# de Geus mechanics
+# --------------------------------------------------------------------------------------
+def trans2(A2):
+    return torch.einsum("...ij->...ji", A2)                 # src/utils/MarlinUtils.C:147-151
+
+
+def ddot42(A4, B2):
+    return torch.einsum("...ijkl,...lk->...ij", A4, B2)     # :153-157
+
+
+def ddot44(A4, B4):
+    return torch.einsum("...ijkl,...lkmn->...ijmn", A4, B4)  # :159-163
+
+
+def dot22(A2, B2):
+    return torch.einsum("...ij,...jk->...ik", A2, B2)       # :165-169
+
+
+def dot24(A2, B4):
+    return torch.einsum("...ij,...jkmn->...ikmn", A2, B4)   # :171-175
+
+
+def dot42(A4, B2):
+    return torch.einsum("...ijkl,...lm->...ijkm", A4, B2)   # :177-181
+
+
+def dyad22(A2, B2):
+    return torch.einsum("...ij,...kl->...ijkl", A2, B2)     # :183-187
+
+
+def _unsqueeze0(t, ndim):
+    for _ in range(ndim):
+        t = t.unsqueeze(0)
+    return t
+
+
+class MechIdentities:
+    """Identity tensors of FFTMechanics / HyperElasticIsotropic ctors (src/tensor_computes/FFTMechanics.C:49-55)."""
+
+    def __init__(self, dim: int):
+        ti = torch.eye(dim, dtype=F64)
+        self.ti = ti
+        self.I = _unsqueeze0(ti, dim)
+        self.I4 = _unsqueeze0(torch.einsum("il,jk", ti, ti), dim)
+        self.I4rt = _unsqueeze0(torch.einsum("ik,jl", ti, ti), dim)
+        self.I4s = (self.I4 + self.I4rt) / 2.0
+        self.II = dyad22(self.I, self.I)
+
+
+def ghat4(dom: Domain) -> torch.Tensor:
+    """Projection operator as the reference stores it (src/tensor_computes/FFTMechanics.C:74-84)."""
+    dim = dom.dim
+    ti = torch.eye(dim, dtype=F64)
+    q = dom.k_grid()
+    Q = dom.k_square().unsqueeze(-1).unsqueeze(-1)
+    M = torch.where(Q == 0, 0.0, q.unsqueeze(-2) * q.unsqueeze(-1) / Q)
+    M = M.unsqueeze(-3).unsqueeze(-1)
+    delta_im = ti.unsqueeze(1).unsqueeze(1).expand(dim, dim, dim, dim)
+    return (M * delta_im).to(C128)
+
+
+def hyper_elastic_isotropic(dom: Domain, ids: MechIdentities, F, K, mu):
+    """src/tensor_computes/HyperElasticIsotropic.C:42-52 -> (P, K4)."""
+    vs = dom.value_shape([1, 1, 1, 1])
+    C4 = K.reshape(vs) * ids.II + 2.0 * mu.reshape(vs) * (ids.I4s - 1.0 / 3.0 * ids.II)
+    S = ddot42(C4, 0.5 * (dot22(trans2(F), F) - ids.I))
+    P = dot22(F, S)
+    K4 = dot24(S, ids.I4) + ddot44(ddot44(ids.I4rt, dot42(dot24(F, C4), trans2(F))), ids.I4rt)
+    return P, K4
+
+
+def conjugate_gradient_solve(A, b, x0=None, tol=1e-6, maxiter=0):
+    """MooseTensor::conjugateGradientSolve with identity preconditioner (include/utils/MarlinUtils.h:55-131)."""
+    x = x0.clone() if x0 is not None else torch.zeros_like(b)
+    b_norm = torch.norm(b).item()
+    if b_norm == 0.0:
+        return x, 0, 0.0
+    if not maxiter:
+        maxiter = b.numel()
+    r = b - A(x)
+    z = r
+    p = z.clone()
+    rz_old = torch.sum(r * z).item()
+    res_norm = float("nan")
+    for k in range(maxiter):
+        Ap = A(p)
+        alpha = rz_old / torch.sum(p * Ap).item()
+        x = x + alpha * p
+        r = r - alpha * Ap
+        res_norm = torch.norm(r).item()
+        if res_norm <= tol * b_norm:
+            return x, k + 1, res_norm
+        z = r
+        rz_new = torch.sum(r * z).item()
+        beta = rz_new / rz_old
+        p = z + beta * p
+        rz_old = rz_new
+    return x, maxiter, res_norm
+
+
+@dataclass
+class MechStats:
+    newton_its: int = 0
+    cg_its: List[int] = field(default_factory=list)
+
+
+class FFTMechanicsOracle:
+    """FFTMechanics::computeBuffer (src/tensor_computes/FFTMechanics.C:96-163) with HyperElasticIsotropic."""
+
+    def __init__(self, dom: Domain, K, mu, l_tol, nl_rel_tol, nl_abs_tol, l_max_its=None, nl_max_its=100):
+        self.dom = dom
+        self.ids = MechIdentities(dom.dim)
+        self.K, self.mu = K, mu
+        self.Ghat4 = ghat4(dom)
+        self.l_tol, self.nl_rel_tol, self.nl_abs_tol = l_tol, nl_rel_tol, nl_abs_tol
+        self.l_max_its = l_max_its if l_max_its is not None else int(torch.tensor(dom.shape).prod().item())
+        self.nl_max_its = nl_max_its
+        self.r2_shape = dom.value_shape([dom.dim, dom.dim])
+        self.P = None
+        self.K4 = None
+
+    def G(self, A2):
+        return self.dom.ifft_batched(ddot42(self.Ghat4, self.dom.fft_batched(A2))).reshape(-1)
+
+    def K_dF(self, dFm):
+        return trans2(ddot42(self.K4, trans2(dFm.reshape(self.r2_shape))))
+
+    def G_K_dF(self, dFm):
+        return self.G(self.K_dF(dFm))
+
+    def compute(self, F, applied: Optional[torch.Tensor]) -> Tuple[torch.Tensor, MechStats]:
+        stats = MechStats()
+        u = F
+        self.P, self.K4 = hyper_elastic_isotropic(self.dom, self.ids, u, self.K, self.mu)
+        if applied is not None:
+            b = -self.G_K_dF(applied.expand(self.r2_shape))
+            u = u + applied.expand(self.r2_shape)
+        else:
+            b = -self.G_K_dF(torch.zeros_like(F))
+        Fn = torch.linalg.norm(u).item()
+        iiter = 0
+        dFm = torch.zeros_like(b)
+        while True:
+            dFm, its, _ = conjugate_gradient_solve(self.G_K_dF, b, dFm, self.l_tol, self.l_max_its)
+            stats.cg_its.append(its)
+            u = u + dFm.reshape(self.r2_shape)
+            self.P, self.K4 = hyper_elastic_isotropic(self.dom, self.ids, u, self.K, self.mu)
+            b = -self.G(self.P)
+            anorm = torch.linalg.norm(dFm).item()
+            rnorm = anorm / Fn
+            if (rnorm < self.nl_rel_tol or anorm < self.nl_abs_tol) and iiter > 0:
+                break
+            iiter += 1
+            if iiter > self.nl_max_its:
+                raise RuntimeError("Exceeded the maximum number of nonlinear iterations without converging.")
+        stats.newton_its = iiter + 1
+        return u, stats
+
+
+# batched transforms: trailing value dims are batch (DomainAction.C:859-863 applies
+# rfftn over the leading `dim` axes of a [..., 3, 3] tensor)
+def _fft_batched(self: Domain, t):
+    axes = tuple(range(self.dim))
+    return torch.fft.rfftn(t, dim=axes)
+
+
+def _ifft_batched(self: Domain, t):
+    axes = tuple(range(self.dim))
+    return torch.fft.irfftn(t, self.shape, dim=axes)
+
+
+Domain.fft_batched = _fft_batched
+Domain.ifft_batched = _ifft_batched
+
+
+def macroscopic_shear(dom: Domain, F, t: float) -> torch.Tensor:
+    """test/src/tensor_computes/MacroscopicShearTensor.C:31-41."""
+    avg = dom.average(F)
+    applied = torch.eye(dom.dim, dtype=F64)
+    applied[0, 1] = applied[0, 1] + t
+    return applied - avg
+
+
+def gamma_closed_form(dom: Domain, A2: torch.Tensor) -> torch.Tensor:
+    """Closed form of G(A): out_ij = q_j (sum_k A^_ik q_k)/|q|^2, zero at q=0.
+
+    Not a reference call sequence: used by tests to show the stored-Ghat4 form and the fused
+    form agree (4e-14), which is what the HIP kernel implements.
+    """
+    Ah = dom.fft_batched(A2)
+    q = dom.k_grid().to(C128)
+    Q = dom.k_square()
+    s = torch.einsum("...ik,...k->...i", Ah, q)
+    invQ = torch.where(Q == 0, torch.zeros_like(Q), 1.0 / Q)
+    out = torch.einsum("...i,...j->...ij", s, q) * invQ.unsqueeze(-1).unsqueeze(-1)
+    return dom.ifft_batched(out)

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/*.npz from the reference's own gold files.
+
+Run in the build container only (needs /root/reference and /opt/conda/bin/h5dump;
+neither exists on the GPU box).  The .npz files are DATA: the datasets of the
+reference's committed HDF5 gold files, converted losslessly (raw little-endian
+IEEE f64 dumped by `h5dump -b LE`), plus the CSV gold tables of the solver tests.
+
+Sources (relative to /root/reference):
+  test/tests/cahnhilliard/gold/cahnhilliard.h5           spec test/tests/cahnhilliard/tests:46-57  (abs_tol 1e-13)
+  test/tests/cahnhilliard/gold/cahnhilliard.rank0001.h5  spec test/tests/cahnhilliard/tests:58-70  (2-rank FFT_SLAB, rank 1)
+  test/tests/mechanics/gold/mech3d.h5, mech.h5           spec test/tests/mechanics/tests:2-21      (abs_tol 1e-10)
+  test/tests/solvers/gold/diagonal_*.csv                 spec test/tests/solvers/tests
+  test/tests/tensor_compute/gold/backandforth_out.csv, test/tests/gradient/gold/gradient_out.csv
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+REF = "/root/reference"
+H5DUMP = "/opt/conda/bin/h5dump"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def h5_names(path):
+    txt = subprocess.check_output([H5DUMP, "-n", path], text=True)
+    return re.findall(r"dataset\s+/(\S+)", txt)
+
+
+def h5_shape(path, name):
+    txt = subprocess.check_output([H5DUMP, "-H", "-d", "/" + name, path], text=True)
+    m = re.search(r"SIMPLE \{ \(([^)]*)\)", txt)
+    assert "H5T_IEEE_F64LE" in txt, txt
+    return tuple(int(s) for s in m.group(1).split(","))
+
+
+def h5_read(path, name):
+    shape = h5_shape(path, name)
+    with tempfile.NamedTemporaryFile(suffix=".bin") as tmp:
+        subprocess.check_call(
+            [H5DUMP, "-d", "/" + name, "-b", "LE", "-o", tmp.name, path],
+            stdout=subprocess.DEVNULL,
+        )
+        a = np.fromfile(tmp.name, dtype="<f8")
+    assert a.size == int(np.prod(shape)), (name, a.size, shape)
+    return a.reshape(shape)
+
+
+def convert_h5(rel, out_name):
+    path = os.path.join(REF, rel)
+    data = {n: h5_read(path, n) for n in h5_names(path)}
+    np.savez_compressed(os.path.join(OUT, out_name), **data)
+    print(f"{out_name}: {len(data)} datasets from {rel}")
+
+
+def convert_csv(rels, out_name):
+    data = {}
+    for rel in rels:
+        path = os.path.join(REF, rel)
+        with open(path) as f:
+            header = f.readline().strip().split(",")
+        a = np.loadtxt(path, delimiter=",", skiprows=1, ndmin=2)
+        key = os.path.splitext(os.path.basename(rel))[0]
+        data[key] = a
+        data[key + "__columns"] = np.array(header)
+    np.savez_compressed(os.path.join(OUT, out_name), **data)
+    print(f"{out_name}: {len(rels)} csv tables")
+
+
+def main():
+    convert_h5("test/tests/cahnhilliard/gold/cahnhilliard.h5", "cahnhilliard_gold.npz")
+    convert_h5("test/tests/cahnhilliard/gold/cahnhilliard.rank0001.h5", "cahnhilliard_rank0001_gold.npz")
+    convert_h5("test/tests/mechanics/gold/mech3d.h5", "mech3d_gold.npz")
+    convert_h5("test/tests/mechanics/gold/mech.h5", "mech2d_gold.npz")
+    sol = sorted(
+        os.path.join("test/tests/solvers/gold", f)
+        for f in os.listdir(os.path.join(REF, "test/tests/solvers/gold"))
+        if f.startswith("diagonal_") or f.startswith("etdrk4")
+    )
+    convert_csv(sol, "solvers_gold.npz")
+    convert_csv(
+        ["test/tests/tensor_compute/gold/backandforth_out.csv", "test/tests/gradient/gold/gradient_out.csv"],
+        "fft_gold.npz",
+    )
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("needs /root/reference (build container only)")
+    main()

@@ -1,0 +1,150 @@
+"""Pin the CPU oracle against the reference's own gold files.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import marlin_oracle as mo
+from tests.conftest import load_golden
+
+
+def _ch_test_setup(slab=False):
+    # test/tests/cahnhilliard/cahnhilliard.i:7-14 (2-D 20^2, L=3), :22-30 (seed 0, [0.44,0.56])
+    dom = mo.Domain(2, [20, 20], [3.0, 3.0], slab_c2c=slab)
+    torch.manual_seed(0)
+    if slab:
+        # both ranks draw the same seed-0 rand(20,10) block (RandomTensor.C:41-54)
+        blk = torch.rand(20, 10, dtype=torch.float64) * (0.56 - 0.44) + 0.44
+        c0 = torch.cat([blk, blk], dim=1)
+    else:
+        c0 = torch.rand(20, 20, dtype=torch.float64) * (0.56 - 0.44) + 0.44
+    solver = mo.CahnHilliardABM(dom, c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=10)
+    return dom, c0, solver
+
+
+def test_ch_gold_serial():
+    """test/tests/cahnhilliard/tests:46-57 -- abs_tol 1e-13 on c.0..c.10 (NODE, periodic wrap) and mu.k (CELL)."""
+    g = load_golden("cahnhilliard_gold.npz")
+    dom, c0, s = _ch_test_setup()
+    assert np.array_equal(g["c.0"][:20, :20], c0.numpy())          # IC bit-identical
+    assert np.array_equal(g["c.0"][20, :20], c0.numpy()[0])         # wrap layer
+    worst = 0.0
+    for step in range(1, 11):
+        s.step(1e-3)
+        worst = max(worst, np.abs(g[f"c.{step}"][:20, :20] - s.c.numpy()).max())
+    assert worst <= 1e-13, worst
+    # first MOOSE step is all AB1, then AB2
+    assert s.order_log[:10] == [0] * 10 and set(s.order_log[10:]) == {1}
+    # mu.k is the chemical potential of the state *entering* the last substep of step k
+    assert np.abs(g["mu.10"] - s.mu.numpy()).max() <= 1e-13
+
+
+def test_ch_gold_slab_rank1():
+    """tests:58-70 -- rank 1 of the 2-rank FFT_SLAB run holds global[:, 10:20]."""
+    g = load_golden("cahnhilliard_rank0001_gold.npz")
+    dom, c0, s = _ch_test_setup(slab=True)
+    assert np.array_equal(g["c.0"], c0.numpy()[:, 10:20])
+    worst = 0.0
+    for step in range(1, 11):
+        s.step(1e-3)
+        worst = max(worst, np.abs(g[f"c.{step}"] - s.c.numpy()[:, 10:20]).max())
+    assert worst <= 1e-13, worst
+
+
+def test_partition_helper():
+    # include/actions/DomainAction.h:247-280
+    assert mo.partition_helper(20, [1, 1]) == [10, 10]
+    assert mo.partition_helper(21, [1, 1, 1]) == [7, 7, 7]
+    assert mo.partition_helper(22, [1, 1, 1]) == [7, 7, 8]
+    assert mo.partition_helper(512, [1] * 8) == [64] * 8
+    assert mo.partition_helper(10, [3, 1]) == [7, 3]
+    assert sum(mo.partition_helper(257, [1] * 8)) == 257
+
+
+def _mech_setup(dim, n):
+    L = 2.0 * math.pi
+    dom = mo.Domain(dim, [n] * dim, [L] * dim)
+    # phase = prod(cos(x_d)/2 + 0.5), K: 1->10, mu: 0.5->5   (test/tests/mechanics/mech3d.i:14-35)
+    phase = torch.ones(dom.shape, dtype=torch.float64)
+    ph = None
+    for d in range(dim):
+        term = torch.pow(torch.cos(dom.axis[d]) / 2.0 + 0.5, 1.0)
+        ph = term if ph is None else ph * term
+    phase = ph.expand(dom.shape).contiguous()
+    K = (1.0 - phase) * 1.0 + phase * 10.0
+    mu = (1.0 - phase) * 0.5 + phase * 5.0
+    return dom, phase, K, mu
+
+
+MECH_CASES = {
+    # test/tests/mechanics/mech3d.i:56-63,84-92,103-107
+    "mech3d": dict(dim=3, n=16, gold="mech3d_gold.npz", l_tol=1e-2, nl_rel=2e-2, nl_abs=2e-2, l_max_its=None,
+                   dt=0.01, substeps=10),
+    # test/tests/mechanics/mech.i:61-64,84-92,103-107
+    "mech2d": dict(dim=2, n=32, gold="mech2d_gold.npz", l_tol=1e-5, nl_rel=2e-4, nl_abs=2e-3, l_max_its=40,
+                   dt=0.02, substeps=3),
+}
+
+
+@pytest.mark.parametrize("case", ["mech3d", "mech2d"])
+def test_mech_gold(case):
+    """test/tests/mechanics/tests:2-21 -- F_k.frame, abs_tol 1e-10; 3 steps, shear ramp F01 = t."""
+    p = MECH_CASES[case]
+    dim, n = p["dim"], p["n"]
+    g = load_golden(p["gold"])
+    dom, phase, K, mu = _mech_setup(dim, n)
+    mech = mo.FFTMechanicsOracle(dom, K, mu, l_tol=p["l_tol"], nl_rel_tol=p["nl_rel"], nl_abs_tol=p["nl_abs"],
+                                 l_max_its=p["l_max_its"])
+    F = torch.eye(dim, dtype=torch.float64).expand(dom.value_shape([dim, dim])).contiguous()
+    dt, substeps = p["dt"], p["substeps"]
+    nsteps = 3
+    t_old = 0.0
+    perm = (2, 1, 0) if dim == 3 else (1, 0)     # XDMF default transpose=true
+    worst = 0.0
+    for step in range(1, nsteps + 1):
+        sub_dt = dt / substeps
+        for s in range(substeps):
+            t = t_old + s * sub_dt             # _sub_time
+            applied = mo.macroscopic_shear(dom, F, t)
+            Fnew, stats = mech.compute(F, applied)
+            F = Fnew                            # forwardBuffers
+        t_old += dt
+        for k in range(dim * dim):
+            ref = g[f"F_{k}.{step - 1}"]   # output only at TIMESTEP_END: frame 0 = end of step 1
+            got = F.reshape(dom.shape + [dim * dim])[..., k].permute(*perm).numpy()
+            worst = max(worst, np.abs(ref - got).max())
+    assert worst <= 1e-10, worst
+
+
+def test_gamma_closed_form_matches_stored_operator():
+    dom = mo.Domain(3, [8, 6, 10], [1.0, 2.0, 3.0])
+    torch.manual_seed(1)
+    A = torch.rand(dom.value_shape([3, 3]), dtype=torch.float64)
+    G4 = mo.ghat4(dom)
+    ref = dom.ifft_batched(mo.ddot42(G4, dom.fft_batched(A)))
+    got = mo.gamma_closed_form(dom, A)
+    assert (ref - got).abs().max().item() < 1e-13
+
+
+def test_cg_iteration_counts():
+    """unit/src/ConjugateGradientTest.C:12-37 -- SPD 2x2 converges in 2, 4x4 in 4 iterations."""
+    A2 = torch.tensor([[4.0, 1.0], [1.0, 3.0]], dtype=torch.float64)
+    b2 = torch.tensor([1.0, 2.0], dtype=torch.float64)
+    x, its, _ = mo.conjugate_gradient_solve(lambda v: A2 @ v, b2, None, 1e-12, 0)
+    assert its == 2 and torch.allclose(A2 @ x, b2, atol=1e-10)
+    A4 = torch.tensor([[10.0, 1, 2, 0], [1, 12, 0, 3], [2, 0, 9, 1], [0, 3, 1, 11]], dtype=torch.float64)
+    b4 = torch.tensor([1.0, 2.0, 3.0, 4.0], dtype=torch.float64)
+    x, its, _ = mo.conjugate_gradient_solve(lambda v: A4 @ v, b4, None, 1e-12, 0)
+    assert its <= 4 and torch.allclose(A4 @ x, b4, atol=1e-9)
+
+
+def test_fft_roundtrip_gold():
+    """test/tests/tensor_compute/backandforth.i -- fft->ifft identity for even/odd sizes, 1-3 D (gold norm 0)."""
+    g = load_golden("fft_gold.npz")
+    assert np.all(g["backandforth_out"][:, 1] == 0)
+    torch.manual_seed(3)
+    for shape in [(9,), (10,), (7, 9), (8, 6), (5, 7, 9), (6, 8, 4), (5, 6, 7)]:
+        dom = mo.Domain(len(shape), list(shape), [1.0] * len(shape))
+        a = torch.rand(shape, dtype=torch.float64)
+        assert (dom.ifft(dom.fft(a)) - a).abs().max().item() < 1e-14
