@@ -1,0 +1,198 @@
+/*
+ * marlin_hip.h -- C ABI of the MI355X-native FFT spectral-solver inner loop for Marlin.
+ *
+ * Drop-in boundary: these entry points are what Marlin's MOOSE objects bind to in place of
+ * their libTorch call sequences (see INTEGRATION.md for the shim classes).  Every function
+ * cites the reference interface it replaces (paths relative to the idaholab/marlin tree).
+ *
+ * Conventions
+ *   - all pointers named d_* are DEVICE pointers (HBM) owned by the caller and only borrowed
+ *     for the call (+ until the next mrl_sync for the asynchronous work it enqueued);
+ *   - real fields are dense row-major double, last spatial axis fastest: [nx][ny][nz]
+ *     (= torch `.contiguous()` of the reference's buffers); spectra are interleaved
+ *     (re,im) complex128 [nx][ny][nzc] with nzc = nz/2+1 (HALF spectrum, the layout of
+ *     torch::fft::rfftn that DomainAction::fftSerial returns) or nzc = nz (FULL spectrum, the
+ *     c2c layout of DomainAction::fftSlab);
+ *   - every function returns MRL_OK (0) or a negative error code; the message is available
+ *     from mrl_last_error().  No exceptions cross the boundary, no C++ or torch types appear;
+ *   - work is enqueued on the context's HIP stream and is asynchronous unless stated.
+ *   - one context per rank / per GPU; a context is not thread-safe (the reference drives each
+ *     rank from one host thread, src/problems/TensorProblem.C:154-197).
+ */
+#ifndef MARLIN_HIP_H
+#define MARLIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRL_ABI_VERSION 1
+
+enum mrl_status {
+  MRL_OK = 0,
+  MRL_ERR_INVALID = -1,      /* bad argument (paramError in the reference) */
+  MRL_ERR_UNSUPPORTED = -2,  /* valid request this build cannot serve */
+  MRL_ERR_HIP = -3,          /* HIP runtime failure */
+  MRL_ERR_NOMEM = -4,
+  MRL_ERR_NOT_CONVERGED = -5 /* nl_max_its exceeded (FFTMechanics.C:159-161) */
+};
+
+enum mrl_spectrum {
+  MRL_SPECTRUM_HALF = 0, /* r2c on the last axis: DomainAction.C:273-275 (parallel_mode NONE) */
+  MRL_SPECTRUM_FULL = 1  /* c2c on every axis:    DomainAction.C:279-281 (parallel_mode FFT_SLAB) */
+};
+
+typedef struct mrl_ctx mrl_ctx;
+
+/* Mirrors the [Domain] block / DomainAction ctor + gridChanged (src/actions/DomainAction.C:94-338). */
+typedef struct mrl_domain {
+  int32_t dim;             /* 1..3 */
+  int64_t n[3];            /* nx, ny, nz (entries >= dim ignored) */
+  double min[3], max[3];   /* xmin..zmax */
+  int32_t device;          /* HIP device ordinal; <0 = current device */
+  int32_t nranks, rank;    /* FFT_SLAB decomposition (DomainAction.C:510-566); nranks=1 = serial */
+  const int64_t *weights;  /* device_weights (nranks entries) or NULL = equal */
+  int32_t spectrum;        /* enum mrl_spectrum */
+  void *stream;            /* hipStream_t to enqueue on; NULL = the context creates its own */
+} mrl_domain;
+
+/* ---- context ------------------------------------------------------------------------ */
+int mrl_abi_version(void);
+/* DomainAction::DomainAction + gridChanged + partitionSlabs */
+int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom);
+void mrl_ctx_destroy(mrl_ctx *ctx);
+/* message of the last failing call on ctx (ctx may be NULL: failure of mrl_ctx_create) */
+const char *mrl_last_error(const mrl_ctx *ctx);
+/* hipStreamSynchronize on the context stream */
+int mrl_sync(mrl_ctx *ctx);
+int mrl_set_stream(mrl_ctx *ctx, void *stream);
+
+/* Local extents: DomainAction::getLocalShape / getReciprocalShape and the partition getters
+ * (_local_begin/_local_end, DomainAction.C:524-533).  real_n/recip_n: local extents per axis,
+ * real_begin/recip_begin: global index of the first local entry. */
+int mrl_local_shape(const mrl_ctx *ctx, int64_t real_n[3], int64_t real_begin[3], int64_t recip_n[3],
+                    int64_t recip_begin[3]);
+/* Host-only helpers (no GPU needed).
+ * mrl_reciprocal_axis: DomainAction.C:268-293, k = 2*pi*fftfreq / rfftfreq, same rounding sequence.
+ * mrl_partition:       DomainAction::partitionHepler, include/actions/DomainAction.h:247-280. */
+int mrl_reciprocal_axis(int64_t n, double dx, int rfft, double *h_out /* n or n/2+1 */);
+int mrl_partition(int64_t total, int32_t nranks, const int64_t *weights, int64_t *h_counts);
+/* local reciprocal axis of this context (host copy), axis in [0,dim) */
+int mrl_ctx_reciprocal_axis(const mrl_ctx *ctx, int axis, double *h_out, int64_t cap);
+
+/* ---- FFT service: DomainAction::fft / ifft (src/actions/DomainAction.C:833-867, 1049-1078) -- */
+/* batch: number of fields; layout 0: field-major [batch][grid], 1: value-major [grid][batch]
+ * (the reference's trailing value dimensions, e.g. [n,n,n,3,3]).  Forward is unnormalised,
+ * inverse scales by 1/N ("backward" norm); the inverse does not modify d_in. Serial contexts only. */
+int mrl_fft_r2c(mrl_ctx *ctx, const double *d_in, double *d_out, int64_t batch, int layout);
+int mrl_fft_c2r(mrl_ctx *ctx, const double *d_in, double *d_out, int64_t batch, int layout);
+
+/* Slab-decomposed transform split at its exchange (DomainAction::fftSlab / ifftSlab,
+ * DomainAction.C:869-1019).  The caller owns the exchange (RCCL all-to-all, MPI, ...):
+ *   forward : mrl_slab_fwd_local -> exchange(send -> recv) -> mrl_slab_fwd_finish
+ *   inverse : mrl_slab_inv_local -> exchange(send -> recv) -> mrl_slab_inv_finish
+ * send/recv buffers hold nranks chunks, chunk p at element offset mrl_slab_chunk_offset(p)
+ * (complex elements); chunk p of `send` goes to rank p, chunk p of `recv` came from rank p. */
+int mrl_slab_counts(const mrl_ctx *ctx, int forward, int64_t *h_send_counts, int64_t *h_recv_counts,
+                    int64_t *h_send_offsets, int64_t *h_recv_offsets); /* complex elements, nranks each */
+int mrl_slab_fwd_local(mrl_ctx *ctx, const double *d_real_in, double *d_send);
+int mrl_slab_fwd_finish(mrl_ctx *ctx, const double *d_recv, double *d_spec_out);
+int mrl_slab_inv_local(mrl_ctx *ctx, const double *d_spec_in, double *d_send);
+int mrl_slab_inv_finish(mrl_ctx *ctx, const double *d_recv, double *d_real_out);
+
+/* ---- Cahn-Hilliard semi-implicit substep ------------------------------------------------ */
+enum mrl_free_energy {
+  MRL_FE_DOUBLE_WELL = 0, /* f = A*c^2*(c-1)^2           coef = {A}        (examples/cahn_hilliard/cahnhilliard2.i:74-80) */
+  MRL_FE_PFHUB = 1        /* f = rho*(c-ca)^2*(cb-c)^2   coef = {rho,ca,cb} (benchmarks/01_spinodal_decomposition/1a_solver.i:62-70) */
+};
+typedef struct mrl_ch_params {
+  int32_t family;  /* enum mrl_free_energy */
+  double coef[4];
+  double mobility; /* ReciprocalLaplacianFactor factor:        Mbar = -k^2 * M        (ReciprocalLaplacianFactor.C:28-31) */
+  double kappa;    /* ReciprocalLaplacianSquareFactor factor:  Lbar = k^2 * k^2 * f   (ReciprocalLaplacianSquareFactor.C:28-32) */
+} mrl_ch_params;
+
+/* ParsedCompute f'(c) (src/tensor_computes/ParsedCompute.C:184-265) for the built-in families */
+int mrl_ch_mu(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c, double *d_mu, int64_t count);
+
+/* One AdamsBashforthMoulton::substep for the CH system including its root compute group
+ * (src/tensor_solver/AdamsBashforthMoulton.C:60-101, src/tensor_computes/ComputeGroup.C:61-84):
+ *   mu = f'(c); mubar = fft(mu); Nhat = Mbar*mubar; cbar = fft(c);
+ *   ubar = (cbar + (dt*b0)*Nhat + sum_i (dt*b_{i+1})*Nhat_old[i]) / (1 - dt*Lbar);  c_out = ifft(ubar)
+ * order = number of history terms used (0 = AB1 ... 4 = AB5), d_Nhat_old[i] = i-th old Mbarmubar.
+ * d_Nhat_new is always written (it enters the history); d_cbar / d_mu may be NULL (not materialised).
+ * c_out may alias c_in.  Serial contexts only; slab contexts use the mrl_slab_ch_* stages. */
+int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_c_out,
+                   double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt,
+                   double *d_cbar, double *d_mu);
+
+/* Generic k-space ABM update for caller-supplied reciprocal arrays (AdamsBashforthMoulton.C:94-99):
+ *   ubar = (ubar0 + sum_i coef[i]*N[i]) / (1 - dt*L)   (L may be NULL: no division)
+ * N[i] complex arrays of n_spec elements, L real array. */
+int mrl_kspace_abm(mrl_ctx *ctx, double *d_ubar_out, const double *d_ubar0, const double *const *d_N,
+                   const double *h_coef, int nterms, const double *d_L, double dt, int64_t n_spec);
+
+/* Slab (multi-GPU) CH substep, split at its two exchanges (forward pair, inverse):
+ *   mrl_slab_ch_fwd_local  : mu=f'(c); local passes of fft(c), fft(mu) -> d_send (2 fields per chunk)
+ *   [exchange]
+ *   mrl_slab_ch_kspace     : finish both forward transforms, Nhat/ubar update, first inverse pass -> d_send
+ *   [exchange]
+ *   mrl_slab_inv_finish    : remaining inverse passes -> c_out
+ * Chunk sizes for the forward exchange are 2x those of mrl_slab_counts. */
+int mrl_slab_ch_fwd_local(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_send, double *d_mu);
+int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_recv, double *d_send,
+                       double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt,
+                       double *d_cbar);
+
+/* ---- de Geus mechanics ------------------------------------------------------------------ */
+/* Fields are value-major as in the reference: rank-2 [grid][3][3] (dim x dim in 2-D). */
+/* G(A) = ifft( Ghat4 : fft(A) )   (FFTMechanics.C:74-84, 105-106) without materialising Ghat4 */
+int mrl_gamma_apply(mrl_ctx *ctx, const double *d_A, double *d_out);
+/* HyperElasticIsotropic::computeBuffer (HyperElasticIsotropic.C:42-52): P(F) ; K4 is not stored */
+int mrl_mech_stress(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu, double *d_P);
+/* K_dF(dF) = trans2(ddot42(K4, trans2(dF)))  (FFTMechanics.C:107-108), K4 rebuilt on the fly from (F,K,mu) */
+int mrl_mech_tangent_apply(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu,
+                           const double *d_dF, double *d_out);
+
+typedef struct mrl_mech_params {
+  double l_tol;       /* FFTMechanics l_tol */
+  int64_t l_max_its;  /* 0 = number of cells (FFTMechanics.C:63-64) */
+  double nl_rel_tol, nl_abs_tol;
+  int32_t nl_max_its;
+} mrl_mech_params;
+typedef struct mrl_mech_stats {
+  int32_t newton_its;
+  int32_t cg_its_total;
+  int32_t cg_its[64];  /* per Newton iteration (first 64) */
+  double last_anorm, last_rnorm, Fn;
+} mrl_mech_stats;
+/* FFTMechanics::computeBuffer (FFTMechanics.C:96-163) with conjugateGradientSolve
+ * (include/utils/MarlinUtils.h:55-131).  d_applied: [3][3] (dim x dim) device array or NULL.
+ * Writes Fnew and the final stress P.  Synchronous (host reads CG scalars). */
+int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *p, const double *d_F, const double *d_K,
+                       const double *d_mu, const double *d_applied, double *d_Fnew, double *d_P,
+                       mrl_mech_stats *stats);
+
+/* ---- reductions: torch::sum / torch::norm call sites of the CG (MarlinUtils.h:63,82,92,99,109) */
+/* Synchronous: result returned in *h_out. */
+int mrl_dot(mrl_ctx *ctx, const double *d_a, const double *d_b, int64_t n, double *h_out);
+int mrl_norm2(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_out);
+int mrl_sum(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_out);
+/* DomainAction::average over the grid of a value-major field [grid][ncomp] -> h_out[ncomp] */
+int mrl_average(mrl_ctx *ctx, const double *d_a, int64_t ncomp, double *h_out);
+
+/* ---- timing on the context stream (hipEvents): used by bench.py for roofline.achieved ---- */
+int mrl_timer_start(mrl_ctx *ctx);
+int mrl_timer_stop(mrl_ctx *ctx, float *h_ms); /* records, synchronises, returns elapsed ms */
+/* per-kernel-class accumulated device time of the calls made between start/stop when
+ * profiling is enabled via mrl_set_profiling(ctx,1) (adds an event pair per launch). */
+int mrl_set_profiling(mrl_ctx *ctx, int on);
+int mrl_get_profile(mrl_ctx *ctx, int slot, const char **name, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARLIN_HIP_H */

@@ -1,0 +1,213 @@
+"""Thin Python plumbing above the C ABI: device memory comes from torch, everything else is
+`libmarlin_hip.so`.  No arithmetic happens here."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import MrlChParams, MrlDomain, MrlMechParams, MrlMechStats
+
+SPECTRUM_HALF, SPECTRUM_FULL = 0, 1
+FE_DOUBLE_WELL, FE_PFHUB = 0, 1
+
+
+class MarlinHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[mrl {code}] {msg}")
+        self.code = code
+        self.message = msg
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("device tensor required (the HIP path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError("contiguous tensor required")
+    return C.c_void_p(t.data_ptr())
+
+
+def reciprocal_axis(n: int, dx: float, rfft: bool) -> List[float]:
+    lib = _lib.load()
+    cnt = n // 2 + 1 if rfft else n
+    out = (C.c_double * cnt)()
+    rc = lib.mrl_reciprocal_axis(n, dx, 1 if rfft else 0, out)
+    if rc != 0:
+        raise MarlinHipError(rc, lib.mrl_last_error(None).decode())
+    return list(out)
+
+
+def partition(total: int, nranks: int, weights: Optional[Sequence[int]] = None) -> List[int]:
+    lib = _lib.load()
+    out = (C.c_int64 * nranks)()
+    w = (C.c_int64 * nranks)(*weights) if weights is not None else None
+    rc = lib.mrl_partition(total, nranks, w, out)
+    if rc != 0:
+        raise MarlinHipError(rc, lib.mrl_last_error(None).decode())
+    return list(out)
+
+
+def ch_params(family=FE_DOUBLE_WELL, coef=(0.1,), mobility=0.2, kappa=-0.001) -> MrlChParams:
+    p = MrlChParams()
+    p.family = family
+    for i, v in enumerate(coef):
+        p.coef[i] = v
+    p.mobility = mobility
+    p.kappa = kappa
+    return p
+
+
+class Context:
+    """One mrl_ctx (= one DomainAction on one rank / GPU)."""
+
+    def __init__(self, dim: int, n: Sequence[int], mx: Sequence[float], mn: Sequence[float] = (0.0, 0.0, 0.0),
+                 nranks: int = 1, rank: int = 0, weights: Optional[Sequence[int]] = None,
+                 spectrum: int = SPECTRUM_HALF, device: Optional[int] = None, use_torch_stream: bool = True):
+        self.lib = _lib.load()
+        d = MrlDomain()
+        d.dim = dim
+        for i in range(3):
+            d.n[i] = int(n[i]) if i < dim else 1
+            d.min[i] = float(mn[i]) if i < len(mn) else 0.0
+            d.max[i] = float(mx[i]) if i < dim else 1.0
+        if device is None:
+            device = torch.cuda.current_device()
+        d.device = device
+        d.nranks, d.rank = nranks, rank
+        self._weights = (C.c_int64 * nranks)(*weights) if weights is not None else None
+        d.weights = self._weights
+        d.spectrum = spectrum
+        d.stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if use_torch_stream else None
+        h = C.c_void_p()
+        rc = self.lib.mrl_ctx_create(C.byref(h), C.byref(d))
+        if rc != 0:
+            raise MarlinHipError(rc, self.lib.mrl_last_error(None).decode())
+        self.h = h
+        self.dim = dim
+        self.device = torch.device("cuda", device)
+        rn, rb, kn, kb = ((C.c_int64 * 3)() for _ in range(4))
+        self._check(self.lib.mrl_local_shape(h, rn, rb, kn, kb))
+        self.real_shape = [rn[i] for i in range(dim)]
+        self.real_begin = [rb[i] for i in range(dim)]
+        self.recip_shape = [kn[i] for i in range(dim)]
+        self.recip_begin = [kb[i] for i in range(dim)]
+        self.nranks, self.rank = nranks, rank
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mrl_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MarlinHipError(rc, self.lib.mrl_last_error(self.h).decode())
+
+    # ---- helpers
+    def empty_real(self, *value_dims, batch_first: Optional[int] = None):
+        shape = ([batch_first] if batch_first else []) + list(self.real_shape) + list(value_dims)
+        return torch.empty(shape, dtype=torch.float64, device=self.device)
+
+    def empty_spec(self, *value_dims, batch_first: Optional[int] = None):
+        shape = ([batch_first] if batch_first else []) + list(self.recip_shape) + list(value_dims)
+        return torch.empty(shape, dtype=torch.complex128, device=self.device)
+
+    def reciprocal_axis(self, axis: int) -> torch.Tensor:
+        n = self.recip_shape[axis]
+        out = (C.c_double * n)()
+        self._check(self.lib.mrl_ctx_reciprocal_axis(self.h, axis, out, n))
+        return torch.tensor(list(out), dtype=torch.float64)
+
+    def sync(self):
+        self._check(self.lib.mrl_sync(self.h))
+
+    # ---- FFT service (DomainAction::fft / ifft)
+    def fft(self, t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """t: [grid...] or value-major [grid..., *values]"""
+        vals = list(t.shape[self.dim:])
+        batch = 1
+        for v in vals:
+            batch *= v
+        assert list(t.shape[:self.dim]) == self.real_shape, (t.shape, self.real_shape)
+        if out is None:
+            out = self.empty_spec(*vals)
+        self._check(self.lib.mrl_fft_r2c(self.h, _ptr(t), _ptr(out), batch, 1 if batch > 1 else 0))
+        return out
+
+    def ifft(self, t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        vals = list(t.shape[self.dim:])
+        batch = 1
+        for v in vals:
+            batch *= v
+        assert list(t.shape[:self.dim]) == self.recip_shape, (t.shape, self.recip_shape)
+        if out is None:
+            out = self.empty_real(*vals)
+        self._check(self.lib.mrl_fft_c2r(self.h, _ptr(t), _ptr(out), batch, 1 if batch > 1 else 0))
+        return out
+
+    def fft_fields(self, t: torch.Tensor) -> torch.Tensor:
+        """field-major batch: t [B, grid...] -> [B, recip...]"""
+        B = t.shape[0]
+        out = self.empty_spec(batch_first=B)
+        self._check(self.lib.mrl_fft_r2c(self.h, _ptr(t), _ptr(out), B, 0))
+        return out
+
+    def ifft_fields(self, t: torch.Tensor) -> torch.Tensor:
+        B = t.shape[0]
+        out = self.empty_real(batch_first=B)
+        self._check(self.lib.mrl_fft_c2r(self.h, _ptr(t), _ptr(out), B, 0))
+        return out
+
+    # ---- Cahn-Hilliard
+    def ch_mu(self, p: MrlChParams, c: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty_like(c)
+        self._check(self.lib.mrl_ch_mu(self.h, C.byref(p), _ptr(c), _ptr(out), c.numel()))
+        return out
+
+    def ch_substep(self, p: MrlChParams, c_in, c_out, Nhat_new, Nhat_old: Sequence[torch.Tensor], order: int,
+                   sub_dt: float, cbar=None, mu=None):
+        arr = (C.c_void_p * max(1, len(Nhat_old)))(*[t.data_ptr() for t in Nhat_old])
+        self._check(self.lib.mrl_ch_substep(self.h, C.byref(p), _ptr(c_in), _ptr(c_out), _ptr(Nhat_new), arr, order,
+                                            sub_dt, _ptr(cbar), _ptr(mu)))
+
+    def kspace_abm(self, out, ubar0, N: Sequence[torch.Tensor], coef: Sequence[float], L, dt: float):
+        n = len(N)
+        arr = (C.c_void_p * max(1, n))(*[t.data_ptr() for t in N])
+        cf = (C.c_double * max(1, n))(*coef)
+        self._check(self.lib.mrl_kspace_abm(self.h, _ptr(out), _ptr(ubar0), arr, cf, n, _ptr(L), dt, ubar0.numel()))
+
+    # ---- timing
+    def timer_start(self):
+        self._check(self.lib.mrl_timer_start(self.h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.mrl_timer_stop(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    def set_profiling(self, on: bool):
+        self._check(self.lib.mrl_set_profiling(self.h, 1 if on else 0))
+
+    def get_profile(self):
+        res = []
+        slot = 0
+        while True:
+            name = C.c_char_p()
+            ms = C.c_double()
+            cnt = C.c_int64()
+            rc = self.lib.mrl_get_profile(self.h, slot, C.byref(name), C.byref(ms), C.byref(cnt))
+            if rc != 0:
+                break
+            res.append((name.value.decode(), ms.value, cnt.value))
+            slot += 1
+        return res

@@ -1,0 +1,254 @@
+// Cahn-Hilliard pointwise operators and the substep driver.
+//   mu      : ParsedCompute f'(c)            (src/tensor_computes/ParsedCompute.C:184-265; op tree SURVEY A.3)
+//   k-space : Mbar*mubar + ABM predictor     (src/tensor_solver/AdamsBashforthMoulton.C:94-99)
+// k, Mbar = -k^2 M and Lbar = k^2 k^2 f are recomputed from the 1-D reciprocal axes (no full arrays).
+#include "mrl_internal.h"
+
+namespace mrl {
+
+struct ChP {
+  int family;
+  double c0, c1, c2;
+  double M, kappa;
+};
+
+__device__ __forceinline__ double ch_mu_eval(const ChP &p, double c) {
+#pragma clang fp contract(off)
+  if (p.family == MRL_FE_DOUBLE_WELL) {
+    // (A*(2*c)) * pow(c-1,2) + (A*pow(c,2)) * (2*(c-1))
+    const double cm1 = c - 1.0;
+    return (p.c0 * (2.0 * c)) * (cm1 * cm1) + (p.c0 * (c * c)) * (2.0 * cm1);
+  } else {
+    // (rho*(2*(c-ca))) * pow(cb-c,2) + (rho*pow(c-ca,2)) * ((2*(cb-c))*-1)
+    const double a = c - p.c1;
+    const double b = p.c2 - c;
+    return (p.c0 * (2.0 * a)) * (b * b) + (p.c0 * (a * a)) * ((2.0 * b) * -1.0);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_ch_mu(ChP p, const double *__restrict__ c, double *__restrict__ mu, long long n) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  const long long stride = (long long)gridDim.x * blockDim.x * 2;
+  for (; i + 1 < n; i += stride) {
+    const double2 v = *reinterpret_cast<const double2 *>(c + i);
+    double2 r;
+    r.x = ch_mu_eval(p, v.x);
+    r.y = ch_mu_eval(p, v.y);
+    *reinterpret_cast<double2 *>(mu + i) = r;
+  }
+  if (i < n) mu[i] = ch_mu_eval(p, c[i]);
+}
+
+struct KspaceArgs {
+  int dim;
+  long long n0, n1, n2;  // local reciprocal extents
+  const double *k0, *k1, *k2;
+  double M, kappa, dt;
+  int order;
+  double coef[6];        // dt*beta[order][i]
+  const double *Nold[5];
+};
+
+__device__ __forceinline__ double ksq(int dim, double a, double b, double c) {
+#pragma clang fp contract(off)
+  if (dim == 3) return a * a + b * b + c * c;
+  if (dim == 2) return b * b + c * c;
+  return c * c;
+}
+
+// one thread per spectral point; cbar / mubar interleaved complex
+__global__ void __launch_bounds__(256) k_ch_kspace(KspaceArgs a, const double2 *__restrict__ cbar,
+                                                   const double2 *__restrict__ mubar, double2 *__restrict__ Nhat,
+                                                   double2 *__restrict__ ubar) {
+#pragma clang fp contract(off)
+  const long long total = a.n0 * a.n1 * a.n2;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long i2 = e % a.n2;
+    const long long t = e / a.n2;
+    const long long i1 = t % a.n1;
+    const long long i0 = t / a.n1;
+    const double k2v = ksq(a.dim, a.k0[i0], a.k1[i1], a.k2[i2]);
+    const double Mbar = -k2v * a.M;
+    const double L = k2v * k2v * a.kappa;
+    const double2 m = mubar[e];
+    double2 N = make_double2(Mbar * m.x, Mbar * m.y);
+    Nhat[e] = N;
+    double2 u = cbar[e];
+    u.x = u.x + a.coef[0] * N.x;
+    u.y = u.y + a.coef[0] * N.y;
+    for (int i = 0; i < a.order; ++i) {
+      const double2 o = reinterpret_cast<const double2 *>(a.Nold[i])[e];
+      u.x += a.coef[i + 1] * o.x;
+      u.y += a.coef[i + 1] * o.y;
+    }
+    const double den = 1.0 - a.dt * L;
+    const double scl = 1.0 / den;
+    u.x = u.x * scl;
+    u.y = u.y * scl;
+    ubar[e] = u;
+  }
+}
+
+struct AbmArgs {
+  int nterms;
+  double coef[8];
+  const double *N[8];
+  double dt;
+};
+
+__global__ void __launch_bounds__(256) k_kspace_abm(AbmArgs a, double2 *__restrict__ out, const double2 *__restrict__ u0,
+                                                    const double *__restrict__ L, long long n) {
+#pragma clang fp contract(off)
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    double2 u = u0[e];
+    for (int i = 0; i < a.nterms; ++i) {
+      const double2 o = reinterpret_cast<const double2 *>(a.N[i])[e];
+      u.x += a.coef[i] * o.x;
+      u.y += a.coef[i] * o.y;
+    }
+    if (L) {
+      const double scl = 1.0 / (1.0 - a.dt * L[e]);
+      u.x *= scl;
+      u.y *= scl;
+    }
+    out[e] = u;
+  }
+}
+
+// Adams-Bashforth coefficients (src/tensor_solver/AdamsBashforthMoulton.C:67-73, incl. the AB5 190/720 entry)
+static const double kBeta[5][5] = {
+    {1.0, 0.0, 0.0, 0.0, 0.0},
+    {3.0 / 2.0, -1.0 / 2.0, 0.0, 0.0, 0.0},
+    {23.0 / 12.0, -16.0 / 12.0, 5.0 / 12.0, 0.0, 0.0},
+    {55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -9.0 / 24.0, 0.0},
+    {190.0 / 720.0, -2774.0 / 720.0, 2616.0 / 720.0, -1274.0 / 720.0, 251.0 / 720.0},
+};
+
+static int check_params(mrl_ctx *ctx, const mrl_ch_params *p, ChP &cp) {
+  if (!p) return set_error(ctx, MRL_ERR_INVALID, "null mrl_ch_params");
+  if (p->family != MRL_FE_DOUBLE_WELL && p->family != MRL_FE_PFHUB)
+    return set_error(ctx, MRL_ERR_INVALID, "unknown free energy family %d", p->family);
+  cp.family = p->family;
+  cp.c0 = p->coef[0];
+  cp.c1 = p->coef[1];
+  cp.c2 = p->coef[2];
+  cp.M = p->mobility;
+  cp.kappa = p->kappa;
+  return MRL_OK;
+}
+
+static inline int grid_for(long long n, int per_thread = 1) {
+  long long b = (n / per_thread + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const double *mubar, double *Nhat, double *ubar,
+                     const double *const *Nold, int order, double sub_dt) {
+  KspaceArgs a{};
+  a.dim = ctx->dim;
+  a.n0 = ctx->nrec[0];
+  a.n1 = ctx->nrec[1];
+  a.n2 = ctx->nrec[2];
+  a.k0 = ctx->d_k[0];
+  a.k1 = ctx->d_k[1];
+  a.k2 = ctx->d_k[2];
+  a.M = cp.M;
+  a.kappa = cp.kappa;
+  a.dt = sub_dt;
+  a.order = order;
+  for (int i = 0; i <= order; ++i) a.coef[i] = sub_dt * kBeta[order][i];
+  for (int i = 0; i < order; ++i) a.Nold[i] = Nold[i];
+  const long long total = a.n0 * a.n1 * a.n2;
+  hipLaunchKernelGGL(k_ch_kspace, dim3(grid_for(total)), dim3(256), 0, ctx->stream, a,
+                     reinterpret_cast<const double2 *>(cbar), reinterpret_cast<const double2 *>(mubar),
+                     reinterpret_cast<double2 *>(Nhat), reinterpret_cast<double2 *>(ubar));
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+// fast fused path (ch_fused.hip); returns MRL_ERR_UNSUPPORTED when the shape has no fast kernels
+int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new,
+                     const double *const *Nhat_old, int order, double sub_dt, double *cbar, double *mu);
+
+}  // namespace mrl
+
+using namespace mrl;
+
+extern "C" {
+
+int mrl_ch_mu(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c, double *d_mu, int64_t count) {
+  if (!ctx) return MRL_ERR_INVALID;
+  ChP cp;
+  MRL_TRY(check_params(ctx, p, cp));
+  if (!d_c || !d_mu || count < 0) return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_mu: bad argument");
+  if (count == 0) return MRL_OK;
+  if ((reinterpret_cast<uintptr_t>(d_c) | reinterpret_cast<uintptr_t>(d_mu)) & 15)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_mu: pointers must be 16-byte aligned");
+  ProfScope ps(ctx, "ch_mu");
+  hipLaunchKernelGGL(k_ch_mu, dim3(grid_for(count, 2)), dim3(256), 0, ctx->stream, cp, d_c, d_mu, (long long)count);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_c_out, double *d_Nhat_new,
+                   const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar, double *d_mu) {
+  if (!ctx) return MRL_ERR_INVALID;
+  ChP cp;
+  MRL_TRY(check_params(ctx, p, cp));
+  if (!d_c_in || !d_c_out || !d_Nhat_new) return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substep: null buffer");
+  if (order < 0 || order > 4) return set_error(ctx, MRL_ERR_INVALID, "predictor order %d out of range", order + 1);
+  if (order > 0 && !d_Nhat_old) return set_error(ctx, MRL_ERR_INVALID, "history pointers missing");
+  for (int i = 0; i < order; ++i)
+    if (!d_Nhat_old[i]) return set_error(ctx, MRL_ERR_INVALID, "history entry %d missing", i);
+  if (ctx->nranks > 1)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substep on a slab context: use the mrl_slab_ch_* stages");
+
+  int rc = ch_substep_fused(ctx, cp, d_c_in, d_c_out, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, d_mu);
+  if (rc != MRL_ERR_UNSUPPORTED) return rc;
+
+  // generic sequence: separate pointwise kernels around the generic transforms
+  const long long nreal = real_count_local(ctx), nspec = spec_count_local(ctx);
+  MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nspec));
+  MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nspec));
+  double *mu = d_mu;
+  if (!mu) {
+    MRL_TRY(ensure_work(ctx, 3, sizeof(double) * (nreal + 2)));
+    mu = ctx->d_work[3];
+  }
+  MRL_TRY(mrl_ch_mu(ctx, p, d_c_in, mu, nreal));
+  double *mubar = ctx->d_work[1];
+  double *cbar = d_cbar ? d_cbar : ctx->d_work[2];
+  double *ubar = ctx->d_work[2];
+  MRL_TRY(fft_forward_serial(ctx, mu, mubar, 1, 0));
+  MRL_TRY(fft_forward_serial(ctx, d_c_in, cbar, 1, 0));
+  {
+    ProfScope ps(ctx, "ch_kspace");
+    MRL_TRY(ch_kspace_launch(ctx, cp, cbar, mubar, d_Nhat_new, ubar, d_Nhat_old, order, sub_dt));
+  }
+  return fft_inverse_serial(ctx, ubar, d_c_out, 1, 0);
+}
+
+int mrl_kspace_abm(mrl_ctx *ctx, double *d_ubar_out, const double *d_ubar0, const double *const *d_N,
+                   const double *h_coef, int nterms, const double *d_L, double dt, int64_t n_spec) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!d_ubar_out || !d_ubar0 || nterms < 0 || nterms > 8 || n_spec < 0 || (nterms > 0 && (!d_N || !h_coef)))
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_kspace_abm: bad argument");
+  if (n_spec == 0) return MRL_OK;
+  AbmArgs a{};
+  a.nterms = nterms;
+  a.dt = dt;
+  for (int i = 0; i < nterms; ++i) {
+    a.coef[i] = h_coef[i];
+    a.N[i] = d_N[i];
+  }
+  ProfScope ps(ctx, "kspace_abm");
+  hipLaunchKernelGGL(k_kspace_abm, dim3(grid_for(n_spec)), dim3(256), 0, ctx->stream, a,
+                     reinterpret_cast<double2 *>(d_ubar_out), reinterpret_cast<const double2 *>(d_ubar0), d_L,
+                     (long long)n_spec);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,394 @@
+// Context, planning and the host-only helpers of the C ABI (mirrors DomainAction's set-up work).
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "mrl_internal.h"
+
+namespace mrl {
+
+thread_local std::string g_create_error;
+
+int set_error(const mrl_ctx *ctx, int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx)
+    ctx->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+int ensure_work(mrl_ctx *ctx, int slot, size_t bytes) {
+  if (ctx->work_bytes[slot] >= bytes) return MRL_OK;
+  if (ctx->d_work[slot]) {
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MRL_HIP(ctx, hipFree(ctx->d_work[slot]));
+    ctx->d_work[slot] = nullptr;
+    ctx->work_bytes[slot] = 0;
+  }
+  void *p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess)
+    return set_error(ctx, MRL_ERR_NOMEM, "hipMalloc of %zu scratch bytes failed", bytes);
+  ctx->d_work[slot] = static_cast<double *>(p);
+  ctx->work_bytes[slot] = bytes;
+  return MRL_OK;
+}
+
+ProfScope::ProfScope(mrl_ctx *c, const char *name) : ctx(c), slot(-1) {
+  if (!c->profiling) return;
+  for (size_t i = 0; i < c->prof.size(); ++i)
+    if (c->prof[i].name == name || std::strcmp(c->prof[i].name, name) == 0) slot = (int)i;
+  if (slot < 0) {
+    c->prof.push_back(Profile{name, 0.0, 0});
+    slot = (int)c->prof.size() - 1;
+  }
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  hipEventRecord(a, c->stream);
+}
+
+ProfScope::~ProfScope() {
+  if (slot < 0) return;
+  hipEventRecord(b, ctx->stream);
+  ctx->prof_events.emplace_back(a, b);
+  ctx->prof_slots.push_back(slot);
+}
+
+// radix sequence: 4s, then 2, then odd primes ascending (any n >= 1)
+static std::vector<int> factorize(long long n) {
+  std::vector<int> r;
+  while (n % 4 == 0) {
+    r.push_back(4);
+    n /= 4;
+  }
+  while (n % 2 == 0) {
+    r.push_back(2);
+    n /= 2;
+  }
+  for (long long p = 3; p * p <= n; p += 2)
+    while (n % p == 0) {
+      r.push_back((int)p);
+      n /= p;
+    }
+  if (n > 1) r.push_back((int)n);
+  return r;
+}
+
+static int build_axis(mrl_ctx *ctx, AxisPlan &ax, long long n) {
+  ax.n = (int)n;
+  ax.radix = factorize(n);
+  if ((int)ax.radix.size() > kMaxRadixPasses)
+    return set_error(ctx, MRL_ERR_UNSUPPORTED, "too many radix passes for n=%lld", n);
+  std::vector<cplx> tw(n);
+  const long double two_pi = 6.283185307179586476925286766559005768L;
+  for (long long k = 0; k < n; ++k) {
+    const long double a = two_pi * (long double)k / (long double)n;
+    tw[k] = make_double2((double)cosl(a), (double)(-sinl(a)));
+  }
+  MRL_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ax.d_tw), sizeof(cplx) * n));
+  MRL_HIP(ctx, hipMemcpy(ax.d_tw, tw.data(), sizeof(cplx) * n, hipMemcpyHostToDevice));
+  return MRL_OK;
+}
+
+// torch::fft::fftfreq / rfftfreq followed by `* 2.0 * pi` (DomainAction.C:284-293):
+//   arange values times the scalar 1.0/(n*d), then *2.0, then *pi  -- same rounding sequence.
+static void reciprocal_axis(long long n, double dx, bool rfft, std::vector<double> &out) {
+  const double scale = 1.0 / ((double)n * dx);
+  const long long cnt = rfft ? n / 2 + 1 : n;
+  out.resize(cnt);
+  for (long long i = 0; i < cnt; ++i) {
+    long long idx = i;
+    if (!rfft && i >= (n + 1) / 2) idx = i - n;
+    const double f = (double)idx * scale;
+    out[i] = f * 2.0 * M_PI;
+  }
+}
+
+static int partition(long long total, int nranks, const int64_t *weights, std::vector<long long> &ns) {
+  // DomainAction::partitionHepler (include/actions/DomainAction.h:247-280)
+  ns.clear();
+  long long remaining = 0;
+  for (int r = 0; r < nranks; ++r) remaining += weights ? weights[r] : 1;
+  for (int r = 0; r < nranks; ++r) {
+    const long long w = weights ? weights[r] : 1;
+    if (remaining == 0) return MRL_ERR_INVALID;
+    long long nn = (total * w) / remaining;
+    if (nn < 1) nn = 1;
+    ns.push_back(nn);
+    remaining -= w;
+    if (total < nn) return MRL_ERR_INVALID;
+    total -= nn;
+  }
+  ns.back() += total;
+  return MRL_OK;
+}
+
+}  // namespace mrl
+
+using namespace mrl;
+
+extern "C" {
+
+int mrl_abi_version(void) { return MRL_ABI_VERSION; }
+
+const char *mrl_last_error(const mrl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mrl_reciprocal_axis(int64_t n, double dx, int rfft, double *h_out) {
+  if (n < 1 || !h_out || !(dx > 0)) return set_error(nullptr, MRL_ERR_INVALID, "mrl_reciprocal_axis: bad argument");
+  std::vector<double> v;
+  reciprocal_axis(n, dx, rfft != 0, v);
+  std::memcpy(h_out, v.data(), v.size() * sizeof(double));
+  return MRL_OK;
+}
+
+int mrl_partition(int64_t total, int32_t nranks, const int64_t *weights, int64_t *h_counts) {
+  if (nranks < 1 || !h_counts || total < nranks)
+    return set_error(nullptr, MRL_ERR_INVALID, "mrl_partition: need total >= nranks >= 1");
+  std::vector<long long> ns;
+  if (partition(total, nranks, weights, ns) != MRL_OK)
+    return set_error(nullptr, MRL_ERR_INVALID, "Internal partitioning error.");
+  for (int r = 0; r < nranks; ++r) h_counts[r] = ns[r];
+  return MRL_OK;
+}
+
+int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
+  if (!out || !dom) return set_error(nullptr, MRL_ERR_INVALID, "mrl_ctx_create: null argument");
+  *out = nullptr;
+  if (dom->dim < 1 || dom->dim > 3) return set_error(nullptr, MRL_ERR_INVALID, "Unsupported mesh dimension %d", dom->dim);
+  if (dom->nranks < 1 || dom->rank < 0 || dom->rank >= dom->nranks)
+    return set_error(nullptr, MRL_ERR_INVALID, "invalid rank %d of %d", dom->rank, dom->nranks);
+  if (dom->nranks > 1 && dom->dim < 2)
+    return set_error(nullptr, MRL_ERR_INVALID, "Dimension must be 2 or 3 for slab decomposition.");
+  if (dom->nranks > 1 && dom->dim == 2 && dom->spectrum != MRL_SPECTRUM_FULL)
+    return set_error(nullptr, MRL_ERR_UNSUPPORTED, "2-D slab decomposition needs spectrum = MRL_SPECTRUM_FULL");
+  for (int d = 0; d < dom->dim; ++d) {
+    if (dom->n[d] < 1) return set_error(nullptr, MRL_ERR_INVALID, "grid size must be positive");
+    if (!(dom->max[d] > dom->min[d]))
+      return set_error(nullptr, MRL_ERR_INVALID, "Max coordinate must be larger than the min coordinate in every dimension");
+  }
+  mrl_ctx *c = new (std::nothrow) mrl_ctx();
+  if (!c) return set_error(nullptr, MRL_ERR_NOMEM, "out of host memory");
+
+  int rc = MRL_OK;
+  auto fail = [&](int code) {
+    g_create_error = c->err;
+    mrl_ctx_destroy(c);
+    return code;
+  };
+
+  c->dim = dom->dim;
+  c->spectrum = dom->spectrum;
+  c->nranks = dom->nranks;
+  c->rank = dom->rank;
+  const int off = 3 - c->dim;
+  for (int a = 0; a < 3; ++a) {
+    c->n[a] = 1;
+    c->gmin[a] = 0.0;
+    c->gmax[a] = 1.0;
+    c->dx[a] = 1.0;
+  }
+  for (int d = 0; d < c->dim; ++d) {
+    const int a = d + off;
+    c->n[a] = dom->n[d];
+    c->gmin[a] = dom->min[d];
+    c->gmax[a] = dom->max[d];
+    c->dx[a] = (dom->max[d] - dom->min[d]) / (double)dom->n[d];  // DomainAction.C:241
+  }
+
+  if (dom->device >= 0) {
+    if (hipSetDevice(dom->device) != hipSuccess) {
+      set_error(c, MRL_ERR_HIP, "hipSetDevice(%d) failed", dom->device);
+      return fail(MRL_ERR_HIP);
+    }
+    c->device = dom->device;
+  } else if (hipGetDevice(&c->device) != hipSuccess) {
+    set_error(c, MRL_ERR_HIP, "no HIP device available (the HIP path has no CPU fallback)");
+    return fail(MRL_ERR_HIP);
+  }
+  if (dom->stream) {
+    c->stream = static_cast<hipStream_t>(dom->stream);
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      set_error(c, MRL_ERR_HIP, "hipStreamCreate failed (no usable GPU?)");
+      return fail(MRL_ERR_HIP);
+    }
+    c->own_stream = true;
+  }
+
+  // reciprocal axes (global)
+  for (int a = 0; a < 3; ++a) {
+    if (a < off) {
+      c->h_k[a] = {0.0};  // DomainAction.C:295-296
+      c->nrec_glob[a] = 1;
+    } else {
+      const bool rfft = (a == 2) && c->spectrum == MRL_SPECTRUM_HALF;
+      reciprocal_axis(c->n[a], c->dx[a], rfft, c->h_k[a]);
+      c->nrec_glob[a] = (long long)c->h_k[a].size();
+    }
+  }
+
+  // partition
+  for (int a = 0; a < 3; ++a) {
+    c->nloc[a] = c->n[a];
+    c->rbeg[a] = 0;
+    c->nrec[a] = c->nrec_glob[a];
+    c->kbeg[a] = 0;
+  }
+  if (c->nranks > 1) {
+    c->split_recip_axis = off + 0;  // x: DomainAction.C:519-520
+    c->split_real_axis = off + 1;   // y: DomainAction.C:522-523
+    if (c->n[c->split_recip_axis] < c->nranks || c->n[c->split_real_axis] < c->nranks) {
+      set_error(c, MRL_ERR_INVALID, "slab decomposition needs at least one layer per rank");
+      return fail(MRL_ERR_INVALID);
+    }
+    if (partition(c->nrec_glob[c->split_recip_axis], c->nranks, dom->weights, c->part_recip) != MRL_OK ||
+        partition(c->n[c->split_real_axis], c->nranks, dom->weights, c->part_real) != MRL_OK) {
+      set_error(c, MRL_ERR_INVALID, "Internal partitioning error.");
+      return fail(MRL_ERR_INVALID);
+    }
+    long long b = 0;
+    for (int r = 0; r < c->rank; ++r) b += c->part_real[r];
+    c->rbeg[c->split_real_axis] = b;
+    c->nloc[c->split_real_axis] = c->part_real[c->rank];
+    b = 0;
+    for (int r = 0; r < c->rank; ++r) b += c->part_recip[r];
+    c->kbeg[c->split_recip_axis] = b;
+    c->nrec[c->split_recip_axis] = c->part_recip[c->rank];
+  }
+
+  for (int a = 0; a < 3 && rc == MRL_OK; ++a) {
+    rc = build_axis(c, c->ax[a], c->n[a]);
+    if (rc != MRL_OK) break;
+    const size_t bytes = sizeof(double) * c->nrec[a];
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_k[a]), bytes) != hipSuccess ||
+        hipMemcpy(c->d_k[a], c->h_k[a].data() + c->kbeg[a], bytes, hipMemcpyHostToDevice) != hipSuccess) {
+      set_error(c, MRL_ERR_HIP, "uploading reciprocal axis failed");
+      rc = MRL_ERR_HIP;
+    }
+  }
+  if (rc != MRL_OK) return fail(rc);
+
+  if (hipMalloc(reinterpret_cast<void **>(&c->d_red), sizeof(double) * 4096) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void **>(&c->h_red), sizeof(double) * 64) != hipSuccess ||
+      hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+    set_error(c, MRL_ERR_HIP, "allocating reduction scratch / events failed");
+    return fail(MRL_ERR_HIP);
+  }
+  *out = c;
+  return MRL_OK;
+}
+
+void mrl_ctx_destroy(mrl_ctx *c) {
+  if (!c) return;
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (int a = 0; a < 3; ++a) {
+    if (c->ax[a].d_tw) hipFree(c->ax[a].d_tw);
+    if (c->d_k[a]) hipFree(c->d_k[a]);
+  }
+  for (int s = 0; s < 4; ++s)
+    if (c->d_work[s]) hipFree(c->d_work[s]);
+  if (c->d_red) hipFree(c->d_red);
+  if (c->h_red) hipHostFree(c->h_red);
+  if (c->ev_start) hipEventDestroy(c->ev_start);
+  if (c->ev_stop) hipEventDestroy(c->ev_stop);
+  for (auto &p : c->prof_events) {
+    hipEventDestroy(p.first);
+    hipEventDestroy(p.second);
+  }
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int mrl_sync(mrl_ctx *ctx) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MRL_OK;
+}
+
+int mrl_set_stream(mrl_ctx *ctx, void *stream) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (ctx->own_stream && ctx->stream) {
+    hipStreamSynchronize(ctx->stream);
+    hipStreamDestroy(ctx->stream);
+    ctx->own_stream = false;
+  }
+  ctx->stream = static_cast<hipStream_t>(stream);
+  return MRL_OK;
+}
+
+int mrl_local_shape(const mrl_ctx *ctx, int64_t real_n[3], int64_t real_begin[3], int64_t recip_n[3],
+                    int64_t recip_begin[3]) {
+  if (!ctx) return MRL_ERR_INVALID;
+  const int off = 3 - ctx->dim;
+  for (int d = 0; d < 3; ++d) {
+    const bool act = d < ctx->dim;
+    if (real_n) real_n[d] = act ? ctx->nloc[d + off] : 1;
+    if (real_begin) real_begin[d] = act ? ctx->rbeg[d + off] : 0;
+    if (recip_n) recip_n[d] = act ? ctx->nrec[d + off] : 1;
+    if (recip_begin) recip_begin[d] = act ? ctx->kbeg[d + off] : 0;
+  }
+  return MRL_OK;
+}
+
+int mrl_ctx_reciprocal_axis(const mrl_ctx *ctx, int axis, double *h_out, int64_t cap) {
+  if (!ctx || axis < 0 || axis >= ctx->dim || !h_out) return set_error(ctx, MRL_ERR_INVALID, "bad axis");
+  const int a = axis + 3 - ctx->dim;
+  if (cap < ctx->nrec[a]) return set_error(ctx, MRL_ERR_INVALID, "output capacity too small");
+  std::memcpy(h_out, ctx->h_k[a].data() + ctx->kbeg[a], sizeof(double) * ctx->nrec[a]);
+  return MRL_OK;
+}
+
+int mrl_timer_start(mrl_ctx *ctx) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+  return MRL_OK;
+}
+
+int mrl_timer_stop(mrl_ctx *ctx, float *h_ms) {
+  if (!ctx || !h_ms) return MRL_ERR_INVALID;
+  MRL_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  MRL_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
+  MRL_HIP(ctx, hipEventElapsedTime(h_ms, ctx->ev_start, ctx->ev_stop));
+  return MRL_OK;
+}
+
+int mrl_set_profiling(mrl_ctx *ctx, int on) {
+  if (!ctx) return MRL_ERR_INVALID;
+  ctx->profiling = on != 0;
+  if (on) {
+    for (auto &p : ctx->prof) {
+      p.ms = 0;
+      p.launches = 0;
+    }
+  }
+  return MRL_OK;
+}
+
+int mrl_get_profile(mrl_ctx *ctx, int slot, const char **name, double *total_ms, int64_t *launches) {
+  if (!ctx) return MRL_ERR_INVALID;
+  // fold pending event pairs
+  if (!ctx->prof_events.empty()) {
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ctx->prof_events.size(); ++i) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, ctx->prof_events[i].first, ctx->prof_events[i].second);
+      ctx->prof[ctx->prof_slots[i]].ms += ms;
+      ctx->prof[ctx->prof_slots[i]].launches += 1;
+      hipEventDestroy(ctx->prof_events[i].first);
+      hipEventDestroy(ctx->prof_events[i].second);
+    }
+    ctx->prof_events.clear();
+    ctx->prof_slots.clear();
+  }
+  if (slot < 0 || slot >= (int)ctx->prof.size()) return MRL_ERR_INVALID;
+  if (name) *name = ctx->prof[slot].name;
+  if (total_ms) *total_ms = ctx->prof[slot].ms;
+  if (launches) *launches = ctx->prof[slot].launches;
+  return MRL_OK;
+}
+
+}  // extern "C"

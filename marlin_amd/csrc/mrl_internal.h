@@ -1,0 +1,132 @@
+// Internal declarations shared by the host planner and the HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "marlin_hip.h"
+
+namespace mrl {
+
+typedef double2 cplx;  // interleaved (re, im) complex128
+
+constexpr int kMaxRadixPasses = 24;
+
+// One generic Stockham pass sequence along one axis (see fft_generic.hip).
+struct PassDesc {
+  int n;                      // transform length
+  int npass;                  // number of radix passes
+  int radix[kMaxRadixPasses];
+  int sign;                   // -1 forward, +1 inverse
+  // line enumeration: line L in [0, outer*inner): o = L / inner, i = L % inner
+  long long inner, outer;
+  long long in_so, in_si, in_sn;     // element offsets (in units of the input scalar kind)
+  long long out_so, out_si, out_sn;
+  long long in_sb, out_sb;           // batch strides (blockIdx.y)
+  int in_kind;                // 0 complex, 1 real (imag = 0), 2 hermitian half line (n/2+1 stored)
+  int out_kind;               // 0 complex, 2 real part
+  int nout;                   // number of output elements stored per line (<= n)
+  double scale;               // applied on store
+  int tile;                   // lines per workgroup
+  int lines_fastest;          // thread->(line,element) mapping for global access
+};
+
+struct AxisPlan {
+  int n = 1;
+  std::vector<int> radix;
+  cplx *d_tw = nullptr;  // exp(-2 pi i k / n), k = 0..n-1
+};
+
+struct Profile {
+  const char *name;
+  double ms;
+  long long launches;
+};
+
+}  // namespace mrl
+
+struct mrl_ctx {
+  int dim = 0;
+  long long n[3] = {1, 1, 1};      // global real extents in internal order (A0, A1, A2), A2 contiguous
+  double gmin[3], gmax[3], dx[3];
+  int spectrum = MRL_SPECTRUM_HALF;
+  int nranks = 1, rank = 0;
+  int device = 0;
+  // internal axis a <-> user axis a - (3 - dim)
+  long long nloc[3] = {1, 1, 1};   // local real extents
+  long long rbeg[3] = {0, 0, 0};   // local real begin
+  long long nrec[3] = {1, 1, 1};   // local reciprocal extents
+  long long kbeg[3] = {0, 0, 0};   // local reciprocal begin
+  long long nrec_glob[3] = {1, 1, 1};
+  std::vector<long long> part_real;   // split of the real-space slab axis per rank
+  std::vector<long long> part_recip;  // split of the reciprocal slab axis per rank
+  int split_real_axis = -1, split_recip_axis = -1;  // internal axes (slab mode)
+
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  mrl::AxisPlan ax[3];
+  std::vector<double> h_k[3];   // reciprocal axis values (global), internal axis order
+  double *d_k[3] = {nullptr, nullptr, nullptr};  // device copies of the LOCAL reciprocal axes
+
+  // scratch (complex spectra), grown on demand
+  double *d_work[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t work_bytes[4] = {0, 0, 0, 0};
+  double *d_red = nullptr;      // reduction scratch
+  double *h_red = nullptr;      // pinned host scratch
+
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  bool profiling = false;
+  std::vector<mrl::Profile> prof;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  std::vector<int> prof_slots;
+
+  mutable std::string err;
+};
+
+namespace mrl {
+
+int set_error(const mrl_ctx *ctx, int code, const char *fmt, ...);
+extern thread_local std::string g_create_error;
+
+#define MRL_HIP(ctx, expr)                                                                      \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return mrl::set_error(ctx, MRL_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                            __FILE__, __LINE__);                                                \
+  } while (0)
+
+#define MRL_TRY(expr)          \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != MRL_OK) return rc_; \
+  } while (0)
+
+// scratch management
+int ensure_work(mrl_ctx *ctx, int slot, size_t bytes);
+
+// generic pass launcher (fft_generic.hip)
+int launch_pass(mrl_ctx *ctx, const PassDesc &d, const double *in, double *out, const cplx *d_tw, long long nbatch);
+
+// spectral sizes
+inline long long spec_count_local(const mrl_ctx *c) { return c->nrec[0] * c->nrec[1] * c->nrec[2]; }
+inline long long real_count_local(const mrl_ctx *c) { return c->nloc[0] * c->nloc[1] * c->nloc[2]; }
+
+// profiling scope
+struct ProfScope {
+  mrl_ctx *ctx;
+  int slot;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(mrl_ctx *c, const char *name);
+  ~ProfScope();
+};
+
+// serial transforms (fft_plan.hip)
+int fft_forward_serial(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch, int layout);
+int fft_inverse_serial(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch, int layout);
+
+}  // namespace mrl

@@ -1,0 +1,89 @@
+"""Cahn-Hilliard substep on the GPU vs the reference gold file and the oracle, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import marlin_oracle as mo
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_hip_ch(ctx, p, c0, nsteps, substeps, dt, pred=1, want_mu=False):
+    """TensorSolver::computeBuffer loop with the history rules of TensorProblem::advanceState (host logic only)."""
+    c = c0.cuda()
+    hist = []
+    Nhat = None
+    states = []
+    mu = torch.empty_like(c) if want_mu else None
+    time_step = 0
+
+    def advance():
+        nonlocal hist
+        if time_step <= 1 or Nhat is None:
+            return
+        if len(hist) < pred:
+            hist.append(None)
+        if hist:
+            for i in range(len(hist) - 1, 0, -1):
+                hist[i] = hist[i - 1]
+            hist[0] = Nhat
+
+    for step in range(nsteps):
+        time_step += 1
+        advance()
+        sub_dt = dt / substeps
+        for s in range(substeps):
+            order = min(len(hist), pred)
+            Nnew = ctx.empty_spec()
+            cn = torch.empty_like(c)
+            ctx.ch_substep(p, c, cn, Nnew, hist[:order], order, sub_dt, mu=mu)
+            c, Nhat = cn, Nnew
+            if s < substeps - 1:
+                advance()
+        states.append(c.cpu())
+    return states, (mu.cpu() if want_mu else None)
+
+
+def test_ch_gold_file():
+    """test/tests/cahnhilliard/tests:46-57: c.1..c.10 and mu.10 to abs_tol 1e-13"""
+    from marlin_amd.api import Context, ch_params
+    g = load_golden("cahnhilliard_gold.npz")
+    ctx = Context(2, [20, 20], [3.0, 3.0])
+    c0 = torch.from_numpy(g["c.0"][:20, :20].copy())
+    states, mu = _run_hip_ch(ctx, ch_params(), c0, 10, 10, 1e-3, want_mu=True)
+    worst = max(np.abs(g[f"c.{k + 1}"][:20, :20] - states[k].numpy()).max() for k in range(10))
+    assert worst <= 1e-13, worst
+    assert np.abs(g["mu.10"] - mu.numpy()).max() <= 1e-13
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 16), (12, 10, 9), (32, 32, 32), (24,), (64, 64, 64)])
+def test_ch_vs_oracle(shape):
+    from marlin_amd.api import Context, ch_params
+    dim = len(shape)
+    L = [2.0 + d for d in range(dim)]
+    ctx = Context(dim, list(shape), L)
+    dom = mo.Domain(dim, list(shape), L)
+    torch.manual_seed(11)
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    ref = mo.CahnHilliardABM(dom, c0, 0.2, -0.001, mo.mu_double_well, substeps=5)
+    for _ in range(3):
+        ref.step(5e-3)
+    states, _ = _run_hip_ch(ctx, ch_params(), c0, 3, 5, 5e-3)
+    assert (states[-1] - ref.c).abs().max().item() <= 1e-13
+
+
+def test_ch_pfhub_family_and_ab3():
+    from marlin_amd.api import Context, ch_params, FE_PFHUB
+    shape = (32, 32)
+    ctx = Context(2, list(shape), [200.0, 200.0])
+    dom = mo.Domain(2, list(shape), [200.0, 200.0])
+    x, y = dom.axis[0], dom.axis[1]
+    c0 = (0.5 + 0.01 * (torch.cos(0.105 * x) * torch.cos(0.11 * y))).expand(shape).contiguous()
+    mu_fn = lambda c: mo.mu_pfhub(c, 5.0, 0.3, 0.7)
+    ref = mo.CahnHilliardABM(dom, c0, 5.0, -10.0, mu_fn, substeps=4, predictor_order=3)
+    for _ in range(3):
+        ref.step(1.0)
+    p = ch_params(FE_PFHUB, (5.0, 0.3, 0.7), mobility=5.0, kappa=-10.0)
+    states, _ = _run_hip_ch(ctx, p, c0, 3, 4, 1.0, pred=2)
+    assert (states[-1] - ref.c).abs().max().item() <= 1e-13

@@ -1,0 +1,78 @@
+"""HIP FFT service vs the oracle (DomainAction::fft / ifft), through the C ABI.  Needs a GPU."""
+import pytest
+import torch
+
+from oracle import marlin_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    (9,), (10,), (16,), (127,), (200,),
+    (7, 9), (8, 6), (20, 20), (33, 17), (64, 128),
+    (5, 7, 9), (6, 8, 4), (5, 6, 7), (16, 16, 16), (12, 20, 30), (32, 64, 128), (40, 40, 40),
+]
+
+
+def _ctx(shape, **kw):
+    from marlin_amd.api import Context
+    L = [1.0 + 0.5 * i for i in range(len(shape))]
+    return Context(len(shape), list(shape), L, **kw), mo.Domain(len(shape), list(shape), L)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_forward_inverse_match_oracle(shape):
+    ctx, dom = _ctx(shape)
+    torch.manual_seed(len(shape) * 100 + shape[0])
+    a = torch.rand(shape, dtype=torch.float64)
+    ref = dom.fft(a)
+    got = ctx.fft(a.cuda()).cpu()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 1e-13 * scale, (got - ref).abs().max().item()
+    # inverse of an arbitrary (not hermitian-consistent) half spectrum must match irfftn too
+    spec = torch.randn(ref.shape, dtype=torch.complex128)
+    ref_r = dom.ifft(spec)
+    got_r = ctx.ifft(spec.cuda()).cpu()
+    assert (got_r - ref_r).abs().max().item() <= 1e-13 * max(1.0, ref_r.abs().max().item())
+    # round trip (test/tests/tensor_compute/backandforth.i)
+    back = ctx.ifft(ctx.fft(a.cuda())).cpu()
+    assert (back - a).abs().max().item() <= 1e-14
+
+
+@pytest.mark.parametrize("shape", [(6, 8, 4), (16, 16, 16), (9, 10), (12, 10, 14)])
+def test_value_major_batch(shape):
+    """trailing value dimensions are batch (mechanics [n,n,n,3,3]); SURVEY A.2"""
+    ctx, dom = _ctx(shape)
+    d = len(shape)
+    torch.manual_seed(5)
+    a = torch.rand(list(shape) + [d, d], dtype=torch.float64)
+    ref = dom.fft_batched(a)
+    got = ctx.fft(a.cuda()).cpu()
+    assert (got - ref).abs().max().item() <= 1e-13 * ref.abs().max().item()
+    back = ctx.ifft(got.cuda()).cpu()
+    assert (back - a).abs().max().item() <= 1e-14
+
+
+def test_field_major_batch():
+    ctx, dom = _ctx((8, 12, 10))
+    a = torch.rand(3, 8, 12, 10, dtype=torch.float64)
+    got = ctx.fft_fields(a.cuda()).cpu()
+    for b in range(3):
+        assert (got[b] - dom.fft(a[b])).abs().max().item() <= 1e-12
+    back = ctx.ifft_fields(got.cuda()).cpu()
+    assert (back - a).abs().max().item() <= 1e-14
+
+
+def test_reciprocal_axis_bit_exact():
+    from marlin_amd.api import Context
+    ctx = Context(3, [12, 9, 10], [3.0, 2.0, 7.0])
+    dom = mo.Domain(3, [12, 9, 10], [3.0, 2.0, 7.0])
+    for d in range(3):
+        assert torch.equal(ctx.reciprocal_axis(d), dom.kaxis[d].reshape(-1))
+
+
+def test_errors_are_reported():
+    from marlin_amd.api import Context, MarlinHipError
+    with pytest.raises(MarlinHipError, match="Max coordinate must be larger"):
+        Context(2, [8, 8], [0.0, 1.0])
+    with pytest.raises(MarlinHipError, match="Unsupported mesh dimension"):
+        Context(4, [8, 8, 8], [1.0, 1.0, 1.0])
