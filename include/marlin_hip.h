@@ -56,8 +56,11 @@ typedef struct mrl_domain {
   int32_t nranks, rank;    /* FFT_SLAB decomposition (DomainAction.C:510-566); nranks=1 = serial */
   const int64_t *weights;  /* device_weights (nranks entries) or NULL = equal */
   int32_t spectrum;        /* enum mrl_spectrum */
-  void *stream;            /* hipStream_t to enqueue on; NULL = the context creates its own */
+  void *stream;            /* hipStream_t to enqueue on; NULL = the HIP null stream (unless MRL_FLAG_OWN_STREAM) */
+  int32_t flags;           /* MRL_FLAG_* */
 } mrl_domain;
+
+#define MRL_FLAG_OWN_STREAM 1 /* the context creates (and owns) a non-blocking stream; `stream` is ignored */
 
 /* ---- context ------------------------------------------------------------------------ */
 int mrl_abi_version(void);

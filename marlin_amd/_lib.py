@@ -21,6 +21,7 @@ class MrlDomain(C.Structure):
         ("weights", C.POINTER(C.c_int64)),
         ("spectrum", C.c_int32),
         ("stream", C.c_void_p),
+        ("flags", C.c_int32),
     ]
 
 

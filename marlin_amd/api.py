@@ -82,6 +82,7 @@ class Context:
         d.weights = self._weights
         d.spectrum = spectrum
         d.stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if use_torch_stream else None
+        d.flags = 0 if use_torch_stream else 1  # MRL_FLAG_OWN_STREAM
         h = C.c_void_p()
         rc = self.lib.mrl_ctx_create(C.byref(h), C.byref(d))
         if rc != 0:

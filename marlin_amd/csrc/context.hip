@@ -209,8 +209,13 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
     set_error(c, MRL_ERR_HIP, "no HIP device available (the HIP path has no CPU fallback)");
     return fail(MRL_ERR_HIP);
   }
-  if (dom->stream) {
+  if (!(dom->flags & MRL_FLAG_OWN_STREAM)) {
     c->stream = static_cast<hipStream_t>(dom->stream);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+      set_error(c, MRL_ERR_HIP, "no HIP device available (the HIP path has no CPU fallback)");
+      return fail(MRL_ERR_HIP);
+    }
   } else {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
       set_error(c, MRL_ERR_HIP, "hipStreamCreate failed (no usable GPU?)");

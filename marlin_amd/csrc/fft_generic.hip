@@ -29,8 +29,9 @@ __global__ void __launch_bounds__(256) k_fft_generic(PassDesc d, const double *_
   const long long nlines = d.inner * d.outer;
   const long long L0 = (long long)blockIdx.x * d.tile;
   const int nl = (int)min((long long)d.tile, nlines - L0);
-  const double *inb = in + (long long)blockIdx.y * d.in_sb;
-  double *outb = out + (long long)blockIdx.y * d.out_sb;
+  // batch offsets are in elements of the respective kind (real: double, complex: double2)
+  const double *inb = in + (long long)blockIdx.y * d.in_sb * (d.in_kind == 1 ? 1 : 2);
+  double *outb = out + (long long)blockIdx.y * d.out_sb * (d.out_kind == 2 ? 1 : 2);
 
   for (int i = tid; i < n; i += nt) {
     cplx w = tw[i];
