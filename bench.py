@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: grid-point-updates/s of the Cahn-Hilliard semi-implicit spectral substep
+(BASELINE.json: 3-D 256^3 fp64, AB2) on N MI355X GPUs + fraction of the HBM roofline.
+
+A "step" is one solver substep (AdamsBashforthMoulton::substep + its compute group) of the whole
+grid.  N=1: 256^3 on one GPU.  N>1: slab decomposition with an RCCL all-to-all per transform;
+per-GPU work is held at 256^3 points (weak scaling; N=8 is the 512^3 configuration of north_star).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+
+def splitmix64_uniform(count, seed=0, lo=0.44, hi=0.56, offset=0):
+    """Counter-based IC: element i = lo + (hi-lo) * (splitmix64(seed + offset + i) >> 11) * 2^-53."""
+    idx = np.arange(offset, offset + count, dtype=np.uint64) + np.uint64(seed)
+    with np.errstate(over="ignore"):
+        z = idx * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return lo + (hi - lo) * u
+
+
+def algorithmic_bytes_per_update(n_last, n_old):
+    """3*B_fft(n) + n_old*8*(1+2/n), B_fft = 8 + 5*8*(1+2/n)."""
+    h = 8.0 * (1.0 + 2.0 / n_last)
+    return 3.0 * (8.0 + 5.0 * h) + n_old * h
+
+
+def grid_for(ngpus, base):
+    """weak scaling: per-GPU work fixed at base^3 points; axes doubled in the order y, x, z."""
+    g = [base, base, base]
+    order = [1, 0, 2]
+    k = 0
+    m = ngpus
+    while m > 1:
+        g[order[k % 3]] *= 2
+        m //= 2
+        k += 1
+    return g
+
+
+def cpu_baseline(shape, dx, sample_steps):
+    """The oracle (libTorch CPU ops in the reference's order) timed on this box's host cores."""
+    from oracle import marlin_oracle as mo
+
+    L = [s * dx for s in shape]
+    dom = mo.Domain(3, list(shape), L)
+    Mbar = mo.reciprocal_laplacian_factor(dom, 0.2)
+    Lbar = mo.reciprocal_laplacian_square_factor(dom, -0.001)
+    n = int(np.prod(shape))
+    c = torch.from_numpy(splitmix64_uniform(n).reshape(shape))
+    threads = torch.get_num_threads()
+    c, N0, _, _ = mo.ch_substep_ops(c, Mbar, Lbar, [], 1e-3, 0, mo.mu_double_well, dom)  # warm-up + history
+    t0 = time.perf_counter()
+    for _ in range(sample_steps):
+        c, N1, _, _ = mo.ch_substep_ops(c, Mbar, Lbar, [N0], 1e-3, 1, mo.mu_double_well, dom)
+        N0 = N1
+    dt = time.perf_counter() - t0
+    return {
+        "value": n * sample_steps / dt,
+        "unit": "grid-point-updates/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{sample_steps} AB2 substeps of the same {shape[0]}x{shape[1]}x{shape[2]} fp64 grid "
+                  f"(libTorch CPU ops in the reference's order, {threads} threads, {dt:.1f} s)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=256, help="base grid edge (per-GPU work = n^3 points)")
+    ap.add_argument("--cpu-steps", type=int, default=8, help="substeps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--profile-steps", type=int, default=10)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    from marlin_amd.api import Context, ch_params
+
+    dx = 8.0 * np.pi / 200.0   # examples/cahn_hilliard/cahnhilliard2.i:8-13
+    shape = grid_for(world, args.n)
+    L = [s * dx for s in shape]
+    p = ch_params()             # f = 0.1 c^2 (c-1)^2, M = 0.2, kappa factor -0.001 (cahnhilliard2.i:61-91)
+    sub_dt = 1e-3
+    npts = int(np.prod(shape))
+
+    if world > 1:
+        import torch.distributed as dist
+        from marlin_amd.slab import SlabCahnHilliard
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        solver = SlabCahnHilliard(3, shape, L, p, world, rank)
+        step = solver.substep
+        barrier = dist.barrier
+        solver.set_initial(lambda count, offset: splitmix64_uniform(count, offset=offset))
+    else:
+        ctx = Context(3, shape, L)
+        c = [torch.from_numpy(splitmix64_uniform(npts).reshape(shape)).cuda(), None]
+        c[1] = torch.empty_like(c[0])
+        Nh = [ctx.empty_spec(), ctx.empty_spec()]
+        state = {"i": 0, "have_old": False}
+
+        def step():
+            i = state["i"]
+            order = 1 if state["have_old"] else 0
+            ctx.ch_substep(p, c[i], c[1 - i], Nh[i], [Nh[1 - i]] if order else [], order, sub_dt)
+            state["i"] = 1 - i
+            state["have_old"] = True
+
+        def barrier():
+            pass
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the field must still be a bounded concentration field
+    cur = solver.current() if world > 1 else c[state["i"]]
+    assert torch.isfinite(cur).all() and 0.0 < float(cur.min()) and float(cur.max()) < 1.0
+
+    # per-kernel device time with HIP events on the launch stream (event pair per launch)
+    prof_ctx = solver.ctx if world > 1 else ctx
+    prof_ctx.set_profiling(True)
+    for _ in range(args.profile_steps):
+        step()
+    torch.cuda.synchronize()
+    kernels = prof_ctx.get_profile()
+    prof_ctx.set_profiling(False)
+
+    if rank == 0:
+        value = npts * args.steps / elapsed
+        bpu = algorithmic_bytes_per_update(shape[2], 1)
+        kernels = [k for k in kernels if k["launches"] > 0]
+        for k in kernels:
+            k["avg_ms"] = k["ms"] / k["launches"]
+            k["gbps"] = k["bytes_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9 if k["avg_ms"] > 0 else 0.0
+        dom_k = max(kernels, key=lambda k: k["ms"]) if kernels else None
+        roofline = None
+        if dom_k:
+            roofline = {
+                "bound": "hbm",
+                "kernel": dom_k["kernel"],
+                "achieved": round(dom_k["gbps"], 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(dom_k["gbps"] / HBM_PEAK_GBPS, 4),
+                "traffic": None,
+                "avg_launch_ms": round(dom_k["avg_ms"], 5),
+                "algorithmic_bytes_per_launch": dom_k["bytes_per_launch"],
+            }
+        out = {
+            "metric": "grid-point-updates/sec, 3-D Cahn-Hilliard semi-implicit spectral substep (AB2, fp64)",
+            "value": value,
+            "unit": "grid-point-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (splitmix64 uniform [0.44,0.56] initial concentration)",
+            "config": {
+                "workload": f"3D Cahn-Hilliard {shape[0]}x{shape[1]}x{shape[2]} fp64 semi-implicit spectral step, AB2, "
+                            f"f=0.1c^2(c-1)^2, M=0.2, kappa=-0.001, sub_dt=1e-3",
+                "grid": shape,
+                "decomposition": "none" if world == 1 else f"slab x{world} (RCCL all-to-all)",
+            },
+            "substep_algorithmic_bytes_per_update": bpu,
+            "substep_achieved_GBps": value * bpu / 1e9,
+            "substep_frac_of_hbm_peak": value * bpu / 1e9 / HBM_PEAK_GBPS,
+            "roofline": roofline,
+            "kernels": [{"kernel": k["kernel"], "avg_ms": round(k["avg_ms"], 5), "launches_per_step":
+                         k["launches"] / args.profile_steps, "algorithmic_GBps": round(k["gbps"], 1)} for k in kernels],
+        }
+        if world == 1 and args.cpu_steps > 0:
+            out["cpu_baseline"] = cpu_baseline(shape, dx, args.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

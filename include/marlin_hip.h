@@ -193,7 +193,8 @@ int mrl_timer_stop(mrl_ctx *ctx, float *h_ms); /* records, synchronises, returns
 /* per-kernel-class accumulated device time of the calls made between start/stop when
  * profiling is enabled via mrl_set_profiling(ctx,1) (adds an event pair per launch). */
 int mrl_set_profiling(mrl_ctx *ctx, int on);
-int mrl_get_profile(mrl_ctx *ctx, int slot, const char **name, double *total_ms, int64_t *launches);
+int mrl_get_profile(mrl_ctx *ctx, int slot, const char **name, double *total_ms, int64_t *launches,
+                    double *bytes_per_launch /* algorithmic HBM bytes of one launch */);
 
 #ifdef __cplusplus
 }

@@ -93,7 +93,7 @@ SIGNATURES = {
     "mrl_timer_start": (_i32, [_vp]),
     "mrl_timer_stop": (_i32, [_vp, C.POINTER(C.c_float)]),
     "mrl_set_profiling": (_i32, [_vp, _i32]),
-    "mrl_get_profile": (_i32, [_vp, _i32, C.POINTER(C.c_char_p), C.POINTER(_dbl), C.POINTER(_i64)]),
+    "mrl_get_profile": (_i32, [_vp, _i32, C.POINTER(C.c_char_p), C.POINTER(_dbl), C.POINTER(_i64), C.POINTER(_dbl)]),
 }
 
 _lib = None

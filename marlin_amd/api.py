@@ -206,9 +206,11 @@ class Context:
             name = C.c_char_p()
             ms = C.c_double()
             cnt = C.c_int64()
-            rc = self.lib.mrl_get_profile(self.h, slot, C.byref(name), C.byref(ms), C.byref(cnt))
+            nbytes = C.c_double()
+            rc = self.lib.mrl_get_profile(self.h, slot, C.byref(name), C.byref(ms), C.byref(cnt), C.byref(nbytes))
             if rc != 0:
                 break
-            res.append((name.value.decode(), ms.value, cnt.value))
+            res.append({"kernel": name.value.decode(), "ms": ms.value, "launches": cnt.value,
+                        "bytes_per_launch": nbytes.value})
             slot += 1
         return res

@@ -6,12 +6,6 @@
 
 namespace mrl {
 
-struct ChP {
-  int family;
-  double c0, c1, c2;
-  double M, kappa;
-};
-
 __device__ __forceinline__ double ch_mu_eval(const ChP &p, double c) {
 #pragma clang fp contract(off)
   if (p.family == MRL_FE_DOUBLE_WELL) {
@@ -186,7 +180,7 @@ int mrl_ch_mu(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c, double *d
   if (count == 0) return MRL_OK;
   if ((reinterpret_cast<uintptr_t>(d_c) | reinterpret_cast<uintptr_t>(d_mu)) & 15)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_mu: pointers must be 16-byte aligned");
-  ProfScope ps(ctx, "ch_mu");
+  ProfScope ps(ctx, "ch_mu", 16.0 * (double)count);
   hipLaunchKernelGGL(k_ch_mu, dim3(grid_for(count, 2)), dim3(256), 0, ctx->stream, cp, d_c, d_mu, (long long)count);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
@@ -224,7 +218,7 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
   MRL_TRY(fft_forward_serial(ctx, mu, mubar, 1, 0));
   MRL_TRY(fft_forward_serial(ctx, d_c_in, cbar, 1, 0));
   {
-    ProfScope ps(ctx, "ch_kspace");
+    ProfScope ps(ctx, "ch_kspace", 16.0 * (double)nspec * (4 + order));
     MRL_TRY(ch_kspace_launch(ctx, cp, cbar, mubar, d_Nhat_new, ubar, d_Nhat_old, order, sub_dt));
   }
   return fft_inverse_serial(ctx, ubar, d_c_out, 1, 0);

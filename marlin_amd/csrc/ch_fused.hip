@@ -1,9 +1,363 @@
-// Fused Cahn-Hilliard fast path (power-of-two grids). Placeholder until the fast kernels land.
-#include "mrl_internal.h"
+// Fast path: 3-D power-of-two grids on one GPU.
+//   forward r2c / inverse c2r built from the pow2 kernels, and the fused Cahn-Hilliard substep:
+//     A  k_z_fwd<CH>   c -> (c-hat_z, mu-hat_z)          mu = f'(c) evaluated in the loader
+//     B  k_pass<y>     both fields, forward along y
+//     C  k_ch_xfused   forward x on both fields, Nhat = Mbar*mu-hat (stored: history), ABM predictor,
+//                      1/(1 - dt*Lbar), inverse x                      (AdamsBashforthMoulton.C:94-101)
+//     D  k_pass<y>     inverse along y
+//     E  k_z_inv       c2r along z, 1/N
+//   Forward order z,y,x and inverse order x,y,z: the fused pass runs along x because its tiles are
+//   contiguous in (y,kz) jointly, so the user-visible Nhat arrays are accessed in aligned 256-B pieces.
+#include "fft_pow2_kernels.h"
+
 namespace mrl {
-struct ChP;
-int ch_substep_fused(mrl_ctx *, const ChP &, const double *, double *, double *, const double *const *, int, double,
-                     double *, double *) {
-  return MRL_ERR_UNSUPPORTED;
+
+namespace p2 {
+
+struct FusedArgs {
+  const cplx *chat;   // c-hat after z,y passes     [x][inner]
+  const cplx *muhat;  // mu-hat after z,y passes
+  cplx *ubar;         // out: inverse-x-transformed ubar (may alias chat)
+  cplx *Nnew;         // out: Mbar*mubar (reference layout [x][y][kz])
+  cplx *cbar;         // optional out: fully transformed c-hat
+  const cplx *Nold[4];
+  double coef[5];     // sub_dt * beta[order][i]
+  int order;
+  long long inner;    // ny*nzc
+  int nzc;
+  const double *kx, *ky, *kz;
+  double M, kappa, dt;
+};
+
+template <int N>
+__global__ void __launch_bounds__(256) k_ch_xfused(FusedArgs a, const cplx *__restrict__ tw) {
+#pragma clang fp contract(off)
+  constexpr int TPL = N / 16, T = 4096 / N;
+  using Map = MapStrided<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  double *KX = reinterpret_cast<double *>(X + Map::size);
+  const int l = threadIdx.x % T, q = threadIdx.x / T;
+  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const long long i = (long long)logical * T + l;
+  const bool valid = i < a.inner;
+  load_twiddles<N>(W, tw);
+  for (int j = threadIdx.x; j < N; j += 256) KX[j] = a.kx[j];
+  const long long sn = a.inner;
+  const long long off = i + (long long)q * sn;
+
+  // 1. mu-hat: forward x
+  cplx v[16];
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = a.muhat[off + (long long)m * TPL * sn];
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
+  }
+  fft_line<N, Map>(v, q, l, X, W);
+
+  // 2. Nhat = Mbar * mu-hat  (Mbar = -k^2 * M, ReciprocalLaplacianFactor.C:28-31)
+  double ky2 = 0.0, kz2 = 0.0;
+  if (valid) {
+    const double ky = a.ky[i / a.nzc], kz = a.kz[i % a.nzc];
+    ky2 = ky * ky;
+    kz2 = kz * kz;
+  }
+  cplx Nv[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const double kx = KX[q + m * TPL];
+    const double k2 = kx * kx + ky2 + kz2;
+    const double Mbar = -k2 * a.M;
+    Nv[m] = make_double2(Mbar * v[m].x, Mbar * v[m].y);
+  }
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) a.Nnew[off + (long long)m * TPL * sn] = Nv[m];
+  }
+
+  // 3. c-hat: forward x
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = a.chat[off + (long long)m * TPL * sn];
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
+  }
+  fft_line<N, Map>(v, q, l, X, W);
+  if (a.cbar && valid) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) a.cbar[off + (long long)m * TPL * sn] = v[m];
+  }
+
+  // 4. ubar = (cbar + (dt b0) N + sum (dt b_i) Nold_i) / (1 - dt*Lbar), in the reference's association
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    cplx u = v[m];
+    u.x = u.x + a.coef[0] * Nv[m].x;
+    u.y = u.y + a.coef[0] * Nv[m].y;
+    if (valid) {
+      for (int h = 0; h < a.order; ++h) {
+        const cplx o = a.Nold[h][off + (long long)m * TPL * sn];
+        u.x += a.coef[h + 1] * o.x;
+        u.y += a.coef[h + 1] * o.y;
+      }
+    }
+    const double kx = KX[q + m * TPL];
+    const double k2 = kx * kx + ky2 + kz2;
+    const double Lb = k2 * k2 * a.kappa;
+    const double scl = 1.0 / (1.0 - a.dt * Lb);
+    // swapped for the inverse transform
+    v[m] = make_double2(u.y * scl, u.x * scl);
+  }
+
+  // 5. inverse x (unnormalised; 1/N applied by the final z pass)
+  fft_line<N, Map>(v, q, l, X, W);
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) a.ubar[off + (long long)m * TPL * sn] = cswap(v[m]);
+  }
 }
+
+template <class K>
+static int set_lds_attr(mrl_ctx *ctx, K kernel, size_t lds) {
+  if (lds > 64 * 1024) {
+    MRL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+  }
+  return MRL_OK;
+}
+
+template <int N, int MODE>
+static int launch_z_fwd(mrl_ctx *ctx, const double *in, cplx *o0, cplx *o1, double *mu, const ChDev &chp,
+                        long long nlines) {
+  static bool attr = false;
+  constexpr size_t lds = lds_line<N>();
+  if (!attr) {
+    MRL_TRY(set_lds_attr(ctx, k_z_fwd<N, MODE>, lds));
+    attr = true;
+  }
+  constexpr int LPB = 4096 / N;
+  const long long nb = (nlines + LPB - 1) / LPB;
+  hipLaunchKernelGGL((k_z_fwd<N, MODE>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, o0, o1, mu, chp, nlines,
+                     ctx->ax[2].d_tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+template <int N>
+static int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale, long long nlines) {
+  static bool attr = false;
+  constexpr size_t lds = lds_line<N>();
+  if (!attr) {
+    MRL_TRY(set_lds_attr(ctx, k_z_inv<N>, lds));
+    attr = true;
+  }
+  constexpr int LPB = 4096 / N;
+  const long long nb = (nlines + LPB - 1) / LPB;
+  hipLaunchKernelGGL((k_z_inv<N>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, out, scale, nlines,
+                     ctx->ax[2].d_tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+template <int N, bool INV, int NF>
+static int launch_pass_t(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
+  static bool attr = false;
+  constexpr size_t lds = lds_strided<N>();
+  if (!attr) {
+    MRL_TRY(set_lds_attr(ctx, k_pass<N, INV, NF>, lds));
+    attr = true;
+  }
+  constexpr int T = 4096 / N;
+  a.tiles_per_outer = (int)((a.inner + T - 1) / T);
+  const long long nb = a.outer * a.tiles_per_outer;
+  hipLaunchKernelGGL((k_pass<N, INV, NF>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+template <int N>
+static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a) {
+  static bool attr = false;
+  constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
+  if (!attr) {
+    MRL_TRY(set_lds_attr(ctx, k_ch_xfused<N>, lds));
+    attr = true;
+  }
+  constexpr int T = 4096 / N;
+  const long long nb = (a.inner + T - 1) / T;
+  hipLaunchKernelGGL((k_ch_xfused<N>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, ctx->ax[0].d_tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+}  // namespace p2
+
+#define MRL_SWITCH_N(n, CALL)  \
+  switch (n) {                 \
+    case 64: { constexpr int NN = 64; CALL; } break;   \
+    case 128: { constexpr int NN = 128; CALL; } break; \
+    case 256: { constexpr int NN = 256; CALL; } break; \
+    case 512: { constexpr int NN = 512; CALL; } break; \
+    default: return MRL_ERR_UNSUPPORTED;               \
+  }
+
+static bool pow2_ok(long long n) { return n == 64 || n == 128 || n == 256 || n == 512; }
+
+bool fast_path_ok(const mrl_ctx *ctx) {
+  return ctx->dim == 3 && ctx->nranks == 1 && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
+         pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]);
+}
+
+// strided pass along internal axis `a` (0 = x, 1 = y) of NF complex [nx][ny][nzc] arrays
+static int pass_axis(mrl_ctx *ctx, int axis, bool inv, int nf, const cplx *in0, const cplx *in1, cplx *out0,
+                     cplx *out1) {
+  const long long nx = ctx->n[0], ny = ctx->n[1], nzc = ctx->nrec[2];
+  p2::PassArgs a{};
+  a.in[0] = in0;
+  a.in[1] = in1;
+  a.out[0] = out0;
+  a.out[1] = out1;
+  a.scale = 1.0;
+  if (axis == 1) {
+    a.inner = nzc;
+    a.outer = nx;
+    a.so_in = a.so_out = ny * nzc;
+    a.sn_in = a.sn_out = nzc;
+  } else {
+    a.inner = ny * nzc;
+    a.outer = 1;
+    a.so_in = a.so_out = 0;
+    a.sn_in = a.sn_out = ny * nzc;
+  }
+  const cplx *tw = ctx->ax[axis].d_tw;
+  const long long n = ctx->n[axis];
+  if (nf == 2) {
+    if (inv) {
+      MRL_SWITCH_N(n, MRL_TRY((p2::launch_pass_t<NN, true, 2>(ctx, a, tw))));
+    } else {
+      MRL_SWITCH_N(n, MRL_TRY((p2::launch_pass_t<NN, false, 2>(ctx, a, tw))));
+    }
+  } else {
+    if (inv) {
+      MRL_SWITCH_N(n, MRL_TRY((p2::launch_pass_t<NN, true, 1>(ctx, a, tw))));
+    } else {
+      MRL_SWITCH_N(n, MRL_TRY((p2::launch_pass_t<NN, false, 1>(ctx, a, tw))));
+    }
+  }
+  return MRL_OK;
+}
+
+// plain transforms (field-major batch), used by mrl_fft_r2c / mrl_fft_c2r on fast-path shapes
+int fft_forward_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch) {
+  const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
+  const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
+  p2::ChDev none{};
+  for (long long b = 0; b < batch; ++b) {
+    const double *in = d_in + b * nreal;
+    cplx *out = reinterpret_cast<cplx *>(d_out) + b * nspec;
+    {
+      ProfScope ps(ctx, "z_fwd_pair", 8.0 * nreal + 16.0 * nspec);
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0>(ctx, in, out, nullptr, nullptr, none, nx * ny / 2))));
+    }
+    {
+      ProfScope ps(ctx, "pass_y", 32.0 * nspec);
+      MRL_TRY(pass_axis(ctx, 1, false, 1, out, nullptr, out, nullptr));
+    }
+    {
+      ProfScope ps(ctx, "pass_x", 32.0 * nspec);
+      MRL_TRY(pass_axis(ctx, 0, false, 1, out, nullptr, out, nullptr));
+    }
+  }
+  return MRL_OK;
+}
+
+int fft_inverse_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch) {
+  const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
+  const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
+  const double scale = 1.0 / ((double)nx * (double)ny * (double)nz);
+  MRL_TRY(ensure_work(ctx, 0, sizeof(cplx) * nspec));
+  cplx *w = reinterpret_cast<cplx *>(ctx->d_work[0]);
+  for (long long b = 0; b < batch; ++b) {
+    const cplx *in = reinterpret_cast<const cplx *>(d_in) + b * nspec;
+    double *out = d_out + b * nreal;
+    {
+      ProfScope ps(ctx, "pass_x", 32.0 * nspec);
+      MRL_TRY(pass_axis(ctx, 0, true, 1, in, nullptr, w, nullptr));
+    }
+    {
+      ProfScope ps(ctx, "pass_y", 32.0 * nspec);
+      MRL_TRY(pass_axis(ctx, 1, true, 1, w, nullptr, w, nullptr));
+    }
+    {
+      ProfScope ps(ctx, "z_inv_pair", 8.0 * nreal + 16.0 * nspec);
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w, out, scale, nx * ny / 2))));
+    }
+  }
+  return MRL_OK;
+}
+
+static const double kBetaF[5][5] = {
+    {1.0, 0.0, 0.0, 0.0, 0.0},
+    {3.0 / 2.0, -1.0 / 2.0, 0.0, 0.0, 0.0},
+    {23.0 / 12.0, -16.0 / 12.0, 5.0 / 12.0, 0.0, 0.0},
+    {55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -9.0 / 24.0, 0.0},
+    {190.0 / 720.0, -2774.0 / 720.0, 2616.0 / 720.0, -1274.0 / 720.0, 251.0 / 720.0},
+};
+
+int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new,
+                     const double *const *Nhat_old, int order, double sub_dt, double *cbar, double *mu) {
+  if (!fast_path_ok(ctx)) return MRL_ERR_UNSUPPORTED;
+  const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
+  const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
+  MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nspec));
+  MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nspec));
+  cplx *w_c = reinterpret_cast<cplx *>(ctx->d_work[1]);
+  cplx *w_mu = reinterpret_cast<cplx *>(ctx->d_work[2]);
+  p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2};
+  const double h = 16.0 * nspec;  // bytes of one complex half-spectrum array
+  {
+    ProfScope ps(ctx, "ch_A_z_fwd", 8.0 * nreal + 2.0 * h + (mu ? 8.0 * nreal : 0.0));
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1>(ctx, c_in, w_c, w_mu, mu, chp, nx * ny))));
+  }
+  {
+    ProfScope ps(ctx, "ch_B_y_fwd", 4.0 * h);
+    MRL_TRY(pass_axis(ctx, 1, false, 2, w_c, w_mu, w_c, w_mu));
+  }
+  {
+    ProfScope ps(ctx, "ch_C_x_fused", (4.0 + order + (cbar ? 1.0 : 0.0)) * h);
+    p2::FusedArgs a{};
+    a.chat = w_c;
+    a.muhat = w_mu;
+    a.ubar = w_c;
+    a.Nnew = reinterpret_cast<cplx *>(Nhat_new);
+    a.cbar = reinterpret_cast<cplx *>(cbar);
+    for (int i = 0; i < order; ++i) a.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
+    for (int i = 0; i <= order; ++i) a.coef[i] = sub_dt * kBetaF[order][i];
+    a.order = order;
+    a.inner = ny * nzc;
+    a.nzc = (int)nzc;
+    a.kx = ctx->d_k[0];
+    a.ky = ctx->d_k[1];
+    a.kz = ctx->d_k[2];
+    a.M = cp.M;
+    a.kappa = cp.kappa;
+    a.dt = sub_dt;
+    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN>(ctx, a))));
+  }
+  {
+    ProfScope ps(ctx, "ch_D_y_inv", 2.0 * h);
+    MRL_TRY(pass_axis(ctx, 1, true, 1, w_c, nullptr, w_c, nullptr));
+  }
+  {
+    ProfScope ps(ctx, "ch_E_z_inv", h + 8.0 * nreal);
+    const double scale = 1.0 / ((double)nx * (double)ny * (double)nz);
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w_c, c_out, scale, nx * ny / 2))));
+  }
+  return MRL_OK;
+}
+
 }  // namespace mrl

@@ -38,14 +38,15 @@ int ensure_work(mrl_ctx *ctx, int slot, size_t bytes) {
   return MRL_OK;
 }
 
-ProfScope::ProfScope(mrl_ctx *c, const char *name) : ctx(c), slot(-1) {
+ProfScope::ProfScope(mrl_ctx *c, const char *name, double bytes) : ctx(c), slot(-1) {
   if (!c->profiling) return;
   for (size_t i = 0; i < c->prof.size(); ++i)
     if (c->prof[i].name == name || std::strcmp(c->prof[i].name, name) == 0) slot = (int)i;
   if (slot < 0) {
-    c->prof.push_back(Profile{name, 0.0, 0});
+    c->prof.push_back(Profile{name, 0.0, 0, bytes});
     slot = (int)c->prof.size() - 1;
   }
+  c->prof[slot].bytes = bytes;
   hipEventCreate(&a);
   hipEventCreate(&b);
   hipEventRecord(a, c->stream);
@@ -373,7 +374,8 @@ int mrl_set_profiling(mrl_ctx *ctx, int on) {
   return MRL_OK;
 }
 
-int mrl_get_profile(mrl_ctx *ctx, int slot, const char **name, double *total_ms, int64_t *launches) {
+int mrl_get_profile(mrl_ctx *ctx, int slot, const char **name, double *total_ms, int64_t *launches,
+                    double *bytes_per_launch) {
   if (!ctx) return MRL_ERR_INVALID;
   // fold pending event pairs
   if (!ctx->prof_events.empty()) {
@@ -393,6 +395,7 @@ int mrl_get_profile(mrl_ctx *ctx, int slot, const char **name, double *total_ms,
   if (name) *name = ctx->prof[slot].name;
   if (total_ms) *total_ms = ctx->prof[slot].ms;
   if (launches) *launches = ctx->prof[slot].launches;
+  if (bytes_per_launch) *bytes_per_launch = ctx->prof[slot].bytes;
   return MRL_OK;
 }
 

@@ -113,15 +113,15 @@ int pass_z_inverse(mrl_ctx *ctx, const double *d_in, double *d_out, long long A0
 int fft_forward_serial(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch, int layout) {
   const long long A0 = ctx->n[0], A1 = ctx->n[1], nzc = ctx->nrec[2];
   {
-    ProfScope ps(ctx, "fft_z_fwd_generic");
+    ProfScope ps(ctx, "fft_z_fwd_generic", (double)batch * (8.0 * A0 * A1 * ctx->n[2] + 16.0 * A0 * A1 * nzc));
     MRL_TRY(pass_z_forward(ctx, d_in, d_out, A0, A1, batch, layout));
   }
   if (A1 > 1) {
-    ProfScope ps(ctx, "fft_y_generic");
+    ProfScope ps(ctx, "fft_y_generic", (double)batch * 32.0 * A0 * A1 * nzc);
     MRL_TRY(pass_strided(ctx, 1, -1, d_out, d_out, A0, A1, nzc, batch, layout));
   }
   if (A0 > 1) {
-    ProfScope ps(ctx, "fft_x_generic");
+    ProfScope ps(ctx, "fft_x_generic", (double)batch * 32.0 * A0 * A1 * nzc);
     MRL_TRY(pass_strided(ctx, 0, -1, d_out, d_out, A0, A1, nzc, batch, layout));
   }
   return MRL_OK;
@@ -135,17 +135,17 @@ int fft_inverse_serial(mrl_ctx *ctx, const double *d_in, double *d_out, long lon
     MRL_TRY(ensure_work(ctx, 0, sizeof(cplx) * A0 * A1 * nzc * batch));
     double *w = ctx->d_work[0];
     if (A0 > 1) {
-      ProfScope ps(ctx, "fft_x_generic");
+      ProfScope ps(ctx, "fft_x_generic", (double)batch * 32.0 * A0 * A1 * nzc);
       MRL_TRY(pass_strided(ctx, 0, +1, cur, w, A0, A1, nzc, batch, layout));
       cur = w;
     }
     if (A1 > 1) {
-      ProfScope ps(ctx, "fft_y_generic");
+      ProfScope ps(ctx, "fft_y_generic", (double)batch * 32.0 * A0 * A1 * nzc);
       MRL_TRY(pass_strided(ctx, 1, +1, cur, w, A0, A1, nzc, batch, layout));
       cur = w;
     }
   }
-  ProfScope ps(ctx, "fft_z_inv_generic");
+  ProfScope ps(ctx, "fft_z_inv_generic", (double)batch * (8.0 * A0 * A1 * A2 + 16.0 * A0 * A1 * nzc));
   return pass_z_inverse(ctx, cur, d_out, A0, A1, batch, layout, scale);
 }
 
@@ -161,6 +161,7 @@ int mrl_fft_r2c(mrl_ctx *ctx, const double *d_in, double *d_out, int64_t batch, 
     return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_r2c: bad argument");
   if (ctx->nranks > 1)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_r2c on a slab context: use the mrl_slab_* stages");
+  if (fast_path_ok(ctx) && (layout == 0 || batch == 1)) return fft_forward_fast(ctx, d_in, d_out, batch);
   return fft_forward_serial(ctx, d_in, d_out, batch, layout);
 }
 
@@ -170,6 +171,7 @@ int mrl_fft_c2r(mrl_ctx *ctx, const double *d_in, double *d_out, int64_t batch, 
     return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_c2r: bad argument");
   if (ctx->nranks > 1)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_c2r on a slab context: use the mrl_slab_* stages");
+  if (fast_path_ok(ctx) && (layout == 0 || batch == 1)) return fft_inverse_fast(ctx, d_in, d_out, batch);
   return fft_inverse_serial(ctx, d_in, d_out, batch, layout);
 }
 

@@ -1,0 +1,200 @@
+// Fast-path kernels (3-D, power-of-two extents) built from fft_pow2.h.
+//   k_z_fwd      real lines -> half spectra along z; two real sequences per complex transform
+//                (CH mode: c and mu=f'(c) of the same line; PAIR mode: two adjacent lines)
+//   k_pass       c2c transform along a strided axis (x or y), forward or inverse, NF fields
+//   k_z_inv      half spectra -> real lines (two lines per complex transform), scaled
+// The fused Cahn-Hilliard x-pass lives in ch_fused.hip.
+#pragma once
+#include "fft_pow2.h"
+
+namespace mrl {
+namespace p2 {
+
+struct ChDev {
+  int family;
+  double c0, c1, c2;
+};
+
+__device__ __forceinline__ double mu_eval(const ChDev &p, double c) {
+#pragma clang fp contract(off)
+  if (p.family == MRL_FE_DOUBLE_WELL) {
+    const double cm1 = c - 1.0;
+    return (p.c0 * (2.0 * c)) * (cm1 * cm1) + (p.c0 * (c * c)) * (2.0 * cm1);
+  } else {
+    const double a = c - p.c1;
+    const double b = p.c2 - c;
+    return (p.c0 * (2.0 * a)) * (b * b) + (p.c0 * (a * a)) * ((2.0 * b) * -1.0);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// z forward.  MODE 0 (PAIR): rows 2L, 2L+1 of `in` -> rows 2L, 2L+1 of out0.
+//             MODE 1 (CH)  : row L of `in` (=c) -> row L of out0 (c-hat_z) and out1 (mu-hat_z);
+//                            optionally writes mu to mu_out.
+// nlines = number of complex transforms.
+template <int N, int MODE>
+__global__ void __launch_bounds__(256) k_z_fwd(const double *__restrict__ in, cplx *__restrict__ out0,
+                                               cplx *__restrict__ out1, double *__restrict__ mu_out, ChDev chp,
+                                               long long nlines, const cplx *__restrict__ tw) {
+  constexpr int TPL = N / 16, LPB = 4096 / N, NZC = N / 2 + 1;
+  using Map = MapLine<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
+  const long long L = (long long)blockIdx.x * LPB + l;
+  const bool valid = L < nlines;
+  load_twiddles<N>(W, tw);
+
+  cplx v[16];
+  const long long r0 = (MODE == 0) ? 2 * L : L;
+  if (valid) {
+    const double *p0 = in + r0 * N + q;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const double a = p0[m * TPL];
+      double b;
+      if (MODE == 0)
+        b = p0[N + m * TPL];
+      else
+        b = mu_eval(chp, a);
+      v[m] = make_double2(a, b);
+    }
+    if (MODE == 1 && mu_out) {
+      double *pm = mu_out + r0 * N + q;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) pm[m * TPL] = v[m].y;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
+  }
+  fft_line<N, Map>(v, q, l, X, W);
+  // natural-order copy in LDS for the k <-> N-k pairing
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 16; ++m) X[Map::at(q + m * TPL, l)] = v[m];
+  __syncthreads();
+  if (!valid) return;
+  cplx *o0 = (MODE == 0) ? out0 + (2 * L) * NZC : out0 + L * NZC;
+  cplx *o1 = (MODE == 0) ? out0 + (2 * L + 1) * NZC : out1 + L * NZC;
+#pragma unroll
+  for (int m = 0; m <= 8; ++m) {
+    const int k = q + m * TPL;
+    if (m == 8 && q != 0) break;
+    const cplx xk = v[m];
+    const cplx xn = X[Map::at((N - k) & (N - 1), l)];
+    o0[k] = make_double2(0.5 * (xk.x + xn.x), 0.5 * (xk.y - xn.y));
+    o1[k] = make_double2(0.5 * (xk.y + xn.y), -0.5 * (xk.x - xn.x));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// z inverse (PAIR): rows 2L, 2L+1 of the half spectrum `in` -> real rows 2L, 2L+1 of out, * scale.
+template <int N>
+__global__ void __launch_bounds__(256) k_z_inv(const cplx *__restrict__ in, double *__restrict__ out, double scale,
+                                               long long nlines, const cplx *__restrict__ tw) {
+  constexpr int TPL = N / 16, LPB = 4096 / N, NZC = N / 2 + 1;
+  using Map = MapLine<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
+  const long long L = (long long)blockIdx.x * LPB + l;
+  const bool valid = L < nlines;
+  load_twiddles<N>(W, tw);
+  cplx v[16];
+  if (valid) {
+    const cplx *A = in + (2 * L) * NZC;
+    const cplx *B = A + NZC;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int p = q + m * TPL;
+      const bool lo = p <= N / 2;
+      const int k = lo ? p : N - p;
+      cplx a = A[k], b = B[k];
+      if (k == 0 || k == N / 2) {  // c2r ignores the imaginary part of the self-conjugate bins
+        a.y = 0.0;
+        b.y = 0.0;
+      }
+      // X[p] = A + iB (p <= N/2), conj(A[k]) + i conj(B[k]) otherwise ; then swap for the inverse
+      const cplx x = lo ? make_double2(a.x - b.y, a.y + b.x) : make_double2(a.x + b.y, b.x - a.y);
+      v[m] = cswap(x);
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
+  }
+  fft_line<N, Map>(v, q, l, X, W);
+  if (!valid) return;
+  double *o0 = out + (2 * L) * N + q;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    // swap back: real part (row 2L) = v.y, imaginary part (row 2L+1) = v.x
+    o0[m * TPL] = v[m].y * scale;
+    o0[N + m * TPL] = v[m].x * scale;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// strided c2c pass.  Arrays are [outer][N][inner] complex (inner contiguous); a workgroup owns
+// T = 4096/N consecutive `inner` positions of one `outer` slice for all N points of the axis.
+struct PassArgs {
+  const cplx *in[2];
+  cplx *out[2];
+  long long inner;           // contiguous extent
+  long long outer;           // number of outer slices
+  long long so_in, so_out;   // outer strides (elements)
+  long long sn_in, sn_out;   // stride between successive points of the axis
+  int tiles_per_outer;
+  double scale;
+};
+
+template <int N, bool INV, int NF>
+__global__ void __launch_bounds__(256) k_pass(PassArgs a, const cplx *__restrict__ tw) {
+  constexpr int TPL = N / 16, T = 4096 / N;
+  using Map = MapStrided<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  const int l = threadIdx.x % T, q = threadIdx.x / T;
+  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const long long o = logical / a.tiles_per_outer;
+  const long long i = (long long)(logical % a.tiles_per_outer) * T + l;
+  const bool valid = i < a.inner;
+  load_twiddles<N>(W, tw);
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    cplx v[16];
+    if (valid) {
+      const cplx *p = a.in[f] + o * a.so_in + i + (long long)q * a.sn_in;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const cplx x = p[(long long)m * TPL * a.sn_in];
+        v[m] = INV ? cswap(x) : x;
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
+    }
+    fft_line<N, Map>(v, q, l, X, W);
+    if (valid) {
+      cplx *p = a.out[f] + o * a.so_out + i + (long long)q * a.sn_out;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) p[(long long)m * TPL * a.sn_out] = INV ? cswap(v[m]) : v[m];
+    }
+  }
+}
+
+template <int N>
+constexpr size_t lds_line() {
+  return sizeof(cplx) * (N + MapLine<N>::size);
+}
+template <int N>
+constexpr size_t lds_strided() {
+  return sizeof(cplx) * (N + MapStrided<N>::size);
+}
+
+}  // namespace p2
+}  // namespace mrl

@@ -45,6 +45,7 @@ struct Profile {
   const char *name;
   double ms;
   long long launches;
+  double bytes;  // algorithmic HBM bytes of one launch (DESIGN.md "Kernels")
 };
 
 }  // namespace mrl
@@ -121,9 +122,21 @@ struct ProfScope {
   mrl_ctx *ctx;
   int slot;
   hipEvent_t a = nullptr, b = nullptr;
-  ProfScope(mrl_ctx *c, const char *name);
+  ProfScope(mrl_ctx *c, const char *name, double bytes = 0.0);
   ~ProfScope();
 };
+
+// Cahn-Hilliard parameters as the kernels take them
+struct ChP {
+  int family;
+  double c0, c1, c2;
+  double M, kappa;
+};
+
+// power-of-two fast path (ch_fused.hip)
+bool fast_path_ok(const mrl_ctx *ctx);
+int fft_forward_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
+int fft_inverse_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
 
 // serial transforms (fft_plan.hip)
 int fft_forward_serial(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch, int layout);

@@ -87,3 +87,38 @@ def test_ch_pfhub_family_and_ab3():
     p = ch_params(FE_PFHUB, (5.0, 0.3, 0.7), mobility=5.0, kappa=-10.0)
     states, _ = _run_hip_ch(ctx, p, c0, 3, 4, 1.0, pred=2)
     assert (states[-1] - ref.c).abs().max().item() <= 1e-13
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (64, 128, 64), (128, 64, 64)])
+def test_ch_fused_fast_path_outputs(shape):
+    """fused fast path: c, Nhat (history buffer), optional cbar and mu outputs vs the oracle's op sequence"""
+    from marlin_amd.api import Context, ch_params
+    L = [4.0, 5.0, 6.0]
+    ctx = Context(3, list(shape), L)
+    dom = mo.Domain(3, list(shape), L)
+    torch.manual_seed(3)
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    Mbar = mo.reciprocal_laplacian_factor(dom, 0.2)
+    Lbar = mo.reciprocal_laplacian_square_factor(dom, -0.001)
+    r1, N1, cb1, mu1 = mo.ch_substep_ops(c0, Mbar, Lbar, [], 2e-3, 0, mo.mu_double_well, dom)
+    r2, N2, cb2, mu2 = mo.ch_substep_ops(r1, Mbar, Lbar, [N1], 2e-3, 1, mo.mu_double_well, dom)
+    r3, N3, _, _ = mo.ch_substep_ops(r2, Mbar, Lbar, [N2, N1], 2e-3, 2, mo.mu_double_well, dom)
+    p = ch_params()
+    c = c0.cuda()
+    Na, Nb, Nc = ctx.empty_spec(), ctx.empty_spec(), ctx.empty_spec()
+    cbar, mu = ctx.empty_spec(), torch.empty_like(c)
+    c1, c2, c3 = torch.empty_like(c), torch.empty_like(c), torch.empty_like(c)
+    ctx.ch_substep(p, c, c1, Na, [], 0, 2e-3, cbar=cbar, mu=mu)
+    sc = cb1.abs().max().item()
+    assert (cbar.cpu() - cb1).abs().max().item() <= 1e-13 * sc
+    assert (mu.cpu() - mu1).abs().max().item() <= 1e-15
+    assert (Na.cpu() - N1).abs().max().item() <= 1e-13 * max(1.0, N1.abs().max().item())
+    assert (c1.cpu() - r1).abs().max().item() <= 1e-14
+    ctx.ch_substep(p, c1, c2, Nb, [Na], 1, 2e-3)
+    assert (c2.cpu() - r2).abs().max().item() <= 1e-14
+    ctx.ch_substep(p, c2, c3, Nc, [Nb, Na], 2, 2e-3)
+    assert (c3.cpu() - r3).abs().max().item() <= 1e-14
+    # in-place (c_out aliases c_in) gives the same result
+    c2b = c1.clone()
+    ctx.ch_substep(p, c2b, c2b, Nc, [Na], 1, 2e-3)
+    assert torch.equal(c2b, c2)

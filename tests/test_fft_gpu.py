@@ -76,3 +76,23 @@ def test_errors_are_reported():
         Context(2, [8, 8], [0.0, 1.0])
     with pytest.raises(MarlinHipError, match="Unsupported mesh dimension"):
         Context(4, [8, 8, 8], [1.0, 1.0, 1.0])
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (128, 64, 256), (64, 128, 64), (256, 64, 128), (64, 512, 64)])
+def test_fast_path_pow2(shape):
+    """power-of-two fast path (fft_pow2*.h) vs the oracle, incl. non-hermitian-consistent inverse input"""
+    ctx, dom = _ctx(shape)
+    torch.manual_seed(shape[0] + shape[2])
+    a = torch.rand(shape, dtype=torch.float64)
+    ref = dom.fft(a)
+    got = ctx.fft(a.cuda()).cpu()
+    assert (got - ref).abs().max().item() <= 1e-13 * ref.abs().max().item()
+    spec = torch.randn(ref.shape, dtype=torch.complex128)
+    ref_r = dom.ifft(spec)
+    got_r = ctx.ifft(spec.cuda()).cpu()
+    assert (got_r - ref_r).abs().max().item() <= 1e-13 * max(1.0, ref_r.abs().max().item())
+    b = torch.rand((2,) + tuple(shape), dtype=torch.float64)
+    gb = ctx.fft_fields(b.cuda())
+    for i in range(2):
+        assert (gb[i].cpu() - dom.fft(b[i])).abs().max().item() <= 1e-13 * ref.abs().max().item()
+    assert (ctx.ifft_fields(gb).cpu() - b).abs().max().item() <= 1e-14
