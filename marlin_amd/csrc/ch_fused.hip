@@ -29,7 +29,7 @@ struct FusedArgs {
   double M, kappa, dt;
 };
 
-template <int N>
+template <int N, int ORDER>
 __global__ void __launch_bounds__(256) k_ch_xfused(FusedArgs a, const cplx *__restrict__ tw) {
 #pragma clang fp contract(off)
   constexpr int TPL = N / 16, T = 4096 / N;
@@ -92,25 +92,38 @@ __global__ void __launch_bounds__(256) k_ch_xfused(FusedArgs a, const cplx *__re
     for (int m = 0; m < 16; ++m) a.cbar[off + (long long)m * TPL * sn] = v[m];
   }
 
-  // 4. ubar = (cbar + (dt b0) N + sum (dt b_i) Nold_i) / (1 - dt*Lbar), in the reference's association
+  // 4. ubar = (cbar + (dt b0) N + sum (dt b_i) Nold_i) / (1 - dt*Lbar), in the reference's association.
+  //    ORDER is a template constant and the history loads are issued 8 at a time ahead of their use
+  //    (a run-time trip count here makes hipcc wait vmcnt(0) per element).
 #pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    cplx u = v[m];
-    u.x = u.x + a.coef[0] * Nv[m].x;
-    u.y = u.y + a.coef[0] * Nv[m].y;
-    if (valid) {
-      for (int h = 0; h < a.order; ++h) {
-        const cplx o = a.Nold[h][off + (long long)m * TPL * sn];
-        u.x += a.coef[h + 1] * o.x;
-        u.y += a.coef[h + 1] * o.y;
+  for (int half = 0; half < 2; ++half) {
+    cplx o[ORDER > 0 ? ORDER : 1][8];
+    if (ORDER > 0) {
+#pragma unroll
+      for (int h = 0; h < ORDER; ++h) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          o[h][j] = valid ? a.Nold[h][off + (long long)(half * 8 + j) * TPL * sn] : make_double2(0.0, 0.0);
       }
     }
-    const double kx = KX[q + m * TPL];
-    const double k2 = kx * kx + ky2 + kz2;
-    const double Lb = k2 * k2 * a.kappa;
-    const double scl = 1.0 / (1.0 - a.dt * Lb);
-    // swapped for the inverse transform
-    v[m] = make_double2(u.y * scl, u.x * scl);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = half * 8 + j;
+      cplx u = v[m];
+      u.x = u.x + a.coef[0] * Nv[m].x;
+      u.y = u.y + a.coef[0] * Nv[m].y;
+#pragma unroll
+      for (int h = 0; h < ORDER; ++h) {
+        u.x += a.coef[h + 1] * o[h][j].x;
+        u.y += a.coef[h + 1] * o[h][j].y;
+      }
+      const double kx = KX[q + m * TPL];
+      const double k2 = kx * kx + ky2 + kz2;
+      const double Lb = k2 * k2 * a.kappa;
+      const double scl = 1.0 / (1.0 - a.dt * Lb);
+      // swapped for the inverse transform
+      v[m] = make_double2(u.y * scl, u.x * scl);
+    }
   }
 
   // 5. inverse x (unnormalised; 1/N applied by the final z pass)
@@ -130,18 +143,18 @@ static int set_lds_attr(mrl_ctx *ctx, K kernel, size_t lds) {
   return MRL_OK;
 }
 
-template <int N, int MODE>
+template <int N, int MODE, int FAM>
 static int launch_z_fwd(mrl_ctx *ctx, const double *in, cplx *o0, cplx *o1, double *mu, const ChDev &chp,
                         long long nlines) {
   static bool attr = false;
   constexpr size_t lds = lds_line<N>();
   if (!attr) {
-    MRL_TRY(set_lds_attr(ctx, k_z_fwd<N, MODE>, lds));
+    MRL_TRY(set_lds_attr(ctx, k_z_fwd<N, MODE, FAM>, lds));
     attr = true;
   }
   constexpr int LPB = 4096 / N;
   const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_fwd<N, MODE>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, o0, o1, mu, chp, nlines,
+  hipLaunchKernelGGL((k_z_fwd<N, MODE, FAM>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, o0, o1, mu, chp, nlines,
                      ctx->ax[2].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
@@ -179,17 +192,17 @@ static int launch_pass_t(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
   return MRL_OK;
 }
 
-template <int N>
+template <int N, int ORDER>
 static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
   if (!attr) {
-    MRL_TRY(set_lds_attr(ctx, k_ch_xfused<N>, lds));
+    MRL_TRY(set_lds_attr(ctx, k_ch_xfused<N, ORDER>, lds));
     attr = true;
   }
   constexpr int T = 4096 / N;
   const long long nb = (a.inner + T - 1) / T;
-  hipLaunchKernelGGL((k_ch_xfused<N>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, ctx->ax[0].d_tw);
+  hipLaunchKernelGGL((k_ch_xfused<N, ORDER>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, ctx->ax[0].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
@@ -261,7 +274,7 @@ int fft_forward_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long 
     cplx *out = reinterpret_cast<cplx *>(d_out) + b * nspec;
     {
       ProfScope ps(ctx, "z_fwd_pair", 8.0 * nreal + 16.0 * nspec);
-      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0>(ctx, in, out, nullptr, nullptr, none, nx * ny / 2))));
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, in, out, nullptr, nullptr, none, nx * ny / 2))));
     }
     {
       ProfScope ps(ctx, "pass_y", 32.0 * nspec);
@@ -321,7 +334,11 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
   const double h = 16.0 * nspec;  // bytes of one complex half-spectrum array
   {
     ProfScope ps(ctx, "ch_A_z_fwd", 8.0 * nreal + 2.0 * h + (mu ? 8.0 * nreal : 0.0));
-    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1>(ctx, c_in, w_c, w_mu, mu, chp, nx * ny))));
+    if (cp.family == MRL_FE_DOUBLE_WELL) {
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_c, w_mu, mu, chp, nx * ny))));
+    } else {
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, w_c, w_mu, mu, chp, nx * ny))));
+    }
   }
   {
     ProfScope ps(ctx, "ch_B_y_fwd", 4.0 * h);
@@ -346,7 +363,13 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
     a.M = cp.M;
     a.kappa = cp.kappa;
     a.dt = sub_dt;
-    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN>(ctx, a))));
+    switch (order) {
+      case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0>(ctx, a)))); break;
+      case 1: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 1>(ctx, a)))); break;
+      case 2: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 2>(ctx, a)))); break;
+      case 3: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 3>(ctx, a)))); break;
+      default: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 4>(ctx, a)))); break;
+    }
   }
   {
     ProfScope ps(ctx, "ch_D_y_inv", 2.0 * h);

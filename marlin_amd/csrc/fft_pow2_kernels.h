@@ -15,9 +15,12 @@ struct ChDev {
   double c0, c1, c2;
 };
 
+// FAM is a compile-time constant: a run-time family test inside the unrolled load loop makes hipcc
+// branch around every element and wait vmcnt(0) per load (16 dependent HBM round trips).
+template <int FAM>
 __device__ __forceinline__ double mu_eval(const ChDev &p, double c) {
 #pragma clang fp contract(off)
-  if (p.family == MRL_FE_DOUBLE_WELL) {
+  if (FAM == MRL_FE_DOUBLE_WELL) {
     const double cm1 = c - 1.0;
     return (p.c0 * (2.0 * c)) * (cm1 * cm1) + (p.c0 * (c * c)) * (2.0 * cm1);
   } else {
@@ -33,7 +36,7 @@ __device__ __forceinline__ double mu_eval(const ChDev &p, double c) {
 //             MODE 1 (CH)  : row L of `in` (=c) -> row L of out0 (c-hat_z) and out1 (mu-hat_z);
 //                            optionally writes mu to mu_out.
 // nlines = number of complex transforms.
-template <int N, int MODE>
+template <int N, int MODE, int FAM>
 __global__ void __launch_bounds__(256) k_z_fwd(const double *__restrict__ in, cplx *__restrict__ out0,
                                                cplx *__restrict__ out1, double *__restrict__ mu_out, ChDev chp,
                                                long long nlines, const cplx *__restrict__ tw) {
@@ -51,16 +54,18 @@ __global__ void __launch_bounds__(256) k_z_fwd(const double *__restrict__ in, cp
   const long long r0 = (MODE == 0) ? 2 * L : L;
   if (valid) {
     const double *p0 = in + r0 * N + q;
+    double a[16], b[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const double a = p0[m * TPL];
-      double b;
-      if (MODE == 0)
-        b = p0[N + m * TPL];
-      else
-        b = mu_eval(chp, a);
-      v[m] = make_double2(a, b);
+    for (int m = 0; m < 16; ++m) a[m] = p0[m * TPL];
+    if (MODE == 0) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) b[m] = p0[N + m * TPL];
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) b[m] = mu_eval<FAM>(chp, a[m]);
     }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = make_double2(a[m], b[m]);
     if (MODE == 1 && mu_out) {
       double *pm = mu_out + r0 * N + q;
 #pragma unroll
