@@ -1,0 +1,186 @@
+// Device reductions: the torch::sum / torch::norm call sites of the CG and the Newton loop
+// (include/utils/MarlinUtils.h:63,82,92,99,109; src/tensor_computes/FFTMechanics.C:124,146) and
+// DomainAction::average (src/actions/DomainAction.C:1558-1574).
+//
+// Two deterministic stages (no atomics): up to kRedBlocks workgroups write one partial each into
+// ctx->d_red, a single workgroup folds the partials into a device scalar slot (ctx->d_red + kScalarBase).
+// Scalars stay on the device for kernels that consume them (CG step sizes); the synchronous C ABI
+// entry points copy them to pinned host memory.
+#include "mrl_internal.h"
+
+namespace mrl {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// block sum of `v` over 256 threads -> valid in thread 0
+__device__ __forceinline__ double block_sum256(double v, double *sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return r;
+}
+
+// OP 0: sum a ; 1: sum a*b ; 2: sum a*a
+template <int OP>
+__global__ void __launch_bounds__(256) k_reduce_partial(const double *__restrict__ a, const double *__restrict__ b,
+                                                         long long n, double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  const long long stride = (long long)gridDim.x * 256 * 2;
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+  for (; i + 1 < n; i += stride) {
+    const double2 x = *reinterpret_cast<const double2 *>(a + i);
+    if (OP == 0) {
+      acc += x.x + x.y;
+    } else if (OP == 1) {
+      const double2 y = *reinterpret_cast<const double2 *>(b + i);
+      acc += x.x * y.x + x.y * y.y;
+    } else {
+      acc += x.x * x.x + x.y * x.y;
+    }
+  }
+  if (i < n) {
+    const double x = a[i];
+    acc += (OP == 0) ? x : (OP == 1 ? x * b[i] : x * x);
+  }
+  const double r = block_sum256(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// fold `nb` partials of `nslots` interleaved quantities (partial[b*nslots + s]) into out[s]
+__global__ void __launch_bounds__(256) k_reduce_final(const double *__restrict__ partial, int nb, int nslots,
+                                                       double *__restrict__ out) {
+  __shared__ double sh[4];
+  for (int s = 0; s < nslots; ++s) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += partial[(long long)i * nslots + s];
+    const double r = block_sum256(acc, sh);
+    if (threadIdx.x == 0) out[s] = r;
+  }
+}
+
+// per-component sums of a value-major field [npts][ncomp]; partial[b*ncomp + c]
+__global__ void __launch_bounds__(256) k_component_sums(const double *__restrict__ a, long long npts, int ncomp,
+                                                         double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.0;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npts; p += (long long)gridDim.x * 256) {
+    const double *q = a + p * ncomp;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < ncomp) acc[c] += q[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    if (c < ncomp) {
+      const double r = block_sum256(acc[c], sh);
+      if (threadIdx.x == 0) partial[(long long)blockIdx.x * ncomp + c] = r;
+    }
+  }
+}
+
+static int red_blocks(long long n) {
+  long long b = (n / 2 + 255) / 256;
+  if (b > kRedBlocks) b = kRedBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// enqueue: d_scalar[0] = reduction result
+int reduce_async(mrl_ctx *ctx, int op, const double *a, const double *b, long long n, double *d_scalar) {
+  if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) != 0)
+    return set_error(ctx, MRL_ERR_INVALID, "reduction operands must be 16-byte aligned");
+  const int nb = red_blocks(n);
+  switch (op) {
+    case 0: hipLaunchKernelGGL(k_reduce_partial<0>, dim3(nb), dim3(256), 0, ctx->stream, a, b, n, ctx->d_red); break;
+    case 1: hipLaunchKernelGGL(k_reduce_partial<1>, dim3(nb), dim3(256), 0, ctx->stream, a, b, n, ctx->d_red); break;
+    default: hipLaunchKernelGGL(k_reduce_partial<2>, dim3(nb), dim3(256), 0, ctx->stream, a, b, n, ctx->d_red); break;
+  }
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, ctx->d_red, nb, 1, d_scalar);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+// fold partials that another kernel left in ctx->d_red (nb blocks x nslots) into d_scalar[0..nslots)
+int reduce_finalize(mrl_ctx *ctx, int nb, int nslots, double *d_scalar) {
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, ctx->d_red, nb, nslots, d_scalar);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+// copy `count` device scalars starting at d_scalar to host (synchronises the stream)
+int read_scalars(mrl_ctx *ctx, const double *d_scalar, int count, double *h_out) {
+  MRL_HIP(ctx, hipMemcpyAsync(ctx->h_red, d_scalar, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+  MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < count; ++i) h_out[i] = ctx->h_red[i];
+  return MRL_OK;
+}
+
+int component_sums_async(mrl_ctx *ctx, const double *a, long long npts, int ncomp, double *d_scalar) {
+  long long nb = (npts + 255) / 256;
+  if (nb > kRedBlocks / 16) nb = kRedBlocks / 16;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_component_sums, dim3((unsigned)nb), dim3(256), 0, ctx->stream, a, npts, ncomp, ctx->d_red);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, ctx->d_red, (int)nb, ncomp, d_scalar);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+}  // namespace mrl
+
+using namespace mrl;
+
+static int sync_reduce(mrl_ctx *ctx, int op, const double *a, const double *b, int64_t n, double *h_out,
+                       const char *what) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!a || (op == 1 && !b) || n < 0 || !h_out) return set_error(ctx, MRL_ERR_INVALID, "%s: bad argument", what);
+  if (n == 0) {
+    *h_out = 0.0;
+    return MRL_OK;
+  }
+  double *slot = ctx->d_red + kScalarBase;
+  MRL_TRY(reduce_async(ctx, op, a, op == 1 ? b : a, n, slot));
+  return read_scalars(ctx, slot, 1, h_out);
+}
+
+extern "C" {
+
+int mrl_dot(mrl_ctx *ctx, const double *d_a, const double *d_b, int64_t n, double *h_out) {
+  return sync_reduce(ctx, 1, d_a, d_b, n, h_out, "mrl_dot");
+}
+
+int mrl_norm2(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_out) {
+  int rc = sync_reduce(ctx, 2, d_a, nullptr, n, h_out, "mrl_norm2");
+  if (rc == MRL_OK) *h_out = sqrt(*h_out);
+  return rc;
+}
+
+int mrl_sum(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_out) {
+  return sync_reduce(ctx, 0, d_a, nullptr, n, h_out, "mrl_sum");
+}
+
+int mrl_average(mrl_ctx *ctx, const double *d_a, int64_t ncomp, double *h_out) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!d_a || !h_out || ncomp < 1 || ncomp > 16)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_average: need 1 <= ncomp <= 16");
+  if (ctx->nranks > 1)
+    return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_average: reduce the per-rank sums across ranks in the caller");
+  const long long npts = real_count_local(ctx);
+  double *slot = ctx->d_red + kScalarBase;
+  MRL_TRY(component_sums_async(ctx, d_a, npts, (int)ncomp, slot));
+  MRL_TRY(read_scalars(ctx, slot, (int)ncomp, h_out));
+  for (int c = 0; c < ncomp; ++c) h_out[c] /= (double)npts;
+  return MRL_OK;
+}
+
+}  // extern "C"
