@@ -139,13 +139,16 @@ int mrl_kspace_abm(mrl_ctx *ctx, double *d_ubar_out, const double *d_ubar0, cons
                    const double *h_coef, int nterms, const double *d_L, double dt, int64_t n_spec);
 
 /* Slab (multi-GPU) CH substep, split at its two exchanges (forward pair, inverse):
- *   mrl_slab_ch_fwd_local  : mu=f'(c); local passes of fft(c), fft(mu) -> d_send (2 fields per chunk)
- *   [exchange]
+ *   mrl_slab_ch_fwd_local  : mu=f'(c); local passes of fft(c), fft(mu) -> d_send
+ *   [exchange x2]            d_send/d_recv hold two fields back to back (c first, then mu), each laid
+ *                            out as mrl_slab_counts(forward) says; each field is exchanged on its own.
  *   mrl_slab_ch_kspace     : finish both forward transforms, Nhat/ubar update, first inverse pass -> d_send
  *   [exchange]
  *   mrl_slab_inv_finish    : remaining inverse passes -> c_out
- * Chunk sizes for the forward exchange are 2x those of mrl_slab_counts. */
-int mrl_slab_ch_fwd_local(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_send, double *d_mu);
+ * `part` lets the caller start the exchange of the c field while the mu field is still being
+ * transformed: 0 = everything up to and including the c field, 1 = the rest (mu field), -1 = both. */
+int mrl_slab_ch_fwd_local(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_send, double *d_mu,
+                          int part);
 int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_recv, double *d_send,
                        double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt,
                        double *d_cbar);

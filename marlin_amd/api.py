@@ -187,6 +187,67 @@ class Context:
         cf = (C.c_double * max(1, n))(*coef)
         self._check(self.lib.mrl_kspace_abm(self.h, _ptr(out), _ptr(ubar0), arr, cf, n, _ptr(L), dt, ubar0.numel()))
 
+    # ---- de Geus mechanics (value-major [grid..., D, D] fields)
+    def gamma_apply(self, A: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty_like(A)
+        self._check(self.lib.mrl_gamma_apply(self.h, _ptr(A), _ptr(out)))
+        return out
+
+    def mech_stress(self, F, K, mu, out=None):
+        if out is None:
+            out = torch.empty_like(F)
+        self._check(self.lib.mrl_mech_stress(self.h, _ptr(F), _ptr(K), _ptr(mu), _ptr(out)))
+        return out
+
+    def mech_tangent_apply(self, F, K, mu, dF, out=None):
+        if out is None:
+            out = torch.empty_like(F)
+        self._check(self.lib.mrl_mech_tangent_apply(self.h, _ptr(F), _ptr(K), _ptr(mu), _ptr(dF), _ptr(out)))
+        return out
+
+    def mech_newton_cg(self, F, K, mu, applied, l_tol=1e-2, l_max_its=0, nl_rel_tol=1e-5, nl_abs_tol=1e-8,
+                       nl_max_its=100, Fnew=None, P=None):
+        """FFTMechanics::computeBuffer; returns (Fnew, P, stats dict)."""
+        prm = MrlMechParams()
+        prm.l_tol, prm.l_max_its = l_tol, l_max_its
+        prm.nl_rel_tol, prm.nl_abs_tol, prm.nl_max_its = nl_rel_tol, nl_abs_tol, nl_max_its
+        if Fnew is None:
+            Fnew = torch.empty_like(F)
+        if P is None:
+            P = torch.empty_like(F)
+        st = MrlMechStats()
+        self._check(self.lib.mrl_mech_newton_cg(self.h, C.byref(prm), _ptr(F), _ptr(K), _ptr(mu), _ptr(applied),
+                                                _ptr(Fnew), _ptr(P), C.byref(st)))
+        stats = {"newton_its": st.newton_its, "cg_its": [st.cg_its[i] for i in range(min(st.newton_its, 64))],
+                 "cg_its_total": st.cg_its_total, "anorm": st.last_anorm, "rnorm": st.last_rnorm, "Fn": st.Fn}
+        return Fnew, P, stats
+
+    # ---- reductions (synchronous)
+    def _scalar(self, fn, *args):
+        out = C.c_double()
+        self._check(fn(self.h, *args, C.byref(out)))
+        return float(out.value)
+
+    def dot(self, a, b):
+        return self._scalar(self.lib.mrl_dot, _ptr(a), _ptr(b), a.numel())
+
+    def norm2(self, a):
+        return self._scalar(self.lib.mrl_norm2, _ptr(a), a.numel())
+
+    def sum(self, a):
+        return self._scalar(self.lib.mrl_sum, _ptr(a), a.numel())
+
+    def average(self, a: torch.Tensor) -> torch.Tensor:
+        """DomainAction::average of a value-major field -> host tensor of the value shape"""
+        vals = list(a.shape[self.dim:])
+        ncomp = 1
+        for v in vals:
+            ncomp *= v
+        out = (C.c_double * ncomp)()
+        self._check(self.lib.mrl_average(self.h, _ptr(a), ncomp, out))
+        return torch.tensor(list(out), dtype=torch.float64).reshape(vals)
+
     # ---- timing
     def timer_start(self):
         self._check(self.lib.mrl_timer_start(self.h))

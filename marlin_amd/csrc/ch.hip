@@ -43,11 +43,11 @@ struct KspaceArgs {
   const double *Nold[5];
 };
 
-__device__ __forceinline__ double ksq(int dim, double a, double b, double c) {
+// kx*kx + ky*ky + kz*kz with unused axes = {0} (DomainAction.C:1503-1509): adding the exact zeros of
+// the unused axes changes nothing, so one expression serves every dimension and axis alignment.
+__device__ __forceinline__ double ksq(int, double a, double b, double c) {
 #pragma clang fp contract(off)
-  if (dim == 3) return a * a + b * b + c * c;
-  if (dim == 2) return b * b + c * c;
-  return c * c;
+  return a * a + b * b + c * c;
 }
 
 // one thread per spectral point; cbar / mubar interleaved complex
@@ -118,7 +118,7 @@ static const double kBeta[5][5] = {
     {190.0 / 720.0, -2774.0 / 720.0, 2616.0 / 720.0, -1274.0 / 720.0, 251.0 / 720.0},
 };
 
-static int check_params(mrl_ctx *ctx, const mrl_ch_params *p, ChP &cp) {
+int ch_check_params(mrl_ctx *ctx, const mrl_ch_params *p, ChP &cp) {
   if (!p) return set_error(ctx, MRL_ERR_INVALID, "null mrl_ch_params");
   if (p->family != MRL_FE_DOUBLE_WELL && p->family != MRL_FE_PFHUB)
     return set_error(ctx, MRL_ERR_INVALID, "unknown free energy family %d", p->family);
@@ -136,6 +136,16 @@ static inline int grid_for(long long n, int per_thread = 1) {
   if (b > 8192) b = 8192;
   if (b < 1) b = 1;
   return (int)b;
+}
+
+int ch_mu_launch(mrl_ctx *ctx, const ChP &cp, const double *c, double *mu, long long count) {
+  if (count == 0) return MRL_OK;
+  if ((reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(mu)) & 15)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_mu: pointers must be 16-byte aligned");
+  ProfScope ps(ctx, "ch_mu", 16.0 * (double)count);
+  hipLaunchKernelGGL(k_ch_mu, dim3(grid_for(count, 2)), dim3(256), 0, ctx->stream, cp, c, mu, count);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
 }
 
 int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const double *mubar, double *Nhat, double *ubar,
@@ -175,22 +185,16 @@ extern "C" {
 int mrl_ch_mu(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c, double *d_mu, int64_t count) {
   if (!ctx) return MRL_ERR_INVALID;
   ChP cp;
-  MRL_TRY(check_params(ctx, p, cp));
+  MRL_TRY(ch_check_params(ctx, p, cp));
   if (!d_c || !d_mu || count < 0) return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_mu: bad argument");
-  if (count == 0) return MRL_OK;
-  if ((reinterpret_cast<uintptr_t>(d_c) | reinterpret_cast<uintptr_t>(d_mu)) & 15)
-    return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_mu: pointers must be 16-byte aligned");
-  ProfScope ps(ctx, "ch_mu", 16.0 * (double)count);
-  hipLaunchKernelGGL(k_ch_mu, dim3(grid_for(count, 2)), dim3(256), 0, ctx->stream, cp, d_c, d_mu, (long long)count);
-  MRL_HIP(ctx, hipGetLastError());
-  return MRL_OK;
+  return ch_mu_launch(ctx, cp, d_c, d_mu, (long long)count);
 }
 
 int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_c_out, double *d_Nhat_new,
                    const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar, double *d_mu) {
   if (!ctx) return MRL_ERR_INVALID;
   ChP cp;
-  MRL_TRY(check_params(ctx, p, cp));
+  MRL_TRY(ch_check_params(ctx, p, cp));
   if (!d_c_in || !d_c_out || !d_Nhat_new) return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substep: null buffer");
   if (order < 0 || order > 4) return set_error(ctx, MRL_ERR_INVALID, "predictor order %d out of range", order + 1);
   if (order > 0 && !d_Nhat_old) return set_error(ctx, MRL_ERR_INVALID, "history pointers missing");

@@ -185,7 +185,11 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
   c->spectrum = dom->spectrum;
   c->nranks = dom->nranks;
   c->rank = dom->rank;
-  const int off = 3 - c->dim;
+  // internal axes: serial contexts right-align the user axes (the r2c axis is always A2); slab
+  // contexts left-align them so that x = A0 is the reciprocal split axis and y = A1 the real-space
+  // split axis in 2-D and 3-D alike (a 2-D slab domain is [nx][ny][1]).
+  c->off = (c->nranks > 1) ? 0 : 3 - c->dim;
+  const int off = c->off;
   for (int a = 0; a < 3; ++a) {
     c->n[a] = 1;
     c->gmin[a] = 0.0;
@@ -227,7 +231,7 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
 
   // reciprocal axes (global)
   for (int a = 0; a < 3; ++a) {
-    if (a < off) {
+    if (a < off || a >= off + c->dim) {
       c->h_k[a] = {0.0};  // DomainAction.C:295-296
       c->nrec_glob[a] = 1;
     } else {
@@ -295,7 +299,7 @@ void mrl_ctx_destroy(mrl_ctx *c) {
     if (c->ax[a].d_tw) hipFree(c->ax[a].d_tw);
     if (c->d_k[a]) hipFree(c->d_k[a]);
   }
-  for (int s = 0; s < 4; ++s)
+  for (int s = 0; s < kWorkSlots; ++s)
     if (c->d_work[s]) hipFree(c->d_work[s]);
   if (c->d_red) hipFree(c->d_red);
   if (c->h_red) hipHostFree(c->h_red);
@@ -329,7 +333,7 @@ int mrl_set_stream(mrl_ctx *ctx, void *stream) {
 int mrl_local_shape(const mrl_ctx *ctx, int64_t real_n[3], int64_t real_begin[3], int64_t recip_n[3],
                     int64_t recip_begin[3]) {
   if (!ctx) return MRL_ERR_INVALID;
-  const int off = 3 - ctx->dim;
+  const int off = ctx->off;
   for (int d = 0; d < 3; ++d) {
     const bool act = d < ctx->dim;
     if (real_n) real_n[d] = act ? ctx->nloc[d + off] : 1;
@@ -342,7 +346,7 @@ int mrl_local_shape(const mrl_ctx *ctx, int64_t real_n[3], int64_t real_begin[3]
 
 int mrl_ctx_reciprocal_axis(const mrl_ctx *ctx, int axis, double *h_out, int64_t cap) {
   if (!ctx || axis < 0 || axis >= ctx->dim || !h_out) return set_error(ctx, MRL_ERR_INVALID, "bad axis");
-  const int a = axis + 3 - ctx->dim;
+  const int a = axis + ctx->off;
   if (cap < ctx->nrec[a]) return set_error(ctx, MRL_ERR_INVALID, "output capacity too small");
   std::memcpy(h_out, ctx->h_k[a].data() + ctx->kbeg[a], sizeof(double) * ctx->nrec[a]);
   return MRL_OK;

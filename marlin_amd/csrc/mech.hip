@@ -1,0 +1,423 @@
+// de Geus finite-strain mechanics: Gamma-operator projection, St-Venant-Kirchhoff stress / tangent
+// application and the Newton-CG driver.
+//   G(A)    = ifft( Ghat4 : fft(A) )                      src/tensor_computes/FFTMechanics.C:74-84,105-106
+//   K_dF    = trans2(ddot42(K4, trans2(dF)))              src/tensor_computes/FFTMechanics.C:107-108
+//   P, K4   : HyperElasticIsotropic::computeBuffer        src/tensor_computes/HyperElasticIsotropic.C:42-52
+//   CG      : MooseTensor::conjugateGradientSolve         include/utils/MarlinUtils.h:55-131
+//   Newton  : FFTMechanics::computeBuffer                 src/tensor_computes/FFTMechanics.C:96-163
+//
+// Nothing 4th-order is ever stored.  With Ghat4_ijlm = delta_im q_j q_l / |q|^2 the projection is
+//   (Ghat4 : A)_ij = q_j (sum_k A_ik q_k) / |q|^2   (0 at q = 0)
+// and with C4 = K II + 2 mu (I4s - II/3), S = C4 : E, E = (F^T F - I)/2 the tangent applied to dF is
+//   K_dF(dF) = dF.S + F.Y,   W = F^T dF,  Y = K tr(W) I + 2 mu (sym(W) - tr(W)/3 I)
+// (the contraction of K4 = S.I4 + I4rt:((F.C4).F^T):I4rt written out).  The "1/3" is
+// the reference's literal 1./3. in every dimension.
+// Fields are value-major [grid][D][D] as in the reference.
+#include "mrl_internal.h"
+
+namespace mrl {
+
+template <int D>
+struct Mat {
+  double a[D][D];
+};
+
+template <int D>
+__device__ __forceinline__ Mat<D> load_mat(const double *p) {
+  Mat<D> m;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) m.a[i][j] = p[i * D + j];
+  return m;
+}
+
+template <int D>
+__device__ __forceinline__ void store_mat(double *p, const Mat<D> &m) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) p[i * D + j] = m.a[i][j];
+}
+
+// second Piola-Kirchhoff stress S = C4 : (F^T F - I)/2
+template <int D>
+__device__ __forceinline__ Mat<D> svk_S(const Mat<D> &F, double K, double mu) {
+  Mat<D> E;
+  double tr = 0.0;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s += F.a[k][i] * F.a[k][j];
+      E.a[i][j] = 0.5 * (s - (i == j ? 1.0 : 0.0));
+    }
+#pragma unroll
+  for (int i = 0; i < D; ++i) tr += E.a[i][i];
+  Mat<D> S;
+  const double two_mu = 2.0 * mu;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const double dev = 0.5 * (E.a[i][j] + E.a[j][i]) - (i == j ? (1.0 / 3.0) * tr : 0.0);
+      S.a[i][j] = (i == j ? K * tr : 0.0) + two_mu * dev;
+    }
+  return S;
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) k_mech_stress(const double *__restrict__ F, const double *__restrict__ K,
+                                                      const double *__restrict__ mu, double *__restrict__ P,
+                                                      long long npts) {
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npts; p += (long long)gridDim.x * 256) {
+    const Mat<D> f = load_mat<D>(F + p * D * D);
+    const Mat<D> S = svk_S<D>(f, K[p], mu[p]);
+    Mat<D> o;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) s += f.a[i][k] * S.a[k][j];
+        o.a[i][j] = s;
+      }
+    store_mat<D>(P + p * D * D, o);
+  }
+}
+
+// out = dF.S + F.Y ; dF_stride = D*D (field) or 0 (one tensor broadcast over the grid)
+template <int D>
+__global__ void __launch_bounds__(256) k_mech_tangent(const double *__restrict__ F, const double *__restrict__ K,
+                                                       const double *__restrict__ mu, const double *__restrict__ dF,
+                                                       long long dF_stride, double *__restrict__ out, long long npts) {
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npts; p += (long long)gridDim.x * 256) {
+    const Mat<D> f = load_mat<D>(F + p * D * D);
+    const Mat<D> d = load_mat<D>(dF + p * dF_stride);
+    const double Kp = K[p], mup = mu[p];
+    const Mat<D> S = svk_S<D>(f, Kp, mup);
+    Mat<D> W;
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) s += f.a[k][i] * d.a[k][j];
+        W.a[i][j] = s;
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i) tr += W.a[i][i];
+    Mat<D> Y;
+    const double two_mu = 2.0 * mup;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const double dev = 0.5 * (W.a[i][j] + W.a[j][i]) - (i == j ? (1.0 / 3.0) * tr : 0.0);
+        Y.a[i][j] = (i == j ? Kp * tr : 0.0) + two_mu * dev;
+      }
+    Mat<D> o;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) s += d.a[i][k] * S.a[k][j] + f.a[i][k] * Y.a[k][j];
+        o.a[i][j] = s;
+      }
+    store_mat<D>(out + p * D * D, o);
+  }
+}
+
+// in-place projection of a value-major spectrum [n0][n1][n2][D][D] (complex), times `scale`
+template <int D>
+__global__ void __launch_bounds__(256) k_gamma_project(double2 *__restrict__ spec, long long n0, long long n1,
+                                                        long long n2, const double *__restrict__ k0,
+                                                        const double *__restrict__ k1, const double *__restrict__ k2,
+                                                        double scale) {
+  const long long total = n0 * n1 * n2;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long i2 = e % n2, t = e / n2, i1 = t % n1, i0 = t / n1;
+    double q[3];
+    // internal axes (A0, A1, A2) carry the user axes right-aligned: user axis d = internal 3 - D + d
+    const double kk[3] = {k0[i0], k1[i1], k2[i2]};
+#pragma unroll
+    for (int d = 0; d < D; ++d) q[d] = kk[3 - D + d];
+    double Q = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) Q += q[d] * q[d];
+    const double inv = (Q == 0.0) ? 0.0 : scale / Q;
+    double2 *A = spec + e * D * D;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double2 s = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double2 v = A[i * D + k];
+        s.x += v.x * q[k];
+        s.y += v.y * q[k];
+      }
+      s.x *= inv;
+      s.y *= inv;
+#pragma unroll
+      for (int j = 0; j < D; ++j) A[i * D + j] = make_double2(s.x * q[j], s.y * q[j]);
+    }
+  }
+}
+
+// ---- CG vector kernels (device-resident scalars S) ---------------------------------------------
+// r = b - Ax ; p = r ; partial sum r.r
+__global__ void __launch_bounds__(256) k_cg_init(const double *__restrict__ b, const double *__restrict__ Ax,
+                                                  double *__restrict__ r, double *__restrict__ p, long long n,
+                                                  double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double v = b[i] - Ax[i];
+    r[i] = v;
+    p[i] = v;
+    acc += v * v;
+  }
+  acc = wave_sum_f64(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// alpha = S[i_rz] / S[i_pAp] ; x += alpha p ; r -= alpha Ap ; partial sum r.r
+__global__ void __launch_bounds__(256) k_cg_update(const double *__restrict__ S, int i_rz, int i_pAp,
+                                                    double *__restrict__ x, double *__restrict__ r,
+                                                    const double *__restrict__ p, const double *__restrict__ Ap,
+                                                    long long n, double *__restrict__ partial) {
+#pragma clang fp contract(off)
+  __shared__ double sh[4];
+  const double alpha = S[i_rz] / S[i_pAp];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    x[i] = x[i] + alpha * p[i];
+    const double v = r[i] - alpha * Ap[i];
+    r[i] = v;
+    acc += v * v;
+  }
+  acc = wave_sum_f64(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// beta = S[i_new] / S[i_old] ; p = r + beta p
+__global__ void __launch_bounds__(256) k_cg_dir(const double *__restrict__ S, int i_new, int i_old,
+                                                 const double *__restrict__ r, double *__restrict__ p, long long n) {
+#pragma clang fp contract(off)
+  const double beta = S[i_new] / S[i_old];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    p[i] = r[i] + beta * p[i];
+}
+
+// y[i] += x[i % period_or_n]   (period = D*D broadcasts one tensor over the grid)
+__global__ void __launch_bounds__(256) k_add(double *__restrict__ y, const double *__restrict__ x, long long n,
+                                              long long period) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    y[i] = y[i] + x[period ? i % period : i];
+}
+
+static inline int grid_for(long long n) {
+  long long b = (n + 255) / 256;
+  if (b > kRedBlocks) b = kRedBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+static int check_dim(mrl_ctx *ctx, const char *what) {
+  if (ctx->dim != 2 && ctx->dim != 3)
+    return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: mechanics needs a 2-D or 3-D domain", what);
+  if (ctx->nranks > 1) return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: serial contexts only", what);
+  if (ctx->spectrum != MRL_SPECTRUM_HALF)
+    return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: needs spectrum = MRL_SPECTRUM_HALF", what);
+  return MRL_OK;
+}
+
+int stress_launch(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *P) {
+  const long long npts = real_count_local(ctx);
+  ProfScope ps(ctx, "mech_stress", (double)npts * 8.0 * (2 * ctx->dim * ctx->dim + 2));
+  if (ctx->dim == 3)
+    hipLaunchKernelGGL(k_mech_stress<3>, dim3(grid_for(npts)), dim3(256), 0, ctx->stream, F, K, mu, P, npts);
+  else
+    hipLaunchKernelGGL(k_mech_stress<2>, dim3(grid_for(npts)), dim3(256), 0, ctx->stream, F, K, mu, P, npts);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+int tangent_launch(mrl_ctx *ctx, const double *F, const double *K, const double *mu, const double *dF, bool bcast,
+                   double *out) {
+  const long long npts = real_count_local(ctx);
+  const int dd = ctx->dim * ctx->dim;
+  ProfScope ps(ctx, "mech_tangent", (double)npts * 8.0 * ((bcast ? 2 : 3) * dd + 2));
+  if (ctx->dim == 3)
+    hipLaunchKernelGGL(k_mech_tangent<3>, dim3(grid_for(npts)), dim3(256), 0, ctx->stream, F, K, mu, dF,
+                       (long long)(bcast ? 0 : dd), out, npts);
+  else
+    hipLaunchKernelGGL(k_mech_tangent<2>, dim3(grid_for(npts)), dim3(256), 0, ctx->stream, F, K, mu, dF,
+                       (long long)(bcast ? 0 : dd), out, npts);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+// out = scale * G(A)
+int gamma_launch(mrl_ctx *ctx, const double *A, double *out, double scale) {
+  const int dd = ctx->dim * ctx->dim;
+  const long long nspec = spec_count_local(ctx);
+  MRL_TRY(ensure_work(ctx, 4, sizeof(cplx) * nspec * dd));
+  double *spec = ctx->d_work[4];
+  MRL_TRY(fft_forward_serial(ctx, A, spec, dd, 1));
+  {
+    ProfScope ps(ctx, "mech_gamma_project", 32.0 * (double)nspec * dd);
+    const int nb = grid_for(nspec);
+    if (ctx->dim == 3)
+      hipLaunchKernelGGL(k_gamma_project<3>, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2 *>(spec),
+                         ctx->nrec[0], ctx->nrec[1], ctx->nrec[2], ctx->d_k[0], ctx->d_k[1], ctx->d_k[2], scale);
+    else
+      hipLaunchKernelGGL(k_gamma_project<2>, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2 *>(spec),
+                         ctx->nrec[0], ctx->nrec[1], ctx->nrec[2], ctx->d_k[0], ctx->d_k[1], ctx->d_k[2], scale);
+    MRL_HIP(ctx, hipGetLastError());
+  }
+  return fft_inverse_serial(ctx, spec, out, dd, 1);
+}
+
+}  // namespace mrl
+
+using namespace mrl;
+
+extern "C" {
+
+int mrl_gamma_apply(mrl_ctx *ctx, const double *d_A, double *d_out) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_dim(ctx, "mrl_gamma_apply"));
+  if (!d_A || !d_out) return set_error(ctx, MRL_ERR_INVALID, "mrl_gamma_apply: null buffer");
+  return gamma_launch(ctx, d_A, d_out, 1.0);
+}
+
+int mrl_mech_stress(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu, double *d_P) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_dim(ctx, "mrl_mech_stress"));
+  if (!d_F || !d_K || !d_mu || !d_P) return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_stress: null buffer");
+  return stress_launch(ctx, d_F, d_K, d_mu, d_P);
+}
+
+int mrl_mech_tangent_apply(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu,
+                           const double *d_dF, double *d_out) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_dim(ctx, "mrl_mech_tangent_apply"));
+  if (!d_F || !d_K || !d_mu || !d_dF || !d_out)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_tangent_apply: null buffer");
+  return tangent_launch(ctx, d_F, d_K, d_mu, d_dF, false, d_out);
+}
+
+int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d_F, const double *d_K,
+                       const double *d_mu, const double *d_applied, double *d_Fnew, double *d_P,
+                       mrl_mech_stats *stats) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_dim(ctx, "mrl_mech_newton_cg"));
+  if (!prm || !d_F || !d_K || !d_mu || !d_Fnew || !d_P)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_newton_cg: null argument");
+  if (d_Fnew == d_F) return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_newton_cg: Fnew must not alias F");
+  const int dd = ctx->dim * ctx->dim;
+  const long long npts = real_count_local(ctx);
+  const long long n = npts * dd;
+  const size_t vb = sizeof(double) * (size_t)(n + 2);
+  for (int s = 5; s <= 10; ++s) MRL_TRY(ensure_work(ctx, s, vb));
+  double *b = ctx->d_work[5], *r = ctx->d_work[6], *p = ctx->d_work[7], *Ap = ctx->d_work[8], *tmp = ctx->d_work[9],
+         *x = ctx->d_work[10];
+  double *S = ctx->d_red + kScalarBase + 32;  // device scalars: [0],[2] r.r ping-pong, [1] p.Ap, [3] scratch
+  const int nb = grid_for(n);
+  const long long l_max_its = prm->l_max_its > 0 ? prm->l_max_its : ctx->n[0] * ctx->n[1] * ctx->n[2];
+  mrl_mech_stats st{};
+  double h[4];
+
+  // _u = _tF ; constitutive at F (the tangent of the first linear solve stays linearised at F)
+  MRL_HIP(ctx, hipMemcpyAsync(d_Fnew, d_F, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
+  const double *lin = d_F;
+  // b = -G_K_dF(applied.expand) | -G_K_dF(0)                              FFTMechanics.C:116-117
+  if (d_applied) {
+    MRL_TRY(tangent_launch(ctx, lin, d_K, d_mu, d_applied, true, tmp));
+    MRL_TRY(gamma_launch(ctx, tmp, b, -1.0));
+    hipLaunchKernelGGL(k_add, dim3(nb), dim3(256), 0, ctx->stream, d_Fnew, d_applied, n, (long long)dd);  // :120-121
+  } else {
+    MRL_HIP(ctx, hipMemsetAsync(b, 0, sizeof(double) * n, ctx->stream));
+  }
+  MRL_TRY(reduce_async(ctx, 2, d_Fnew, d_Fnew, n, S + 3));
+  MRL_TRY(read_scalars(ctx, S + 3, 1, h));
+  const double Fn = sqrt(h[0]);  // :123-124
+  st.Fn = Fn;
+  MRL_HIP(ctx, hipMemsetAsync(x, 0, sizeof(double) * n, ctx->stream));  // dFm = zeros_like(b)
+
+  auto apply_A = [&](const double *v, double *out) -> int {  // G_K_dF
+    MRL_TRY(tangent_launch(ctx, lin, d_K, d_mu, v, false, tmp));
+    return gamma_launch(ctx, tmp, out, 1.0);
+  };
+
+  int iiter = 0;
+  while (true) {
+    // ---- conjugateGradientSolve(G_K_dF, b, dFm, l_tol, l_max_its)        MarlinUtils.h:55-123
+    int its = 0;
+    double res_norm = 0.0;
+    MRL_TRY(reduce_async(ctx, 2, b, b, n, S + 3));
+    MRL_TRY(read_scalars(ctx, S + 3, 1, h));
+    const double b_norm = sqrt(h[0]);
+    if (b_norm != 0.0) {
+      MRL_TRY(apply_A(x, Ap));
+      hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(256), 0, ctx->stream, b, Ap, r, p, n, ctx->d_red);
+      MRL_TRY(reduce_finalize(ctx, nb, 1, S + 0));
+      int i_old = 0, i_new = 2;
+      its = (int)l_max_its;
+      for (long long k = 0; k < l_max_its; ++k) {
+        MRL_TRY(apply_A(p, Ap));
+        MRL_TRY(reduce_async(ctx, 1, p, Ap, n, S + 1));
+        hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
+        MRL_TRY(reduce_finalize(ctx, nb, 1, S + i_new));
+        MRL_TRY(read_scalars(ctx, S + i_new, 1, h));  // the one host sync of the iteration
+        res_norm = sqrt(h[0]);
+        if (res_norm <= prm->l_tol * b_norm) {
+          its = (int)k + 1;
+          break;
+        }
+        hipLaunchKernelGGL(k_cg_dir, dim3(nb), dim3(256), 0, ctx->stream, S, i_new, i_old, r, p, n);
+        const int t = i_old;
+        i_old = i_new;
+        i_new = t;
+      }
+    }
+    if (st.newton_its < 64) st.cg_its[st.newton_its] = its;
+    st.cg_its_total += its;
+    st.newton_its += 1;
+
+    // _u = _u + dFm ; constitutive ; b = -G(P)                              FFTMechanics.C:137-143
+    hipLaunchKernelGGL(k_add, dim3(nb), dim3(256), 0, ctx->stream, d_Fnew, x, n, 0LL);
+    lin = d_Fnew;
+    MRL_TRY(stress_launch(ctx, d_Fnew, d_K, d_mu, d_P));
+    MRL_TRY(gamma_launch(ctx, d_P, b, -1.0));
+    MRL_TRY(reduce_async(ctx, 2, x, x, n, S + 3));
+    MRL_TRY(read_scalars(ctx, S + 3, 1, h));
+    const double anorm = sqrt(h[0]);
+    const double rnorm = anorm / Fn;
+    st.last_anorm = anorm;
+    st.last_rnorm = rnorm;
+    if ((rnorm < prm->nl_rel_tol || anorm < prm->nl_abs_tol) && iiter > 0) break;  // :151-155
+    iiter++;
+    if (iiter > prm->nl_max_its) {
+      if (stats) *stats = st;
+      return set_error(ctx, MRL_ERR_NOT_CONVERGED,
+                       "Exceeded the maximum number of nonlinear iterations without converging.");
+    }
+  }
+  if (stats) *stats = st;
+  return MRL_OK;
+}
+
+}  // extern "C"

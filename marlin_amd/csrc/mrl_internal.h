@@ -15,6 +15,9 @@ namespace mrl {
 typedef double2 cplx;  // interleaved (re, im) complex128
 
 constexpr int kMaxRadixPasses = 24;
+constexpr int kWorkSlots = 16;
+constexpr int kRedBlocks = 2048;    // partial sums of a reduction live in ctx->d_red[0, kRedBlocks)
+constexpr int kScalarBase = 3072;   // device scalar slots: ctx->d_red[kScalarBase, 4096)
 
 // One generic Stockham pass sequence along one axis (see fft_generic.hip).
 struct PassDesc {
@@ -52,12 +55,12 @@ struct Profile {
 
 struct mrl_ctx {
   int dim = 0;
+  int off = 0;                     // internal axis of user axis d is d + off
   long long n[3] = {1, 1, 1};      // global real extents in internal order (A0, A1, A2), A2 contiguous
   double gmin[3], gmax[3], dx[3];
   int spectrum = MRL_SPECTRUM_HALF;
   int nranks = 1, rank = 0;
   int device = 0;
-  // internal axis a <-> user axis a - (3 - dim)
   long long nloc[3] = {1, 1, 1};   // local real extents
   long long rbeg[3] = {0, 0, 0};   // local real begin
   long long nrec[3] = {1, 1, 1};   // local reciprocal extents
@@ -74,8 +77,9 @@ struct mrl_ctx {
   double *d_k[3] = {nullptr, nullptr, nullptr};  // device copies of the LOCAL reciprocal axes
 
   // scratch (complex spectra), grown on demand
-  double *d_work[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t work_bytes[4] = {0, 0, 0, 0};
+  // slots: 0 inverse-transform scratch, 1-3 Cahn-Hilliard, 4-10 mechanics, 11-15 slab stages
+  double *d_work[mrl::kWorkSlots] = {};
+  size_t work_bytes[mrl::kWorkSlots] = {};
   double *d_red = nullptr;      // reduction scratch
   double *h_red = nullptr;      // pinned host scratch
 
@@ -107,6 +111,12 @@ extern thread_local std::string g_create_error;
     if (rc_ != MRL_OK) return rc_; \
   } while (0)
 
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
 // scratch management
 int ensure_work(mrl_ctx *ctx, int slot, size_t bytes);
 
@@ -137,6 +147,12 @@ struct ChP {
 bool fast_path_ok(const mrl_ctx *ctx);
 int fft_forward_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
 int fft_inverse_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
+
+// reductions (reduce.hip): op 0 sum(a), 1 sum(a*b), 2 sum(a*a); results stay on the device
+int reduce_async(mrl_ctx *ctx, int op, const double *a, const double *b, long long n, double *d_scalar);
+int reduce_finalize(mrl_ctx *ctx, int nb, int nslots, double *d_scalar);
+int read_scalars(mrl_ctx *ctx, const double *d_scalar, int count, double *h_out);
+int component_sums_async(mrl_ctx *ctx, const double *a, long long npts, int ncomp, double *d_scalar);
 
 // serial transforms (fft_plan.hip)
 int fft_forward_serial(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch, int layout);

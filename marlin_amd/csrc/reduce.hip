@@ -10,15 +10,9 @@
 
 namespace mrl {
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
 // block sum of `v` over 256 threads -> valid in thread 0
 __device__ __forceinline__ double block_sum256(double v, double *sh) {
-  v = wave_sum(v);
+  v = wave_sum_f64(v);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) sh[w] = v;
   __syncthreads();

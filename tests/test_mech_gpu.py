@@ -1,0 +1,110 @@
+"""de Geus mechanics on the GPU vs the reference gold files and the oracle, through the C ABI."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import marlin_oracle as mo
+from tests.conftest import load_golden
+from tests.test_oracle_golden import MECH_CASES, _mech_setup
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(dim, shape, L):
+    from marlin_amd.api import Context
+    return Context(dim, list(shape), list(L))
+
+
+@pytest.mark.parametrize("shape,L", [((8, 6, 10), (1.0, 2.0, 3.0)), ((16, 16, 16), (2 * math.pi,) * 3),
+                                     ((9, 7), (1.0, 1.5)), ((32, 32), (2 * math.pi,) * 2), ((5, 7, 9), (1.0, 1.0, 1.0))])
+def test_gamma_apply(shape, L):
+    """G(A) = ifft(Ghat4 : fft(A)) with the stored operator of FFTMechanics.C:74-84 (oracle), 1e-12"""
+    dim = len(shape)
+    dom = mo.Domain(dim, list(shape), list(L))
+    torch.manual_seed(5)
+    A = torch.rand(dom.value_shape([dim, dim]), dtype=torch.float64)
+    ref = dom.ifft_batched(mo.ddot42(mo.ghat4(dom), dom.fft_batched(A)))
+    ctx = _ctx(dim, shape, L)
+    got = ctx.gamma_apply(A.cuda()).cpu()
+    assert (got - ref).abs().max().item() <= 1e-12
+    # projection: G(G(A)) = G(A)
+    twice = ctx.gamma_apply(got.cuda()).cpu()
+    assert (twice - got).abs().max().item() <= 1e-12
+
+
+@pytest.mark.parametrize("dim,n", [(3, 8), (2, 12)])
+def test_stress_and_tangent(dim, n):
+    """HyperElasticIsotropic.C:42-52 (P) and K_dF of FFTMechanics.C:107-108 with the stored K4 (oracle)"""
+    dom, phase, K, mu = _mech_setup(dim, n)
+    ids = mo.MechIdentities(dim)
+    torch.manual_seed(7)
+    F = torch.eye(dim, dtype=torch.float64) + 0.1 * (torch.rand(dom.value_shape([dim, dim]), dtype=torch.float64) - 0.5)
+    dF = torch.rand(dom.value_shape([dim, dim]), dtype=torch.float64) - 0.5
+    P_ref, K4 = mo.hyper_elastic_isotropic(dom, ids, F, K, mu)
+    KdF_ref = mo.trans2(mo.ddot42(K4, mo.trans2(dF)))
+    ctx = _ctx(dim, dom.shape, [2 * math.pi] * dim)
+    P = ctx.mech_stress(F.cuda(), K.cuda(), mu.cuda()).cpu()
+    KdF = ctx.mech_tangent_apply(F.cuda(), K.cuda(), mu.cuda(), dF.cuda()).cpu()
+    assert (P - P_ref).abs().max().item() <= 1e-13
+    assert (KdF - KdF_ref).abs().max().item() <= 1e-12
+
+
+def test_reductions():
+    """torch::sum / torch::norm call sites of the CG (MarlinUtils.h:63-109) and DomainAction::average"""
+    ctx = _ctx(3, (8, 6, 10), (1.0, 1.0, 1.0))
+    torch.manual_seed(2)
+    for n in (1, 2, 7, 4320, 100003):
+        a = torch.rand(n, dtype=torch.float64) - 0.5
+        b = torch.rand(n, dtype=torch.float64) - 0.5
+        ad, bd = a.cuda(), b.cuda()
+        scale = max(1.0, float(a.abs().sum()))
+        assert abs(ctx.dot(ad, bd) - float(torch.sum(a * b))) <= 1e-14 * scale
+        assert abs(ctx.norm2(ad) - float(torch.norm(a))) <= 1e-14 * scale
+        assert abs(ctx.sum(ad) - float(torch.sum(a))) <= 1e-14 * scale
+    f = torch.rand(8, 6, 10, 3, 3, dtype=torch.float64)
+    avg = ctx.average(f.cuda())
+    assert (avg - f.sum(dim=(0, 1, 2)) / 480.0).abs().max().item() <= 1e-14
+
+
+@pytest.mark.parametrize("case", ["mech3d", "mech2d"])
+def test_mech_gold(case):
+    """test/tests/mechanics/tests:2-21 -- F_k.frame to abs_tol 1e-10; iteration counts as the oracle's"""
+    p = MECH_CASES[case]
+    dim, n = p["dim"], p["n"]
+    g = load_golden(p["gold"])
+    dom, phase, K, mu = _mech_setup(dim, n)
+    ctx = _ctx(dim, dom.shape, [2 * math.pi] * dim)
+    oracle = mo.FFTMechanicsOracle(dom, K, mu, l_tol=p["l_tol"], nl_rel_tol=p["nl_rel"], nl_abs_tol=p["nl_abs"],
+                                   l_max_its=p["l_max_its"])
+    Kd, mud = K.cuda(), mu.cuda()
+    F = torch.eye(dim, dtype=torch.float64).expand(dom.value_shape([dim, dim])).contiguous().cuda()
+    F_or = F.cpu()
+    dt, substeps = p["dt"], p["substeps"]
+    t_old = 0.0
+    perm = (2, 1, 0) if dim == 3 else (1, 0)
+    worst = 0.0
+    for step in range(1, 4):
+        sub_dt = dt / substeps
+        for s in range(substeps):
+            t = t_old + s * sub_dt
+            # MacroscopicShearTensor.C:31-41 on the host from the device average
+            applied = torch.eye(dim, dtype=torch.float64)
+            applied[0, 1] = applied[0, 1] + t
+            applied = applied - ctx.average(F)
+            Fnew, P, stats = ctx.mech_newton_cg(F, Kd, mud, applied.cuda(), l_tol=p["l_tol"],
+                                                l_max_its=p["l_max_its"] or 0, nl_rel_tol=p["nl_rel"],
+                                                nl_abs_tol=p["nl_abs"])
+            if step == 1 and s < 2:   # compare the solver trace with the oracle on the first substeps
+                F_or_new, st_or = oracle.compute(F_or, mo.macroscopic_shear(dom, F_or, t))
+                assert stats["newton_its"] == st_or.newton_its and stats["cg_its"] == st_or.cg_its
+                assert (Fnew.cpu() - F_or_new).abs().max().item() <= 1e-10
+                F_or = F_or_new
+            F = Fnew
+        t_old += dt
+        for k in range(dim * dim):
+            ref = g[f"F_{k}.{step - 1}"]
+            got = F.cpu().reshape(dom.shape + [dim * dim])[..., k].permute(*perm).numpy()
+            worst = max(worst, np.abs(ref - got).max())
+    assert worst <= 1e-10, worst

@@ -1,0 +1,171 @@
+"""HIP slab stages on ONE GPU: the P ranks of a slab decomposition are P contexts in this process and
+the global transpose is a loop-back copy between their send/recv buffers (the RCCL exchange itself is
+covered over gloo in test_slab_gloo.py).  Parity against the serial oracle on the global field and the
+reference's 2-rank gold file."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import marlin_oracle as mo
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+class Loopback:
+    """all-to-all between P in-process ranks: recv[q] chunk p = send[p] chunk q"""
+
+    def __init__(self):
+        self.members = []   # (send_counts, recv_counts)
+
+    def factory(self, send_counts, recv_counts):
+        x = _LoopX(self, len(self.members), send_counts, recv_counts)
+        self.members.append(x)
+        return x
+
+
+class _LoopX:
+    def __init__(self, hub, idx, sc, rc):
+        self.hub, self.idx = hub, idx
+        self.sc, self.rc = [2 * c for c in sc], [2 * c for c in rc]
+
+    def run(self, send, recv, async_op=False):
+        raise RuntimeError("loop-back ranks are driven phase by phase")
+
+
+def _a2a(xs, sends, recvs):
+    P = len(xs)
+    soff = [np.concatenate([[0], np.cumsum(x.sc)]) for x in xs]
+    roff = [np.concatenate([[0], np.cumsum(x.rc)]) for x in xs]
+    for q in range(P):
+        for p in range(P):
+            assert xs[p].sc[q] == xs[q].rc[p]
+            recvs[q][roff[q][p]:roff[q][p + 1]].copy_(sends[p][soff[p][q]:soff[p][q + 1]])
+
+
+def _make(dim, shape, L, P, **kw):
+    from marlin_amd.api import ch_params
+    from marlin_amd.slab import SlabCahnHilliard
+    fwd, inv = Loopback(), Loopback()
+    solvers = []
+    for r in range(P):
+        calls = {"n": 0}
+
+        def fac(sc, rc, calls=calls):
+            calls["n"] += 1
+            return (fwd if calls["n"] == 1 else inv).factory(sc, rc)
+        solvers.append(SlabCahnHilliard(dim, shape, L, ch_params(), P, r, exchange_factory=fac, **kw))
+    return solvers
+
+
+def _substep_all(solvers):
+    for s in solvers:
+        s.phase_a()
+        s.phase_a2()
+    nf, nr = solvers[0].n_fs, [s.n_fr for s in solvers]
+    _a2a([s.x_fwd for s in solvers], [s.send2[:s.n_fs] for s in solvers], [s.recv2[:s.n_fr] for s in solvers])
+    _a2a([s.x_fwd for s in solvers], [s.send2[s.n_fs:] for s in solvers], [s.recv2[s.n_fr:] for s in solvers])
+    for s in solvers:
+        s.phase_b()
+    _a2a([s.x_inv for s in solvers], [s.send for s in solvers], [s.recv for s in solvers])
+    for s in solvers:
+        s.phase_c()
+
+
+def _step_all(solvers, dt, substeps):
+    for s in solvers:
+        s.time_step += 1
+        if s.time_step > 1:
+            s.advance_state()
+        s.sub_dt = dt / substeps
+    for k in range(substeps):
+        _substep_all(solvers)
+        for s in solvers:
+            if k < substeps - 1 and s.time_step > 1:
+                s.advance_state()
+
+
+def _gather(solvers):
+    return torch.cat([s.current().cpu() for s in solvers], dim=1)
+
+
+@pytest.mark.parametrize("shape,P,spectrum", [((8, 6, 10), 2, 0), ((9, 7, 5), 3, 0), ((16, 12), 2, 1), ((20, 20), 4, 1),
+                                               ((8, 6, 4), 2, 1), ((64, 64, 64), 4, 0)])
+def test_slab_fft_roundtrip_and_spectrum(shape, P, spectrum):
+    """mrl_slab_fwd_* == rows [xb:xe] of the serial transform; inverse stages bring the field back"""
+    from marlin_amd.slab import HipSlabStages
+    dim = len(shape)
+    L = [1.0 + 0.5 * d for d in range(dim)]
+    torch.manual_seed(11)
+    a = torch.rand(shape, dtype=torch.float64)
+    full = torch.fft.fftn(a) if spectrum == 1 else torch.fft.rfftn(a)
+    sts = [HipSlabStages(dim, list(shape), L, P, r, spectrum=spectrum) for r in range(P)]
+    cnt_f = [st.counts(True) for st in sts]
+    cnt_b = [st.counts(False) for st in sts]
+
+    class X:
+        def __init__(self, sc, rc):
+            self.sc, self.rc = [2 * c for c in sc], [2 * c for c in rc]
+    sends, recvs, specs = [], [], []
+    for st, (sc, rc) in zip(sts, cnt_f):
+        yb, nyl = st.real_begin[1], st.real_shape[1]
+        loc = a[:, yb:yb + nyl].contiguous().cuda()
+        send = st.empty(2 * sum(sc))
+        st.fwd_local(loc, send)
+        sends.append(send)
+        recvs.append(st.empty(2 * sum(rc)))
+    _a2a([X(*c) for c in cnt_f], sends, recvs)
+    for st, recv in zip(sts, recvs):
+        nspec = int(np.prod(st.recip_shape))
+        spec = st.empty(2 * nspec)
+        st.fwd_finish(recv, spec)
+        xb, nxl = st.recip_begin[0], st.recip_shape[0]
+        got = torch.view_as_complex(spec.cpu().reshape(-1, 2)).reshape(st.recip_shape)
+        assert (got - full[xb:xb + nxl]).abs().max().item() <= 1e-11
+        specs.append(spec)
+    sends, recvs = [], []
+    for st, spec, (sc, rc) in zip(sts, specs, cnt_b):
+        send = st.empty(2 * sum(sc))
+        st.inv_local(spec, send)
+        sends.append(send)
+        recvs.append(st.empty(2 * sum(rc)))
+    _a2a([X(*c) for c in cnt_b], sends, recvs)
+    for st, recv in zip(sts, recvs):
+        yb, nyl = st.real_begin[1], st.real_shape[1]
+        out = st.empty(int(np.prod(st.real_shape)))
+        st.inv_finish(recv, out)
+        assert (out.cpu().reshape(st.real_shape) - a[:, yb:yb + nyl]).abs().max().item() <= 1e-13
+
+
+def test_slab_ch_gold_rank1():
+    """test/tests/cahnhilliard/tests:58-70: rank 1 of the 2-rank FFT_SLAB run, c.1..c.10 to 1e-13"""
+    g = load_golden("cahnhilliard_rank0001_gold.npz")
+    torch.manual_seed(0)
+    blk = torch.rand(20, 10, dtype=torch.float64) * (0.56 - 0.44) + 0.44
+    solvers = _make(2, [20, 20], [3.0, 3.0], 2)
+    for s in solvers:
+        s.set_local(blk.cuda())
+    worst = 0.0
+    for k in range(10):
+        _step_all(solvers, 1e-3, 10)
+        worst = max(worst, np.abs(g[f"c.{k + 1}"] - solvers[1].current().cpu().numpy()).max())
+    assert worst <= 1e-13, worst
+
+
+@pytest.mark.parametrize("shape,P", [((8, 6, 10), 2), ((9, 7, 5), 3), ((32, 32, 32), 4), ((64, 64, 64), 2),
+                                     ((64, 128, 64), 8)])
+def test_slab_ch_matches_serial_oracle(shape, P):
+    torch.manual_seed(4)
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    L = [3.0, 2.0, 2.5]
+    solvers = _make(3, list(shape), L, P)
+    for s in solvers:
+        yb, nyl = s.st.real_begin[1], s.st.real_shape[1]
+        s.set_local(c0[:, yb:yb + nyl].contiguous().cuda())
+    dom = mo.Domain(3, list(shape), L)
+    ref = mo.CahnHilliardABM(dom, c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=3)
+    for k in range(2):
+        ref.step(1e-3)
+        _step_all(solvers, 1e-3, 3)
+        assert (_gather(solvers) - ref.c).abs().max().item() <= 1e-13
+    assert [s.last_order for s in solvers] == [1] * P
