@@ -64,12 +64,19 @@ def cpu_baseline(shape, dx, sample_steps):
     Lbar = mo.reciprocal_laplacian_square_factor(dom, -0.001)
     n = int(np.prod(shape))
     c = torch.from_numpy(splitmix64_uniform(n).reshape(shape))
-    threads = torch.get_num_threads()
+    # the host cores this process may actually use (the GPU box hands out a CPU share, not the whole host)
+    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    torch.set_num_threads(threads)
     c, N0, _, _ = mo.ch_substep_ops(c, Mbar, Lbar, [], 1e-3, 0, mo.mu_double_well, dom)  # warm-up + history
     t0 = time.perf_counter()
+    done = 0
     for _ in range(sample_steps):
         c, N1, _, _ = mo.ch_substep_ops(c, Mbar, Lbar, [N0], 1e-3, 1, mo.mu_double_well, dom)
         N0 = N1
+        done += 1
+        if time.perf_counter() - t0 > 20.0:   # bounded sample: stop after ~20 s of CPU work
+            break
+    sample_steps = done
     dt = time.perf_counter() - t0
     return {
         "value": n * sample_steps / dt,
@@ -87,7 +94,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=256, help="base grid edge (per-GPU work = n^3 points)")
-    ap.add_argument("--cpu-steps", type=int, default=8, help="substeps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=24, help="substeps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=10)
     args = ap.parse_args()
 

@@ -1,0 +1,342 @@
+// Fast path of the slab-decomposed Cahn-Hilliard substep (3-D, power-of-two extents, r2c on z, equal
+// partitions).  Same kernels as the serial fast path (fft_pow2_kernels.h); the only kernel that sees
+// the exchange layout is the fused y pass:
+//   A  k_z_fwd<CH>      c -> (c-hat_z, mu-hat_z) on the real slab [nx][nyl][nzc], written into the send buffer
+//      k_pass<x>        forward x, in place: the result is already ordered by destination rank
+//   -- exchange (per field) --
+//   B  k_ch_yfused      gathers lines along y from the received chunks [p][nxl][nyl][nzc], forward y on both
+//                       fields, Nhat = Mbar*mu-hat (dense, reference layout), ABM predictor, 1/(1-dt*Lbar),
+//                       inverse y, scattered back into the same chunk layout for the inverse exchange
+//   -- exchange --
+//   C  k_pass<x>        inverse x on the dense [nx][nyl][nzc] array that arrived
+//      k_z_inv          c2r along z, 1/N
+// (AdamsBashforthMoulton.C:60-101 with DomainAction::fftSlab/ifftSlab, DomainAction.C:869-1019.)
+#include "fft_pow2_kernels.h"
+
+namespace mrl {
+
+namespace p2 {
+
+struct YFusedArgs {
+  const cplx *chat;   // received chunks of c-hat (after z,x passes)
+  const cplx *muhat;  // received chunks of mu-hat
+  cplx *ubar;         // out: chunks of the inverse-y-transformed ubar
+  cplx *Nnew;         // out: Mbar*mubar, dense [nxl][ny][nzc]
+  cplx *cbar;         // optional out: c-hat, dense
+  const cplx *Nold[4];
+  double coef[5];
+  int nxl, nzc;
+  int nyl_shift;      // log2(ny / P)
+  long long chunk;    // nxl * nyl * nzc: elements of one chunk
+  int tiles_per_x;
+  const double *kx, *ky, *kz;  // local reciprocal axes
+  double M, kappa, dt;
+};
+
+template <int N, int ORDER>
+__global__ void __launch_bounds__(256) k_ch_yfused(YFusedArgs a, const cplx *__restrict__ tw) {
+#pragma clang fp contract(off)
+  constexpr int TPL = N / 16, T = 4096 / N;
+  using Map = MapStrided<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  double *KY = reinterpret_cast<double *>(X + Map::size);
+  const int l = threadIdx.x % T, q = threadIdx.x / T;
+  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int ix = logical / a.tiles_per_x;
+  const int kzi = (logical % a.tiles_per_x) * T + l;
+  const bool valid = kzi < a.nzc;
+  load_twiddles<N>(W, tw);
+  for (int j = threadIdx.x; j < N; j += 256) KY[j] = a.ky[j];
+
+  // element (ix, j, kz): chunked buffers  p*chunk + (ix*nyl + (j - p*nyl))*nzc + kz,  p = j >> nyl_shift
+  //                      dense buffers    (ix*N + j)*nzc + kz
+  const int nyl = 1 << a.nyl_shift;
+  long long offc[16], offd[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int j = q + m * TPL;
+    const int p = j >> a.nyl_shift;
+    offc[m] = (long long)p * a.chunk + ((long long)ix * nyl + (j - (p << a.nyl_shift))) * a.nzc + kzi;
+    offd[m] = ((long long)ix * N + j) * a.nzc + kzi;
+  }
+
+  cplx v[16];
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = a.muhat[offc[m]];
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
+  }
+  fft_line<N, Map>(v, q, l, X, W);
+
+  double kx2 = 0.0, kz2 = 0.0;
+  if (valid) {
+    const double kx = a.kx[ix], kz = a.kz[kzi];
+    kx2 = kx * kx;
+    kz2 = kz * kz;
+  }
+  cplx Nv[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const double ky = KY[q + m * TPL];
+    const double k2 = kx2 + ky * ky + kz2;
+    const double Mbar = -k2 * a.M;
+    Nv[m] = make_double2(Mbar * v[m].x, Mbar * v[m].y);
+  }
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) a.Nnew[offd[m]] = Nv[m];
+  }
+
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = a.chat[offc[m]];
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
+  }
+  fft_line<N, Map>(v, q, l, X, W);
+  if (a.cbar && valid) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) a.cbar[offd[m]] = v[m];
+  }
+
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    cplx o[ORDER > 0 ? ORDER : 1][8];
+    if (ORDER > 0) {
+#pragma unroll
+      for (int h = 0; h < ORDER; ++h) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[h][j] = valid ? a.Nold[h][offd[half * 8 + j]] : make_double2(0.0, 0.0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = half * 8 + j;
+      cplx u = v[m];
+      u.x = u.x + a.coef[0] * Nv[m].x;
+      u.y = u.y + a.coef[0] * Nv[m].y;
+#pragma unroll
+      for (int h = 0; h < ORDER; ++h) {
+        u.x += a.coef[h + 1] * o[h][j].x;
+        u.y += a.coef[h + 1] * o[h][j].y;
+      }
+      const double ky = KY[q + m * TPL];
+      const double k2 = kx2 + ky * ky + kz2;
+      const double Lb = k2 * k2 * a.kappa;
+      const double scl = 1.0 / (1.0 - a.dt * Lb);
+      v[m] = make_double2(u.y * scl, u.x * scl);  // swapped for the inverse transform
+    }
+  }
+
+  fft_line<N, Map>(v, q, l, X, W);
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) a.ubar[offc[m]] = cswap(v[m]);
+  }
+}
+
+template <class K>
+static int set_lds(mrl_ctx *ctx, K kernel, size_t lds) {
+  if (lds > 64 * 1024)
+    MRL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+  return MRL_OK;
+}
+
+template <int N, int FAM>
+static int launch_z_fwd_ch(mrl_ctx *ctx, const double *in, cplx *o0, cplx *o1, double *mu, const ChDev &chp,
+                           long long nlines) {
+  static bool attr = false;
+  constexpr size_t lds = lds_line<N>();
+  if (!attr) {
+    MRL_TRY(set_lds(ctx, k_z_fwd<N, 1, FAM>, lds));
+    attr = true;
+  }
+  constexpr int LPB = 4096 / N;
+  const long long nb = (nlines + LPB - 1) / LPB;
+  hipLaunchKernelGGL((k_z_fwd<N, 1, FAM>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, o0, o1, mu, chp, nlines,
+                     ctx->ax[2].d_tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+template <int N>
+static int launch_z_inv_s(mrl_ctx *ctx, const cplx *in, double *out, double scale, long long nlines) {
+  static bool attr = false;
+  constexpr size_t lds = lds_line<N>();
+  if (!attr) {
+    MRL_TRY(set_lds(ctx, k_z_inv<N>, lds));
+    attr = true;
+  }
+  constexpr int LPB = 4096 / N;
+  const long long nb = (nlines + LPB - 1) / LPB;
+  hipLaunchKernelGGL((k_z_inv<N>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, out, scale, nlines,
+                     ctx->ax[2].d_tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+template <int N, bool INV>
+static int launch_xpass(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
+  static bool attr = false;
+  constexpr size_t lds = lds_strided<N>();
+  if (!attr) {
+    MRL_TRY(set_lds(ctx, k_pass<N, INV, 1>, lds));
+    attr = true;
+  }
+  constexpr int T = 4096 / N;
+  a.tiles_per_outer = (int)((a.inner + T - 1) / T);
+  const long long nb = a.outer * a.tiles_per_outer;
+  hipLaunchKernelGGL((k_pass<N, INV, 1>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+template <int N, int ORDER>
+static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
+  static bool attr = false;
+  constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
+  if (!attr) {
+    MRL_TRY(set_lds(ctx, k_ch_yfused<N, ORDER>, lds));
+    attr = true;
+  }
+  constexpr int T = 4096 / N;
+  a.tiles_per_x = (a.nzc + T - 1) / T;
+  const long long nb = (long long)a.nxl * a.tiles_per_x;
+  hipLaunchKernelGGL((k_ch_yfused<N, ORDER>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, ctx->ax[1].d_tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+}  // namespace p2
+
+#define MRL_SWITCH_N(n, CALL)  \
+  switch (n) {                 \
+    case 64: { constexpr int NN = 64; CALL; } break;   \
+    case 128: { constexpr int NN = 128; CALL; } break; \
+    case 256: { constexpr int NN = 256; CALL; } break; \
+    case 512: { constexpr int NN = 512; CALL; } break; \
+    default: return MRL_ERR_UNSUPPORTED;               \
+  }
+
+static bool pow2_ok(long long n) { return n == 64 || n == 128 || n == 256 || n == 512; }
+
+int slab_fast_ok(const mrl_ctx *ctx) {
+  if (!(ctx->dim == 3 && ctx->nranks > 1 && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
+        pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2])))
+    return 0;
+  // equal power-of-two partitions: chunk addressing by shifts in k_ch_yfused
+  const long long nyl = ctx->n[1] / ctx->nranks, nxl = ctx->n[0] / ctx->nranks;
+  if (nyl * ctx->nranks != ctx->n[1] || nxl * ctx->nranks != ctx->n[0] || (nyl & (nyl - 1))) return 0;
+  for (int p = 0; p < ctx->nranks; ++p)
+    if (ctx->part_real[p] != nyl || ctx->part_recip[p] != nxl) return 0;
+  return 1;
+}
+
+static const double kBetaS[5][5] = {
+    {1.0, 0.0, 0.0, 0.0, 0.0},
+    {3.0 / 2.0, -1.0 / 2.0, 0.0, 0.0, 0.0},
+    {23.0 / 12.0, -16.0 / 12.0, 5.0 / 12.0, 0.0, 0.0},
+    {55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -9.0 / 24.0, 0.0},
+    {190.0 / 720.0, -2774.0 / 720.0, 2616.0 / 720.0, -1274.0 / 720.0, 251.0 / 720.0},
+};
+
+static int xpass(mrl_ctx *ctx, bool inv, const cplx *in, cplx *out) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2];
+  p2::PassArgs a{};
+  a.in[0] = in;
+  a.out[0] = out;
+  a.scale = 1.0;
+  a.inner = nyl * nzc;
+  a.outer = 1;
+  a.sn_in = a.sn_out = nyl * nzc;
+  const cplx *tw = ctx->ax[0].d_tw;
+  if (inv) {
+    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xpass<NN, true>(ctx, a, tw))));
+  } else {
+    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xpass<NN, false>(ctx, a, tw))));
+  }
+  return MRL_OK;
+}
+
+int slab_ch_fwd_local_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *send, double *mu, int part) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2];
+  const long long nfield = nx * nyl * nzc;
+  cplx *s_c = reinterpret_cast<cplx *>(send), *s_mu = s_c + nfield;
+  const double h = 16.0 * nfield;
+  if (part != 1) {
+    {
+      ProfScope ps(ctx, "slab_A_z_fwd", 8.0 * nx * nyl * nz + 2.0 * h + (mu ? 8.0 * nx * nyl * nz : 0.0));
+      p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2};
+      if (cp.family == MRL_FE_DOUBLE_WELL) {
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd_ch<NN, MRL_FE_DOUBLE_WELL>(ctx, c_in, s_c, s_mu, mu, chp, nx * nyl))));
+      } else {
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd_ch<NN, MRL_FE_PFHUB>(ctx, c_in, s_c, s_mu, mu, chp, nx * nyl))));
+      }
+    }
+    ProfScope ps(ctx, "slab_A_x_fwd", 2.0 * h);
+    MRL_TRY(xpass(ctx, false, s_c, s_c));
+  }
+  if (part != 0) {
+    ProfScope ps(ctx, "slab_A_x_fwd", 2.0 * h);
+    MRL_TRY(xpass(ctx, false, s_mu, s_mu));
+  }
+  return MRL_OK;
+}
+
+int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, const double *recv, double *send, double *Nhat_new,
+                        const double *const *Nhat_old, int order, double sub_dt, double *cbar) {
+  const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2];
+  const long long nspec = nxl * ny * nzc;
+  const long long nyl = ny / ctx->nranks;
+  p2::YFusedArgs a{};
+  a.chat = reinterpret_cast<const cplx *>(recv);
+  a.muhat = a.chat + nspec;
+  a.ubar = reinterpret_cast<cplx *>(send);
+  a.Nnew = reinterpret_cast<cplx *>(Nhat_new);
+  a.cbar = reinterpret_cast<cplx *>(cbar);
+  for (int i = 0; i < order; ++i) a.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
+  for (int i = 0; i <= order; ++i) a.coef[i] = sub_dt * kBetaS[order][i];
+  a.nxl = (int)nxl;
+  a.nzc = (int)nzc;
+  a.nyl_shift = 0;
+  while ((1LL << a.nyl_shift) < nyl) ++a.nyl_shift;
+  a.chunk = nxl * nyl * nzc;
+  a.kx = ctx->d_k[0];
+  a.ky = ctx->d_k[1];
+  a.kz = ctx->d_k[2];
+  a.M = cp.M;
+  a.kappa = cp.kappa;
+  a.dt = sub_dt;
+  ProfScope ps(ctx, "slab_B_y_fused", (4.0 + order + (cbar ? 1.0 : 0.0)) * 16.0 * nspec);
+  switch (order) {
+    case 0: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 0>(ctx, a)))); break;
+    case 1: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 1>(ctx, a)))); break;
+    case 2: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 2>(ctx, a)))); break;
+    case 3: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 3>(ctx, a)))); break;
+    default: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 4>(ctx, a)))); break;
+  }
+  return MRL_OK;
+}
+
+int slab_inv_finish_fast(mrl_ctx *ctx, const double *recv, double *real_out) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2];
+  const long long nfield = nx * nyl * nzc;
+  MRL_TRY(ensure_work(ctx, 11, sizeof(cplx) * nfield));
+  cplx *w = reinterpret_cast<cplx *>(ctx->d_work[11]);
+  {
+    ProfScope ps(ctx, "slab_C_x_inv", 32.0 * nfield);
+    MRL_TRY(xpass(ctx, true, reinterpret_cast<const cplx *>(recv), w));
+  }
+  ProfScope ps(ctx, "slab_C_z_inv", 16.0 * nfield + 8.0 * nx * nyl * nz);
+  const double scale = 1.0 / ((double)nx * (double)ctx->n[1] * (double)nz);
+  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_s<NN>(ctx, w, real_out, scale, nx * nyl / 2))));
+  return MRL_OK;
+}
+
+}  // namespace mrl

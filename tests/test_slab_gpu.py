@@ -169,3 +169,26 @@ def test_slab_ch_matches_serial_oracle(shape, P):
         _step_all(solvers, 1e-3, 3)
         assert (_gather(solvers) - ref.c).abs().max().item() <= 1e-13
     assert [s.last_order for s in solvers] == [1] * P
+
+
+def test_rccl_exchange_single_rank():
+    """SlabExchange over the nccl (= RCCL) backend: a world of one rank exercises the all_to_all_single
+    call path (split sizes, float64 payload, async work handle) on the GPU box's single device."""
+    import os
+    import torch.distributed as dist
+    from marlin_amd.slab import SlabExchange
+    from tests.test_slab_gloo import _free_port
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        x = SlabExchange([1000], [1000])
+        assert x.mode == "a2a"
+        send = torch.rand(2000, dtype=torch.float64, device="cuda")
+        recv = torch.zeros_like(send)
+        w = x.run(send, recv, async_op=True)
+        w.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+    finally:
+        dist.destroy_process_group()
