@@ -97,7 +97,7 @@ int mrl_fft_c2r(mrl_ctx *ctx, const double *d_in, double *d_out, int64_t batch, 
  * DomainAction.C:869-1019).  The caller owns the exchange (RCCL all-to-all, MPI, ...):
  *   forward : mrl_slab_fwd_local -> exchange(send -> recv) -> mrl_slab_fwd_finish
  *   inverse : mrl_slab_inv_local -> exchange(send -> recv) -> mrl_slab_inv_finish
- * send/recv buffers hold nranks chunks, chunk p at element offset mrl_slab_chunk_offset(p)
+ * send/recv buffers hold nranks chunks, chunk p at the element offset mrl_slab_counts returns for it
  * (complex elements); chunk p of `send` goes to rank p, chunk p of `recv` came from rank p. */
 int mrl_slab_counts(const mrl_ctx *ctx, int forward, int64_t *h_send_counts, int64_t *h_recv_counts,
                     int64_t *h_send_offsets, int64_t *h_recv_offsets); /* complex elements, nranks each */

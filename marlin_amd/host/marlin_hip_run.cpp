@@ -1,0 +1,174 @@
+// marlin-hip-run: drives the host mirror (marlin_host.h) for the reference's regression cases, the way
+// `marlin-opt -i case.i` drives the MOOSE objects.  Input is a flat list of key=value arguments that carry
+// the same parameters as the reference's input files; output is one raw little-endian f64 file per
+// buffer and time step (<out>/<buffer>.<frame>.bin), the data XDMFTensorOutput writes to HDF5.
+//
+//   marlin-hip-run problem=cahnhilliard dim=2 nx=20 ny=20 xmax=3 ymax=3 ic=c0.bin substeps=10 num_steps=10 dt=1e-3 out=dir
+//        (test/tests/cahnhilliard/cahnhilliard.i)
+//   marlin-hip-run problem=mechanics dim=3 nx=16 ny=16 nz=16 substeps=10 num_steps=3 dt=0.01 l_tol=1e-2 nl_rel_tol=2e-2
+//        nl_abs_tol=2e-2 out=dir          (test/tests/mechanics/mech3d.i)
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "marlin_host.h"
+
+using namespace marlin_host;
+
+static std::map<std::string, std::string> g_args;
+static std::string arg(const std::string & k, const std::string & dflt = "")
+{
+  auto it = g_args.find(k);
+  return it == g_args.end() ? dflt : it->second;
+}
+static double argd(const std::string & k, double dflt) { return g_args.count(k) ? std::atof(g_args[k].c_str()) : dflt; }
+static long argi(const std::string & k, long dflt) { return g_args.count(k) ? std::atol(g_args[k].c_str()) : dflt; }
+
+static void dump(const std::string & dir, const std::string & name, int frame, const DeviceTensor & t)
+{
+  const auto h = t.toHost();
+  const std::string path = dir + "/" + name + "." + std::to_string(frame) + ".bin";
+  std::ofstream f(path, std::ios::binary);
+  if (!f)
+    mooseError("cannot write " + path);
+  f.write(reinterpret_cast<const char *>(h.data()), sizeof(double) * h.size());
+}
+
+static std::vector<double> read_bin(const std::string & path, std::size_t count)
+{
+  std::vector<double> v(count);
+  std::ifstream f(path, std::ios::binary);
+  if (!f || !f.read(reinterpret_cast<char *>(v.data()), sizeof(double) * count))
+    mooseError("cannot read " + std::to_string(count) + " doubles from " + path);
+  return v;
+}
+
+static int run_cahnhilliard(DomainAction & domain, const std::string & out)
+{
+  TensorProblem problem(domain);
+  const std::size_t n = domain.getNumberOfCells();
+  problem.getBuffer("c") = DeviceTensor::fromHost(read_bin(arg("ic"), n));  // RandomTensor IC (seed-0 torch stream)
+  problem.getBuffer("mu") = DeviceTensor::zeros(n);                        // ConstantTensor
+  AdamsBashforthMoulton::Params p;
+  p.substeps = (unsigned int)argi("substeps", 1);
+  p.predictor_order = (std::size_t)argi("predictor_order", 2);
+  p.ch.family = arg("free_energy", "DOUBLE_WELL") == "PFHUB" ? MRL_FE_PFHUB : MRL_FE_DOUBLE_WELL;
+  p.ch.coef[0] = argd("A", 0.1);          // expression = '0.1*c^2*(c-1)^2'
+  p.ch.coef[1] = argd("c_alpha", 0.3);
+  p.ch.coef[2] = argd("c_beta", 0.7);
+  p.ch.mobility = argd("mobility", 0.2);  // ReciprocalLaplacianFactor factor
+  p.ch.kappa = argd("kappa", -0.001);     // ReciprocalLaplacianSquareFactor factor
+  AdamsBashforthMoulton solver(problem, "solver", p);
+  Transient ex(problem, solver, argd("dt", 1e-3));
+  dump(out, "c", 0, problem.getBuffer("c"));
+  ex.execute((int)argi("num_steps", 1), [&](int step) {
+    dump(out, "c", step, problem.getBuffer("c"));
+    dump(out, "mu", step, problem.getBuffer("mu"));
+  });
+  return 0;
+}
+
+static int run_mechanics(DomainAction & domain, const std::string & out)
+{
+  TensorProblem problem(domain);
+  const int dim = domain.getDim();
+  const auto & shape = domain.getShape();
+  const std::size_t n = domain.getNumberOfCells();
+  // phase = prod_d (cos(x_d)/2 + 0.5); K = (1-phase)*Ka + phase*Kb; mu likewise   (mech3d.i:14-35)
+  std::vector<std::vector<double>> ax;
+  for (int d = 0; d < dim; ++d)
+    ax.push_back(domain.getAxis(d));
+  const double Ka = argd("Ka", 1.0), Kb = argd("Kb", 10.0), mua = argd("mua", 0.5), mub = argd("mub", 5.0);
+  std::vector<double> K(n), mu(n), F(n * dim * dim, 0.0);
+  for (std::size_t e = 0; e < n; ++e)
+  {
+    std::size_t r = e;
+    std::vector<int64_t> idx(dim);
+    for (int d = dim - 1; d >= 0; --d)
+    {
+      idx[d] = r % shape[d];
+      r /= shape[d];
+    }
+    double phase = 1.0;
+    for (int d = 0; d < dim; ++d)
+    {
+      const double term = std::cos(ax[d][idx[d]]) / 2.0 + 0.5;
+      phase = d == 0 ? term : phase * term;
+    }
+    K[e] = (1.0 - phase) * Ka + phase * Kb;
+    mu[e] = (1.0 - phase) * mua + phase * mub;
+    for (int i = 0; i < dim; ++i)
+      F[e * dim * dim + i * dim + i] = 1.0;  // RankTwoIdentity
+  }
+  problem.getBuffer("K") = DeviceTensor::fromHost(K);
+  problem.getBuffer("mu") = DeviceTensor::fromHost(mu);
+  problem.getBuffer("F") = DeviceTensor::fromHost(F);
+
+  auto root = std::make_shared<ComputeGroup>(problem, "root");
+  root->add(std::make_shared<MacroscopicShearTensor>(problem, "applied_strain", "applied_strain", "F"));
+  FFTMechanics::Params mp;
+  mp.applied_macroscopic_strain = "applied_strain";
+  mp.l_tol = argd("l_tol", 1e-2);
+  mp.nl_rel_tol = argd("nl_rel_tol", 1e-5);
+  mp.nl_abs_tol = argd("nl_abs_tol", 1e-8);
+  mp.l_max_its = argi("l_max_its", 0);
+  mp.nl_max_its = (unsigned int)argi("nl_max_its", 100);
+  auto mech = std::make_shared<FFTMechanics>(problem, "mech", mp);
+  root->add(mech);
+  ForwardEulerSolver solver(problem, "solver", (unsigned int)argi("substeps", 1), root);
+  solver.addForwardBuffer("F", "Fnew");
+  Transient ex(problem, solver, argd("dt", 0.01));
+  ex.execute((int)argi("num_steps", 1), [&](int step) {
+    dump(out, "F", step - 1, problem.getBuffer("F"));  // frame 0 = end of step 1 (output on TIMESTEP_END only)
+    const auto & st = mech->stats();
+    std::printf("step %d: newton_its=%d cg_its_total=%d |R|=%.6e\n", step, st.newton_its, st.cg_its_total, st.last_anorm);
+  });
+  return 0;
+}
+
+int main(int argc, char ** argv)
+{
+  for (int i = 1; i < argc; ++i)
+  {
+    const std::string a = argv[i];
+    const auto eq = a.find('=');
+    if (eq == std::string::npos)
+    {
+      std::cerr << "expected key=value, got '" << a << "'\n";
+      return 2;
+    }
+    g_args[a.substr(0, eq)] = a.substr(eq + 1);
+  }
+  try
+  {
+    const int dim = (int)argi("dim", 0);
+    if (dim < 1 || dim > 3)
+      mooseError("Unsupported mesh dimension");
+    const char * nn[3] = {"nx", "ny", "nz"};
+    const char * mx[3] = {"xmax", "ymax", "zmax"};
+    const char * mn[3] = {"xmin", "ymin", "zmin"};
+    std::vector<int64_t> n;
+    std::vector<double> lo, hi;
+    const double two_pi = 2.0 * M_PI;
+    for (int d = 0; d < dim; ++d)
+    {
+      n.push_back(argi(nn[d], 1));
+      lo.push_back(argd(mn[d], 0.0));
+      hi.push_back(arg(mx[d]) == "2pi" ? two_pi : argd(mx[d], 1.0));
+    }
+    DomainAction domain(dim, n, hi, lo);
+    const std::string out = arg("out", ".");
+    const std::string problem = arg("problem");
+    if (problem == "cahnhilliard")
+      return run_cahnhilliard(domain, out);
+    if (problem == "mechanics")
+      return run_mechanics(domain, out);
+    mooseError("unknown problem '" + problem + "'");
+  }
+  catch (const std::exception & e)
+  {
+    std::cerr << "*** ERROR ***\n" << e.what() << "\n";
+    return 1;
+  }
+}

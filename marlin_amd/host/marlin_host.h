@@ -1,0 +1,488 @@
+// Host-side mirror (C++17) of the part of Marlin's MOOSE-object API that drives the hot path, over the
+// C ABI of include/marlin_hip.h.  Same names, argument meaning and error behaviour as the reference:
+//   DeviceTensor                    torch::Tensor handle semantics (assignment rebinds, copies share storage)
+//   TensorBuffer                    include/tensor_buffers/TensorBuffer.h:16-116 (history by handle copy)
+//   TensorProblem                   src/problems/TensorProblem.C:154-197, 451-472 (advanceState rule, sub time)
+//   DomainAction                    src/actions/DomainAction.C (fft / ifft / average / axes)
+//   TensorOperatorBase, ComputeGroup        include/tensor_computes/TensorOperatorBase.h:27-171, ComputeGroup.C:50-87
+//   TensorSolver                    src/tensor_solver/TensorSolver.C:86-109
+//   AdamsBashforthMoulton           src/tensor_solver/AdamsBashforthMoulton.C:48-101  (Cahn-Hilliard system, fused)
+//   ForwardEulerSolver              src/tensor_solver/ForwardEulerSolver.C:29-38
+//   MacroscopicShearTensor          test/src/tensor_computes/MacroscopicShearTensor.C:31-41
+//   FFTMechanics                    src/tensor_computes/FFTMechanics.C:96-163 (+ HyperElasticIsotropic)
+//   Transient                       MOOSE's executioner loop as far as the path needs it
+// The MOOSE factory / input parser is NOT mirrored: objects are constructed directly (marlin_hip_run.cpp).
+// All arithmetic happens in libmarlin_hip.so; this layer only owns handles, history and control flow.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "marlin_hip.h"
+
+namespace marlin_host {
+
+[[noreturn]] inline void mooseError(const std::string & msg) { throw std::runtime_error(msg); }
+[[noreturn]] inline void paramError(const std::string & param, const std::string & msg)
+{
+  throw std::runtime_error(param + ": " + msg);
+}
+
+/// shared handle to a device array of doubles (complex spectra are interleaved re,im)
+class DeviceTensor
+{
+public:
+  DeviceTensor() = default;
+  static DeviceTensor empty(std::size_t count)
+  {
+    DeviceTensor t;
+    double * p = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&p), sizeof(double) * (count ? count : 1)) != hipSuccess)
+      mooseError("hipMalloc failed");
+    t._p = std::shared_ptr<double>(p, [](double * q) { (void)hipFree(q); });
+    t._n = count;
+    return t;
+  }
+  static DeviceTensor zeros(std::size_t count)
+  {
+    auto t = empty(count);
+    if (hipMemset(t.data(), 0, sizeof(double) * count) != hipSuccess)
+      mooseError("hipMemset failed");
+    return t;
+  }
+  static DeviceTensor fromHost(const std::vector<double> & h)
+  {
+    auto t = empty(h.size());
+    if (hipMemcpy(t.data(), h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice) != hipSuccess)
+      mooseError("hipMemcpy (host to device) failed");
+    return t;
+  }
+  std::vector<double> toHost() const
+  {
+    std::vector<double> h(_n);
+    if (hipMemcpy(h.data(), _p.get(), sizeof(double) * _n, hipMemcpyDeviceToHost) != hipSuccess)
+      mooseError("hipMemcpy (device to host) failed");
+    return h;
+  }
+  bool defined() const { return (bool)_p; }
+  double * data() const { return _p.get(); }
+  std::size_t numel() const { return _n; }
+
+private:
+  std::shared_ptr<double> _p;
+  std::size_t _n = 0;
+};
+
+/// TensorBuffer<T>: current tensor + history of handles
+class TensorBuffer
+{
+public:
+  DeviceTensor & getTensor() { return _u; }
+  std::size_t advanceState()
+  {
+    if (_u_old.size() < _max_states)
+      _u_old.resize(_u_old.size() + 1);
+    if (!_u_old.empty())
+    {
+      for (std::size_t i = _u_old.size() - 1; i > 0; --i)
+        _u_old[i] = _u_old[i - 1];
+      _u_old[0] = _u;
+    }
+    return _u_old.size();
+  }
+  const std::vector<DeviceTensor> & getOldTensor(std::size_t states_requested)
+  {
+    _max_states = std::max(_max_states, states_requested);
+    return _u_old;
+  }
+  void clearStates() { _u_old.clear(); }
+
+private:
+  DeviceTensor _u;
+  std::vector<DeviceTensor> _u_old;
+  std::size_t _max_states = 0;
+};
+
+/// DomainAction as a math service
+class DomainAction
+{
+public:
+  DomainAction(int dim, const std::vector<int64_t> & n, const std::vector<double> & max,
+               const std::vector<double> & min = {0, 0, 0})
+    : _dim(dim), _n(n)
+  {
+    mrl_domain d{};
+    d.dim = dim;
+    for (int i = 0; i < dim; ++i)
+    {
+      d.n[i] = n[i];
+      d.min[i] = i < (int)min.size() ? min[i] : 0.0;
+      d.max[i] = max[i];
+      _dx.push_back((d.max[i] - d.min[i]) / n[i]);
+      _min.push_back(d.min[i]);
+      _max.push_back(d.max[i]);
+    }
+    d.device = -1;
+    d.nranks = 1;
+    d.rank = 0;
+    d.spectrum = MRL_SPECTRUM_HALF;
+    d.stream = nullptr;  // the HIP null stream: hipMemcpy/hipMemset of this layer are ordered with the kernels
+    d.flags = 0;
+    if (mrl_ctx_create(&_ctx, &d) != MRL_OK)
+      mooseError(std::string("DomainAction: ") + mrl_last_error(nullptr));
+    _n_real = 1;
+    _n_recip = 1;
+    for (int i = 0; i < dim; ++i)
+    {
+      _n_real *= n[i];
+      _n_recip *= (i == dim - 1) ? n[i] / 2 + 1 : n[i];
+    }
+  }
+  ~DomainAction() { mrl_ctx_destroy(_ctx); }
+  DomainAction(const DomainAction &) = delete;
+
+  mrl_ctx * ctx() const { return _ctx; }
+  int getDim() const { return _dim; }
+  const std::vector<int64_t> & getShape() const { return _n; }
+  int64_t getNumberOfCells() const { return _n_real; }
+  int64_t getReciprocalSize() const { return _n_recip; }
+  /// real-space axis: linspace(min + dx/2, max - dx/2, n)  (DomainAction.C:246-251)
+  std::vector<double> getAxis(int d) const
+  {
+    std::vector<double> a(_n[d]);
+    const double lo = _min[d] + _dx[d] / 2.0, hi = _max[d] - _dx[d] / 2.0;
+    const double step = _n[d] > 1 ? (hi - lo) / (double)(_n[d] - 1) : 0.0;
+    // torch::linspace fills the upper half from the end (start + step*i below the midpoint, end - step*(n-1-i) above)
+    for (int64_t i = 0; i < _n[d]; ++i)
+      a[i] = (i < _n[d] / 2) ? lo + step * (double)i : hi - step * (double)(_n[d] - 1 - i);
+    return a;
+  }
+  void check(int rc) const
+  {
+    if (rc != MRL_OK)
+      mooseError(std::string("marlin_hip: ") + mrl_last_error(_ctx));
+  }
+  DeviceTensor fft(const DeviceTensor & t, int64_t batch = 1) const
+  {
+    auto out = DeviceTensor::empty(2 * _n_recip * batch);
+    check(mrl_fft_r2c(_ctx, t.data(), out.data(), batch, batch > 1));
+    return out;
+  }
+  DeviceTensor ifft(const DeviceTensor & t, int64_t batch = 1) const
+  {
+    auto out = DeviceTensor::empty(_n_real * batch);
+    check(mrl_fft_c2r(_ctx, t.data(), out.data(), batch, batch > 1));
+    return out;
+  }
+  std::vector<double> average(const DeviceTensor & t, int ncomp) const
+  {
+    std::vector<double> a(ncomp);
+    check(mrl_average(_ctx, t.data(), ncomp, a.data()));
+    return a;
+  }
+
+private:
+  const int _dim;
+  std::vector<int64_t> _n;
+  std::vector<double> _dx, _min, _max;
+  mrl_ctx * _ctx = nullptr;
+  int64_t _n_real, _n_recip;
+};
+
+/// the part of TensorProblem the solvers talk to: buffer registry, time bookkeeping, history advance
+class TensorProblem
+{
+public:
+  explicit TensorProblem(DomainAction & domain) : _domain(domain) {}
+  DomainAction & domain() { return _domain; }
+  TensorBuffer & getBufferObject(const std::string & name) { return _tensor_buffer[name]; }
+  DeviceTensor & getBuffer(const std::string & name) { return _tensor_buffer[name].getTensor(); }
+  const std::vector<DeviceTensor> & getBufferOld(const std::string & name, unsigned int max_states)
+  {
+    return _tensor_buffer[name].getOldTensor(max_states);
+  }
+  /// TensorProblem::advanceState (TensorProblem.C:451-472): a no-op while timeStep() <= 1
+  void advanceState()
+  {
+    if (_t_step <= 1)
+      return;
+    for (auto & pair : _tensor_buffer)
+      pair.second.advanceState();
+  }
+  int & timeStep() { return _t_step; }
+  double & time() { return _time; }
+  double & timeOld() { return _time_old; }
+  double & dt() { return _dt; }
+  double & subDt() { return _sub_dt; }
+  double & subTime() { return _sub_time; }
+
+private:
+  DomainAction & _domain;
+  std::map<std::string, TensorBuffer> _tensor_buffer;
+  int _t_step = 0;
+  double _time = 0.0, _time_old = 0.0, _dt = 0.0, _sub_dt = 0.0, _sub_time = 0.0;
+};
+
+class TensorOperatorBase
+{
+public:
+  TensorOperatorBase(TensorProblem & problem, std::string name)
+    : _tensor_problem(problem), _domain(problem.domain()), _name(std::move(name)), _time(problem.subTime())
+  {
+  }
+  virtual ~TensorOperatorBase() = default;
+  virtual void computeBuffer() = 0;
+  virtual void init() {}
+  virtual bool supportsJIT() const { return false; }
+  const std::string & name() const { return _name; }
+
+protected:
+  DeviceTensor & getInputBuffer(const std::string & buffer) { return _tensor_problem.getBuffer(buffer); }
+  DeviceTensor & getOutputBuffer(const std::string & buffer) { return _tensor_problem.getBuffer(buffer); }
+  TensorProblem & _tensor_problem;
+  DomainAction & _domain;
+  const std::string _name;
+  const double & _time;  // TensorOperatorBase.C:40: operators see the sub time
+};
+
+/// ComputeGroup: runs its computes in the given (already dependency-sorted) order
+class ComputeGroup : public TensorOperatorBase
+{
+public:
+  using TensorOperatorBase::TensorOperatorBase;
+  void add(std::shared_ptr<TensorOperatorBase> cmp) { _computes.push_back(std::move(cmp)); }
+  void computeBuffer() override
+  {
+    for (auto & cmp : _computes)
+    {
+      try
+      {
+        cmp->computeBuffer();
+      }
+      catch (const std::exception & e)
+      {
+        mooseError("Exception in compute '" + cmp->name() + "': " + e.what());  // ComputeGroup.C:73-83
+      }
+    }
+  }
+
+private:
+  std::vector<std::shared_ptr<TensorOperatorBase>> _computes;
+};
+
+class TensorSolver : public TensorOperatorBase
+{
+public:
+  TensorSolver(TensorProblem & problem, std::string name, unsigned int substeps,
+               std::shared_ptr<TensorOperatorBase> root_compute)
+    : TensorOperatorBase(problem, std::move(name)), _substeps(substeps), _sub_dt(problem.subDt()),
+      _sub_time(problem.subTime()), _dt(problem.dt()), _compute(std::move(root_compute))
+  {
+  }
+  /// TensorSolver::computeBuffer (TensorSolver.C:93-109)
+  void computeBuffer() override
+  {
+    _sub_dt = _dt / _substeps;
+    for (_substep = 0; _substep < _substeps; _substep++)
+    {
+      substep();
+      if (_substep < _substeps - 1)
+        _tensor_problem.advanceState();
+      _sub_time += _sub_dt;
+    }
+  }
+  void addForwardBuffer(const std::string & forward_buffer, const std::string & forward_buffer_new)
+  {
+    _forwarded.emplace_back(forward_buffer, forward_buffer_new);
+  }
+
+protected:
+  void forwardBuffers()
+  {
+    for (auto & [dst, src] : _forwarded)
+      _tensor_problem.getBuffer(dst) = _tensor_problem.getBuffer(src);  // handle assignment (TensorSolver.C:86-90)
+  }
+  virtual void substep() = 0;
+  const unsigned int _substeps;
+  unsigned int _substep = 0;
+  double & _sub_dt;
+  double & _sub_time;
+  const double & _dt;
+  std::shared_ptr<TensorOperatorBase> _compute;
+  std::vector<std::pair<std::string, std::string>> _forwarded;
+};
+
+/// AdamsBashforthMoulton for the Cahn-Hilliard system: variable {buffer=c, reciprocal_buffer=cbar,
+/// linear_reciprocal=kappabarbar, nonlinear_reciprocal=Mbarmubar}; the root compute group (mu, mubar,
+/// Mbarmubar, cbar) is fused into the substep kernel sequence, its buffers are still published.
+class AdamsBashforthMoulton : public TensorSolver
+{
+public:
+  struct Params
+  {
+    std::string buffer = "c", reciprocal_buffer = "cbar", nonlinear_reciprocal = "Mbarmubar", mu = "mu";
+    unsigned int substeps = 1;
+    std::size_t predictor_order = 2;
+    mrl_ch_params ch{};
+    bool publish_mu = true, publish_cbar = false;
+  };
+  AdamsBashforthMoulton(TensorProblem & problem, const std::string & name, const Params & p)
+    : TensorSolver(problem, name, p.substeps, nullptr), _p(p), _predictor_order(p.predictor_order - 1),
+      _u(problem.getBuffer(p.buffer)), _nonlinear(problem.getBuffer(p.nonlinear_reciprocal)),
+      _old_nonlinear(problem.getBufferOld(p.nonlinear_reciprocal, (unsigned int)(p.predictor_order - 1)))
+  {
+    if (p.predictor_order < 1 || p.predictor_order > 5)
+      paramError("predictor_order", "predictor_order > 0 & predictor_order <= 5");
+  }
+
+protected:
+  void substep() override
+  {
+    const std::size_t n_old = _old_nonlinear.size();
+    const int order = (int)std::min(n_old, _predictor_order);  // AdamsBashforthMoulton.C:90-91 (dt constant)
+    const std::size_t nreal = _domain.getNumberOfCells(), nspec = 2 * _domain.getReciprocalSize();
+    auto c_out = DeviceTensor::empty(nreal);
+    auto Nnew = DeviceTensor::empty(nspec);
+    DeviceTensor mu, cbar;
+    if (_p.publish_mu)
+      mu = DeviceTensor::empty(nreal);
+    if (_p.publish_cbar)
+      cbar = DeviceTensor::empty(nspec);
+    std::vector<const double *> old(order > 0 ? order : 1, nullptr);
+    for (int i = 0; i < order; ++i)
+      old[i] = _old_nonlinear[i].data();
+    _domain.check(mrl_ch_substep(_domain.ctx(), &_p.ch, _u.data(), c_out.data(), Nnew.data(), old.data(), order,
+                                 _sub_dt, cbar.defined() ? cbar.data() : nullptr, mu.defined() ? mu.data() : nullptr));
+    _nonlinear = Nnew;  // what the compute group assigns to Mbarmubar
+    if (mu.defined())
+      _tensor_problem.getBuffer(_p.mu) = mu;
+    if (cbar.defined())
+      _tensor_problem.getBuffer(_p.reciprocal_buffer) = cbar;
+    _u = c_out;  // AdamsBashforthMoulton.C:101
+  }
+  const Params _p;
+  const std::size_t _predictor_order;
+  DeviceTensor & _u;
+  DeviceTensor & _nonlinear;
+  const std::vector<DeviceTensor> & _old_nonlinear;
+};
+
+/// ForwardEulerSolver with no integrated variables (the mechanics driver): root compute, then forward buffers
+class ForwardEulerSolver : public TensorSolver
+{
+public:
+  using TensorSolver::TensorSolver;
+
+protected:
+  void substep() override
+  {
+    _compute->computeBuffer();
+    forwardBuffers();
+  }
+};
+
+/// test object: DbarF = (I + t e0 x e1) - <F>
+class MacroscopicShearTensor : public TensorOperatorBase
+{
+public:
+  MacroscopicShearTensor(TensorProblem & problem, const std::string & name, const std::string & buffer,
+                         const std::string & F)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer)), _tF(getInputBuffer(F))
+  {
+  }
+  void computeBuffer() override
+  {
+    const int d = _domain.getDim();
+    const auto avg = _domain.average(_tF, d * d);
+    std::vector<double> a(d * d, 0.0);
+    for (int i = 0; i < d; ++i)
+      a[i * d + i] = 1.0;
+    a[1] = a[1] + _time;
+    for (int i = 0; i < d * d; ++i)
+      a[i] = a[i] - avg[i];
+    _u = DeviceTensor::fromHost(a);
+  }
+
+private:
+  DeviceTensor & _u;
+  DeviceTensor & _tF;
+};
+
+/// FFTMechanics with the HyperElasticIsotropic constitutive model
+class FFTMechanics : public TensorOperatorBase
+{
+public:
+  struct Params
+  {
+    std::string buffer = "Fnew", F = "F", K = "K", mu = "mu", stress = "stress", applied_macroscopic_strain;
+    double l_tol = 1e-2, nl_rel_tol = 1e-5, nl_abs_tol = 1e-8;
+    int64_t l_max_its = 0;
+    unsigned int nl_max_its = 100;
+  };
+  FFTMechanics(TensorProblem & problem, const std::string & name, const Params & p)
+    : TensorOperatorBase(problem, name), _p(p), _u(getOutputBuffer(p.buffer)), _tF(getInputBuffer(p.F)),
+      _tK(getInputBuffer(p.K)), _tmu(getInputBuffer(p.mu)), _tP(getOutputBuffer(p.stress)),
+      _applied(p.applied_macroscopic_strain.empty() ? nullptr : &getInputBuffer(p.applied_macroscopic_strain))
+  {
+  }
+  void computeBuffer() override
+  {
+    mrl_mech_params prm{_p.l_tol, _p.l_max_its, _p.nl_rel_tol, _p.nl_abs_tol, (int32_t)_p.nl_max_its};
+    auto Fnew = DeviceTensor::empty(_tF.numel());
+    auto P = DeviceTensor::empty(_tF.numel());
+    const int rc = mrl_mech_newton_cg(_domain.ctx(), &prm, _tF.data(), _tK.data(), _tmu.data(),
+                                      _applied ? _applied->data() : nullptr, Fnew.data(), P.data(), &_stats);
+    if (rc == MRL_ERR_NOT_CONVERGED)
+      paramError("nl_max_its", mrl_last_error(_domain.ctx()));  // FFTMechanics.C:159-161
+    _domain.check(rc);
+    _u = Fnew;
+    _tP = P;
+  }
+  const mrl_mech_stats & stats() const { return _stats; }
+
+private:
+  const Params _p;
+  DeviceTensor & _u;
+  DeviceTensor & _tF;
+  DeviceTensor & _tK;
+  DeviceTensor & _tmu;
+  DeviceTensor & _tP;
+  DeviceTensor * _applied;
+  mrl_mech_stats _stats{};
+};
+
+/// MOOSE Transient as far as the path sees it: advanceState, then the solver at EXEC_TIMESTEP_BEGIN
+class Transient
+{
+public:
+  Transient(TensorProblem & problem, TensorSolver & solver, double dt) : _problem(problem), _solver(solver), _dt(dt) {}
+  template <typename F>
+  void execute(int num_steps, F && on_timestep_end)
+  {
+    for (int s = 0; s < num_steps; ++s)
+    {
+      _problem.timeOld() = _problem.time();
+      _problem.timeStep() += 1;
+      _problem.dt() = _dt;
+      _problem.time() = _problem.timeOld() + _dt;
+      _problem.advanceState();                         // incrementStepOrReject -> advanceState
+      _problem.subTime() = _problem.timeOld();         // TensorProblem.C:179
+      _solver.computeBuffer();                         // EXEC_TIMESTEP_BEGIN
+      on_timestep_end(_problem.timeStep());            // EXEC_TIMESTEP_END: outputs
+    }
+  }
+
+private:
+  TensorProblem & _problem;
+  TensorSolver & _solver;
+  const double _dt;
+};
+
+}  // namespace marlin_host
