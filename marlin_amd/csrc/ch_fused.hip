@@ -8,6 +8,7 @@
 //     E  k_z_inv       c2r along z, 1/N
 //   Forward order z,y,x and inverse order x,y,z: the fused pass runs along x because its tiles are
 //   contiguous in (y,kz) jointly, so the user-visible Nhat arrays are accessed in aligned 256-B pieces.
+#include "ch_fused_body.h"
 #include "fft_pow2_kernels.h"
 
 namespace mrl {
@@ -15,23 +16,14 @@ namespace mrl {
 namespace p2 {
 
 struct FusedArgs {
-  const cplx *chat;   // c-hat after z,y passes     [x][inner]
-  const cplx *muhat;  // mu-hat after z,y passes
-  cplx *ubar;         // out: inverse-x-transformed ubar (may alias chat)
-  cplx *Nnew;         // out: Mbar*mubar (reference layout [x][y][kz])
-  cplx *cbar;         // optional out: fully transformed c-hat
-  const cplx *Nold[4];
-  double coef[5];     // sub_dt * beta[order][i]
-  int order;
+  FusedCommon c;      // chat/muhat/ubar in the work layout [x][inner]; Nnew/cbar/Nold dense [x][y][kz]
   long long inner;    // ny*nzc
   int nzc;
   const double *kx, *ky, *kz;
-  double M, kappa, dt;
 };
 
 template <int N, int ORDER>
-__global__ void __launch_bounds__(256) k_ch_xfused(FusedArgs a, const cplx *__restrict__ tw) {
-#pragma clang fp contract(off)
+__global__ void __launch_bounds__(256, 2) k_ch_xfused(FusedArgs a, const cplx *__restrict__ tw) {
   constexpr int TPL = N / 16, T = 4096 / N;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -42,96 +34,11 @@ __global__ void __launch_bounds__(256) k_ch_xfused(FusedArgs a, const cplx *__re
   const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
   const long long i = (long long)logical * T + l;
   const bool valid = i < a.inner;
-  load_twiddles<N>(W, tw);
-  for (int j = threadIdx.x; j < N; j += 256) KX[j] = a.kx[j];
-  const long long sn = a.inner;
-  const long long off = i + (long long)q * sn;
-
-  // 1. mu-hat: forward x
-  cplx v[16];
-  if (valid) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = a.muhat[off + (long long)m * TPL * sn];
-  } else {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
-  }
-  fft_line<N, Map>(v, q, l, X, W);
-
-  // 2. Nhat = Mbar * mu-hat  (Mbar = -k^2 * M, ReciprocalLaplacianFactor.C:28-31)
-  double ky2 = 0.0, kz2 = 0.0;
-  if (valid) {
-    const double ky = a.ky[i / a.nzc], kz = a.kz[i % a.nzc];
-    ky2 = ky * ky;
-    kz2 = kz * kz;
-  }
-  cplx Nv[16];
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    const double kx = KX[q + m * TPL];
-    const double k2 = kx * kx + ky2 + kz2;
-    const double Mbar = -k2 * a.M;
-    Nv[m] = make_double2(Mbar * v[m].x, Mbar * v[m].y);
-  }
-  if (valid) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) a.Nnew[off + (long long)m * TPL * sn] = Nv[m];
-  }
-
-  // 3. c-hat: forward x
-  if (valid) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = a.chat[off + (long long)m * TPL * sn];
-  } else {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
-  }
-  fft_line<N, Map>(v, q, l, X, W);
-  if (a.cbar && valid) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) a.cbar[off + (long long)m * TPL * sn] = v[m];
-  }
-
-  // 4. ubar = (cbar + (dt b0) N + sum (dt b_i) Nold_i) / (1 - dt*Lbar), in the reference's association.
-  //    ORDER is a template constant and the history loads are issued 8 at a time ahead of their use
-  //    (a run-time trip count here makes hipcc wait vmcnt(0) per element).
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    cplx o[ORDER > 0 ? ORDER : 1][8];
-    if (ORDER > 0) {
-#pragma unroll
-      for (int h = 0; h < ORDER; ++h) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          o[h][j] = valid ? a.Nold[h][off + (long long)(half * 8 + j) * TPL * sn] : make_double2(0.0, 0.0);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int m = half * 8 + j;
-      cplx u = v[m];
-      u.x = u.x + a.coef[0] * Nv[m].x;
-      u.y = u.y + a.coef[0] * Nv[m].y;
-#pragma unroll
-      for (int h = 0; h < ORDER; ++h) {
-        u.x += a.coef[h + 1] * o[h][j].x;
-        u.y += a.coef[h + 1] * o[h][j].y;
-      }
-      const double kx = KX[q + m * TPL];
-      const double k2 = kx * kx + ky2 + kz2;
-      const double Lb = k2 * k2 * a.kappa;
-      const double scl = 1.0 / (1.0 - a.dt * Lb);
-      // swapped for the inverse transform
-      v[m] = make_double2(u.y * scl, u.x * scl);
-    }
-  }
-
-  // 5. inverse x (unnormalised; 1/N applied by the final z pass)
-  fft_line<N, Map>(v, q, l, X, W);
-  if (valid) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) a.ubar[off + (long long)m * TPL * sn] = cswap(v[m]);
-  }
+  const long long iv = valid ? i : 0;
+  // byte offset of line element m: (i + (q + m*TPL)*inner) * 16, the same in the work and the dense layout
+  const unsigned off0 = (unsigned)(iv + (long long)q * a.inner) * 16u, step = (unsigned)(TPL * a.inner) * 16u;
+  auto off = [=](int m) { return off0 + (unsigned)m * step; };
+  ch_fused_body<N, ORDER, true>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, W, X, KX);
 }
 
 template <class K>
@@ -347,22 +254,21 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
   {
     ProfScope ps(ctx, "ch_C_x_fused", (4.0 + order + (cbar ? 1.0 : 0.0)) * h);
     p2::FusedArgs a{};
-    a.chat = w_c;
-    a.muhat = w_mu;
-    a.ubar = w_c;
-    a.Nnew = reinterpret_cast<cplx *>(Nhat_new);
-    a.cbar = reinterpret_cast<cplx *>(cbar);
-    for (int i = 0; i < order; ++i) a.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
-    for (int i = 0; i <= order; ++i) a.coef[i] = sub_dt * kBetaF[order][i];
-    a.order = order;
+    a.c.chat = w_c;
+    a.c.muhat = w_mu;
+    a.c.ubar = w_c;
+    a.c.Nnew = reinterpret_cast<cplx *>(Nhat_new);
+    a.c.cbar = reinterpret_cast<cplx *>(cbar);
+    for (int i = 0; i < order; ++i) a.c.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
+    for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaF[order][i];
     a.inner = ny * nzc;
     a.nzc = (int)nzc;
     a.kx = ctx->d_k[0];
     a.ky = ctx->d_k[1];
     a.kz = ctx->d_k[2];
-    a.M = cp.M;
-    a.kappa = cp.kappa;
-    a.dt = sub_dt;
+    a.c.M = cp.M;
+    a.c.kappa = cp.kappa;
+    a.c.dt = sub_dt;
     switch (order) {
       case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0>(ctx, a)))); break;
       case 1: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 1>(ctx, a)))); break;

@@ -1,0 +1,154 @@
+// Body of the fused Cahn-Hilliard k-space pass, shared by the serial kernel (lines along x, ch_fused.hip)
+// and the slab kernel (lines along y on the exchange layout, slab_fused.hip):
+//   forward transform of mu-hat and c-hat along the line axis, Nhat = Mbar*mu-hat (stored: it is the
+//   history), ABM predictor with ORDER old Nhat, 1/(1 - dt*Lbar), inverse transform of ubar.
+//   (AdamsBashforthMoulton.C:94-101, ReciprocalLaplacianFactor.C:28-31, ReciprocalLaplacianSquareFactor.C:28-32)
+//
+// Memory-latency structure: every HBM load of the workgroup is issued as early as its registers allow --
+// the small twiddle / k-axis loads first (vmcnt retires in order), then the 16 mu-hat and the 16 c-hat
+// values of the thread, and the old Nhat values right after the Nhat stores -- so the three transforms run
+// while the next operands are in flight instead of paying one full HBM latency per phase.
+#pragma once
+#include "fft_pow2.h"
+
+namespace mrl {
+namespace p2 {
+
+struct FusedCommon {
+  const cplx *chat;   // c-hat, work layout
+  const cplx *muhat;  // mu-hat, work layout
+  cplx *ubar;         // out, work layout (may alias chat)
+  cplx *Nnew;         // out, dense reference layout
+  cplx *cbar;         // optional out, dense
+  const cplx *Nold[4];
+  double coef[5];     // sub_dt * beta[order][i]
+  double M, kappa, dt;
+};
+
+// LINE_IS_X: the line axis is x (k^2 = (kl^2 + ka^2) + kb^2 with ka = ky, kb = kz); otherwise the line
+// axis is y (k^2 = (ka^2 + kl^2) + kb^2 with ka = kx, kb = kz) -- the reference's association kx*kx + ky*ky + kz*kz.
+// 32-bit BYTE offsets from a wave-uniform base pointer: the loads / stores take the "SGPR base + 32-bit VGPR
+// offset" form, which halves the address registers of the 5 x 16 accesses (arrays of the fast path are < 4 GiB).
+__device__ __forceinline__ cplx ldc(const cplx *base, unsigned boff) {
+  return *reinterpret_cast<const cplx *>(reinterpret_cast<const char *>(base) + boff);
+}
+__device__ __forceinline__ void stc(cplx *base, unsigned boff, cplx v) {
+  *reinterpret_cast<cplx *>(reinterpret_cast<char *>(base) + boff) = v;
+}
+
+// OffW / OffD: callables m -> byte offset of the thread's m-th line element in the work layout / the dense
+// reference layout (computed from a few live values instead of 2 x 16 held registers).
+template <int N, int ORDER, bool LINE_IS_X, class OffW, class OffD>
+__device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *__restrict__ tw,
+                                              const double *__restrict__ kline, const double *__restrict__ ka_ptr,
+                                              const double *__restrict__ kb_ptr, bool valid, int q, int l,
+                                              OffW offw, OffD offd, cplx *W, cplx *X,
+                                              double *KL) {
+#pragma clang fp contract(off)
+  constexpr int TPL = N / 16;
+  using Map = MapStrided<N>;
+
+  // ---- issue every early load: small ones first
+  cplx twv[(N + 255) / 256];
+  double klv[(N + 255) / 256];
+#pragma unroll
+  for (int j = 0; j < (N + 255) / 256; ++j) {
+    const int idx = threadIdx.x + j * 256;
+    twv[j] = idx < N ? tw[idx] : make_double2(0.0, 0.0);
+    klv[j] = idx < N ? kline[idx] : 0.0;
+  }
+  // Loads are unconditional (the caller clamps the offsets of out-of-range lanes to a valid element; their
+  // results are never stored): a branch around them would make hipcc's vmcnt bookkeeping fall back to vmcnt(0).
+  const double ka = *ka_ptr, kb = *kb_ptr;
+  cplx v[16], cp[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) v[m] = ldc(a.muhat, offw(m));
+#pragma unroll
+  for (int m = 0; m < 16; ++m) cp[m] = ldc(a.chat, offw(m));
+#pragma unroll
+  for (int j = 0; j < (N + 255) / 256; ++j) {
+    const int idx = threadIdx.x + j * 256;
+    if (idx < N) {
+      W[idx] = twv[j];
+      KL[idx] = klv[j];
+    }
+  }
+  const double ka2 = ka * ka, kb2 = kb * kb;
+
+  // ---- 1. mu-hat: forward transform (its first exchange publishes W and KL to the workgroup)
+  fft_line<N, Map>(v, q, l, X, W);
+
+  // ---- 2. Nhat = Mbar * mu-hat, Mbar = -k^2 * M
+  cplx Nv[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const double kl = KL[q + m * TPL];
+    const double k2 = LINE_IS_X ? (kl * kl + ka2) + kb2 : (ka2 + kl * kl) + kb2;
+    const double Mbar = -k2 * a.M;
+    Nv[m] = make_double2(Mbar * v[m].x, Mbar * v[m].y);
+  }
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) stc(a.Nnew, offd(m), Nv[m]);
+  }
+
+  // ---- first-order history: the first half of the old Nhat values is requested before the c-hat transform and
+  //      is in flight during it; the second half is requested right after it and lands while the first half is
+  //      combined (all 16 up front would push the kernel past 256 VGPRs = one wave per SIMD).
+  cplx o1[ORDER == 1 ? 8 : 1];
+  if (ORDER == 1) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) o1[ORDER == 1 ? m : 0] = ldc(a.Nold[0], offd(m));
+  }
+
+  // ---- 3. c-hat: forward transform
+  fft_line<N, Map>(cp, q, l, X, W);
+  if (a.cbar && valid) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) stc(a.cbar, offd(m), cp[m]);
+  }
+
+  // ---- 4. ubar = (cbar + (dt b0) N + sum (dt b_i) Nold_i) / (1 - dt*Lbar), the reference's association
+  //      (deeper histories: 8 points at a time; a run-time trip count here would make hipcc wait vmcnt(0) per element)
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    cplx o[ORDER > 0 ? ORDER : 1][8];
+#pragma unroll
+    for (int h = 0; h < ORDER; ++h) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (ORDER == 1 && half == 0)
+          o[h][j] = o1[ORDER == 1 ? j : 0];
+        else
+          o[h][j] = ldc(a.Nold[h], offd(half * 8 + j));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = half * 8 + j;
+      cplx u = cp[m];
+      u.x = u.x + a.coef[0] * Nv[m].x;
+      u.y = u.y + a.coef[0] * Nv[m].y;
+#pragma unroll
+      for (int h = 0; h < ORDER; ++h) {
+        u.x += a.coef[h + 1] * o[h][j].x;
+        u.y += a.coef[h + 1] * o[h][j].y;
+      }
+      const double kl = KL[q + m * TPL];
+      const double k2 = LINE_IS_X ? (kl * kl + ka2) + kb2 : (ka2 + kl * kl) + kb2;
+      const double Lb = k2 * k2 * a.kappa;
+      const double scl = 1.0 / (1.0 - a.dt * Lb);
+      v[m] = make_double2(u.y * scl, u.x * scl);  // swapped for the inverse transform
+    }
+  }
+
+  // ---- 5. inverse transform (unnormalised; 1/N applied by the final z pass)
+  fft_line<N, Map>(v, q, l, X, W);
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) stc(a.ubar, offw(m), cswap(v[m]));
+  }
+}
+
+}  // namespace p2
+}  // namespace mrl

@@ -194,5 +194,29 @@ __device__ __forceinline__ void load_twiddles(cplx *W, const cplx *__restrict__ 
   for (int i = threadIdx.x; i < N; i += 256) W[i] = tw[i];
 }
 
+// Twiddle staging split in two so that a kernel can issue the table loads BEFORE its operand loads (vmcnt
+// retires in order: the small L2-resident table loads must not queue behind a full HBM round trip) and
+// write them to LDS AFTER the operand loads are in flight.
+template <int N>
+struct TwRegs {
+  cplx v[(N + 255) / 256];
+};
+template <int N>
+__device__ __forceinline__ void tw_issue(TwRegs<N> &r, const cplx *__restrict__ tw) {
+#pragma unroll
+  for (int j = 0; j < (N + 255) / 256; ++j) {
+    const int idx = threadIdx.x + j * 256;
+    r.v[j] = idx < N ? tw[idx] : make_double2(0.0, 0.0);
+  }
+}
+template <int N>
+__device__ __forceinline__ void tw_commit(const TwRegs<N> &r, cplx *W) {
+#pragma unroll
+  for (int j = 0; j < (N + 255) / 256; ++j) {
+    const int idx = threadIdx.x + j * 256;
+    if (idx < N) W[idx] = r.v[j];
+  }
+}
+
 }  // namespace p2
 }  // namespace mrl

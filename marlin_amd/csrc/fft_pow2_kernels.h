@@ -37,7 +37,7 @@ __device__ __forceinline__ double mu_eval(const ChDev &p, double c) {
 //                            optionally writes mu to mu_out.
 // nlines = number of complex transforms.
 template <int N, int MODE, int FAM>
-__global__ void __launch_bounds__(256) k_z_fwd(const double *__restrict__ in, cplx *__restrict__ out0,
+__global__ void __launch_bounds__(256, 2) k_z_fwd(const double *__restrict__ in, cplx *__restrict__ out0,
                                                cplx *__restrict__ out1, double *__restrict__ mu_out, ChDev chp,
                                                long long nlines, const cplx *__restrict__ tw) {
   constexpr int TPL = N / 16, LPB = 4096 / N, NZC = N / 2 + 1;
@@ -48,11 +48,13 @@ __global__ void __launch_bounds__(256) k_z_fwd(const double *__restrict__ in, cp
   const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
   const long long L = (long long)blockIdx.x * LPB + l;
   const bool valid = L < nlines;
-  load_twiddles<N>(W, tw);
+  TwRegs<N> twr;
+  tw_issue<N>(twr, tw);
 
   cplx v[16];
-  const long long r0 = (MODE == 0) ? 2 * L : L;
-  if (valid) {
+  const long long Lc = valid ? L : 0;  // out-of-range lanes transform line 0 again and store nothing
+  const long long r0 = (MODE == 0) ? 2 * Lc : Lc;
+  {
     const double *p0 = in + r0 * N + q;
     double a[16], b[16];
 #pragma unroll
@@ -60,20 +62,19 @@ __global__ void __launch_bounds__(256) k_z_fwd(const double *__restrict__ in, cp
     if (MODE == 0) {
 #pragma unroll
       for (int m = 0; m < 16; ++m) b[m] = p0[N + m * TPL];
-    } else {
+    }
+    tw_commit<N>(twr, W);
+    if (MODE != 0) {
 #pragma unroll
       for (int m = 0; m < 16; ++m) b[m] = mu_eval<FAM>(chp, a[m]);
     }
 #pragma unroll
     for (int m = 0; m < 16; ++m) v[m] = make_double2(a[m], b[m]);
-    if (MODE == 1 && mu_out) {
+    if (MODE == 1 && mu_out && valid) {
       double *pm = mu_out + r0 * N + q;
 #pragma unroll
       for (int m = 0; m < 16; ++m) pm[m * TPL] = v[m].y;
     }
-  } else {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
   }
   fft_line<N, Map>(v, q, l, X, W);
   // natural-order copy in LDS for the k <-> N-k pairing
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(256) k_z_fwd(const double *__restrict__ in, cp
 // ---------------------------------------------------------------------------------------------
 // z inverse (PAIR): rows 2L, 2L+1 of the half spectrum `in` -> real rows 2L, 2L+1 of out, * scale.
 template <int N>
-__global__ void __launch_bounds__(256) k_z_inv(const cplx *__restrict__ in, double *__restrict__ out, double scale,
+__global__ void __launch_bounds__(256, 2) k_z_inv(const cplx *__restrict__ in, double *__restrict__ out, double scale,
                                                long long nlines, const cplx *__restrict__ tw) {
   constexpr int TPL = N / 16, LPB = 4096 / N, NZC = N / 2 + 1;
   using Map = MapLine<N>;
@@ -108,17 +109,27 @@ __global__ void __launch_bounds__(256) k_z_inv(const cplx *__restrict__ in, doub
   const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
   const long long L = (long long)blockIdx.x * LPB + l;
   const bool valid = L < nlines;
-  load_twiddles<N>(W, tw);
+  TwRegs<N> twr;
+  tw_issue<N>(twr, tw);
   cplx v[16];
-  if (valid) {
-    const cplx *A = in + (2 * L) * NZC;
+  {
+    const cplx *A = in + (2 * (valid ? L : 0)) * NZC;
     const cplx *B = A + NZC;
+    cplx av[16], bv[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int p = q + m * TPL;
+      const int k = (p <= N / 2) ? p : N - p;
+      av[m] = A[k];
+      bv[m] = B[k];
+    }
+    tw_commit<N>(twr, W);
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       const int p = q + m * TPL;
       const bool lo = p <= N / 2;
       const int k = lo ? p : N - p;
-      cplx a = A[k], b = B[k];
+      cplx a = av[m], b = bv[m];
       if (k == 0 || k == N / 2) {  // c2r ignores the imaginary part of the self-conjugate bins
         a.y = 0.0;
         b.y = 0.0;
@@ -127,9 +138,6 @@ __global__ void __launch_bounds__(256) k_z_inv(const cplx *__restrict__ in, doub
       const cplx x = lo ? make_double2(a.x - b.y, a.y + b.x) : make_double2(a.x + b.y, b.x - a.y);
       v[m] = cswap(x);
     }
-  } else {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
   }
   fft_line<N, Map>(v, q, l, X, W);
   if (!valid) return;
@@ -157,7 +165,7 @@ struct PassArgs {
 };
 
 template <int N, bool INV, int NF>
-__global__ void __launch_bounds__(256) k_pass(PassArgs a, const cplx *__restrict__ tw) {
+__global__ void __launch_bounds__(256, 2) k_pass(PassArgs a, const cplx *__restrict__ tw) {
   constexpr int TPL = N / 16, T = 4096 / N;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -168,26 +176,30 @@ __global__ void __launch_bounds__(256) k_pass(PassArgs a, const cplx *__restrict
   const long long o = logical / a.tiles_per_outer;
   const long long i = (long long)(logical % a.tiles_per_outer) * T + l;
   const bool valid = i < a.inner;
-  load_twiddles<N>(W, tw);
+  TwRegs<N> twr;
+  tw_issue<N>(twr, tw);
+  // all fields' operands are requested up front: field 1 is in flight while field 0 is transformed
+  // (unconditional loads from a clamped position: a branch here degrades hipcc's vmcnt counting to vmcnt(0))
+  const long long ic = valid ? i : 0;
+  cplx v[NF][16];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
-    cplx v[16];
-    if (valid) {
-      const cplx *p = a.in[f] + o * a.so_in + i + (long long)q * a.sn_in;
+    const cplx *p = a.in[f] + o * a.so_in + ic + (long long)q * a.sn_in;
 #pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const cplx x = p[(long long)m * TPL * a.sn_in];
-        v[m] = INV ? cswap(x) : x;
-      }
-    } else {
+    for (int m = 0; m < 16; ++m) v[f][m] = p[(long long)m * TPL * a.sn_in];
+  }
+  tw_commit<N>(twr, W);
 #pragma unroll
-      for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
+  for (int f = 0; f < NF; ++f) {
+    if (INV) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) v[f][m] = cswap(v[f][m]);
     }
-    fft_line<N, Map>(v, q, l, X, W);
+    fft_line<N, Map>(v[f], q, l, X, W);
     if (valid) {
       cplx *p = a.out[f] + o * a.so_out + i + (long long)q * a.sn_out;
 #pragma unroll
-      for (int m = 0; m < 16; ++m) p[(long long)m * TPL * a.sn_out] = INV ? cswap(v[m]) : v[m];
+      for (int m = 0; m < 16; ++m) p[(long long)m * TPL * a.sn_out] = INV ? cswap(v[f][m]) : v[f][m];
     }
   }
 }

@@ -11,6 +11,7 @@
 //   C  k_pass<x>        inverse x on the dense [nx][nyl][nzc] array that arrived
 //      k_z_inv          c2r along z, 1/N
 // (AdamsBashforthMoulton.C:60-101 with DomainAction::fftSlab/ifftSlab, DomainAction.C:869-1019.)
+#include "ch_fused_body.h"
 #include "fft_pow2_kernels.h"
 
 namespace mrl {
@@ -18,24 +19,16 @@ namespace mrl {
 namespace p2 {
 
 struct YFusedArgs {
-  const cplx *chat;   // received chunks of c-hat (after z,x passes)
-  const cplx *muhat;  // received chunks of mu-hat
-  cplx *ubar;         // out: chunks of the inverse-y-transformed ubar
-  cplx *Nnew;         // out: Mbar*mubar, dense [nxl][ny][nzc]
-  cplx *cbar;         // optional out: c-hat, dense
-  const cplx *Nold[4];
-  double coef[5];
+  FusedCommon c;      // chat/muhat/ubar in the exchange layout [p][nxl][nyl][nzc]; Nnew/cbar/Nold dense [nxl][ny][nzc]
   int nxl, nzc;
   int nyl_shift;      // log2(ny / P)
   long long chunk;    // nxl * nyl * nzc: elements of one chunk
   int tiles_per_x;
   const double *kx, *ky, *kz;  // local reciprocal axes
-  double M, kappa, dt;
 };
 
 template <int N, int ORDER>
-__global__ void __launch_bounds__(256) k_ch_yfused(YFusedArgs a, const cplx *__restrict__ tw) {
-#pragma clang fp contract(off)
+__global__ void __launch_bounds__(256, 2) k_ch_yfused(YFusedArgs a, const cplx *__restrict__ tw) {
   constexpr int TPL = N / 16, T = 4096 / N;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -45,99 +38,20 @@ __global__ void __launch_bounds__(256) k_ch_yfused(YFusedArgs a, const cplx *__r
   const int l = threadIdx.x % T, q = threadIdx.x / T;
   const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
   const int ix = logical / a.tiles_per_x;
-  const int kzi = (logical % a.tiles_per_x) * T + l;
-  const bool valid = kzi < a.nzc;
-  load_twiddles<N>(W, tw);
-  for (int j = threadIdx.x; j < N; j += 256) KY[j] = a.ky[j];
-
-  // element (ix, j, kz): chunked buffers  p*chunk + (ix*nyl + (j - p*nyl))*nzc + kz,  p = j >> nyl_shift
-  //                      dense buffers    (ix*N + j)*nzc + kz
-  const int nyl = 1 << a.nyl_shift;
-  long long offc[16], offd[16];
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
+  const int kz0 = (logical % a.tiles_per_x) * T + l;
+  const bool valid = kz0 < a.nzc;
+  const int kzi = valid ? kz0 : 0;
+  // element (ix, j, kz): exchange layout  p*chunk + (ix*nyl + (j - p*nyl))*nzc + kz,  p = j >> nyl_shift
+  //                      dense layout     (ix*N + j)*nzc + kz
+  const unsigned nzcB = (unsigned)a.nzc * 16u, chunkB = (unsigned)a.chunk * 16u, kzB = (unsigned)kzi * 16u;
+  const int sh = a.nyl_shift, msk = (1 << sh) - 1;
+  auto offc = [=](int m) {
     const int j = q + m * TPL;
-    const int p = j >> a.nyl_shift;
-    offc[m] = (long long)p * a.chunk + ((long long)ix * nyl + (j - (p << a.nyl_shift))) * a.nzc + kzi;
-    offd[m] = ((long long)ix * N + j) * a.nzc + kzi;
-  }
-
-  cplx v[16];
-  if (valid) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = a.muhat[offc[m]];
-  } else {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
-  }
-  fft_line<N, Map>(v, q, l, X, W);
-
-  double kx2 = 0.0, kz2 = 0.0;
-  if (valid) {
-    const double kx = a.kx[ix], kz = a.kz[kzi];
-    kx2 = kx * kx;
-    kz2 = kz * kz;
-  }
-  cplx Nv[16];
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    const double ky = KY[q + m * TPL];
-    const double k2 = kx2 + ky * ky + kz2;
-    const double Mbar = -k2 * a.M;
-    Nv[m] = make_double2(Mbar * v[m].x, Mbar * v[m].y);
-  }
-  if (valid) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) a.Nnew[offd[m]] = Nv[m];
-  }
-
-  if (valid) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = a.chat[offc[m]];
-  } else {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
-  }
-  fft_line<N, Map>(v, q, l, X, W);
-  if (a.cbar && valid) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) a.cbar[offd[m]] = v[m];
-  }
-
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    cplx o[ORDER > 0 ? ORDER : 1][8];
-    if (ORDER > 0) {
-#pragma unroll
-      for (int h = 0; h < ORDER; ++h) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[h][j] = valid ? a.Nold[h][offd[half * 8 + j]] : make_double2(0.0, 0.0);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int m = half * 8 + j;
-      cplx u = v[m];
-      u.x = u.x + a.coef[0] * Nv[m].x;
-      u.y = u.y + a.coef[0] * Nv[m].y;
-#pragma unroll
-      for (int h = 0; h < ORDER; ++h) {
-        u.x += a.coef[h + 1] * o[h][j].x;
-        u.y += a.coef[h + 1] * o[h][j].y;
-      }
-      const double ky = KY[q + m * TPL];
-      const double k2 = kx2 + ky * ky + kz2;
-      const double Lb = k2 * k2 * a.kappa;
-      const double scl = 1.0 / (1.0 - a.dt * Lb);
-      v[m] = make_double2(u.y * scl, u.x * scl);  // swapped for the inverse transform
-    }
-  }
-
-  fft_line<N, Map>(v, q, l, X, W);
-  if (valid) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) a.ubar[offc[m]] = cswap(v[m]);
-  }
+    return (unsigned)(j >> sh) * chunkB + (unsigned)((ix << sh) + (j & msk)) * nzcB + kzB;
+  };
+  const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + kzi) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
+  auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
+  ch_fused_body<N, ORDER, false>(a.c, tw, a.ky, a.kx + ix, a.kz + kzi, valid, q, l, offc, offd, W, X, KY);
 }
 
 template <class K>
@@ -295,13 +209,13 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, const double *recv, double 
   const long long nspec = nxl * ny * nzc;
   const long long nyl = ny / ctx->nranks;
   p2::YFusedArgs a{};
-  a.chat = reinterpret_cast<const cplx *>(recv);
-  a.muhat = a.chat + nspec;
-  a.ubar = reinterpret_cast<cplx *>(send);
-  a.Nnew = reinterpret_cast<cplx *>(Nhat_new);
-  a.cbar = reinterpret_cast<cplx *>(cbar);
-  for (int i = 0; i < order; ++i) a.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
-  for (int i = 0; i <= order; ++i) a.coef[i] = sub_dt * kBetaS[order][i];
+  a.c.chat = reinterpret_cast<const cplx *>(recv);
+  a.c.muhat = a.c.chat + nspec;
+  a.c.ubar = reinterpret_cast<cplx *>(send);
+  a.c.Nnew = reinterpret_cast<cplx *>(Nhat_new);
+  a.c.cbar = reinterpret_cast<cplx *>(cbar);
+  for (int i = 0; i < order; ++i) a.c.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
+  for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaS[order][i];
   a.nxl = (int)nxl;
   a.nzc = (int)nzc;
   a.nyl_shift = 0;
@@ -310,9 +224,9 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, const double *recv, double 
   a.kx = ctx->d_k[0];
   a.ky = ctx->d_k[1];
   a.kz = ctx->d_k[2];
-  a.M = cp.M;
-  a.kappa = cp.kappa;
-  a.dt = sub_dt;
+  a.c.M = cp.M;
+  a.c.kappa = cp.kappa;
+  a.c.dt = sub_dt;
   ProfScope ps(ctx, "slab_B_y_fused", (4.0 + order + (cbar ? 1.0 : 0.0)) * 16.0 * nspec);
   switch (order) {
     case 0: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 0>(ctx, a)))); break;
