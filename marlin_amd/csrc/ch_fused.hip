@@ -134,7 +134,7 @@ bool fast_path_ok(const mrl_ctx *ctx) {
 
 // strided pass along internal axis `a` (0 = x, 1 = y) of NF complex [nx][ny][nzc] arrays
 static int pass_axis(mrl_ctx *ctx, int axis, bool inv, int nf, const cplx *in0, const cplx *in1, cplx *out0,
-                     cplx *out1) {
+                     cplx *out1, bool reverse = false) {
   const long long nx = ctx->n[0], ny = ctx->n[1], nzc = ctx->nrec[2];
   p2::PassArgs a{};
   a.in[0] = in0;
@@ -142,6 +142,7 @@ static int pass_axis(mrl_ctx *ctx, int axis, bool inv, int nf, const cplx *in0, 
   a.out[0] = out0;
   a.out[1] = out1;
   a.scale = 1.0;
+  a.reverse = reverse ? 1 : 0;
   if (axis == 1) {
     a.inner = nzc;
     a.outer = nx;
@@ -249,7 +250,7 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
   }
   {
     ProfScope ps(ctx, "ch_B_y_fwd", 4.0 * h);
-    MRL_TRY(pass_axis(ctx, 1, false, 2, w_c, w_mu, w_c, w_mu));
+    MRL_TRY(pass_axis(ctx, 1, false, 2, w_c, w_mu, w_c, w_mu, true));
   }
   {
     ProfScope ps(ctx, "ch_C_x_fused", (4.0 + order + (cbar ? 1.0 : 0.0)) * h);

@@ -189,6 +189,15 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nb) {
   return (xcd < r8) ? xcd * (q8 + 1) + idx : r8 * (q8 + 1) + (xcd - r8) * q8 + idx;
 }
 
+// the same ranges walked in descending order: a consumer kernel that starts where its producer ended finds the
+// producer's last ~256 MB still in the Infinity Cache
+__device__ __forceinline__ unsigned xcd_remap_rev(unsigned b, unsigned nb) {
+  const unsigned q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, idx = b >> 3;
+  const unsigned len = q8 + (xcd < r8 ? 1u : 0u);
+  const unsigned start = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  return start + (len - 1 - idx);
+}
+
 template <int N>
 __device__ __forceinline__ void load_twiddles(cplx *W, const cplx *__restrict__ tw) {
   for (int i = threadIdx.x; i < N; i += 256) W[i] = tw[i];

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256, 2) k_z_fwd(const double *__restrict__ in,
   cplx *W = reinterpret_cast<cplx *>(smem);
   cplx *X = W + N;
   const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
-  const long long L = (long long)blockIdx.x * LPB + l;
+  const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
   const bool valid = L < nlines;
   TwRegs<N> twr;
   tw_issue<N>(twr, tw);
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256, 2) k_z_inv(const cplx *__restrict__ in, d
   cplx *W = reinterpret_cast<cplx *>(smem);
   cplx *X = W + N;
   const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
-  const long long L = (long long)blockIdx.x * LPB + l;
+  const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
   const bool valid = L < nlines;
   TwRegs<N> twr;
   tw_issue<N>(twr, tw);
@@ -162,6 +162,7 @@ struct PassArgs {
   long long sn_in, sn_out;   // stride between successive points of the axis
   int tiles_per_outer;
   double scale;
+  int reverse;  // traverse tiles in descending order: start where the producer kernel ended (Infinity Cache reuse)
 };
 
 template <int N, bool INV, int NF>
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(256, 2) k_pass(PassArgs a, const cplx *__restr
   cplx *W = reinterpret_cast<cplx *>(smem);
   cplx *X = W + N;
   const int l = threadIdx.x % T, q = threadIdx.x / T;
-  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned logical = a.reverse ? xcd_remap_rev(blockIdx.x, gridDim.x) : xcd_remap(blockIdx.x, gridDim.x);
   const long long o = logical / a.tiles_per_outer;
   const long long i = (long long)(logical % a.tiles_per_outer) * T + l;
   const bool valid = i < a.inner;

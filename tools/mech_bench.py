@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""de Geus RVE benchmark (BASELINE.json configs[2]): 3-D n^3, cubic inclusion
+phase[-s:, :s, -s:] = 1 with s = 9n/32 (test/src/tensor_computes/PhaseMechanicsTest.C:36-45), K = 0.833/8.33,
+mu = 0.386/3.86 (examples/degeus_mechanics/mech.i:23-38), shear ramp, l_tol = 1e-2, nl tolerances 2e-2.
+Reports time per CG iteration and the per-kernel device times.   usage: mech_bench.py [n] [substeps]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from marlin_amd.api import Context  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    substeps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    L = 2.0 * torch.pi
+    ctx = Context(3, [n, n, n], [L, L, L])
+    s = 9 * n // 32
+    phase = torch.zeros(n, n, n, dtype=torch.float64)
+    phase[-s:, :s, -s:] = 1.0
+    K = ((1.0 - phase) * 0.833 + phase * 8.33).cuda()
+    mu = ((1.0 - phase) * 0.386 + phase * 3.86).cuda()
+    F = torch.eye(3, dtype=torch.float64).expand(n, n, n, 3, 3).contiguous().cuda()
+    sub_dt = 0.01 / 10
+    res = []
+    for it in range(substeps + 1):
+        if it == 1:
+            ctx.set_profiling(True)
+        t = it * sub_dt
+        applied = torch.eye(3, dtype=torch.float64)
+        applied[0, 1] += t
+        applied = (applied - ctx.average(F)).cuda()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        Fnew, P, st = ctx.mech_newton_cg(F, K, mu, applied, l_tol=1e-2, nl_rel_tol=2e-2, nl_abs_tol=2e-2)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        F = Fnew
+        if it >= 1:
+            res.append((dt, st["cg_its_total"], st["newton_its"]))
+    prof = [k for k in ctx.get_profile() if k["launches"]]
+    tot_its = sum(r[1] for r in res)
+    tot_t = sum(r[0] for r in res)
+    npts = n ** 3
+    # 2*9*B_fft(n) + 232 + 504 bytes per point per CG iteration
+    h = 8.0 * (1.0 + 2.0 / n)
+    bpi = 2 * 9 * (8.0 + 5.0 * h) + 232 + 504
+    out = {"n": n, "substeps": substeps, "newton_its": [r[2] for r in res], "cg_its": [r[1] for r in res],
+           "ms_per_cg_iteration": tot_t / max(tot_its, 1) * 1e3,
+           "algorithmic_bytes_per_point_per_cg_iteration": bpi,
+           "achieved_GBps": bpi * npts * tot_its / tot_t / 1e9,
+           "kernels": sorted([{"kernel": k["kernel"], "total_ms": round(k["ms"], 3), "launches": k["launches"],
+                               "avg_ms": round(k["ms"] / k["launches"], 4),
+                               "GBps": round(k["bytes_per_launch"] / (k["ms"] / k["launches"]) / 1e6, 1)} for k in prof],
+                             key=lambda k: -k["total_ms"])}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
