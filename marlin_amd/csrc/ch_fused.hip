@@ -9,7 +9,7 @@
 //   Forward order z,y,x and inverse order x,y,z: the fused pass runs along x because its tiles are
 //   contiguous in (y,kz) jointly, so the user-visible Nhat arrays are accessed in aligned 256-B pieces.
 #include "ch_fused_body.h"
-#include "fft_pow2_kernels.h"
+#include "fft_pow2_launch.h"
 
 namespace mrl {
 
@@ -41,64 +41,6 @@ __global__ void __launch_bounds__(256, 2) k_ch_xfused(FusedArgs a, const cplx *_
   ch_fused_body<N, ORDER, true>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, W, X, KX);
 }
 
-template <class K>
-static int set_lds_attr(mrl_ctx *ctx, K kernel, size_t lds) {
-  if (lds > 64 * 1024) {
-    MRL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
-  }
-  return MRL_OK;
-}
-
-template <int N, int MODE, int FAM>
-static int launch_z_fwd(mrl_ctx *ctx, const double *in, cplx *o0, cplx *o1, double *mu, const ChDev &chp,
-                        long long nlines) {
-  static bool attr = false;
-  constexpr size_t lds = lds_line<N>();
-  if (!attr) {
-    MRL_TRY(set_lds_attr(ctx, k_z_fwd<N, MODE, FAM>, lds));
-    attr = true;
-  }
-  constexpr int LPB = 4096 / N;
-  const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_fwd<N, MODE, FAM>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, o0, o1, mu, chp, nlines,
-                     ctx->ax[2].d_tw);
-  MRL_HIP(ctx, hipGetLastError());
-  return MRL_OK;
-}
-
-template <int N>
-static int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale, long long nlines) {
-  static bool attr = false;
-  constexpr size_t lds = lds_line<N>();
-  if (!attr) {
-    MRL_TRY(set_lds_attr(ctx, k_z_inv<N>, lds));
-    attr = true;
-  }
-  constexpr int LPB = 4096 / N;
-  const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_inv<N>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, out, scale, nlines,
-                     ctx->ax[2].d_tw);
-  MRL_HIP(ctx, hipGetLastError());
-  return MRL_OK;
-}
-
-template <int N, bool INV, int NF>
-static int launch_pass_t(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
-  static bool attr = false;
-  constexpr size_t lds = lds_strided<N>();
-  if (!attr) {
-    MRL_TRY(set_lds_attr(ctx, k_pass<N, INV, NF>, lds));
-    attr = true;
-  }
-  constexpr int T = 4096 / N;
-  a.tiles_per_outer = (int)((a.inner + T - 1) / T);
-  const long long nb = a.outer * a.tiles_per_outer;
-  hipLaunchKernelGGL((k_pass<N, INV, NF>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, tw);
-  MRL_HIP(ctx, hipGetLastError());
-  return MRL_OK;
-}
-
 template <int N, int ORDER>
 static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a) {
   static bool attr = false;
@@ -115,17 +57,6 @@ static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a) {
 }
 
 }  // namespace p2
-
-#define MRL_SWITCH_N(n, CALL)  \
-  switch (n) {                 \
-    case 64: { constexpr int NN = 64; CALL; } break;   \
-    case 128: { constexpr int NN = 128; CALL; } break; \
-    case 256: { constexpr int NN = 256; CALL; } break; \
-    case 512: { constexpr int NN = 512; CALL; } break; \
-    default: return MRL_ERR_UNSUPPORTED;               \
-  }
-
-static bool pow2_ok(long long n) { return n == 64 || n == 128 || n == 256 || n == 512; }
 
 bool fast_path_ok(const mrl_ctx *ctx) {
   return ctx->dim == 3 && ctx->nranks == 1 && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
@@ -221,14 +152,6 @@ int fft_inverse_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long 
   return MRL_OK;
 }
 
-static const double kBetaF[5][5] = {
-    {1.0, 0.0, 0.0, 0.0, 0.0},
-    {3.0 / 2.0, -1.0 / 2.0, 0.0, 0.0, 0.0},
-    {23.0 / 12.0, -16.0 / 12.0, 5.0 / 12.0, 0.0, 0.0},
-    {55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -9.0 / 24.0, 0.0},
-    {190.0 / 720.0, -2774.0 / 720.0, 2616.0 / 720.0, -1274.0 / 720.0, 251.0 / 720.0},
-};
-
 int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new,
                      const double *const *Nhat_old, int order, double sub_dt, double *cbar, double *mu) {
   if (!fast_path_ok(ctx)) return MRL_ERR_UNSUPPORTED;
@@ -261,7 +184,7 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
     a.c.Nnew = reinterpret_cast<cplx *>(Nhat_new);
     a.c.cbar = reinterpret_cast<cplx *>(cbar);
     for (int i = 0; i < order; ++i) a.c.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
-    for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaF[order][i];
+    for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaAB[order][i];
     a.inner = ny * nzc;
     a.nzc = (int)nzc;
     a.kx = ctx->d_k[0];

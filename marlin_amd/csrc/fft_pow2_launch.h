@@ -1,0 +1,89 @@
+// Host-side launchers of the power-of-two kernels, shared by ch_fused.hip, slab_fused.hip and mech_fused.hip.
+#pragma once
+#include "fft_pow2_kernels.h"
+
+namespace mrl {
+namespace p2 {
+
+template <class K>
+inline int set_lds_attr(mrl_ctx *ctx, K kernel, size_t lds) {
+  if (lds > 64 * 1024) {
+    MRL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+  }
+  return MRL_OK;
+}
+
+// nlines = number of complex transforms (MODE 0: pairs of real lines; MODE 1: one CH line each)
+template <int N, int MODE, int FAM>
+inline int launch_z_fwd(mrl_ctx *ctx, const double *in, cplx *o0, cplx *o1, double *mu, const ChDev &chp,
+                        long long nlines) {
+  static bool attr = false;
+  constexpr size_t lds = lds_line<N>();
+  if (!attr) {
+    MRL_TRY(set_lds_attr(ctx, k_z_fwd<N, MODE, FAM>, lds));
+    attr = true;
+  }
+  constexpr int LPB = 4096 / N;
+  const long long nb = (nlines + LPB - 1) / LPB;
+  hipLaunchKernelGGL((k_z_fwd<N, MODE, FAM>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, o0, o1, mu, chp, nlines,
+                     ctx->ax[2].d_tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+template <int N>
+inline int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale, long long nlines) {
+  static bool attr = false;
+  constexpr size_t lds = lds_line<N>();
+  if (!attr) {
+    MRL_TRY(set_lds_attr(ctx, k_z_inv<N>, lds));
+    attr = true;
+  }
+  constexpr int LPB = 4096 / N;
+  const long long nb = (nlines + LPB - 1) / LPB;
+  hipLaunchKernelGGL((k_z_inv<N>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, out, scale, nlines,
+                     ctx->ax[2].d_tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+template <int N, bool INV, int NF>
+inline int launch_pass_t(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
+  static bool attr = false;
+  constexpr size_t lds = lds_strided<N>();
+  if (!attr) {
+    MRL_TRY(set_lds_attr(ctx, k_pass<N, INV, NF>, lds));
+    attr = true;
+  }
+  constexpr int T = 4096 / N;
+  a.tiles_per_outer = (int)((a.inner + T - 1) / T);
+  const long long nb = a.outer * a.tiles_per_outer;
+  hipLaunchKernelGGL((k_pass<N, INV, NF>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+}  // namespace p2
+
+#define MRL_SWITCH_N(n, CALL)  \
+  switch (n) {                 \
+    case 64: { constexpr int NN = 64; CALL; } break;   \
+    case 128: { constexpr int NN = 128; CALL; } break; \
+    case 256: { constexpr int NN = 256; CALL; } break; \
+    case 512: { constexpr int NN = 512; CALL; } break; \
+    default: return MRL_ERR_UNSUPPORTED;               \
+  }
+
+inline bool pow2_ok(long long n) { return n == 64 || n == 128 || n == 256 || n == 512; }
+
+// Adams-Bashforth coefficients (src/tensor_solver/AdamsBashforthMoulton.C:67-73, incl. the AB5 190/720 entry)
+static const double kBetaAB[5][5] = {
+    {1.0, 0.0, 0.0, 0.0, 0.0},
+    {3.0 / 2.0, -1.0 / 2.0, 0.0, 0.0, 0.0},
+    {23.0 / 12.0, -16.0 / 12.0, 5.0 / 12.0, 0.0, 0.0},
+    {55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -9.0 / 24.0, 0.0},
+    {190.0 / 720.0, -2774.0 / 720.0, 2616.0 / 720.0, -1274.0 / 720.0, 251.0 / 720.0},
+};
+
+}  // namespace mrl

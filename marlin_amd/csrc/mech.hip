@@ -22,22 +22,28 @@ struct Mat {
   double a[D][D];
 };
 
-template <int D>
-__device__ __forceinline__ Mat<D> load_mat(const double *p) {
+// tensor of grid point p: value-major (reference layout) base[p*D*D + c] or field-major base[c*npts + p]
+template <int D, bool SOA>
+__device__ __forceinline__ Mat<D> load_mat(const double *base, long long p, long long npts) {
   Mat<D> m;
 #pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
-    for (int j = 0; j < D; ++j) m.a[i][j] = p[i * D + j];
+    for (int j = 0; j < D; ++j) m.a[i][j] = SOA ? base[(long long)(i * D + j) * npts + p] : base[p * D * D + i * D + j];
   return m;
 }
 
-template <int D>
-__device__ __forceinline__ void store_mat(double *p, const Mat<D> &m) {
+template <int D, bool SOA>
+__device__ __forceinline__ void store_mat(double *base, long long p, long long npts, const Mat<D> &m) {
 #pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
-    for (int j = 0; j < D; ++j) p[i * D + j] = m.a[i][j];
+    for (int j = 0; j < D; ++j) {
+      if (SOA)
+        base[(long long)(i * D + j) * npts + p] = m.a[i][j];
+      else
+        base[p * D * D + i * D + j] = m.a[i][j];
+    }
 }
 
 // second Piola-Kirchhoff stress S = C4 : (F^T F - I)/2
@@ -68,12 +74,12 @@ __device__ __forceinline__ Mat<D> svk_S(const Mat<D> &F, double K, double mu) {
   return S;
 }
 
-template <int D>
+template <int D, bool SOA>
 __global__ void __launch_bounds__(256) k_mech_stress(const double *__restrict__ F, const double *__restrict__ K,
                                                       const double *__restrict__ mu, double *__restrict__ P,
                                                       long long npts) {
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npts; p += (long long)gridDim.x * 256) {
-    const Mat<D> f = load_mat<D>(F + p * D * D);
+    const Mat<D> f = load_mat<D, SOA>(F, p, npts);
     const Mat<D> S = svk_S<D>(f, K[p], mu[p]);
     Mat<D> o;
 #pragma unroll
@@ -85,18 +91,18 @@ __global__ void __launch_bounds__(256) k_mech_stress(const double *__restrict__ 
         for (int k = 0; k < D; ++k) s += f.a[i][k] * S.a[k][j];
         o.a[i][j] = s;
       }
-    store_mat<D>(P + p * D * D, o);
+    store_mat<D, SOA>(P, p, npts, o);
   }
 }
 
-// out = dF.S + F.Y ; dF_stride = D*D (field) or 0 (one tensor broadcast over the grid)
-template <int D>
+// out = dF.S + F.Y ; bcast: dF is ONE tensor (D*D doubles) broadcast over the grid
+template <int D, bool SOA>
 __global__ void __launch_bounds__(256) k_mech_tangent(const double *__restrict__ F, const double *__restrict__ K,
                                                        const double *__restrict__ mu, const double *__restrict__ dF,
-                                                       long long dF_stride, double *__restrict__ out, long long npts) {
+                                                       int bcast, double *__restrict__ out, long long npts) {
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npts; p += (long long)gridDim.x * 256) {
-    const Mat<D> f = load_mat<D>(F + p * D * D);
-    const Mat<D> d = load_mat<D>(dF + p * dF_stride);
+    const Mat<D> f = load_mat<D, SOA>(F, p, npts);
+    const Mat<D> d = bcast ? load_mat<D, false>(dF, 0, 1) : load_mat<D, SOA>(dF, p, npts);
     const double Kp = K[p], mup = mu[p];
     const Mat<D> S = svk_S<D>(f, Kp, mup);
     Mat<D> W;
@@ -131,7 +137,7 @@ __global__ void __launch_bounds__(256) k_mech_tangent(const double *__restrict__
         for (int k = 0; k < D; ++k) s += d.a[i][k] * S.a[k][j] + f.a[i][k] * Y.a[k][j];
         o.a[i][j] = s;
       }
-    store_mat<D>(out + p * D * D, o);
+    store_mat<D, SOA>(out, p, npts, o);
   }
 }
 
@@ -220,11 +226,28 @@ __global__ void __launch_bounds__(256) k_cg_dir(const double *__restrict__ S, in
     p[i] = r[i] + beta * p[i];
 }
 
-// y[i] += x[i % period_or_n]   (period = D*D broadcasts one tensor over the grid)
+// y[i] += x[i]                       (period = 0, block = 0)
+// y[i] += x[i % period]              (value-major broadcast of one tensor, period = D*D)
+// y[i] += x[i / block]               (field-major broadcast, block = number of grid points)
 __global__ void __launch_bounds__(256) k_add(double *__restrict__ y, const double *__restrict__ x, long long n,
-                                              long long period) {
+                                              long long period, long long block) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-    y[i] = y[i] + x[period ? i % period : i];
+    y[i] = y[i] + x[block ? i / block : (period ? i % period : i)];
+}
+
+// value-major [npts][dd] <-> field-major [dd][npts]
+template <bool TO_SOA>
+__global__ void __launch_bounds__(256) k_relayout(const double *__restrict__ in, double *__restrict__ out, long long npts,
+                                                   int dd) {
+  const long long n = npts * dd;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    // i indexes the field-major array (coalesced on that side)
+    const long long c = i / npts, p = i - c * npts;
+    if (TO_SOA)
+      out[i] = in[p * dd + c];
+    else
+      out[p * dd + c] = in[i];
+  }
 }
 
 static inline int grid_for(long long n) {
@@ -243,33 +266,52 @@ static int check_dim(mrl_ctx *ctx, const char *what) {
   return MRL_OK;
 }
 
-int stress_launch(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *P) {
+bool mech_fast_ok(const mrl_ctx *ctx);
+int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale);
+
+int stress_launch(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *P, bool soa) {
   const long long npts = real_count_local(ctx);
   ProfScope ps(ctx, "mech_stress", (double)npts * 8.0 * (2 * ctx->dim * ctx->dim + 2));
-  if (ctx->dim == 3)
-    hipLaunchKernelGGL(k_mech_stress<3>, dim3(grid_for(npts)), dim3(256), 0, ctx->stream, F, K, mu, P, npts);
+  const dim3 g(grid_for(npts)), b(256);
+  if (ctx->dim == 3 && soa)
+    hipLaunchKernelGGL((k_mech_stress<3, true>), g, b, 0, ctx->stream, F, K, mu, P, npts);
+  else if (ctx->dim == 3)
+    hipLaunchKernelGGL((k_mech_stress<3, false>), g, b, 0, ctx->stream, F, K, mu, P, npts);
   else
-    hipLaunchKernelGGL(k_mech_stress<2>, dim3(grid_for(npts)), dim3(256), 0, ctx->stream, F, K, mu, P, npts);
+    hipLaunchKernelGGL((k_mech_stress<2, false>), g, b, 0, ctx->stream, F, K, mu, P, npts);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
 
 int tangent_launch(mrl_ctx *ctx, const double *F, const double *K, const double *mu, const double *dF, bool bcast,
-                   double *out) {
+                   double *out, bool soa) {
   const long long npts = real_count_local(ctx);
   const int dd = ctx->dim * ctx->dim;
   ProfScope ps(ctx, "mech_tangent", (double)npts * 8.0 * ((bcast ? 2 : 3) * dd + 2));
-  if (ctx->dim == 3)
-    hipLaunchKernelGGL(k_mech_tangent<3>, dim3(grid_for(npts)), dim3(256), 0, ctx->stream, F, K, mu, dF,
-                       (long long)(bcast ? 0 : dd), out, npts);
+  const dim3 g(grid_for(npts)), b(256);
+  if (ctx->dim == 3 && soa)
+    hipLaunchKernelGGL((k_mech_tangent<3, true>), g, b, 0, ctx->stream, F, K, mu, dF, bcast ? 1 : 0, out, npts);
+  else if (ctx->dim == 3)
+    hipLaunchKernelGGL((k_mech_tangent<3, false>), g, b, 0, ctx->stream, F, K, mu, dF, bcast ? 1 : 0, out, npts);
   else
-    hipLaunchKernelGGL(k_mech_tangent<2>, dim3(grid_for(npts)), dim3(256), 0, ctx->stream, F, K, mu, dF,
-                       (long long)(bcast ? 0 : dd), out, npts);
+    hipLaunchKernelGGL((k_mech_tangent<2, false>), g, b, 0, ctx->stream, F, K, mu, dF, bcast ? 1 : 0, out, npts);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
 
-// out = scale * G(A)
+int relayout_launch(mrl_ctx *ctx, bool to_soa, const double *in, double *out) {
+  const long long npts = real_count_local(ctx);
+  const int dd = ctx->dim * ctx->dim;
+  ProfScope ps(ctx, to_soa ? "mech_to_field_major" : "mech_to_value_major", 16.0 * npts * dd);
+  if (to_soa)
+    hipLaunchKernelGGL(k_relayout<true>, dim3(grid_for(npts * dd)), dim3(256), 0, ctx->stream, in, out, npts, dd);
+  else
+    hipLaunchKernelGGL(k_relayout<false>, dim3(grid_for(npts * dd)), dim3(256), 0, ctx->stream, in, out, npts, dd);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+// out = scale * G(A), value-major fields through the generic batched transforms
 int gamma_launch(mrl_ctx *ctx, const double *A, double *out, double scale) {
   const int dd = ctx->dim * ctx->dim;
   const long long nspec = spec_count_local(ctx);
@@ -300,6 +342,14 @@ int mrl_gamma_apply(mrl_ctx *ctx, const double *d_A, double *d_out) {
   if (!ctx) return MRL_ERR_INVALID;
   MRL_TRY(check_dim(ctx, "mrl_gamma_apply"));
   if (!d_A || !d_out) return set_error(ctx, MRL_ERR_INVALID, "mrl_gamma_apply: null buffer");
+  if (mech_fast_ok(ctx)) {
+    // the fused kernels work on field-major data: convert at this (value-major) boundary
+    const size_t vb = sizeof(double) * (size_t)(real_count_local(ctx) * 9 + 2);
+    MRL_TRY(ensure_work(ctx, 9, vb));
+    MRL_TRY(relayout_launch(ctx, true, d_A, ctx->d_work[9]));
+    MRL_TRY(gamma_fast(ctx, ctx->d_work[9], ctx->d_work[9], 1.0));
+    return relayout_launch(ctx, false, ctx->d_work[9], d_out);
+  }
   return gamma_launch(ctx, d_A, d_out, 1.0);
 }
 
@@ -307,7 +357,7 @@ int mrl_mech_stress(mrl_ctx *ctx, const double *d_F, const double *d_K, const do
   if (!ctx) return MRL_ERR_INVALID;
   MRL_TRY(check_dim(ctx, "mrl_mech_stress"));
   if (!d_F || !d_K || !d_mu || !d_P) return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_stress: null buffer");
-  return stress_launch(ctx, d_F, d_K, d_mu, d_P);
+  return stress_launch(ctx, d_F, d_K, d_mu, d_P, false);
 }
 
 int mrl_mech_tangent_apply(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu,
@@ -316,7 +366,7 @@ int mrl_mech_tangent_apply(mrl_ctx *ctx, const double *d_F, const double *d_K, c
   MRL_TRY(check_dim(ctx, "mrl_mech_tangent_apply"));
   if (!d_F || !d_K || !d_mu || !d_dF || !d_out)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_tangent_apply: null buffer");
-  return tangent_launch(ctx, d_F, d_K, d_mu, d_dF, false, d_out);
+  return tangent_launch(ctx, d_F, d_K, d_mu, d_dF, false, d_out, false);
 }
 
 int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d_F, const double *d_K,
@@ -334,6 +384,20 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
   for (int s = 5; s <= 10; ++s) MRL_TRY(ensure_work(ctx, s, vb));
   double *b = ctx->d_work[5], *r = ctx->d_work[6], *p = ctx->d_work[7], *Ap = ctx->d_work[8], *tmp = ctx->d_work[9],
          *x = ctx->d_work[10];
+  // Fast-path shapes run the whole solve on field-major vectors [9][grid] (coalesced streams for every kernel);
+  // the caller's value-major F is converted once on entry, Fnew and P once on exit.
+  const bool soa = mech_fast_ok(ctx);
+  double *Fin = nullptr, *Fwork = d_Fnew, *Pwork = d_P;
+  if (soa) {
+    for (int s = 11; s <= 13; ++s) MRL_TRY(ensure_work(ctx, s, vb));
+    Fin = ctx->d_work[11];
+    Fwork = ctx->d_work[12];
+    Pwork = ctx->d_work[13];
+    MRL_TRY(relayout_launch(ctx, true, d_F, Fin));
+  }
+  auto gamma = [&](const double *A, double *out, double scale) -> int {
+    return soa ? gamma_fast(ctx, A, out, scale) : gamma_launch(ctx, A, out, scale);
+  };
   double *S = ctx->d_red + kScalarBase + 32;  // device scalars: [0],[2] r.r ping-pong, [1] p.Ap, [3] scratch
   const int nb = grid_for(n);
   const long long l_max_its = prm->l_max_its > 0 ? prm->l_max_its : ctx->n[0] * ctx->n[1] * ctx->n[2];
@@ -341,25 +405,26 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
   double h[4];
 
   // _u = _tF ; constitutive at F (the tangent of the first linear solve stays linearised at F)
-  MRL_HIP(ctx, hipMemcpyAsync(d_Fnew, d_F, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
-  const double *lin = d_F;
+  const double *lin = soa ? Fin : d_F;
+  MRL_HIP(ctx, hipMemcpyAsync(Fwork, lin, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
   // b = -G_K_dF(applied.expand) | -G_K_dF(0)                              FFTMechanics.C:116-117
   if (d_applied) {
-    MRL_TRY(tangent_launch(ctx, lin, d_K, d_mu, d_applied, true, tmp));
-    MRL_TRY(gamma_launch(ctx, tmp, b, -1.0));
-    hipLaunchKernelGGL(k_add, dim3(nb), dim3(256), 0, ctx->stream, d_Fnew, d_applied, n, (long long)dd);  // :120-121
+    MRL_TRY(tangent_launch(ctx, lin, d_K, d_mu, d_applied, true, tmp, soa));
+    MRL_TRY(gamma(tmp, b, -1.0));
+    hipLaunchKernelGGL(k_add, dim3(nb), dim3(256), 0, ctx->stream, Fwork, d_applied, n, soa ? 0LL : (long long)dd,
+                       soa ? npts : 0LL);  // :120-121
   } else {
     MRL_HIP(ctx, hipMemsetAsync(b, 0, sizeof(double) * n, ctx->stream));
   }
-  MRL_TRY(reduce_async(ctx, 2, d_Fnew, d_Fnew, n, S + 3));
+  MRL_TRY(reduce_async(ctx, 2, Fwork, Fwork, n, S + 3));
   MRL_TRY(read_scalars(ctx, S + 3, 1, h));
   const double Fn = sqrt(h[0]);  // :123-124
   st.Fn = Fn;
   MRL_HIP(ctx, hipMemsetAsync(x, 0, sizeof(double) * n, ctx->stream));  // dFm = zeros_like(b)
 
   auto apply_A = [&](const double *v, double *out) -> int {  // G_K_dF
-    MRL_TRY(tangent_launch(ctx, lin, d_K, d_mu, v, false, tmp));
-    return gamma_launch(ctx, tmp, out, 1.0);
+    MRL_TRY(tangent_launch(ctx, lin, d_K, d_mu, v, false, tmp, soa));
+    return gamma(tmp, out, 1.0);
   };
 
   int iiter = 0;
@@ -378,16 +443,25 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
       its = (int)l_max_its;
       for (long long k = 0; k < l_max_its; ++k) {
         MRL_TRY(apply_A(p, Ap));
-        MRL_TRY(reduce_async(ctx, 1, p, Ap, n, S + 1));
-        hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
-        MRL_TRY(reduce_finalize(ctx, nb, 1, S + i_new));
+        {
+          ProfScope ps(ctx, "cg_dot_pAp", 16.0 * n);
+          MRL_TRY(reduce_async(ctx, 1, p, Ap, n, S + 1));
+        }
+        {
+          ProfScope ps(ctx, "cg_update_x_r", 48.0 * n);
+          hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
+          MRL_TRY(reduce_finalize(ctx, nb, 1, S + i_new));
+        }
         MRL_TRY(read_scalars(ctx, S + i_new, 1, h));  // the one host sync of the iteration
         res_norm = sqrt(h[0]);
         if (res_norm <= prm->l_tol * b_norm) {
           its = (int)k + 1;
           break;
         }
-        hipLaunchKernelGGL(k_cg_dir, dim3(nb), dim3(256), 0, ctx->stream, S, i_new, i_old, r, p, n);
+        {
+          ProfScope ps(ctx, "cg_direction", 24.0 * n);
+          hipLaunchKernelGGL(k_cg_dir, dim3(nb), dim3(256), 0, ctx->stream, S, i_new, i_old, r, p, n);
+        }
         const int t = i_old;
         i_old = i_new;
         i_new = t;
@@ -398,10 +472,10 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
     st.newton_its += 1;
 
     // _u = _u + dFm ; constitutive ; b = -G(P)                              FFTMechanics.C:137-143
-    hipLaunchKernelGGL(k_add, dim3(nb), dim3(256), 0, ctx->stream, d_Fnew, x, n, 0LL);
-    lin = d_Fnew;
-    MRL_TRY(stress_launch(ctx, d_Fnew, d_K, d_mu, d_P));
-    MRL_TRY(gamma_launch(ctx, d_P, b, -1.0));
+    hipLaunchKernelGGL(k_add, dim3(nb), dim3(256), 0, ctx->stream, Fwork, x, n, 0LL, 0LL);
+    lin = Fwork;
+    MRL_TRY(stress_launch(ctx, Fwork, d_K, d_mu, Pwork, soa));
+    MRL_TRY(gamma(Pwork, b, -1.0));
     MRL_TRY(reduce_async(ctx, 2, x, x, n, S + 3));
     MRL_TRY(read_scalars(ctx, S + 3, 1, h));
     const double anorm = sqrt(h[0]);
@@ -412,9 +486,17 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
     iiter++;
     if (iiter > prm->nl_max_its) {
       if (stats) *stats = st;
+      if (soa) {
+        relayout_launch(ctx, false, Fwork, d_Fnew);
+        relayout_launch(ctx, false, Pwork, d_P);
+      }
       return set_error(ctx, MRL_ERR_NOT_CONVERGED,
                        "Exceeded the maximum number of nonlinear iterations without converging.");
     }
+  }
+  if (soa) {
+    MRL_TRY(relayout_launch(ctx, false, Fwork, d_Fnew));
+    MRL_TRY(relayout_launch(ctx, false, Pwork, d_P));
   }
   if (stats) *stats = st;
   return MRL_OK;

@@ -12,7 +12,7 @@
 //      k_z_inv          c2r along z, 1/N
 // (AdamsBashforthMoulton.C:60-101 with DomainAction::fftSlab/ifftSlab, DomainAction.C:869-1019.)
 #include "ch_fused_body.h"
-#include "fft_pow2_kernels.h"
+#include "fft_pow2_launch.h"
 
 namespace mrl {
 
@@ -54,69 +54,12 @@ __global__ void __launch_bounds__(256, 2) k_ch_yfused(YFusedArgs a, const cplx *
   ch_fused_body<N, ORDER, false>(a.c, tw, a.ky, a.kx + ix, a.kz + kzi, valid, q, l, offc, offd, W, X, KY);
 }
 
-template <class K>
-static int set_lds(mrl_ctx *ctx, K kernel, size_t lds) {
-  if (lds > 64 * 1024)
-    MRL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
-  return MRL_OK;
-}
-
-template <int N, int FAM>
-static int launch_z_fwd_ch(mrl_ctx *ctx, const double *in, cplx *o0, cplx *o1, double *mu, const ChDev &chp,
-                           long long nlines) {
-  static bool attr = false;
-  constexpr size_t lds = lds_line<N>();
-  if (!attr) {
-    MRL_TRY(set_lds(ctx, k_z_fwd<N, 1, FAM>, lds));
-    attr = true;
-  }
-  constexpr int LPB = 4096 / N;
-  const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_fwd<N, 1, FAM>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, o0, o1, mu, chp, nlines,
-                     ctx->ax[2].d_tw);
-  MRL_HIP(ctx, hipGetLastError());
-  return MRL_OK;
-}
-
-template <int N>
-static int launch_z_inv_s(mrl_ctx *ctx, const cplx *in, double *out, double scale, long long nlines) {
-  static bool attr = false;
-  constexpr size_t lds = lds_line<N>();
-  if (!attr) {
-    MRL_TRY(set_lds(ctx, k_z_inv<N>, lds));
-    attr = true;
-  }
-  constexpr int LPB = 4096 / N;
-  const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_inv<N>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, out, scale, nlines,
-                     ctx->ax[2].d_tw);
-  MRL_HIP(ctx, hipGetLastError());
-  return MRL_OK;
-}
-
-template <int N, bool INV>
-static int launch_xpass(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
-  static bool attr = false;
-  constexpr size_t lds = lds_strided<N>();
-  if (!attr) {
-    MRL_TRY(set_lds(ctx, k_pass<N, INV, 1>, lds));
-    attr = true;
-  }
-  constexpr int T = 4096 / N;
-  a.tiles_per_outer = (int)((a.inner + T - 1) / T);
-  const long long nb = a.outer * a.tiles_per_outer;
-  hipLaunchKernelGGL((k_pass<N, INV, 1>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, tw);
-  MRL_HIP(ctx, hipGetLastError());
-  return MRL_OK;
-}
-
 template <int N, int ORDER>
 static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
   if (!attr) {
-    MRL_TRY(set_lds(ctx, k_ch_yfused<N, ORDER>, lds));
+    MRL_TRY(set_lds_attr(ctx, k_ch_yfused<N, ORDER>, lds));
     attr = true;
   }
   constexpr int T = 4096 / N;
@@ -128,17 +71,6 @@ static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
 }
 
 }  // namespace p2
-
-#define MRL_SWITCH_N(n, CALL)  \
-  switch (n) {                 \
-    case 64: { constexpr int NN = 64; CALL; } break;   \
-    case 128: { constexpr int NN = 128; CALL; } break; \
-    case 256: { constexpr int NN = 256; CALL; } break; \
-    case 512: { constexpr int NN = 512; CALL; } break; \
-    default: return MRL_ERR_UNSUPPORTED;               \
-  }
-
-static bool pow2_ok(long long n) { return n == 64 || n == 128 || n == 256 || n == 512; }
 
 int slab_fast_ok(const mrl_ctx *ctx) {
   if (!(ctx->dim == 3 && ctx->nranks > 1 && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
@@ -152,14 +84,6 @@ int slab_fast_ok(const mrl_ctx *ctx) {
   return 1;
 }
 
-static const double kBetaS[5][5] = {
-    {1.0, 0.0, 0.0, 0.0, 0.0},
-    {3.0 / 2.0, -1.0 / 2.0, 0.0, 0.0, 0.0},
-    {23.0 / 12.0, -16.0 / 12.0, 5.0 / 12.0, 0.0, 0.0},
-    {55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -9.0 / 24.0, 0.0},
-    {190.0 / 720.0, -2774.0 / 720.0, 2616.0 / 720.0, -1274.0 / 720.0, 251.0 / 720.0},
-};
-
 static int xpass(mrl_ctx *ctx, bool inv, const cplx *in, cplx *out) {
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2];
   p2::PassArgs a{};
@@ -171,9 +95,9 @@ static int xpass(mrl_ctx *ctx, bool inv, const cplx *in, cplx *out) {
   a.sn_in = a.sn_out = nyl * nzc;
   const cplx *tw = ctx->ax[0].d_tw;
   if (inv) {
-    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xpass<NN, true>(ctx, a, tw))));
+    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_t<NN, true, 1>(ctx, a, tw))));
   } else {
-    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xpass<NN, false>(ctx, a, tw))));
+    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_t<NN, false, 1>(ctx, a, tw))));
   }
   return MRL_OK;
 }
@@ -188,9 +112,9 @@ int slab_ch_fwd_local_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, doub
       ProfScope ps(ctx, "slab_A_z_fwd", 8.0 * nx * nyl * nz + 2.0 * h + (mu ? 8.0 * nx * nyl * nz : 0.0));
       p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2};
       if (cp.family == MRL_FE_DOUBLE_WELL) {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd_ch<NN, MRL_FE_DOUBLE_WELL>(ctx, c_in, s_c, s_mu, mu, chp, nx * nyl))));
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, s_c, s_mu, mu, chp, nx * nyl))));
       } else {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd_ch<NN, MRL_FE_PFHUB>(ctx, c_in, s_c, s_mu, mu, chp, nx * nyl))));
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, s_c, s_mu, mu, chp, nx * nyl))));
       }
     }
     ProfScope ps(ctx, "slab_A_x_fwd", 2.0 * h);
@@ -215,7 +139,7 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, const double *recv, double 
   a.c.Nnew = reinterpret_cast<cplx *>(Nhat_new);
   a.c.cbar = reinterpret_cast<cplx *>(cbar);
   for (int i = 0; i < order; ++i) a.c.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
-  for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaS[order][i];
+  for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaAB[order][i];
   a.nxl = (int)nxl;
   a.nzc = (int)nzc;
   a.nyl_shift = 0;
@@ -249,7 +173,7 @@ int slab_inv_finish_fast(mrl_ctx *ctx, const double *recv, double *real_out) {
   }
   ProfScope ps(ctx, "slab_C_z_inv", 16.0 * nfield + 8.0 * nx * nyl * nz);
   const double scale = 1.0 / ((double)nx * (double)ctx->n[1] * (double)nz);
-  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_s<NN>(ctx, w, real_out, scale, nx * nyl / 2))));
+  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w, real_out, scale, nx * nyl / 2))));
   return MRL_OK;
 }
 
