@@ -138,20 +138,29 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
 int mrl_kspace_abm(mrl_ctx *ctx, double *d_ubar_out, const double *d_ubar0, const double *const *d_N,
                    const double *h_coef, int nterms, const double *d_L, double dt, int64_t n_spec);
 
-/* Slab (multi-GPU) CH substep, split at its two exchanges (forward pair, inverse):
- *   mrl_slab_ch_fwd_local  : mu=f'(c); local passes of fft(c), fft(mu) -> d_send
- *   [exchange x2]            d_send/d_recv hold two fields back to back (c first, then mu), each laid
- *                            out as mrl_slab_counts(forward) says; each field is exchanged on its own.
- *   mrl_slab_ch_kspace     : finish both forward transforms, Nhat/ubar update, first inverse pass -> d_send
- *   [exchange]
- *   mrl_slab_inv_finish    : remaining inverse passes -> c_out
- * `part` lets the caller start the exchange of the c field while the mu field is still being
- * transformed: 0 = everything up to and including the c field, 1 = the rest (mu field), -1 = both. */
-int mrl_slab_ch_fwd_local(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_send, double *d_mu,
-                          int part);
-int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_recv, double *d_send,
-                       double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt,
-                       double *d_cbar);
+/* Slab (multi-GPU) CH substep (AdamsBashforthMoulton::substep over DomainAction::fftSlab/ifftSlab), split at its
+ * exchanges and pipelined over `nsub` sub-blocks of the kz axis: after the z pass every kz plane is an independent
+ * 2-D problem, so the caller can put sub-block s on the wire while sub-block s+1 is being transformed.
+ *   mrl_slab_ch_z_fwd                : mu = f'(c); z pass of c and mu (kept in context scratch)
+ *   for s: mrl_slab_ch_x_fwd(s)      : forward x pass of both fields for kz in K_s       -> d_send
+ *          [exchange s, forward]       one message per peer carrying both fields
+ *   for s: mrl_slab_ch_kspace(s)     : forward y pass, Nhat / ubar update, inverse y pass -> d_send
+ *          [exchange s, inverse]
+ *   for s: mrl_slab_ch_x_inv(s)      : inverse x pass (into context scratch)
+ *   mrl_slab_ch_z_inv                : inverse z pass, 1/N                                -> c_out
+ * K_s = kz range s of mrl_partition(nzc, nsub).  Buffer layouts (complex elements, peer chunks back to back in rank
+ * order, sizes from mrl_slab_ch_counts; x_p / y_p = the x / y range rank p owns, "me" = this rank):
+ *   forward send  [p][field c, mu][x_p ][y_me][K_s]      forward recv  [p][field c, mu][x_me][y_p ][K_s]
+ *   inverse send  [p][x_me][y_p ][K_s]                   inverse recv  [p][x_p ][y_me][K_s]
+ * d_Nhat_new / d_Nhat_old / d_cbar are the dense reciprocal arrays [x_me][ny][nzc] of the reference. */
+int mrl_slab_ch_counts(const mrl_ctx *ctx, int sub, int nsub, int forward, int64_t *h_send_counts,
+                       int64_t *h_recv_counts);
+int mrl_slab_ch_z_fwd(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_mu /* optional out */);
+int mrl_slab_ch_x_fwd(mrl_ctx *ctx, int sub, int nsub, double *d_send);
+int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, int sub, int nsub, const double *d_recv, double *d_send,
+                       double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar);
+int mrl_slab_ch_x_inv(mrl_ctx *ctx, int sub, int nsub, const double *d_recv);
+int mrl_slab_ch_z_inv(mrl_ctx *ctx, double *d_c_out);
 
 /* ---- de Geus mechanics ------------------------------------------------------------------ */
 /* Fields are value-major as in the reference: rank-2 [grid][3][3] (dim x dim in 2-D). */

@@ -80,8 +80,12 @@ SIGNATURES = {
     "mrl_ch_mu": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _i64]),
     "mrl_ch_substep": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _vp, _pp, _i32, _dbl, _vp, _vp]),
     "mrl_kspace_abm": (_i32, [_vp, _vp, _vp, _pp, C.POINTER(_dbl), _i32, _vp, _dbl, _i64]),
-    "mrl_slab_ch_fwd_local": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _vp, _i32]),
-    "mrl_slab_ch_kspace": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _vp, _pp, _i32, _dbl, _vp]),
+    "mrl_slab_ch_counts": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "mrl_slab_ch_z_fwd": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp]),
+    "mrl_slab_ch_x_fwd": (_i32, [_vp, _i32, _i32, _vp]),
+    "mrl_slab_ch_kspace": (_i32, [_vp, C.POINTER(MrlChParams), _i32, _i32, _vp, _vp, _vp, _pp, _i32, _dbl, _vp]),
+    "mrl_slab_ch_x_inv": (_i32, [_vp, _i32, _i32, _vp]),
+    "mrl_slab_ch_z_inv": (_i32, [_vp, _vp]),
     "mrl_gamma_apply": (_i32, [_vp, _vp, _vp]),
     "mrl_mech_stress": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "mrl_mech_tangent_apply": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),

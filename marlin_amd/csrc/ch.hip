@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(256) k_ch_mu(ChP p, const double *__restrict__
 
 struct KspaceArgs {
   int dim;
+  long long kz0, ksub;   // kz sub-range handled by this launch (kz0 = 0, ksub = n2: everything)
   long long n0, n1, n2;  // local reciprocal extents
   const double *k0, *k1, *k2;
   double M, kappa, dt;
@@ -55,12 +56,13 @@ __global__ void __launch_bounds__(256) k_ch_kspace(KspaceArgs a, const double2 *
                                                    const double2 *__restrict__ mubar, double2 *__restrict__ Nhat,
                                                    double2 *__restrict__ ubar) {
 #pragma clang fp contract(off)
-  const long long total = a.n0 * a.n1 * a.n2;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const long long i2 = e % a.n2;
-    const long long t = e / a.n2;
+  const long long total = a.n0 * a.n1 * a.ksub;
+  for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (long long)gridDim.x * blockDim.x) {
+    const long long i2 = a.kz0 + s % a.ksub;
+    const long long t = s / a.ksub;
     const long long i1 = t % a.n1;
     const long long i0 = t / a.n1;
+    const long long e = (i0 * a.n1 + i1) * a.n2 + i2;
     const double k2v = ksq(a.dim, a.k0[i0], a.k1[i1], a.k2[i2]);
     const double Mbar = -k2v * a.M;
     const double L = k2v * k2v * a.kappa;
@@ -148,10 +150,12 @@ int ch_mu_launch(mrl_ctx *ctx, const ChP &cp, const double *c, double *mu, long 
   return MRL_OK;
 }
 
-int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const double *mubar, double *Nhat, double *ubar,
-                     const double *const *Nold, int order, double sub_dt) {
+int ch_kspace_sub_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const double *mubar, double *Nhat, double *ubar,
+                         const double *const *Nold, int order, double sub_dt, long long k0, long long ksub) {
   KspaceArgs a{};
   a.dim = ctx->dim;
+  a.kz0 = k0;
+  a.ksub = ksub;
   a.n0 = ctx->nrec[0];
   a.n1 = ctx->nrec[1];
   a.n2 = ctx->nrec[2];
@@ -164,12 +168,17 @@ int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const doub
   a.order = order;
   for (int i = 0; i <= order; ++i) a.coef[i] = sub_dt * kBeta[order][i];
   for (int i = 0; i < order; ++i) a.Nold[i] = Nold[i];
-  const long long total = a.n0 * a.n1 * a.n2;
+  const long long total = a.n0 * a.n1 * a.ksub;
   hipLaunchKernelGGL(k_ch_kspace, dim3(grid_for(total)), dim3(256), 0, ctx->stream, a,
                      reinterpret_cast<const double2 *>(cbar), reinterpret_cast<const double2 *>(mubar),
                      reinterpret_cast<double2 *>(Nhat), reinterpret_cast<double2 *>(ubar));
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
+}
+
+int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const double *mubar, double *Nhat, double *ubar,
+                     const double *const *Nold, int order, double sub_dt) {
+  return ch_kspace_sub_launch(ctx, cp, cbar, mubar, Nhat, ubar, Nold, order, sub_dt, 0, ctx->nrec[2]);
 }
 
 // fast fused path (ch_fused.hip); returns MRL_ERR_UNSUPPORTED when the shape has no fast kernels

@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256, 2) k_ch_xfused(FusedArgs a, const cplx *_
   // byte offset of line element m: (i + (q + m*TPL)*inner) * 16, the same in the work and the dense layout
   const unsigned off0 = (unsigned)(iv + (long long)q * a.inner) * 16u, step = (unsigned)(TPL * a.inner) * 16u;
   auto off = [=](int m) { return off0 + (unsigned)m * step; };
-  ch_fused_body<N, ORDER, true>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, W, X, KX);
+  ch_fused_body<N, ORDER, true>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, W, X, KX);
 }
 
 template <int N, int ORDER>

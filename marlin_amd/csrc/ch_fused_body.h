@@ -38,11 +38,12 @@ __device__ __forceinline__ void stc(cplx *base, unsigned boff, cplx v) {
 
 // OffW / OffD: callables m -> byte offset of the thread's m-th line element in the work layout / the dense
 // reference layout (computed from a few live values instead of 2 x 16 held registers).
-template <int N, int ORDER, bool LINE_IS_X, class OffW, class OffD>
+// OffU: the same for the ubar output (the inverse exchange layout of the slab path differs from the forward one).
+template <int N, int ORDER, bool LINE_IS_X, class OffW, class OffD, class OffU>
 __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *__restrict__ tw,
                                               const double *__restrict__ kline, const double *__restrict__ ka_ptr,
                                               const double *__restrict__ kb_ptr, bool valid, int q, int l,
-                                              OffW offw, OffD offd, cplx *W, cplx *X,
+                                              OffW offw, OffD offd, OffU offu, cplx *W, cplx *X,
                                               double *KL) {
 #pragma clang fp contract(off)
   constexpr int TPL = N / 16;
@@ -146,7 +147,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   fft_line<N, Map>(v, q, l, X, W);
   if (valid) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) stc(a.ubar, offw(m), cswap(v[m]));
+    for (int m = 0; m < 16; ++m) stc(a.ubar, offu(m), cswap(v[m]));
   }
 }
 

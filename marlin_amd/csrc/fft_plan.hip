@@ -84,6 +84,22 @@ int pass_strided(mrl_ctx *ctx, int a, int sign, const double *d_in, double *d_ou
   return launch_pass(ctx, d, d_in, d_out, ctx->ax[a].d_tw, batch);
 }
 
+// c2c pass along `axis` over an explicit set of lines: line (o, i), o < outer, i < inner, starts at o*so + i*si,
+// successive points are sn apart (complex elements); used on kz sub-ranges by the slab pipeline
+int pass_lines(mrl_ctx *ctx, int axis, int sign, const double *in, double *out, long long outer, long long inner,
+               long long so, long long si, long long sn) {
+  PassDesc d{};
+  fill_radix(d, ctx->ax[axis], sign);
+  d.inner = inner;
+  d.outer = outer;
+  d.in_so = d.out_so = so;
+  d.in_si = d.out_si = si;
+  d.in_sn = d.out_sn = sn;
+  d.in_sb = d.out_sb = 0;
+  d.lines_fastest = 1;
+  return launch_pass(ctx, d, in, out, ctx->ax[axis].d_tw, 1);
+}
+
 // z pass inverse: complex [..][nzc] -> real [..][A2], scaled
 int pass_z_inverse(mrl_ctx *ctx, const double *d_in, double *d_out, long long A0, long long A1, long long batch,
                    int layout, double scale) {

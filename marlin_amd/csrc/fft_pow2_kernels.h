@@ -205,6 +205,67 @@ __global__ void __launch_bounds__(256, 2) k_pass(PassArgs a, const cplx *__restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// strided c2c pass on a kz SUB-BLOCK of the slab pipeline.  The contiguous index is 2-D (row, col) with
+// separate row pitches for input and output, and the axis index n may be chunked by destination / source
+// rank:  element(n, row, col) = base + (n >> sh)*cs + (n & ((1<<sh)-1))*sn + row*pitch + col.
+// (sh = 31: plain stride.)  Offsets are 32-bit element counts (fast-path arrays are < 2^31 elements).
+struct SubPassArgs {
+  const cplx *in[2];
+  cplx *out[2];
+  int rows, cols;
+  unsigned pitch_in, pitch_out;
+  unsigned sn_in, sn_out;
+  int sh_in, sh_out;
+  unsigned cs_in, cs_out;
+};
+
+template <int N, bool INV, int NF>
+__global__ void __launch_bounds__(256, 2) k_pass_sub(SubPassArgs a, const cplx *__restrict__ tw) {
+  constexpr int TPL = N / 16, T = 4096 / N;
+  using Map = MapStrided<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  const int l = threadIdx.x % T, q = threadIdx.x / T;
+  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned i = logical * T + l;
+  const bool valid = i < (unsigned)(a.rows * a.cols);
+  const unsigned ic = valid ? i : 0u;
+  const unsigned row = ic / (unsigned)a.cols, col = ic - row * (unsigned)a.cols;
+  const unsigned bi = row * a.pitch_in + col, bo = row * a.pitch_out + col;
+  const unsigned mi = (a.sh_in < 31) ? ((1u << a.sh_in) - 1u) : 0xffffffffu;
+  const unsigned mo = (a.sh_out < 31) ? ((1u << a.sh_out) - 1u) : 0xffffffffu;
+  TwRegs<N> twr;
+  tw_issue<N>(twr, tw);
+  cplx v[NF][16];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const unsigned n = q + m * TPL;
+      v[f][m] = a.in[f][bi + (a.sh_in < 31 ? (n >> a.sh_in) * a.cs_in : 0u) + (n & mi) * a.sn_in];
+    }
+  }
+  tw_commit<N>(twr, W);
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    if (INV) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) v[f][m] = cswap(v[f][m]);
+    }
+    fft_line<N, Map>(v[f], q, l, X, W);
+    if (valid) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const unsigned n = q + m * TPL;
+        a.out[f][bo + (a.sh_out < 31 ? (n >> a.sh_out) * a.cs_out : 0u) + (n & mo) * a.sn_out] =
+            INV ? cswap(v[f][m]) : v[f][m];
+      }
+    }
+  }
+}
+
 template <int N>
 constexpr size_t lds_line() {
   return sizeof(cplx) * (N + MapLine<N>::size);

@@ -64,6 +64,21 @@ inline int launch_pass_t(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
   return MRL_OK;
 }
 
+template <int N, bool INV, int NF>
+inline int launch_pass_sub(mrl_ctx *ctx, const SubPassArgs &a, const cplx *tw) {
+  static bool attr = false;
+  constexpr size_t lds = lds_strided<N>();
+  if (!attr) {
+    MRL_TRY(set_lds_attr(ctx, k_pass_sub<N, INV, NF>, lds));
+    attr = true;
+  }
+  constexpr int T = 4096 / N;
+  const long long nb = ((long long)a.rows * a.cols + T - 1) / T;
+  hipLaunchKernelGGL((k_pass_sub<N, INV, NF>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
 }  // namespace p2
 
 #define MRL_SWITCH_N(n, CALL)  \

@@ -95,49 +95,110 @@ __global__ void __launch_bounds__(256) k_mech_stress(const double *__restrict__ 
   }
 }
 
-// out = dF.S + F.Y ; bcast: dF is ONE tensor (D*D doubles) broadcast over the grid
-template <int D, bool SOA>
+// out = dF.S + F.Y for one grid point
+template <int D>
+__device__ __forceinline__ Mat<D> svk_tangent(const Mat<D> &f, const Mat<D> &d, double Kp, double mup) {
+  const Mat<D> S = svk_S<D>(f, Kp, mup);
+  Mat<D> W;
+  double tr = 0.0;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s += f.a[k][i] * d.a[k][j];
+      W.a[i][j] = s;
+    }
+#pragma unroll
+  for (int i = 0; i < D; ++i) tr += W.a[i][i];
+  Mat<D> Y;
+  const double two_mu = 2.0 * mup;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const double dev = 0.5 * (W.a[i][j] + W.a[j][i]) - (i == j ? (1.0 / 3.0) * tr : 0.0);
+      Y.a[i][j] = (i == j ? Kp * tr : 0.0) + two_mu * dev;
+    }
+  Mat<D> o;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s += d.a[i][k] * S.a[k][j] + f.a[i][k] * Y.a[k][j];
+      o.a[i][j] = s;
+    }
+  return o;
+}
+
+// out = K_dF(dF) ; bcast: dF is ONE tensor (D*D doubles) broadcast over the grid.
+// DIR fuses the CG direction update into the operator application: dF <- r + beta*dF (beta = S[i_num]/S[i_den],
+// written back: dF is the search direction p), then out = K_dF(dF)    (MarlinUtils.h:116 + FFTMechanics.C:107-108)
+template <int D, bool SOA, bool DIR>
 __global__ void __launch_bounds__(256) k_mech_tangent(const double *__restrict__ F, const double *__restrict__ K,
-                                                       const double *__restrict__ mu, const double *__restrict__ dF,
-                                                       int bcast, double *__restrict__ out, long long npts) {
+                                                       const double *__restrict__ mu, double *__restrict__ dF,
+                                                       int bcast, double *__restrict__ out, long long npts,
+                                                       const double *__restrict__ r, const double *__restrict__ S,
+                                                       int i_num, int i_den) {
+#pragma clang fp contract(off)
+  double beta = 0.0;
+  if (DIR) beta = S[i_num] / S[i_den];
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npts; p += (long long)gridDim.x * 256) {
     const Mat<D> f = load_mat<D, SOA>(F, p, npts);
-    const Mat<D> d = bcast ? load_mat<D, false>(dF, 0, 1) : load_mat<D, SOA>(dF, p, npts);
-    const double Kp = K[p], mup = mu[p];
-    const Mat<D> S = svk_S<D>(f, Kp, mup);
-    Mat<D> W;
-    double tr = 0.0;
+    Mat<D> d = bcast ? load_mat<D, false>(dF, 0, 1) : load_mat<D, SOA>(dF, p, npts);
+    if (DIR) {
+      const Mat<D> rv = load_mat<D, SOA>(r, p, npts);
 #pragma unroll
-    for (int i = 0; i < D; ++i)
+      for (int i = 0; i < D; ++i)
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        double s = 0.0;
+        for (int j = 0; j < D; ++j) d.a[i][j] = rv.a[i][j] + beta * d.a[i][j];
+      store_mat<D, SOA>(dF, p, npts, d);
+    }
+    store_mat<D, SOA>(out, p, npts, svk_tangent<D>(f, d, K[p], mu[p]));
+  }
+}
+
+// field-major, two grid points per thread: every component stream is read / written 16 B per lane
+template <bool DIR>
+__global__ void __launch_bounds__(256) k_mech_tangent_fm2(const double *__restrict__ F, const double *__restrict__ K,
+                                                           const double *__restrict__ mu, double *__restrict__ dF,
+                                                           int bcast, double *__restrict__ out, long long npts,
+                                                           const double *__restrict__ r, const double *__restrict__ S,
+                                                           int i_num, int i_den) {
+#pragma clang fp contract(off)
+  double beta = 0.0;
+  if (DIR) beta = S[i_num] / S[i_den];
+  const long long half = npts >> 1;  // npts is even on every fast-path shape
+  for (long long h = (long long)blockIdx.x * 256 + threadIdx.x; h < half; h += (long long)gridDim.x * 256) {
+    Mat<3> f[2], d[2];
 #pragma unroll
-        for (int k = 0; k < D; ++k) s += f.a[k][i] * d.a[k][j];
-        W.a[i][j] = s;
+    for (int c = 0; c < 9; ++c) {
+      const double2 fv = reinterpret_cast<const double2 *>(F + (long long)c * npts)[h];
+      f[0].a[c / 3][c % 3] = fv.x;
+      f[1].a[c / 3][c % 3] = fv.y;
+      double2 dv;
+      if (bcast) {
+        dv = make_double2(dF[c], dF[c]);
+      } else {
+        dv = reinterpret_cast<const double2 *>(dF + (long long)c * npts)[h];
       }
-#pragma unroll
-    for (int i = 0; i < D; ++i) tr += W.a[i][i];
-    Mat<D> Y;
-    const double two_mu = 2.0 * mup;
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        const double dev = 0.5 * (W.a[i][j] + W.a[j][i]) - (i == j ? (1.0 / 3.0) * tr : 0.0);
-        Y.a[i][j] = (i == j ? Kp * tr : 0.0) + two_mu * dev;
+      if (DIR) {
+        const double2 rv = reinterpret_cast<const double2 *>(r + (long long)c * npts)[h];
+        dv = make_double2(rv.x + beta * dv.x, rv.y + beta * dv.y);
+        reinterpret_cast<double2 *>(dF + (long long)c * npts)[h] = dv;
       }
-    Mat<D> o;
+      d[0].a[c / 3][c % 3] = dv.x;
+      d[1].a[c / 3][c % 3] = dv.y;
+    }
+    const double2 Kv = reinterpret_cast<const double2 *>(K)[h], mv = reinterpret_cast<const double2 *>(mu)[h];
+    const Mat<3> o0 = svk_tangent<3>(f[0], d[0], Kv.x, mv.x);
+    const Mat<3> o1 = svk_tangent<3>(f[1], d[1], Kv.y, mv.y);
 #pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) s += d.a[i][k] * S.a[k][j] + f.a[i][k] * Y.a[k][j];
-        o.a[i][j] = s;
-      }
-    store_mat<D, SOA>(out, p, npts, o);
+    for (int c = 0; c < 9; ++c)
+      reinterpret_cast<double2 *>(out + (long long)c * npts)[h] = make_double2(o0.a[c / 3][c % 3], o1.a[c / 3][c % 3]);
   }
 }
 
@@ -196,7 +257,7 @@ __global__ void __launch_bounds__(256) k_cg_init(const double *__restrict__ b, c
   if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// alpha = S[i_rz] / S[i_pAp] ; x += alpha p ; r -= alpha Ap ; partial sum r.r
+// alpha = S[i_rz] / S[i_pAp] ; x += alpha p ; r -= alpha Ap ; partial sum r.r      (16 B per lane per access)
 __global__ void __launch_bounds__(256) k_cg_update(const double *__restrict__ S, int i_rz, int i_pAp,
                                                     double *__restrict__ x, double *__restrict__ r,
                                                     const double *__restrict__ p, const double *__restrict__ Ap,
@@ -205,7 +266,18 @@ __global__ void __launch_bounds__(256) k_cg_update(const double *__restrict__ S,
   __shared__ double sh[4];
   const double alpha = S[i_rz] / S[i_pAp];
   double acc = 0.0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+  const long long n2 = n >> 1;
+  double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
+  const double2 *p2 = reinterpret_cast<const double2 *>(p), *A2 = reinterpret_cast<const double2 *>(Ap);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256) {
+    const double2 xv = x2[i], pv = p2[i], rv = r2[i], av = A2[i];
+    x2[i] = make_double2(xv.x + alpha * pv.x, xv.y + alpha * pv.y);
+    const double2 v = make_double2(rv.x - alpha * av.x, rv.y - alpha * av.y);
+    r2[i] = v;
+    acc += v.x * v.x + v.y * v.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long i = n - 1;
     x[i] = x[i] + alpha * p[i];
     const double v = r[i] - alpha * Ap[i];
     r[i] = v;
@@ -215,15 +287,6 @@ __global__ void __launch_bounds__(256) k_cg_update(const double *__restrict__ S,
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
-
-// beta = S[i_new] / S[i_old] ; p = r + beta p
-__global__ void __launch_bounds__(256) k_cg_dir(const double *__restrict__ S, int i_new, int i_old,
-                                                 const double *__restrict__ r, double *__restrict__ p, long long n) {
-#pragma clang fp contract(off)
-  const double beta = S[i_new] / S[i_old];
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-    p[i] = r[i] + beta * p[i];
 }
 
 // y[i] += x[i]                       (period = 0, block = 0)
@@ -289,12 +352,34 @@ int tangent_launch(mrl_ctx *ctx, const double *F, const double *K, const double 
   const int dd = ctx->dim * ctx->dim;
   ProfScope ps(ctx, "mech_tangent", (double)npts * 8.0 * ((bcast ? 2 : 3) * dd + 2));
   const dim3 g(grid_for(npts)), b(256);
+  double *d = const_cast<double *>(dF);  // only written by the DIR variant
   if (ctx->dim == 3 && soa)
-    hipLaunchKernelGGL((k_mech_tangent<3, true>), g, b, 0, ctx->stream, F, K, mu, dF, bcast ? 1 : 0, out, npts);
+    hipLaunchKernelGGL((k_mech_tangent_fm2<false>), dim3(grid_for(npts / 2)), b, 0, ctx->stream, F, K, mu, d,
+                       bcast ? 1 : 0, out, npts, nullptr, nullptr, 0, 0);
   else if (ctx->dim == 3)
-    hipLaunchKernelGGL((k_mech_tangent<3, false>), g, b, 0, ctx->stream, F, K, mu, dF, bcast ? 1 : 0, out, npts);
+    hipLaunchKernelGGL((k_mech_tangent<3, false, false>), g, b, 0, ctx->stream, F, K, mu, d, bcast ? 1 : 0, out, npts,
+                       nullptr, nullptr, 0, 0);
   else
-    hipLaunchKernelGGL((k_mech_tangent<2, false>), g, b, 0, ctx->stream, F, K, mu, dF, bcast ? 1 : 0, out, npts);
+    hipLaunchKernelGGL((k_mech_tangent<2, false, false>), g, b, 0, ctx->stream, F, K, mu, d, bcast ? 1 : 0, out, npts,
+                       nullptr, nullptr, 0, 0);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+// p <- r + (S[i_num]/S[i_den]) p ; out = K_dF(p)
+int tangent_dir_launch(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
+                       const double *S, int i_num, int i_den, double *out, bool soa) {
+  const long long npts = real_count_local(ctx);
+  const int dd = ctx->dim * ctx->dim;
+  ProfScope ps(ctx, "mech_tangent_dir", (double)npts * 8.0 * (5 * dd + 2));
+  const dim3 g(grid_for(npts)), b(256);
+  if (ctx->dim == 3 && soa)
+    hipLaunchKernelGGL((k_mech_tangent_fm2<true>), dim3(grid_for(npts / 2)), b, 0, ctx->stream, F, K, mu, p, 0, out, npts,
+                       r, S, i_num, i_den);
+  else if (ctx->dim == 3)
+    hipLaunchKernelGGL((k_mech_tangent<3, false, true>), g, b, 0, ctx->stream, F, K, mu, p, 0, out, npts, r, S, i_num, i_den);
+  else
+    hipLaunchKernelGGL((k_mech_tangent<2, false, true>), g, b, 0, ctx->stream, F, K, mu, p, 0, out, npts, r, S, i_num, i_den);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
@@ -442,7 +527,13 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
       int i_old = 0, i_new = 2;
       its = (int)l_max_its;
       for (long long k = 0; k < l_max_its; ++k) {
-        MRL_TRY(apply_A(p, Ap));
+        if (k == 0) {
+          MRL_TRY(apply_A(p, Ap));
+        } else {
+          // p = r + beta p (beta = rr_new / rr_old of the previous iteration) fused into the operator application
+          MRL_TRY(tangent_dir_launch(ctx, lin, d_K, d_mu, p, r, S, i_old, i_new, tmp, soa));
+          MRL_TRY(gamma(tmp, Ap, 1.0));
+        }
         {
           ProfScope ps(ctx, "cg_dot_pAp", 16.0 * n);
           MRL_TRY(reduce_async(ctx, 1, p, Ap, n, S + 1));
@@ -458,11 +549,7 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
           its = (int)k + 1;
           break;
         }
-        {
-          ProfScope ps(ctx, "cg_direction", 24.0 * n);
-          hipLaunchKernelGGL(k_cg_dir, dim3(nb), dim3(256), 0, ctx->stream, S, i_new, i_old, r, p, n);
-        }
-        const int t = i_old;
+        const int t = i_old;  // rr_new becomes rr_old; the next iteration's beta = S[i_old] / S[i_new]
         i_old = i_new;
         i_new = t;
       }

@@ -129,12 +129,177 @@ int slab_inv_finish(mrl_ctx *ctx, const double *recv, double *real_out) {
   return pass_z_inverse(ctx, ctx->d_work[11], real_out, nx, nyl, 1, 0, scale);
 }
 
-// fast path (slab_fused.hip): returns MRL_ERR_UNSUPPORTED when the shape has no fast kernels
+// ---- Cahn-Hilliard substep pipelined over kz sub-blocks -------------------------------------------------
+// fast path (slab_fused.hip)
 int slab_fast_ok(const mrl_ctx *ctx);
-int slab_ch_fwd_local_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *send, double *mu, int part);
-int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, const double *recv, double *send, double *Nhat_new,
+int slab_ch_z_fwd_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *mu);
+int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, double *send);
+int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const double *recv, double *send, double *Nhat_new,
                         const double *const *Nhat_old, int order, double sub_dt, double *cbar);
-int slab_inv_finish_fast(mrl_ctx *ctx, const double *recv, double *real_out);
+int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv);
+int slab_ch_z_inv_fast(mrl_ctx *ctx, double *real_out);
+// generic passes on a sub-range (fft_plan.hip), k-space update on a kz sub-range (ch.hip)
+int pass_lines(mrl_ctx *ctx, int axis, int sign, const double *in, double *out, long long outer, long long inner,
+               long long so, long long si, long long sn);
+int ch_kspace_sub_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const double *mubar, double *Nhat, double *ubar,
+                         const double *const *Nold, int order, double sub_dt, long long k0, long long ksub);
+
+// kz sub-block s of nsub: DomainAction's partition helper with equal weights
+static int sub_range(mrl_ctx *ctx, int sub, int nsub, long long *k0, long long *ksub) {
+  const long long nzc = ctx->nrec[2];
+  if (nsub < 1 || nsub > nzc || sub < 0 || sub >= nsub)
+    return set_error(ctx, MRL_ERR_INVALID, "kz sub-block %d of %d out of range (nzc = %lld)", sub, nsub, nzc);
+  long long total = nzc, remaining = nsub, b = 0;
+  for (int i = 0; i <= sub; ++i) {
+    long long n = total / remaining;
+    if (i == nsub - 1) n = total;
+    if (i == sub) {
+      *k0 = b;
+      *ksub = n;
+    }
+    b += n;
+    total -= n;
+    remaining -= 1;
+  }
+  return MRL_OK;
+}
+
+// copy a [n0][n1][n2] block (n2 contiguous) between two strided complex arrays
+__global__ void __launch_bounds__(256) k_copy3(const double2 *__restrict__ src, double2 *__restrict__ dst, long long n0,
+                                               long long n1, long long n2, long long ss0, long long ss1, long long ds0,
+                                               long long ds1) {
+  const long long total = n0 * n1 * n2;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long c = e % n2, r = e / n2, b = r % n1, a = r / n1;
+    dst[a * ds0 + b * ds1 + c] = src[a * ss0 + b * ss1 + c];
+  }
+}
+
+static int copy3(mrl_ctx *ctx, const double *src, double *dst, long long n0, long long n1, long long n2, long long ss0,
+                 long long ss1, long long ds0, long long ds1) {
+  const long long total = n0 * n1 * n2;
+  if (total == 0) return MRL_OK;
+  long long nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(k_copy3, dim3((unsigned)nb), dim3(256), 0, ctx->stream, reinterpret_cast<const double2 *>(src),
+                     reinterpret_cast<double2 *>(dst), n0, n1, n2, ss0, ss1, ds0, ds1);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+// generic work arrays: 13, 14 = c-hat / mu-hat on the real slab [nx][nyl][nzc]; 12 = mu; 15 = dense reciprocal
+// c-hat [nxl][ny][nzc]; 11 = dense reciprocal mu-hat / ubar, later the inverse x output [nx][nyl][nzc]
+static int gen_work(mrl_ctx *ctx) {
+  const size_t a = sizeof(cplx) * (size_t)(ctx->n[0] * ctx->nloc[1] * ctx->nrec[2]);
+  const size_t b = sizeof(cplx) * (size_t)(ctx->nrec[0] * ctx->n[1] * ctx->nrec[2]);
+  MRL_TRY(ensure_work(ctx, 13, a));
+  MRL_TRY(ensure_work(ctx, 14, a));
+  MRL_TRY(ensure_work(ctx, 15, b));
+  MRL_TRY(ensure_work(ctx, 11, a > b ? a : b));
+  MRL_TRY(ensure_work(ctx, 10, a > b ? a : b));
+  return MRL_OK;
+}
+
+static int gen_z_fwd(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *d_mu) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1];
+  const long long nreal = real_count_local(ctx);
+  MRL_TRY(gen_work(ctx));
+  double *mu = d_mu;
+  if (!mu) {
+    MRL_TRY(ensure_work(ctx, 12, sizeof(double) * (nreal + 2)));
+    mu = ctx->d_work[12];
+  }
+  MRL_TRY(ch_mu_launch(ctx, cp, c_in, mu, nreal));
+  ProfScope ps(ctx, "slab_z_fwd", 2.0 * (8.0 * nreal + 16.0 * nx * nyl * ctx->nrec[2]));
+  MRL_TRY(pass_z_forward(ctx, c_in, ctx->d_work[13], nx, nyl, 1, 0));
+  return pass_z_forward(ctx, mu, ctx->d_work[14], nx, nyl, 1, 0);
+}
+
+static int gen_x_fwd(mrl_ctx *ctx, long long k0, long long ksub, double *send) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2];
+  long long off = 0, xb = 0;
+  for (int f = 0; f < 2; ++f) {
+    double *w = ctx->d_work[13 + f] + 2 * k0;
+    ProfScope ps(ctx, "slab_x_fwd", 32.0 * nx * nyl * ksub);
+    MRL_TRY(pass_lines(ctx, 0, -1, w, w, nyl, ksub, nzc, 1, nyl * nzc));
+  }
+  ProfScope ps(ctx, "slab_pack", 2.0 * 32.0 * nx * nyl * ksub);
+  for (int p = 0; p < ctx->nranks; ++p) {
+    const long long nxp = ctx->part_recip[p], chunk = nxp * nyl * ksub;
+    for (int f = 0; f < 2; ++f)
+      MRL_TRY(copy3(ctx, ctx->d_work[13 + f] + 2 * (xb * nyl * nzc + k0), send + 2 * (off + f * chunk), nxp, nyl, ksub,
+                    nyl * nzc, nzc, nyl * ksub, ksub));
+    off += 2 * chunk;
+    xb += nxp;
+  }
+  return MRL_OK;
+}
+
+static int gen_kspace(mrl_ctx *ctx, const ChP &cp, long long k0, long long ksub, const double *recv, double *send,
+                      double *Nhat_new, const double *const *Nhat_old, int order, double sub_dt, double *d_cbar) {
+  const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2];
+  MRL_TRY(gen_work(ctx));
+  double *cbar = d_cbar ? d_cbar : ctx->d_work[15];
+  double *mubar = ctx->d_work[11], *ubar = ctx->d_work[10];
+  {
+    ProfScope ps(ctx, "slab_unpack", 2.0 * 32.0 * nxl * ny * ksub);
+    long long off = 0, yb = 0;
+    for (int p = 0; p < ctx->nranks; ++p) {
+      const long long nyp = ctx->part_real[p], chunk = nxl * nyp * ksub;
+      MRL_TRY(copy3(ctx, recv + 2 * off, cbar + 2 * (yb * nzc + k0), nxl, nyp, ksub, nyp * ksub, ksub, ny * nzc, nzc));
+      MRL_TRY(copy3(ctx, recv + 2 * (off + chunk), mubar + 2 * (yb * nzc + k0), nxl, nyp, ksub, nyp * ksub, ksub, ny * nzc, nzc));
+      off += 2 * chunk;
+      yb += nyp;
+    }
+  }
+  {
+    ProfScope ps(ctx, "slab_y_fwd", 2.0 * 32.0 * nxl * ny * ksub);
+    MRL_TRY(pass_lines(ctx, 1, -1, cbar + 2 * k0, cbar + 2 * k0, nxl, ksub, ny * nzc, 1, nzc));
+    MRL_TRY(pass_lines(ctx, 1, -1, mubar + 2 * k0, mubar + 2 * k0, nxl, ksub, ny * nzc, 1, nzc));
+  }
+  {
+    ProfScope ps(ctx, "ch_kspace", 16.0 * (double)(nxl * ny * ksub) * (4 + order));
+    MRL_TRY(ch_kspace_sub_launch(ctx, cp, cbar, mubar, Nhat_new, ubar, Nhat_old, order, sub_dt, k0, ksub));
+  }
+  {
+    ProfScope ps(ctx, "slab_y_inv", 32.0 * nxl * ny * ksub);
+    MRL_TRY(pass_lines(ctx, 1, +1, ubar + 2 * k0, ubar + 2 * k0, nxl, ksub, ny * nzc, 1, nzc));
+  }
+  ProfScope ps(ctx, "slab_pack", 32.0 * nxl * ny * ksub);
+  long long off = 0, yb = 0;
+  for (int p = 0; p < ctx->nranks; ++p) {
+    const long long nyp = ctx->part_real[p];
+    MRL_TRY(copy3(ctx, ubar + 2 * (yb * nzc + k0), send + 2 * off, nxl, nyp, ksub, ny * nzc, nzc, nyp * ksub, ksub));
+    off += nxl * nyp * ksub;
+    yb += nyp;
+  }
+  return MRL_OK;
+}
+
+static int gen_x_inv(mrl_ctx *ctx, long long k0, long long ksub, const double *recv) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2];
+  MRL_TRY(gen_work(ctx));
+  double *w = ctx->d_work[13];  // the forward work array of field c is free again
+  {
+    ProfScope ps(ctx, "slab_unpack", 32.0 * nx * nyl * ksub);
+    long long off = 0, xb = 0;
+    for (int p = 0; p < ctx->nranks; ++p) {
+      const long long nxp = ctx->part_recip[p];
+      MRL_TRY(copy3(ctx, recv + 2 * off, w + 2 * (xb * nyl * nzc + k0), nxp, nyl, ksub, nyl * ksub, ksub, nyl * nzc, nzc));
+      off += nxp * nyl * ksub;
+      xb += nxp;
+    }
+  }
+  ProfScope ps(ctx, "slab_x_inv", 32.0 * nx * nyl * ksub);
+  return pass_lines(ctx, 0, +1, w + 2 * k0, w + 2 * k0, nyl, ksub, nzc, 1, nyl * nzc);
+}
+
+static int gen_z_inv(mrl_ctx *ctx, double *real_out) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1];
+  const double scale = 1.0 / ((double)ctx->n[0] * (double)ctx->n[1] * (double)ctx->n[2]);
+  ProfScope ps(ctx, "slab_z_inv", 8.0 * nx * nyl * ctx->n[2] + 16.0 * nx * nyl * ctx->nrec[2]);
+  return pass_z_inverse(ctx, ctx->d_work[13], real_out, nx, nyl, 1, 0, scale);
+}
 
 }  // namespace mrl
 
@@ -187,36 +352,46 @@ int mrl_slab_inv_finish(mrl_ctx *ctx, const double *d_recv, double *d_real_out) 
   if (!ctx) return MRL_ERR_INVALID;
   MRL_TRY(check_slab(ctx, "mrl_slab_inv_finish"));
   if (!d_recv || !d_real_out) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_inv_finish: null buffer");
-  if (slab_fast_ok(ctx)) return slab_inv_finish_fast(ctx, d_recv, d_real_out);
   return slab_inv_finish(ctx, d_recv, d_real_out);
 }
 
-int mrl_slab_ch_fwd_local(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_send, double *d_mu,
-                          int part) {
+int mrl_slab_ch_counts(const mrl_ctx *ctx, int sub, int nsub, int forward, int64_t *h_send_counts,
+                       int64_t *h_recv_counts) {
   if (!ctx) return MRL_ERR_INVALID;
-  MRL_TRY(check_slab(ctx, "mrl_slab_ch_fwd_local"));
-  ChP cp;
-  MRL_TRY(ch_check_params(ctx, p, cp));
-  if (!d_c_in || !d_send) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_fwd_local: null buffer");
-  if (part < -1 || part > 1) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_fwd_local: part must be -1, 0 or 1");
-  if (slab_fast_ok(ctx)) return slab_ch_fwd_local_fast(ctx, cp, d_c_in, d_send, d_mu, part);
-  const long long nreal = real_count_local(ctx);
-  const long long nchunk = ctx->n[0] * ctx->nloc[1] * ctx->nrec[2];  // complex elements of one field's send buffer
-  double *mu = d_mu;
-  if (!mu) {
-    MRL_TRY(ensure_work(ctx, 12, sizeof(double) * (nreal + 2)));
-    mu = ctx->d_work[12];
+  if (ctx->nranks < 2) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_counts: not a slab context");
+  long long k0, ksub;
+  MRL_TRY(sub_range(const_cast<mrl_ctx *>(ctx), sub, nsub, &k0, &ksub));
+  const long long nf = forward ? 2 : 1;  // the forward messages carry both fields
+  for (int p = 0; p < ctx->nranks; ++p) {
+    const long long x_p_y_me = ctx->part_recip[p] * ctx->nloc[1] * ksub, x_me_y_p = ctx->nrec[0] * ctx->part_real[p] * ksub;
+    if (h_send_counts) h_send_counts[p] = nf * (forward ? x_p_y_me : x_me_y_p);
+    if (h_recv_counts) h_recv_counts[p] = nf * (forward ? x_me_y_p : x_p_y_me);
   }
-  if (part != 1) {
-    MRL_TRY(ch_mu_launch(ctx, cp, d_c_in, mu, nreal));
-    MRL_TRY(slab_fwd_local(ctx, d_c_in, d_send));
-  }
-  if (part != 0) MRL_TRY(slab_fwd_local(ctx, mu, d_send + 2 * nchunk));
   return MRL_OK;
 }
 
-int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_recv, double *d_send, double *d_Nhat_new,
-                       const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar) {
+int mrl_slab_ch_z_fwd(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_mu) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_slab(ctx, "mrl_slab_ch_z_fwd"));
+  ChP cp;
+  MRL_TRY(ch_check_params(ctx, p, cp));
+  if (!d_c_in) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_z_fwd: null buffer");
+  if (slab_fast_ok(ctx)) return slab_ch_z_fwd_fast(ctx, cp, d_c_in, d_mu);
+  return gen_z_fwd(ctx, cp, d_c_in, d_mu);
+}
+
+int mrl_slab_ch_x_fwd(mrl_ctx *ctx, int sub, int nsub, double *d_send) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_slab(ctx, "mrl_slab_ch_x_fwd"));
+  if (!d_send) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_x_fwd: null buffer");
+  long long k0, ksub;
+  MRL_TRY(sub_range(ctx, sub, nsub, &k0, &ksub));
+  if (slab_fast_ok(ctx)) return slab_ch_x_fwd_fast(ctx, (int)k0, (int)ksub, d_send);
+  return gen_x_fwd(ctx, k0, ksub, d_send);
+}
+
+int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, int sub, int nsub, const double *d_recv, double *d_send,
+                       double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar) {
   if (!ctx) return MRL_ERR_INVALID;
   MRL_TRY(check_slab(ctx, "mrl_slab_ch_kspace"));
   ChP cp;
@@ -225,22 +400,29 @@ int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_rec
   if (order < 0 || order > 4) return set_error(ctx, MRL_ERR_INVALID, "predictor order %d out of range", order + 1);
   for (int i = 0; i < order; ++i)
     if (!d_Nhat_old || !d_Nhat_old[i]) return set_error(ctx, MRL_ERR_INVALID, "history entry %d missing", i);
+  long long k0, ksub;
+  MRL_TRY(sub_range(ctx, sub, nsub, &k0, &ksub));
   if (slab_fast_ok(ctx))
-    return slab_ch_kspace_fast(ctx, cp, d_recv, d_send, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar);
-  const long long nspec = spec_count_local(ctx);
-  MRL_TRY(ensure_work(ctx, 13, sizeof(cplx) * nspec));
-  MRL_TRY(ensure_work(ctx, 14, sizeof(cplx) * nspec));
-  MRL_TRY(ensure_work(ctx, 15, sizeof(cplx) * nspec));
-  double *cbar = d_cbar ? d_cbar : ctx->d_work[13];
-  double *mubar = ctx->d_work[14];
-  MRL_TRY(slab_fwd_finish(ctx, d_recv, cbar));
-  MRL_TRY(slab_fwd_finish(ctx, d_recv + 2 * nspec, mubar));
-  double *ubar = ctx->d_work[15];
-  {
-    ProfScope ps(ctx, "ch_kspace", 16.0 * (double)nspec * (4 + order));
-    MRL_TRY(ch_kspace_launch(ctx, cp, cbar, mubar, d_Nhat_new, ubar, d_Nhat_old, order, sub_dt));
-  }
-  return slab_inv_local(ctx, ubar, d_send);
+    return slab_ch_kspace_fast(ctx, cp, (int)k0, (int)ksub, d_recv, d_send, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar);
+  return gen_kspace(ctx, cp, k0, ksub, d_recv, d_send, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar);
+}
+
+int mrl_slab_ch_x_inv(mrl_ctx *ctx, int sub, int nsub, const double *d_recv) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_slab(ctx, "mrl_slab_ch_x_inv"));
+  if (!d_recv) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_x_inv: null buffer");
+  long long k0, ksub;
+  MRL_TRY(sub_range(ctx, sub, nsub, &k0, &ksub));
+  if (slab_fast_ok(ctx)) return slab_ch_x_inv_fast(ctx, (int)k0, (int)ksub, d_recv);
+  return gen_x_inv(ctx, k0, ksub, d_recv);
+}
+
+int mrl_slab_ch_z_inv(mrl_ctx *ctx, double *d_c_out) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_slab(ctx, "mrl_slab_ch_z_inv"));
+  if (!d_c_out) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_z_inv: null buffer");
+  if (slab_fast_ok(ctx)) return slab_ch_z_inv_fast(ctx, d_c_out);
+  return gen_z_inv(ctx, d_c_out);
 }
 
 }  // extern "C"

@@ -1,15 +1,17 @@
 // Fast path of the slab-decomposed Cahn-Hilliard substep (3-D, power-of-two extents, r2c on z, equal
-// partitions).  Same kernels as the serial fast path (fft_pow2_kernels.h); the only kernel that sees
-// the exchange layout is the fused y pass:
-//   A  k_z_fwd<CH>      c -> (c-hat_z, mu-hat_z) on the real slab [nx][nyl][nzc], written into the send buffer
-//      k_pass<x>        forward x, in place: the result is already ordered by destination rank
-//   -- exchange (per field) --
-//   B  k_ch_yfused      gathers lines along y from the received chunks [p][nxl][nyl][nzc], forward y on both
-//                       fields, Nhat = Mbar*mu-hat (dense, reference layout), ABM predictor, 1/(1-dt*Lbar),
-//                       inverse y, scattered back into the same chunk layout for the inverse exchange
-//   -- exchange --
-//   C  k_pass<x>        inverse x on the dense [nx][nyl][nzc] array that arrived
-//      k_z_inv          c2r along z, 1/N
+// partitions), pipelined over `nsub` sub-blocks of the kz axis.  After the z pass every kz plane is an
+// independent 2-D problem (x pass -> exchange -> y pass with the k-space update -> exchange -> inverse x pass),
+// so sub-block s can be on the wire while sub-block s+1 is being transformed:
+//   Z   k_z_fwd<CH>      c -> (c-hat_z, mu-hat_z) on the real slab, into work arrays [nx][nyl][nzc]
+//   A_s k_pass_sub<x>    forward x of both fields for kz in K_s, written straight into the exchange layout
+//                        [p][field][nxl_p][nyl][ksub]      (ordered by destination rank: no pack kernel)
+//   -- all-to-all s (both fields in one message per peer) --
+//   B_s k_ch_yfused      gathers lines along y from [p][field][nxl][nyl_p][ksub], forward y on both fields,
+//                        Nhat = Mbar*mu-hat (dense reference layout), ABM predictor, 1/(1-dt*Lbar), inverse y,
+//                        scattered into the inverse exchange layout [p][nxl][nyl_p][ksub]
+//   -- all-to-all s --
+//   C_s k_pass_sub<x>    inverse x from [p][nxl_p][nyl][ksub] into the work array [nx][nyl][nzc]
+//   E   k_z_inv          c2r along z, 1/N
 // (AdamsBashforthMoulton.C:60-101 with DomainAction::fftSlab/ifftSlab, DomainAction.C:869-1019.)
 #include "ch_fused_body.h"
 #include "fft_pow2_launch.h"
@@ -19,10 +21,11 @@ namespace mrl {
 namespace p2 {
 
 struct YFusedArgs {
-  FusedCommon c;      // chat/muhat/ubar in the exchange layout [p][nxl][nyl][nzc]; Nnew/cbar/Nold dense [nxl][ny][nzc]
-  int nxl, nzc;
+  FusedCommon c;      // chat: received chunks (field 0 of each chunk; field 1 = mu-hat follows at +chunk)
+  int nxl, nzc;       // local x extent, full kz extent (pitch of the dense arrays)
+  int k0, ksub;       // kz sub-block
   int nyl_shift;      // log2(ny / P)
-  long long chunk;    // nxl * nyl * nzc: elements of one chunk
+  unsigned chunk;     // nxl * nyl * ksub: elements of one field of one chunk
   int tiles_per_x;
   const double *kx, *ky, *kz;  // local reciprocal axes
 };
@@ -38,20 +41,26 @@ __global__ void __launch_bounds__(256, 2) k_ch_yfused(YFusedArgs a, const cplx *
   const int l = threadIdx.x % T, q = threadIdx.x / T;
   const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
   const int ix = logical / a.tiles_per_x;
-  const int kz0 = (logical % a.tiles_per_x) * T + l;
-  const bool valid = kz0 < a.nzc;
-  const int kzi = valid ? kz0 : 0;
-  // element (ix, j, kz): exchange layout  p*chunk + (ix*nyl + (j - p*nyl))*nzc + kz,  p = j >> nyl_shift
-  //                      dense layout     (ix*N + j)*nzc + kz
-  const unsigned nzcB = (unsigned)a.nzc * 16u, chunkB = (unsigned)a.chunk * 16u, kzB = (unsigned)kzi * 16u;
+  const int kl0 = (logical % a.tiles_per_x) * T + l;
+  const bool valid = kl0 < a.ksub;
+  const int kl = valid ? kl0 : 0;
+  // element (ix, j, k0+kl), p = j >> nyl_shift, jl = j & (nyl-1)       [byte offsets]
+  //   forward exchange layout  (p*2 + field)*chunk + (ix*nyl + jl)*ksub + kl
+  //   inverse exchange layout   p*chunk            + (ix*nyl + jl)*ksub + kl
+  //   dense layout              (ix*N + j)*nzc + k0 + kl
   const int sh = a.nyl_shift, msk = (1 << sh) - 1;
-  auto offc = [=](int m) {
+  const unsigned ksB = (unsigned)a.ksub * 16u, chB = a.chunk * 16u, klB = (unsigned)kl * 16u;
+  auto offf = [=](int m) {
     const int j = q + m * TPL;
-    return (unsigned)(j >> sh) * chunkB + (unsigned)((ix << sh) + (j & msk)) * nzcB + kzB;
+    return (unsigned)(j >> sh) * (2u * chB) + (unsigned)((ix << sh) + (j & msk)) * ksB + klB;
   };
-  const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + kzi) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
+  auto offu = [=](int m) {
+    const int j = q + m * TPL;
+    return (unsigned)(j >> sh) * chB + (unsigned)((ix << sh) + (j & msk)) * ksB + klB;
+  };
+  const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + a.k0 + kl) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
   auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
-  ch_fused_body<N, ORDER, false>(a.c, tw, a.ky, a.kx + ix, a.kz + kzi, valid, q, l, offc, offd, W, X, KY);
+  ch_fused_body<N, ORDER, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
 }
 
 template <int N, int ORDER>
@@ -63,7 +72,7 @@ static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
     attr = true;
   }
   constexpr int T = 4096 / N;
-  a.tiles_per_x = (a.nzc + T - 1) / T;
+  a.tiles_per_x = (a.ksub + T - 1) / T;
   const long long nb = (long long)a.nxl * a.tiles_per_x;
   hipLaunchKernelGGL((k_ch_yfused<N, ORDER>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, ctx->ax[1].d_tw);
   MRL_HIP(ctx, hipGetLastError());
@@ -76,65 +85,78 @@ int slab_fast_ok(const mrl_ctx *ctx) {
   if (!(ctx->dim == 3 && ctx->nranks > 1 && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
         pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2])))
     return 0;
-  // equal power-of-two partitions: chunk addressing by shifts in k_ch_yfused
+  // equal power-of-two partitions: chunk addressing by shifts
   const long long nyl = ctx->n[1] / ctx->nranks, nxl = ctx->n[0] / ctx->nranks;
-  if (nyl * ctx->nranks != ctx->n[1] || nxl * ctx->nranks != ctx->n[0] || (nyl & (nyl - 1))) return 0;
+  if (nyl * ctx->nranks != ctx->n[1] || nxl * ctx->nranks != ctx->n[0] || (nyl & (nyl - 1)) || (nxl & (nxl - 1))) return 0;
   for (int p = 0; p < ctx->nranks; ++p)
     if (ctx->part_real[p] != nyl || ctx->part_recip[p] != nxl) return 0;
   return 1;
 }
 
-static int xpass(mrl_ctx *ctx, bool inv, const cplx *in, cplx *out) {
-  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2];
-  p2::PassArgs a{};
-  a.in[0] = in;
-  a.out[0] = out;
-  a.scale = 1.0;
-  a.inner = nyl * nzc;
-  a.outer = 1;
-  a.sn_in = a.sn_out = nyl * nzc;
-  const cplx *tw = ctx->ax[0].d_tw;
-  if (inv) {
-    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_t<NN, true, 1>(ctx, a, tw))));
-  } else {
-    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_t<NN, false, 1>(ctx, a, tw))));
-  }
+static int ilog2(long long v) {
+  int s = 0;
+  while ((1LL << s) < v) ++s;
+  return s;
+}
+
+// work arrays of the pipeline: slots 13, 14 = c-hat_z, mu-hat_z [nx][nyl][nzc]; slot 11 = inverse x output
+static int slab_work(mrl_ctx *ctx, cplx **w_c, cplx **w_mu, cplx **w_inv) {
+  const size_t bytes = sizeof(cplx) * (size_t)(ctx->n[0] * ctx->nloc[1] * ctx->nrec[2]);
+  MRL_TRY(ensure_work(ctx, 13, bytes));
+  MRL_TRY(ensure_work(ctx, 14, bytes));
+  MRL_TRY(ensure_work(ctx, 11, bytes));
+  *w_c = reinterpret_cast<cplx *>(ctx->d_work[13]);
+  *w_mu = reinterpret_cast<cplx *>(ctx->d_work[14]);
+  *w_inv = reinterpret_cast<cplx *>(ctx->d_work[11]);
   return MRL_OK;
 }
 
-int slab_ch_fwd_local_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *send, double *mu, int part) {
+int slab_ch_z_fwd_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *mu) {
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2];
-  const long long nfield = nx * nyl * nzc;
-  cplx *s_c = reinterpret_cast<cplx *>(send), *s_mu = s_c + nfield;
-  const double h = 16.0 * nfield;
-  if (part != 1) {
-    {
-      ProfScope ps(ctx, "slab_A_z_fwd", 8.0 * nx * nyl * nz + 2.0 * h + (mu ? 8.0 * nx * nyl * nz : 0.0));
-      p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2};
-      if (cp.family == MRL_FE_DOUBLE_WELL) {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, s_c, s_mu, mu, chp, nx * nyl))));
-      } else {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, s_c, s_mu, mu, chp, nx * nyl))));
-      }
-    }
-    ProfScope ps(ctx, "slab_A_x_fwd", 2.0 * h);
-    MRL_TRY(xpass(ctx, false, s_c, s_c));
-  }
-  if (part != 0) {
-    ProfScope ps(ctx, "slab_A_x_fwd", 2.0 * h);
-    MRL_TRY(xpass(ctx, false, s_mu, s_mu));
+  cplx *w_c, *w_mu, *w_inv;
+  MRL_TRY(slab_work(ctx, &w_c, &w_mu, &w_inv));
+  ProfScope ps(ctx, "slab_Z_z_fwd", 8.0 * nx * nyl * nz + 32.0 * nx * nyl * nzc + (mu ? 8.0 * nx * nyl * nz : 0.0));
+  p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2};
+  if (cp.family == MRL_FE_DOUBLE_WELL) {
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_c, w_mu, mu, chp, nx * nyl))));
+  } else {
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, w_c, w_mu, mu, chp, nx * nyl))));
   }
   return MRL_OK;
 }
 
-int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, const double *recv, double *send, double *Nhat_new,
+int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, double *send) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
+  cplx *w_c, *w_mu, *w_inv;
+  MRL_TRY(slab_work(ctx, &w_c, &w_mu, &w_inv));
+  const unsigned chunk = (unsigned)(nxl * nyl * ksub);
+  p2::SubPassArgs a{};
+  a.in[0] = w_c + k0;
+  a.in[1] = w_mu + k0;
+  a.out[0] = reinterpret_cast<cplx *>(send);
+  a.out[1] = a.out[0] + chunk;
+  a.rows = (int)nyl;
+  a.cols = ksub;
+  a.pitch_in = (unsigned)nzc;
+  a.pitch_out = (unsigned)ksub;
+  a.sn_in = (unsigned)(nyl * nzc);
+  a.sn_out = (unsigned)(nyl * ksub);
+  a.sh_in = 31;
+  a.sh_out = ilog2(nxl);
+  a.cs_out = 2u * chunk;
+  ProfScope ps(ctx, "slab_A_x_fwd", 4.0 * 16.0 * nx * nyl * ksub);
+  MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 2>(ctx, a, ctx->ax[0].d_tw))));
+  return MRL_OK;
+}
+
+int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const double *recv, double *send, double *Nhat_new,
                         const double *const *Nhat_old, int order, double sub_dt, double *cbar) {
   const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2];
-  const long long nspec = nxl * ny * nzc;
   const long long nyl = ny / ctx->nranks;
   p2::YFusedArgs a{};
+  a.chunk = (unsigned)(nxl * nyl * ksub);
   a.c.chat = reinterpret_cast<const cplx *>(recv);
-  a.c.muhat = a.c.chat + nspec;
+  a.c.muhat = a.c.chat + a.chunk;
   a.c.ubar = reinterpret_cast<cplx *>(send);
   a.c.Nnew = reinterpret_cast<cplx *>(Nhat_new);
   a.c.cbar = reinterpret_cast<cplx *>(cbar);
@@ -142,16 +164,16 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, const double *recv, double 
   for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaAB[order][i];
   a.nxl = (int)nxl;
   a.nzc = (int)nzc;
-  a.nyl_shift = 0;
-  while ((1LL << a.nyl_shift) < nyl) ++a.nyl_shift;
-  a.chunk = nxl * nyl * nzc;
+  a.k0 = k0;
+  a.ksub = ksub;
+  a.nyl_shift = ilog2(nyl);
   a.kx = ctx->d_k[0];
   a.ky = ctx->d_k[1];
   a.kz = ctx->d_k[2];
   a.c.M = cp.M;
   a.c.kappa = cp.kappa;
   a.c.dt = sub_dt;
-  ProfScope ps(ctx, "slab_B_y_fused", (4.0 + order + (cbar ? 1.0 : 0.0)) * 16.0 * nspec);
+  ProfScope ps(ctx, "slab_B_y_fused", (4.0 + order + (cbar ? 1.0 : 0.0)) * 16.0 * nxl * ny * ksub);
   switch (order) {
     case 0: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 0>(ctx, a)))); break;
     case 1: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 1>(ctx, a)))); break;
@@ -162,18 +184,34 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, const double *recv, double 
   return MRL_OK;
 }
 
-int slab_inv_finish_fast(mrl_ctx *ctx, const double *recv, double *real_out) {
+int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
+  cplx *w_c, *w_mu, *w_inv;
+  MRL_TRY(slab_work(ctx, &w_c, &w_mu, &w_inv));
+  p2::SubPassArgs a{};
+  a.in[0] = reinterpret_cast<const cplx *>(recv);
+  a.out[0] = w_inv + k0;
+  a.rows = (int)nyl;
+  a.cols = ksub;
+  a.pitch_in = (unsigned)ksub;
+  a.pitch_out = (unsigned)nzc;
+  a.sn_in = (unsigned)(nyl * ksub);
+  a.sn_out = (unsigned)(nyl * nzc);
+  a.sh_in = ilog2(nxl);
+  a.cs_in = (unsigned)(nxl * nyl * ksub);
+  a.sh_out = 31;
+  ProfScope ps(ctx, "slab_C_x_inv", 32.0 * nx * nyl * ksub);
+  MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, true, 1>(ctx, a, ctx->ax[0].d_tw))));
+  return MRL_OK;
+}
+
+int slab_ch_z_inv_fast(mrl_ctx *ctx, double *real_out) {
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2];
-  const long long nfield = nx * nyl * nzc;
-  MRL_TRY(ensure_work(ctx, 11, sizeof(cplx) * nfield));
-  cplx *w = reinterpret_cast<cplx *>(ctx->d_work[11]);
-  {
-    ProfScope ps(ctx, "slab_C_x_inv", 32.0 * nfield);
-    MRL_TRY(xpass(ctx, true, reinterpret_cast<const cplx *>(recv), w));
-  }
-  ProfScope ps(ctx, "slab_C_z_inv", 16.0 * nfield + 8.0 * nx * nyl * nz);
+  cplx *w_c, *w_mu, *w_inv;
+  MRL_TRY(slab_work(ctx, &w_c, &w_mu, &w_inv));
+  ProfScope ps(ctx, "slab_E_z_inv", 16.0 * nx * nyl * nzc + 8.0 * nx * nyl * nz);
   const double scale = 1.0 / ((double)nx * (double)ctx->n[1] * (double)nz);
-  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w, real_out, scale, nx * nyl / 2))));
+  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w_inv, real_out, scale, nx * nyl / 2))));
   return MRL_OK;
 }
 

@@ -4,13 +4,16 @@ DomainAction::fftSlab / ifftSlab (src/actions/DomainAction.C:869-1019) done as a
 Host logic only.  The local stages are the `mrl_slab_*` entry points of libmarlin_hip.so (HIP kernels);
 this module owns the exchange (torch.distributed: `nccl` = RCCL over xGMI on the GPUs, `gloo` in the CPU
 tests), the send/receive buffers and the solver's history rotation (TensorSolver.C:93-109,
-TensorBuffer.h:62-79).  A substep is three phases separated by the two exchanges:
+TensorBuffer.h:62-79).  A substep is pipelined over `nsub` sub-blocks of the kz axis (after the z pass
+every kz plane is an independent 2-D problem), so the links and the GPU work at the same time:
 
-    A  mu = f'(c); z and x passes of fft(c), fft(mu)           -> send (2 fields)
-       exchange (forward, per field; the c field travels while the mu field's x pass runs)
-    B  y pass of both fields, Mbar*mubar, ABM update, inverse y pass    -> send
-       exchange (inverse)
-    C  inverse x and z passes                                            -> c
+    Z    mu = f'(c); z pass of c and mu
+    A_s  forward x pass of both fields for kz in K_s                      -> send_f[s]
+         all-to-all s (asynchronous; both fields in one message per peer)
+    B_s  forward y pass, Mbar*mubar, ABM update, inverse y pass            -> send_i[s]
+         all-to-all s (asynchronous)
+    C_s  inverse x pass
+    E    inverse z pass                                                    -> c
 """
 from __future__ import annotations
 
@@ -129,14 +132,28 @@ class HipSlabStages:
     def inv_finish(self, recv, real_out):
         self.ctx._check(self.lib.mrl_slab_inv_finish(self.ctx.h, self._p(recv), self._p(real_out)))
 
-    def ch_fwd_local(self, p, c_in, send2, part=-1, mu=None):
-        self.ctx._check(self.lib.mrl_slab_ch_fwd_local(self.ctx.h, C.byref(p), self._p(c_in), self._p(send2),
-                                                       self._p(mu), part))
+    def ch_counts(self, sub, nsub, forward: bool):
+        n = self.ctx.nranks
+        sc, rc = (C.c_int64 * n)(), (C.c_int64 * n)()
+        self.ctx._check(self.lib.mrl_slab_ch_counts(self.ctx.h, sub, nsub, 1 if forward else 0, sc, rc))
+        return list(sc), list(rc)
 
-    def ch_kspace(self, p, recv2, send, Nnew, Nold, order, sub_dt, cbar=None):
+    def ch_z_fwd(self, p, c_in, mu=None):
+        self.ctx._check(self.lib.mrl_slab_ch_z_fwd(self.ctx.h, C.byref(p), self._p(c_in), self._p(mu)))
+
+    def ch_x_fwd(self, sub, nsub, send):
+        self.ctx._check(self.lib.mrl_slab_ch_x_fwd(self.ctx.h, sub, nsub, self._p(send)))
+
+    def ch_kspace(self, p, sub, nsub, recv, send, Nnew, Nold, order, sub_dt, cbar=None):
         arr = (C.c_void_p * max(1, len(Nold)))(*[t.data_ptr() for t in Nold])
-        self.ctx._check(self.lib.mrl_slab_ch_kspace(self.ctx.h, C.byref(p), self._p(recv2), self._p(send),
+        self.ctx._check(self.lib.mrl_slab_ch_kspace(self.ctx.h, C.byref(p), sub, nsub, self._p(recv), self._p(send),
                                                     self._p(Nnew), arr, order, sub_dt, self._p(cbar)))
+
+    def ch_x_inv(self, sub, nsub, recv):
+        self.ctx._check(self.lib.mrl_slab_ch_x_inv(self.ctx.h, sub, nsub, self._p(recv)))
+
+    def ch_z_inv(self, c_out):
+        self.ctx._check(self.lib.mrl_slab_ch_z_inv(self.ctx.h, self._p(c_out)))
 
     def empty(self, n):
         return torch.empty(n, dtype=torch.float64, device=self.device)
@@ -148,29 +165,32 @@ class SlabCahnHilliard:
     `stages` is the rank-local compute (HipSlabStages by default; the CPU tests inject an oracle-backed
     object with the same methods to exercise this host logic over gloo).  `exchange_factory(send_counts,
     recv_counts)` builds the transposes (SlabExchange by default; the single-GPU loop-back harness of
-    the GPU tests injects its own and drives the phases of all ranks in lock step)."""
+    the GPU tests injects its own and drives the phases of all ranks in lock step).  `nsub` = number of
+    kz sub-blocks the substep is pipelined over."""
 
     def __init__(self, dim, shape, L, params, nranks, rank, predictor_order: int = 2, sub_dt: float = 1e-3,
-                 stages=None, exchange_factory: Optional[Callable] = None, overlap: bool = True):
+                 stages=None, exchange_factory: Optional[Callable] = None, nsub: int = 4):
         self.p = params
         self.nranks, self.rank = nranks, rank
         self.st = stages if stages is not None else HipSlabStages(dim, shape, L, nranks, rank)
         self.ctx = getattr(self.st, "ctx", None)
         self.pred = predictor_order - 1            # AdamsBashforthMoulton.C:48
         self.sub_dt = sub_dt
-        self.overlap = overlap
+        nzc = self.st.recip_shape[2] if dim == 3 else 1
+        self.nsub = max(1, min(nsub, nzc))
         mk = exchange_factory if exchange_factory is not None else (lambda s, r: SlabExchange(s, r))
-        fs, fr = self.st.counts(True)
-        bs, br = self.st.counts(False)
-        self.x_fwd = mk(fs, fr)
-        self.x_inv = mk(bs, br)
-        self.n_fs, self.n_fr = 2 * sum(fs), 2 * sum(fr)   # doubles per field
-        self.n_bs, self.n_br = 2 * sum(bs), 2 * sum(br)
         e = self.st.empty
-        self.send2 = e(2 * self.n_fs)
-        self.recv2 = e(2 * self.n_fr)
-        self.send = e(self.n_bs)
-        self.recv = e(self.n_br)
+        self.x_fwd, self.x_inv = [], []
+        self.send_f, self.recv_f, self.send_i, self.recv_i = [], [], [], []
+        for s in range(self.nsub):
+            fs, fr = self.st.ch_counts(s, self.nsub, True)
+            bs, br = self.st.ch_counts(s, self.nsub, False)
+            self.x_fwd.append(mk(fs, fr))
+            self.x_inv.append(mk(bs, br))
+            self.send_f.append(e(2 * sum(fs)))
+            self.recv_f.append(e(2 * sum(fr)))
+            self.send_i.append(e(2 * sum(bs)))
+            self.recv_i.append(e(2 * sum(br)))
         nreal = 1
         for s in self.st.real_shape:
             nreal *= s
@@ -180,10 +200,9 @@ class SlabCahnHilliard:
         self.c = e(nreal)
         self.c_new = e(nreal)
         self.Nhat = [e(2 * nspec) for _ in range(self.pred + 2)]   # ring: current + history + one free
-        self.hist: List[torch.Tensor] = []                         # N̂_old[0..] (handles into the ring)
-        self.cur: Optional[torch.Tensor] = None                    # N̂ of the last substep
+        self.hist: List[torch.Tensor] = []                         # N-hat_old[0..] (handles into the ring)
+        self.cur: Optional[torch.Tensor] = None                    # N-hat of the last substep
         self.time_step = 0
-        self._pending = []
 
     # ---- state ---------------------------------------------------------------------------------
     def set_initial(self, gen: Callable[[int, int], "object"]):
@@ -232,42 +251,48 @@ class SlabCahnHilliard:
                 return t
         raise RuntimeError("history ring exhausted")
 
-    # ---- the three phases ------------------------------------------------------------------------
-    def phase_a(self):
-        if self.overlap:
-            self.st.ch_fwd_local(self.p, self.c, self.send2, part=0)
-        else:
-            self.st.ch_fwd_local(self.p, self.c, self.send2, part=-1)
+    # ---- the phases of one substep -------------------------------------------------------------------
+    def phase_z(self):
+        self.st.ch_z_fwd(self.p, self.c)
+        self._order = min(len(self.hist), self.pred)       # AdamsBashforthMoulton.C:90-91 (constant dt)
+        self._new = self._free_Nhat()
 
-    def phase_a2(self):
-        if self.overlap:
-            self.st.ch_fwd_local(self.p, self.c, self.send2, part=1)
+    def phase_a(self, s):
+        self.st.ch_x_fwd(s, self.nsub, self.send_f[s])
 
-    def phase_b(self):
-        order = min(len(self.hist), self.pred)       # AdamsBashforthMoulton.C:90-91 (constant dt)
-        new = self._free_Nhat()
-        self.st.ch_kspace(self.p, self.recv2, self.send, new, self.hist[:order], order, self.sub_dt)
-        self.cur = new
-        self.last_order = order
+    def phase_b(self, s):
+        self.st.ch_kspace(self.p, s, self.nsub, self.recv_f[s], self.send_i[s], self._new, self.hist[:self._order],
+                          self._order, self.sub_dt)
 
-    def phase_c(self):
-        self.st.inv_finish(self.recv, self.c_new)
+    def phase_c(self, s):
+        self.st.ch_x_inv(s, self.nsub, self.recv_i[s])
+
+    def phase_e(self):
+        self.st.ch_z_inv(self.c_new)
         self.c, self.c_new = self.c_new, self.c
+        self.cur = self._new
+        self.last_order = self._order
 
     def substep(self, advance: bool = True):
-        """One substep including both exchanges; `advance` rotates the history afterwards (what
-        TensorSolver::computeBuffer does between substeps)."""
-        nf, nr = self.n_fs, self.n_fr
-        self.phase_a()
-        w0 = self.x_fwd.run(self.send2[:nf], self.recv2[:nr], async_op=True)
-        self.phase_a2()
-        w1 = self.x_fwd.run(self.send2[nf:], self.recv2[nr:], async_op=True)
-        for w in (w0, w1):
-            if w is not None:
-                w.wait()
-        self.phase_b()
-        self.x_inv.run(self.send, self.recv)
-        self.phase_c()
+        """One substep including all exchanges; `advance` rotates the history afterwards (what
+        TensorSolver::computeBuffer does between substeps).  Exchanges are asynchronous: a work handle's
+        wait() only orders the compute stream behind that exchange, the host never blocks."""
+        S = range(self.nsub)
+        self.phase_z()
+        wf, wi = [], []
+        for s in S:
+            self.phase_a(s)
+            wf.append(self.x_fwd[s].run(self.send_f[s], self.recv_f[s], async_op=True))
+        for s in S:
+            if wf[s] is not None:
+                wf[s].wait()
+            self.phase_b(s)
+            wi.append(self.x_inv[s].run(self.send_i[s], self.recv_i[s], async_op=True))
+        for s in S:
+            if wi[s] is not None:
+                wi[s].wait()
+            self.phase_c(s)
+        self.phase_e()
         if advance:
             self.advance_state()
 

@@ -82,24 +82,80 @@ class OracleSlabStages:
             r = torch.real(torch.fft.ifft(d, dim=2))
         real_out[:] = r.reshape(-1)
 
-    def ch_fwd_local(self, p, c_in, send2, part=-1, mu=None):
-        n = send2.numel() // 2
-        if part != 1:
-            self._mu = mo.mu_double_well(c_in, p.coef[0])
-            self.fwd_local(c_in, send2[:n])
-        if part != 0:
-            self.fwd_local(self._mu, send2[n:])
+    # ---- Cahn-Hilliard substep pipelined over kz sub-blocks (layouts: include/marlin_hip.h) ------------
+    def _sub(self, sub, nsub):
+        ks = mo.partition_helper(self.nzc, [1] * nsub)
+        return sum(ks[:sub]), ks[sub]
 
-    def ch_kspace(self, p, recv2, send, Nnew, Nold, order, sub_dt, cbar=None):
-        n = recv2.numel() // 2
-        cb = torch.fft.fft(self._unpack(self._c(recv2[:n])), dim=1)
-        mb = torch.fft.fft(self._unpack(self._c(recv2[n:])), dim=1)
-        Mbar = -self.k2 * p.mobility
-        Lbar = self.k2 * self.k2 * p.kappa
+    def ch_counts(self, sub, nsub, forward):
+        k0, ksub = self._sub(sub, nsub)
+        to_p = [self.px[p] * self.nyl * ksub for p in range(self.nranks)]
+        from_p = [self.nxl * self.py[p] * ksub for p in range(self.nranks)]
+        return ([2 * c for c in to_p], [2 * c for c in from_p]) if forward else (from_p, to_p)
+
+    def ch_z_fwd(self, p, c_in, mu=None):
+        r = c_in.reshape(self.n[0], self.nyl, self.n[2])
+        m = mo.mu_double_well(r, p.coef[0])
+        zf = (lambda t: torch.fft.rfft(t, dim=2)) if self.half else (lambda t: torch.fft.fft(t.to(torch.complex128), dim=2))
+        self._w = [zf(r), zf(m)]
+
+    def ch_x_fwd(self, sub, nsub, send):
+        k0, ksub = self._sub(sub, nsub)
+        sc = self._c(send)
+        off = 0
+        xs = [torch.fft.fft(w[:, :, k0:k0 + ksub], dim=0) for w in self._w]
+        for p in range(self.nranks):
+            cnt = self.px[p] * self.nyl * ksub
+            for f in range(2):
+                sc[off:off + cnt] = xs[f][self.xb[p]:self.xb[p] + self.px[p]].reshape(-1)
+                off += cnt
+
+    def ch_kspace(self, p, sub, nsub, recv, send, Nnew, Nold, order, sub_dt, cbar=None):
+        k0, ksub = self._sub(sub, nsub)
+        rc = self._c(recv)
+        dense = [torch.empty(self.nxl, self.n[1], ksub, dtype=torch.complex128) for _ in range(2)]
+        off = 0
+        for q in range(self.nranks):
+            cnt = self.nxl * self.py[q] * ksub
+            for f in range(2):
+                dense[f][:, self.yb[q]:self.yb[q] + self.py[q], :] = rc[off:off + cnt].reshape(self.nxl, self.py[q], ksub)
+                off += cnt
+        cb = torch.fft.fft(dense[0], dim=1)
+        mb = torch.fft.fft(dense[1], dim=1)
+        k2 = self.k2[:, :, k0:k0 + ksub]
+        Mbar = -k2 * p.mobility
+        Lbar = k2 * k2 * p.kappa
         Nhat = Mbar * mb
-        self._c(Nnew)[:] = Nhat.reshape(-1)
+        shape = (self.nxl, self.n[1], self.nzc)
+        self._c(Nnew).reshape(shape)[:, :, k0:k0 + ksub] = Nhat
         ubar = cb + (sub_dt * mo.AB_BETA[order][0]) * Nhat
         for i in range(order):
-            ubar += (sub_dt * mo.AB_BETA[order][i + 1]) * self._c(Nold[i]).reshape(Nhat.shape)
+            ubar += (sub_dt * mo.AB_BETA[order][i + 1]) * self._c(Nold[i]).reshape(shape)[:, :, k0:k0 + ksub]
         ubar /= (1.0 - sub_dt * Lbar)
-        self._pack(torch.fft.ifft(ubar, dim=1), self._c(send))
+        u = torch.fft.ifft(ubar, dim=1)
+        sc = self._c(send)
+        off = 0
+        for q in range(self.nranks):
+            cnt = self.nxl * self.py[q] * ksub
+            sc[off:off + cnt] = u[:, self.yb[q]:self.yb[q] + self.py[q], :].reshape(-1)
+            off += cnt
+
+    def ch_x_inv(self, sub, nsub, recv):
+        k0, ksub = self._sub(sub, nsub)
+        if sub == 0:
+            self._winv = torch.empty(self.n[0], self.nyl, self.nzc, dtype=torch.complex128)
+        rc = self._c(recv)
+        d = torch.empty(self.n[0], self.nyl, ksub, dtype=torch.complex128)
+        off = 0
+        for p in range(self.nranks):
+            cnt = self.px[p] * self.nyl * ksub
+            d[self.xb[p]:self.xb[p] + self.px[p]] = rc[off:off + cnt].reshape(self.px[p], self.nyl, ksub)
+            off += cnt
+        self._winv[:, :, k0:k0 + ksub] = torch.fft.ifft(d, dim=0)
+
+    def ch_z_inv(self, c_out):
+        if self.half:
+            r = torch.fft.irfft(self._winv, n=self.n[2], dim=2)
+        else:
+            r = torch.real(torch.fft.ifft(self._winv, dim=2))
+        c_out[:] = r.reshape(-1)

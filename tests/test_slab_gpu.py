@@ -46,30 +46,27 @@ def _a2a(xs, sends, recvs):
 def _make(dim, shape, L, P, **kw):
     from marlin_amd.api import ch_params
     from marlin_amd.slab import SlabCahnHilliard
-    fwd, inv = Loopback(), Loopback()
-    solvers = []
-    for r in range(P):
-        calls = {"n": 0}
-
-        def fac(sc, rc, calls=calls):
-            calls["n"] += 1
-            return (fwd if calls["n"] == 1 else inv).factory(sc, rc)
-        solvers.append(SlabCahnHilliard(dim, shape, L, ch_params(), P, r, exchange_factory=fac, **kw))
-    return solvers
+    hub = Loopback()
+    return [SlabCahnHilliard(dim, shape, L, ch_params(), P, r, exchange_factory=hub.factory, **kw) for r in range(P)]
 
 
 def _substep_all(solvers):
+    S = range(solvers[0].nsub)
     for s in solvers:
-        s.phase_a()
-        s.phase_a2()
-    nf, nr = solvers[0].n_fs, [s.n_fr for s in solvers]
-    _a2a([s.x_fwd for s in solvers], [s.send2[:s.n_fs] for s in solvers], [s.recv2[:s.n_fr] for s in solvers])
-    _a2a([s.x_fwd for s in solvers], [s.send2[s.n_fs:] for s in solvers], [s.recv2[s.n_fr:] for s in solvers])
+        s.phase_z()
+    for k in S:
+        for s in solvers:
+            s.phase_a(k)
+        _a2a([s.x_fwd[k] for s in solvers], [s.send_f[k] for s in solvers], [s.recv_f[k] for s in solvers])
+    for k in S:
+        for s in solvers:
+            s.phase_b(k)
+        _a2a([s.x_inv[k] for s in solvers], [s.send_i[k] for s in solvers], [s.recv_i[k] for s in solvers])
+    for k in S:
+        for s in solvers:
+            s.phase_c(k)
     for s in solvers:
-        s.phase_b()
-    _a2a([s.x_inv for s in solvers], [s.send for s in solvers], [s.recv for s in solvers])
-    for s in solvers:
-        s.phase_c()
+        s.phase_e()
 
 
 def _step_all(solvers, dt, substeps):
@@ -142,7 +139,7 @@ def test_slab_ch_gold_rank1():
     g = load_golden("cahnhilliard_rank0001_gold.npz")
     torch.manual_seed(0)
     blk = torch.rand(20, 10, dtype=torch.float64) * (0.56 - 0.44) + 0.44
-    solvers = _make(2, [20, 20], [3.0, 3.0], 2)
+    solvers = _make(2, [20, 20], [3.0, 3.0], 2, nsub=1)
     for s in solvers:
         s.set_local(blk.cuda())
     worst = 0.0
@@ -152,13 +149,13 @@ def test_slab_ch_gold_rank1():
     assert worst <= 1e-13, worst
 
 
-@pytest.mark.parametrize("shape,P", [((8, 6, 10), 2), ((9, 7, 5), 3), ((32, 32, 32), 4), ((64, 64, 64), 2),
-                                     ((64, 128, 64), 8)])
-def test_slab_ch_matches_serial_oracle(shape, P):
+@pytest.mark.parametrize("shape,P,nsub", [((8, 6, 10), 2, 1), ((9, 7, 5), 3, 2), ((32, 32, 32), 4, 3), ((64, 64, 64), 2, 1),
+                                          ((64, 64, 64), 2, 4), ((64, 128, 64), 8, 5), ((128, 64, 64), 4, 2)])
+def test_slab_ch_matches_serial_oracle(shape, P, nsub):
     torch.manual_seed(4)
     c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
     L = [3.0, 2.0, 2.5]
-    solvers = _make(3, list(shape), L, P)
+    solvers = _make(3, list(shape), L, P, nsub=nsub)
     for s in solvers:
         yb, nyl = s.st.real_begin[1], s.st.real_shape[1]
         s.set_local(c0[:, yb:yb + nyl].contiguous().cuda())
