@@ -54,6 +54,33 @@ def grid_for(ngpus, base):
     return g
 
 
+# bench profile slot -> kernel name prefix in the rocprofv3 traces
+KERNEL_OF_SLOT = {"ch_A_z_fwd": "k_z_fwd<", "ch_B_y_fwd": "k_pass<", "ch_C_x_fused": "k_ch_xfused<", "ch_D_y_inv": "k_pass<",
+                  "ch_E_z_inv": "k_z_inv<"}
+
+
+def measured_traffic(slot, n, order_tag):
+    """HBM bytes per launch of the kernel behind `slot`, from the committed rocprofv3 PMC passes of this same
+    command (profiles/traffic_ch<n>.json, written by tools/profile_gpu.sh: FETCH_SIZE x2 (gfx950) + WRITE_SIZE)."""
+    path = os.path.join(ROOT, "profiles", f"traffic_ch{n}.json")
+    if not os.path.exists(path) or slot not in KERNEL_OF_SLOT:
+        return None, None
+    with open(path) as f:
+        t = json.load(f)
+    pref = KERNEL_OF_SLOT[slot]
+    cands = [k for k in t if k.startswith(pref) and (order_tag is None or order_tag in k)]
+    if slot == "ch_B_y_fwd":
+        cands = [k for k in cands if "false, 2" in k]
+    if slot == "ch_D_y_inv":
+        cands = [k for k in cands if "true, 1" in k]
+    if len(cands) != 1:
+        return None, None
+    v = t[cands[0]]
+    if v.get("fetch_bytes") is None or v.get("write_bytes") is None:
+        return None, None
+    return v["fetch_bytes"] + v["write_bytes"], os.path.relpath(path, ROOT)
+
+
 def cpu_baseline(shape, dx, sample_steps):
     """The oracle (libTorch CPU ops in the reference's order) timed on this box's host cores."""
     from oracle import marlin_oracle as mo
@@ -96,6 +123,7 @@ def main():
     ap.add_argument("--n", type=int, default=256, help="base grid edge (per-GPU work = n^3 points)")
     ap.add_argument("--cpu-steps", type=int, default=24, help="substeps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--nsub", type=int, default=4, help="kz sub-blocks the slab substep is pipelined over (N > 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,7 +150,7 @@ def main():
         from marlin_amd.slab import SlabCahnHilliard
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        solver = SlabCahnHilliard(3, shape, L, p, world, rank)
+        solver = SlabCahnHilliard(3, shape, L, p, world, rank, nsub=args.nsub)
         step = solver.substep
         barrier = dist.barrier
         solver.set_initial(lambda count, offset: splitmix64_uniform(count, offset=offset))
@@ -191,9 +219,13 @@ def main():
                 "unit": "GB/s",
                 "frac": round(dom_k["gbps"] / HBM_PEAK_GBPS, 4),
                 "traffic": None,
+                "traffic_source": None,
                 "avg_launch_ms": round(dom_k["avg_ms"], 5),
                 "algorithmic_bytes_per_launch": dom_k["bytes_per_launch"],
             }
+        if roofline and world == 1:
+            tr, src = measured_traffic(dom_k["kernel"], args.n, f"<{args.n}, 1>" if dom_k["kernel"] == "ch_C_x_fused" else None)
+            roofline["traffic"], roofline["traffic_source"] = tr, src
         out = {
             "metric": "grid-point-updates/sec, 3-D Cahn-Hilliard semi-implicit spectral substep (AB2, fp64)",
             "value": value,
@@ -211,7 +243,7 @@ def main():
                 "workload": f"3D Cahn-Hilliard {shape[0]}x{shape[1]}x{shape[2]} fp64 semi-implicit spectral step, AB2, "
                             f"f=0.1c^2(c-1)^2, M=0.2, kappa=-0.001, sub_dt=1e-3",
                 "grid": shape,
-                "decomposition": "none" if world == 1 else f"slab x{world} (RCCL all-to-all)",
+                "decomposition": "none" if world == 1 else f"slab x{world} (RCCL all-to-all, {args.nsub} kz sub-blocks in flight)",
             },
             "substep_algorithmic_bytes_per_update": bpu,
             "substep_achieved_GBps": value * bpu / 1e9,

@@ -1,5 +1,6 @@
 // Context, planning and the host-only helpers of the C ABI (mirrors DomainAction's set-up work).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -181,6 +182,7 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
     return code;
   };
 
+  if (const char *e = getenv("MRL_EXP")) c->exp = atoi(e);
   c->dim = dom->dim;
   c->spectrum = dom->spectrum;
   c->nranks = dom->nranks;

@@ -89,6 +89,8 @@ struct mrl_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   std::vector<int> prof_slots;
 
+  int exp = 0;  // experiment switches (env MRL_EXP, bit mask): A/B testing of kernel variants inside one process
+
   mutable std::string err;
 };
 

@@ -17,3 +17,4 @@ python3 $R/tools/summarize_prof.py $OUT > $OUT/summary.md 2>&1
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +2M -delete
 cat $OUT/summary.md
+[ -f $OUT/traffic.json ] && cp $OUT/traffic.json $OUT/../traffic_$TAG.json

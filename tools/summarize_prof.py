@@ -15,6 +15,8 @@ def short(name):
 
 
 def main(root):
+    import json
+    traffic = {}
     print(f"# rocprofv3 summary ({os.path.basename(root)})\n")
     stats = glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
@@ -42,6 +44,13 @@ def main(root):
         print("|---|---|---|")
         for k, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             print(f"| {k} | {n} | {tot / n * 1024.0 * scale / 1e6:.1f} |")
+            traffic.setdefault(k, {})[label] = tot / n * 1024.0 * scale
+    if traffic:
+        # per-launch HBM bytes (FETCH_SIZE x2 + WRITE_SIZE) per kernel: read back by bench.py as roofline.traffic
+        out = {k: {"fetch_bytes": v.get("FETCH_SIZE"), "write_bytes": v.get("WRITE_SIZE")} for k, v in traffic.items()
+               if k.startswith("k_")}
+        with open(os.path.join(root, "traffic.json"), "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
