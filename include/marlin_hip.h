@@ -191,6 +191,24 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *p, const double *d_F
                        const double *d_mu, const double *d_applied, double *d_Fnew, double *d_P,
                        mrl_mech_stats *stats);
 
+/* ---- parsed pointwise expressions: ParsedCompute (src/tensor_computes/ParsedCompute.C:50-265) ----------------
+ * expression text -> AST -> d/d(derivatives[0]) d/d(derivatives[1]) ... -> simplify -> one fused HIP kernel (hiprtc).
+ * Grammar, derivative and simplification rules follow the reference's parser (they fix the floating-point
+ * evaluation order); see marlin_amd/csrc/expr.hip.  Inputs are full-size device arrays, real or interleaved complex;
+ * named constants stay symbolic; with extra_symbols the names x y z kx ky kz k2 t pi e i are available and the
+ * expression is evaluated on the whole real (space = 0) or reciprocal (space = 1) grid of the context.
+ * ctx may be NULL: the expression is parsed / differentiated / simplified only (mrl_parsed_string), no GPU needed. */
+typedef struct mrl_parsed mrl_parsed;
+int mrl_parsed_create(mrl_ctx *ctx, mrl_parsed **out, const char *expression, int n_inputs, const char *const *input_names,
+                      const int *input_is_complex, int n_constants, const char *const *constant_names,
+                      const double *constant_values, int n_derivatives, const char *const *derivatives, int extra_symbols,
+                      int space);
+void mrl_parsed_destroy(mrl_parsed *p);
+int mrl_parsed_is_complex(const mrl_parsed *p);      /* 1: the result is complex */
+const char *mrl_parsed_string(const mrl_parsed *p);  /* the simplified tree, fully parenthesised */
+const char *mrl_parsed_source(const mrl_parsed *p);  /* the generated HIP source */
+int mrl_parsed_eval(mrl_parsed *p, const double *const *d_inputs, double *d_out, int64_t count, double time);
+
 /* ---- reductions: torch::sum / torch::norm call sites of the CG (MarlinUtils.h:63,82,92,99,109) */
 /* Synchronous: result returned in *h_out. */
 int mrl_dot(mrl_ctx *ctx, const double *d_a, const double *d_b, int64_t n, double *h_out);

@@ -90,6 +90,13 @@ SIGNATURES = {
     "mrl_mech_stress": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "mrl_mech_tangent_apply": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mrl_mech_newton_cg": (_i32, [_vp, C.POINTER(MrlMechParams), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(MrlMechStats)]),
+    "mrl_parsed_create": (_i32, [_vp, C.POINTER(_vp), C.c_char_p, _i32, C.POINTER(C.c_char_p), C.POINTER(_i32), _i32,
+                                 C.POINTER(C.c_char_p), C.POINTER(_dbl), _i32, C.POINTER(C.c_char_p), _i32, _i32]),
+    "mrl_parsed_destroy": (None, [_vp]),
+    "mrl_parsed_is_complex": (_i32, [_vp]),
+    "mrl_parsed_string": (C.c_char_p, [_vp]),
+    "mrl_parsed_source": (C.c_char_p, [_vp]),
+    "mrl_parsed_eval": (_i32, [_vp, _pp, _vp, _i64, _dbl]),
     "mrl_dot": (_i32, [_vp, _vp, _vp, _i64, C.POINTER(_dbl)]),
     "mrl_norm2": (_i32, [_vp, _vp, _i64, C.POINTER(_dbl)]),
     "mrl_sum": (_i32, [_vp, _vp, _i64, C.POINTER(_dbl)]),

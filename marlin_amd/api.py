@@ -275,3 +275,53 @@ class Context:
                         "bytes_per_launch": nbytes.value})
             slot += 1
         return res
+
+
+class ParsedCompute:
+    """ParsedCompute (src/tensor_computes/ParsedCompute.C:50-265): expression -> derivatives -> fused HIP kernel.
+    ctx=None parses / differentiates / simplifies only (no GPU): `.tree` is the simplified expression."""
+
+    def __init__(self, ctx: Optional[Context], expression: str, inputs: Sequence[str] = (), complex_inputs: Sequence[str] = (),
+                 constants: Optional[dict] = None, derivatives: Sequence[str] = (), extra_symbols: bool = False,
+                 reciprocal: bool = False):
+        self.lib = _lib.load()
+        self.ctx = ctx
+        constants = constants or {}
+        names = [n.encode() for n in inputs]
+        cn = [n.encode() for n in constants]
+        dn = [n.encode() for n in derivatives]
+        arr = lambda items: (C.c_char_p * max(1, len(items)))(*items)
+        flags = (C.c_int * max(1, len(inputs)))(*[1 if n in complex_inputs else 0 for n in inputs])
+        cv = (C.c_double * max(1, len(constants)))(*[float(v) for v in constants.values()])
+        h = C.c_void_p()
+        rc = self.lib.mrl_parsed_create(ctx.h if ctx else None, C.byref(h), expression.encode(), len(names), arr(names), flags,
+                                        len(cn), arr(cn), cv, len(dn), arr(dn), 1 if extra_symbols else 0,
+                                        1 if reciprocal else 0)
+        if rc != 0:
+            raise MarlinHipError(rc, self.lib.mrl_last_error(ctx.h if ctx else None).decode())
+        self.h = h
+        self.inputs = list(inputs)
+        self.is_complex = bool(self.lib.mrl_parsed_is_complex(h))
+        self.tree = self.lib.mrl_parsed_string(h).decode()
+        self.source = self.lib.mrl_parsed_source(h).decode()
+
+    def __call__(self, *tensors: torch.Tensor, out: Optional[torch.Tensor] = None, count: Optional[int] = None,
+                 time: float = 0.0) -> torch.Tensor:
+        assert self.ctx is not None, "created without a context"
+        assert len(tensors) == len(self.inputs)
+        if count is None:
+            count = tensors[0].numel()
+        if out is None:
+            shape = tensors[0].shape if tensors else (count,)
+            out = torch.empty(shape, dtype=torch.complex128 if self.is_complex else torch.float64, device=self.ctx.device)
+        arr = (C.c_void_p * max(1, len(tensors)))(*[t.data_ptr() for t in tensors])
+        self.ctx._check(self.lib.mrl_parsed_eval(self.h, arr, _ptr(out), count, time))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.mrl_parsed_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

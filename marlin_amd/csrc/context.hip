@@ -243,6 +243,20 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
     }
   }
 
+  // real-space axes: torch::linspace(min + dx/2, max - dx/2, n) (DomainAction.C:246-251); ATen fills the lower half
+  // as start + step*i and the upper half as end - step*(n-1-i)
+  for (int a = 0; a < 3; ++a) {
+    if (a < off || a >= off + c->dim) {
+      c->h_x[a] = {0.0};
+    } else {
+      const long long n = c->n[a];
+      const double lo = c->gmin[a] + c->dx[a] / 2.0, hi = c->gmax[a] - c->dx[a] / 2.0;
+      const double step = n > 1 ? (hi - lo) / (double)(n - 1) : 0.0;
+      c->h_x[a].resize(n);
+      for (long long i = 0; i < n; ++i) c->h_x[a][i] = (i < n / 2) ? lo + step * (double)i : hi - step * (double)(n - 1 - i);
+    }
+  }
+
   // partition
   for (int a = 0; a < 3; ++a) {
     c->nloc[a] = c->n[a];
@@ -281,6 +295,12 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
       set_error(c, MRL_ERR_HIP, "uploading reciprocal axis failed");
       rc = MRL_ERR_HIP;
     }
+    const size_t xb = sizeof(double) * c->nloc[a];
+    if (rc == MRL_OK && (hipMalloc(reinterpret_cast<void **>(&c->d_x[a]), xb) != hipSuccess ||
+                         hipMemcpy(c->d_x[a], c->h_x[a].data() + c->rbeg[a], xb, hipMemcpyHostToDevice) != hipSuccess)) {
+      set_error(c, MRL_ERR_HIP, "uploading real-space axis failed");
+      rc = MRL_ERR_HIP;
+    }
   }
   if (rc != MRL_OK) return fail(rc);
 
@@ -300,6 +320,7 @@ void mrl_ctx_destroy(mrl_ctx *c) {
   for (int a = 0; a < 3; ++a) {
     if (c->ax[a].d_tw) hipFree(c->ax[a].d_tw);
     if (c->d_k[a]) hipFree(c->d_k[a]);
+    if (c->d_x[a]) hipFree(c->d_x[a]);
   }
   for (int s = 0; s < kWorkSlots; ++s)
     if (c->d_work[s]) hipFree(c->d_work[s]);

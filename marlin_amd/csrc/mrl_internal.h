@@ -75,6 +75,8 @@ struct mrl_ctx {
   mrl::AxisPlan ax[3];
   std::vector<double> h_k[3];   // reciprocal axis values (global), internal axis order
   double *d_k[3] = {nullptr, nullptr, nullptr};  // device copies of the LOCAL reciprocal axes
+  std::vector<double> h_x[3];   // real-space axis values (global): linspace(min+dx/2, max-dx/2, n), DomainAction.C:246-251
+  double *d_x[3] = {nullptr, nullptr, nullptr};  // device copies of the LOCAL real-space axes
 
   // scratch (complex spectra), grown on demand
   // slots: 0 inverse-transform scratch, 1-3 Cahn-Hilliard, 4-10 mechanics, 11-15 slab stages

@@ -1,0 +1,113 @@
+"""Native ParsedCompute on the GPU: fused hiprtc kernels vs the same op sequence in libTorch (oracle) and vs finite
+differences (the strategy of the reference's unit/src/ParsedTensorTest.C)."""
+import math
+
+import pytest
+import torch
+
+from oracle import marlin_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from marlin_amd.api import Context
+    return Context(2, [12, 10], [2 * math.pi, 3.0])
+
+
+def _pc(ctx, *a, **k):
+    from marlin_amd.api import ParsedCompute
+    return ParsedCompute(ctx, *a, **k)
+
+
+def test_chemical_potentials_bit_exact(ctx):
+    """the two free energies of the benchmark configs, derived symbolically, == the oracle's op sequence bit for bit"""
+    torch.manual_seed(0)
+    c = torch.rand(4097, dtype=torch.float64)
+    mu = _pc(ctx, "0.1*c^2*(c-1)^2", inputs=["c"], derivatives=["c"])(c.cuda()).cpu()
+    assert torch.equal(mu, mo.mu_double_well(c, 0.1))
+    mu = _pc(ctx, "rho_s*(c-c_alpha)^2*(c_beta-c)^2", inputs=["c"], constants={"rho_s": 5.0, "c_alpha": 0.3, "c_beta": 0.7},
+             derivatives=["c"])(c.cuda()).cpu()
+    assert torch.equal(mu, mo.mu_pfhub(c, 5.0, 0.3, 0.7))
+
+
+def test_brusselator_sources_bit_exact(ctx):
+    """test/tests/solvers/diagonal.i:58-77"""
+    torch.manual_seed(1)
+    u, v = torch.rand(1000, dtype=torch.float64) * 3, torch.rand(1000, dtype=torch.float64)
+    A, B = 1.0, 3.5
+    su = _pc(ctx, "A - (B+1)*u +u^2*v", inputs=["u", "v"], constants={"A": A, "B": B})(u.cuda(), v.cuda()).cpu()
+    sv = _pc(ctx, "B*u - u^2*v", inputs=["u", "v"], constants={"A": A, "B": B})(u.cuda(), v.cuda()).cpu()
+    assert torch.equal(su, (A - (B + 1.0) * u) + torch.pow(u, 2.0) * v)
+    assert torch.equal(sv, B * u - torch.pow(u, 2.0) * v)
+
+
+def test_reciprocal_product_complex(ctx):
+    """Mbarmubar = Mbar*mubar (examples/cahn_hilliard/cahnhilliard2.i:86-91): real x complex"""
+    torch.manual_seed(2)
+    M = torch.rand(777, dtype=torch.float64) - 0.5
+    z = torch.complex(torch.rand(777, dtype=torch.float64), torch.rand(777, dtype=torch.float64))
+    p = _pc(ctx, "Mbar*mubar", inputs=["Mbar", "mubar"], complex_inputs=["mubar"])
+    assert p.is_complex
+    assert torch.equal(p(M.cuda(), z.cuda()).cpu(), M * z)
+    q = _pc(ctx, "(a*b + a/b - a)*2", inputs=["a", "b"], complex_inputs=["a", "b"])
+    w = torch.complex(torch.rand(777, dtype=torch.float64) + 0.5, torch.rand(777, dtype=torch.float64))
+    ref = (z * w + z / w - z) * 2
+    assert (q(z.cuda(), w.cuda()).cpu() - ref).abs().max().item() <= 1e-14
+
+
+def test_extra_symbols_real_and_reciprocal(ctx):
+    """x, y, kx, ky, k2, t, pi (ParsedCompute.C:139-161) on the context's grids (diagonal.i:20-27: sin(x)*sin(y))"""
+    dom = mo.Domain(2, [12, 10], [2 * math.pi, 3.0])
+    n = 120
+    got = _pc(ctx, "sin(x)*sin(y) + t*pi", extra_symbols=True)(count=n, time=0.25).cpu().reshape(12, 10)
+    ref = torch.sin(dom.axis[0]) * torch.sin(dom.axis[1]) + 0.25 * math.pi
+    assert (got - ref).abs().max().item() <= 4e-16
+    nk = 12 * 6
+    got = _pc(ctx, "-k2*0.2 + kx - 2*ky", extra_symbols=True, reciprocal=True)(count=nk).cpu().reshape(12, 6)
+    ref = -dom.k_square() * 0.2 + dom.kaxis[0] - 2 * dom.kaxis[1]
+    assert torch.equal(got, ref)
+    spec = _pc(ctx, "i*kx*a", inputs=["a"], complex_inputs=["a"], extra_symbols=True, reciprocal=True)
+    a = torch.complex(torch.rand(12, 6, dtype=torch.float64), torch.rand(12, 6, dtype=torch.float64))
+    assert (spec(a.cuda()).cpu() - 1j * dom.kaxis[0] * a).abs().max().item() <= 1e-14
+
+
+FUNCS = ["sin(a)", "cos(a)", "tan(a)", "sinh(a)", "cosh(a)", "tanh(a)", "asin(a/2)", "acos(a/2)", "atan(a)", "exp(a)", "log(a)",
+         "log10(a)", "log2(a)", "sqrt(a)", "abs(a-0.5)", "a^2.5", "a^b", "a^-2", "a^0.5", "a^3", "atan2(a, b)", "hypot(a, b)",
+         "min(a, b)*max(a, b)", "if(a > b, a*a, b)", "a % 0.3", "floor(a*3) + ceil(b*3) + round(a*7) + trunc(b*5)"]
+
+
+@pytest.mark.parametrize("expr", FUNCS)
+def test_functions_match_torch(ctx, expr):
+    torch.manual_seed(3)
+    a = torch.rand(513, dtype=torch.float64) + 0.1
+    b = torch.rand(513, dtype=torch.float64) + 0.1
+    env = {"a": a, "b": b, "sin": torch.sin, "cos": torch.cos, "tan": torch.tan, "sinh": torch.sinh, "cosh": torch.cosh,
+           "tanh": torch.tanh, "asin": torch.asin, "acos": torch.acos, "atan": torch.atan, "exp": torch.exp, "log": torch.log,
+           "log10": torch.log10, "log2": torch.log2, "sqrt": torch.sqrt, "abs": torch.abs, "atan2": torch.atan2,
+           "hypot": torch.hypot, "min": torch.minimum, "max": torch.maximum, "floor": torch.floor, "ceil": torch.ceil,
+           "round": torch.round, "trunc": torch.trunc}
+    py = expr.replace("^", "**")
+    if expr.startswith("if("):
+        ref = torch.where(a > b, a * a, b)
+    elif "%" in expr:
+        ref = torch.remainder(a, 0.3)
+    else:
+        ref = eval(py, {"__builtins__": {}}, env)
+    got = _pc(ctx, expr, inputs=["a", "b"])(a.cuda(), b.cuda()).cpu()
+    assert ((got - ref).abs() / ref.abs().clamp_min(1.0)).max().item() <= 1e-14
+
+
+@pytest.mark.parametrize("expr", ["a^3*b - sin(a*b)", "exp(-a^2)/(1+b^2)", "sqrt(a*a+b*b)*log(a+2)", "tanh(a)*atan(b) + a^b",
+                                  "hypot(a, b) + atan2(a, b)"])
+def test_derivative_vs_finite_difference(ctx, expr):
+    torch.manual_seed(4)
+    a = (torch.rand(257, dtype=torch.float64) + 0.2).cuda()
+    b = (torch.rand(257, dtype=torch.float64) + 0.2).cuda()
+    f = _pc(ctx, expr, inputs=["a", "b"])
+    for var, (da, db) in (("a", (1.0, 0.0)), ("b", (0.0, 1.0))):
+        h = 1e-6
+        fd = (f(a + h * da, b + h * db) - f(a - h * da, b - h * db)) / (2 * h)
+        d = _pc(ctx, expr, inputs=["a", "b"], derivatives=[var])(a, b)
+        assert (d - fd).abs().max().item() <= 1e-7 * max(1.0, fd.abs().max().item())
