@@ -132,6 +132,11 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
                    double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt,
                    double *d_cbar, double *d_mu);
 
+/* ReciprocalLaplacianFactor (power = 1: -k^2 * factor, ReciprocalLaplacianFactor.C:28-31) and
+ * ReciprocalLaplacianSquareFactor (power = 2: k^2 * k^2 * factor, ReciprocalLaplacianSquareFactor.C:28-32) as real
+ * arrays on the local reciprocal grid, for solvers that take their linear operator as a buffer. */
+int mrl_reciprocal_laplacian(mrl_ctx *ctx, int power, double factor, double *d_out);
+
 /* Generic k-space ABM update for caller-supplied reciprocal arrays (AdamsBashforthMoulton.C:94-99):
  *   ubar = (ubar0 + sum_i coef[i]*N[i]) / (1 - dt*L)   (L may be NULL: no division)
  * N[i] complex arrays of n_spec elements, L real array. */
@@ -214,6 +219,8 @@ int mrl_parsed_eval(mrl_parsed *p, const double *const *d_inputs, double *d_out,
 int mrl_dot(mrl_ctx *ctx, const double *d_a, const double *d_b, int64_t n, double *h_out);
 int mrl_norm2(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_out);
 int mrl_sum(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_out);
+/* TensorExtremeValuePostprocessor (src/postprocessors/TensorExtremeValuePostprocessor.C:30-44) */
+int mrl_minmax(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_min, double *h_max);
 /* DomainAction::average over the grid of a value-major field [grid][ncomp] -> h_out[ncomp] */
 int mrl_average(mrl_ctx *ctx, const double *d_a, int64_t ncomp, double *h_out);
 

@@ -100,6 +100,8 @@ SIGNATURES = {
     "mrl_dot": (_i32, [_vp, _vp, _vp, _i64, C.POINTER(_dbl)]),
     "mrl_norm2": (_i32, [_vp, _vp, _i64, C.POINTER(_dbl)]),
     "mrl_sum": (_i32, [_vp, _vp, _i64, C.POINTER(_dbl)]),
+    "mrl_minmax": (_i32, [_vp, _vp, _i64, C.POINTER(_dbl), C.POINTER(_dbl)]),
+    "mrl_reciprocal_laplacian": (_i32, [_vp, _i32, _dbl, _vp]),
     "mrl_average": (_i32, [_vp, _vp, _i64, C.POINTER(_dbl)]),
     "mrl_timer_start": (_i32, [_vp]),
     "mrl_timer_stop": (_i32, [_vp, C.POINTER(C.c_float)]),

@@ -85,6 +85,21 @@ __global__ void __launch_bounds__(256) k_ch_kspace(KspaceArgs a, const double2 *
   }
 }
 
+// ReciprocalLaplacianFactor (-k^2 * f, ReciprocalLaplacianFactor.C:28-31) / ReciprocalLaplacianSquareFactor
+// (k^2 * k^2 * f, ReciprocalLaplacianSquareFactor.C:28-32) as full reciprocal-grid arrays, for solvers that take
+// their linear operator as a buffer
+__global__ void __launch_bounds__(256) k_recip_factor(int power, double factor, long long n0, long long n1, long long n2,
+                                                       const double *__restrict__ k0, const double *__restrict__ k1,
+                                                       const double *__restrict__ k2, double *__restrict__ out) {
+#pragma clang fp contract(off)
+  const long long total = n0 * n1 * n2;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long i2 = e % n2, t = e / n2, i1 = t % n1, i0 = t / n1;
+    const double q = ksq(3, k0[i0], k1[i1], k2[i2]);
+    out[e] = power == 1 ? -q * factor : q * q * factor;
+  }
+}
+
 struct AbmArgs {
   int nterms;
   double coef[8];
@@ -235,6 +250,18 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
     MRL_TRY(ch_kspace_launch(ctx, cp, cbar, mubar, d_Nhat_new, ubar, d_Nhat_old, order, sub_dt));
   }
   return fft_inverse_serial(ctx, ubar, d_c_out, 1, 0);
+}
+
+int mrl_reciprocal_laplacian(mrl_ctx *ctx, int power, double factor, double *d_out) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!d_out || (power != 1 && power != 2))
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_reciprocal_laplacian: power must be 1 (-k^2 f) or 2 (k^4 f)");
+  const long long total = spec_count_local(ctx);
+  ProfScope ps(ctx, "recip_factor", 8.0 * total);
+  hipLaunchKernelGGL(k_recip_factor, dim3(grid_for(total)), dim3(256), 0, ctx->stream, power, factor, ctx->nrec[0],
+                     ctx->nrec[1], ctx->nrec[2], ctx->d_k[0], ctx->d_k[1], ctx->d_k[2], d_out);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
 }
 
 int mrl_kspace_abm(mrl_ctx *ctx, double *d_ubar_out, const double *d_ubar0, const double *const *d_N,

@@ -83,6 +83,48 @@ __global__ void __launch_bounds__(256) k_component_sums(const double *__restrict
   }
 }
 
+// min and max: partial[2b], partial[2b+1]
+__global__ void __launch_bounds__(256) k_minmax_partial(const double *__restrict__ a, long long n, double *__restrict__ partial) {
+  __shared__ double smin[4], smax[4];
+  double lo = INFINITY, hi = -INFINITY;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double v = a[i];
+    lo = fmin(lo, v);
+    hi = fmax(hi, v);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fmin(lo, __shfl_down(lo, off, 64));
+    hi = fmax(hi, __shfl_down(hi, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    smin[threadIdx.x >> 6] = lo;
+    smax[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+    partial[2 * blockIdx.x + 1] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+  }
+}
+
+__global__ void __launch_bounds__(64) k_minmax_final(const double *__restrict__ partial, int nb, double *__restrict__ out) {
+  double lo = INFINITY, hi = -INFINITY;
+  for (int i = threadIdx.x; i < nb; i += 64) {
+    lo = fmin(lo, partial[2 * i]);
+    hi = fmax(hi, partial[2 * i + 1]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fmin(lo, __shfl_down(lo, off, 64));
+    hi = fmax(hi, __shfl_down(hi, off, 64));
+  }
+  if (threadIdx.x == 0) {
+    out[0] = lo;
+    out[1] = hi;
+  }
+}
+
 static int red_blocks(long long n) {
   long long b = (n / 2 + 255) / 256;
   if (b > kRedBlocks) b = kRedBlocks;
@@ -161,6 +203,23 @@ int mrl_norm2(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_out) {
 
 int mrl_sum(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_out) {
   return sync_reduce(ctx, 0, d_a, nullptr, n, h_out, "mrl_sum");
+}
+
+/* TensorExtremeValuePostprocessor (src/postprocessors/TensorExtremeValuePostprocessor.C:30-44) */
+int mrl_minmax(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_min, double *h_max) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!d_a || n < 1 || !h_min || !h_max) return set_error(ctx, MRL_ERR_INVALID, "mrl_minmax: bad argument");
+  long long nb = (n + 255) / 256;
+  if (nb > kRedBlocks / 2) nb = kRedBlocks / 2;
+  double *slot = ctx->d_red + kScalarBase;
+  hipLaunchKernelGGL(k_minmax_partial, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_a, (long long)n, ctx->d_red);
+  hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(64), 0, ctx->stream, ctx->d_red, (int)nb, slot);
+  MRL_HIP(ctx, hipGetLastError());
+  double h[2];
+  MRL_TRY(read_scalars(ctx, slot, 2, h));
+  *h_min = h[0];
+  *h_max = h[1];
+  return MRL_OK;
 }
 
 int mrl_average(mrl_ctx *ctx, const double *d_a, int64_t ncomp, double *h_out) {

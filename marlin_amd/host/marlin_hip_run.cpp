@@ -5,6 +5,8 @@
 //
 //   marlin-hip-run problem=cahnhilliard dim=2 nx=20 ny=20 xmax=3 ymax=3 ic=c0.bin substeps=10 num_steps=10 dt=1e-3 out=dir
 //        (test/tests/cahnhilliard/cahnhilliard.i)
+//   marlin-hip-run problem=brusselator dim=2 nx=150 ny=150 xmax=2pi ymax=2pi ss=10 cs=0 order=2 num_steps=25 dt=0.5 out=dir
+//        (test/tests/solvers/diagonal.i; writes brusselator.csv with the columns of the reference's CSV output)
 //   marlin-hip-run problem=mechanics dim=3 nx=16 ny=16 nz=16 substeps=10 num_steps=3 dt=0.01 l_tol=1e-2 nl_rel_tol=2e-2
 //        nl_abs_tol=2e-2 out=dir          (test/tests/mechanics/mech3d.i)
 #include <cstdio>
@@ -127,6 +129,58 @@ static int run_mechanics(DomainAction & domain, const std::string & out)
   return 0;
 }
 
+// test/tests/solvers/diagonal.i: 2-D Brusselator, ABM orders 1-4 with 0-2 Adams-Moulton corrector steps
+static int run_brusselator(DomainAction & domain, const std::string & out)
+{
+  TensorProblem problem(domain);
+  const std::vector<std::pair<std::string, double>> consts = {{"A", argd("A", 1.0)}, {"B", argd("B", 3.5)}};
+  // [Initialize]
+  ParsedCompute::Params ic;
+  ic.buffer = "u";
+  ic.expression = arg("u0", "sin(x)*sin(y)");
+  ic.extra_symbols = true;
+  ParsedCompute(problem, "u", ic).computeBuffer();
+  problem.getBuffer("v") = DeviceTensor::zeros(domain.getNumberOfCells());
+  ReciprocalLaplacianFactor(problem, "Du", "Du", argd("Du", 1e-2)).computeBuffer();
+  ReciprocalLaplacianFactor(problem, "Dv", "Dv", argd("Dv", 1e-3)).computeBuffer();
+  // [Solve] in dependency order
+  auto root = std::make_shared<ComputeGroup>(problem, "root");
+  root->add(std::make_shared<ForwardFFT>(problem, "u_bar", "u_bar", "u"));
+  root->add(std::make_shared<ForwardFFT>(problem, "v_bar", "v_bar", "v"));
+  ParsedCompute::Params su;
+  su.buffer = "source_u";
+  su.expression = arg("source_u", "A - (B+1)*u +u^2*v");
+  su.inputs = {"u", "v"};
+  su.constants = consts;
+  root->add(std::make_shared<ParsedCompute>(problem, "source_u", su));
+  root->add(std::make_shared<ForwardFFT>(problem, "source_u_bar", "source_u_bar", "source_u"));
+  ParsedCompute::Params sv = su;
+  sv.buffer = "source_v";
+  sv.expression = arg("source_v", "B*u - u^2*v");
+  root->add(std::make_shared<ParsedCompute>(problem, "source_v", sv));
+  root->add(std::make_shared<ForwardFFT>(problem, "source_v_bar", "source_v_bar", "source_v"));
+  const std::size_t order = (std::size_t)argi("order", 2);
+  SplitOperatorABM solver(problem, "solver", (unsigned int)argi("ss", 10), root,
+                          {{"u", "u_bar", "Du", "source_u_bar"}, {"v", "v_bar", "Dv", "source_v_bar"}}, order, order,
+                          (std::size_t)argi("cs", 0));
+  Transient ex(problem, solver, argd("dt", 0.5));
+  double volume = 1.0;
+  for (int d = 0; d < domain.getDim(); ++d)
+    volume *= domain.getExtent(d);
+  std::ofstream csv(out + "/brusselator.csv");
+  csv.precision(17);
+  csv << "time,U,V,u_max,u_min,v_max,v_min\n0,0,0,0,0,0,0\n";
+  ex.execute((int)argi("num_steps", 25), [&](int) {
+    double umin, umax, vmin, vmax;
+    TensorPostprocessors::extreme(domain, problem.getBuffer("u"), umin, umax);
+    TensorPostprocessors::extreme(domain, problem.getBuffer("v"), vmin, vmax);
+    csv << problem.time() << ',' << TensorPostprocessors::integral(domain, problem.getBuffer("u"), volume) << ','
+        << TensorPostprocessors::integral(domain, problem.getBuffer("v"), volume) << ',' << umax << ',' << umin << ','
+        << vmax << ',' << vmin << "\n";
+  });
+  return 0;
+}
+
 int main(int argc, char ** argv)
 {
   for (int i = 1; i < argc; ++i)
@@ -164,6 +218,8 @@ int main(int argc, char ** argv)
       return run_cahnhilliard(domain, out);
     if (problem == "mechanics")
       return run_mechanics(domain, out);
+    if (problem == "brusselator")
+      return run_brusselator(domain, out);
     mooseError("unknown problem '" + problem + "'");
   }
   catch (const std::exception & e)

@@ -10,12 +10,17 @@
 //   ForwardEulerSolver              src/tensor_solver/ForwardEulerSolver.C:29-38
 //   MacroscopicShearTensor          test/src/tensor_computes/MacroscopicShearTensor.C:31-41
 //   FFTMechanics                    src/tensor_computes/FFTMechanics.C:96-163 (+ HyperElasticIsotropic)
+//   ParsedCompute, ForwardFFT, ReciprocalLaplacianFactor    src/tensor_computes/{ParsedCompute,PerformFFT,ReciprocalLaplacianFactor}.C
+//   SplitOperatorABM                src/tensor_solver/AdamsBashforthMoulton.C:60-178 for any number of variables, with
+//                                   the Adams-Moulton corrector (compute group evaluated operator by operator)
+//   TensorExtremeValuePostprocessor, TensorIntegralPostprocessor    src/postprocessors/*.C
 //   Transient                       MOOSE's executioner loop as far as the path needs it
 // The MOOSE factory / input parser is NOT mirrored: objects are constructed directly (marlin_hip_run.cpp).
 // All arithmetic happens in libmarlin_hip.so; this layer only owns handles, history and control flow.
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <map>
@@ -152,6 +157,7 @@ public:
   int getDim() const { return _dim; }
   const std::vector<int64_t> & getShape() const { return _n; }
   int64_t getNumberOfCells() const { return _n_real; }
+  double getExtent(int d) const { return _max[d] - _min[d]; }
   int64_t getReciprocalSize() const { return _n_recip; }
   /// real-space axis: linspace(min + dx/2, max - dx/2, n)  (DomainAction.C:246-251)
   std::vector<double> getAxis(int d) const
@@ -456,6 +462,224 @@ private:
   DeviceTensor & _tP;
   DeviceTensor * _applied;
   mrl_mech_stats _stats{};
+};
+
+/// ParsedCompute: pointwise expression of input buffers (and x, y, z, kx, ky, kz, k2, t with extra_symbols)
+class ParsedCompute : public TensorOperatorBase
+{
+public:
+  struct Params
+  {
+    std::string buffer, expression;
+    std::vector<std::string> inputs, complex_inputs, derivatives;
+    std::vector<std::pair<std::string, double>> constants;
+    bool extra_symbols = false, reciprocal = false;
+  };
+  ParsedCompute(TensorProblem & problem, const std::string & name, const Params & p)
+    : TensorOperatorBase(problem, name), _p(p), _u(getOutputBuffer(p.buffer))
+  {
+    std::vector<const char *> in, cn, dn;
+    std::vector<int> cplx;
+    std::vector<double> cv;
+    for (auto & n : _p.inputs)
+    {
+      in.push_back(n.c_str());
+      cplx.push_back(std::count(_p.complex_inputs.begin(), _p.complex_inputs.end(), n) ? 1 : 0);
+      _params.push_back(&getInputBuffer(n));
+    }
+    for (auto & c : _p.constants)
+    {
+      cn.push_back(c.first.c_str());
+      cv.push_back(c.second);
+    }
+    for (auto & d : _p.derivatives)
+      dn.push_back(d.c_str());
+    if (mrl_parsed_create(_domain.ctx(), &_parsed, _p.expression.c_str(), (int)in.size(), in.data(), cplx.data(), (int)cn.size(),
+                          cn.data(), cv.data(), (int)dn.size(), dn.data(), _p.extra_symbols, _p.reciprocal) != MRL_OK)
+      paramError("expression", mrl_last_error(_domain.ctx()));
+  }
+  ~ParsedCompute() { mrl_parsed_destroy(_parsed); }
+  void computeBuffer() override
+  {
+    const int64_t count = _p.reciprocal ? _domain.getReciprocalSize() : _domain.getNumberOfCells();
+    auto out = DeviceTensor::empty(count * (mrl_parsed_is_complex(_parsed) ? 2 : 1));
+    std::vector<const double *> in;
+    for (auto * t : _params)
+      in.push_back(t->data());
+    _domain.check(mrl_parsed_eval(_parsed, in.data(), out.data(), count, _time));
+    _u = out;
+  }
+
+private:
+  const Params _p;
+  DeviceTensor & _u;
+  std::vector<DeviceTensor *> _params;
+  mrl_parsed * _parsed = nullptr;
+};
+
+/// PerformFFT<true>: _u = _domain.fft(_input)   (PerformFFT.C:34-40)
+class ForwardFFT : public TensorOperatorBase
+{
+public:
+  ForwardFFT(TensorProblem & problem, const std::string & name, const std::string & buffer, const std::string & input)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer)), _input(getInputBuffer(input))
+  {
+  }
+  void computeBuffer() override { _u = _domain.fft(_input); }
+
+private:
+  DeviceTensor & _u;
+  DeviceTensor & _input;
+};
+
+/// ReciprocalLaplacianFactor (-k^2 f) / ReciprocalLaplacianSquareFactor (k^4 f)
+class ReciprocalLaplacianFactor : public TensorOperatorBase
+{
+public:
+  ReciprocalLaplacianFactor(TensorProblem & problem, const std::string & name, const std::string & buffer, double factor,
+                            int power = 1)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer)), _factor(factor), _power(power)
+  {
+  }
+  void computeBuffer() override
+  {
+    auto out = DeviceTensor::empty(_domain.getReciprocalSize());
+    _domain.check(mrl_reciprocal_laplacian(_domain.ctx(), _power, _factor, out.data()));
+    _u = out;
+  }
+
+private:
+  DeviceTensor & _u;
+  const double _factor;
+  const int _power;
+};
+
+/// AdamsBashforthMoulton for any number of split-operator variables, with the Adams-Moulton corrector
+class SplitOperatorABM : public TensorSolver
+{
+public:
+  struct VariableNames
+  {
+    std::string buffer, reciprocal_buffer, linear_reciprocal /* "0" = none */, nonlinear_reciprocal;
+  };
+  SplitOperatorABM(TensorProblem & problem, const std::string & name, unsigned int substeps,
+                   std::shared_ptr<TensorOperatorBase> root_compute, const std::vector<VariableNames> & vars,
+                   std::size_t predictor_order, std::size_t corrector_order, std::size_t corrector_steps)
+    : TensorSolver(problem, name, substeps, std::move(root_compute)), _predictor_order(predictor_order - 1),
+      _corrector_order(corrector_order - 1), _corrector_steps(corrector_steps)
+  {
+    if (predictor_order < 1 || predictor_order > 5)
+      paramError("predictor_order", "predictor_order > 0 & predictor_order <= 5");
+    if (corrector_order < 1 || corrector_order > 5)
+      paramError("corrector_order", "corrector_order > 0 & corrector_order <= 5");
+    const auto history = (unsigned int)std::max(_predictor_order, _corrector_order);  // AdamsBashforthMoulton.C:55-56
+    for (const auto & v : vars)
+      _variables.push_back(Variable{problem.getBuffer(v.buffer), problem.getBuffer(v.reciprocal_buffer),
+                                    v.linear_reciprocal == "0" ? nullptr : &problem.getBuffer(v.linear_reciprocal),
+                                    problem.getBuffer(v.nonlinear_reciprocal),
+                                    problem.getBufferOld(v.nonlinear_reciprocal, history)});
+  }
+
+protected:
+  struct Variable  // SplitOperatorBase.h:27-34
+  {
+    DeviceTensor & _buffer;
+    const DeviceTensor & _reciprocal_buffer;
+    const DeviceTensor * _linear_reciprocal;
+    const DeviceTensor & _nonlinear_reciprocal;
+    const std::vector<DeviceTensor> & _old_nonlinear_reciprocal;
+  };
+
+  /// u = ifft( (ubar0 + sum coef_i N_i) / (1 - dt L) )
+  void update(Variable & v, const DeviceTensor & ubar0, const std::vector<const double *> & N, const std::vector<double> & coef)
+  {
+    auto ubar = DeviceTensor::empty(ubar0.numel());
+    _domain.check(mrl_kspace_abm(_domain.ctx(), ubar.data(), ubar0.data(), N.data(), coef.data(), (int)N.size(),
+                                 v._linear_reciprocal ? v._linear_reciprocal->data() : nullptr, _sub_dt,
+                                 _domain.getReciprocalSize()));
+    v._buffer = _domain.ifft(ubar);
+  }
+
+  void substep() override
+  {
+    static const double beta[5][5] = {{1.0, 0.0, 0.0, 0.0, 0.0},
+                                      {3.0 / 2.0, -1.0 / 2.0, 0.0, 0.0, 0.0},
+                                      {23.0 / 12.0, -16.0 / 12.0, 5.0 / 12.0, 0.0, 0.0},
+                                      {55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -9.0 / 24.0, 0.0},
+                                      {190.0 / 720.0, -2774.0 / 720.0, 2616.0 / 720.0, -1274.0 / 720.0, 251.0 / 720.0}};
+    static const double alpha[5][5] = {{1.0, 0.0, 0.0, 0.0, 0.0},
+                                       {0.5, 0.5, 0.0, 0.0, 0.0},
+                                       {5.0 / 12.0, 8.0 / 12.0, -1.0 / 12.0, 0.0, 0.0},
+                                       {9.0 / 24.0, 19.0 / 24.0, -5.0 / 24.0, 1.0 / 24.0, 0.0},
+                                       {251.0 / 720.0, 646.0 / 720.0, -264.0 / 720.0, 106.0 / 720.0, -19.0 / 720.0}};
+    _compute->computeBuffer();
+    forwardBuffers();
+    // Adams-Bashforth predictor on all variables (constant dt)                       AdamsBashforthMoulton.C:80-102
+    for (auto & v : _variables)
+    {
+      const std::size_t n_old = v._old_nonlinear_reciprocal.size();
+      const std::size_t order = std::min(n_old, _predictor_order);
+      std::vector<const double *> N{v._nonlinear_reciprocal.data()};
+      std::vector<double> coef{_sub_dt * beta[order][0]};
+      for (std::size_t i = 0; i < order; ++i)
+      {
+        N.push_back(v._old_nonlinear_reciprocal[i].data());
+        coef.push_back(_sub_dt * beta[order][i + 1]);
+      }
+      update(v, v._reciprocal_buffer, N, coef);
+    }
+    if (_corrector_steps)                                                             // :117-177
+    {
+      _sub_time += _sub_dt;
+      std::vector<DeviceTensor> ubar_n, N_n;  // handle copies keep the step-n tensors alive
+      for (auto & v : _variables)
+      {
+        ubar_n.push_back(v._reciprocal_buffer);
+        N_n.push_back(v._nonlinear_reciprocal);
+      }
+      for (std::size_t j = 0; j < _corrector_steps; ++j)
+      {
+        _compute->computeBuffer();
+        forwardBuffers();
+        for (std::size_t k = 0; k < _variables.size(); ++k)
+        {
+          auto & v = _variables[k];
+          const std::size_t n_old = v._old_nonlinear_reciprocal.size();
+          const std::size_t order = std::min(n_old + 1, _corrector_order);
+          if (order == 0)
+            continue;
+          std::vector<const double *> N{v._nonlinear_reciprocal.data(), N_n[k].data()};
+          std::vector<double> coef{_sub_dt * alpha[order][0], _sub_dt * alpha[order][1]};
+          for (std::size_t i = 0; i + 1 < order; ++i)
+          {
+            N.push_back(v._old_nonlinear_reciprocal[i].data());
+            coef.push_back(_sub_dt * alpha[order][i + 2]);
+          }
+          update(v, ubar_n[k], N, coef);
+        }
+      }
+      _sub_time -= _sub_dt;
+    }
+  }
+
+  const std::size_t _predictor_order, _corrector_order, _corrector_steps;
+  std::vector<Variable> _variables;
+};
+
+/// TensorExtremeValuePostprocessor / TensorIntegralPostprocessor
+struct TensorPostprocessors
+{
+  static void extreme(DomainAction & d, const DeviceTensor & t, double & mn, double & mx)
+  {
+    d.check(mrl_minmax(d.ctx(), t.data(), (int64_t)t.numel(), &mn, &mx));
+  }
+  /// integral = average * domain volume   (TensorIntegralPostprocessor.C:29-38)
+  static double integral(DomainAction & d, const DeviceTensor & t, double volume)
+  {
+    double s = 0.0;
+    d.check(mrl_sum(d.ctx(), t.data(), (int64_t)t.numel(), &s));
+    return s / (double)t.numel() * volume;
+  }
 };
 
 /// MOOSE Transient as far as the path sees it: advanceState, then the solver at EXEC_TIMESTEP_BEGIN

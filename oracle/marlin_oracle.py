@@ -474,3 +474,95 @@ def gamma_closed_form(dom: Domain, A2: torch.Tensor) -> torch.Tensor:
     invQ = torch.where(Q == 0, torch.zeros_like(Q), 1.0 / Q)
     out = torch.einsum("...i,...j->...ij", s, q) * invQ.unsqueeze(-1).unsqueeze(-1)
     return dom.ifft_batched(out)
+
+
+# --------------------------------------------------------------------------------------
+# General (multi-variable) Adams-Bashforth-Moulton solver with the Adams-Moulton corrector
+# --------------------------------------------------------------------------------------
+class SplitOperatorABM:
+    """TensorSolver::computeBuffer + AdamsBashforthMoulton::substep for any number of variables, with the optional
+    corrector (src/tensor_solver/AdamsBashforthMoulton.C:48-178, SplitOperatorBase.C:39-64, TensorSolver.C:93-109).
+
+    `compute(state) -> None` is the root compute group: it reads the real-space buffers in `state` and (re)binds the
+    reciprocal buffers; `variables` = list of (buffer, reciprocal_buffer, linear_reciprocal tensor | None,
+    nonlinear_reciprocal).  History of the nonlinear reciprocal buffers follows TensorBuffer<T>::advanceState with the
+    TensorProblem rule that nothing advances while timeStep() <= 1.
+    """
+
+    def __init__(self, dom: Domain, state: dict, compute: Callable[[dict], None], variables, substeps: int,
+                 predictor_order: int = 2, corrector_order: int = 2, corrector_steps: int = 0):
+        self.dom, self.state, self.compute, self.vars = dom, state, compute, variables
+        self.substeps = substeps
+        self.pred = predictor_order - 1
+        self.corr = corrector_order - 1
+        self.csteps = corrector_steps
+        depth = max(self.pred, self.corr)                    # :55-56
+        self.hist = {v[3]: History(max_states=depth) for v in variables}
+        self.time_step = 0
+
+    def _advance_state(self):
+        if self.time_step <= 1:
+            return
+        for name, h in self.hist.items():
+            if name in self.state:
+                h.advance(self.state[name])
+
+    def substep(self, sub_dt: float):
+        s = self.state
+        self.compute(s)                                      # :63
+        for (u, rb, L, N) in self.vars:
+            old = self.hist[N].old
+            order = min(len(old), self.pred)                 # :90-91 (dt constant)
+            ubar = s[rb] + (sub_dt * AB_BETA[order][0]) * s[N]
+            for i in range(order):
+                ubar += (sub_dt * AB_BETA[order][i + 1]) * old[i]
+            if L is not None:
+                ubar /= (1.0 - sub_dt * L)
+            s[u] = self.dom.ifft(ubar)
+        if self.csteps:                                      # :117-177
+            ubar_n = [s[rb] for (_, rb, _, _) in self.vars]
+            N_n = [s[N] for (_, _, _, N) in self.vars] if self.corr > 0 else None
+            for _ in range(self.csteps):
+                self.compute(s)
+                for k, (u, rb, L, N) in enumerate(self.vars):
+                    old = self.hist[N].old
+                    order = min(len(old) + 1, self.corr)
+                    if order == 0:
+                        continue
+                    ubar = ubar_n[k] + (sub_dt * AM_ALPHA[order][0]) * s[N]
+                    ubar += (sub_dt * AM_ALPHA[order][1]) * N_n[k]
+                    for i in range(order - 1):
+                        ubar += (sub_dt * AM_ALPHA[order][i + 2]) * old[i]
+                    if L is not None:
+                        ubar /= (1.0 - sub_dt * L)
+                    s[u] = self.dom.ifft(ubar)
+
+    def step(self, dt: float):
+        self.time_step += 1
+        self._advance_state()
+        sub_dt = dt / self.substeps
+        for k in range(self.substeps):
+            self.substep(sub_dt)
+            if k < self.substeps - 1:
+                self._advance_state()
+
+
+def brusselator_problem(n: int = 150, A: float = 1.0, B: float = 3.5):
+    """test/tests/solvers/diagonal.i: 2-D n^2 on [0, 2 pi]^2, u0 = sin(x) sin(y), v0 = 0, Du = -1e-2 k^2, Dv = -1e-3 k^2."""
+    dom = Domain(2, [n, n], [2.0 * math.pi, 2.0 * math.pi])
+    state = {"u": (torch.sin(dom.axis[0]) * torch.sin(dom.axis[1])).expand(dom.shape).contiguous(),
+             "v": torch.zeros(dom.shape, dtype=F64)}
+    Du = reciprocal_laplacian_factor(dom, 1e-2)
+    Dv = reciprocal_laplacian_factor(dom, 1e-3)
+
+    def compute(s):
+        s["u_bar"] = dom.fft(s["u"])
+        s["v_bar"] = dom.fft(s["v"])
+        u, v = s["u"], s["v"]
+        s["source_u"] = (A - (B + 1.0) * u) + torch.pow(u, 2.0) * v           # 'A - (B+1)*u +u^2*v'
+        s["source_u_bar"] = dom.fft(s["source_u"])
+        s["source_v"] = B * u - torch.pow(u, 2.0) * v                          # 'B*u - u^2*v'
+        s["source_v_bar"] = dom.fft(s["source_v"])
+
+    variables = [("u", "u_bar", Du, "source_u_bar"), ("v", "v_bar", Dv, "source_v_bar")]
+    return dom, state, compute, variables

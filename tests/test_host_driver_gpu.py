@@ -64,3 +64,21 @@ def test_error_behaviour(tmp_path):
     out = subprocess.run([RUN, "problem=cahnhilliard", "dim=2", "nx=8", "ny=8", "xmax=1", "ymax=1", "ic=/nonexistent"],
                          capture_output=True, text=True)
     assert out.returncode == 1 and "cannot read" in out.stderr
+
+
+@pytest.mark.parametrize("name,ss,cs,order", [("diagonal_10_0_1", 10, 0, 1), ("diagonal_10_0_2", 10, 0, 2),
+                                              ("diagonal_10_0_3", 10, 0, 3), ("diagonal_20_0_4", 20, 0, 4),
+                                              ("diagonal_10_1_1", 10, 1, 1), ("diagonal_10_2_1", 10, 2, 1),
+                                              ("diagonal_10_2_2", 10, 2, 2)])
+def test_solver_cases(name, ss, cs, order, tmp_path):
+    """test/tests/solvers/tests (diagonal.i, CSVDiff): 150^2 Brusselator through the native ParsedCompute, ForwardFFT,
+    ReciprocalLaplacianFactor and the multi-variable ABM with Adams-Moulton corrector; min / max / integral per step
+    against the reference's gold CSV (14 significant digits)"""
+    g = load_golden("solvers_gold.npz")[name]
+    _run(["problem=brusselator", "dim=2", "nx=150", "ny=150", "xmax=2pi", "ymax=2pi", f"ss={ss}", f"cs={cs}", f"order={order}",
+          "num_steps=25", "dt=0.5"], tmp_path)
+    got = np.loadtxt(tmp_path / "brusselator.csv", delimiter=",", skiprows=1)
+    assert got.shape == g.shape
+    assert np.allclose(got[:, 0], g[:, 0])
+    err = np.abs(got[1:, 1:] - g[1:, 1:]) / np.maximum(1.0, np.abs(g[1:, 1:]))
+    assert err.max() <= 5e-11, err.max()

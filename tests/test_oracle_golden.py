@@ -148,3 +148,27 @@ def test_fft_roundtrip_gold():
         dom = mo.Domain(len(shape), list(shape), [1.0] * len(shape))
         a = torch.rand(shape, dtype=torch.float64)
         assert (dom.ifft(dom.fft(a)) - a).abs().max().item() < 1e-14
+
+
+SOLVER_CASES = [("diagonal_10_0_1", 10, 0, 1), ("diagonal_10_0_2", 10, 0, 2), ("diagonal_10_0_3", 10, 0, 3),
+                ("diagonal_20_0_4", 20, 0, 4), ("diagonal_10_1_1", 10, 1, 1), ("diagonal_10_2_1", 10, 2, 1),
+                ("diagonal_10_2_2", 10, 2, 2)]
+
+
+@pytest.mark.parametrize("name,ss,cs,order", SOLVER_CASES)
+def test_solver_gold_brusselator(name, ss, cs, order):
+    """test/tests/solvers/tests (diagonal.i): min/max/integral of u, v per step for ABM orders 1-4 and the AM
+    corrector; the gold CSV carries ~14 significant digits (MOOSE CSVDiff)."""
+    g = load_golden("solvers_gold.npz")[name]
+    dom, state, compute, variables = mo.brusselator_problem()
+    s = mo.SplitOperatorABM(dom, state, compute, variables, substeps=ss, predictor_order=order, corrector_order=order,
+                            corrector_steps=cs)
+    vol = (2.0 * math.pi) ** 2
+    worst = 0.0
+    for step in range(1, 26):
+        s.step(0.5)
+        u, v = state["u"], state["v"]
+        row = [u.mean().item() * vol, v.mean().item() * vol, u.max().item(), u.min().item(), v.max().item(), v.min().item()]
+        ref = g[step][1:]
+        worst = max(worst, max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(row, ref)))
+    assert worst <= 5e-12, worst
