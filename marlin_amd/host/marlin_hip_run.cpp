@@ -181,6 +181,50 @@ static int run_brusselator(DomainAction & domain, const std::string & out)
   return 0;
 }
 
+// test/tests/solvers/etdrk4_diffusion.i: 1-D diffusion with ETDRK4 and a zero nonlinear term
+static int run_etdrk4_diffusion(DomainAction & domain, const std::string & out)
+{
+  TensorProblem problem(domain);
+  const double D = argd("D", 0.05), k = argd("k", 1.0);
+  ParsedCompute::Params p0;
+  p0.buffer = "u0";
+  p0.expression = "sin(kk*x)";
+  p0.constants = {{"kk", k}};
+  p0.extra_symbols = true;
+  ParsedCompute(problem, "u0", p0).computeBuffer();
+  ParsedCompute::Params pu;
+  pu.buffer = "u";
+  pu.expression = "u0";
+  pu.inputs = {"u0"};
+  ParsedCompute(problem, "u", pu).computeBuffer();
+  ReciprocalLaplacianFactor(problem, "L", "L", D).computeBuffer();
+  problem.getBuffer("zero") = DeviceTensor::zeros(2 * domain.getReciprocalSize());  // ConstantReciprocalTensor
+  auto root = std::make_shared<ComputeGroup>(problem, "root");
+  root->add(std::make_shared<ForwardFFT>(problem, "u_bar", "u_bar", "u"));
+  ParsedCompute::Params pe;
+  pe.buffer = "u_exact";
+  pe.expression = "u0*exp(-DD*kk^2*t)";
+  pe.inputs = {"u0"};
+  pe.constants = {{"DD", D}, {"kk", k}};
+  pe.extra_symbols = true;
+  root->add(std::make_shared<ParsedCompute>(problem, "u_exact", pe));
+  ParsedCompute::Params pd;
+  pd.buffer = "u_diff_sq";
+  pd.expression = "(u - u_exact)^2";
+  pd.inputs = {"u", "u_exact"};
+  root->add(std::make_shared<ParsedCompute>(problem, "u_diff_sq", pd));
+  ETDRK4Solver solver(problem, "solver", (unsigned int)argi("ss", 1), root, {{"u", "u_bar", "L", "zero"}});
+  Transient ex(problem, solver, argd("dt", 10.0));
+  std::ofstream csv(out + "/etdrk4.csv");
+  csv.precision(17);
+  csv << "time,mse,rmse\n0,0,0\n";
+  ex.execute((int)argi("num_steps", 10), [&](int) {
+    const double mse = TensorPostprocessors::integral(domain, problem.getBuffer("u_diff_sq"), domain.getExtent(0));
+    csv << problem.time() << ',' << mse << ',' << std::sqrt(mse) << "\n";
+  });
+  return 0;
+}
+
 int main(int argc, char ** argv)
 {
   for (int i = 1; i < argc; ++i)
@@ -220,6 +264,8 @@ int main(int argc, char ** argv)
       return run_mechanics(domain, out);
     if (problem == "brusselator")
       return run_brusselator(domain, out);
+    if (problem == "etdrk4_diffusion")
+      return run_etdrk4_diffusion(domain, out);
     mooseError("unknown problem '" + problem + "'");
   }
   catch (const std::exception & e)

@@ -82,3 +82,12 @@ def test_solver_cases(name, ss, cs, order, tmp_path):
     assert np.allclose(got[:, 0], g[:, 0])
     err = np.abs(got[1:, 1:] - g[1:, 1:]) / np.maximum(1.0, np.abs(g[1:, 1:]))
     assert err.max() <= 5e-11, err.max()
+
+
+def test_etdrk4_case(tmp_path):
+    """test/tests/solvers/tests (etdrk4_diffusion.i): ETDRK4Solver built from fused parsed kernels vs gold mse / rmse"""
+    g = load_golden("solvers_gold.npz")["etdrk4_diffusion_rmse"]
+    _run(["problem=etdrk4_diffusion", "dim=1", "nx=64", "xmax=2pi", "D=0.05", "k=1.0", "ss=1", "dt=10", "num_steps=10"], tmp_path)
+    got = np.loadtxt(tmp_path / "etdrk4.csv", delimiter=",", skiprows=1)
+    assert got.shape == g.shape
+    assert np.abs(got[1:, 1:] - g[1:, 1:]).max() <= 1e-12

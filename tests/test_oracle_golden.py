@@ -172,3 +172,28 @@ def test_solver_gold_brusselator(name, ss, cs, order):
         ref = g[step][1:]
         worst = max(worst, max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(row, ref)))
     assert worst <= 5e-12, worst
+
+
+def test_etdrk4_gold():
+    """test/tests/solvers/etdrk4_diffusion.i: 1-D diffusion, ETDRK4 with a zero nonlinear term; the postprocessed buffer
+    u_diff_sq is the one left by the LAST compute-group evaluation of the substep (stage d vs the exact solution at the
+    substep's start time), which is what the gold CSV records"""
+    g = load_golden("solvers_gold.npz")["etdrk4_diffusion_rmse"]
+    D, k, n = 0.05, 1.0, 64
+    dom = mo.Domain(1, [n], [2.0 * math.pi])
+    u0 = torch.sin(k * dom.axis[0])
+    state = {"u": u0.clone(), "u0": u0, "zero": torch.zeros(dom.rshape, dtype=torch.complex128)}
+    L = mo.reciprocal_laplacian_factor(dom, D)
+    solver = None
+
+    def compute(s):
+        s["u_bar"] = dom.fft(s["u"])
+        s["u_exact"] = s["u0"] * torch.exp(torch.tensor(-D * k ** 2.0 * solver.sub_time, dtype=torch.float64))
+        s["u_diff_sq"] = torch.pow(s["u"] - s["u_exact"], 2.0)
+
+    solver = mo.ETDRK4(dom, state, compute, [("u", "u_bar", L, "zero")])
+    for step in range(1, 11):
+        solver.step(10.0)
+        mse = state["u_diff_sq"].mean().item() * 2.0 * math.pi
+        assert abs(mse - g[step][1]) <= 1e-12 * max(1.0, abs(g[step][1]))
+        assert abs(math.sqrt(mse) - g[step][2]) <= 1e-12
