@@ -177,6 +177,19 @@ int mrl_mech_stress(mrl_ctx *ctx, const double *d_F, const double *d_K, const do
 int mrl_mech_tangent_apply(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu,
                            const double *d_dF, double *d_out);
 
+/* Building blocks of the same solve on a SLAB context (BASELINE configs[4]); the Newton-CG driver, the exchanges and
+ * the all-reduce of the CG scalars belong to the caller (marlin_amd/slab.py: SlabMechanics):
+ *   G(A):  mrl_relayout(to field-major) -> per component mrl_slab_fwd_local / exchange / mrl_slab_fwd_finish
+ *          -> mrl_slab_gamma_project -> per component mrl_slab_inv_local / exchange / mrl_slab_inv_finish -> mrl_relayout
+ *   mrl_mech_stress / mrl_mech_tangent_apply are pointwise and work on the local real slab of any context;
+ *   mrl_dot / mrl_norm2 / mrl_sum return the LOCAL value (the caller all-reduces), mrl_axpby is the vector update. */
+/* in-place Gamma projection of field-major spectra [D*D][x_me][ny][nzc] (complex), times scale */
+int mrl_slab_gamma_project(mrl_ctx *ctx, double *d_spec, double scale);
+/* value-major [npts][ncomp] <-> field-major [ncomp][npts] */
+int mrl_relayout(mrl_ctx *ctx, int to_field_major, const double *d_in, double *d_out, int64_t npts, int32_t ncomp);
+/* out = a*x + b*y (out may alias x or y) */
+int mrl_axpby(mrl_ctx *ctx, double a, const double *d_x, double b, const double *d_y, double *d_out, int64_t n);
+
 typedef struct mrl_mech_params {
   double l_tol;       /* FFTMechanics l_tol */
   int64_t l_max_its;  /* 0 = number of cells (FFTMechanics.C:63-64) */
@@ -221,7 +234,8 @@ int mrl_norm2(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_out);
 int mrl_sum(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_out);
 /* TensorExtremeValuePostprocessor (src/postprocessors/TensorExtremeValuePostprocessor.C:30-44) */
 int mrl_minmax(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_min, double *h_max);
-/* DomainAction::average over the grid of a value-major field [grid][ncomp] -> h_out[ncomp] */
+/* DomainAction::average over the grid of a value-major field [grid][ncomp] -> h_out[ncomp]; on a slab context the
+ * local sum divided by the GLOBAL point count (the sum over ranks is the average) */
 int mrl_average(mrl_ctx *ctx, const double *d_a, int64_t ncomp, double *h_out);
 
 /* ---- timing on the context stream (hipEvents): used by bench.py for roofline.achieved ---- */

@@ -238,6 +238,48 @@ __global__ void __launch_bounds__(256) k_gamma_project(double2 *__restrict__ spe
   }
 }
 
+// in-place projection of FIELD-MAJOR spectra [D*D][n0][n1][n2] (complex), times `scale`; `off` = internal axis of
+// user axis 0 (slab contexts are left-aligned, serial ones right-aligned)
+template <int D>
+__global__ void __launch_bounds__(256) k_gamma_project_fm(double2 *__restrict__ spec, long long n0, long long n1,
+                                                           long long n2, const double *__restrict__ k0,
+                                                           const double *__restrict__ k1, const double *__restrict__ k2,
+                                                           int off, double scale) {
+  const long long total = n0 * n1 * n2;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long i2 = e % n2, t = e / n2, i1 = t % n1, i0 = t / n1;
+    const double kk[3] = {k0[i0], k1[i1], k2[i2]};
+    double q[3];
+#pragma unroll
+    for (int d = 0; d < D; ++d) q[d] = kk[off + d];
+    double Q = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) Q += q[d] * q[d];
+    const double inv = (Q == 0.0) ? 0.0 : scale / Q;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double2 s = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double2 v = spec[(long long)(i * D + k) * total + e];
+        s.x += v.x * q[k];
+        s.y += v.y * q[k];
+      }
+      s.x *= inv;
+      s.y *= inv;
+#pragma unroll
+      for (int j = 0; j < D; ++j) spec[(long long)(i * D + j) * total + e] = make_double2(s.x * q[j], s.y * q[j]);
+    }
+  }
+}
+
+// out = a*x + b*y
+__global__ void __launch_bounds__(256) k_axpby(double a, const double *x, double b, const double *y, double *out, long long n) {
+#pragma clang fp contract(off)
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    out[i] = a * x[i] + b * y[i];
+}
+
 // ---- CG vector kernels (device-resident scalars S) ---------------------------------------------
 // r = b - Ax ; p = r ; partial sum r.r
 __global__ void __launch_bounds__(256) k_cg_init(const double *__restrict__ b, const double *__restrict__ Ax,
@@ -320,10 +362,13 @@ static inline int grid_for(long long n) {
   return (int)b;
 }
 
-static int check_dim(mrl_ctx *ctx, const char *what) {
+// serial = false: pointwise operators, valid on the local slab of any context
+static int check_dim(mrl_ctx *ctx, const char *what, bool serial = true) {
   if (ctx->dim != 2 && ctx->dim != 3)
     return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: mechanics needs a 2-D or 3-D domain", what);
-  if (ctx->nranks > 1) return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: serial contexts only", what);
+  if (!serial) return MRL_OK;
+  if (ctx->nranks > 1)
+    return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: serial contexts only (slab contexts: mrl_slab_gamma_project + the slab FFT stages)", what);
   if (ctx->spectrum != MRL_SPECTRUM_HALF)
     return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: needs spectrum = MRL_SPECTRUM_HALF", what);
   return MRL_OK;
@@ -438,9 +483,50 @@ int mrl_gamma_apply(mrl_ctx *ctx, const double *d_A, double *d_out) {
   return gamma_launch(ctx, d_A, d_out, 1.0);
 }
 
+int mrl_slab_gamma_project(mrl_ctx *ctx, double *d_spec, double scale) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_dim(ctx, "mrl_slab_gamma_project", false));
+  if (!d_spec) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_project: null buffer");
+  const long long nspec = spec_count_local(ctx);
+  ProfScope ps(ctx, "gamma_project_fm", 32.0 * (double)nspec * ctx->dim * ctx->dim);
+  const int nb = grid_for(nspec);
+  if (ctx->dim == 3)
+    hipLaunchKernelGGL(k_gamma_project_fm<3>, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2 *>(d_spec),
+                       ctx->nrec[0], ctx->nrec[1], ctx->nrec[2], ctx->d_k[0], ctx->d_k[1], ctx->d_k[2], ctx->off, scale);
+  else
+    hipLaunchKernelGGL(k_gamma_project_fm<2>, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2 *>(d_spec),
+                       ctx->nrec[0], ctx->nrec[1], ctx->nrec[2], ctx->d_k[0], ctx->d_k[1], ctx->d_k[2], ctx->off, scale);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+int mrl_relayout(mrl_ctx *ctx, int to_field_major, const double *d_in, double *d_out, int64_t npts, int32_t ncomp) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!d_in || !d_out || d_in == d_out || npts < 0 || ncomp < 1)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_relayout: bad argument (in and out must be distinct)");
+  if (npts == 0) return MRL_OK;
+  ProfScope ps(ctx, to_field_major ? "to_field_major" : "to_value_major", 16.0 * npts * ncomp);
+  if (to_field_major)
+    hipLaunchKernelGGL(k_relayout<true>, dim3(grid_for(npts * ncomp)), dim3(256), 0, ctx->stream, d_in, d_out, (long long)npts, ncomp);
+  else
+    hipLaunchKernelGGL(k_relayout<false>, dim3(grid_for(npts * ncomp)), dim3(256), 0, ctx->stream, d_in, d_out, (long long)npts, ncomp);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+int mrl_axpby(mrl_ctx *ctx, double a, const double *d_x, double b, const double *d_y, double *d_out, int64_t n) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!d_x || !d_y || !d_out || n < 0) return set_error(ctx, MRL_ERR_INVALID, "mrl_axpby: bad argument");
+  if (n == 0) return MRL_OK;
+  ProfScope ps(ctx, "axpby", 24.0 * n);
+  hipLaunchKernelGGL(k_axpby, dim3(grid_for(n)), dim3(256), 0, ctx->stream, a, d_x, b, d_y, d_out, (long long)n);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
 int mrl_mech_stress(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu, double *d_P) {
   if (!ctx) return MRL_ERR_INVALID;
-  MRL_TRY(check_dim(ctx, "mrl_mech_stress"));
+  MRL_TRY(check_dim(ctx, "mrl_mech_stress", false));
   if (!d_F || !d_K || !d_mu || !d_P) return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_stress: null buffer");
   return stress_launch(ctx, d_F, d_K, d_mu, d_P, false);
 }
@@ -448,7 +534,7 @@ int mrl_mech_stress(mrl_ctx *ctx, const double *d_F, const double *d_K, const do
 int mrl_mech_tangent_apply(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu,
                            const double *d_dF, double *d_out) {
   if (!ctx) return MRL_ERR_INVALID;
-  MRL_TRY(check_dim(ctx, "mrl_mech_tangent_apply"));
+  MRL_TRY(check_dim(ctx, "mrl_mech_tangent_apply", false));
   if (!d_F || !d_K || !d_mu || !d_dF || !d_out)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_tangent_apply: null buffer");
   return tangent_launch(ctx, d_F, d_K, d_mu, d_dF, false, d_out, false);

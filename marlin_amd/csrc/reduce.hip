@@ -226,13 +226,13 @@ int mrl_average(mrl_ctx *ctx, const double *d_a, int64_t ncomp, double *h_out) {
   if (!ctx) return MRL_ERR_INVALID;
   if (!d_a || !h_out || ncomp < 1 || ncomp > 16)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_average: need 1 <= ncomp <= 16");
-  if (ctx->nranks > 1)
-    return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_average: reduce the per-rank sums across ranks in the caller");
+  // slab contexts: the local sum over the GLOBAL point count, so that the sum over ranks is the average
   const long long npts = real_count_local(ctx);
+  const double nglob = (double)ctx->n[0] * (double)ctx->n[1] * (double)ctx->n[2];
   double *slot = ctx->d_red + kScalarBase;
   MRL_TRY(component_sums_async(ctx, d_a, npts, (int)ncomp, slot));
   MRL_TRY(read_scalars(ctx, slot, (int)ncomp, h_out));
-  for (int c = 0; c < ncomp; ++c) h_out[c] /= (double)npts;
+  for (int c = 0; c < ncomp; ++c) h_out[c] /= nglob;
   return MRL_OK;
 }
 
