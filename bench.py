@@ -134,7 +134,8 @@ def main():
             sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    dev = local_rank % torch.cuda.device_count()   # (several ranks on one GPU only in the single-GPU smoke run)
+    torch.cuda.set_device(dev)
 
     from marlin_amd.api import Context, ch_params
 
@@ -149,7 +150,7 @@ def main():
         import torch.distributed as dist
         from marlin_amd.slab import SlabCahnHilliard
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         solver = SlabCahnHilliard(3, shape, L, p, world, rank, nsub=args.nsub)
         step = solver.substep
         barrier = dist.barrier

@@ -441,11 +441,15 @@ class FFTMechanicsOracle:
 # rfftn over the leading `dim` axes of a [..., 3, 3] tensor)
 def _fft_batched(self: Domain, t):
     axes = tuple(range(self.dim))
+    if self.slab_c2c:                       # FFT_SLAB: full c2c transform (DomainAction.C:279-281, 869-938)
+        return torch.fft.fftn(t, dim=axes)
     return torch.fft.rfftn(t, dim=axes)
 
 
 def _ifft_batched(self: Domain, t):
     axes = tuple(range(self.dim))
+    if self.slab_c2c:                       # ifftSlab returns torch::real (DomainAction.C:1016)
+        return torch.real(torch.fft.ifftn(t, dim=axes))
     return torch.fft.irfftn(t, self.shape, dim=axes)
 
 
