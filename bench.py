@@ -120,9 +120,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=256, help="base grid edge (per-GPU work = n^3 points)")
+    ap.add_argument("--grid", dest="n", type=int, default=256, help="base grid edge (per-GPU work = n^3 points)")
     ap.add_argument("--cpu-steps", type=int, default=24, help="substeps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke runs)")
     ap.add_argument("--nsub", type=int, default=4, help="kz sub-blocks the slab substep is pipelined over (N > 1)")
     args = ap.parse_args()
 
@@ -150,7 +151,10 @@ def main():
         import torch.distributed as dist
         from marlin_amd.slab import SlabCahnHilliard
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend)
         solver = SlabCahnHilliard(3, shape, L, p, world, rank, nsub=args.nsub)
         step = solver.substep
         barrier = dist.barrier
@@ -185,7 +189,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -65,6 +65,12 @@ class SlabExchange:
         if self.mode == "a2a":
             return dist.all_to_all_single(recv, send, self.recv_split, self.send_split, group=self.group,
                                           async_op=async_op)
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":
+            # smoke-test path only (several ranks sharing one GPU, where RCCL refuses to run): stage through the host
+            hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+            self.run(hs, hr)
+            recv.copy_(hr)
+            return _WorkList([]) if async_op else None
         # own chunk: local copy; the others: one isend + one irecv per peer
         r = self.rank
         recv[self.recv_off[r]:self.recv_off[r] + self.recv_split[r]].copy_(
