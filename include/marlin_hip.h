@@ -109,13 +109,18 @@ int mrl_slab_inv_finish(mrl_ctx *ctx, const double *d_recv, double *d_real_out);
 /* ---- Cahn-Hilliard semi-implicit substep ------------------------------------------------ */
 enum mrl_free_energy {
   MRL_FE_DOUBLE_WELL = 0, /* f = A*c^2*(c-1)^2           coef = {A}        (examples/cahn_hilliard/cahnhilliard2.i:74-80) */
-  MRL_FE_PFHUB = 1        /* f = rho*(c-ca)^2*(cb-c)^2   coef = {rho,ca,cb} (benchmarks/01_spinodal_decomposition/1a_solver.i:62-70) */
+  MRL_FE_PFHUB = 1,       /* f = rho*(c-ca)^2*(cb-c)^2   coef = {rho,ca,cb} (benchmarks/01_spinodal_decomposition/1a_solver.i:62-70) */
+  MRL_FE_PARSED = 2       /* any ParsedCompute expression: `parsed` = mrl_parsed_create(free energy, inputs = {c},
+                             derivatives = {c}); on fast-path shapes the generated chemical potential is compiled INTO the
+                             forward z pass (hiprtc), so a user free energy runs at the speed of the built-in ones */
 };
+struct mrl_parsed;
 typedef struct mrl_ch_params {
   int32_t family;  /* enum mrl_free_energy */
   double coef[4];
   double mobility; /* ReciprocalLaplacianFactor factor:        Mbar = -k^2 * M        (ReciprocalLaplacianFactor.C:28-31) */
   double kappa;    /* ReciprocalLaplacianSquareFactor factor:  Lbar = k^2 * k^2 * f   (ReciprocalLaplacianSquareFactor.C:28-32) */
+  struct mrl_parsed *parsed; /* MRL_FE_PARSED only: one real input, real result; must outlive the calls that use it */
 } mrl_ch_params;
 
 /* ParsedCompute f'(c) (src/tensor_computes/ParsedCompute.C:184-265) for the built-in families */

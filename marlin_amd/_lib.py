@@ -31,6 +31,7 @@ class MrlChParams(C.Structure):
         ("coef", C.c_double * 4),
         ("mobility", C.c_double),
         ("kappa", C.c_double),
+        ("parsed", C.c_void_p),
     ]
 
 

@@ -11,7 +11,7 @@ from . import _lib
 from ._lib import MrlChParams, MrlDomain, MrlMechParams, MrlMechStats
 
 SPECTRUM_HALF, SPECTRUM_FULL = 0, 1
-FE_DOUBLE_WELL, FE_PFHUB = 0, 1
+FE_DOUBLE_WELL, FE_PFHUB, FE_PARSED = 0, 1, 2
 
 
 class MarlinHipError(RuntimeError):
@@ -51,8 +51,13 @@ def partition(total: int, nranks: int, weights: Optional[Sequence[int]] = None) 
     return list(out)
 
 
-def ch_params(family=FE_DOUBLE_WELL, coef=(0.1,), mobility=0.2, kappa=-0.001) -> MrlChParams:
+def ch_params(family=FE_DOUBLE_WELL, coef=(0.1,), mobility=0.2, kappa=-0.001, parsed=None) -> MrlChParams:
+    """parsed: a ParsedCompute of the free energy differentiated w.r.t. its single input (family is then FE_PARSED)"""
     p = MrlChParams()
+    if parsed is not None:
+        family = FE_PARSED
+        p.parsed = parsed.h
+        p._keepalive = parsed
     p.family = family
     for i, v in enumerate(coef):
         p.coef[i] = v

@@ -137,8 +137,13 @@ static const double kBeta[5][5] = {
 
 int ch_check_params(mrl_ctx *ctx, const mrl_ch_params *p, ChP &cp) {
   if (!p) return set_error(ctx, MRL_ERR_INVALID, "null mrl_ch_params");
-  if (p->family != MRL_FE_DOUBLE_WELL && p->family != MRL_FE_PFHUB)
+  if (p->family != MRL_FE_DOUBLE_WELL && p->family != MRL_FE_PFHUB && p->family != MRL_FE_PARSED)
     return set_error(ctx, MRL_ERR_INVALID, "unknown free energy family %d", p->family);
+  cp.parsed = nullptr;
+  if (p->family == MRL_FE_PARSED) {
+    MRL_TRY(parsed_check_mu(ctx, p->parsed));
+    cp.parsed = p->parsed;
+  }
   cp.family = p->family;
   cp.c0 = p->coef[0];
   cp.c1 = p->coef[1];
@@ -157,6 +162,7 @@ static inline int grid_for(long long n, int per_thread = 1) {
 
 int ch_mu_launch(mrl_ctx *ctx, const ChP &cp, const double *c, double *mu, long long count) {
   if (count == 0) return MRL_OK;
+  if (cp.family == MRL_FE_PARSED) return parsed_eval1(cp.parsed, c, mu, count);
   if ((reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(mu)) & 15)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_mu: pointers must be 16-byte aligned");
   ProfScope ps(ctx, "ch_mu", 16.0 * (double)count);

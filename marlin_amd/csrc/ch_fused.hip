@@ -161,11 +161,13 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
   MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nspec));
   cplx *w_c = reinterpret_cast<cplx *>(ctx->d_work[1]);
   cplx *w_mu = reinterpret_cast<cplx *>(ctx->d_work[2]);
-  p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2};
+  p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
   const double h = 16.0 * nspec;  // bytes of one complex half-spectrum array
   {
     ProfScope ps(ctx, "ch_A_z_fwd", 8.0 * nreal + 2.0 * h + (mu ? 8.0 * nreal : 0.0));
-    if (cp.family == MRL_FE_DOUBLE_WELL) {
+    if (cp.family == MRL_FE_PARSED) {
+      MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, c_in, w_c, w_mu, mu, nx * ny));
+    } else if (cp.family == MRL_FE_DOUBLE_WELL) {
       MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_c, w_mu, mu, chp, nx * ny))));
     } else {
       MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, w_c, w_mu, mu, chp, nx * ny))));

@@ -652,6 +652,8 @@ struct mrl_parsed {
   std::string text, source, err;
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;
+  // k_z_fwd<N, CH> instances with this expression compiled in as the chemical potential (MRL_FE_PARSED)
+  std::map<int, std::pair<hipModule_t, hipFunction_t>> zfwd;
 };
 
 struct ExprArgsHost {
@@ -741,6 +743,114 @@ static int compile_module(mrl_parsed *p) {
   return MRL_OK;
 }
 
+// ---- the parsed expression as the chemical potential of the fused Cahn-Hilliard z pass ---------------------
+static const char *kPow2Embed =
+#include "pow2_embed.inc"
+    ;
+
+namespace mrl {
+
+int parsed_check_mu(mrl_ctx *ctx, const mrl_parsed *p) {
+  if (!p) return set_error(ctx, MRL_ERR_INVALID, "MRL_FE_PARSED: mrl_ch_params.parsed is null");
+  if (p->ctx != ctx) return set_error(ctx, MRL_ERR_INVALID, "MRL_FE_PARSED: the expression belongs to another context");
+  if (p->inputs.size() != 1 || p->input_cplx[0] || p->out_cplx || p->extra)
+    return set_error(ctx, MRL_ERR_INVALID,
+                     "MRL_FE_PARSED: the free energy must be a real expression of exactly one real input (no extra symbols)");
+  if (p->const_values.size() > 8) return set_error(ctx, MRL_ERR_INVALID, "MRL_FE_PARSED: at most 8 named constants");
+  return MRL_OK;
+}
+
+int parsed_eval1(mrl_parsed *p, const double *c, double *mu, long long n) {
+  const double *in[1] = {c};
+  return mrl_parsed_eval(p, in, mu, n, 0.0);
+}
+
+// the same tree as the stand-alone kernel, emitted as a device function of (c, named constants)
+static int build_mu_function(mrl_parsed *p, std::string &out) {
+  ex::Gen g;
+  g.syms[p->inputs[0]] = ex::Val{"c_", false};
+  for (size_t i = 0; i < p->const_names.size(); ++i) g.syms[p->const_names[i]] = ex::Val{"k_[" + std::to_string(i) + "]", false};
+  ex::Val r;
+  try {
+    r = g.gen(p->ast);
+  } catch (const ex::Error &er) {
+    p->err = er.msg;
+    return MRL_ERR_INVALID;
+  }
+  std::string body = g.body.str();
+  // the kernel generator indents for a loop body and names the temporaries t<i>: reuse as is
+  // contraction is switched off for the expression only: the transform around it keeps the AOT build's code generation,
+  // so the run-time compiled pass is bit-identical to a built-in family with the same tree
+  out = "namespace mrl { namespace p2 {\n__device__ double mrl_user_mu(double c_, const double *k_) {\n#pragma clang fp contract(off)\n" + body + "    return " + r.code +
+        ";\n}\n} }\n";
+  return MRL_OK;
+}
+
+int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const double *in, cplx *out0, cplx *out1, double *mu_out,
+                        long long nlines) {
+  if (N != 64 && N != 128 && N != 256 && N != 512) return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
+  auto it = p->zfwd.find(N);
+  if (it == p->zfwd.end()) {
+    std::string mu_fn;
+    if (build_mu_function(p, mu_fn) != MRL_OK) return set_error(ctx, MRL_ERR_INVALID, "expression: %s", p->err.c_str());
+    // device-only translation unit: vector types and the public enum values, the embedded kernel headers, the generated
+    // chemical potential; k_z_fwd<N, 1, MRL_FE_PARSED> is instantiated through a name expression
+    std::string src =
+        "typedef double2 cplx;\n"
+        "#define MRL_FE_DOUBLE_WELL 0\n#define MRL_FE_PFHUB 1\n#define MRL_FE_PARSED 2\n"
+        "namespace mrl { typedef ::cplx cplx; }\n";
+    src += kPow2Embed;
+    src += mu_fn;
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "mrl_z_fwd_parsed.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+      return set_error(ctx, MRL_ERR_HIP, "hiprtcCreateProgram failed");
+    const std::string name = "mrl::p2::k_z_fwd<" + std::to_string(N) + ", 1, 2>";
+    hiprtcAddNameExpression(prog, name.c_str());
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    if (hiprtcCompileProgram(prog, 3, opts) != HIPRTC_SUCCESS) {
+      size_t ls = 0;
+      hiprtcGetProgramLogSize(prog, &ls);
+      std::string log(ls, '\0');
+      if (ls) hiprtcGetProgramLog(prog, &log[0]);
+      hiprtcDestroyProgram(&prog);
+      return set_error(ctx, MRL_ERR_HIP, "hiprtc compilation of the fused z pass failed: %s", log.c_str());
+    }
+    const char *lowered = nullptr;
+    if (hiprtcGetLoweredName(prog, name.c_str(), &lowered) != HIPRTC_SUCCESS || !lowered) {
+      hiprtcDestroyProgram(&prog);
+      return set_error(ctx, MRL_ERR_HIP, "hiprtcGetLoweredName failed for %s", name.c_str());
+    }
+    const std::string mangled = lowered;
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, mangled.c_str()) != hipSuccess)
+      return set_error(ctx, MRL_ERR_HIP, "loading the run-time compiled z pass failed");
+    it = p->zfwd.emplace(N, std::make_pair(mod, fn)).first;
+  }
+  // the argument block of k_z_fwd(const double*, cplx*, cplx*, double*, ChDev, long long, const cplx*)
+  struct ChDevHost {
+    int family;
+    double c0, c1, c2;
+    double k[8];
+  } chp{};
+  chp.family = MRL_FE_PARSED;
+  for (size_t i = 0; i < p->const_values.size(); ++i) chp.k[i] = p->const_values[i];
+  const cplx *tw = ctx->ax[2].d_tw;
+  void *params[] = {&in, &out0, &out1, &mu_out, &chp, &nlines, &tw};
+  const int LPB = 4096 / N, LP = N + N / 16;
+  const size_t lds = sizeof(cplx) * (size_t)(N + (4096 / N) * LP);
+  const long long nb = (nlines + LPB - 1) / LPB;
+  MRL_HIP(ctx, hipModuleLaunchKernel(it->second.second, (unsigned)nb, 1, 1, 256, 1, 1, (unsigned)lds, ctx->stream, params, nullptr));
+  return MRL_OK;
+}
+
+}  // namespace mrl
+
 extern "C" {
 
 int mrl_parsed_create(mrl_ctx *ctx, mrl_parsed **out, const char *expression, int n_inputs, const char *const *input_names,
@@ -809,6 +919,8 @@ int mrl_parsed_create(mrl_ctx *ctx, mrl_parsed **out, const char *expression, in
 void mrl_parsed_destroy(mrl_parsed *p) {
   if (!p) return;
   if (p->module) (void)hipModuleUnload(p->module);
+  for (auto &kv : p->zfwd)
+    if (kv.second.first) (void)hipModuleUnload(kv.second.first);
   delete p;
 }
 

@@ -13,20 +13,27 @@ namespace p2 {
 struct ChDev {
   int family;
   double c0, c1, c2;
+  double k[8];  // named constants of a parsed free energy (MRL_FE_PARSED)
 };
+
+// MRL_FE_PARSED: the chemical potential generated from the user's expression (expr.hip); it only exists in the
+// run-time compiled (hiprtc) instance of k_z_fwd, where its definition is appended to these headers
+__device__ double mrl_user_mu(double c, const double *k);
 
 // FAM is a compile-time constant: a run-time family test inside the unrolled load loop makes hipcc
 // branch around every element and wait vmcnt(0) per load (16 dependent HBM round trips).
 template <int FAM>
 __device__ __forceinline__ double mu_eval(const ChDev &p, double c) {
 #pragma clang fp contract(off)
-  if (FAM == MRL_FE_DOUBLE_WELL) {
+  if constexpr (FAM == MRL_FE_DOUBLE_WELL) {
     const double cm1 = c - 1.0;
     return (p.c0 * (2.0 * c)) * (cm1 * cm1) + (p.c0 * (c * c)) * (2.0 * cm1);
-  } else {
+  } else if constexpr (FAM == MRL_FE_PFHUB) {
     const double a = c - p.c1;
     const double b = p.c2 - c;
     return (p.c0 * (2.0 * a)) * (b * b) + (p.c0 * (a * a)) * ((2.0 * b) * -1.0);
+  } else {
+    return mrl_user_mu(c, p.k);
   }
 }
 

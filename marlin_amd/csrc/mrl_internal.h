@@ -145,7 +145,15 @@ struct ChP {
   int family;
   double c0, c1, c2;
   double M, kappa;
+  mrl_parsed *parsed;  // MRL_FE_PARSED
 };
+
+// parsed free energies (expr.hip)
+int parsed_check_mu(mrl_ctx *ctx, const mrl_parsed *p);                     // one real input, real output, same context
+int parsed_eval1(mrl_parsed *p, const double *c, double *mu, long long n);  // mu = expression(c), pointwise
+// k_z_fwd<N, CH> with the generated chemical potential compiled in (hiprtc), N in {64,128,256,512}
+int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const double *in, cplx *out0, cplx *out1, double *mu_out,
+                        long long nlines);
 
 // power-of-two fast path (ch_fused.hip)
 bool fast_path_ok(const mrl_ctx *ctx);

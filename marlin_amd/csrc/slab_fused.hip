@@ -116,8 +116,10 @@ int slab_ch_z_fwd_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *
   cplx *w_c, *w_mu, *w_inv;
   MRL_TRY(slab_work(ctx, &w_c, &w_mu, &w_inv));
   ProfScope ps(ctx, "slab_Z_z_fwd", 8.0 * nx * nyl * nz + 32.0 * nx * nyl * nzc + (mu ? 8.0 * nx * nyl * nz : 0.0));
-  p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2};
-  if (cp.family == MRL_FE_DOUBLE_WELL) {
+  p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
+  if (cp.family == MRL_FE_PARSED) {
+    MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, c_in, w_c, w_mu, mu, nx * nyl));
+  } else if (cp.family == MRL_FE_DOUBLE_WELL) {
     MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_c, w_mu, mu, chp, nx * nyl))));
   } else {
     MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, w_c, w_mu, mu, chp, nx * nyl))));

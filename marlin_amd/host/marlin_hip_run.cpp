@@ -61,6 +61,19 @@ static int run_cahnhilliard(DomainAction & domain, const std::string & out)
   p.ch.coef[2] = argd("c_beta", 0.7);
   p.ch.mobility = argd("mobility", 0.2);  // ReciprocalLaplacianFactor factor
   p.ch.kappa = argd("kappa", -0.001);     // ReciprocalLaplacianSquareFactor factor
+  // expression=... : the [mu] ParsedCompute block of the input file (expression + derivatives = c) instead of a
+  // built-in family; the derivative is taken symbolically and compiled into the solver's forward z pass
+  mrl_parsed * parsed = nullptr;
+  if (!arg("expression").empty())
+  {
+    const std::string expr = arg("expression");
+    const char * in[] = {"c"};
+    const char * dv[] = {"c"};
+    if (mrl_parsed_create(domain.ctx(), &parsed, expr.c_str(), 1, in, nullptr, 0, nullptr, nullptr, 1, dv, 0, 0) != MRL_OK)
+      paramError("expression", mrl_last_error(domain.ctx()));
+    p.ch.family = MRL_FE_PARSED;
+    p.ch.parsed = parsed;
+  }
   AdamsBashforthMoulton solver(problem, "solver", p);
   Transient ex(problem, solver, argd("dt", 1e-3));
   dump(out, "c", 0, problem.getBuffer("c"));
@@ -68,6 +81,7 @@ static int run_cahnhilliard(DomainAction & domain, const std::string & out)
     dump(out, "c", step, problem.getBuffer("c"));
     dump(out, "mu", step, problem.getBuffer("mu"));
   });
+  mrl_parsed_destroy(parsed);
   return 0;
 }
 

@@ -20,13 +20,15 @@ def _run(args, tmp_path):
     return out.stdout
 
 
-def test_cahnhilliard_case(tmp_path):
-    """test/tests/cahnhilliard/tests:46-57 (cahnhilliard.i): c.1..c.10, mu.10 vs gold, abs_tol 1e-13"""
+@pytest.mark.parametrize("free_energy", [["A=0.1"], ["expression=0.1*c^2*(c-1)^2"]])
+def test_cahnhilliard_case(free_energy, tmp_path):
+    """test/tests/cahnhilliard/tests:46-57 (cahnhilliard.i): c.1..c.10, mu.10 vs gold, abs_tol 1e-13 -- with the
+    built-in double well and with the input file's own ParsedCompute text (expression + derivatives = c)"""
     g = load_golden("cahnhilliard_gold.npz")
     ic = tmp_path / "c0.bin"
     g["c.0"][:20, :20].astype("<f8").tofile(ic)     # the seed-0 RandomTensor IC is the gold file's frame 0
     _run(["problem=cahnhilliard", "dim=2", "nx=20", "ny=20", "xmax=3", "ymax=3", f"ic={ic}", "substeps=10",
-          "num_steps=10", "dt=1e-3", "predictor_order=2", "mobility=0.2", "kappa=-0.001", "A=0.1"], tmp_path)
+          "num_steps=10", "dt=1e-3", "predictor_order=2", "mobility=0.2", "kappa=-0.001"] + free_energy, tmp_path)
     worst = 0.0
     for k in range(1, 11):
         c = np.fromfile(tmp_path / f"c.{k}.bin", dtype="<f8").reshape(20, 20)

@@ -111,3 +111,29 @@ def test_derivative_vs_finite_difference(ctx, expr):
         fd = (f(a + h * da, b + h * db) - f(a - h * da, b - h * db)) / (2 * h)
         d = _pc(ctx, expr, inputs=["a", "b"], derivatives=[var])(a, b)
         assert (d - fd).abs().max().item() <= 1e-7 * max(1.0, fd.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (12, 10, 9), (128, 64, 64)])
+def test_parsed_free_energy_in_ch_substep(shape):
+    """MRL_FE_PARSED: the user's free energy, differentiated symbolically and compiled INTO the forward z pass on
+    fast-path shapes (hiprtc instance of k_z_fwd), must reproduce the built-in families bit for bit (same tree)"""
+    from marlin_amd.api import Context, ParsedCompute, ch_params, FE_PFHUB
+    L = [3.0, 2.0, 2.5]
+    ctx = Context(3, list(shape), L)
+    torch.manual_seed(9)
+    c0 = (torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44).cuda()
+    cases = [(ch_params(), ParsedCompute(ctx, "0.1*c^2*(c-1)^2", inputs=["c"], derivatives=["c"])),
+             (ch_params(family=FE_PFHUB, coef=(5.0, 0.3, 0.7), mobility=5.0, kappa=-10.0),
+              ParsedCompute(ctx, "rho_s*(c-c_alpha)^2*(c_beta-c)^2", inputs=["c"],
+                            constants={"rho_s": 5.0, "c_alpha": 0.3, "c_beta": 0.7}, derivatives=["c"]))]
+    for builtin, parsed in cases:
+        pp = ch_params(mobility=builtin.mobility, kappa=builtin.kappa, parsed=parsed)
+        res = []
+        for prm in (builtin, pp):
+            c, N0, N1 = c0.clone(), ctx.empty_spec(), ctx.empty_spec()
+            c1, c2, mu = torch.empty_like(c), torch.empty_like(c), torch.empty_like(c)
+            ctx.ch_substep(prm, c, c1, N0, [], 0, 1e-3)
+            ctx.ch_substep(prm, c1, c2, N1, [N0], 1, 1e-3, mu=mu)
+            res.append((c2.cpu(), N1.cpu(), mu.cpu()))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
