@@ -22,7 +22,7 @@ struct FusedArgs {
   const double *kx, *ky, *kz;
 };
 
-template <int N, int ORDER>
+template <int N, int ORDER, int PRE>
 __global__ void __launch_bounds__(256, 2) k_ch_xfused(FusedArgs a, const cplx *__restrict__ tw) {
   constexpr int TPL = N / 16, T = 4096 / N;
   using Map = MapStrided<N>;
@@ -38,20 +38,20 @@ __global__ void __launch_bounds__(256, 2) k_ch_xfused(FusedArgs a, const cplx *_
   // byte offset of line element m: (i + (q + m*TPL)*inner) * 16, the same in the work and the dense layout
   const unsigned off0 = (unsigned)(iv + (long long)q * a.inner) * 16u, step = (unsigned)(TPL * a.inner) * 16u;
   auto off = [=](int m) { return off0 + (unsigned)m * step; };
-  ch_fused_body<N, ORDER, true>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, W, X, KX);
+  ch_fused_body<N, ORDER, true, PRE>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, W, X, KX);
 }
 
-template <int N, int ORDER>
+template <int N, int ORDER, int PRE = 8>
 static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
   if (!attr) {
-    MRL_TRY(set_lds_attr(ctx, k_ch_xfused<N, ORDER>, lds));
+    MRL_TRY(set_lds_attr(ctx, k_ch_xfused<N, ORDER, PRE>, lds));
     attr = true;
   }
   constexpr int T = 4096 / N;
   const long long nb = (a.inner + T - 1) / T;
-  hipLaunchKernelGGL((k_ch_xfused<N, ORDER>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, ctx->ax[0].d_tw);
+  hipLaunchKernelGGL((k_ch_xfused<N, ORDER, PRE>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, ctx->ax[0].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
@@ -65,8 +65,15 @@ bool fast_path_ok(const mrl_ctx *ctx) {
 
 // strided pass along internal axis `a` (0 = x, 1 = y) of NF complex [nx][ny][nzc] arrays
 static int pass_axis(mrl_ctx *ctx, int axis, bool inv, int nf, const cplx *in0, const cplx *in1, cplx *out0,
-                     cplx *out1, bool reverse = false) {
-  const long long nx = ctx->n[0], ny = ctx->n[1], nzc = ctx->nrec[2];
+                     cplx *out1, bool reverse = false, long long x0 = 0, long long x1 = -1) {
+  const long long ny = ctx->n[1], nzc = ctx->nrec[2];
+  const long long nx = (x1 < 0 ? ctx->n[0] : x1) - x0;  // y pass only: restrict to the x planes [x0, x1)
+  if (x0 > 0) {
+    in0 += x0 * ny * nzc;
+    out0 += x0 * ny * nzc;
+    if (in1) in1 += x0 * ny * nzc;
+    if (out1) out1 += x0 * ny * nzc;
+  }
   p2::PassArgs a{};
   a.in[0] = in0;
   a.in[1] = in1;
@@ -163,19 +170,30 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
   cplx *w_mu = reinterpret_cast<cplx *>(ctx->d_work[2]);
   p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
   const double h = 16.0 * nspec;  // bytes of one complex half-spectrum array
-  {
-    ProfScope ps(ctx, "ch_A_z_fwd", 8.0 * nreal + 2.0 * h + (mu ? 8.0 * nreal : 0.0));
-    if (cp.family == MRL_FE_PARSED) {
-      MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, c_in, w_c, w_mu, mu, nx * ny));
-    } else if (cp.family == MRL_FE_DOUBLE_WELL) {
-      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_c, w_mu, mu, chp, nx * ny))));
-    } else {
-      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, w_c, w_mu, mu, chp, nx * ny))));
+  // A (z pass) and B (y pass) are both local to an x plane and can run chunk by chunk over x, so that B reads what A
+  // has just written while it is still in the 256 MB Infinity Cache (B walks its tiles in reverse, starting where A ended)
+  // (measured: 2 and 4 chunks are slower than one launch each -- the smaller grids cost more than the cache hits gain)
+  const int nchunk = (ctx->exp & 16) ? 4 : ((ctx->exp & 8) ? 2 : 1);
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const long long x0 = nx * ch / nchunk, x1 = nx * (ch + 1) / nchunk;
+    const long long l0 = x0 * ny, nl = (x1 - x0) * ny;
+    const double *cin = c_in + l0 * nz;
+    cplx *wc = w_c + l0 * nzc, *wm = w_mu + l0 * nzc;
+    double *muc = mu ? mu + l0 * nz : nullptr;
+    {
+      ProfScope ps(ctx, "ch_A_z_fwd", (8.0 * nreal + 2.0 * h + (mu ? 8.0 * nreal : 0.0)) / nchunk);
+      if (cp.family == MRL_FE_PARSED) {
+        MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, cin, wc, wm, muc, nl));
+      } else if (cp.family == MRL_FE_DOUBLE_WELL) {
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, cin, wc, wm, muc, chp, nl))));
+      } else {
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, cin, wc, wm, muc, chp, nl))));
+      }
     }
-  }
-  {
-    ProfScope ps(ctx, "ch_B_y_fwd", 4.0 * h);
-    MRL_TRY(pass_axis(ctx, 1, false, 2, w_c, w_mu, w_c, w_mu, true));
+    {
+      ProfScope ps(ctx, "ch_B_y_fwd", 4.0 * h / nchunk);
+      MRL_TRY(pass_axis(ctx, 1, false, 2, w_c, w_mu, w_c, w_mu, true, x0, x1));
+    }
   }
   {
     ProfScope ps(ctx, "ch_C_x_fused", (4.0 + order + (cbar ? 1.0 : 0.0)) * h);
@@ -197,7 +215,7 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
     a.c.dt = sub_dt;
     switch (order) {
       case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0>(ctx, a)))); break;
-      case 1: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 1>(ctx, a)))); break;
+      case 1: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 1>(ctx, a)))); break;  // PRE = 8 (4, 12: same; 16 spills: -12 %)
       case 2: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 2>(ctx, a)))); break;
       case 3: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 3>(ctx, a)))); break;
       default: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 4>(ctx, a)))); break;

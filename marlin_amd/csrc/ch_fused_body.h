@@ -39,7 +39,7 @@ __device__ __forceinline__ void stc(cplx *base, unsigned boff, cplx v) {
 // OffW / OffD: callables m -> byte offset of the thread's m-th line element in the work layout / the dense
 // reference layout (computed from a few live values instead of 2 x 16 held registers).
 // OffU: the same for the ubar output (the inverse exchange layout of the slab path differs from the forward one).
-template <int N, int ORDER, bool LINE_IS_X, class OffW, class OffD, class OffU>
+template <int N, int ORDER, bool LINE_IS_X, int PRE, class OffW, class OffD, class OffU>
 __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *__restrict__ tw,
                                               const double *__restrict__ kline, const double *__restrict__ ka_ptr,
                                               const double *__restrict__ kb_ptr, bool valid, int q, int l,
@@ -93,13 +93,12 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
     for (int m = 0; m < 16; ++m) stc(a.Nnew, offd(m), Nv[m]);
   }
 
-  // ---- first-order history: the first half of the old Nhat values is requested before the c-hat transform and
-  //      is in flight during it; the second half is requested right after it and lands while the first half is
-  //      combined (all 16 up front would push the kernel past 256 VGPRs = one wave per SIMD).
-  cplx o1[ORDER == 1 ? 8 : 1];
+  // ---- first-order history: PRE of the 16 old Nhat values are requested before the c-hat transform and are in flight
+  //      during it, the rest right after it (PRE is tuned per kernel against the 256-VGPR / two-waves-per-SIMD limit)
+  cplx o1[ORDER == 1 ? 16 : 1];
   if (ORDER == 1) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) o1[ORDER == 1 ? m : 0] = ldc(a.Nold[0], offd(m));
+    for (int m = 0; m < PRE; ++m) o1[ORDER == 1 ? m : 0] = ldc(a.Nold[0], offd(m));
   }
 
   // ---- 3. c-hat: forward transform
@@ -110,36 +109,49 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   }
 
   // ---- 4. ubar = (cbar + (dt b0) N + sum (dt b_i) Nold_i) / (1 - dt*Lbar), the reference's association
-  //      (deeper histories: 8 points at a time; a run-time trip count here would make hipcc wait vmcnt(0) per element)
+  if (ORDER == 1) {
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    cplx o[ORDER > 0 ? ORDER : 1][8];
+    for (int m = PRE; m < 16; ++m) o1[ORDER == 1 ? m : 0] = ldc(a.Nold[0], offd(m));
 #pragma unroll
-    for (int h = 0; h < ORDER; ++h) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (ORDER == 1 && half == 0)
-          o[h][j] = o1[ORDER == 1 ? j : 0];
-        else
-          o[h][j] = ldc(a.Nold[h], offd(half * 8 + j));
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int m = half * 8 + j;
+    for (int m = 0; m < 16; ++m) {
       cplx u = cp[m];
       u.x = u.x + a.coef[0] * Nv[m].x;
       u.y = u.y + a.coef[0] * Nv[m].y;
-#pragma unroll
-      for (int h = 0; h < ORDER; ++h) {
-        u.x += a.coef[h + 1] * o[h][j].x;
-        u.y += a.coef[h + 1] * o[h][j].y;
-      }
+      u.x += a.coef[1] * o1[ORDER == 1 ? m : 0].x;
+      u.y += a.coef[1] * o1[ORDER == 1 ? m : 0].y;
       const double kl = KL[q + m * TPL];
       const double k2 = LINE_IS_X ? (kl * kl + ka2) + kb2 : (ka2 + kl * kl) + kb2;
       const double Lb = k2 * k2 * a.kappa;
       const double scl = 1.0 / (1.0 - a.dt * Lb);
       v[m] = make_double2(u.y * scl, u.x * scl);  // swapped for the inverse transform
+    }
+  } else {
+    //    (deeper histories: 8 points at a time; a run-time trip count here would make hipcc wait vmcnt(0) per element)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      cplx o[ORDER > 0 ? ORDER : 1][8];
+#pragma unroll
+      for (int h = 0; h < ORDER; ++h) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[h][j] = ldc(a.Nold[h], offd(half * 8 + j));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int m = half * 8 + j;
+        cplx u = cp[m];
+        u.x = u.x + a.coef[0] * Nv[m].x;
+        u.y = u.y + a.coef[0] * Nv[m].y;
+#pragma unroll
+        for (int h = 0; h < ORDER; ++h) {
+          u.x += a.coef[h + 1] * o[h][j].x;
+          u.y += a.coef[h + 1] * o[h][j].y;
+        }
+        const double kl = KL[q + m * TPL];
+        const double k2 = LINE_IS_X ? (kl * kl + ka2) + kb2 : (ka2 + kl * kl) + kb2;
+        const double Lb = k2 * k2 * a.kappa;
+        const double scl = 1.0 / (1.0 - a.dt * Lb);
+        v[m] = make_double2(u.y * scl, u.x * scl);
+      }
     }
   }
 

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256, 2) k_ch_yfused(YFusedArgs a, const cplx *
   };
   const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + a.k0 + kl) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
   auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
-  ch_fused_body<N, ORDER, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
+  ch_fused_body<N, ORDER, false, 8>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
 }
 
 template <int N, int ORDER>
