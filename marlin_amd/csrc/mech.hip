@@ -340,20 +340,28 @@ __global__ void __launch_bounds__(256) k_add(double *__restrict__ y, const doubl
     y[i] = y[i] + x[block ? i / block : (period ? i % period : i)];
 }
 
-// value-major [npts][dd] <-> field-major [dd][npts]
-template <bool TO_SOA>
-__global__ void __launch_bounds__(256) k_relayout(const double *__restrict__ in, double *__restrict__ out, long long npts,
-                                                   int dd) {
-  const long long n = npts * dd;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    // i indexes the field-major array (coalesced on that side)
-    const long long c = i / npts, p = i - c * npts;
-    if (TO_SOA)
-      out[i] = in[p * dd + c];
-    else
-      out[p * dd + c] = in[i];
+// value-major [npts][dd] <-> field-major [dd][npts]: one thread per grid point moves all dd components, so the
+// field-major side is coalesced per component and the value-major side is touched in whole 8*dd-byte records by one
+// wave within a few instructions (one thread per ELEMENT leaves the value-major side as isolated 8-byte accesses)
+template <bool TO_SOA, int DD>
+__global__ void __launch_bounds__(256) k_relayout(const double *__restrict__ in, double *__restrict__ out, long long npts) {
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npts; p += (long long)gridDim.x * 256) {
+    double v[DD];
+    if (TO_SOA) {
+#pragma unroll
+      for (int c = 0; c < DD; ++c) v[c] = in[p * DD + c];
+#pragma unroll
+      for (int c = 0; c < DD; ++c) out[(long long)c * npts + p] = v[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < DD; ++c) v[c] = in[(long long)c * npts + p];
+#pragma unroll
+      for (int c = 0; c < DD; ++c) out[p * DD + c] = v[c];
+    }
   }
 }
+
+static int relayout_any(mrl_ctx *ctx, bool to_soa, const double *in, double *out, long long npts, int dd);
 
 static inline int grid_for(long long n) {
   long long b = (n + 255) / 256;
@@ -429,16 +437,32 @@ int tangent_dir_launch(mrl_ctx *ctx, const double *F, const double *K, const dou
   return MRL_OK;
 }
 
+static int relayout_any(mrl_ctx *ctx, bool to_soa, const double *in, double *out, long long npts, int dd) {
+  const dim3 g(grid_for(npts)), b(256);
+#define MRL_RL(DD)                                                                                  \
+  if (to_soa)                                                                                       \
+    hipLaunchKernelGGL((k_relayout<true, DD>), g, b, 0, ctx->stream, in, out, npts);                \
+  else                                                                                              \
+    hipLaunchKernelGGL((k_relayout<false, DD>), g, b, 0, ctx->stream, in, out, npts);
+  switch (dd) {
+    case 1: MRL_RL(1) break;
+    case 2: MRL_RL(2) break;
+    case 3: MRL_RL(3) break;
+    case 4: MRL_RL(4) break;
+    case 6: MRL_RL(6) break;
+    case 9: MRL_RL(9) break;
+    default: return set_error(ctx, MRL_ERR_UNSUPPORTED, "relayout: %d components per point not supported (1,2,3,4,6,9)", dd);
+  }
+#undef MRL_RL
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
 int relayout_launch(mrl_ctx *ctx, bool to_soa, const double *in, double *out) {
   const long long npts = real_count_local(ctx);
   const int dd = ctx->dim * ctx->dim;
   ProfScope ps(ctx, to_soa ? "mech_to_field_major" : "mech_to_value_major", 16.0 * npts * dd);
-  if (to_soa)
-    hipLaunchKernelGGL(k_relayout<true>, dim3(grid_for(npts * dd)), dim3(256), 0, ctx->stream, in, out, npts, dd);
-  else
-    hipLaunchKernelGGL(k_relayout<false>, dim3(grid_for(npts * dd)), dim3(256), 0, ctx->stream, in, out, npts, dd);
-  MRL_HIP(ctx, hipGetLastError());
-  return MRL_OK;
+  return relayout_any(ctx, to_soa, in, out, npts, dd);
 }
 
 // out = scale * G(A), value-major fields through the generic batched transforms
@@ -506,12 +530,7 @@ int mrl_relayout(mrl_ctx *ctx, int to_field_major, const double *d_in, double *d
     return set_error(ctx, MRL_ERR_INVALID, "mrl_relayout: bad argument (in and out must be distinct)");
   if (npts == 0) return MRL_OK;
   ProfScope ps(ctx, to_field_major ? "to_field_major" : "to_value_major", 16.0 * npts * ncomp);
-  if (to_field_major)
-    hipLaunchKernelGGL(k_relayout<true>, dim3(grid_for(npts * ncomp)), dim3(256), 0, ctx->stream, d_in, d_out, (long long)npts, ncomp);
-  else
-    hipLaunchKernelGGL(k_relayout<false>, dim3(grid_for(npts * ncomp)), dim3(256), 0, ctx->stream, d_in, d_out, (long long)npts, ncomp);
-  MRL_HIP(ctx, hipGetLastError());
-  return MRL_OK;
+  return relayout_any(ctx, to_field_major != 0, d_in, d_out, (long long)npts, ncomp);
 }
 
 int mrl_axpby(mrl_ctx *ctx, double a, const double *d_x, double b, const double *d_y, double *d_out, int64_t n) {
