@@ -23,8 +23,8 @@ struct FusedArgs {
 };
 
 template <int N, int ORDER, int PRE>
-__global__ void __launch_bounds__(256, 2) k_ch_xfused(FusedArgs a, const cplx *__restrict__ tw) {
-  constexpr int TPL = N / 16, T = 4096 / N;
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const cplx *__restrict__ tw) {
+  constexpr int TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256, 2) k_ch_xfused(FusedArgs a, const cplx *_
   ch_fused_body<N, ORDER, true, PRE>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, W, X, KX);
 }
 
-template <int N, int ORDER, int PRE = 8>
+template <int N, int ORDER, int PRE = Plan<N>::P / 2>
 static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
@@ -49,9 +49,9 @@ static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a) {
     MRL_TRY(set_lds_attr(ctx, k_ch_xfused<N, ORDER, PRE>, lds));
     attr = true;
   }
-  constexpr int T = 4096 / N;
+  constexpr int T = Plan<N>::T;
   const long long nb = (a.inner + T - 1) / T;
-  hipLaunchKernelGGL((k_ch_xfused<N, ORDER, PRE>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, ctx->ax[0].d_tw);
+  hipLaunchKernelGGL((k_ch_xfused<N, ORDER, PRE>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[0].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }

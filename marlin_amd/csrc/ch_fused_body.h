@@ -46,29 +46,30 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
                                               OffW offw, OffD offd, OffU offu, cplx *W, cplx *X,
                                               double *KL) {
 #pragma clang fp contract(off)
-  constexpr int TPL = N / 16;
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, NT = Plan<N>::NT, CNT = (N + NT - 1) / NT;
+  static_assert(PRE <= P, "prefetch depth");
   using Map = MapStrided<N>;
 
   // ---- issue every early load: small ones first
-  cplx twv[(N + 255) / 256];
-  double klv[(N + 255) / 256];
+  cplx twv[CNT];
+  double klv[CNT];
 #pragma unroll
-  for (int j = 0; j < (N + 255) / 256; ++j) {
-    const int idx = threadIdx.x + j * 256;
+  for (int j = 0; j < CNT; ++j) {
+    const int idx = threadIdx.x + j * NT;
     twv[j] = idx < N ? tw[idx] : make_double2(0.0, 0.0);
     klv[j] = idx < N ? kline[idx] : 0.0;
   }
   // Loads are unconditional (the caller clamps the offsets of out-of-range lanes to a valid element; their
   // results are never stored): a branch around them would make hipcc's vmcnt bookkeeping fall back to vmcnt(0).
   const double ka = *ka_ptr, kb = *kb_ptr;
-  cplx v[16], cp[16];
+  cplx v[P], cp[P];
 #pragma unroll
-  for (int m = 0; m < 16; ++m) v[m] = ldc(a.muhat, offw(m));
+  for (int m = 0; m < P; ++m) v[m] = ldc(a.muhat, offw(m));
 #pragma unroll
-  for (int m = 0; m < 16; ++m) cp[m] = ldc(a.chat, offw(m));
+  for (int m = 0; m < P; ++m) cp[m] = ldc(a.chat, offw(m));
 #pragma unroll
-  for (int j = 0; j < (N + 255) / 256; ++j) {
-    const int idx = threadIdx.x + j * 256;
+  for (int j = 0; j < CNT; ++j) {
+    const int idx = threadIdx.x + j * NT;
     if (idx < N) {
       W[idx] = twv[j];
       KL[idx] = klv[j];
@@ -80,9 +81,9 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   fft_line<N, Map>(v, q, l, X, W);
 
   // ---- 2. Nhat = Mbar * mu-hat, Mbar = -k^2 * M
-  cplx Nv[16];
+  cplx Nv[P];
 #pragma unroll
-  for (int m = 0; m < 16; ++m) {
+  for (int m = 0; m < P; ++m) {
     const double kl = KL[q + m * TPL];
     const double k2 = LINE_IS_X ? (kl * kl + ka2) + kb2 : (ka2 + kl * kl) + kb2;
     const double Mbar = -k2 * a.M;
@@ -90,12 +91,12 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   }
   if (valid) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) stc(a.Nnew, offd(m), Nv[m]);
+    for (int m = 0; m < P; ++m) stc(a.Nnew, offd(m), Nv[m]);
   }
 
   // ---- first-order history: PRE of the 16 old Nhat values are requested before the c-hat transform and are in flight
   //      during it, the rest right after it (PRE is tuned per kernel against the 256-VGPR / two-waves-per-SIMD limit)
-  cplx o1[ORDER == 1 ? 16 : 1];
+  cplx o1[ORDER == 1 ? P : 1];
   if (ORDER == 1) {
 #pragma unroll
     for (int m = 0; m < PRE; ++m) o1[ORDER == 1 ? m : 0] = ldc(a.Nold[0], offd(m));
@@ -105,15 +106,15 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   fft_line<N, Map>(cp, q, l, X, W);
   if (a.cbar && valid) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) stc(a.cbar, offd(m), cp[m]);
+    for (int m = 0; m < P; ++m) stc(a.cbar, offd(m), cp[m]);
   }
 
   // ---- 4. ubar = (cbar + (dt b0) N + sum (dt b_i) Nold_i) / (1 - dt*Lbar), the reference's association
   if (ORDER == 1) {
 #pragma unroll
-    for (int m = PRE; m < 16; ++m) o1[ORDER == 1 ? m : 0] = ldc(a.Nold[0], offd(m));
+    for (int m = PRE; m < P; ++m) o1[ORDER == 1 ? m : 0] = ldc(a.Nold[0], offd(m));
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
+    for (int m = 0; m < P; ++m) {
       cplx u = cp[m];
       u.x = u.x + a.coef[0] * Nv[m].x;
       u.y = u.y + a.coef[0] * Nv[m].y;
@@ -126,18 +127,19 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
       v[m] = make_double2(u.y * scl, u.x * scl);  // swapped for the inverse transform
     }
   } else {
-    //    (deeper histories: 8 points at a time; a run-time trip count here would make hipcc wait vmcnt(0) per element)
+    //    (deeper histories: half of the points at a time; a run-time trip count here would make hipcc wait vmcnt(0) per element)
+    constexpr int H = P / 2;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      cplx o[ORDER > 0 ? ORDER : 1][8];
+      cplx o[ORDER > 0 ? ORDER : 1][H];
 #pragma unroll
       for (int h = 0; h < ORDER; ++h) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[h][j] = ldc(a.Nold[h], offd(half * 8 + j));
+        for (int j = 0; j < H; ++j) o[h][j] = ldc(a.Nold[h], offd(half * H + j));
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int m = half * 8 + j;
+      for (int j = 0; j < H; ++j) {
+        const int m = half * H + j;
         cplx u = cp[m];
         u.x = u.x + a.coef[0] * Nv[m].x;
         u.y = u.y + a.coef[0] * Nv[m].y;
@@ -159,7 +161,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   fft_line<N, Map>(v, q, l, X, W);
   if (valid) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) stc(a.ubar, offu(m), cswap(v[m]));
+    for (int m = 0; m < P; ++m) stc(a.ubar, offu(m), cswap(v[m]));
   }
 }
 

@@ -788,7 +788,15 @@ static int build_mu_function(mrl_parsed *p, std::string &out) {
 
 int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const double *in, cplx *out0, cplx *out1, double *mu_out,
                         long long nlines) {
-  if (N != 64 && N != 128 && N != 256 && N != 512) return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
+  // lines per workgroup / threads per workgroup of Plan<N> (fft_pow2.h)
+  int T = 0, NT = 0;
+  switch (N) {
+    case 64: case 128: case 256: case 512: T = 4096 / N; NT = 256; break;
+    case 100: T = 25; NT = 250; break;
+    case 200: T = 12; NT = 240; break;
+    case 400: T = 6; NT = 240; break;
+    default: return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
+  }
   auto it = p->zfwd.find(N);
   if (it == p->zfwd.end()) {
     std::string mu_fn;
@@ -842,10 +850,10 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const double *in, cp
   for (size_t i = 0; i < p->const_values.size(); ++i) chp.k[i] = p->const_values[i];
   const cplx *tw = ctx->ax[2].d_tw;
   void *params[] = {&in, &out0, &out1, &mu_out, &chp, &nlines, &tw};
-  const int LPB = 4096 / N, LP = N + N / 16;
-  const size_t lds = sizeof(cplx) * (size_t)(N + (4096 / N) * LP);
+  const int LPB = T, LP = N + N / 16;
+  const size_t lds = sizeof(cplx) * (size_t)(N + T * LP);
   const long long nb = (nlines + LPB - 1) / LPB;
-  MRL_HIP(ctx, hipModuleLaunchKernel(it->second.second, (unsigned)nb, 1, 1, 256, 1, 1, (unsigned)lds, ctx->stream, params, nullptr));
+  MRL_HIP(ctx, hipModuleLaunchKernel(it->second.second, (unsigned)nb, 1, 1, (unsigned)NT, 1, 1, (unsigned)lds, ctx->stream, params, nullptr));
   return MRL_OK;
 }
 

@@ -1,11 +1,11 @@
 // Power-of-two Stockham FFT building blocks for gfx950 (fp64, no MFMA: the path is HBM-bound).
 //
-// Every thread owns 16 complex values of one line: positions q + m*(N/16), m = 0..15, where
-// q = thread index within the line (N/16 threads per line).  A transform is 2 or 3 radix stages
-// (16/8/4 point butterflies in registers); between stages the line is exchanged through LDS in
-// natural (Stockham autosort) order, after which each thread again owns q + m*(N/16).  The first
-// stage therefore loads straight from HBM and the last stage stores straight to HBM with the same
-// index pattern, and 256-thread workgroups always hold 4096 points = 64 KiB of exchange space.
+// Every thread owns P complex values of one line (P = 16 for the power-of-two sizes, 10 for the 2^a 5^b sizes):
+// positions q + m*TPL, m = 0..P-1, where q = thread index within the line (TPL = N/P threads per line).  A
+// transform is 2 to 4 radix stages (16/8/4/10/5/2 point butterflies in registers); between stages the line is
+// exchanged through LDS in natural (Stockham autosort) order, after which each thread again owns q + m*TPL.  The
+// first stage therefore loads straight from HBM and the last stage stores straight to HBM with the same index
+// pattern; a workgroup holds T lines (4096 points = 64 KiB of exchange space for the power-of-two sizes).
 // Twiddles exp(-2 pi i k/N) are staged once per workgroup into LDS (exact table values, no
 // recurrences).  Inverse transforms use the swap trick: ifft(x) = swap(fft(swap(x))).
 #pragma once
@@ -22,33 +22,32 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
 __device__ __forceinline__ cplx mul_mi(cplx a) { return make_double2(a.y, -a.x); }  // * (-i)
 __device__ __forceinline__ cplx cswap(cplx a) { return make_double2(a.y, a.x); }
 
+// Plan<N>: P = points per thread, up to four radix stages r0..r3 (1 = unused; every radix divides P), T = lines per
+// workgroup.  TPL = N/P threads own one line, a workgroup is NT = T*TPL threads (256 for the power-of-two sizes,
+// 240-255 for the 2^a 5^b sizes) and exchanges T*N points through LDS.
 template <int N>
 struct Plan;
-template <>
-struct Plan<64> {
-  static constexpr int ns = 2;
-  static constexpr int r0 = 8, r1 = 8, r2 = 1;
-};
-template <>
-struct Plan<128> {
-  static constexpr int ns = 2;
-  static constexpr int r0 = 16, r1 = 8, r2 = 1;
-};
-template <>
-struct Plan<256> {
-  static constexpr int ns = 2;
-  static constexpr int r0 = 16, r1 = 16, r2 = 1;
-};
-template <>
-struct Plan<512> {
-  static constexpr int ns = 3;
-  static constexpr int r0 = 8, r1 = 8, r2 = 8;
-};
-template <>
-struct Plan<1024> {
-  static constexpr int ns = 3;
-  static constexpr int r0 = 16, r1 = 8, r2 = 8;
-};
+#define MRL_PLAN(N_, P_, R0, R1, R2, R3, T_)                                              \
+  template <>                                                                             \
+  struct Plan<N_> {                                                                       \
+    static constexpr int P = P_, r0 = R0, r1 = R1, r2 = R2, r3 = R3, T = T_;              \
+    static constexpr int ns = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);                         \
+    static constexpr int TPL = N_ / P_, NT = T_ * (N_ / P_);                              \
+    static_assert(R0 * R1 * R2 * R3 == N_ && N_ % P_ == 0 && NT <= 256, "bad plan");      \
+  };
+MRL_PLAN(64, 16, 8, 8, 1, 1, 64)
+MRL_PLAN(128, 16, 16, 8, 1, 1, 32)
+MRL_PLAN(256, 16, 16, 16, 1, 1, 16)
+MRL_PLAN(512, 16, 8, 8, 8, 1, 8)
+MRL_PLAN(1024, 16, 16, 8, 8, 1, 4)
+// sizes 2^a 5^b (the reference's own examples run 100^3 and 200^3 grids): radix 10 / 5 / 2, 10 points per thread
+MRL_PLAN(50, 10, 10, 5, 1, 1, 51)
+MRL_PLAN(100, 10, 10, 10, 1, 1, 25)
+MRL_PLAN(200, 10, 10, 10, 2, 1, 12)
+MRL_PLAN(250, 10, 10, 5, 5, 1, 10)
+MRL_PLAN(400, 10, 10, 10, 2, 2, 6)
+MRL_PLAN(500, 10, 10, 10, 5, 1, 5)
+#undef MRL_PLAN
 
 __device__ __forceinline__ void bfly4(cplx &a0, cplx &a1, cplx &a2, cplx &a3) {
   const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
@@ -116,31 +115,85 @@ __device__ __forceinline__ void bfly<16>(cplx (&a)[16]) {
 #undef MRL_SWAP
 }
 
+template <>
+__device__ __forceinline__ void bfly<2>(cplx (&a)[2]) {
+  const cplx t = a[0];
+  a[0] = cadd(t, a[1]);
+  a[1] = csub(t, a[1]);
+}
+
+// radix 5: X1,4 = m1 -+ i n1, X2,3 = m2 -+ i n2 (forward sign)
+__device__ __forceinline__ void bfly5(cplx &a0, cplx &a1, cplx &a2, cplx &a3, cplx &a4) {
+  const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;  // cos(2 pi/5), cos(4 pi/5)
+  const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;   // sin(2 pi/5), sin(4 pi/5)
+  const cplx t1 = cadd(a1, a4), t2 = cadd(a2, a3), t3 = csub(a1, a4), t4 = csub(a2, a3);
+  const cplx m1 = make_double2(a0.x + c1 * t1.x + c2 * t2.x, a0.y + c1 * t1.y + c2 * t2.y);
+  const cplx m2 = make_double2(a0.x + c2 * t1.x + c1 * t2.x, a0.y + c2 * t1.y + c1 * t2.y);
+  const cplx n1 = make_double2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+  const cplx n2 = make_double2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+  a0 = make_double2(a0.x + t1.x + t2.x, a0.y + t1.y + t2.y);
+  a1 = make_double2(m1.x + n1.y, m1.y - n1.x);  // m1 - i n1
+  a4 = make_double2(m1.x - n1.y, m1.y + n1.x);  // m1 + i n1
+  a2 = make_double2(m2.x + n2.y, m2.y - n2.x);
+  a3 = make_double2(m2.x - n2.y, m2.y + n2.x);
+}
+
+template <>
+__device__ __forceinline__ void bfly<5>(cplx (&a)[5]) {
+  bfly5(a[0], a[1], a[2], a[3], a[4]);
+}
+
+// radix 10 = 2 x 5 (Cooley-Tukey): n = 5 n1 + n2, k = k1 + 2 k2
+template <>
+__device__ __forceinline__ void bfly<10>(cplx (&a)[10]) {
+  // W10^j = exp(-2 pi i j / 10), j = 1..4
+  const double c1 = 0.80901699437494742410, s1 = 0.58778525229247312917;  // cos, sin(pi/5)
+  const double c2 = 0.30901699437494742410, s2 = 0.95105651629515357212;  // cos, sin(2 pi/5)
+  cplx e[5], o[5];
+#pragma unroll
+  for (int n2 = 0; n2 < 5; ++n2) {
+    e[n2] = cadd(a[n2], a[n2 + 5]);  // k1 = 0
+    o[n2] = csub(a[n2], a[n2 + 5]);  // k1 = 1
+  }
+  o[1] = cmul(o[1], make_double2(c1, -s1));
+  o[2] = cmul(o[2], make_double2(c2, -s2));
+  o[3] = cmul(o[3], make_double2(-c2, -s2));
+  o[4] = cmul(o[4], make_double2(-c1, -s1));
+  bfly5(e[0], e[1], e[2], e[3], e[4]);  // X[2 k2]
+  bfly5(o[0], o[1], o[2], o[3], o[4]);  // X[1 + 2 k2]
+#pragma unroll
+  for (int k2 = 0; k2 < 5; ++k2) {
+    a[2 * k2] = e[k2];
+    a[2 * k2 + 1] = o[k2];
+  }
+}
+
 // LDS index maps: p = position within the line, l = line within the workgroup
 template <int N>
 struct MapStrided {  // lines fastest (lanes of a wave vary l): conflict-free without padding
-  static constexpr int T = 4096 / N;
+  static constexpr int T = Plan<N>::T;
   __device__ __forceinline__ static int at(int p, int l) { return p * T + l; }
-  static constexpr int size = 4096;
+  static constexpr int size = N * T;
 };
 template <int N>
 struct MapLine {  // position fastest (lanes vary q): one pad element per 16 positions
   static constexpr int LP = N + N / 16;
   __device__ __forceinline__ static int at(int p, int l) { return l * LP + p + (p >> 4); }
-  static constexpr int size = (4096 / N) * LP;
+  static constexpr int size = Plan<N>::T * LP;
 };
 
-// radix stage STAGE on the 16 register values (v[i + S*t] = element t of butterfly i)
+// radix-R stage on the P register values (v[i + S*t] = element t of butterfly i, S = P/R butterflies per thread)
 template <int N, int R, int NS>
-__device__ __forceinline__ void stage(cplx (&v)[16], int q, const cplx *W) {
-  constexpr int S = 16 / R;
+__device__ __forceinline__ void stage(cplx (&v)[Plan<N>::P], int q, const cplx *W) {
+  constexpr int P = Plan<N>::P, S = P / R, TPL = N / P;
+  static_assert(P % R == 0, "radix must divide the points per thread");
 #pragma unroll
   for (int i = 0; i < S; ++i) {
     cplx a[R];
 #pragma unroll
     for (int t = 0; t < R; ++t) a[t] = v[i + S * t];
     if (NS > 1) {
-      const int b = q + i * (N / 16);
+      const int b = q + i * TPL;
       const int k = b % NS;
       const int step = k * (N / (NS * R));
 #pragma unroll
@@ -152,33 +205,37 @@ __device__ __forceinline__ void stage(cplx (&v)[16], int q, const cplx *W) {
   }
 }
 
-// write the outputs of a radix-R stage (Ns = NS) in Stockham order, then re-own q + m*N/16
+// write the outputs of a radix-R stage (Ns = NS) in Stockham order, then re-own q + m*TPL
 template <int N, int R, int NS, class Map>
-__device__ __forceinline__ void exchange(cplx (&v)[16], int q, int l, cplx *X) {
-  constexpr int S = 16 / R;
+__device__ __forceinline__ void exchange(cplx (&v)[Plan<N>::P], int q, int l, cplx *X) {
+  constexpr int P = Plan<N>::P, S = P / R, TPL = N / P;
   __syncthreads();  // previous readers of X are done
 #pragma unroll
   for (int i = 0; i < S; ++i) {
-    const int b = q + i * (N / 16);
+    const int b = q + i * TPL;
     const int p0 = (b / NS) * NS * R + (b % NS);
 #pragma unroll
     for (int t = 0; t < R; ++t) X[Map::at(p0 + t * NS, l)] = v[i + S * t];
   }
   __syncthreads();
 #pragma unroll
-  for (int m = 0; m < 16; ++m) v[m] = X[Map::at(q + m * (N / 16), l)];
+  for (int m = 0; m < P; ++m) v[m] = X[Map::at(q + m * TPL, l)];
 }
 
-// full forward transform of the line owned by (q, l); v in: x[q + m*N/16], out: X[q + m*N/16]
+// full forward transform of the line owned by (q, l); v in: x[q + m*TPL], out: X[q + m*TPL]
 template <int N, class Map>
-__device__ __forceinline__ void fft_line(cplx (&v)[16], int q, int l, cplx *X, const cplx *W) {
-  using P = Plan<N>;
-  stage<N, P::r0, 1>(v, q, W);
-  exchange<N, P::r0, 1, Map>(v, q, l, X);
-  stage<N, P::r1, P::r0>(v, q, W);
-  if (P::ns == 3) {
-    exchange<N, P::r1, P::r0, Map>(v, q, l, X);
-    stage<N, P::r2, P::r0 * P::r1>(v, q, W);
+__device__ __forceinline__ void fft_line(cplx (&v)[Plan<N>::P], int q, int l, cplx *X, const cplx *W) {
+  using Pl = Plan<N>;
+  stage<N, Pl::r0, 1>(v, q, W);
+  exchange<N, Pl::r0, 1, Map>(v, q, l, X);
+  stage<N, Pl::r1, Pl::r0>(v, q, W);
+  if constexpr (Pl::ns >= 3) {
+    exchange<N, Pl::r1, Pl::r0, Map>(v, q, l, X);
+    stage<N, Pl::r2, Pl::r0 * Pl::r1>(v, q, W);
+  }
+  if constexpr (Pl::ns >= 4) {
+    exchange<N, Pl::r2, Pl::r0 * Pl::r1, Map>(v, q, l, X);
+    stage<N, Pl::r3, Pl::r0 * Pl::r1 * Pl::r2>(v, q, W);
   }
 }
 
@@ -198,31 +255,27 @@ __device__ __forceinline__ unsigned xcd_remap_rev(unsigned b, unsigned nb) {
   return start + (len - 1 - idx);
 }
 
-template <int N>
-__device__ __forceinline__ void load_twiddles(cplx *W, const cplx *__restrict__ tw) {
-  for (int i = threadIdx.x; i < N; i += 256) W[i] = tw[i];
-}
-
 // Twiddle staging split in two so that a kernel can issue the table loads BEFORE its operand loads (vmcnt
 // retires in order: the small L2-resident table loads must not queue behind a full HBM round trip) and
 // write them to LDS AFTER the operand loads are in flight.
 template <int N>
 struct TwRegs {
-  cplx v[(N + 255) / 256];
+  static constexpr int NT = Plan<N>::NT, CNT = (N + NT - 1) / NT;
+  cplx v[CNT];
 };
 template <int N>
 __device__ __forceinline__ void tw_issue(TwRegs<N> &r, const cplx *__restrict__ tw) {
 #pragma unroll
-  for (int j = 0; j < (N + 255) / 256; ++j) {
-    const int idx = threadIdx.x + j * 256;
+  for (int j = 0; j < TwRegs<N>::CNT; ++j) {
+    const int idx = threadIdx.x + j * TwRegs<N>::NT;
     r.v[j] = idx < N ? tw[idx] : make_double2(0.0, 0.0);
   }
 }
 template <int N>
 __device__ __forceinline__ void tw_commit(const TwRegs<N> &r, cplx *W) {
 #pragma unroll
-  for (int j = 0; j < (N + 255) / 256; ++j) {
-    const int idx = threadIdx.x + j * 256;
+  for (int j = 0; j < TwRegs<N>::CNT; ++j) {
+    const int idx = threadIdx.x + j * TwRegs<N>::NT;
     if (idx < N) W[idx] = r.v[j];
   }
 }

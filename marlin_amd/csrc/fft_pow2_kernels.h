@@ -44,10 +44,10 @@ __device__ __forceinline__ double mu_eval(const ChDev &p, double c) {
 //                            optionally writes mu to mu_out.
 // nlines = number of complex transforms.
 template <int N, int MODE, int FAM>
-__global__ void __launch_bounds__(256, 2) k_z_fwd(const double *__restrict__ in, cplx *__restrict__ out0,
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_fwd(const double *__restrict__ in, cplx *__restrict__ out0,
                                                cplx *__restrict__ out1, double *__restrict__ mu_out, ChDev chp,
                                                long long nlines, const cplx *__restrict__ tw) {
-  constexpr int TPL = N / 16, LPB = 4096 / N, NZC = N / 2 + 1;
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = Plan<N>::T, NZC = N / 2 + 1;
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
@@ -58,46 +58,46 @@ __global__ void __launch_bounds__(256, 2) k_z_fwd(const double *__restrict__ in,
   TwRegs<N> twr;
   tw_issue<N>(twr, tw);
 
-  cplx v[16];
+  cplx v[P];
   const long long Lc = valid ? L : 0;  // out-of-range lanes transform line 0 again and store nothing
   const long long r0 = (MODE == 0) ? 2 * Lc : Lc;
   {
     const double *p0 = in + r0 * N + q;
-    double a[16], b[16];
+    double a[P], b[P];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) a[m] = p0[m * TPL];
+    for (int m = 0; m < P; ++m) a[m] = p0[m * TPL];
     if (MODE == 0) {
 #pragma unroll
-      for (int m = 0; m < 16; ++m) b[m] = p0[N + m * TPL];
+      for (int m = 0; m < P; ++m) b[m] = p0[N + m * TPL];
     }
     tw_commit<N>(twr, W);
     if (MODE != 0) {
 #pragma unroll
-      for (int m = 0; m < 16; ++m) b[m] = mu_eval<FAM>(chp, a[m]);
+      for (int m = 0; m < P; ++m) b[m] = mu_eval<FAM>(chp, a[m]);
     }
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = make_double2(a[m], b[m]);
+    for (int m = 0; m < P; ++m) v[m] = make_double2(a[m], b[m]);
     if (MODE == 1 && mu_out && valid) {
       double *pm = mu_out + r0 * N + q;
 #pragma unroll
-      for (int m = 0; m < 16; ++m) pm[m * TPL] = v[m].y;
+      for (int m = 0; m < P; ++m) pm[m * TPL] = v[m].y;
     }
   }
   fft_line<N, Map>(v, q, l, X, W);
   // natural-order copy in LDS for the k <-> N-k pairing
   __syncthreads();
 #pragma unroll
-  for (int m = 0; m < 16; ++m) X[Map::at(q + m * TPL, l)] = v[m];
+  for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
   __syncthreads();
   if (!valid) return;
   cplx *o0 = (MODE == 0) ? out0 + (2 * L) * NZC : out0 + L * NZC;
   cplx *o1 = (MODE == 0) ? out0 + (2 * L + 1) * NZC : out1 + L * NZC;
 #pragma unroll
-  for (int m = 0; m <= 8; ++m) {
+  for (int m = 0; m <= P / 2; ++m) {
     const int k = q + m * TPL;
-    if (m == 8 && q != 0) break;
+    if (k > N / 2) break;  // (only q = 0 owns the Nyquist bin)
     const cplx xk = v[m];
-    const cplx xn = X[Map::at((N - k) & (N - 1), l)];
+    const cplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
     o0[k] = make_double2(0.5 * (xk.x + xn.x), 0.5 * (xk.y - xn.y));
     o1[k] = make_double2(0.5 * (xk.y + xn.y), -0.5 * (xk.x - xn.x));
   }
@@ -106,9 +106,9 @@ __global__ void __launch_bounds__(256, 2) k_z_fwd(const double *__restrict__ in,
 // ---------------------------------------------------------------------------------------------
 // z inverse (PAIR): rows 2L, 2L+1 of the half spectrum `in` -> real rows 2L, 2L+1 of out, * scale.
 template <int N>
-__global__ void __launch_bounds__(256, 2) k_z_inv(const cplx *__restrict__ in, double *__restrict__ out, double scale,
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv(const cplx *__restrict__ in, double *__restrict__ out, double scale,
                                                long long nlines, const cplx *__restrict__ tw) {
-  constexpr int TPL = N / 16, LPB = 4096 / N, NZC = N / 2 + 1;
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = Plan<N>::T, NZC = N / 2 + 1;
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
@@ -118,13 +118,13 @@ __global__ void __launch_bounds__(256, 2) k_z_inv(const cplx *__restrict__ in, d
   const bool valid = L < nlines;
   TwRegs<N> twr;
   tw_issue<N>(twr, tw);
-  cplx v[16];
+  cplx v[P];
   {
     const cplx *A = in + (2 * (valid ? L : 0)) * NZC;
     const cplx *B = A + NZC;
-    cplx av[16], bv[16];
+    cplx av[P], bv[P];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
+    for (int m = 0; m < P; ++m) {
       const int p = q + m * TPL;
       const int k = (p <= N / 2) ? p : N - p;
       av[m] = A[k];
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256, 2) k_z_inv(const cplx *__restrict__ in, d
     }
     tw_commit<N>(twr, W);
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
+    for (int m = 0; m < P; ++m) {
       const int p = q + m * TPL;
       const bool lo = p <= N / 2;
       const int k = lo ? p : N - p;
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256, 2) k_z_inv(const cplx *__restrict__ in, d
   if (!valid) return;
   double *o0 = out + (2 * L) * N + q;
 #pragma unroll
-  for (int m = 0; m < 16; ++m) {
+  for (int m = 0; m < P; ++m) {
     // swap back: real part (row 2L) = v.y, imaginary part (row 2L+1) = v.x
     o0[m * TPL] = v[m].y * scale;
     o0[N + m * TPL] = v[m].x * scale;
@@ -173,8 +173,8 @@ struct PassArgs {
 };
 
 template <int N, bool INV, int NF>
-__global__ void __launch_bounds__(256, 2) k_pass(PassArgs a, const cplx *__restrict__ tw) {
-  constexpr int TPL = N / 16, T = 4096 / N;
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass(PassArgs a, const cplx *__restrict__ tw) {
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
@@ -189,25 +189,25 @@ __global__ void __launch_bounds__(256, 2) k_pass(PassArgs a, const cplx *__restr
   // all fields' operands are requested up front: field 1 is in flight while field 0 is transformed
   // (unconditional loads from a clamped position: a branch here degrades hipcc's vmcnt counting to vmcnt(0))
   const long long ic = valid ? i : 0;
-  cplx v[NF][16];
+  cplx v[NF][P];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
     const cplx *p = a.in[f] + o * a.so_in + ic + (long long)q * a.sn_in;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[f][m] = p[(long long)m * TPL * a.sn_in];
+    for (int m = 0; m < P; ++m) v[f][m] = p[(long long)m * TPL * a.sn_in];
   }
   tw_commit<N>(twr, W);
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
     if (INV) {
 #pragma unroll
-      for (int m = 0; m < 16; ++m) v[f][m] = cswap(v[f][m]);
+      for (int m = 0; m < P; ++m) v[f][m] = cswap(v[f][m]);
     }
     fft_line<N, Map>(v[f], q, l, X, W);
     if (valid) {
       cplx *p = a.out[f] + o * a.so_out + i + (long long)q * a.sn_out;
 #pragma unroll
-      for (int m = 0; m < 16; ++m) p[(long long)m * TPL * a.sn_out] = INV ? cswap(v[f][m]) : v[f][m];
+      for (int m = 0; m < P; ++m) p[(long long)m * TPL * a.sn_out] = INV ? cswap(v[f][m]) : v[f][m];
     }
   }
 }
@@ -228,8 +228,8 @@ struct SubPassArgs {
 };
 
 template <int N, bool INV, int NF>
-__global__ void __launch_bounds__(256, 2) k_pass_sub(SubPassArgs a, const cplx *__restrict__ tw) {
-  constexpr int TPL = N / 16, T = 4096 / N;
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub(SubPassArgs a, const cplx *__restrict__ tw) {
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
@@ -245,11 +245,11 @@ __global__ void __launch_bounds__(256, 2) k_pass_sub(SubPassArgs a, const cplx *
   const unsigned mo = (a.sh_out < 31) ? ((1u << a.sh_out) - 1u) : 0xffffffffu;
   TwRegs<N> twr;
   tw_issue<N>(twr, tw);
-  cplx v[NF][16];
+  cplx v[NF][P];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
+    for (int m = 0; m < P; ++m) {
       const unsigned n = q + m * TPL;
       v[f][m] = a.in[f][bi + (a.sh_in < 31 ? (n >> a.sh_in) * a.cs_in : 0u) + (n & mi) * a.sn_in];
     }
@@ -259,12 +259,12 @@ __global__ void __launch_bounds__(256, 2) k_pass_sub(SubPassArgs a, const cplx *
   for (int f = 0; f < NF; ++f) {
     if (INV) {
 #pragma unroll
-      for (int m = 0; m < 16; ++m) v[f][m] = cswap(v[f][m]);
+      for (int m = 0; m < P; ++m) v[f][m] = cswap(v[f][m]);
     }
     fft_line<N, Map>(v[f], q, l, X, W);
     if (valid) {
 #pragma unroll
-      for (int m = 0; m < 16; ++m) {
+      for (int m = 0; m < P; ++m) {
         const unsigned n = q + m * TPL;
         a.out[f][bo + (a.sh_out < 31 ? (n >> a.sh_out) * a.cs_out : 0u) + (n & mo) * a.sn_out] =
             INV ? cswap(v[f][m]) : v[f][m];

@@ -24,9 +24,9 @@ inline int launch_z_fwd(mrl_ctx *ctx, const double *in, cplx *o0, cplx *o1, doub
     MRL_TRY(set_lds_attr(ctx, k_z_fwd<N, MODE, FAM>, lds));
     attr = true;
   }
-  constexpr int LPB = 4096 / N;
+  constexpr int LPB = Plan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_fwd<N, MODE, FAM>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, o0, o1, mu, chp, nlines,
+  hipLaunchKernelGGL((k_z_fwd<N, MODE, FAM>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, nlines,
                      ctx->ax[2].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
@@ -40,9 +40,9 @@ inline int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale,
     MRL_TRY(set_lds_attr(ctx, k_z_inv<N>, lds));
     attr = true;
   }
-  constexpr int LPB = 4096 / N;
+  constexpr int LPB = Plan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_inv<N>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, in, out, scale, nlines,
+  hipLaunchKernelGGL((k_z_inv<N>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
                      ctx->ax[2].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
@@ -56,10 +56,10 @@ inline int launch_pass_t(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
     MRL_TRY(set_lds_attr(ctx, k_pass<N, INV, NF>, lds));
     attr = true;
   }
-  constexpr int T = 4096 / N;
+  constexpr int T = Plan<N>::T;
   a.tiles_per_outer = (int)((a.inner + T - 1) / T);
   const long long nb = a.outer * a.tiles_per_outer;
-  hipLaunchKernelGGL((k_pass<N, INV, NF>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, tw);
+  hipLaunchKernelGGL((k_pass<N, INV, NF>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
@@ -72,25 +72,30 @@ inline int launch_pass_sub(mrl_ctx *ctx, const SubPassArgs &a, const cplx *tw) {
     MRL_TRY(set_lds_attr(ctx, k_pass_sub<N, INV, NF>, lds));
     attr = true;
   }
-  constexpr int T = 4096 / N;
+  constexpr int T = Plan<N>::T;
   const long long nb = ((long long)a.rows * a.cols + T - 1) / T;
-  hipLaunchKernelGGL((k_pass_sub<N, INV, NF>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, tw);
+  hipLaunchKernelGGL((k_pass_sub<N, INV, NF>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
 
 }  // namespace p2
 
+// every length with a Plan<N> that the fast paths are instantiated for
 #define MRL_SWITCH_N(n, CALL)  \
   switch (n) {                 \
     case 64: { constexpr int NN = 64; CALL; } break;   \
     case 128: { constexpr int NN = 128; CALL; } break; \
     case 256: { constexpr int NN = 256; CALL; } break; \
     case 512: { constexpr int NN = 512; CALL; } break; \
+    case 100: { constexpr int NN = 100; CALL; } break; \
+    case 200: { constexpr int NN = 200; CALL; } break; \
+    case 400: { constexpr int NN = 400; CALL; } break; \
     default: return MRL_ERR_UNSUPPORTED;               \
   }
 
-inline bool pow2_ok(long long n) { return n == 64 || n == 128 || n == 256 || n == 512; }
+inline bool pow2_ok(long long n) { return n == 64 || n == 128 || n == 256 || n == 512 || n == 100 || n == 200 || n == 400; }
+inline bool is_pow2(long long n) { return n > 0 && (n & (n - 1)) == 0; }
 
 // Adams-Bashforth coefficients (src/tensor_solver/AdamsBashforthMoulton.C:67-73, incl. the AB5 190/720 entry)
 static const double kBetaAB[5][5] = {

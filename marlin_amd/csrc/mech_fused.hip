@@ -25,9 +25,9 @@ struct GammaArgs {
 };
 
 template <int N>
-__global__ void __launch_bounds__(256, 2) k_gamma_xfused(GammaArgs a, const cplx *__restrict__ tw) {
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_xfused(GammaArgs a, const cplx *__restrict__ tw) {
 #pragma clang fp contract(off)
-  constexpr int TPL = N / 16, T = 4096 / N;
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
@@ -40,11 +40,12 @@ __global__ void __launch_bounds__(256, 2) k_gamma_xfused(GammaArgs a, const cplx
   const bool valid = i < a.inner;
   const long long iv = valid ? i : 0;
 
-  cplx twv[(N + 255) / 256];
-  double kxv[(N + 255) / 256];
+  constexpr int NT = Plan<N>::NT, CNT = (N + NT - 1) / NT;
+  cplx twv[CNT];
+  double kxv[CNT];
 #pragma unroll
-  for (int j = 0; j < (N + 255) / 256; ++j) {
-    const int idx = threadIdx.x + j * 256;
+  for (int j = 0; j < CNT; ++j) {
+    const int idx = threadIdx.x + j * NT;
     twv[j] = idx < N ? tw[idx] : make_double2(0.0, 0.0);
     kxv[j] = idx < N ? a.kx[idx] : 0.0;
   }
@@ -52,14 +53,14 @@ __global__ void __launch_bounds__(256, 2) k_gamma_xfused(GammaArgs a, const cplx
   cplx *f0 = a.spec + (long long)(row * 3 + 0) * a.field + iv + (long long)q * a.inner;
   cplx *f1 = f0 + a.field, *f2 = f1 + a.field;
   const long long step = (long long)TPL * a.inner;
-  cplx v0[16], v1[16];
+  cplx v0[P], v1[P];
 #pragma unroll
-  for (int m = 0; m < 16; ++m) v0[m] = f0[m * step];
+  for (int m = 0; m < P; ++m) v0[m] = f0[m * step];
 #pragma unroll
-  for (int m = 0; m < 16; ++m) v1[m] = f1[m * step];
+  for (int m = 0; m < P; ++m) v1[m] = f1[m * step];
 #pragma unroll
-  for (int j = 0; j < (N + 255) / 256; ++j) {
-    const int idx = threadIdx.x + j * 256;
+  for (int j = 0; j < CNT; ++j) {
+    const int idx = threadIdx.x + j * NT;
     if (idx < N) {
       W[idx] = twv[j];
       KX[idx] = kxv[j];
@@ -67,25 +68,25 @@ __global__ void __launch_bounds__(256, 2) k_gamma_xfused(GammaArgs a, const cplx
   }
 
   // s = sum_k A_ik q_k  (q = (kx along the line, ky, kz))
-  cplx s[16];
+  cplx s[P];
   fft_line<N, Map>(v0, q, l, X, W);
 #pragma unroll
-  for (int m = 0; m < 16; ++m) {
+  for (int m = 0; m < P; ++m) {
     const double kx = KX[q + m * TPL];
     s[m] = make_double2(v0[m].x * kx, v0[m].y * kx);
   }
 #pragma unroll
-  for (int m = 0; m < 16; ++m) v0[m] = f2[m * step];  // third component: in flight during the second transform
+  for (int m = 0; m < P; ++m) v0[m] = f2[m * step];  // third component: in flight during the second transform
   fft_line<N, Map>(v1, q, l, X, W);
 #pragma unroll
-  for (int m = 0; m < 16; ++m) {
+  for (int m = 0; m < P; ++m) {
     s[m].x += v1[m].x * ky;
     s[m].y += v1[m].y * ky;
   }
   fft_line<N, Map>(v0, q, l, X, W);
   const double kyz2 = ky * ky + kz * kz;
 #pragma unroll
-  for (int m = 0; m < 16; ++m) {
+  for (int m = 0; m < P; ++m) {
     const double kx = KX[q + m * TPL];
     const double Q = kx * kx + kyz2;
     const double inv = (Q == 0.0) ? 0.0 : a.scale / Q;
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256, 2) k_gamma_xfused(GammaArgs a, const cplx
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
+    for (int m = 0; m < P; ++m) {
       const double qj = (j == 0) ? KX[q + m * TPL] : (j == 1 ? ky : kz);
       v0[m] = make_double2(s[m].y * qj, s[m].x * qj);
     }
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256, 2) k_gamma_xfused(GammaArgs a, const cplx
     if (valid) {
       cplx *o = (j == 0) ? f0 : (j == 1 ? f1 : f2);
 #pragma unroll
-      for (int m = 0; m < 16; ++m) o[m * step] = cswap(v0[m]);
+      for (int m = 0; m < P; ++m) o[m * step] = cswap(v0[m]);
     }
   }
 }
@@ -118,9 +119,9 @@ static int launch_gamma_xfused(mrl_ctx *ctx, const GammaArgs &a) {
     MRL_TRY(set_lds_attr(ctx, k_gamma_xfused<N>, lds));
     attr = true;
   }
-  constexpr int T = 4096 / N;
+  constexpr int T = Plan<N>::T;
   const long long nb = (a.inner + T - 1) / T;
-  hipLaunchKernelGGL((k_gamma_xfused<N>), dim3((unsigned)nb, 3), dim3(256), lds, ctx->stream, a, ctx->ax[0].d_tw);
+  hipLaunchKernelGGL((k_gamma_xfused<N>), dim3((unsigned)nb, 3), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[0].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }

@@ -31,8 +31,8 @@ struct YFusedArgs {
 };
 
 template <int N, int ORDER>
-__global__ void __launch_bounds__(256, 2) k_ch_yfused(YFusedArgs a, const cplx *__restrict__ tw) {
-  constexpr int TPL = N / 16, T = 4096 / N;
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, const cplx *__restrict__ tw) {
+  constexpr int TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256, 2) k_ch_yfused(YFusedArgs a, const cplx *
   };
   const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + a.k0 + kl) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
   auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
-  ch_fused_body<N, ORDER, false, 8>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
+  ch_fused_body<N, ORDER, false, Plan<N>::P / 2>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
 }
 
 template <int N, int ORDER>
@@ -71,10 +71,10 @@ static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
     MRL_TRY(set_lds_attr(ctx, k_ch_yfused<N, ORDER>, lds));
     attr = true;
   }
-  constexpr int T = 4096 / N;
+  constexpr int T = Plan<N>::T;
   a.tiles_per_x = (a.ksub + T - 1) / T;
   const long long nb = (long long)a.nxl * a.tiles_per_x;
-  hipLaunchKernelGGL((k_ch_yfused<N, ORDER>), dim3((unsigned)nb), dim3(256), lds, ctx->stream, a, ctx->ax[1].d_tw);
+  hipLaunchKernelGGL((k_ch_yfused<N, ORDER>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[1].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }

@@ -57,7 +57,8 @@ def test_ch_gold_file():
     assert np.abs(g["mu.10"] - mu.numpy()).max() <= 1e-13
 
 
-@pytest.mark.parametrize("shape", [(16, 16, 16), (12, 10, 9), (32, 32, 32), (24,), (64, 64, 64)])
+@pytest.mark.parametrize("shape", [(16, 16, 16), (12, 10, 9), (32, 32, 32), (24,), (64, 64, 64), (100, 100, 100),
+                                   (200, 64, 100)])
 def test_ch_vs_oracle(shape):
     from marlin_amd.api import Context, ch_params
     dim = len(shape)

@@ -136,3 +136,14 @@ def test_mech_fast_path_vs_oracle():
         assert (Fnew.cpu() - F_ref).abs().max().item() <= 1e-10
         assert (P.cpu() - oracle.P).abs().max().item() <= 1e-9
         F, Fd = F_ref, Fnew
+
+
+def test_gamma_apply_radix10_sizes():
+    """100^3 (register-radix path with the radix 10 plans) against the closed form evaluated with libTorch"""
+    shape, L = (100, 100, 100), (1.0, 2.0, 3.0)
+    dom = mo.Domain(3, list(shape), list(L))
+    torch.manual_seed(6)
+    A = torch.rand(dom.value_shape([3, 3]), dtype=torch.float64)
+    ref = mo.gamma_closed_form(dom, A)
+    got = _ctx(3, shape, L).gamma_apply(A.cuda()).cpu()
+    assert (got - ref).abs().max().item() <= 1e-12
