@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const
 }
 
 template <int N, int ORDER, int PRE = Plan<N>::P / 2>
-static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a) {
+static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
   if (!attr) {
@@ -51,23 +51,49 @@ static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a) {
   }
   constexpr int T = Plan<N>::T;
   const long long nb = (a.inner + T - 1) / T;
-  hipLaunchKernelGGL((k_ch_xfused<N, ORDER, PRE>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[0].d_tw);
+  hipLaunchKernelGGL((k_ch_xfused<N, ORDER, PRE>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
 
 }  // namespace p2
 
+// 3-D grids [nx][ny][nz], and 2-D grids [nx][nz'] run as [nx][1][nz'] (serial contexts hold them as internal axes
+// (1, nx, ny_user): the user's y is the contiguous r2c axis; the absent middle axis contributes k = 0 exactly)
 bool fast_path_ok(const mrl_ctx *ctx) {
-  return ctx->dim == 3 && ctx->nranks == 1 && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
-         pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]);
+  if (ctx->nranks != 1 || ctx->spectrum != MRL_SPECTRUM_HALF) return false;
+  if (ctx->dim == 3) return pow2_ok(ctx->n[0]) && pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]);
+  if (ctx->dim == 2) return pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]);
+  return false;
+}
+
+struct Geo {
+  long long nx, ny, nz, nzc;
+  const cplx *tw_x, *tw_y;
+  const double *kx, *ky, *kz;
+};
+static Geo geo_of(const mrl_ctx *ctx) {
+  Geo g;
+  const int ax = ctx->dim == 3 ? 0 : 1;  // internal axis that carries x
+  g.nx = ctx->n[ax];
+  g.ny = ctx->dim == 3 ? ctx->n[1] : 1;
+  g.nz = ctx->n[2];
+  g.nzc = ctx->nrec[2];
+  g.tw_x = ctx->ax[ax].d_tw;
+  g.tw_y = ctx->ax[1].d_tw;
+  g.kx = ctx->d_k[ax];
+  g.ky = ctx->dim == 3 ? ctx->d_k[1] : ctx->d_k[0];  // 2-D: the unused axis {0}
+  g.kz = ctx->d_k[2];
+  return g;
 }
 
 // strided pass along internal axis `a` (0 = x, 1 = y) of NF complex [nx][ny][nzc] arrays
 static int pass_axis(mrl_ctx *ctx, int axis, bool inv, int nf, const cplx *in0, const cplx *in1, cplx *out0,
                      cplx *out1, bool reverse = false, long long x0 = 0, long long x1 = -1) {
-  const long long ny = ctx->n[1], nzc = ctx->nrec[2];
-  const long long nx = (x1 < 0 ? ctx->n[0] : x1) - x0;  // y pass only: restrict to the x planes [x0, x1)
+  const Geo g = geo_of(ctx);
+  if (axis == 1 && g.ny == 1) return MRL_OK;  // 2-D: there is no middle axis
+  const long long ny = g.ny, nzc = g.nzc;
+  const long long nx = (x1 < 0 ? g.nx : x1) - x0;  // y pass only: restrict to the x planes [x0, x1)
   if (x0 > 0) {
     in0 += x0 * ny * nzc;
     out0 += x0 * ny * nzc;
@@ -92,8 +118,8 @@ static int pass_axis(mrl_ctx *ctx, int axis, bool inv, int nf, const cplx *in0, 
     a.so_in = a.so_out = 0;
     a.sn_in = a.sn_out = ny * nzc;
   }
-  const cplx *tw = ctx->ax[axis].d_tw;
-  const long long n = ctx->n[axis];
+  const cplx *tw = axis == 1 ? g.tw_y : g.tw_x;
+  const long long n = axis == 1 ? g.ny : g.nx;
   if (nf == 2) {
     if (inv) {
       MRL_SWITCH_N(n, MRL_TRY((p2::launch_pass_t<NN, true, 2>(ctx, a, tw))));
@@ -112,7 +138,8 @@ static int pass_axis(mrl_ctx *ctx, int axis, bool inv, int nf, const cplx *in0, 
 
 // plain transforms (field-major batch), used by mrl_fft_r2c / mrl_fft_c2r on fast-path shapes
 int fft_forward_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch) {
-  const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
+  const Geo g = geo_of(ctx);
+  const long long nx = g.nx, ny = g.ny, nz = g.nz, nzc = g.nzc;
   const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
   p2::ChDev none{};
   for (long long b = 0; b < batch; ++b) {
@@ -135,7 +162,8 @@ int fft_forward_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long 
 }
 
 int fft_inverse_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch) {
-  const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
+  const Geo g = geo_of(ctx);
+  const long long nx = g.nx, ny = g.ny, nz = g.nz, nzc = g.nzc;
   const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
   const double scale = 1.0 / ((double)nx * (double)ny * (double)nz);
   MRL_TRY(ensure_work(ctx, 0, sizeof(cplx) * nspec));
@@ -162,7 +190,8 @@ int fft_inverse_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long 
 int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new,
                      const double *const *Nhat_old, int order, double sub_dt, double *cbar, double *mu) {
   if (!fast_path_ok(ctx)) return MRL_ERR_UNSUPPORTED;
-  const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
+  const Geo g = geo_of(ctx);
+  const long long nx = g.nx, ny = g.ny, nz = g.nz, nzc = g.nzc;
   const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
   MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nspec));
   MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nspec));
@@ -207,18 +236,18 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
     for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaAB[order][i];
     a.inner = ny * nzc;
     a.nzc = (int)nzc;
-    a.kx = ctx->d_k[0];
-    a.ky = ctx->d_k[1];
-    a.kz = ctx->d_k[2];
+    a.kx = g.kx;
+    a.ky = g.ky;
+    a.kz = g.kz;
     a.c.M = cp.M;
     a.c.kappa = cp.kappa;
     a.c.dt = sub_dt;
     switch (order) {
-      case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0>(ctx, a)))); break;
-      case 1: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 1>(ctx, a)))); break;  // PRE = 8 (4, 12: same; 16 spills: -12 %)
-      case 2: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 2>(ctx, a)))); break;
-      case 3: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 3>(ctx, a)))); break;
-      default: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 4>(ctx, a)))); break;
+      case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0>(ctx, a, g.tw_x)))); break;
+      case 1: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 1>(ctx, a, g.tw_x)))); break;  // PRE = 8 (4, 12: same; 16 spills: -12 %)
+      case 2: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 2>(ctx, a, g.tw_x)))); break;
+      case 3: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 3>(ctx, a, g.tw_x)))); break;
+      default: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 4>(ctx, a, g.tw_x)))); break;
     }
   }
   {

@@ -791,7 +791,7 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const double *in, cp
   // lines per workgroup / threads per workgroup of Plan<N> (fft_pow2.h)
   int T = 0, NT = 0;
   switch (N) {
-    case 64: case 128: case 256: case 512: T = 4096 / N; NT = 256; break;
+    case 64: case 128: case 256: case 512: case 1024: T = 4096 / N; NT = 256; break;
     case 100: T = 25; NT = 250; break;
     case 200: T = 12; NT = 240; break;
     case 400: T = 6; NT = 240; break;

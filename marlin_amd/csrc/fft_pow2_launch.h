@@ -88,13 +88,16 @@ inline int launch_pass_sub(mrl_ctx *ctx, const SubPassArgs &a, const cplx *tw) {
     case 128: { constexpr int NN = 128; CALL; } break; \
     case 256: { constexpr int NN = 256; CALL; } break; \
     case 512: { constexpr int NN = 512; CALL; } break; \
+    case 1024: { constexpr int NN = 1024; CALL; } break; \
     case 100: { constexpr int NN = 100; CALL; } break; \
     case 200: { constexpr int NN = 200; CALL; } break; \
     case 400: { constexpr int NN = 400; CALL; } break; \
     default: return MRL_ERR_UNSUPPORTED;               \
   }
 
-inline bool pow2_ok(long long n) { return n == 64 || n == 128 || n == 256 || n == 512 || n == 100 || n == 200 || n == 400; }
+inline bool pow2_ok(long long n) {
+  return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024 || n == 100 || n == 200 || n == 400;
+}
 inline bool is_pow2(long long n) { return n > 0 && (n & (n - 1)) == 0; }
 
 // Adams-Bashforth coefficients (src/tensor_solver/AdamsBashforthMoulton.C:67-73, incl. the AB5 190/720 entry)

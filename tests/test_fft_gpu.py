@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [
     (9,), (10,), (16,), (127,), (200,),
-    (7, 9), (8, 6), (20, 20), (33, 17), (64, 128),
+    (7, 9), (8, 6), (20, 20), (33, 17), (64, 128), (200, 100), (256, 512), (1024, 64),
     (5, 7, 9), (6, 8, 4), (5, 6, 7), (16, 16, 16), (12, 20, 30), (32, 64, 128), (40, 40, 40),
     (100, 100, 100), (200, 100, 64), (64, 200, 100), (100, 64, 400),     # register-radix path, radix 10 / 5 / 2 plans
 ]
