@@ -229,7 +229,7 @@ def main():
                 "algorithmic_bytes_per_launch": dom_k["bytes_per_launch"],
             }
         if roofline and world == 1:
-            tr, src = measured_traffic(dom_k["kernel"], args.n, f"<{args.n}, 1>" if dom_k["kernel"] == "ch_C_x_fused" else None)
+            tr, src = measured_traffic(dom_k["kernel"], args.n, f"<{args.n}, 1" if dom_k["kernel"] == "ch_C_x_fused" else None)
             roofline["traffic"], roofline["traffic_source"] = tr, src
         out = {
             "metric": "grid-point-updates/sec, 3-D Cahn-Hilliard semi-implicit spectral substep (AB2, fp64)",

@@ -105,9 +105,12 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_fwd(const double *__restri
 
 // ---------------------------------------------------------------------------------------------
 // z inverse (PAIR): rows 2L, 2L+1 of the half spectrum `in` -> real rows 2L, 2L+1 of out, * scale.
-template <int N>
+// DOT: additionally accumulates sum(out * dotv) over the rows written (one partial per workgroup, deterministic): the
+// p.Ap of the conjugate-gradient iteration, taken while Ap is still in registers instead of re-reading it from HBM.
+template <int N, bool DOT = false>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv(const cplx *__restrict__ in, double *__restrict__ out, double scale,
-                                               long long nlines, const cplx *__restrict__ tw) {
+                                               long long nlines, const cplx *__restrict__ tw,
+                                               const double *__restrict__ dotv = nullptr, double *__restrict__ partial = nullptr) {
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = Plan<N>::T, NZC = N / 2 + 1;
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -147,13 +150,41 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv(const cplx *__restrict
     }
   }
   fft_line<N, Map>(v, q, l, X, W);
-  if (!valid) return;
-  double *o0 = out + (2 * L) * N + q;
+  double acc = 0.0;
+  if (valid) {
+    double *o0 = out + (2 * L) * N + q;
+    double pa[DOT ? P : 1], pb[DOT ? P : 1];
+    if (DOT) {
+      const double *d0 = dotv + (2 * L) * N + q;
 #pragma unroll
-  for (int m = 0; m < P; ++m) {
-    // swap back: real part (row 2L) = v.y, imaginary part (row 2L+1) = v.x
-    o0[m * TPL] = v[m].y * scale;
-    o0[N + m * TPL] = v[m].x * scale;
+      for (int m = 0; m < P; ++m) {
+        pa[DOT ? m : 0] = d0[m * TPL];
+        pb[DOT ? m : 0] = d0[N + m * TPL];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      // swap back: real part (row 2L) = v.y, imaginary part (row 2L+1) = v.x
+      const double ra = v[m].y * scale, rb = v[m].x * scale;
+      o0[m * TPL] = ra;
+      o0[N + m * TPL] = rb;
+      if (DOT) acc += ra * pa[DOT ? m : 0] + rb * pb[DOT ? m : 0];
+    }
+  }
+  if (DOT) {
+    // workgroup sum through LDS (the exchange tile is free again); NT need not be a multiple of 64
+    constexpr int NT = Plan<N>::NT;
+    double *S = reinterpret_cast<double *>(X);
+    __syncthreads();
+    S[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      double s = 0.0;
+      for (int i = threadIdx.x; i < NT; i += 64) s += S[i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+      if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    }
   }
 }
 

@@ -37,14 +37,33 @@ inline int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale,
   static bool attr = false;
   constexpr size_t lds = lds_line<N>();
   if (!attr) {
-    MRL_TRY(set_lds_attr(ctx, k_z_inv<N>, lds));
+    MRL_TRY(set_lds_attr(ctx, k_z_inv<N, false>, lds));
     attr = true;
   }
   constexpr int LPB = Plan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_inv<N>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
-                     ctx->ax[2].d_tw);
+  hipLaunchKernelGGL((k_z_inv<N, false>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
+                     ctx->ax[2].d_tw, nullptr, nullptr);
   MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+// z inverse that also leaves sum(out * dotv) as one partial per workgroup in `partial`; *nblocks = their number
+template <int N>
+inline int launch_z_inv_dot(mrl_ctx *ctx, const cplx *in, double *out, double scale, long long nlines, const double *dotv,
+                            double *partial, int *nblocks) {
+  static bool attr = false;
+  constexpr size_t lds = lds_line<N>();
+  if (!attr) {
+    MRL_TRY(set_lds_attr(ctx, k_z_inv<N, true>, lds));
+    attr = true;
+  }
+  constexpr int LPB = Plan<N>::T;
+  const long long nb = (nlines + LPB - 1) / LPB;
+  hipLaunchKernelGGL((k_z_inv<N, true>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
+                     ctx->ax[2].d_tw, dotv, partial);
+  MRL_HIP(ctx, hipGetLastError());
+  *nblocks = (int)nb;
   return MRL_OK;
 }
 

@@ -383,7 +383,8 @@ static int check_dim(mrl_ctx *ctx, const char *what, bool serial = true) {
 }
 
 bool mech_fast_ok(const mrl_ctx *ctx);
-int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale);
+int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale, const double *dotv = nullptr,
+               double *d_dot = nullptr);
 
 int stress_launch(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *P, bool soa) {
   const long long npts = real_count_local(ctx);
@@ -637,9 +638,13 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
         } else {
           // p = r + beta p (beta = rr_new / rr_old of the previous iteration) fused into the operator application
           MRL_TRY(tangent_dir_launch(ctx, lin, d_K, d_mu, p, r, S, i_old, i_new, tmp, soa));
-          MRL_TRY(gamma(tmp, Ap, 1.0));
+          if (soa) {
+            MRL_TRY(gamma_fast(ctx, tmp, Ap, 1.0, p, S + 1));  // p.Ap taken in the last pass of G
+          } else {
+            MRL_TRY(gamma(tmp, Ap, 1.0));
+          }
         }
-        {
+        if (!(soa && k > 0)) {
           ProfScope ps(ctx, "cg_dot_pAp", 16.0 * n);
           MRL_TRY(reduce_async(ctx, 1, p, Ap, n, S + 1));
         }

@@ -133,8 +133,10 @@ bool mech_fast_ok(const mrl_ctx *ctx) {
          pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]);
 }
 
-// out = scale * G(A), A and out field-major real [9][nx][ny][nz] (out may alias A)
-int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale) {
+// out = scale * G(A), A and out field-major real [9][nx][ny][nz] (out may alias A).  dotv != nullptr: the last pass
+// also accumulates sum(out * dotv) into the device scalar d_dot (deterministic two-stage sum)
+int reduce_finalize_from(mrl_ctx *ctx, const double *partial, int nb, double *d_scalar);
+int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale, const double *dotv, double *d_dot) {
   const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
   const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
   MRL_TRY(ensure_work(ctx, 4, sizeof(cplx) * nspec * 9));
@@ -176,10 +178,18 @@ int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale) {
     pa.reverse = 0;
     MRL_SWITCH_N(ny, MRL_TRY((p2::launch_pass_t<NN, true, 1>(ctx, pa, ctx->ax[1].d_tw))));
   }
-  ProfScope ps(ctx, "gamma_z_inv", r + h);
   const double norm = 1.0 / ((double)nx * (double)ny * (double)nz);
-  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, spec, out, norm, 9 * nx * ny / 2))));
-  return MRL_OK;
+  if (!dotv) {
+    ProfScope ps(ctx, "gamma_z_inv", r + h);
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, spec, out, norm, 9 * nx * ny / 2))));
+    return MRL_OK;
+  }
+  ProfScope ps(ctx, "gamma_z_inv_dot", 2.0 * r + h);
+  const long long max_blocks = 9 * nx * ny / 2;  // >= the number of workgroups for every plan
+  MRL_TRY(ensure_work(ctx, 3, sizeof(double) * (size_t)max_blocks));
+  int nb = 0;
+  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_dot<NN>(ctx, spec, out, norm, 9 * nx * ny / 2, dotv, ctx->d_work[3], &nb))));
+  return reduce_finalize_from(ctx, ctx->d_work[3], nb, d_dot);
 }
 
 }  // namespace mrl

@@ -154,6 +154,13 @@ int reduce_finalize(mrl_ctx *ctx, int nb, int nslots, double *d_scalar) {
   return MRL_OK;
 }
 
+// the same for partials in a caller-supplied buffer (any number of workgroups)
+int reduce_finalize_from(mrl_ctx *ctx, const double *partial, int nb, double *d_scalar) {
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, partial, nb, 1, d_scalar);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
 // copy `count` device scalars starting at d_scalar to host (synchronises the stream)
 int read_scalars(mrl_ctx *ctx, const double *d_scalar, int count, double *h_out) {
   MRL_HIP(ctx, hipMemcpyAsync(ctx->h_red, d_scalar, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
