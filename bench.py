@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--grid", dest="n", type=int, default=256, help="base grid edge (per-GPU work = n^3 points)")
     ap.add_argument("--cpu-steps", type=int, default=24, help="substeps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--mech-grid", type=int, default=128, help="edge of the de Geus RVE side benchmark (config C); 0 = skip")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke runs)")
     ap.add_argument("--nsub", type=int, default=4, help="kz sub-blocks the slab substep is pipelined over (N > 1)")
     args = ap.parse_args()
@@ -257,6 +258,16 @@ def main():
             "kernels": [{"kernel": k["kernel"], "avg_ms": round(k["avg_ms"], 5), "launches_per_step":
                          k["launches"] / args.profile_steps, "algorithmic_GBps": round(k["gbps"], 1)} for k in kernels],
         }
+        if world == 1 and args.mech_grid > 0:
+            # side measurement (BASELINE configs[2]): de Geus RVE Newton-CG, time per CG iteration, SURVEY 8(d) byte model
+            from tools.mech_bench import run as mech_run
+            del c, Nh
+            torch.cuda.empty_cache()
+            m = mech_run(args.mech_grid, 2, profile=False)
+            out["mechanics"] = {"workload": f"de Geus finite-strain RVE {args.mech_grid}^3, Newton-CG (l_tol 1e-2)",
+                                "ms_per_cg_iteration": m["ms_per_cg_iteration"], "cg_iterations_per_substep": m["cg_its"],
+                                "algorithmic_bytes_per_point_per_cg_iteration": m["algorithmic_bytes_per_point_per_cg_iteration"],
+                                "achieved_GBps": m["achieved_GBps"], "frac_of_hbm_peak": m["achieved_GBps"] / HBM_PEAK_GBPS}
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(shape, dx, args.cpu_steps)
         print(json.dumps(out))

@@ -14,9 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from marlin_amd.api import Context  # noqa: E402
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-    substeps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+def run(n=128, substeps=2, profile=True):
     L = 2.0 * torch.pi
     ctx = Context(3, [n, n, n], [L, L, L])
     s = 9 * n // 32
@@ -27,7 +25,7 @@ def main():
     F = torch.eye(3, dtype=torch.float64).expand(n, n, n, 3, 3).contiguous().cuda()
     sub_dt = 0.01 / 10
     res = []
-    for it in range(2 * substeps + 1):
+    for it in range((2 if profile else 1) * substeps + 1):
         if it == substeps + 1:      # second half: per-kernel event timing (adds launch overhead; not part of the headline time)
             ctx.set_profiling(True)
         t = it * sub_dt
@@ -57,7 +55,13 @@ def main():
                                "avg_ms": round(k["ms"] / k["launches"], 4),
                                "GBps": round(k["bytes_per_launch"] / (k["ms"] / k["launches"]) / 1e6, 1)} for k in prof],
                              key=lambda k: -k["total_ms"])}
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    substeps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    print(json.dumps(run(n, substeps)))
 
 
 if __name__ == "__main__":
