@@ -795,6 +795,9 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const double *in, cp
     case 100: T = 25; NT = 250; break;
     case 200: T = 12; NT = 240; break;
     case 400: T = 6; NT = 240; break;
+    case 96: T = 32; NT = 256; break;
+    case 192: T = 16; NT = 256; break;
+    case 384: T = 8; NT = 256; break;
     default: return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
   }
   auto it = p->zfwd.find(N);

@@ -47,6 +47,12 @@ MRL_PLAN(200, 10, 10, 10, 2, 1, 12)
 MRL_PLAN(250, 10, 10, 5, 5, 1, 10)
 MRL_PLAN(400, 10, 10, 10, 2, 2, 6)
 MRL_PLAN(500, 10, 10, 10, 5, 1, 5)
+// sizes 2^a 3^b: radix 12 / 4 / 2, 12 points per thread
+MRL_PLAN(48, 12, 12, 4, 1, 1, 64)
+MRL_PLAN(96, 12, 12, 4, 2, 1, 32)
+MRL_PLAN(144, 12, 12, 12, 1, 1, 21)
+MRL_PLAN(192, 12, 12, 4, 4, 1, 16)
+MRL_PLAN(384, 12, 12, 4, 4, 2, 8)
 #undef MRL_PLAN
 
 __device__ __forceinline__ void bfly4(cplx &a0, cplx &a1, cplx &a2, cplx &a3) {
@@ -113,6 +119,44 @@ __device__ __forceinline__ void bfly<16>(cplx (&a)[16]) {
   a[j] = t;
   MRL_SWAP(1, 4) MRL_SWAP(2, 8) MRL_SWAP(3, 12) MRL_SWAP(6, 9) MRL_SWAP(7, 13) MRL_SWAP(11, 14)
 #undef MRL_SWAP
+}
+
+template <>
+__device__ __forceinline__ void bfly<3>(cplx (&a)[3]) {
+  const double s = 0.86602540378443864676;  // sin(pi/3)
+  const cplx t = cadd(a[1], a[2]);
+  const cplx m = make_double2(a[0].x - 0.5 * t.x, a[0].y - 0.5 * t.y);
+  const cplx n = make_double2(s * (a[1].x - a[2].x), s * (a[1].y - a[2].y));
+  a[0] = cadd(a[0], t);
+  a[1] = make_double2(m.x + n.y, m.y - n.x);  // m - i n
+  a[2] = make_double2(m.x - n.y, m.y + n.x);  // m + i n
+}
+
+// radix 12 = 4 x 3 (Cooley-Tukey): n = 3 n1 + n2, k = k1 + 4 k2
+template <>
+__device__ __forceinline__ void bfly<12>(cplx (&a)[12]) {
+  const double h = 0.5, s = 0.86602540378443864676;
+  // radix 4 over n1 for each n2: (a[n2], a[n2+3], a[n2+6], a[n2+9]) -> A[n2][k1] left in the same slots (k1 = slot/3)
+#pragma unroll
+  for (int n2 = 0; n2 < 3; ++n2) bfly4(a[n2], a[n2 + 3], a[n2 + 6], a[n2 + 9]);
+  // twiddles W12^(n2*k1): slot n2 + 3*k1
+  a[4] = cmul(a[4], make_double2(s, -h));     // 1*1 -> W12^1
+  a[7] = cmul(a[7], make_double2(h, -s));     // 1*2 -> W12^2
+  a[10] = mul_mi(a[10]);                      // 1*3 -> W12^3 = -i
+  a[5] = cmul(a[5], make_double2(h, -s));     // 2*1 -> W12^2
+  a[8] = cmul(a[8], make_double2(-h, -s));    // 2*2 -> W12^4
+  a[11] = make_double2(-a[11].x, -a[11].y);   // 2*3 -> W12^6 = -1
+  // radix 3 over n2 for each k1: X[k1 + 4 k2]
+  cplx r[12];
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    cplx b[3] = {a[3 * k1], a[3 * k1 + 1], a[3 * k1 + 2]};
+    bfly<3>(b);
+#pragma unroll
+    for (int k2 = 0; k2 < 3; ++k2) r[k1 + 4 * k2] = b[k2];
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) a[i] = r[i];
 }
 
 template <>

@@ -111,11 +111,15 @@ inline int launch_pass_sub(mrl_ctx *ctx, const SubPassArgs &a, const cplx *tw) {
     case 100: { constexpr int NN = 100; CALL; } break; \
     case 200: { constexpr int NN = 200; CALL; } break; \
     case 400: { constexpr int NN = 400; CALL; } break; \
+    case 96: { constexpr int NN = 96; CALL; } break;   \
+    case 192: { constexpr int NN = 192; CALL; } break; \
+    case 384: { constexpr int NN = 384; CALL; } break; \
     default: return MRL_ERR_UNSUPPORTED;               \
   }
 
 inline bool pow2_ok(long long n) {
-  return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024 || n == 100 || n == 200 || n == 400;
+  return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024 || n == 100 || n == 200 || n == 400 || n == 96 || n == 192 ||
+         n == 384;
 }
 inline bool is_pow2(long long n) { return n > 0 && (n & (n - 1)) == 0; }
 

@@ -58,7 +58,7 @@ def test_ch_gold_file():
 
 
 @pytest.mark.parametrize("shape", [(16, 16, 16), (12, 10, 9), (32, 32, 32), (24,), (64, 64, 64), (100, 100, 100),
-                                   (200, 64, 100), (128, 128), (200, 100), (64, 400)])
+                                   (200, 64, 100), (128, 128), (200, 100), (64, 400), (96, 192, 64), (384, 96)])
 def test_ch_vs_oracle(shape):
     from marlin_amd.api import Context, ch_params
     dim = len(shape)

@@ -11,6 +11,7 @@ SHAPES = [
     (7, 9), (8, 6), (20, 20), (33, 17), (64, 128), (200, 100), (256, 512), (1024, 64),
     (5, 7, 9), (6, 8, 4), (5, 6, 7), (16, 16, 16), (12, 20, 30), (32, 64, 128), (40, 40, 40),
     (100, 100, 100), (200, 100, 64), (64, 200, 100), (100, 64, 400),     # register-radix path, radix 10 / 5 / 2 plans
+    (96, 96, 96), (192, 64, 100), (64, 96, 384), (192, 96),               # radix 12 / 4 / 2 plans
 ]
 
 
