@@ -239,6 +239,35 @@ static int run_etdrk4_diffusion(DomainAction & domain, const std::string & out)
   return 0;
 }
 
+// test/tests/gradient/gradient.i: spectral gradient of sin(x)+sin(y)+sin(z) on an anisotropic box vs the analytic one
+static int run_gradient(DomainAction & domain, const std::string & out)
+{
+  TensorProblem problem(domain);
+  auto parsed = [&](const std::string & buffer, const std::string & expr, std::vector<std::string> inputs, bool extra) {
+    ParsedCompute::Params p;
+    p.buffer = buffer;
+    p.expression = expr;
+    p.inputs = std::move(inputs);
+    p.extra_symbols = extra;
+    ParsedCompute(problem, buffer, p).computeBuffer();
+  };
+  parsed("s", "sin(x)+sin(y)+sin(z)", {}, true);
+  parsed("cx", "cos(x)", {}, true);
+  parsed("cy", "cos(y)", {}, true);
+  parsed("cz", "cos(z)", {}, true);
+  FFTGradient(problem, "gradx_sin", "gradx_s", "s", 0).computeBuffer();
+  FFTGradient(problem, "grady_sin", "grady_s", "s", 1).computeBuffer();
+  FFTGradient(problem, "gradz_sin", "gradz_s", "s", 2).computeBuffer();
+  parsed("diff", "abs(gradx_s - cx)+abs(grady_s - cy)+abs(gradz_s - cz)", {"gradx_s", "grady_s", "gradz_s", "cx", "cy", "cz"}, false);
+  double volume = 1.0;
+  for (int d = 0; d < domain.getDim(); ++d)
+    volume *= domain.getExtent(d);
+  std::ofstream csv(out + "/gradient.csv");
+  csv.precision(17);
+  csv << "time,diff\n0,0\n1," << TensorPostprocessors::integral(domain, problem.getBuffer("diff"), volume) << "\n";
+  return 0;
+}
+
 int main(int argc, char ** argv)
 {
   for (int i = 1; i < argc; ++i)
@@ -262,12 +291,12 @@ int main(int argc, char ** argv)
     const char * mn[3] = {"xmin", "ymin", "zmin"};
     std::vector<int64_t> n;
     std::vector<double> lo, hi;
-    const double two_pi = 2.0 * M_PI;
     for (int d = 0; d < dim; ++d)
     {
       n.push_back(argi(nn[d], 1));
       lo.push_back(argd(mn[d], 0.0));
-      hi.push_back(arg(mx[d]) == "2pi" ? two_pi : argd(mx[d], 1.0));
+      const std::string m = arg(mx[d]);  // "2pi", "4pi", "6pi" or a number
+      hi.push_back(m.size() > 2 && m.substr(m.size() - 2) == "pi" ? std::atof(m.c_str()) * M_PI : argd(mx[d], 1.0));
     }
     DomainAction domain(dim, n, hi, lo);
     const std::string out = arg("out", ".");
@@ -280,6 +309,8 @@ int main(int argc, char ** argv)
       return run_brusselator(domain, out);
     if (problem == "etdrk4_diffusion")
       return run_etdrk4_diffusion(domain, out);
+    if (problem == "gradient")
+      return run_gradient(domain, out);
     mooseError("unknown problem '" + problem + "'");
   }
   catch (const std::exception & e)

@@ -532,6 +532,38 @@ private:
   DeviceTensor & _input;
 };
 
+/// FFTGradient::computeBuffer (src/tensor_computes/FFTGradient.C:36-40): _u = ifft(fft(input) * k_direction * i),
+/// the k-space product as one fused parsed kernel
+class FFTGradient : public TensorOperatorBase
+{
+public:
+  FFTGradient(TensorProblem & problem, const std::string & name, const std::string & buffer, const std::string & input,
+              int direction)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer)), _input(getInputBuffer(input))
+  {
+    static const char * k[] = {"kx", "ky", "kz"};
+    const std::string expr = std::string("abar*") + k[direction] + "*i";
+    const char * in[] = {"abar"};
+    const int cplx[] = {1};
+    if (mrl_parsed_create(_domain.ctx(), &_parsed, expr.c_str(), 1, in, cplx, 0, nullptr, nullptr, 0, nullptr, 1, 1) != MRL_OK)
+      paramError("direction", mrl_last_error(_domain.ctx()));
+  }
+  ~FFTGradient() { mrl_parsed_destroy(_parsed); }
+  void computeBuffer() override
+  {
+    const auto abar = _domain.fft(_input);
+    auto gbar = DeviceTensor::empty(abar.numel());
+    const double * in[] = {abar.data()};
+    _domain.check(mrl_parsed_eval(_parsed, in, gbar.data(), _domain.getReciprocalSize(), 0.0));
+    _u = _domain.ifft(gbar);
+  }
+
+private:
+  DeviceTensor & _u;
+  DeviceTensor & _input;
+  mrl_parsed * _parsed = nullptr;
+};
+
 /// ReciprocalLaplacianFactor (-k^2 f) / ReciprocalLaplacianSquareFactor (k^4 f)
 class ReciprocalLaplacianFactor : public TensorOperatorBase
 {

@@ -93,3 +93,12 @@ def test_etdrk4_case(tmp_path):
     got = np.loadtxt(tmp_path / "etdrk4.csv", delimiter=",", skiprows=1)
     assert got.shape == g.shape
     assert np.abs(got[1:, 1:] - g[1:, 1:]).max() <= 1e-12
+
+
+def test_gradient_case(tmp_path):
+    """test/tests/gradient/tests (gradient.i): FFTGradient of sin(x)+sin(y)+sin(z) on a 40^3 anisotropic box vs the
+    analytic gradient; the gold value is the integrated round-off (7.6e-12) -- ours must be round-off too"""
+    g = load_golden("fft_gold.npz")["gradient_out"]
+    _run(["problem=gradient", "dim=3", "nx=40", "ny=40", "nz=40", "xmax=2pi", "ymax=4pi", "zmax=6pi"], tmp_path)
+    got = np.loadtxt(tmp_path / "gradient.csv", delimiter=",", skiprows=1)
+    assert 0.0 <= got[1, 1] <= 10.0 * g[1, 1]
