@@ -148,6 +148,21 @@ int mrl_reciprocal_laplacian(mrl_ctx *ctx, int power, double factor, double *d_o
 int mrl_kspace_abm(mrl_ctx *ctx, double *d_ubar_out, const double *d_ubar0, const double *const *d_N,
                    const double *h_coef, int nterms, const double *d_L, double dt, int64_t n_spec);
 
+/* Coupled k-space update of AdamsBashforthMoultonCoupled::substep (AdamsBashforthMoultonCoupled.C:118-186, corrector
+ * :214-270): for nvar <= 4 variables, at every reciprocal grid point
+ *   rhs_i = ubar0_i + sum_t coef[i][t] * N[i][t]          (h_nterms[i] <= 6 terms; d_N / h_coef are the rows concatenated)
+ *   solve (I - dt * Lhat) ubar = rhs                       (dense nvar x nvar, LU with partial pivoting, one thread per k)
+ * d_L[i*nvar + j] = real array of the linear operator entry the input file names (row i, column j), NULL = zero.
+ * Default flags (0) reproduce the reference bit for bit in structure, including two of its quirks that its gold files
+ * (test/tests/solvers/gold/coupled_*.csv) pin: the matrix is assembled transposed (A_ab = delta_ab - dt*L_ba, :160-178)
+ * and the complex right-hand side is cast to the real dtype of L, dropping Im(rhs) (:183; outputs then have Im = 0).
+ * MRL_COUPLED_L_AS_WRITTEN uses A_ab = delta_ab - dt*L_ab; MRL_COUPLED_COMPLEX_RHS solves for the full complex rhs. */
+#define MRL_COUPLED_L_AS_WRITTEN 1
+#define MRL_COUPLED_COMPLEX_RHS 2
+int mrl_kspace_coupled(mrl_ctx *ctx, int nvar, double *const *d_ubar_out, const double *const *d_ubar0,
+                       const double *const *d_N, const double *h_coef, const int *h_nterms, const double *const *d_L,
+                       double dt, int flags, int64_t n_spec);
+
 /* Slab (multi-GPU) CH substep (AdamsBashforthMoulton::substep over DomainAction::fftSlab/ifftSlab), split at its
  * exchanges and pipelined over `nsub` sub-blocks of the kz axis: after the z pass every kz plane is an independent
  * 2-D problem, so the caller can put sub-block s on the wire while sub-block s+1 is being transformed.

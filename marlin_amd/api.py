@@ -192,6 +192,22 @@ class Context:
         cf = (C.c_double * max(1, n))(*coef)
         self._check(self.lib.mrl_kspace_abm(self.h, _ptr(out), _ptr(ubar0), arr, cf, n, _ptr(L), dt, ubar0.numel()))
 
+    COUPLED_L_AS_WRITTEN, COUPLED_COMPLEX_RHS = 1, 2
+
+    def kspace_coupled(self, out: Sequence[torch.Tensor], ubar0: Sequence[torch.Tensor], N: Sequence[Sequence[torch.Tensor]],
+                       coef: Sequence[Sequence[float]], L: Sequence[Sequence[Optional[torch.Tensor]]], dt: float, flags: int = 0):
+        """AdamsBashforthMoultonCoupled's per-k dense solve (see mrl_kspace_coupled); L[i][j] = real array or None"""
+        nv = len(out)
+        flatN = [t for row in N for t in row]
+        flatc = [float(c) for row in coef for c in row]
+        outs = (C.c_void_p * nv)(*[t.data_ptr() for t in out])
+        u0 = (C.c_void_p * nv)(*[t.data_ptr() for t in ubar0])
+        arr = (C.c_void_p * max(1, len(flatN)))(*[t.data_ptr() for t in flatN])
+        cf = (C.c_double * max(1, len(flatc)))(*flatc)
+        nt = (C.c_int32 * nv)(*[len(row) for row in N])
+        Lp = (C.c_void_p * (nv * nv))(*[(L[i][j].data_ptr() if L[i][j] is not None else None) for i in range(nv) for j in range(nv)])
+        self._check(self.lib.mrl_kspace_coupled(self.h, nv, outs, u0, arr, cf, nt, Lp, dt, flags, ubar0[0].numel()))
+
     # ---- de Geus mechanics (value-major [grid..., D, D] fields)
     def gamma_apply(self, A: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:

@@ -126,6 +126,98 @@ __global__ void __launch_bounds__(256) k_kspace_abm(AbmArgs a, double2 *__restri
   }
 }
 
+// AdamsBashforthMoultonCoupled (AdamsBashforthMoultonCoupled.C:141-186): per reciprocal grid point, rhs_i = ubar0_i + sum_t coef_it N_it
+// and the dense nvar x nvar solve of (I - dt*L) ubar = rhs by LU with partial pivoting (what at::linalg_solve's gesv does).
+// The reference stacks the columns of each row on the last axis and then the rows on a new last axis (:160-176), so the
+// matrix it hands to the solver is A[a][b] = delta_ab - dt * L_ba (the transpose of the operator table of the input file),
+// and it casts the complex right-hand side to the real dtype of L (:183), i.e. only Re(rhs) enters the solve; both are
+// reproduced unless the corresponding flag asks for the operator as written / the full complex solve.
+struct CoupledArgs {
+  int nterms[4];
+  double coef[4][6];
+  const double *N[4][6];
+  const double *u0[4];
+  const double *L[16];
+  double *out[4];
+  double dt;
+  int flags;
+};
+
+template <int NV>
+__global__ void __launch_bounds__(256) k_kspace_coupled(CoupledArgs a, long long n) {
+#pragma clang fp contract(off)
+  const bool real_rhs = !(a.flags & MRL_COUPLED_COMPLEX_RHS), transposed = !(a.flags & MRL_COUPLED_L_AS_WRITTEN);
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    double A[NV][NV], br[NV], bi[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      double2 u = reinterpret_cast<const double2 *>(a.u0[i])[e];
+      for (int t = 0; t < a.nterms[i]; ++t) {
+        const double2 o = reinterpret_cast<const double2 *>(a.N[i][t])[e];
+        u.x += a.coef[i][t] * o.x;
+        u.y += a.coef[i][t] * o.y;
+      }
+      br[i] = u.x;
+      bi[i] = real_rhs ? 0.0 : u.y;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const double *Lp = transposed ? a.L[j * NV + i] : a.L[i * NV + j];
+        const double l = Lp ? Lp[e] : 0.0;
+        A[i][j] = (i == j ? 1.0 : 0.0) - a.dt * l;
+      }
+    }
+    // LU with partial pivoting (row swaps done with selects so that A stays in registers)
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      int piv = c;
+      double best = fabs(A[c][c]);
+#pragma unroll
+      for (int r = c + 1; r < NV; ++r)
+        if (fabs(A[r][c]) > best) {
+          best = fabs(A[r][c]);
+          piv = r;
+        }
+#pragma unroll
+      for (int r = c + 1; r < NV; ++r)
+        if (piv == r) {
+#pragma unroll
+          for (int j = 0; j < NV; ++j) {
+            const double t = A[c][j];
+            A[c][j] = A[r][j];
+            A[r][j] = t;
+          }
+          double t = br[c];
+          br[c] = br[r];
+          br[r] = t;
+          t = bi[c];
+          bi[c] = bi[r];
+          bi[r] = t;
+        }
+      const double inv = 1.0 / A[c][c];
+#pragma unroll
+      for (int r = c + 1; r < NV; ++r) {
+        const double f = A[r][c] * inv;
+#pragma unroll
+        for (int j = c + 1; j < NV; ++j) A[r][j] -= f * A[c][j];
+        br[r] -= f * br[c];
+        bi[r] -= f * bi[c];
+      }
+    }
+#pragma unroll
+    for (int c = NV - 1; c >= 0; --c) {
+#pragma unroll
+      for (int j = c + 1; j < NV; ++j) {
+        br[c] -= A[c][j] * br[j];
+        bi[c] -= A[c][j] * bi[j];
+      }
+      br[c] /= A[c][c];
+      bi[c] /= A[c][c];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) reinterpret_cast<double2 *>(a.out[i])[e] = make_double2(br[i], bi[i]);
+  }
+}
+
 // Adams-Bashforth coefficients (src/tensor_solver/AdamsBashforthMoulton.C:67-73, incl. the AB5 190/720 entry)
 static const double kBeta[5][5] = {
     {1.0, 0.0, 0.0, 0.0, 0.0},
@@ -287,6 +379,41 @@ int mrl_kspace_abm(mrl_ctx *ctx, double *d_ubar_out, const double *d_ubar0, cons
   hipLaunchKernelGGL(k_kspace_abm, dim3(grid_for(n_spec)), dim3(256), 0, ctx->stream, a,
                      reinterpret_cast<double2 *>(d_ubar_out), reinterpret_cast<const double2 *>(d_ubar0), d_L,
                      (long long)n_spec);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+int mrl_kspace_coupled(mrl_ctx *ctx, int nvar, double *const *d_ubar_out, const double *const *d_ubar0,
+                       const double *const *d_N, const double *h_coef, const int *h_nterms, const double *const *d_L,
+                       double dt, int flags, int64_t n_spec) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (nvar < 1 || nvar > 4 || !d_ubar_out || !d_ubar0 || !d_L || !h_nterms || n_spec < 0)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_kspace_coupled: bad argument (1 <= nvar <= 4)");
+  if (n_spec == 0) return MRL_OK;
+  CoupledArgs a{};
+  a.dt = dt;
+  a.flags = flags;
+  int at = 0;
+  for (int i = 0; i < nvar; ++i) {
+    if (!d_ubar_out[i] || !d_ubar0[i] || h_nterms[i] < 0 || h_nterms[i] > 6 || (h_nterms[i] > 0 && (!d_N || !h_coef)))
+      return set_error(ctx, MRL_ERR_INVALID, "mrl_kspace_coupled: bad variable %d (at most 6 terms each)", i);
+    a.nterms[i] = h_nterms[i];
+    a.u0[i] = d_ubar0[i];
+    a.out[i] = d_ubar_out[i];
+    for (int t = 0; t < h_nterms[i]; ++t, ++at) {
+      a.coef[i][t] = h_coef[at];
+      a.N[i][t] = d_N[at];
+    }
+    for (int j = 0; j < nvar; ++j) a.L[i * nvar + j] = d_L[i * nvar + j];
+  }
+  ProfScope ps(ctx, "kspace_coupled");
+  const dim3 grid(grid_for(n_spec)), block(256);
+  switch (nvar) {
+    case 1: hipLaunchKernelGGL(k_kspace_coupled<1>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
+    case 2: hipLaunchKernelGGL(k_kspace_coupled<2>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
+    case 3: hipLaunchKernelGGL(k_kspace_coupled<3>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
+    default: hipLaunchKernelGGL(k_kspace_coupled<4>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
+  }
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }

@@ -7,6 +7,8 @@
 //        (test/tests/cahnhilliard/cahnhilliard.i)
 //   marlin-hip-run problem=brusselator dim=2 nx=150 ny=150 xmax=2pi ymax=2pi ss=10 cs=0 order=2 num_steps=25 dt=0.5 out=dir
 //        (test/tests/solvers/diagonal.i; writes brusselator.csv with the columns of the reference's CSV output)
+//   marlin-hip-run problem=coupled|nl_coupled dim=2 nx=150 ny=150 xmax=2pi ymax=2pi ss=10 cs=0 order=2 num_steps=25 dt=10 out=dir
+//        (test/tests/solvers/coupled.i: AdamsBashforthMoultonCoupled; nl_coupled.i: reciprocal-space ParsedComputes)
 //   marlin-hip-run problem=mechanics dim=3 nx=16 ny=16 nz=16 substeps=10 num_steps=3 dt=0.01 l_tol=1e-2 nl_rel_tol=2e-2
 //        nl_abs_tol=2e-2 out=dir          (test/tests/mechanics/mech3d.i)
 #include <cstdio>
@@ -195,6 +197,72 @@ static int run_brusselator(DomainAction & domain, const std::string & out)
   return 0;
 }
 
+// test/tests/solvers/coupled.i (AdamsBashforthMoultonCoupled, dense operator [[D1, D2], [D2, D1]], zero nonlinear terms) and
+// nl_coupled.i (diagonal AdamsBashforthMoulton with the cross terms as reciprocal-space ParsedComputes Du = D2*v_bar, Dv = D2*u_bar)
+static int run_coupled(DomainAction & domain, const std::string & out, bool nonlinear)
+{
+  TensorProblem problem(domain);
+  ParsedCompute::Params ic;
+  ic.buffer = "u";
+  ic.expression = arg("u0", "sin(x)*sin(y)");
+  ic.extra_symbols = true;
+  ParsedCompute(problem, "u", ic).computeBuffer();
+  ic.buffer = "v";
+  ic.expression = arg("v0", "cos(x)*cos(y)");
+  ParsedCompute(problem, "v", ic).computeBuffer();
+  problem.getBuffer("zero") = DeviceTensor::zeros(2 * domain.getReciprocalSize());  // ConstantReciprocalTensor
+  ReciprocalLaplacianFactor(problem, "D1", "D1", argd("D1", 1e-2)).computeBuffer();
+  ReciprocalLaplacianFactor(problem, "D2", "D2", argd("D2", 1e-3)).computeBuffer();
+  auto root = std::make_shared<ComputeGroup>(problem, "root");
+  root->add(std::make_shared<ForwardFFT>(problem, "u_bar", "u_bar", "u"));
+  root->add(std::make_shared<ForwardFFT>(problem, "v_bar", "v_bar", "v"));
+  const std::size_t order = (std::size_t)argi("order", 2);
+  const auto ss = (unsigned int)argi("ss", 10);
+  const auto cs = (std::size_t)argi("cs", 0);
+  std::unique_ptr<TensorSolver> solver;
+  if (nonlinear)
+  {
+    ParsedCompute::Params du;
+    du.buffer = "Du";
+    du.expression = "D2*v_bar";
+    du.inputs = {"D2", "v_bar"};
+    du.complex_inputs = {"v_bar"};
+    du.reciprocal = true;
+    root->add(std::make_shared<ParsedCompute>(problem, "Du", du));
+    ParsedCompute::Params dv = du;
+    dv.buffer = "Dv";
+    dv.expression = "D2*u_bar";
+    dv.inputs = {"D2", "u_bar"};
+    dv.complex_inputs = {"u_bar"};
+    root->add(std::make_shared<ParsedCompute>(problem, "Dv", dv));
+    solver = std::make_unique<SplitOperatorABM>(
+        problem, "solver", ss, root,
+        std::vector<SplitOperatorABM::VariableNames>{{"u", "u_bar", "D1", "Du"}, {"v", "v_bar", "D1", "Dv"}}, order, order, cs);
+  }
+  else
+    solver = std::make_unique<AdamsBashforthMoultonCoupled>(
+        problem, "solver", ss, root,
+        std::vector<SplitOperatorABM::VariableNames>{{"u", "u_bar", "D1", "zero"}, {"v", "v_bar", "D1", "zero"}},
+        std::vector<AdamsBashforthMoultonCoupled::OffDiagonal>{{1, 0, "D2"}, {0, 1, "D2"}}, false, order, order, cs,
+        (int)argi("flags", 0));
+  Transient ex(problem, *solver, argd("dt", 10.0));
+  double volume = 1.0;
+  for (int d = 0; d < domain.getDim(); ++d)
+    volume *= domain.getExtent(d);
+  std::ofstream csv(out + (nonlinear ? "/nl_coupled.csv" : "/coupled.csv"));
+  csv.precision(17);
+  csv << "time,U,V,u_max,u_min,v_max,v_min\n0,0,0,0,0,0,0\n";
+  ex.execute((int)argi("num_steps", 25), [&](int) {
+    double umin, umax, vmin, vmax;
+    TensorPostprocessors::extreme(domain, problem.getBuffer("u"), umin, umax);
+    TensorPostprocessors::extreme(domain, problem.getBuffer("v"), vmin, vmax);
+    csv << problem.time() << ',' << TensorPostprocessors::integral(domain, problem.getBuffer("u"), volume) << ','
+        << TensorPostprocessors::integral(domain, problem.getBuffer("v"), volume) << ',' << umax << ',' << umin << ','
+        << vmax << ',' << vmin << "\n";
+  });
+  return 0;
+}
+
 // test/tests/solvers/etdrk4_diffusion.i: 1-D diffusion with ETDRK4 and a zero nonlinear term
 static int run_etdrk4_diffusion(DomainAction & domain, const std::string & out)
 {
@@ -307,6 +375,8 @@ int main(int argc, char ** argv)
       return run_mechanics(domain, out);
     if (problem == "brusselator")
       return run_brusselator(domain, out);
+    if (problem == "coupled" || problem == "nl_coupled")
+      return run_coupled(domain, out, problem == "nl_coupled");
     if (problem == "etdrk4_diffusion")
       return run_etdrk4_diffusion(domain, out);
     if (problem == "gradient")

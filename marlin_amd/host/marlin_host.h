@@ -622,6 +622,25 @@ protected:
     const std::vector<DeviceTensor> & _old_nonlinear_reciprocal;
   };
 
+  static double abBeta(std::size_t order, std::size_t i)  // AdamsBashforthMoulton.C:67-73 (incl. the AB5 190/720 entry)
+  {
+    static const double beta[5][5] = {{1.0, 0.0, 0.0, 0.0, 0.0},
+                                      {3.0 / 2.0, -1.0 / 2.0, 0.0, 0.0, 0.0},
+                                      {23.0 / 12.0, -16.0 / 12.0, 5.0 / 12.0, 0.0, 0.0},
+                                      {55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -9.0 / 24.0, 0.0},
+                                      {190.0 / 720.0, -2774.0 / 720.0, 2616.0 / 720.0, -1274.0 / 720.0, 251.0 / 720.0}};
+    return beta[order][i];
+  }
+  static double amAlpha(std::size_t order, std::size_t i)  // :108-114
+  {
+    static const double alpha[5][5] = {{1.0, 0.0, 0.0, 0.0, 0.0},
+                                       {0.5, 0.5, 0.0, 0.0, 0.0},
+                                       {5.0 / 12.0, 8.0 / 12.0, -1.0 / 12.0, 0.0, 0.0},
+                                       {9.0 / 24.0, 19.0 / 24.0, -5.0 / 24.0, 1.0 / 24.0, 0.0},
+                                       {251.0 / 720.0, 646.0 / 720.0, -264.0 / 720.0, 106.0 / 720.0, -19.0 / 720.0}};
+    return alpha[order][i];
+  }
+
   /// u = ifft( (ubar0 + sum coef_i N_i) / (1 - dt L) )
   void update(Variable & v, const DeviceTensor & ubar0, const std::vector<const double *> & N, const std::vector<double> & coef)
   {
@@ -634,16 +653,6 @@ protected:
 
   void substep() override
   {
-    static const double beta[5][5] = {{1.0, 0.0, 0.0, 0.0, 0.0},
-                                      {3.0 / 2.0, -1.0 / 2.0, 0.0, 0.0, 0.0},
-                                      {23.0 / 12.0, -16.0 / 12.0, 5.0 / 12.0, 0.0, 0.0},
-                                      {55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -9.0 / 24.0, 0.0},
-                                      {190.0 / 720.0, -2774.0 / 720.0, 2616.0 / 720.0, -1274.0 / 720.0, 251.0 / 720.0}};
-    static const double alpha[5][5] = {{1.0, 0.0, 0.0, 0.0, 0.0},
-                                       {0.5, 0.5, 0.0, 0.0, 0.0},
-                                       {5.0 / 12.0, 8.0 / 12.0, -1.0 / 12.0, 0.0, 0.0},
-                                       {9.0 / 24.0, 19.0 / 24.0, -5.0 / 24.0, 1.0 / 24.0, 0.0},
-                                       {251.0 / 720.0, 646.0 / 720.0, -264.0 / 720.0, 106.0 / 720.0, -19.0 / 720.0}};
     _compute->computeBuffer();
     forwardBuffers();
     // Adams-Bashforth predictor on all variables (constant dt)                       AdamsBashforthMoulton.C:80-102
@@ -652,11 +661,11 @@ protected:
       const std::size_t n_old = v._old_nonlinear_reciprocal.size();
       const std::size_t order = std::min(n_old, _predictor_order);
       std::vector<const double *> N{v._nonlinear_reciprocal.data()};
-      std::vector<double> coef{_sub_dt * beta[order][0]};
+      std::vector<double> coef{_sub_dt * abBeta(order, 0)};
       for (std::size_t i = 0; i < order; ++i)
       {
         N.push_back(v._old_nonlinear_reciprocal[i].data());
-        coef.push_back(_sub_dt * beta[order][i + 1]);
+        coef.push_back(_sub_dt * abBeta(order, i + 1));
       }
       update(v, v._reciprocal_buffer, N, coef);
     }
@@ -681,11 +690,11 @@ protected:
           if (order == 0)
             continue;
           std::vector<const double *> N{v._nonlinear_reciprocal.data(), N_n[k].data()};
-          std::vector<double> coef{_sub_dt * alpha[order][0], _sub_dt * alpha[order][1]};
+          std::vector<double> coef{_sub_dt * amAlpha(order, 0), _sub_dt * amAlpha(order, 1)};
           for (std::size_t i = 0; i + 1 < order; ++i)
           {
             N.push_back(v._old_nonlinear_reciprocal[i].data());
-            coef.push_back(_sub_dt * alpha[order][i + 2]);
+            coef.push_back(_sub_dt * amAlpha(order, i + 2));
           }
           update(v, ubar_n[k], N, coef);
         }
@@ -696,6 +705,130 @@ protected:
 
   const std::size_t _predictor_order, _corrector_order, _corrector_steps;
   std::vector<Variable> _variables;
+};
+
+
+/// AdamsBashforthMoultonCoupled: ABM right-hand sides for all variables + one dense per-k solve with off-diagonal
+/// linear operators (AdamsBashforthMoultonCoupled.C:84-272).  `flags` = 0 reproduces the reference (and its gold files),
+/// see mrl_kspace_coupled.
+class AdamsBashforthMoultonCoupled : public SplitOperatorABM
+{
+public:
+  struct OffDiagonal
+  {
+    unsigned int row, col;
+    std::string buffer;
+  };
+  AdamsBashforthMoultonCoupled(TensorProblem & problem, const std::string & name, unsigned int substeps,
+                               std::shared_ptr<TensorOperatorBase> root_compute, const std::vector<VariableNames> & vars,
+                               const std::vector<OffDiagonal> & offdiag, bool assume_symmetric, std::size_t predictor_order,
+                               std::size_t corrector_order, std::size_t corrector_steps, int flags = 0)
+    : SplitOperatorABM(problem, name, substeps, std::move(root_compute), vars, predictor_order, corrector_order, corrector_steps),
+      _flags(flags)
+  {
+    const std::size_t N = _variables.size();
+    if (N > 4)
+      paramError("buffer", "at most 4 coupled variables");
+    _L.assign(N * N, nullptr);
+    for (std::size_t i = 0; i < N; ++i)
+      _L[i * N + i] = _variables[i]._linear_reciprocal;
+    for (const auto & o : offdiag)
+    {
+      if (o.row >= N)
+        paramError("linear_offdiag_rows", "Off-diagonal indices out of range.");
+      if (o.col >= N)
+        paramError("linear_offdiag_cols", "Off-diagonal indices out of range.");
+      _L[o.row * N + o.col] = &problem.getBuffer(o.buffer);
+    }
+    if (assume_symmetric)                                                            // :153-156
+      for (const auto & o : offdiag)
+        if (o.row != o.col && !_L[o.col * N + o.row])
+          _L[o.col * N + o.row] = &problem.getBuffer(o.buffer);
+  }
+
+protected:
+  void solve(const std::vector<const double *> & ubar0, const std::vector<std::vector<const double *>> & N,
+             const std::vector<std::vector<double>> & coef)
+  {
+    const std::size_t nv = _variables.size();
+    std::vector<DeviceTensor> ubar;
+    std::vector<double *> out;
+    std::vector<const double *> flatN, L;
+    std::vector<double> flatc;
+    std::vector<int> nterms;
+    for (std::size_t i = 0; i < nv; ++i)
+    {
+      ubar.push_back(DeviceTensor::empty(2 * _domain.getReciprocalSize()));
+      out.push_back(ubar.back().data());
+      nterms.push_back((int)N[i].size());
+      flatN.insert(flatN.end(), N[i].begin(), N[i].end());
+      flatc.insert(flatc.end(), coef[i].begin(), coef[i].end());
+    }
+    for (auto * l : _L)
+      L.push_back(l ? l->data() : nullptr);
+    _domain.check(mrl_kspace_coupled(_domain.ctx(), (int)nv, out.data(), ubar0.data(), flatN.data(), flatc.data(), nterms.data(),
+                                     L.data(), _sub_dt, _flags, _domain.getReciprocalSize()));
+    for (std::size_t i = 0; i < nv; ++i)
+      _variables[i]._buffer = _domain.ifft(ubar[i]);
+  }
+
+  void substep() override
+  {
+    _compute->computeBuffer();
+    forwardBuffers();
+    const std::size_t nv = _variables.size();
+    std::vector<const double *> u0(nv);
+    std::vector<std::vector<const double *>> N(nv);
+    std::vector<std::vector<double>> coef(nv);
+    for (std::size_t k = 0; k < nv; ++k)                                              // :118-138
+    {
+      auto & v = _variables[k];
+      const std::size_t order = std::min(v._old_nonlinear_reciprocal.size(), _predictor_order);
+      u0[k] = v._reciprocal_buffer.data();
+      N[k] = {v._nonlinear_reciprocal.data()};
+      coef[k] = {_sub_dt * abBeta(order, 0)};
+      for (std::size_t i = 0; i < order; ++i)
+      {
+        N[k].push_back(v._old_nonlinear_reciprocal[i].data());
+        coef[k].push_back(_sub_dt * abBeta(order, i + 1));
+      }
+    }
+    solve(u0, N, coef);
+    if (!_corrector_steps)
+      return;
+    std::vector<DeviceTensor> ubar_n, N_n;                                            // :198-211
+    for (auto & v : _variables)
+    {
+      ubar_n.push_back(v._reciprocal_buffer);
+      N_n.push_back(v._nonlinear_reciprocal);
+    }
+    for (std::size_t j = 0; j < _corrector_steps; ++j)
+    {
+      _compute->computeBuffer();
+      forwardBuffers();
+      for (std::size_t k = 0; k < nv; ++k)
+      {
+        auto & v = _variables[k];
+        const std::size_t order = std::min(v._old_nonlinear_reciprocal.size() + 1, _corrector_order);
+        u0[k] = ubar_n[k].data();
+        N[k].clear();
+        coef[k].clear();
+        if (order == 0)                                                               // rhs = ubar_n, still solved (:225-229)
+          continue;
+        N[k] = {v._nonlinear_reciprocal.data(), N_n[k].data()};
+        coef[k] = {_sub_dt * amAlpha(order, 0), _sub_dt * amAlpha(order, 1)};
+        for (std::size_t i = 0; i + 1 < order; ++i)
+        {
+          N[k].push_back(v._old_nonlinear_reciprocal[i].data());
+          coef[k].push_back(_sub_dt * amAlpha(order, i + 2));
+        }
+      }
+      solve(u0, N, coef);
+    }
+  }
+
+  const int _flags;
+  std::vector<const DeviceTensor *> _L;
 };
 
 /// a fused pointwise kernel over explicit device arrays (mrl_parsed_* with pointer inputs)

@@ -572,6 +572,105 @@ def brusselator_problem(n: int = 150, A: float = 1.0, B: float = 3.5):
     return dom, state, compute, variables
 
 
+class CoupledABM:
+    """AdamsBashforthMoultonCoupled::substep (src/tensor_solver/AdamsBashforthMoultonCoupled.C:84-272) under
+    TensorSolver::computeBuffer: Adams-Bashforth right-hand sides per variable (:118-138), the dense operator assembled by
+    stacking the columns of each row and then the rows on a new LAST axis (:160-178; the solver therefore sees
+    A[..., a, b] = delta_ab - dt * L_ba), the cast of the stacked complex right-hand side to the real dtype of L (:183,
+    which keeps Re(rhs) only -- the gold files test/tests/solvers/gold/coupled_*.csv are reproduced only with this cast),
+    at::linalg_solve (:187), inverse transforms (:190-192) and the optional Adams-Moulton corrector (:198-270), where an
+    order-0 corrector re-solves with rhs = ubar_n.  `L[i][j]` = real tensor or None; `variables` as in SplitOperatorABM
+    (their linear_reciprocal entry is the diagonal and is ignored here in favour of L)."""
+
+    def __init__(self, dom: Domain, state: dict, compute: Callable[[dict], None], variables, L, substeps: int,
+                 predictor_order: int = 2, corrector_order: int = 2, corrector_steps: int = 0,
+                 real_rhs: bool = True, transposed: bool = True):
+        self.dom, self.state, self.compute, self.vars, self.L = dom, state, compute, variables, L
+        self.substeps = substeps
+        self.pred, self.corr, self.csteps = predictor_order - 1, corrector_order - 1, corrector_steps
+        self.real_rhs, self.transposed = real_rhs, transposed
+        self.hist = {v[3]: History(max_states=max(self.pred, self.corr)) for v in variables}
+        self.time_step = 0
+
+    _advance_state = SplitOperatorABM._advance_state
+    step = SplitOperatorABM.step
+
+    def solve(self, rhs, sub_dt):
+        n = len(rhs)
+        zeros = torch.zeros(self.dom.rshape, dtype=F64)
+        rows = [torch.stack([self.L[i][j] if self.L[i][j] is not None else zeros for j in range(n)], -1) for i in range(n)]
+        Lm = torch.stack(rows, -1)                            # [grid..., j, i]  (:176)
+        if not self.transposed:
+            Lm = Lm.transpose(-1, -2)
+        A = torch.eye(n, dtype=F64) - sub_dt * Lm
+        b = torch.stack(rhs, -1)
+        if self.real_rhs:
+            b = b.real.contiguous()                           # .to(base_dtype) of a complex tensor keeps the real part (:183)
+        else:
+            A = A.to(torch.complex128)
+        return torch.unbind(torch.linalg.solve(A, b), -1)
+
+    def _publish(self, sol):
+        for (u, _, _, _), x in zip(self.vars, sol):
+            self.state[u] = self.dom.ifft(x if x.is_complex() else x.to(torch.complex128))
+
+    def substep(self, sub_dt: float):
+        s = self.state
+        self.compute(s)
+        rhs = []
+        for (u, rb, _, N) in self.vars:
+            old = self.hist[N].old
+            order = min(len(old), self.pred)
+            r = s[rb] + (sub_dt * AB_BETA[order][0]) * s[N]
+            for i in range(order):
+                r += (sub_dt * AB_BETA[order][i + 1]) * old[i]
+            rhs.append(r)
+        self._publish(self.solve(rhs, sub_dt))
+        if self.csteps:
+            ubar_n = [s[rb] for (_, rb, _, _) in self.vars]
+            N_n = [s[N] for (_, _, _, N) in self.vars] if self.corr > 0 else None
+            for _ in range(self.csteps):
+                self.compute(s)
+                rhs = []
+                for k, (u, rb, _, N) in enumerate(self.vars):
+                    old = self.hist[N].old
+                    order = min(len(old) + 1, self.corr)
+                    if order == 0:
+                        rhs.append(ubar_n[k])
+                        continue
+                    r = ubar_n[k] + (sub_dt * AM_ALPHA[order][0]) * s[N]
+                    r += (sub_dt * AM_ALPHA[order][1]) * N_n[k]
+                    for i in range(order - 1):
+                        r += (sub_dt * AM_ALPHA[order][i + 2]) * old[i]
+                    rhs.append(r)
+                self._publish(self.solve(rhs, sub_dt))
+
+
+def coupled_diffusion_problem(n: int = 150, nonlinear: bool = False):
+    """test/tests/solvers/coupled.i (dense operator [[D1, D2], [D2, D1]], zero nonlinear terms, for
+    AdamsBashforthMoultonCoupled) and nl_coupled.i (the same cross-diffusion written as nonlinear terms Du = D2*v_bar,
+    Dv = D2*u_bar for the diagonal AdamsBashforthMoulton): 2-D n^2 on [0, 2 pi]^2, u0 = sin x sin y, v0 = cos x cos y."""
+    dom = Domain(2, [n, n], [2.0 * math.pi, 2.0 * math.pi])
+    state = {"u": (torch.sin(dom.axis[0]) * torch.sin(dom.axis[1])).expand(dom.shape).contiguous(),
+             "v": (torch.cos(dom.axis[0]) * torch.cos(dom.axis[1])).expand(dom.shape).contiguous(),
+             "zero": torch.zeros(dom.rshape, dtype=torch.complex128)}
+    D1 = reciprocal_laplacian_factor(dom, 1e-2)
+    D2 = reciprocal_laplacian_factor(dom, 1e-3)
+
+    def compute(s):
+        s["u_bar"] = dom.fft(s["u"])
+        s["v_bar"] = dom.fft(s["v"])
+        if nonlinear:
+            s["Du"] = D2 * s["v_bar"]
+            s["Dv"] = D2 * s["u_bar"]
+
+    if nonlinear:
+        variables = [("u", "u_bar", D1, "Du"), ("v", "v_bar", D1, "Dv")]
+    else:
+        variables = [("u", "u_bar", D1, "zero"), ("v", "v_bar", D1, "zero")]
+    return dom, state, compute, variables, [[D1, D2], [D2, D1]]
+
+
 class ETDRK4:
     """ETDRK4Solver::substep (src/tensor_solver/ETDRK4Solver.C:29-115) for the same variable tuples as SplitOperatorABM."""
 

@@ -10,7 +10,7 @@ Sources (relative to /root/reference):
   test/tests/cahnhilliard/gold/cahnhilliard.h5           spec test/tests/cahnhilliard/tests:46-57  (abs_tol 1e-13)
   test/tests/cahnhilliard/gold/cahnhilliard.rank0001.h5  spec test/tests/cahnhilliard/tests:58-70  (2-rank FFT_SLAB, rank 1)
   test/tests/mechanics/gold/mech3d.h5, mech.h5           spec test/tests/mechanics/tests:2-21      (abs_tol 1e-10)
-  test/tests/solvers/gold/diagonal_*.csv                 spec test/tests/solvers/tests
+  test/tests/solvers/gold/*.csv                          spec test/tests/solvers/tests
   test/tests/tensor_compute/gold/backandforth_out.csv, test/tests/gradient/gold/gradient_out.csv
 """
 import os
@@ -79,7 +79,7 @@ def main():
     sol = sorted(
         os.path.join("test/tests/solvers/gold", f)
         for f in os.listdir(os.path.join(REF, "test/tests/solvers/gold"))
-        if f.startswith("diagonal_") or f.startswith("etdrk4")
+        if f.endswith(".csv")
     )
     convert_csv(sol, "solvers_gold.npz")
     convert_csv(

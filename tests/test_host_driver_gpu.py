@@ -86,6 +86,24 @@ def test_solver_cases(name, ss, cs, order, tmp_path):
     assert err.max() <= 5e-11, err.max()
 
 
+_COUPLED = [(10, 0, 1), (10, 0, 2), (10, 0, 3), (20, 0, 4), (10, 1, 1), (10, 2, 1), (10, 2, 2)]
+
+
+@pytest.mark.parametrize("kind", ["coupled", "nl_coupled"])
+@pytest.mark.parametrize("ss,cs,order", _COUPLED)
+def test_coupled_solver_cases(kind, ss, cs, order, tmp_path):
+    """test/tests/solvers/tests (coupled.i: AdamsBashforthMoultonCoupled, per-k dense 2x2 solve incl. the reference's
+    real cast of the right-hand side; nl_coupled.i: diagonal ABM with complex reciprocal-space ParsedComputes) vs gold CSV"""
+    g = load_golden("solvers_gold.npz")[f"{kind}_{ss}_{cs}_{order}"]
+    _run([f"problem={kind}", "dim=2", "nx=150", "ny=150", "xmax=2pi", "ymax=2pi", f"ss={ss}", f"cs={cs}", f"order={order}",
+          "num_steps=25", "dt=10"], tmp_path)
+    got = np.loadtxt(tmp_path / f"{kind}.csv", delimiter=",", skiprows=1)
+    assert got.shape == g.shape
+    assert np.allclose(got[:, 0], g[:, 0])
+    err = np.abs(got[1:, 1:] - g[1:, 1:]) / np.maximum(1.0, np.abs(g[1:, 1:]))
+    assert err.max() <= 5e-11, err.max()
+
+
 def test_etdrk4_case(tmp_path):
     """test/tests/solvers/tests (etdrk4_diffusion.i): ETDRK4Solver built from fused parsed kernels vs gold mse / rmse"""
     g = load_golden("solvers_gold.npz")["etdrk4_diffusion_rmse"]

@@ -174,6 +174,57 @@ def test_solver_gold_brusselator(name, ss, cs, order):
     assert worst <= 5e-12, worst
 
 
+COUPLED_CASES = [(10, 0, 1), (10, 0, 2), (10, 0, 3), (20, 0, 4), (10, 1, 1), (10, 2, 1), (10, 2, 2)]
+
+
+def _six_columns(state, vol):
+    u, v = state["u"], state["v"]
+    return [u.mean().item() * vol, v.mean().item() * vol, u.max().item(), u.min().item(), v.max().item(), v.min().item()]
+
+
+@pytest.mark.parametrize("ss,cs,order", COUPLED_CASES)
+def test_solver_gold_nl_coupled(ss, cs, order):
+    """test/tests/solvers/tests (nl_coupled.i): the diagonal ABM with the cross-diffusion as reciprocal-space nonlinear terms"""
+    g = load_golden("solvers_gold.npz")[f"nl_coupled_{ss}_{cs}_{order}"]
+    dom, state, compute, variables, _ = mo.coupled_diffusion_problem(nonlinear=True)
+    s = mo.SplitOperatorABM(dom, state, compute, variables, substeps=ss, predictor_order=order, corrector_order=order,
+                            corrector_steps=cs)
+    worst = 0.0
+    for step in range(1, 26):
+        s.step(10.0)
+        row = _six_columns(state, (2.0 * math.pi) ** 2)
+        worst = max(worst, max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(row, g[step][1:])))
+    assert worst <= 5e-12, worst
+
+
+@pytest.mark.parametrize("ss,cs,order", COUPLED_CASES + [(1, 0, 1), (2, 0, 1), (3, 0, 1), (5, 0, 1), (20, 0, 1)])
+def test_solver_gold_coupled(ss, cs, order):
+    """test/tests/solvers/tests (coupled.i): AdamsBashforthMoultonCoupled with the dense 2x2 operator; the gold files are
+    reproduced only WITH the reference's cast of the complex right-hand side to real (see CoupledABM).  The extra
+    substep counts are gold files the spec no longer lists; coupled_30_0_1.csv among them matches no variant of the current
+    source (1e-5 from the complex solve, 7e-4 from the real one: written by an older revision) and is left out."""
+    g = load_golden("solvers_gold.npz")[f"coupled_{ss}_{cs}_{order}"]
+    dom, state, compute, variables, L = mo.coupled_diffusion_problem()
+    s = mo.CoupledABM(dom, state, compute, variables, L, substeps=ss, predictor_order=order, corrector_order=order,
+                      corrector_steps=cs)
+    worst = 0.0
+    for step in range(1, len(g)):
+        s.step(10.0)
+        row = _six_columns(state, (2.0 * math.pi) ** 2)
+        worst = max(worst, max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(row, g[step][1:])))
+    assert worst <= 5e-12, worst
+
+
+def test_coupled_complex_solve_differs_from_gold():
+    """documents the reference defect: the mathematically intended complex solve is 7e-4 away from the gold file"""
+    g = load_golden("solvers_gold.npz")["coupled_10_0_1"]
+    dom, state, compute, variables, L = mo.coupled_diffusion_problem()
+    s = mo.CoupledABM(dom, state, compute, variables, L, substeps=10, predictor_order=1, corrector_order=1, real_rhs=False)
+    s.step(10.0)
+    row = _six_columns(state, (2.0 * math.pi) ** 2)
+    assert max(abs(a - b) for a, b in zip(row, g[1][1:])) > 1e-4
+
+
 def test_etdrk4_gold():
     """test/tests/solvers/etdrk4_diffusion.i: 1-D diffusion, ETDRK4 with a zero nonlinear term; the postprocessed buffer
     u_diff_sq is the one left by the LAST compute-group evaluation of the substep (stage d vs the exact solution at the
