@@ -163,6 +163,21 @@ int mrl_kspace_coupled(mrl_ctx *ctx, int nvar, double *const *d_ubar_out, const 
                        const double *const *d_N, const double *h_coef, const int *h_nterms, const double *const *d_L,
                        double dt, int flags, int64_t n_spec);
 
+/* SecantSolver::substep (src/tensor_solver/SecantSolver.C:60-176), the reciprocal-space work for one variable; complex arrays
+ * of n_spec elements, d_L real or NULL.  The caller (the solver object) keeps the reference's control flow: evaluate the
+ * compute group, call these, inverse-transform the new iterate into the variable's buffer, test convergence.
+ *   mrl_secant_begin  (:79-101): R0 = (N + L*u)*sub_dt ; guess = (u + dt_epsilon*N)/(1 - dt_epsilon*L) ; h_sumsq[0] = sum|R0|^2
+ *   mrl_secant_iterate (:121-140): R = (N + L*u)*sub_dt + u_old - u ; du = where(R - R_prev != 0, -R*(u - u_prev)/(R - R_prev), 0) ;
+ *        u_new = u + du*damping ; R_prev <- R in place ; h_sumsq = { sum|R|^2, sum|du|^2 }   (complex division as
+ *        c10::complex does it).  The previous iterate is simply the caller's previous `u` buffer (`uprev[i] = u` is a handle
+ *        copy in the reference too).  Sums are over this rank's reciprocal grid; torch::norm = sqrt of them.
+ * Both calls synchronise the context's stream to return the sums (the reference's .item() calls). */
+int mrl_secant_begin(mrl_ctx *ctx, const double *d_u, const double *d_N, const double *d_L, double sub_dt, double dt_epsilon,
+                     double *d_R0_out, double *d_guess_out, double *h_sumsq, int64_t n_spec);
+int mrl_secant_iterate(mrl_ctx *ctx, const double *d_u, const double *d_N, const double *d_L, const double *d_u_old,
+                       const double *d_u_prev, double *d_R_prev, double sub_dt, double damping, double *d_u_new,
+                       double *h_sumsq, int64_t n_spec);
+
 /* Slab (multi-GPU) CH substep (AdamsBashforthMoulton::substep over DomainAction::fftSlab/ifftSlab), split at its
  * exchanges and pipelined over `nsub` sub-blocks of the kz axis: after the z pass every kz plane is an independent
  * 2-D problem, so the caller can put sub-block s on the wire while sub-block s+1 is being transformed.

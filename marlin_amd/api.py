@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import List, Optional, Sequence
 
 import torch
@@ -207,6 +208,22 @@ class Context:
         nt = (C.c_int32 * nv)(*[len(row) for row in N])
         Lp = (C.c_void_p * (nv * nv))(*[(L[i][j].data_ptr() if L[i][j] is not None else None) for i in range(nv) for j in range(nv)])
         self._check(self.lib.mrl_kspace_coupled(self.h, nv, outs, u0, arr, cf, nt, Lp, dt, flags, ubar0[0].numel()))
+
+    def secant_begin(self, u, N, L, sub_dt: float, dt_epsilon: float):
+        """-> (R0, guess, |R0|)  (SecantSolver.C:79-101)"""
+        R0, guess = torch.empty_like(u), torch.empty_like(u)
+        ss = (C.c_double * 1)()
+        self._check(self.lib.mrl_secant_begin(self.h, _ptr(u), _ptr(N), _ptr(L), sub_dt, dt_epsilon, _ptr(R0), _ptr(guess), ss,
+                                              u.numel()))
+        return R0, guess, math.sqrt(ss[0])
+
+    def secant_iterate(self, u, N, L, u_old, u_prev, R_prev, sub_dt: float, damping: float = 1.0):
+        """-> (u_new, |R|, |du|); R_prev is replaced by the new residual in place  (SecantSolver.C:121-140)"""
+        u_new = torch.empty_like(u)
+        ss = (C.c_double * 2)()
+        self._check(self.lib.mrl_secant_iterate(self.h, _ptr(u), _ptr(N), _ptr(L), _ptr(u_old), _ptr(u_prev), _ptr(R_prev), sub_dt,
+                                                damping, _ptr(u_new), ss, u.numel()))
+        return u_new, math.sqrt(ss[0]), math.sqrt(ss[1])
 
     # ---- de Geus mechanics (value-major [grid..., D, D] fields)
     def gamma_apply(self, A: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

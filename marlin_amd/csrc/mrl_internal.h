@@ -121,6 +121,18 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// block sum of `v` over 256 threads -> valid in thread 0
+__device__ __forceinline__ double block_sum256(double v, double *sh) {
+  v = wave_sum_f64(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return r;
+}
+
 // scratch management
 int ensure_work(mrl_ctx *ctx, int slot, size_t bytes);
 

@@ -10,18 +10,6 @@
 
 namespace mrl {
 
-// block sum of `v` over 256 threads -> valid in thread 0
-__device__ __forceinline__ double block_sum256(double v, double *sh) {
-  v = wave_sum_f64(v);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) sh[w] = v;
-  __syncthreads();
-  double r = 0.0;
-  if (threadIdx.x == 0) r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-  __syncthreads();
-  return r;
-}
-
 // OP 0: sum a ; 1: sum a*b ; 2: sum a*a
 template <int OP>
 __global__ void __launch_bounds__(256) k_reduce_partial(const double *__restrict__ a, const double *__restrict__ b,

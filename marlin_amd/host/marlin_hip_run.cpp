@@ -9,6 +9,8 @@
 //        (test/tests/solvers/diagonal.i; writes brusselator.csv with the columns of the reference's CSV output)
 //   marlin-hip-run problem=coupled|nl_coupled dim=2 nx=150 ny=150 xmax=2pi ymax=2pi ss=10 cs=0 order=2 num_steps=25 dt=10 out=dir
 //        (test/tests/solvers/coupled.i: AdamsBashforthMoultonCoupled; nl_coupled.i: reciprocal-space ParsedComputes)
+//   marlin-hip-run problem=rotating_grain_secant dim=2 nx=40 ny=40 xmax=12pi ymax=<..> ic=psi0.bin num_steps=10 out=dir
+//        (test/tests/tensor_compute/rotating_grain_secant.i: SecantSolver + SwiftHohenbergLinear + iteration-adaptive dt)
 //   marlin-hip-run problem=mechanics dim=3 nx=16 ny=16 nz=16 substeps=10 num_steps=3 dt=0.01 l_tol=1e-2 nl_rel_tol=2e-2
 //        nl_abs_tol=2e-2 out=dir          (test/tests/mechanics/mech3d.i)
 #include <cstdio>
@@ -263,6 +265,43 @@ static int run_coupled(DomainAction & domain, const std::string & out, bool nonl
   return 0;
 }
 
+// test/tests/tensor_compute/rotating_grain_secant.i: 2-D Swift-Hohenberg with the SecantSolver and iteration-adaptive dt;
+// ic= holds psi at t = 0 (the reference evaluates a MOOSE ParsedFunction there)
+static int run_rotating_grain_secant(DomainAction & domain, const std::string & out)
+{
+  TensorProblem problem(domain);
+  problem.getBuffer("psi") = DeviceTensor::fromHost(read_bin(arg("ic"), (std::size_t)domain.getNumberOfCells()));
+  SwiftHohenbergLinear(problem, "linear", "linear", argd("r", 0.025), argd("alpha", 1.0)).computeBuffer();
+  auto root = std::make_shared<ComputeGroup>(problem, "root");
+  ParsedCompute::Params p3;
+  p3.buffer = "psi3";
+  p3.expression = arg("expression", "0.20*psi^2-psi^3");
+  p3.inputs = {"psi"};
+  root->add(std::make_shared<ParsedCompute>(problem, "psi3", p3));
+  root->add(std::make_shared<ForwardFFT>(problem, "psibar", "psibar", "psi"));
+  root->add(std::make_shared<ForwardFFT>(problem, "psi3bar", "psi3bar", "psi3"));
+  SecantSolver::Params sp;
+  sp.substeps = (unsigned int)argi("substeps", 3);
+  sp.max_iterations = (unsigned int)argi("max_iterations", 30);
+  sp.relative_tolerance = argd("relative_tolerance", 1e-9);
+  sp.absolute_tolerance = argd("absolute_tolerance", 1e-9);
+  sp.damping = argd("damping", 1.0);
+  sp.dt_epsilon = argd("dt_epsilon", 1e-4);
+  sp.verbose = argi("verbose", 0) != 0;
+  SecantSolver solver(problem, "solver", root, {{"psi", "psibar", "linear", "psi3bar"}}, sp);
+  TensorSolveIterationAdaptiveDT ts(solver, argd("dt", 1.0), (unsigned int)argi("ts_min_iterations", 100),
+                                    (unsigned int)argi("ts_max_iterations", 400), argd("growth_factor", 1.4),
+                                    argd("cutback_factor", 0.9), argd("dtmax", 500.0));
+  Transient ex(problem, solver, argd("dt", 1.0));
+  ex.setTimeStepper([&](int t_step) { return ts.computeDT(t_step); });
+  dump(out, "psi", 0, problem.getBuffer("psi"));
+  ex.execute((int)argi("num_steps", 10), [&](int step) {
+    dump(out, "psi", step, problem.getBuffer("psi"));
+    std::printf("step %d: dt=%.17g iterations=%u converged=%d\n", step, problem.dt(), solver.getIterations(), (int)solver.isConverged());
+  });
+  return 0;
+}
+
 // test/tests/solvers/etdrk4_diffusion.i: 1-D diffusion with ETDRK4 and a zero nonlinear term
 static int run_etdrk4_diffusion(DomainAction & domain, const std::string & out)
 {
@@ -377,6 +416,8 @@ int main(int argc, char ** argv)
       return run_brusselator(domain, out);
     if (problem == "coupled" || problem == "nl_coupled")
       return run_coupled(domain, out, problem == "nl_coupled");
+    if (problem == "rotating_grain_secant")
+      return run_rotating_grain_secant(domain, out);
     if (problem == "etdrk4_diffusion")
       return run_etdrk4_diffusion(domain, out);
     if (problem == "gradient")

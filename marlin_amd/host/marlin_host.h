@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -831,6 +832,167 @@ protected:
   std::vector<const DeviceTensor *> _L;
 };
 
+
+/// IterativeTensorSolverInterface (include/tensor_solver/IterativeTensorSolverInterface.h): what the time stepper queries
+class IterativeTensorSolverInterface
+{
+public:
+  const unsigned int & getIterations() const { return _iterations; }
+  const bool & isConverged() const { return _is_converged; }
+
+protected:
+  unsigned int _iterations = 0;
+  bool _is_converged = true;
+};
+
+/// SwiftHohenbergLinear: _u = r - alpha^2 (1 - k^2)^2   (SwiftHohenbergLinear.C:35-39) as one generated kernel
+class SwiftHohenbergLinear : public TensorOperatorBase
+{
+public:
+  SwiftHohenbergLinear(TensorProblem & problem, const std::string & name, const std::string & buffer, double r, double alpha)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer))
+  {
+    const char * cn[] = {"r", "aa"};
+    const double cv[] = {r, alpha * alpha};
+    if (mrl_parsed_create(_domain.ctx(), &_parsed, "r-aa*(1-k2)*(1-k2)", 0, nullptr, nullptr, 2, cn, cv, 0, nullptr, 1, 1) != MRL_OK)
+      paramError("buffer", mrl_last_error(_domain.ctx()));
+  }
+  ~SwiftHohenbergLinear() { mrl_parsed_destroy(_parsed); }
+  void computeBuffer() override
+  {
+    auto out = DeviceTensor::empty(_domain.getReciprocalSize());
+    _domain.check(mrl_parsed_eval(_parsed, nullptr, out.data(), _domain.getReciprocalSize(), _time));
+    _u = out;
+  }
+
+private:
+  DeviceTensor & _u;
+  mrl_parsed * _parsed = nullptr;
+};
+
+/// SecantSolver (src/tensor_solver/SecantSolver.C:42-185): control flow of the reference, k-space work in two fused kernels
+class SecantSolver : public SplitOperatorABM, public IterativeTensorSolverInterface
+{
+public:
+  struct Params
+  {
+    unsigned int substeps = 1, max_iterations = 30;
+    double relative_tolerance = 1e-9, absolute_tolerance = 1e-9, damping = 1.0, dt_epsilon = 1e-4;
+    bool verbose = false;
+  };
+  SecantSolver(TensorProblem & problem, const std::string & name, std::shared_ptr<TensorOperatorBase> root_compute,
+               const std::vector<VariableNames> & vars, const Params & p)
+    : SplitOperatorABM(problem, name, p.substeps, std::move(root_compute), vars, 1, 1, 0), _p(p)  // getVariables(0): no history
+  {
+  }
+
+protected:
+  void substep() override
+  {
+    const std::size_t n = _variables.size();
+    const int64_t ns = _domain.getReciprocalSize();
+    std::vector<DeviceTensor> u_old(n), Rprev(n), uprev(n);
+    std::vector<double> R0norm(n);
+    _compute->computeBuffer();                                                       // :73
+    forwardBuffers();
+    for (std::size_t i = 0; i < n; ++i)
+    {
+      auto & v = _variables[i];
+      Rprev[i] = DeviceTensor::empty(2 * ns);
+      auto guess = DeviceTensor::empty(2 * ns);
+      double ss = 0.0;
+      _domain.check(mrl_secant_begin(_domain.ctx(), v._reciprocal_buffer.data(), v._nonlinear_reciprocal.data(),
+                                     v._linear_reciprocal ? v._linear_reciprocal->data() : nullptr, _sub_dt, _p.dt_epsilon,
+                                     Rprev[i].data(), guess.data(), &ss, ns));
+      R0norm[i] = std::sqrt(ss);
+      uprev[i] = v._reciprocal_buffer;                                               // handle copies (:85,:90)
+      u_old[i] = v._reciprocal_buffer;
+      v._buffer = _domain.ifft(guess);
+      if (_p.verbose)
+        std::printf("|R0|=%g\n", R0norm[i]);
+    }
+    bool all_converged = false;
+    for (_iterations = 0; _iterations < _p.max_iterations; ++_iterations)           // :112-165
+    {
+      _compute->computeBuffer();
+      forwardBuffers();
+      all_converged = true;
+      for (std::size_t i = 0; i < n; ++i)
+      {
+        auto & v = _variables[i];
+        auto unew = DeviceTensor::empty(2 * ns);
+        double ss[2];
+        _domain.check(mrl_secant_iterate(_domain.ctx(), v._reciprocal_buffer.data(), v._nonlinear_reciprocal.data(),
+                                         v._linear_reciprocal ? v._linear_reciprocal->data() : nullptr, u_old[i].data(),
+                                         uprev[i].data(), Rprev[i].data(), _sub_dt, _p.damping, unew.data(), ss, ns));
+        uprev[i] = v._reciprocal_buffer;
+        v._buffer = _domain.ifft(unew);
+        const double Rnorm = std::sqrt(ss[0]);
+        if (_p.verbose)
+          std::printf("%u |du| = %g |R|=%g\n", _iterations, std::sqrt(ss[1]), Rnorm);
+        if (std::isnan(Rnorm))
+        {
+          all_converged = false;
+          _iterations = _p.max_iterations;
+          std::printf("NaN detected, aborting solve.\n");
+          break;
+        }
+        all_converged = all_converged && (Rnorm < _p.absolute_tolerance || Rnorm / R0norm[i] < _p.relative_tolerance);
+      }
+      if (all_converged)
+      {
+        _is_converged = true;
+        break;
+      }
+    }
+    if (!all_converged)
+    {
+      std::printf("Solve not converged.\n");
+      for (std::size_t i = 0; i < n; ++i)
+        _variables[i]._buffer = _domain.ifft(u_old[i]);                              // :171-173
+      _is_converged = false;
+    }
+  }
+
+  const Params _p;
+};
+
+/// TensorSolveIterationAdaptiveDT (src/timesteppers/TensorSolveIterationAdaptiveDT.C:66-88,162-175) + Transient's dtmax
+class TensorSolveIterationAdaptiveDT
+{
+public:
+  TensorSolveIterationAdaptiveDT(const IterativeTensorSolverInterface & solver, double dt, unsigned int min_iterations,
+                                 unsigned int max_iterations, double growth_factor = 2.0, double cutback_factor = 0.5,
+                                 double dtmax = 1e30)
+    : _solver(solver), _input_dt(dt), _min_iterations(min_iterations), _max_iterations(max_iterations),
+      _growth_factor(growth_factor), _cutback_factor(cutback_factor), _dtmax(dtmax)
+  {
+  }
+  double computeDT(int t_step)
+  {
+    double dt = _input_dt;                       // computeInitialDT
+    if (t_step > 1)
+    {
+      dt = _dt_old;
+      const auto previous_iterations = _solver.getIterations();
+      if (previous_iterations < _min_iterations)
+        dt *= _growth_factor;
+      else if (previous_iterations > _max_iterations)
+        dt *= _cutback_factor;
+    }
+    dt = std::min(dt, _dtmax);
+    _dt_old = dt;                                // acceptStep
+    return dt;
+  }
+
+private:
+  const IterativeTensorSolverInterface & _solver;
+  const double _input_dt;
+  const unsigned int _min_iterations, _max_iterations;
+  const double _growth_factor, _cutback_factor, _dtmax;
+  double _dt_old = 0.0;
+};
+
 /// a fused pointwise kernel over explicit device arrays (mrl_parsed_* with pointer inputs)
 class FusedExpression
 {
@@ -985,6 +1147,8 @@ class Transient
 {
 public:
   Transient(TensorProblem & problem, TensorSolver & solver, double dt) : _problem(problem), _solver(solver), _dt(dt) {}
+  /// [TimeStepper]: dt for time step `t_step` (1-based); default = the constant dt
+  void setTimeStepper(std::function<double(int)> stepper) { _stepper = std::move(stepper); }
   template <typename F>
   void execute(int num_steps, F && on_timestep_end)
   {
@@ -992,6 +1156,8 @@ public:
     {
       _problem.timeOld() = _problem.time();
       _problem.timeStep() += 1;
+      if (_stepper)
+        _dt = _stepper(_problem.timeStep());
       _problem.dt() = _dt;
       _problem.time() = _problem.timeOld() + _dt;
       _problem.advanceState();                         // incrementStepOrReject -> advanceState
@@ -1004,7 +1170,8 @@ public:
 private:
   TensorProblem & _problem;
   TensorSolver & _solver;
-  const double _dt;
+  double _dt;
+  std::function<double(int)> _stepper;
 };
 
 }  // namespace marlin_host

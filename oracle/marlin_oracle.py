@@ -722,3 +722,94 @@ class ETDRK4:
         for _ in range(self.substeps):
             self.substep(sub_dt)
             self.sub_time += sub_dt
+
+
+# --------------------------------------------------------------------------------------
+# Iterative solvers
+# --------------------------------------------------------------------------------------
+def swift_hohenberg_linear(dom: Domain, r: float, alpha: float) -> torch.Tensor:
+    """SwiftHohenbergLinear::computeBuffer (src/tensor_computes/SwiftHohenbergLinear.C:35-39)."""
+    k2 = dom.k_square()
+    return r - alpha * alpha * (1.0 - k2) * (1.0 - k2)
+
+
+class SecantSolver:
+    """SecantSolver::substep under TensorSolver::computeBuffer (src/tensor_solver/SecantSolver.C:60-176): per variable a
+    pointwise secant iteration in reciprocal space on R(u) = (N(u) + L u) dt + u_old - u, bootstrapped by a semi-implicit
+    Euler step of length dt_epsilon; a failed solve restores the old solution.  No history.  `variables` as in
+    SplitOperatorABM.  `iterations` / `converged` are what IterativeTensorSolverInterface exposes to the time stepper."""
+
+    def __init__(self, dom: Domain, state: dict, compute: Callable[[dict], None], variables, substeps: int = 1,
+                 max_iterations: int = 30, relative_tolerance: float = 1e-9, absolute_tolerance: float = 1e-9,
+                 damping: float = 1.0, dt_epsilon: float = 1e-4):
+        self.dom, self.state, self.compute, self.vars, self.substeps = dom, state, compute, variables, substeps
+        self.max_it, self.rtol, self.atol, self.damping, self.eps = (max_iterations, relative_tolerance, absolute_tolerance,
+                                                                     damping, dt_epsilon)
+        self.iterations, self.converged = 0, True
+
+    def substep(self, sub_dt: float):
+        s, n = self.state, len(self.vars)
+        self.compute(s)                                               # :73
+        u_old, Rprev, uprev, R0 = [None] * n, [None] * n, [None] * n, [0.0] * n
+        for i, (ub, rb, L, N) in enumerate(self.vars):
+            u, Nn = s[rb], s[N]
+            Rprev[i] = (Nn + L * u) * sub_dt if L is not None else Nn * sub_dt
+            uprev[i] = u
+            R0[i] = torch.norm(Rprev[i]).item()
+            u_old[i] = u
+            s[ub] = self.dom.ifft((u + self.eps * Nn) / (1.0 - self.eps * L) if L is not None else u + self.eps * Nn)
+        all_converged = False
+        self.iterations = 0
+        while self.iterations < self.max_it:                          # :112-165
+            self.compute(s)
+            all_converged = True
+            for i, (ub, rb, L, N) in enumerate(self.vars):
+                u, Nn = s[rb], s[N]
+                R = (Nn + L * u) * sub_dt + u_old[i] - u if L is not None else Nn * sub_dt + u_old[i] - u
+                dx, dy = u - uprev[i], R - Rprev[i]
+                du = torch.where(dy != 0, -R * dx / dy, 0.0)
+                uprev[i], Rprev[i] = u, R
+                s[ub] = self.dom.ifft(u + du if self.damping == 1.0 else u + du * self.damping)
+                Rn = torch.norm(R).item()
+                if math.isnan(Rn):
+                    all_converged = False
+                    self.iterations = self.max_it
+                    break
+                all_converged = all_converged and (Rn < self.atol or Rn / R0[i] < self.rtol)
+            if all_converged:
+                self.converged = True
+                break
+            self.iterations += 1
+        if not all_converged:
+            for i, (ub, _, _, _) in enumerate(self.vars):
+                s[ub] = self.dom.ifft(u_old[i])
+            self.converged = False
+
+    def step(self, dt: float):
+        for _ in range(self.substeps):
+            self.substep(dt / self.substeps)
+
+
+class IterationAdaptiveDT:
+    """TensorSolveIterationAdaptiveDT (src/timesteppers/TensorSolveIterationAdaptiveDT.C:66-88,162-175): the first step
+    uses `dt`; afterwards dt_old grows by growth_factor when the solver's last iteration count is below min_iterations and
+    shrinks by cutback_factor above max_iterations; MOOSE's Transient clamps to dtmax."""
+
+    def __init__(self, dt: float, min_iterations: int, max_iterations: int, growth_factor: float = 2.0,
+                 cutback_factor: float = 0.5, dtmax: float = 1e30):
+        self.dt0, self.min_it, self.max_it, self.grow, self.cut, self.dtmax = (dt, min_iterations, max_iterations,
+                                                                               growth_factor, cutback_factor, dtmax)
+        self.dt_old = 0.0
+
+    def next_dt(self, t_step: int, iterations: int) -> float:
+        if t_step == 1:
+            dt = self.dt0
+        else:
+            dt = self.dt_old
+            if iterations < self.min_it:
+                dt *= self.grow
+            elif iterations > self.max_it:
+                dt *= self.cut
+        dt = min(dt, self.dtmax)
+        self.dt_old = dt
+        return dt

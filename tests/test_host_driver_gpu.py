@@ -104,6 +104,24 @@ def test_coupled_solver_cases(kind, ss, cs, order, tmp_path):
     assert err.max() <= 5e-11, err.max()
 
 
+def test_rotating_grain_secant_case(tmp_path):
+    """test/tests/tensor_compute/tests:90-100 (rotating_grain_secant.i, HDF5Diff abs_tol 1e-10): SecantSolver +
+    SwiftHohenbergLinear + TensorSolveIterationAdaptiveDT through the host mirror; psi.0 (a MOOSE ParsedFunction) is the IC"""
+    import math
+    g = load_golden("rotating_grain_secant_gold.npz")
+    ic = tmp_path / "psi0.bin"
+    g["psi.0"].astype("<f8").tofile(ic)
+    ymax = 6 * math.pi * 2 / math.sin(math.pi / 3)
+    log = _run(["problem=rotating_grain_secant", "dim=2", "nx=40", "ny=40", "xmax=12pi", f"ymax={ymax!r}", f"ic={ic}",
+                "substeps=3", "num_steps=10", "dt=1"], tmp_path)
+    assert log.count("converged=1") == 10
+    worst = 0.0
+    for k in range(0, 11):
+        psi = np.fromfile(tmp_path / f"psi.{k}.bin", dtype="<f8").reshape(40, 40)
+        worst = max(worst, np.abs(g[f"psi.{k}"] - psi).max())
+    assert worst <= 1e-10, worst
+
+
 def test_etdrk4_case(tmp_path):
     """test/tests/solvers/tests (etdrk4_diffusion.i): ETDRK4Solver built from fused parsed kernels vs gold mse / rmse"""
     g = load_golden("solvers_gold.npz")["etdrk4_diffusion_rmse"]

@@ -248,3 +248,35 @@ def test_etdrk4_gold():
         mse = state["u_diff_sq"].mean().item() * 2.0 * math.pi
         assert abs(mse - g[step][1]) <= 1e-12 * max(1.0, abs(g[step][1]))
         assert abs(math.sqrt(mse) - g[step][2]) <= 1e-12
+
+
+def rotating_grain_problem(psi0):
+    """test/tests/tensor_compute/rotating_grain_secant.i: 2-D 40^2 Swift-Hohenberg (phase field crystal), psi3 =
+    0.20*psi^2 - psi^3, SwiftHohenbergLinear(alpha = 1, r = 0.025), SecantSolver with 3 substeps, iteration-adaptive dt"""
+    w = 6
+    dom = mo.Domain(2, [40, 40], [w * math.pi * 2, w * math.pi * 2 / math.sin(math.pi / 3)])
+    lin = mo.swift_hohenberg_linear(dom, 0.025, 1.0)
+    state = {"psi": psi0.clone()}
+
+    def compute(s):
+        p = s["psi"]
+        s["psi3"] = 0.20 * torch.pow(p, 2.0) - torch.pow(p, 3.0)
+        s["psibar"] = dom.fft(p)
+        s["psi3bar"] = dom.fft(s["psi3"])
+
+    return dom, state, compute, [("psi", "psibar", lin, "psi3bar")]
+
+
+def test_secant_solver_gold():
+    """test/tests/tensor_compute/tests:90-100 (HDF5Diff abs_tol 1e-10): psi.0 is the initial condition (a MOOSE
+    ParsedFunction, taken from the gold file), psi.1 ... psi.10 the ten adaptive steps"""
+    g = load_golden("rotating_grain_secant_gold.npz")
+    dom, state, compute, variables = rotating_grain_problem(torch.from_numpy(g["psi.0"]))
+    solver = mo.SecantSolver(dom, state, compute, variables, substeps=3)
+    ts = mo.IterationAdaptiveDT(1.0, min_iterations=100, max_iterations=400, growth_factor=1.4, cutback_factor=0.9, dtmax=500.0)
+    for step in range(1, 11):
+        solver.step(ts.next_dt(step, solver.iterations))
+        assert solver.converged
+        assert (state["psi"] - torch.from_numpy(g[f"psi.{step}"])).abs().max().item() <= 1e-10
+    assert abs(ts.dt_old - 1.4 ** 9) < 1e-12
+
