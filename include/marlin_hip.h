@@ -244,6 +244,16 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *p, const double *d_F
                        const double *d_mu, const double *d_applied, double *d_Fnew, double *d_P,
                        mrl_mech_stats *stats);
 
+/* ComputeDisplacements::computeBuffer (src/tensor_computes/ComputeDisplacements.C:53-107): displacement field of a deformation
+ * gradient F [grid..., D, D]:  u = (<F> - I) X + ifft( fft(F - <F>) . (-i q) / |q|^2 )  (zero at q = 0), linearly interpolated
+ * (torch interpolate, align_corners = true) from the n cell centres to n + 1 points per axis.
+ * d_disp: [(n_0+1)...(n_{D-1}+1)][D] doubles, value-major.  Serial contexts. */
+int mrl_mech_displacements(mrl_ctx *ctx, const double *d_F, double *d_disp);
+
+/* ComputeVonMisesStress::computeBuffer (src/tensor_computes/ComputeVonMisesStress.C:31-66): von Mises measure of a
+ * rank-two field [grid..., D, D] -> [grid...] with the reference's 2-D / 3-D formulas and term order. */
+int mrl_mech_von_mises(mrl_ctx *ctx, const double *d_stress, double *d_out);
+
 /* ---- parsed pointwise expressions: ParsedCompute (src/tensor_computes/ParsedCompute.C:50-265) ----------------
  * expression text -> AST -> d/d(derivatives[0]) d/d(derivatives[1]) ... -> simplify -> one fused HIP kernel (hiprtc).
  * Grammar, derivative and simplification rules follow the reference's parser (they fix the floating-point

@@ -82,6 +82,8 @@ SIGNATURES = {
     "mrl_ch_substep": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _vp, _pp, _i32, _dbl, _vp, _vp]),
     "mrl_kspace_abm": (_i32, [_vp, _vp, _vp, _pp, C.POINTER(_dbl), _i32, _vp, _dbl, _i64]),
     "mrl_kspace_coupled": (_i32, [_vp, _i32, _pp, _pp, _pp, C.POINTER(_dbl), C.POINTER(_i32), _pp, _dbl, _i32, _i64]),
+    "mrl_mech_displacements": (_i32, [_vp, _vp, _vp]),
+    "mrl_mech_von_mises": (_i32, [_vp, _vp, _vp]),
     "mrl_secant_begin": (_i32, [_vp, _vp, _vp, _vp, _dbl, _dbl, _vp, _vp, C.POINTER(_dbl), _i64]),
     "mrl_secant_iterate": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, C.POINTER(_dbl), _i64]),
     "mrl_slab_ch_counts": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -238,6 +238,17 @@ class Context:
         self._check(self.lib.mrl_mech_stress(self.h, _ptr(F), _ptr(K), _ptr(mu), _ptr(out)))
         return out
 
+    def mech_displacements(self, F: torch.Tensor) -> torch.Tensor:
+        """ComputeDisplacements: [grid..., D, D] -> node values [(n+1)..., D]"""
+        out = torch.empty([n + 1 for n in F.shape[:self.dim]] + [self.dim], dtype=torch.float64, device=F.device)
+        self._check(self.lib.mrl_mech_displacements(self.h, _ptr(F), _ptr(out)))
+        return out
+
+    def mech_von_mises(self, stress: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(stress.shape[:self.dim], dtype=torch.float64, device=stress.device)
+        self._check(self.lib.mrl_mech_von_mises(self.h, _ptr(stress), _ptr(out)))
+        return out
+
     def mech_tangent_apply(self, F, K, mu, dF, out=None):
         if out is None:
             out = torch.empty_like(F)

@@ -139,7 +139,14 @@ static int run_mechanics(DomainAction & domain, const std::string & out)
   ForwardEulerSolver solver(problem, "solver", (unsigned int)argi("substeps", 1), root);
   solver.addForwardBuffer("F", "Fnew");
   Transient ex(problem, solver, argd("dt", 0.01));
+  // [Postprocess] group: evaluated before the outputs of a time step
+  ComputeDisplacements displacements(problem, "displacements", "disp", "F");
+  ComputeVonMisesStress vonmises(problem, "vonmises", "sV");
   ex.execute((int)argi("num_steps", 1), [&](int step) {
+    displacements.computeBuffer();
+    vonmises.computeBuffer();
+    dump(out, "disp", step - 1, problem.getBuffer("disp"));
+    dump(out, "sV", step - 1, problem.getBuffer("sV"));
     dump(out, "F", step - 1, problem.getBuffer("F"));  // frame 0 = end of step 1 (output on TIMESTEP_END only)
     const auto & st = mech->stats();
     std::printf("step %d: newton_its=%d cg_its_total=%d |R|=%.6e\n", step, st.newton_its, st.cg_its_total, st.last_anorm);
@@ -302,6 +309,41 @@ static int run_rotating_grain_secant(DomainAction & domain, const std::string & 
   return 0;
 }
 
+// test/tests/postprocessors/postprocessors.i: c = -x+y+0.3 on 40^2, [0,2]x[0,3]; ForwardEulerSolver on u = 0 with du/dt = c_bar,
+// 10 substeps; min/max/average/integral/ReciprocalIntegral of c and the root group's execution count
+static int run_postprocessors(DomainAction & domain, const std::string & out)
+{
+  TensorProblem problem(domain);
+  ParsedCompute::Params pc;
+  pc.buffer = "c";
+  pc.expression = arg("expression", "-x+y+0.3");
+  pc.extra_symbols = true;
+  ParsedCompute(problem, "c", pc).computeBuffer();
+  ForwardFFT(problem, "c_bar", "c_bar", "c").computeBuffer();
+  problem.getBuffer("u") = DeviceTensor::zeros(domain.getNumberOfCells());  // ConstantTensor real = 0
+  auto root = std::make_shared<ComputeGroup>(problem, "root");
+  root->add(std::make_shared<ForwardFFT>(problem, "test", "u_bar", "u"));
+  ForwardEulerSolver solver(problem, "solver", (unsigned int)argi("substeps", 10), root, {{"u", "u_bar", "c_bar"}});
+  Transient ex(problem, solver, argd("dt", 1.0));
+  double volume = 1.0;
+  for (int d = 0; d < domain.getDim(); ++d)
+    volume *= domain.getExtent(d);
+  std::ofstream csv(out + "/postprocessors.csv");
+  csv.precision(17);
+  csv << "time,max_c,min_c,avg_c,int_c,int_c_bar,count,int_u\n";
+  auto row = [&]() {
+    double mn, mx;
+    TensorPostprocessors::extreme(domain, problem.getBuffer("c"), mn, mx);
+    csv << problem.time() << ',' << mx << ',' << mn << ',' << TensorPostprocessors::average(domain, problem.getBuffer("c")) << ','
+        << TensorPostprocessors::integral(domain, problem.getBuffer("c"), volume) << ','
+        << TensorPostprocessors::reciprocalIntegral(domain, problem.getBuffer("c_bar"), volume) << ',' << root->getComputeCount()
+        << ',' << TensorPostprocessors::integral(domain, problem.getBuffer("u"), volume) << "\n";
+  };
+  row();                                                                     // execute_on = INITIAL
+  ex.execute((int)argi("num_steps", 0), [&](int) { row(); });
+  return 0;
+}
+
 // test/tests/solvers/etdrk4_diffusion.i: 1-D diffusion with ETDRK4 and a zero nonlinear term
 static int run_etdrk4_diffusion(DomainAction & domain, const std::string & out)
 {
@@ -359,6 +401,19 @@ static int run_gradient(DomainAction & domain, const std::string & out)
     ParsedCompute(problem, buffer, p).computeBuffer();
   };
   parsed("s", "sin(x)+sin(y)+sin(z)", {}, true);
+  if (arg("problem") == "gradient_square")  // test/tests/gradient/gradient_square.i
+  {
+    parsed("c2", "cos(x)^2+cos(y)^2+cos(z)^2", {}, true);
+    FFTGradientSquare(problem, "grad_sq", "grad_sq", "s").computeBuffer();
+    parsed("diff", "abs(grad_sq - c2)", {"grad_sq", "c2"}, false);
+    double vol = 1.0;
+    for (int d = 0; d < domain.getDim(); ++d)
+      vol *= domain.getExtent(d);
+    std::ofstream csv2(out + "/gradient_square.csv");
+    csv2.precision(17);
+    csv2 << "time,diff\n0,0\n1," << TensorPostprocessors::integral(domain, problem.getBuffer("diff"), vol) << "\n";
+    return 0;
+  }
   parsed("cx", "cos(x)", {}, true);
   parsed("cy", "cos(y)", {}, true);
   parsed("cz", "cos(z)", {}, true);
@@ -418,9 +473,11 @@ int main(int argc, char ** argv)
       return run_coupled(domain, out, problem == "nl_coupled");
     if (problem == "rotating_grain_secant")
       return run_rotating_grain_secant(domain, out);
+    if (problem == "postprocessors")
+      return run_postprocessors(domain, out);
     if (problem == "etdrk4_diffusion")
       return run_etdrk4_diffusion(domain, out);
-    if (problem == "gradient")
+    if (problem == "gradient" || problem == "gradient_square")
       return run_gradient(domain, out);
     mooseError("unknown problem '" + problem + "'");
   }

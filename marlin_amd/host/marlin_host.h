@@ -267,6 +267,7 @@ public:
   void add(std::shared_ptr<TensorOperatorBase> cmp) { _computes.push_back(std::move(cmp)); }
   void computeBuffer() override
   {
+    _compute_count++;                                                                // ComputeGroup.C:53
     for (auto & cmp : _computes)
     {
       try
@@ -280,8 +281,11 @@ public:
     }
   }
 
+  unsigned int getComputeCount() const { return _compute_count; }                   // ComputeGroupExecutionCount
+
 private:
   std::vector<std::shared_ptr<TensorOperatorBase>> _computes;
+  unsigned int _compute_count = 0;
 };
 
 class TensorSolver : public TensorOperatorBase
@@ -381,18 +385,46 @@ protected:
   const std::vector<DeviceTensor> & _old_nonlinear;
 };
 
-/// ForwardEulerSolver with no integrated variables (the mechanics driver): root compute, then forward buffers
+/// ForwardEulerSolver (src/tensor_solver/ForwardEulerSolver.C:27-38, ExplicitSolverBase.C:33-51): root compute, forward
+/// buffers, then u = ifft(reciprocal_buffer + sub_dt * time_derivative_reciprocal) per variable (none for the mechanics driver)
 class ForwardEulerSolver : public TensorSolver
 {
 public:
-  using TensorSolver::TensorSolver;
+  struct VariableNames
+  {
+    std::string buffer, reciprocal_buffer, time_derivative_reciprocal;
+  };
+  ForwardEulerSolver(TensorProblem & problem, const std::string & name, unsigned int substeps,
+                     std::shared_ptr<TensorOperatorBase> root_compute, const std::vector<VariableNames> & vars = {})
+    : TensorSolver(problem, name, substeps, std::move(root_compute))
+  {
+    for (const auto & v : vars)
+      _variables.push_back(Variable{problem.getBuffer(v.buffer), problem.getBuffer(v.reciprocal_buffer),
+                                    problem.getBuffer(v.time_derivative_reciprocal)});
+  }
 
 protected:
+  struct Variable
+  {
+    DeviceTensor & _buffer;
+    const DeviceTensor & _reciprocal_buffer;
+    const DeviceTensor & _time_derivative_reciprocal;
+  };
   void substep() override
   {
     _compute->computeBuffer();
     forwardBuffers();
+    for (auto & v : _variables)
+    {
+      auto ubar = DeviceTensor::empty(v._reciprocal_buffer.numel());
+      const double * N[] = {v._time_derivative_reciprocal.data()};
+      const double coef[] = {_sub_dt};
+      _domain.check(mrl_kspace_abm(_domain.ctx(), ubar.data(), v._reciprocal_buffer.data(), N, coef, 1, nullptr, _sub_dt,
+                                   _domain.getReciprocalSize()));
+      v._buffer = _domain.ifft(ubar);
+    }
   }
+  std::vector<Variable> _variables;
 };
 
 /// test object: DbarF = (I + t e0 x e1) - <F>
@@ -463,6 +495,55 @@ private:
   DeviceTensor & _tP;
   DeviceTensor * _applied;
   mrl_mech_stats _stats{};
+};
+
+
+/// ComputeDisplacements (src/tensor_computes/ComputeDisplacements.C:53-107): node displacements [(n+1)..., dim] of F
+class ComputeDisplacements : public TensorOperatorBase
+{
+public:
+  ComputeDisplacements(TensorProblem & problem, const std::string & name, const std::string & buffer, const std::string & F)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer)), _F(getInputBuffer(F))
+  {
+  }
+  void computeBuffer() override
+  {
+    if (!_F.defined())
+      return;
+    std::size_t nodes = 1;
+    for (int d = 0; d < _domain.getDim(); ++d)
+      nodes *= (std::size_t)_domain.getShape()[d] + 1;
+    auto out = DeviceTensor::empty(nodes * _domain.getDim());
+    _domain.check(mrl_mech_displacements(_domain.ctx(), _F.data(), out.data()));
+    _u = out;
+  }
+
+private:
+  DeviceTensor & _u;
+  DeviceTensor & _F;
+};
+
+/// ComputeVonMisesStress (src/tensor_computes/ComputeVonMisesStress.C:31-66)
+class ComputeVonMisesStress : public TensorOperatorBase
+{
+public:
+  ComputeVonMisesStress(TensorProblem & problem, const std::string & name, const std::string & buffer,
+                        const std::string & stress = "stress")
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer)), _stress(getInputBuffer(stress))
+  {
+  }
+  void computeBuffer() override
+  {
+    if (!_stress.defined())
+      return;
+    auto out = DeviceTensor::empty(_domain.getNumberOfCells());
+    _domain.check(mrl_mech_von_mises(_domain.ctx(), _stress.data(), out.data()));
+    _u = out;
+  }
+
+private:
+  DeviceTensor & _u;
+  DeviceTensor & _stress;
 };
 
 /// ParsedCompute: pointwise expression of input buffers (and x, y, z, kx, ky, kz, k2, t with extra_symbols)
@@ -563,6 +644,71 @@ private:
   DeviceTensor & _u;
   DeviceTensor & _input;
   mrl_parsed * _parsed = nullptr;
+};
+
+
+/// FFTGradientSquare::computeBuffer (src/tensor_computes/FFTGradientSquare.C:37-50): _u = factor * sum_d ifft(fft(input) k_d i)^2;
+/// one forward transform, per axis one generated k-space kernel + inverse transform, one generated kernel for the squares
+class FFTGradientSquare : public TensorOperatorBase
+{
+public:
+  FFTGradientSquare(TensorProblem & problem, const std::string & name, const std::string & buffer, const std::string & input,
+                    double factor = 1.0, bool input_is_reciprocal = false)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer)), _input(getInputBuffer(input)),
+      _input_is_reciprocal(input_is_reciprocal)
+  {
+    static const char * k[] = {"kx", "ky", "kz"};
+    static const char * g[] = {"gx", "gy", "gz"};
+    const int dim = _domain.getDim();
+    const char * in[] = {"abar"};
+    const int cplx[] = {1};
+    std::string sq;
+    for (int d = 0; d < dim; ++d)
+    {
+      mrl_parsed * p = nullptr;
+      const std::string expr = std::string("abar*") + k[d] + "*i";
+      if (mrl_parsed_create(_domain.ctx(), &p, expr.c_str(), 1, in, cplx, 0, nullptr, nullptr, 0, nullptr, 1, 1) != MRL_OK)
+        paramError("input", mrl_last_error(_domain.ctx()));
+      _grad.push_back(p);
+      sq += std::string(d ? "+" : "") + g[d] + "*" + g[d];
+    }
+    if (factor != 1.0)
+      sq = "(" + sq + ")*f";
+    const int real[] = {0, 0, 0};
+    const char * cn[] = {"f"};
+    if (mrl_parsed_create(_domain.ctx(), &_square, sq.c_str(), dim, g, real, 1, cn, &factor, 0, nullptr, 0, 0) != MRL_OK)
+      paramError("factor", mrl_last_error(_domain.ctx()));
+  }
+  ~FFTGradientSquare()
+  {
+    for (auto * p : _grad)
+      mrl_parsed_destroy(p);
+    mrl_parsed_destroy(_square);
+  }
+  void computeBuffer() override
+  {
+    const auto r = _input_is_reciprocal ? _input : _domain.fft(_input);
+    std::vector<DeviceTensor> g;
+    std::vector<const double *> gp;
+    for (auto * p : _grad)
+    {
+      auto gbar = DeviceTensor::empty(r.numel());
+      const double * in[] = {r.data()};
+      _domain.check(mrl_parsed_eval(p, in, gbar.data(), _domain.getReciprocalSize(), 0.0));
+      g.push_back(_domain.ifft(gbar));
+      gp.push_back(g.back().data());
+    }
+    auto out = DeviceTensor::empty(_domain.getNumberOfCells());
+    _domain.check(mrl_parsed_eval(_square, gp.data(), out.data(), _domain.getNumberOfCells(), 0.0));
+    _u = out;
+  }
+
+private:
+  DeviceTensor & _u;
+  DeviceTensor & _input;
+  const bool _input_is_reciprocal;
+  std::vector<mrl_parsed *> _grad;
+  mrl_parsed * _square = nullptr;
 };
 
 /// ReciprocalLaplacianFactor (-k^2 f) / ReciprocalLaplacianSquareFactor (k^4 f)
@@ -1132,6 +1278,22 @@ struct TensorPostprocessors
   static void extreme(DomainAction & d, const DeviceTensor & t, double & mn, double & mx)
   {
     d.check(mrl_minmax(d.ctx(), t.data(), (int64_t)t.numel(), &mn, &mx));
+  }
+  /// TensorAveragePostprocessor.C:37-51
+  static double average(DomainAction & d, const DeviceTensor & t)
+  {
+    double s = 0.0;
+    d.check(mrl_sum(d.ctx(), t.data(), (int64_t)t.numel(), &s));
+    return s / (double)t.numel();
+  }
+  /// ReciprocalIntegral.C:28-47: Re(ubar[0,...,0]) / (number of cells) * volume (rank owning k = 0)
+  static double reciprocalIntegral(DomainAction & d, const DeviceTensor & tbar, double volume)
+  {
+    double re = 0.0;
+    d.check(mrl_sync(d.ctx()));
+    if (hipMemcpy(&re, tbar.data(), sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+      mooseError("ReciprocalIntegral: hipMemcpy failed");
+    return re / (double)d.getNumberOfCells() * volume;
   }
   /// integral = average * domain volume   (TensorIntegralPostprocessor.C:29-38)
   static double integral(DomainAction & d, const DeviceTensor & t, double volume)

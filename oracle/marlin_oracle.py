@@ -465,6 +465,34 @@ def macroscopic_shear(dom: Domain, F, t: float) -> torch.Tensor:
     return applied - avg
 
 
+def compute_displacements(dom: Domain, F: torch.Tensor) -> torch.Tensor:
+    """ComputeDisplacements::computeBuffer (src/tensor_computes/ComputeDisplacements.C:53-107) -> [(n+1)..., dim]."""
+    dim = dom.dim
+    Fbox = dom.average(F)
+    Hbar = dom.fft_batched(F - Fbox)
+    q = dom.k_grid() * (-1j)
+    numer = torch.einsum("...ij,...j->...i", Hbar, q.to(torch.complex128))
+    denom = dom.k_square().unsqueeze(-1)
+    u_periodic_bar = torch.where(denom == 0, 0.0, numer / denom)
+    X = torch.stack([a.expand(dom.shape) for a in dom.axis[:dim]], -1)            # DomainAction::updateXGrid (:1457-1477)
+    u_aff = torch.einsum("ij,...j->...i", Fbox - torch.eye(dim, dtype=F64), X)
+    u_periodic = dom.ifft_batched(u_periodic_bar)
+    mode = {3: "trilinear", 2: "bilinear", 1: "linear"}[dim]
+    return torch.nn.functional.interpolate((u_aff + u_periodic).movedim(-1, 0).unsqueeze(1), size=[n + 1 for n in dom.shape],
+                                           mode=mode, align_corners=True).squeeze(1).movedim(0, -1)
+
+
+def von_mises_stress(stress: torch.Tensor, dim: int) -> torch.Tensor:
+    """ComputeVonMisesStress::computeBuffer (src/tensor_computes/ComputeVonMisesStress.C:31-66)."""
+    if dim == 3:
+        xx, yy, zz = stress[..., 0, 0], stress[..., 1, 1], stress[..., 2, 2]
+        xy, yz, zx = stress[..., 0, 1], stress[..., 1, 2], stress[..., 2, 0]
+        term4 = 6 * (xy.pow(2) + yz.pow(2) + zx.pow(2))
+        return torch.sqrt(0.5 * ((xx - yy).pow(2) + (yy - zz).pow(2) + (zz - xx).pow(2) + term4))
+    xx, yy, xy = stress[..., 0, 0], stress[..., 1, 1], stress[..., 0, 1]
+    return torch.sqrt(0.5 * ((xx - yy).pow(2) + 6 * xy.pow(2)))
+
+
 def gamma_closed_form(dom: Domain, A2: torch.Tensor) -> torch.Tensor:
     """Closed form of G(A): out_ij = q_j (sum_k A^_ik q_k)/|q|^2, zero at q=0.
 

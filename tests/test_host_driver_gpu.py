@@ -56,6 +56,12 @@ def test_mechanics_case(case, tmp_path):
         F = np.fromfile(tmp_path / f"F.{frame}.bin", dtype="<f8").reshape([n] * dim + [dim * dim])
         for k in range(dim * dim):
             worst = max(worst, np.abs(g[f"F_{k}.{frame}"] - np.transpose(F[..., k], perm)).max())
+        disp = np.fromfile(tmp_path / f"disp.{frame}.bin", dtype="<f8").reshape([n + 1] * dim + [dim])
+        for k, nm in enumerate(("disp_x", "disp_y", "disp_z")[:dim]):
+            worst = max(worst, np.abs(g[f"{nm}.{frame}"] - np.transpose(disp[..., k], perm)).max())
+        if f"sV.{frame}" in g:
+            sv = np.fromfile(tmp_path / f"sV.{frame}.bin", dtype="<f8").reshape([n] * dim)
+            worst = max(worst, np.abs(g[f"sV.{frame}"] - np.transpose(sv, perm)).max())
     assert worst <= 1e-10, worst
 
 
@@ -138,3 +144,24 @@ def test_gradient_case(tmp_path):
     _run(["problem=gradient", "dim=3", "nx=40", "ny=40", "nz=40", "xmax=2pi", "ymax=4pi", "zmax=6pi"], tmp_path)
     got = np.loadtxt(tmp_path / "gradient.csv", delimiter=",", skiprows=1)
     assert 0.0 <= got[1, 1] <= 10.0 * g[1, 1]
+
+
+def test_gradient_square_case(tmp_path):
+    """test/tests/gradient/tests (gradient_square.i): FFTGradientSquare of sin(x)+sin(y)+sin(z) vs cos^2 sums; the gold
+    value is integrated round-off (6.9e-12)"""
+    g = load_golden("fft_gold.npz")["gradient_square_out"]
+    _run(["problem=gradient_square", "dim=3", "nx=40", "ny=40", "nz=40", "xmax=2pi", "ymax=4pi", "zmax=6pi"], tmp_path)
+    got = np.loadtxt(tmp_path / "gradient_square.csv", delimiter=",", skiprows=1)
+    assert 0.0 <= got[1, 1] <= 10.0 * g[1, 1]
+
+
+def test_postprocessors_case(tmp_path):
+    """test/tests/postprocessors/tests (postprocessors.i): extreme_value.csv, average.csv, integral.csv,
+    reciprocal_integral.csv at t = 0 and count.csv over two steps of the ForwardEulerSolver (10 substeps each); u integrates
+    du/dt = c exactly, so its integral after t is t * int_c"""
+    _run(["problem=postprocessors", "dim=2", "nx=40", "ny=40", "xmax=2", "ymax=3", "num_steps=2", "substeps=10", "dt=1"], tmp_path)
+    got = np.loadtxt(tmp_path / "postprocessors.csv", delimiter=",", skiprows=1)
+    assert np.allclose(got[0, 1:6], [3.2375, -1.6375, 0.8, 4.8, 4.8], rtol=0, atol=1e-12)   # the five gold CSVs
+    assert got[:, 6].tolist() == [0, 10, 20]                                                  # count.csv
+    assert np.allclose(got[:, 7], [0.0, 4.8, 9.6], rtol=0, atol=1e-11)
+

@@ -112,7 +112,30 @@ def test_mech_gold(case):
             ref = g[f"F_{k}.{step - 1}"]
             got = F.cpu().reshape(dom.shape + [dim * dim])[..., k].permute(*perm).numpy()
             worst = max(worst, np.abs(ref - got).max())
+        # [Postprocess] group of mech3d.i / mech.i: ComputeDisplacements and ComputeVonMisesStress vs the same gold files
+        disp = ctx.mech_displacements(F).cpu()
+        for k, nm in enumerate(("disp_x", "disp_y", "disp_z")[:dim]):
+            worst = max(worst, np.abs(g[f"{nm}.{step - 1}"] - disp[..., k].permute(*perm).numpy()).max())
+        if f"sV.{step - 1}" in g:
+            sv = ctx.mech_von_mises(P).cpu()
+            worst = max(worst, np.abs(g[f"sV.{step - 1}"] - sv.permute(*perm).numpy()).max())
     assert worst <= 1e-10, worst
+
+
+@pytest.mark.parametrize("shape,L", [((12, 10, 9), (1.0, 2.0, 3.0)), ((15, 8), (2.0, 1.5)), ((64, 64, 64), (1.0, 1.0, 1.0))])
+def test_displacements_and_von_mises_vs_oracle(shape, L):
+    """random smooth-ish deformation gradients on anisotropic, odd and fast-path grids"""
+    torch.manual_seed(3)
+    dim = len(shape)
+    dom = mo.Domain(dim, list(shape), list(L))
+    ctx = _ctx(dim, list(shape), list(L))
+    F = torch.eye(dim, dtype=torch.float64) + 0.1 * torch.randn(list(shape) + [dim, dim], dtype=torch.float64)
+    want = mo.compute_displacements(dom, F)
+    got = ctx.mech_displacements(F.cuda()).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 1e-13 * max(1.0, want.abs().max().item())
+    S = torch.randn(list(shape) + [dim, dim], dtype=torch.float64)
+    assert (ctx.mech_von_mises(S.cuda()).cpu() - mo.von_mises_stress(S, dim)).abs().max().item() <= 1e-14
 
 
 def test_mech_fast_path_vs_oracle():

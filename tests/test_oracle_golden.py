@@ -114,6 +114,13 @@ def test_mech_gold(case):
             ref = g[f"F_{k}.{step - 1}"]   # output only at TIMESTEP_END: frame 0 = end of step 1
             got = F.reshape(dom.shape + [dim * dim])[..., k].permute(*perm).numpy()
             worst = max(worst, np.abs(ref - got).max())
+        # [Postprocess]: ComputeDisplacements (OVERSIZED_NODAL output, n + 1 points per axis) and ComputeVonMisesStress
+        disp = mo.compute_displacements(dom, F)
+        for k, nm in enumerate(("disp_x", "disp_y", "disp_z")[:dim]):
+            worst = max(worst, np.abs(g[f"{nm}.{step - 1}"] - disp[..., k].permute(*perm).numpy()).max())
+        if f"sV.{step - 1}" in g:
+            sv = mo.von_mises_stress(mech.P, dim)
+            worst = max(worst, np.abs(g[f"sV.{step - 1}"] - sv.permute(*perm).numpy()).max())
     assert worst <= 1e-10, worst
 
 
