@@ -11,6 +11,7 @@ Sources (relative to /root/reference):
   test/tests/cahnhilliard/gold/cahnhilliard.rank0001.h5  spec test/tests/cahnhilliard/tests:58-70  (2-rank FFT_SLAB, rank 1)
   test/tests/mechanics/gold/mech3d.h5, mech.h5           spec test/tests/mechanics/tests:2-21      (abs_tol 1e-10)
   test/tests/tensor_compute/gold/rotating_grain_secant.h5 spec test/tests/tensor_compute/tests:90-100 (abs_tol 1e-10)
+  test/tests/typed_tensors/gold/gradient.h5               spec test/tests/typed_tensors/tests (GradientTensor, 20x10x5, NODE mode)
   test/tests/solvers/gold/*.csv                          spec test/tests/solvers/tests
   test/tests/tensor_compute/gold/backandforth_out.csv, test/tests/gradient/gold/gradient_out.csv
 """
@@ -78,6 +79,7 @@ def main():
     convert_h5("test/tests/mechanics/gold/mech3d.h5", "mech3d_gold.npz")
     convert_h5("test/tests/mechanics/gold/mech.h5", "mech2d_gold.npz")
     convert_h5("test/tests/tensor_compute/gold/rotating_grain_secant.h5", "rotating_grain_secant_gold.npz")
+    convert_h5("test/tests/typed_tensors/gold/gradient.h5", "typed_gradient_gold.npz")
     sol = sorted(
         os.path.join("test/tests/solvers/gold", f)
         for f in os.listdir(os.path.join(REF, "test/tests/solvers/gold"))

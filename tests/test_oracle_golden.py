@@ -287,3 +287,23 @@ def test_secant_solver_gold():
         assert (state["psi"] - torch.from_numpy(g[f"psi.{step}"])).abs().max().item() <= 1e-10
     assert abs(ts.dt_old - 1.4 ** 9) < 1e-12
 
+
+def _node_mode(t):
+    """XDMFTensorOutput NODE mode with the default transpose: periodic wrap layer, then x <-> z"""
+    for d in range(t.dim()):
+        t = torch.cat([t, t.narrow(d, 0, 1)], d)
+    return t.permute(*reversed(range(t.dim()))).numpy()
+
+
+def test_gradient_tensor_gold():
+    """test/tests/typed_tensors/tests (gradient.i): GradientTensor (src/tensor_computes/GradientTensor.C:43-53) =
+    ifft(fft(c) * i * k_d) per axis on a 20 x 10 x 5 unit box (odd r2c axis), NODE-mode output"""
+    g = load_golden("typed_gradient_gold.npz")
+    dom = mo.Domain(3, [20, 10, 5], [1.0, 1.0, 1.0])
+    x, y, z = dom.axis
+    c = (torch.sin(x * 8 * math.pi) + torch.cos(y * 4 * math.pi)) + torch.sin(z * 2 * math.pi)
+    assert np.abs(_node_mode(c) - g["c.1"]).max() <= 1e-15
+    ibar = dom.fft(c) * torch.tensor(1j, dtype=torch.complex128)
+    for d, nm in enumerate("xyz"):
+        assert np.abs(_node_mode(dom.ifft(ibar * dom.kaxis[d])) - g[f"grad_c_{nm}.1"]).max() <= 1e-12
+

@@ -137,3 +137,31 @@ def test_parsed_free_energy_in_ch_substep(shape):
             res.append((c2.cpu(), N1.cpu(), mu.cpu()))
         for a, b in zip(*res):
             assert torch.equal(a, b)
+
+
+def test_gradient_tensor_gold_gpu():
+    """test/tests/typed_tensors/tests (gradient.i): the three components of GradientTensor through the HIP transforms
+    (generic path: 20 x 10 x 5, odd r2c axis) and generated k-space kernels `cbar*i*k_d`, against the reference's gold file"""
+    import numpy as np
+    from marlin_amd.api import Context, ParsedCompute
+    from tests.conftest import load_golden
+    from tests.test_oracle_golden import _node_mode
+    g = load_golden("typed_gradient_gold.npz")
+    ctx = Context(3, [20, 10, 5], [1.0, 1.0, 1.0])
+    c = ParsedCompute(ctx, "sin(x*8*pi)+cos(y*4*pi)+sin(z*2*pi)", extra_symbols=True)()
+    assert np.abs(_node_mode(c.cpu()) - g["c.1"]).max() <= 1e-14
+    cbar = ctx.fft(c)
+    for k, nm in zip(("kx", "ky", "kz"), "xyz"):
+        gbar = ParsedCompute(ctx, f"cbar*i*{k}", ["cbar"], complex_inputs=["cbar"], extra_symbols=True, reciprocal=True)(cbar)
+        assert np.abs(_node_mode(ctx.ifft(gbar).cpu()) - g[f"grad_c_{nm}.1"]).max() <= 1e-12
+
+
+def test_local_vars_derivative_gpu():
+    """test/tests/parsed_tensor/tests (local_vars_derivative.i): d/da of `r:=sqrt(a^2+1); r^2` equals 2a"""
+    from marlin_amd.api import Context, ParsedCompute
+    ctx = Context(2, [20, 20], [2.0, 2.0])
+    a = ParsedCompute(ctx, "x + 0.5*y", extra_symbols=True)()
+    d = ParsedCompute(ctx, "r:=sqrt(a^2+1); r^2", ["a"], derivatives=["a"])(a)
+    err = (d - 2 * a).abs()
+    assert ctx.sum(err) / 400 * 4.0 <= 1e-13          # TensorIntegralPostprocessor of |df_da - 2a|; gold: 0
+
