@@ -9,6 +9,7 @@ per-GPU work is held at 256^3 points (weak scaling; N=8 is the 512^3 configurati
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -93,25 +94,32 @@ def cpu_baseline(shape, dx, sample_steps):
     c = torch.from_numpy(splitmix64_uniform(n).reshape(shape))
     # the host cores this process may actually use (the GPU box hands out a CPU share, not the whole host)
     threads = max(1, min(len(os.sched_getaffinity(0)), 16))
-    torch.set_num_threads(threads)
-    c, N0, _, _ = mo.ch_substep_ops(c, Mbar, Lbar, [], 1e-3, 0, mo.mu_double_well, dom)  # warm-up + history
-    t0 = time.perf_counter()
-    done = 0
-    for _ in range(sample_steps):
-        c, N1, _, _ = mo.ch_substep_ops(c, Mbar, Lbar, [N0], 1e-3, 1, mo.mu_double_well, dom)
-        N0 = N1
-        done += 1
-        if time.perf_counter() - t0 > 20.0:   # bounded sample: stop after ~20 s of CPU work
-            break
-    sample_steps = done
-    dt = time.perf_counter() - t0
+
+    def sample(nthreads, budget_s, max_steps):
+        torch.set_num_threads(nthreads)
+        cc, N0, _, _ = mo.ch_substep_ops(c, Mbar, Lbar, [], 1e-3, 0, mo.mu_double_well, dom)  # warm-up + history
+        t0 = time.perf_counter()
+        done = 0
+        for _ in range(max_steps):
+            cc, N1, _, _ = mo.ch_substep_ops(cc, Mbar, Lbar, [N0], 1e-3, 1, mo.mu_double_well, dom)
+            N0 = N1
+            done += 1
+            if time.perf_counter() - t0 > budget_s:   # bounded sample
+                break
+        return done, time.perf_counter() - t0
+
+    steps_mt, dt_mt = sample(threads, 16.0, sample_steps)
+    # the reference's default is ONE libTorch thread (it only raises the count for --n-threads, TensorProblem.C:77-82)
+    steps_1t, dt_1t = sample(1, 6.0, max(1, sample_steps // 8))
     return {
-        "value": n * sample_steps / dt,
+        "value": n * steps_mt / dt_mt,
         "unit": "grid-point-updates/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{sample_steps} AB2 substeps of the same {shape[0]}x{shape[1]}x{shape[2]} fp64 grid "
-                  f"(libTorch CPU ops in the reference's order, {threads} threads, {dt:.1f} s)",
+        "sample": f"{steps_mt} AB2 substeps of the same {shape[0]}x{shape[1]}x{shape[2]} fp64 grid "
+                  f"(libTorch CPU ops in the reference's order, {threads} threads, {dt_mt:.1f} s)",
+        "single_thread": {"value": n * steps_1t / dt_1t, "cores": 1,
+                          "sample": f"{steps_1t} substeps, 1 thread (the reference's default), {dt_1t:.1f} s"},
     }
 
 
@@ -126,6 +134,15 @@ def main():
     ap.add_argument("--mech-grid", type=int, default=128, help="edge of the de Geus RVE side benchmark (config C); 0 = skip")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke runs)")
     ap.add_argument("--nsub", type=int, default=4, help="kz sub-blocks the slab substep is pipelined over (N > 1)")
+    ap.add_argument("--compute-stream", default="high", choices=["high", "default"],
+                    help="N > 1: run the local passes on a high-priority stream so that they do not share a hardware queue "
+                         "with RCCL's stream (streams of equal priority are multiplexed onto a few queues and then serialise)")
+    ap.add_argument("--carry", default="on", choices=["on", "off"],
+                    help="N > 1: spectral carry-over (c-hat of a substep = ubar of the previous one, so only mu is transformed "
+                         "and exchanged forward: 2 slab transposes per substep instead of the reference's 3; results agree to "
+                         "rounding, see include/marlin_hip.h).  The metric is scored with the reference's 153 B/update either way")
+    ap.add_argument("--force-slab", action="store_true",
+                    help="run the slab pipeline (incl. the RCCL all-to-all calls) even with one rank: a single-GPU check of the N>1 code path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,15 +165,21 @@ def main():
     sub_dt = 1e-3
     npts = int(np.prod(shape))
 
-    if world > 1:
+    slab = world > 1 or args.force_slab
+    if slab:
         import torch.distributed as dist
         from marlin_amd.slab import SlabCahnHilliard
+
+        if "RANK" not in os.environ:       # --force-slab without a launcher
+            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0", "WORLD_SIZE": "1"})
 
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(args.backend)
-        solver = SlabCahnHilliard(3, shape, L, p, world, rank, nsub=args.nsub)
+        if args.compute_stream == "high":
+            torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
+        solver = SlabCahnHilliard(3, shape, L, p, world, rank, nsub=args.nsub, carry=args.carry == "on")
         step = solver.substep
         barrier = dist.barrier
         solver.set_initial(lambda count, offset: splitmix64_uniform(count, offset=offset))
@@ -189,17 +212,17 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if slab:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # sanity: the field must still be a bounded concentration field
-    cur = solver.current() if world > 1 else c[state["i"]]
+    cur = solver.current() if slab else c[state["i"]]
     assert torch.isfinite(cur).all() and 0.0 < float(cur.min()) and float(cur.max()) < 1.0
 
     # per-kernel device time with HIP events on the launch stream (event pair per launch)
-    prof_ctx = solver.ctx if world > 1 else ctx
+    prof_ctx = solver.ctx if slab else ctx
     prof_ctx.set_profiling(True)
     for _ in range(args.profile_steps):
         step()
@@ -229,7 +252,7 @@ def main():
                 "avg_launch_ms": round(dom_k["avg_ms"], 5),
                 "algorithmic_bytes_per_launch": dom_k["bytes_per_launch"],
             }
-        if roofline and world == 1:
+        if roofline and not slab:
             tr, src = measured_traffic(dom_k["kernel"], args.n, f"<{args.n}, 1" if dom_k["kernel"] == "ch_C_x_fused" else None)
             roofline["traffic"], roofline["traffic_source"] = tr, src
         out = {
@@ -249,7 +272,8 @@ def main():
                 "workload": f"3D Cahn-Hilliard {shape[0]}x{shape[1]}x{shape[2]} fp64 semi-implicit spectral step, AB2, "
                             f"f=0.1c^2(c-1)^2, M=0.2, kappa=-0.001, sub_dt=1e-3",
                 "grid": shape,
-                "decomposition": "none" if world == 1 else f"slab x{world} (RCCL all-to-all, {args.nsub} kz sub-blocks in flight)",
+                "decomposition": "none" if not slab else f"slab x{world} (RCCL all-to-all, {args.nsub} kz sub-blocks in flight)",
+                "spectral_carry_over": bool(slab and args.carry == "on"),
             },
             "substep_algorithmic_bytes_per_update": bpu,
             "substep_achieved_GBps": value * bpu / 1e9,
@@ -258,7 +282,7 @@ def main():
             "kernels": [{"kernel": k["kernel"], "avg_ms": round(k["avg_ms"], 5), "launches_per_step":
                          k["launches"] / args.profile_steps, "algorithmic_GBps": round(k["gbps"], 1)} for k in kernels],
         }
-        if world == 1 and args.mech_grid > 0:
+        if not slab and args.mech_grid > 0:
             # side measurement (BASELINE configs[2]): de Geus RVE Newton-CG, time per CG iteration, SURVEY 8(d) byte model
             from tools.mech_bench import run as mech_run
             del c, Nh
@@ -268,11 +292,15 @@ def main():
                                 "ms_per_cg_iteration": m["ms_per_cg_iteration"], "cg_iterations_per_substep": m["cg_its"],
                                 "algorithmic_bytes_per_point_per_cg_iteration": m["algorithmic_bytes_per_point_per_cg_iteration"],
                                 "achieved_GBps": m["achieved_GBps"], "frac_of_hbm_peak": m["achieved_GBps"] / HBM_PEAK_GBPS}
-        if world == 1 and args.cpu_steps > 0:
+        if not slab and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(shape, dx, args.cpu_steps)
-        print(json.dumps(out))
-    if world > 1:
+    if slab:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to the C stdout buffer; drain it first so that the JSON line is the last line
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

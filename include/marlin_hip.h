@@ -61,6 +61,7 @@ typedef struct mrl_domain {
 } mrl_domain;
 
 #define MRL_FLAG_OWN_STREAM 1 /* the context creates (and owns) a non-blocking stream; `stream` is ignored */
+#define MRL_FLAG_SLAB 2       /* slab context even with nranks = 1 (the staged mrl_slab_* pipeline on one rank; exchanges are self-copies) */
 
 /* ---- context ------------------------------------------------------------------------ */
 int mrl_abi_version(void);
@@ -192,13 +193,28 @@ int mrl_secant_iterate(mrl_ctx *ctx, const double *d_u, const double *d_N, const
  * order, sizes from mrl_slab_ch_counts; x_p / y_p = the x / y range rank p owns, "me" = this rank):
  *   forward send  [p][field c, mu][x_p ][y_me][K_s]      forward recv  [p][field c, mu][x_me][y_p ][K_s]
  *   inverse send  [p][x_me][y_p ][K_s]                   inverse recv  [p][x_p ][y_me][K_s]
- * d_Nhat_new / d_Nhat_old / d_cbar are the dense reciprocal arrays [x_me][ny][nzc] of the reference. */
-int mrl_slab_ch_counts(const mrl_ctx *ctx, int sub, int nsub, int forward, int64_t *h_send_counts,
+ * d_Nhat_new / d_Nhat_old / d_cbar are the dense reciprocal arrays [x_me][ny][nzc] of the reference.
+ *
+ * Spectral carry-over (`carry`).  The reference recomputes cbar = fft(c) in every substep although c = ifft(ubar) of
+ * the previous one; fft(ifft(.)) is the identity up to rounding (1e-16 relative), so a rank can keep ubar -- it is produced
+ * on that rank, in reciprocal layout -- and use it as the next cbar.  The forward stages then move ONE field (mu) instead of
+ * two and a substep needs 2 slab transposes instead of 3, which is what bounds the multi-GPU rate.
+ *   MRL_CARRY_NONE  the reference's data flow; d_cbar = optional output (cbar of this substep)
+ *   MRL_CARRY_OUT   the reference's data flow, and ubar is additionally written to d_cbar (required): the bootstrap substep,
+ *                   also to be used again whenever c was modified by anything but this solver
+ *   MRL_CARRY_IN    d_cbar (required) holds cbar on entry and receives ubar; z_fwd / x_fwd / the forward exchange carry
+ *                   mu only: forward layouts lose the field index, [p][x_p][y_me][K_s] / [p][x_me][y_p][K_s]
+ * The same value has to be passed to the four calls of one substep.  Results differ from MRL_CARRY_NONE at rounding level
+ * only (tests: <= 1e-13 after 20 substeps, and against the reference's gold file). */
+#define MRL_CARRY_NONE 0
+#define MRL_CARRY_OUT 1
+#define MRL_CARRY_IN 2
+int mrl_slab_ch_counts(const mrl_ctx *ctx, int sub, int nsub, int forward, int carry, int64_t *h_send_counts,
                        int64_t *h_recv_counts);
-int mrl_slab_ch_z_fwd(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_mu /* optional out */);
-int mrl_slab_ch_x_fwd(mrl_ctx *ctx, int sub, int nsub, double *d_send);
+int mrl_slab_ch_z_fwd(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_mu /* optional out */, int carry);
+int mrl_slab_ch_x_fwd(mrl_ctx *ctx, int sub, int nsub, double *d_send, int carry);
 int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, int sub, int nsub, const double *d_recv, double *d_send,
-                       double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar);
+                       double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar, int carry);
 int mrl_slab_ch_x_inv(mrl_ctx *ctx, int sub, int nsub, const double *d_recv);
 int mrl_slab_ch_z_inv(mrl_ctx *ctx, double *d_c_out);
 

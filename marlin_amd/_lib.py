@@ -86,10 +86,10 @@ SIGNATURES = {
     "mrl_mech_von_mises": (_i32, [_vp, _vp, _vp]),
     "mrl_secant_begin": (_i32, [_vp, _vp, _vp, _vp, _dbl, _dbl, _vp, _vp, C.POINTER(_dbl), _i64]),
     "mrl_secant_iterate": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, C.POINTER(_dbl), _i64]),
-    "mrl_slab_ch_counts": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
-    "mrl_slab_ch_z_fwd": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp]),
-    "mrl_slab_ch_x_fwd": (_i32, [_vp, _i32, _i32, _vp]),
-    "mrl_slab_ch_kspace": (_i32, [_vp, C.POINTER(MrlChParams), _i32, _i32, _vp, _vp, _vp, _pp, _i32, _dbl, _vp]),
+    "mrl_slab_ch_counts": (_i32, [_vp, _i32, _i32, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "mrl_slab_ch_z_fwd": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _i32]),
+    "mrl_slab_ch_x_fwd": (_i32, [_vp, _i32, _i32, _vp, _i32]),
+    "mrl_slab_ch_kspace": (_i32, [_vp, C.POINTER(MrlChParams), _i32, _i32, _vp, _vp, _vp, _pp, _i32, _dbl, _vp, _i32]),
     "mrl_slab_ch_x_inv": (_i32, [_vp, _i32, _i32, _vp]),
     "mrl_slab_ch_z_inv": (_i32, [_vp, _vp]),
     "mrl_gamma_apply": (_i32, [_vp, _vp, _vp]),

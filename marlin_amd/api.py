@@ -72,7 +72,8 @@ class Context:
 
     def __init__(self, dim: int, n: Sequence[int], mx: Sequence[float], mn: Sequence[float] = (0.0, 0.0, 0.0),
                  nranks: int = 1, rank: int = 0, weights: Optional[Sequence[int]] = None,
-                 spectrum: int = SPECTRUM_HALF, device: Optional[int] = None, use_torch_stream: bool = True):
+                 spectrum: int = SPECTRUM_HALF, device: Optional[int] = None, use_torch_stream: bool = True,
+                 slab: bool = False):
         self.lib = _lib.load()
         d = MrlDomain()
         d.dim = dim
@@ -88,7 +89,7 @@ class Context:
         d.weights = self._weights
         d.spectrum = spectrum
         d.stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if use_torch_stream else None
-        d.flags = 0 if use_torch_stream else 1  # MRL_FLAG_OWN_STREAM
+        d.flags = (0 if use_torch_stream else 1) | (2 if slab else 0)  # MRL_FLAG_OWN_STREAM | MRL_FLAG_SLAB
         h = C.c_void_p()
         rc = self.lib.mrl_ctx_create(C.byref(h), C.byref(d))
         if rc != 0:
@@ -350,6 +351,7 @@ class ParsedCompute:
             raise MarlinHipError(rc, self.lib.mrl_last_error(ctx.h if ctx else None).decode())
         self.h = h
         self.inputs = list(inputs)
+        self.reciprocal = reciprocal
         self.is_complex = bool(self.lib.mrl_parsed_is_complex(h))
         self.tree = self.lib.mrl_parsed_string(h).decode()
         self.source = self.lib.mrl_parsed_source(h).decode()
@@ -358,10 +360,15 @@ class ParsedCompute:
                  time: float = 0.0) -> torch.Tensor:
         assert self.ctx is not None, "created without a context"
         assert len(tensors) == len(self.inputs)
+        grid = None
         if count is None:
-            count = tensors[0].numel()
+            if tensors:
+                count = tensors[0].numel()
+            else:           # no inputs: the context's local (reciprocal) grid
+                grid = self.ctx.recip_shape if self.reciprocal else self.ctx.real_shape
+                count = int(math.prod(grid))
         if out is None:
-            shape = tensors[0].shape if tensors else (count,)
+            shape = tensors[0].shape if tensors else (tuple(grid) if grid else (count,))
             out = torch.empty(shape, dtype=torch.complex128 if self.is_complex else torch.float64, device=self.ctx.device)
         arr = (C.c_void_p * max(1, len(tensors)))(*[t.data_ptr() for t in tensors])
         self.ctx._check(self.lib.mrl_parsed_eval(self.h, arr, _ptr(out), count, time))

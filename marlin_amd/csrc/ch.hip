@@ -322,7 +322,7 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
   if (order > 0 && !d_Nhat_old) return set_error(ctx, MRL_ERR_INVALID, "history pointers missing");
   for (int i = 0; i < order; ++i)
     if (!d_Nhat_old[i]) return set_error(ctx, MRL_ERR_INVALID, "history entry %d missing", i);
-  if (ctx->nranks > 1)
+  if (ctx->slab)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substep on a slab context: use the mrl_slab_ch_* stages");
 
   int rc = ch_substep_fused(ctx, cp, d_c_in, d_c_out, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, d_mu);

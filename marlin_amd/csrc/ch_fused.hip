@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const
   // byte offset of line element m: (i + (q + m*TPL)*inner) * 16, the same in the work and the dense layout
   const unsigned off0 = (unsigned)(iv + (long long)q * a.inner) * 16u, step = (unsigned)(TPL * a.inner) * 16u;
   auto off = [=](int m) { return off0 + (unsigned)m * step; };
-  ch_fused_body<N, ORDER, true, PRE>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, W, X, KX);
+  ch_fused_body<N, ORDER, true, PRE, false>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, W, X, KX);
 }
 
 template <int N, int ORDER, int PRE = Plan<N>::P / 2>
@@ -61,7 +61,7 @@ static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
 // 3-D grids [nx][ny][nz], and 2-D grids [nx][nz'] run as [nx][1][nz'] (serial contexts hold them as internal axes
 // (1, nx, ny_user): the user's y is the contiguous r2c axis; the absent middle axis contributes k = 0 exactly)
 bool fast_path_ok(const mrl_ctx *ctx) {
-  if (ctx->nranks != 1 || ctx->spectrum != MRL_SPECTRUM_HALF) return false;
+  if (ctx->slab || ctx->spectrum != MRL_SPECTRUM_HALF) return false;
   if (ctx->dim == 3) return pow2_ok(ctx->n[0]) && pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]);
   if (ctx->dim == 2) return pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]);
   return false;
@@ -212,7 +212,7 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
     {
       ProfScope ps(ctx, "ch_A_z_fwd", (8.0 * nreal + 2.0 * h + (mu ? 8.0 * nreal : 0.0)) / nchunk);
       if (cp.family == MRL_FE_PARSED) {
-        MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, cin, wc, wm, muc, nl));
+        MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 1, cin, wc, wm, muc, nl));
       } else if (cp.family == MRL_FE_DOUBLE_WELL) {
         MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, cin, wc, wm, muc, chp, nl))));
       } else {

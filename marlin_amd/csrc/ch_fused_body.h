@@ -19,7 +19,9 @@ struct FusedCommon {
   const cplx *muhat;  // mu-hat, work layout
   cplx *ubar;         // out, work layout (may alias chat)
   cplx *Nnew;         // out, dense reference layout
-  cplx *cbar;         // optional out, dense
+  cplx *cbar;         // optional out, dense: c-hat of this substep (the reference's cbar buffer)
+  cplx *carry;        // spectral carry-over (dense): SPEC_C -> in: c-hat of this substep, out: ubar = c-hat of the next one;
+                      // otherwise optional out (ubar), which bootstraps the carry-over
   const cplx *Nold[4];
   double coef[5];     // sub_dt * beta[order][i]
   double M, kappa, dt;
@@ -39,7 +41,9 @@ __device__ __forceinline__ void stc(cplx *base, unsigned boff, cplx v) {
 // OffW / OffD: callables m -> byte offset of the thread's m-th line element in the work layout / the dense
 // reference layout (computed from a few live values instead of 2 x 16 held registers).
 // OffU: the same for the ubar output (the inverse exchange layout of the slab path differs from the forward one).
-template <int N, int ORDER, bool LINE_IS_X, int PRE, class OffW, class OffD, class OffU>
+// SPEC_C: c-hat is not transformed from the work layout but read, already in reciprocal space, from a.carry (dense), which
+// receives ubar in place: irfftn followed by rfftn is the identity up to rounding, so the next substep's c-hat IS this ubar.
+template <int N, int ORDER, bool LINE_IS_X, int PRE, bool SPEC_C, class OffW, class OffD, class OffU>
 __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *__restrict__ tw,
                                               const double *__restrict__ kline, const double *__restrict__ ka_ptr,
                                               const double *__restrict__ kb_ptr, bool valid, int q, int l,
@@ -66,7 +70,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
 #pragma unroll
   for (int m = 0; m < P; ++m) v[m] = ldc(a.muhat, offw(m));
 #pragma unroll
-  for (int m = 0; m < P; ++m) cp[m] = ldc(a.chat, offw(m));
+  for (int m = 0; m < P; ++m) cp[m] = SPEC_C ? ldc(a.carry, offd(m)) : ldc(a.chat, offw(m));
 #pragma unroll
   for (int j = 0; j < CNT; ++j) {
     const int idx = threadIdx.x + j * NT;
@@ -102,8 +106,8 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
     for (int m = 0; m < PRE; ++m) o1[ORDER == 1 ? m : 0] = ldc(a.Nold[0], offd(m));
   }
 
-  // ---- 3. c-hat: forward transform
-  fft_line<N, Map>(cp, q, l, X, W);
+  // ---- 3. c-hat: forward transform (unless it is carried over in reciprocal space)
+  if (!SPEC_C) fft_line<N, Map>(cp, q, l, X, W);
   if (a.cbar && valid) {
 #pragma unroll
     for (int m = 0; m < P; ++m) stc(a.cbar, offd(m), cp[m]);
@@ -155,6 +159,11 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
         v[m] = make_double2(u.y * scl, u.x * scl);
       }
     }
+  }
+
+  if ((SPEC_C || a.carry) && valid) {
+#pragma unroll
+    for (int m = 0; m < P; ++m) stc(a.carry, offd(m), cswap(v[m]));
   }
 
   // ---- 5. inverse transform (unnormalised; 1/N applied by the final z pass)

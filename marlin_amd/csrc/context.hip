@@ -163,9 +163,10 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
   if (dom->dim < 1 || dom->dim > 3) return set_error(nullptr, MRL_ERR_INVALID, "Unsupported mesh dimension %d", dom->dim);
   if (dom->nranks < 1 || dom->rank < 0 || dom->rank >= dom->nranks)
     return set_error(nullptr, MRL_ERR_INVALID, "invalid rank %d of %d", dom->rank, dom->nranks);
-  if (dom->nranks > 1 && dom->dim < 2)
+  const bool slab = dom->nranks > 1 || (dom->flags & MRL_FLAG_SLAB);
+  if (slab && dom->dim < 2)
     return set_error(nullptr, MRL_ERR_INVALID, "Dimension must be 2 or 3 for slab decomposition.");
-  if (dom->nranks > 1 && dom->dim == 2 && dom->spectrum != MRL_SPECTRUM_FULL)
+  if (slab && dom->dim == 2 && dom->spectrum != MRL_SPECTRUM_FULL)
     return set_error(nullptr, MRL_ERR_UNSUPPORTED, "2-D slab decomposition needs spectrum = MRL_SPECTRUM_FULL");
   for (int d = 0; d < dom->dim; ++d) {
     if (dom->n[d] < 1) return set_error(nullptr, MRL_ERR_INVALID, "grid size must be positive");
@@ -187,10 +188,11 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
   c->spectrum = dom->spectrum;
   c->nranks = dom->nranks;
   c->rank = dom->rank;
+  c->slab = slab;
   // internal axes: serial contexts right-align the user axes (the r2c axis is always A2); slab
   // contexts left-align them so that x = A0 is the reciprocal split axis and y = A1 the real-space
   // split axis in 2-D and 3-D alike (a 2-D slab domain is [nx][ny][1]).
-  c->off = (c->nranks > 1) ? 0 : 3 - c->dim;
+  c->off = c->slab ? 0 : 3 - c->dim;
   const int off = c->off;
   for (int a = 0; a < 3; ++a) {
     c->n[a] = 1;
@@ -264,7 +266,7 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
     c->nrec[a] = c->nrec_glob[a];
     c->kbeg[a] = 0;
   }
-  if (c->nranks > 1) {
+  if (c->slab) {
     c->split_recip_axis = off + 0;  // x: DomainAction.C:519-520
     c->split_real_axis = off + 1;   // y: DomainAction.C:522-523
     if (c->n[c->split_recip_axis] < c->nranks || c->n[c->split_real_axis] < c->nranks) {

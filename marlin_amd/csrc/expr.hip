@@ -786,7 +786,7 @@ static int build_mu_function(mrl_parsed *p, std::string &out) {
   return MRL_OK;
 }
 
-int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const double *in, cplx *out0, cplx *out1, double *mu_out,
+int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const double *in, cplx *out0, cplx *out1, double *mu_out,
                         long long nlines) {
   // lines per workgroup / threads per workgroup of Plan<N> (fft_pow2.h)
   int T = 0, NT = 0;
@@ -800,7 +800,9 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const double *in, cp
     case 384: T = 8; NT = 256; break;
     default: return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
   }
-  auto it = p->zfwd.find(N);
+  if (mode != 1 && mode != 2) return set_error(ctx, MRL_ERR_INVALID, "parsed z pass: mode %d", mode);
+  const int key = N * 4 + mode;
+  auto it = p->zfwd.find(key);
   if (it == p->zfwd.end()) {
     std::string mu_fn;
     if (build_mu_function(p, mu_fn) != MRL_OK) return set_error(ctx, MRL_ERR_INVALID, "expression: %s", p->err.c_str());
@@ -815,7 +817,7 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const double *in, cp
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "mrl_z_fwd_parsed.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
       return set_error(ctx, MRL_ERR_HIP, "hiprtcCreateProgram failed");
-    const std::string name = "mrl::p2::k_z_fwd<" + std::to_string(N) + ", 1, 2>";
+    const std::string name = "mrl::p2::k_z_fwd<" + std::to_string(N) + ", " + std::to_string(mode) + ", 2>";
     hiprtcAddNameExpression(prog, name.c_str());
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
     if (hiprtcCompileProgram(prog, 3, opts) != HIPRTC_SUCCESS) {
@@ -841,7 +843,7 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const double *in, cp
     hipFunction_t fn = nullptr;
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, mangled.c_str()) != hipSuccess)
       return set_error(ctx, MRL_ERR_HIP, "loading the run-time compiled z pass failed");
-    it = p->zfwd.emplace(N, std::make_pair(mod, fn)).first;
+    it = p->zfwd.emplace(key, std::make_pair(mod, fn)).first;
   }
   // the argument block of k_z_fwd(const double*, cplx*, cplx*, double*, ChDev, long long, const cplx*)
   struct ChDevHost {

@@ -175,7 +175,7 @@ int mrl_fft_r2c(mrl_ctx *ctx, const double *d_in, double *d_out, int64_t batch, 
   if (!ctx) return MRL_ERR_INVALID;
   if (!d_in || !d_out || batch < 1 || (layout != 0 && layout != 1))
     return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_r2c: bad argument");
-  if (ctx->nranks > 1)
+  if (ctx->slab)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_r2c on a slab context: use the mrl_slab_* stages");
   if (fast_path_ok(ctx) && (layout == 0 || batch == 1)) return fft_forward_fast(ctx, d_in, d_out, batch);
   return fft_forward_serial(ctx, d_in, d_out, batch, layout);
@@ -185,7 +185,7 @@ int mrl_fft_c2r(mrl_ctx *ctx, const double *d_in, double *d_out, int64_t batch, 
   if (!ctx) return MRL_ERR_INVALID;
   if (!d_in || !d_out || batch < 1 || (layout != 0 && layout != 1))
     return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_c2r: bad argument");
-  if (ctx->nranks > 1)
+  if (ctx->slab)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_c2r on a slab context: use the mrl_slab_* stages");
   if (fast_path_ok(ctx) && (layout == 0 || batch == 1)) return fft_inverse_fast(ctx, d_in, d_out, batch);
   return fft_inverse_serial(ctx, d_in, d_out, batch, layout);

@@ -42,6 +42,8 @@ __device__ __forceinline__ double mu_eval(const ChDev &p, double c) {
 // z forward.  MODE 0 (PAIR): rows 2L, 2L+1 of `in` -> rows 2L, 2L+1 of out0.
 //             MODE 1 (CH)  : row L of `in` (=c) -> row L of out0 (c-hat_z) and out1 (mu-hat_z);
 //                            optionally writes mu to mu_out.
+//             MODE 2 (MU)  : rows 2L, 2L+1 of `in` (=c) -> rows 2L, 2L+1 of out0 = transform of mu = f'(c) only
+//                            (the spectral carry-over pipeline, where c-hat is not recomputed); optional mu_out.
 // nlines = number of complex transforms.
 template <int N, int MODE, int FAM>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_fwd(const double *__restrict__ in, cplx *__restrict__ out0,
@@ -60,20 +62,27 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_fwd(const double *__restri
 
   cplx v[P];
   const long long Lc = valid ? L : 0;  // out-of-range lanes transform line 0 again and store nothing
-  const long long r0 = (MODE == 0) ? 2 * Lc : Lc;
+  const long long r0 = (MODE == 1) ? Lc : 2 * Lc;
   {
     const double *p0 = in + r0 * N + q;
     double a[P], b[P];
 #pragma unroll
     for (int m = 0; m < P; ++m) a[m] = p0[m * TPL];
-    if (MODE == 0) {
+    if (MODE != 1) {
 #pragma unroll
       for (int m = 0; m < P; ++m) b[m] = p0[N + m * TPL];
     }
     tw_commit<N>(twr, W);
-    if (MODE != 0) {
+    if (MODE == 1) {
 #pragma unroll
       for (int m = 0; m < P; ++m) b[m] = mu_eval<FAM>(chp, a[m]);
+    }
+    if (MODE == 2) {
+#pragma unroll
+      for (int m = 0; m < P; ++m) {
+        a[m] = mu_eval<FAM>(chp, a[m]);
+        b[m] = mu_eval<FAM>(chp, b[m]);
+      }
     }
 #pragma unroll
     for (int m = 0; m < P; ++m) v[m] = make_double2(a[m], b[m]);
@@ -81,6 +90,14 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_fwd(const double *__restri
       double *pm = mu_out + r0 * N + q;
 #pragma unroll
       for (int m = 0; m < P; ++m) pm[m * TPL] = v[m].y;
+    }
+    if (MODE == 2 && mu_out && valid) {
+      double *pm = mu_out + r0 * N + q;
+#pragma unroll
+      for (int m = 0; m < P; ++m) {
+        pm[m * TPL] = v[m].x;
+        pm[N + m * TPL] = v[m].y;
+      }
     }
   }
   fft_line<N, Map>(v, q, l, X, W);
@@ -90,8 +107,8 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_fwd(const double *__restri
   for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
   __syncthreads();
   if (!valid) return;
-  cplx *o0 = (MODE == 0) ? out0 + (2 * L) * NZC : out0 + L * NZC;
-  cplx *o1 = (MODE == 0) ? out0 + (2 * L + 1) * NZC : out1 + L * NZC;
+  cplx *o0 = (MODE != 1) ? out0 + (2 * L) * NZC : out0 + L * NZC;
+  cplx *o1 = (MODE != 1) ? out0 + (2 * L + 1) * NZC : out1 + L * NZC;
 #pragma unroll
   for (int m = 0; m <= P / 2; ++m) {
     const int k = q + m * TPL;

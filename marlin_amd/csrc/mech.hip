@@ -375,7 +375,7 @@ static int check_dim(mrl_ctx *ctx, const char *what, bool serial = true) {
   if (ctx->dim != 2 && ctx->dim != 3)
     return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: mechanics needs a 2-D or 3-D domain", what);
   if (!serial) return MRL_OK;
-  if (ctx->nranks > 1)
+  if (ctx->slab)
     return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: serial contexts only (slab contexts: mrl_slab_gamma_project + the slab FFT stages)", what);
   if (ctx->spectrum != MRL_SPECTRUM_HALF)
     return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: needs spectrum = MRL_SPECTRUM_HALF", what);

@@ -129,7 +129,7 @@ static int launch_gamma_xfused(mrl_ctx *ctx, const GammaArgs &a) {
 }  // namespace p2
 
 bool mech_fast_ok(const mrl_ctx *ctx) {
-  return ctx->dim == 3 && ctx->nranks == 1 && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
+  return ctx->dim == 3 && !ctx->slab && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
          pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]);
 }
 

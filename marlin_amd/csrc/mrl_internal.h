@@ -60,6 +60,7 @@ struct mrl_ctx {
   double gmin[3], gmax[3], dx[3];
   int spectrum = MRL_SPECTRUM_HALF;
   int nranks = 1, rank = 0;
+  bool slab = false;            // FFT_SLAB layout and staged entry points (nranks > 1, or MRL_FLAG_SLAB)
   int device = 0;
   long long nloc[3] = {1, 1, 1};   // local real extents
   long long rbeg[3] = {0, 0, 0};   // local real begin
@@ -163,8 +164,8 @@ struct ChP {
 // parsed free energies (expr.hip)
 int parsed_check_mu(mrl_ctx *ctx, const mrl_parsed *p);                     // one real input, real output, same context
 int parsed_eval1(mrl_parsed *p, const double *c, double *mu, long long n);  // mu = expression(c), pointwise
-// k_z_fwd<N, CH> with the generated chemical potential compiled in (hiprtc), N in {64,128,256,512}
-int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const double *in, cplx *out0, cplx *out1, double *mu_out,
+// k_z_fwd<N, mode, PARSED> (mode 1: c and mu per line, 2: mu of two lines) with the generated chemical potential compiled in (hiprtc)
+int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const double *in, cplx *out0, cplx *out1, double *mu_out,
                         long long nlines);
 
 // power-of-two fast path (ch_fused.hip)

@@ -66,7 +66,7 @@ static void chunk_table(const mrl_ctx *ctx, ChunkTab &t) {
 }
 
 static int check_slab(mrl_ctx *ctx, const char *what) {
-  if (ctx->nranks < 2) return set_error(ctx, MRL_ERR_INVALID, "%s: not a slab context (nranks = 1)", what);
+  if (!ctx->slab) return set_error(ctx, MRL_ERR_INVALID, "%s: not a slab context (nranks = 1 without MRL_FLAG_SLAB)", what);
   if (ctx->nranks > 64) return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: at most 64 ranks", what);
   return MRL_OK;
 }
@@ -132,10 +132,10 @@ int slab_inv_finish(mrl_ctx *ctx, const double *recv, double *real_out) {
 // ---- Cahn-Hilliard substep pipelined over kz sub-blocks -------------------------------------------------
 // fast path (slab_fused.hip)
 int slab_fast_ok(const mrl_ctx *ctx);
-int slab_ch_z_fwd_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *mu);
-int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, double *send);
+int slab_ch_z_fwd_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *mu, int carry);
+int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, double *send, int carry);
 int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const double *recv, double *send, double *Nhat_new,
-                        const double *const *Nhat_old, int order, double sub_dt, double *cbar);
+                        const double *const *Nhat_old, int order, double sub_dt, double *cbar, int carry);
 int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv);
 int slab_ch_z_inv_fast(mrl_ctx *ctx, double *real_out);
 // generic passes on a sub-range (fft_plan.hip), k-space update on a kz sub-range (ch.hip)
@@ -200,7 +200,7 @@ static int gen_work(mrl_ctx *ctx) {
   return MRL_OK;
 }
 
-static int gen_z_fwd(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *d_mu) {
+static int gen_z_fwd(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *d_mu, int carry) {
   const long long nx = ctx->n[0], nyl = ctx->nloc[1];
   const long long nreal = real_count_local(ctx);
   MRL_TRY(gen_work(ctx));
@@ -210,57 +210,65 @@ static int gen_z_fwd(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *d_
     mu = ctx->d_work[12];
   }
   MRL_TRY(ch_mu_launch(ctx, cp, c_in, mu, nreal));
-  ProfScope ps(ctx, "slab_z_fwd", 2.0 * (8.0 * nreal + 16.0 * nx * nyl * ctx->nrec[2]));
-  MRL_TRY(pass_z_forward(ctx, c_in, ctx->d_work[13], nx, nyl, 1, 0));
+  ProfScope ps(ctx, "slab_z_fwd", (carry == MRL_CARRY_IN ? 1.0 : 2.0) * (8.0 * nreal + 16.0 * nx * nyl * ctx->nrec[2]));
+  if (carry != MRL_CARRY_IN) MRL_TRY(pass_z_forward(ctx, c_in, ctx->d_work[13], nx, nyl, 1, 0));
   return pass_z_forward(ctx, mu, ctx->d_work[14], nx, nyl, 1, 0);
 }
 
-static int gen_x_fwd(mrl_ctx *ctx, long long k0, long long ksub, double *send) {
+static int gen_x_fwd(mrl_ctx *ctx, long long k0, long long ksub, double *send, int carry) {
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2];
   long long off = 0, xb = 0;
-  for (int f = 0; f < 2; ++f) {
+  const int f0 = carry == MRL_CARRY_IN ? 1 : 0, nf = 2 - f0;  // carry-over: mu-hat only
+  for (int f = f0; f < 2; ++f) {
     double *w = ctx->d_work[13 + f] + 2 * k0;
     ProfScope ps(ctx, "slab_x_fwd", 32.0 * nx * nyl * ksub);
     MRL_TRY(pass_lines(ctx, 0, -1, w, w, nyl, ksub, nzc, 1, nyl * nzc));
   }
-  ProfScope ps(ctx, "slab_pack", 2.0 * 32.0 * nx * nyl * ksub);
+  ProfScope ps(ctx, "slab_pack", nf * 32.0 * nx * nyl * ksub);
   for (int p = 0; p < ctx->nranks; ++p) {
     const long long nxp = ctx->part_recip[p], chunk = nxp * nyl * ksub;
-    for (int f = 0; f < 2; ++f)
-      MRL_TRY(copy3(ctx, ctx->d_work[13 + f] + 2 * (xb * nyl * nzc + k0), send + 2 * (off + f * chunk), nxp, nyl, ksub,
+    for (int f = f0; f < 2; ++f)
+      MRL_TRY(copy3(ctx, ctx->d_work[13 + f] + 2 * (xb * nyl * nzc + k0), send + 2 * (off + (f - f0) * chunk), nxp, nyl, ksub,
                     nyl * nzc, nzc, nyl * ksub, ksub));
-    off += 2 * chunk;
+    off += nf * chunk;
     xb += nxp;
   }
   return MRL_OK;
 }
 
 static int gen_kspace(mrl_ctx *ctx, const ChP &cp, long long k0, long long ksub, const double *recv, double *send,
-                      double *Nhat_new, const double *const *Nhat_old, int order, double sub_dt, double *d_cbar) {
+                      double *Nhat_new, const double *const *Nhat_old, int order, double sub_dt, double *d_cbar, int carry) {
   const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2];
   MRL_TRY(gen_work(ctx));
-  double *cbar = d_cbar ? d_cbar : ctx->d_work[15];
+  const bool spec = carry == MRL_CARRY_IN;
+  // carry-over: d_cbar holds c-hat (already in reciprocal space) on entry and receives ubar; otherwise it is the optional
+  // c-hat output (MRL_CARRY_NONE) or receives ubar only (MRL_CARRY_OUT)
+  double *cbar = (d_cbar && carry != MRL_CARRY_OUT) ? d_cbar : ctx->d_work[15];
   double *mubar = ctx->d_work[11], *ubar = ctx->d_work[10];
+  const long long nf = spec ? 1 : 2;
   {
-    ProfScope ps(ctx, "slab_unpack", 2.0 * 32.0 * nxl * ny * ksub);
+    ProfScope ps(ctx, "slab_unpack", nf * 32.0 * nxl * ny * ksub);
     long long off = 0, yb = 0;
     for (int p = 0; p < ctx->nranks; ++p) {
       const long long nyp = ctx->part_real[p], chunk = nxl * nyp * ksub;
-      MRL_TRY(copy3(ctx, recv + 2 * off, cbar + 2 * (yb * nzc + k0), nxl, nyp, ksub, nyp * ksub, ksub, ny * nzc, nzc));
-      MRL_TRY(copy3(ctx, recv + 2 * (off + chunk), mubar + 2 * (yb * nzc + k0), nxl, nyp, ksub, nyp * ksub, ksub, ny * nzc, nzc));
-      off += 2 * chunk;
+      if (!spec)
+        MRL_TRY(copy3(ctx, recv + 2 * off, cbar + 2 * (yb * nzc + k0), nxl, nyp, ksub, nyp * ksub, ksub, ny * nzc, nzc));
+      MRL_TRY(copy3(ctx, recv + 2 * (off + (nf - 1) * chunk), mubar + 2 * (yb * nzc + k0), nxl, nyp, ksub, nyp * ksub, ksub, ny * nzc, nzc));
+      off += nf * chunk;
       yb += nyp;
     }
   }
   {
-    ProfScope ps(ctx, "slab_y_fwd", 2.0 * 32.0 * nxl * ny * ksub);
-    MRL_TRY(pass_lines(ctx, 1, -1, cbar + 2 * k0, cbar + 2 * k0, nxl, ksub, ny * nzc, 1, nzc));
+    ProfScope ps(ctx, "slab_y_fwd", nf * 32.0 * nxl * ny * ksub);
+    if (!spec) MRL_TRY(pass_lines(ctx, 1, -1, cbar + 2 * k0, cbar + 2 * k0, nxl, ksub, ny * nzc, 1, nzc));
     MRL_TRY(pass_lines(ctx, 1, -1, mubar + 2 * k0, mubar + 2 * k0, nxl, ksub, ny * nzc, 1, nzc));
   }
   {
     ProfScope ps(ctx, "ch_kspace", 16.0 * (double)(nxl * ny * ksub) * (4 + order));
     MRL_TRY(ch_kspace_sub_launch(ctx, cp, cbar, mubar, Nhat_new, ubar, Nhat_old, order, sub_dt, k0, ksub));
   }
+  if (carry != MRL_CARRY_NONE)  // ubar of this kz sub-block = c-hat of the next substep
+    MRL_TRY(copy3(ctx, ubar + 2 * k0, d_cbar + 2 * k0, nxl, ny, ksub, ny * nzc, nzc, ny * nzc, nzc));
   {
     ProfScope ps(ctx, "slab_y_inv", 32.0 * nxl * ny * ksub);
     MRL_TRY(pass_lines(ctx, 1, +1, ubar + 2 * k0, ubar + 2 * k0, nxl, ksub, ny * nzc, 1, nzc));
@@ -310,7 +318,7 @@ extern "C" {
 int mrl_slab_counts(const mrl_ctx *ctx, int forward, int64_t *h_send_counts, int64_t *h_recv_counts,
                     int64_t *h_send_offsets, int64_t *h_recv_offsets) {
   if (!ctx) return MRL_ERR_INVALID;
-  if (ctx->nranks < 2) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_counts: not a slab context");
+  if (!ctx->slab) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_counts: not a slab context");
   const long long nzc = ctx->nrec[2];
   long long so = 0, ro = 0;
   for (int p = 0; p < ctx->nranks; ++p) {
@@ -355,13 +363,13 @@ int mrl_slab_inv_finish(mrl_ctx *ctx, const double *d_recv, double *d_real_out) 
   return slab_inv_finish(ctx, d_recv, d_real_out);
 }
 
-int mrl_slab_ch_counts(const mrl_ctx *ctx, int sub, int nsub, int forward, int64_t *h_send_counts,
+int mrl_slab_ch_counts(const mrl_ctx *ctx, int sub, int nsub, int forward, int carry, int64_t *h_send_counts,
                        int64_t *h_recv_counts) {
   if (!ctx) return MRL_ERR_INVALID;
-  if (ctx->nranks < 2) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_counts: not a slab context");
+  if (!ctx->slab) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_counts: not a slab context");
   long long k0, ksub;
   MRL_TRY(sub_range(const_cast<mrl_ctx *>(ctx), sub, nsub, &k0, &ksub));
-  const long long nf = forward ? 2 : 1;  // the forward messages carry both fields
+  const long long nf = (forward && carry != MRL_CARRY_IN) ? 2 : 1;  // the forward messages carry both fields (mu-hat only with the carry-over)
   for (int p = 0; p < ctx->nranks; ++p) {
     const long long x_p_y_me = ctx->part_recip[p] * ctx->nloc[1] * ksub, x_me_y_p = ctx->nrec[0] * ctx->part_real[p] * ksub;
     if (h_send_counts) h_send_counts[p] = nf * (forward ? x_p_y_me : x_me_y_p);
@@ -370,30 +378,41 @@ int mrl_slab_ch_counts(const mrl_ctx *ctx, int sub, int nsub, int forward, int64
   return MRL_OK;
 }
 
-int mrl_slab_ch_z_fwd(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_mu) {
+static int check_carry(mrl_ctx *ctx, const char *what, int carry) {
+  if (carry != MRL_CARRY_NONE && carry != MRL_CARRY_OUT && carry != MRL_CARRY_IN)
+    return set_error(ctx, MRL_ERR_INVALID, "%s: carry must be MRL_CARRY_NONE, _OUT or _IN", what);
+  return MRL_OK;
+}
+
+int mrl_slab_ch_z_fwd(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_mu, int carry) {
   if (!ctx) return MRL_ERR_INVALID;
   MRL_TRY(check_slab(ctx, "mrl_slab_ch_z_fwd"));
   ChP cp;
   MRL_TRY(ch_check_params(ctx, p, cp));
   if (!d_c_in) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_z_fwd: null buffer");
-  if (slab_fast_ok(ctx)) return slab_ch_z_fwd_fast(ctx, cp, d_c_in, d_mu);
-  return gen_z_fwd(ctx, cp, d_c_in, d_mu);
+  MRL_TRY(check_carry(ctx, "mrl_slab_ch_z_fwd", carry));
+  if (slab_fast_ok(ctx)) return slab_ch_z_fwd_fast(ctx, cp, d_c_in, d_mu, carry);
+  return gen_z_fwd(ctx, cp, d_c_in, d_mu, carry);
 }
 
-int mrl_slab_ch_x_fwd(mrl_ctx *ctx, int sub, int nsub, double *d_send) {
+int mrl_slab_ch_x_fwd(mrl_ctx *ctx, int sub, int nsub, double *d_send, int carry) {
   if (!ctx) return MRL_ERR_INVALID;
   MRL_TRY(check_slab(ctx, "mrl_slab_ch_x_fwd"));
   if (!d_send) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_x_fwd: null buffer");
   long long k0, ksub;
   MRL_TRY(sub_range(ctx, sub, nsub, &k0, &ksub));
-  if (slab_fast_ok(ctx)) return slab_ch_x_fwd_fast(ctx, (int)k0, (int)ksub, d_send);
-  return gen_x_fwd(ctx, k0, ksub, d_send);
+  MRL_TRY(check_carry(ctx, "mrl_slab_ch_x_fwd", carry));
+  if (slab_fast_ok(ctx)) return slab_ch_x_fwd_fast(ctx, (int)k0, (int)ksub, d_send, carry);
+  return gen_x_fwd(ctx, k0, ksub, d_send, carry);
 }
 
 int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, int sub, int nsub, const double *d_recv, double *d_send,
-                       double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar) {
+                       double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar, int carry) {
   if (!ctx) return MRL_ERR_INVALID;
   MRL_TRY(check_slab(ctx, "mrl_slab_ch_kspace"));
+  MRL_TRY(check_carry(ctx, "mrl_slab_ch_kspace", carry));
+  if (carry != MRL_CARRY_NONE && !d_cbar)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_kspace: the carry-over needs the d_cbar array");
   ChP cp;
   MRL_TRY(ch_check_params(ctx, p, cp));
   if (!d_recv || !d_send || !d_Nhat_new) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_kspace: null buffer");
@@ -403,8 +422,8 @@ int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, int sub, int nsub, 
   long long k0, ksub;
   MRL_TRY(sub_range(ctx, sub, nsub, &k0, &ksub));
   if (slab_fast_ok(ctx))
-    return slab_ch_kspace_fast(ctx, cp, (int)k0, (int)ksub, d_recv, d_send, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar);
-  return gen_kspace(ctx, cp, k0, ksub, d_recv, d_send, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar);
+    return slab_ch_kspace_fast(ctx, cp, (int)k0, (int)ksub, d_recv, d_send, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, carry);
+  return gen_kspace(ctx, cp, k0, ksub, d_recv, d_send, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, carry);
 }
 
 int mrl_slab_ch_x_inv(mrl_ctx *ctx, int sub, int nsub, const double *d_recv) {

@@ -13,6 +13,12 @@
 //   C_s k_pass_sub<x>    inverse x from [p][nxl_p][nyl][ksub] into the work array [nx][nyl][nzc]
 //   E   k_z_inv          c2r along z, 1/N
 // (AdamsBashforthMoulton.C:60-101 with DomainAction::fftSlab/ifftSlab, DomainAction.C:869-1019.)
+//
+// Spectral carry-over (carry = MRL_CARRY_IN): the reference recomputes c-hat = fftSlab(c) every substep although c =
+// ifftSlab(ubar) of the previous one; rfftn(irfftn(.)) is the identity up to rounding, so each rank keeps ubar
+// [nxl][ny][nzc] (it is produced right there, in B_s) and uses it as the next c-hat.  Z then transforms mu only, A_s and the
+// forward all-to-all carry ONE field instead of two: the exchange volume of a substep drops from 3 to 2 slab transposes,
+// which is what bounds the multi-GPU rate on point-to-point xGMI links.
 #include "ch_fused_body.h"
 #include "fft_pow2_launch.h"
 
@@ -30,7 +36,7 @@ struct YFusedArgs {
   const double *kx, *ky, *kz;  // local reciprocal axes
 };
 
-template <int N, int ORDER>
+template <int N, int ORDER, bool SPEC_C>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, const cplx *__restrict__ tw) {
   constexpr int TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
@@ -50,9 +56,10 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
   //   dense layout              (ix*N + j)*nzc + k0 + kl
   const int sh = a.nyl_shift, msk = (1 << sh) - 1;
   const unsigned ksB = (unsigned)a.ksub * 16u, chB = a.chunk * 16u, klB = (unsigned)kl * 16u;
+  // (with the carry-over only mu-hat is received: one field per chunk)
   auto offf = [=](int m) {
     const int j = q + m * TPL;
-    return (unsigned)(j >> sh) * (2u * chB) + (unsigned)((ix << sh) + (j & msk)) * ksB + klB;
+    return (unsigned)(j >> sh) * (SPEC_C ? chB : 2u * chB) + (unsigned)((ix << sh) + (j & msk)) * ksB + klB;
   };
   auto offu = [=](int m) {
     const int j = q + m * TPL;
@@ -60,21 +67,21 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
   };
   const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + a.k0 + kl) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
   auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
-  ch_fused_body<N, ORDER, false, Plan<N>::P / 2>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
+  ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
 }
 
-template <int N, int ORDER>
+template <int N, int ORDER, bool SPEC_C>
 static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
   if (!attr) {
-    MRL_TRY(set_lds_attr(ctx, k_ch_yfused<N, ORDER>, lds));
+    MRL_TRY((set_lds_attr(ctx, k_ch_yfused<N, ORDER, SPEC_C>, lds)));
     attr = true;
   }
   constexpr int T = Plan<N>::T;
   a.tiles_per_x = (a.ksub + T - 1) / T;
   const long long nb = (long long)a.nxl * a.tiles_per_x;
-  hipLaunchKernelGGL((k_ch_yfused<N, ORDER>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[1].d_tw);
+  hipLaunchKernelGGL((k_ch_yfused<N, ORDER, SPEC_C>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[1].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
@@ -82,7 +89,7 @@ static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
 }  // namespace p2
 
 int slab_fast_ok(const mrl_ctx *ctx) {
-  if (!(ctx->dim == 3 && ctx->nranks > 1 && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
+  if (!(ctx->dim == 3 && ctx->slab && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
         pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2])))
     return 0;
   // equal power-of-two partitions: chunk addressing by shifts
@@ -111,14 +118,26 @@ static int slab_work(mrl_ctx *ctx, cplx **w_c, cplx **w_mu, cplx **w_inv) {
   return MRL_OK;
 }
 
-int slab_ch_z_fwd_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *mu) {
+int slab_ch_z_fwd_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *mu, int carry) {
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2];
   cplx *w_c, *w_mu, *w_inv;
   MRL_TRY(slab_work(ctx, &w_c, &w_mu, &w_inv));
-  ProfScope ps(ctx, "slab_Z_z_fwd", 8.0 * nx * nyl * nz + 32.0 * nx * nyl * nzc + (mu ? 8.0 * nx * nyl * nz : 0.0));
   p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
+  if (carry == MRL_CARRY_IN) {  // mu = f'(c) only, two lines per transform
+    if (nyl % 2) return set_error(ctx, MRL_ERR_UNSUPPORTED, "carry-over z pass needs an even number of local lines");
+    ProfScope ps(ctx, "slab_Z_z_fwd", 8.0 * nx * nyl * nz + 16.0 * nx * nyl * nzc + (mu ? 8.0 * nx * nyl * nz : 0.0));
+    if (cp.family == MRL_FE_PARSED) {
+      MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 2, c_in, w_mu, nullptr, mu, nx * nyl / 2));
+    } else if (cp.family == MRL_FE_DOUBLE_WELL) {
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 2, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_mu, nullptr, mu, chp, nx * nyl / 2))));
+    } else {
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 2, MRL_FE_PFHUB>(ctx, c_in, w_mu, nullptr, mu, chp, nx * nyl / 2))));
+    }
+    return MRL_OK;
+  }
+  ProfScope ps(ctx, "slab_Z_z_fwd", 8.0 * nx * nyl * nz + 32.0 * nx * nyl * nzc + (mu ? 8.0 * nx * nyl * nz : 0.0));
   if (cp.family == MRL_FE_PARSED) {
-    MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, c_in, w_c, w_mu, mu, nx * nyl));
+    MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 1, c_in, w_c, w_mu, mu, nx * nyl));
   } else if (cp.family == MRL_FE_DOUBLE_WELL) {
     MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_c, w_mu, mu, chp, nx * nyl))));
   } else {
@@ -127,13 +146,14 @@ int slab_ch_z_fwd_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *
   return MRL_OK;
 }
 
-int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, double *send) {
+int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, double *send, int carry) {
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
   cplx *w_c, *w_mu, *w_inv;
   MRL_TRY(slab_work(ctx, &w_c, &w_mu, &w_inv));
   const unsigned chunk = (unsigned)(nxl * nyl * ksub);
+  const bool one = carry == MRL_CARRY_IN;  // mu-hat only
   p2::SubPassArgs a{};
-  a.in[0] = w_c + k0;
+  a.in[0] = (one ? w_mu : w_c) + k0;
   a.in[1] = w_mu + k0;
   a.out[0] = reinterpret_cast<cplx *>(send);
   a.out[1] = a.out[0] + chunk;
@@ -145,23 +165,29 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, double *send) {
   a.sn_out = (unsigned)(nyl * ksub);
   a.sh_in = 31;
   a.sh_out = ilog2(nxl);
-  a.cs_out = 2u * chunk;
-  ProfScope ps(ctx, "slab_A_x_fwd", 4.0 * 16.0 * nx * nyl * ksub);
-  MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 2>(ctx, a, ctx->ax[0].d_tw))));
+  a.cs_out = one ? chunk : 2u * chunk;
+  ProfScope ps(ctx, "slab_A_x_fwd", (one ? 2.0 : 4.0) * 16.0 * nx * nyl * ksub);
+  if (one) {
+    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 1>(ctx, a, ctx->ax[0].d_tw))));
+  } else {
+    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 2>(ctx, a, ctx->ax[0].d_tw))));
+  }
   return MRL_OK;
 }
 
 int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const double *recv, double *send, double *Nhat_new,
-                        const double *const *Nhat_old, int order, double sub_dt, double *cbar) {
+                        const double *const *Nhat_old, int order, double sub_dt, double *cbar, int carry) {
   const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2];
   const long long nyl = ny / ctx->nranks;
+  const bool spec = carry == MRL_CARRY_IN;
   p2::YFusedArgs a{};
   a.chunk = (unsigned)(nxl * nyl * ksub);
   a.c.chat = reinterpret_cast<const cplx *>(recv);
-  a.c.muhat = a.c.chat + a.chunk;
+  a.c.muhat = spec ? a.c.chat : a.c.chat + a.chunk;
   a.c.ubar = reinterpret_cast<cplx *>(send);
   a.c.Nnew = reinterpret_cast<cplx *>(Nhat_new);
-  a.c.cbar = reinterpret_cast<cplx *>(cbar);
+  a.c.cbar = carry == MRL_CARRY_NONE ? reinterpret_cast<cplx *>(cbar) : nullptr;
+  a.c.carry = carry == MRL_CARRY_NONE ? nullptr : reinterpret_cast<cplx *>(cbar);
   for (int i = 0; i < order; ++i) a.c.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
   for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaAB[order][i];
   a.nxl = (int)nxl;
@@ -175,13 +201,24 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const dou
   a.c.M = cp.M;
   a.c.kappa = cp.kappa;
   a.c.dt = sub_dt;
-  ProfScope ps(ctx, "slab_B_y_fused", (4.0 + order + (cbar ? 1.0 : 0.0)) * 16.0 * nxl * ny * ksub);
+  // NONE: recv 2, Nnew, send (+ cbar) ; OUT: + carry write ; IN: recv 1, carry read + write, Nnew, send
+  ProfScope ps(ctx, "slab_B_y_fused", ((spec ? 5.0 : 4.0) + order + (cbar && !spec ? 1.0 : 0.0)) * 16.0 * nxl * ny * ksub);
+  if (spec) {
+    switch (order) {
+      case 0: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 0, true>(ctx, a)))); break;
+      case 1: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 1, true>(ctx, a)))); break;
+      case 2: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 2, true>(ctx, a)))); break;
+      case 3: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 3, true>(ctx, a)))); break;
+      default: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 4, true>(ctx, a)))); break;
+    }
+    return MRL_OK;
+  }
   switch (order) {
-    case 0: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 0>(ctx, a)))); break;
-    case 1: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 1>(ctx, a)))); break;
-    case 2: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 2>(ctx, a)))); break;
-    case 3: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 3>(ctx, a)))); break;
-    default: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 4>(ctx, a)))); break;
+    case 0: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 0, false>(ctx, a)))); break;
+    case 1: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 1, false>(ctx, a)))); break;
+    case 2: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 2, false>(ctx, a)))); break;
+    case 3: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 3, false>(ctx, a)))); break;
+    default: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 4, false>(ctx, a)))); break;
   }
   return MRL_OK;
 }

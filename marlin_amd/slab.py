@@ -32,6 +32,9 @@ def _prefix(counts: Sequence[int]) -> List[int]:
     return out
 
 
+CARRY_NONE, CARRY_OUT, CARRY_IN = 0, 1, 2
+
+
 class SlabExchange:
     """The global transpose: chunk p of `send` goes to rank p, chunk p of `recv` came from rank p.
 
@@ -108,7 +111,7 @@ class HipSlabStages:
 
         if spectrum is None:
             spectrum = api.SPECTRUM_HALF if dim == 3 else api.SPECTRUM_FULL
-        self.ctx = api.Context(dim, shape, L, nranks=nranks, rank=rank, weights=weights, spectrum=spectrum,
+        self.ctx = api.Context(dim, shape, L, nranks=nranks, rank=rank, weights=weights, spectrum=spectrum, slab=True,
                                device=device)
         self.lib = self.ctx.lib
         self.device = self.ctx.device
@@ -138,22 +141,23 @@ class HipSlabStages:
     def inv_finish(self, recv, real_out):
         self.ctx._check(self.lib.mrl_slab_inv_finish(self.ctx.h, self._p(recv), self._p(real_out)))
 
-    def ch_counts(self, sub, nsub, forward: bool):
+    # carry: CARRY_NONE / CARRY_OUT / CARRY_IN (include/marlin_hip.h: spectral carry-over)
+    def ch_counts(self, sub, nsub, forward: bool, carry: int = 0):
         n = self.ctx.nranks
         sc, rc = (C.c_int64 * n)(), (C.c_int64 * n)()
-        self.ctx._check(self.lib.mrl_slab_ch_counts(self.ctx.h, sub, nsub, 1 if forward else 0, sc, rc))
+        self.ctx._check(self.lib.mrl_slab_ch_counts(self.ctx.h, sub, nsub, 1 if forward else 0, carry, sc, rc))
         return list(sc), list(rc)
 
-    def ch_z_fwd(self, p, c_in, mu=None):
-        self.ctx._check(self.lib.mrl_slab_ch_z_fwd(self.ctx.h, C.byref(p), self._p(c_in), self._p(mu)))
+    def ch_z_fwd(self, p, c_in, mu=None, carry: int = 0):
+        self.ctx._check(self.lib.mrl_slab_ch_z_fwd(self.ctx.h, C.byref(p), self._p(c_in), self._p(mu), carry))
 
-    def ch_x_fwd(self, sub, nsub, send):
-        self.ctx._check(self.lib.mrl_slab_ch_x_fwd(self.ctx.h, sub, nsub, self._p(send)))
+    def ch_x_fwd(self, sub, nsub, send, carry: int = 0):
+        self.ctx._check(self.lib.mrl_slab_ch_x_fwd(self.ctx.h, sub, nsub, self._p(send), carry))
 
-    def ch_kspace(self, p, sub, nsub, recv, send, Nnew, Nold, order, sub_dt, cbar=None):
+    def ch_kspace(self, p, sub, nsub, recv, send, Nnew, Nold, order, sub_dt, cbar=None, carry: int = 0):
         arr = (C.c_void_p * max(1, len(Nold)))(*[t.data_ptr() for t in Nold])
         self.ctx._check(self.lib.mrl_slab_ch_kspace(self.ctx.h, C.byref(p), sub, nsub, self._p(recv), self._p(send),
-                                                    self._p(Nnew), arr, order, sub_dt, self._p(cbar)))
+                                                    self._p(Nnew), arr, order, sub_dt, self._p(cbar), carry))
 
     def ch_x_inv(self, sub, nsub, recv):
         self.ctx._check(self.lib.mrl_slab_ch_x_inv(self.ctx.h, sub, nsub, self._p(recv)))
@@ -172,11 +176,19 @@ class SlabCahnHilliard:
     object with the same methods to exercise this host logic over gloo).  `exchange_factory(send_counts,
     recv_counts)` builds the transposes (SlabExchange by default; the single-GPU loop-back harness of
     the GPU tests injects its own and drives the phases of all ranks in lock step).  `nsub` = number of
-    kz sub-blocks the substep is pipelined over."""
+    kz sub-blocks the substep is pipelined over.
+
+    `carry=True` switches the spectral carry-over on (include/marlin_hip.h): the first substep after the field was set
+    runs the reference's data flow and keeps ubar; every later substep uses it as c-hat, so that only mu travels forward
+    (2 slab transposes per substep instead of 3).  Anything that changes c from outside must go through set_local /
+    set_initial / invalidate_carry()."""
 
     def __init__(self, dim, shape, L, params, nranks, rank, predictor_order: int = 2, sub_dt: float = 1e-3,
-                 stages=None, exchange_factory: Optional[Callable] = None, nsub: int = 4):
+                 stages=None, exchange_factory: Optional[Callable] = None, nsub: int = 4, carry: bool = False):
         self.p = params
+        self.carry = carry
+        self._carry_valid = False
+        self.mode = CARRY_NONE
         self.nranks, self.rank = nranks, rank
         self.st = stages if stages is not None else HipSlabStages(dim, shape, L, nranks, rank)
         self.ctx = getattr(self.st, "ctx", None)
@@ -186,13 +198,17 @@ class SlabCahnHilliard:
         self.nsub = max(1, min(nsub, nzc))
         mk = exchange_factory if exchange_factory is not None else (lambda s, r: SlabExchange(s, r))
         e = self.st.empty
-        self.x_fwd, self.x_inv = [], []
+        self.x_fwd, self.x_inv, self.x_fwd1, self._len1 = [], [], [], []
         self.send_f, self.recv_f, self.send_i, self.recv_i = [], [], [], []
         for s in range(self.nsub):
             fs, fr = self.st.ch_counts(s, self.nsub, True)
             bs, br = self.st.ch_counts(s, self.nsub, False)
             self.x_fwd.append(mk(fs, fr))
             self.x_inv.append(mk(bs, br))
+            if carry:   # the one-field forward exchange (mu only); its buffers are prefixes of the two-field ones
+                f1s, f1r = self.st.ch_counts(s, self.nsub, True, CARRY_IN)
+                self.x_fwd1.append(mk(f1s, f1r))
+                self._len1.append((2 * sum(f1s), 2 * sum(f1r)))
             self.send_f.append(e(2 * sum(fs)))
             self.recv_f.append(e(2 * sum(fr)))
             self.send_i.append(e(2 * sum(bs)))
@@ -206,6 +222,7 @@ class SlabCahnHilliard:
         self.c = e(nreal)
         self.c_new = e(nreal)
         self.Nhat = [e(2 * nspec) for _ in range(self.pred + 2)]   # ring: current + history + one free
+        self.cbar = e(2 * nspec) if carry else None                # carried spectrum: ubar of the last substep
         self.hist: List[torch.Tensor] = []                         # N-hat_old[0..] (handles into the ring)
         self.cur: Optional[torch.Tensor] = None                    # N-hat of the last substep
         self.time_step = 0
@@ -227,9 +244,15 @@ class SlabCahnHilliard:
             for ix in range(nx):
                 host[ix] = torch.as_tensor(gen(nyl * nz, (ix * ny_glob + beg[1]) * nz), dtype=torch.float64).reshape(nyl, nz)
         self.c.copy_(host.reshape(-1))
+        self._carry_valid = False
 
     def set_local(self, c_local: torch.Tensor):
         self.c.copy_(c_local.reshape(-1))
+        self._carry_valid = False
+
+    def invalidate_carry(self):
+        """c was modified by something else than this solver: the next substep recomputes c-hat from it"""
+        self._carry_valid = False
 
     @property
     def _global_ny(self):
@@ -259,16 +282,24 @@ class SlabCahnHilliard:
 
     # ---- the phases of one substep -------------------------------------------------------------------
     def phase_z(self):
-        self.st.ch_z_fwd(self.p, self.c)
+        self.mode = CARRY_NONE if not self.carry else (CARRY_IN if self._carry_valid else CARRY_OUT)
+        self.st.ch_z_fwd(self.p, self.c, carry=self.mode)
         self._order = min(len(self.hist), self.pred)       # AdamsBashforthMoulton.C:90-91 (constant dt)
         self._new = self._free_Nhat()
 
     def phase_a(self, s):
-        self.st.ch_x_fwd(s, self.nsub, self.send_f[s])
+        self.st.ch_x_fwd(s, self.nsub, self.send_f[s], carry=self.mode)
+
+    def fwd_exchange(self, s):
+        """(exchange object, send view, recv view) of sub-block s for the current carry mode"""
+        if self.mode == CARRY_IN:
+            ns, nr = self._len1[s]
+            return self.x_fwd1[s], self.send_f[s][:ns], self.recv_f[s][:nr]
+        return self.x_fwd[s], self.send_f[s], self.recv_f[s]
 
     def phase_b(self, s):
         self.st.ch_kspace(self.p, s, self.nsub, self.recv_f[s], self.send_i[s], self._new, self.hist[:self._order],
-                          self._order, self.sub_dt)
+                          self._order, self.sub_dt, cbar=self.cbar, carry=self.mode)
 
     def phase_c(self, s):
         self.st.ch_x_inv(s, self.nsub, self.recv_i[s])
@@ -278,6 +309,7 @@ class SlabCahnHilliard:
         self.c, self.c_new = self.c_new, self.c
         self.cur = self._new
         self.last_order = self._order
+        self._carry_valid = self.carry
 
     def substep(self, advance: bool = True):
         """One substep including all exchanges; `advance` rotates the history afterwards (what
@@ -288,7 +320,8 @@ class SlabCahnHilliard:
         wf, wi = [], []
         for s in S:
             self.phase_a(s)
-            wf.append(self.x_fwd[s].run(self.send_f[s], self.recv_f[s], async_op=True))
+            x, snd, rcv = self.fwd_exchange(s)
+            wf.append(x.run(snd, rcv, async_op=True))
         for s in S:
             if wf[s] is not None:
                 wf[s].wait()

@@ -87,41 +87,48 @@ class OracleSlabStages:
         ks = mo.partition_helper(self.nzc, [1] * nsub)
         return sum(ks[:sub]), ks[sub]
 
-    def ch_counts(self, sub, nsub, forward):
+    # carry: 0 = the reference's data flow, 1 = same + ubar kept in cbar, 2 = c-hat taken from cbar, only mu travels forward
+    def ch_counts(self, sub, nsub, forward, carry=0):
         k0, ksub = self._sub(sub, nsub)
         to_p = [self.px[p] * self.nyl * ksub for p in range(self.nranks)]
         from_p = [self.nxl * self.py[p] * ksub for p in range(self.nranks)]
-        return ([2 * c for c in to_p], [2 * c for c in from_p]) if forward else (from_p, to_p)
+        nf = 1 if carry == 2 else 2
+        return ([nf * c for c in to_p], [nf * c for c in from_p]) if forward else (from_p, to_p)
 
-    def ch_z_fwd(self, p, c_in, mu=None):
+    def ch_z_fwd(self, p, c_in, mu=None, carry=0):
         r = c_in.reshape(self.n[0], self.nyl, self.n[2])
         m = mo.mu_double_well(r, p.coef[0])
         zf = (lambda t: torch.fft.rfft(t, dim=2)) if self.half else (lambda t: torch.fft.fft(t.to(torch.complex128), dim=2))
-        self._w = [zf(r), zf(m)]
+        self._w = [zf(m)] if carry == 2 else [zf(r), zf(m)]
 
-    def ch_x_fwd(self, sub, nsub, send):
+    def ch_x_fwd(self, sub, nsub, send, carry=0):
         k0, ksub = self._sub(sub, nsub)
         sc = self._c(send)
         off = 0
         xs = [torch.fft.fft(w[:, :, k0:k0 + ksub], dim=0) for w in self._w]
         for p in range(self.nranks):
             cnt = self.px[p] * self.nyl * ksub
-            for f in range(2):
+            for f in range(len(xs)):
                 sc[off:off + cnt] = xs[f][self.xb[p]:self.xb[p] + self.px[p]].reshape(-1)
                 off += cnt
 
-    def ch_kspace(self, p, sub, nsub, recv, send, Nnew, Nold, order, sub_dt, cbar=None):
+    def ch_kspace(self, p, sub, nsub, recv, send, Nnew, Nold, order, sub_dt, cbar=None, carry=0):
         k0, ksub = self._sub(sub, nsub)
         rc = self._c(recv)
-        dense = [torch.empty(self.nxl, self.n[1], ksub, dtype=torch.complex128) for _ in range(2)]
+        nf = 1 if carry == 2 else 2
+        dense = [torch.empty(self.nxl, self.n[1], ksub, dtype=torch.complex128) for _ in range(nf)]
         off = 0
         for q in range(self.nranks):
             cnt = self.nxl * self.py[q] * ksub
-            for f in range(2):
+            for f in range(nf):
                 dense[f][:, self.yb[q]:self.yb[q] + self.py[q], :] = rc[off:off + cnt].reshape(self.nxl, self.py[q], ksub)
                 off += cnt
-        cb = torch.fft.fft(dense[0], dim=1)
-        mb = torch.fft.fft(dense[1], dim=1)
+        full = (self.nxl, self.n[1], self.nzc)
+        if carry == 2:
+            cb = self._c(cbar).reshape(full)[:, :, k0:k0 + ksub].clone()
+        else:
+            cb = torch.fft.fft(dense[0], dim=1)
+        mb = torch.fft.fft(dense[-1], dim=1)
         k2 = self.k2[:, :, k0:k0 + ksub]
         Mbar = -k2 * p.mobility
         Lbar = k2 * k2 * p.kappa
@@ -132,6 +139,8 @@ class OracleSlabStages:
         for i in range(order):
             ubar += (sub_dt * mo.AB_BETA[order][i + 1]) * self._c(Nold[i]).reshape(shape)[:, :, k0:k0 + ksub]
         ubar /= (1.0 - sub_dt * Lbar)
+        if carry:
+            self._c(cbar).reshape(full)[:, :, k0:k0 + ksub] = ubar
         u = torch.fft.ifft(ubar, dim=1)
         sc = self._c(send)
         off = 0

@@ -34,7 +34,8 @@ def _worker(rank, world, port, case, q):
 
         dim, shape, L, c0 = case["dim"], case["shape"], case["L"], case["c0"]
         st = OracleSlabStages(dim, shape, L, world, rank)
-        s = SlabCahnHilliard(dim, shape, L, ch_params(), world, rank, stages=st, nsub=case["nsub"])
+        s = SlabCahnHilliard(dim, shape, L, ch_params(), world, rank, stages=st, nsub=case["nsub"],
+                             carry=case.get("carry", False))
         yb, nyl = st.real_begin[1], st.real_shape[1]
         s.set_local(c0[:, yb:yb + nyl].contiguous())
         out = []
@@ -60,13 +61,15 @@ def _run(world, case):
     return sorted(res)
 
 
-def test_slab_gold_rank1_two_ranks():
-    """2-rank FFT_SLAB Cahn-Hilliard: rank 1 must reproduce gold/cahnhilliard.rank0001.h5 to 1e-13"""
+@pytest.mark.parametrize("carry", [False, True])
+def test_slab_gold_rank1_two_ranks(carry):
+    """2-rank FFT_SLAB Cahn-Hilliard: rank 1 must reproduce gold/cahnhilliard.rank0001.h5 to 1e-13 -- with the reference's
+    data flow and with the spectral carry-over (c-hat = ubar of the previous substep, one field on the forward exchange)"""
     g = load_golden("cahnhilliard_rank0001_gold.npz")
     torch.manual_seed(0)
     blk = torch.rand(20, 10, dtype=torch.float64) * (0.56 - 0.44) + 0.44
     c0 = torch.cat([blk, blk], dim=1)           # every rank draws the same seed-0 block (RandomTensor.C:41-54)
-    case = dict(dim=2, shape=[20, 20], L=[3.0, 3.0], c0=c0, nsteps=10, dt=1e-3, substeps=10, nsub=1)
+    case = dict(dim=2, shape=[20, 20], L=[3.0, 3.0], c0=c0, nsteps=10, dt=1e-3, substeps=10, nsub=1, carry=carry)
     res = _run(2, case)
     rank, yb, nyl, states = res[1]
     assert (yb, nyl) == (10, 10)
@@ -74,13 +77,13 @@ def test_slab_gold_rank1_two_ranks():
     assert worst <= 1e-13, worst
 
 
-@pytest.mark.parametrize("world,shape,nsub", [(2, [8, 6, 10], 3), (3, [9, 7, 5], 1)])
-def test_slab_3d_matches_serial_oracle(world, shape, nsub):
+@pytest.mark.parametrize("world,shape,nsub,carry", [(2, [8, 6, 10], 3, False), (3, [9, 7, 5], 1, False), (2, [8, 6, 10], 2, True)])
+def test_slab_3d_matches_serial_oracle(world, shape, nsub, carry):
     """3-D r2c slab run (uneven partitions, odd sizes) == serial oracle restricted to the rank's y-slab"""
     torch.manual_seed(4)
     c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
     L = [3.0, 2.0, 2.5]
-    case = dict(dim=3, shape=shape, L=L, c0=c0, nsteps=2, dt=1e-3, substeps=3, nsub=nsub)
+    case = dict(dim=3, shape=shape, L=L, c0=c0, nsteps=2, dt=1e-3, substeps=3, nsub=nsub, carry=carry)
     res = _run(world, case)
     dom = mo.Domain(3, shape, L)
     ref = mo.CahnHilliardABM(dom, c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=3)

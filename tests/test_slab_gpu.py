@@ -2,6 +2,8 @@
 the global transpose is a loop-back copy between their send/recv buffers (the RCCL exchange itself is
 covered over gloo in test_slab_gloo.py).  Parity against the serial oracle on the global field and the
 reference's 2-rank gold file."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -57,7 +59,8 @@ def _substep_all(solvers):
     for k in S:
         for s in solvers:
             s.phase_a(k)
-        _a2a([s.x_fwd[k] for s in solvers], [s.send_f[k] for s in solvers], [s.recv_f[k] for s in solvers])
+        ex = [s.fwd_exchange(k) for s in solvers]     # (exchange, send view, recv view): one field only with the carry-over
+        _a2a([e[0] for e in ex], [e[1] for e in ex], [e[2] for e in ex])
     for k in S:
         for s in solvers:
             s.phase_b(k)
@@ -134,12 +137,14 @@ def test_slab_fft_roundtrip_and_spectrum(shape, P, spectrum):
         assert (out.cpu().reshape(st.real_shape) - a[:, yb:yb + nyl]).abs().max().item() <= 1e-13
 
 
-def test_slab_ch_gold_rank1():
-    """test/tests/cahnhilliard/tests:58-70: rank 1 of the 2-rank FFT_SLAB run, c.1..c.10 to 1e-13"""
+@pytest.mark.parametrize("carry", [False, True])
+def test_slab_ch_gold_rank1(carry):
+    """test/tests/cahnhilliard/tests:58-70: rank 1 of the 2-rank FFT_SLAB run, c.1..c.10 to 1e-13 (also with the spectral
+    carry-over: c-hat = ubar of the previous substep)"""
     g = load_golden("cahnhilliard_rank0001_gold.npz")
     torch.manual_seed(0)
     blk = torch.rand(20, 10, dtype=torch.float64) * (0.56 - 0.44) + 0.44
-    solvers = _make(2, [20, 20], [3.0, 3.0], 2, nsub=1)
+    solvers = _make(2, [20, 20], [3.0, 3.0], 2, nsub=1, carry=carry)
     for s in solvers:
         s.set_local(blk.cuda())
     worst = 0.0
@@ -166,6 +171,45 @@ def test_slab_ch_matches_serial_oracle(shape, P, nsub):
         _step_all(solvers, 1e-3, 3)
         assert (_gather(solvers) - ref.c).abs().max().item() <= 1e-13
     assert [s.last_order for s in solvers] == [1] * P
+
+
+@pytest.mark.parametrize("shape,P,nsub", [((8, 6, 10), 2, 2), ((9, 7, 5), 3, 1), ((64, 64, 64), 2, 4), ((64, 128, 64), 8, 3),
+                                          ((128, 64, 64), 4, 2)])
+def test_slab_ch_carry_over(shape, P, nsub):
+    """spectral carry-over (MRL_CARRY_OUT on the first substep, MRL_CARRY_IN afterwards) vs the reference's data flow on
+    the same kernels and vs the serial oracle: generic path (odd / uneven) and fused fast path, AB1 -> AB2 history"""
+    torch.manual_seed(4)
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    L = [3.0, 2.0, 2.5]
+    plain = _make(3, list(shape), L, P, nsub=nsub)
+    carry = _make(3, list(shape), L, P, nsub=nsub, carry=True)
+    for s in plain + carry:
+        yb, nyl = s.st.real_begin[1], s.st.real_shape[1]
+        s.set_local(c0[:, yb:yb + nyl].contiguous().cuda())
+    dom = mo.Domain(3, list(shape), L)
+    ref = mo.CahnHilliardABM(dom, c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=5)
+    for k in range(4):
+        ref.step(1e-3)
+        _step_all(plain, 1e-3, 5)
+        _step_all(carry, 1e-3, 5)
+        assert (_gather(carry) - _gather(plain)).abs().max().item() <= 1e-13
+        assert (_gather(carry) - ref.c).abs().max().item() <= 1e-13
+    assert [s.mode for s in carry] == [2] * P and [s.last_order for s in carry] == [1] * P
+    # the N-hat history agrees with the plain run's up to the rounding of the transforms: the two flows pack different
+    # pairs of real sequences into one complex z transform (c + i*mu vs two lines of mu), so mu-hat inherits an error of a few
+    # eps * |c-hat|_max = eps * sum(c), which N-hat = -k^2 M mu-hat scales by up to k_max^2 * M
+    k2max = sum((math.pi * n / l) ** 2 for n, l in zip(shape, L))
+    tol = 64 * 2.2e-16 * float(c0.sum()) * k2max * 0.2
+    for a, b in zip(carry, plain):
+        assert (a.cur - b.cur).abs().max().item() <= tol
+    # an external change of c invalidates the carried spectrum
+    for s in carry:
+        s.set_local(s.current() * 0.5 + 0.25)
+    for s in plain:
+        s.set_local(s.current() * 0.5 + 0.25)
+    _step_all(plain, 1e-3, 2)
+    _step_all(carry, 1e-3, 2)
+    assert (_gather(carry) - _gather(plain)).abs().max().item() <= 1e-13
 
 
 def test_rccl_exchange_single_rank():
