@@ -137,10 +137,11 @@ def main():
     ap.add_argument("--compute-stream", default="high", choices=["high", "default"],
                     help="N > 1: run the local passes on a high-priority stream so that they do not share a hardware queue "
                          "with RCCL's stream (streams of equal priority are multiplexed onto a few queues and then serialise)")
-    ap.add_argument("--carry", default="on", choices=["on", "off"],
-                    help="N > 1: spectral carry-over (c-hat of a substep = ubar of the previous one, so only mu is transformed "
-                         "and exchanged forward: 2 slab transposes per substep instead of the reference's 3; results agree to "
-                         "rounding, see include/marlin_hip.h).  The metric is scored with the reference's 153 B/update either way")
+    ap.add_argument("--carry", default="auto", choices=["auto", "on", "off"],
+                    help="spectral carry-over (c-hat of a substep = ubar of the previous one, so only mu is transformed "
+                         "forward: 2 slab transposes per substep instead of the reference's 3; results agree to rounding, see "
+                         "include/marlin_hip.h).  auto = on for N > 1 (exchange-bound), off for N = 1 (the reference's data flow). "
+                         "The metric is scored with the reference's 153 B/update either way")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the slab pipeline (incl. the RCCL all-to-all calls) even with one rank: a single-GPU check of the N>1 code path")
     args = ap.parse_args()
@@ -179,7 +180,7 @@ def main():
             dist.init_process_group(args.backend)
         if args.compute_stream == "high":
             torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
-        solver = SlabCahnHilliard(3, shape, L, p, world, rank, nsub=args.nsub, carry=args.carry == "on")
+        solver = SlabCahnHilliard(3, shape, L, p, world, rank, nsub=args.nsub, carry=args.carry != "off")
         step = solver.substep
         barrier = dist.barrier
         solver.set_initial(lambda count, offset: splitmix64_uniform(count, offset=offset))
@@ -189,11 +190,13 @@ def main():
         c[1] = torch.empty_like(c[0])
         Nh = [ctx.empty_spec(), ctx.empty_spec()]
         state = {"i": 0, "have_old": False}
+        carried = ctx.empty_spec() if args.carry == "on" else None
 
         def step():
             i = state["i"]
             order = 1 if state["have_old"] else 0
-            ctx.ch_substep(p, c[i], c[1 - i], Nh[i], [Nh[1 - i]] if order else [], order, sub_dt)
+            mode = 0 if carried is None else (2 if state["have_old"] else 1)
+            ctx.ch_substep(p, c[i], c[1 - i], Nh[i], [Nh[1 - i]] if order else [], order, sub_dt, cbar=carried, carry=mode)
             state["i"] = 1 - i
             state["have_old"] = True
 
@@ -273,7 +276,7 @@ def main():
                             f"f=0.1c^2(c-1)^2, M=0.2, kappa=-0.001, sub_dt=1e-3",
                 "grid": shape,
                 "decomposition": "none" if not slab else f"slab x{world} (RCCL all-to-all, {args.nsub} kz sub-blocks in flight)",
-                "spectral_carry_over": bool(slab and args.carry == "on"),
+                "spectral_carry_over": bool(args.carry == "on" or (slab and args.carry == "auto")),
             },
             "substep_algorithmic_bytes_per_update": bpu,
             "substep_achieved_GBps": value * bpu / 1e9,

@@ -133,10 +133,18 @@ int mrl_ch_mu(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c, double *d
  *   ubar = (cbar + (dt*b0)*Nhat + sum_i (dt*b_{i+1})*Nhat_old[i]) / (1 - dt*Lbar);  c_out = ifft(ubar)
  * order = number of history terms used (0 = AB1 ... 4 = AB5), d_Nhat_old[i] = i-th old Mbarmubar.
  * d_Nhat_new is always written (it enters the history); d_cbar / d_mu may be NULL (not materialised).
- * c_out may alias c_in.  Serial contexts only; slab contexts use the mrl_slab_ch_* stages. */
+ * c_out may alias c_in.  Serial contexts only; slab contexts use the mrl_slab_ch_* stages.
+ * carry (spectral carry-over, opt-in; see the slab stages below for the rationale):
+ *   MRL_CARRY_NONE  the reference's data flow, d_cbar = optional output (cbar of this substep)
+ *   MRL_CARRY_OUT   the reference's data flow, ubar additionally written to d_cbar (required)
+ *   MRL_CARRY_IN    d_cbar (required) holds cbar = ubar of the previous substep on entry and receives the new ubar; c_in is
+ *                   only used for mu = f'(c): one forward transform instead of two (results agree to rounding) */
+#define MRL_CARRY_NONE 0
+#define MRL_CARRY_OUT 1
+#define MRL_CARRY_IN 2
 int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_c_out,
                    double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt,
-                   double *d_cbar, double *d_mu);
+                   double *d_cbar, double *d_mu, int carry);
 
 /* ReciprocalLaplacianFactor (power = 1: -k^2 * factor, ReciprocalLaplacianFactor.C:28-31) and
  * ReciprocalLaplacianSquareFactor (power = 2: k^2 * k^2 * factor, ReciprocalLaplacianSquareFactor.C:28-32) as real
@@ -205,10 +213,7 @@ int mrl_secant_iterate(mrl_ctx *ctx, const double *d_u, const double *d_N, const
  *   MRL_CARRY_IN    d_cbar (required) holds cbar on entry and receives ubar; z_fwd / x_fwd / the forward exchange carry
  *                   mu only: forward layouts lose the field index, [p][x_p][y_me][K_s] / [p][x_me][y_p][K_s]
  * The same value has to be passed to the four calls of one substep.  Results differ from MRL_CARRY_NONE at rounding level
- * only (tests: <= 1e-13 after 20 substeps, and against the reference's gold file). */
-#define MRL_CARRY_NONE 0
-#define MRL_CARRY_OUT 1
-#define MRL_CARRY_IN 2
+ * only (tests: <= 1e-13 after 20 substeps, and against the reference's gold file).  (MRL_CARRY_* are defined above.) */
 int mrl_slab_ch_counts(const mrl_ctx *ctx, int sub, int nsub, int forward, int carry, int64_t *h_send_counts,
                        int64_t *h_recv_counts);
 int mrl_slab_ch_z_fwd(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_mu /* optional out */, int carry);

@@ -183,10 +183,12 @@ class Context:
         return out
 
     def ch_substep(self, p: MrlChParams, c_in, c_out, Nhat_new, Nhat_old: Sequence[torch.Tensor], order: int,
-                   sub_dt: float, cbar=None, mu=None):
+                   sub_dt: float, cbar=None, mu=None, carry: int = 0):
+        """carry: 0 = the reference's data flow; 1 = same, ubar kept in `cbar`; 2 = `cbar` holds c-hat (the previous ubar) on
+        entry and receives the new ubar (spectral carry-over, include/marlin_hip.h)"""
         arr = (C.c_void_p * max(1, len(Nhat_old)))(*[t.data_ptr() for t in Nhat_old])
         self._check(self.lib.mrl_ch_substep(self.h, C.byref(p), _ptr(c_in), _ptr(c_out), _ptr(Nhat_new), arr, order,
-                                            sub_dt, _ptr(cbar), _ptr(mu)))
+                                            sub_dt, _ptr(cbar), _ptr(mu), carry))
 
     def kspace_abm(self, out, ubar0, N: Sequence[torch.Tensor], coef: Sequence[float], L, dt: float):
         n = len(N)

@@ -52,9 +52,9 @@ __device__ __forceinline__ double ksq(int, double a, double b, double c) {
 }
 
 // one thread per spectral point; cbar / mubar interleaved complex
-__global__ void __launch_bounds__(256) k_ch_kspace(KspaceArgs a, const double2 *__restrict__ cbar,
+__global__ void __launch_bounds__(256) k_ch_kspace(KspaceArgs a, const double2 *cbar /* may alias ubar */,
                                                    const double2 *__restrict__ mubar, double2 *__restrict__ Nhat,
-                                                   double2 *__restrict__ ubar) {
+                                                   double2 *ubar) {
 #pragma clang fp contract(off)
   const long long total = a.n0 * a.n1 * a.ksub;
   for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (long long)gridDim.x * blockDim.x) {
@@ -296,7 +296,7 @@ int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const doub
 
 // fast fused path (ch_fused.hip); returns MRL_ERR_UNSUPPORTED when the shape has no fast kernels
 int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new,
-                     const double *const *Nhat_old, int order, double sub_dt, double *cbar, double *mu);
+                     const double *const *Nhat_old, int order, double sub_dt, double *cbar, double *mu, int carry);
 
 }  // namespace mrl
 
@@ -313,7 +313,7 @@ int mrl_ch_mu(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c, double *d
 }
 
 int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_c_out, double *d_Nhat_new,
-                   const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar, double *d_mu) {
+                   const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar, double *d_mu, int carry) {
   if (!ctx) return MRL_ERR_INVALID;
   ChP cp;
   MRL_TRY(ch_check_params(ctx, p, cp));
@@ -325,7 +325,12 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
   if (ctx->slab)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substep on a slab context: use the mrl_slab_ch_* stages");
 
-  int rc = ch_substep_fused(ctx, cp, d_c_in, d_c_out, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, d_mu);
+  if (carry != MRL_CARRY_NONE && carry != MRL_CARRY_OUT && carry != MRL_CARRY_IN)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substep: carry must be MRL_CARRY_NONE, _OUT or _IN");
+  if (carry != MRL_CARRY_NONE && !d_cbar)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substep: the carry-over needs the d_cbar array");
+
+  int rc = ch_substep_fused(ctx, cp, d_c_in, d_c_out, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, d_mu, carry);
   if (rc != MRL_ERR_UNSUPPORTED) return rc;
 
   // generic sequence: separate pointwise kernels around the generic transforms
@@ -339,15 +344,19 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
   }
   MRL_TRY(mrl_ch_mu(ctx, p, d_c_in, mu, nreal));
   double *mubar = ctx->d_work[1];
-  double *cbar = d_cbar ? d_cbar : ctx->d_work[2];
-  double *ubar = ctx->d_work[2];
+  // carry-over: MRL_CARRY_IN reads c-hat from d_cbar (no transform of c) and both carry modes leave ubar there
+  double *cbar = (d_cbar && carry != MRL_CARRY_OUT) ? d_cbar : ctx->d_work[2];
+  double *ubar = carry == MRL_CARRY_NONE ? ctx->d_work[2] : d_cbar;
   MRL_TRY(fft_forward_serial(ctx, mu, mubar, 1, 0));
-  MRL_TRY(fft_forward_serial(ctx, d_c_in, cbar, 1, 0));
+  if (carry != MRL_CARRY_IN) MRL_TRY(fft_forward_serial(ctx, d_c_in, cbar, 1, 0));
   {
     ProfScope ps(ctx, "ch_kspace", 16.0 * (double)nspec * (4 + order));
-    MRL_TRY(ch_kspace_launch(ctx, cp, cbar, mubar, d_Nhat_new, ubar, d_Nhat_old, order, sub_dt));
+    MRL_TRY(ch_kspace_launch(ctx, cp, cbar, mubar, d_Nhat_new, ubar, d_Nhat_old, order, sub_dt));  // elementwise: ubar may alias cbar
   }
-  return fft_inverse_serial(ctx, ubar, d_c_out, 1, 0);
+  if (carry == MRL_CARRY_NONE) return fft_inverse_serial(ctx, ubar, d_c_out, 1, 0);
+  // the inverse transform may overwrite its input: run it on a copy so that d_cbar keeps ubar
+  MRL_HIP(ctx, hipMemcpyAsync(mubar, ubar, sizeof(cplx) * nspec, hipMemcpyDeviceToDevice, ctx->stream));
+  return fft_inverse_serial(ctx, mubar, d_c_out, 1, 0);
 }
 
 int mrl_reciprocal_laplacian(mrl_ctx *ctx, int power, double factor, double *d_out) {

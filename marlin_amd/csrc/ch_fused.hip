@@ -22,7 +22,7 @@ struct FusedArgs {
   const double *kx, *ky, *kz;
 };
 
-template <int N, int ORDER, int PRE>
+template <int N, int ORDER, int PRE, bool SPEC_C>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const cplx *__restrict__ tw) {
   constexpr int TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
@@ -38,20 +38,20 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const
   // byte offset of line element m: (i + (q + m*TPL)*inner) * 16, the same in the work and the dense layout
   const unsigned off0 = (unsigned)(iv + (long long)q * a.inner) * 16u, step = (unsigned)(TPL * a.inner) * 16u;
   auto off = [=](int m) { return off0 + (unsigned)m * step; };
-  ch_fused_body<N, ORDER, true, PRE, false>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, W, X, KX);
+  ch_fused_body<N, ORDER, true, PRE, SPEC_C>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, W, X, KX);
 }
 
-template <int N, int ORDER, int PRE = Plan<N>::P / 2>
+template <int N, int ORDER, bool SPEC_C, int PRE = Plan<N>::P / 2>
 static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
   if (!attr) {
-    MRL_TRY(set_lds_attr(ctx, k_ch_xfused<N, ORDER, PRE>, lds));
+    MRL_TRY((set_lds_attr(ctx, k_ch_xfused<N, ORDER, PRE, SPEC_C>, lds)));
     attr = true;
   }
   constexpr int T = Plan<N>::T;
   const long long nb = (a.inner + T - 1) / T;
-  hipLaunchKernelGGL((k_ch_xfused<N, ORDER, PRE>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
+  hipLaunchKernelGGL((k_ch_xfused<N, ORDER, PRE, SPEC_C>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
@@ -188,8 +188,9 @@ int fft_inverse_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long 
 }
 
 int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new,
-                     const double *const *Nhat_old, int order, double sub_dt, double *cbar, double *mu) {
+                     const double *const *Nhat_old, int order, double sub_dt, double *cbar, double *mu, int carry) {
   if (!fast_path_ok(ctx)) return MRL_ERR_UNSUPPORTED;
+  const bool spec = carry == MRL_CARRY_IN;  // spectral carry-over: c-hat is `cbar` (= ubar of the previous substep)
   const Geo g = geo_of(ctx);
   const long long nx = g.nx, ny = g.ny, nz = g.nz, nzc = g.nzc;
   const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
@@ -209,6 +210,21 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
     const double *cin = c_in + l0 * nz;
     cplx *wc = w_c + l0 * nzc, *wm = w_mu + l0 * nzc;
     double *muc = mu ? mu + l0 * nz : nullptr;
+    if (spec) {  // mu only: two lines per complex transform, one field through the y pass
+      {
+        ProfScope ps(ctx, "ch_A_z_fwd", (8.0 * nreal + h + (mu ? 8.0 * nreal : 0.0)) / nchunk);
+        if (cp.family == MRL_FE_PARSED) {
+          MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 2, cin, wm, nullptr, muc, nl / 2));
+        } else if (cp.family == MRL_FE_DOUBLE_WELL) {
+          MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 2, MRL_FE_DOUBLE_WELL>(ctx, cin, wm, nullptr, muc, chp, nl / 2))));
+        } else {
+          MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 2, MRL_FE_PFHUB>(ctx, cin, wm, nullptr, muc, chp, nl / 2))));
+        }
+      }
+      ProfScope ps(ctx, "ch_B_y_fwd", 2.0 * h / nchunk);
+      MRL_TRY(pass_axis(ctx, 1, false, 1, w_mu, nullptr, w_mu, nullptr, true, x0, x1));
+      continue;
+    }
     {
       ProfScope ps(ctx, "ch_A_z_fwd", (8.0 * nreal + 2.0 * h + (mu ? 8.0 * nreal : 0.0)) / nchunk);
       if (cp.family == MRL_FE_PARSED) {
@@ -225,13 +241,14 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
     }
   }
   {
-    ProfScope ps(ctx, "ch_C_x_fused", (4.0 + order + (cbar ? 1.0 : 0.0)) * h);
+    ProfScope ps(ctx, "ch_C_x_fused", ((spec ? 5.0 : 4.0) + order + (cbar && !spec ? 1.0 : 0.0)) * h);
     p2::FusedArgs a{};
     a.c.chat = w_c;
     a.c.muhat = w_mu;
     a.c.ubar = w_c;
     a.c.Nnew = reinterpret_cast<cplx *>(Nhat_new);
-    a.c.cbar = reinterpret_cast<cplx *>(cbar);
+    a.c.cbar = carry == MRL_CARRY_NONE ? reinterpret_cast<cplx *>(cbar) : nullptr;
+    a.c.carry = carry == MRL_CARRY_NONE ? nullptr : reinterpret_cast<cplx *>(cbar);
     for (int i = 0; i < order; ++i) a.c.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
     for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaAB[order][i];
     a.inner = ny * nzc;
@@ -242,12 +259,22 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
     a.c.M = cp.M;
     a.c.kappa = cp.kappa;
     a.c.dt = sub_dt;
-    switch (order) {
-      case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0>(ctx, a, g.tw_x)))); break;
-      case 1: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 1>(ctx, a, g.tw_x)))); break;  // PRE = 8 (4, 12: same; 16 spills: -12 %)
-      case 2: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 2>(ctx, a, g.tw_x)))); break;
-      case 3: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 3>(ctx, a, g.tw_x)))); break;
-      default: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 4>(ctx, a, g.tw_x)))); break;
+    if (spec) {
+      switch (order) {
+        case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0, true>(ctx, a, g.tw_x)))); break;
+        case 1: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 1, true>(ctx, a, g.tw_x)))); break;
+        case 2: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 2, true>(ctx, a, g.tw_x)))); break;
+        case 3: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 3, true>(ctx, a, g.tw_x)))); break;
+        default: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 4, true>(ctx, a, g.tw_x)))); break;
+      }
+    } else {
+      switch (order) {
+        case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0, false>(ctx, a, g.tw_x)))); break;
+        case 1: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 1, false>(ctx, a, g.tw_x)))); break;  // PRE = 8 (4, 12: same; 16 spills: -12 %)
+        case 2: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 2, false>(ctx, a, g.tw_x)))); break;
+        case 3: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 3, false>(ctx, a, g.tw_x)))); break;
+        default: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 4, false>(ctx, a, g.tw_x)))); break;
+      }
     }
   }
   {

@@ -343,6 +343,8 @@ public:
     std::size_t predictor_order = 2;
     mrl_ch_params ch{};
     bool publish_mu = true, publish_cbar = false;
+    /// opt-in: cbar of a substep = ubar of the previous one (MRL_CARRY_*), valid while `buffer` is only written by this solver
+    bool spectral_carry = false;
   };
   AdamsBashforthMoulton(TensorProblem & problem, const std::string & name, const Params & p)
     : TensorSolver(problem, name, p.substeps, nullptr), _p(p), _predictor_order(p.predictor_order - 1),
@@ -351,6 +353,8 @@ public:
   {
     if (p.predictor_order < 1 || p.predictor_order > 5)
       paramError("predictor_order", "predictor_order > 0 & predictor_order <= 5");
+    if (p.spectral_carry && p.publish_cbar)
+      paramError("spectral_carry", "cbar is not materialised separately when it is carried over");
   }
 
 protected:
@@ -369,8 +373,19 @@ protected:
     std::vector<const double *> old(order > 0 ? order : 1, nullptr);
     for (int i = 0; i < order; ++i)
       old[i] = _old_nonlinear[i].data();
-    _domain.check(mrl_ch_substep(_domain.ctx(), &_p.ch, _u.data(), c_out.data(), Nnew.data(), old.data(), order,
-                                 _sub_dt, cbar.defined() ? cbar.data() : nullptr, mu.defined() ? mu.data() : nullptr));
+    int carry = MRL_CARRY_NONE;
+    if (_p.spectral_carry)
+    {
+      // the carried spectrum belongs to the tensor this solver published last; any other writer rebinds the handle
+      const bool valid = _carry.defined() && _u.data() == _last_c;
+      if (!valid)
+        _carry = DeviceTensor::empty(nspec);
+      carry = valid ? MRL_CARRY_IN : MRL_CARRY_OUT;
+    }
+    _domain.check(mrl_ch_substep(_domain.ctx(), &_p.ch, _u.data(), c_out.data(), Nnew.data(), old.data(), order, _sub_dt,
+                                 carry != MRL_CARRY_NONE ? _carry.data() : (cbar.defined() ? cbar.data() : nullptr),
+                                 mu.defined() ? mu.data() : nullptr, carry));
+    _last_c = c_out.data();
     _nonlinear = Nnew;  // what the compute group assigns to Mbarmubar
     if (mu.defined())
       _tensor_problem.getBuffer(_p.mu) = mu;
@@ -383,6 +398,8 @@ protected:
   DeviceTensor & _u;
   DeviceTensor & _nonlinear;
   const std::vector<DeviceTensor> & _old_nonlinear;
+  DeviceTensor _carry;
+  const double * _last_c = nullptr;
 };
 
 /// ForwardEulerSolver (src/tensor_solver/ForwardEulerSolver.C:27-38, ExplicitSolverBase.C:33-51): root compute, forward

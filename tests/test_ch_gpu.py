@@ -9,9 +9,12 @@ from tests.conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-def _run_hip_ch(ctx, p, c0, nsteps, substeps, dt, pred=1, want_mu=False):
-    """TensorSolver::computeBuffer loop with the history rules of TensorProblem::advanceState (host logic only)."""
+def _run_hip_ch(ctx, p, c0, nsteps, substeps, dt, pred=1, want_mu=False, carry=False):
+    """TensorSolver::computeBuffer loop with the history rules of TensorProblem::advanceState (host logic only).
+    carry: spectral carry-over (first substep MRL_CARRY_OUT, then MRL_CARRY_IN on the same array)"""
     c = c0.cuda()
+    carried = ctx.empty_spec() if carry else None
+    nsub_done = 0
     hist = []
     Nhat = None
     states = []
@@ -37,7 +40,9 @@ def _run_hip_ch(ctx, p, c0, nsteps, substeps, dt, pred=1, want_mu=False):
             order = min(len(hist), pred)
             Nnew = ctx.empty_spec()
             cn = torch.empty_like(c)
-            ctx.ch_substep(p, c, cn, Nnew, hist[:order], order, sub_dt, mu=mu)
+            ctx.ch_substep(p, c, cn, Nnew, hist[:order], order, sub_dt, mu=mu, cbar=carried,
+                           carry=0 if not carry else (1 if nsub_done == 0 else 2))
+            nsub_done += 1
             c, Nhat = cn, Nnew
             if s < substeps - 1:
                 advance()
@@ -45,13 +50,14 @@ def _run_hip_ch(ctx, p, c0, nsteps, substeps, dt, pred=1, want_mu=False):
     return states, (mu.cpu() if want_mu else None)
 
 
-def test_ch_gold_file():
-    """test/tests/cahnhilliard/tests:46-57: c.1..c.10 and mu.10 to abs_tol 1e-13"""
+@pytest.mark.parametrize("carry", [False, True])
+def test_ch_gold_file(carry):
+    """test/tests/cahnhilliard/tests:46-57: c.1..c.10 and mu.10 to abs_tol 1e-13 (also with the opt-in spectral carry-over)"""
     from marlin_amd.api import Context, ch_params
     g = load_golden("cahnhilliard_gold.npz")
     ctx = Context(2, [20, 20], [3.0, 3.0])
     c0 = torch.from_numpy(g["c.0"][:20, :20].copy())
-    states, mu = _run_hip_ch(ctx, ch_params(), c0, 10, 10, 1e-3, want_mu=True)
+    states, mu = _run_hip_ch(ctx, ch_params(), c0, 10, 10, 1e-3, want_mu=True, carry=carry)
     worst = max(np.abs(g[f"c.{k + 1}"][:20, :20] - states[k].numpy()).max() for k in range(10))
     assert worst <= 1e-13, worst
     assert np.abs(g["mu.10"] - mu.numpy()).max() <= 1e-13
@@ -72,6 +78,9 @@ def test_ch_vs_oracle(shape):
         ref.step(5e-3)
     states, _ = _run_hip_ch(ctx, ch_params(), c0, 3, 5, 5e-3)
     assert (states[-1] - ref.c).abs().max().item() <= 1e-13
+    # opt-in spectral carry-over (c-hat = ubar of the previous substep): same fields to rounding
+    carried, _ = _run_hip_ch(ctx, ch_params(), c0, 3, 5, 5e-3, carry=True)
+    assert (carried[-1] - ref.c).abs().max().item() <= 1e-13
 
 
 def test_ch_pfhub_family_and_ab3():
@@ -88,6 +97,8 @@ def test_ch_pfhub_family_and_ab3():
     p = ch_params(FE_PFHUB, (5.0, 0.3, 0.7), mobility=5.0, kappa=-10.0)
     states, _ = _run_hip_ch(ctx, p, c0, 3, 4, 1.0, pred=2)
     assert (states[-1] - ref.c).abs().max().item() <= 1e-13
+    carried, _ = _run_hip_ch(ctx, p, c0, 3, 4, 1.0, pred=2, carry=True)
+    assert (carried[-1] - ref.c).abs().max().item() <= 1e-13
 
 
 @pytest.mark.parametrize("shape", [(64, 64, 64), (64, 128, 64), (128, 64, 64)])

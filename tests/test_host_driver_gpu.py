@@ -20,7 +20,7 @@ def _run(args, tmp_path):
     return out.stdout
 
 
-@pytest.mark.parametrize("free_energy", [["A=0.1"], ["expression=0.1*c^2*(c-1)^2"]])
+@pytest.mark.parametrize("free_energy", [["A=0.1"], ["expression=0.1*c^2*(c-1)^2"], ["A=0.1", "spectral_carry=1"]])
 def test_cahnhilliard_case(free_energy, tmp_path):
     """test/tests/cahnhilliard/tests:46-57 (cahnhilliard.i): c.1..c.10, mu.10 vs gold, abs_tol 1e-13 -- with the
     built-in double well and with the input file's own ParsedCompute text (expression + derivatives = c)"""
