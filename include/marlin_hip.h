@@ -241,6 +241,25 @@ int mrl_mech_tangent_apply(mrl_ctx *ctx, const double *d_F, const double *d_K, c
  *   mrl_dot / mrl_norm2 / mrl_sum return the LOCAL value (the caller all-reduces), mrl_axpby is the vector update. */
 /* in-place Gamma projection of field-major spectra [D*D][x_me][ny][nzc] (complex), times scale */
 int mrl_slab_gamma_project(mrl_ctx *ctx, double *d_spec, double scale);
+/* Fused slab Gamma operator on FIELD-MAJOR data [9][x][y_me][z] (3-D, planned extents, equal power-of-two partitions;
+ * MRL_ERR_UNSUPPORTED otherwise -- use the per-component stages above).  out_ij = q_j (sum_k A_ik q_k)/|q|^2 couples only
+ * the three components of one tensor row, so the rows are three independent pipelines (row r+1 is transformed while row r
+ * is on the wire).  Per row r = 0..2:
+ *   mrl_slab_gamma_row_fwd(r, A_fm, send)   z + x passes of fields 3r..3r+2           -> send  [p][3][x_p ][y_me][nzc]
+ *   [exchange]                                                                          -> recv  [p][3][x_me][y_p ][nzc]
+ *   mrl_slab_gamma_row_mid(recv, scale)     y pass, projection * scale, inverse y pass, IN PLACE (same chunked layout)
+ *   [exchange, inverse: send = that buffer]                                             -> recv2 [p][3][x_p ][y_me][nzc]
+ *   mrl_slab_gamma_row_inv(r, recv2, out_fm) inverse x + z passes, 1/N                -> fields 3r..3r+2 of out_fm
+ * mrl_slab_gamma_counts: complex elements per peer of one row's message (forward / inverse direction). */
+int mrl_slab_fast_path(const mrl_ctx *ctx); /* 1 if the fused slab kernels (CH pipeline fast path, mrl_slab_gamma_row_*) apply to this context */
+int mrl_slab_gamma_counts(const mrl_ctx *ctx, int forward, int64_t *h_send_counts, int64_t *h_recv_counts);
+int mrl_slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *d_A_fm, double *d_send);
+int mrl_slab_gamma_row_mid(mrl_ctx *ctx, double *d_recv_inout, double scale);
+int mrl_slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *d_recv, double *d_out_fm);
+/* mrl_mech_stress / mrl_mech_tangent_apply on field-major fields [9][npts] (3-D; K, mu are [npts]); npts must be even */
+int mrl_mech_stress_fm(mrl_ctx *ctx, const double *d_F_fm, const double *d_K, const double *d_mu, double *d_P_fm);
+int mrl_mech_tangent_apply_fm(mrl_ctx *ctx, const double *d_F_fm, const double *d_K, const double *d_mu, const double *d_dF_fm,
+                              double *d_out_fm);
 /* value-major [npts][ncomp] <-> field-major [ncomp][npts] */
 int mrl_relayout(mrl_ctx *ctx, int to_field_major, const double *d_in, double *d_out, int64_t npts, int32_t ncomp);
 /* out = a*x + b*y (out may alias x or y) */

@@ -82,6 +82,13 @@ SIGNATURES = {
     "mrl_ch_substep": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _vp, _pp, _i32, _dbl, _vp, _vp, _i32]),
     "mrl_kspace_abm": (_i32, [_vp, _vp, _vp, _pp, C.POINTER(_dbl), _i32, _vp, _dbl, _i64]),
     "mrl_kspace_coupled": (_i32, [_vp, _i32, _pp, _pp, _pp, C.POINTER(_dbl), C.POINTER(_i32), _pp, _dbl, _i32, _i64]),
+    "mrl_slab_fast_path": (_i32, [_vp]),
+    "mrl_slab_gamma_counts": (_i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "mrl_slab_gamma_row_fwd": (_i32, [_vp, _i32, _vp, _vp]),
+    "mrl_slab_gamma_row_mid": (_i32, [_vp, _vp, _dbl]),
+    "mrl_slab_gamma_row_inv": (_i32, [_vp, _i32, _vp, _vp]),
+    "mrl_mech_stress_fm": (_i32, [_vp, _vp, _vp, _vp, _vp]),
+    "mrl_mech_tangent_apply_fm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mrl_mech_displacements": (_i32, [_vp, _vp, _vp]),
     "mrl_mech_von_mises": (_i32, [_vp, _vp, _vp]),
     "mrl_secant_begin": (_i32, [_vp, _vp, _vp, _vp, _dbl, _dbl, _vp, _vp, C.POINTER(_dbl), _i64]),

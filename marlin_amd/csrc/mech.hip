@@ -560,6 +560,23 @@ int mrl_mech_tangent_apply(mrl_ctx *ctx, const double *d_F, const double *d_K, c
   return tangent_launch(ctx, d_F, d_K, d_mu, d_dF, false, d_out, false);
 }
 
+int mrl_mech_stress_fm(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu, double *d_P) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (ctx->dim != 3) return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_mech_stress_fm: 3-D only");
+  if (!d_F || !d_K || !d_mu || !d_P) return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_stress_fm: null buffer");
+  return stress_launch(ctx, d_F, d_K, d_mu, d_P, true);
+}
+
+int mrl_mech_tangent_apply_fm(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu, const double *d_dF,
+                              double *d_out) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (ctx->dim != 3) return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_mech_tangent_apply_fm: 3-D only");
+  if (real_count_local(ctx) % 2) return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_mech_tangent_apply_fm: odd number of local points");
+  if (!d_F || !d_K || !d_mu || !d_dF || !d_out)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_tangent_apply_fm: null buffer");
+  return tangent_launch(ctx, d_F, d_K, d_mu, d_dF, false, d_out, true);
+}
+
 int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d_F, const double *d_K,
                        const double *d_mu, const double *d_applied, double *d_Fnew, double *d_P,
                        mrl_mech_stats *stats) {

@@ -1,0 +1,268 @@
+// Fast path of the Gamma-operator application on a slab-decomposed grid (BASELINE configs[4]: de Geus mechanics over the
+// GPUs of a node): G(A) = ifftSlab( Ghat4 : fftSlab(A) ) (FFTMechanics.C:74-84,105-106 over DomainAction.C:869-1019) on
+// FIELD-MAJOR data [9][nx][nyl][nz], 3-D power-of-two extents, equal partitions.
+//
+// out_ij = q_j (sum_k A^_ik q_k)/|q|^2 couples only the three components of one tensor ROW i, so the three rows are
+// independent from the first z pass to the last one and form the natural pipeline: while row i is on the wire, row i+1 is
+// being transformed (full z lines per row, so -- unlike the kz sub-blocks of the Cahn-Hilliard pipeline -- the z passes
+// overlap with communication too).  Per row:
+//   fwd   k_z_fwd<PAIR> of the row's 3 fields, forward x pass written straight into the exchange layout
+//         [p][3 fields][x_p][y_me][nzc]                      (one message per peer and row, no pack kernel)
+//   -- all-to-all --
+//   mid   k_gamma_yfused: gathers lines along y from [p][3][x_me][y_p][nzc], forward y of the 3 components,
+//         s = (A_i0 kx + A_i1 ky + A_i2 kz)/|q|^2, out_ij = s q_j, inverse y, written back IN PLACE (the inverse
+//         exchange layout is the same chunked layout), Ghat4 (1296 B per k-point in the reference) is never formed
+//   -- all-to-all --
+//   inv   inverse x pass from [p][3][x_p][y_me][nzc] into the work arrays, k_z_inv<PAIR> * 1/N into the row's 3 output fields
+#include "fft_pow2_launch.h"
+
+namespace mrl {
+
+int slab_fast_ok(const mrl_ctx *ctx);
+
+namespace p2 {
+
+struct GammaYArgs {
+  cplx *buf;          // [p][3][nxl][nyl_p][nzc], projected in place
+  int nxl, nzc;
+  int nyl_shift;      // log2(ny / P)
+  unsigned chunk;     // nxl * nyl * nzc: elements of one field of one chunk
+  int tiles_per_x;
+  const double *kx, *ky, *kz;  // local reciprocal axes (kx already offset to this rank's x range)
+  double scale;
+};
+
+template <int N>
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_yfused(GammaYArgs a, const cplx *__restrict__ tw) {
+#pragma clang fp contract(off)
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T, NT = Plan<N>::NT, CNT = (N + NT - 1) / NT;
+  using Map = MapStrided<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  double *KY = reinterpret_cast<double *>(X + Map::size);
+  const int l = threadIdx.x % T, q = threadIdx.x / T;
+  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int ix = logical / a.tiles_per_x;
+  const int kl0 = (logical % a.tiles_per_x) * T + l;
+  const bool valid = kl0 < a.nzc;
+  const int kl = valid ? kl0 : 0;
+  cplx twv[CNT];
+  double kyv[CNT];
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const int idx = threadIdx.x + j * NT;
+    twv[j] = idx < N ? tw[idx] : make_double2(0.0, 0.0);
+    kyv[j] = idx < N ? a.ky[idx] : 0.0;
+  }
+  const double kx = a.kx[ix], kz = a.kz[kl];
+  // element (f, ix, j, kl): (j >> sh) * 3*chunk + f*chunk + ((ix << sh) + (j & msk)) * nzc + kl     [byte offsets]
+  const int sh = a.nyl_shift, msk = (1 << sh) - 1;
+  const unsigned chB = a.chunk * 16u, rowB = (unsigned)a.nzc * 16u, klB = (unsigned)kl * 16u;
+  auto off = [=](int m) {
+    const int j = q + m * TPL;
+    return (unsigned)(j >> sh) * (3u * chB) + (unsigned)((ix << sh) + (j & msk)) * rowB + klB;
+  };
+  auto ld = [=](unsigned f, int m) {
+    return *reinterpret_cast<const cplx *>(reinterpret_cast<const char *>(a.buf) + f * chB + off(m));
+  };
+  cplx v0[P], v1[P];
+#pragma unroll
+  for (int m = 0; m < P; ++m) v0[m] = ld(0u, m);
+#pragma unroll
+  for (int m = 0; m < P; ++m) v1[m] = ld(1u, m);
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const int idx = threadIdx.x + j * NT;
+    if (idx < N) {
+      W[idx] = twv[j];
+      KY[idx] = kyv[j];
+    }
+  }
+  // s = sum_k A_ik q_k with q = (kx, ky along the line, kz); same association as the serial kernel (k_gamma_xfused)
+  cplx s[P];
+  fft_line<N, Map>(v0, q, l, X, W);
+#pragma unroll
+  for (int m = 0; m < P; ++m) s[m] = make_double2(v0[m].x * kx, v0[m].y * kx);
+#pragma unroll
+  for (int m = 0; m < P; ++m) v0[m] = ld(2u, m);  // third component: in flight during the second transform
+  fft_line<N, Map>(v1, q, l, X, W);
+#pragma unroll
+  for (int m = 0; m < P; ++m) {
+    const double ky = KY[q + m * TPL];
+    s[m].x += v1[m].x * ky;
+    s[m].y += v1[m].y * ky;
+  }
+  fft_line<N, Map>(v0, q, l, X, W);
+#pragma unroll
+  for (int m = 0; m < P; ++m) {
+    const double ky = KY[q + m * TPL];
+    const double Q = kx * kx + (ky * ky + kz * kz);
+    const double inv = (Q == 0.0) ? 0.0 : a.scale / Q;
+    s[m].x = (s[m].x + v0[m].x * kz) * inv;
+    s[m].y = (s[m].y + v0[m].y * kz) * inv;
+  }
+  // out_ij = s q_j, inverse y (unnormalised; 1/N applied by the z pass); swap trick for the inverse
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      const double qj = (j == 0) ? kx : (j == 1 ? KY[q + m * TPL] : kz);
+      v0[m] = make_double2(s[m].y * qj, s[m].x * qj);
+    }
+    fft_line<N, Map>(v0, q, l, X, W);
+    if (valid) {
+#pragma unroll
+      for (int m = 0; m < P; ++m)
+        *reinterpret_cast<cplx *>(reinterpret_cast<char *>(a.buf) + (unsigned)j * chB + off(m)) = cswap(v0[m]);
+    }
+  }
+}
+
+template <int N>
+static int launch_gamma_yfused(mrl_ctx *ctx, GammaYArgs a) {
+  static bool attr = false;
+  constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
+  if (!attr) {
+    MRL_TRY(set_lds_attr(ctx, k_gamma_yfused<N>, lds));
+    attr = true;
+  }
+  constexpr int T = Plan<N>::T;
+  a.tiles_per_x = (a.nzc + T - 1) / T;
+  const long long nb = (long long)a.nxl * a.tiles_per_x;
+  hipLaunchKernelGGL((k_gamma_yfused<N>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[1].d_tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+}  // namespace p2
+
+static int ilog2(long long v) {
+  int s = 0;
+  while ((1LL << s) < v) ++s;
+  return s;
+}
+
+// work arrays: slot 4 = the three z/x-transformed fields of a row [3][nx][nyl][nzc] (one row at a time per direction:
+// slot 4 forward, slot 5 inverse, so that the forward stage of row i+1 can run while row i's inverse stage is pending)
+static int row_work(mrl_ctx *ctx, int slot, cplx **w) {
+  const size_t bytes = sizeof(cplx) * (size_t)(3 * ctx->n[0] * ctx->nloc[1] * ctx->nrec[2]);
+  MRL_TRY(ensure_work(ctx, slot, bytes));
+  *w = reinterpret_cast<cplx *>(ctx->d_work[slot]);
+  return MRL_OK;
+}
+
+static int check_fast(mrl_ctx *ctx, const char *what, int row) {
+  if (!slab_fast_ok(ctx))
+    return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: needs a 3-D slab context with planned extents and equal power-of-two partitions", what);
+  if (ctx->nloc[1] % 2) return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: needs an even number of local y planes", what);
+  if (row < 0 || row > 2) return set_error(ctx, MRL_ERR_INVALID, "%s: row %d out of range", what, row);
+  return MRL_OK;
+}
+
+}  // namespace mrl
+
+using namespace mrl;
+
+extern "C" {
+
+int mrl_slab_fast_path(const mrl_ctx *ctx) { return ctx && slab_fast_ok(ctx) && ctx->nloc[1] % 2 == 0 ? 1 : 0; }
+
+int mrl_slab_gamma_counts(const mrl_ctx *ctx, int forward, int64_t *h_send_counts, int64_t *h_recv_counts) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!ctx->slab || ctx->dim != 3) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_counts: needs a 3-D slab context");
+  const long long nzc = ctx->nrec[2];
+  for (int p = 0; p < ctx->nranks; ++p) {
+    const long long x_p_y_me = 3 * ctx->part_recip[p] * ctx->nloc[1] * nzc, x_me_y_p = 3 * ctx->nrec[0] * ctx->part_real[p] * nzc;
+    if (h_send_counts) h_send_counts[p] = forward ? x_p_y_me : x_me_y_p;
+    if (h_recv_counts) h_recv_counts[p] = forward ? x_me_y_p : x_p_y_me;
+  }
+  return MRL_OK;
+}
+
+int mrl_slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *d_A_fm, double *d_send) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_fast(ctx, "mrl_slab_gamma_row_fwd", row));
+  if (!d_A_fm || !d_send) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_fwd: null buffer");
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
+  const long long nreal = nx * nyl * nz, nspec = nx * nyl * nzc;
+  cplx *w;
+  MRL_TRY(row_work(ctx, 4, &w));
+  {
+    ProfScope ps(ctx, "slab_gamma_z_fwd", 3.0 * (8.0 * nreal + 16.0 * nspec));
+    p2::ChDev none{};
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, d_A_fm + 3 * row * nreal, w, nullptr, nullptr, none, 3 * nx * nyl / 2))));
+  }
+  const unsigned chunk = (unsigned)(nxl * nyl * nzc);
+  p2::SubPassArgs a{};
+  a.rows = (int)nyl;
+  a.cols = (int)nzc;
+  a.pitch_in = a.pitch_out = (unsigned)nzc;
+  a.sn_in = a.sn_out = (unsigned)(nyl * nzc);
+  a.sh_in = 31;
+  a.sh_out = ilog2(nxl);
+  a.cs_out = 3u * chunk;
+  ProfScope ps(ctx, "slab_gamma_x_fwd", 3.0 * 32.0 * nspec);
+  a.in[0] = w;
+  a.in[1] = w + nspec;
+  a.out[0] = reinterpret_cast<cplx *>(d_send);
+  a.out[1] = a.out[0] + chunk;
+  MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 2>(ctx, a, ctx->ax[0].d_tw))));
+  a.in[0] = w + 2 * nspec;
+  a.out[0] = reinterpret_cast<cplx *>(d_send) + 2 * chunk;
+  MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 1>(ctx, a, ctx->ax[0].d_tw))));
+  return MRL_OK;
+}
+
+int mrl_slab_gamma_row_mid(mrl_ctx *ctx, double *d_recv_inout, double scale) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_fast(ctx, "mrl_slab_gamma_row_mid", 0));
+  if (!d_recv_inout) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_mid: null buffer");
+  const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2], nyl = ny / ctx->nranks;
+  p2::GammaYArgs a{};
+  a.buf = reinterpret_cast<cplx *>(d_recv_inout);
+  a.nxl = (int)nxl;
+  a.nzc = (int)nzc;
+  a.nyl_shift = ilog2(nyl);
+  a.chunk = (unsigned)(nxl * nyl * nzc);
+  a.kx = ctx->d_k[0];
+  a.ky = ctx->d_k[1];
+  a.kz = ctx->d_k[2];
+  a.scale = scale;
+  ProfScope ps(ctx, "slab_gamma_y_fused", 3.0 * 32.0 * nxl * ny * nzc);
+  MRL_SWITCH_N(ny, MRL_TRY((p2::launch_gamma_yfused<NN>(ctx, a))));
+  return MRL_OK;
+}
+
+int mrl_slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *d_recv, double *d_out_fm) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_fast(ctx, "mrl_slab_gamma_row_inv", row));
+  if (!d_recv || !d_out_fm) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_inv: null buffer");
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
+  const long long nreal = nx * nyl * nz, nspec = nx * nyl * nzc;
+  cplx *w;
+  MRL_TRY(row_work(ctx, 5, &w));
+  const unsigned chunk = (unsigned)(nxl * nyl * nzc);
+  {
+    p2::SubPassArgs a{};
+    a.rows = (int)nyl;
+    a.cols = (int)nzc;
+    a.pitch_in = a.pitch_out = (unsigned)nzc;
+    a.sn_in = a.sn_out = (unsigned)(nyl * nzc);
+    a.sh_in = ilog2(nxl);
+    a.cs_in = 3u * chunk;
+    a.sh_out = 31;
+    ProfScope ps(ctx, "slab_gamma_x_inv", 3.0 * 32.0 * nspec);
+    for (int f = 0; f < 3; ++f) {
+      a.in[0] = reinterpret_cast<const cplx *>(d_recv) + (long long)f * chunk;
+      a.out[0] = w + (long long)f * nspec;
+      MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, true, 1>(ctx, a, ctx->ax[0].d_tw))));
+    }
+  }
+  ProfScope ps(ctx, "slab_gamma_z_inv", 3.0 * (16.0 * nspec + 8.0 * nreal));
+  const double scale = 1.0 / ((double)nx * (double)ctx->n[1] * (double)nz);
+  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w, d_out_fm + 3 * row * nreal, scale, 3 * nx * nyl / 2))));
+  return MRL_OK;
+}
+
+}  // extern "C"

@@ -375,7 +375,8 @@ class SlabMechanics:
     (its norms are serial-only, DomainAction.C:1564-1567)."""
 
     def __init__(self, dim, shape, L, nranks, rank, K_local, mu_local, comm=None, l_tol=1e-2, l_max_its=0, nl_rel_tol=1e-5,
-                 nl_abs_tol=1e-8, nl_max_its=100, stages=None):
+                 nl_abs_tol=1e-8, nl_max_its=100, stages=None, fast: Optional[bool] = None):
+        """fast=None: use the fused field-major row pipeline (mrl_slab_gamma_row_*) when the context supports it"""
         self.st = stages if stages is not None else HipSlabStages(dim, shape, L, nranks, rank)
         self.ctx = self.st.ctx
         self.lib = self.ctx.lib
@@ -402,6 +403,20 @@ class SlabMechanics:
         self.spec = e(2 * self.nspec * self.dd)          # field-major spectra
         self.l_tol, self.l_max_its = l_tol, (l_max_its or self.nglobal)
         self.nl_rel_tol, self.nl_abs_tol, self.nl_max_its = nl_rel_tol, nl_abs_tol, nl_max_its
+        can = dim == 3 and self.npts % 2 == 0 and bool(self.lib.mrl_slab_fast_path(self.ctx.h))
+        if fast and not can:
+            raise ValueError("the fused slab mechanics path needs a 3-D context with planned extents and equal power-of-two partitions")
+        self.fast = can if fast is None else bool(fast)
+        if self.fast:
+            # one message per tensor row and peer; the inverse exchange lands in the (by then free) send buffer of the row
+            n = self.ctx.nranks
+            sc, rc = (C.c_int64 * n)(), (C.c_int64 * n)()
+            self._chk(self.lib.mrl_slab_gamma_counts(self.ctx.h, 1, sc, rc))
+            gs, gr = list(sc), list(rc)
+            self.xg_fwd = self.comm.exchange(gs, gr)
+            self.xg_inv = self.comm.exchange(gr, gs)
+            self.g_send = [e(2 * sum(gs)) for _ in range(3)]
+            self.g_recv = [e(2 * sum(gr)) for _ in range(3)]
 
     # ---- thin wrappers over the C ABI (local work only)
     def _chk(self, rc):
@@ -425,15 +440,40 @@ class SlabMechanics:
         self._chk(self.lib.mrl_average(self.ctx.h, self._p(F), self.dd, out))
         return self.comm.allreduce(list(out))
 
+    # (fast path: every vector of the solve is field-major [D*D][npts]; otherwise value-major as in the reference)
     def stress(self, F, out):
-        self._chk(self.lib.mrl_mech_stress(self.ctx.h, self._p(F), self._p(self.K), self._p(self.mu), self._p(out)))
+        fn = self.lib.mrl_mech_stress_fm if self.fast else self.lib.mrl_mech_stress
+        self._chk(fn(self.ctx.h, self._p(F), self._p(self.K), self._p(self.mu), self._p(out)))
 
     def tangent(self, Flin, dF, out):
-        self._chk(self.lib.mrl_mech_tangent_apply(self.ctx.h, self._p(Flin), self._p(self.K), self._p(self.mu), self._p(dF),
-                                                  self._p(out)))
+        fn = self.lib.mrl_mech_tangent_apply_fm if self.fast else self.lib.mrl_mech_tangent_apply
+        self._chk(fn(self.ctx.h, self._p(Flin), self._p(self.K), self._p(self.mu), self._p(dF), self._p(out)))
+
+    def _relayout(self, to_fm: bool, src, dst):
+        self._chk(self.lib.mrl_relayout(self.ctx.h, 1 if to_fm else 0, self._p(src), self._p(dst), self.npts, self.dd))
+
+    def gamma_fast(self, A, out, scale=1.0):
+        """out = scale * G(A) on field-major fields: three tensor rows, each z+x passes -> all-to-all -> fused y pass with the
+        projection -> all-to-all -> inverse x+z passes; row r+1 is transformed while row r is on the wire"""
+        h = self.ctx.h
+        wf, wi = [], []
+        for r in range(3):
+            self._chk(self.lib.mrl_slab_gamma_row_fwd(h, r, self._p(A), self._p(self.g_send[r])))
+            wf.append(self.xg_fwd.run(self.g_send[r], self.g_recv[r], async_op=True))
+        for r in range(3):
+            if wf[r] is not None:
+                wf[r].wait()
+            self._chk(self.lib.mrl_slab_gamma_row_mid(h, self._p(self.g_recv[r]), scale))
+            wi.append(self.xg_inv.run(self.g_recv[r], self.g_send[r], async_op=True))
+        for r in range(3):
+            if wi[r] is not None:
+                wi[r].wait()
+            self._chk(self.lib.mrl_slab_gamma_row_inv(h, r, self._p(self.g_send[r]), self._p(out)))
 
     def gamma(self, A, out, scale=1.0):
         """out = scale * G(A): per component slab transform, field-major projection, inverse"""
+        if self.fast:
+            return self.gamma_fast(A, out, scale)
         self._chk(self.lib.mrl_relayout(self.ctx.h, 1, self._p(A), self._p(self.fm), self.npts, self.dd))
         for c in range(self.dd):
             self.st.fwd_local(self.fm[c * self.npts:(c + 1) * self.npts], self.send_f)
@@ -477,10 +517,17 @@ class SlabMechanics:
         e = self.st.empty
         n = self.npts * self.dd
         F = F.reshape(-1)
+        if self.fast:                               # the solve runs on field-major vectors; convert at this boundary only
+            Ffm = e(n)
+            self._relayout(True, F, Ffm)
+            F = Ffm
         u, P, b, x, tmp = F.clone(), e(n), e(n), torch.zeros(n, dtype=torch.float64, device=F.device), e(n)
         stats = {"newton_its": 0, "cg_its": []}
         if applied is not None:
-            app = applied.reshape(1, self.dd).expand(self.npts, self.dd).contiguous().reshape(-1)
+            if self.fast:
+                app = applied.reshape(self.dd, 1).expand(self.dd, self.npts).contiguous().reshape(-1)
+            else:
+                app = applied.reshape(1, self.dd).expand(self.npts, self.dd).contiguous().reshape(-1)
             self.tangent(F, app, tmp)               # K4 stays linearised at F for the first solve
             self.gamma(tmp, b, -1.0)
             self._axpby(1.0, u, 1.0, app, u)
@@ -503,4 +550,8 @@ class SlabMechanics:
             iiter += 1
             if iiter > self.nl_max_its:
                 raise RuntimeError("nl_max_its: Exceeded the maximum number of nonlinear iterations without converging.")
+        if self.fast:                               # back to the reference's value-major layout
+            self._relayout(False, u, tmp)
+            self._relayout(False, P, b)
+            u, P = tmp, b
         return u, P, stats

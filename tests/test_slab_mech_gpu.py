@@ -144,3 +144,100 @@ def test_slab_mechanics_2d_full_spectrum():
         t_old += p["dt"]
         got = torch.cat([o[2][step] for o in out], dim=1)
         assert (got - F.reshape(got.shape)).abs().max().item() <= 1e-10
+
+
+def _run_threads(P, target, *args):
+    hub = ThreadComm(P)
+    out, errors = [None] * P, []
+
+    def main(r):
+        try:
+            out[r] = target(r, P, hub.for_rank(r), *args)
+        except Exception as e:      # surface the failure in the main thread and release the others
+            errors.append(e)
+            hub.bar.abort()
+
+    threads = [threading.Thread(target=main, args=(r,)) for r in range(P)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert all(o is not None for o in out)
+    return out
+
+
+_FAST_SHAPE, _FAST_L = [64, 64, 64], [2.0 * math.pi, 3.0, 4.0]
+
+
+def _gamma_rank(r, P, comm, A, fast):
+    from marlin_amd.slab import HipSlabStages, SlabMechanics
+    st = HipSlabStages(3, _FAST_SHAPE, _FAST_L, P, r)
+    yb, nyl = st.real_begin[1], st.real_shape[1]
+    one = torch.ones(st.real_shape, dtype=torch.float64, device="cuda")
+    m = SlabMechanics(3, _FAST_SHAPE, _FAST_L, P, r, one, one, comm=comm, stages=st, fast=fast)
+    assert m.fast == fast
+    loc = A[:, yb:yb + nyl].contiguous().cuda().reshape(-1)
+    out = torch.empty_like(loc)
+    if fast:
+        fm, ofm = torch.empty_like(loc), torch.empty_like(loc)
+        m._relayout(True, loc, fm)
+        m.gamma(fm, ofm, -2.0)
+        m._relayout(False, ofm, out)
+    else:
+        m.gamma(loc, out, -2.0)
+    return yb, nyl, out.cpu().reshape(list(st.real_shape) + [3, 3])
+
+
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_slab_gamma_fused_rows(P):
+    """the fused row pipeline (z+x passes -> exchange -> y pass with the projection in place -> exchange -> x+z passes) ==
+    the oracle's closed-form Gamma operator on the global field == the per-component generic stages"""
+    from oracle import marlin_oracle as mo
+    torch.manual_seed(21)
+    A = torch.rand(_FAST_SHAPE + [3, 3], dtype=torch.float64) - 0.5
+    dom = mo.Domain(3, _FAST_SHAPE, _FAST_L)
+    want = -2.0 * mo.gamma_closed_form(dom, A)
+    fast = _run_threads(P, _gamma_rank, A, True)
+    got = torch.cat([o[2] for o in fast], dim=1)
+    assert (got - want).abs().max().item() <= 1e-13
+    if P == 2:
+        slow = _run_threads(P, _gamma_rank, A, False)
+        assert (torch.cat([o[2] for o in slow], dim=1) - got).abs().max().item() <= 1e-13
+
+
+def _newton_rank(r, P, comm, K, mu, applied):
+    from marlin_amd.slab import HipSlabStages, SlabMechanics
+    st = HipSlabStages(3, _FAST_SHAPE, _FAST_L, P, r)
+    yb, nyl = st.real_begin[1], st.real_shape[1]
+    m = SlabMechanics(3, _FAST_SHAPE, _FAST_L, P, r, K[:, yb:yb + nyl].contiguous().cuda(), mu[:, yb:yb + nyl].contiguous().cuda(),
+                      comm=comm, l_tol=1e-2, nl_rel_tol=2e-2, nl_abs_tol=2e-2, stages=st)
+    assert m.fast
+    F = torch.eye(3, dtype=torch.float64).expand(list(st.real_shape) + [3, 3]).contiguous().cuda().reshape(-1)
+    Fn, Pn, stats = m.newton_cg(F, applied.cuda())
+    return yb, nyl, Fn.cpu().reshape(list(st.real_shape) + [3, 3]), Pn.cpu().reshape(list(st.real_shape) + [3, 3]), stats
+
+
+def test_slab_mechanics_fused_vs_serial():
+    """one Newton-CG solve of the de Geus RVE at 64^3 on 4 loop-back ranks (fused field-major slab path) == the serial
+    fused solver of the same library: same Newton / CG iteration counts, F and P to 1e-10"""
+    from marlin_amd.api import Context
+    torch.manual_seed(2)
+    n = 64
+    phase = torch.zeros(_FAST_SHAPE, dtype=torch.float64)
+    s = 9 * n // 32
+    phase[-s:, :s, -s:] = 1.0                                # test/src/tensor_computes/PhaseMechanicsTest.C:36-45
+    K = 0.833 + phase * (8.33 - 0.833)
+    mu = 0.386 + phase * (3.86 - 0.386)
+    applied = torch.zeros(3, 3, dtype=torch.float64)
+    applied[0, 1] = 0.01
+    out = _run_threads(4, _newton_rank, K, mu, applied)
+    F = torch.cat([o[2] for o in out], dim=1)
+    P_ = torch.cat([o[3] for o in out], dim=1)
+    ctx = Context(3, _FAST_SHAPE, _FAST_L)
+    F0 = torch.eye(3, dtype=torch.float64).expand(_FAST_SHAPE + [3, 3]).contiguous().cuda()
+    Fs, Ps, st = ctx.mech_newton_cg(F0, K.cuda(), mu.cuda(), applied.cuda(), l_tol=1e-2, l_max_its=0, nl_rel_tol=2e-2, nl_abs_tol=2e-2)
+    assert len({(o[4]["newton_its"], tuple(o[4]["cg_its"])) for o in out}) == 1
+    assert out[0][4]["newton_its"] == st["newton_its"] and list(out[0][4]["cg_its"]) == list(st["cg_its"])
+    assert (F - Fs.cpu()).abs().max().item() <= 1e-10
+    assert (P_ - Ps.cpu()).abs().max().item() <= 1e-10
