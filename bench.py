@@ -133,7 +133,10 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--mech-grid", type=int, default=128, help="edge of the de Geus RVE side benchmark (config C); 0 = skip")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke runs)")
-    ap.add_argument("--nsub", type=int, default=4, help="kz sub-blocks the slab substep is pipelined over (N > 1)")
+    ap.add_argument("--nsub", type=int, default=2,
+                    help="kz sub-blocks the slab substep is pipelined over (N > 1).  2: the rank-local kernels of 512^3 / 8 take 0.56 ms "
+                         "per substep against 0.60 ms for 4 (smaller launches fill the chip worse), and every extra collective costs "
+                         "~22 us of launch gap on the exchange stream, which is the critical path (DESIGN.md section 4)")
     ap.add_argument("--compute-stream", default="high", choices=["high", "default"],
                     help="N > 1: run the local passes on a high-priority stream so that they do not share a hardware queue "
                          "with RCCL's stream (streams of equal priority are multiplexed onto a few queues and then serialise)")

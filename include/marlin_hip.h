@@ -255,7 +255,18 @@ int mrl_slab_fast_path(const mrl_ctx *ctx); /* 1 if the fused slab kernels (CH p
 int mrl_slab_gamma_counts(const mrl_ctx *ctx, int forward, int64_t *h_send_counts, int64_t *h_recv_counts);
 int mrl_slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *d_A_fm, double *d_send);
 int mrl_slab_gamma_row_mid(mrl_ctx *ctx, double *d_recv_inout, double scale);
-int mrl_slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *d_recv, double *d_out_fm);
+int mrl_slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *d_recv, double *d_out_fm,
+                           const double *d_dotv_fm /* optional [9][npts]: accumulate sum(out * dotv), rows in order 0,1,2 */);
+/* the local sum(out * dotv) over the three rows just inverted with d_dotv_fm (the p.Ap of the CG, taken while Ap is in
+ * registers); synchronises the stream */
+int mrl_slab_gamma_dot(mrl_ctx *ctx, double *h_local);
+/* CG vector kernels for callers that own the iteration (slab contexts all-reduce the scalars between the calls):
+ *   mrl_cg_update:           x += alpha p ; r -= alpha Ap ; *h_rr_local = sum r^2 over the local vector   (MarlinUtils.h:95-100)
+ *   mrl_mech_tangent_dir_fm: p <- r + beta p ; out = K_dF(p)   (MarlinUtils.h:112 fused with FFTMechanics.C:107-108; field-major) */
+int mrl_cg_update(mrl_ctx *ctx, double alpha, double *d_x, double *d_r, const double *d_p, const double *d_Ap, int64_t n,
+                  double *h_rr_local);
+int mrl_mech_tangent_dir_fm(mrl_ctx *ctx, const double *d_F_fm, const double *d_K, const double *d_mu, double *d_p_fm,
+                            const double *d_r_fm, double beta, double *d_out_fm);
 /* mrl_mech_stress / mrl_mech_tangent_apply on field-major fields [9][npts] (3-D; K, mu are [npts]); npts must be even */
 int mrl_mech_stress_fm(mrl_ctx *ctx, const double *d_F_fm, const double *d_K, const double *d_mu, double *d_P_fm);
 int mrl_mech_tangent_apply_fm(mrl_ctx *ctx, const double *d_F_fm, const double *d_K, const double *d_mu, const double *d_dF_fm,

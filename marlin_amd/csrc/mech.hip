@@ -577,6 +577,43 @@ int mrl_mech_tangent_apply_fm(mrl_ctx *ctx, const double *d_F, const double *d_K
   return tangent_launch(ctx, d_F, d_K, d_mu, d_dF, false, d_out, true);
 }
 
+// CG building blocks for callers that own the iteration (slab contexts: the scalars are all-reduced between the calls)
+static int put_scalars(mrl_ctx *ctx, double a, double b, double **S) {
+  *S = ctx->d_red + kScalarBase + 8;
+  const double hs[2] = {a, b};  // pageable source: staged by the runtime before the call returns
+  MRL_HIP(ctx, hipMemcpyAsync(*S, hs, sizeof(hs), hipMemcpyHostToDevice, ctx->stream));
+  return MRL_OK;
+}
+
+int mrl_cg_update(mrl_ctx *ctx, double alpha, double *d_x, double *d_r, const double *d_p, const double *d_Ap, int64_t n,
+                  double *h_rr_local) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!d_x || !d_r || !d_p || !d_Ap || !h_rr_local || n < 0) return set_error(ctx, MRL_ERR_INVALID, "mrl_cg_update: bad argument");
+  double *S;
+  MRL_TRY(put_scalars(ctx, alpha, 1.0, &S));  // the kernel forms alpha = S[0] / S[1]
+  int nb = (int)((n / 2 + 255) / 256);
+  nb = nb < 1 ? 1 : (nb > kRedBlocks ? kRedBlocks : nb);
+  {
+    ProfScope ps(ctx, "cg_update", 48.0 * (double)n);
+    hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, ctx->stream, S, 0, 1, d_x, d_r, d_p, d_Ap, (long long)n, ctx->d_red);
+    MRL_HIP(ctx, hipGetLastError());
+  }
+  double *slot = ctx->d_red + kScalarBase;
+  MRL_TRY(reduce_finalize(ctx, nb, 1, slot));
+  return read_scalars(ctx, slot, 1, h_rr_local);
+}
+
+int mrl_mech_tangent_dir_fm(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu, double *d_p,
+                            const double *d_r, double beta, double *d_out) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (ctx->dim != 3) return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_mech_tangent_dir_fm: 3-D only");
+  if (real_count_local(ctx) % 2) return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_mech_tangent_dir_fm: odd number of local points");
+  if (!d_F || !d_K || !d_mu || !d_p || !d_r || !d_out) return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_tangent_dir_fm: null buffer");
+  double *S;
+  MRL_TRY(put_scalars(ctx, beta, 1.0, &S));
+  return tangent_dir_launch(ctx, d_F, d_K, d_mu, d_p, d_r, S, 0, 1, d_out, true);
+}
+
 int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d_F, const double *d_K,
                        const double *d_mu, const double *d_applied, double *d_Fnew, double *d_P,
                        mrl_mech_stats *stats) {

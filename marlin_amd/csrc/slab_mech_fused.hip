@@ -19,6 +19,7 @@
 namespace mrl {
 
 int slab_fast_ok(const mrl_ctx *ctx);
+int reduce_finalize_from(mrl_ctx *ctx, const double *partial, int nb, double *d_scalar);
 
 namespace p2 {
 
@@ -234,7 +235,7 @@ int mrl_slab_gamma_row_mid(mrl_ctx *ctx, double *d_recv_inout, double scale) {
   return MRL_OK;
 }
 
-int mrl_slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *d_recv, double *d_out_fm) {
+int mrl_slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *d_recv, double *d_out_fm, const double *d_dotv_fm) {
   if (!ctx) return MRL_ERR_INVALID;
   MRL_TRY(check_fast(ctx, "mrl_slab_gamma_row_inv", row));
   if (!d_recv || !d_out_fm) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_inv: null buffer");
@@ -259,10 +260,33 @@ int mrl_slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *d_recv, double *
       MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, true, 1>(ctx, a, ctx->ax[0].d_tw))));
     }
   }
-  ProfScope ps(ctx, "slab_gamma_z_inv", 3.0 * (16.0 * nspec + 8.0 * nreal));
+  ProfScope ps(ctx, "slab_gamma_z_inv", 3.0 * (16.0 * nspec + 8.0 * nreal) + (d_dotv_fm ? 3.0 * 8.0 * nreal : 0.0));
   const double scale = 1.0 / ((double)nx * (double)ctx->n[1] * (double)nz);
-  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w, d_out_fm + 3 * row * nreal, scale, 3 * nx * nyl / 2))));
+  if (!d_dotv_fm) {
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w, d_out_fm + 3 * row * nreal, scale, 3 * nx * nyl / 2))));
+    return MRL_OK;
+  }
+  // sum(out * dotv) of this row while `out` is still in registers: one partial per workgroup, rows back to back
+  const long long max_blocks = 3 * nx * nyl / 2;  // >= the number of workgroups of one row for every plan
+  MRL_TRY(ensure_work(ctx, 3, sizeof(double) * (size_t)(3 * max_blocks)));
+  int nb = 0;
+  if (row > 0 && ctx->gamma_dot_nb == 0)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_inv: dot-product rows must start with row 0");
+  const long long at = row == 0 ? 0 : (long long)row * ctx->gamma_dot_nb;
+  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_dot<NN>(ctx, w, d_out_fm + 3 * row * nreal, scale, 3 * nx * nyl / 2,
+                                                       d_dotv_fm + 3 * row * nreal, ctx->d_work[3] + at, &nb))));
+  ctx->gamma_dot_nb = nb;
   return MRL_OK;
+}
+
+int mrl_slab_gamma_dot(mrl_ctx *ctx, double *h_local) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!h_local || ctx->gamma_dot_nb <= 0)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_dot: no dot-product rows pending");
+  double *slot = ctx->d_red + kScalarBase;
+  MRL_TRY(mrl::reduce_finalize_from(ctx, ctx->d_work[3], 3 * ctx->gamma_dot_nb, slot));
+  ctx->gamma_dot_nb = 0;
+  return read_scalars(ctx, slot, 1, h_local);
 }
 
 }  // extern "C"

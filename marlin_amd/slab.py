@@ -184,7 +184,7 @@ class SlabCahnHilliard:
     set_initial / invalidate_carry()."""
 
     def __init__(self, dim, shape, L, params, nranks, rank, predictor_order: int = 2, sub_dt: float = 1e-3,
-                 stages=None, exchange_factory: Optional[Callable] = None, nsub: int = 4, carry: bool = False):
+                 stages=None, exchange_factory: Optional[Callable] = None, nsub: int = 2, carry: bool = False):
         self.p = params
         self.carry = carry
         self._carry_valid = False
@@ -452,9 +452,10 @@ class SlabMechanics:
     def _relayout(self, to_fm: bool, src, dst):
         self._chk(self.lib.mrl_relayout(self.ctx.h, 1 if to_fm else 0, self._p(src), self._p(dst), self.npts, self.dd))
 
-    def gamma_fast(self, A, out, scale=1.0):
+    def gamma_fast(self, A, out, scale=1.0, dotv=None):
         """out = scale * G(A) on field-major fields: three tensor rows, each z+x passes -> all-to-all -> fused y pass with the
-        projection -> all-to-all -> inverse x+z passes; row r+1 is transformed while row r is on the wire"""
+        projection -> all-to-all -> inverse x+z passes; row r+1 is transformed while row r is on the wire.
+        dotv: also return the all-reduced sum(out * dotv), accumulated by the last z pass (the p.Ap of the CG)"""
         h = self.ctx.h
         wf, wi = [], []
         for r in range(3):
@@ -468,7 +469,13 @@ class SlabMechanics:
         for r in range(3):
             if wi[r] is not None:
                 wi[r].wait()
-            self._chk(self.lib.mrl_slab_gamma_row_inv(h, r, self._p(self.g_send[r]), self._p(out)))
+            self._chk(self.lib.mrl_slab_gamma_row_inv(h, r, self._p(self.g_send[r]), self._p(out),
+                                                      self._p(dotv) if dotv is not None else None))
+        if dotv is not None:
+            loc = C.c_double()
+            self._chk(self.lib.mrl_slab_gamma_dot(h, C.byref(loc)))
+            return self.comm.allreduce([loc.value])[0]
+        return None
 
     def gamma(self, A, out, scale=1.0):
         """out = scale * G(A): per component slab transform, field-major projection, inverse"""
@@ -486,8 +493,39 @@ class SlabMechanics:
             self.st.inv_finish(self.recv_i, self.fm[c * self.npts:(c + 1) * self.npts])
         self._chk(self.lib.mrl_relayout(self.ctx.h, 0, self._p(self.fm), self._p(out), self.npts, self.dd))
 
+    def _cg_fast(self, Flin, b, x):
+        """the same iteration with the vector work fused into three kernels per iteration: p <- r + beta p inside the tangent
+        kernel, p.Ap inside the last z pass of the Gamma pipeline, x / r updates and r.r in one pass"""
+        e = self.st.empty
+        n = b.numel()
+        b_norm = self._norm(b)
+        if b_norm == 0.0:
+            return 0
+        tmp, Ap, r, p = e(n), e(n), e(n), e(n)
+        self.tangent(Flin, x, tmp)
+        self.gamma(tmp, Ap)
+        self._axpby(1.0, b, -1.0, Ap, r)            # r = b - A x
+        p.copy_(r)
+        rz_old = self._dot(r, r)
+        beta = 0.0
+        rr = C.c_double()
+        for k in range(self.l_max_its):
+            self._chk(self.lib.mrl_mech_tangent_dir_fm(self.ctx.h, self._p(Flin), self._p(self.K), self._p(self.mu), self._p(p),
+                                                       self._p(r), beta, self._p(tmp)))       # p = r + beta p ; tmp = K_dF(p)
+            pAp = self.gamma_fast(tmp, Ap, 1.0, dotv=p)
+            alpha = rz_old / pAp
+            self._chk(self.lib.mrl_cg_update(self.ctx.h, alpha, self._p(x), self._p(r), self._p(p), self._p(Ap), n, C.byref(rr)))
+            rz_new = self.comm.allreduce([rr.value])[0]
+            if rz_new ** 0.5 <= self.l_tol * b_norm:
+                return k + 1
+            beta = rz_new / rz_old
+            rz_old = rz_new
+        return self.l_max_its
+
     # ---- MooseTensor::conjugateGradientSolve with A = G o K_dF
     def _cg(self, Flin, b, x):
+        if self.fast:
+            return self._cg_fast(Flin, b, x)
         e = self.st.empty
         n = b.numel()
         b_norm = self._norm(b)
