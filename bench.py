@@ -278,7 +278,7 @@ def main():
                 "workload": f"3D Cahn-Hilliard {shape[0]}x{shape[1]}x{shape[2]} fp64 semi-implicit spectral step, AB2, "
                             f"f=0.1c^2(c-1)^2, M=0.2, kappa=-0.001, sub_dt=1e-3",
                 "grid": shape,
-                "decomposition": "none" if not slab else f"slab x{world} (RCCL all-to-all, {args.nsub} kz sub-blocks in flight)",
+                "decomposition": "none" if not slab else f"slab x{world} ({'RCCL' if args.backend == 'nccl' else args.backend} all-to-all, {args.nsub} kz sub-blocks in flight)",
                 "spectral_carry_over": bool(args.carry == "on" or (slab and args.carry == "auto")),
             },
             "substep_algorithmic_bytes_per_update": bpu,
