@@ -187,6 +187,26 @@ int mrl_secant_iterate(mrl_ctx *ctx, const double *d_u, const double *d_N, const
                        const double *d_u_prev, double *d_R_prev, double sub_dt, double damping, double *d_u_new,
                        double *h_sumsq, int64_t n_spec);
 
+/* BroydenSolver::substep (src/tensor_solver/BroydenSolver.C:63-176) for nvar <= 8 coupled variables: per reciprocal grid point
+ * a Broyden iteration on R(u) = (N + L u) sub_dt + u_old - u with a persistent complex nvar x nvar approximation M of the inverse
+ * Jacobian.  The caller keeps the reference's control flow (compute group, inverse transforms, convergence tests); per iteration:
+ *   mrl_broyden_predict: S = -M R ; u_out_i = u_i + step * S_i                    (:124-133; the reference hard-wires step = 0.5)
+ *   [u_i = ifft(u_out_i); compute group]
+ *   mrl_broyden_update : Rnew = (N + L u) sub_dt + u_old - u ; y = Rnew - R ; d = S^T y ;
+ *                        M += where(|d| > 1e-12, (S - M y) S^T / d, 0) ; R <- Rnew ; h_sumsq = sum |Rnew|^2      (:139-166)
+ * mrl_broyden_residual fills R before the first iteration (d_u_old = NULL: (N + L u) sub_dt, :99) and mrl_broyden_init sets
+ * M = factor * I (:57-63; M persists over substeps).  Arrays owned by the caller, field-major: d_M [nvar*nvar][n_spec],
+ * d_R / d_S [nvar][n_spec] complex.  No regression test of the reference exercises this solver: parity is against the
+ * oracle's restatement only. */
+int mrl_broyden_init(mrl_ctx *ctx, int nvar, double factor, double *d_M, int64_t n_spec);
+int mrl_broyden_residual(mrl_ctx *ctx, int nvar, const double *const *d_u, const double *const *d_N, const double *const *d_L,
+                         const double *const *d_u_old, double sub_dt, double *d_R, double *h_sumsq, int64_t n_spec);
+int mrl_broyden_predict(mrl_ctx *ctx, int nvar, const double *d_M, const double *d_R, const double *const *d_u, double step,
+                        double *d_S, double *const *d_u_out, int64_t n_spec);
+int mrl_broyden_update(mrl_ctx *ctx, int nvar, double *d_M, double *d_R, const double *d_S, const double *const *d_u,
+                       const double *const *d_N, const double *const *d_L, const double *const *d_u_old, double sub_dt,
+                       double *h_sumsq, int64_t n_spec);
+
 /* Slab (multi-GPU) CH substep (AdamsBashforthMoulton::substep over DomainAction::fftSlab/ifftSlab), split at its
  * exchanges and pipelined over `nsub` sub-blocks of the kz axis: after the z pass every kz plane is an independent
  * 2-D problem, so the caller can put sub-block s on the wire while sub-block s+1 is being transformed.

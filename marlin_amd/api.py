@@ -228,6 +228,38 @@ class Context:
                                                 damping, _ptr(u_new), ss, u.numel()))
         return u_new, math.sqrt(ss[0]), math.sqrt(ss[1])
 
+    # ---- BroydenSolver building blocks (field-major state arrays owned by the caller)
+    @staticmethod
+    def _pp(ts):
+        return (C.c_void_p * max(1, len(ts)))(*[(t.data_ptr() if t is not None else None) for t in ts])
+
+    def broyden_init(self, nvar: int, factor: float, nspec: int) -> torch.Tensor:
+        M = torch.empty(nvar * nvar, nspec, dtype=torch.complex128, device=self.device)
+        self._check(self.lib.mrl_broyden_init(self.h, nvar, factor, _ptr(M), nspec))
+        return M
+
+    def broyden_residual(self, u, N, L, u_old, sub_dt: float):
+        nv, n = len(u), u[0].numel()
+        R = torch.empty(nv, n, dtype=torch.complex128, device=self.device)
+        ss = (C.c_double * 1)()
+        self._check(self.lib.mrl_broyden_residual(self.h, nv, self._pp(u), self._pp(N), self._pp(L),
+                                                  self._pp(u_old) if u_old is not None else None, sub_dt, _ptr(R), ss, n))
+        return R, math.sqrt(ss[0])
+
+    def broyden_predict(self, M, R, u, step: float = 0.5):
+        nv, n = len(u), u[0].numel()
+        S = torch.empty(nv, n, dtype=torch.complex128, device=self.device)
+        out = [torch.empty_like(t) for t in u]
+        self._check(self.lib.mrl_broyden_predict(self.h, nv, _ptr(M), _ptr(R), self._pp(u), step, _ptr(S), self._pp(out), n))
+        return S, out
+
+    def broyden_update(self, M, R, S, u, N, L, u_old, sub_dt: float) -> float:
+        nv, n = len(u), u[0].numel()
+        ss = (C.c_double * 1)()
+        self._check(self.lib.mrl_broyden_update(self.h, nv, _ptr(M), _ptr(R), _ptr(S), self._pp(u), self._pp(N), self._pp(L),
+                                                self._pp(u_old), sub_dt, ss, n))
+        return math.sqrt(ss[0])
+
     # ---- de Geus mechanics (value-major [grid..., D, D] fields)
     def gamma_apply(self, A: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:

@@ -146,3 +146,206 @@ int mrl_secant_iterate(mrl_ctx *ctx, const double *d_u, const double *d_N, const
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// BroydenSolver::substep (src/tensor_solver/BroydenSolver.C:63-176): a "good Broyden" iteration per reciprocal grid point
+// on the stacked residual R(u) = (N + L u) dt + u_old - u of nvar coupled variables, with a persistent nvar x nvar complex
+// approximation M of the inverse Jacobian per k-point.  The reference stacks u, N, L into [grid, nvar] tensors and runs ~25
+// batched matmul / where / norm kernels per iteration; here an iteration is two kernels around the compute group:
+//   predict: s = -M R ; u_out_i = u_i + step * s_i
+//   update : Rnew = (N + L u) dt + u_old - u ; y = Rnew - R ; d = s^T y (no conjugation, as torch::matmul) ;
+//            M += where(|d| > 1e-12, (s - M y) s^T / d, 0) ; R <- Rnew ; sum |Rnew|^2
+// M, R, s are field-major ([nvar*nvar][n], [nvar][n] complex) so that every access is coalesced.
+namespace mrl {
+
+constexpr int kBroydenMax = 8;
+struct BroydenPtrs {
+  const double2 *u[kBroydenMax], *N[kBroydenMax], *uold[kBroydenMax];
+  const double *L[kBroydenMax];
+  double2 *uout[kBroydenMax];
+};
+
+__global__ void __launch_bounds__(256) k_broyden_init(int nv, double factor, double2 *__restrict__ M, long long n) {
+  const long long total = (long long)nv * nv * n;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int ij = (int)(e / n);
+    M[e] = make_double2((ij / nv == ij % nv) ? factor : 0.0, 0.0);
+  }
+}
+
+// initial residual (uold == nullptr: (N + L u) dt, BroydenSolver.C:99) or the full one
+__global__ void __launch_bounds__(256) k_broyden_residual(int nv, BroydenPtrs p, int with_old, double dt, double2 *__restrict__ R,
+                                                           long long n, double *__restrict__ partial) {
+#pragma clang fp contract(off)
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    for (int i = 0; i < nv; ++i) {
+      const double2 u = p.u[i][e], Nn = p.N[i][e];
+      const double l = p.L[i] ? p.L[i][e] : 0.0;
+      double2 r = make_double2((Nn.x + l * u.x) * dt, (Nn.y + l * u.y) * dt);
+      if (with_old) {
+        const double2 uo = p.uold[i][e];
+        r = make_double2(r.x + uo.x - u.x, r.y + uo.y - u.y);
+      }
+      R[(long long)i * n + e] = r;
+      acc += r.x * r.x + r.y * r.y;
+    }
+  }
+  const double s = block_sum256(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_broyden_predict(int nv, BroydenPtrs p, const double2 *__restrict__ M,
+                                                          const double2 *__restrict__ R, double2 *__restrict__ S, double step,
+                                                          long long n) {
+#pragma clang fp contract(off)
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    double2 r[kBroydenMax];
+    for (int j = 0; j < nv; ++j) r[j] = R[(long long)j * n + e];
+    for (int i = 0; i < nv; ++i) {
+      double2 s = make_double2(0.0, 0.0);
+      for (int j = 0; j < nv; ++j) {
+        const double2 m = cmul(M[(long long)(i * nv + j) * n + e], r[j]);
+        s.x += m.x;
+        s.y += m.y;
+      }
+      s = make_double2(-s.x, -s.y);
+      S[(long long)i * n + e] = s;
+      const double2 u = p.u[i][e];
+      p.uout[i][e] = make_double2(u.x + s.x * step, u.y + s.y * step);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_broyden_update(int nv, BroydenPtrs p, double2 *__restrict__ M, double2 *__restrict__ R,
+                                                         const double2 *__restrict__ S, double dt, long long n,
+                                                         double *__restrict__ partial) {
+#pragma clang fp contract(off)
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    double2 y[kBroydenMax], s[kBroydenMax];
+    double2 d = make_double2(0.0, 0.0);
+    for (int i = 0; i < nv; ++i) {
+      const double2 u = p.u[i][e], Nn = p.N[i][e], uo = p.uold[i][e];
+      const double l = p.L[i] ? p.L[i][e] : 0.0;
+      double2 rn = make_double2((Nn.x + l * u.x) * dt, (Nn.y + l * u.y) * dt);
+      rn = make_double2(rn.x + uo.x - u.x, rn.y + uo.y - u.y);
+      const double2 ro = R[(long long)i * n + e];
+      y[i] = make_double2(rn.x - ro.x, rn.y - ro.y);
+      R[(long long)i * n + e] = rn;
+      acc += rn.x * rn.x + rn.y * rn.y;
+      s[i] = S[(long long)i * n + e];
+      const double2 sy = cmul(s[i], y[i]);
+      d.x += sy.x;
+      d.y += sy.y;
+    }
+    if (hypot(d.x, d.y) > 1e-12) {  // torch::abs(denom) > 1e-12 (BroydenSolver.C:158)
+      for (int i = 0; i < nv; ++i) {
+        double2 my = make_double2(0.0, 0.0);
+        for (int j = 0; j < nv; ++j) {
+          const double2 t = cmul(M[(long long)(i * nv + j) * n + e], y[j]);
+          my.x += t.x;
+          my.y += t.y;
+        }
+        const double2 c = make_double2(s[i].x - my.x, s[i].y - my.y);
+        for (int j = 0; j < nv; ++j) {
+          const double2 upd = cdiv(cmul(c, s[j]), d);
+          double2 *m = M + (long long)(i * nv + j) * n + e;
+          *m = make_double2(m->x + upd.x, m->y + upd.y);
+        }
+      }
+    }
+  }
+  const double sR = block_sum256(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = sR;
+}
+
+static int broyden_ptrs(mrl_ctx *ctx, int nv, const double *const *u, const double *const *N, const double *const *L,
+                        const double *const *uold, double *const *uout, BroydenPtrs &p) {
+  if (nv < 1 || nv > kBroydenMax) return set_error(ctx, MRL_ERR_INVALID, "Broyden: 1 <= nvar <= %d", kBroydenMax);
+  for (int i = 0; i < nv; ++i) {
+    if ((u && !u[i]) || (N && !N[i]) || (uold && !uold[i]) || (uout && !uout[i]))
+      return set_error(ctx, MRL_ERR_INVALID, "Broyden: null buffer for variable %d", i);
+    p.u[i] = u ? reinterpret_cast<const double2 *>(u[i]) : nullptr;
+    p.N[i] = N ? reinterpret_cast<const double2 *>(N[i]) : nullptr;
+    p.uold[i] = uold ? reinterpret_cast<const double2 *>(uold[i]) : nullptr;
+    p.L[i] = L ? L[i] : nullptr;
+    p.uout[i] = uout ? reinterpret_cast<double2 *>(uout[i]) : nullptr;
+  }
+  return MRL_OK;
+}
+
+}  // namespace mrl
+
+extern "C" {
+
+int mrl_broyden_init(mrl_ctx *ctx, int nvar, double factor, double *d_M, int64_t n_spec) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (nvar < 1 || nvar > kBroydenMax || !d_M || n_spec < 0) return set_error(ctx, MRL_ERR_INVALID, "mrl_broyden_init: bad argument");
+  if (n_spec == 0) return MRL_OK;
+  hipLaunchKernelGGL(k_broyden_init, dim3(blocks_for((long long)nvar * nvar * n_spec)), dim3(256), 0, ctx->stream, nvar, factor,
+                     reinterpret_cast<double2 *>(d_M), (long long)n_spec);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+int mrl_broyden_residual(mrl_ctx *ctx, int nvar, const double *const *d_u, const double *const *d_N, const double *const *d_L,
+                         const double *const *d_u_old, double sub_dt, double *d_R, double *h_sumsq, int64_t n_spec) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!d_u || !d_N || !d_R || !h_sumsq || n_spec < 0) return set_error(ctx, MRL_ERR_INVALID, "mrl_broyden_residual: bad argument");
+  BroydenPtrs p{};
+  MRL_TRY(broyden_ptrs(ctx, nvar, d_u, d_N, d_L, d_u_old, nullptr, p));
+  h_sumsq[0] = 0.0;
+  if (n_spec == 0) return MRL_OK;
+  const int nb = blocks_for(n_spec);
+  double *slot = ctx->d_red + kScalarBase;
+  {
+    ProfScope ps(ctx, "broyden_residual");
+    hipLaunchKernelGGL(k_broyden_residual, dim3(nb), dim3(256), 0, ctx->stream, nvar, p, d_u_old ? 1 : 0, sub_dt,
+                       reinterpret_cast<double2 *>(d_R), (long long)n_spec, ctx->d_red);
+    MRL_HIP(ctx, hipGetLastError());
+  }
+  MRL_TRY(reduce_finalize(ctx, nb, 1, slot));
+  return read_scalars(ctx, slot, 1, h_sumsq);
+}
+
+int mrl_broyden_predict(mrl_ctx *ctx, int nvar, const double *d_M, const double *d_R, const double *const *d_u, double step,
+                        double *d_S, double *const *d_u_out, int64_t n_spec) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!d_M || !d_R || !d_u || !d_S || !d_u_out || n_spec < 0) return set_error(ctx, MRL_ERR_INVALID, "mrl_broyden_predict: bad argument");
+  BroydenPtrs p{};
+  MRL_TRY(broyden_ptrs(ctx, nvar, d_u, nullptr, nullptr, nullptr, d_u_out, p));
+  if (n_spec == 0) return MRL_OK;
+  ProfScope ps(ctx, "broyden_predict");
+  hipLaunchKernelGGL(k_broyden_predict, dim3(blocks_for(n_spec)), dim3(256), 0, ctx->stream, nvar, p,
+                     reinterpret_cast<const double2 *>(d_M), reinterpret_cast<const double2 *>(d_R), reinterpret_cast<double2 *>(d_S),
+                     step, (long long)n_spec);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+int mrl_broyden_update(mrl_ctx *ctx, int nvar, double *d_M, double *d_R, const double *d_S, const double *const *d_u,
+                       const double *const *d_N, const double *const *d_L, const double *const *d_u_old, double sub_dt,
+                       double *h_sumsq, int64_t n_spec) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!d_M || !d_R || !d_S || !d_u || !d_N || !d_u_old || !h_sumsq || n_spec < 0)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_broyden_update: bad argument");
+  BroydenPtrs p{};
+  MRL_TRY(broyden_ptrs(ctx, nvar, d_u, d_N, d_L, d_u_old, nullptr, p));
+  h_sumsq[0] = 0.0;
+  if (n_spec == 0) return MRL_OK;
+  const int nb = blocks_for(n_spec);
+  double *slot = ctx->d_red + kScalarBase;
+  {
+    ProfScope ps(ctx, "broyden_update");
+    hipLaunchKernelGGL(k_broyden_update, dim3(nb), dim3(256), 0, ctx->stream, nvar, p, reinterpret_cast<double2 *>(d_M),
+                       reinterpret_cast<double2 *>(d_R), reinterpret_cast<const double2 *>(d_S), sub_dt, (long long)n_spec, ctx->d_red);
+    MRL_HIP(ctx, hipGetLastError());
+  }
+  MRL_TRY(reduce_finalize(ctx, nb, 1, slot));
+  return read_scalars(ctx, slot, 1, h_sumsq);
+}
+
+}  // extern "C"

@@ -1120,6 +1120,97 @@ protected:
   const Params _p;
 };
 
+
+/// BroydenSolver (src/tensor_solver/BroydenSolver.C:34-176): the reference's control flow, two fused kernels per iteration
+class BroydenSolver : public SplitOperatorABM, public IterativeTensorSolverInterface
+{
+public:
+  struct Params
+  {
+    unsigned int substeps = 1, max_iterations = 5;
+    double relative_tolerance = 1e-9, absolute_tolerance = 1e-9, initial_jacobian_guess = 1.0;
+    bool verbose = false;
+  };
+  BroydenSolver(TensorProblem & problem, const std::string & name, std::shared_ptr<TensorOperatorBase> root_compute,
+                const std::vector<VariableNames> & vars, const Params & p)
+    : SplitOperatorABM(problem, name, p.substeps, std::move(root_compute), vars, 1, 1, 0), _p(p)
+  {
+    const int n = (int)_variables.size();
+    if (n > 8)
+      paramError("buffer", "at most 8 coupled variables");
+    const int64_t ns = _domain.getReciprocalSize();
+    _M = DeviceTensor::empty((std::size_t)(2 * n * n * ns));   // persists over substeps (:57-63)
+    _domain.check(mrl_broyden_init(_domain.ctx(), n, _p.initial_jacobian_guess, _M.data(), ns));
+  }
+
+protected:
+  void gather(std::vector<const double *> & u, std::vector<const double *> & N, std::vector<const double *> & L)
+  {
+    u.clear();
+    N.clear();
+    L.clear();
+    for (auto & v : _variables)
+    {
+      u.push_back(v._reciprocal_buffer.data());
+      N.push_back(v._nonlinear_reciprocal.data());
+      L.push_back(v._linear_reciprocal ? v._linear_reciprocal->data() : nullptr);
+    }
+  }
+  void substep() override
+  {
+    const int n = (int)_variables.size();
+    const int64_t ns = _domain.getReciprocalSize();
+    _compute->computeBuffer();
+    forwardBuffers();
+    std::vector<DeviceTensor> keep;                           // u_old handles (:71-77)
+    std::vector<const double *> u, N, L, u_old;
+    for (auto & v : _variables)
+    {
+      keep.push_back(v._reciprocal_buffer);
+      u_old.push_back(keep.back().data());
+    }
+    gather(u, N, L);
+    auto R = DeviceTensor::empty((std::size_t)(2 * n * ns)), S = DeviceTensor::empty((std::size_t)(2 * n * ns));
+    double ss = 0.0;
+    _domain.check(mrl_broyden_residual(_domain.ctx(), n, u.data(), N.data(), L.data(), nullptr, _sub_dt, R.data(), &ss, ns));
+    const double R0norm = std::sqrt(ss);
+    double Rnorm = R0norm;
+    for (_iterations = 0; _iterations < _p.max_iterations; ++_iterations)
+    {
+      if (std::isnan(Rnorm))
+        mooseError("NAN!");
+      if (Rnorm < _p.absolute_tolerance || Rnorm / R0norm < _p.relative_tolerance)
+      {
+        _is_converged = true;
+        return;
+      }
+      if (_p.verbose)
+        std::printf("%u |R|=%g\n", _iterations, Rnorm);
+      std::vector<DeviceTensor> out;
+      std::vector<double *> outp;
+      for (int i = 0; i < n; ++i)
+      {
+        out.push_back(DeviceTensor::empty((std::size_t)(2 * ns)));
+        outp.push_back(out.back().data());
+      }
+      _domain.check(mrl_broyden_predict(_domain.ctx(), n, _M.data(), R.data(), u.data(), 0.5, S.data(), outp.data(), ns));
+      for (int i = 0; i < n; ++i)
+        _variables[i]._buffer = _domain.ifft(out[i]);
+      _compute->computeBuffer();
+      forwardBuffers();
+      gather(u, N, L);
+      _domain.check(mrl_broyden_update(_domain.ctx(), n, _M.data(), R.data(), S.data(), u.data(), N.data(), L.data(), u_old.data(),
+                                       _sub_dt, &ss, ns));
+      Rnorm = std::sqrt(ss);
+    }
+    std::fprintf(stderr, "Broyden solve did not converge within the maximum number of iterations.\n");
+    _is_converged = false;
+  }
+
+  const Params _p;
+  DeviceTensor _M;
+};
+
 /// TensorSolveIterationAdaptiveDT (src/timesteppers/TensorSolveIterationAdaptiveDT.C:66-88,162-175) + Transient's dtmax
 class TensorSolveIterationAdaptiveDT
 {
