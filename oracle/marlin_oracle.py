@@ -17,8 +17,13 @@ compiled here (every TU needs MOOSE/libMesh headers and `moose/` is an empty sub
 Pinning (see tests/test_oracle_golden.py, runs with -m "not gpu"):
   * cahnhilliard.h5 gold  (reference test/tests/cahnhilliard/tests:46-57, abs_tol 1e-13)
   * cahnhilliard.rank0001.h5 gold (2-rank FFT_SLAB, tests:58-70)
-  * mech3d.h5 / mech.h5 gold (test/tests/mechanics/tests:2-21, abs_tol 1e-10)
-  * backandforth / gradient CSV gold, ConjugateGradientTest iteration counts.
+  * mech3d.h5 / mech.h5 gold (test/tests/mechanics/tests:2-21, abs_tol 1e-10): F_*, disp_* (ComputeDisplacements), sV
+  * test/tests/solvers/gold/*.csv: diagonal_* (ABM orders 1-4, AM corrector), coupled_* (AdamsBashforthMoultonCoupled),
+    nl_coupled_*, etdrk4_diffusion_rmse
+  * rotating_grain_secant.h5 (SecantSolver + SwiftHohenbergLinear + iteration-adaptive dt, abs_tol 1e-10)
+  * typed_tensors/gradient.h5 (GradientTensor), backandforth / gradient(_square) CSV gold, ConjugateGradientTest iteration counts.
+NOT pinned (parity unpinned): class BroydenSolver -- the reference ships no regression test, golden vector or fixture for
+it; it restates src/tensor_solver/BroydenSolver.C line by line and is only compared with the HIP kernels.
 
 All file:line citations are relative to /root/reference.
 """
