@@ -233,3 +233,42 @@ def test_rccl_exchange_single_rank():
         assert torch.equal(send, recv)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("carry,nsub", [(False, 4), (True, 2), (True, 3)])
+def test_slab_pipeline_over_rccl_single_rank(carry, nsub):
+    """the production driver end to end on the GPU box's single device: SlabCahnHilliard.substep() with its asynchronous
+    RCCL all_to_all_single exchanges (a one-rank communicator, MRL_FLAG_SLAB context), the local passes on a high-priority
+    stream as bench.py runs them -- against the serial fused substep of the same library"""
+    import os
+    import torch.distributed as dist
+    from marlin_amd.api import Context, ch_params
+    from marlin_amd.slab import SlabCahnHilliard
+    from tests.test_slab_gloo import _free_port
+    shape, L = [64, 64, 64], [3.0, 2.0, 2.5]
+    torch.manual_seed(8)
+    c0 = (torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44).cuda()
+    p = ch_params()
+    ctx = Context(3, shape, L)
+    want, Nh = [c0.clone(), torch.empty_like(c0)], [ctx.empty_spec(), ctx.empty_spec()]
+    for k in range(6):
+        ctx.ch_substep(p, want[k % 2], want[1 - k % 2], Nh[k % 2], [Nh[1 - k % 2]] if k else [], 1 if k else 0, 1e-3)
+    want = want[0].clone()
+    torch.cuda.synchronize()        # the reference ran on the default stream; the pipeline below runs on another one
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    prev = torch.cuda.current_stream()
+    try:
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
+        s = SlabCahnHilliard(3, shape, L, p, 1, 0, nsub=nsub, carry=carry)
+        assert s.x_fwd[0].mode == "a2a"
+        s.set_local(c0)
+        for _ in range(6):
+            s.substep()
+        torch.cuda.synchronize()
+        assert s.last_order == 1 and s.mode == (2 if carry else 0)
+        assert (s.current() - want).abs().max().item() <= 1e-13
+    finally:
+        torch.cuda.set_stream(prev)
+        dist.destroy_process_group()
