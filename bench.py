@@ -206,6 +206,14 @@ def main():
         def barrier():
             pass
 
+    def total_mass():
+        m = (solver.current() if slab else c[state["i"]]).sum(dtype=torch.float64).reshape(1)
+        if slab:
+            m = m if args.backend == "nccl" else m.cpu()
+            dist.all_reduce(m)
+        return float(m.item())
+
+    mass0 = total_mass()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -223,9 +231,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # sanity: the field must still be a bounded concentration field
+    # sanity: the field must still be a bounded concentration field, and the scheme conserves mass exactly (the k = 0 mode has
+    # Mbar = Lbar = 0), on every rank count -- a wrong exchange or a missed stream dependency shows up here
     cur = solver.current() if slab else c[state["i"]]
     assert torch.isfinite(cur).all() and 0.0 < float(cur.min()) and float(cur.max()) < 1.0
+    mass1 = total_mass()
+    assert abs(mass1 - mass0) <= 1e-11 * abs(mass0), (mass0, mass1)
 
     # per-kernel device time with HIP events on the launch stream (event pair per launch)
     prof_ctx = solver.ctx if slab else ctx
