@@ -35,24 +35,29 @@ struct Plan;
     static constexpr int TPL = N_ / P_, NT = T_ * (N_ / P_);                              \
     static_assert(R0 * R1 * R2 * R3 == N_ && N_ % P_ == 0 && NT <= 256, "bad plan");      \
   };
+MRL_PLAN(32, 16, 16, 2, 1, 1, 128)
 MRL_PLAN(64, 16, 8, 8, 1, 1, 64)
 MRL_PLAN(128, 16, 16, 8, 1, 1, 32)
 MRL_PLAN(256, 16, 16, 16, 1, 1, 16)
 MRL_PLAN(512, 16, 8, 8, 8, 1, 8)
 MRL_PLAN(1024, 16, 16, 8, 8, 1, 4)
 // sizes 2^a 5^b (the reference's own examples run 100^3 and 200^3 grids): radix 10 / 5 / 2, 10 points per thread
+MRL_PLAN(40, 10, 10, 2, 2, 1, 64)
 MRL_PLAN(50, 10, 10, 5, 1, 1, 51)
+MRL_PLAN(80, 10, 10, 2, 2, 2, 32)
 MRL_PLAN(100, 10, 10, 10, 1, 1, 25)
 MRL_PLAN(200, 10, 10, 10, 2, 1, 12)
 MRL_PLAN(250, 10, 10, 5, 5, 1, 10)
 MRL_PLAN(400, 10, 10, 10, 2, 2, 6)
 MRL_PLAN(500, 10, 10, 10, 5, 1, 5)
+MRL_PLAN(1000, 10, 10, 10, 10, 1, 2)
 // sizes 2^a 3^b: radix 12 / 4 / 2, 12 points per thread
 MRL_PLAN(48, 12, 12, 4, 1, 1, 64)
 MRL_PLAN(96, 12, 12, 4, 2, 1, 32)
 MRL_PLAN(144, 12, 12, 12, 1, 1, 21)
 MRL_PLAN(192, 12, 12, 4, 4, 1, 16)
 MRL_PLAN(384, 12, 12, 4, 4, 2, 8)
+MRL_PLAN(768, 12, 12, 4, 4, 4, 4)
 #undef MRL_PLAN
 
 __device__ __forceinline__ void bfly4(cplx &a0, cplx &a1, cplx &a2, cplx &a3) {

@@ -114,12 +114,28 @@ inline int launch_pass_sub(mrl_ctx *ctx, const SubPassArgs &a, const cplx *tw) {
     case 96: { constexpr int NN = 96; CALL; } break;   \
     case 192: { constexpr int NN = 192; CALL; } break; \
     case 384: { constexpr int NN = 384; CALL; } break; \
+    case 32: { constexpr int NN = 32; CALL; } break;   \
+    case 40: { constexpr int NN = 40; CALL; } break;   \
+    case 50: { constexpr int NN = 50; CALL; } break;   \
+    case 80: { constexpr int NN = 80; CALL; } break;   \
+    case 250: { constexpr int NN = 250; CALL; } break; \
+    case 500: { constexpr int NN = 500; CALL; } break; \
+    case 1000: { constexpr int NN = 1000; CALL; } break; \
+    case 48: { constexpr int NN = 48; CALL; } break;   \
+    case 144: { constexpr int NN = 144; CALL; } break; \
+    case 768: { constexpr int NN = 768; CALL; } break; \
     default: return MRL_ERR_UNSUPPORTED;               \
   }
 
 inline bool pow2_ok(long long n) {
-  return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024 || n == 100 || n == 200 || n == 400 || n == 96 || n == 192 ||
-         n == 384;
+  switch (n) {
+    case 32: case 64: case 128: case 256: case 512: case 1024:            // 2^a
+    case 40: case 50: case 80: case 100: case 200: case 250: case 400: case 500: case 1000:  // 2^a 5^b
+    case 48: case 96: case 144: case 192: case 384: case 768:             // 2^a 3^b
+      return true;
+    default:
+      return false;
+  }
 }
 inline bool is_pow2(long long n) { return n > 0 && (n & (n - 1)) == 0; }
 

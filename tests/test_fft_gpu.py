@@ -12,6 +12,8 @@ SHAPES = [
     (5, 7, 9), (6, 8, 4), (5, 6, 7), (16, 16, 16), (12, 20, 30), (32, 64, 128), (40, 40, 40),
     (100, 100, 100), (200, 100, 64), (64, 200, 100), (100, 64, 400),     # register-radix path, radix 10 / 5 / 2 plans
     (96, 96, 96), (192, 64, 100), (64, 96, 384), (192, 96),               # radix 12 / 4 / 2 plans
+    (50, 50, 50), (250, 48, 40), (500, 32, 80), (144, 768, 48), (80, 40, 32), (1000, 32), (48, 144), (32, 1000, 40),
+    (768, 50, 250),                                                        # the remaining planned lengths
 ]
 
 

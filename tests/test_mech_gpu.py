@@ -161,9 +161,10 @@ def test_mech_fast_path_vs_oracle():
         F, Fd = F_ref, Fnew
 
 
-def test_gamma_apply_radix10_sizes():
-    """100^3 (register-radix path with the radix 10 plans) against the closed form evaluated with libTorch"""
-    shape, L = (100, 100, 100), (1.0, 2.0, 3.0)
+@pytest.mark.parametrize("shape", [(100, 100, 100), (40, 48, 50), (80, 32, 144)])
+def test_gamma_apply_radix10_sizes(shape):
+    """register-radix path with the radix 10 / 12 plans against the closed form evaluated with libTorch"""
+    L = (1.0, 2.0, 3.0)
     dom = mo.Domain(3, list(shape), list(L))
     torch.manual_seed(6)
     A = torch.rand(dom.value_shape([3, 3]), dtype=torch.float64)
