@@ -11,6 +11,8 @@
 //        (test/tests/solvers/coupled.i: AdamsBashforthMoultonCoupled; nl_coupled.i: reciprocal-space ParsedComputes)
 //   marlin-hip-run problem=rotating_grain_secant dim=2 nx=40 ny=40 xmax=12pi ymax=<..> ic=psi0.bin num_steps=10 out=dir
 //        (test/tests/tensor_compute/rotating_grain_secant.i: SecantSolver + SwiftHohenbergLinear + iteration-adaptive dt)
+//   marlin-hip-run problem=cahnhilliard_explicit dim=2 nx=50 ny=50 xmax=3 ymax=3 ic=c0.bin method=SHARP substeps=50 num_steps=20 dt=0.5
+//        (test/tests/cahnhilliard/cahnhilliard_explicit_smooth.i: ForwardEulerSolver + DeAliasingTensor + reciprocal ParsedCompute)
 //   marlin-hip-run problem=mechanics dim=3 nx=16 ny=16 nz=16 substeps=10 num_steps=3 dt=0.01 l_tol=1e-2 nl_rel_tol=2e-2
 //        nl_abs_tol=2e-2 out=dir          (test/tests/mechanics/mech3d.i)
 #include <cstdio>
@@ -345,6 +347,54 @@ static int run_postprocessors(DomainAction & domain, const std::string & out)
   return 0;
 }
 
+// test/tests/cahnhilliard/cahnhilliard_explicit_smooth.i: explicit Euler Cahn-Hilliard, the k-space right-hand side filtered by a
+// DeAliasingTensor (method=SHARP|HOULI; method=NONE = cahnhilliard_explicit.i); ic= holds the seed-0 RandomTensor field
+static int run_cahnhilliard_explicit(DomainAction & domain, const std::string & out)
+{
+  TensorProblem problem(domain);
+  const std::size_t n = domain.getNumberOfCells();
+  problem.getBuffer("c") = DeviceTensor::fromHost(read_bin(arg("ic"), n));
+  problem.getBuffer("mu") = DeviceTensor::zeros(n);                                      // ConstantTensor
+  problem.getBuffer("dc_dt_bar") = DeviceTensor::zeros(2 * domain.getReciprocalSize());  // ConstantReciprocalTensor
+  ReciprocalLaplacianFactor(problem, "Mbar", "Mbar", argd("mobility", 0.2)).computeBuffer();
+  ReciprocalLaplacianFactor(problem, "Mkappabarbar", "Mkappabarbar", argd("Mkappa", 0.2 * 1e-4), 2).computeBuffer();
+  const std::string method = arg("method", "NONE");
+  if (method != "NONE")
+    DeAliasingTensor(problem, "smooth", "smooth", method, argd("p", 16.0), argd("alpha", 36.0)).computeBuffer();
+  auto root = std::make_shared<ComputeGroup>(problem, "cahn_hilliard");
+  ParsedCompute::Params pm;
+  pm.buffer = "mu";
+  pm.expression = arg("expression", "0.1*c^2*(c-1)^2");
+  pm.inputs = {"c"};
+  pm.derivatives = {"c"};
+  root->add(std::make_shared<ParsedCompute>(problem, "mu", pm));
+  root->add(std::make_shared<ForwardFFT>(problem, "mubar", "mubar", "mu"));
+  root->add(std::make_shared<ForwardFFT>(problem, "cbar", "cbar", "c"));
+  ParsedCompute::Params pd;
+  pd.buffer = "dc_dt_bar";
+  pd.reciprocal = true;
+  pd.complex_inputs = {"mubar", "cbar"};
+  if (method != "NONE")
+  {
+    pd.expression = "smooth * (Mbar*mubar - Mkappabarbar*cbar)";
+    pd.inputs = {"Mbar", "mubar", "Mkappabarbar", "cbar", "smooth"};
+  }
+  else
+  {
+    pd.expression = "Mbar*mubar - Mkappabarbar*cbar";
+    pd.inputs = {"Mbar", "mubar", "Mkappabarbar", "cbar"};
+  }
+  root->add(std::make_shared<ParsedCompute>(problem, "dc_dt_bar", pd));
+  ForwardEulerSolver solver(problem, "solver", (unsigned int)argi("substeps", 50), root, {{"c", "cbar", "dc_dt_bar"}});
+  Transient ex(problem, solver, argd("dt", 0.5));
+  dump(out, "c", 0, problem.getBuffer("c"));
+  ex.execute((int)argi("num_steps", 20), [&](int step) {
+    dump(out, "c", step, problem.getBuffer("c"));
+    dump(out, "mu", step, problem.getBuffer("mu"));
+  });
+  return 0;
+}
+
 // test/tests/solvers/etdrk4_diffusion.i: 1-D diffusion with ETDRK4 and a zero nonlinear term
 static int run_etdrk4_diffusion(DomainAction & domain, const std::string & out)
 {
@@ -476,6 +526,8 @@ int main(int argc, char ** argv)
       return run_rotating_grain_secant(domain, out);
     if (problem == "postprocessors")
       return run_postprocessors(domain, out);
+    if (problem == "cahnhilliard_explicit")
+      return run_cahnhilliard_explicit(domain, out);
     if (problem == "etdrk4_diffusion")
       return run_etdrk4_diffusion(domain, out);
     if (problem == "gradient" || problem == "gradient_square")

@@ -171,6 +171,14 @@ public:
       a[i] = (i < _n[d] / 2) ? lo + step * (double)i : hi - step * (double)(_n[d] - 1 - i);
     return a;
   }
+  /// reciprocal axis d (2 pi fftfreq / rfftfreq, DomainAction.C:259-303) as the library holds it
+  std::vector<double> getReciprocalAxis(int d) const
+  {
+    const int64_t n = (d == _dim - 1) ? _n[d] / 2 + 1 : _n[d];
+    std::vector<double> k((std::size_t)n);
+    check(mrl_ctx_reciprocal_axis(_ctx, d, k.data(), n));
+    return k;
+  }
   void check(int rc) const
   {
     if (rc != MRL_OK)
@@ -1021,6 +1029,53 @@ public:
       paramError("buffer", mrl_last_error(_domain.ctx()));
   }
   ~SwiftHohenbergLinear() { mrl_parsed_destroy(_parsed); }
+  void computeBuffer() override
+  {
+    auto out = DeviceTensor::empty(_domain.getReciprocalSize());
+    _domain.check(mrl_parsed_eval(_parsed, nullptr, out.data(), _domain.getReciprocalSize(), _time));
+    _u = out;
+  }
+
+private:
+  DeviceTensor & _u;
+  mrl_parsed * _parsed = nullptr;
+};
+
+
+/// DeAliasingTensor (src/tensor_computes/DeAliasingTensor.C:37-65) as one generated kernel on the reciprocal grid
+class DeAliasingTensor : public TensorOperatorBase
+{
+public:
+  DeAliasingTensor(TensorProblem & problem, const std::string & name, const std::string & buffer, const std::string & method,
+                   double p = 16.0, double alpha = 36.0)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer))
+  {
+    double mx[3] = {0.0, 0.0, 0.0};  // maximum |k| per axis; absent axes are {0}
+    for (int d = 0; d < _domain.getDim(); ++d)
+      for (double k : _domain.getReciprocalAxis(d))
+        mx[d] = std::max(mx[d], std::fabs(k));
+    std::string expr;
+    std::vector<const char *> cn;
+    std::vector<double> cv;
+    if (method == "SHARP")
+    {
+      expr = "if((abs(kx) > cx) | (abs(ky) > cy) | (abs(kz) > cz), 0, 1)";
+      cn = {"cx", "cy", "cz"};
+      cv = {2 * mx[0] / 3, 2 * mx[1] / 3, 2 * mx[2] / 3};
+    }
+    else if (method == "HOULI")
+    {
+      expr = "exp(0-alpha*((abs(kx)/mx)^p + (abs(ky)/my)^p + (abs(kz)/mz)^p))";
+      cn = {"alpha", "p", "mx", "my", "mz"};
+      cv = {alpha, p, mx[0] ? mx[0] : 1.0, mx[1] ? mx[1] : 1.0, mx[2] ? mx[2] : 1.0};
+    }
+    else
+      paramError("method", "SHARP or HOULI");
+    if (mrl_parsed_create(_domain.ctx(), &_parsed, expr.c_str(), 0, nullptr, nullptr, (int)cn.size(), cn.data(), cv.data(), 0, nullptr,
+                          1, 1) != MRL_OK)
+      paramError("method", mrl_last_error(_domain.ctx()));
+  }
+  ~DeAliasingTensor() { mrl_parsed_destroy(_parsed); }
   void computeBuffer() override
   {
     auto out = DeviceTensor::empty(_domain.getReciprocalSize());

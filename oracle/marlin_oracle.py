@@ -20,6 +20,7 @@ Pinning (see tests/test_oracle_golden.py, runs with -m "not gpu"):
   * mech3d.h5 / mech.h5 gold (test/tests/mechanics/tests:2-21, abs_tol 1e-10): F_*, disp_* (ComputeDisplacements), sV
   * test/tests/solvers/gold/*.csv: diagonal_* (ABM orders 1-4, AM corrector), coupled_* (AdamsBashforthMoultonCoupled),
     nl_coupled_*, etdrk4_diffusion_rmse
+  * cahnhilliard/gold/sharp.e, houli.e (Exodus: explicit Euler Cahn-Hilliard with DeAliasingTensor SHARP / HOULI, 1000 substeps)
   * rotating_grain_secant.h5 (SecantSolver + SwiftHohenbergLinear + iteration-adaptive dt, abs_tol 1e-10)
   * typed_tensors/gradient.h5 (GradientTensor), backandforth / gradient(_square) CSV gold, ConjugateGradientTest iteration counts.
 NOT pinned (parity unpinned): class BroydenSolver -- the reference ships no regression test, golden vector or fixture for
@@ -755,6 +756,30 @@ class ETDRK4:
         for _ in range(self.substeps):
             self.substep(sub_dt)
             self.sub_time += sub_dt
+
+
+def dealiasing_tensor(dom: Domain, method: str, p: float = 16.0, alpha: float = 36.0) -> torch.Tensor:
+    """DeAliasingTensor::computeBuffer (src/tensor_computes/DeAliasingTensor.C:37-65): SHARP 2/3-rule mask or the Hou-Li
+    exponential filter on the reciprocal axes (unused axes are the 1-element tensor {0}: they never cut and add exp(0))."""
+    ax = [dom.kaxis[d] if d < dom.dim else torch.zeros(1, dtype=F64) for d in range(3)]
+    mx = [torch.max(torch.abs(a)).item() for a in ax]
+    if method == "SHARP":
+        return torch.where((torch.abs(ax[0]) > 2 * mx[0] / 3) | (torch.abs(ax[1]) > 2 * mx[1] / 3) | (torch.abs(ax[2]) > 2 * mx[2] / 3),
+                           0.0, 1.0).reshape(dom.rshape)
+    px = torch.pow(torch.abs(ax[0]) / (mx[0] if mx[0] else 1.0), p)
+    py = torch.pow(torch.abs(ax[1]) / (mx[1] if mx[1] else 1.0), p)
+    pz = torch.pow(torch.abs(ax[2]) / (mx[2] if mx[2] else 1.0), p)
+    return torch.exp(-alpha * (px + py + pz)).reshape(dom.rshape)
+
+
+def explicit_cahn_hilliard_substep(dom: Domain, c, Mbar, Mkappabarbar, smooth, sub_dt, A: float = 0.1):
+    """one ForwardEulerSolver::substep (src/tensor_solver/ForwardEulerSolver.C:27-38) of test/tests/cahnhilliard/
+    cahnhilliard_explicit_smooth.i: mu = f'(c); dc_dt_bar = smooth * (Mbar*mubar - Mkappabarbar*cbar); c = ifft(cbar + sub_dt *
+    dc_dt_bar).  -> (c_new, mu)"""
+    mu = mu_double_well(c, A)
+    mubar, cbar = dom.fft(mu), dom.fft(c)
+    dc_dt_bar = smooth * (Mbar * mubar - Mkappabarbar * cbar)
+    return dom.ifft(cbar + sub_dt * dc_dt_bar), mu
 
 
 # --------------------------------------------------------------------------------------

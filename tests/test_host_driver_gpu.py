@@ -165,3 +165,19 @@ def test_postprocessors_case(tmp_path):
     assert got[:, 6].tolist() == [0, 10, 20]                                                  # count.csv
     assert np.allclose(got[:, 7], [0.0, 4.8, 9.6], rtol=0, atol=1e-11)
 
+
+@pytest.mark.parametrize("method", ["SHARP", "HOULI"])
+def test_cahnhilliard_explicit_smooth_case(method, tmp_path):
+    """test/tests/cahnhilliard/tests:121-143 (cahnhilliard_explicit_smooth.i, Exodiff: rel 5.5e-6): explicit Euler (1000 substeps)
+    with the DeAliasingTensor filter; nodal c and elemental mu of sharp.e / houli.e mapped back onto the 50 x 50 grid"""
+    g = load_golden(f"cahnhilliard_explicit_{method.lower()}_gold.npz")
+    ic = tmp_path / "c0.bin"
+    g["c.0"].astype("<f8").tofile(ic)
+    _run(["problem=cahnhilliard_explicit", "dim=2", "nx=50", "ny=50", "xmax=3", "ymax=3", f"ic={ic}", f"method={method}",
+          "substeps=50", "num_steps=20", "dt=0.5"], tmp_path)
+    for k in (1, 2, 5, 10, 20):
+        c = np.fromfile(tmp_path / f"c.{k}.bin", dtype="<f8").reshape(50, 50)
+        mu = np.fromfile(tmp_path / f"mu.{k}.bin", dtype="<f8").reshape(50, 50)
+        assert np.abs(g[f"c.{k}"] - c).max() <= 1e-9
+        assert np.abs(g[f"mu.{k}"] - mu).max() <= 1e-10
+

@@ -307,3 +307,23 @@ def test_gradient_tensor_gold():
     for d, nm in enumerate("xyz"):
         assert np.abs(_node_mode(dom.ifft(ibar * dom.kaxis[d])) - g[f"grad_c_{nm}.1"]).max() <= 1e-12
 
+
+@pytest.mark.parametrize("method", ["SHARP", "HOULI"])
+def test_explicit_ch_dealiasing_gold(method):
+    """test/tests/cahnhilliard/tests:121-143 (cahnhilliard_explicit_smooth.i, Exodiff): ForwardEulerSolver with 50 substeps per
+    step, DeAliasingTensor filter on the k-space right-hand side; nodal c and elemental mu of sharp.e / houli.e"""
+    g = load_golden(f"cahnhilliard_explicit_{method.lower()}_gold.npz")
+    dom = mo.Domain(2, [50, 50], [3.0, 3.0])
+    Mbar = mo.reciprocal_laplacian_factor(dom, 0.2)
+    Mk = mo.reciprocal_laplacian_square_factor(dom, 0.2 * 1e-4)
+    smooth = mo.dealiasing_tensor(dom, method)
+    torch.manual_seed(0)
+    c = torch.rand(50, 50, dtype=torch.float64) * (0.56 - 0.44) + 0.44          # RandomTensor seed 0
+    assert np.array_equal(c.numpy(), g["c.0"])
+    for step in range(1, 21):
+        for _ in range(50):
+            c, mu = mo.explicit_cahn_hilliard_substep(dom, c, Mbar, Mk, smooth, 0.5 / 50)
+        if f"c.{step}" in g:
+            assert np.abs(g[f"c.{step}"] - c.numpy()).max() <= 1e-10
+            assert np.abs(g[f"mu.{step}"] - mu.numpy()).max() <= 1e-11
+
