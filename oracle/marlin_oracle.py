@@ -17,6 +17,7 @@ compiled here (every TU needs MOOSE/libMesh headers and `moose/` is an empty sub
 Pinning (see tests/test_oracle_golden.py, runs with -m "not gpu"):
   * cahnhilliard.h5 gold  (reference test/tests/cahnhilliard/tests:46-57, abs_tol 1e-13)
   * cahnhilliard.rank0001.h5 gold (2-rank FFT_SLAB, tests:58-70)
+  * map_to_aux_3d.e (Exodus; cahnhilliard.i in 3-D, 5^3: nodal c, elemental mu; tests:13-22)
   * mech3d.h5 / mech.h5 gold (test/tests/mechanics/tests:2-21, abs_tol 1e-10): F_*, disp_* (ComputeDisplacements), sV
   * test/tests/solvers/gold/*.csv: diagonal_* (ABM orders 1-4, AM corrector), coupled_* (AdamsBashforthMoultonCoupled),
     nl_coupled_*, etdrk4_diffusion_rmse

@@ -11,6 +11,7 @@ Sources (relative to /root/reference):
   test/tests/cahnhilliard/gold/cahnhilliard.rank0001.h5  spec test/tests/cahnhilliard/tests:58-70  (2-rank FFT_SLAB, rank 1)
   test/tests/mechanics/gold/mech3d.h5, mech.h5           spec test/tests/mechanics/tests:2-21      (abs_tol 1e-10)
   test/tests/tensor_compute/gold/rotating_grain_secant.h5 spec test/tests/tensor_compute/tests:90-100 (abs_tol 1e-10)
+  test/tests/cahnhilliard/gold/map_to_aux_3d.e            spec test/tests/cahnhilliard/tests:13-22 (3-D 5^3 Cahn-Hilliard; Exodus)
   test/tests/cahnhilliard/gold/sharp.e, houli.e           spec test/tests/cahnhilliard/tests:121-143 (explicit Euler + DeAliasingTensor; Exodus)
   test/tests/typed_tensors/gold/gradient.h5               spec test/tests/typed_tensors/tests (GradientTensor, 20x10x5, NODE mode)
   test/tests/solvers/gold/*.csv                          spec test/tests/solvers/tests
@@ -60,26 +61,27 @@ def convert_h5(rel, out_name):
     print(f"{out_name}: {len(data)} datasets from {rel}")
 
 
-def convert_exodus(rel, out_name, n, length, frames):
-    """nodal / elemental variables of a MOOSE Exodus file (netCDF classic, read with scipy) back onto the n x n tensor grid:
-    ProjectTensorAux (src/auxkernels/ProjectTensorAux.C:36-71) puts cell (i, j) on node (i, j) (periodic wrap at i = n) and on
-    element (i, j)"""
+def convert_exodus(rel, out_name, n, length, frames, dim=2):
+    """nodal / elemental variables of a MOOSE Exodus file (netCDF classic, read with scipy) back onto the n^dim tensor grid:
+    ProjectTensorAux (src/auxkernels/ProjectTensorAux.C:36-71) puts cell (i, j[, k]) on node (i, j[, k]) (periodic wrap at
+    i = n) and on element (i, j[, k])"""
     from scipy.io import netcdf_file
     f = netcdf_file(os.path.join(REF, rel), "r", mmap=False)
-    x, y = f.variables["coordx"][:], f.variables["coordy"][:]
+    xyz = [f.variables["coord" + a][:] for a in "xyz"[:dim]]
     dx = length / n
-    i, j = np.rint(x / dx).astype(int), np.rint(y / dx).astype(int)
+    ni = tuple(np.rint(a / dx).astype(int) for a in xyz)
     conn = f.variables["connect1"][:] - 1
-    ei, ej = np.floor(x[conn].mean(1) / dx).astype(int), np.floor(y[conn].mean(1) / dx).astype(int)
+    ei = tuple(np.floor(a[conn].mean(1) / dx).astype(int) for a in xyz)
     nod, el = f.variables["vals_nod_var1"][:], f.variables["vals_elem_var1eb1"][:]
     data = {"time": np.array(f.variables["time_whole"][:])[list(frames)]}
+    inner = (slice(0, n),) * dim
     for k in frames:
-        c = np.zeros((n + 1, n + 1))
-        c[i, j] = nod[k]
-        m = np.zeros((n, n))
-        m[ei, ej] = el[k]
-        assert np.array_equal(c[n, :n], c[0, :n]) and np.array_equal(c[:n, n], c[:n, 0])
-        data[f"c.{k}"], data[f"mu.{k}"] = c[:n, :n].copy(), m
+        c = np.zeros((n + 1,) * dim)
+        c[ni] = nod[k]
+        m = np.zeros((n,) * dim)
+        m[ei] = el[k]
+        assert np.array_equal(c[(n,) + inner[1:]], c[(0,) + inner[1:]])
+        data[f"c.{k}"], data[f"mu.{k}"] = c[inner].copy(), m
     np.savez_compressed(os.path.join(OUT, out_name), **data)
     print(f"{out_name}: frames {list(frames)} of {rel}")
 
@@ -105,6 +107,8 @@ def main():
     convert_h5("test/tests/mechanics/gold/mech.h5", "mech2d_gold.npz")
     convert_h5("test/tests/tensor_compute/gold/rotating_grain_secant.h5", "rotating_grain_secant_gold.npz")
     convert_h5("test/tests/typed_tensors/gold/gradient.h5", "typed_gradient_gold.npz")
+    # cahnhilliard.i with Domain/dim=3 nx=ny=nz=5 zmax=3 (tests:13-22): the only 3-D Cahn-Hilliard gold data of the reference
+    convert_exodus("test/tests/cahnhilliard/gold/map_to_aux_3d.e", "cahnhilliard_3d_gold.npz", 5, 3.0, range(11), dim=3)
     for m in ("sharp", "houli"):      # cahnhilliard_explicit_smooth.i with DeAliasingTensor method = SHARP / HOULI (Exodiff)
         convert_exodus(f"test/tests/cahnhilliard/gold/{m}.e", f"cahnhilliard_explicit_{m}_gold.npz", 50, 3.0, (0, 1, 2, 5, 10, 20))
     sol = sorted(

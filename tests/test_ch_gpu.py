@@ -63,6 +63,17 @@ def test_ch_gold_file(carry):
     assert np.abs(g["mu.10"] - mu.numpy()).max() <= 1e-13
 
 
+def test_ch_gold_file_3d():
+    """test/tests/cahnhilliard/tests:13-22 (Domain/dim=3 nx=ny=nz=5): nodal c / elemental mu of map_to_aux_3d.e, abs 1e-13"""
+    from marlin_amd.api import Context, ch_params
+    g = load_golden("cahnhilliard_3d_gold.npz")
+    ctx = Context(3, [5, 5, 5], [3.0, 3.0, 3.0])
+    states, mu = _run_hip_ch(ctx, ch_params(), torch.from_numpy(g["c.0"].copy()), 10, 10, 1e-3, want_mu=True)
+    worst = max(np.abs(g[f"c.{k + 1}"] - states[k].numpy()).max() for k in range(10))
+    assert worst <= 1e-13, worst
+    assert np.abs(g["mu.10"] - mu.numpy()).max() <= 1e-13
+
+
 @pytest.mark.parametrize("shape", [(16, 16, 16), (12, 10, 9), (32, 32, 32), (24,), (64, 64, 64), (100, 100, 100),
                                    (200, 64, 100), (128, 128), (200, 100), (64, 400), (96, 192, 64), (384, 96),
                                    (40, 40, 40), (50, 80, 32), (48, 144, 250), (500, 32), (1000, 48), (768, 40, 32)])

@@ -181,3 +181,17 @@ def test_cahnhilliard_explicit_smooth_case(method, tmp_path):
         assert np.abs(g[f"c.{k}"] - c).max() <= 1e-9
         assert np.abs(g[f"mu.{k}"] - mu).max() <= 1e-10
 
+
+def test_cahnhilliard_3d_case(tmp_path):
+    """test/tests/cahnhilliard/tests:13-22: cahnhilliard.i with Domain/dim=3 nx=ny=nz=5 zmax=3 vs map_to_aux_3d.e"""
+    g = load_golden("cahnhilliard_3d_gold.npz")
+    ic = tmp_path / "c0.bin"
+    g["c.0"].astype("<f8").tofile(ic)
+    _run(["problem=cahnhilliard", "dim=3", "nx=5", "ny=5", "nz=5", "xmax=3", "ymax=3", "zmax=3", f"ic={ic}", "substeps=10",
+          "num_steps=10", "dt=1e-3", "predictor_order=2", "mobility=0.2", "kappa=-0.001", "A=0.1"], tmp_path)
+    for k in range(1, 11):
+        c = np.fromfile(tmp_path / f"c.{k}.bin", dtype="<f8").reshape(5, 5, 5)
+        mu = np.fromfile(tmp_path / f"mu.{k}.bin", dtype="<f8").reshape(5, 5, 5)
+        assert np.abs(g[f"c.{k}"] - c).max() <= 1e-13
+        assert np.abs(g[f"mu.{k}"] - mu).max() <= 1e-13
+

@@ -327,3 +327,18 @@ def test_explicit_ch_dealiasing_gold(method):
             assert np.abs(g[f"c.{step}"] - c.numpy()).max() <= 1e-10
             assert np.abs(g[f"mu.{step}"] - mu.numpy()).max() <= 1e-11
 
+
+def test_ch_gold_3d():
+    """test/tests/cahnhilliard/tests:13-22 (cahnhilliard.i with Domain/dim=3 nx=ny=nz=5 zmax=3, Exodiff of map_to_aux_3d.e):
+    the reference's only 3-D Cahn-Hilliard gold data -- nodal c and elemental mu over 10 steps x 10 substeps (odd r2c axis)"""
+    g = load_golden("cahnhilliard_3d_gold.npz")
+    torch.manual_seed(0)
+    c0 = torch.rand(5, 5, 5, dtype=torch.float64) * (0.56 - 0.44) + 0.44
+    assert np.abs(g["c.0"] - c0.numpy()).max() <= 2e-16
+    dom = mo.Domain(3, [5, 5, 5], [3.0, 3.0, 3.0])
+    s = mo.CahnHilliardABM(dom, c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=10)
+    for k in range(1, 11):
+        s.step(1e-3)
+        assert np.abs(g[f"c.{k}"] - s.c.numpy()).max() <= 1e-13
+        assert np.abs(g[f"mu.{k}"] - s.mu.numpy()).max() <= 1e-13
+
