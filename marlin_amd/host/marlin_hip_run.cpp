@@ -13,6 +13,8 @@
 //        (test/tests/tensor_compute/rotating_grain_secant.i: SecantSolver + SwiftHohenbergLinear + iteration-adaptive dt)
 //   marlin-hip-run problem=cahnhilliard_explicit dim=2 nx=50 ny=50 xmax=3 ymax=3 ic=c0.bin method=SHARP substeps=50 num_steps=20 dt=0.5
 //        (test/tests/cahnhilliard/cahnhilliard_explicit_smooth.i: ForwardEulerSolver + DeAliasingTensor + reciprocal ParsedCompute)
+//   marlin-hip-run problem=kks dim=2 nx=20 ny=20 xmin=-50 xmax=50 ymin=-50 ymax=50 c=c0.bin eta=eta0.bin psi=psi0.bin num_steps=10 dt=0.1
+//        (test/tests/kks/KKS_no_flux_bc.i: ReciprocalMatDiffusion, ReciprocalAllenCahn, ParsedCompute derivatives, ABM order 3)
 //   marlin-hip-run problem=mechanics dim=3 nx=16 ny=16 nz=16 substeps=10 num_steps=3 dt=0.01 l_tol=1e-2 nl_rel_tol=2e-2
 //        nl_abs_tol=2e-2 out=dir          (test/tests/mechanics/mech3d.i)
 #include <cstdio>
@@ -395,6 +397,71 @@ static int run_cahnhilliard_explicit(DomainAction & domain, const std::string & 
   return 0;
 }
 
+// test/tests/kks/KKS_no_flux_bc.i: two-variable Kim-Kim-Suzuki model with the smooth boundary method: ParsedCompute derivatives of
+// the Gibbs energy, ReciprocalMatDiffusion / ReciprocalAllenCahn, AdamsBashforthMoulton order 3 with 1000 substeps per step;
+// c=, eta=, psi= hold the initial fields (the reference evaluates MOOSE parsed functions there)
+static int run_kks(DomainAction & domain, const std::string & out)
+{
+  TensorProblem problem(domain);
+  const std::size_t n = domain.getNumberOfCells();
+  for (const char * b : {"c", "eta", "psi"})
+    problem.getBuffer(b) = DeviceTensor::fromHost(read_bin(arg(b), n));
+  auto constant = [&](const char * b, double v) { problem.getBuffer(b) = DeviceTensor::fromHost(std::vector<double>(n, v)); };
+  constant("M", argd("M", 5.0));
+  constant("L", argd("L", 5.0));
+  constant("L_kappa", argd("L", 5.0) * argd("kappa_eta", 5.0));
+  // ${F} after MOOSE's textual substitution of h_eta, rho_sq, w, c0_a, c0_b (KKS_no_flux_bc.i:24-25)
+  const std::string h = "eta^3*(6*eta^2-15*eta+10)";
+  const std::string F = arg("F", h + "*(2*((c - (1-" + h + ")*(0.7 - 0.3))-0.3)^2) + (1-" + h + ")*(2*((c + (" + h +
+                                     ")*(0.7 - 0.3))-0.7)^2 ) + 1*(eta^2)*(1-eta)^2");
+  auto root = std::make_shared<ComputeGroup>(problem, "root");
+  root->add(std::make_shared<ForwardFFT>(problem, "cbar", "cbar", "c"));
+  root->add(std::make_shared<ForwardFFT>(problem, "etabar", "etabar", "eta"));
+  ParsedCompute::Params pm;
+  pm.buffer = "mu";
+  pm.expression = F;
+  pm.inputs = {"c", "eta"};
+  pm.derivatives = {"c"};
+  root->add(std::make_shared<ParsedCompute>(problem, "mu", pm));
+  root->add(std::make_shared<ReciprocalMatDiffusion>(problem, "div_J", "div_J", "mu", "M", "psi"));
+  ParsedCompute::Params po;
+  po.buffer = "domega_chem_deta";
+  po.expression = F + " - mu*c";
+  po.inputs = {"mu", "c", "eta"};
+  po.derivatives = {"eta"};
+  root->add(std::make_shared<ParsedCompute>(problem, "domega_chem_deta", po));
+  root->add(std::make_shared<ReciprocalAllenCahn>(problem, "AC_bulk", "AC_bulk", "domega_chem_deta", "L", "psi"));
+  root->add(std::make_shared<ReciprocalMatDiffusion>(problem, "kappa_grad_eta", "kappa_grad_eta", "eta", "L_kappa", "psi"));
+  ParsedCompute::Params pa;
+  pa.buffer = "AC_bar";
+  pa.expression = "kappa_grad_eta + AC_bulk";
+  pa.inputs = {"AC_bulk", "kappa_grad_eta"};
+  pa.complex_inputs = {"AC_bulk", "kappa_grad_eta"};
+  pa.reciprocal = true;
+  root->add(std::make_shared<ParsedCompute>(problem, "AC_bar", pa));
+  const std::size_t order = (std::size_t)argi("predictor_order", 3);
+  // linear_reciprocal = 'zero zero': dividing by (1 - dt * 0) is the identity
+  SplitOperatorABM solver(problem, "solver", (unsigned int)argi("substeps", 1000), root,
+                          {{"c", "cbar", "0", "div_J"}, {"eta", "etabar", "0", "AC_bar"}}, order, order, 0);
+  Transient ex(problem, solver, argd("dt", 0.1));
+  double volume = 1.0;
+  for (int d = 0; d < domain.getDim(); ++d)
+    volume *= domain.getExtent(d);
+  std::ofstream csv(out + "/kks.csv");
+  csv.precision(17);
+  csv << "time,total_C,total_eta\n";
+  auto row = [&](int frame) {
+    csv << problem.time() << ',' << TensorPostprocessors::integral(domain, problem.getBuffer("c"), volume) << ','
+        << TensorPostprocessors::integral(domain, problem.getBuffer("eta"), volume) << "\n";
+    for (const char * b : {"c", "eta", "mu"})
+      if (problem.getBuffer(b).defined())
+        dump(out, b, frame, problem.getBuffer(b));
+  };
+  row(0);
+  ex.execute((int)argi("num_steps", 10), [&](int step) { row(step); });
+  return 0;
+}
+
 // test/tests/solvers/etdrk4_diffusion.i: 1-D diffusion with ETDRK4 and a zero nonlinear term
 static int run_etdrk4_diffusion(DomainAction & domain, const std::string & out)
 {
@@ -528,6 +595,8 @@ int main(int argc, char ** argv)
       return run_postprocessors(domain, out);
     if (problem == "cahnhilliard_explicit")
       return run_cahnhilliard_explicit(domain, out);
+    if (problem == "kks")
+      return run_kks(domain, out);
     if (problem == "etdrk4_diffusion")
       return run_etdrk4_diffusion(domain, out);
     if (problem == "gradient" || problem == "gradient_square")

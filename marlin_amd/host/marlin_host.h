@@ -1307,7 +1307,8 @@ class FusedExpression
 {
 public:
   FusedExpression(DomainAction & domain, const std::string & expression, const std::vector<std::string> & inputs,
-                  const std::vector<std::string> & complex_inputs, const std::vector<std::pair<std::string, double>> & constants)
+                  const std::vector<std::string> & complex_inputs, const std::vector<std::pair<std::string, double>> & constants,
+                  bool extra_symbols = false, bool reciprocal = true)
     : _domain(domain)
   {
     std::vector<const char *> in, cn;
@@ -1324,7 +1325,7 @@ public:
       cv.push_back(c.second);
     }
     if (mrl_parsed_create(domain.ctx(), &_p, expression.c_str(), (int)in.size(), in.data(), cplx.data(), (int)cn.size(), cn.data(),
-                          cv.data(), 0, nullptr, 0, 1) != MRL_OK)
+                          cv.data(), 0, nullptr, extra_symbols ? 1 : 0, reciprocal ? 1 : 0) != MRL_OK)
       mooseError(std::string("FusedExpression: ") + mrl_last_error(domain.ctx()));
   }
   ~FusedExpression() { mrl_parsed_destroy(_p); }
@@ -1342,6 +1343,107 @@ public:
 private:
   DomainAction & _domain;
   mrl_parsed * _p = nullptr;
+};
+
+
+/// ReciprocalMatDiffusion (src/tensor_computes/ReciprocalMatDiffusion.C:44-66): divergence of the flux M grad(mu) with a no-flux
+/// condition on the boundary of {psi > 0} (smooth boundary method), every pointwise step one generated kernel
+class ReciprocalMatDiffusion : public TensorOperatorBase
+{
+public:
+  ReciprocalMatDiffusion(TensorProblem & problem, const std::string & name, const std::string & buffer,
+                         const std::string & chemical_potential, const std::string & mobility, const std::string & psi,
+                         bool always_update_psi = false)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer)), _chem_pot(getInputBuffer(chemical_potential)),
+      _M(getInputBuffer(mobility)), _psi(getInputBuffer(psi)), _always_update_psi(always_update_psi), _dim(_domain.getDim())
+  {
+    static const char * k[] = {"kx", "ky", "kz"};
+    static const char * g[] = {"gx", "gy", "gz"}, * j[] = {"jx", "jy", "jz"}, * a[] = {"ax", "ay", "az"};
+    std::string div, nof;
+    std::vector<std::string> ga, ja, aa;
+    for (int d = 0; d < _dim; ++d)
+    {
+      _grad.emplace_back(new FusedExpression(_domain, std::string(k[d]) + "*a*i", {"a"}, {"a"}, {}, true, true));   // _i * fft(.) * _imag
+      div += std::string(d ? "+" : "") + k[d] + "*" + a[d];
+      nof += std::string(d ? "+" : "") + g[d] + "*" + j[d];
+      ga.push_back(g[d]);
+      ja.push_back(j[d]);
+      aa.push_back(a[d]);
+    }
+    _by_psi.reset(new FusedExpression(_domain, "if(psi>0, g/psi, 0)", {"psi", "g"}, {}, {}, false, false));
+    _flux.reset(new FusedExpression(_domain, "M*(psi>0)*g", {"M", "psi", "g"}, {}, {}, false, false));
+    _div.reset(new FusedExpression(_domain, "i*(" + div + ")", aa, aa, {}, true, true));
+    std::vector<std::string> gj = ga;
+    gj.insert(gj.end(), ja.begin(), ja.end());
+    _noflux.reset(new FusedExpression(_domain, nof, gj, {}, {}, false, false));
+    _sum.reset(new FusedExpression(_domain, "a+b", {"a", "b"}, {"a", "b"}, {}, false, true));
+  }
+  void computeBuffer() override
+  {
+    const int64_t nr = _domain.getNumberOfCells(), ns = _domain.getReciprocalSize();
+    if (_update_psi || _always_update_psi)
+    {
+      const auto psibar = _domain.fft(_psi);
+      _grad_psi_by_psi.clear();
+      for (int d = 0; d < _dim; ++d)
+      {
+        const auto g = _domain.ifft((*_grad[d])({&psibar}, ns));
+        _grad_psi_by_psi.push_back((*_by_psi)({&_psi, &g}, nr));
+      }
+      _update_psi = false;
+    }
+    const auto mubar = _domain.fft(_chem_pot);
+    std::vector<DeviceTensor> J, Jbar;
+    for (int d = 0; d < _dim; ++d)
+    {
+      const auto g = _domain.ifft((*_grad[d])({&mubar}, ns));
+      J.push_back((*_flux)({&_M, &_psi, &g}, nr));
+      Jbar.push_back(_domain.fft(J.back()));
+    }
+    std::vector<const DeviceTensor *> in;
+    for (auto & t : Jbar)
+      in.push_back(&t);
+    const auto div_J_hat = (*_div)(in, ns);
+    in.clear();
+    for (auto & t : _grad_psi_by_psi)
+      in.push_back(&t);
+    for (auto & t : J)
+      in.push_back(&t);
+    const auto no_flux_hat = _domain.fft((*_noflux)(in, nr));
+    _u = (*_sum)({&div_J_hat, &no_flux_hat}, ns);
+  }
+
+private:
+  DeviceTensor & _u;
+  DeviceTensor & _chem_pot;
+  DeviceTensor & _M;
+  DeviceTensor & _psi;
+  const bool _always_update_psi;
+  const int _dim;
+  bool _update_psi = true;
+  std::vector<std::unique_ptr<FusedExpression>> _grad;
+  std::unique_ptr<FusedExpression> _by_psi, _flux, _div, _noflux, _sum;
+  std::vector<DeviceTensor> _grad_psi_by_psi;
+};
+
+/// ReciprocalAllenCahn (src/tensor_computes/ReciprocalAllenCahn.C:39-50): fft(where(psi > 0, -1 * L * dF_chem_deta, 0))
+class ReciprocalAllenCahn : public TensorOperatorBase
+{
+public:
+  ReciprocalAllenCahn(TensorProblem & problem, const std::string & name, const std::string & buffer, const std::string & dF_chem_deta,
+                      const std::string & L, const std::string & psi)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer)), _dF(getInputBuffer(dF_chem_deta)), _L(getInputBuffer(L)),
+      _psi(getInputBuffer(psi)), _rate(_domain, "if(psi>0, -1*L*dF, 0)", {"psi", "L", "dF"}, {}, {}, false, false)
+  {
+  }
+  void computeBuffer() override { _u = _domain.fft(_rate({&_psi, &_L, &_dF}, _domain.getNumberOfCells())); }
+
+private:
+  DeviceTensor & _u;
+  DeviceTensor & _dF;
+  DeviceTensor & _L;
+  DeviceTensor & _psi;
+  FusedExpression _rate;
 };
 
 /// ETDRK4Solver::substep (src/tensor_solver/ETDRK4Solver.C:29-115).  Every k-space stage combination is ONE fused

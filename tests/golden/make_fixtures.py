@@ -13,6 +13,7 @@ Sources (relative to /root/reference):
   test/tests/tensor_compute/gold/rotating_grain_secant.h5 spec test/tests/tensor_compute/tests:90-100 (abs_tol 1e-10)
   test/tests/cahnhilliard/gold/map_to_aux_3d.e            spec test/tests/cahnhilliard/tests:13-22 (3-D 5^3 Cahn-Hilliard; Exodus)
   test/tests/cahnhilliard/gold/sharp.e, houli.e           spec test/tests/cahnhilliard/tests:121-143 (explicit Euler + DeAliasingTensor; Exodus)
+  test/tests/kks/gold/KKS_no_flux_bc.h5, _out.csv         spec test/tests/kks/tests:13-31 (2-variable KKS, smooth boundary method, abs_tol 1e-10)
   test/tests/typed_tensors/gold/gradient.h5               spec test/tests/typed_tensors/tests (GradientTensor, 20x10x5, NODE mode)
   test/tests/solvers/gold/*.csv                          spec test/tests/solvers/tests
   test/tests/tensor_compute/gold/backandforth_out.csv, test/tests/gradient/gold/gradient_out.csv
@@ -107,6 +108,7 @@ def main():
     convert_h5("test/tests/mechanics/gold/mech.h5", "mech2d_gold.npz")
     convert_h5("test/tests/tensor_compute/gold/rotating_grain_secant.h5", "rotating_grain_secant_gold.npz")
     convert_h5("test/tests/typed_tensors/gold/gradient.h5", "typed_gradient_gold.npz")
+    convert_h5("test/tests/kks/gold/KKS_no_flux_bc.h5", "kks_no_flux_bc_gold.npz")
     # cahnhilliard.i with Domain/dim=3 nx=ny=nz=5 zmax=3 (tests:13-22): the only 3-D Cahn-Hilliard gold data of the reference
     convert_exodus("test/tests/cahnhilliard/gold/map_to_aux_3d.e", "cahnhilliard_3d_gold.npz", 5, 3.0, range(11), dim=3)
     for m in ("sharp", "houli"):      # cahnhilliard_explicit_smooth.i with DeAliasingTensor method = SHARP / HOULI (Exodiff)
@@ -119,7 +121,7 @@ def main():
     convert_csv(sol, "solvers_gold.npz")
     convert_csv(
         ["test/tests/tensor_compute/gold/backandforth_out.csv", "test/tests/gradient/gold/gradient_out.csv",
-         "test/tests/gradient/gold/gradient_square_out.csv"],
+         "test/tests/gradient/gold/gradient_square_out.csv", "test/tests/kks/gold/KKS_no_flux_bc_out.csv"],
         "fft_gold.npz",
     )
 

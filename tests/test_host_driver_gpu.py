@@ -195,3 +195,26 @@ def test_cahnhilliard_3d_case(tmp_path):
         assert np.abs(g[f"c.{k}"] - c).max() <= 1e-13
         assert np.abs(g[f"mu.{k}"] - mu).max() <= 1e-13
 
+
+def test_kks_no_flux_bc_case(tmp_path):
+    """test/tests/kks/tests:13-31 (KKS_no_flux_bc.i; HDF5Diff abs_tol 1e-10, CSVDiff): two coupled variables, ParsedCompute with
+    symbolic derivatives of the KKS Gibbs energy, ReciprocalMatDiffusion / ReciprocalAllenCahn with the smooth-boundary mask,
+    AdamsBashforthMoulton order 3, 10 x 1000 substeps.  The initial fields (MOOSE parsed functions) are frame 0 of the gold file."""
+    g = load_golden("kks_no_flux_bc_gold.npz")
+    files = []
+    for b in ("c", "eta", "psi"):
+        f = tmp_path / f"{b}0.bin"
+        g[f"{b}.0"].astype("<f8").tofile(f)
+        files.append(f"{b}={f}")
+    _run(["problem=kks", "dim=2", "nx=20", "ny=20", "xmin=-50", "xmax=50", "ymin=-50", "ymax=50", "num_steps=10", "dt=0.1",
+          "substeps=1000", "predictor_order=3"] + files, tmp_path)
+    worst = {}
+    for b in ("c", "eta", "mu"):
+        worst[b] = max(np.abs(g[f"{b}.{k}"] - np.fromfile(tmp_path / f"{b}.{k}.bin", dtype="<f8").reshape(20, 20)).max()
+                       for k in range(1, 11))
+    assert max(worst.values()) <= 1e-10, worst
+    csv = np.loadtxt(tmp_path / "kks.csv", delimiter=",", skiprows=1)
+    ref = load_golden("fft_gold.npz")["KKS_no_flux_bc_out"]
+    assert csv.shape == ref.shape
+    assert np.abs(csv - ref).max() <= 1e-9 * np.abs(ref).max()
+
