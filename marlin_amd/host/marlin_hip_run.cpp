@@ -462,6 +462,27 @@ static int run_kks(DomainAction & domain, const std::string & out)
   return 0;
 }
 
+// test/tests/postprocessors/interface_velocity.i: c = sin(x + 0.2 t) re-evaluated every step (no solver: the compute group runs at
+// timeOld), TensorInterfaceVelocityPostprocessor on c and its previous state
+static int run_interface_velocity(DomainAction & domain, const std::string & out)
+{
+  TensorProblem problem(domain);
+  auto root = std::make_shared<ComputeGroup>(problem, "root");
+  ParsedCompute::Params pc;
+  pc.buffer = "c";
+  pc.expression = arg("expression", "sin(x+0.2*t)");
+  pc.extra_symbols = true;
+  root->add(std::make_shared<ParsedCompute>(problem, "c", pc));
+  TensorInterfaceVelocityPostprocessor v(problem, "c");
+  ForwardEulerSolver solver(problem, "none", 1, root);   // no [TensorSolver]: TensorProblem::execute runs the computes (TensorProblem.C:176-187)
+  Transient ex(problem, solver, argd("dt", 0.01));
+  std::ofstream csv(out + "/interface_velocity.csv");
+  csv.precision(17);
+  csv << "time,v\n0,0\n";
+  ex.execute((int)argi("num_steps", 10), [&](int) { csv << problem.time() << ',' << v.getValue() << "\n"; });
+  return 0;
+}
+
 // test/tests/solvers/etdrk4_diffusion.i: 1-D diffusion with ETDRK4 and a zero nonlinear term
 static int run_etdrk4_diffusion(DomainAction & domain, const std::string & out)
 {
@@ -597,6 +618,8 @@ int main(int argc, char ** argv)
       return run_cahnhilliard_explicit(domain, out);
     if (problem == "kks")
       return run_kks(domain, out);
+    if (problem == "interface_velocity")
+      return run_interface_velocity(domain, out);
     if (problem == "etdrk4_diffusion")
       return run_etdrk4_diffusion(domain, out);
     if (problem == "gradient" || problem == "gradient_square")

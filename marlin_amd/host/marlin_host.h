@@ -1569,6 +1569,65 @@ struct TensorPostprocessors
   }
 };
 
+
+/// TensorInterfaceVelocityPostprocessor (src/postprocessors/TensorInterfaceVelocityPostprocessor.C:36-62): sqrt(max_cells sum_d
+/// v_d^2), v_d = (u - u_old)/dt / grad_d(u) where |grad_d(u)| > 1e-3 (the reference hard-wires that threshold), else 0
+class TensorInterfaceVelocityPostprocessor
+{
+public:
+  TensorInterfaceVelocityPostprocessor(TensorProblem & problem, const std::string & buffer)
+    : _problem(problem), _domain(problem.domain()), _u(problem.getBuffer(buffer)), _u_old(problem.getBufferOld(buffer, 1))
+  {
+    static const char * k[] = {"kx", "ky", "kz"};
+    static const char * g[] = {"gx", "gy", "gz"};
+    std::string expr = "du := (u - uo) / dt; ";
+    std::vector<std::string> in = {"u", "uo"};
+    std::string sum;
+    for (int d = 0; d < _domain.getDim(); ++d)
+    {
+      _grad.emplace_back(new FusedExpression(_domain, std::string("ubar*") + k[d] + "*i", {"ubar"}, {"ubar"}, {}, true, true));
+      expr += std::string("v") + g[d] + " := if(abs(" + g[d] + ") > 0.001, du / " + g[d] + ", 0); ";
+      sum += std::string(d ? " + " : "") + "v" + g[d] + "*v" + g[d];
+      in.push_back(g[d]);
+    }
+    _expr = expr + sum;
+    _inputs = in;
+  }
+  double getValue()
+  {
+    if (_u_old.empty())
+      return 0.0;
+    const int64_t nr = _domain.getNumberOfCells(), ns = _domain.getReciprocalSize();
+    if (!_vsq || _dt_built != _problem.dt())
+    {
+      _vsq.reset(new FusedExpression(_domain, _expr, _inputs, {}, {{"dt", _problem.dt()}}, false, false));
+      _dt_built = _problem.dt();
+    }
+    const auto ubar = _domain.fft(_u);
+    std::vector<DeviceTensor> g;
+    for (auto & e : _grad)
+      g.push_back(_domain.ifft((*e)({&ubar}, ns)));
+    std::vector<const DeviceTensor *> in = {&_u, &_u_old[0]};
+    for (auto & t : g)
+      in.push_back(&t);
+    const auto vsquare = (*_vsq)(in, nr);
+    double mn, mx;
+    TensorPostprocessors::extreme(_domain, vsquare, mn, mx);
+    return std::sqrt(mx);
+  }
+
+private:
+  TensorProblem & _problem;
+  DomainAction & _domain;
+  DeviceTensor & _u;
+  const std::vector<DeviceTensor> & _u_old;
+  std::vector<std::unique_ptr<FusedExpression>> _grad;
+  std::unique_ptr<FusedExpression> _vsq;
+  std::string _expr;
+  std::vector<std::string> _inputs;
+  double _dt_built = 0.0;
+};
+
 /// MOOSE Transient as far as the path sees it: advanceState, then the solver at EXEC_TIMESTEP_BEGIN
 class Transient
 {

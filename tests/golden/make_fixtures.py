@@ -121,7 +121,8 @@ def main():
     convert_csv(sol, "solvers_gold.npz")
     convert_csv(
         ["test/tests/tensor_compute/gold/backandforth_out.csv", "test/tests/gradient/gold/gradient_out.csv",
-         "test/tests/gradient/gold/gradient_square_out.csv", "test/tests/kks/gold/KKS_no_flux_bc_out.csv"],
+         "test/tests/gradient/gold/gradient_square_out.csv", "test/tests/kks/gold/KKS_no_flux_bc_out.csv",
+         "test/tests/postprocessors/gold/interface_velocity_out.csv"],
         "fft_gold.npz",
     )
 

@@ -218,3 +218,13 @@ def test_kks_no_flux_bc_case(tmp_path):
     assert csv.shape == ref.shape
     assert np.abs(csv - ref).max() <= 1e-9 * np.abs(ref).max()
 
+
+def test_interface_velocity_case(tmp_path):
+    """test/tests/postprocessors/tests (interface_velocity.i, CSVDiff): TensorInterfaceVelocityPostprocessor of c = sin(x + 0.2 t)
+    on a 10 x 2 grid -- FFT gradients, the previous state of the buffer, the |grad| > 1e-3 mask, max reduction"""
+    ref = load_golden("fft_gold.npz")["interface_velocity_out"]
+    _run(["problem=interface_velocity", "dim=2", "nx=10", "ny=2", "xmax=4pi", "ymax=1", "num_steps=10", "dt=0.01"], tmp_path)
+    got = np.loadtxt(tmp_path / "interface_velocity.csv", delimiter=",", skiprows=1)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-12
+
