@@ -353,6 +353,10 @@ int mrl_minmax(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_min, double
 /* DomainAction::average over the grid of a value-major field [grid][ncomp] -> h_out[ncomp]; on a slab context the
  * local sum divided by the GLOBAL point count (the sum over ranks is the average) */
 int mrl_average(mrl_ctx *ctx, const double *d_a, int64_t ncomp, double *h_out);
+/* TensorHistogram (src/vectorpostprocessors/TensorHistogram.C:48-79, at::native::histogramdd with explicit edges): counts of the
+ * values of d_a per bin [edge_i, edge_i+1) -- the last bin closed on the right, values outside the edges ignored.  h_edges has
+ * nbins + 1 non-decreasing entries (the reference uses torch::linspace(min, max, bins + 1)).  Local count; synchronises. */
+int mrl_histogram(mrl_ctx *ctx, const double *d_a, int64_t n, const double *h_edges, int nbins, int64_t *h_counts);
 
 /* ---- timing on the context stream (hipEvents): used by bench.py for roofline.achieved ---- */
 int mrl_timer_start(mrl_ctx *ctx);

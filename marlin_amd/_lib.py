@@ -98,6 +98,7 @@ SIGNATURES = {
     "mrl_broyden_residual": (_i32, [_vp, _i32, _pp, _pp, _pp, _pp, _dbl, _vp, C.POINTER(_dbl), _i64]),
     "mrl_broyden_predict": (_i32, [_vp, _i32, _vp, _vp, _pp, _dbl, _vp, _pp, _i64]),
     "mrl_broyden_update": (_i32, [_vp, _i32, _vp, _vp, _vp, _pp, _pp, _pp, _pp, _dbl, C.POINTER(_dbl), _i64]),
+    "mrl_histogram": (_i32, [_vp, _vp, _i64, C.POINTER(_dbl), _i32, C.POINTER(_i64)]),
     "mrl_secant_begin": (_i32, [_vp, _vp, _vp, _vp, _dbl, _dbl, _vp, _vp, C.POINTER(_dbl), _i64]),
     "mrl_secant_iterate": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, C.POINTER(_dbl), _i64]),
     "mrl_slab_ch_counts": (_i32, [_vp, _i32, _i32, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),

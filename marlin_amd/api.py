@@ -228,6 +228,14 @@ class Context:
                                                 damping, _ptr(u_new), ss, u.numel()))
         return u_new, math.sqrt(ss[0]), math.sqrt(ss[1])
 
+    def histogram(self, a: torch.Tensor, edges: Sequence[float]):
+        """TensorHistogram: counts per bin [edge_i, edge_i+1), last bin closed"""
+        nb = len(edges) - 1
+        e = (C.c_double * (nb + 1))(*[float(v) for v in edges])
+        out = (C.c_int64 * nb)()
+        self._check(self.lib.mrl_histogram(self.h, _ptr(a), a.numel(), e, nb, out))
+        return list(out)
+
     # ---- BroydenSolver building blocks (field-major state arrays owned by the caller)
     @staticmethod
     def _pp(ts):

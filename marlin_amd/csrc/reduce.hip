@@ -232,3 +232,64 @@ int mrl_average(mrl_ctx *ctx, const double *d_a, int64_t ncomp, double *h_out) {
 }
 
 }  // extern "C"
+
+// ---- TensorHistogram (src/vectorpostprocessors/TensorHistogram.C:48-79 -> at::native::histogramdd with explicit bin edges):
+// bin i = [edge_i, edge_i+1), the last bin closed on the right, values outside [edge_0, edge_nbins] not counted
+namespace mrl {
+
+__global__ void __launch_bounds__(256) k_histogram(const double *__restrict__ a, long long n, const double *__restrict__ edges,
+                                                    int nbins, unsigned long long *__restrict__ counts) {
+  extern __shared__ unsigned long long sh_counts[];
+  double *sh_edges = reinterpret_cast<double *>(sh_counts + nbins);
+  for (int i = threadIdx.x; i < nbins; i += 256) sh_counts[i] = 0ull;
+  for (int i = threadIdx.x; i <= nbins; i += 256) sh_edges[i] = edges[i];
+  __syncthreads();
+  const double lo = sh_edges[0], hi = sh_edges[nbins];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double v = a[i];
+    if (!(v >= lo && v <= hi)) continue;   // also drops NaN
+    // upper_bound(edges, v) - 1, the right-most edge counted into the last bin
+    int l = 0, r = nbins + 1;
+    while (l < r) {
+      const int m = (l + r) >> 1;
+      if (sh_edges[m] <= v)
+        l = m + 1;
+      else
+        r = m;
+    }
+    int b = l - 1;
+    if (b >= nbins) b = nbins - 1;
+    atomicAdd(&sh_counts[b], 1ull);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nbins; i += 256)
+    if (sh_counts[i]) atomicAdd(&counts[i], sh_counts[i]);
+}
+
+}  // namespace mrl
+
+extern "C" int mrl_histogram(mrl_ctx *ctx, const double *d_a, int64_t n, const double *h_edges, int nbins, int64_t *h_counts) {
+  using namespace mrl;
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!d_a || !h_edges || !h_counts || nbins < 1 || nbins > 4096 || n < 0)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_histogram: bad argument (1 <= bins <= 4096)");
+  for (int i = 0; i < nbins; ++i)
+    if (!(h_edges[i] <= h_edges[i + 1])) return set_error(ctx, MRL_ERR_INVALID, "mrl_histogram: bin edges must not decrease");
+  const size_t cb = sizeof(unsigned long long) * (size_t)nbins, eb = sizeof(double) * (size_t)(nbins + 1);
+  MRL_TRY(ensure_work(ctx, 3, cb + eb + 16));
+  unsigned long long *d_counts = reinterpret_cast<unsigned long long *>(ctx->d_work[3]);
+  double *d_edges = reinterpret_cast<double *>(d_counts + nbins);
+  MRL_HIP(ctx, hipMemsetAsync(d_counts, 0, cb, ctx->stream));
+  MRL_HIP(ctx, hipMemcpyAsync(d_edges, h_edges, eb, hipMemcpyHostToDevice, ctx->stream));
+  if (n > 0) {
+    long long nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_histogram, dim3((unsigned)nb), dim3(256), cb + eb, ctx->stream, d_a, (long long)n, d_edges, nbins, d_counts);
+    MRL_HIP(ctx, hipGetLastError());
+  }
+  std::vector<unsigned long long> h((size_t)nbins);
+  MRL_HIP(ctx, hipMemcpyAsync(h.data(), d_counts, cb, hipMemcpyDeviceToHost, ctx->stream));
+  MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < nbins; ++i) h_counts[i] = (int64_t)h[i];
+  return MRL_OK;
+}

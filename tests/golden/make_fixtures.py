@@ -122,7 +122,7 @@ def main():
     convert_csv(
         ["test/tests/tensor_compute/gold/backandforth_out.csv", "test/tests/gradient/gold/gradient_out.csv",
          "test/tests/gradient/gold/gradient_square_out.csv", "test/tests/kks/gold/KKS_no_flux_bc_out.csv",
-         "test/tests/postprocessors/gold/interface_velocity_out.csv"],
+         "test/tests/postprocessors/gold/interface_velocity_out.csv", "test/tests/histogram/gold/test_out_hist_0001.csv"],
         "fft_gold.npz",
     )
 

@@ -165,3 +165,21 @@ def test_local_vars_derivative_gpu():
     err = (d - 2 * a).abs()
     assert ctx.sum(err) / 400 * 4.0 <= 1e-13          # TensorIntegralPostprocessor of |df_da - 2a|; gold: 0
 
+
+def test_histogram_gold_gpu():
+    """test/tests/histogram/tests (test.i, CSVDiff): TensorHistogram of 0.1 x^2 + 0.2 y^2 + 0.3 z^2 on 10^3, 20 bins on [0, 1]
+    -- bin edges torch.linspace(0, 1, 21) as the reference builds them -- and the histogramdd edge conventions"""
+    from marlin_amd.api import Context, ParsedCompute
+    from tests.conftest import load_golden
+    g = load_golden("fft_gold.npz")["test_out_hist_0001"]
+    ctx = Context(3, [10, 10, 10], [1.0, 1.0, 1.0])
+    c = ParsedCompute(ctx, "0.1*x^2+0.2*y^2+0.3*z^2", extra_symbols=True)()
+    edges = torch.linspace(0.0, 1.0, 21, dtype=torch.float64)
+    counts = ctx.histogram(c, edges.tolist())
+    assert counts == [int(v) for v in g[:, 1]] and sum(counts) == 1000
+    # conventions: [e_i, e_i+1), last bin closed, outside values and NaN dropped -- against torch.histogramdd on the CPU
+    torch.manual_seed(1)
+    v = torch.cat([torch.rand(5000, dtype=torch.float64) * 1.4 - 0.2, edges, torch.tensor([float("nan"), -0.2, 1.0, 1.0000001])])
+    want = torch.histogramdd(v[~torch.isnan(v)].reshape(-1, 1), [edges]).hist
+    assert ctx.histogram(v.cuda(), edges.tolist()) == [int(x) for x in want]
+
