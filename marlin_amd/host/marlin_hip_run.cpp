@@ -483,6 +483,32 @@ static int run_interface_velocity(DomainAction & domain, const std::string & out
   return 0;
 }
 
+// test/tests/tensor_compute/smooth_rectangle.i: SmoothRectangleCompute with the sharp, COS and TANH profiles
+static int run_smooth_rectangle(DomainAction & domain, const std::string & out)
+{
+  TensorProblem problem(domain);
+  SmoothRectangleCompute::Params p;
+  p.x1 = argd("x1", 5);
+  p.x2 = argd("x2", 15);
+  p.y1 = argd("y1", 5);
+  p.y2 = argd("y2", 15);
+  p.z1 = argd("z1", 0);
+  p.z2 = argd("z2", 0);
+  p.inside = argd("inside", -1);
+  p.outside = argd("outside", 3);
+  const struct { const char * buffer, * profile; double w; } cases[] = {
+      {"rectangle_sharp", "COS", 0.0}, {"rectangle_cos", "COS", argd("int_width", 1.0)}, {"rectangle_tanh", "TANH", argd("int_width", 1.0)}};
+  for (const auto & c : cases)
+  {
+    p.buffer = c.buffer;
+    p.profile = c.profile;
+    p.int_width = c.w;
+    SmoothRectangleCompute(problem, c.buffer, p).computeBuffer();
+    dump(out, c.buffer, 0, problem.getBuffer(c.buffer));
+  }
+  return 0;
+}
+
 // test/tests/solvers/etdrk4_diffusion.i: 1-D diffusion with ETDRK4 and a zero nonlinear term
 static int run_etdrk4_diffusion(DomainAction & domain, const std::string & out)
 {
@@ -620,6 +646,8 @@ int main(int argc, char ** argv)
       return run_kks(domain, out);
     if (problem == "interface_velocity")
       return run_interface_velocity(domain, out);
+    if (problem == "smooth_rectangle")
+      return run_smooth_rectangle(domain, out);
     if (problem == "etdrk4_diffusion")
       return run_etdrk4_diffusion(domain, out);
     if (problem == "gradient" || problem == "gradient_square")

@@ -1088,6 +1088,59 @@ private:
   mrl_parsed * _parsed = nullptr;
 };
 
+
+/// SmoothRectangleCompute (src/tensor_computes/SmoothRectangleCompute.C:58-121): inside / outside value of an axis-aligned box
+/// with a sharp, cosine or tanh profile; one generated kernel (clamp(v, lo, hi) = min(max(v, lo), hi) as ATen evaluates it)
+class SmoothRectangleCompute : public TensorOperatorBase
+{
+public:
+  struct Params
+  {
+    std::string buffer, profile = "COS";
+    double x1 = 0, x2 = 0, y1 = 0, y2 = 0, z1 = 0, z2 = 0, int_width = 0, inside = 1, outside = 0;
+  };
+  SmoothRectangleCompute(TensorProblem & problem, const std::string & name, const Params & p)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(p.buffer))
+  {
+    if (p.int_width < 0.0)
+      mooseError("Interface width must be a non-negative real number.");
+    const int dim = _domain.getDim();
+    static const char * ax[] = {"x", "y", "z"};
+    std::string h;
+    if (p.int_width <= 0.0)
+    {
+      std::string cond;
+      for (int d = 0; d < dim; ++d)
+        cond += std::string(d ? " & " : "") + "(" + ax[d] + " >= " + ax[d] + "1) & (" + ax[d] + " <= " + ax[d] + "2)";
+      h = "if(" + cond + ", 1, 0)";
+    }
+    else
+      for (int d = 0; d < dim; ++d)   // the factors of the absent axes are exactly 1 (sin(pi/2), tanh(>= 20))
+      {
+        const std::string m = std::string("min(") + ax[d] + " - " + ax[d] + "1, " + ax[d] + "2 - " + ax[d] + ")";
+        const std::string f = p.profile == "TANH" ? "(0.5 + 0.5 * tanh(4 * " + m + " / w))"
+                                                  : "(0.5 + 0.5 * sin(pi * min(max(" + m + ", 0 - w / 2), w / 2) / w))";
+        h += (d ? " * " : "") + f;
+      }
+    const std::string expr = "h := " + h + "; h * inside + (1 - h) * outside";
+    const char * cn[] = {"x1", "x2", "y1", "y2", "z1", "z2", "w", "inside", "outside"};
+    const double cv[] = {p.x1, p.x2, p.y1, p.y2, p.z1, p.z2, p.int_width, p.inside, p.outside};
+    if (mrl_parsed_create(_domain.ctx(), &_parsed, expr.c_str(), 0, nullptr, nullptr, 9, cn, cv, 0, nullptr, 1, 0) != MRL_OK)
+      paramError("profile", mrl_last_error(_domain.ctx()));
+  }
+  ~SmoothRectangleCompute() { mrl_parsed_destroy(_parsed); }
+  void computeBuffer() override
+  {
+    auto out = DeviceTensor::empty(_domain.getNumberOfCells());
+    _domain.check(mrl_parsed_eval(_parsed, nullptr, out.data(), _domain.getNumberOfCells(), _time));
+    _u = out;
+  }
+
+private:
+  DeviceTensor & _u;
+  mrl_parsed * _parsed = nullptr;
+};
+
 /// SecantSolver (src/tensor_solver/SecantSolver.C:42-185): control flow of the reference, k-space work in two fused kernels
 class SecantSolver : public SplitOperatorABM, public IterativeTensorSolverInterface
 {

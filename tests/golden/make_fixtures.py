@@ -109,6 +109,7 @@ def main():
     convert_h5("test/tests/tensor_compute/gold/rotating_grain_secant.h5", "rotating_grain_secant_gold.npz")
     convert_h5("test/tests/typed_tensors/gold/gradient.h5", "typed_gradient_gold.npz")
     convert_h5("test/tests/kks/gold/KKS_no_flux_bc.h5", "kks_no_flux_bc_gold.npz")
+    convert_h5("test/tests/tensor_compute/gold/smooth_rectangle.h5", "smooth_rectangle_gold.npz")
     # cahnhilliard.i with Domain/dim=3 nx=ny=nz=5 zmax=3 (tests:13-22): the only 3-D Cahn-Hilliard gold data of the reference
     convert_exodus("test/tests/cahnhilliard/gold/map_to_aux_3d.e", "cahnhilliard_3d_gold.npz", 5, 3.0, range(11), dim=3)
     for m in ("sharp", "houli"):      # cahnhilliard_explicit_smooth.i with DeAliasingTensor method = SHARP / HOULI (Exodiff)

@@ -228,3 +228,13 @@ def test_interface_velocity_case(tmp_path):
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() <= 1e-12
 
+
+def test_smooth_rectangle_case(tmp_path):
+    """test/tests/tensor_compute/tests:101-111 (smooth_rectangle.i, HDF5Diff abs_tol 1e-10): sharp / COS / TANH box profiles on
+    100 x 100 (default transpose of the XDMF output)"""
+    g = load_golden("smooth_rectangle_gold.npz")
+    _run(["problem=smooth_rectangle", "dim=2", "nx=100", "ny=100", "xmax=20", "ymax=20"], tmp_path)
+    for b in ("rectangle_sharp", "rectangle_cos", "rectangle_tanh"):
+        got = np.fromfile(tmp_path / f"{b}.0.bin", dtype="<f8").reshape(100, 100)
+        assert np.abs(g[f"{b}.0"] - got.T).max() <= 1e-13, b
+
