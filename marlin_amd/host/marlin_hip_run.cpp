@@ -83,8 +83,35 @@ static int run_cahnhilliard(DomainAction & domain, const std::string & out)
     p.ch.family = MRL_FE_PARSED;
     p.ch.parsed = parsed;
   }
-  AdamsBashforthMoulton solver(problem, "solver", p);
-  Transient ex(problem, solver, argd("dt", 1e-3));
+  std::unique_ptr<TensorSolver> solver;
+  if (arg("integrator") == "FFTSemiImplicit")
+  {
+    // the legacy [TensorTimeIntegrators] form of the same scheme: explicit compute group + FFTSemiImplicit (history_size 1)
+    ReciprocalLaplacianFactor(problem, "Mbar", "Mbar", p.ch.mobility).computeBuffer();
+    ReciprocalLaplacianFactor(problem, "kappabarbar", "kappabarbar", p.ch.kappa, 2).computeBuffer();
+    auto root = std::make_shared<ComputeGroup>(problem, "root");
+    ParsedCompute::Params pm;
+    pm.buffer = "mu";
+    pm.expression = arg("expression", "0.1*c^2*(c-1)^2");
+    pm.inputs = {"c"};
+    pm.derivatives = {"c"};
+    root->add(std::make_shared<ParsedCompute>(problem, "mu", pm));
+    root->add(std::make_shared<ForwardFFT>(problem, "mubar", "mubar", "mu"));
+    ParsedCompute::Params pn;
+    pn.buffer = "Mbarmubar";
+    pn.expression = "Mbar*mubar";
+    pn.inputs = {"Mbar", "mubar"};
+    pn.complex_inputs = {"mubar"};
+    pn.reciprocal = true;
+    root->add(std::make_shared<ParsedCompute>(problem, "Mbarmubar", pn));
+    root->add(std::make_shared<ForwardFFT>(problem, "cbar", "cbar", "c"));
+    auto ti = std::make_shared<FFTSemiImplicit>(problem, "c", "c", "cbar", "kappabarbar", "Mbarmubar", 1);
+    solver = std::make_unique<TimeIntegratorSolver>(problem, "solver", p.substeps, root,
+                                                    std::vector<std::shared_ptr<TensorOperatorBase>>{ti});
+  }
+  else
+    solver = std::make_unique<AdamsBashforthMoulton>(problem, "solver", p);
+  Transient ex(problem, *solver, argd("dt", 1e-3));
   dump(out, "c", 0, problem.getBuffer("c"));
   ex.execute((int)argi("num_steps", 1), [&](int step) {
     dump(out, "c", step, problem.getBuffer("c"));

@@ -1499,6 +1499,71 @@ private:
   FusedExpression _rate;
 };
 
+
+/// FFTSemiImplicit (src/tensor_timeintegrators/FFTSemiImplicit.C:43-62, the legacy TensorTimeIntegrator form of the semi-implicit
+/// update): ubar = (ubar0 + dt N)/(1 - dt L) without history, (ubar0 + dt/2 (3 N - N_old))/(1 - dt L) with it; u = ifft(ubar).
+/// The same numbers as AdamsBashforthMoulton orders 1 and 2 up to rounding; one generated kernel per form
+class FFTSemiImplicit : public TensorOperatorBase
+{
+public:
+  FFTSemiImplicit(TensorProblem & problem, const std::string & name, const std::string & buffer, const std::string & reciprocal_buffer,
+                  const std::string & linear_reciprocal, const std::string & nonlinear_reciprocal, unsigned int history_size = 1)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer)), _reciprocal_buffer(getInputBuffer(reciprocal_buffer)),
+      _linear_reciprocal(getInputBuffer(linear_reciprocal)), _non_linear_reciprocal(getInputBuffer(nonlinear_reciprocal)),
+      _old_reciprocal_buffer(problem.getBufferOld(reciprocal_buffer, history_size)),
+      _old_non_linear_reciprocal(problem.getBufferOld(nonlinear_reciprocal, history_size))
+  {
+  }
+  void computeBuffer() override
+  {
+    const double dt = _tensor_problem.subDt();
+    if (!_first || _dt_built != dt)
+    {
+      _first.reset(new FusedExpression(_domain, "(ubar + dt * N) / (1 - dt * L)", {"ubar", "N", "L"}, {"ubar", "N"}, {{"dt", dt}}));
+      _second.reset(new FusedExpression(_domain, "(ubar + dt / 2 * (3 * N - No)) / (1 - dt * L)", {"ubar", "N", "No", "L"},
+                                        {"ubar", "N", "No"}, {{"dt", dt}}));
+      _dt_built = dt;
+    }
+    const auto n_old = std::min(_old_reciprocal_buffer.size(), _old_non_linear_reciprocal.size());
+    const int64_t ns = _domain.getReciprocalSize();
+    const auto ubar = n_old == 0 ? (*_first)({&_reciprocal_buffer, &_non_linear_reciprocal, &_linear_reciprocal}, ns)
+                                 : (*_second)({&_reciprocal_buffer, &_non_linear_reciprocal, &_old_non_linear_reciprocal[0],
+                                               &_linear_reciprocal}, ns);
+    _u = _domain.ifft(ubar);
+  }
+
+private:
+  DeviceTensor & _u;
+  DeviceTensor & _reciprocal_buffer;
+  DeviceTensor & _linear_reciprocal;
+  DeviceTensor & _non_linear_reciprocal;
+  const std::vector<DeviceTensor> & _old_reciprocal_buffer;
+  const std::vector<DeviceTensor> & _old_non_linear_reciprocal;
+  std::unique_ptr<FusedExpression> _first, _second;
+  double _dt_built = 0.0;
+};
+
+/// drives TensorTimeIntegrators the way the pre-TensorSolver syntax did: per substep the root compute, then every integrator
+class TimeIntegratorSolver : public TensorSolver
+{
+public:
+  TimeIntegratorSolver(TensorProblem & problem, const std::string & name, unsigned int substeps,
+                       std::shared_ptr<TensorOperatorBase> root_compute, std::vector<std::shared_ptr<TensorOperatorBase>> integrators)
+    : TensorSolver(problem, name, substeps, std::move(root_compute)), _integrators(std::move(integrators))
+  {
+  }
+
+protected:
+  void substep() override
+  {
+    _compute->computeBuffer();
+    forwardBuffers();
+    for (auto & ti : _integrators)
+      ti->computeBuffer();
+  }
+  std::vector<std::shared_ptr<TensorOperatorBase>> _integrators;
+};
+
 /// ETDRK4Solver::substep (src/tensor_solver/ETDRK4Solver.C:29-115).  Every k-space stage combination is ONE fused
 /// kernel generated from the reference's own formulas (exp(L dt), the phi functions with their L dt == 0 limits and
 /// the stage sums are evaluated in registers; the reference materialises ~25 full-size temporaries per variable).
