@@ -22,7 +22,7 @@ struct FusedArgs {
   const double *kx, *ky, *kz;
 };
 
-template <int N, int ORDER, int PRE, bool SPEC_C>
+template <int N, int ORDER, int PRE, bool SPEC_C, bool NT_W = true>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const cplx *__restrict__ tw) {
   constexpr int TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const
   // byte offset of line element m: (i + (q + m*TPL)*inner) * 16, the same in the work and the dense layout
   const unsigned off0 = (unsigned)(iv + (long long)q * a.inner) * 16u, step = (unsigned)(TPL * a.inner) * 16u;
   auto off = [=](int m) { return off0 + (unsigned)m * step; };
-  ch_fused_body<N, ORDER, true, PRE, SPEC_C>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, W, X, KX);
+  ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT_W>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, W, X, KX);
 }
 
 template <int N, int ORDER, bool SPEC_C, int PRE = Plan<N>::P / 2>

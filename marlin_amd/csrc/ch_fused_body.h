@@ -37,13 +37,29 @@ __device__ __forceinline__ cplx ldc(const cplx *base, unsigned boff) {
 __device__ __forceinline__ void stc(cplx *base, unsigned boff, cplx v) {
   *reinterpret_cast<cplx *>(reinterpret_cast<char *>(base) + boff) = v;
 }
+// streaming (non-temporal) forms for the arrays that are not touched again within the substep (old / new Nhat): they
+// should not displace the work arrays, which the next pass re-reads, from the 256 MB Infinity Cache
+typedef double nt_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cplx ldc_nt(const cplx *base, unsigned boff) {
+  const nt_v2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_v2 *>(reinterpret_cast<const char *>(base) + boff));
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void stc_nt(cplx *base, unsigned boff, cplx v) {
+  nt_v2 w;
+  w.x = v.x;
+  w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<nt_v2 *>(reinterpret_cast<char *>(base) + boff));
+}
 
 // OffW / OffD: callables m -> byte offset of the thread's m-th line element in the work layout / the dense
 // reference layout (computed from a few live values instead of 2 x 16 held registers).
 // OffU: the same for the ubar output (the inverse exchange layout of the slab path differs from the forward one).
 // SPEC_C: c-hat is not transformed from the work layout but read, already in reciprocal space, from a.carry (dense), which
 // receives ubar in place: irfftn followed by rfftn is the identity up to rounding, so the next substep's c-hat IS this ubar.
-template <int N, int ORDER, bool LINE_IS_X, int PRE, bool SPEC_C, class OffW, class OffD, class OffU>
+// The old / new Nhat arrays (and the optional cbar output) are accessed non-temporally: they are not touched again within the
+// substep and must not displace the work arrays from the Infinity Cache (measured at 256^3: fused x pass 155 -> 128 us, the
+// following y pass 54.5 -> 49 us).  NT_W: the same for the mu-hat loads, which are dead after this pass (another 2.5 % of the substep).
+template <int N, int ORDER, bool LINE_IS_X, int PRE, bool SPEC_C, bool NT_W = true, class OffW, class OffD, class OffU>
 __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *__restrict__ tw,
                                               const double *__restrict__ kline, const double *__restrict__ ka_ptr,
                                               const double *__restrict__ kb_ptr, bool valid, int q, int l,
@@ -68,9 +84,9 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   const double ka = *ka_ptr, kb = *kb_ptr;
   cplx v[P], cp[P];
 #pragma unroll
-  for (int m = 0; m < P; ++m) v[m] = ldc(a.muhat, offw(m));
+  for (int m = 0; m < P; ++m) v[m] = NT_W ? ldc_nt(a.muhat, offw(m)) : ldc(a.muhat, offw(m));
 #pragma unroll
-  for (int m = 0; m < P; ++m) cp[m] = SPEC_C ? ldc(a.carry, offd(m)) : ldc(a.chat, offw(m));
+  for (int m = 0; m < P; ++m) cp[m] = SPEC_C ? ldc_nt(a.carry, offd(m)) : ldc(a.chat, offw(m));
 #pragma unroll
   for (int j = 0; j < CNT; ++j) {
     const int idx = threadIdx.x + j * NT;
@@ -95,7 +111,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   }
   if (valid) {
 #pragma unroll
-    for (int m = 0; m < P; ++m) stc(a.Nnew, offd(m), Nv[m]);
+    for (int m = 0; m < P; ++m) stc_nt(a.Nnew, offd(m), Nv[m]);
   }
 
   // ---- first-order history: PRE of the 16 old Nhat values are requested before the c-hat transform and are in flight
@@ -103,20 +119,20 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   cplx o1[ORDER == 1 ? P : 1];
   if (ORDER == 1) {
 #pragma unroll
-    for (int m = 0; m < PRE; ++m) o1[ORDER == 1 ? m : 0] = ldc(a.Nold[0], offd(m));
+    for (int m = 0; m < PRE; ++m) o1[ORDER == 1 ? m : 0] = ldc_nt(a.Nold[0], offd(m));
   }
 
   // ---- 3. c-hat: forward transform (unless it is carried over in reciprocal space)
   if (!SPEC_C) fft_line<N, Map>(cp, q, l, X, W);
   if (a.cbar && valid) {
 #pragma unroll
-    for (int m = 0; m < P; ++m) stc(a.cbar, offd(m), cp[m]);
+    for (int m = 0; m < P; ++m) stc_nt(a.cbar, offd(m), cp[m]);
   }
 
   // ---- 4. ubar = (cbar + (dt b0) N + sum (dt b_i) Nold_i) / (1 - dt*Lbar), the reference's association
   if (ORDER == 1) {
 #pragma unroll
-    for (int m = PRE; m < P; ++m) o1[ORDER == 1 ? m : 0] = ldc(a.Nold[0], offd(m));
+    for (int m = PRE; m < P; ++m) o1[ORDER == 1 ? m : 0] = ldc_nt(a.Nold[0], offd(m));
 #pragma unroll
     for (int m = 0; m < P; ++m) {
       cplx u = cp[m];
@@ -139,7 +155,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
 #pragma unroll
       for (int h = 0; h < ORDER; ++h) {
 #pragma unroll
-        for (int j = 0; j < H; ++j) o[h][j] = ldc(a.Nold[h], offd(half * H + j));
+        for (int j = 0; j < H; ++j) o[h][j] = ldc_nt(a.Nold[h], offd(half * H + j));
       }
 #pragma unroll
       for (int j = 0; j < H; ++j) {
@@ -163,7 +179,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
 
   if ((SPEC_C || a.carry) && valid) {
 #pragma unroll
-    for (int m = 0; m < P; ++m) stc(a.carry, offd(m), cswap(v[m]));
+    for (int m = 0; m < P; ++m) stc_nt(a.carry, offd(m), cswap(v[m]));
   }
 
   // ---- 5. inverse transform (unnormalised; 1/N applied by the final z pass)
