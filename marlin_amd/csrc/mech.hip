@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) k_mech_tangent_fm2(const double *__restri
     Mat<3> f[2], d[2];
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-      const double2 fv = reinterpret_cast<const double2 *>(F + (long long)c * npts)[h];
+      const double2 fv = ld_nt(reinterpret_cast<const double2 *>(F + (long long)c * npts) + h);   // streamed once per CG iteration
       f[0].a[c / 3][c % 3] = fv.x;
       f[1].a[c / 3][c % 3] = fv.y;
       double2 dv;
@@ -188,12 +188,12 @@ __global__ void __launch_bounds__(256) k_mech_tangent_fm2(const double *__restri
       if (DIR) {
         const double2 rv = reinterpret_cast<const double2 *>(r + (long long)c * npts)[h];
         dv = make_double2(rv.x + beta * dv.x, rv.y + beta * dv.y);
-        reinterpret_cast<double2 *>(dF + (long long)c * npts)[h] = dv;
+        st_nt(reinterpret_cast<double2 *>(dF + (long long)c * npts) + h, dv);   // p: next read at the far end of the Gamma passes
       }
       d[0].a[c / 3][c % 3] = dv.x;
       d[1].a[c / 3][c % 3] = dv.y;
     }
-    const double2 Kv = reinterpret_cast<const double2 *>(K)[h], mv = reinterpret_cast<const double2 *>(mu)[h];
+    const double2 Kv = ld_nt(reinterpret_cast<const double2 *>(K) + h), mv = ld_nt(reinterpret_cast<const double2 *>(mu) + h);
     const Mat<3> o0 = svk_tangent<3>(f[0], d[0], Kv.x, mv.x);
     const Mat<3> o1 = svk_tangent<3>(f[1], d[1], Kv.y, mv.y);
 #pragma unroll
@@ -312,8 +312,8 @@ __global__ void __launch_bounds__(256) k_cg_update(const double *__restrict__ S,
   double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
   const double2 *p2 = reinterpret_cast<const double2 *>(p), *A2 = reinterpret_cast<const double2 *>(Ap);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256) {
-    const double2 xv = x2[i], pv = p2[i], rv = r2[i], av = A2[i];
-    x2[i] = make_double2(xv.x + alpha * pv.x, xv.y + alpha * pv.y);
+    const double2 xv = ld_nt(x2 + i), pv = ld_nt(p2 + i), rv = r2[i], av = A2[i];   // x, p: not re-read before ~3 GB of other traffic
+    st_nt(x2 + i, make_double2(xv.x + alpha * pv.x, xv.y + alpha * pv.y));
     const double2 v = make_double2(rv.x - alpha * av.x, rv.y - alpha * av.y);
     r2[i] = v;
     acc += v.x * v.x + v.y * v.y;

@@ -135,6 +135,20 @@ __device__ __forceinline__ double block_sum256(double v, double *sh) {
   return r;
 }
 
+// streaming (non-temporal) accesses for arrays that are not re-read while they could still be in the 256 MB Infinity Cache: they
+// should not displace the arrays that the next kernel does re-read
+typedef double mrl_ntv2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld_nt(const double2 *p) {
+  const mrl_ntv2 v = __builtin_nontemporal_load(reinterpret_cast<const mrl_ntv2 *>(p));
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void st_nt(double2 *p, double2 v) {
+  mrl_ntv2 w;
+  w.x = v.x;
+  w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<mrl_ntv2 *>(p));
+}
+
 // scratch management
 int ensure_work(mrl_ctx *ctx, int slot, size_t bytes);
 
