@@ -59,7 +59,10 @@ __device__ __forceinline__ void stc_nt(cplx *base, unsigned boff, cplx v) {
 // The old / new Nhat arrays (and the optional cbar output) are accessed non-temporally: they are not touched again within the
 // substep and must not displace the work arrays from the Infinity Cache (measured at 256^3: fused x pass 155 -> 128 us, the
 // following y pass 54.5 -> 49 us).  NT_W: the same for the mu-hat loads, which are dead after this pass (another 2.5 % of the substep).
-template <int N, int ORDER, bool LINE_IS_X, int PRE, bool SPEC_C, bool NT_W = true, class OffW, class OffD, class OffU>
+// NT_CARRY: the same for the carried spectrum (read and rewritten once per substep).
+// NT_HIST: ... for the old / new Nhat arrays and the cbar output.
+template <int N, int ORDER, bool LINE_IS_X, int PRE, bool SPEC_C, bool NT_W = true, bool NT_CARRY = true, bool NT_HIST = true, class OffW,
+          class OffD, class OffU>
 __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *__restrict__ tw,
                                               const double *__restrict__ kline, const double *__restrict__ ka_ptr,
                                               const double *__restrict__ kb_ptr, bool valid, int q, int l,
@@ -86,7 +89,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
 #pragma unroll
   for (int m = 0; m < P; ++m) v[m] = NT_W ? ldc_nt(a.muhat, offw(m)) : ldc(a.muhat, offw(m));
 #pragma unroll
-  for (int m = 0; m < P; ++m) cp[m] = SPEC_C ? ldc_nt(a.carry, offd(m)) : ldc(a.chat, offw(m));
+  for (int m = 0; m < P; ++m) cp[m] = SPEC_C ? (NT_CARRY ? ldc_nt(a.carry, offd(m)) : ldc(a.carry, offd(m))) : ldc(a.chat, offw(m));
 #pragma unroll
   for (int j = 0; j < CNT; ++j) {
     const int idx = threadIdx.x + j * NT;
@@ -111,7 +114,12 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   }
   if (valid) {
 #pragma unroll
-    for (int m = 0; m < P; ++m) stc_nt(a.Nnew, offd(m), Nv[m]);
+    for (int m = 0; m < P; ++m) {
+      if (NT_HIST)
+        stc_nt(a.Nnew, offd(m), Nv[m]);
+      else
+        stc(a.Nnew, offd(m), Nv[m]);
+    }
   }
 
   // ---- first-order history: PRE of the 16 old Nhat values are requested before the c-hat transform and are in flight
@@ -119,7 +127,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   cplx o1[ORDER == 1 ? P : 1];
   if (ORDER == 1) {
 #pragma unroll
-    for (int m = 0; m < PRE; ++m) o1[ORDER == 1 ? m : 0] = ldc_nt(a.Nold[0], offd(m));
+    for (int m = 0; m < PRE; ++m) o1[ORDER == 1 ? m : 0] = NT_HIST ? ldc_nt(a.Nold[0], offd(m)) : ldc(a.Nold[0], offd(m));
   }
 
   // ---- 3. c-hat: forward transform (unless it is carried over in reciprocal space)
@@ -132,7 +140,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   // ---- 4. ubar = (cbar + (dt b0) N + sum (dt b_i) Nold_i) / (1 - dt*Lbar), the reference's association
   if (ORDER == 1) {
 #pragma unroll
-    for (int m = PRE; m < P; ++m) o1[ORDER == 1 ? m : 0] = ldc_nt(a.Nold[0], offd(m));
+    for (int m = PRE; m < P; ++m) o1[ORDER == 1 ? m : 0] = NT_HIST ? ldc_nt(a.Nold[0], offd(m)) : ldc(a.Nold[0], offd(m));
 #pragma unroll
     for (int m = 0; m < P; ++m) {
       cplx u = cp[m];
@@ -155,7 +163,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
 #pragma unroll
       for (int h = 0; h < ORDER; ++h) {
 #pragma unroll
-        for (int j = 0; j < H; ++j) o[h][j] = ldc_nt(a.Nold[h], offd(half * H + j));
+        for (int j = 0; j < H; ++j) o[h][j] = NT_HIST ? ldc_nt(a.Nold[h], offd(half * H + j)) : ldc(a.Nold[h], offd(half * H + j));
       }
 #pragma unroll
       for (int j = 0; j < H; ++j) {
@@ -179,7 +187,12 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
 
   if ((SPEC_C || a.carry) && valid) {
 #pragma unroll
-    for (int m = 0; m < P; ++m) stc_nt(a.carry, offd(m), cswap(v[m]));
+    for (int m = 0; m < P; ++m) {
+      if (NT_CARRY)
+        stc_nt(a.carry, offd(m), cswap(v[m]));
+      else
+        stc(a.carry, offd(m), cswap(v[m]));
+    }
   }
 
   // ---- 5. inverse transform (unnormalised; 1/N applied by the final z pass)

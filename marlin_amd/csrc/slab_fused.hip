@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
   };
   const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + a.k0 + kl) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
   auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
-  ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, true>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
+  // default cache policy for every stream: on the sub-block-sized working sets of the slab pipeline the non-temporal accesses of
+  // the serial kernel cost 8-30 % (measured per variant with tools/slab_local_bench.py 8 256)
+  ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
 }
 
 template <int N, int ORDER, bool SPEC_C>

@@ -1,8 +1,9 @@
 #!/bin/bash
-# A/B two builds of the library inside one gpurun: tools/ab_libs.sh <dir with old.so new.so> <command...>
+# A/B several builds of the library inside one gpurun: tools/ab_libs.sh <dir with *.so> <command...>; restores the first one
 D=$1; shift
-for v in old new old new; do
-  cp $D/$v.so marlin_amd/lib/libmarlin_hip.so
-  echo "== $v"; "$@" 2>/dev/null | tail -1 | cut -c1-900
+cp marlin_amd/lib/libmarlin_hip.so /tmp/_keep.so
+for v in $(ls $D/*.so) $(ls $D/*.so); do
+  cp $v marlin_amd/lib/libmarlin_hip.so
+  echo "== $(basename $v)"; "$@" 2>/dev/null | tail -1 | cut -c1-900
 done
-cp $D/new.so marlin_amd/lib/libmarlin_hip.so
+cp /tmp/_keep.so marlin_amd/lib/libmarlin_hip.so
