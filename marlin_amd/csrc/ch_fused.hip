@@ -22,7 +22,8 @@ struct FusedArgs {
   const double *kx, *ky, *kz;
 };
 
-template <int N, int ORDER, int PRE, bool SPEC_C, bool NT_W = true>
+// NT: stream the arrays that are not re-read within the substep past the Infinity Cache (ch_fused_body.h); chosen per launch
+template <int N, int ORDER, int PRE, bool SPEC_C, bool NT>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const cplx *__restrict__ tw) {
   constexpr int TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
@@ -38,22 +39,39 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const
   // byte offset of line element m: (i + (q + m*TPL)*inner) * 16, the same in the work and the dense layout
   const unsigned off0 = (unsigned)(iv + (long long)q * a.inner) * 16u, step = (unsigned)(TPL * a.inner) * 16u;
   auto off = [=](int m) { return off0 + (unsigned)m * step; };
-  ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT_W>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, W, X, KX);
+  ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT, NT, NT>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, W, X, KX);
 }
 
-template <int N, int ORDER, bool SPEC_C, int PRE = Plan<N>::P / 2>
-static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
+// The non-temporal variant pays off when the arrays are large against the 256 MB Infinity Cache (a resident old Nhat is a hit
+// that streaming gives away: 128^3 +8 %, 200^3 +0.5 %, 256^3 -10 %, 384^3 -3.5 %, 512^3 -2 % in A/B runs) and when a thread's
+// accesses cover whole 128-B lines (T lines x 16 B; 400^3 with its 96-B pieces: +7 %): instantiated for the long x axes only.
+template <int N>
+constexpr bool nt_capable() {
+  return (N == 256 || N == 384 || N == 512) && (Plan<N>::T * 16) % 128 == 0;
+}
+
+template <int N, int ORDER, bool SPEC_C, bool NT, int PRE>
+static int launch_xfused_v(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
   if (!attr) {
-    MRL_TRY((set_lds_attr(ctx, k_ch_xfused<N, ORDER, PRE, SPEC_C>, lds)));
+    MRL_TRY((set_lds_attr(ctx, k_ch_xfused<N, ORDER, PRE, SPEC_C, NT>, lds)));
     attr = true;
   }
   constexpr int T = Plan<N>::T;
   const long long nb = (a.inner + T - 1) / T;
-  hipLaunchKernelGGL((k_ch_xfused<N, ORDER, PRE, SPEC_C>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
+  hipLaunchKernelGGL((k_ch_xfused<N, ORDER, PRE, SPEC_C, NT>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
+}
+
+template <int N, int ORDER, bool SPEC_C, int PRE = Plan<N>::P / 2>
+static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
+  if constexpr (nt_capable<N>()) {
+    const double array_bytes = 16.0 * (double)N * (double)a.inner;
+    if (array_bytes >= 96.0e6) return launch_xfused_v<N, ORDER, SPEC_C, true, PRE>(ctx, a, tw);
+  }
+  return launch_xfused_v<N, ORDER, SPEC_C, false, PRE>(ctx, a, tw);
 }
 
 }  // namespace p2

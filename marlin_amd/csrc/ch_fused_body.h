@@ -61,7 +61,7 @@ __device__ __forceinline__ void stc_nt(cplx *base, unsigned boff, cplx v) {
 // following y pass 54.5 -> 49 us).  NT_W: the same for the mu-hat loads, which are dead after this pass (another 2.5 % of the substep).
 // NT_CARRY: the same for the carried spectrum (read and rewritten once per substep).
 // NT_HIST: ... for the old / new Nhat arrays and the cbar output.
-template <int N, int ORDER, bool LINE_IS_X, int PRE, bool SPEC_C, bool NT_W = true, bool NT_CARRY = true, bool NT_HIST = true, class OffW,
+template <int N, int ORDER, bool LINE_IS_X, int PRE, bool SPEC_C, bool NT_W, bool NT_CARRY, bool NT_HIST, class OffW,
           class OffD, class OffU>
 __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *__restrict__ tw,
                                               const double *__restrict__ kline, const double *__restrict__ ka_ptr,

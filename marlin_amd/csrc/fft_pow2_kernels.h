@@ -175,8 +175,8 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv(const cplx *__restrict
       const double *d0 = dotv + (2 * L) * N + q;
 #pragma unroll
       for (int m = 0; m < P; ++m) {
-        pa[DOT ? m : 0] = __builtin_nontemporal_load(d0 + m * TPL);       // (the CG direction: streamed)
-        pb[DOT ? m : 0] = __builtin_nontemporal_load(d0 + N + m * TPL);
+        pa[DOT ? m : 0] = d0[m * TPL];
+        pb[DOT ? m : 0] = d0[N + m * TPL];
       }
     }
 #pragma unroll

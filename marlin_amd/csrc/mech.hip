@@ -162,7 +162,10 @@ __global__ void __launch_bounds__(256) k_mech_tangent(const double *__restrict__
 }
 
 // field-major, two grid points per thread: every component stream is read / written 16 B per lane
-template <bool DIR>
+// NT: stream F, K, mu (read once per CG iteration) and the direction store past the Infinity Cache -- pays off when the 9-field
+// vectors are large against its 256 MB (128^3: 151 MB per vector, 0.771 -> 0.737 ms per iteration), loses where they would have
+// stayed resident (64^3), so the launchers choose per size
+template <bool DIR, bool NT>
 __global__ void __launch_bounds__(256) k_mech_tangent_fm2(const double *__restrict__ F, const double *__restrict__ K,
                                                            const double *__restrict__ mu, double *__restrict__ dF,
                                                            int bcast, double *__restrict__ out, long long npts,
@@ -176,7 +179,8 @@ __global__ void __launch_bounds__(256) k_mech_tangent_fm2(const double *__restri
     Mat<3> f[2], d[2];
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-      const double2 fv = ld_nt(reinterpret_cast<const double2 *>(F + (long long)c * npts) + h);   // streamed once per CG iteration
+      const double2 *fp = reinterpret_cast<const double2 *>(F + (long long)c * npts) + h;
+      const double2 fv = NT ? ld_nt(fp) : *fp;
       f[0].a[c / 3][c % 3] = fv.x;
       f[1].a[c / 3][c % 3] = fv.y;
       double2 dv;
@@ -188,12 +192,17 @@ __global__ void __launch_bounds__(256) k_mech_tangent_fm2(const double *__restri
       if (DIR) {
         const double2 rv = reinterpret_cast<const double2 *>(r + (long long)c * npts)[h];
         dv = make_double2(rv.x + beta * dv.x, rv.y + beta * dv.y);
-        st_nt(reinterpret_cast<double2 *>(dF + (long long)c * npts) + h, dv);   // p: next read at the far end of the Gamma passes
+        double2 *pp = reinterpret_cast<double2 *>(dF + (long long)c * npts) + h;   // p: next read at the far end of the Gamma passes
+        if (NT)
+          st_nt(pp, dv);
+        else
+          *pp = dv;
       }
       d[0].a[c / 3][c % 3] = dv.x;
       d[1].a[c / 3][c % 3] = dv.y;
     }
-    const double2 Kv = ld_nt(reinterpret_cast<const double2 *>(K) + h), mv = ld_nt(reinterpret_cast<const double2 *>(mu) + h);
+    const double2 *Kp = reinterpret_cast<const double2 *>(K) + h, *mp = reinterpret_cast<const double2 *>(mu) + h;
+    const double2 Kv = NT ? ld_nt(Kp) : *Kp, mv = NT ? ld_nt(mp) : *mp;
     const Mat<3> o0 = svk_tangent<3>(f[0], d[0], Kv.x, mv.x);
     const Mat<3> o1 = svk_tangent<3>(f[1], d[1], Kv.y, mv.y);
 #pragma unroll
@@ -300,6 +309,7 @@ __global__ void __launch_bounds__(256) k_cg_init(const double *__restrict__ b, c
 }
 
 // alpha = S[i_rz] / S[i_pAp] ; x += alpha p ; r -= alpha Ap ; partial sum r.r      (16 B per lane per access)
+template <bool NT>
 __global__ void __launch_bounds__(256) k_cg_update(const double *__restrict__ S, int i_rz, int i_pAp,
                                                     double *__restrict__ x, double *__restrict__ r,
                                                     const double *__restrict__ p, const double *__restrict__ Ap,
@@ -312,8 +322,12 @@ __global__ void __launch_bounds__(256) k_cg_update(const double *__restrict__ S,
   double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
   const double2 *p2 = reinterpret_cast<const double2 *>(p), *A2 = reinterpret_cast<const double2 *>(Ap);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256) {
-    const double2 xv = ld_nt(x2 + i), pv = ld_nt(p2 + i), rv = r2[i], av = A2[i];   // x, p: not re-read before ~3 GB of other traffic
-    st_nt(x2 + i, make_double2(xv.x + alpha * pv.x, xv.y + alpha * pv.y));
+    const double2 xv = NT ? ld_nt(x2 + i) : x2[i], pv = NT ? ld_nt(p2 + i) : p2[i], rv = r2[i], av = A2[i];   // NT: x, p are not re-read
+    const double2 xn = make_double2(xv.x + alpha * pv.x, xv.y + alpha * pv.y);                               // before ~3 GB of other traffic
+    if (NT)
+      st_nt(x2 + i, xn);
+    else
+      x2[i] = xn;
     const double2 v = make_double2(rv.x - alpha * av.x, rv.y - alpha * av.y);
     r2[i] = v;
     acc += v.x * v.x + v.y * v.y;
@@ -370,6 +384,9 @@ static inline int grid_for(long long n) {
   return (int)b;
 }
 
+// 9-field vectors of at least 96 MB do not survive in the 256 MB Infinity Cache from one use to the next: stream them
+static inline bool mech_stream_vectors(long long npts) { return 72.0 * (double)npts >= 96.0e6; }
+
 // serial = false: pointwise operators, valid on the local slab of any context
 static int check_dim(mrl_ctx *ctx, const char *what, bool serial = true) {
   if (ctx->dim != 2 && ctx->dim != 3)
@@ -408,8 +425,14 @@ int tangent_launch(mrl_ctx *ctx, const double *F, const double *K, const double 
   const dim3 g(grid_for(npts)), b(256);
   double *d = const_cast<double *>(dF);  // only written by the DIR variant
   if (ctx->dim == 3 && soa)
-    hipLaunchKernelGGL((k_mech_tangent_fm2<false>), dim3(grid_for(npts / 2)), b, 0, ctx->stream, F, K, mu, d,
-                       bcast ? 1 : 0, out, npts, nullptr, nullptr, 0, 0);
+  {
+    if (mech_stream_vectors(npts))
+      hipLaunchKernelGGL((k_mech_tangent_fm2<false, true>), dim3(grid_for(npts / 2)), b, 0, ctx->stream, F, K, mu, d,
+                         bcast ? 1 : 0, out, npts, nullptr, nullptr, 0, 0);
+    else
+      hipLaunchKernelGGL((k_mech_tangent_fm2<false, false>), dim3(grid_for(npts / 2)), b, 0, ctx->stream, F, K, mu, d,
+                         bcast ? 1 : 0, out, npts, nullptr, nullptr, 0, 0);
+  }
   else if (ctx->dim == 3)
     hipLaunchKernelGGL((k_mech_tangent<3, false, false>), g, b, 0, ctx->stream, F, K, mu, d, bcast ? 1 : 0, out, npts,
                        nullptr, nullptr, 0, 0);
@@ -428,8 +451,14 @@ int tangent_dir_launch(mrl_ctx *ctx, const double *F, const double *K, const dou
   ProfScope ps(ctx, "mech_tangent_dir", (double)npts * 8.0 * (5 * dd + 2));
   const dim3 g(grid_for(npts)), b(256);
   if (ctx->dim == 3 && soa)
-    hipLaunchKernelGGL((k_mech_tangent_fm2<true>), dim3(grid_for(npts / 2)), b, 0, ctx->stream, F, K, mu, p, 0, out, npts,
-                       r, S, i_num, i_den);
+  {
+    if (mech_stream_vectors(npts))
+      hipLaunchKernelGGL((k_mech_tangent_fm2<true, true>), dim3(grid_for(npts / 2)), b, 0, ctx->stream, F, K, mu, p, 0, out, npts,
+                         r, S, i_num, i_den);
+    else
+      hipLaunchKernelGGL((k_mech_tangent_fm2<true, false>), dim3(grid_for(npts / 2)), b, 0, ctx->stream, F, K, mu, p, 0, out, npts,
+                         r, S, i_num, i_den);
+  }
   else if (ctx->dim == 3)
     hipLaunchKernelGGL((k_mech_tangent<3, false, true>), g, b, 0, ctx->stream, F, K, mu, p, 0, out, npts, r, S, i_num, i_den);
   else
@@ -595,7 +624,10 @@ int mrl_cg_update(mrl_ctx *ctx, double alpha, double *d_x, double *d_r, const do
   nb = nb < 1 ? 1 : (nb > kRedBlocks ? kRedBlocks : nb);
   {
     ProfScope ps(ctx, "cg_update", 48.0 * (double)n);
-    hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, ctx->stream, S, 0, 1, d_x, d_r, d_p, d_Ap, (long long)n, ctx->d_red);
+    if (mech_stream_vectors(n / 9))
+      hipLaunchKernelGGL(k_cg_update<true>, dim3(nb), dim3(256), 0, ctx->stream, S, 0, 1, d_x, d_r, d_p, d_Ap, (long long)n, ctx->d_red);
+    else
+      hipLaunchKernelGGL(k_cg_update<false>, dim3(nb), dim3(256), 0, ctx->stream, S, 0, 1, d_x, d_r, d_p, d_Ap, (long long)n, ctx->d_red);
     MRL_HIP(ctx, hipGetLastError());
   }
   double *slot = ctx->d_red + kScalarBase;
@@ -704,7 +736,10 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
         }
         {
           ProfScope ps(ctx, "cg_update_x_r", 48.0 * n);
-          hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
+          if (mech_stream_vectors(npts))
+            hipLaunchKernelGGL(k_cg_update<true>, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
+          else
+            hipLaunchKernelGGL(k_cg_update<false>, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
           MRL_TRY(reduce_finalize(ctx, nb, 1, S + i_new));
         }
         MRL_TRY(read_scalars(ctx, S + i_new, 1, h));  // the one host sync of the iteration
