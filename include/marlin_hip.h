@@ -146,6 +146,23 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
                    double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt,
                    double *d_cbar, double *d_mu, int carry);
 
+/* `count` consecutive substeps: the substep loop of TensorSolver::computeBuffer (src/tensor_solver/TensorSolver.C:93-109) for the
+ * Cahn-Hilliard system, i.e. count x { AdamsBashforthMoulton::substep ; advanceState between substeps }.  The reference's
+ * examples run 1000 substeps per solver call; inside the loop the real field c of an intermediate substep is not visible to
+ * anything (the buffer is rebound every substep, outputs and postprocessors run at the end of the time step), so on planned
+ * shapes the inverse z pass of substep k and the forward z pass of substep k+1 are one kernel and that field never reaches HBM
+ * (bit-identical results; 12 % less traffic at 256^3).
+ *   d_Nhat_ring : ring_size >= predictor_order arrays (complex, reciprocal grid).  *head = slot of the newest history entry
+ *                 (Nhat_old[0]), *n_old = number of valid history entries.  A substep uses order = min(*n_old, predictor_order-1),
+ *                 writes its Nhat into slot (*head + 1) % ring_size, and with advance != 0 that slot becomes the head before
+ *                 the next substep (TensorBuffer<T>::advanceState; pass 0 while timeStep() <= 1, TensorProblem.C:455).
+ *                 On return the newest Nhat is in slot (*head + 1) % ring_size -- the caller's own advanceState makes it the head.
+ *   d_mu        : optional, f'(c) of the last substep's input field (what the mu buffer holds after the call).
+ * c_in and c_out must not alias when count > 1 on unplanned shapes. */
+int mrl_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_c_out, double *const *d_Nhat_ring,
+                    int ring_size, int *head, int *n_old, int predictor_order, int count, int advance, double sub_dt,
+                    double *d_mu);
+
 /* ReciprocalLaplacianFactor (power = 1: -k^2 * factor, ReciprocalLaplacianFactor.C:28-31) and
  * ReciprocalLaplacianSquareFactor (power = 2: k^2 * k^2 * factor, ReciprocalLaplacianSquareFactor.C:28-32) as real
  * arrays on the local reciprocal grid, for solvers that take their linear operator as a buffer. */

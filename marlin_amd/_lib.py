@@ -80,6 +80,8 @@ SIGNATURES = {
     "mrl_slab_inv_finish": (_i32, [_vp, _vp, _vp]),
     "mrl_ch_mu": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _i64]),
     "mrl_ch_substep": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _vp, _pp, _i32, _dbl, _vp, _vp, _i32]),
+    "mrl_ch_substeps": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _pp, _i32, C.POINTER(_i32), C.POINTER(_i32), _i32, _i32, _i32,
+                        _dbl, _vp]),
     "mrl_kspace_abm": (_i32, [_vp, _vp, _vp, _pp, C.POINTER(_dbl), _i32, _vp, _dbl, _i64]),
     "mrl_kspace_coupled": (_i32, [_vp, _i32, _pp, _pp, _pp, C.POINTER(_dbl), C.POINTER(_i32), _pp, _dbl, _i32, _i64]),
     "mrl_slab_fast_path": (_i32, [_vp]),

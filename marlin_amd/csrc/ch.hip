@@ -294,6 +294,8 @@ int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const doub
   return ch_kspace_sub_launch(ctx, cp, cbar, mubar, Nhat, ubar, Nold, order, sub_dt, 0, ctx->nrec[2]);
 }
 
+int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *const *ring, int ring_size,
+                      int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu);
 // fast fused path (ch_fused.hip); returns MRL_ERR_UNSUPPORTED when the shape has no fast kernels
 int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new,
                      const double *const *Nhat_old, int order, double sub_dt, double *cbar, double *mu, int carry);
@@ -424,6 +426,45 @@ int mrl_kspace_coupled(mrl_ctx *ctx, int nvar, double *const *d_ubar_out, const 
     default: hipLaunchKernelGGL(k_kspace_coupled<4>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
   }
   MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+int mrl_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_c_out, double *const *d_Nhat_ring,
+                    int ring_size, int *head, int *n_old, int predictor_order, int count, int advance, double sub_dt,
+                    double *d_mu) {
+  if (!ctx) return MRL_ERR_INVALID;
+  ChP cp;
+  MRL_TRY(ch_check_params(ctx, p, cp));
+  const int pred = predictor_order - 1;
+  if (!d_c_in || !d_c_out || !d_Nhat_ring || !head || !n_old || count < 1)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substeps: bad argument");
+  if (predictor_order < 1 || predictor_order > 5) return set_error(ctx, MRL_ERR_INVALID, "predictor order %d out of range", predictor_order);
+  if (ring_size < pred + 1 || *head < 0 || *head >= ring_size || *n_old < 0 || *n_old > pred)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substeps: history ring of %d arrays needed (head %d, n_old %d)", pred + 1, *head, *n_old);
+  for (int i = 0; i < ring_size; ++i)
+    if (!d_Nhat_ring[i]) return set_error(ctx, MRL_ERR_INVALID, "history ring entry %d missing", i);
+  if (ctx->slab) return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substeps on a slab context: use the mrl_slab_ch_* stages");
+  int rc = ch_substeps_fused(ctx, cp, d_c_in, d_c_out, d_Nhat_ring, ring_size, head, n_old, pred, count, advance, sub_dt, d_mu);
+  if (rc != MRL_ERR_UNSUPPORTED) return rc;
+  // generic shapes: one mrl_ch_substep per substep, the intermediate fields ping-pong between d_c_out and a scratch array
+  const long long nreal = real_count_local(ctx);
+  MRL_TRY(ensure_work(ctx, 15, sizeof(double) * (size_t)(nreal + 2)));   // (slot 15: a slab slot, free on serial contexts)
+  double *tmp = ctx->d_work[15];
+  const double *src = d_c_in;
+  for (int k = 0; k < count; ++k) {
+    double *dst = ((count - 1 - k) % 2 == 0) ? d_c_out : tmp;   // the last substep lands in d_c_out
+    const int order = *n_old < pred ? *n_old : pred;
+    const int slot_new = (*head + 1) % ring_size;
+    const double *old[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < order; ++i) old[i] = d_Nhat_ring[((*head - i) % ring_size + ring_size) % ring_size];
+    MRL_TRY(mrl_ch_substep(ctx, p, src, dst, d_Nhat_ring[slot_new], old, order, sub_dt, nullptr, k == count - 1 ? d_mu : nullptr,
+                           MRL_CARRY_NONE));
+    src = dst;
+    if (advance && k < count - 1) {
+      *head = slot_new;
+      if (*n_old < pred) *n_old += 1;
+    }
+  }
   return MRL_OK;
 }
 

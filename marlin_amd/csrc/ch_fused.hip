@@ -307,4 +307,89 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
   return MRL_OK;
 }
 
+// `count` consecutive substeps of one TensorSolver::computeBuffer call (TensorSolver.C:93-109): between two substeps the z inverse
+// of substep k and the z forward of substep k + 1 are ONE kernel (k_z_inv_fwd) and the intermediate real field never touches HBM.
+// ring: `ring_size` = pred + 1 Nhat arrays; *head = slot of the newest history entry, *n_old = valid history entries;
+// the substep writes its Nhat into slot (*head + 1) % ring_size and, if `advance`, that slot becomes the head before the next
+// substep (TensorBuffer<T>::advanceState between substeps).  After the call the newest Nhat is in slot (*head + 1) % ring_size.
+int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *const *ring, int ring_size,
+                      int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu) {
+  if (!fast_path_ok(ctx)) return MRL_ERR_UNSUPPORTED;
+  const Geo g = geo_of(ctx);
+  const long long nx = g.nx, ny = g.ny, nz = g.nz, nzc = g.nzc;
+  if ((nx * ny) % 2) return MRL_ERR_UNSUPPORTED;
+  const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
+  MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nspec));
+  MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nspec));
+  cplx *w_c = reinterpret_cast<cplx *>(ctx->d_work[1]);
+  cplx *w_mu = reinterpret_cast<cplx *>(ctx->d_work[2]);
+  p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
+  const double h = 16.0 * nspec;
+  const double scale = 1.0 / ((double)nx * (double)ny * (double)nz);
+  for (int k = 0; k < count; ++k) {
+    double *mu_k = (k == count - 1) ? mu : nullptr;   // the buffer `mu` holds f'(c) of the last substep's input field
+    if (k == 0) {
+      ProfScope ps(ctx, "ch_A_z_fwd", 8.0 * nreal + 2.0 * h + (mu_k ? 8.0 * nreal : 0.0));
+      if (cp.family == MRL_FE_PARSED) {
+        MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 1, c_in, w_c, w_mu, mu_k, nx * ny));
+      } else if (cp.family == MRL_FE_DOUBLE_WELL) {
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_c, w_mu, mu_k, chp, nx * ny))));
+      } else {
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, w_c, w_mu, mu_k, chp, nx * ny))));
+      }
+    } else {
+      ProfScope ps(ctx, "ch_EA_z_inv_fwd", 3.0 * h + (mu_k ? 8.0 * nreal : 0.0));
+      if (cp.family == MRL_FE_PARSED) {
+        MRL_TRY(parsed_z_inv_fwd_launch(ctx, cp.parsed, (int)nz, w_c, w_c, w_mu, mu_k, scale, nx * ny / 2));
+      } else if (cp.family == MRL_FE_DOUBLE_WELL) {
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_DOUBLE_WELL>(ctx, w_c, w_c, w_mu, mu_k, chp, scale, nx * ny / 2))));
+      } else {
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_PFHUB>(ctx, w_c, w_c, w_mu, mu_k, chp, scale, nx * ny / 2))));
+      }
+    }
+    {
+      ProfScope ps(ctx, "ch_B_y_fwd", 4.0 * h);
+      MRL_TRY(pass_axis(ctx, 1, false, 2, w_c, w_mu, w_c, w_mu, true));
+    }
+    const int order = *n_old < pred ? *n_old : pred;
+    const int slot_new = (*head + 1) % ring_size;
+    {
+      ProfScope ps(ctx, "ch_C_x_fused", (4.0 + order) * h);
+      p2::FusedArgs a{};
+      a.c.chat = w_c;
+      a.c.muhat = w_mu;
+      a.c.ubar = w_c;
+      a.c.Nnew = reinterpret_cast<cplx *>(ring[slot_new]);
+      for (int i = 0; i < order; ++i) a.c.Nold[i] = reinterpret_cast<const cplx *>(ring[((*head - i) % ring_size + ring_size) % ring_size]);
+      for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaAB[order][i];
+      a.inner = ny * nzc;
+      a.nzc = (int)nzc;
+      a.kx = g.kx;
+      a.ky = g.ky;
+      a.kz = g.kz;
+      a.c.M = cp.M;
+      a.c.kappa = cp.kappa;
+      a.c.dt = sub_dt;
+      switch (order) {
+        case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0, false>(ctx, a, g.tw_x)))); break;
+        case 1: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 1, false>(ctx, a, g.tw_x)))); break;
+        case 2: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 2, false>(ctx, a, g.tw_x)))); break;
+        case 3: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 3, false>(ctx, a, g.tw_x)))); break;
+        default: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 4, false>(ctx, a, g.tw_x)))); break;
+      }
+    }
+    {
+      ProfScope ps(ctx, "ch_D_y_inv", 2.0 * h);
+      MRL_TRY(pass_axis(ctx, 1, true, 1, w_c, nullptr, w_c, nullptr));
+    }
+    if (advance && k < count - 1) {   // TensorSolver.C:105-106
+      *head = slot_new;
+      if (*n_old < pred) *n_old += 1;
+    }
+  }
+  ProfScope ps(ctx, "ch_E_z_inv", h + 8.0 * nreal);
+  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w_c, c_out, scale, nx * ny / 2))));
+  return MRL_OK;
+}
+
 }  // namespace mrl

@@ -786,37 +786,41 @@ static int build_mu_function(mrl_parsed *p, std::string &out) {
   return MRL_OK;
 }
 
-int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const double *in, cplx *out0, cplx *out1, double *mu_out,
-                        long long nlines) {
-  // lines per workgroup / threads per workgroup of Plan<N> (fft_pow2.h)
-  int T = 0, NT = 0;
+// lines per workgroup / threads per workgroup of Plan<N> (fft_pow2.h)
+static int plan_shape(mrl_ctx *ctx, int N, int *T, int *NT) {
   switch (N) {
-    case 32: case 64: case 128: case 256: case 512: case 1024: T = 4096 / N; NT = 256; break;
-    case 40: T = 64; NT = 256; break;
-    case 50: T = 51; NT = 255; break;
-    case 80: T = 32; NT = 256; break;
-    case 100: T = 25; NT = 250; break;
-    case 200: T = 12; NT = 240; break;
-    case 250: T = 10; NT = 250; break;
-    case 400: T = 6; NT = 240; break;
-    case 500: T = 5; NT = 250; break;
-    case 1000: T = 2; NT = 200; break;
-    case 48: T = 64; NT = 256; break;
-    case 96: T = 32; NT = 256; break;
-    case 144: T = 21; NT = 252; break;
-    case 192: T = 16; NT = 256; break;
-    case 384: T = 8; NT = 256; break;
-    case 768: T = 4; NT = 256; break;
+    case 32: case 64: case 128: case 256: case 512: case 1024: *T = 4096 / N; *NT = 256; break;
+    case 40: *T = 64; *NT = 256; break;
+    case 50: *T = 51; *NT = 255; break;
+    case 80: *T = 32; *NT = 256; break;
+    case 100: *T = 25; *NT = 250; break;
+    case 200: *T = 12; *NT = 240; break;
+    case 250: *T = 10; *NT = 250; break;
+    case 400: *T = 6; *NT = 240; break;
+    case 500: *T = 5; *NT = 250; break;
+    case 1000: *T = 2; *NT = 200; break;
+    case 48: *T = 64; *NT = 256; break;
+    case 96: *T = 32; *NT = 256; break;
+    case 144: *T = 21; *NT = 252; break;
+    case 192: *T = 16; *NT = 256; break;
+    case 384: *T = 8; *NT = 256; break;
+    case 768: *T = 4; *NT = 256; break;
     default: return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
   }
-  if (mode != 1 && mode != 2) return set_error(ctx, MRL_ERR_INVALID, "parsed z pass: mode %d", mode);
+  return MRL_OK;
+}
+
+// run-time compiled z passes with the generated chemical potential: mode 1 = k_z_fwd<N, 1, PARSED>, 2 = k_z_fwd<N, 2, PARSED>,
+// 3 = k_z_inv_fwd<N, PARSED>; cached per (N, mode)
+static int parsed_z_kernel(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, hipFunction_t *fn_out) {
+  if (mode < 1 || mode > 3) return set_error(ctx, MRL_ERR_INVALID, "parsed z pass: mode %d", mode);
   const int key = N * 4 + mode;
   auto it = p->zfwd.find(key);
   if (it == p->zfwd.end()) {
     std::string mu_fn;
     if (build_mu_function(p, mu_fn) != MRL_OK) return set_error(ctx, MRL_ERR_INVALID, "expression: %s", p->err.c_str());
     // device-only translation unit: vector types and the public enum values, the embedded kernel headers, the generated
-    // chemical potential; k_z_fwd<N, 1, MRL_FE_PARSED> is instantiated through a name expression
+    // chemical potential; the kernel is instantiated through a name expression
     std::string src =
         "typedef double2 cplx;\n"
         "#define MRL_FE_DOUBLE_WELL 0\n#define MRL_FE_PFHUB 1\n#define MRL_FE_PARSED 2\n"
@@ -826,7 +830,8 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const doub
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "mrl_z_fwd_parsed.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
       return set_error(ctx, MRL_ERR_HIP, "hiprtcCreateProgram failed");
-    const std::string name = "mrl::p2::k_z_fwd<" + std::to_string(N) + ", " + std::to_string(mode) + ", 2>";
+    const std::string name = mode == 3 ? "mrl::p2::k_z_inv_fwd<" + std::to_string(N) + ", 2>"
+                                       : "mrl::p2::k_z_fwd<" + std::to_string(N) + ", " + std::to_string(mode) + ", 2>";
     hiprtcAddNameExpression(prog, name.c_str());
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
     if (hiprtcCompileProgram(prog, 3, opts) != HIPRTC_SUCCESS) {
@@ -854,20 +859,54 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const doub
       return set_error(ctx, MRL_ERR_HIP, "loading the run-time compiled z pass failed");
     it = p->zfwd.emplace(key, std::make_pair(mod, fn)).first;
   }
-  // the argument block of k_z_fwd(const double*, cplx*, cplx*, double*, ChDev, long long, const cplx*)
-  struct ChDevHost {
-    int family;
-    double c0, c1, c2;
-    double k[8];
-  } chp{};
+  *fn_out = it->second.second;
+  return MRL_OK;
+}
+
+struct ChDevHost {  // = p2::ChDev
+  int family;
+  double c0, c1, c2;
+  double k[8];
+};
+static ChDevHost parsed_chdev(const mrl_parsed *p) {
+  ChDevHost chp{};
   chp.family = MRL_FE_PARSED;
   for (size_t i = 0; i < p->const_values.size(); ++i) chp.k[i] = p->const_values[i];
+  return chp;
+}
+
+int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const double *in, cplx *out0, cplx *out1, double *mu_out,
+                        long long nlines) {
+  int T = 0, NT = 0;
+  MRL_TRY(plan_shape(ctx, N, &T, &NT));
+  if (mode != 1 && mode != 2) return set_error(ctx, MRL_ERR_INVALID, "parsed z pass: mode %d", mode);
+  hipFunction_t fn;
+  MRL_TRY(parsed_z_kernel(ctx, p, N, mode, &fn));
+  // the argument block of k_z_fwd(const double*, cplx*, cplx*, double*, ChDev, long long, const cplx*)
+  ChDevHost chp = parsed_chdev(p);
   const cplx *tw = ctx->ax[2].d_tw;
   void *params[] = {&in, &out0, &out1, &mu_out, &chp, &nlines, &tw};
-  const int LPB = T, LP = N + N / 16;
+  const int LP = N + N / 16;
   const size_t lds = sizeof(cplx) * (size_t)(N + T * LP);
-  const long long nb = (nlines + LPB - 1) / LPB;
-  MRL_HIP(ctx, hipModuleLaunchKernel(it->second.second, (unsigned)nb, 1, 1, (unsigned)NT, 1, 1, (unsigned)lds, ctx->stream, params, nullptr));
+  const long long nb = (nlines + T - 1) / T;
+  MRL_HIP(ctx, hipModuleLaunchKernel(fn, (unsigned)nb, 1, 1, (unsigned)NT, 1, 1, (unsigned)lds, ctx->stream, params, nullptr));
+  return MRL_OK;
+}
+
+// k_z_inv_fwd<N, PARSED>(const cplx*, cplx*, cplx*, double*, ChDev, double, long long, const cplx*); nlines = line pairs
+int parsed_z_inv_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const cplx *in, cplx *out0, cplx *out1, double *mu_out,
+                            double scale, long long nlines) {
+  int T = 0, NT = 0;
+  MRL_TRY(plan_shape(ctx, N, &T, &NT));
+  hipFunction_t fn;
+  MRL_TRY(parsed_z_kernel(ctx, p, N, 3, &fn));
+  ChDevHost chp = parsed_chdev(p);
+  const cplx *tw = ctx->ax[2].d_tw;
+  void *params[] = {&in, &out0, &out1, &mu_out, &chp, &scale, &nlines, &tw};
+  const int LP = N + N / 16;
+  const size_t lds = sizeof(cplx) * (size_t)(N + T * LP);
+  const long long nb = (nlines + T - 1) / T;
+  MRL_HIP(ctx, hipModuleLaunchKernel(fn, (unsigned)nb, 1, 1, (unsigned)NT, 1, 1, (unsigned)lds, ctx->stream, params, nullptr));
   return MRL_OK;
 }
 

@@ -206,6 +206,96 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv(const cplx *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// z inverse of substep n fused with the z forward (CH mode) of substep n + 1: rows 2L, 2L+1 of the half spectrum `in`
+// (ubar after the inverse x and y passes) -> the two real lines c = irfft(.) * scale stay in registers -> mu = f'(c) ->
+// each line packed as c + i*mu and transformed forward -> rows 2L, 2L+1 of out0 (c-hat_z) and out1 (mu-hat_z).
+// Between two substeps of one TensorSolver::computeBuffer call the real field c is neither written nor read again (the
+// reference rebinds the buffer every substep and only the last one is visible outside the solver): 268 MB of the 673 MB that
+// the two separate passes move at 256^3.  in == out0 is allowed (a workgroup reads its rows before it writes them).
+// Same arithmetic, in the same order, as k_z_inv followed by k_z_fwd<CH>: bit-identical fields.
+template <int N, int FAM>
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv_fwd(const cplx *__restrict__ in, cplx *__restrict__ out0,
+                                                                cplx *__restrict__ out1, double *__restrict__ mu_out, ChDev chp,
+                                                                double scale, long long nlines, const cplx *__restrict__ tw) {
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = Plan<N>::T, NZC = N / 2 + 1;
+  using Map = MapLine<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
+  const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
+  const bool valid = L < nlines;
+  TwRegs<N> twr;
+  tw_issue<N>(twr, tw);
+  cplx v[P];
+  {
+    const cplx *A = in + (2 * (valid ? L : 0)) * NZC;
+    const cplx *B = A + NZC;
+    cplx av[P], bv[P];
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      const int p = q + m * TPL;
+      const int k = (p <= N / 2) ? p : N - p;
+      av[m] = A[k];
+      bv[m] = B[k];
+    }
+    tw_commit<N>(twr, W);
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      const int p = q + m * TPL;
+      const bool lo = p <= N / 2;
+      const int k = lo ? p : N - p;
+      cplx a = av[m], b = bv[m];
+      if (k == 0 || k == N / 2) {
+        a.y = 0.0;
+        b.y = 0.0;
+      }
+      const cplx x = lo ? make_double2(a.x - b.y, a.y + b.x) : make_double2(a.x + b.y, b.x - a.y);
+      v[m] = cswap(x);
+    }
+  }
+  fft_line<N, Map>(v, q, l, X, W);
+  double cb[P];  // second line (row 2L+1), kept while the first one is transformed
+  {
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      const double ca = v[m].y * scale;
+      cb[m] = v[m].x * scale;
+      v[m] = make_double2(ca, mu_eval<FAM>(chp, ca));
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half == 1) {
+#pragma unroll
+      for (int m = 0; m < P; ++m) v[m] = make_double2(cb[m], mu_eval<FAM>(chp, cb[m]));
+    }
+    if (mu_out && valid) {
+      double *pm = mu_out + (2 * L + half) * N + q;
+#pragma unroll
+      for (int m = 0; m < P; ++m) pm[m * TPL] = v[m].y;
+    }
+    fft_line<N, Map>(v, q, l, X, W);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
+    __syncthreads();
+    if (valid) {
+      cplx *o0 = out0 + (2 * L + half) * NZC, *o1 = out1 + (2 * L + half) * NZC;
+#pragma unroll
+      for (int m = 0; m <= P / 2; ++m) {
+        const int k = q + m * TPL;
+        if (k > N / 2) break;
+        const cplx xk = v[m];
+        const cplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
+        o0[k] = make_double2(0.5 * (xk.x + xn.x), 0.5 * (xk.y - xn.y));
+        o1[k] = make_double2(0.5 * (xk.y + xn.y), -0.5 * (xk.x - xn.x));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // strided c2c pass.  Arrays are [outer][N][inner] complex (inner contiguous); a workgroup owns
 // T = 4096/N consecutive `inner` positions of one `outer` slice for all N points of the axis.
 struct PassArgs {

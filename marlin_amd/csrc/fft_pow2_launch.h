@@ -48,6 +48,24 @@ inline int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale,
   return MRL_OK;
 }
 
+// nlines = number of line PAIRS (= complex inverse transforms)
+template <int N, int FAM>
+inline int launch_z_inv_fwd(mrl_ctx *ctx, const cplx *in, cplx *o0, cplx *o1, double *mu, const ChDev &chp, double scale,
+                            long long nlines) {
+  static bool attr = false;
+  constexpr size_t lds = lds_line<N>();
+  if (!attr) {
+    MRL_TRY((set_lds_attr(ctx, k_z_inv_fwd<N, FAM>, lds)));
+    attr = true;
+  }
+  constexpr int LPB = Plan<N>::T;
+  const long long nb = (nlines + LPB - 1) / LPB;
+  hipLaunchKernelGGL((k_z_inv_fwd<N, FAM>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, scale,
+                     nlines, ctx->ax[2].d_tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
 // z inverse that also leaves sum(out * dotv) as one partial per workgroup in `partial`; *nblocks = their number
 template <int N>
 inline int launch_z_inv_dot(mrl_ctx *ctx, const cplx *in, double *out, double scale, long long nlines, const double *dotv,

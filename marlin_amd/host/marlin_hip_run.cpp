@@ -70,6 +70,7 @@ static int run_cahnhilliard(DomainAction & domain, const std::string & out)
   p.ch.mobility = argd("mobility", 0.2);  // ReciprocalLaplacianFactor factor
   p.ch.kappa = argd("kappa", -0.001);     // ReciprocalLaplacianSquareFactor factor
   p.spectral_carry = argi("spectral_carry", 0) != 0;
+  p.substep_calls = argi("substep_calls", 0) != 0;
   // expression=... : the [mu] ParsedCompute block of the input file (expression + derivatives = c) instead of a
   // built-in family; the derivative is taken symbolically and compiled into the solver's forward z pass
   mrl_parsed * parsed = nullptr;

@@ -109,6 +109,13 @@ public:
     return _u_old;
   }
   void clearStates() { _u_old.clear(); }
+  std::size_t maxStates() const { return _max_states; }
+  /// rebind the current tensor and the whole history at once (a solver that ran several substeps in one library call)
+  void setStates(const DeviceTensor & u, const std::vector<DeviceTensor> & old)
+  {
+    _u = u;
+    _u_old = old;
+  }
 
 private:
   DeviceTensor _u;
@@ -230,6 +237,14 @@ public:
       return;
     for (auto & pair : _tensor_buffer)
       pair.second.advanceState();
+  }
+  /// true if `name` is the only buffer whose history anything asked for
+  bool onlyHistoryOf(const std::string & name) const
+  {
+    for (const auto & pair : _tensor_buffer)
+      if (pair.second.maxStates() > 0 && pair.first != name)
+        return false;
+    return true;
   }
   int & timeStep() { return _t_step; }
   double & time() { return _time; }
@@ -353,6 +368,8 @@ public:
     bool publish_mu = true, publish_cbar = false;
     /// opt-in: cbar of a substep = ubar of the previous one (MRL_CARRY_*), valid while `buffer` is only written by this solver
     bool spectral_carry = false;
+    /// one library call per substep (the reference's loop, operator by operator) instead of one per computeBuffer
+    bool substep_calls = false;
   };
   AdamsBashforthMoulton(TensorProblem & problem, const std::string & name, const Params & p)
     : TensorSolver(problem, name, p.substeps, nullptr), _p(p), _predictor_order(p.predictor_order - 1),
@@ -363,6 +380,62 @@ public:
       paramError("predictor_order", "predictor_order > 0 & predictor_order <= 5");
     if (p.spectral_carry && p.publish_cbar)
       paramError("spectral_carry", "cbar is not materialised separately when it is carried over");
+  }
+
+  /// TensorSolver::computeBuffer (TensorSolver.C:93-109).  When nothing else in the problem keeps a history and no per-substep
+  /// output is requested, the whole substep loop is ONE library call (mrl_ch_substeps): the history ring it rotates is handed
+  /// back to the TensorBuffer afterwards, so that the next advanceState sees exactly the reference's handles.
+  void computeBuffer() override
+  {
+    if (_substeps < 2 || _p.spectral_carry || _p.publish_cbar || _p.substep_calls || !_tensor_problem.onlyHistoryOf(_p.nonlinear_reciprocal))
+      return TensorSolver::computeBuffer();
+    _sub_dt = _dt / _substeps;
+    const std::size_t nreal = _domain.getNumberOfCells(), nspec = 2 * _domain.getReciprocalSize();
+    const int size = (int)_predictor_order + 1;   // history depth + the array being written
+    // ring slot (size-1-i) = Nhat_old[i]; the remaining slots are scratch arrays that hold no live state
+    std::vector<DeviceTensor> ring(size);
+    const int n_old0 = (int)std::min(_old_nonlinear.size(), _predictor_order);
+    for (int i = 0; i < n_old0; ++i)
+      ring[size - 1 - i] = _old_nonlinear[i];
+    for (int j = 0; j < size - n_old0; ++j)
+    {
+      // reuse an array of the pool that is not part of the history
+      for (auto & cand : _pool)
+      {
+        bool used = false;
+        for (int q = 0; q < size; ++q)
+          used = used || (ring[q].defined() && ring[q].data() == cand.data());
+        if (!used)
+        {
+          ring[j] = cand;
+          break;
+        }
+      }
+      if (!ring[j].defined())
+      {
+        ring[j] = DeviceTensor::empty(nspec);
+        _pool.push_back(ring[j]);
+      }
+    }
+    std::vector<double *> ptr(size);
+    for (int q = 0; q < size; ++q)
+      ptr[q] = ring[q].data();
+    int head = size - 1, n_old = n_old0;
+    auto c_out = DeviceTensor::empty(nreal);
+    DeviceTensor mu;
+    if (_p.publish_mu)
+      mu = DeviceTensor::empty(nreal);
+    const int advance = _tensor_problem.timeStep() > 1 ? 1 : 0;   // TensorProblem::advanceState is a no-op while timeStep() <= 1
+    _domain.check(mrl_ch_substeps(_domain.ctx(), &_p.ch, _u.data(), c_out.data(), ptr.data(), size, &head, &n_old,
+                                  (int)_predictor_order + 1, (int)_substeps, advance, _sub_dt, mu.defined() ? mu.data() : nullptr));
+    std::vector<DeviceTensor> old;
+    for (int i = 0; i < n_old; ++i)
+      old.push_back(ring[((head - i) % size + size) % size]);
+    _tensor_problem.getBufferObject(_p.nonlinear_reciprocal).setStates(ring[(head + 1) % size], old);
+    if (mu.defined())
+      _tensor_problem.getBuffer(_p.mu) = mu;
+    _u = c_out;
+    _sub_time += _sub_dt * _substeps;
   }
 
 protected:
@@ -408,6 +481,7 @@ protected:
   const std::vector<DeviceTensor> & _old_nonlinear;
   DeviceTensor _carry;
   const double * _last_c = nullptr;
+  std::vector<DeviceTensor> _pool;   // Nhat arrays of the multi-substep path that are not (yet / any more) in the history
 };
 
 /// ForwardEulerSolver (src/tensor_solver/ForwardEulerSolver.C:27-38, ExplicitSolverBase.C:33-51): root compute, forward

@@ -146,3 +146,33 @@ def test_ch_fused_fast_path_outputs(shape):
     c2b = c1.clone()
     ctx.ch_substep(p, c2b, c2b, Nc, [Na], 1, 2e-3)
     assert torch.equal(c2b, c2)
+
+
+@pytest.mark.parametrize("shape,pred", [((64, 64, 64), 2), ((128, 64, 96), 3), ((100, 40, 50), 2), ((12, 10, 9), 2), ((64, 128), 2)])
+def test_ch_multi_substep_call(shape, pred):
+    """mrl_ch_substeps (the substep loop of TensorSolver::computeBuffer in one call; on planned shapes the inverse z pass of a
+    substep is fused with the forward z pass of the next one) == the same substeps one call at a time, bit for bit on the fused
+    path; history ring, advance rule of the first time step, mu output"""
+    from marlin_amd.api import Context, ch_params
+    dim = len(shape)
+    L = [2.0 + d for d in range(dim)]
+    ctx = Context(dim, list(shape), L)
+    p = ch_params()
+    torch.manual_seed(5)
+    c0 = (torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44).cuda()
+    sub_dt, substeps = 2e-3, 7
+    # reference: one mrl_ch_substep per substep with the host-side history logic (two time steps: the first never advances)
+    states, mu_ref = _run_hip_ch(ctx, p, c0.cpu(), 2, substeps, sub_dt * substeps, pred=pred - 1, want_mu=True)
+    ring = [ctx.empty_spec() for _ in range(pred)]
+    head, n_old = 0, 0
+    c, mu = c0.clone(), torch.empty_like(c0)
+    for step in range(2):
+        advance = step > 0
+        if advance:           # TensorProblem::advanceState at the start of the time step
+            head, n_old = (head + 1) % pred, min(n_old + 1, pred - 1)
+        out = torch.empty_like(c)
+        head, n_old = ctx.ch_substeps(p, c, out, ring, head, n_old, pred, substeps, advance, sub_dt, mu=mu)
+        c = out
+        diff = (c.cpu() - states[step]).abs().max().item()
+        assert diff <= 1e-15, diff
+    assert (mu.cpu() - mu_ref).abs().max().item() <= 1e-16

@@ -21,12 +21,12 @@ def _run(args, tmp_path):
 
 
 @pytest.mark.parametrize("free_energy", [["A=0.1"], ["expression=0.1*c^2*(c-1)^2"], ["A=0.1", "spectral_carry=1"],
-                                         ["integrator=FFTSemiImplicit"]])
+                                         ["integrator=FFTSemiImplicit"], ["A=0.1", "substep_calls=1"]])
 def test_cahnhilliard_case(free_energy, tmp_path):
     """test/tests/cahnhilliard/tests:46-57 (cahnhilliard.i): c.1..c.10, mu.10 vs gold, abs_tol 1e-13 -- with the
     built-in double well, with the input file's own ParsedCompute text (expression + derivatives = c), with the spectral
-    carry-over, and through the legacy FFTSemiImplicit time integrator (FFTSemiImplicit.C:43-62: the same scheme, operator by
-    operator)"""
+    carry-over, through the legacy FFTSemiImplicit time integrator (FFTSemiImplicit.C:43-62: the same scheme, operator by
+    operator), and with one library call per substep instead of one per TensorSolver::computeBuffer (mrl_ch_substeps, default)"""
     g = load_golden("cahnhilliard_gold.npz")
     ic = tmp_path / "c0.bin"
     g["c.0"][:20, :20].astype("<f8").tofile(ic)     # the seed-0 RandomTensor IC is the gold file's frame 0

@@ -137,6 +137,15 @@ def test_parsed_free_energy_in_ch_substep(shape):
             res.append((c2.cpu(), N1.cpu(), mu.cpu()))
         for a, b in zip(*res):
             assert torch.equal(a, b)
+        # the multi-substep call (run-time compiled k_z_inv_fwd with the generated chemical potential between two substeps)
+        multi = []
+        for prm in (builtin, pp):
+            ring = [ctx.empty_spec(), ctx.empty_spec()]
+            out, mu = torch.empty_like(c0), torch.empty_like(c0)
+            ctx.ch_substeps(prm, c0.clone(), out, ring, 1, 0, 2, 4, True, 1e-3, mu=mu)
+            multi.append((out.cpu(), mu.cpu()))
+        for a, b in zip(*multi):
+            assert torch.equal(a, b)
 
 
 def test_gradient_tensor_gold_gpu():
