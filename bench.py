@@ -141,7 +141,7 @@ def main():
                     help="N > 1: run the local passes on a high-priority stream so that they do not share a hardware queue "
                          "with RCCL's stream (streams of equal priority are multiplexed onto a few queues and then serialise)")
     ap.add_argument("--substeps-per-call", type=int, default=0,
-                    help="N = 1: substeps per library call (mrl_ch_substeps = the substep loop of TensorSolver::computeBuffer; the "
+                    help="substeps per solver call (N = 1: one library call, (mrl_ch_substeps = the substep loop of TensorSolver::computeBuffer; the "
                          "reference's cahnhilliard2.i runs 1000 substeps per solver call).  0 = all timed steps in one call; 1 = one "
                          "mrl_ch_substep per step.  Within a call the inverse z pass of a substep is fused with the forward z pass of the "
                          "next one (bit-identical fields; the intermediate real field is not written)")
@@ -190,6 +190,10 @@ def main():
             torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
         solver = SlabCahnHilliard(3, shape, L, p, world, rank, nsub=args.nsub, carry=args.carry != "off")
         step = solver.substep
+
+        def steps(count):   # `count` substeps per solver call: the z passes between two substeps are one kernel
+            solver.run(count, advance=True, advance_after=True)
+
         barrier = dist.barrier
         solver.set_initial(lambda count, offset: splitmix64_uniform(count, offset=offset))
     else:
@@ -233,7 +237,7 @@ def main():
         return float(m.item())
 
     mass0 = total_mass()
-    per_call = 1 if (slab or args.carry == "on") else (args.substeps_per_call if args.substeps_per_call > 0 else args.steps)
+    per_call = 1 if (not slab and args.carry == "on") else (args.substeps_per_call if args.substeps_per_call > 0 else args.steps)
 
     def run(nsteps):
         if per_call == 1:
@@ -257,8 +261,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     single_ms = None
-    if not slab and per_call != 1:
-        # for comparison: the same substeps with one library call each (mrl_ch_substep: every substep writes and re-reads c)
+    if per_call != 1:
+        # for comparison: the same substeps with one call each (mrl_ch_substep: every substep writes and re-reads c)
         n1 = min(args.steps, 50)
         step()
         torch.cuda.synchronize()

@@ -258,6 +258,9 @@ int mrl_slab_ch_x_fwd(mrl_ctx *ctx, int sub, int nsub, double *d_send, int carry
 int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, int sub, int nsub, const double *d_recv, double *d_send,
                        double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar, int carry);
 int mrl_slab_ch_x_inv(mrl_ctx *ctx, int sub, int nsub, const double *d_recv);
+/* between two substeps of one solver call: mrl_slab_ch_z_inv of substep k fused with mrl_slab_ch_z_fwd of substep k + 1 (both
+ * are local to the rank; the intermediate real field is not written; `carry` = the mode of substep k + 1) */
+int mrl_slab_ch_z_inv_fwd(mrl_ctx *ctx, const mrl_ch_params *p, double *d_mu /* optional out */, int carry);
 int mrl_slab_ch_z_inv(mrl_ctx *ctx, double *d_c_out);
 
 /* ---- de Geus mechanics ------------------------------------------------------------------ */

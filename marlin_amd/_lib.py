@@ -109,6 +109,7 @@ SIGNATURES = {
     "mrl_slab_ch_kspace": (_i32, [_vp, C.POINTER(MrlChParams), _i32, _i32, _vp, _vp, _vp, _pp, _i32, _dbl, _vp, _i32]),
     "mrl_slab_ch_x_inv": (_i32, [_vp, _i32, _i32, _vp]),
     "mrl_slab_ch_z_inv": (_i32, [_vp, _vp]),
+    "mrl_slab_ch_z_inv_fwd": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _i32]),
     "mrl_gamma_apply": (_i32, [_vp, _vp, _vp]),
     "mrl_mech_stress": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "mrl_mech_tangent_apply": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),

@@ -811,10 +811,10 @@ static int plan_shape(mrl_ctx *ctx, int N, int *T, int *NT) {
 }
 
 // run-time compiled z passes with the generated chemical potential: mode 1 = k_z_fwd<N, 1, PARSED>, 2 = k_z_fwd<N, 2, PARSED>,
-// 3 = k_z_inv_fwd<N, PARSED>; cached per (N, mode)
+// 3 = k_z_inv_fwd<N, PARSED>, 4 = its MU_ONLY form; cached per (N, mode)
 static int parsed_z_kernel(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, hipFunction_t *fn_out) {
-  if (mode < 1 || mode > 3) return set_error(ctx, MRL_ERR_INVALID, "parsed z pass: mode %d", mode);
-  const int key = N * 4 + mode;
+  if (mode < 1 || mode > 4) return set_error(ctx, MRL_ERR_INVALID, "parsed z pass: mode %d", mode);
+  const int key = N * 8 + mode;
   auto it = p->zfwd.find(key);
   if (it == p->zfwd.end()) {
     std::string mu_fn;
@@ -830,8 +830,9 @@ static int parsed_z_kernel(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, hipFunc
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "mrl_z_fwd_parsed.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
       return set_error(ctx, MRL_ERR_HIP, "hiprtcCreateProgram failed");
-    const std::string name = mode == 3 ? "mrl::p2::k_z_inv_fwd<" + std::to_string(N) + ", 2>"
-                                       : "mrl::p2::k_z_fwd<" + std::to_string(N) + ", " + std::to_string(mode) + ", 2>";
+    const std::string name = mode == 3   ? "mrl::p2::k_z_inv_fwd<" + std::to_string(N) + ", 2, false>"
+                             : mode == 4 ? "mrl::p2::k_z_inv_fwd<" + std::to_string(N) + ", 2, true>"
+                                         : "mrl::p2::k_z_fwd<" + std::to_string(N) + ", " + std::to_string(mode) + ", 2>";
     hiprtcAddNameExpression(prog, name.c_str());
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
     if (hiprtcCompileProgram(prog, 3, opts) != HIPRTC_SUCCESS) {
@@ -895,11 +896,11 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const doub
 
 // k_z_inv_fwd<N, PARSED>(const cplx*, cplx*, cplx*, double*, ChDev, double, long long, const cplx*); nlines = line pairs
 int parsed_z_inv_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const cplx *in, cplx *out0, cplx *out1, double *mu_out,
-                            double scale, long long nlines) {
+                            double scale, long long nlines, bool mu_only) {
   int T = 0, NT = 0;
   MRL_TRY(plan_shape(ctx, N, &T, &NT));
   hipFunction_t fn;
-  MRL_TRY(parsed_z_kernel(ctx, p, N, 3, &fn));
+  MRL_TRY(parsed_z_kernel(ctx, p, N, mu_only ? 4 : 3, &fn));
   ChDevHost chp = parsed_chdev(p);
   const cplx *tw = ctx->ax[2].d_tw;
   void *params[] = {&in, &out0, &out1, &mu_out, &chp, &scale, &nlines, &tw};

@@ -213,7 +213,9 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv(const cplx *__restrict
 // reference rebinds the buffer every substep and only the last one is visible outside the solver): 268 MB of the 673 MB that
 // the two separate passes move at 256^3.  in == out0 is allowed (a workgroup reads its rows before it writes them).
 // Same arithmetic, in the same order, as k_z_inv followed by k_z_fwd<CH>: bit-identical fields.
-template <int N, int FAM>
+// MU_ONLY (the spectral carry-over of the slab pipeline, where c-hat is not recomputed): the two lines of mu are packed into
+// ONE forward transform -> rows 2L, 2L+1 of out0 = mu-hat_z; out1 unused.
+template <int N, int FAM, bool MU_ONLY = false>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv_fwd(const cplx *__restrict__ in, cplx *__restrict__ out0,
                                                                 cplx *__restrict__ out1, double *__restrict__ mu_out, ChDev chp,
                                                                 double scale, long long nlines, const cplx *__restrict__ tw) {
@@ -255,6 +257,36 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv_fwd(const cplx *__rest
     }
   }
   fft_line<N, Map>(v, q, l, X, W);
+  if constexpr (MU_ONLY) {
+#pragma unroll
+    for (int m = 0; m < P; ++m) v[m] = make_double2(mu_eval<FAM>(chp, v[m].y * scale), mu_eval<FAM>(chp, v[m].x * scale));
+    if (mu_out && valid) {
+      double *pm = mu_out + (2 * L) * N + q;
+#pragma unroll
+      for (int m = 0; m < P; ++m) {
+        pm[m * TPL] = v[m].x;
+        pm[N + m * TPL] = v[m].y;
+      }
+    }
+    fft_line<N, Map>(v, q, l, X, W);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
+    __syncthreads();
+    if (valid) {
+      cplx *o0 = out0 + (2 * L) * NZC, *o1 = o0 + NZC;
+#pragma unroll
+      for (int m = 0; m <= P / 2; ++m) {
+        const int k = q + m * TPL;
+        if (k > N / 2) break;
+        const cplx xk = v[m];
+        const cplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
+        o0[k] = make_double2(0.5 * (xk.x + xn.x), 0.5 * (xk.y - xn.y));
+        o1[k] = make_double2(0.5 * (xk.y + xn.y), -0.5 * (xk.x - xn.x));
+      }
+    }
+    return;
+  }
   double cb[P];  // second line (row 2L+1), kept while the first one is transformed
   {
 #pragma unroll

@@ -49,18 +49,18 @@ inline int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale,
 }
 
 // nlines = number of line PAIRS (= complex inverse transforms)
-template <int N, int FAM>
+template <int N, int FAM, bool MU_ONLY = false>
 inline int launch_z_inv_fwd(mrl_ctx *ctx, const cplx *in, cplx *o0, cplx *o1, double *mu, const ChDev &chp, double scale,
                             long long nlines) {
   static bool attr = false;
   constexpr size_t lds = lds_line<N>();
   if (!attr) {
-    MRL_TRY((set_lds_attr(ctx, k_z_inv_fwd<N, FAM>, lds)));
+    MRL_TRY((set_lds_attr(ctx, k_z_inv_fwd<N, FAM, MU_ONLY>, lds)));
     attr = true;
   }
   constexpr int LPB = Plan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_inv_fwd<N, FAM>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, scale,
+  hipLaunchKernelGGL((k_z_inv_fwd<N, FAM, MU_ONLY>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, scale,
                      nlines, ctx->ax[2].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;

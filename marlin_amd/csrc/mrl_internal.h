@@ -183,7 +183,7 @@ int parsed_eval1(mrl_parsed *p, const double *c, double *mu, long long n);  // m
 int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const double *in, cplx *out0, cplx *out1, double *mu_out,
                         long long nlines);
 int parsed_z_inv_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const cplx *in, cplx *out0, cplx *out1, double *mu_out, double scale,
-                            long long nlines);
+                            long long nlines, bool mu_only = false);
 
 // power-of-two fast path (ch_fused.hip)
 bool fast_path_ok(const mrl_ctx *ctx);

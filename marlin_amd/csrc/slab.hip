@@ -138,6 +138,7 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const dou
                         const double *const *Nhat_old, int order, double sub_dt, double *cbar, int carry);
 int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv);
 int slab_ch_z_inv_fast(mrl_ctx *ctx, double *real_out);
+int slab_ch_z_inv_fwd_fast(mrl_ctx *ctx, const ChP &cp, double *mu, int carry);
 // generic passes on a sub-range (fft_plan.hip), k-space update on a kz sub-range (ch.hip)
 int pass_lines(mrl_ctx *ctx, int axis, int sign, const double *in, double *out, long long outer, long long inner,
                long long so, long long si, long long sn);
@@ -443,6 +444,20 @@ int mrl_slab_ch_z_inv(mrl_ctx *ctx, double *d_c_out) {
   if (!d_c_out) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_z_inv: null buffer");
   if (slab_fast_ok(ctx)) return slab_ch_z_inv_fast(ctx, d_c_out);
   return gen_z_inv(ctx, d_c_out);
+}
+
+int mrl_slab_ch_z_inv_fwd(mrl_ctx *ctx, const mrl_ch_params *p, double *d_mu, int carry) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_slab(ctx, "mrl_slab_ch_z_inv_fwd"));
+  MRL_TRY(check_carry(ctx, "mrl_slab_ch_z_inv_fwd", carry));
+  ChP cp;
+  MRL_TRY(ch_check_params(ctx, p, cp));
+  if (slab_fast_ok(ctx) && (ctx->n[0] * ctx->nloc[1]) % 2 == 0) return slab_ch_z_inv_fwd_fast(ctx, cp, d_mu, carry);
+  // generic shapes: the two passes one after the other through a scratch real field
+  const long long nreal = real_count_local(ctx);
+  MRL_TRY(ensure_work(ctx, 9, sizeof(double) * (size_t)(nreal + 2)));
+  MRL_TRY(gen_z_inv(ctx, ctx->d_work[9]));
+  return gen_z_fwd(ctx, cp, ctx->d_work[9], d_mu, carry);
 }
 
 }  // extern "C"

@@ -246,6 +246,36 @@ int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv) {
   return MRL_OK;
 }
 
+// inverse z pass of substep k fused with the forward z pass of substep k + 1 (both are local to the rank: no exchange lies between
+// them).  With the carry-over only mu travels forward, so the two real lines of a pair become ONE forward transform of (mu, mu').
+int slab_ch_z_inv_fwd_fast(mrl_ctx *ctx, const ChP &cp, double *mu, int carry) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2];
+  if ((nx * nyl) % 2) return set_error(ctx, MRL_ERR_UNSUPPORTED, "fused z passes need an even number of local lines");
+  cplx *w_c, *w_mu, *w_inv;
+  MRL_TRY(slab_work(ctx, &w_c, &w_mu, &w_inv));
+  const bool mu_only = carry == MRL_CARRY_IN;
+  ProfScope ps(ctx, "slab_EZ_z_inv_fwd", (mu_only ? 2.0 : 3.0) * 16.0 * nx * nyl * nzc + (mu ? 8.0 * nx * nyl * nz : 0.0));
+  const double scale = 1.0 / ((double)nx * (double)ctx->n[1] * (double)nz);
+  p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
+  const long long np = nx * nyl / 2;
+  if (cp.family == MRL_FE_PARSED) {
+    MRL_TRY(parsed_z_inv_fwd_launch(ctx, cp.parsed, (int)nz, w_inv, mu_only ? w_mu : w_c, w_mu, mu, scale, np, mu_only));
+  } else if (cp.family == MRL_FE_DOUBLE_WELL) {
+    if (mu_only) {
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_DOUBLE_WELL, true>(ctx, w_inv, w_mu, nullptr, mu, chp, scale, np))));
+    } else {
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_DOUBLE_WELL, false>(ctx, w_inv, w_c, w_mu, mu, chp, scale, np))));
+    }
+  } else {
+    if (mu_only) {
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_PFHUB, true>(ctx, w_inv, w_mu, nullptr, mu, chp, scale, np))));
+    } else {
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_PFHUB, false>(ctx, w_inv, w_c, w_mu, mu, chp, scale, np))));
+    }
+  }
+  return MRL_OK;
+}
+
 int slab_ch_z_inv_fast(mrl_ctx *ctx, double *real_out) {
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2];
   cplx *w_c, *w_mu, *w_inv;

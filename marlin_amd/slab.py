@@ -165,6 +165,9 @@ class HipSlabStages:
     def ch_z_inv(self, c_out):
         self.ctx._check(self.lib.mrl_slab_ch_z_inv(self.ctx.h, self._p(c_out)))
 
+    def ch_z_inv_fwd(self, p, mu=None, carry: int = 0):
+        self.ctx._check(self.lib.mrl_slab_ch_z_inv_fwd(self.ctx.h, C.byref(p), self._p(mu), carry))
+
     def empty(self, n):
         return torch.empty(n, dtype=torch.float64, device=self.device)
 
@@ -304,19 +307,39 @@ class SlabCahnHilliard:
     def phase_c(self, s):
         self.st.ch_x_inv(s, self.nsub, self.recv_i[s])
 
-    def phase_e(self):
-        self.st.ch_z_inv(self.c_new)
-        self.c, self.c_new = self.c_new, self.c
+    def _finish(self):
         self.cur = self._new
         self.last_order = self._order
         self._carry_valid = self.carry
+
+    def phase_e(self):
+        self.st.ch_z_inv(self.c_new)
+        self.c, self.c_new = self.c_new, self.c
+        self._finish()
+
+    def phase_ez(self, advance: bool = True):
+        """between two substeps of one run(): the inverse z pass of the finished substep fused with the forward z pass of the
+        next one (the intermediate real field is not materialised; current() is valid again after the closing phase_e)"""
+        self._finish()
+        if advance:
+            self.advance_state()
+        self.mode = CARRY_NONE if not self.carry else CARRY_IN
+        self.st.ch_z_inv_fwd(self.p, carry=self.mode)
+        self._order = min(len(self.hist), self.pred)
+        self._new = self._free_Nhat()
 
     def substep(self, advance: bool = True):
         """One substep including all exchanges; `advance` rotates the history afterwards (what
         TensorSolver::computeBuffer does between substeps).  Exchanges are asynchronous: a work handle's
         wait() only orders the compute stream behind that exchange, the host never blocks."""
-        S = range(self.nsub)
         self.phase_z()
+        self._exchange_phases()
+        self.phase_e()
+        if advance:
+            self.advance_state()
+
+    def _exchange_phases(self):
+        S = range(self.nsub)
         wf, wi = [], []
         for s in S:
             self.phase_a(s)
@@ -331,8 +354,19 @@ class SlabCahnHilliard:
             if wi[s] is not None:
                 wi[s].wait()
             self.phase_c(s)
+
+    def run(self, count: int, advance: bool = True, advance_after: bool = False):
+        """`count` substeps as one unit (the substep loop of TensorSolver::computeBuffer): between two substeps the two z passes
+        are one kernel.  `advance`: rotate the history between substeps (False while timeStep() <= 1); `advance_after`: also
+        after the last one (what a following run() / substep() of the same time step needs)."""
+        for k in range(count):
+            if k == 0:
+                self.phase_z()
+            else:
+                self.phase_ez(advance)
+            self._exchange_phases()
         self.phase_e()
-        if advance:
+        if advance_after:
             self.advance_state()
 
     def step(self, dt: float, substeps: int):
@@ -342,10 +376,7 @@ class SlabCahnHilliard:
         if self.time_step > 1:
             self.advance_state()
         self.sub_dt = dt / substeps
-        for s in range(substeps):
-            self.substep(advance=False)
-            if s < substeps - 1 and self.time_step > 1:
-                self.advance_state()
+        self.run(substeps, advance=self.time_step > 1)
 
 
 class TorchComm:

@@ -162,6 +162,11 @@ class OracleSlabStages:
             off += cnt
         self._winv[:, :, k0:k0 + ksub] = torch.fft.ifft(d, dim=0)
 
+    def ch_z_inv_fwd(self, p, mu=None, carry=0):
+        r = torch.empty(self.n[0] * self.nyl * self.n[2], dtype=torch.float64)
+        self.ch_z_inv(r)
+        self.ch_z_fwd(p, r, mu, carry)
+
     def ch_z_inv(self, c_out):
         if self.half:
             r = torch.fft.irfft(self._winv, n=self.n[2], dim=2)

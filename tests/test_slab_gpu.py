@@ -72,6 +72,31 @@ def _substep_all(solvers):
         s.phase_e()
 
 
+def _run_all(solvers, count, advance=True):
+    """SlabCahnHilliard.run() for all loop-back ranks in lock step: the fused z passes between the substeps"""
+    for k in range(count):
+        for s in solvers:
+            if k == 0:
+                s.phase_z()
+            else:
+                s.phase_ez(advance)
+        S = range(solvers[0].nsub)
+        for j in S:
+            for s in solvers:
+                s.phase_a(j)
+            ex = [s.fwd_exchange(j) for s in solvers]
+            _a2a([e[0] for e in ex], [e[1] for e in ex], [e[2] for e in ex])
+        for j in S:
+            for s in solvers:
+                s.phase_b(j)
+            _a2a([s.x_inv[j] for s in solvers], [s.send_i[j] for s in solvers], [s.recv_i[j] for s in solvers])
+        for j in S:
+            for s in solvers:
+                s.phase_c(j)
+    for s in solvers:
+        s.phase_e()
+
+
 def _step_all(solvers, dt, substeps):
     for s in solvers:
         s.time_step += 1
@@ -210,6 +235,41 @@ def test_slab_ch_carry_over(shape, P, nsub):
     _step_all(plain, 1e-3, 2)
     _step_all(carry, 1e-3, 2)
     assert (_gather(carry) - _gather(plain)).abs().max().item() <= 1e-13
+
+
+@pytest.mark.parametrize("shape,P,nsub,carry", [((64, 64, 64), 2, 2, False), ((64, 64, 64), 2, 2, True), ((64, 128, 64), 4, 3, True),
+                                                ((12, 10, 8), 2, 1, True), ((9, 7, 5), 3, 1, False)])
+def test_slab_run_fused_z_passes(shape, P, nsub, carry):
+    """run(count): the inverse z pass of a substep fused with the forward z pass of the next one (planned shapes; the generic
+    path runs the two passes back to back) == the same substeps one at a time, incl. the first-time-step rule (no history
+    rotation) and the carry-over"""
+    torch.manual_seed(4)
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    L = [3.0, 2.0, 2.5]
+    a = _make(3, list(shape), L, P, nsub=nsub, carry=carry)
+    b = _make(3, list(shape), L, P, nsub=nsub, carry=carry)
+    for s in a + b:
+        yb, nyl = s.st.real_begin[1], s.st.real_shape[1]
+        s.set_local(c0[:, yb:yb + nyl].contiguous().cuda())
+    # time step 1: 4 substeps without history rotation; time step 2: 5 substeps with it
+    for s in a:
+        s.time_step, s.sub_dt = 1, 1e-3
+    for k in range(4):
+        _substep_all(a)
+    _run_all(b, 4, advance=False)
+    assert (_gather(a) - _gather(b)).abs().max().item() <= 1e-15
+    for s in a + b:
+        s.advance_state()
+    for k in range(5):
+        _substep_all(a)
+        if k < 4:
+            for s in a:
+                s.advance_state()
+    _run_all(b, 5, advance=True)
+    assert (_gather(a) - _gather(b)).abs().max().item() <= 1e-15
+    assert [s.last_order for s in b] == [1] * P
+    for x, y in zip(a, b):
+        assert (x.cur - y.cur).abs().max().item() <= 1e-12 * max(1.0, x.cur.abs().max().item())
 
 
 def test_rccl_exchange_single_rank():

@@ -2,7 +2,7 @@
 """Time the LOCAL stages of one rank of a P-rank slab decomposition on a single GPU (the exchange is
 replaced by a device copy of the rank's own send buffer, same byte count as the receive buffer), to
 size the compute side of the 512^3 / 8-GPU configuration without an 8-GPU node.
-usage: slab_local_bench.py [P] [n] [steps] [nsub] [carry 0|1]"""
+usage: slab_local_bench.py [P] [n] [steps] [nsub] [carry 0|1] [fused-run 0|1]"""
 import json
 import os
 import sys
@@ -32,6 +32,7 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
     nsub = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     carry = bool(int(sys.argv[5])) if len(sys.argv) > 5 else True
+    fused = bool(int(sys.argv[6])) if len(sys.argv) > 6 else True
     shape = grid_for(P, n)
     dx = 8.0 * np.pi / 200.0
     s = SlabCahnHilliard(3, shape, [x * dx for x in shape], ch_params(), P, 0, exchange_factory=lambda a, b: _Copy(a, b), nsub=nsub,
@@ -41,19 +42,25 @@ def main():
         s.substep()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        s.substep()
+    if fused:
+        s.run(steps, advance=True, advance_after=True)
+    else:
+        for _ in range(steps):
+            s.substep()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     s.ctx.set_profiling(True)
-    for _ in range(10):
-        s.substep()
+    if fused:
+        s.run(10, advance=True, advance_after=True)
+    else:
+        for _ in range(10):
+            s.substep()
     torch.cuda.synchronize()
     prof = [k for k in s.ctx.get_profile() if k["launches"]]
     for k in prof:
         k["avg_ms"] = k["ms"] / k["launches"]
         k["GBps"] = k["bytes_per_launch"] / k["avg_ms"] / 1e6
-    print(json.dumps({"P": P, "nsub": nsub, "carry": carry, "global_grid": shape, "local_real": s.st.real_shape, "ms_per_substep_local_incl_copies": ms,
+    print(json.dumps({"P": P, "nsub": nsub, "carry": carry, "fused_run": fused, "global_grid": shape, "local_real": s.st.real_shape, "ms_per_substep_local_incl_copies": ms,
                       "kernels": [{k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in k.items()} for k in prof]}))
 
 
