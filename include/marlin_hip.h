@@ -251,6 +251,12 @@ int mrl_broyden_update(mrl_ctx *ctx, int nvar, double *d_M, double *d_R, const d
  *                   mu only: forward layouts lose the field index, [p][x_p][y_me][K_s] / [p][x_me][y_p][K_s]
  * The same value has to be passed to the four calls of one substep.  Results differ from MRL_CARRY_NONE at rounding level
  * only (tests: <= 1e-13 after 20 substeps, and against the reference's gold file).  (MRL_CARRY_* are defined above.) */
+/* Last-axis pitch, in complex elements, of the rank-local spectral arrays of the slab CH stages (d_Nhat_new, d_Nhat_old[], d_cbar):
+ * [x_me][ny][pitch], element (ix, j, kz) at (ix*ny + j)*pitch + kz.  Equal to the reciprocal extent nz/2+1 on generic shapes; the
+ * planned pipeline pads rows to a multiple of 8 elements so that every row starts on a 128-byte line (its y pass gathers 128-byte
+ * row segments: with the odd natural pitch each of them straddles two lines and the pass moves 1.5x its algorithmic bytes, measured
+ * with the FETCH_SIZE / WRITE_SIZE counters).  Allocate x_me*ny*pitch complex values per array; the padding is never read. */
+int64_t mrl_slab_ch_spec_pitch(const mrl_ctx *ctx);
 int mrl_slab_ch_counts(const mrl_ctx *ctx, int sub, int nsub, int forward, int carry, int64_t *h_send_counts,
                        int64_t *h_recv_counts);
 int mrl_slab_ch_z_fwd(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_mu /* optional out */, int carry);

@@ -408,6 +408,12 @@ int mrl_slab_ch_x_fwd(mrl_ctx *ctx, int sub, int nsub, double *d_send, int carry
   return gen_x_fwd(ctx, k0, ksub, d_send, carry);
 }
 
+int64_t mrl_slab_ch_spec_pitch(const mrl_ctx *ctx) {
+  if (!ctx) return 0;
+  const long long nzc = ctx->nrec[ctx->dim - 1];
+  return (ctx->slab && slab_fast_ok(ctx)) ? ((nzc + 7) & ~7LL) : nzc;
+}
+
 int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, int sub, int nsub, const double *d_recv, double *d_send,
                        double *d_Nhat_new, const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar, int carry) {
   if (!ctx) return MRL_ERR_INVALID;

@@ -28,7 +28,7 @@ namespace p2 {
 
 struct YFusedArgs {
   FusedCommon c;      // chat: received chunks (field 0 of each chunk; field 1 = mu-hat follows at +chunk)
-  int nxl, nzc;       // local x extent, full kz extent (pitch of the dense arrays)
+  int nxl, nzc;       // local x extent, kz pitch of the rank-local spectral arrays (Nhat, cbar): mrl_slab_ch_spec_pitch
   int k0, ksub;       // kz sub-block
   int nyl_shift;      // log2(ny / P)
   unsigned chunk;     // nxl * nyl * ksub: elements of one field of one chunk
@@ -193,7 +193,7 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const dou
   for (int i = 0; i < order; ++i) a.c.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
   for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaAB[order][i];
   a.nxl = (int)nxl;
-  a.nzc = (int)nzc;
+  a.nzc = (int)((nzc + 7) & ~7LL);  // mrl_slab_ch_spec_pitch: rows of the rank-local spectral arrays start on 128-byte lines
   a.k0 = k0;
   a.ksub = ksub;
   a.nyl_shift = ilog2(nyl);

@@ -119,6 +119,7 @@ class HipSlabStages:
         self.real_begin = self.ctx.real_begin
         self.recip_shape = self.ctx.recip_shape
         self.recip_begin = self.ctx.recip_begin
+        self.spec_pitch = int(self.lib.mrl_slab_ch_spec_pitch(self.ctx.h))
 
     def counts(self, forward: bool):
         n = self.ctx.nranks
@@ -169,7 +170,7 @@ class HipSlabStages:
         self.ctx._check(self.lib.mrl_slab_ch_z_inv_fwd(self.ctx.h, C.byref(p), self._p(mu), carry))
 
     def empty(self, n):
-        return torch.empty(n, dtype=torch.float64, device=self.device)
+        return torch.zeros(n, dtype=torch.float64, device=self.device)
 
 
 class SlabCahnHilliard:
@@ -224,6 +225,8 @@ class SlabCahnHilliard:
             nspec *= s
         self.c = e(nreal)
         self.c_new = e(nreal)
+        self._pitch = int(self.st.spec_pitch)              # padded kz pitch of the rank-local spectral arrays
+        nspec = nspec // self.st.recip_shape[-1] * self._pitch
         self.Nhat = [e(2 * nspec) for _ in range(self.pred + 2)]   # ring: current + history + one free
         self.cbar = e(2 * nspec) if carry else None                # carried spectrum: ubar of the last substep
         self.hist: List[torch.Tensor] = []                         # N-hat_old[0..] (handles into the ring)
@@ -252,6 +255,12 @@ class SlabCahnHilliard:
     def set_local(self, c_local: torch.Tensor):
         self.c.copy_(c_local.reshape(-1))
         self._carry_valid = False
+
+    def spec(self, t: torch.Tensor) -> torch.Tensor:
+        """complex view [x_me][ny]..[nz/2+1] of one of the rank-local spectral arrays (Nhat ring, cbar) without its row padding"""
+        shp = list(self.st.recip_shape)
+        v = torch.view_as_complex(t.view(*shp[:-1], self._pitch, 2))
+        return v[..., :shp[-1]]
 
     def invalidate_carry(self):
         """c was modified by something else than this solver: the next substep recomputes c-hat from it"""

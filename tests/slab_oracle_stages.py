@@ -21,6 +21,7 @@ class OracleSlabStages:
         self.real_shape = [self.n[0], self.nyl] + ([self.n[2]] if dim == 3 else [])
         self.real_begin = [0, self.yb[rank]] + ([0] if dim == 3 else [])
         self.recip_shape = [self.nxl, self.n[1]] + ([self.nzc] if dim == 3 else [])
+        self.spec_pitch = self.recip_shape[-1]
         self.recip_begin = [self.xb[rank], 0] + ([0] if dim == 3 else [])
         self.device = torch.device("cpu")
         k = [a.reshape(-1) for a in self.dom.kaxis]
