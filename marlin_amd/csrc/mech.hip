@@ -13,66 +13,9 @@
 // (the contraction of K4 = S.I4 + I4rt:((F.C4).F^T):I4rt written out).  The "1/3" is
 // the reference's literal 1./3. in every dimension.
 // Fields are value-major [grid][D][D] as in the reference.
-#include "mrl_internal.h"
+#include "mech_math.h"
 
 namespace mrl {
-
-template <int D>
-struct Mat {
-  double a[D][D];
-};
-
-// tensor of grid point p: value-major (reference layout) base[p*D*D + c] or field-major base[c*npts + p]
-template <int D, bool SOA>
-__device__ __forceinline__ Mat<D> load_mat(const double *base, long long p, long long npts) {
-  Mat<D> m;
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) m.a[i][j] = SOA ? base[(long long)(i * D + j) * npts + p] : base[p * D * D + i * D + j];
-  return m;
-}
-
-template <int D, bool SOA>
-__device__ __forceinline__ void store_mat(double *base, long long p, long long npts, const Mat<D> &m) {
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      if (SOA)
-        base[(long long)(i * D + j) * npts + p] = m.a[i][j];
-      else
-        base[p * D * D + i * D + j] = m.a[i][j];
-    }
-}
-
-// second Piola-Kirchhoff stress S = C4 : (F^T F - I)/2
-template <int D>
-__device__ __forceinline__ Mat<D> svk_S(const Mat<D> &F, double K, double mu) {
-  Mat<D> E;
-  double tr = 0.0;
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < D; ++k) s += F.a[k][i] * F.a[k][j];
-      E.a[i][j] = 0.5 * (s - (i == j ? 1.0 : 0.0));
-    }
-#pragma unroll
-  for (int i = 0; i < D; ++i) tr += E.a[i][i];
-  Mat<D> S;
-  const double two_mu = 2.0 * mu;
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const double dev = 0.5 * (E.a[i][j] + E.a[j][i]) - (i == j ? (1.0 / 3.0) * tr : 0.0);
-      S.a[i][j] = (i == j ? K * tr : 0.0) + two_mu * dev;
-    }
-  return S;
-}
 
 template <int D, bool SOA>
 __global__ void __launch_bounds__(256) k_mech_stress(const double *__restrict__ F, const double *__restrict__ K,
@@ -95,44 +38,6 @@ __global__ void __launch_bounds__(256) k_mech_stress(const double *__restrict__ 
   }
 }
 
-// out = dF.S + F.Y for one grid point
-template <int D>
-__device__ __forceinline__ Mat<D> svk_tangent(const Mat<D> &f, const Mat<D> &d, double Kp, double mup) {
-  const Mat<D> S = svk_S<D>(f, Kp, mup);
-  Mat<D> W;
-  double tr = 0.0;
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < D; ++k) s += f.a[k][i] * d.a[k][j];
-      W.a[i][j] = s;
-    }
-#pragma unroll
-  for (int i = 0; i < D; ++i) tr += W.a[i][i];
-  Mat<D> Y;
-  const double two_mu = 2.0 * mup;
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const double dev = 0.5 * (W.a[i][j] + W.a[j][i]) - (i == j ? (1.0 / 3.0) * tr : 0.0);
-      Y.a[i][j] = (i == j ? Kp * tr : 0.0) + two_mu * dev;
-    }
-  Mat<D> o;
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < D; ++k) s += d.a[i][k] * S.a[k][j] + f.a[i][k] * Y.a[k][j];
-      o.a[i][j] = s;
-    }
-  return o;
-}
 
 // out = K_dF(dF) ; bcast: dF is ONE tensor (D*D doubles) broadcast over the grid.
 // DIR fuses the CG direction update into the operator application: dF <- r + beta*dF (beta = S[i_num]/S[i_den],
@@ -309,7 +214,8 @@ __global__ void __launch_bounds__(256) k_cg_init(const double *__restrict__ b, c
 }
 
 // alpha = S[i_rz] / S[i_pAp] ; x += alpha p ; r -= alpha Ap ; partial sum r.r      (16 B per lane per access)
-template <bool NT>
+// SKIP_X: r and r.r only -- the solution update is deferred into the next iteration's direction kernel (k_gamma_z_fwd_tangent<XUPD>)
+template <bool NT, bool SKIP_X = false>
 __global__ void __launch_bounds__(256) k_cg_update(const double *__restrict__ S, int i_rz, int i_pAp,
                                                     double *__restrict__ x, double *__restrict__ r,
                                                     const double *__restrict__ p, const double *__restrict__ Ap,
@@ -322,19 +228,22 @@ __global__ void __launch_bounds__(256) k_cg_update(const double *__restrict__ S,
   double2 *x2 = reinterpret_cast<double2 *>(x), *r2 = reinterpret_cast<double2 *>(r);
   const double2 *p2 = reinterpret_cast<const double2 *>(p), *A2 = reinterpret_cast<const double2 *>(Ap);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256) {
-    const double2 xv = NT ? ld_nt(x2 + i) : x2[i], pv = NT ? ld_nt(p2 + i) : p2[i], rv = r2[i], av = A2[i];   // NT: x, p are not re-read
-    const double2 xn = make_double2(xv.x + alpha * pv.x, xv.y + alpha * pv.y);                               // before ~3 GB of other traffic
-    if (NT)
-      st_nt(x2 + i, xn);
-    else
-      x2[i] = xn;
+    const double2 rv = r2[i], av = A2[i];
+    if (!SKIP_X) {
+      const double2 xv = NT ? ld_nt(x2 + i) : x2[i], pv = NT ? ld_nt(p2 + i) : p2[i];   // NT: x, p are not re-read
+      const double2 xn = make_double2(xv.x + alpha * pv.x, xv.y + alpha * pv.y);         // before ~3 GB of other traffic
+      if (NT)
+        st_nt(x2 + i, xn);
+      else
+        x2[i] = xn;
+    }
     const double2 v = make_double2(rv.x - alpha * av.x, rv.y - alpha * av.y);
     r2[i] = v;
     acc += v.x * v.x + v.y * v.y;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const long long i = n - 1;
-    x[i] = x[i] + alpha * p[i];
+    if (!SKIP_X) x[i] = x[i] + alpha * p[i];
     const double v = r[i] - alpha * Ap[i];
     r[i] = v;
     acc += v * v;
@@ -343,6 +252,14 @@ __global__ void __launch_bounds__(256) k_cg_update(const double *__restrict__ S,
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// x += (S[i_a] / S[i_b]) p : the last, still pending solution update of a CG solve with deferred updates
+__global__ void __launch_bounds__(256) k_axpy_ratio(const double *__restrict__ S, int i_a, int i_b, double *__restrict__ x,
+                                                     const double *__restrict__ p, long long n) {
+#pragma clang fp contract(off)
+  const double alpha = S[i_a] / S[i_b];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] = x[i] + alpha * p[i];
 }
 
 // y[i] += x[i]                       (period = 0, block = 0)
@@ -400,6 +317,10 @@ static int check_dim(mrl_ctx *ctx, const char *what, bool serial = true) {
 }
 
 bool mech_fast_ok(const mrl_ctx *ctx);
+bool gamma_tangent_fusable(const mrl_ctx *ctx);
+int gamma_fast_tangent_dir(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
+                           const double *S, int i_num, int i_den, double *out, double *d_dot, bool nt, double *x, int i_arz,
+                           int i_apAp);
 int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale, const double *dotv = nullptr,
                double *d_dot = nullptr);
 
@@ -704,6 +625,7 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
     return gamma(tmp, out, 1.0);
   };
 
+  const bool fuse_dir = soa && gamma_tangent_fusable(ctx) && !(ctx->exp & 32);
   int iiter = 0;
   while (true) {
     // ---- conjugateGradientSolve(G_K_dF, b, dFm, l_tol, l_max_its)        MarlinUtils.h:55-123
@@ -717,17 +639,24 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
       hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(256), 0, ctx->stream, b, Ap, r, p, n, ctx->d_red);
       MRL_TRY(reduce_finalize(ctx, nb, 1, S + 0));
       int i_old = 0, i_new = 2;
+      int pend_rz = -1;  // slot of r.r of the iteration whose x update is still pending (deferred updates, fuse_dir)
       its = (int)l_max_its;
       for (long long k = 0; k < l_max_its; ++k) {
         if (k == 0) {
           MRL_TRY(apply_A(p, Ap));
         } else {
           // p = r + beta p (beta = rr_new / rr_old of the previous iteration) fused into the operator application
-          MRL_TRY(tangent_dir_launch(ctx, lin, d_K, d_mu, p, r, S, i_old, i_new, tmp, soa));
-          if (soa) {
-            MRL_TRY(gamma_fast(ctx, tmp, Ap, 1.0, p, S + 1));  // p.Ap taken in the last pass of G
+          if (fuse_dir) {  // ... and into the forward z pass of G: K4:p is never written; the pending x update rides along
+            MRL_TRY(gamma_fast_tangent_dir(ctx, lin, d_K, d_mu, p, r, S, i_old, i_new, Ap, S + 1, mech_stream_vectors(npts), x,
+                                           pend_rz, 1));
+            pend_rz = -1;
           } else {
-            MRL_TRY(gamma(tmp, Ap, 1.0));
+            MRL_TRY(tangent_dir_launch(ctx, lin, d_K, d_mu, p, r, S, i_old, i_new, tmp, soa));
+            if (soa) {
+              MRL_TRY(gamma_fast(ctx, tmp, Ap, 1.0, p, S + 1));  // p.Ap taken in the last pass of G
+            } else {
+              MRL_TRY(gamma(tmp, Ap, 1.0));
+            }
           }
         }
         if (!(soa && k > 0)) {
@@ -735,8 +664,11 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
           MRL_TRY(reduce_async(ctx, 1, p, Ap, n, S + 1));
         }
         {
-          ProfScope ps(ctx, "cg_update_x_r", 48.0 * n);
-          if (mech_stream_vectors(npts))
+          ProfScope ps(ctx, "cg_update_x_r", (fuse_dir ? 24.0 : 48.0) * n);
+          if (fuse_dir) {  // x += alpha p is deferred into the next direction kernel (or the k_axpy_ratio after the loop)
+            hipLaunchKernelGGL((k_cg_update<false, true>), dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
+            pend_rz = i_old;
+          } else if (mech_stream_vectors(npts))
             hipLaunchKernelGGL(k_cg_update<true>, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
           else
             hipLaunchKernelGGL(k_cg_update<false>, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
@@ -751,6 +683,10 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
         const int t = i_old;  // rr_new becomes rr_old; the next iteration's beta = S[i_old] / S[i_new]
         i_old = i_new;
         i_new = t;
+      }
+      if (pend_rz >= 0) {
+        hipLaunchKernelGGL(k_axpy_ratio, dim3(nb), dim3(256), 0, ctx->stream, S, pend_rz, 1, x, p, n);
+        MRL_HIP(ctx, hipGetLastError());
       }
     }
     if (st.newton_its < 64) st.cg_its[st.newton_its] = its;

@@ -10,6 +10,7 @@
 //   z inverse   k_z_inv, x scale/N                                h + r
 // = 9 * (2r + 8h) bytes per application (r = 8 B, h = 8(1+2/n) B per grid point): 724.5 B/pt at n = 128.
 #include "fft_pow2_launch.h"
+#include "mech_math.h"
 
 namespace mrl {
 
@@ -126,6 +127,140 @@ static int launch_gamma_xfused(mrl_ctx *ctx, const GammaArgs &a) {
   return MRL_OK;
 }
 
+
+// Conjugate-gradient direction update + tangent application fused into the forward z pass of the Gamma operator:
+//   p <- r + (S[i_num]/S[i_den]) p ;  spec = fft_z( K4 : p )        (MarlinUtils.h:107-117 + FFTMechanics.C:107-108 + the z pass of :105)
+// The tangent couples the 9 components of a grid point, a z transform the points of one line, so a workgroup takes a tile of
+// 512 grid points = R = 512/N complete z lines (the same lines of all 9 fields): phase 1 evaluates the tangent at two points
+// per thread, 16 B per lane and component stream exactly as k_mech_tangent_fm2 does, and parks the 9 results in LDS as the
+// inputs of 9*R/2 complex transforms (two real lines each); phase 2 runs them.  K4:p (9 fields) is never written to HBM nor read
+// back: 2 x 72 of the 450 B per grid point that the two separate kernels move.
+// XUPD: the solution update of the PREVIOUS iteration, x += (S[i_arz]/S[i_apAp]) p_old, rides along (p_old is in registers here
+// anyway; k_cg_update<.., SKIP_X> then leaves x and p alone): one read of the 9-field direction less per iteration.
+template <int N, bool NTV, bool XUPD>
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_z_fwd_tangent(const double *__restrict__ F, const double *__restrict__ K,
+                                                                        const double *__restrict__ mu, double *__restrict__ pdir,
+                                                                        const double *__restrict__ r, const double *__restrict__ S,
+                                                                        int i_num, int i_den, cplx *__restrict__ spec,
+                                                                        long long npts, long long rows_total,
+                                                                        const cplx *__restrict__ tw, double *__restrict__ xsol,
+                                                                        int i_arz, int i_apAp) {
+#pragma clang fp contract(off)
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, NZC = N / 2 + 1, R = 512 / N, NL = 9 * R / 2;
+  static_assert(Plan<N>::NT == 256 && R >= 2 && R % 2 == 0 && NL <= Plan<N>::T, "tile shape");
+  using Map = MapLine<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  double *Xd = reinterpret_cast<double *>(X);
+  const int t = threadIdx.x;
+  const long long tile = xcd_remap(blockIdx.x, gridDim.x);
+  TwRegs<N> twr;
+  tw_issue<N>(twr, tw);
+
+  // ---- phase 1: two grid points per thread
+  const double beta = S[i_num] / S[i_den];
+  const double alpha = XUPD ? S[i_arz] / S[i_apAp] : 0.0;
+  const long long h = tile * 256 + t;
+  {
+    Mat<3> f[2], d[2];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const double2 *fp = reinterpret_cast<const double2 *>(F + (long long)c * npts) + h;
+      const double2 fv = NTV ? ld_nt(fp) : *fp;
+      f[0].a[c / 3][c % 3] = fv.x;
+      f[1].a[c / 3][c % 3] = fv.y;
+      double2 *pp = reinterpret_cast<double2 *>(pdir + (long long)c * npts) + h;
+      const double2 pv = *pp;
+      if (XUPD) {
+        double2 *xp = reinterpret_cast<double2 *>(xsol + (long long)c * npts) + h;
+        const double2 xv = NTV ? ld_nt(xp) : *xp;
+        const double2 xn = make_double2(xv.x + alpha * pv.x, xv.y + alpha * pv.y);
+        if (NTV)
+          st_nt(xp, xn);
+        else
+          *xp = xn;
+      }
+      const double2 rv = reinterpret_cast<const double2 *>(r + (long long)c * npts)[h];
+      const double2 dv = make_double2(rv.x + beta * pv.x, rv.y + beta * pv.y);
+      if (NTV)
+        st_nt(pp, dv);
+      else
+        *pp = dv;
+      d[0].a[c / 3][c % 3] = dv.x;
+      d[1].a[c / 3][c % 3] = dv.y;
+    }
+    const double2 *Kp = reinterpret_cast<const double2 *>(K) + h, *mp = reinterpret_cast<const double2 *>(mu) + h;
+    const double2 Kv = NTV ? ld_nt(Kp) : *Kp, mv = NTV ? ld_nt(mp) : *mp;
+    tw_commit<N>(twr, W);
+    const Mat<3> o0 = svk_tangent<3>(f[0], d[0], Kv.x, mv.x);
+    const Mat<3> o1 = svk_tangent<3>(f[1], d[1], Kv.y, mv.y);
+    // points 2t, 2t+1 of the tile: line (2t)/N, positions z, z+1; lines 2j, 2j+1 are the real / imaginary part of transform j
+    const int row = (2 * t) / N, z = (2 * t) % N, pair = row >> 1, odd = row & 1;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const int line = c * (R / 2) + pair;
+      Xd[2 * Map::at(z, line) + odd] = o0.a[c / 3][c % 3];
+      Xd[2 * Map::at(z + 1, line) + odd] = o1.a[c / 3][c % 3];
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: the 9*R/2 transforms (threads beyond them transform line 0 again and store nothing)
+  const int q = t % TPL, l = t / TPL;
+  const bool valid = l < NL;
+  const int lr = valid ? l : 0;
+  cplx v[P];
+#pragma unroll
+  for (int m = 0; m < P; ++m) v[m] = X[Map::at(q + m * TPL, lr)];
+  __syncthreads();
+  fft_line<N, Map>(v, q, l, X, W);
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
+  __syncthreads();
+  if (!valid) return;
+  const int c = l / (R / 2), pr = l % (R / 2);
+  cplx *o0 = spec + ((long long)c * rows_total + tile * R + 2 * pr) * NZC;
+  cplx *o1 = o0 + NZC;
+#pragma unroll
+  for (int m = 0; m <= P / 2; ++m) {
+    const int k = q + m * TPL;
+    if (k > N / 2) break;
+    const cplx xk = v[m];
+    const cplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
+    o0[k] = make_double2(0.5 * (xk.x + xn.x), 0.5 * (xk.y - xn.y));
+    o1[k] = make_double2(0.5 * (xk.y + xn.y), -0.5 * (xk.x - xn.x));
+  }
+}
+
+template <int N>
+static int launch_gamma_z_fwd_tangent(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
+                                      const double *S, int i_num, int i_den, cplx *spec, long long npts, long long rows, bool nt,
+                                      double *x, int i_arz, int i_apAp) {
+  static bool attr = false;
+  constexpr size_t lds = lds_line<N>();
+  if (!attr) {
+    MRL_TRY(set_lds_attr(ctx, k_gamma_z_fwd_tangent<N, true, true>, lds));
+    MRL_TRY(set_lds_attr(ctx, k_gamma_z_fwd_tangent<N, false, true>, lds));
+    MRL_TRY(set_lds_attr(ctx, k_gamma_z_fwd_tangent<N, true, false>, lds));
+    MRL_TRY(set_lds_attr(ctx, k_gamma_z_fwd_tangent<N, false, false>, lds));
+    attr = true;
+  }
+  const unsigned nb = (unsigned)(npts / 512);
+#define MRL_GZT(NTV_, XU_)                                                                                                        \
+  hipLaunchKernelGGL((k_gamma_z_fwd_tangent<N, NTV_, XU_>), dim3(nb), dim3(256), lds, ctx->stream, F, K, mu, p, r, S, i_num, i_den, \
+                     spec, npts, rows, ctx->ax[2].d_tw, x, i_arz, i_apAp)
+  if (nt) {
+    if (x) MRL_GZT(true, true); else MRL_GZT(true, false);
+  } else {
+    if (x) MRL_GZT(false, true); else MRL_GZT(false, false);
+  }
+#undef MRL_GZT
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
 }  // namespace p2
 
 bool mech_fast_ok(const mrl_ctx *ctx) {
@@ -136,17 +271,11 @@ bool mech_fast_ok(const mrl_ctx *ctx) {
 // out = scale * G(A), A and out field-major real [9][nx][ny][nz] (out may alias A).  dotv != nullptr: the last pass
 // also accumulates sum(out * dotv) into the device scalar d_dot (deterministic two-stage sum)
 int reduce_finalize_from(mrl_ctx *ctx, const double *partial, int nb, double *d_scalar);
-int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale, const double *dotv, double *d_dot) {
+// the passes after the forward z pass: y forward, x + projection, y inverse, z inverse (+ optional dot product)
+static int gamma_fast_rest(mrl_ctx *ctx, cplx *spec, double *out, double scale, const double *dotv, double *d_dot) {
   const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
   const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
-  MRL_TRY(ensure_work(ctx, 4, sizeof(cplx) * nspec * 9));
-  cplx *spec = reinterpret_cast<cplx *>(ctx->d_work[4]);
   const double r = 8.0 * nreal * 9, h = 16.0 * nspec * 9;
-  {
-    ProfScope ps(ctx, "gamma_z_fwd", r + h);
-    p2::ChDev none{};
-    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, A, spec, nullptr, nullptr, none, 9 * nx * ny / 2))));
-  }
   p2::PassArgs pa{};
   pa.in[0] = spec;
   pa.out[0] = spec;
@@ -190,6 +319,50 @@ int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale, const d
   int nb = 0;
   MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_dot<NN>(ctx, spec, out, norm, 9 * nx * ny / 2, dotv, ctx->d_work[3], &nb))));
   return reduce_finalize_from(ctx, ctx->d_work[3], nb, d_dot);
+}
+
+int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale, const double *dotv, double *d_dot) {
+  const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
+  const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
+  MRL_TRY(ensure_work(ctx, 4, sizeof(cplx) * nspec * 9));
+  cplx *spec = reinterpret_cast<cplx *>(ctx->d_work[4]);
+  const double r = 8.0 * nreal * 9, h = 16.0 * nspec * 9;
+  {
+    ProfScope ps(ctx, "gamma_z_fwd", r + h);
+    p2::ChDev none{};
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, A, spec, nullptr, nullptr, none, 9 * nx * ny / 2))));
+  }
+  return gamma_fast_rest(ctx, spec, out, scale, dotv, d_dot);
+}
+
+// the fused CG direction update + tangent + forward z pass exists for z lines of 32 ... 256 points in whole 512-point tiles
+bool gamma_tangent_fusable(const mrl_ctx *ctx) {
+  if (!mech_fast_ok(ctx)) return false;
+  const long long nz = ctx->n[2], rows = ctx->n[0] * ctx->n[1];
+  if (!(nz == 32 || nz == 64 || nz == 128 || nz == 256)) return false;
+  return rows % (512 / nz) == 0;
+}
+
+// [x += (S[i_arz]/S[i_apAp]) p, the previous iteration's solution update, if x != nullptr ;]
+// p <- r + (S[i_num]/S[i_den]) p ; out = G(K4 : p) ; *d_dot = p . out     (one CG iteration's operator application)
+int gamma_fast_tangent_dir(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
+                           const double *S, int i_num, int i_den, double *out, double *d_dot, bool nt, double *x, int i_arz,
+                           int i_apAp) {
+  const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
+  const long long npts = nx * ny * nz, nspec = nx * ny * nzc;
+  MRL_TRY(ensure_work(ctx, 4, sizeof(cplx) * nspec * 9));
+  cplx *spec = reinterpret_cast<cplx *>(ctx->d_work[4]);
+  {
+    ProfScope ps(ctx, "gamma_z_fwd_tangent_dir", 8.0 * npts * ((x ? 6 : 4) * 9 + 2) + 16.0 * nspec * 9);
+    switch (nz) {
+      case 32: MRL_TRY((p2::launch_gamma_z_fwd_tangent<32>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp))); break;
+      case 64: MRL_TRY((p2::launch_gamma_z_fwd_tangent<64>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp))); break;
+      case 128: MRL_TRY((p2::launch_gamma_z_fwd_tangent<128>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp))); break;
+      case 256: MRL_TRY((p2::launch_gamma_z_fwd_tangent<256>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp))); break;
+      default: return set_error(ctx, MRL_ERR_UNSUPPORTED, "gamma_fast_tangent_dir: unplanned z length");
+    }
+  }
+  return gamma_fast_rest(ctx, spec, out, 1.0, p, d_dot);
 }
 
 }  // namespace mrl
