@@ -15,8 +15,11 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# the host driver of this pool only supports dmabuf IPC (RCCL / cross-process device memory); harmless elsewhere
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
