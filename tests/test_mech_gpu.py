@@ -171,3 +171,44 @@ def test_gamma_apply_radix10_sizes(shape):
     ref = mo.gamma_closed_form(dom, A)
     got = _ctx(3, shape, L).gamma_apply(A.cuda()).cpu()
     assert (got - ref).abs().max().item() <= 1e-12
+
+
+def _newton_cg_run(shape, exp, substeps=2):
+    """Newton-CG over `substeps` shear increments on a two-phase RVE of the given shape with the library's experiment mask
+    `exp` (MRL_EXP is read when the context is created)"""
+    import os
+    old = os.environ.get("MRL_EXP")
+    os.environ["MRL_EXP"] = str(exp)
+    try:
+        ctx = _ctx(3, list(shape), [2 * math.pi] * 3)
+    finally:
+        if old is None:
+            del os.environ["MRL_EXP"]
+        else:
+            os.environ["MRL_EXP"] = old
+    nx, ny, nz = shape
+    phase = torch.zeros(shape, dtype=torch.float64)
+    phase[-(9 * nx // 32):, :9 * ny // 32, -(9 * nz // 32):] = 1.0
+    K = ((1.0 - phase) * 0.833 + phase * 8.33).cuda()
+    mu = ((1.0 - phase) * 0.386 + phase * 3.86).cuda()
+    F = torch.eye(3, dtype=torch.float64).expand(*shape, 3, 3).contiguous().cuda()
+    out = []
+    for s in range(substeps):
+        app = torch.eye(3, dtype=torch.float64)
+        app[0, 1] += 0.001 * (s + 1)
+        app = (app - ctx.average(F)).cuda()
+        F, P, st = ctx.mech_newton_cg(F, K, mu, app, l_tol=1e-2, nl_rel_tol=2e-2, nl_abs_tol=2e-2)
+        out.append((F.clone(), P.clone(), st["newton_its"], list(st["cg_its"])))
+    return out
+
+
+@pytest.mark.parametrize("shape", [(32, 32, 32), (40, 32, 64), (32, 48, 256), (128, 128, 128)])
+def test_cg_fused_direction_tangent_z_pass(shape):
+    """the CG iteration with the direction update, the tangent and the forward z pass of G in one kernel and the solution update
+    deferred into it (k_gamma_z_fwd_tangent, z lines of 32 ... 256 points; 128^3 = the streaming variant of BASELINE configs[2])
+    against the same solve with separate kernels (MRL_EXP=32): same Newton / CG iteration counts, same fields"""
+    fused, plain = _newton_cg_run(shape, 0), _newton_cg_run(shape, 32)
+    for (Ff, Pf, nf, cf), (Fp, Pp, np_, cp) in zip(fused, plain):
+        assert nf == np_ and cf == cp
+        assert (Ff - Fp).abs().max().item() <= 1e-13
+        assert (Pf - Pp).abs().max().item() <= 1e-12
