@@ -25,6 +25,7 @@
 #include <sstream>
 
 #include "mrl_internal.h"
+#include "fft_pow2_launch.h"
 
 namespace mrl {
 namespace ex {
@@ -786,27 +787,12 @@ static int build_mu_function(mrl_parsed *p, std::string &out) {
   return MRL_OK;
 }
 
-// lines per workgroup / threads per workgroup of Plan<N> (fft_pow2.h)
+// lines per workgroup / threads per workgroup of the z kernels (ZPlan<N>, fft_pow2.h)
 static int plan_shape(mrl_ctx *ctx, int N, int *T, int *NT) {
-  switch (N) {
-    case 32: case 64: case 128: case 256: case 512: case 1024: *T = 4096 / N; *NT = 256; break;
-    case 40: *T = 64; *NT = 256; break;
-    case 50: *T = 51; *NT = 255; break;
-    case 80: *T = 32; *NT = 256; break;
-    case 100: *T = 25; *NT = 250; break;
-    case 200: *T = 12; *NT = 240; break;
-    case 250: *T = 10; *NT = 250; break;
-    case 400: *T = 6; *NT = 240; break;
-    case 500: *T = 5; *NT = 250; break;
-    case 1000: *T = 2; *NT = 200; break;
-    case 48: *T = 64; *NT = 256; break;
-    case 96: *T = 32; *NT = 256; break;
-    case 144: *T = 21; *NT = 252; break;
-    case 192: *T = 16; *NT = 256; break;
-    case 384: *T = 8; *NT = 256; break;
-    case 768: *T = 4; *NT = 256; break;
-    default: return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
-  }
+  *T = 0;
+  if (!pow2_ok(N)) return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
+  MRL_SWITCH_N(N, (*T = p2::ZPlan<NN>::T, *NT = p2::ZPlan<NN>::NT));
+  if (*T == 0) return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
   return MRL_OK;
 }
 

@@ -58,6 +58,20 @@ MRL_PLAN(144, 12, 12, 12, 1, 1, 21)
 MRL_PLAN(192, 12, 12, 4, 4, 1, 16)
 MRL_PLAN(384, 12, 12, 4, 4, 2, 8)
 MRL_PLAN(768, 12, 12, 4, 4, 4, 4)
+
+// Lines per workgroup of the z kernels (k_z_fwd / k_z_inv / k_z_inv_fwd): their lines are contiguous in memory, so the tile
+// width T of the strided passes (T adjacent lines = one coalesced segment) buys them nothing, while smaller workgroups mean more
+// of them per CU in different phases (load / transform / store).  Measured at 256^3 with 8 instead of 16 lines: z inverse+forward
+// 80 -> 75 us, substep 0.329 -> 0.324 ms in a same-box A/B; the strided passes lose 8-15 % with the same change, hence a
+// separate constant.  Halving or quartering the lines at 128 / 200 / 384 / 512 points changed nothing measurable.
+template <int N>
+struct ZPlan {
+  static constexpr int T = Plan<N>::T, NT = Plan<N>::NT;
+};
+template <>
+struct ZPlan<256> {
+  static constexpr int T = 8, NT = 8 * Plan<256>::TPL;
+};
 #undef MRL_PLAN
 
 __device__ __forceinline__ void bfly4(cplx &a0, cplx &a1, cplx &a2, cplx &a3) {
@@ -228,7 +242,8 @@ template <int N>
 struct MapLine {  // position fastest (lanes vary q): one pad element per 16 positions
   static constexpr int LP = N + N / 16;
   __device__ __forceinline__ static int at(int p, int l) { return l * LP + p + (p >> 4); }
-  static constexpr int size = Plan<N>::T * LP;
+  static constexpr int size = Plan<N>::T * LP;    // for Plan<N>::T lines
+  static constexpr int zsize = ZPlan<N>::T * LP;  // for the z kernels' ZPlan<N>::T lines
 };
 
 // radix-R stage on the P register values (v[i + S*t] = element t of butterfly i, S = P/R butterflies per thread)
@@ -307,24 +322,24 @@ __device__ __forceinline__ unsigned xcd_remap_rev(unsigned b, unsigned nb) {
 // Twiddle staging split in two so that a kernel can issue the table loads BEFORE its operand loads (vmcnt
 // retires in order: the small L2-resident table loads must not queue behind a full HBM round trip) and
 // write them to LDS AFTER the operand loads are in flight.
-template <int N>
+template <int N, int NTH = Plan<N>::NT>
 struct TwRegs {
-  static constexpr int NT = Plan<N>::NT, CNT = (N + NT - 1) / NT;
+  static constexpr int NT = NTH, CNT = (N + NT - 1) / NT;
   cplx v[CNT];
 };
-template <int N>
-__device__ __forceinline__ void tw_issue(TwRegs<N> &r, const cplx *__restrict__ tw) {
+template <int N, int NTH>
+__device__ __forceinline__ void tw_issue(TwRegs<N, NTH> &r, const cplx *__restrict__ tw) {
 #pragma unroll
-  for (int j = 0; j < TwRegs<N>::CNT; ++j) {
-    const int idx = threadIdx.x + j * TwRegs<N>::NT;
+  for (int j = 0; j < TwRegs<N, NTH>::CNT; ++j) {
+    const int idx = threadIdx.x + j * NTH;
     r.v[j] = idx < N ? tw[idx] : make_double2(0.0, 0.0);
   }
 }
-template <int N>
-__device__ __forceinline__ void tw_commit(const TwRegs<N> &r, cplx *W) {
+template <int N, int NTH>
+__device__ __forceinline__ void tw_commit(const TwRegs<N, NTH> &r, cplx *W) {
 #pragma unroll
-  for (int j = 0; j < TwRegs<N>::CNT; ++j) {
-    const int idx = threadIdx.x + j * TwRegs<N>::NT;
+  for (int j = 0; j < TwRegs<N, NTH>::CNT; ++j) {
+    const int idx = threadIdx.x + j * NTH;
     if (idx < N) W[idx] = r.v[j];
   }
 }

@@ -46,10 +46,10 @@ __device__ __forceinline__ double mu_eval(const ChDev &p, double c) {
 //                            (the spectral carry-over pipeline, where c-hat is not recomputed); optional mu_out.
 // nlines = number of complex transforms.
 template <int N, int MODE, int FAM>
-__global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_fwd(const double *__restrict__ in, cplx *__restrict__ out0,
+__global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_fwd(const double *__restrict__ in, cplx *__restrict__ out0,
                                                cplx *__restrict__ out1, double *__restrict__ mu_out, ChDev chp,
                                                long long nlines, const cplx *__restrict__ tw) {
-  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = Plan<N>::T, NZC = N / 2 + 1;
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = ZPlan<N>::T, NZC = N / 2 + 1;
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_fwd(const double *__restri
   const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
   const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
   const bool valid = L < nlines;
-  TwRegs<N> twr;
+  TwRegs<N, ZPlan<N>::NT> twr;
   tw_issue<N>(twr, tw);
 
   cplx v[P];
@@ -125,10 +125,10 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_fwd(const double *__restri
 // DOT: additionally accumulates sum(out * dotv) over the rows written (one partial per workgroup, deterministic): the
 // p.Ap of the conjugate-gradient iteration, taken while Ap is still in registers instead of re-reading it from HBM.
 template <int N, bool DOT = false>
-__global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv(const cplx *__restrict__ in, double *__restrict__ out, double scale,
+__global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const cplx *__restrict__ in, double *__restrict__ out, double scale,
                                                long long nlines, const cplx *__restrict__ tw,
                                                const double *__restrict__ dotv = nullptr, double *__restrict__ partial = nullptr) {
-  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = Plan<N>::T, NZC = N / 2 + 1;
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = ZPlan<N>::T, NZC = N / 2 + 1;
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv(const cplx *__restrict
   const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
   const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
   const bool valid = L < nlines;
-  TwRegs<N> twr;
+  TwRegs<N, ZPlan<N>::NT> twr;
   tw_issue<N>(twr, tw);
   cplx v[P];
   {
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv(const cplx *__restrict
   }
   if (DOT) {
     // workgroup sum through LDS (the exchange tile is free again); NT need not be a multiple of 64
-    constexpr int NT = Plan<N>::NT;
+    constexpr int NT = ZPlan<N>::NT;
     double *S = reinterpret_cast<double *>(X);
     __syncthreads();
     S[threadIdx.x] = acc;
@@ -216,10 +216,10 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv(const cplx *__restrict
 // MU_ONLY (the spectral carry-over of the slab pipeline, where c-hat is not recomputed): the two lines of mu are packed into
 // ONE forward transform -> rows 2L, 2L+1 of out0 = mu-hat_z; out1 unused.
 template <int N, int FAM, bool MU_ONLY = false>
-__global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv_fwd(const cplx *__restrict__ in, cplx *__restrict__ out0,
+__global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const cplx *__restrict__ in, cplx *__restrict__ out0,
                                                                 cplx *__restrict__ out1, double *__restrict__ mu_out, ChDev chp,
                                                                 double scale, long long nlines, const cplx *__restrict__ tw) {
-  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = Plan<N>::T, NZC = N / 2 + 1;
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = ZPlan<N>::T, NZC = N / 2 + 1;
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_z_inv_fwd(const cplx *__rest
   const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
   const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
   const bool valid = L < nlines;
-  TwRegs<N> twr;
+  TwRegs<N, ZPlan<N>::NT> twr;
   tw_issue<N>(twr, tw);
   cplx v[P];
   {
@@ -444,7 +444,11 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub(SubPassArgs a, cons
 }
 
 template <int N>
-constexpr size_t lds_line() {
+constexpr size_t lds_line() {  // the z kernels: ZPlan<N>::T lines
+  return sizeof(cplx) * (N + MapLine<N>::zsize);
+}
+template <int N>
+constexpr size_t lds_line_full() {  // MapLine tiles of Plan<N>::T lines (k_gamma_z_fwd_tangent)
   return sizeof(cplx) * (N + MapLine<N>::size);
 }
 template <int N>

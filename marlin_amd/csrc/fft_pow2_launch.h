@@ -24,9 +24,9 @@ inline int launch_z_fwd(mrl_ctx *ctx, const double *in, cplx *o0, cplx *o1, doub
     MRL_TRY(set_lds_attr(ctx, k_z_fwd<N, MODE, FAM>, lds));
     attr = true;
   }
-  constexpr int LPB = Plan<N>::T;
+  constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_fwd<N, MODE, FAM>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, nlines,
+  hipLaunchKernelGGL((k_z_fwd<N, MODE, FAM>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, nlines,
                      ctx->ax[2].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
@@ -40,9 +40,9 @@ inline int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale,
     MRL_TRY(set_lds_attr(ctx, k_z_inv<N, false>, lds));
     attr = true;
   }
-  constexpr int LPB = Plan<N>::T;
+  constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_inv<N, false>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
+  hipLaunchKernelGGL((k_z_inv<N, false>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
                      ctx->ax[2].d_tw, nullptr, nullptr);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
@@ -58,9 +58,9 @@ inline int launch_z_inv_fwd(mrl_ctx *ctx, const cplx *in, cplx *o0, cplx *o1, do
     MRL_TRY((set_lds_attr(ctx, k_z_inv_fwd<N, FAM, MU_ONLY>, lds)));
     attr = true;
   }
-  constexpr int LPB = Plan<N>::T;
+  constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_inv_fwd<N, FAM, MU_ONLY>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, scale,
+  hipLaunchKernelGGL((k_z_inv_fwd<N, FAM, MU_ONLY>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, scale,
                      nlines, ctx->ax[2].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
@@ -76,9 +76,9 @@ inline int launch_z_inv_dot(mrl_ctx *ctx, const cplx *in, double *out, double sc
     MRL_TRY(set_lds_attr(ctx, k_z_inv<N, true>, lds));
     attr = true;
   }
-  constexpr int LPB = Plan<N>::T;
+  constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_inv<N, true>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
+  hipLaunchKernelGGL((k_z_inv<N, true>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
                      ctx->ax[2].d_tw, dotv, partial);
   MRL_HIP(ctx, hipGetLastError());
   *nblocks = (int)nb;

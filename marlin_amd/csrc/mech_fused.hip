@@ -239,7 +239,7 @@ static int launch_gamma_z_fwd_tangent(mrl_ctx *ctx, const double *F, const doubl
                                       const double *S, int i_num, int i_den, cplx *spec, long long npts, long long rows, bool nt,
                                       double *x, int i_arz, int i_apAp) {
   static bool attr = false;
-  constexpr size_t lds = lds_line<N>();
+  constexpr size_t lds = lds_line_full<N>();
   if (!attr) {
     MRL_TRY(set_lds_attr(ctx, k_gamma_z_fwd_tangent<N, true, true>, lds));
     MRL_TRY(set_lds_attr(ctx, k_gamma_z_fwd_tangent<N, false, true>, lds));
