@@ -351,6 +351,18 @@ int mrl_mech_displacements(mrl_ctx *ctx, const double *d_F, double *d_disp);
  * rank-two field [grid..., D, D] -> [grid...] with the reference's 2-D / 3-D formulas and term order. */
 int mrl_mech_von_mises(mrl_ctx *ctx, const double *d_stress, double *d_out);
 
+/* Homogeneous small-strain elasticity coupled to a concentration field by the volumetric eigenstrain e0*c (3-D, serial,
+ * half-spectrum contexts; test/tests/tensor_compute/coupled_pf_mech.i).
+ *   mrl_qs_elasticity               FFTQuasistaticElasticity::computeBuffer (src/tensor_computes/FFTQuasistaticElasticity.C:46-104):
+ *                                   per k-point A u-hat = b with A_ij from (mu, lambda) and k = 2 pi i * reciprocal axis,
+ *                                   b = k * 2 e0 (3 lambda + mu) c-hat, A_ii = 1 and b = 0 at k = 0; d_disp[0..2] (real
+ *                                   [nx][ny][nz]) receive the inverse transforms.  d_cbar: half spectrum of c (mrl_fft_r2c).
+ *   mrl_elastic_chemical_potential  FFTElasticChemicalPotential::computeBuffer (src/tensor_computes/FFTElasticChemicalPotential.C:47-61):
+ *                                   d_out (half spectrum) = -e0 (e0 (9 lambda + 6 mu) c-hat - (2 mu + 3 lambda) k . u-hat). */
+int mrl_qs_elasticity(mrl_ctx *ctx, const double *d_cbar, double mu, double lambda, double e0, double *const *d_disp);
+int mrl_elastic_chemical_potential(mrl_ctx *ctx, const double *d_cbar, const double *const *d_disp, double mu, double lambda,
+                                   double e0, double *d_out);
+
 /* ---- parsed pointwise expressions: ParsedCompute (src/tensor_computes/ParsedCompute.C:50-265) ----------------
  * expression text -> AST -> d/d(derivatives[0]) d/d(derivatives[1]) ... -> simplify -> one fused HIP kernel (hiprtc).
  * Grammar, derivative and simplification rules follow the reference's parser (they fix the floating-point

@@ -96,6 +96,8 @@ SIGNATURES = {
     "mrl_mech_tangent_apply_fm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mrl_mech_displacements": (_i32, [_vp, _vp, _vp]),
     "mrl_mech_von_mises": (_i32, [_vp, _vp, _vp]),
+    "mrl_qs_elasticity": (_i32, [_vp, _vp, _dbl, _dbl, _dbl, _pp]),
+    "mrl_elastic_chemical_potential": (_i32, [_vp, _vp, _pp, _dbl, _dbl, _dbl, _vp]),
     "mrl_broyden_init": (_i32, [_vp, _i32, _dbl, _vp, _i64]),
     "mrl_broyden_residual": (_i32, [_vp, _i32, _pp, _pp, _pp, _pp, _dbl, _vp, C.POINTER(_dbl), _i64]),
     "mrl_broyden_predict": (_i32, [_vp, _i32, _vp, _vp, _pp, _dbl, _vp, _pp, _i64]),

@@ -302,6 +302,20 @@ class Context:
         self._check(self.lib.mrl_mech_von_mises(self.h, _ptr(stress), _ptr(out)))
         return out
 
+    def qs_elasticity(self, cbar: torch.Tensor, mu: float, lam: float, e0: float):
+        """FFTQuasistaticElasticity: the three displacement fields of the homogeneous elastic equilibrium with eigenstrain e0*c"""
+        disp = [torch.empty(self.real_shape, dtype=torch.float64, device=cbar.device) for _ in range(3)]
+        arr = (C.c_void_p * 3)(*[d.data_ptr() for d in disp])
+        self._check(self.lib.mrl_qs_elasticity(self.h, _ptr(cbar), mu, lam, e0, arr))
+        return disp
+
+    def elastic_chemical_potential(self, cbar: torch.Tensor, disp, mu: float, lam: float, e0: float) -> torch.Tensor:
+        """FFTElasticChemicalPotential: reciprocal-space elastic contribution to the chemical potential"""
+        out = self.empty_spec()
+        arr = (C.c_void_p * 3)(*[d.data_ptr() for d in disp])
+        self._check(self.lib.mrl_elastic_chemical_potential(self.h, _ptr(cbar), arr, mu, lam, e0, _ptr(out)))
+        return out
+
     def mech_tangent_apply(self, F, K, mu, dF, out=None):
         if out is None:
             out = torch.empty_like(F)

@@ -122,6 +122,53 @@ static int run_cahnhilliard(DomainAction & domain, const std::string & out)
   return 0;
 }
 
+// test/tests/tensor_compute/coupled_pf_mech.i: Cahn-Hilliard + the elastic chemical potential of a homogeneous solid with the
+// eigenstrain e0*c (FFTQuasistaticElasticity, FFTElasticChemicalPotential), legacy FFTSemiImplicit integrator.  Operators are
+// added in the dependency-resolved order of the input's [Solve] group.
+static int run_coupled_pf_mech(DomainAction & domain, const std::string & out)
+{
+  TensorProblem problem(domain);
+  const std::size_t n = domain.getNumberOfCells();
+  problem.getBuffer("c") = DeviceTensor::fromHost(read_bin(arg("ic"), n));
+  for (const char * d : {"disp_x", "disp_y", "disp_z"})
+    problem.getBuffer(d) = DeviceTensor::zeros(n);  // RandomTensor min = max = 0
+  const double lame_mu = argd("mu", 50.0), lambda = argd("lambda", 100.0), e0 = argd("e0", 0.02);
+  ReciprocalLaplacianFactor(problem, "Mbar", "Mbar", argd("mobility", 0.2)).computeBuffer();
+  ReciprocalLaplacianFactor(problem, "kappabarbar", "kappabarbar", argd("kappa", -0.001), 2).computeBuffer();
+  const std::vector<std::string> disp = {"disp_x", "disp_y", "disp_z"};
+  auto root = std::make_shared<ComputeGroup>(problem, "Solve");
+  ParsedCompute::Params pm;
+  pm.buffer = "mu";
+  pm.expression = arg("expression", "0.1*c^2*(c-1)^2");
+  pm.inputs = {"c"};
+  pm.derivatives = {"c"};
+  root->add(std::make_shared<ParsedCompute>(problem, "mu", pm));
+  root->add(std::make_shared<ForwardFFT>(problem, "mubar", "mubar", "mu"));
+  root->add(std::make_shared<ForwardFFT>(problem, "cbar", "cbar", "c"));
+  root->add(std::make_shared<FFTQuasistaticElasticity>(problem, "qsmech", disp, "cbar", lame_mu, lambda, e0));
+  root->add(std::make_shared<FFTElasticChemicalPotential>(problem, "mumechbar", "mumechbar", disp, "cbar", lame_mu, lambda, e0));
+  root->add(std::make_shared<InverseFFT>(problem, "mumech", "mumech", "mumechbar"));
+  ParsedCompute::Params pn;
+  pn.buffer = "Mbarmubar";
+  pn.expression = "Mbar*(mubar+mumechbar)";
+  pn.inputs = {"Mbar", "mubar", "mumechbar"};
+  pn.complex_inputs = {"mubar", "mumechbar"};
+  pn.reciprocal = true;
+  root->add(std::make_shared<ParsedCompute>(problem, "Mbarmubar", pn));
+  auto ti = std::make_shared<FFTSemiImplicit>(problem, "c", "c", "cbar", "kappabarbar", "Mbarmubar", 1);
+  TimeIntegratorSolver solver(problem, "solver", (unsigned int)argi("substeps", 10), root,
+                              std::vector<std::shared_ptr<TensorOperatorBase>>{ti});
+  Transient ex(problem, solver, argd("dt", 0.1));
+  dump(out, "c", 0, problem.getBuffer("c"));
+  ex.execute((int)argi("num_steps", 2), [&](int step) {
+    dump(out, "c", step, problem.getBuffer("c"));
+    dump(out, "mumech", step, problem.getBuffer("mumech"));
+    for (const auto & d : disp)
+      dump(out, d, step, problem.getBuffer(d));
+  });
+  return 0;
+}
+
 static int run_mechanics(DomainAction & domain, const std::string & out)
 {
   TensorProblem problem(domain);
@@ -670,6 +717,8 @@ int main(int argc, char ** argv)
       return run_postprocessors(domain, out);
     if (problem == "cahnhilliard_explicit")
       return run_cahnhilliard_explicit(domain, out);
+    if (problem == "coupled_pf_mech")
+      return run_coupled_pf_mech(domain, out);
     if (problem == "kks")
       return run_kks(domain, out);
     if (problem == "interface_velocity")

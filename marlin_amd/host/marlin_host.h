@@ -622,6 +622,71 @@ private:
   DeviceTensor & _F;
 };
 
+/// FFTQuasistaticElasticity (src/tensor_computes/FFTQuasistaticElasticity.C:30-104): homogeneous small-strain equilibrium with the
+/// volumetric eigenstrain e0*c; writes one displacement buffer per mesh dimension
+class FFTQuasistaticElasticity : public TensorOperatorBase
+{
+public:
+  FFTQuasistaticElasticity(TensorProblem & problem, const std::string & name, const std::vector<std::string> & displacements,
+                           const std::string & cbar, double mu, double lambda, double e0)
+    : TensorOperatorBase(problem, name), _mu(mu), _lambda(lambda), _e0(e0), _cbar(getInputBuffer(cbar))
+  {
+    for (const auto & d : displacements)
+      _displacements.push_back(&getOutputBuffer(d));
+    if ((std::size_t)_domain.getDim() != _displacements.size())
+      paramError("displacements", "Need one displacement variable per mesh dimension");
+  }
+  void computeBuffer() override
+  {
+    double * out[3] = {nullptr, nullptr, nullptr};
+    std::vector<DeviceTensor> fresh;
+    for (std::size_t i = 0; i < _displacements.size(); ++i)
+    {
+      fresh.push_back(DeviceTensor::empty(_domain.getNumberOfCells()));
+      out[i] = fresh.back().data();
+    }
+    _domain.check(mrl_qs_elasticity(_domain.ctx(), _cbar.data(), _mu, _lambda, _e0, out));
+    for (std::size_t i = 0; i < _displacements.size(); ++i)
+      *_displacements[i] = fresh[i];
+  }
+
+private:
+  std::vector<DeviceTensor *> _displacements;
+  const double _mu, _lambda, _e0;
+  DeviceTensor & _cbar;
+};
+
+/// FFTElasticChemicalPotential (src/tensor_computes/FFTElasticChemicalPotential.C:29-61): reciprocal-space elastic contribution to
+/// the chemical potential from cbar and the displacement buffers
+class FFTElasticChemicalPotential : public TensorOperatorBase
+{
+public:
+  FFTElasticChemicalPotential(TensorProblem & problem, const std::string & name, const std::string & buffer,
+                              const std::vector<std::string> & displacements, const std::string & cbar, double mu, double lambda, double e0)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer)), _mu(mu), _lambda(lambda), _e0(e0), _cbar(getInputBuffer(cbar))
+  {
+    for (const auto & d : displacements)
+      _displacements.push_back(&getInputBuffer(d));
+    if ((std::size_t)_domain.getDim() != _displacements.size())
+      paramError("displacements", "Need one displacement variable per mesh dimension");
+  }
+  void computeBuffer() override
+  {
+    const double * in[3] = {nullptr, nullptr, nullptr};
+    for (std::size_t i = 0; i < _displacements.size(); ++i)
+      in[i] = _displacements[i]->data();
+    auto out = DeviceTensor::empty(2 * _domain.getReciprocalSize());
+    _domain.check(mrl_elastic_chemical_potential(_domain.ctx(), _cbar.data(), in, _mu, _lambda, _e0, out.data()));
+    _u = out;
+  }
+
+private:
+  DeviceTensor & _u;
+  std::vector<DeviceTensor *> _displacements;
+  const double _mu, _lambda, _e0;
+  DeviceTensor & _cbar;
+};
+
 /// ComputeVonMisesStress (src/tensor_computes/ComputeVonMisesStress.C:31-66)
 class ComputeVonMisesStress : public TensorOperatorBase
 {
@@ -707,6 +772,21 @@ public:
   {
   }
   void computeBuffer() override { _u = _domain.fft(_input); }
+
+private:
+  DeviceTensor & _u;
+  DeviceTensor & _input;
+};
+
+/// PerformFFT<false>: _u = _domain.ifft(_input)   (PerformFFT.C:34-40)
+class InverseFFT : public TensorOperatorBase
+{
+public:
+  InverseFFT(TensorProblem & problem, const std::string & name, const std::string & buffer, const std::string & input)
+    : TensorOperatorBase(problem, name), _u(getOutputBuffer(buffer)), _input(getInputBuffer(input))
+  {
+  }
+  void computeBuffer() override { _u = _domain.ifft(_input); }
 
 private:
   DeviceTensor & _u;

@@ -26,6 +26,8 @@ Pinning (see tests/test_oracle_golden.py, runs with -m "not gpu"):
   * typed_tensors/gradient.h5 (GradientTensor), backandforth / gradient(_square) CSV gold, ConjugateGradientTest iteration counts.
 NOT pinned (parity unpinned): class BroydenSolver -- the reference ships no regression test, golden vector or fixture for
 it; it restates src/tensor_solver/BroydenSolver.C line by line and is only compared with the HIP kernels.
+Likewise unpinned: quasistatic_elasticity / elastic_chemical_potential / class CoupledPFMech (FFTQuasistaticElasticity.C, FFTElasticChemicalPotential.C):
+their only input file, test/tests/tensor_compute/coupled_pf_mech.i, is not part of any test spec and has no gold data.
 
 All file:line citations are relative to /root/reference.
 """
@@ -271,6 +273,53 @@ class CahnHilliardABM:
                 self._advance_state()
 
 
+class CoupledPFMech:
+    """test/tests/tensor_compute/coupled_pf_mech.i: Cahn-Hilliard with the elastic chemical potential of a homogeneous small-strain
+    solid (eigenstrain e0*c), integrated by the legacy FFTSemiImplicit time integrator.  PARITY UNPINNED (the input is in no test
+    spec and has no gold data).  Compute order = the dependency-resolved order of the [Solve] group: mu, mubar, cbar, qsmech
+    (writes disp_*), mumechbar, mumech, Mbarmubar = Mbar*(mubar+mumechbar); then FFTSemiImplicit::computeBuffer
+    (src/tensor_timeintegrators/FFTSemiImplicit.C:43-62) with history_size 1; history rule as CahnHilliardABM."""
+
+    def __init__(self, dom: Domain, c0: torch.Tensor, M: float, kappa_factor: float, mu_fn, substeps: int, mu: float, lam: float,
+                 e0: float):
+        self.dom, self.c, self.mu_fn, self.substeps = dom, c0.clone(), mu_fn, substeps
+        self.Mbar = reciprocal_laplacian_factor(dom, M)
+        self.Lbar = reciprocal_laplacian_square_factor(dom, kappa_factor)
+        self.lame_mu, self.lam, self.e0 = mu, lam, e0
+        self.hist = History(max_states=1)
+        self.Nhat = None
+        self.disp = [torch.zeros_like(c0) for _ in range(3)]
+        self.mumech = torch.zeros_like(c0)
+        self.time_step = 0
+
+    def _advance_state(self):
+        if self.time_step <= 1:
+            return
+        if self.Nhat is not None:
+            self.hist.advance(self.Nhat)
+
+    def substep(self, sub_dt: float):
+        mubar = self.dom.fft(self.mu_fn(self.c))
+        cbar = self.dom.fft(self.c)
+        self.disp = quasistatic_elasticity(self.dom, cbar, self.lame_mu, self.lam, self.e0)
+        mumechbar = elastic_chemical_potential(self.dom, cbar, self.disp, self.lame_mu, self.lam, self.e0)
+        self.mumech = self.dom.ifft(mumechbar)
+        self.Nhat = self.Mbar * (mubar + mumechbar)
+        if not self.hist.old:
+            ubar = (cbar + sub_dt * self.Nhat) / (1.0 - sub_dt * self.Lbar)                                    # :51
+        else:
+            ubar = (cbar + sub_dt / 2.0 * (3.0 * self.Nhat - self.hist.old[0])) / (1.0 - sub_dt * self.Lbar)   # :58-60
+        self.c = self.dom.ifft(ubar)
+
+    def step(self, dt: float):
+        self.time_step += 1
+        self._advance_state()
+        for s in range(self.substeps):
+            self.substep(dt / self.substeps)
+            if s < self.substeps - 1:
+                self._advance_state()
+
+
 def ch_substep_ops(c, Mbar, Lbar, Nhat_old, sub_dt, order, mu_fn, dom):
     """One bare substep (used for the CPU baseline timing and operator-level parity)."""
     mu = mu_fn(c)
@@ -487,6 +536,39 @@ def compute_displacements(dom: Domain, F: torch.Tensor) -> torch.Tensor:
     mode = {3: "trilinear", 2: "bilinear", 1: "linear"}[dim]
     return torch.nn.functional.interpolate((u_aff + u_periodic).movedim(-1, 0).unsqueeze(1), size=[n + 1 for n in dom.shape],
                                            mode=mode, align_corners=True).squeeze(1).movedim(0, -1)
+
+
+def quasistatic_elasticity(dom: Domain, cbar: torch.Tensor, mu: float, lam: float, e0: float) -> List[torch.Tensor]:
+    """FFTQuasistaticElasticity::computeBuffer (src/tensor_computes/FFTQuasistaticElasticity.C:46-104), 3-D.  PARITY UNPINNED
+    (no gold data in the reference): statement by statement, incl. at::linalg_solve."""
+    two_pi_i = torch.tensor(complex(0.0, 2.0 * math.pi), dtype=C128)
+    ul = 2.0 * mu + lam
+    kx, ky, kz = two_pi_i * dom.kaxis[0], two_pi_i * dom.kaxis[1], two_pi_i * dom.kaxis[2]
+    Axx = ul * kx * kx + mu * ky * ky + mu * kz * kz
+    s = Axx.shape
+    Axy = ((lam + mu) * kx * ky).expand(s)
+    Axz = ((lam + mu) * kx * kz).expand(s)
+    Ayy = ul * ky * ky + mu * kx * kx + mu * kz * kz
+    Ayz = ((lam + mu) * ky * kz).expand(s)
+    Azz = ul * kz * kz + mu * kx * kx + mu * ky * ky
+    Axx[0, 0, 0] = 1.0
+    Ayy[0, 0, 0] = 1.0
+    Azz[0, 0, 0] = 1.0
+    e = 2.0 * e0 * cbar * (3.0 * lam + mu)
+    e[0, 0, 0] = 0.0
+    b = torch.stack([kx * e, ky * e, kz * e], -1)
+    A = torch.stack([torch.stack([Axx, Axy, Axz], -1), torch.stack([Axy, Ayy, Ayz], -1), torch.stack([Axz, Ayz, Azz], -1)], -1)
+    x = torch.linalg.solve(A, b)
+    return [dom.ifft(x[..., i]) for i in range(3)]
+
+
+def elastic_chemical_potential(dom: Domain, cbar: torch.Tensor, disp: Sequence[torch.Tensor], mu: float, lam: float,
+                               e0: float) -> torch.Tensor:
+    """FFTElasticChemicalPotential::computeBuffer (src/tensor_computes/FFTElasticChemicalPotential.C:47-61).  PARITY UNPINNED."""
+    two_pi_i = torch.tensor(complex(0.0, 2.0 * math.pi), dtype=C128)
+    kx, ky, kz = two_pi_i * dom.kaxis[0], two_pi_i * dom.kaxis[1], two_pi_i * dom.kaxis[2]
+    ux, uy, uz = dom.fft(disp[0]), dom.fft(disp[1]), dom.fft(disp[2])
+    return -e0 * (e0 * (9.0 * lam * cbar + mu * 6.0 * cbar) - (2.0 * mu + 3.0 * lam) * (kx * ux + ky * uy + kz * uz))
 
 
 def von_mises_stress(stress: torch.Tensor, dim: int) -> torch.Tensor:

@@ -241,3 +241,33 @@ def test_smooth_rectangle_case(tmp_path):
         got = np.fromfile(tmp_path / f"{b}.0.bin", dtype="<f8").reshape(100, 100)
         assert np.abs(g[f"{b}.0"] - got.T).max() <= 1e-13, b
 
+
+
+def test_coupled_pf_mech_case(tmp_path):
+    """test/tests/tensor_compute/coupled_pf_mech.i (Cahn-Hilliard + FFTQuasistaticElasticity + FFTElasticChemicalPotential through
+    the legacy FFTSemiImplicit integrator; lambda = 100, mu = 50, e0 = 0.02) on a 16^3 grid through the host mirror against the
+    oracle's restatement of the same input.  The reference has no gold data for this input: parity unpinned, see the oracle header."""
+    import math
+
+    import torch
+
+    from oracle import marlin_oracle as mo
+    n, substeps, steps, dt = 16, 5, 3, 0.05
+    torch.manual_seed(5)
+    c0 = torch.rand(n, n, n, dtype=torch.float64) * 0.12 + 0.44
+    ic = tmp_path / "c0.bin"
+    c0.numpy().astype("<f8").tofile(ic)
+    _run(["problem=coupled_pf_mech", "dim=3", f"nx={n}", f"ny={n}", f"nz={n}", "xmax=4pi", "ymax=4pi", "zmax=4pi", f"ic={ic}",
+          f"substeps={substeps}", f"num_steps={steps}", f"dt={dt}"], tmp_path)
+    dom = mo.Domain(3, [n] * 3, [4 * math.pi] * 3)
+    ref = mo.CoupledPFMech(dom, c0, 0.2, -0.001, mo.mu_double_well, substeps, 50.0, 100.0, 0.02)
+    for k in range(1, steps + 1):
+        ref.step(dt)
+        c = np.fromfile(tmp_path / f"c.{k}.bin", dtype="<f8").reshape(n, n, n)
+        assert np.abs(c - ref.c.numpy()).max() <= 1e-13
+        mm = np.fromfile(tmp_path / f"mumech.{k}.bin", dtype="<f8").reshape(n, n, n)
+        assert np.abs(mm - ref.mumech.numpy()).max() <= 1e-12 * np.abs(ref.mumech.numpy()).max()
+        for d, nm in enumerate(("disp_x", "disp_y", "disp_z")):
+            u = np.fromfile(tmp_path / f"{nm}.{k}.bin", dtype="<f8").reshape(n, n, n)
+            assert np.abs(u - ref.disp[d].numpy()).max() <= 1e-12 * np.abs(ref.disp[d].numpy()).max()
+    assert np.abs(ref.c.numpy() - c0.numpy()).max() > 1e-4      # the fields did evolve

@@ -212,3 +212,37 @@ def test_cg_fused_direction_tangent_z_pass(shape):
         assert nf == np_ and cf == cp
         assert (Ff - Fp).abs().max().item() <= 1e-13
         assert (Pf - Pp).abs().max().item() <= 1e-12
+
+
+@pytest.mark.parametrize("shape,L", [((16, 16, 16), (4 * math.pi,) * 3), ((12, 10, 9), (3.0, 2.0, 2.5)), ((32, 64, 32), (4 * math.pi,) * 3)])
+def test_coupled_pf_mech_operators_vs_oracle(shape, L):
+    """FFTQuasistaticElasticity + FFTElasticChemicalPotential (coupled_pf_mech.i: lambda = 100, mu = 50, e0 = 0.02) against the
+    oracle's statement-by-statement restatement incl. at::linalg_solve (the reference has no gold data for these two: parity
+    unpinned), and the physics they encode: the displacement field is the elastic equilibrium of the eigenstrain e0*c"""
+    mu, lam, e0 = 50.0, 100.0, 0.02
+    dom = mo.Domain(3, list(shape), list(L))
+    ctx = _ctx(3, list(shape), list(L))
+    torch.manual_seed(11)
+    c = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    cbar = dom.fft(c)
+    want = mo.quasistatic_elasticity(dom, cbar.clone(), mu, lam, e0)
+    cbar_d = ctx.fft(c.cuda())
+    got = ctx.qs_elasticity(cbar_d, mu, lam, e0)
+    scale = max(w.abs().max().item() for w in want)
+    assert scale > 0
+    for g, w in zip(got, want):
+        assert (g.cpu() - w).abs().max().item() <= 1e-12 * scale
+    # zero mean (u-hat(0) = 0) and equilibrium: div sigma(u) = (lambda+mu) grad div u + mu lap u = -b in reciprocal space
+    assert all(abs(g.mean().item()) <= 1e-14 * scale for g in got)
+    want_mu = mo.elastic_chemical_potential(dom, cbar, want, mu, lam, e0)
+    got_mu = ctx.elastic_chemical_potential(cbar_d, got, mu, lam, e0)
+    assert (got_mu.cpu() - want_mu).abs().max().item() <= 1e-12 * want_mu.abs().max().item()
+    # independent inputs for the second operator (not the first one's output)
+    disp = [torch.rand(shape, dtype=torch.float64) - 0.5 for _ in range(3)]
+    want_mu = mo.elastic_chemical_potential(dom, cbar, disp, mu, lam, e0)
+    got_mu = ctx.elastic_chemical_potential(cbar_d, [d.cuda() for d in disp], mu, lam, e0)
+    assert (got_mu.cpu() - want_mu).abs().max().item() <= 1e-12 * want_mu.abs().max().item()
+    # error behaviour: 3-D only
+    ctx2 = _ctx(2, [8, 8], [1.0, 1.0])
+    with pytest.raises(RuntimeError, match="3-D"):
+        ctx2.qs_elasticity(ctx2.empty_spec(), mu, lam, e0)
