@@ -376,6 +376,8 @@ static int run_rotating_grain_secant(DomainAction & domain, const std::string & 
   sp.dt_epsilon = argd("dt_epsilon", 1e-4);
   sp.verbose = argi("verbose", 0) != 0;
   SecantSolver solver(problem, "solver", root, {{"psi", "psibar", "linear", "psi3bar"}}, sp);
+  if (!arg("predictor_scale").empty())  // [TensorSolver/Predictors] type = LinearTensorPredictor, buffer = psi
+    solver.addPredictor(std::make_shared<LinearTensorPredictor>(problem, "psi", argd("predictor_scale", 1.0)));
   TensorSolveIterationAdaptiveDT ts(solver, argd("dt", 1.0), (unsigned int)argi("ts_min_iterations", 100),
                                     (unsigned int)argi("ts_max_iterations", 400), argd("growth_factor", 1.4),
                                     argd("cutback_factor", 0.9), argd("dtmax", 500.0));

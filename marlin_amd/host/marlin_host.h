@@ -1159,15 +1159,66 @@ protected:
 
 
 /// IterativeTensorSolverInterface (include/tensor_solver/IterativeTensorSolverInterface.h): what the time stepper queries
+/// TensorPredictor (src/tensor_predictor/TensorPredictor.C:15-41): forward-predicts a solver output buffer from its old states
+class TensorPredictor
+{
+public:
+  TensorPredictor(TensorProblem & problem, const std::string & buffer, unsigned int history_size = 1)
+    : _domain(problem.domain()), _u(problem.getBuffer(buffer)), _u_old(problem.getBufferOld(buffer, history_size))
+  {
+  }
+  virtual ~TensorPredictor() = default;
+  virtual void computeBuffer() = 0;
+
+protected:
+  DomainAction & _domain;
+  DeviceTensor & _u;
+  const std::vector<DeviceTensor> & _u_old;
+};
+
+/// LinearTensorPredictor (src/tensor_predictor/LinearTensorPredictor.C:19-46): u += scale * (u_old[0] - u_old[1]), history_size 2
+class LinearTensorPredictor : public TensorPredictor
+{
+public:
+  LinearTensorPredictor(TensorProblem & problem, const std::string & buffer, double scale = 1.0)
+    : TensorPredictor(problem, buffer, 2), _scale(scale)
+  {
+  }
+  void computeBuffer() override
+  {
+    if (_u_old.size() > 1)
+    {
+      const int64_t n = (int64_t)_u.numel();
+      auto diff = DeviceTensor::empty(_u.numel());
+      _domain.check(mrl_axpby(_domain.ctx(), 1.0, _u_old[0].data(), -1.0, _u_old[1].data(), diff.data(), n));   // :38
+      auto out = DeviceTensor::empty(_u.numel());
+      // :39-42 (diff * 1.0 is exact, so the two branches of the reference coincide)
+      _domain.check(mrl_axpby(_domain.ctx(), 1.0, _u.data(), _scale, diff.data(), out.data(), n));
+      _u = out;
+    }
+  }
+
+private:
+  const double _scale;
+};
+
+/// IterativeTensorSolverInterface (src/tensor_solver/IterativeTensorSolverInterface.C:12-31)
 class IterativeTensorSolverInterface
 {
 public:
   const unsigned int & getIterations() const { return _iterations; }
   const bool & isConverged() const { return _is_converged; }
+  void addPredictor(std::shared_ptr<TensorPredictor> predictor) { _predictors.push_back(std::move(predictor)); }
 
 protected:
+  void applyPredictors()
+  {
+    for (const auto & pred : _predictors)
+      pred->computeBuffer();
+  }
   unsigned int _iterations = 0;
   bool _is_converged = true;
+  std::vector<std::shared_ptr<TensorPredictor>> _predictors;
 };
 
 /// SwiftHohenbergLinear: _u = r - alpha^2 (1 - k^2)^2   (SwiftHohenbergLinear.C:35-39) as one generated kernel
@@ -1336,6 +1387,7 @@ protected:
       if (_p.verbose)
         std::printf("|R0|=%g\n", R0norm[i]);
     }
+    applyPredictors();                                                               // :100 (on solver outputs)
     bool all_converged = false;
     for (_iterations = 0; _iterations < _p.max_iterations; ++_iterations)           // :112-165
     {

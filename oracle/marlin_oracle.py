@@ -26,7 +26,8 @@ Pinning (see tests/test_oracle_golden.py, runs with -m "not gpu"):
   * typed_tensors/gradient.h5 (GradientTensor), backandforth / gradient(_square) CSV gold, ConjugateGradientTest iteration counts.
 NOT pinned (parity unpinned): class BroydenSolver -- the reference ships no regression test, golden vector or fixture for
 it; it restates src/tensor_solver/BroydenSolver.C line by line and is only compared with the HIP kernels.
-Likewise unpinned: quasistatic_elasticity / elastic_chemical_potential / class CoupledPFMech (FFTQuasistaticElasticity.C, FFTElasticChemicalPotential.C):
+Likewise unpinned: SecantSolver.add_predictor (LinearTensorPredictor; no reference test uses a predictor), quasistatic_elasticity /
+elastic_chemical_potential / class CoupledPFMech (FFTQuasistaticElasticity.C, FFTElasticChemicalPotential.C):
 their only input file, test/tests/tensor_compute/coupled_pf_mech.i, is not part of any test spec and has no gold data.
 
 All file:line citations are relative to /root/reference.
@@ -887,6 +888,28 @@ class SecantSolver:
         self.max_it, self.rtol, self.atol, self.damping, self.eps = (max_iterations, relative_tolerance, absolute_tolerance,
                                                                      damping, dt_epsilon)
         self.iterations, self.converged = 0, True
+        self.predictors: List[Tuple[str, float]] = []
+        self.hist: dict = {}
+        self.time_step = 0
+
+    def add_predictor(self, buffer: str, scale: float = 1.0) -> None:
+        """LinearTensorPredictor on a solver output (src/tensor_predictor/LinearTensorPredictor.C:19-46; history_size 2).  The
+        reference has no test with a predictor: this part is NOT pinned by gold data."""
+        self.predictors.append((buffer, scale))
+        self.hist[buffer] = History(max_states=2)
+
+    def _advance_state(self) -> None:                                 # TensorProblem.C:451-472
+        if self.time_step <= 1:
+            return
+        for b, h in self.hist.items():
+            h.advance(self.state[b])
+
+    def _apply_predictors(self) -> None:                              # IterativeTensorSolverInterface.C:19-24
+        for b, scale in self.predictors:
+            old = self.hist[b].old
+            if len(old) > 1:
+                diff = old[0] - old[1]
+                self.state[b] = self.state[b] + diff if scale == 1.0 else self.state[b] + diff * scale
 
     def substep(self, sub_dt: float):
         s, n = self.state, len(self.vars)
@@ -899,6 +922,7 @@ class SecantSolver:
             R0[i] = torch.norm(Rprev[i]).item()
             u_old[i] = u
             s[ub] = self.dom.ifft((u + self.eps * Nn) / (1.0 - self.eps * L) if L is not None else u + self.eps * Nn)
+        self._apply_predictors()                                      # :100
         all_converged = False
         self.iterations = 0
         while self.iterations < self.max_it:                          # :112-165
@@ -927,8 +951,12 @@ class SecantSolver:
             self.converged = False
 
     def step(self, dt: float):
-        for _ in range(self.substeps):
+        self.time_step += 1
+        self._advance_state()
+        for k in range(self.substeps):
             self.substep(dt / self.substeps)
+            if k < self.substeps - 1:                                 # TensorSolver.C:104-105
+                self._advance_state()
 
 
 class BroydenSolver:

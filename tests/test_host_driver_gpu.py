@@ -131,6 +131,37 @@ def test_rotating_grain_secant_case(tmp_path):
     assert worst <= 1e-10, worst
 
 
+@pytest.mark.parametrize("scale", [1.0, 0.5])
+def test_rotating_grain_secant_with_predictor(scale, tmp_path):
+    """the same case with a LinearTensorPredictor on psi (src/tensor_predictor/LinearTensorPredictor.C:19-46, applied by
+    SecantSolver.C:100 through IterativeTensorSolverInterface::applyPredictors): host mirror against the oracle.  The reference
+    has no test that uses a predictor, so this is parity against the restatement only (unpinned)"""
+    import math
+
+    import torch
+
+    from oracle import marlin_oracle as mo
+    from tests.test_oracle_golden import rotating_grain_problem
+    g = load_golden("rotating_grain_secant_gold.npz")
+    ic = tmp_path / "psi0.bin"
+    g["psi.0"].astype("<f8").tofile(ic)
+    ymax = 6 * math.pi * 2 / math.sin(math.pi / 3)
+    log = _run(["problem=rotating_grain_secant", "dim=2", "nx=40", "ny=40", "xmax=12pi", f"ymax={ymax!r}", f"ic={ic}",
+                "substeps=3", "num_steps=6", "dt=1", f"predictor_scale={scale}"], tmp_path)
+    assert log.count("converged=1") == 6
+    dom, state, compute, variables = rotating_grain_problem(torch.from_numpy(g["psi.0"]))
+    solver = mo.SecantSolver(dom, state, compute, variables, substeps=3)
+    solver.add_predictor("psi", scale)
+    ts = mo.IterationAdaptiveDT(1.0, min_iterations=100, max_iterations=400, growth_factor=1.4, cutback_factor=0.9, dtmax=500.0)
+    plain = 0.0
+    for step in range(1, 7):
+        solver.step(ts.next_dt(step, solver.iterations))
+        psi = np.fromfile(tmp_path / f"psi.{step}.bin", dtype="<f8").reshape(40, 40)
+        assert np.abs(state["psi"].numpy() - psi).max() <= 1e-10
+        plain = max(plain, np.abs(g[f"psi.{step}"] - psi).max())
+    assert plain <= 1e-7      # the predictor only moves the starting guess: the converged fields agree with the plain run's
+
+
 def test_etdrk4_case(tmp_path):
     """test/tests/solvers/tests (etdrk4_diffusion.i): ETDRK4Solver built from fused parsed kernels vs gold mse / rmse"""
     g = load_golden("solvers_gold.npz")["etdrk4_diffusion_rmse"]
