@@ -16,6 +16,23 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
   return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// a / d and a % d for 0 <= a < 2^24, d >= 1 with a precomputed float reciprocal: the quotient estimate is off by at most one.
+// (hipcc expands a run-time integer division into ~30 instructions, a 64-bit modulo into a loop; this kernel did four of the
+// former and one of the latter per element and pass, which is what bounded it.)
+__device__ __forceinline__ int fast_divmod(int a, int d, float inv, int &rem) {
+  int q = (int)((float)a * inv);
+  int r = a - q * d;
+  if (r < 0) {
+    --q;
+    r += d;
+  } else if (r >= d) {
+    ++q;
+    r -= d;
+  }
+  rem = r;
+  return q;
+}
+
 __global__ void __launch_bounds__(256) k_fft_generic(PassDesc d, const double *__restrict__ in,
                                                      double *__restrict__ out, const cplx *__restrict__ tw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -39,19 +56,28 @@ __global__ void __launch_bounds__(256) k_fft_generic(PassDesc d, const double *_
     W[i] = w;
   }
 
+  const long long o0 = L0 / d.inner, i0 = L0 % d.inner;
   const int total = n * nl;
+  const float inv_n = 1.0f / (float)n, inv_nl = 1.0f / (float)nl;
   // ---- load
   for (int e = tid; e < total; e += nt) {
     int l, j;
     if (d.lines_fastest) {
-      l = e % nl;
-      j = e / nl;
+      j = fast_divmod(e, nl, inv_nl, l);
     } else {
-      l = e / n;
-      j = e % n;
+      l = fast_divmod(e, n, inv_n, j);
     }
-    const long long L = L0 + l;
-    const long long o = L / d.inner, i = L % d.inner;
+    // line L0 + l -> (outer, inner) index from the block's first line (one 64-bit division per workgroup instead of two per element)
+    long long o = o0, i = i0 + l;
+    if (d.inner == 1) {
+      o += l;
+      i = 0;
+    } else {
+      while (i >= d.inner) {
+        i -= d.inner;
+        ++o;
+      }
+    }
     const long long base = o * d.in_so + i * d.in_si;
     cplx v;
     if (d.in_kind == 1) {
@@ -83,14 +109,15 @@ __global__ void __launch_bounds__(256) k_fft_generic(PassDesc d, const double *_
     const int r = d.radix[p];
     const int m = n / r;            // distance between the r inputs of a butterfly
     const int step1 = n / (Ns * r); // twiddle step of the inter-stage factor
+    const float inv_Ns = 1.0f / (float)Ns, inv_r = 1.0f / (float)r;
     for (int e = tid; e < total; e += nt) {
-      const int l = e / n;
-      const int o = e - l * n;
-      const int k = o % Ns;
-      const int u = (o / Ns) % r;
-      const int jhi = o / (Ns * r);
+      int o, k, u;
+      const int l = fast_divmod(e, n, inv_n, o);
+      const int qn = fast_divmod(o, Ns, inv_Ns, k);
+      const int jhi = fast_divmod(qn, r, inv_r, u);
       const int j = jhi * Ns + k;
-      const int base = (int)(((long long)k * step1 + (long long)u * m) % n);
+      int base = k * step1 + u * m;   // k step1 < n / r and u m < n: one conditional subtraction reduces it mod n
+      if (base >= n) base -= n;
       const cplx *x = A + l * n + j;
       cplx acc = x[0];
       int idx = 0;
@@ -114,17 +141,25 @@ __global__ void __launch_bounds__(256) k_fft_generic(PassDesc d, const double *_
   // ---- store
   const int nout = d.nout;
   const int total_out = nout * nl;
+  const float inv_nout = 1.0f / (float)nout;
   for (int e = tid; e < total_out; e += nt) {
     int l, j;
     if (d.lines_fastest) {
-      l = e % nl;
-      j = e / nl;
+      j = fast_divmod(e, nl, inv_nl, l);
     } else {
-      l = e / nout;
-      j = e % nout;
+      l = fast_divmod(e, nout, inv_nout, j);
     }
-    const long long L = L0 + l;
-    const long long o = L / d.inner, i = L % d.inner;
+    // line L0 + l -> (outer, inner) index from the block's first line (one 64-bit division per workgroup instead of two per element)
+    long long o = o0, i = i0 + l;
+    if (d.inner == 1) {
+      o += l;
+      i = 0;
+    } else {
+      while (i >= d.inner) {
+        i -= d.inner;
+        ++o;
+      }
+    }
     const long long base = o * d.out_so + i * d.out_si;
     cplx v = A[l * n + j];
     if (d.out_kind == 2) {
@@ -142,10 +177,12 @@ int launch_pass(mrl_ctx *ctx, const PassDesc &d0, const double *in, double *out,
   PassDesc d = d0;
   const long long nlines = d.inner * d.outer;
   if (nlines <= 0 || nbatch <= 0) return MRL_OK;
-  // tile: as many lines as fit a 64 KiB LDS budget (max 16), at least 1
+  // tile: as many lines as fit a 32 KiB LDS budget (max 16), at least 1.  The budget sets the occupancy: a workgroup alternates
+  // between a load, several LDS-only passes and a store, so HBM is only busy if other workgroups of the CU are in another phase
+  // (swept 20 ... 64 KiB over 120^3 ... 405^2 x 40: 32 KiB is best or within 10 % of it; 240^3 substep 2.19 -> 1.38 ms vs 64 KiB)
   const size_t per_line = (size_t)d.n * sizeof(cplx) * 2;
   const size_t tw_bytes = (size_t)d.n * sizeof(cplx);
-  size_t budget = 64 * 1024;
+  size_t budget = 32 * 1024;
   int tile = 1;
   if (per_line + tw_bytes > budget) {
     budget = 160 * 1024;
