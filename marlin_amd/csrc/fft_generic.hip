@@ -33,6 +33,64 @@ __device__ __forceinline__ int fast_divmod(int a, int d, float inv, int &rem) {
   return q;
 }
 
+// One radix-R Stockham pass (R = 2, 3, 4, 5) over the `nl` lines of the tile, one BUTTERFLY per thread: the R inputs
+// x[b + t n/R] are read once, twiddled by W^(t k step1), combined by a length-R DFT in registers and written to their R output
+// positions -- one LDS read, one twiddle read and one write per point, where the one-output-per-thread form below reads R inputs
+// and R-1 twiddles per point.  W already holds the conjugated table for the inverse transform.
+template <int R>
+__device__ __forceinline__ void pass_small_radix(const cplx *__restrict__ A, cplx *__restrict__ B, const cplx *__restrict__ W,
+                                                 int n, int nl, int Ns, int sign, int tid, int nt) {
+  const int m = n / R, step1 = n / (Ns * R);
+  const float inv_m = 1.0f / (float)m, inv_Ns = 1.0f / (float)Ns;
+  cplx wr[R];  // wr[j] = exp(-+ 2 pi i j / R)
+#pragma unroll
+  for (int j = 1; j < R; ++j) wr[j] = W[j * m];
+  const int nb = m * nl;
+  for (int e = tid; e < nb; e += nt) {
+    int b, k;
+    const int l = fast_divmod(e, m, inv_m, b);
+    const int jhi = fast_divmod(b, Ns, inv_Ns, k);
+    const cplx *x = A + l * n + b;
+    cplx a[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) a[t] = x[t * m];
+    const int st = k * step1;  // t * st < n for every t < R
+#pragma unroll
+    for (int t = 1; t < R; ++t) a[t] = cmul(a[t], W[t * st]);
+    cplx *y = B + l * n + jhi * Ns * R + k;
+    if (R == 2) {
+      y[0] = make_double2(a[0].x + a[1].x, a[0].y + a[1].y);
+      y[Ns] = make_double2(a[0].x - a[1].x, a[0].y - a[1].y);
+    } else if (R == 4) {
+      const cplx s02 = make_double2(a[0].x + a[2].x, a[0].y + a[2].y), d02 = make_double2(a[0].x - a[2].x, a[0].y - a[2].y);
+      const cplx s13 = make_double2(a[1].x + a[3].x, a[1].y + a[3].y), d13 = make_double2(a[1].x - a[3].x, a[1].y - a[3].y);
+      // -i d13 (forward) or +i d13 (inverse)
+      const cplx r13 = sign < 0 ? make_double2(d13.y, -d13.x) : make_double2(-d13.y, d13.x);
+      y[0] = make_double2(s02.x + s13.x, s02.y + s13.y);
+      y[Ns] = make_double2(d02.x + r13.x, d02.y + r13.y);
+      y[2 * Ns] = make_double2(s02.x - s13.x, s02.y - s13.y);
+      y[3 * Ns] = make_double2(d02.x - r13.x, d02.y - r13.y);
+    } else {
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        cplx acc = a[0];
+#pragma unroll
+        for (int t = 1; t < R; ++t) {
+          if (u == 0) {
+            acc.x += a[t].x;
+            acc.y += a[t].y;
+          } else {
+            const cplx w = wr[(t * u) % R];
+            acc.x += a[t].x * w.x - a[t].y * w.y;
+            acc.y += a[t].x * w.y + a[t].y * w.x;
+          }
+        }
+        y[u * Ns] = acc;
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_fft_generic(PassDesc d, const double *__restrict__ in,
                                                      double *__restrict__ out, const cplx *__restrict__ tw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -107,6 +165,20 @@ __global__ void __launch_bounds__(256) k_fft_generic(PassDesc d, const double *_
   int Ns = 1;
   for (int p = 0; p < d.npass; ++p) {
     const int r = d.radix[p];
+    if (r <= 5) {
+      switch (r) {
+        case 2: pass_small_radix<2>(A, B, W, n, nl, Ns, d.sign, tid, nt); break;
+        case 3: pass_small_radix<3>(A, B, W, n, nl, Ns, d.sign, tid, nt); break;
+        case 4: pass_small_radix<4>(A, B, W, n, nl, Ns, d.sign, tid, nt); break;
+        default: pass_small_radix<5>(A, B, W, n, nl, Ns, d.sign, tid, nt); break;
+      }
+      __syncthreads();
+      cplx *tmp = A;
+      A = B;
+      B = tmp;
+      Ns *= r;
+      continue;
+    }
     const int m = n / r;            // distance between the r inputs of a butterfly
     const int step1 = n / (Ns * r); // twiddle step of the inter-stage factor
     const float inv_Ns = 1.0f / (float)Ns, inv_r = 1.0f / (float)r;
