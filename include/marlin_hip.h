@@ -309,6 +309,15 @@ int mrl_slab_gamma_dot(mrl_ctx *ctx, double *h_local);
 /* CG vector kernels for callers that own the iteration (slab contexts all-reduce the scalars between the calls):
  *   mrl_cg_update:           x += alpha p ; r -= alpha Ap ; *h_rr_local = sum r^2 over the local vector   (MarlinUtils.h:95-100)
  *   mrl_mech_tangent_dir_fm: p <- r + beta p ; out = K_dF(p)   (MarlinUtils.h:112 fused with FFTMechanics.C:107-108; field-major) */
+/* The CG direction update and the tangent fused into the forward z pass of the row pipelines (z lines of 32 ... 256 points;
+ * mrl_slab_gamma_tangent_fusable tells):  [d_x += alpha_prev * p, the previous iteration's solution update, if d_x != NULL;]
+ * p <- r + beta p ; the z spectra of K_dF(p) for all nine fields stay in context scratch, and the following
+ * mrl_slab_gamma_row_fwd(r, NULL, send) calls run only the x pass from there.  K_dF(p) itself is never written.
+ * mrl_cg_update_r is mrl_cg_update without the x update (r -= alpha Ap ; sum r^2), for callers that defer it this way. */
+int mrl_slab_gamma_tangent_fusable(const mrl_ctx *ctx);
+int mrl_slab_gamma_tangent_z_fwd(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu, double *d_p,
+                                 const double *d_r, double beta, double *d_x /* optional */, double alpha_prev);
+int mrl_cg_update_r(mrl_ctx *ctx, double alpha, double *d_r, const double *d_Ap, int64_t n, double *h_rr_local);
 int mrl_cg_update(mrl_ctx *ctx, double alpha, double *d_x, double *d_r, const double *d_p, const double *d_Ap, int64_t n,
                   double *h_rr_local);
 int mrl_mech_tangent_dir_fm(mrl_ctx *ctx, const double *d_F_fm, const double *d_K, const double *d_mu, double *d_p_fm,

@@ -91,6 +91,9 @@ SIGNATURES = {
     "mrl_slab_gamma_row_inv": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "mrl_slab_gamma_dot": (_i32, [_vp, C.POINTER(_dbl)]),
     "mrl_cg_update": (_i32, [_vp, _dbl, _vp, _vp, _vp, _vp, _i64, C.POINTER(_dbl)]),
+    "mrl_cg_update_r": (_i32, [_vp, _dbl, _vp, _vp, _i64, C.POINTER(_dbl)]),
+    "mrl_slab_gamma_tangent_fusable": (_i32, [_vp]),
+    "mrl_slab_gamma_tangent_z_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _dbl]),
     "mrl_mech_tangent_dir_fm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp]),
     "mrl_mech_stress_fm": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "mrl_mech_tangent_apply_fm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),

@@ -556,6 +556,24 @@ int mrl_cg_update(mrl_ctx *ctx, double alpha, double *d_x, double *d_r, const do
   return read_scalars(ctx, slot, 1, h_rr_local);
 }
 
+int mrl_cg_update_r(mrl_ctx *ctx, double alpha, double *d_r, const double *d_Ap, int64_t n, double *h_rr_local) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!d_r || !d_Ap || !h_rr_local || n < 0) return set_error(ctx, MRL_ERR_INVALID, "mrl_cg_update_r: bad argument");
+  double *S;
+  MRL_TRY(put_scalars(ctx, alpha, 1.0, &S));
+  int nb = (int)((n / 2 + 255) / 256);
+  nb = nb < 1 ? 1 : (nb > kRedBlocks ? kRedBlocks : nb);
+  {
+    ProfScope ps(ctx, "cg_update_r", 24.0 * (double)n);
+    hipLaunchKernelGGL((k_cg_update<false, true>), dim3(nb), dim3(256), 0, ctx->stream, S, 0, 1, nullptr, d_r, nullptr, d_Ap, (long long)n,
+                       ctx->d_red);
+    MRL_HIP(ctx, hipGetLastError());
+  }
+  double *slot = ctx->d_red + kScalarBase;
+  MRL_TRY(reduce_finalize(ctx, nb, 1, slot));
+  return read_scalars(ctx, slot, 1, h_rr_local);
+}
+
 int mrl_mech_tangent_dir_fm(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu, double *d_p,
                             const double *d_r, double beta, double *d_out) {
   if (!ctx) return MRL_ERR_INVALID;

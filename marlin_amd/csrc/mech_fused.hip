@@ -335,6 +335,19 @@ int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale, const d
   return gamma_fast_rest(ctx, spec, out, scale, dotv, d_dot);
 }
 
+// shared with the slab pipeline (slab_mech_fused.hip): the same kernel on the rank's [nx][ny_local][nz] block
+int gamma_z_fwd_tangent_launch(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
+                               const double *S, int i_num, int i_den, cplx *spec, long long npts, long long rows, int nz, bool nt,
+                               double *x, int i_arz, int i_apAp) {
+  switch (nz) {
+    case 32: return p2::launch_gamma_z_fwd_tangent<32>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, rows, nt, x, i_arz, i_apAp);
+    case 64: return p2::launch_gamma_z_fwd_tangent<64>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, rows, nt, x, i_arz, i_apAp);
+    case 128: return p2::launch_gamma_z_fwd_tangent<128>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, rows, nt, x, i_arz, i_apAp);
+    case 256: return p2::launch_gamma_z_fwd_tangent<256>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, rows, nt, x, i_arz, i_apAp);
+    default: return set_error(ctx, MRL_ERR_UNSUPPORTED, "fused tangent + z pass: unplanned z length %d", nz);
+  }
+}
+
 // the fused CG direction update + tangent + forward z pass exists for z lines of 32 ... 256 points in whole 512-point tiles
 bool gamma_tangent_fusable(const mrl_ctx *ctx) {
   if (!mech_fast_ok(ctx)) return false;

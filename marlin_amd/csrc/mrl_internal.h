@@ -61,6 +61,7 @@ struct mrl_ctx {
   int spectrum = MRL_SPECTRUM_HALF;
   int nranks = 1, rank = 0;
   bool slab = false;            // FFT_SLAB layout and staged entry points (nranks > 1, or MRL_FLAG_SLAB)
+  bool gamma_z_ready = false;   // d_work[12] holds the 9 z spectra written by mrl_slab_gamma_tangent_z_fwd
   int gamma_dot_nb = 0;         // workgroups per row of the fused slab Gamma z pass that left dot-product partials (d_work[3])
   int device = 0;
   long long nloc[3] = {1, 1, 1};   // local real extents

@@ -17,6 +17,12 @@
 #include "fft_pow2_launch.h"
 
 namespace mrl {
+int gamma_z_fwd_tangent_launch(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
+                               const double *S, int i_num, int i_den, cplx *spec, long long npts, long long rows, int nz, bool nt,
+                               double *x, int i_arz, int i_apAp);
+}
+
+namespace mrl {
 
 int slab_fast_ok(const mrl_ctx *ctx);
 int reduce_finalize_from(mrl_ctx *ctx, const double *partial, int nb, double *d_scalar);
@@ -181,18 +187,49 @@ int mrl_slab_gamma_counts(const mrl_ctx *ctx, int forward, int64_t *h_send_count
   return MRL_OK;
 }
 
+int mrl_slab_gamma_tangent_fusable(const mrl_ctx *ctx) {
+  if (!ctx || !ctx->slab || !mrl_slab_fast_path(ctx)) return 0;
+  const long long nz = ctx->n[2], rows = ctx->n[0] * ctx->nloc[1];
+  if (!(nz == 32 || nz == 64 || nz == 128 || nz == 256)) return 0;
+  return rows % (512 / nz) == 0 ? 1 : 0;
+}
+
+int mrl_slab_gamma_tangent_z_fwd(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu, double *d_p,
+                                 const double *d_r, double beta, double *d_x, double alpha_prev) {
+  if (!ctx) return MRL_ERR_INVALID;
+  MRL_TRY(check_fast(ctx, "mrl_slab_gamma_tangent_z_fwd", 0));
+  if (!mrl_slab_gamma_tangent_fusable(ctx))
+    return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_slab_gamma_tangent_z_fwd: z lines of 32 ... 256 points in whole 512-point tiles only");
+  if (!d_F || !d_K || !d_mu || !d_p || !d_r) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_tangent_z_fwd: null buffer");
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2];
+  const long long npts = nx * nyl * nz, nspec = nx * nyl * nzc;
+  MRL_TRY(ensure_work(ctx, 12, sizeof(cplx) * (size_t)(9 * nspec)));
+  double *S = ctx->d_red + kScalarBase + 8;
+  const double hs[4] = {beta, 1.0, alpha_prev, 1.0};  // pageable source: staged by the runtime before the call returns
+  MRL_HIP(ctx, hipMemcpyAsync(S, hs, sizeof(hs), hipMemcpyHostToDevice, ctx->stream));
+  ProfScope ps(ctx, "slab_gamma_z_fwd_tangent_dir", 8.0 * npts * ((d_x ? 6 : 4) * 9 + 2) + 16.0 * nspec * 9);
+  MRL_TRY(gamma_z_fwd_tangent_launch(ctx, d_F, d_K, d_mu, d_p, d_r, S, 0, 1, reinterpret_cast<cplx *>(ctx->d_work[12]), npts,
+                                     nx * nyl, (int)nz, 72.0 * (double)npts >= 96.0e6, d_x, 2, 3));
+  ctx->gamma_z_ready = true;
+  return MRL_OK;
+}
+
 int mrl_slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *d_A_fm, double *d_send) {
   if (!ctx) return MRL_ERR_INVALID;
   MRL_TRY(check_fast(ctx, "mrl_slab_gamma_row_fwd", row));
-  if (!d_A_fm || !d_send) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_fwd: null buffer");
+  if (!d_send) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_fwd: null buffer");
+  if (!d_A_fm && !ctx->gamma_z_ready)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_fwd: no input field and no spectra from mrl_slab_gamma_tangent_z_fwd");
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
   const long long nreal = nx * nyl * nz, nspec = nx * nyl * nzc;
   cplx *w;
-  MRL_TRY(row_work(ctx, 4, &w));
-  {
+  if (d_A_fm) {
+    MRL_TRY(row_work(ctx, 4, &w));
     ProfScope ps(ctx, "slab_gamma_z_fwd", 3.0 * (8.0 * nreal + 16.0 * nspec));
     p2::ChDev none{};
     MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, d_A_fm + 3 * row * nreal, w, nullptr, nullptr, none, 3 * nx * nyl / 2))));
+  } else {
+    w = reinterpret_cast<cplx *>(ctx->d_work[12]) + 3 * row * nspec;  // z spectra left by mrl_slab_gamma_tangent_z_fwd
   }
   const unsigned chunk = (unsigned)(nxl * nyl * nzc);
   p2::SubPassArgs a{};

@@ -415,8 +415,10 @@ class SlabMechanics:
     (its norms are serial-only, DomainAction.C:1564-1567)."""
 
     def __init__(self, dim, shape, L, nranks, rank, K_local, mu_local, comm=None, l_tol=1e-2, l_max_its=0, nl_rel_tol=1e-5,
-                 nl_abs_tol=1e-8, nl_max_its=100, stages=None, fast: Optional[bool] = None):
-        """fast=None: use the fused field-major row pipeline (mrl_slab_gamma_row_*) when the context supports it"""
+                 nl_abs_tol=1e-8, nl_max_its=100, stages=None, fast: Optional[bool] = None, tangent_fusion: bool = True):
+        """fast=None: use the fused field-major row pipeline (mrl_slab_gamma_row_*) when the context supports it;
+        tangent_fusion=False keeps the tangent and the forward z pass of the CG iteration as separate kernels (A/B, tests)"""
+        self.no_tangent_fusion = not tangent_fusion
         self.st = stages if stages is not None else HipSlabStages(dim, shape, L, nranks, rank)
         self.ctx = self.st.ctx
         self.lib = self.ctx.lib
@@ -495,11 +497,12 @@ class SlabMechanics:
     def gamma_fast(self, A, out, scale=1.0, dotv=None):
         """out = scale * G(A) on field-major fields: three tensor rows, each z+x passes -> all-to-all -> fused y pass with the
         projection -> all-to-all -> inverse x+z passes; row r+1 is transformed while row r is on the wire.
-        dotv: also return the all-reduced sum(out * dotv), accumulated by the last z pass (the p.Ap of the CG)"""
+        dotv: also return the all-reduced sum(out * dotv), accumulated by the last z pass (the p.Ap of the CG).
+        A = None: the z spectra of the nine fields were left in the context by mrl_slab_gamma_tangent_z_fwd (x passes only)"""
         h = self.ctx.h
         wf, wi = [], []
         for r in range(3):
-            self._chk(self.lib.mrl_slab_gamma_row_fwd(h, r, self._p(A), self._p(self.g_send[r])))
+            self._chk(self.lib.mrl_slab_gamma_row_fwd(h, r, self._p(A) if A is not None else None, self._p(self.g_send[r])))
             wf.append(self.xg_fwd.run(self.g_send[r], self.g_recv[r], async_op=True))
         for r in range(3):
             if wf[r] is not None:
@@ -549,17 +552,34 @@ class SlabMechanics:
         rz_old = self._dot(r, r)
         beta = 0.0
         rr = C.c_double()
+        fuse = bool(self.lib.mrl_slab_gamma_tangent_fusable(self.ctx.h)) and not self.no_tangent_fusion
+        alpha_prev, pending = 0.0, False
         for k in range(self.l_max_its):
-            self._chk(self.lib.mrl_mech_tangent_dir_fm(self.ctx.h, self._p(Flin), self._p(self.K), self._p(self.mu), self._p(p),
-                                                       self._p(r), beta, self._p(tmp)))       # p = r + beta p ; tmp = K_dF(p)
-            pAp = self.gamma_fast(tmp, Ap, 1.0, dotv=p)
+            if fuse:
+                # [x += alpha_prev p ;] p = r + beta p ; z spectra of K_dF(p) stay in the context: K_dF(p) is never written
+                self._chk(self.lib.mrl_slab_gamma_tangent_z_fwd(self.ctx.h, self._p(Flin), self._p(self.K), self._p(self.mu),
+                                                               self._p(p), self._p(r), beta,
+                                                               self._p(x) if pending else None, alpha_prev))
+                pAp = self.gamma_fast(None, Ap, 1.0, dotv=p)
+            else:
+                self._chk(self.lib.mrl_mech_tangent_dir_fm(self.ctx.h, self._p(Flin), self._p(self.K), self._p(self.mu), self._p(p),
+                                                           self._p(r), beta, self._p(tmp)))       # p = r + beta p ; tmp = K_dF(p)
+                pAp = self.gamma_fast(tmp, Ap, 1.0, dotv=p)
             alpha = rz_old / pAp
-            self._chk(self.lib.mrl_cg_update(self.ctx.h, alpha, self._p(x), self._p(r), self._p(p), self._p(Ap), n, C.byref(rr)))
+            if fuse:   # the x update waits for the next direction kernel (or the axpby after the loop)
+                self._chk(self.lib.mrl_cg_update_r(self.ctx.h, alpha, self._p(r), self._p(Ap), n, C.byref(rr)))
+                alpha_prev, pending = alpha, True
+            else:
+                self._chk(self.lib.mrl_cg_update(self.ctx.h, alpha, self._p(x), self._p(r), self._p(p), self._p(Ap), n, C.byref(rr)))
             rz_new = self.comm.allreduce([rr.value])[0]
             if rz_new ** 0.5 <= self.l_tol * b_norm:
+                if pending:
+                    self._axpby(alpha_prev, p, 1.0, x, x)
                 return k + 1
             beta = rz_new / rz_old
             rz_old = rz_new
+        if pending:
+            self._axpby(alpha_prev, p, 1.0, x, x)
         return self.l_max_its
 
     # ---- MooseTensor::conjugateGradientSolve with A = G o K_dF

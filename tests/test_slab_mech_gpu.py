@@ -206,21 +206,24 @@ def test_slab_gamma_fused_rows(P):
         assert (torch.cat([o[2] for o in slow], dim=1) - got).abs().max().item() <= 1e-13
 
 
-def _newton_rank(r, P, comm, K, mu, applied):
+def _newton_rank(r, P, comm, K, mu, applied, tangent_fusion=True):
     from marlin_amd.slab import HipSlabStages, SlabMechanics
     st = HipSlabStages(3, _FAST_SHAPE, _FAST_L, P, r)
     yb, nyl = st.real_begin[1], st.real_shape[1]
     m = SlabMechanics(3, _FAST_SHAPE, _FAST_L, P, r, K[:, yb:yb + nyl].contiguous().cuda(), mu[:, yb:yb + nyl].contiguous().cuda(),
-                      comm=comm, l_tol=1e-2, nl_rel_tol=2e-2, nl_abs_tol=2e-2, stages=st)
+                      comm=comm, l_tol=1e-2, nl_rel_tol=2e-2, nl_abs_tol=2e-2, stages=st, tangent_fusion=tangent_fusion)
     assert m.fast
+    assert bool(m.lib.mrl_slab_gamma_tangent_fusable(m.ctx.h))
     F = torch.eye(3, dtype=torch.float64).expand(list(st.real_shape) + [3, 3]).contiguous().cuda().reshape(-1)
     Fn, Pn, stats = m.newton_cg(F, applied.cuda())
     return yb, nyl, Fn.cpu().reshape(list(st.real_shape) + [3, 3]), Pn.cpu().reshape(list(st.real_shape) + [3, 3]), stats
 
 
-def test_slab_mechanics_fused_vs_serial():
-    """one Newton-CG solve of the de Geus RVE at 64^3 on 4 loop-back ranks (fused field-major slab path) == the serial
-    fused solver of the same library: same Newton / CG iteration counts, F and P to 1e-10"""
+@pytest.mark.parametrize("tangent_fusion", [True, False])
+def test_slab_mechanics_fused_vs_serial(tangent_fusion):
+    """one Newton-CG solve of the de Geus RVE at 64^3 on 4 loop-back ranks (fused field-major slab path; with the CG direction
+    update + tangent fused into the forward z pass and the solution update deferred, mrl_slab_gamma_tangent_z_fwd, and with the
+    separate kernels) == the serial fused solver of the same library: same Newton / CG iteration counts, F and P to 1e-10"""
     from marlin_amd.api import Context
     torch.manual_seed(2)
     n = 64
@@ -231,7 +234,7 @@ def test_slab_mechanics_fused_vs_serial():
     mu = 0.386 + phase * (3.86 - 0.386)
     applied = torch.zeros(3, 3, dtype=torch.float64)
     applied[0, 1] = 0.01
-    out = _run_threads(4, _newton_rank, K, mu, applied)
+    out = _run_threads(4, _newton_rank, K, mu, applied, tangent_fusion)
     F = torch.cat([o[2] for o in out], dim=1)
     P_ = torch.cat([o[3] for o in out], dim=1)
     ctx = Context(3, _FAST_SHAPE, _FAST_L)

@@ -39,11 +39,12 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     its = int(sys.argv[3]) if len(sys.argv) > 3 else 10
     fast = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
+    fusion = bool(int(sys.argv[5])) if len(sys.argv) > 5 else True
     shape, L = [n] * 3, [6.283185307179586] * 3
     st = HipSlabStages(3, shape, L, P, 0)
     K = torch.full(st.real_shape, 0.833, dtype=torch.float64, device="cuda")
     mu = torch.full(st.real_shape, 0.386, dtype=torch.float64, device="cuda")
-    m = SlabMechanics(3, shape, L, P, 0, K, mu, comm=_Comm(P), l_tol=0.0, l_max_its=its, stages=st, fast=fast)
+    m = SlabMechanics(3, shape, L, P, 0, K, mu, comm=_Comm(P), l_tol=0.0, l_max_its=its, stages=st, fast=fast, tangent_fusion=fusion)
     nvec = m.npts * 9
     g = torch.Generator(device="cuda").manual_seed(1)
     F = torch.eye(3, dtype=torch.float64, device="cuda").reshape(9, 1).expand(9, m.npts).contiguous().reshape(-1) if fast else \
@@ -65,7 +66,7 @@ def main():
     for k in prof:
         k["avg_ms"] = k["ms"] / k["launches"]
         k["per_iteration_ms"] = k["ms"] / (its + 1)
-    print(json.dumps({"P": P, "grid": shape, "local_real": st.real_shape, "fast": fast, "cg_iterations": done,
+    print(json.dumps({"P": P, "grid": shape, "local_real": st.real_shape, "fast": fast, "tangent_fusion": fusion, "cg_iterations": done,
                       "ms_per_cg_iteration_local_incl_copies_and_syncs": round(ms, 4),
                       "kernels": [{"kernel": k["kernel"], "launches": k["launches"], "avg_ms": round(k["avg_ms"], 4),
                                    "per_iteration_ms": round(k["per_iteration_ms"], 4)} for k in prof]}))
