@@ -10,6 +10,17 @@
 //   z inverse   k_z_inv, x scale/N                                h + r
 // = 9 * (2r + 8h) bytes per application (r = 8 B, h = 8(1+2/n) B per grid point): 724.5 B/pt at n = 128.
 #include "fft_pow2_launch.h"
+
+// Register budget of k_gamma_xfused (16 points per thread: s, v0, v1 = 192 VGPRs of the 256 that two workgroups per CU allow):
+// the three output transforms must NOT be unrolled into each other (the scheduler then overlaps them and spills 50-90 VGPRs: 128^3
+// 78 -> 62 us without the unrolling), and only half of the third component is prefetched behind the second transform (-> 58 us).
+// Compile-time switches so that variants can be built side by side (make EXTRA=-D...) and compared on one GPU box.
+#ifndef MRL_GAMMA_PRE
+#define MRL_GAMMA_PRE 8
+#endif
+#ifndef MRL_GAMMA_JUNROLL
+#define MRL_GAMMA_JUNROLL 1
+#endif
 #include "mech_math.h"
 
 namespace mrl {
@@ -29,6 +40,7 @@ template <int N>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_xfused(GammaArgs a, const cplx *__restrict__ tw) {
 #pragma clang fp contract(off)
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T;
+  constexpr int GPRE = MRL_GAMMA_PRE < P ? MRL_GAMMA_PRE : P;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
@@ -51,14 +63,17 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_xfused(GammaArgs a, co
     kxv[j] = idx < N ? a.kx[idx] : 0.0;
   }
   const double ky = a.ky[iv / a.nzc], kz = a.kz[iv % a.nzc];
-  cplx *f0 = a.spec + (long long)(row * 3 + 0) * a.field + iv + (long long)q * a.inner;
-  cplx *f1 = f0 + a.field, *f2 = f1 + a.field;
-  const long long step = (long long)TPL * a.inner;
+  // wave-uniform field bases + one 32-bit byte offset per thread (fields are < 4 GiB, checked by mech_fast_ok): the loads and
+  // stores take the "SGPR base + VGPR offset" form instead of 3 x 16 64-bit addresses held in registers
+  char *b0 = reinterpret_cast<char *>(a.spec + (long long)(row * 3 + 0) * a.field);
+  char *b1 = b0 + a.field * 16, *b2 = b1 + a.field * 16;
+  const unsigned boff0 = (unsigned)((iv + (long long)q * a.inner) * 16), stepB = (unsigned)((long long)TPL * a.inner * 16);
+  auto ldf = [=](const char *b, int m) { return *reinterpret_cast<const cplx *>(b + (boff0 + (unsigned)m * stepB)); };
   cplx v0[P], v1[P];
 #pragma unroll
-  for (int m = 0; m < P; ++m) v0[m] = f0[m * step];
+  for (int m = 0; m < P; ++m) v0[m] = ldf(b0, m);
 #pragma unroll
-  for (int m = 0; m < P; ++m) v1[m] = f1[m * step];
+  for (int m = 0; m < P; ++m) v1[m] = ldf(b1, m);
 #pragma unroll
   for (int j = 0; j < CNT; ++j) {
     const int idx = threadIdx.x + j * NT;
@@ -77,8 +92,10 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_xfused(GammaArgs a, co
     s[m] = make_double2(v0[m].x * kx, v0[m].y * kx);
   }
 #pragma unroll
-  for (int m = 0; m < P; ++m) v0[m] = f2[m * step];  // third component: in flight during the second transform
+  for (int m = 0; m < GPRE; ++m) v0[m] = ldf(b2, m);  // third component: GPRE values in flight during the second transform
   fft_line<N, Map>(v1, q, l, X, W);
+#pragma unroll
+  for (int m = GPRE; m < P; ++m) v0[m] = ldf(b2, m);
 #pragma unroll
   for (int m = 0; m < P; ++m) {
     s[m].x += v1[m].x * ky;
@@ -96,7 +113,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_xfused(GammaArgs a, co
   }
 
   // out_ij = s q_j, inverse x (unnormalised; 1/N applied by the z pass); swap trick for the inverse
-#pragma unroll
+#pragma unroll MRL_GAMMA_JUNROLL
   for (int j = 0; j < 3; ++j) {
 #pragma unroll
     for (int m = 0; m < P; ++m) {
@@ -105,9 +122,9 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_xfused(GammaArgs a, co
     }
     fft_line<N, Map>(v0, q, l, X, W);
     if (valid) {
-      cplx *o = (j == 0) ? f0 : (j == 1 ? f1 : f2);
+      char *o = (j == 0) ? b0 : (j == 1 ? b1 : b2);
 #pragma unroll
-      for (int m = 0; m < P; ++m) o[m * step] = cswap(v0[m]);
+      for (int m = 0; m < P; ++m) *reinterpret_cast<cplx *>(o + (boff0 + (unsigned)m * stepB)) = cswap(v0[m]);
     }
   }
 }
@@ -264,8 +281,9 @@ static int launch_gamma_z_fwd_tangent(mrl_ctx *ctx, const double *F, const doubl
 }  // namespace p2
 
 bool mech_fast_ok(const mrl_ctx *ctx) {
+  // (one spectral field < 4 GiB: k_gamma_xfused addresses it with 32-bit byte offsets)
   return ctx->dim == 3 && !ctx->slab && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
-         pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]);
+         pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]) && 16.0 * (double)(ctx->n[0] * ctx->n[1] * ctx->nrec[2]) < 4294967296.0;
 }
 
 // out = scale * G(A), A and out field-major real [9][nx][ny][nz] (out may alias A).  dotv != nullptr: the last pass

@@ -20,6 +20,10 @@
 // forward all-to-all carry ONE field instead of two: the exchange volume of a substep drops from 3 to 2 slab transposes,
 // which is what bounds the multi-GPU rate on point-to-point xGMI links.
 #include "ch_fused_body.h"
+
+#ifndef MRL_YF_PRE_SPEC
+#define MRL_YF_PRE_SPEC 8
+#endif
 #include "fft_pow2_launch.h"
 
 namespace mrl {
@@ -69,7 +73,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
   auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
   // default cache policy for every stream: on the sub-block-sized working sets of the slab pipeline the non-temporal accesses of
   // the serial kernel cost 8-30 % (measured per variant with tools/slab_local_bench.py 8 256)
-  ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
+  ch_fused_body<N, ORDER, false, (SPEC_C ? (MRL_YF_PRE_SPEC < Plan<N>::P ? MRL_YF_PRE_SPEC : Plan<N>::P) : Plan<N>::P / 2), SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
 }
 
 template <int N, int ORDER, bool SPEC_C>

@@ -16,6 +16,15 @@
 //   inv   inverse x pass from [p][3][x_p][y_me][nzc] into the work arrays, k_z_inv<PAIR> * 1/N into the row's 3 output fields
 #include "fft_pow2_launch.h"
 
+// register budget of k_gamma_yfused: see k_gamma_xfused (mech_fused.hip); here the full prefetch of the third component measured
+// best once the output transforms are no longer unrolled into each other (rank-local 256^3 / 8: 60 -> 45 us per row)
+#ifndef MRL_GAMMAY_PRE
+#define MRL_GAMMAY_PRE 16
+#endif
+#ifndef MRL_GAMMA_JUNROLL
+#define MRL_GAMMA_JUNROLL 1
+#endif
+
 namespace mrl {
 int gamma_z_fwd_tangent_launch(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
                                const double *S, int i_num, int i_den, cplx *spec, long long npts, long long rows, int nz, bool nt,
@@ -43,6 +52,7 @@ template <int N>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_yfused(GammaYArgs a, const cplx *__restrict__ tw) {
 #pragma clang fp contract(off)
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T, NT = Plan<N>::NT, CNT = (N + NT - 1) / NT;
+  constexpr int GPRE = MRL_GAMMAY_PRE < P ? MRL_GAMMAY_PRE : P;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
@@ -92,8 +102,10 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_yfused(GammaYArgs a, c
 #pragma unroll
   for (int m = 0; m < P; ++m) s[m] = make_double2(v0[m].x * kx, v0[m].y * kx);
 #pragma unroll
-  for (int m = 0; m < P; ++m) v0[m] = ld(2u, m);  // third component: in flight during the second transform
+  for (int m = 0; m < GPRE; ++m) v0[m] = ld(2u, m);  // third component: GPRE values in flight during the second transform
   fft_line<N, Map>(v1, q, l, X, W);
+#pragma unroll
+  for (int m = GPRE; m < P; ++m) v0[m] = ld(2u, m);
 #pragma unroll
   for (int m = 0; m < P; ++m) {
     const double ky = KY[q + m * TPL];
@@ -110,7 +122,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_yfused(GammaYArgs a, c
     s[m].y = (s[m].y + v0[m].y * kz) * inv;
   }
   // out_ij = s q_j, inverse y (unnormalised; 1/N applied by the z pass); swap trick for the inverse
-#pragma unroll
+#pragma unroll MRL_GAMMA_JUNROLL
   for (int j = 0; j < 3; ++j) {
 #pragma unroll
     for (int m = 0; m < P; ++m) {
