@@ -11,6 +11,7 @@
 #pragma once
 #include "fft_pow2.h"
 
+
 namespace mrl {
 namespace p2 {
 
@@ -121,6 +122,15 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
         stc(a.Nnew, offd(m), Nv[m]);
     }
   }
+  if (SPEC_C) {
+    // the carried c-hat needs no transform, so the first term of the update, cbar + (dt b0) N, is formed here and N's 64 registers
+    // are free again before the history arrives (the same expression as in step 4, only evaluated earlier)
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      cp[m].x = cp[m].x + a.coef[0] * Nv[m].x;
+      cp[m].y = cp[m].y + a.coef[0] * Nv[m].y;
+    }
+  }
 
   // ---- first-order history: PRE of the 16 old Nhat values are requested before the c-hat transform and are in flight
   //      during it, the rest right after it (PRE is tuned per kernel against the 256-VGPR / two-waves-per-SIMD limit)
@@ -144,8 +154,10 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
 #pragma unroll
     for (int m = 0; m < P; ++m) {
       cplx u = cp[m];
-      u.x = u.x + a.coef[0] * Nv[m].x;
-      u.y = u.y + a.coef[0] * Nv[m].y;
+      if (!SPEC_C) {
+        u.x = u.x + a.coef[0] * Nv[m].x;
+        u.y = u.y + a.coef[0] * Nv[m].y;
+      }
       u.x += a.coef[1] * o1[ORDER == 1 ? m : 0].x;
       u.y += a.coef[1] * o1[ORDER == 1 ? m : 0].y;
       const double kl = KL[q + m * TPL];
@@ -169,8 +181,10 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
       for (int j = 0; j < H; ++j) {
         const int m = half * H + j;
         cplx u = cp[m];
-        u.x = u.x + a.coef[0] * Nv[m].x;
-        u.y = u.y + a.coef[0] * Nv[m].y;
+        if (!SPEC_C) {
+          u.x = u.x + a.coef[0] * Nv[m].x;
+          u.y = u.y + a.coef[0] * Nv[m].y;
+        }
 #pragma unroll
         for (int h = 0; h < ORDER; ++h) {
           u.x += a.coef[h + 1] * o[h][j].x;

@@ -21,9 +21,6 @@
 // which is what bounds the multi-GPU rate on point-to-point xGMI links.
 #include "ch_fused_body.h"
 
-#ifndef MRL_YF_PRE_SPEC
-#define MRL_YF_PRE_SPEC 8
-#endif
 #include "fft_pow2_launch.h"
 
 namespace mrl {
@@ -40,7 +37,7 @@ struct YFusedArgs {
   const double *kx, *ky, *kz;  // local reciprocal axes
 };
 
-template <int N, int ORDER, bool SPEC_C>
+template <int N, int ORDER, bool SPEC_C, bool ALIGNED>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, const cplx *__restrict__ tw) {
   constexpr int TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
@@ -61,35 +58,50 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
   const int sh = a.nyl_shift, msk = (1 << sh) - 1;
   const unsigned ksB = (unsigned)a.ksub * 16u, chB = a.chunk * 16u, klB = (unsigned)kl * 16u;
   // (with the carry-over only mu-hat is received: one field per chunk)
+  // ALIGNED (ny/P is a multiple of the TPL threads of a line, the usual case): the chunk index and the row within the chunk of
+  // element j = q + m TPL split into a wave-uniform part that depends on m only and the per-thread constant q ksB + klB, so the
+  // 3 x 16 offsets are scalar arithmetic plus one VGPR instead of 48 VGPRs (which made the kernel spill 50-60 registers)
+  const unsigned tq = (ALIGNED ? (unsigned)q * ksB : 0u) + klB;
+  const int q0 = ALIGNED ? 0 : q;
   auto offf = [=](int m) {
-    const int j = q + m * TPL;
-    return (unsigned)(j >> sh) * (SPEC_C ? chB : 2u * chB) + (unsigned)((ix << sh) + (j & msk)) * ksB + klB;
+    const int j = q0 + m * TPL;
+    return (unsigned)(j >> sh) * (SPEC_C ? chB : 2u * chB) + (unsigned)((ix << sh) + (j & msk)) * ksB + tq;
   };
   auto offu = [=](int m) {
-    const int j = q + m * TPL;
-    return (unsigned)(j >> sh) * chB + (unsigned)((ix << sh) + (j & msk)) * ksB + klB;
+    const int j = q0 + m * TPL;
+    return (unsigned)(j >> sh) * chB + (unsigned)((ix << sh) + (j & msk)) * ksB + tq;
   };
   const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + a.k0 + kl) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
   auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
   // default cache policy for every stream: on the sub-block-sized working sets of the slab pipeline the non-temporal accesses of
   // the serial kernel cost 8-30 % (measured per variant with tools/slab_local_bench.py 8 256)
-  ch_fused_body<N, ORDER, false, (SPEC_C ? (MRL_YF_PRE_SPEC < Plan<N>::P ? MRL_YF_PRE_SPEC : Plan<N>::P) : Plan<N>::P / 2), SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
+  ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
 }
 
-template <int N, int ORDER, bool SPEC_C>
-static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
+template <int N, int ORDER, bool SPEC_C, bool ALIGNED>
+static int launch_yfused_v(mrl_ctx *ctx, YFusedArgs a) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
   if (!attr) {
-    MRL_TRY((set_lds_attr(ctx, k_ch_yfused<N, ORDER, SPEC_C>, lds)));
+    MRL_TRY((set_lds_attr(ctx, k_ch_yfused<N, ORDER, SPEC_C, ALIGNED>, lds)));
     attr = true;
   }
   constexpr int T = Plan<N>::T;
   a.tiles_per_x = (a.ksub + T - 1) / T;
   const long long nb = (long long)a.nxl * a.tiles_per_x;
-  hipLaunchKernelGGL((k_ch_yfused<N, ORDER, SPEC_C>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[1].d_tw);
+  hipLaunchKernelGGL((k_ch_yfused<N, ORDER, SPEC_C, ALIGNED>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a,
+                     ctx->ax[1].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
+}
+
+template <int N, int ORDER, bool SPEC_C>
+static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
+  constexpr int TPL = Plan<N>::TPL;
+  if constexpr ((TPL & (TPL - 1)) == 0) {  // (ny/P is a power of two: a multiple of TPL iff TPL is one and not larger)
+    if ((1 << a.nyl_shift) % TPL == 0) return launch_yfused_v<N, ORDER, SPEC_C, true>(ctx, a);
+  }
+  return launch_yfused_v<N, ORDER, SPEC_C, false>(ctx, a);
 }
 
 }  // namespace p2
