@@ -168,9 +168,10 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
     }
   } else {
     //    (deeper histories: half of the points at a time; a run-time trip count here would make hipcc wait vmcnt(0) per element)
-    constexpr int H = P / 2;
+    //    (third and fourth order histories: a quarter at a time, 4 x P/4 old values in flight instead of 4 x P/2 = 128 VGPRs)
+    constexpr int H = (ORDER >= 3 && P % 4 == 0) ? P / 4 : P / 2;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < P / H; ++half) {
       cplx o[ORDER > 0 ? ORDER : 1][H];
 #pragma unroll
       for (int h = 0; h < ORDER; ++h) {
