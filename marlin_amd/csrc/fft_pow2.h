@@ -41,6 +41,9 @@ MRL_PLAN(128, 16, 16, 8, 1, 1, 32)
 MRL_PLAN(256, 16, 16, 16, 1, 1, 16)
 MRL_PLAN(512, 16, 8, 8, 8, 1, 8)
 MRL_PLAN(1024, 16, 16, 8, 8, 1, 4)
+// long lines of 1-D / 2-D problems: the strided passes only gather 32 / 16 bytes per row here (their LDS tile holds T whole lines)
+MRL_PLAN(2048, 16, 16, 16, 8, 1, 2)
+MRL_PLAN(4096, 16, 16, 16, 16, 1, 1)
 // sizes 2^a 5^b (the reference's own examples run 100^3 and 200^3 grids): radix 10 / 5 / 2, 10 points per thread
 MRL_PLAN(40, 10, 10, 2, 2, 1, 64)
 MRL_PLAN(50, 10, 10, 5, 1, 1, 51)

@@ -126,6 +126,8 @@ inline int launch_pass_sub(mrl_ctx *ctx, const SubPassArgs &a, const cplx *tw) {
     case 256: { constexpr int NN = 256; CALL; } break; \
     case 512: { constexpr int NN = 512; CALL; } break; \
     case 1024: { constexpr int NN = 1024; CALL; } break; \
+    case 2048: { constexpr int NN = 2048; CALL; } break; \
+    case 4096: { constexpr int NN = 4096; CALL; } break; \
     case 100: { constexpr int NN = 100; CALL; } break; \
     case 200: { constexpr int NN = 200; CALL; } break; \
     case 400: { constexpr int NN = 400; CALL; } break; \
@@ -147,7 +149,7 @@ inline int launch_pass_sub(mrl_ctx *ctx, const SubPassArgs &a, const cplx *tw) {
 
 inline bool pow2_ok(long long n) {
   switch (n) {
-    case 32: case 64: case 128: case 256: case 512: case 1024:            // 2^a
+    case 32: case 64: case 128: case 256: case 512: case 1024: case 2048: case 4096:  // 2^a
     case 40: case 50: case 80: case 100: case 200: case 250: case 400: case 500: case 1000:  // 2^a 5^b
     case 48: case 96: case 144: case 192: case 384: case 768:             // 2^a 3^b
       return true;

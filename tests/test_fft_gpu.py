@@ -14,6 +14,7 @@ SHAPES = [
     (96, 96, 96), (192, 64, 100), (64, 96, 384), (192, 96),               # radix 12 / 4 / 2 plans
     (50, 50, 50), (250, 48, 40), (500, 32, 80), (144, 768, 48), (80, 40, 32), (1000, 32), (48, 144), (32, 1000, 40),
     (768, 50, 250),                                                        # the remaining planned lengths
+    (2048, 64), (32, 4096), (2048, 32, 40), (4096, 2048),                  # long lines of 2-D problems (planned lengths only)
 ]
 
 
