@@ -18,6 +18,8 @@
  *   - work is enqueued on the context's HIP stream and is asynchronous unless stated.
  *   - one context per rank / per GPU; a context is not thread-safe (the reference drives each
  *     rank from one host thread, src/problems/TensorProblem.C:154-197).
+ *   - one DEVICE per process (DomainAction.C:197-198: one MPI rank <-> one device): all contexts of a process must live on
+ *     the same GPU -- per-kernel attributes (dynamic LDS sizes) are set once per process, on the device current at first use.
  */
 #ifndef MARLIN_HIP_H
 #define MARLIN_HIP_H
