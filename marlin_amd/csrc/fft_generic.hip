@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_fft_generic(PassDesc d, const double *_
   const int tid = threadIdx.x;
   const int nt = blockDim.x;
   const int n = d.n;
-  const long long nlines = d.inner * d.outer;
+  const long long nlines = d.pair ? (d.nreal_lines + 1) / 2 : d.inner * d.outer;
   const long long L0 = (long long)blockIdx.x * d.tile;
   const int nl = (int)min((long long)d.tile, nlines - L0);
   // batch offsets are in elements of the respective kind (real: double, complex: double2)
@@ -124,6 +124,30 @@ __global__ void __launch_bounds__(256) k_fft_generic(PassDesc d, const double *_
       j = fast_divmod(e, nl, inv_nl, l);
     } else {
       l = fast_divmod(e, n, inv_n, j);
+    }
+    if (d.pair) {
+      // two real lines (forward) or two hermitian half lines (inverse) in one complex transform: z = a + i b
+      const long long La = 2 * (L0 + l), Lb = La + 1;
+      const bool hb = Lb < d.nreal_lines;
+      const long long ba = La * d.in_so, bb = Lb * d.in_so;
+      cplx v;
+      if (d.in_kind == 1) {
+        v = make_double2(inb[ba + (long long)j * d.in_sn], hb ? inb[bb + (long long)j * d.in_sn] : 0.0);
+      } else {
+        const int nh = n / 2;
+        const bool lo = j <= nh;
+        const int k = lo ? j : n - j;
+        const double2 *pa = reinterpret_cast<const double2 *>(inb) + ba + (long long)k * d.in_sn;
+        const double2 *pb = reinterpret_cast<const double2 *>(inb) + bb + (long long)k * d.in_sn;
+        cplx a = *pa, b = hb ? *pb : make_double2(0.0, 0.0);
+        if (k == 0 || 2 * k == n) {  // a c2r transform ignores the imaginary parts of the self-conjugate bins
+          a.y = 0.0;
+          b.y = 0.0;
+        }
+        v = lo ? make_double2(a.x - b.y, a.y + b.x) : make_double2(a.x + b.y, b.x - a.y);
+      }
+      A[l * n + j] = v;
+      continue;
     }
     // line L0 + l -> (outer, inner) index from the block's first line (one 64-bit division per workgroup instead of two per element)
     long long o = o0, i = i0 + l;
@@ -221,6 +245,25 @@ __global__ void __launch_bounds__(256) k_fft_generic(PassDesc d, const double *_
     } else {
       l = fast_divmod(e, nout, inv_nout, j);
     }
+    if (d.pair) {
+      const long long La = 2 * (L0 + l), Lb = La + 1;
+      const bool hb = Lb < d.nreal_lines;
+      const long long ba = La * d.out_so, bb = Lb * d.out_so;
+      const cplx z = A[l * n + j];
+      if (d.out_kind == 2) {  // inverse: the two real lines are the real and the imaginary part
+        outb[ba + (long long)j * d.out_sn] = z.x * d.scale;
+        if (hb) outb[bb + (long long)j * d.out_sn] = z.y * d.scale;
+      } else {                // forward: X_a[k] = (Z[k] + conj Z[n-k]) / 2, X_b[k] = (Z[k] - conj Z[n-k]) / (2i)
+        const cplx zc = A[l * n + (j == 0 ? 0 : n - j)];
+        double2 *pa = reinterpret_cast<double2 *>(outb) + ba + (long long)j * d.out_sn;
+        *pa = make_double2(0.5 * (z.x + zc.x) * d.scale, 0.5 * (z.y - zc.y) * d.scale);
+        if (hb) {
+          double2 *pb = reinterpret_cast<double2 *>(outb) + bb + (long long)j * d.out_sn;
+          *pb = make_double2(0.5 * (z.y + zc.y) * d.scale, -0.5 * (z.x - zc.x) * d.scale);
+        }
+      }
+      continue;
+    }
     // line L0 + l -> (outer, inner) index from the block's first line (one 64-bit division per workgroup instead of two per element)
     long long o = o0, i = i0 + l;
     if (d.inner == 1) {
@@ -247,8 +290,12 @@ __global__ void __launch_bounds__(256) k_fft_generic(PassDesc d, const double *_
 
 int launch_pass(mrl_ctx *ctx, const PassDesc &d0, const double *in, double *out, const cplx *d_tw, long long nbatch) {
   PassDesc d = d0;
-  const long long nlines = d.inner * d.outer;
+  long long nlines = d.inner * d.outer;
   if (nlines <= 0 || nbatch <= 0) return MRL_OK;
+  // real <-> half-spectrum passes over contiguous line sets: two lines per complex transform (half the LDS passes)
+  d.pair = (d.inner == 1 && d.in_si == 0 && d.out_si == 0 && ((d.in_kind == 1 && d.out_kind == 0) || (d.in_kind == 2 && d.out_kind == 2))) ? 1 : 0;
+  d.nreal_lines = nlines;
+  if (d.pair) nlines = (nlines + 1) / 2;
   // tile: as many lines as fit a 32 KiB LDS budget (max 16), at least 1.  The budget sets the occupancy: a workgroup alternates
   // between a load, several LDS-only passes and a store, so HBM is only busy if other workgroups of the CU are in another phase
   // (swept 20 ... 64 KiB over 120^3 ... 405^2 x 40: 32 KiB is best or within 10 % of it; 240^3 substep 2.19 -> 1.38 ms vs 64 KiB)

@@ -36,6 +36,8 @@ struct PassDesc {
   double scale;               // applied on store
   int tile;                   // lines per workgroup
   int lines_fastest;          // thread->(line,element) mapping for global access
+  int pair;                   // real <-> half-spectrum passes with inner == 1: one complex transform carries lines 2L and 2L+1
+  long long nreal_lines;      // (pair) number of real lines; the last pair may lack its second line
 };
 
 struct AxisPlan {
