@@ -308,8 +308,10 @@ int launch_pass(mrl_ctx *ctx, const PassDesc &d0, const double *in, double *out,
     if (per_line + tw_bytes > budget)
       return set_error(ctx, MRL_ERR_UNSUPPORTED, "FFT length %d exceeds the LDS-resident line limit", d.n);
   } else {
+    if (d.lines_fastest) budget = 40 * 1024;  // strided passes gather tile x 16 B per row: a little more room buys whole 64-byte sectors
     tile = (int)((budget - tw_bytes) / per_line);
     if (tile > 16) tile = 16;
+    if (d.lines_fastest && tile >= 4) tile &= ~3;  // 4, 8, 12 or 16 lines = 64 ... 256 contiguous bytes per row
     // keep enough workgroups in flight
     while (tile > 1 && (nlines + tile - 1) / tile * nbatch < 1024) tile >>= 1;
     if (tile < 1) tile = 1;
