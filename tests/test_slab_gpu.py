@@ -332,3 +332,26 @@ def test_slab_pipeline_over_rccl_single_rank(carry, nsub):
     finally:
         torch.cuda.set_stream(prev)
         dist.destroy_process_group()
+
+
+def test_spec_pitch_and_stage_argument_checks():
+    """mrl_slab_ch_spec_pitch: padded to 128-byte rows on the planned pipeline, the natural nz/2+1 otherwise; the fused mechanics
+    stage refuses contexts it was not built for (error code + message, no launch)"""
+    from marlin_amd.api import Context
+    from marlin_amd.slab import HipSlabStages
+    fast = HipSlabStages(3, [64, 64, 64], [1.0, 1.0, 1.0], 2, 0)
+    assert fast.recip_shape[-1] == 33 and fast.spec_pitch == 40
+    generic = HipSlabStages(3, [12, 10, 9], [1.0, 1.0, 1.0], 2, 1)
+    assert generic.spec_pitch == generic.recip_shape[-1] == 5
+    serial = Context(3, [64, 64, 64], [1.0, 1.0, 1.0])
+    assert int(serial.lib.mrl_slab_ch_spec_pitch(serial.h)) == 33
+    assert not serial.lib.mrl_slab_gamma_tangent_fusable(serial.h)
+    assert fast.ctx.lib.mrl_slab_gamma_tangent_fusable(fast.ctx.h) and not generic.ctx.lib.mrl_slab_gamma_tangent_fusable(generic.ctx.h)
+    z = torch.zeros(16, dtype=torch.float64, device="cuda")
+    rc = serial.lib.mrl_slab_gamma_tangent_z_fwd(serial.h, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 0.0,
+                                                 None, 0.0)
+    assert rc != 0 and b"slab" in serial.lib.mrl_last_error(serial.h).lower()
+    # row stage without an input field and without spectra left by the fused stage
+    snd = torch.zeros(8, dtype=torch.float64, device="cuda")
+    rc = fast.ctx.lib.mrl_slab_gamma_row_fwd(fast.ctx.h, 0, None, snd.data_ptr())
+    assert rc != 0 and b"mrl_slab_gamma_tangent_z_fwd" in fast.ctx.lib.mrl_last_error(fast.ctx.h)
