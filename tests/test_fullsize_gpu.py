@@ -92,6 +92,37 @@ def test_slab_pipeline_equals_serial_at_full_size(ctx256):
     assert [s.last_order for s in solvers] == [1] * 4
 
 
+@pytest.mark.parametrize("P", [8, 4, 2])
+def test_slab_bench_configuration_equals_serial(P):
+    """exactly what `bench.py --gpus P` runs per rank -- grid_for(P) (512^3 on 8 ranks, 256 x 512 x 256 on 2), 2 kz sub-blocks,
+    spectral carry-over, SlabCahnHilliard.run() with the fused z passes -- on loop-back ranks of one GPU against the serial
+    mrl_ch_substeps of the same global grid: 4 substeps, fields to 1e-13"""
+    from bench import grid_for, splitmix64_uniform
+    from marlin_amd.api import Context, ch_params
+    from tests.test_slab_gpu import _make, _run_all
+    shape = grid_for(P, 256)
+    dx = 8.0 * math.pi / 200.0
+    L = [n * dx for n in shape]
+    npts = shape[0] * shape[1] * shape[2]
+    c0 = torch.from_numpy(splitmix64_uniform(npts).reshape(shape)).cuda()
+    solvers = _make(3, list(shape), L, P, nsub=2, carry=True)
+    for s in solvers:
+        yb, nyl = s.st.real_begin[1], s.st.real_shape[1]
+        s.set_local(c0[:, yb:yb + nyl].contiguous())
+        s.sub_dt = 1e-3
+    _run_all(solvers, 4, advance=True)
+    got = torch.cat([s.current() for s in solvers], dim=1)
+    assert [s.last_order for s in solvers] == [1] * P and [s.mode for s in solvers] == [2] * P
+    del solvers
+    torch.cuda.empty_cache()
+    ctx = Context(3, list(shape), L)
+    ring = [ctx.empty_spec(), ctx.empty_spec()]
+    want = torch.empty_like(c0)
+    ctx.ch_substeps(ch_params(), c0, want, ring, 1, 0, 2, 4, True, 1e-3)
+    assert (got - want).abs().max().item() <= 1e-13
+    assert abs(got.sum(dtype=torch.float64).item() - c0.sum(dtype=torch.float64).item()) <= 1e-11 * npts * 0.5
+
+
 def test_gamma_operator_properties_128():
     """config C size: G is linear, self-adjoint on real tensor fields, annihilates uniform fields and reproduces
     compatible fields (gradients of periodic displacements) when no axis has... all axes even -> compare via G(G(A))
