@@ -242,6 +242,7 @@ int mrl_slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *d_A_fm, double *
     MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, d_A_fm + 3 * row * nreal, w, nullptr, nullptr, none, 3 * nx * nyl / 2))));
   } else {
     w = reinterpret_cast<cplx *>(ctx->d_work[12]) + 3 * row * nspec;  // z spectra left by mrl_slab_gamma_tangent_z_fwd
+    if (row == 2) ctx->gamma_z_ready = false;                         // consumed: a later call needs a new fused z pass
   }
   const unsigned chunk = (unsigned)(nxl * nyl * nzc);
   p2::SubPassArgs a{};
