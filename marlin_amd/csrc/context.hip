@@ -312,6 +312,11 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
     set_error(c, MRL_ERR_HIP, "allocating reduction scratch / events failed");
     return fail(MRL_ERR_HIP);
   }
+  {  // device-side address of the pinned scratch (hipHostMalloc memory is mapped by default); optional
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, c->h_red, 0) == hipSuccess) c->d_h_red = static_cast<double *>(dp);
+    else (void)hipGetLastError();
+  }
   *out = c;
   return MRL_OK;
 }

@@ -552,8 +552,7 @@ int mrl_cg_update(mrl_ctx *ctx, double alpha, double *d_x, double *d_r, const do
     MRL_HIP(ctx, hipGetLastError());
   }
   double *slot = ctx->d_red + kScalarBase;
-  MRL_TRY(reduce_finalize(ctx, nb, 1, slot));
-  return read_scalars(ctx, slot, 1, h_rr_local);
+  return reduce_finalize_to_host(ctx, nb, 1, slot, h_rr_local);
 }
 
 int mrl_cg_update_r(mrl_ctx *ctx, double alpha, double *d_r, const double *d_Ap, int64_t n, double *h_rr_local) {
@@ -570,8 +569,7 @@ int mrl_cg_update_r(mrl_ctx *ctx, double alpha, double *d_r, const double *d_Ap,
     MRL_HIP(ctx, hipGetLastError());
   }
   double *slot = ctx->d_red + kScalarBase;
-  MRL_TRY(reduce_finalize(ctx, nb, 1, slot));
-  return read_scalars(ctx, slot, 1, h_rr_local);
+  return reduce_finalize_to_host(ctx, nb, 1, slot, h_rr_local);
 }
 
 int mrl_mech_tangent_dir_fm(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu, double *d_p,
@@ -690,9 +688,8 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
             hipLaunchKernelGGL(k_cg_update<true>, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
           else
             hipLaunchKernelGGL(k_cg_update<false>, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
-          MRL_TRY(reduce_finalize(ctx, nb, 1, S + i_new));
+          MRL_TRY(reduce_finalize_to_host(ctx, nb, 1, S + i_new, h));  // the one host sync of the iteration (no copy command)
         }
-        MRL_TRY(read_scalars(ctx, S + i_new, 1, h));  // the one host sync of the iteration
         res_norm = sqrt(h[0]);
         if (res_norm <= prm->l_tol * b_norm) {
           its = (int)k + 1;

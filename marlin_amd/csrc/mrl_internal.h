@@ -89,6 +89,7 @@ struct mrl_ctx {
   size_t work_bytes[mrl::kWorkSlots] = {};
   double *d_red = nullptr;      // reduction scratch
   double *h_red = nullptr;      // pinned host scratch
+  double *d_h_red = nullptr;    // its device-side address (kernels may write results there), nullptr if not mappable
 
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool profiling = false;
@@ -197,6 +198,7 @@ int fft_inverse_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long 
 int reduce_async(mrl_ctx *ctx, int op, const double *a, const double *b, long long n, double *d_scalar);
 int reduce_finalize(mrl_ctx *ctx, int nb, int nslots, double *d_scalar);
 int read_scalars(mrl_ctx *ctx, const double *d_scalar, int count, double *h_out);
+int reduce_finalize_to_host(mrl_ctx *ctx, int nb, int nslots, double *d_scalar, double *h_out);
 int component_sums_async(mrl_ctx *ctx, const double *a, long long npts, int ncomp, double *d_scalar);
 
 // serial transforms (fft_plan.hip)

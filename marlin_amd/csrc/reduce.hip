@@ -38,14 +38,19 @@ __global__ void __launch_bounds__(256) k_reduce_partial(const double *__restrict
 }
 
 // fold `nb` partials of `nslots` interleaved quantities (partial[b*nslots + s]) into out[s]
+// `mirror` (optional): the same values also go to pinned host memory, so that a host that needs them only has to wait for the
+// stream -- no device-to-host copy command (one per CG iteration otherwise)
 __global__ void __launch_bounds__(256) k_reduce_final(const double *__restrict__ partial, int nb, int nslots,
-                                                       double *__restrict__ out) {
+                                                       double *__restrict__ out, double *__restrict__ mirror = nullptr) {
   __shared__ double sh[4];
   for (int s = 0; s < nslots; ++s) {
     double acc = 0.0;
     for (int i = threadIdx.x; i < nb; i += 256) acc += partial[(long long)i * nslots + s];
     const double r = block_sum256(acc, sh);
-    if (threadIdx.x == 0) out[s] = r;
+    if (threadIdx.x == 0) {
+      out[s] = r;
+      if (mirror) mirror[s] = r;
+    }
   }
 }
 
@@ -146,6 +151,21 @@ int reduce_finalize(mrl_ctx *ctx, int nb, int nslots, double *d_scalar) {
 int reduce_finalize_from(mrl_ctx *ctx, const double *partial, int nb, double *d_scalar) {
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, partial, nb, 1, d_scalar);
   MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+int read_scalars(mrl_ctx *ctx, const double *d_scalar, int count, double *h_out);
+// reduce_finalize + the values on the host after the stream has drained (at most 64 slots): the final kernel writes them to the
+// context's pinned, device-mapped scratch itself
+int reduce_finalize_to_host(mrl_ctx *ctx, int nb, int nslots, double *d_scalar, double *h_out) {
+  if (!ctx->d_h_red) {
+    MRL_TRY(reduce_finalize(ctx, nb, nslots, d_scalar));
+    return read_scalars(ctx, d_scalar, nslots, h_out);
+  }
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, ctx->d_red, nb, nslots, d_scalar, ctx->d_h_red);
+  MRL_HIP(ctx, hipGetLastError());
+  MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < nslots; ++i) h_out[i] = ctx->h_red[i];
   return MRL_OK;
 }
 
