@@ -238,7 +238,10 @@ def test_slab_ch_carry_over(shape, P, nsub):
 
 
 @pytest.mark.parametrize("shape,P,nsub,carry", [((64, 64, 64), 2, 2, False), ((64, 64, 64), 2, 2, True), ((64, 128, 64), 4, 3, True),
-                                                ((12, 10, 8), 2, 1, True), ((9, 7, 5), 3, 1, False)])
+                                                ((12, 10, 8), 2, 1, True), ((9, 7, 5), 3, 1, False),
+                                                # ny / P = 2 rows per chunk < the 4 threads of a 64-point line: the y pass without
+                                                # the wave-uniform chunk offsets (k_ch_yfused<.., ALIGNED = false>)
+                                                ((32, 64, 32), 32, 1, True), ((32, 64, 32), 32, 2, False)])
 def test_slab_run_fused_z_passes(shape, P, nsub, carry):
     """run(count): the inverse z pass of a substep fused with the forward z pass of the next one (planned shapes; the generic
     path runs the two passes back to back) == the same substeps one at a time, incl. the first-time-step rule (no history
