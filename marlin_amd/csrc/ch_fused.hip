@@ -80,6 +80,8 @@ static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
 // (1, nx, ny_user): the user's y is the contiguous r2c axis; the absent middle axis contributes k = 0 exactly)
 bool fast_path_ok(const mrl_ctx *ctx) {
   if (ctx->slab || ctx->spectrum != MRL_SPECTRUM_HALF) return false;
+  // the fused kernels address one spectral array with 32-bit byte offsets from its base (ch_fused_body.h)
+  if (16.0 * (double)ctx->nrec[0] * (double)ctx->nrec[1] * (double)ctx->nrec[2] >= 4294967296.0) return false;
   if (ctx->dim == 3) return pow2_ok(ctx->n[0]) && pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]);
   if (ctx->dim == 2) return pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]);
   return false;
