@@ -110,8 +110,8 @@ int slab_fast_ok(const mrl_ctx *ctx) {
   if (!(ctx->dim == 3 && ctx->slab && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
         pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2])))
     return 0;
-  // 32-bit byte offsets within a rank-local spectral array / an exchange buffer of both fields
-  if (32.0 * (double)ctx->n[0] * (double)ctx->nloc[1] * (double)ctx->nrec[2] >= 4294967296.0) return 0;
+  // 32-bit byte offsets within an exchange buffer (two fields in the CH pipeline, the three of a tensor row in the mechanics one)
+  if (48.0 * (double)ctx->n[0] * (double)ctx->nloc[1] * (double)ctx->nrec[2] >= 4294967296.0) return 0;
   // equal power-of-two partitions: chunk addressing by shifts
   const long long nyl = ctx->n[1] / ctx->nranks, nxl = ctx->n[0] / ctx->nranks;
   if (nyl * ctx->nranks != ctx->n[1] || nxl * ctx->nranks != ctx->n[0] || (nyl & (nyl - 1)) || (nxl & (nxl - 1))) return 0;
