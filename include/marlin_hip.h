@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MRL_ABI_VERSION 1
+#define MRL_ABI_VERSION 2
 
 enum mrl_status {
   MRL_OK = 0,
@@ -39,7 +39,8 @@ enum mrl_status {
   MRL_ERR_UNSUPPORTED = -2,  /* valid request this build cannot serve */
   MRL_ERR_HIP = -3,          /* HIP runtime failure */
   MRL_ERR_NOMEM = -4,
-  MRL_ERR_NOT_CONVERGED = -5 /* nl_max_its exceeded (FFTMechanics.C:159-161) */
+  MRL_ERR_NOT_CONVERGED = -5, /* nl_max_its exceeded (FFTMechanics.C:159-161) */
+  MRL_ERR_COMM = -6           /* multi-GPU transport failure (a peer did not arrive in time, bootstrap / IPC / RCCL error) */
 };
 
 enum mrl_spectrum {
@@ -75,6 +76,54 @@ const char *mrl_last_error(const mrl_ctx *ctx);
 /* hipStreamSynchronize on the context stream */
 int mrl_sync(mrl_ctx *ctx);
 int mrl_set_stream(mrl_ctx *ctx, void *stream);
+
+/* Run-time options of a context (no environment variables are read by the library). */
+enum mrl_option {
+  MRL_OPT_EXPERIMENT = 0,  /* bit mask of A/B switches for kernel variants (tools/ only; 0 = product defaults) */
+  MRL_OPT_SLAB_NSUB = 1,   /* kz sub-blocks the slab Cahn-Hilliard substep is pipelined over (default 1) */
+  MRL_OPT_SLAB_CARRY = 2   /* 1: spectral carry-over inside mrl_ch_substeps on slab contexts (see mrl_slab_ch_*; default 0 =
+                              the reference's data flow, three slab transposes per substep) */
+};
+int mrl_ctx_set_option(mrl_ctx *ctx, int option, int64_t value);
+int64_t mrl_ctx_get_option(const mrl_ctx *ctx, int option);
+
+/* ---- multi-GPU transport: one process per GPU, the GPUs of ONE node (xGMI) ---------------------------------------------
+ * Replaces the host-staged MPI point-to-point transposes of DomainAction::fftSlab / ifftSlab (src/actions/DomainAction.C:
+ * 869-938, 940-1019: MPI_Isend / blocking MPI_Recv of host tensors in rank order) and adds the sum over ranks that the
+ * reference's norms lack in parallel (DomainAction.C:1564-1567).  A communicator is created collectively by the `nranks`
+ * processes of a job; `name` identifies the job on the node (a POSIX shared-memory object "/name" is the bootstrap channel:
+ * barriers, the exchange of HIP IPC handles and of the RCCL unique id -- the MOOSE shim broadcasts a unique string over MPI,
+ * see INTEGRATION.md).  Every rank owns receive buffers that all peers map through HIP IPC; an exchange is
+ *   MRL_TRANSPORT_PEER_STORE  the producing kernels store their output chunks straight into the peers' receive buffers
+ *                             (no send buffer, no copy), then raise a per-source arrival flag there
+ *   MRL_TRANSPORT_PEER_COPY   the kernels write a local send buffer and the copy engines push the chunks to the peers
+ *   MRL_TRANSPORT_RCCL        grouped ncclSend / ncclRecv on a side stream (librccl.so.1 is loaded at run time)
+ * MRL_TRANSPORT_AUTO = PEER_STORE where HIP IPC works, else RCCL.  All ranks must select the same transport.
+ * Once a communicator is attached to a slab context, the whole-solver entry points work on it as they do on a serial context:
+ * mrl_ch_substeps, mrl_mech_newton_cg, mrl_fft_r2c / mrl_fft_c2r, and mrl_dot / mrl_norm2 / mrl_sum / mrl_minmax / mrl_average
+ * return the GLOBAL value.  Consumers wait for arrivals on the GPU with a bounded spin: a peer that never arrives makes the
+ * next synchronising call return MRL_ERR_COMM instead of hanging the device. */
+typedef struct mrl_comm mrl_comm;
+enum mrl_transport {
+  MRL_TRANSPORT_AUTO = 0,
+  MRL_TRANSPORT_PEER_STORE = 1,
+  MRL_TRANSPORT_PEER_COPY = 2,
+  MRL_TRANSPORT_RCCL = 3
+};
+int mrl_comm_create(mrl_comm **out, const char *name, int32_t nranks, int32_t rank, int32_t device, int32_t transport);
+void mrl_comm_destroy(mrl_comm *comm);
+const char *mrl_comm_last_error(const mrl_comm *comm); /* comm may be NULL: failure of mrl_comm_create */
+int mrl_comm_transport(const mrl_comm *comm);
+/* collective; contexts attached to the communicator rebuild their exchange buffers on the next call */
+int mrl_comm_set_transport(mrl_comm *comm, int32_t transport);
+int mrl_comm_set_timeout(mrl_comm *comm, double seconds); /* bound of every host barrier and device-side wait (default 60 s) */
+int mrl_comm_barrier(mrl_comm *comm);                     /* host barrier over the ranks */
+/* in-place all-reduce of n <= 16 host values: op 0 sum (rank order: identical bits on every rank), 1 min, 2 max */
+int mrl_comm_allreduce(mrl_comm *comm, double *h_values, int32_t n, int32_t op);
+/* cumulative count of exchanges posted and payload bytes sent to OTHER ranks by this rank */
+int mrl_comm_stats(const mrl_comm *comm, int64_t *n_exchanges, double *bytes_sent);
+/* slab contexts only; nranks / rank must match; the context does not own the communicator */
+int mrl_ctx_attach_comm(mrl_ctx *ctx, mrl_comm *comm);
 
 /* Local extents: DomainAction::getLocalShape / getReciprocalShape and the partition getters
  * (_local_begin/_local_end, DomainAction.C:524-533).  real_n/recip_n: local extents per axis,

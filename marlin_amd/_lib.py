@@ -136,6 +136,18 @@ SIGNATURES = {
     "mrl_minmax": (_i32, [_vp, _vp, _i64, C.POINTER(_dbl), C.POINTER(_dbl)]),
     "mrl_reciprocal_laplacian": (_i32, [_vp, _i32, _dbl, _vp]),
     "mrl_average": (_i32, [_vp, _vp, _i64, C.POINTER(_dbl)]),
+    "mrl_ctx_set_option": (_i32, [_vp, _i32, _i64]),
+    "mrl_ctx_get_option": (_i64, [_vp, _i32]),
+    "mrl_comm_create": (_i32, [C.POINTER(_vp), C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "mrl_comm_destroy": (None, [_vp]),
+    "mrl_comm_last_error": (C.c_char_p, [_vp]),
+    "mrl_comm_transport": (_i32, [_vp]),
+    "mrl_comm_set_transport": (_i32, [_vp, C.c_int32]),
+    "mrl_comm_set_timeout": (_i32, [_vp, _dbl]),
+    "mrl_comm_barrier": (_i32, [_vp]),
+    "mrl_comm_allreduce": (_i32, [_vp, C.POINTER(_dbl), C.c_int32, C.c_int32]),
+    "mrl_comm_stats": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_dbl)]),
+    "mrl_ctx_attach_comm": (_i32, [_vp, _vp]),
     "mrl_timer_start": (_i32, [_vp]),
     "mrl_timer_stop": (_i32, [_vp, C.POINTER(C.c_float)]),
     "mrl_set_profiling": (_i32, [_vp, _i32]),
@@ -160,7 +172,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.mrl_abi_version() != 1:
+    if lib.mrl_abi_version() != 2:
         raise RuntimeError("libmarlin_hip.so ABI version mismatch")
     _lib = lib
     return lib

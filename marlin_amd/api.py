@@ -67,6 +67,60 @@ def ch_params(family=FE_DOUBLE_WELL, coef=(0.1,), mobility=0.2, kappa=-0.001, pa
     return p
 
 
+TRANSPORT_AUTO, TRANSPORT_PEER_STORE, TRANSPORT_PEER_COPY, TRANSPORT_RCCL = 0, 1, 2, 3
+TRANSPORT_NAMES = {1: "peer_store", 2: "peer_copy", 3: "rccl"}
+OPT_EXPERIMENT, OPT_SLAB_NSUB, OPT_SLAB_CARRY = 0, 1, 2
+
+
+class Comm:
+    """One mrl_comm: the library-owned multi-GPU transport of a job of `nranks` processes on one node (one process per GPU).
+    `name` identifies the job (all ranks pass the same string; it names the POSIX shared-memory bootstrap segment)."""
+
+    def __init__(self, name: str, nranks: int, rank: int, device: Optional[int] = None, transport: int = TRANSPORT_AUTO,
+                 timeout: Optional[float] = None):
+        self.lib = _lib.load()
+        if device is None:
+            device = torch.cuda.current_device()
+        h = C.c_void_p()
+        rc = self.lib.mrl_comm_create(C.byref(h), name.encode(), nranks, rank, device, transport)
+        if rc != 0:
+            raise MarlinHipError(rc, self.lib.mrl_comm_last_error(None).decode())
+        self.h = h
+        self.nranks, self.rank = nranks, rank
+        if timeout is not None:
+            self._check(self.lib.mrl_comm_set_timeout(h, float(timeout)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MarlinHipError(rc, self.lib.mrl_comm_last_error(self.h).decode())
+
+    @property
+    def transport(self) -> int:
+        return self.lib.mrl_comm_transport(self.h)
+
+    def set_transport(self, transport: int):
+        self._check(self.lib.mrl_comm_set_transport(self.h, transport))
+
+    def barrier(self):
+        self._check(self.lib.mrl_comm_barrier(self.h))
+
+    def allreduce(self, values: Sequence[float], op: int = 0) -> List[float]:
+        n = len(values)
+        arr = (C.c_double * max(1, n))(*values)
+        self._check(self.lib.mrl_comm_allreduce(self.h, arr, n, op))
+        return list(arr)[:n]
+
+    def stats(self):
+        n, b = C.c_int64(), C.c_double()
+        self._check(self.lib.mrl_comm_stats(self.h, C.byref(n), C.byref(b)))
+        return {"exchanges": n.value, "bytes_sent": b.value}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mrl_comm_destroy(self.h)
+            self.h = None
+
+
 class Context:
     """One mrl_ctx (= one DomainAction on one rank / GPU)."""
 
@@ -119,6 +173,19 @@ class Context:
     def _check(self, rc):
         if rc != 0:
             raise MarlinHipError(rc, self.lib.mrl_last_error(self.h).decode())
+
+    def attach_comm(self, comm: Optional["Comm"]):
+        """slab contexts: hand the exchanges to the library (mrl_ch_substeps, mrl_fft_*, mrl_mech_newton_cg, reductions become global)"""
+        self._check(self.lib.mrl_ctx_attach_comm(self.h, comm.h if comm is not None else None))
+        self._comm = comm
+
+    def set_option(self, option: int, value: int):
+        self._check(self.lib.mrl_ctx_set_option(self.h, option, int(value)))
+
+    @property
+    def spec_pitch(self) -> int:
+        """last-axis pitch (complex elements) of the rank-local spectral arrays of the slab Cahn-Hilliard pipeline"""
+        return int(self.lib.mrl_slab_ch_spec_pitch(self.h))
 
     # ---- helpers
     def empty_real(self, *value_dims, batch_first: Optional[int] = None):

@@ -299,6 +299,9 @@ int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c
 // fast fused path (ch_fused.hip); returns MRL_ERR_UNSUPPORTED when the shape has no fast kernels
 int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new,
                      const double *const *Nhat_old, int order, double sub_dt, double *cbar, double *mu, int carry);
+// slab contexts with a communicator (slab_driver.hip)
+int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, double *c_out, double *const *ring, int ring_size,
+                     int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu);
 
 }  // namespace mrl
 
@@ -324,8 +327,21 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
   if (order > 0 && !d_Nhat_old) return set_error(ctx, MRL_ERR_INVALID, "history pointers missing");
   for (int i = 0; i < order; ++i)
     if (!d_Nhat_old[i]) return set_error(ctx, MRL_ERR_INVALID, "history entry %d missing", i);
-  if (ctx->slab)
-    return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substep on a slab context: use the mrl_slab_ch_* stages");
+  if (ctx->slab) {
+    // one substep of the library-owned slab pipeline: the explicit history pointers as a ring {old[order-1] ... old[0], new}
+    if (carry != MRL_CARRY_NONE || d_cbar)
+      return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_ch_substep on a slab context: cbar / carry are handled inside mrl_ch_substeps (MRL_OPT_SLAB_CARRY)");
+    if (order == 0) {
+      double *ring0[1] = {d_Nhat_new};
+      int head = 0, n_old = 0;
+      return slab_ch_substeps(ctx, p, d_c_in, d_c_out, ring0, 1, &head, &n_old, 0, 1, 0, sub_dt, d_mu);
+    }
+    double *ring[5];
+    for (int i = 0; i < order; ++i) ring[order - 1 - i] = const_cast<double *>(d_Nhat_old[i]);
+    ring[order] = d_Nhat_new;
+    int head = order - 1, n_old = order;
+    return slab_ch_substeps(ctx, p, d_c_in, d_c_out, ring, order + 1, &head, &n_old, order, 1, 0, sub_dt, d_mu);
+  }
 
   if (carry != MRL_CARRY_NONE && carry != MRL_CARRY_OUT && carry != MRL_CARRY_IN)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substep: carry must be MRL_CARRY_NONE, _OUT or _IN");
@@ -443,7 +459,8 @@ int mrl_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, 
     return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substeps: history ring of %d arrays needed (head %d, n_old %d)", pred + 1, *head, *n_old);
   for (int i = 0; i < ring_size; ++i)
     if (!d_Nhat_ring[i]) return set_error(ctx, MRL_ERR_INVALID, "history ring entry %d missing", i);
-  if (ctx->slab) return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substeps on a slab context: use the mrl_slab_ch_* stages");
+  if (ctx->slab)  // the library owns the exchanges (communicator attached with mrl_ctx_attach_comm)
+    return slab_ch_substeps(ctx, p, d_c_in, d_c_out, d_Nhat_ring, ring_size, head, n_old, pred, count, advance, sub_dt, d_mu);
   int rc = ch_substeps_fused(ctx, cp, d_c_in, d_c_out, d_Nhat_ring, ring_size, head, n_old, pred, count, advance, sub_dt, d_mu);
   if (rc != MRL_ERR_UNSUPPORTED) return rc;
   // generic shapes: one mrl_ch_substep per substep, the intermediate fields ping-pong between d_c_out and a scratch array

@@ -39,7 +39,9 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const
   // byte offset of line element m: (i + (q + m*TPL)*inner) * 16, the same in the work and the dense layout
   const unsigned off0 = (unsigned)(iv + (long long)q * a.inner) * 16u, step = (unsigned)(TPL * a.inner) * 16u;
   auto off = [=](int m) { return off0 + (unsigned)m * step; };
-  ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT, NT, NT>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, W, X, KX);
+  cplx *const ubar = a.c.ubar;
+  auto stu = [=](int m, cplx val) { stc(ubar, off0 + (unsigned)m * step, val); };
+  ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT, NT, NT>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, stu, W, X, KX);
 }
 
 // The non-temporal variant pays off when the arrays are large against the 256 MB Infinity Cache (a resident old Nhat is a hit

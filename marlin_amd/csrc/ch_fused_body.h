@@ -54,7 +54,8 @@ __device__ __forceinline__ void stc_nt(cplx *base, unsigned boff, cplx v) {
 
 // OffW / OffD: callables m -> byte offset of the thread's m-th line element in the work layout / the dense
 // reference layout (computed from a few live values instead of 2 x 16 held registers).
-// OffU: the same for the ubar output (the inverse exchange layout of the slab path differs from the forward one).
+// StU: callable (m, value) that stores the thread's m-th element of the ubar output (work layout on one GPU; on the slab path
+// the inverse exchange layout, scattered through a per-destination pointer table).
 // SPEC_C: c-hat is not transformed from the work layout but read, already in reciprocal space, from a.carry (dense), which
 // receives ubar in place: irfftn followed by rfftn is the identity up to rounding, so the next substep's c-hat IS this ubar.
 // The old / new Nhat arrays (and the optional cbar output) are accessed non-temporally: they are not touched again within the
@@ -63,11 +64,11 @@ __device__ __forceinline__ void stc_nt(cplx *base, unsigned boff, cplx v) {
 // NT_CARRY: the same for the carried spectrum (read and rewritten once per substep).
 // NT_HIST: ... for the old / new Nhat arrays and the cbar output.
 template <int N, int ORDER, bool LINE_IS_X, int PRE, bool SPEC_C, bool NT_W, bool NT_CARRY, bool NT_HIST, class OffW,
-          class OffD, class OffU>
+          class OffD, class StU>
 __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *__restrict__ tw,
                                               const double *__restrict__ kline, const double *__restrict__ ka_ptr,
                                               const double *__restrict__ kb_ptr, bool valid, int q, int l,
-                                              OffW offw, OffD offd, OffU offu, cplx *W, cplx *X,
+                                              OffW offw, OffD offd, StU stu, cplx *W, cplx *X,
                                               double *KL) {
 #pragma clang fp contract(off)
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, NT = Plan<N>::NT, CNT = (N + NT - 1) / NT;
@@ -214,7 +215,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   fft_line<N, Map>(v, q, l, X, W);
   if (valid) {
 #pragma unroll
-    for (int m = 0; m < P; ++m) stc(a.ubar, offu(m), cswap(v[m]));
+    for (int m = 0; m < P; ++m) stu(m, cswap(v[m]));
   }
 }
 

@@ -1,0 +1,720 @@
+// Multi-GPU transport: one process per GPU on one node (see comm.h for the design).
+// Replaces the host-staged MPI transposes of DomainAction::fftSlab / ifftSlab (src/actions/DomainAction.C:869-1019).
+#include "comm.h"
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <rccl/rccl.h>  // types only: the library is loaded at run time (dlopen) when the RCCL transport is selected
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "comm_dev.h"
+
+namespace mrl {
+
+static thread_local std::string g_comm_create_error;
+
+int comm_error(const mrl_comm *c, int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c)
+    c->err = buf;
+  else
+    g_comm_create_error = buf;
+  return code;
+}
+
+#define COMM_HIP(c, expr)                                                                                         \
+  do {                                                                                                            \
+    hipError_t e_ = (expr);                                                                                       \
+    if (e_ != hipSuccess)                                                                                         \
+      return mrl::comm_error(c, MRL_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define COMM_TRY(expr)             \
+  do {                             \
+    int rc_ = (expr);              \
+    if (rc_ != MRL_OK) return rc_; \
+  } while (0)
+
+// ---- host bootstrap segment ---------------------------------------------------------------------------------------------
+struct ShmSeg {
+  std::atomic<uint32_t> attached;
+  std::atomic<uint32_t> bar_count, bar_gen;
+  std::atomic<int32_t> abort_flag;
+  unsigned char pad[48];
+  unsigned char blob[kMaxRanks][256];
+  double red[2][kMaxRanks][16];
+};
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int comm_barrier(mrl_comm *c) {
+  if (c->nranks == 1) return MRL_OK;
+  ShmSeg *s = c->shm;
+  const uint32_t gen = s->bar_gen.load(std::memory_order_acquire);
+  if (s->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)c->nranks) {
+    s->bar_count.store(0, std::memory_order_relaxed);
+    s->bar_gen.fetch_add(1, std::memory_order_release);
+    return MRL_OK;
+  }
+  const double t0 = now_s();
+  int spins = 0;
+  while (s->bar_gen.load(std::memory_order_acquire) == gen) {
+    if (s->abort_flag.load(std::memory_order_relaxed))
+      return comm_error(c, MRL_ERR_COMM, "another rank aborted the job (rank %d at a host barrier)", c->rank);
+    if (++spins > 2000) {
+      usleep(20);
+      if (now_s() - t0 > c->timeout_s) {
+        s->abort_flag.store(1);
+        return comm_error(c, MRL_ERR_COMM, "host barrier timed out after %.0f s (rank %d of %d)", c->timeout_s, c->rank, c->nranks);
+      }
+    }
+  }
+  return MRL_OK;
+}
+
+int comm_allgather(mrl_comm *c, const void *mine, size_t bytes, void *all) {
+  if (bytes > 256) return comm_error(c, MRL_ERR_INVALID, "bootstrap all-gather of more than 256 bytes");
+  if (c->nranks == 1) {
+    std::memcpy(all, mine, bytes);
+    return MRL_OK;
+  }
+  std::memcpy(c->shm->blob[c->rank], mine, bytes);
+  COMM_TRY(comm_barrier(c));
+  for (int p = 0; p < c->nranks; ++p) std::memcpy(static_cast<char *>(all) + p * bytes, c->shm->blob[p], bytes);
+  return comm_barrier(c);  // nobody overwrites a blob before everybody has read it
+}
+
+int comm_allreduce_host(mrl_comm *c, double *v, int n, int op) {
+  if (n < 0 || n > 16) return comm_error(c, MRL_ERR_INVALID, "all-reduce of at most 16 values");
+  if (c->nranks == 1 || n == 0) return MRL_OK;
+  // double-buffered by call parity: a rank can be at most one call ahead of the slowest reader (the barrier of call e + 1
+  // is passed only after every rank has finished reading call e)
+  const uint32_t par = c->red_parity++ & 1u;
+  for (int i = 0; i < n; ++i) c->shm->red[par][c->rank][i] = v[i];
+  COMM_TRY(comm_barrier(c));
+  for (int i = 0; i < n; ++i) {
+    double acc = c->shm->red[par][0][i];
+    for (int p = 1; p < c->nranks; ++p) {
+      const double x = c->shm->red[par][p][i];
+      acc = op == 0 ? acc + x : (op == 1 ? (x < acc ? x : acc) : (x > acc ? x : acc));
+    }
+    v[i] = acc;
+  }
+  return MRL_OK;
+}
+
+// ---- symmetric device memory ------------------------------------------------------------------------------------------
+int sym_alloc(mrl_comm *c, size_t bytes, SymBuf *out, bool uncached) {
+  out->bytes = bytes;
+  // attempt 0: uncached (fine-grained) device memory for flag words; attempt 1: plain hipMalloc.  The verdict of an attempt is
+  // collective, so every rank ends up with the same kind of allocation.
+  for (int attempt = uncached ? 0 : 1; attempt < 2; ++attempt) {
+    out->peer.assign(c->nranks, nullptr);
+    void *p = nullptr;
+    hipError_t e = attempt == 0 ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) : hipMalloc(&p, bytes);
+    int ok = e == hipSuccess ? 1 : 0;
+    if (!ok) {
+      (void)hipGetLastError();
+      p = nullptr;
+    }
+    if (ok && (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) ok = 0;
+    out->local = p;
+    out->peer[c->rank] = p;
+    if (c->nranks == 1) {
+      if (ok) return MRL_OK;
+      if (p) (void)hipFree(p);
+      out->local = nullptr;
+      continue;
+    }
+    if (!c->ipc_ok) {  // RCCL-only communicator: nothing to map
+      double v = ok ? 1.0 : 0.0;
+      COMM_TRY(comm_allreduce_host(c, &v, 1, 1));
+      if (v != 0.0) return MRL_OK;
+      if (p) (void)hipFree(p);
+      out->local = nullptr;
+      continue;
+    }
+    hipIpcMemHandle_t mine, all[kMaxRanks];
+    std::memset(&mine, 0, sizeof(mine));
+    if (ok && hipIpcGetMemHandle(&mine, p) != hipSuccess) {
+      (void)hipGetLastError();
+      ok = 0;
+    }
+    static_assert(sizeof(hipIpcMemHandle_t) <= 256, "IPC handle does not fit a bootstrap blob");
+    double v = ok ? 1.0 : 0.0;
+    COMM_TRY(comm_allreduce_host(c, &v, 1, 1));
+    if (v != 0.0) {
+      COMM_TRY(comm_allgather(c, &mine, sizeof(mine), all));
+      for (int q = 0; q < c->nranks && ok; ++q) {
+        if (q == c->rank) continue;
+        void *m = nullptr;
+        if (hipIpcOpenMemHandle(&m, all[q], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+          (void)hipGetLastError();
+          ok = 0;
+          break;
+        }
+        out->peer[q] = m;
+      }
+      v = ok ? 1.0 : 0.0;  // every rank must agree on whether the mapping worked
+      COMM_TRY(comm_allreduce_host(c, &v, 1, 1));
+      if (v != 0.0) return MRL_OK;
+    }
+    // undo this attempt on every rank
+    for (int q = 0; q < c->nranks; ++q)
+      if (q != c->rank && out->peer[q]) (void)hipIpcCloseMemHandle(out->peer[q]);
+    COMM_TRY(comm_barrier(c));
+    if (p) (void)hipFree(p);
+    out->local = nullptr;
+  }
+  out->peer.clear();
+  if (c->nranks > 1 && c->ipc_ok)
+    return comm_error(c, MRL_ERR_COMM, "HIP IPC mapping of a %zu byte peer buffer failed (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", bytes);
+  return comm_error(c, MRL_ERR_NOMEM, "hipMalloc of %zu bytes for an exchange buffer failed", bytes);
+}
+
+int sym_free(mrl_comm *c, SymBuf *b) {
+  if (!b->local) return MRL_OK;
+  int rc = MRL_OK;
+  if (c->nranks > 1) rc = comm_barrier(c);  // nobody is still writing into it
+  for (int q = 0; q < (int)b->peer.size(); ++q)
+    if (q != c->rank && b->peer[q]) (void)hipIpcCloseMemHandle(b->peer[q]);
+  if (c->nranks > 1 && rc == MRL_OK) rc = comm_barrier(c);  // every mapping is closed before the owner frees
+  (void)hipFree(b->local);
+  b->local = nullptr;
+  b->peer.clear();
+  b->bytes = 0;
+  return rc;
+}
+
+// ---- device-side flags ----------------------------------------------------------------------------------------------------
+__global__ void k_comm_signal(unsigned long long *const *tab, int nranks, int me, int row, unsigned long long epoch, int only) {
+  const int p = threadIdx.x;
+  if (p < nranks && (only < 0 || p == only)) {
+    __threadfence_system();
+    __hip_atomic_store(tab[p] + row + me, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// one thread per source rank; bounded spin (wall_clock64 = the constant 100 MHz counter)
+__global__ void k_comm_wait(const unsigned long long *row, int nranks, unsigned long long epoch, int *status, long long max_ticks) {
+  const int p = threadIdx.x;
+  if (p >= nranks) return;
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(row + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+    if (wall_clock64() - t0 > max_ticks) {
+      atomicMax(status, 1 + p);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+// sum over ranks of n scalars: every rank stores its values into every peer's mailbox, raises a flag, waits for all flags and
+// adds the P contributions in rank order (identical bits everywhere).  One workgroup of 64 threads.
+__global__ void k_comm_allreduce(double *const *mbox_tab, unsigned long long *const *flag_tab, const unsigned long long *my_row,
+                                 int nranks, int me, int row, unsigned long long epoch, const double *in, int n, double *out,
+                                 double *h_out, int *status, long long max_ticks) {
+  const int t = threadIdx.x;
+  const int par = (int)(epoch & 1ull);
+  typedef unsigned long long u64;
+  if (t < nranks) {
+    u64 *dst = reinterpret_cast<u64 *>(mbox_tab[t]) + ((size_t)par * kMaxRanks + me) * 16;
+    for (int i = 0; i < n; ++i) __hip_atomic_store(dst + i, __double_as_longlong(in[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(flag_tab[t] + row + me, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(my_row + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+      if (wall_clock64() - t0 > max_ticks) {
+        atomicMax(status, 1 + t);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  if (t < n) {
+    const u64 *src = reinterpret_cast<const u64 *>(mbox_tab[me]) + (size_t)par * kMaxRanks * 16 + t;
+    double acc = 0.0;
+    for (int p = 0; p < nranks; ++p)
+      acc += __longlong_as_double((long long)__hip_atomic_load(src + (size_t)p * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    out[t] = acc;
+    if (h_out) h_out[t] = acc;
+  }
+}
+
+static long long max_ticks(const mrl_comm *c) { return (long long)(c->timeout_s * (double)c->wall_khz * 1000.0); }
+
+int comm_check(mrl_comm *c) {
+  if (c->h_status && *c->h_status != 0) {
+    const int who = *c->h_status - 1;
+    *c->h_status = 0;
+    if (c->shm) c->shm->abort_flag.store(1);
+    return comm_error(c, MRL_ERR_COMM, "rank %d: the data of rank %d did not arrive within %.0f s (device-side wait timed out)", c->rank,
+                      who, c->timeout_s);
+  }
+  return MRL_OK;
+}
+
+int comm_allreduce_device(mrl_comm *c, hipStream_t stream, const double *d_in, int n, double *d_out, double *h_out) {
+  if (n < 1 || n > 16) return comm_error(c, MRL_ERR_INVALID, "device all-reduce of 1..16 values");
+  if (c->transport == MRL_TRANSPORT_RCCL && c->nranks > 1) {
+    // no mapped mailboxes: through the host (one synchronisation, as the reference's .item() calls)
+    double h[16];
+    COMM_HIP(c, hipMemcpyAsync(h, d_in, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+    COMM_HIP(c, hipStreamSynchronize(stream));
+    COMM_TRY(comm_allreduce_host(c, h, n, 0));
+    COMM_HIP(c, hipMemcpyAsync(d_out, h, sizeof(double) * n, hipMemcpyHostToDevice, stream));
+    COMM_HIP(c, hipStreamSynchronize(stream));
+    if (h_out) std::memcpy(h_out, h, sizeof(double) * n);
+    return MRL_OK;
+  }
+  const unsigned long long epoch = ++c->mbox_epoch;
+  const int row = c->mbox_channel * kFlagRow;
+  hipLaunchKernelGGL(k_comm_allreduce, dim3(1), dim3(64), 0, stream, c->d_mbox_tab, c->d_flag_tab,
+                     static_cast<const unsigned long long *>(c->flags.local) + row, c->nranks, c->rank, row, epoch, d_in, n, d_out,
+                     h_out ? c->d_h_mbox : nullptr, c->d_status, max_ticks(c));
+  COMM_HIP(c, hipGetLastError());
+  if (h_out) {
+    COMM_HIP(c, hipStreamSynchronize(stream));
+    COMM_TRY(comm_check(c));
+    std::memcpy(h_out, c->h_mbox, sizeof(double) * n);
+  }
+  return MRL_OK;
+}
+
+// ---- RCCL (loaded at run time) ------------------------------------------------------------------------------------------
+struct RcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*GroupStart)();
+  ncclResult_t (*GroupEnd)();
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  const char *(*GetErrorString)(ncclResult_t);
+};
+
+static int rccl_init(mrl_comm *c) {
+  if (c->rccl_comm) return MRL_OK;
+  int ok = 1;
+  if (!c->rccl_lib) {
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+      c->rccl_lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (c->rccl_lib) break;
+    }
+    if (c->rccl_lib) {
+      c->rccl = new RcclApi();
+#define MRL_SYM(field, name) ok = ok && (*reinterpret_cast<void **>(&c->rccl->field) = dlsym(c->rccl_lib, name)) != nullptr
+      MRL_SYM(GetUniqueId, "ncclGetUniqueId");
+      MRL_SYM(CommInitRank, "ncclCommInitRank");
+      MRL_SYM(CommDestroy, "ncclCommDestroy");
+      MRL_SYM(GroupStart, "ncclGroupStart");
+      MRL_SYM(GroupEnd, "ncclGroupEnd");
+      MRL_SYM(Send, "ncclSend");
+      MRL_SYM(Recv, "ncclRecv");
+      MRL_SYM(GetErrorString, "ncclGetErrorString");
+#undef MRL_SYM
+    } else {
+      ok = 0;
+    }
+  }
+  double v = ok ? 1.0 : 0.0;
+  COMM_TRY(comm_allreduce_host(c, &v, 1, 1));
+  if (v == 0.0) return comm_error(c, MRL_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded on every rank (%s)", ok ? "another rank" : dlerror());
+  ncclUniqueId id, all[kMaxRanks];
+  std::memset(&id, 0, sizeof(id));
+  static_assert(sizeof(ncclUniqueId) <= 256, "unique id does not fit a bootstrap blob");
+  if (c->rank == 0 && c->rccl->GetUniqueId(&id) != ncclSuccess) ok = 0;
+  COMM_TRY(comm_allgather(c, &id, sizeof(id), all));
+  ncclComm_t nc = nullptr;
+  const ncclResult_t r = ok ? c->rccl->CommInitRank(&nc, c->nranks, all[0], c->rank) : ncclInternalError;
+  v = (r == ncclSuccess) ? 1.0 : 0.0;
+  COMM_TRY(comm_allreduce_host(c, &v, 1, 1));
+  if (v == 0.0) {
+    if (nc) c->rccl->CommDestroy(nc);
+    return comm_error(c, MRL_ERR_COMM, "ncclCommInitRank failed (%s)", r == ncclSuccess ? "on another rank" : c->rccl->GetErrorString(r));
+  }
+  c->rccl_comm = nc;
+  return MRL_OK;
+}
+
+// ---- exchange endpoints -------------------------------------------------------------------------------------------------
+int xchg_create(mrl_comm *c, Xchg *x, const size_t *send_cnt, const size_t *recv_cnt, bool want_send_buffer) {
+  const int P = c->nranks;
+  if (c->next_channel >= kMaxChannels) return comm_error(c, MRL_ERR_UNSUPPORTED, "out of exchange channels");
+  x->channel = c->next_channel++;
+  x->epoch = 0;
+  x->send_cnt.assign(send_cnt, send_cnt + P);
+  x->recv_cnt.assign(recv_cnt, recv_cnt + P);
+  x->send_off.assign(P, 0);
+  x->recv_off.assign(P, 0);
+  size_t so = 0, ro = 0;
+  for (int p = 0; p < P; ++p) {
+    x->send_off[p] = so;
+    x->recv_off[p] = ro;
+    so += send_cnt[p];
+    ro += recv_cnt[p];
+  }
+  x->send_bytes = so;
+  // where my chunk lands in peer p's buffer = p's recv_off[me]: gather every rank's offset row (<= 256 bytes per round)
+  x->slot_at_peer.assign(P, 0);
+  for (int base = 0; base < P; base += 32) {
+    const int cnt = (P - base) < 32 ? (P - base) : 32;
+    size_t mine[32], all[kMaxRanks * 32];
+    for (int i = 0; i < cnt; ++i) mine[i] = x->recv_off[base + i];
+    COMM_TRY(comm_allgather(c, mine, sizeof(size_t) * cnt, all));
+    if (c->rank >= base && c->rank < base + cnt)
+      for (int p = 0; p < P; ++p) x->slot_at_peer[p] = all[(size_t)p * cnt + (c->rank - base)];
+  }
+  // consistency: what I send to p is what p expects from me
+  {
+    double bad = 0.0;
+    for (int base = 0; base < P; base += 32) {
+      const int cnt = (P - base) < 32 ? (P - base) : 32;
+      size_t mine[32], all[kMaxRanks * 32];
+      for (int i = 0; i < cnt; ++i) mine[i] = x->recv_cnt[base + i];
+      COMM_TRY(comm_allgather(c, mine, sizeof(size_t) * cnt, all));
+      if (c->rank >= base && c->rank < base + cnt)
+        for (int p = 0; p < P; ++p)
+          if (all[(size_t)p * cnt + (c->rank - base)] != x->send_cnt[p]) bad = 1.0;
+    }
+    COMM_TRY(comm_allreduce_host(c, &bad, 1, 2));
+    if (bad != 0.0) return comm_error(c, MRL_ERR_INVALID, "exchange counts of the ranks do not match");
+  }
+  COMM_TRY(sym_alloc(c, ro ? ro : 16, &x->recv));
+  if (want_send_buffer && so) {
+    void *s = nullptr;
+    if (hipMalloc(&s, so) != hipSuccess) return comm_error(c, MRL_ERR_NOMEM, "hipMalloc of a %zu byte send buffer failed", so);
+    x->send = static_cast<double *>(s);
+  }
+  COMM_HIP(c, hipMalloc(reinterpret_cast<void **>(&x->d_tab), sizeof(char *) * P));
+  COMM_HIP(c, hipMalloc(reinterpret_cast<void **>(&x->d_counter), 64));
+  COMM_HIP(c, hipMemset(x->d_counter, 0, 64));
+  COMM_HIP(c, hipEventCreateWithFlags(&x->rccl_done, hipEventDisableTiming));
+  x->copy_done.resize(c->side.size());
+  for (auto &e : x->copy_done) COMM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return MRL_OK;
+}
+
+void xchg_destroy(mrl_comm *c, Xchg *x) {
+  if (x->channel < 0) return;
+  (void)hipDeviceSynchronize();
+  sym_free(c, &x->recv);
+  if (x->send) (void)hipFree(x->send);
+  if (x->d_tab) (void)hipFree(x->d_tab);
+  if (x->d_counter) (void)hipFree(x->d_counter);
+  if (x->rccl_done) (void)hipEventDestroy(x->rccl_done);
+  for (auto &e : x->copy_done) (void)hipEventDestroy(e);
+  *x = Xchg();
+}
+
+int xchg_build_table(mrl_comm *c, Xchg *x, bool direct) {
+  const int P = c->nranks;
+  std::vector<char *> t(P);
+  if (direct && !c->ipc_ok && P > 1) return comm_error(c, MRL_ERR_UNSUPPORTED, "direct peer stores need HIP IPC");
+  for (int p = 0; p < P; ++p) {
+    if (direct)
+      t[p] = static_cast<char *>(x->recv.peer[p]) + x->slot_at_peer[p];
+    else {
+      if (!x->send) return comm_error(c, MRL_ERR_INVALID, "exchange without a send buffer");
+      t[p] = reinterpret_cast<char *>(x->send) + x->send_off[p];
+    }
+  }
+  COMM_HIP(c, hipMemcpy(x->d_tab, t.data(), sizeof(char *) * P, hipMemcpyHostToDevice));
+  x->tab_direct = direct;
+  return MRL_OK;
+}
+
+int xchg_begin(mrl_comm *c, Xchg *x, hipStream_t stream) {
+  if (!x->pending_send_guard) return MRL_OK;
+  // the previous pushes out of the send buffer must have finished before it is overwritten
+  if (c->transport == MRL_TRANSPORT_RCCL) {
+    COMM_HIP(c, hipStreamWaitEvent(stream, x->rccl_done, 0));
+  } else {
+    for (auto &e : x->copy_done) COMM_HIP(c, hipStreamWaitEvent(stream, e, 0));
+  }
+  x->pending_send_guard = false;
+  return MRL_OK;
+}
+
+SignalArgs xchg_signal_args(const mrl_comm *c, const Xchg *x, unsigned int nblocks) {
+  SignalArgs s{};
+  if (!x->tab_direct) return s;  // counter == nullptr: the host posts the exchange
+  s.counter = x->d_counter;
+  s.flag_tab = c->d_flag_tab;
+  s.epoch = x->epoch + 1;
+  s.expected = nblocks;
+  s.nranks = c->nranks;
+  s.me = c->rank;
+  s.row = x->channel * kFlagRow;
+  return s;
+}
+
+int xchg_post(mrl_comm *c, Xchg *x, hipStream_t stream, bool kernel_signalled) {
+  const int P = c->nranks, me = c->rank;
+  x->epoch += 1;
+  c->n_exchanges += 1;
+  for (int p = 0; p < P; ++p)
+    if (p != me) c->bytes_sent += (double)x->send_cnt[p];
+  const int row = x->channel * kFlagRow;
+  if (x->tab_direct) {
+    // the producer scattered into the peers' buffers: only the flags are left (unless the kernel raised them itself)
+    if (kernel_signalled) return MRL_OK;
+    hipLaunchKernelGGL(k_comm_signal, dim3(1), dim3(64), 0, stream, c->d_flag_tab, P, me,
+                       row, (unsigned long long)x->epoch, -1);
+    COMM_HIP(c, hipGetLastError());
+    return MRL_OK;
+  }
+  if (!x->send && x->send_bytes) return comm_error(c, MRL_ERR_INVALID, "exchange posted without a send buffer");
+  if (c->transport == MRL_TRANSPORT_RCCL) {
+    COMM_TRY(rccl_init(c));
+    hipStream_t rs = c->side[0];
+    COMM_HIP(c, hipEventRecord(c->ev_prod, stream));
+    COMM_HIP(c, hipStreamWaitEvent(rs, c->ev_prod, 0));
+    ncclComm_t nc = static_cast<ncclComm_t>(c->rccl_comm);
+    ncclResult_t r = c->rccl->GroupStart();
+    for (int i = 0; i < P && r == ncclSuccess; ++i) {
+      const int p = (me + i) % P;
+      if (x->send_cnt[p]) r = c->rccl->Send(reinterpret_cast<const char *>(x->send) + x->send_off[p], x->send_cnt[p] / 8, ncclDouble, p, nc, rs);
+      if (r == ncclSuccess && x->recv_cnt[p])
+        r = c->rccl->Recv(static_cast<char *>(x->recv.local) + x->recv_off[p], x->recv_cnt[p] / 8, ncclDouble, p, nc, rs);
+    }
+    if (r == ncclSuccess) r = c->rccl->GroupEnd();
+    if (r != ncclSuccess) return comm_error(c, MRL_ERR_COMM, "RCCL send/recv failed: %s", c->rccl->GetErrorString(r));
+    COMM_HIP(c, hipEventRecord(x->rccl_done, rs));
+    x->pending_send_guard = true;
+    return MRL_OK;
+  }
+  // copy engines: one side stream per peer offset so that the pushes run concurrently; the flag follows its copy in order
+  COMM_HIP(c, hipEventRecord(c->ev_prod, stream));
+  const int ns = (int)c->side.size();
+  for (int i = 0; i < P; ++i) {
+    const int p = (me + i) % P;
+    hipStream_t cs = c->side[i % ns];
+    COMM_HIP(c, hipStreamWaitEvent(cs, c->ev_prod, 0));
+    if (x->send_cnt[p])
+      COMM_HIP(c, hipMemcpyAsync(static_cast<char *>(x->recv.peer[p]) + x->slot_at_peer[p], reinterpret_cast<const char *>(x->send) + x->send_off[p],
+                                 x->send_cnt[p], hipMemcpyDeviceToDevice, cs));
+    hipLaunchKernelGGL(k_comm_signal, dim3(1), dim3(64), 0, cs, c->d_flag_tab, P, me, row,
+                       (unsigned long long)x->epoch, p);
+    COMM_HIP(c, hipGetLastError());
+  }
+  for (int i = 0; i < ns && i < P; ++i) COMM_HIP(c, hipEventRecord(x->copy_done[i], c->side[i]));
+  x->pending_send_guard = true;
+  return MRL_OK;
+}
+
+int xchg_wait(mrl_comm *c, Xchg *x, hipStream_t stream) {
+  if (c->transport == MRL_TRANSPORT_RCCL && !x->tab_direct) {
+    COMM_HIP(c, hipStreamWaitEvent(stream, x->rccl_done, 0));
+    return MRL_OK;
+  }
+  hipLaunchKernelGGL(k_comm_wait, dim3(1), dim3(64), 0, stream,
+                     static_cast<const unsigned long long *>(c->flags.local) + (size_t)x->channel * kFlagRow, c->nranks,
+                     (unsigned long long)x->epoch, c->d_status, max_ticks(c));
+  COMM_HIP(c, hipGetLastError());
+  return MRL_OK;
+}
+
+}  // namespace mrl
+
+using namespace mrl;
+
+extern "C" {
+
+const char *mrl_comm_last_error(const mrl_comm *c) { return c ? c->err.c_str() : g_comm_create_error.c_str(); }
+
+void mrl_comm_destroy(mrl_comm *c) {
+  if (!c) return;
+  (void)hipDeviceSynchronize();
+  if (c->rccl_comm && c->rccl) c->rccl->CommDestroy(static_cast<ncclComm_t>(c->rccl_comm));
+  delete c->rccl;
+  // (the RCCL library stays loaded: unloading it under a live HIP runtime is not safe)
+  sym_free(c, &c->mbox);
+  sym_free(c, &c->flags);
+  if (c->d_flag_tab) (void)hipFree(c->d_flag_tab);
+  if (c->d_mbox_tab) (void)hipFree(c->d_mbox_tab);
+  if (c->h_status) (void)hipHostFree(c->h_status);
+  if (c->h_mbox) (void)hipHostFree(c->h_mbox);
+  for (auto s : c->side) (void)hipStreamDestroy(s);
+  if (c->ev_prod) (void)hipEventDestroy(c->ev_prod);
+  if (c->shm) munmap(c->shm, sizeof(ShmSeg));
+  delete c;
+}
+
+int mrl_comm_create(mrl_comm **out, const char *name, int32_t nranks, int32_t rank, int32_t device, int32_t transport) {
+  if (!out) return comm_error(nullptr, MRL_ERR_INVALID, "mrl_comm_create: null argument");
+  *out = nullptr;
+  if (nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks)
+    return comm_error(nullptr, MRL_ERR_INVALID, "mrl_comm_create: invalid rank %d of %d (at most %d ranks)", rank, nranks, kMaxRanks);
+  if (transport < MRL_TRANSPORT_AUTO || transport > MRL_TRANSPORT_RCCL)
+    return comm_error(nullptr, MRL_ERR_INVALID, "mrl_comm_create: unknown transport %d", transport);
+  if (nranks > 1 && (!name || !name[0] || std::strlen(name) > 200 || std::strchr(name, '/')))
+    return comm_error(nullptr, MRL_ERR_INVALID, "mrl_comm_create: a job name (no '/') is needed for more than one rank");
+  mrl_comm *c = new (std::nothrow) mrl_comm();
+  if (!c) return comm_error(nullptr, MRL_ERR_NOMEM, "out of host memory");
+  auto fail = [&](int code) {
+    g_comm_create_error = c->err;
+    if (c->shm) c->shm->abort_flag.store(1);
+    mrl_comm_destroy(c);
+    return code;
+  };
+  c->nranks = nranks;
+  c->rank = rank;
+  if (device >= 0) {
+    if (hipSetDevice(device) != hipSuccess) {
+      comm_error(c, MRL_ERR_HIP, "hipSetDevice(%d) failed", device);
+      return fail(MRL_ERR_HIP);
+    }
+    c->device = device;
+  } else if (hipGetDevice(&c->device) != hipSuccess) {
+    comm_error(c, MRL_ERR_HIP, "no HIP device available");
+    return fail(MRL_ERR_HIP);
+  }
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) c->wall_khz = khz;
+  else (void)hipGetLastError();
+
+  if (nranks > 1) {
+    c->shm_name = std::string("/") + name;
+    const int fd = shm_open(c->shm_name.c_str(), O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, sizeof(ShmSeg)) != 0) {
+      if (fd >= 0) close(fd);
+      comm_error(c, MRL_ERR_COMM, "cannot create the bootstrap segment %s", c->shm_name.c_str());
+      return fail(MRL_ERR_COMM);
+    }
+    void *m = mmap(nullptr, sizeof(ShmSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+      comm_error(c, MRL_ERR_COMM, "cannot map the bootstrap segment %s", c->shm_name.c_str());
+      return fail(MRL_ERR_COMM);
+    }
+    c->shm = static_cast<ShmSeg *>(m);
+    const uint32_t a = c->shm->attached.fetch_add(1) + 1;
+    if (a > (uint32_t)nranks) {
+      comm_error(c, MRL_ERR_COMM, "bootstrap segment %s is stale or shared with another job: use a unique name", c->shm_name.c_str());
+      c->shm = nullptr;  // not ours: do not raise its abort flag
+      munmap(m, sizeof(ShmSeg));
+      return fail(MRL_ERR_COMM);
+    }
+    const double t0 = now_s();
+    while (c->shm->attached.load() < (uint32_t)nranks) {
+      usleep(100);
+      if (now_s() - t0 > c->timeout_s || c->shm->abort_flag.load()) {
+        comm_error(c, MRL_ERR_COMM, "only %u of %d ranks reached mrl_comm_create within %.0f s", c->shm->attached.load(), nranks, c->timeout_s);
+        shm_unlink(c->shm_name.c_str());
+        return fail(MRL_ERR_COMM);
+      }
+    }
+    if (comm_barrier(c) != MRL_OK) return fail(MRL_ERR_COMM);
+    if (rank == 0) shm_unlink(c->shm_name.c_str());  // the mappings stay; the name is free again
+  }
+
+  // side streams: one per peer offset (copy engines) / the RCCL stream
+  const int ns = nranks < 8 ? nranks : 8;
+  for (int i = 0; i < ns; ++i) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+      comm_error(c, MRL_ERR_HIP, "hipStreamCreate failed");
+      return fail(MRL_ERR_HIP);
+    }
+    c->side.push_back(s);
+  }
+  if (hipEventCreateWithFlags(&c->ev_prod, hipEventDisableTiming) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void **>(&c->h_status), sizeof(int)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void **>(&c->h_mbox), sizeof(double) * 16) != hipSuccess) {
+    comm_error(c, MRL_ERR_HIP, "allocating the pinned status words failed");
+    return fail(MRL_ERR_HIP);
+  }
+  *c->h_status = 0;
+  void *dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, c->h_status, 0) != hipSuccess) {
+    comm_error(c, MRL_ERR_HIP, "pinned host memory is not device-mappable");
+    return fail(MRL_ERR_HIP);
+  }
+  c->d_status = static_cast<int *>(dp);
+  if (hipHostGetDevicePointer(&dp, c->h_mbox, 0) != hipSuccess) {
+    comm_error(c, MRL_ERR_HIP, "pinned host memory is not device-mappable");
+    return fail(MRL_ERR_HIP);
+  }
+  c->d_h_mbox = static_cast<double *>(dp);
+
+  // flags + mailboxes.  If HIP IPC is unusable every rank agrees to fall back to RCCL (sym_alloc's verdict is collective).
+  c->transport = MRL_TRANSPORT_PEER_STORE;
+  int rc = sym_alloc(c, sizeof(unsigned long long) * kMaxChannels * kFlagRow, &c->flags, true);
+  if (rc == MRL_ERR_COMM && nranks > 1 && (transport == MRL_TRANSPORT_AUTO || transport == MRL_TRANSPORT_RCCL)) {
+    c->ipc_ok = false;
+    c->transport = MRL_TRANSPORT_RCCL;
+    rc = MRL_OK;
+  }
+  if (rc != MRL_OK) return fail(rc);
+  if (c->ipc_ok) {
+    rc = sym_alloc(c, sizeof(double) * 2 * kMaxRanks * 16, &c->mbox, true);
+    if (rc != MRL_OK) return fail(rc);
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_flag_tab), sizeof(void *) * nranks) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->d_mbox_tab), sizeof(void *) * nranks) != hipSuccess ||
+        hipMemcpy(c->d_flag_tab, c->flags.peer.data(), sizeof(void *) * nranks, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_mbox_tab, c->mbox.peer.data(), sizeof(void *) * nranks, hipMemcpyHostToDevice) != hipSuccess) {
+      comm_error(c, MRL_ERR_HIP, "uploading the peer tables failed");
+      return fail(MRL_ERR_HIP);
+    }
+  }
+  c->mbox_channel = c->next_channel++;
+  if (transport != MRL_TRANSPORT_AUTO && c->ipc_ok) {
+    c->transport = transport;
+    if (transport == MRL_TRANSPORT_RCCL && (rc = rccl_init(c)) != MRL_OK) return fail(rc);
+  }
+  *out = c;
+  return MRL_OK;
+}
+
+int mrl_comm_transport(const mrl_comm *c) { return c ? c->transport : MRL_ERR_INVALID; }
+
+int mrl_comm_set_transport(mrl_comm *c, int32_t transport) {
+  if (!c) return MRL_ERR_INVALID;
+  if (transport < MRL_TRANSPORT_AUTO || transport > MRL_TRANSPORT_RCCL) return comm_error(c, MRL_ERR_INVALID, "unknown transport %d", transport);
+  if (transport == MRL_TRANSPORT_AUTO) transport = c->ipc_ok ? MRL_TRANSPORT_PEER_STORE : MRL_TRANSPORT_RCCL;
+  if (!c->ipc_ok && transport != MRL_TRANSPORT_RCCL) return comm_error(c, MRL_ERR_UNSUPPORTED, "HIP IPC is not usable on this node: RCCL only");
+  (void)hipDeviceSynchronize();
+  COMM_TRY(comm_barrier(c));
+  if (transport == MRL_TRANSPORT_RCCL) COMM_TRY(rccl_init(c));
+  c->transport = transport;
+  return MRL_OK;
+}
+
+int mrl_comm_set_timeout(mrl_comm *c, double seconds) {
+  if (!c || !(seconds > 0.0)) return MRL_ERR_INVALID;
+  c->timeout_s = seconds;
+  return MRL_OK;
+}
+
+int mrl_comm_barrier(mrl_comm *c) { return c ? comm_barrier(c) : MRL_ERR_INVALID; }
+
+int mrl_comm_allreduce(mrl_comm *c, double *h_values, int32_t n, int32_t op) {
+  if (!c || (!h_values && n > 0) || op < 0 || op > 2) return MRL_ERR_INVALID;
+  return comm_allreduce_host(c, h_values, n, op);
+}
+
+int mrl_comm_stats(const mrl_comm *c, int64_t *n_exchanges, double *bytes_sent) {
+  if (!c) return MRL_ERR_INVALID;
+  if (n_exchanges) *n_exchanges = c->n_exchanges;
+  if (bytes_sent) *bytes_sent = c->bytes_sent;
+  return MRL_OK;
+}
+
+}  // extern "C"

@@ -23,6 +23,20 @@ int set_error(const mrl_ctx *ctx, int code, const char *fmt, ...) {
   return code;
 }
 
+__global__ void k_fill_tab(char **tab, char *base, size_t stride, int n) {
+  if ((int)threadIdx.x < n) tab[threadIdx.x] = base + (size_t)threadIdx.x * stride;
+}
+
+int local_tab(mrl_ctx *ctx, int slot, void *base, size_t stride_bytes, cplx *const **out) {
+  if (ctx->nranks > 64 || slot < 0 || slot > 7) return set_error(ctx, MRL_ERR_UNSUPPORTED, "pointer tables hold at most 64 ranks");
+  if (!ctx->d_tabs) MRL_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_tabs), sizeof(char *) * 64 * 8));
+  char **t = ctx->d_tabs + 64 * slot;
+  hipLaunchKernelGGL(k_fill_tab, dim3(1), dim3(64), 0, ctx->stream, t, static_cast<char *>(base), stride_bytes, ctx->nranks);
+  MRL_HIP(ctx, hipGetLastError());
+  *out = reinterpret_cast<cplx *const *>(t);
+  return MRL_OK;
+}
+
 int ensure_work(mrl_ctx *ctx, int slot, size_t bytes) {
   if (ctx->work_bytes[slot] >= bytes) return MRL_OK;
   if (ctx->d_work[slot]) {
@@ -183,7 +197,6 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
     return code;
   };
 
-  if (const char *e = getenv("MRL_EXP")) c->exp = atoi(e);
   c->dim = dom->dim;
   c->spectrum = dom->spectrum;
   c->nranks = dom->nranks;
@@ -324,6 +337,8 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
 void mrl_ctx_destroy(mrl_ctx *c) {
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
+  slab_pipes_destroy(c);
+  if (c->d_tabs) hipFree(c->d_tabs);
   for (int a = 0; a < 3; ++a) {
     if (c->ax[a].d_tw) hipFree(c->ax[a].d_tw);
     if (c->d_k[a]) hipFree(c->d_k[a]);
@@ -346,7 +361,30 @@ void mrl_ctx_destroy(mrl_ctx *c) {
 int mrl_sync(mrl_ctx *ctx) {
   if (!ctx) return MRL_ERR_INVALID;
   MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return MRL_OK;
+  return slab_comm_check(ctx);  // a device-side wait that timed out surfaces here
+}
+
+int mrl_ctx_set_option(mrl_ctx *ctx, int option, int64_t value) {
+  if (!ctx) return MRL_ERR_INVALID;
+  switch (option) {
+    case MRL_OPT_EXPERIMENT: ctx->exp = (int)value; return MRL_OK;
+    case MRL_OPT_SLAB_NSUB:
+      if (value < 1 || value > 64) return set_error(ctx, MRL_ERR_INVALID, "MRL_OPT_SLAB_NSUB must be in 1..64");
+      ctx->opt_nsub = (int)value;
+      return MRL_OK;
+    case MRL_OPT_SLAB_CARRY: ctx->opt_carry = value != 0; return MRL_OK;
+    default: return set_error(ctx, MRL_ERR_INVALID, "unknown option %d", option);
+  }
+}
+
+int64_t mrl_ctx_get_option(const mrl_ctx *ctx, int option) {
+  if (!ctx) return 0;
+  switch (option) {
+    case MRL_OPT_EXPERIMENT: return ctx->exp;
+    case MRL_OPT_SLAB_NSUB: return ctx->opt_nsub;
+    case MRL_OPT_SLAB_CARRY: return ctx->opt_carry;
+    default: return 0;
+  }
 }
 
 int mrl_set_stream(mrl_ctx *ctx, void *stream) {

@@ -165,6 +165,9 @@ int fft_inverse_serial(mrl_ctx *ctx, const double *d_in, double *d_out, long lon
   return pass_z_inverse(ctx, cur, d_out, A0, A1, batch, layout, scale);
 }
 
+int slab_fft_forward(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);   // slab_driver.hip
+int slab_fft_inverse(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
+
 }  // namespace mrl
 
 using namespace mrl;
@@ -175,8 +178,10 @@ int mrl_fft_r2c(mrl_ctx *ctx, const double *d_in, double *d_out, int64_t batch, 
   if (!ctx) return MRL_ERR_INVALID;
   if (!d_in || !d_out || batch < 1 || (layout != 0 && layout != 1))
     return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_r2c: bad argument");
-  if (ctx->slab)
-    return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_r2c on a slab context: use the mrl_slab_* stages");
+  if (ctx->slab) {  // DomainAction::fftSlab with the library-owned exchange (communicator attached)
+    if (layout == 1 && batch > 1) return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_fft_r2c on a slab context: field-major batches only");
+    return slab_fft_forward(ctx, d_in, d_out, batch);
+  }
   if (fast_path_ok(ctx) && (layout == 0 || batch == 1)) return fft_forward_fast(ctx, d_in, d_out, batch);
   return fft_forward_serial(ctx, d_in, d_out, batch, layout);
 }
@@ -185,8 +190,10 @@ int mrl_fft_c2r(mrl_ctx *ctx, const double *d_in, double *d_out, int64_t batch, 
   if (!ctx) return MRL_ERR_INVALID;
   if (!d_in || !d_out || batch < 1 || (layout != 0 && layout != 1))
     return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_c2r: bad argument");
-  if (ctx->slab)
-    return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_c2r on a slab context: use the mrl_slab_* stages");
+  if (ctx->slab) {  // DomainAction::ifftSlab
+    if (layout == 1 && batch > 1) return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_fft_c2r on a slab context: field-major batches only");
+    return slab_fft_inverse(ctx, d_in, d_out, batch);
+  }
   if (fast_path_ok(ctx) && (layout == 0 || batch == 1)) return fft_inverse_fast(ctx, d_in, d_out, batch);
   return fft_inverse_serial(ctx, d_in, d_out, batch, layout);
 }

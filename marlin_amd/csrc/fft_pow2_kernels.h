@@ -5,6 +5,7 @@
 //   k_z_inv      half spectra -> real lines (two lines per complex transform), scaled
 // The fused Cahn-Hilliard x-pass lives in ch_fused.hip.
 #pragma once
+#include "comm_dev.h"
 #include "fft_pow2.h"
 
 namespace mrl {
@@ -387,14 +388,21 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass(PassArgs a, const cplx 
 // separate row pitches for input and output, and the axis index n may be chunked by destination / source
 // rank:  element(n, row, col) = base + (n >> sh)*cs + (n & ((1<<sh)-1))*sn + row*pitch + col.
 // (sh = 31: plain stride.)  Offsets are 32-bit element counts (fast-path arrays are < 2^31 elements).
+// Forward passes (INV = false) write the exchange layout: chunk c = n >> sh_out belongs to destination rank c and
+// starts at otab[c] -- an address in rank c's receive buffer (peer stores over xGMI, transport PEER_STORE) or in the local
+// send buffer; field f of a chunk lies fs_out elements further.  After its last store every workgroup counts itself and the
+// last one raises the arrival flags (comm_dev.h) when `sig` asks for it.
 struct SubPassArgs {
   const cplx *in[2];
-  cplx *out[2];
+  cplx *out[2];              // INV only (dense output)
+  cplx *const *otab;         // !INV: destination of chunk c (device table, one entry per rank)
   int rows, cols;
   unsigned pitch_in, pitch_out;
   unsigned sn_in, sn_out;
   int sh_in, sh_out;
-  unsigned cs_in, cs_out;
+  unsigned cs_in;
+  unsigned fs_out, fo_out;   // !INV: element offset of field f within a chunk = fo_out + f * fs_out
+  SignalArgs sig;
 };
 
 template <int N, bool INV, int NF>
@@ -436,11 +444,16 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub(SubPassArgs a, cons
 #pragma unroll
       for (int m = 0; m < P; ++m) {
         const unsigned n = q + m * TPL;
-        a.out[f][bo + (a.sh_out < 31 ? (n >> a.sh_out) * a.cs_out : 0u) + (n & mo) * a.sn_out] =
-            INV ? cswap(v[f][m]) : v[f][m];
+        if (INV) {
+          a.out[f][bo + (n & mo) * a.sn_out] = cswap(v[f][m]);
+        } else {
+          cplx *base = a.otab[n >> a.sh_out];
+          base[a.fo_out + (unsigned)f * a.fs_out + bo + (n & mo) * a.sn_out] = v[f][m];
+        }
       }
     }
   }
+  if (!INV) signal_tail(a.sig);
 }
 
 template <int N>

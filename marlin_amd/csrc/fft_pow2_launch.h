@@ -102,7 +102,7 @@ inline int launch_pass_t(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
 }
 
 template <int N, bool INV, int NF>
-inline int launch_pass_sub(mrl_ctx *ctx, const SubPassArgs &a, const cplx *tw) {
+inline int launch_pass_sub(mrl_ctx *ctx, SubPassArgs a, const cplx *tw) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>();
   if (!attr) {
@@ -111,6 +111,7 @@ inline int launch_pass_sub(mrl_ctx *ctx, const SubPassArgs &a, const cplx *tw) {
   }
   constexpr int T = Plan<N>::T;
   const long long nb = ((long long)a.rows * a.cols + T - 1) / T;
+  if (a.sig.expected == 0) a.sig.expected = (unsigned)nb;  // (a caller that spreads one exchange over several launches sets the total)
   hipLaunchKernelGGL((k_pass_sub<N, INV, NF>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
@@ -146,6 +147,13 @@ inline int launch_pass_sub(mrl_ctx *ctx, const SubPassArgs &a, const cplx *tw) {
     case 768: { constexpr int NN = 768; CALL; } break; \
     default: return MRL_ERR_UNSUPPORTED;               \
   }
+
+// workgroups of one k_pass_sub launch over rows x cols lines
+template <int N>
+inline unsigned pass_sub_blocks(long long rows, long long cols) {
+  constexpr int T = p2::Plan<N>::T;
+  return (unsigned)((rows * cols + T - 1) / T);
+}
 
 inline bool pow2_ok(long long n) {
   switch (n) {

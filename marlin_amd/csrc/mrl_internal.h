@@ -10,9 +10,12 @@
 
 #include "marlin_hip.h"
 
+struct mrl_comm;
+
 namespace mrl {
 
 typedef double2 cplx;  // interleaved (re, im) complex128
+struct SlabPipes;
 
 constexpr int kMaxRadixPasses = 24;
 constexpr int kWorkSlots = 16;
@@ -97,7 +100,14 @@ struct mrl_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   std::vector<int> prof_slots;
 
-  int exp = 0;  // experiment switches (env MRL_EXP, bit mask): A/B testing of kernel variants inside one process
+  int exp = 0;  // experiment switches (MRL_OPT_EXPERIMENT, bit mask): A/B testing of kernel variants inside one process
+  int opt_nsub = 1;    // MRL_OPT_SLAB_NSUB
+  int opt_carry = 0;   // MRL_OPT_SLAB_CARRY
+
+  // multi-GPU (slab contexts): the attached communicator (not owned) and the exchange pipelines built on it (slab_driver.hip)
+  mrl_comm *comm = nullptr;
+  struct mrl::SlabPipes *pipes = nullptr;
+  char **d_tabs = nullptr;  // 8 device pointer tables of 64 entries for the staged entry points (caller-owned send buffers)
 
   mutable std::string err;
 };
@@ -155,6 +165,11 @@ __device__ __forceinline__ void st_nt(double2 *p, double2 v) {
 
 // scratch management
 int ensure_work(mrl_ctx *ctx, int slot, size_t bytes);
+// device pointer table `slot` (0..7) filled on the context's stream with base + p * stride_bytes, p = 0..nranks-1: the
+// destination table of a scatter-capable kernel when the chunks go to one contiguous local buffer
+int local_tab(mrl_ctx *ctx, int slot, void *base, size_t stride_bytes, cplx *const **out);
+void slab_pipes_destroy(mrl_ctx *ctx);
+int slab_comm_check(mrl_ctx *ctx);  // MRL_ERR_COMM if a device-side wait of the attached communicator timed out
 
 // generic pass launcher (fft_generic.hip)
 int launch_pass(mrl_ctx *ctx, const PassDesc &d, const double *in, double *out, const cplx *d_tw, long long nbatch);

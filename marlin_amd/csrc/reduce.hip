@@ -6,9 +6,19 @@
 // ctx->d_red, a single workgroup folds the partials into a device scalar slot (ctx->d_red + kScalarBase).
 // Scalars stay on the device for kernels that consume them (CG step sizes); the synchronous C ABI
 // entry points copy them to pinned host memory.
+#include "comm.h"
 #include "mrl_internal.h"
 
 namespace mrl {
+
+// slab contexts with a communicator: the value over all ranks (the reference's norms / sums are serial-only,
+// DomainAction.C:1564-1567).  op 0 sum, 1 min, 2 max.
+static int global_values(mrl_ctx *ctx, double *h, int n, int op) {
+  if (!ctx->comm || ctx->comm->nranks == 1) return MRL_OK;
+  const int rc = comm_allreduce_host(ctx->comm, h, n, op);
+  if (rc != MRL_OK) set_error(ctx, rc, "%s", ctx->comm->err.c_str());
+  return rc;
+}
 
 // OP 0: sum a ; 1: sum a*b ; 2: sum a*a
 template <int OP>
@@ -197,11 +207,12 @@ static int sync_reduce(mrl_ctx *ctx, int op, const double *a, const double *b, i
   if (!a || (op == 1 && !b) || n < 0 || !h_out) return set_error(ctx, MRL_ERR_INVALID, "%s: bad argument", what);
   if (n == 0) {
     *h_out = 0.0;
-    return MRL_OK;
+    return global_values(ctx, h_out, 1, 0);
   }
   double *slot = ctx->d_red + kScalarBase;
   MRL_TRY(reduce_async(ctx, op, a, op == 1 ? b : a, n, slot));
-  return read_scalars(ctx, slot, 1, h_out);
+  MRL_TRY(read_scalars(ctx, slot, 1, h_out));
+  return global_values(ctx, h_out, 1, 0);
 }
 
 extern "C" {
@@ -234,7 +245,8 @@ int mrl_minmax(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_min, double
   MRL_TRY(read_scalars(ctx, slot, 2, h));
   *h_min = h[0];
   *h_max = h[1];
-  return MRL_OK;
+  MRL_TRY(global_values(ctx, h_min, 1, 1));
+  return global_values(ctx, h_max, 1, 2);
 }
 
 int mrl_average(mrl_ctx *ctx, const double *d_a, int64_t ncomp, double *h_out) {
@@ -248,7 +260,7 @@ int mrl_average(mrl_ctx *ctx, const double *d_a, int64_t ncomp, double *h_out) {
   MRL_TRY(component_sums_async(ctx, d_a, npts, (int)ncomp, slot));
   MRL_TRY(read_scalars(ctx, slot, (int)ncomp, h_out));
   for (int c = 0; c < ncomp; ++c) h_out[c] /= nglob;
-  return MRL_OK;
+  return global_values(ctx, h_out, (int)ncomp, 0);  // with a communicator: the global average
 }
 
 }  // extern "C"

@@ -12,7 +12,8 @@
 // Deviation from the reference, results identical: with MRL_SPECTRUM_HALF the z axis stays r2c in slab
 // mode (the reference switches to a full c2c transform, DomainAction.C:279-281), which halves the
 // exchanged volume.  MRL_SPECTRUM_FULL reproduces the reference's layout exactly.
-#include "mrl_internal.h"
+#include "comm_dev.h"
+#include "slab_stages.h"
 
 namespace mrl {
 
@@ -130,15 +131,6 @@ int slab_inv_finish(mrl_ctx *ctx, const double *recv, double *real_out) {
 }
 
 // ---- Cahn-Hilliard substep pipelined over kz sub-blocks -------------------------------------------------
-// fast path (slab_fused.hip)
-int slab_fast_ok(const mrl_ctx *ctx);
-int slab_ch_z_fwd_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *mu, int carry);
-int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, double *send, int carry);
-int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const double *recv, double *send, double *Nhat_new,
-                        const double *const *Nhat_old, int order, double sub_dt, double *cbar, int carry);
-int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv);
-int slab_ch_z_inv_fast(mrl_ctx *ctx, double *real_out);
-int slab_ch_z_inv_fwd_fast(mrl_ctx *ctx, const ChP &cp, double *mu, int carry);
 // generic passes on a sub-range (fft_plan.hip), k-space update on a kz sub-range (ch.hip)
 int pass_lines(mrl_ctx *ctx, int axis, int sign, const double *in, double *out, long long outer, long long inner,
                long long so, long long si, long long sn);
@@ -146,7 +138,7 @@ int ch_kspace_sub_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const 
                          const double *const *Nold, int order, double sub_dt, long long k0, long long ksub);
 
 // kz sub-block s of nsub: DomainAction's partition helper with equal weights
-static int sub_range(mrl_ctx *ctx, int sub, int nsub, long long *k0, long long *ksub) {
+int slab_sub_range(mrl_ctx *ctx, int sub, int nsub, long long *k0, long long *ksub) {
   const long long nzc = ctx->nrec[2];
   if (nsub < 1 || nsub > nzc || sub < 0 || sub >= nsub)
     return set_error(ctx, MRL_ERR_INVALID, "kz sub-block %d of %d out of range (nzc = %lld)", sub, nsub, nzc);
@@ -202,7 +194,7 @@ static int gen_work(mrl_ctx *ctx) {
   return MRL_OK;
 }
 
-static int gen_z_fwd(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *d_mu, int carry) {
+int gen_z_fwd(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *d_mu, int carry) {
   const long long nx = ctx->n[0], nyl = ctx->nloc[1];
   const long long nreal = real_count_local(ctx);
   MRL_TRY(gen_work(ctx));
@@ -217,7 +209,7 @@ static int gen_z_fwd(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *d_
   return pass_z_forward(ctx, mu, ctx->d_work[14], nx, nyl, 1, 0);
 }
 
-static int gen_x_fwd(mrl_ctx *ctx, long long k0, long long ksub, double *send, int carry) {
+int gen_x_fwd(mrl_ctx *ctx, long long k0, long long ksub, double *send, int carry) {
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2];
   long long off = 0, xb = 0;
   const int f0 = carry == MRL_CARRY_IN ? 1 : 0, nf = 2 - f0;  // carry-over: mu-hat only
@@ -238,7 +230,7 @@ static int gen_x_fwd(mrl_ctx *ctx, long long k0, long long ksub, double *send, i
   return MRL_OK;
 }
 
-static int gen_kspace(mrl_ctx *ctx, const ChP &cp, long long k0, long long ksub, const double *recv, double *send,
+int gen_kspace(mrl_ctx *ctx, const ChP &cp, long long k0, long long ksub, const double *recv, double *send,
                       double *Nhat_new, const double *const *Nhat_old, int order, double sub_dt, double *d_cbar, int carry) {
   const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2];
   MRL_TRY(gen_work(ctx));
@@ -286,7 +278,7 @@ static int gen_kspace(mrl_ctx *ctx, const ChP &cp, long long k0, long long ksub,
   return MRL_OK;
 }
 
-static int gen_x_inv(mrl_ctx *ctx, long long k0, long long ksub, const double *recv) {
+int gen_x_inv(mrl_ctx *ctx, long long k0, long long ksub, const double *recv) {
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2];
   MRL_TRY(gen_work(ctx));
   double *w = ctx->d_work[13];  // the forward work array of field c is free again
@@ -304,7 +296,7 @@ static int gen_x_inv(mrl_ctx *ctx, long long k0, long long ksub, const double *r
   return pass_lines(ctx, 0, +1, w + 2 * k0, w + 2 * k0, nyl, ksub, nzc, 1, nyl * nzc);
 }
 
-static int gen_z_inv(mrl_ctx *ctx, double *real_out) {
+int gen_z_inv(mrl_ctx *ctx, double *real_out) {
   const long long nx = ctx->n[0], nyl = ctx->nloc[1];
   const double scale = 1.0 / ((double)ctx->n[0] * (double)ctx->n[1] * (double)ctx->n[2]);
   ProfScope ps(ctx, "slab_z_inv", 8.0 * nx * nyl * ctx->n[2] + 16.0 * nx * nyl * ctx->nrec[2]);
@@ -370,7 +362,7 @@ int mrl_slab_ch_counts(const mrl_ctx *ctx, int sub, int nsub, int forward, int c
   if (!ctx) return MRL_ERR_INVALID;
   if (!ctx->slab) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_counts: not a slab context");
   long long k0, ksub;
-  MRL_TRY(sub_range(const_cast<mrl_ctx *>(ctx), sub, nsub, &k0, &ksub));
+  MRL_TRY(slab_sub_range(const_cast<mrl_ctx *>(ctx), sub, nsub, &k0, &ksub));
   const long long nf = (forward && carry != MRL_CARRY_IN) ? 2 : 1;  // the forward messages carry both fields (mu-hat only with the carry-over)
   for (int p = 0; p < ctx->nranks; ++p) {
     const long long x_p_y_me = ctx->part_recip[p] * ctx->nloc[1] * ksub, x_me_y_p = ctx->nrec[0] * ctx->part_real[p] * ksub;
@@ -402,9 +394,15 @@ int mrl_slab_ch_x_fwd(mrl_ctx *ctx, int sub, int nsub, double *d_send, int carry
   MRL_TRY(check_slab(ctx, "mrl_slab_ch_x_fwd"));
   if (!d_send) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_x_fwd: null buffer");
   long long k0, ksub;
-  MRL_TRY(sub_range(ctx, sub, nsub, &k0, &ksub));
+  MRL_TRY(slab_sub_range(ctx, sub, nsub, &k0, &ksub));
   MRL_TRY(check_carry(ctx, "mrl_slab_ch_x_fwd", carry));
-  if (slab_fast_ok(ctx)) return slab_ch_x_fwd_fast(ctx, (int)k0, (int)ksub, d_send, carry);
+  if (slab_fast_ok(ctx)) {
+    // the pass scatters through a destination table: here every chunk goes to the caller's contiguous send buffer
+    const size_t nf = carry == MRL_CARRY_IN ? 1 : 2;
+    cplx *const *tab;
+    MRL_TRY(local_tab(ctx, 0, d_send, sizeof(cplx) * nf * (size_t)(ctx->nrec[0] * ctx->nloc[1] * ksub), &tab));
+    return slab_ch_x_fwd_fast(ctx, (int)k0, (int)ksub, tab, SignalArgs{}, carry);
+  }
   return gen_x_fwd(ctx, k0, ksub, d_send, carry);
 }
 
@@ -428,9 +426,12 @@ int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, int sub, int nsub, 
   for (int i = 0; i < order; ++i)
     if (!d_Nhat_old || !d_Nhat_old[i]) return set_error(ctx, MRL_ERR_INVALID, "history entry %d missing", i);
   long long k0, ksub;
-  MRL_TRY(sub_range(ctx, sub, nsub, &k0, &ksub));
-  if (slab_fast_ok(ctx))
-    return slab_ch_kspace_fast(ctx, cp, (int)k0, (int)ksub, d_recv, d_send, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, carry);
+  MRL_TRY(slab_sub_range(ctx, sub, nsub, &k0, &ksub));
+  if (slab_fast_ok(ctx)) {
+    cplx *const *tab;
+    MRL_TRY(local_tab(ctx, 1, d_send, sizeof(cplx) * (size_t)(ctx->nrec[0] * (ctx->n[1] / ctx->nranks) * ksub), &tab));
+    return slab_ch_kspace_fast(ctx, cp, (int)k0, (int)ksub, d_recv, tab, SignalArgs{}, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, carry);
+  }
   return gen_kspace(ctx, cp, k0, ksub, d_recv, d_send, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, carry);
 }
 
@@ -439,7 +440,7 @@ int mrl_slab_ch_x_inv(mrl_ctx *ctx, int sub, int nsub, const double *d_recv) {
   MRL_TRY(check_slab(ctx, "mrl_slab_ch_x_inv"));
   if (!d_recv) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_ch_x_inv: null buffer");
   long long k0, ksub;
-  MRL_TRY(sub_range(ctx, sub, nsub, &k0, &ksub));
+  MRL_TRY(slab_sub_range(ctx, sub, nsub, &k0, &ksub));
   if (slab_fast_ok(ctx)) return slab_ch_x_inv_fast(ctx, (int)k0, (int)ksub, d_recv);
   return gen_x_inv(ctx, k0, ksub, d_recv);
 }

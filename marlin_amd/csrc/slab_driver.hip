@@ -1,0 +1,369 @@
+// Library-owned multi-GPU drivers on slab contexts with an attached communicator (comm.hip): the solver-level entry points
+// (mrl_ch_substeps, mrl_fft_r2c / mrl_fft_c2r, mrl_mech_newton_cg, the reductions) then behave as on a serial context and the
+// library performs the global transposes itself -- what DomainAction::fftSlab / ifftSlab do from C++ inside the reference
+// (src/actions/DomainAction.C:869-1019), here without host staging:
+//
+//   Cahn-Hilliard substep (AdamsBashforthMoulton.C:60-101 over fftSlab / ifftSlab), per kz sub-block s:
+//     Z / EZ  z pass(es)                                             local
+//     A_s     forward x pass, scattered into the peers' receive buffers (PEER_STORE) or a send buffer   -> exchange F_s
+//     B_s     y pass + k-space update + inverse y pass, scattered likewise                               -> exchange I_s
+//     C_s     inverse x pass                                          local
+//     E       inverse z pass
+//   One HIP stream carries all kernels of a rank.  With PEER_STORE the x and y pass kernels ARE the exchange: their stores go
+//   over xGMI while they compute, and their last workgroup raises the arrival flags.  Write-after-read safety of the receive
+//   buffers needs no extra handshake: a rank overwrites F_s of a peer only after it has consumed that peer's I_s of the
+//   previous substep, which the peer sent after it had finished reading F_s (and symmetrically for I_s).
+//
+//   Plain transforms (DomainAction::fft / ifft in FFT_SLAB mode) have no such request / response structure, so their
+//   exchanges use an explicit acknowledgement flag per receive buffer.
+#include "comm.h"
+#include "slab_stages.h"
+
+namespace mrl {
+
+int ch_check_params(mrl_ctx *ctx, const mrl_ch_params *p, ChP &cp);
+int reduce_async(mrl_ctx *ctx, int op, const double *a, const double *b, long long n, double *d_scalar);
+
+struct ChPipe {
+  bool built = false;
+  int nsub = 0, transport = -1;
+  bool carry = false, fast = false;
+  std::vector<Xchg> fwd2, fwd1, inv;  // two-field forward, one-field forward (carry-over), inverse; one per sub-block
+  double *cbar = nullptr;             // carried spectrum [x_me][ny][pitch]
+};
+
+struct FftPipe {
+  bool built = false;
+  int transport = -1;
+  Xchg fwd, inv;
+  int ack_fwd = -1, ack_inv = -1;  // acknowledgement channels
+  unsigned long long ack_fwd_epoch = 0, ack_inv_epoch = 0;
+};
+
+struct MechPipe {
+  bool built = false;
+  int transport = -1;
+  Xchg fwd[3], inv[3];  // one pair per tensor row
+};
+
+struct SlabPipes {
+  ChPipe ch;
+  FftPipe fft;
+  MechPipe mech;
+};
+
+static int comm_fail(mrl_ctx *ctx, int rc) {
+  if (rc != MRL_OK && ctx->comm) set_error(ctx, rc, "%s", ctx->comm->err.c_str());
+  return rc;
+}
+#define MRL_COMM(ctx, expr)                         \
+  do {                                              \
+    int rc__ = (expr);                              \
+    if (rc__ != MRL_OK) return comm_fail(ctx, rc__); \
+  } while (0)
+
+int slab_comm_check(mrl_ctx *ctx) {
+  if (!ctx->comm) return MRL_OK;
+  return comm_fail(ctx, comm_check(ctx->comm));
+}
+
+static void ch_pipe_destroy(mrl_ctx *ctx, ChPipe &P) {
+  if (!ctx->comm) return;
+  for (auto &x : P.fwd2) xchg_destroy(ctx->comm, &x);
+  for (auto &x : P.fwd1) xchg_destroy(ctx->comm, &x);
+  for (auto &x : P.inv) xchg_destroy(ctx->comm, &x);
+  P.fwd2.clear();
+  P.fwd1.clear();
+  P.inv.clear();
+  if (P.cbar) (void)hipFree(P.cbar);
+  P.cbar = nullptr;
+  P.built = false;
+}
+
+void slab_pipes_destroy(mrl_ctx *ctx) {
+  if (!ctx->pipes) return;
+  ch_pipe_destroy(ctx, ctx->pipes->ch);
+  if (ctx->comm) {
+    xchg_destroy(ctx->comm, &ctx->pipes->fft.fwd);
+    xchg_destroy(ctx->comm, &ctx->pipes->fft.inv);
+    for (int r = 0; r < 3; ++r) {
+      xchg_destroy(ctx->comm, &ctx->pipes->mech.fwd[r]);
+      xchg_destroy(ctx->comm, &ctx->pipes->mech.inv[r]);
+    }
+  }
+  delete ctx->pipes;
+  ctx->pipes = nullptr;
+}
+
+static int need_comm(mrl_ctx *ctx, const char *what) {
+  if (!ctx->slab) return set_error(ctx, MRL_ERR_INVALID, "%s: not a slab context", what);
+  if (!ctx->comm)
+    return set_error(ctx, MRL_ERR_INVALID, "%s on a slab context needs a communicator (mrl_ctx_attach_comm), or use the staged mrl_slab_* entry points", what);
+  if (!ctx->pipes) ctx->pipes = new SlabPipes();
+  return MRL_OK;
+}
+
+// an exchange whose producer scatters through the table: direct peer stores when the transport allows, a send buffer otherwise
+static int prepare_table(mrl_ctx *ctx, Xchg *x, bool scatter_capable) {
+  mrl_comm *c = ctx->comm;
+  const bool direct = scatter_capable && xchg_direct(c) && (c->ipc_ok || c->nranks == 1);
+  if (!direct && !x->send && x->send_bytes) {
+    void *s = nullptr;
+    if (hipMalloc(&s, x->send_bytes) != hipSuccess) return set_error(ctx, MRL_ERR_NOMEM, "hipMalloc of a %zu byte send buffer failed", x->send_bytes);
+    x->send = static_cast<double *>(s);
+  }
+  MRL_COMM(ctx, xchg_build_table(c, x, direct));
+  return MRL_OK;
+}
+
+// ---- Cahn-Hilliard pipeline ---------------------------------------------------------------------------------------------
+static int ch_pipe_build(mrl_ctx *ctx) {
+  ChPipe &P = ctx->pipes->ch;
+  mrl_comm *c = ctx->comm;
+  const long long nzc = ctx->dim == 3 ? ctx->nrec[2] : 1;
+  int nsub = ctx->opt_nsub < 1 ? 1 : ctx->opt_nsub;
+  if (nsub > nzc) nsub = (int)nzc;
+  const bool carry = ctx->opt_carry != 0;
+  if (P.built && P.nsub == nsub && P.carry == carry && P.transport == c->transport) return MRL_OK;
+  if (P.built && (P.nsub != nsub || P.carry != carry)) {
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ch_pipe_destroy(ctx, P);
+  }
+  const int R = ctx->nranks;
+  P.fast = slab_fast_ok(ctx) != 0;
+  if (!P.built) {
+    P.fwd2.resize(nsub);
+    P.inv.resize(nsub);
+    if (carry) P.fwd1.resize(nsub);
+    std::vector<int64_t> sc(R), rc(R);
+    std::vector<size_t> sb(R), rb(R);
+    auto make = [&](Xchg *x, int s, int forward, int mode) -> int {
+      MRL_TRY(mrl_slab_ch_counts(ctx, s, nsub, forward, mode, sc.data(), rc.data()));
+      for (int p = 0; p < R; ++p) {
+        sb[p] = sizeof(cplx) * (size_t)sc[p];
+        rb[p] = sizeof(cplx) * (size_t)rc[p];
+      }
+      MRL_COMM(ctx, xchg_create(c, x, sb.data(), rb.data(), false));
+      return MRL_OK;
+    };
+    for (int s = 0; s < nsub; ++s) {
+      MRL_TRY(make(&P.fwd2[s], s, 1, MRL_CARRY_NONE));
+      MRL_TRY(make(&P.inv[s], s, 0, MRL_CARRY_NONE));
+      if (carry) MRL_TRY(make(&P.fwd1[s], s, 1, MRL_CARRY_IN));
+    }
+    if (carry) {
+      const size_t bytes = sizeof(cplx) * (size_t)(ctx->nrec[0] * ctx->nrec[1] * (ctx->dim == 3 ? mrl_slab_ch_spec_pitch(ctx) : 1));
+      MRL_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&P.cbar), bytes));
+    }
+  } else {
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MRL_COMM(ctx, comm_barrier(c));
+  }
+  for (int s = 0; s < nsub; ++s) {
+    MRL_TRY(prepare_table(ctx, &P.fwd2[s], P.fast));
+    MRL_TRY(prepare_table(ctx, &P.inv[s], P.fast));
+    if (carry) MRL_TRY(prepare_table(ctx, &P.fwd1[s], P.fast));
+  }
+  P.nsub = nsub;
+  P.carry = carry;
+  P.transport = c->transport;
+  P.built = true;
+  return MRL_OK;
+}
+
+// the substep loop of TensorSolver::computeBuffer (TensorSolver.C:93-109) over slab transforms; ring semantics as mrl_ch_substeps
+int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, double *c_out, double *const *ring, int ring_size,
+                     int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu) {
+  MRL_TRY(need_comm(ctx, "mrl_ch_substeps"));
+  ChP cp;
+  MRL_TRY(ch_check_params(ctx, p, cp));
+  MRL_TRY(ch_pipe_build(ctx));
+  ChPipe &P = ctx->pipes->ch;
+  mrl_comm *c = ctx->comm;
+  hipStream_t st = ctx->stream;
+  const int nsub = P.nsub;
+  for (int k = 0; k < count; ++k) {
+    const int mode = !P.carry ? MRL_CARRY_NONE : (k == 0 ? MRL_CARRY_OUT : MRL_CARRY_IN);
+    double *mu_k = (k == count - 1) ? mu : nullptr;
+    if (k == 0) {
+      MRL_TRY(mrl_slab_ch_z_fwd(ctx, p, c_in, mu_k, mode));
+    } else {
+      MRL_TRY(mrl_slab_ch_z_inv_fwd(ctx, p, mu_k, mode));
+    }
+    const int order = *n_old < pred ? *n_old : pred;
+    const int slot_new = (*head + 1) % ring_size;
+    const double *old[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < order; ++i) old[i] = ring[((*head - i) % ring_size + ring_size) % ring_size];
+    std::vector<Xchg> &F = mode == MRL_CARRY_IN ? P.fwd1 : P.fwd2;
+    for (int s = 0; s < nsub; ++s) {
+      long long k0, ks;
+      MRL_TRY(slab_sub_range(ctx, s, nsub, &k0, &ks));
+      MRL_COMM(ctx, xchg_begin(c, &F[s], st));
+      if (P.fast) {
+        const SignalArgs sig = xchg_signal_args(c, &F[s], 0);
+        MRL_TRY(slab_ch_x_fwd_fast(ctx, (int)k0, (int)ks, reinterpret_cast<cplx *const *>(F[s].d_tab), sig, mode));
+        MRL_COMM(ctx, xchg_post(c, &F[s], st, sig.counter != nullptr));
+      } else {
+        MRL_TRY(gen_x_fwd(ctx, k0, ks, F[s].send, mode));
+        MRL_COMM(ctx, xchg_post(c, &F[s], st));
+      }
+    }
+    for (int s = 0; s < nsub; ++s) {
+      long long k0, ks;
+      MRL_TRY(slab_sub_range(ctx, s, nsub, &k0, &ks));
+      MRL_COMM(ctx, xchg_wait(c, &F[s], st));
+      MRL_COMM(ctx, xchg_begin(c, &P.inv[s], st));
+      const double *recv = static_cast<const double *>(F[s].recv.local);
+      if (P.fast) {
+        const SignalArgs sig = xchg_signal_args(c, &P.inv[s], 0);
+        MRL_TRY(slab_ch_kspace_fast(ctx, cp, (int)k0, (int)ks, recv, reinterpret_cast<cplx *const *>(P.inv[s].d_tab), sig, ring[slot_new], old,
+                                    order, sub_dt, P.cbar, mode));
+        MRL_COMM(ctx, xchg_post(c, &P.inv[s], st, sig.counter != nullptr));
+      } else {
+        MRL_TRY(gen_kspace(ctx, cp, k0, ks, recv, P.inv[s].send, ring[slot_new], old, order, sub_dt, P.cbar, mode));
+        MRL_COMM(ctx, xchg_post(c, &P.inv[s], st));
+      }
+    }
+    for (int s = 0; s < nsub; ++s) {
+      MRL_COMM(ctx, xchg_wait(c, &P.inv[s], st));
+      MRL_TRY(mrl_slab_ch_x_inv(ctx, s, nsub, static_cast<const double *>(P.inv[s].recv.local)));
+    }
+    if (advance && k < count - 1) {  // TensorSolver.C:105-106
+      *head = slot_new;
+      if (*n_old < pred) *n_old += 1;
+    }
+  }
+  return mrl_slab_ch_z_inv(ctx, c_out);
+}
+
+// ---- plain slab transforms: DomainAction::fft / ifft with parallel_mode = FFT_SLAB ------------------------------------------
+__global__ void k_ack_signal(unsigned long long *const *tab, int nranks, int me, int row, unsigned long long epoch) {
+  const int p = threadIdx.x;
+  if (p < nranks) __hip_atomic_store(tab[p] + row + me, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_ack_wait(const unsigned long long *row, int nranks, unsigned long long epoch, int *status, long long max_ticks) {
+  const int p = threadIdx.x;
+  if (p >= nranks) return;
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(row + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+    if (wall_clock64() - t0 > max_ticks) {
+      atomicMax(status, 1 + p);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+static int fft_pipe_build(mrl_ctx *ctx) {
+  FftPipe &P = ctx->pipes->fft;
+  mrl_comm *c = ctx->comm;
+  const int R = ctx->nranks;
+  if (!P.built) {
+    std::vector<int64_t> sc(R), rc(R);
+    std::vector<size_t> sb(R), rb(R);
+    for (int dir = 1; dir >= 0; --dir) {
+      MRL_TRY(mrl_slab_counts(ctx, dir, sc.data(), rc.data(), nullptr, nullptr));
+      for (int p = 0; p < R; ++p) {
+        sb[p] = sizeof(cplx) * (size_t)sc[p];
+        rb[p] = sizeof(cplx) * (size_t)rc[p];
+      }
+      MRL_COMM(ctx, xchg_create(c, dir ? &P.fwd : &P.inv, sb.data(), rb.data(), true));
+    }
+    if (c->next_channel + 2 > kMaxChannels) return set_error(ctx, MRL_ERR_UNSUPPORTED, "out of exchange channels");
+    P.ack_fwd = c->next_channel++;
+    P.ack_inv = c->next_channel++;
+    P.built = true;
+  }
+  if (P.transport != c->transport) {
+    MRL_TRY(prepare_table(ctx, &P.fwd, false));
+    MRL_TRY(prepare_table(ctx, &P.inv, false));
+    P.transport = c->transport;
+  }
+  return MRL_OK;
+}
+
+// my receive buffer of `x` may be overwritten again: tell every peer (stream-ordered behind the consumer)
+static int ack_release(mrl_ctx *ctx, int ack_channel, unsigned long long *epoch) {
+  mrl_comm *c = ctx->comm;
+  *epoch += 1;
+  if (!c->ipc_ok && c->nranks > 1) return MRL_OK;  // RCCL only: its own rendezvous orders the buffers
+  hipLaunchKernelGGL(k_ack_signal, dim3(1), dim3(64), 0, ctx->stream, c->d_flag_tab, c->nranks, c->rank, ack_channel * kFlagRow, *epoch);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+// before pushing into the peers' buffers: all of them have released the previous contents
+static int ack_acquire(mrl_ctx *ctx, int ack_channel, unsigned long long epoch) {
+  mrl_comm *c = ctx->comm;
+  if (epoch == 0 || (!c->ipc_ok && c->nranks > 1) || c->transport == MRL_TRANSPORT_RCCL) return MRL_OK;
+  hipLaunchKernelGGL(k_ack_wait, dim3(1), dim3(64), 0, ctx->stream,
+                     static_cast<const unsigned long long *>(c->flags.local) + (size_t)ack_channel * kFlagRow, c->nranks, epoch,
+                     c->d_status, (long long)(c->timeout_s * (double)c->wall_khz * 1000.0));
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+int slab_fft_forward(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch) {
+  MRL_TRY(need_comm(ctx, "mrl_fft_r2c"));
+  MRL_TRY(fft_pipe_build(ctx));
+  FftPipe &P = ctx->pipes->fft;
+  mrl_comm *c = ctx->comm;
+  const long long nreal = real_count_local(ctx), nspec = spec_count_local(ctx);
+  for (long long b = 0; b < batch; ++b) {
+    MRL_COMM(ctx, xchg_begin(c, &P.fwd, ctx->stream));
+    MRL_TRY(slab_fwd_local(ctx, d_in + b * nreal, P.fwd.send));
+    MRL_TRY(ack_acquire(ctx, P.ack_fwd, P.ack_fwd_epoch));
+    MRL_COMM(ctx, xchg_post(c, &P.fwd, ctx->stream));
+    MRL_COMM(ctx, xchg_wait(c, &P.fwd, ctx->stream));
+    MRL_TRY(slab_fwd_finish(ctx, static_cast<const double *>(P.fwd.recv.local), d_out + 2 * b * nspec));
+    MRL_TRY(ack_release(ctx, P.ack_fwd, &P.ack_fwd_epoch));
+  }
+  return MRL_OK;
+}
+
+int slab_fft_inverse(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch) {
+  MRL_TRY(need_comm(ctx, "mrl_fft_c2r"));
+  MRL_TRY(fft_pipe_build(ctx));
+  FftPipe &P = ctx->pipes->fft;
+  mrl_comm *c = ctx->comm;
+  const long long nreal = real_count_local(ctx), nspec = spec_count_local(ctx);
+  for (long long b = 0; b < batch; ++b) {
+    MRL_COMM(ctx, xchg_begin(c, &P.inv, ctx->stream));
+    MRL_TRY(slab_inv_local(ctx, d_in + 2 * b * nspec, P.inv.send));
+    MRL_TRY(ack_acquire(ctx, P.ack_inv, P.ack_inv_epoch));
+    MRL_COMM(ctx, xchg_post(c, &P.inv, ctx->stream));
+    MRL_COMM(ctx, xchg_wait(c, &P.inv, ctx->stream));
+    MRL_TRY(slab_inv_finish(ctx, static_cast<const double *>(P.inv.recv.local), d_out + b * nreal));
+    MRL_TRY(ack_release(ctx, P.ack_inv, &P.ack_inv_epoch));
+  }
+  return MRL_OK;
+}
+
+// sum over ranks of a device scalar produced on the context's stream; result on the host (one synchronisation)
+int slab_allreduce_scalars(mrl_ctx *ctx, const double *d_local, int n, double *d_global, double *h_out) {
+  MRL_COMM(ctx, comm_allreduce_device(ctx->comm, ctx->stream, d_local, n, d_global, h_out));
+  return MRL_OK;
+}
+
+}  // namespace mrl
+
+using namespace mrl;
+
+extern "C" {
+
+int mrl_ctx_attach_comm(mrl_ctx *ctx, mrl_comm *comm) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!ctx->slab) return set_error(ctx, MRL_ERR_INVALID, "mrl_ctx_attach_comm: not a slab context");
+  if (comm && (comm->nranks != ctx->nranks || comm->rank != ctx->rank))
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_ctx_attach_comm: communicator is rank %d of %d, context rank %d of %d", comm->rank,
+                     comm->nranks, ctx->rank, ctx->nranks);
+  if (comm && comm->device != ctx->device)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_ctx_attach_comm: communicator lives on device %d, context on device %d", comm->device, ctx->device);
+  if (ctx->comm && ctx->comm != comm) {
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    slab_pipes_destroy(ctx);
+  }
+  ctx->comm = comm;
+  return MRL_OK;
+}
+
+}  // extern "C"

@@ -35,6 +35,8 @@ struct YFusedArgs {
   unsigned chunk;     // nxl * nyl * ksub: elements of one field of one chunk
   int tiles_per_x;
   const double *kx, *ky, *kz;  // local reciprocal axes
+  cplx *const *utab;  // ubar output: chunk p of the inverse exchange layout starts at utab[p] (a peer's receive buffer or the local send buffer)
+  SignalArgs sig;     // arrival flags raised by the last workgroup (direct peer stores), or none
 };
 
 template <int N, int ORDER, bool SPEC_C, bool ALIGNED>
@@ -67,15 +69,17 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
     const int j = q0 + m * TPL;
     return (unsigned)(j >> sh) * (SPEC_C ? chB : 2u * chB) + (unsigned)((ix << sh) + (j & msk)) * ksB + tq;
   };
-  auto offu = [=](int m) {
+  cplx *const *utab = a.utab;
+  auto stu = [=](int m, cplx val) {  // (ALIGNED: the chunk index depends on m only -> the table entry is a scalar load)
     const int j = q0 + m * TPL;
-    return (unsigned)(j >> sh) * chB + (unsigned)((ix << sh) + (j & msk)) * ksB + tq;
+    stc(utab[j >> sh], (unsigned)((ix << sh) + (j & msk)) * ksB + tq, val);
   };
   const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + a.k0 + kl) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
   auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
   // default cache policy for every stream: on the sub-block-sized working sets of the slab pipeline the non-temporal accesses of
   // the serial kernel cost 8-30 % (measured per variant with tools/slab_local_bench.py 8 256)
-  ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, offu, W, X, KY);
+  ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, stu, W, X, KY);
+  signal_tail(a.sig);
 }
 
 template <int N, int ORDER, bool SPEC_C, bool ALIGNED>
@@ -89,6 +93,7 @@ static int launch_yfused_v(mrl_ctx *ctx, YFusedArgs a) {
   constexpr int T = Plan<N>::T;
   a.tiles_per_x = (a.ksub + T - 1) / T;
   const long long nb = (long long)a.nxl * a.tiles_per_x;
+  a.sig.expected = (unsigned)nb;
   hipLaunchKernelGGL((k_ch_yfused<N, ORDER, SPEC_C, ALIGNED>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a,
                      ctx->ax[1].d_tw);
   MRL_HIP(ctx, hipGetLastError());
@@ -166,7 +171,7 @@ int slab_ch_z_fwd_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *
   return MRL_OK;
 }
 
-int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, double *send, int carry) {
+int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const SignalArgs &sig, int carry) {
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
   cplx *w_c, *w_mu, *w_inv;
   MRL_TRY(slab_work(ctx, &w_c, &w_mu, &w_inv));
@@ -175,8 +180,9 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, double *send, int carry) 
   p2::SubPassArgs a{};
   a.in[0] = (one ? w_mu : w_c) + k0;
   a.in[1] = w_mu + k0;
-  a.out[0] = reinterpret_cast<cplx *>(send);
-  a.out[1] = a.out[0] + chunk;
+  a.otab = otab;
+  a.fs_out = chunk;
+  a.sig = sig;
   a.rows = (int)nyl;
   a.cols = ksub;
   a.pitch_in = (unsigned)nzc;
@@ -185,7 +191,6 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, double *send, int carry) 
   a.sn_out = (unsigned)(nyl * ksub);
   a.sh_in = 31;
   a.sh_out = ilog2(nxl);
-  a.cs_out = one ? chunk : 2u * chunk;
   ProfScope ps(ctx, "slab_A_x_fwd", (one ? 2.0 : 4.0) * 16.0 * nx * nyl * ksub);
   if (one) {
     MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 1>(ctx, a, ctx->ax[0].d_tw))));
@@ -195,8 +200,8 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, double *send, int carry) 
   return MRL_OK;
 }
 
-int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const double *recv, double *send, double *Nhat_new,
-                        const double *const *Nhat_old, int order, double sub_dt, double *cbar, int carry) {
+int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const double *recv, cplx *const *utab, const SignalArgs &sig,
+                        double *Nhat_new, const double *const *Nhat_old, int order, double sub_dt, double *cbar, int carry) {
   const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2];
   const long long nyl = ny / ctx->nranks;
   const bool spec = carry == MRL_CARRY_IN;
@@ -204,7 +209,9 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const dou
   a.chunk = (unsigned)(nxl * nyl * ksub);
   a.c.chat = reinterpret_cast<const cplx *>(recv);
   a.c.muhat = spec ? a.c.chat : a.c.chat + a.chunk;
-  a.c.ubar = reinterpret_cast<cplx *>(send);
+  a.c.ubar = nullptr;  // scattered through utab
+  a.utab = utab;
+  a.sig = sig;
   a.c.Nnew = reinterpret_cast<cplx *>(Nhat_new);
   a.c.cbar = carry == MRL_CARRY_NONE ? reinterpret_cast<cplx *>(cbar) : nullptr;
   a.c.carry = carry == MRL_CARRY_NONE ? nullptr : reinterpret_cast<cplx *>(cbar);

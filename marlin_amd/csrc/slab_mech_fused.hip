@@ -15,6 +15,7 @@
 //   -- all-to-all --
 //   inv   inverse x pass from [p][3][x_p][y_me][nzc] into the work arrays, k_z_inv<PAIR> * 1/N into the row's 3 output fields
 #include "fft_pow2_launch.h"
+#include "slab_stages.h"
 
 // register budget of k_gamma_yfused: see k_gamma_xfused (mech_fused.hip); here the full prefetch of the third component measured
 // best once the output transforms are no longer unrolled into each other (rank-local 256^3 / 8: 60 -> 45 us per row)
@@ -39,7 +40,10 @@ int reduce_finalize_from(mrl_ctx *ctx, const double *partial, int nb, double *d_
 namespace p2 {
 
 struct GammaYArgs {
-  cplx *buf;          // [p][3][nxl][nyl_p][nzc], projected in place
+  const cplx *buf;    // received [p][3][nxl][nyl_p][nzc]
+  cplx *const *otab;  // projected output: chunk p (same layout) starts at otab[p] -- in place (otab[p] = buf + p*3*chunk), the local
+                      // send buffer, or rank p's receive buffer of the inverse exchange (direct peer stores)
+  SignalArgs sig;
   int nxl, nzc;
   int nyl_shift;      // log2(ny / P)
   unsigned chunk;     // nxl * nyl * nzc: elements of one field of one chunk
@@ -80,6 +84,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_yfused(GammaYArgs a, c
     const int j = q + m * TPL;
     return (unsigned)(j >> sh) * (3u * chB) + (unsigned)((ix << sh) + (j & msk)) * rowB + klB;
   };
+  cplx *const *otab = a.otab;
   auto ld = [=](unsigned f, int m) {
     return *reinterpret_cast<const cplx *>(reinterpret_cast<const char *>(a.buf) + f * chB + off(m));
   };
@@ -132,10 +137,14 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_yfused(GammaYArgs a, c
     fft_line<N, Map>(v0, q, l, X, W);
     if (valid) {
 #pragma unroll
-      for (int m = 0; m < P; ++m)
-        *reinterpret_cast<cplx *>(reinterpret_cast<char *>(a.buf) + (unsigned)j * chB + off(m)) = cswap(v0[m]);
+      for (int m = 0; m < P; ++m) {
+        const int jj = q + m * TPL;
+        *reinterpret_cast<cplx *>(reinterpret_cast<char *>(otab[jj >> sh]) + (unsigned)j * chB + (unsigned)((ix << sh) + (jj & msk)) * rowB + klB) =
+            cswap(v0[m]);
+      }
     }
   }
+  signal_tail(a.sig);
 }
 
 template <int N>
@@ -149,6 +158,7 @@ static int launch_gamma_yfused(mrl_ctx *ctx, GammaYArgs a) {
   constexpr int T = Plan<N>::T;
   a.tiles_per_x = (a.nzc + T - 1) / T;
   const long long nb = (long long)a.nxl * a.tiles_per_x;
+  a.sig.expected = (unsigned)nb;
   hipLaunchKernelGGL((k_gamma_yfused<N>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[1].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
@@ -176,6 +186,106 @@ static int check_fast(mrl_ctx *ctx, const char *what, int row) {
     return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: needs a 3-D slab context with planned extents and equal power-of-two partitions", what);
   if (ctx->nloc[1] % 2) return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: needs an even number of local y planes", what);
   if (row < 0 || row > 2) return set_error(ctx, MRL_ERR_INVALID, "%s: row %d out of range", what, row);
+  return MRL_OK;
+}
+
+int slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *d_A_fm, cplx *const *otab, const SignalArgs &sig) {
+  if (!d_A_fm && !ctx->gamma_z_ready)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_fwd: no input field and no spectra from mrl_slab_gamma_tangent_z_fwd");
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
+  const long long nreal = nx * nyl * nz, nspec = nx * nyl * nzc;
+  cplx *w;
+  if (d_A_fm) {
+    MRL_TRY(row_work(ctx, 4, &w));
+    ProfScope ps(ctx, "slab_gamma_z_fwd", 3.0 * (8.0 * nreal + 16.0 * nspec));
+    p2::ChDev none{};
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, d_A_fm + 3 * row * nreal, w, nullptr, nullptr, none, 3 * nx * nyl / 2))));
+  } else {
+    w = reinterpret_cast<cplx *>(ctx->d_work[12]) + 3 * row * nspec;  // z spectra left by mrl_slab_gamma_tangent_z_fwd
+    if (row == 2) ctx->gamma_z_ready = false;                         // consumed: a later call needs a new fused z pass
+  }
+  const unsigned chunk = (unsigned)(nxl * nyl * nzc);
+  p2::SubPassArgs a{};
+  a.rows = (int)nyl;
+  a.cols = (int)nzc;
+  a.pitch_in = a.pitch_out = (unsigned)nzc;
+  a.sn_in = a.sn_out = (unsigned)(nyl * nzc);
+  a.sh_in = 31;
+  a.sh_out = ilog2(nxl);
+  a.otab = otab;
+  a.fs_out = chunk;
+  a.sig = sig;  // the three fields of the row go out in two launches that count towards ONE arrival flag
+  unsigned nb = 0;
+  MRL_SWITCH_N(nx, nb = pass_sub_blocks<NN>(nyl, nzc));
+  a.sig.expected = 2u * nb;
+  ProfScope ps(ctx, "slab_gamma_x_fwd", 3.0 * 32.0 * nspec);
+  a.in[0] = w;
+  a.in[1] = w + nspec;
+  a.fo_out = 0;
+  MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 2>(ctx, a, ctx->ax[0].d_tw))));
+  a.in[0] = w + 2 * nspec;
+  a.fo_out = 2u * chunk;
+  MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 1>(ctx, a, ctx->ax[0].d_tw))));
+  return MRL_OK;
+}
+
+int slab_gamma_row_mid(mrl_ctx *ctx, const double *recv, cplx *const *otab, const SignalArgs &sig, double scale) {
+  const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2], nyl = ny / ctx->nranks;
+  p2::GammaYArgs a{};
+  a.buf = reinterpret_cast<const cplx *>(recv);
+  a.otab = otab;
+  a.sig = sig;
+  a.nxl = (int)nxl;
+  a.nzc = (int)nzc;
+  a.nyl_shift = ilog2(nyl);
+  a.chunk = (unsigned)(nxl * nyl * nzc);
+  a.kx = ctx->d_k[0];
+  a.ky = ctx->d_k[1];
+  a.kz = ctx->d_k[2];
+  a.scale = scale;
+  ProfScope ps(ctx, "slab_gamma_y_fused", 3.0 * 32.0 * nxl * ny * nzc);
+  MRL_SWITCH_N(ny, MRL_TRY((p2::launch_gamma_yfused<NN>(ctx, a))));
+  return MRL_OK;
+}
+
+int slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *d_recv, double *d_out_fm, const double *d_dotv_fm) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
+  const long long nreal = nx * nyl * nz, nspec = nx * nyl * nzc;
+  cplx *w;
+  MRL_TRY(row_work(ctx, 5, &w));
+  const unsigned chunk = (unsigned)(nxl * nyl * nzc);
+  {
+    p2::SubPassArgs a{};
+    a.rows = (int)nyl;
+    a.cols = (int)nzc;
+    a.pitch_in = a.pitch_out = (unsigned)nzc;
+    a.sn_in = a.sn_out = (unsigned)(nyl * nzc);
+    a.sh_in = ilog2(nxl);
+    a.cs_in = 3u * chunk;
+    a.sh_out = 31;
+    ProfScope ps(ctx, "slab_gamma_x_inv", 3.0 * 32.0 * nspec);
+    for (int f = 0; f < 3; ++f) {
+      a.in[0] = reinterpret_cast<const cplx *>(d_recv) + (long long)f * chunk;
+      a.out[0] = w + (long long)f * nspec;
+      MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, true, 1>(ctx, a, ctx->ax[0].d_tw))));
+    }
+  }
+  ProfScope ps(ctx, "slab_gamma_z_inv", 3.0 * (16.0 * nspec + 8.0 * nreal) + (d_dotv_fm ? 3.0 * 8.0 * nreal : 0.0));
+  const double scale = 1.0 / ((double)nx * (double)ctx->n[1] * (double)nz);
+  if (!d_dotv_fm) {
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w, d_out_fm + 3 * row * nreal, scale, 3 * nx * nyl / 2))));
+    return MRL_OK;
+  }
+  // sum(out * dotv) of this row while `out` is still in registers: one partial per workgroup, rows back to back
+  const long long max_blocks = 3 * nx * nyl / 2;  // >= the number of workgroups of one row for every plan
+  MRL_TRY(ensure_work(ctx, 3, sizeof(double) * (size_t)(3 * max_blocks)));
+  int nb = 0;
+  if (row > 0 && ctx->gamma_dot_nb == 0)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_inv: dot-product rows must start with row 0");
+  const long long at = row == 0 ? 0 : (long long)row * ctx->gamma_dot_nb;
+  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_dot<NN>(ctx, w, d_out_fm + 3 * row * nreal, scale, 3 * nx * nyl / 2,
+                                                       d_dotv_fm + 3 * row * nreal, ctx->d_work[3] + at, &nb))));
+  ctx->gamma_dot_nb = nb;
   return MRL_OK;
 }
 
@@ -230,103 +340,25 @@ int mrl_slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *d_A_fm, double *
   if (!ctx) return MRL_ERR_INVALID;
   MRL_TRY(check_fast(ctx, "mrl_slab_gamma_row_fwd", row));
   if (!d_send) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_fwd: null buffer");
-  if (!d_A_fm && !ctx->gamma_z_ready)
-    return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_fwd: no input field and no spectra from mrl_slab_gamma_tangent_z_fwd");
-  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
-  const long long nreal = nx * nyl * nz, nspec = nx * nyl * nzc;
-  cplx *w;
-  if (d_A_fm) {
-    MRL_TRY(row_work(ctx, 4, &w));
-    ProfScope ps(ctx, "slab_gamma_z_fwd", 3.0 * (8.0 * nreal + 16.0 * nspec));
-    p2::ChDev none{};
-    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, d_A_fm + 3 * row * nreal, w, nullptr, nullptr, none, 3 * nx * nyl / 2))));
-  } else {
-    w = reinterpret_cast<cplx *>(ctx->d_work[12]) + 3 * row * nspec;  // z spectra left by mrl_slab_gamma_tangent_z_fwd
-    if (row == 2) ctx->gamma_z_ready = false;                         // consumed: a later call needs a new fused z pass
-  }
-  const unsigned chunk = (unsigned)(nxl * nyl * nzc);
-  p2::SubPassArgs a{};
-  a.rows = (int)nyl;
-  a.cols = (int)nzc;
-  a.pitch_in = a.pitch_out = (unsigned)nzc;
-  a.sn_in = a.sn_out = (unsigned)(nyl * nzc);
-  a.sh_in = 31;
-  a.sh_out = ilog2(nxl);
-  a.cs_out = 3u * chunk;
-  ProfScope ps(ctx, "slab_gamma_x_fwd", 3.0 * 32.0 * nspec);
-  a.in[0] = w;
-  a.in[1] = w + nspec;
-  a.out[0] = reinterpret_cast<cplx *>(d_send);
-  a.out[1] = a.out[0] + chunk;
-  MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 2>(ctx, a, ctx->ax[0].d_tw))));
-  a.in[0] = w + 2 * nspec;
-  a.out[0] = reinterpret_cast<cplx *>(d_send) + 2 * chunk;
-  MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 1>(ctx, a, ctx->ax[0].d_tw))));
-  return MRL_OK;
+  cplx *const *tab;
+  MRL_TRY(local_tab(ctx, 2, d_send, sizeof(cplx) * 3 * (size_t)(ctx->nrec[0] * ctx->nloc[1] * ctx->nrec[2]), &tab));
+  return slab_gamma_row_fwd(ctx, row, d_A_fm, tab, SignalArgs{});
 }
 
 int mrl_slab_gamma_row_mid(mrl_ctx *ctx, double *d_recv_inout, double scale) {
   if (!ctx) return MRL_ERR_INVALID;
   MRL_TRY(check_fast(ctx, "mrl_slab_gamma_row_mid", 0));
   if (!d_recv_inout) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_mid: null buffer");
-  const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2], nyl = ny / ctx->nranks;
-  p2::GammaYArgs a{};
-  a.buf = reinterpret_cast<cplx *>(d_recv_inout);
-  a.nxl = (int)nxl;
-  a.nzc = (int)nzc;
-  a.nyl_shift = ilog2(nyl);
-  a.chunk = (unsigned)(nxl * nyl * nzc);
-  a.kx = ctx->d_k[0];
-  a.ky = ctx->d_k[1];
-  a.kz = ctx->d_k[2];
-  a.scale = scale;
-  ProfScope ps(ctx, "slab_gamma_y_fused", 3.0 * 32.0 * nxl * ny * nzc);
-  MRL_SWITCH_N(ny, MRL_TRY((p2::launch_gamma_yfused<NN>(ctx, a))));
-  return MRL_OK;
+  cplx *const *tab;  // in place: chunk p is written back where it was read
+  MRL_TRY(local_tab(ctx, 3, d_recv_inout, sizeof(cplx) * 3 * (size_t)(ctx->nrec[0] * (ctx->n[1] / ctx->nranks) * ctx->nrec[2]), &tab));
+  return slab_gamma_row_mid(ctx, d_recv_inout, tab, SignalArgs{}, scale);
 }
 
 int mrl_slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *d_recv, double *d_out_fm, const double *d_dotv_fm) {
   if (!ctx) return MRL_ERR_INVALID;
   MRL_TRY(check_fast(ctx, "mrl_slab_gamma_row_inv", row));
   if (!d_recv || !d_out_fm) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_inv: null buffer");
-  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
-  const long long nreal = nx * nyl * nz, nspec = nx * nyl * nzc;
-  cplx *w;
-  MRL_TRY(row_work(ctx, 5, &w));
-  const unsigned chunk = (unsigned)(nxl * nyl * nzc);
-  {
-    p2::SubPassArgs a{};
-    a.rows = (int)nyl;
-    a.cols = (int)nzc;
-    a.pitch_in = a.pitch_out = (unsigned)nzc;
-    a.sn_in = a.sn_out = (unsigned)(nyl * nzc);
-    a.sh_in = ilog2(nxl);
-    a.cs_in = 3u * chunk;
-    a.sh_out = 31;
-    ProfScope ps(ctx, "slab_gamma_x_inv", 3.0 * 32.0 * nspec);
-    for (int f = 0; f < 3; ++f) {
-      a.in[0] = reinterpret_cast<const cplx *>(d_recv) + (long long)f * chunk;
-      a.out[0] = w + (long long)f * nspec;
-      MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, true, 1>(ctx, a, ctx->ax[0].d_tw))));
-    }
-  }
-  ProfScope ps(ctx, "slab_gamma_z_inv", 3.0 * (16.0 * nspec + 8.0 * nreal) + (d_dotv_fm ? 3.0 * 8.0 * nreal : 0.0));
-  const double scale = 1.0 / ((double)nx * (double)ctx->n[1] * (double)nz);
-  if (!d_dotv_fm) {
-    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w, d_out_fm + 3 * row * nreal, scale, 3 * nx * nyl / 2))));
-    return MRL_OK;
-  }
-  // sum(out * dotv) of this row while `out` is still in registers: one partial per workgroup, rows back to back
-  const long long max_blocks = 3 * nx * nyl / 2;  // >= the number of workgroups of one row for every plan
-  MRL_TRY(ensure_work(ctx, 3, sizeof(double) * (size_t)(3 * max_blocks)));
-  int nb = 0;
-  if (row > 0 && ctx->gamma_dot_nb == 0)
-    return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_row_inv: dot-product rows must start with row 0");
-  const long long at = row == 0 ? 0 : (long long)row * ctx->gamma_dot_nb;
-  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_dot<NN>(ctx, w, d_out_fm + 3 * row * nreal, scale, 3 * nx * nyl / 2,
-                                                       d_dotv_fm + 3 * row * nreal, ctx->d_work[3] + at, &nb))));
-  ctx->gamma_dot_nb = nb;
-  return MRL_OK;
+  return slab_gamma_row_inv(ctx, row, d_recv, d_out_fm, d_dotv_fm);
 }
 
 int mrl_slab_gamma_dot(mrl_ctx *ctx, double *h_local) {

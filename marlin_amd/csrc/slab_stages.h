@@ -1,0 +1,41 @@
+// Rank-local stages of the slab pipelines, shared by the staged C-ABI entry points (slab.hip, slab_mech_fused.hip) and by the
+// library-owned multi-GPU drivers (slab_driver.hip).
+#pragma once
+#include "comm_dev.h"
+#include "mrl_internal.h"
+
+namespace mrl {
+
+int slab_fast_ok(const mrl_ctx *ctx);
+int slab_sub_range(mrl_ctx *ctx, int sub, int nsub, long long *k0, long long *ksub);
+
+// Cahn-Hilliard, planned shapes (slab_fused.hip).  otab / utab: destination of chunk p (one entry per rank) in the forward /
+// inverse exchange layout; sig: arrival flags raised by the last workgroup of the launch (or none).
+int slab_ch_z_fwd_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *mu, int carry);
+int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const SignalArgs &sig, int carry);
+int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const double *recv, cplx *const *utab, const SignalArgs &sig,
+                        double *Nhat_new, const double *const *Nhat_old, int order, double sub_dt, double *cbar, int carry);
+int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv);
+int slab_ch_z_inv_fast(mrl_ctx *ctx, double *real_out);
+int slab_ch_z_inv_fwd_fast(mrl_ctx *ctx, const ChP &cp, double *mu, int carry);
+
+// Cahn-Hilliard, any shape (slab.hip): contiguous send / receive buffers
+int gen_z_fwd(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *d_mu, int carry);
+int gen_x_fwd(mrl_ctx *ctx, long long k0, long long ksub, double *send, int carry);
+int gen_kspace(mrl_ctx *ctx, const ChP &cp, long long k0, long long ksub, const double *recv, double *send, double *Nhat_new,
+               const double *const *Nhat_old, int order, double sub_dt, double *d_cbar, int carry);
+int gen_x_inv(mrl_ctx *ctx, long long k0, long long ksub, const double *recv);
+int gen_z_inv(mrl_ctx *ctx, double *real_out);
+
+// plain slab transforms split at the exchange (slab.hip)
+int slab_fwd_local(mrl_ctx *ctx, const double *real_in, double *send);
+int slab_fwd_finish(mrl_ctx *ctx, const double *recv, double *spec_out);
+int slab_inv_local(mrl_ctx *ctx, const double *spec_in, double *send);
+int slab_inv_finish(mrl_ctx *ctx, const double *recv, double *real_out);
+
+// Gamma operator rows on field-major data (slab_mech_fused.hip)
+int slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *A_fm, cplx *const *otab, const SignalArgs &sig);
+int slab_gamma_row_mid(mrl_ctx *ctx, const double *recv, cplx *const *otab, const SignalArgs &sig, double scale);
+int slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *recv, double *out_fm, const double *dotv_fm);
+
+}  // namespace mrl

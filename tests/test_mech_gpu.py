@@ -175,17 +175,9 @@ def test_gamma_apply_radix10_sizes(shape):
 
 def _newton_cg_run(shape, exp, substeps=2):
     """Newton-CG over `substeps` shear increments on a two-phase RVE of the given shape with the library's experiment mask
-    `exp` (MRL_EXP is read when the context is created)"""
-    import os
-    old = os.environ.get("MRL_EXP")
-    os.environ["MRL_EXP"] = str(exp)
-    try:
-        ctx = _ctx(3, list(shape), [2 * math.pi] * 3)
-    finally:
-        if old is None:
-            del os.environ["MRL_EXP"]
-        else:
-            os.environ["MRL_EXP"] = old
+    `exp` (MRL_OPT_EXPERIMENT; 32 = separate tangent / z / update kernels in the CG iteration)"""
+    ctx = _ctx(3, list(shape), [2 * math.pi] * 3)
+    ctx.set_option(0, exp)
     nx, ny, nz = shape
     phase = torch.zeros(shape, dtype=torch.float64)
     phase[-(9 * nx // 32):, :9 * ny // 32, -(9 * nz // 32):] = 1.0
@@ -206,7 +198,7 @@ def _newton_cg_run(shape, exp, substeps=2):
 def test_cg_fused_direction_tangent_z_pass(shape):
     """the CG iteration with the direction update, the tangent and the forward z pass of G in one kernel and the solution update
     deferred into it (k_gamma_z_fwd_tangent, z lines of 32 ... 256 points; 128^3 = the streaming variant of BASELINE configs[2])
-    against the same solve with separate kernels (MRL_EXP=32): same Newton / CG iteration counts, same fields"""
+    against the same solve with separate kernels (experiment option 32): same Newton / CG iteration counts, same fields"""
     fused, plain = _newton_cg_run(shape, 0), _newton_cg_run(shape, 32)
     for (Ff, Pf, nf, cf), (Fp, Pp, np_, cp) in zip(fused, plain):
         assert nf == np_ and cf == cp

@@ -1,0 +1,83 @@
+"""The library-owned multi-GPU path (include/marlin_hip.h: mrl_comm_*, mrl_ctx_attach_comm) with REAL rank processes: every
+test starts P child processes (tests/slab_rank_worker.py), all on GPU 0 of this box, each with its own slab context and
+communicator.  They exchange through HIP IPC peer mappings and device-side flags exactly as P ranks on P GPUs do (RCCL cannot
+be exercised this way: it refuses several ranks on one device).  Parity: the serial oracle on the global field and the
+reference's 2-rank gold file (test/tests/cahnhilliard/gold/cahnhilliard.rank0001.h5, abs 1e-13)."""
+import itertools
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "slab_rank_worker.py")
+_counter = itertools.count()
+
+
+def run_job(P, case, *kv, timeout=240):
+    """start P rank processes, return their RESULT records in rank order; any failure shows every rank's stderr"""
+    job = f"mrltest_{os.getpid()}_{next(_counter)}"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, WORKER, job, str(P), str(r), case, *kv], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env, cwd=ROOT) for r in range(P)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout))
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise
+    finally:
+        shm = f"/dev/shm/{job}"
+        if os.path.exists(shm):
+            os.unlink(shm)
+    res = []
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        line = [ln for ln in so.splitlines() if ln.startswith("RESULT ")]
+        assert p.returncode == 0 and line, f"rank {r} failed (rc {p.returncode}):\n{se[-3000:]}\n{so[-1000:]}"
+        res.append(json.loads(line[-1][7:]))
+    return res
+
+
+@pytest.mark.parametrize("P,transport", [(2, 1), (2, 2), (4, 1)])
+def test_native_slab_ch_gold_rank1(P, transport):
+    """test/tests/cahnhilliard/tests:58-70 (cahnhilliard.i, parallel_mode = FFT_SLAB): c.1 .. c.10 of rank 1's gold file, by P
+    processes through mrl_ch_substeps with peer stores (1) and copy-engine pushes (2)"""
+    res = run_job(P, "chgold", f"transport={transport}")
+    assert all(r["transport"] == transport for r in res)
+    gold = [r["max_gold_err"] for r in res if "max_gold_err" in r]
+    assert len(gold) == P // 2 and max(gold) <= 1e-13, res
+    assert max(r["max_err"] for r in res) <= 1e-13, res
+
+
+@pytest.mark.parametrize("P,shape,transport,nsub,carry", [
+    (2, "64,64,64", 1, 1, 0), (2, "64,64,64", 2, 2, 0), (4, "64,128,64", 1, 1, 0), (4, "64,64,64", 1, 3, 1), (4, "128,64,64", 2, 1, 1),
+    (2, "8,6,10", 1, 1, 0), (3, "9,7,5", 2, 2, 0), (3, "9,7,5", 1, 1, 1), (2, "16,12", 1, 1, 0)])
+def test_native_slab_ch_vs_oracle(P, shape, transport, nsub, carry):
+    """planned shapes (fused kernels scattering into the peers' buffers) and odd / uneven / 2-D shapes (generic stages + pushes):
+    two time steps of three substeps (AB1 then AB2) against the serial oracle"""
+    res = run_job(P, "ch", f"shape={shape}", f"transport={transport}", f"nsub={nsub}", f"carry={carry}")
+    assert max(r["max_err"] for r in res) <= 1e-13, res
+    if P > 1:
+        assert all(r["stats"]["exchanges"] > 0 and r["stats"]["bytes_sent"] > 0 for r in res)
+
+
+@pytest.mark.parametrize("P,shape,transport", [(2, "16,12,10", 1), (3, "9,7,5", 2), (4, "64,64,64", 1), (2, "16,12", 2)])
+def test_native_slab_fft(P, shape, transport):
+    """DomainAction::fft / ifft in FFT_SLAB mode through mrl_fft_r2c / mrl_fft_c2r with the library-owned exchange (repeated
+    forward transforms: the acknowledgement flags), and a global reduction"""
+    res = run_job(P, "fft", f"shape={shape}", f"transport={transport}")
+    assert max(r["max_err"] for r in res) <= 1e-13, res
+
+
+def test_native_single_rank_all_transports():
+    """one rank: the same pipeline with self-exchanges, including the RCCL transport (grouped send/recv to itself)"""
+    for transport in (1, 2, 3):
+        res = run_job(1, "ch", "shape=64,64,64", f"transport={transport}")
+        assert res[0]["transport"] == transport and res[0]["max_err"] <= 1e-13, res
