@@ -14,6 +14,7 @@
 // the reference's literal 1./3. in every dimension.
 // Fields are value-major [grid][D][D] as in the reference.
 #include "mech_math.h"
+#include "slab_stages.h"
 
 namespace mrl {
 
@@ -587,7 +588,12 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
                        const double *d_mu, const double *d_applied, double *d_Fnew, double *d_P,
                        mrl_mech_stats *stats) {
   if (!ctx) return MRL_ERR_INVALID;
-  MRL_TRY(check_dim(ctx, "mrl_mech_newton_cg"));
+  // slab contexts: the same solve on the rank's y-slab, the Gamma operator over the library-owned exchanges and every norm / dot
+  // product summed over the ranks on the device (the reference's norms are serial-only, DomainAction.C:1564-1567)
+  const bool dist = ctx->slab;
+  MRL_TRY(check_dim(ctx, "mrl_mech_newton_cg", !dist));
+  if (dist && !ctx->comm)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_newton_cg on a slab context needs a communicator (mrl_ctx_attach_comm)");
   if (!prm || !d_F || !d_K || !d_mu || !d_Fnew || !d_P)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_newton_cg: null argument");
   if (d_Fnew == d_F) return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_newton_cg: Fnew must not alias F");
@@ -600,7 +606,7 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
          *x = ctx->d_work[10];
   // Fast-path shapes run the whole solve on field-major vectors [9][grid] (coalesced streams for every kernel);
   // the caller's value-major F is converted once on entry, Fnew and P once on exit.
-  const bool soa = mech_fast_ok(ctx);
+  const bool soa = dist ? (ctx->dim == 3 && mrl_slab_fast_path(ctx) && npts % 2 == 0) : mech_fast_ok(ctx);
   double *Fin = nullptr, *Fwork = d_Fnew, *Pwork = d_P;
   if (soa) {
     for (int s = 11; s <= 13; ++s) MRL_TRY(ensure_work(ctx, s, vb));
@@ -610,7 +616,13 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
     MRL_TRY(relayout_launch(ctx, true, d_F, Fin));
   }
   auto gamma = [&](const double *A, double *out, double scale) -> int {
+    if (dist) return soa ? slab_gamma_fm(ctx, A, out, scale, nullptr, nullptr) : slab_gamma_vm(ctx, A, out, scale);
     return soa ? gamma_fast(ctx, A, out, scale) : gamma_launch(ctx, A, out, scale);
+  };
+  // a device scalar produced on the stream becomes the sum over the ranks (in place); h != nullptr: also read back (one sync)
+  auto global = [&](double *slot, double *h) -> int {
+    if (dist) return slab_allreduce_scalars(ctx, slot, 1, slot, h);
+    return h ? read_scalars(ctx, slot, 1, h) : MRL_OK;
   };
   double *S = ctx->d_red + kScalarBase + 32;  // device scalars: [0],[2] r.r ping-pong, [1] p.Ap, [3] scratch
   const int nb = grid_for(n);
@@ -631,7 +643,7 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
     MRL_HIP(ctx, hipMemsetAsync(b, 0, sizeof(double) * n, ctx->stream));
   }
   MRL_TRY(reduce_async(ctx, 2, Fwork, Fwork, n, S + 3));
-  MRL_TRY(read_scalars(ctx, S + 3, 1, h));
+  MRL_TRY(global(S + 3, h));
   const double Fn = sqrt(h[0]);  // :123-124
   st.Fn = Fn;
   MRL_HIP(ctx, hipMemsetAsync(x, 0, sizeof(double) * n, ctx->stream));  // dFm = zeros_like(b)
@@ -641,19 +653,20 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
     return gamma(tmp, out, 1.0);
   };
 
-  const bool fuse_dir = soa && gamma_tangent_fusable(ctx) && !(ctx->exp & 32);
+  const bool fuse_dir = soa && (dist ? mrl_slab_gamma_tangent_fusable(ctx) != 0 : gamma_tangent_fusable(ctx)) && !(ctx->exp & 32);
   int iiter = 0;
   while (true) {
     // ---- conjugateGradientSolve(G_K_dF, b, dFm, l_tol, l_max_its)        MarlinUtils.h:55-123
     int its = 0;
     double res_norm = 0.0;
     MRL_TRY(reduce_async(ctx, 2, b, b, n, S + 3));
-    MRL_TRY(read_scalars(ctx, S + 3, 1, h));
+    MRL_TRY(global(S + 3, h));
     const double b_norm = sqrt(h[0]);
     if (b_norm != 0.0) {
       MRL_TRY(apply_A(x, Ap));
       hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(256), 0, ctx->stream, b, Ap, r, p, n, ctx->d_red);
       MRL_TRY(reduce_finalize(ctx, nb, 1, S + 0));
+      MRL_TRY(global(S + 0, nullptr));
       int i_old = 0, i_new = 2;
       int pend_rz = -1;  // slot of r.r of the iteration whose x update is still pending (deferred updates, fuse_dir)
       its = (int)l_max_its;
@@ -663,13 +676,18 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
         } else {
           // p = r + beta p (beta = rr_new / rr_old of the previous iteration) fused into the operator application
           if (fuse_dir) {  // ... and into the forward z pass of G: K4:p is never written; the pending x update rides along
-            MRL_TRY(gamma_fast_tangent_dir(ctx, lin, d_K, d_mu, p, r, S, i_old, i_new, Ap, S + 1, mech_stream_vectors(npts), x,
-                                           pend_rz, 1));
+            if (dist) {
+              MRL_TRY(slab_gamma_tangent_z(ctx, lin, d_K, d_mu, p, r, S, i_old, i_new, pend_rz >= 0 ? x : nullptr, pend_rz, 1));
+              MRL_TRY(slab_gamma_fm(ctx, nullptr, Ap, 1.0, p, S + 1));
+            } else {
+              MRL_TRY(gamma_fast_tangent_dir(ctx, lin, d_K, d_mu, p, r, S, i_old, i_new, Ap, S + 1, mech_stream_vectors(npts), x,
+                                             pend_rz, 1));
+            }
             pend_rz = -1;
           } else {
             MRL_TRY(tangent_dir_launch(ctx, lin, d_K, d_mu, p, r, S, i_old, i_new, tmp, soa));
-            if (soa) {
-              MRL_TRY(gamma_fast(ctx, tmp, Ap, 1.0, p, S + 1));  // p.Ap taken in the last pass of G
+            if (soa) {  // p.Ap taken in the last pass of G
+              MRL_TRY(dist ? slab_gamma_fm(ctx, tmp, Ap, 1.0, p, S + 1) : gamma_fast(ctx, tmp, Ap, 1.0, p, S + 1));
             } else {
               MRL_TRY(gamma(tmp, Ap, 1.0));
             }
@@ -679,6 +697,7 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
           ProfScope ps(ctx, "cg_dot_pAp", 16.0 * n);
           MRL_TRY(reduce_async(ctx, 1, p, Ap, n, S + 1));
         }
+        MRL_TRY(global(S + 1, nullptr));
         {
           ProfScope ps(ctx, "cg_update_x_r", (fuse_dir ? 24.0 : 48.0) * n);
           if (fuse_dir) {  // x += alpha p is deferred into the next direction kernel (or the k_axpy_ratio after the loop)
@@ -688,7 +707,12 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
             hipLaunchKernelGGL(k_cg_update<true>, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
           else
             hipLaunchKernelGGL(k_cg_update<false>, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
-          MRL_TRY(reduce_finalize_to_host(ctx, nb, 1, S + i_new, h));  // the one host sync of the iteration (no copy command)
+          if (dist) {  // the one host sync of the iteration
+            MRL_TRY(reduce_finalize(ctx, nb, 1, S + i_new));
+            MRL_TRY(global(S + i_new, h));
+          } else {
+            MRL_TRY(reduce_finalize_to_host(ctx, nb, 1, S + i_new, h));  // (no copy command)
+          }
         }
         res_norm = sqrt(h[0]);
         if (res_norm <= prm->l_tol * b_norm) {
@@ -714,7 +738,7 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
     MRL_TRY(stress_launch(ctx, Fwork, d_K, d_mu, Pwork, soa));
     MRL_TRY(gamma(Pwork, b, -1.0));
     MRL_TRY(reduce_async(ctx, 2, x, x, n, S + 3));
-    MRL_TRY(read_scalars(ctx, S + 3, 1, h));
+    MRL_TRY(global(S + 3, h));
     const double anorm = sqrt(h[0]);
     const double rnorm = anorm / Fn;
     st.last_anorm = anorm;

@@ -18,7 +18,7 @@ typedef double2 cplx;  // interleaved (re, im) complex128
 struct SlabPipes;
 
 constexpr int kMaxRadixPasses = 24;
-constexpr int kWorkSlots = 16;
+constexpr int kWorkSlots = 24;
 constexpr int kRedBlocks = 2048;    // partial sums of a reduction live in ctx->d_red[0, kRedBlocks)
 constexpr int kScalarBase = 3072;   // device scalar slots: ctx->d_red[kScalarBase, 4096)
 
@@ -66,7 +66,7 @@ struct mrl_ctx {
   int spectrum = MRL_SPECTRUM_HALF;
   int nranks = 1, rank = 0;
   bool slab = false;            // FFT_SLAB layout and staged entry points (nranks > 1, or MRL_FLAG_SLAB)
-  bool gamma_z_ready = false;   // d_work[12] holds the 9 z spectra written by mrl_slab_gamma_tangent_z_fwd
+  bool gamma_z_ready = false;   // d_work[18] holds the 9 z spectra written by mrl_slab_gamma_tangent_z_fwd
   int gamma_dot_nb = 0;         // workgroups per row of the fused slab Gamma z pass that left dot-product partials (d_work[3])
   int device = 0;
   long long nloc[3] = {1, 1, 1};   // local real extents
@@ -87,7 +87,7 @@ struct mrl_ctx {
   double *d_x[3] = {nullptr, nullptr, nullptr};  // device copies of the LOCAL real-space axes
 
   // scratch (complex spectra), grown on demand
-  // slots: 0 inverse-transform scratch, 1-3 Cahn-Hilliard, 4-10 mechanics, 11-15 slab stages
+  // slots: 0 inverse-transform scratch, 1-3 Cahn-Hilliard, 4-10 mechanics, 11-15 slab stages, 16-18 slab Gamma rows, 19-20 slab Gamma generic
   double *d_work[mrl::kWorkSlots] = {};
   size_t work_bytes[mrl::kWorkSlots] = {};
   double *d_red = nullptr;      // reduction scratch

@@ -338,6 +338,110 @@ int slab_fft_inverse(mrl_ctx *ctx, const double *d_in, double *d_out, long long 
   return MRL_OK;
 }
 
+// ---- Gamma operator on a slab-decomposed grid (FFTMechanics.C:74-84,105-106 over fftSlab / ifftSlab) ------------------------
+int reduce_finalize_from(mrl_ctx *ctx, const double *partial, int nb, double *d_scalar);
+int gamma_z_fwd_tangent_launch(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
+                               const double *S, int i_num, int i_den, cplx *spec, long long npts, long long rows, int nz, bool nt,
+                               double *x, int i_arz, int i_apAp);
+
+static int mech_pipe_build(mrl_ctx *ctx) {
+  MechPipe &P = ctx->pipes->mech;
+  mrl_comm *c = ctx->comm;
+  const int R = ctx->nranks;
+  if (!P.built) {
+    std::vector<int64_t> sc(R), rc(R);
+    std::vector<size_t> sb(R), rb(R);
+    MRL_TRY(mrl_slab_gamma_counts(ctx, 1, sc.data(), rc.data()));
+    for (int p = 0; p < R; ++p) {
+      sb[p] = sizeof(cplx) * (size_t)sc[p];
+      rb[p] = sizeof(cplx) * (size_t)rc[p];
+    }
+    for (int r = 0; r < 3; ++r) {
+      MRL_COMM(ctx, xchg_create(c, &P.fwd[r], sb.data(), rb.data(), false));
+      MRL_COMM(ctx, xchg_create(c, &P.inv[r], rb.data(), sb.data(), false));
+    }
+    P.built = true;
+  } else if (P.transport != c->transport) {
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MRL_COMM(ctx, comm_barrier(c));
+  }
+  if (P.transport != c->transport) {
+    for (int r = 0; r < 3; ++r) {
+      MRL_TRY(prepare_table(ctx, &P.fwd[r], true));
+      MRL_TRY(prepare_table(ctx, &P.inv[r], true));
+    }
+    P.transport = c->transport;
+  }
+  return MRL_OK;
+}
+
+// out = scale * G(A) on FIELD-MAJOR local slabs [9][nx][nyl][nz] (planned shapes, equal partitions): three tensor rows, each
+//   z + x passes -> exchange -> y pass with the projection -> exchange -> inverse x + z passes;
+// row r + 1 is transformed while row r is on the wire.  A_fm == nullptr: the z spectra of the nine fields were left in the context
+// by slab_gamma_tangent_z (x passes only).  dotv_fm: *d_dot = LOCAL sum(out * dotv), taken while `out` is in registers.
+// Write-after-read safety: a rank refills a peer's forward buffer of row r only after it has consumed that peer's inverse message of
+// the previous application, which the peer sent after its y pass had read the forward buffer (and symmetrically).
+int slab_gamma_fm(mrl_ctx *ctx, const double *A_fm, double *out_fm, double scale, const double *dotv_fm, double *d_dot) {
+  MRL_TRY(need_comm(ctx, "slab Gamma operator"));
+  MRL_TRY(mech_pipe_build(ctx));
+  MechPipe &P = ctx->pipes->mech;
+  mrl_comm *c = ctx->comm;
+  hipStream_t st = ctx->stream;
+  for (int r = 0; r < 3; ++r) {
+    MRL_COMM(ctx, xchg_begin(c, &P.fwd[r], st));
+    const SignalArgs sig = xchg_signal_args(c, &P.fwd[r], 0);
+    MRL_TRY(slab_gamma_row_fwd(ctx, r, A_fm, reinterpret_cast<cplx *const *>(P.fwd[r].d_tab), sig));
+    MRL_COMM(ctx, xchg_post(c, &P.fwd[r], st, sig.counter != nullptr));
+  }
+  for (int r = 0; r < 3; ++r) {
+    MRL_COMM(ctx, xchg_wait(c, &P.fwd[r], st));
+    MRL_COMM(ctx, xchg_begin(c, &P.inv[r], st));
+    const SignalArgs sig = xchg_signal_args(c, &P.inv[r], 0);
+    MRL_TRY(slab_gamma_row_mid(ctx, static_cast<const double *>(P.fwd[r].recv.local), reinterpret_cast<cplx *const *>(P.inv[r].d_tab), sig, scale));
+    MRL_COMM(ctx, xchg_post(c, &P.inv[r], st, sig.counter != nullptr));
+  }
+  ctx->gamma_dot_nb = 0;
+  for (int r = 0; r < 3; ++r) {
+    MRL_COMM(ctx, xchg_wait(c, &P.inv[r], st));
+    MRL_TRY(slab_gamma_row_inv(ctx, r, static_cast<const double *>(P.inv[r].recv.local), out_fm, dotv_fm));
+  }
+  if (dotv_fm) {
+    MRL_TRY(reduce_finalize_from(ctx, ctx->d_work[3], 3 * ctx->gamma_dot_nb, d_dot));
+    ctx->gamma_dot_nb = 0;
+  }
+  return MRL_OK;
+}
+
+// [x += (S[i_arz]/S[i_apAp]) p ;] p <- r + (S[i_num]/S[i_den]) p ; z spectra of K_dF(p) for the nine fields -> context scratch
+// (FFTMechanics.C:107-108 fused with MarlinUtils.h:112 and the forward z pass; K_dF(p) is never written)
+int slab_gamma_tangent_z(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r, const double *S,
+                         int i_num, int i_den, double *x, int i_arz, int i_apAp) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2];
+  const long long npts = nx * nyl * nz, nspec = nx * nyl * nzc;
+  MRL_TRY(ensure_work(ctx, 18, sizeof(cplx) * (size_t)(9 * nspec)));
+  ProfScope ps(ctx, "slab_gamma_z_fwd_tangent_dir", 8.0 * npts * ((x ? 6 : 4) * 9 + 2) + 16.0 * nspec * 9);
+  MRL_TRY(gamma_z_fwd_tangent_launch(ctx, F, K, mu, p, r, S, i_num, i_den, reinterpret_cast<cplx *>(ctx->d_work[18]), npts, nx * nyl, (int)nz,
+                                     72.0 * (double)npts >= 96.0e6, x, i_arz, i_apAp));
+  ctx->gamma_z_ready = true;
+  return MRL_OK;
+}
+
+// out = scale * G(A) on VALUE-MAJOR local slabs of any shape: per component slab transform, projection of the field-major
+// spectra, inverse (the generic stages; 2 x D*D blocking exchanges)
+int slab_gamma_vm(mrl_ctx *ctx, const double *A_vm, double *out_vm, double scale) {
+  MRL_TRY(need_comm(ctx, "slab Gamma operator"));
+  const int dd = ctx->dim * ctx->dim;
+  const long long npts = real_count_local(ctx), nspec = spec_count_local(ctx);
+  MRL_TRY(ensure_work(ctx, 19, sizeof(double) * (size_t)(npts * dd + 2)));
+  MRL_TRY(ensure_work(ctx, 20, sizeof(cplx) * (size_t)(nspec * dd)));
+  double *fm = ctx->d_work[19], *spec = ctx->d_work[20];
+  MRL_TRY(mrl_relayout(ctx, 1, A_vm, fm, npts, dd));
+  MRL_TRY(slab_fft_forward(ctx, fm, spec, dd));
+  MRL_TRY(mrl_slab_gamma_project(ctx, spec, scale));
+  MRL_TRY(slab_fft_inverse(ctx, spec, fm, dd));
+  return mrl_relayout(ctx, 0, fm, out_vm, npts, dd);
+}
+
 // sum over ranks of a device scalar produced on the context's stream; result on the host (one synchronisation)
 int slab_allreduce_scalars(mrl_ctx *ctx, const double *d_local, int n, double *d_global, double *h_out) {
   MRL_COMM(ctx, comm_allreduce_device(ctx->comm, ctx->stream, d_local, n, d_global, h_out));

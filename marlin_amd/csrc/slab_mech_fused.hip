@@ -172,8 +172,8 @@ static int ilog2(long long v) {
   return s;
 }
 
-// work arrays: slot 4 = the three z/x-transformed fields of a row [3][nx][nyl][nzc] (one row at a time per direction:
-// slot 4 forward, slot 5 inverse, so that the forward stage of row i+1 can run while row i's inverse stage is pending)
+// work arrays: slot 16 = the three z/x-transformed fields of a row [3][nx][nyl][nzc] (one row at a time per direction:
+// slot 16 forward, slot 17 inverse, so that the forward stage of row i+1 can run while row i's inverse stage is pending)
 static int row_work(mrl_ctx *ctx, int slot, cplx **w) {
   const size_t bytes = sizeof(cplx) * (size_t)(3 * ctx->n[0] * ctx->nloc[1] * ctx->nrec[2]);
   MRL_TRY(ensure_work(ctx, slot, bytes));
@@ -196,12 +196,12 @@ int slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *d_A_fm, cplx *const 
   const long long nreal = nx * nyl * nz, nspec = nx * nyl * nzc;
   cplx *w;
   if (d_A_fm) {
-    MRL_TRY(row_work(ctx, 4, &w));
+    MRL_TRY(row_work(ctx, 16, &w));
     ProfScope ps(ctx, "slab_gamma_z_fwd", 3.0 * (8.0 * nreal + 16.0 * nspec));
     p2::ChDev none{};
     MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, d_A_fm + 3 * row * nreal, w, nullptr, nullptr, none, 3 * nx * nyl / 2))));
   } else {
-    w = reinterpret_cast<cplx *>(ctx->d_work[12]) + 3 * row * nspec;  // z spectra left by mrl_slab_gamma_tangent_z_fwd
+    w = reinterpret_cast<cplx *>(ctx->d_work[18]) + 3 * row * nspec;  // z spectra left by mrl_slab_gamma_tangent_z_fwd
     if (row == 2) ctx->gamma_z_ready = false;                         // consumed: a later call needs a new fused z pass
   }
   const unsigned chunk = (unsigned)(nxl * nyl * nzc);
@@ -252,7 +252,7 @@ int slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *d_recv, double *d_ou
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
   const long long nreal = nx * nyl * nz, nspec = nx * nyl * nzc;
   cplx *w;
-  MRL_TRY(row_work(ctx, 5, &w));
+  MRL_TRY(row_work(ctx, 17, &w));
   const unsigned chunk = (unsigned)(nxl * nyl * nzc);
   {
     p2::SubPassArgs a{};
@@ -325,12 +325,12 @@ int mrl_slab_gamma_tangent_z_fwd(mrl_ctx *ctx, const double *d_F, const double *
   if (!d_F || !d_K || !d_mu || !d_p || !d_r) return set_error(ctx, MRL_ERR_INVALID, "mrl_slab_gamma_tangent_z_fwd: null buffer");
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2];
   const long long npts = nx * nyl * nz, nspec = nx * nyl * nzc;
-  MRL_TRY(ensure_work(ctx, 12, sizeof(cplx) * (size_t)(9 * nspec)));
+  MRL_TRY(ensure_work(ctx, 18, sizeof(cplx) * (size_t)(9 * nspec)));
   double *S = ctx->d_red + kScalarBase + 8;
   const double hs[4] = {beta, 1.0, alpha_prev, 1.0};  // pageable source: staged by the runtime before the call returns
   MRL_HIP(ctx, hipMemcpyAsync(S, hs, sizeof(hs), hipMemcpyHostToDevice, ctx->stream));
   ProfScope ps(ctx, "slab_gamma_z_fwd_tangent_dir", 8.0 * npts * ((d_x ? 6 : 4) * 9 + 2) + 16.0 * nspec * 9);
-  MRL_TRY(gamma_z_fwd_tangent_launch(ctx, d_F, d_K, d_mu, d_p, d_r, S, 0, 1, reinterpret_cast<cplx *>(ctx->d_work[12]), npts,
+  MRL_TRY(gamma_z_fwd_tangent_launch(ctx, d_F, d_K, d_mu, d_p, d_r, S, 0, 1, reinterpret_cast<cplx *>(ctx->d_work[18]), npts,
                                      nx * nyl, (int)nz, 72.0 * (double)npts >= 96.0e6, d_x, 2, 3));
   ctx->gamma_z_ready = true;
   return MRL_OK;

@@ -38,4 +38,15 @@ int slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *A_fm, cplx *const *o
 int slab_gamma_row_mid(mrl_ctx *ctx, const double *recv, cplx *const *otab, const SignalArgs &sig, double scale);
 int slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *recv, double *out_fm, const double *dotv_fm);
 
+
+// library-owned exchanges (slab_driver.hip; need an attached communicator)
+int slab_fft_forward(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
+int slab_fft_inverse(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
+int slab_gamma_fm(mrl_ctx *ctx, const double *A_fm, double *out_fm, double scale, const double *dotv_fm, double *d_dot);
+int slab_gamma_vm(mrl_ctx *ctx, const double *A_vm, double *out_vm, double scale);
+int slab_gamma_tangent_z(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r, const double *S,
+                         int i_num, int i_den, double *x, int i_arz, int i_apAp);
+// in-place sum over ranks of n device scalars (stream-ordered, no host round trip unless h_out)
+int slab_allreduce_scalars(mrl_ctx *ctx, const double *d_local, int n, double *d_global, double *h_out);
+
 }  // namespace mrl

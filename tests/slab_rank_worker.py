@@ -126,9 +126,82 @@ def run_fft(job, P, r, kv):
     return {"max_err": max(errs), "errs": errs}
 
 
+def run_mech(job, P, r, kv):
+    """FFTMechanics::computeBuffer through mrl_mech_newton_cg on a slab context (library-owned exchanges, device-side all-reduce of the
+    CG scalars).  case=gold: test/tests/mechanics/mech3d.i against mech3d.h5 (abs 1e-10); otherwise an n^3 two-phase RVE (planned
+    shapes: the fused field-major row pipeline) against the oracle's serial solve with the same Newton / CG iteration counts."""
+    import numpy as np
+    from marlin_amd import api
+    from oracle import marlin_oracle as mo
+    from tests.conftest import load_golden
+    from tests.test_oracle_golden import MECH_CASES, _mech_setup
+    gold = kv.get("gold", "0") == "1"
+    if gold:
+        pz = MECH_CASES["mech3d"]
+        dim, n = pz["dim"], pz["n"]
+        shape = [n] * dim
+        dom, phase, K, mu = _mech_setup(dim, n)
+        g = load_golden(pz["gold"])
+        l_tol, nl_rel, nl_abs, dt, substeps, nsteps = pz["l_tol"], pz["nl_rel"], pz["nl_abs"], pz["dt"], pz["substeps"], 3
+    else:
+        shape = [int(x) for x in kv.get("shape", "32,32,32").split(",")]
+        dim = 3
+        dom = mo.Domain(3, shape, [2 * math.pi] * 3)
+        nx, ny, nz = shape
+        phase = torch.zeros(shape, dtype=torch.float64)
+        phase[-(9 * nx // 32):, :9 * ny // 32, -(9 * nz // 32):] = 1.0       # test/src/tensor_computes/PhaseMechanicsTest.C:36-45
+        K = (1.0 - phase) * 0.833 + phase * 8.33
+        mu = (1.0 - phase) * 0.386 + phase * 3.86
+        l_tol, nl_rel, nl_abs, dt, substeps, nsteps = 1e-2, 2e-2, 2e-2, 0.01, int(kv.get("substeps", 2)), 1
+    comm = api.Comm(job, P, r, device=0, transport=int(kv.get("transport", 0)), timeout=60.0)
+    ctx = api.Context(dim, shape, [2 * math.pi] * dim, nranks=P, rank=r, slab=True, device=0)
+    ctx.attach_comm(comm)
+    yb, nyl = ctx.real_begin[1], ctx.real_shape[1]
+    Kl, mul = K[:, yb:yb + nyl].contiguous().cuda(), mu[:, yb:yb + nyl].contiguous().cuda()
+    F = torch.eye(dim, dtype=torch.float64).expand(list(ctx.real_shape) + [dim, dim]).contiguous().cuda()
+    ref = mo.FFTMechanicsOracle(dom, K, mu, l_tol=l_tol, nl_rel_tol=nl_rel, nl_abs_tol=nl_abs)
+    Fref = torch.eye(dim, dtype=torch.float64).expand(dom.value_shape([dim, dim])).contiguous()
+    perm = (2, 1, 0)
+    errs, gold_errs, traces_ok = [], [], True
+    t_old = 0.0
+    import time
+    t_lib = t_ref = 0.0
+    nsteps = int(kv.get("steps", nsteps))
+    for step in range(nsteps):
+        sub_dt = dt / substeps
+        for sidx in range(substeps):
+            t = t_old + sidx * sub_dt
+            applied = torch.eye(dim, dtype=torch.float64)
+            applied[0, 1] = applied[0, 1] + t
+            t0 = time.perf_counter()
+            applied = (applied - ctx.average(F)).cuda()                    # MacroscopicShearTensor.C:31-41 (global average)
+            F, Pk, st = ctx.mech_newton_cg(F, Kl, mul, applied, l_tol=l_tol, nl_rel_tol=nl_rel, nl_abs_tol=nl_abs)
+            t1 = time.perf_counter()
+            Fref, rst = ref.compute(Fref, mo.macroscopic_shear(dom, Fref, t))
+            t_lib += t1 - t0
+            t_ref += time.perf_counter() - t1
+            traces_ok = traces_ok and st["newton_its"] == rst.newton_its and list(st["cg_its"]) == list(rst.cg_its)
+        t_old += dt
+        errs.append((F.cpu() - Fref[:, yb:yb + nyl]).abs().max().item())
+        if gold:
+            Fl = F.cpu().reshape(list(ctx.real_shape) + [dim * dim])
+            for k in range(dim * dim):
+                gk = torch.from_numpy(np.ascontiguousarray(g[f"F_{k}.{step}"])).permute(*perm)   # XDMF default transpose (SURVEY A.6)
+                gold_errs.append((Fl[..., k] - gk[:, yb:yb + nyl]).abs().max().item())
+    tr = comm.transport
+    ctx.close()
+    comm.close()
+    out = {"max_err": max(errs), "traces_ok": bool(traces_ok), "transport": tr, "seconds_library": round(t_lib, 2),
+           "seconds_oracle": round(t_ref, 2), "cg_its_last": list(st["cg_its"])}
+    if gold_errs:
+        out["max_gold_err"] = max(gold_errs)
+    return out
+
+
 def main():
     job, P, r, case = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     kv = parse(sys.argv[5:])
+    torch.set_num_threads(max(1, 12 // P))   # the oracle side: the ranks share the box's 16-core CPU allotment
     torch.cuda.set_device(0)
     if case == "ch":
         out = run_ch(job, P, r, kv)
@@ -136,6 +209,8 @@ def main():
         out = run_ch(job, P, r, kv, gold=True)
     elif case == "fft":
         out = run_fft(job, P, r, kv)
+    elif case == "mech":
+        out = run_mech(job, P, r, kv)
     else:
         raise SystemExit(f"unknown case {case}")
     out.update({"rank": r, "case": case})

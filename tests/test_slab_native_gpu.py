@@ -81,3 +81,23 @@ def test_native_single_rank_all_transports():
     for transport in (1, 2, 3):
         res = run_job(1, "ch", "shape=64,64,64", f"transport={transport}")
         assert res[0]["transport"] == transport and res[0]["max_err"] <= 1e-13, res
+
+
+@pytest.mark.parametrize("P,transport", [(2, 1), (4, 2)])
+def test_native_slab_mechanics_gold(P, transport):
+    """test/tests/mechanics/tests:2-21 (mech3d.i, 16^3, 3 steps x 10 substeps) on P rank processes through mrl_mech_newton_cg:
+    F_k of mech3d.h5 to 1e-10, and the serial oracle's Newton / CG iteration counts on every rank (generic stages: 16 is unplanned)"""
+    res = run_job(P, "mech", "gold=1", f"transport={transport}", timeout=600)
+    assert all(r["traces_ok"] for r in res), res
+    assert max(r["max_gold_err"] for r in res) <= 1e-10, res
+    assert max(r["max_err"] for r in res) <= 1e-10, res
+
+
+@pytest.mark.parametrize("P,shape,transport", [(2, "32,32,32", 1), (4, "32,64,32", 1), (4, "64,32,32", 2)])
+def test_native_slab_mechanics_fused_vs_oracle(P, shape, transport):
+    """planned shapes: the fused field-major row pipeline (peer stores from the x / y pass kernels, CG direction + tangent + forward
+    z pass in one kernel, CG scalars all-reduced on the device) against the ORACLE's serial Newton-CG: same iteration counts,
+    F to 1e-10"""
+    res = run_job(P, "mech", f"shape={shape}", f"transport={transport}", timeout=600)
+    assert all(r["traces_ok"] for r in res), res
+    assert max(r["max_err"] for r in res) <= 1e-10, res
