@@ -2,9 +2,19 @@
 """Headline benchmark: grid-point-updates/s of the Cahn-Hilliard semi-implicit spectral substep
 (BASELINE.json: 3-D 256^3 fp64, AB2) on N MI355X GPUs + fraction of the HBM roofline.
 
-A "step" is one solver substep (AdamsBashforthMoulton::substep + its compute group) of the whole
-grid.  N=1: 256^3 on one GPU.  N>1: slab decomposition with an RCCL all-to-all per transform;
-per-GPU work is held at 256^3 points (weak scaling; N=8 is the 512^3 configuration of north_star).
+A "step" is one solver substep (AdamsBashforthMoulton::substep + its compute group) of the whole grid.
+  N = 1   256^3 on one GPU (BASELINE configs[1]).
+  N > 1   slab decomposition, one process per GPU; per-GPU work is held at 256^3 points (weak scaling: N = 8 is the 512^3
+          configuration of north_star, configs[3]); `--global-grid G` fixes the GLOBAL grid instead (strong scaling).
+          The exchange is owned by the library (include/marlin_hip.h: mrl_comm_*): kernels storing straight into the peers'
+          receive buffers over xGMI, copy-engine pushes, or RCCL grouped send/recv -- `--transport tune` (default) times each of them
+          on the real links during the untimed warm-up and keeps the fastest.  `--driver python` runs the torch.distributed driver
+          (marlin_amd/slab.py: RCCL all_to_all_single) over the same kernels instead.
+  --workload mech   de Geus finite-strain RVE (configs[2] at N = 1: 128^3; configs[4] at N = 8: 256^3), time per CG iteration.
+
+The same data flow runs at every N: the reference's (three transforms per substep, `--carry off`).  The spectral carry-over
+variant (two transforms, results equal to rounding; SURVEY 8(d) allows it when disclosed) is timed next to it and reported
+in `variants` -- never mixed into `value`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -24,7 +34,9 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+HBM_COPY_GBPS = 6290.0   # ... and the measured float4-copy ceiling (BASELINE.md section 4 asks for both fractions)
+PARITY_TOL = 1e-13       # reference: test/tests/cahnhilliard/tests:46-57 (abs_tol of the HDF5 diff)
 
 
 def splitmix64_uniform(count, seed=0, lo=0.44, hi=0.56, offset=0):
@@ -43,6 +55,12 @@ def algorithmic_bytes_per_update(n_last, n_old):
     """3*B_fft(n) + n_old*8*(1+2/n), B_fft = 8 + 5*8*(1+2/n)."""
     h = 8.0 * (1.0 + 2.0 / n_last)
     return 3.0 * (8.0 + 5.0 * h) + n_old * h
+
+
+def mech_bytes_per_point(n_last):
+    """2*9*B_fft(n) + 232 + 504 bytes per point per CG iteration."""
+    h = 8.0 * (1.0 + 2.0 / n_last)
+    return 2 * 9 * (8.0 + 5.0 * h) + 232 + 504
 
 
 def grid_for(ngpus, base):
@@ -85,8 +103,10 @@ def measured_traffic(slot, n, order_tag):
     return v["fetch_bytes"] + v["write_bytes"], os.path.relpath(path, ROOT)
 
 
-def cpu_baseline(shape, dx, sample_steps):
-    """The oracle (libTorch CPU ops in the reference's order) timed on this box's host cores."""
+def cpu_baseline(shape, dx, sample_steps, keep=()):
+    """The oracle (libTorch CPU ops in the reference's order) timed on this box's host cores.  `keep`: substep counts k after
+    which the oracle's field is kept (the parity check of the headline configuration: the GPU runs the same k substeps from the
+    same initial condition).  Returns (record, {k: field})."""
     from oracle import marlin_oracle as mo
 
     L = [s * dx for s in shape]
@@ -97,24 +117,30 @@ def cpu_baseline(shape, dx, sample_steps):
     c = torch.from_numpy(splitmix64_uniform(n).reshape(shape))
     # the host cores this process may actually use (the GPU box hands out a CPU share, not the whole host)
     threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    kept = {}
 
-    def sample(nthreads, budget_s, max_steps):
+    def sample(nthreads, budget_s, max_steps, keep_fields):
         torch.set_num_threads(nthreads)
-        cc, N0, _, _ = mo.ch_substep_ops(c, Mbar, Lbar, [], 1e-3, 0, mo.mu_double_well, dom)  # warm-up + history
+        cc, N0, _, _ = mo.ch_substep_ops(c, Mbar, Lbar, [], 1e-3, 0, mo.mu_double_well, dom)  # substep 1 (AB1) = warm-up + history
+        if keep_fields and 1 in keep:
+            kept[1] = cc.clone()
         t0 = time.perf_counter()
         done = 0
         for _ in range(max_steps):
             cc, N1, _, _ = mo.ch_substep_ops(cc, Mbar, Lbar, [N0], 1e-3, 1, mo.mu_double_well, dom)
             N0 = N1
             done += 1
-            if time.perf_counter() - t0 > budget_s:   # bounded sample
+            if keep_fields and done + 1 in keep:
+                kept[done + 1] = cc.clone()
+            # bounded sample (but never before the fields the parity check needs exist)
+            if time.perf_counter() - t0 > budget_s and (not keep_fields or done + 1 >= max(keep, default=0)):
                 break
         return done, time.perf_counter() - t0
 
-    steps_mt, dt_mt = sample(threads, 16.0, sample_steps)
+    steps_mt, dt_mt = sample(threads, 16.0, sample_steps, True)
     # the reference's default is ONE libTorch thread (it only raises the count for --n-threads, TensorProblem.C:77-82)
-    steps_1t, dt_1t = sample(1, 6.0, max(1, sample_steps // 8))
-    return {
+    steps_1t, dt_1t = sample(1, 6.0, max(1, sample_steps // 8), False)
+    rec = {
         "value": n * steps_mt / dt_mt,
         "unit": "grid-point-updates/s",
         "cores": threads,
@@ -124,6 +150,48 @@ def cpu_baseline(shape, dx, sample_steps):
         "single_thread": {"value": n * steps_1t / dt_1t, "cores": 1,
                           "sample": f"{steps_1t} substeps, 1 thread (the reference's default), {dt_1t:.1f} s"},
     }
+    return rec, kept
+
+
+class NativeSlabCH:
+    """One rank of the slab-decomposed solver with the library-owned exchange: mrl_ch_substeps on a slab context with an attached
+    communicator (what the C++ AdamsBashforthMoulton object of marlin_amd/host calls in FFT_SLAB mode)."""
+
+    def __init__(self, api, shape, L, p, world, rank, dev, comm, nsub, carry):
+        self.api, self.p = api, p
+        self.ctx = api.Context(3, shape, L, nranks=world, rank=rank, slab=True, device=dev)
+        self.ctx.attach_comm(comm)
+        self.ctx.set_option(api.OPT_SLAB_NSUB, nsub)
+        self.ctx.set_option(api.OPT_SLAB_CARRY, 1 if carry else 0)
+        shp = self.ctx.recip_shape
+        nspec = shp[0] * shp[1] * self.ctx.spec_pitch
+        self.ring = [torch.zeros(2 * nspec, dtype=torch.float64, device=self.ctx.device) for _ in range(2)]
+        self.c = [self.ctx.empty_real(), self.ctx.empty_real()]
+        self.shape = shape
+        self.reset()
+
+    def reset(self):
+        shp, beg = self.ctx.real_shape, self.ctx.real_begin
+        nx, nyl, nz = shp
+        host = torch.empty(shp, dtype=torch.float64)
+        for ix in range(nx):
+            host[ix] = torch.from_numpy(splitmix64_uniform(nyl * nz, offset=(ix * self.shape[1] + beg[1]) * nz)).reshape(nyl, nz)
+        self.c[0].copy_(host)
+        self.i, self.head, self.n_old, self.started = 0, 1, 0, False
+
+    def set_carry(self, on):
+        self.ctx.set_option(self.api.OPT_SLAB_CARRY, 1 if on else 0)
+
+    def run(self, count, sub_dt=1e-3):
+        if self.started:   # TensorBuffer::advanceState between two solver calls
+            self.head, self.n_old = (self.head + 1) % 2, 1
+        self.head, self.n_old = self.ctx.ch_substeps(self.p, self.c[self.i], self.c[1 - self.i], self.ring, self.head, self.n_old, 2,
+                                                     count, True, sub_dt)
+        self.i = 1 - self.i
+        self.started = True
+
+    def current(self):
+        return self.c[self.i]
 
 
 def main():
@@ -131,85 +199,178 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--grid", dest="n", type=int, default=256, help="base grid edge (per-GPU work = n^3 points)")
-    ap.add_argument("--cpu-steps", type=int, default=24, help="substeps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--workload", default="ch", choices=["ch", "mech"])
+    ap.add_argument("--grid", dest="n", type=int, default=0, help="base grid edge: per-GPU work = n^3 points (default 256; mech: 128)")
+    ap.add_argument("--global-grid", type=int, default=0, help="strong scaling: the GLOBAL grid is G^3 for every N")
+    ap.add_argument("--cpu-steps", type=int, default=24, help="substeps of the CPU baseline sample (0 = skip; N = 1 only)")
+    ap.add_argument("--parity-substeps", default="2,8", help="N = 1: compare the field with the oracle's after these substep counts")
     ap.add_argument("--profile-steps", type=int, default=10)
-    ap.add_argument("--mech-grid", type=int, default=128, help="edge of the de Geus RVE side benchmark (config C); 0 = skip")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke runs)")
-    ap.add_argument("--nsub", type=int, default=2,
-                    help="kz sub-blocks the slab substep is pipelined over (N > 1).  2: the rank-local kernels of 512^3 / 8 take 0.56 ms "
-                         "per substep against 0.60 ms for 4 (smaller launches fill the chip worse), and every extra collective costs "
-                         "~22 us of launch gap on the exchange stream, which is the critical path (DESIGN.md section 4)")
+    ap.add_argument("--mech-grid", type=int, default=128, help="edge of the de Geus RVE side benchmark at N = 1 (config C); 0 = skip")
+    ap.add_argument("--driver", default="native", choices=["native", "python"],
+                    help="N > 1: native = the library owns the exchange (mrl_comm_*); python = marlin_amd/slab.py over torch.distributed")
+    ap.add_argument("--transport", default="tune", choices=["tune", "auto", "peer_store", "peer_copy", "rccl"],
+                    help="native driver: tune = time every transport during the warm-up (identical results required) and keep the fastest")
+    ap.add_argument("--backend", default="nccl", help="python driver: torch.distributed backend (nccl = RCCL; gloo only for smoke runs)")
+    ap.add_argument("--nsub", type=int, default=0, help="kz sub-blocks the slab substep is pipelined over (0: 1 native, 2 python)")
     ap.add_argument("--compute-stream", default="high", choices=["high", "default"],
-                    help="N > 1: run the local passes on a high-priority stream so that they do not share a hardware queue "
-                         "with RCCL's stream (streams of equal priority are multiplexed onto a few queues and then serialise)")
+                    help="python driver: run the local passes on a high-priority stream (does not share a hardware queue with RCCL's)")
     ap.add_argument("--substeps-per-call", type=int, default=0,
-                    help="substeps per solver call (N = 1: one library call, (mrl_ch_substeps = the substep loop of TensorSolver::computeBuffer; the "
-                         "reference's cahnhilliard2.i runs 1000 substeps per solver call).  0 = all timed steps in one call; 1 = one "
-                         "mrl_ch_substep per step.  Within a call the inverse z pass of a substep is fused with the forward z pass of the "
-                         "next one (bit-identical fields; the intermediate real field is not written)")
-    ap.add_argument("--carry", default="auto", choices=["auto", "on", "off"],
-                    help="spectral carry-over (c-hat of a substep = ubar of the previous one, so only mu is transformed "
-                         "forward: 2 slab transposes per substep instead of the reference's 3; results agree to rounding, see "
-                         "include/marlin_hip.h).  auto = on for N > 1 (exchange-bound), off for N = 1 (the reference's data flow). "
-                         "The metric is scored with the reference's 153 B/update either way")
-    ap.add_argument("--force-slab", action="store_true",
-                    help="run the slab pipeline (incl. the RCCL all-to-all calls) even with one rank: a single-GPU check of the N>1 code path")
+                    help="substeps per solver call (mrl_ch_substeps = the substep loop of TensorSolver::computeBuffer; the reference's "
+                         "cahnhilliard2.i runs 1000 per call).  0 = all timed steps in one call; 1 = one library call per substep")
+    ap.add_argument("--carry", default="off", choices=["on", "off"],
+                    help="spectral carry-over for the HEADLINE run (default off at every N = the reference's data flow); the other "
+                         "setting is timed as a variant")
+    ap.add_argument("--no-variants", action="store_true", help="skip the carry-over variant and the local-only timing")
+    ap.add_argument("--exp", type=int, default=0, help="MRL_OPT_EXPERIMENT mask (A/B runs)")
+    ap.add_argument("--force-slab", action="store_true", help="run the slab pipeline with one rank: a single-GPU check of the N > 1 code path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    dev = local_rank % torch.cuda.device_count()   # (several ranks on one GPU only in the single-GPU smoke run)
+    dev = local_rank % torch.cuda.device_count()   # (several ranks on one GPU only in single-GPU smoke runs)
     torch.cuda.set_device(dev)
 
-    from marlin_amd.api import Context, ch_params
-
-    dx = 8.0 * np.pi / 200.0   # examples/cahn_hilliard/cahnhilliard2.i:8-13
-    shape = grid_for(world, args.n)
-    L = [s * dx for s in shape]
-    p = ch_params()             # f = 0.1 c^2 (c-1)^2, M = 0.2, kappa factor -0.001 (cahnhilliard2.i:61-91)
-    sub_dt = 1e-3
-    npts = int(np.prod(shape))
+    from marlin_amd import api
 
     slab = world > 1 or args.force_slab
+    dist = None
     if slab:
         import torch.distributed as dist
-        from marlin_amd.slab import SlabCahnHilliard
-
         if "RANK" not in os.environ:       # --force-slab without a launcher
             os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0", "WORLD_SIZE": "1"})
-
-        if args.backend == "nccl":
+        # the control group (job name agreement, host barriers of this script); the python driver's data path uses --backend
+        if args.driver == "python" and args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group("gloo")
+    if args.workload == "mech":
+        return bench_mech(args, api, world, rank, dev, dist)
+
+    n = args.n or 256
+    dx = 8.0 * np.pi / 200.0   # examples/cahn_hilliard/cahnhilliard2.i:8-13
+    shape = [args.global_grid] * 3 if args.global_grid else grid_for(world, n)
+    L = [s * dx for s in shape]
+    p = api.ch_params()         # f = 0.1 c^2 (c-1)^2, M = 0.2, kappa factor -0.001 (cahnhilliard2.i:61-91)
+    sub_dt = 1e-3
+    npts = int(np.prod(shape))
+    carry = args.carry == "on"
+    transport_report = None
+    comm = None
+
+    def host_max(x):
+        if not slab:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def host_sum(x):
+        if not slab:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t)
+        return float(t.item())
+
+    def barrier():
+        if slab:
+            dist.barrier()
+
+    if slab and args.driver == "native":
+        nsub = args.nsub or 1
+        job = f"mrlbench_{os.environ.get('MASTER_PORT', '0')}"
+        if rank == 0 and os.path.exists(f"/dev/shm/{job}"):
+            os.unlink(f"/dev/shm/{job}")       # a crashed earlier job with the same port
+        barrier()
+        want = {"tune": api.TRANSPORT_AUTO, "auto": api.TRANSPORT_AUTO, "peer_store": api.TRANSPORT_PEER_STORE,
+                "peer_copy": api.TRANSPORT_PEER_COPY, "rccl": api.TRANSPORT_RCCL}[args.transport]
+        comm = api.Comm(job, world, rank, device=dev, transport=want, timeout=120.0)
+        solver = NativeSlabCH(api, shape, L, p, world, rank, dev, comm, nsub, carry)
+        if args.exp:
+            solver.ctx.set_option(api.OPT_EXPERIMENT, args.exp)
+
+        def steps(count):
+            solver.run(count, sub_dt)
+
+        def step():
+            solver.run(1, sub_dt)
+
+        def checksum():
+            cur = solver.current()
+            return host_sum(float((cur * cur).sum(dtype=torch.float64).item()))
+
+        if args.transport == "tune":
+            # every transport this node supports runs the same substeps from the same initial condition: the fields must agree,
+            # and the fastest (max over ranks) carries the timed region
+            cands, tried = [], {}
+            for t in (api.TRANSPORT_PEER_STORE, api.TRANSPORT_PEER_COPY, api.TRANSPORT_RCCL):
+                name = api.TRANSPORT_NAMES[t]
+                try:
+                    comm.set_transport(t)
+                    solver.reset()
+                    steps(3)
+                    torch.cuda.synchronize()
+                    barrier()
+                    t0 = time.perf_counter()
+                    steps(6)
+                    solver.ctx.sync()
+                    ms = host_max((time.perf_counter() - t0) / 6 * 1e3)
+                    tried[name] = {"ms_per_step": round(ms, 4), "checksum": checksum()}
+                    cands.append((ms, t))
+                except api.MarlinHipError as e:     # (the verdict of an unavailable transport is collective: every rank lands here)
+                    tried[name] = {"unavailable": e.message[:160]}
+            sums = [v["checksum"] for v in tried.values() if "checksum" in v]
+            ref_sum = sorted(sums)[len(sums) // 2] if sums else 0.0
+            good = [(ms, t) for ms, t in cands if abs(tried[api.TRANSPORT_NAMES[t]]["checksum"] - ref_sum) <= 1e-12 * abs(ref_sum)]
+            assert good, f"no transport produced a consistent field: {tried}"
+            best = min(good)[1]
+            comm.set_transport(best)
+            transport_report = {"selected": api.TRANSPORT_NAMES[best], "tuned": tried}
+        else:
+            transport_report = {"selected": api.TRANSPORT_NAMES.get(comm.transport, str(comm.transport))}
+        solver.reset()
+        prof_ctx = solver.ctx
+    elif slab:
+        from marlin_amd.slab import SlabCahnHilliard
+        nsub = args.nsub or 2
         if args.compute_stream == "high":
             torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
-        solver = SlabCahnHilliard(3, shape, L, p, world, rank, nsub=args.nsub, carry=args.carry != "off")
+        solver = SlabCahnHilliard(3, shape, L, p, world, rank, nsub=nsub, carry=carry)
         step = solver.substep
 
         def steps(count):   # `count` substeps per solver call: the z passes between two substeps are one kernel
             solver.run(count, advance=True, advance_after=True)
 
-        barrier = dist.barrier
         solver.set_initial(lambda count, offset: splitmix64_uniform(count, offset=offset))
+        prof_ctx = solver.ctx
+        transport_report = {"selected": f"torch.distributed {args.backend} all_to_all_single"}
     else:
-        ctx = Context(3, shape, L)
-        c = [torch.from_numpy(splitmix64_uniform(npts).reshape(shape)).cuda(), None]
+        nsub = 0
+        ctx = api.Context(3, shape, L)
+        if args.exp:
+            ctx.set_option(api.OPT_EXPERIMENT, args.exp)
+        ic = torch.from_numpy(splitmix64_uniform(npts).reshape(shape))
+        c = [ic.cuda(), None]
         c[1] = torch.empty_like(c[0])
         Nh = [ctx.empty_spec(), ctx.empty_spec()]
         state = {"i": 0, "have_old": False}
-        carried = ctx.empty_spec() if args.carry == "on" else None
-
+        carried = ctx.empty_spec() if carry else None
         # Nh is the history ring of the AB2 scheme (two arrays): ring["head"] = slot of Nhat_old[0], the substep writes the other
         # slot; TensorBuffer::advanceState between substeps = the written slot becomes the head
         ring = {"head": 1, "n_old": 0}
+
+        def reset_serial():
+            c[0].copy_(ic)
+            state.update({"i": 0, "have_old": False})
+            ring.update({"head": 1, "n_old": 0})
 
         def step():
             i = state["i"]
@@ -229,71 +390,96 @@ def main():
             state["i"] = 1 - i
             state["have_old"] = True
 
-        def barrier():
-            pass
+        prof_ctx = ctx
+
+    def current():
+        if not slab:
+            return c[state["i"]]
+        return solver.current()
 
     def total_mass():
-        m = (solver.current() if slab else c[state["i"]]).sum(dtype=torch.float64).reshape(1)
-        if slab:
-            m = m if args.backend == "nccl" else m.cpu()
-            dist.all_reduce(m)
-        return float(m.item())
+        return host_sum(float(current().sum(dtype=torch.float64).item()))
 
     mass0 = total_mass()
-    per_call = 1 if (not slab and args.carry == "on") else (args.substeps_per_call if args.substeps_per_call > 0 else args.steps)
+    per_call = 1 if (not slab and carry) else (args.substeps_per_call if args.substeps_per_call > 0 else args.steps)
 
-    def run(nsteps):
-        if per_call == 1:
+    def run(nsteps, pc=None):
+        pc = per_call if pc is None else pc
+        if pc == 1:
             for _ in range(nsteps):
                 step()
             return
         done = 0
         while done < nsteps:
-            n = min(per_call, nsteps - done)
-            steps(n)
-            done += n
+            k = min(pc, nsteps - done)
+            steps(k)
+            done += k
 
+    def timed(nsteps, pc=None):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(nsteps, pc)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        return host_max(time.perf_counter() - t0)
+
+    stats0 = comm.stats() if comm is not None else None
     run(args.warmup)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        torch.cuda.synchronize()
+        stats0 = comm.stats()
+    elapsed = timed(args.steps)
+    stats1 = comm.stats() if comm is not None else None
+
     single_ms = None
     if per_call != 1:
-        # for comparison: the same substeps with one call each (mrl_ch_substep: every substep writes and re-reads c)
+        # for comparison: the same substeps with one library call each (every substep writes and re-reads c)
         n1 = min(args.steps, 50)
         step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(n1):
-            step()
-        torch.cuda.synchronize()
-        single_ms = (time.perf_counter() - t1) / n1 * 1e3
-    if slab:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        single_ms = timed(n1, 1) / n1 * 1e3
 
     # sanity: the field must still be a bounded concentration field, and the scheme conserves mass exactly (the k = 0 mode has
-    # Mbar = Lbar = 0), on every rank count -- a wrong exchange or a missed stream dependency shows up here
-    cur = solver.current() if slab else c[state["i"]]
+    # Mbar = Lbar = 0), on every rank count -- a wrong exchange or a missed dependency shows up here
+    cur = current()
     assert torch.isfinite(cur).all() and 0.0 < float(cur.min()) and float(cur.max()) < 1.0
     mass1 = total_mass()
     assert abs(mass1 - mass0) <= 1e-11 * abs(mass0), (mass0, mass1)
 
     # per-kernel device time with HIP events on the launch stream (event pair per launch)
-    prof_ctx = solver.ctx if slab else ctx
     prof_ctx.set_profiling(True)
     run(args.profile_steps)
     torch.cuda.synchronize()
     kernels = prof_ctx.get_profile()
     prof_ctx.set_profiling(False)
 
+    variants = {}
+    if not args.no_variants and slab and args.driver == "native":
+        # (a) the spectral carry-over variant of the same job; (b) the rank-local kernels alone (exchanges switched off: the
+        # fields are meaningless afterwards, so this comes last)
+        k = min(args.steps, 40)
+        solver.set_carry(not carry)
+        solver.reset()
+        run(3)
+        variants["spectral_carry_over_" + ("off" if carry else "on")] = {"ms_per_step": timed(k) / k * 1e3}
+        solver.set_carry(carry)
+        solver.ctx.set_option(api.OPT_EXPERIMENT, args.exp | 64)
+        solver.reset()
+        run(3)
+        variants["local_kernels_only"] = {"ms_per_step": timed(k) / k * 1e3,
+                                          "note": "the same launches without any exchange or wait: what the rank-local work costs"}
+        solver.ctx.set_option(api.OPT_EXPERIMENT, args.exp)
+    elif not args.no_variants and not slab and not carry:
+        k = min(args.steps, 40)
+        reset_serial()
+        carried = ctx.empty_spec()
+        step()
+        variants["spectral_carry_over_on"] = {"ms_per_step": timed(k, 1) / k * 1e3, "substeps_per_library_call": 1}
+        carried = None
+
+    out = None
     if rank == 0:
         value = npts * args.steps / elapsed
         bpu = algorithmic_bytes_per_update(shape[2], 1)
@@ -301,7 +487,8 @@ def main():
         for k in kernels:
             k["avg_ms"] = k["ms"] / k["launches"]
             k["gbps"] = k["bytes_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9 if k["avg_ms"] > 0 else 0.0
-        dom_k = max(kernels, key=lambda k: k["ms"]) if kernels else None
+        compute = [k for k in kernels if k["bytes_per_launch"] > 0]
+        dom_k = max(compute, key=lambda k: k["ms"]) if compute else None
         roofline = None
         if dom_k:
             roofline = {
@@ -311,14 +498,22 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(dom_k["gbps"] / HBM_PEAK_GBPS, 4),
+                "frac_of_measured_copy_ceiling": round(dom_k["gbps"] / HBM_COPY_GBPS, 4),
                 "traffic": None,
                 "traffic_source": None,
                 "avg_launch_ms": round(dom_k["avg_ms"], 5),
                 "algorithmic_bytes_per_launch": dom_k["bytes_per_launch"],
             }
         if roofline and not slab:
-            tr, src = measured_traffic(dom_k["kernel"], args.n, f"<{args.n}, 1" if dom_k["kernel"] == "ch_C_x_fused" else None)
+            tr, src = measured_traffic(dom_k["kernel"], n, f"<{n}, 1" if dom_k["kernel"] == "ch_C_x_fused" else None)
             roofline["traffic"], roofline["traffic_source"] = tr, src
+        if slab and roofline:
+            roofline["note"] = ("kernels that store into peer memory or wait for it are timed with the exchange they carry; "
+                                "variants.local_kernels_only has the rank-local cost")
+        decomposition = "none"
+        if slab:
+            how = "library-owned exchange (mrl_comm)" if args.driver == "native" else f"torch.distributed {args.backend}"
+            decomposition = f"slab x{world}, {how}, {nsub} kz sub-block(s) in flight"
         out = {
             "metric": "grid-point-updates/sec, 3-D Cahn-Hilliard semi-implicit spectral substep (AB2, fp64)",
             "value": value,
@@ -328,7 +523,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.global_grid else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (splitmix64 uniform [0.44,0.56] initial concentration)",
@@ -336,19 +531,57 @@ def main():
                 "workload": f"3D Cahn-Hilliard {shape[0]}x{shape[1]}x{shape[2]} fp64 semi-implicit spectral step, AB2, "
                             f"f=0.1c^2(c-1)^2, M=0.2, kappa=-0.001, sub_dt=1e-3",
                 "grid": shape,
-                "decomposition": "none" if not slab else f"slab x{world} ({'RCCL' if args.backend == 'nccl' else args.backend} all-to-all, {args.nsub} kz sub-blocks in flight)",
-                "spectral_carry_over": bool(args.carry == "on" or (slab and args.carry == "auto")),
+                "decomposition": decomposition,
+                "driver": (args.driver if slab else "serial"),
+                "spectral_carry_over": carry,
                 "substeps_per_library_call": per_call,
                 "ms_per_step_with_one_call_per_substep": single_ms,
             },
             "substep_algorithmic_bytes_per_update": bpu,
-            "substep_achieved_GBps": value * bpu / 1e9,
-            "substep_frac_of_hbm_peak": value * bpu / 1e9 / HBM_PEAK_GBPS,
+            "substep_model_GBps": value * bpu / 1e9,
+            "substep_model_frac_of_hbm_peak": value * bpu / 1e9 / HBM_PEAK_GBPS / world,
+            "substep_model_frac_of_copy_ceiling": value * bpu / 1e9 / HBM_COPY_GBPS / world,
+            "substep_model_note": "SURVEY 8(d) model bytes (153 B/update) x updates/s per GPU: the metric's yardstick, not the bytes this "
+                                  "implementation moves (its fused pipeline moves fewer; measured traffic: profiles/)",
             "roofline": roofline,
             "kernels": [{"kernel": k["kernel"], "avg_ms": round(k["avg_ms"], 5), "launches_per_step":
                          k["launches"] / args.profile_steps, "algorithmic_GBps": round(k["gbps"], 1)} for k in kernels],
+            "field_checksum": None,
         }
-        if not slab and args.mech_grid > 0:
+        if variants:
+            for v in variants.values():
+                v["value"] = npts / (v["ms_per_step"] * 1e-3)
+            out["variants"] = variants
+        if slab:
+            loc = sum(k["avg_ms"] * k["launches"] / args.profile_steps for k in kernels if k["bytes_per_launch"] > 0)
+            waits = sum(k["avg_ms"] * k["launches"] / args.profile_steps for k in kernels if k["kernel"] == "slab_exchange_wait")
+            ex = {"transport": transport_report, "ranks": world,
+                  "kernel_ms_per_step_incl_peer_stores": round(loc, 4), "exposed_wait_ms_per_step": round(waits, 4)}
+            if stats0 is not None and stats1 is not None:
+                ex["exchanges_per_step"] = (stats1["exchanges"] - stats0["exchanges"]) / args.steps
+                ex["bytes_sent_to_peers_per_step_rank0"] = (stats1["bytes_sent"] - stats0["bytes_sent"]) / args.steps
+                ex["link_GBps_out_rank0"] = ex["bytes_sent_to_peers_per_step_rank0"] / (elapsed / args.steps) / 1e9
+            out["exchange"] = ex
+    # the global field checksum (all ranks take part): lets two drivers / transports be compared from their JSON lines
+    cs = host_sum(float((current() * current()).sum(dtype=torch.float64).item())) if slab else float((cur * cur).sum(dtype=torch.float64).item())
+    if rank == 0:
+        out["field_checksum"] = {"sum_c_squared": cs, "after_substeps": "all of this run (fixed for fixed flags)"}
+
+    if rank == 0 and not slab:
+        if args.cpu_steps > 0:
+            keep = tuple(int(x) for x in args.parity_substeps.split(",") if x)
+            out["cpu_baseline"], kept = cpu_baseline(shape, dx, args.cpu_steps, keep)
+            # parity of the headline configuration: the same k substeps from the same initial condition, HIP path vs oracle
+            diffs = {}
+            for kk in sorted(kept):
+                reset_serial()
+                steps(kk) if kk > 1 else step()
+                torch.cuda.synchronize()
+                diffs[str(kk)] = float((current().cpu() - kept[kk]).abs().max().item())
+            out["parity"] = {"against": "oracle (libTorch CPU ops in the reference's order), same initial condition", "substeps": sorted(kept),
+                             "max_abs_diff": diffs, "tolerance": PARITY_TOL, "ok": all(v <= PARITY_TOL for v in diffs.values())}
+            assert out["parity"]["ok"], out["parity"]
+        if args.mech_grid > 0:
             # side measurement (BASELINE configs[2]): de Geus RVE Newton-CG, time per CG iteration, SURVEY 8(d) byte model
             from tools.mech_bench import run as mech_run
             del c, Nh
@@ -358,8 +591,15 @@ def main():
                                 "ms_per_cg_iteration": m["ms_per_cg_iteration"], "cg_iterations_per_substep": m["cg_its"],
                                 "algorithmic_bytes_per_point_per_cg_iteration": m["algorithmic_bytes_per_point_per_cg_iteration"],
                                 "achieved_GBps": m["achieved_GBps"], "frac_of_hbm_peak": m["achieved_GBps"] / HBM_PEAK_GBPS}
-        if not slab and args.cpu_steps > 0:
-            out["cpu_baseline"] = cpu_baseline(shape, dx, args.cpu_steps)
+    finish(out, rank, slab, dist, comm, [prof_ctx])
+
+
+def finish(out, rank, slab, dist, comm, ctxs):
+    for cx in ctxs:
+        if cx is not None:
+            cx.close()
+    if comm is not None:
+        comm.close()
     if slab:
         dist.destroy_process_group()
     if rank == 0:
@@ -367,6 +607,81 @@ def main():
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
+
+
+def bench_mech(args, api, world, rank, dev, dist):
+    """BASELINE configs[2] (N = 1) / configs[4] (N = 8: 256^3): de Geus finite-strain RVE, Newton-CG with the FFT-applied Gamma
+    operator through mrl_mech_newton_cg; a step = one CG iteration of the whole grid.  Cubic inclusion phase[-s:, :s, -s:] = 1,
+    s = 9n/32 (test/src/tensor_computes/PhaseMechanicsTest.C:36-45), K = 0.833 / 8.33, mu = 0.386 / 3.86
+    (examples/degeus_mechanics/mech.i:23-38), shear ramp, l_tol = 1e-2, nl tolerances 2e-2."""
+    slab = world > 1 or args.force_slab
+    n = args.n or 128
+    shape = [args.global_grid] * 3 if args.global_grid else grid_for(world, n)
+    L = [2.0 * np.pi] * 3
+    comm = None
+    if slab:
+        job = f"mrlbench_{os.environ.get('MASTER_PORT', '0')}"
+        if rank == 0 and os.path.exists(f"/dev/shm/{job}"):
+            os.unlink(f"/dev/shm/{job}")
+        dist.barrier()
+        want = {"tune": api.TRANSPORT_AUTO, "auto": api.TRANSPORT_AUTO, "peer_store": api.TRANSPORT_PEER_STORE,
+                "peer_copy": api.TRANSPORT_PEER_COPY, "rccl": api.TRANSPORT_RCCL}[args.transport]
+        comm = api.Comm(job, world, rank, device=dev, transport=want, timeout=120.0)
+        ctx = api.Context(3, shape, L, nranks=world, rank=rank, slab=True, device=dev)
+        ctx.attach_comm(comm)
+    else:
+        ctx = api.Context(3, shape, L)
+    nx, ny, nz = shape
+    yb, nyl = ctx.real_begin[1], ctx.real_shape[1]
+    phase = torch.zeros(nx, nyl, nz, dtype=torch.float64)
+    sx, sy, sz = 9 * nx // 32, 9 * ny // 32, 9 * nz // 32
+    ylo, yhi = max(0, 0 - yb), min(nyl, sy - yb)       # global y in [0, sy)
+    if yhi > ylo:
+        phase[-sx:, ylo:yhi, -sz:] = 1.0
+    K = ((1.0 - phase) * 0.833 + phase * 8.33).cuda()
+    mu = ((1.0 - phase) * 0.386 + phase * 3.86).cuda()
+    F = torch.eye(3, dtype=torch.float64).expand(nx, nyl, nz, 3, 3).contiguous().cuda()
+    sub_dt = 0.01 / 10
+
+    def solve(it, F):
+        applied = torch.eye(3, dtype=torch.float64)
+        applied[0, 1] += it * sub_dt
+        applied = (applied - ctx.average(F)).cuda()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        Fnew, P, st = ctx.mech_newton_cg(F, K, mu, applied, l_tol=1e-2, nl_rel_tol=2e-2, nl_abs_tol=2e-2)
+        torch.cuda.synchronize()
+        return Fnew, st, time.perf_counter() - t0
+
+    F, st, _ = solve(0, F)                 # warm-up (buffers, exchange pipes)
+    tot_t, tot_its, newton, substeps = 0.0, 0, [], max(1, min(args.steps, 3))
+    for it in range(1, substeps + 1):
+        F, st, dt = solve(it, F)
+        tot_t += dt
+        tot_its += st["cg_its_total"]
+        newton.append(st["newton_its"])
+    if slab:
+        t = torch.tensor([tot_t], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tot_t = float(t.item())
+    npts = nx * ny * nz
+    out = None
+    if rank == 0:
+        bpi = mech_bytes_per_point(nz)
+        ms = tot_t / max(tot_its, 1) * 1e3
+        out = {"metric": "grid-point CG-iteration updates/sec, de Geus finite-strain RVE Newton-CG (fp64)",
+               "value": npts * tot_its / tot_t, "unit": "grid-point-CG-iterations/s", "n_gpus": world, "steps": tot_its, "warmup": 1,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if args.global_grid else "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic (cubic inclusion RVE)",
+               "config": {"workload": f"de Geus finite-strain hyperelastic RVE {nx}x{ny}x{nz}, Newton-CG with FFT-applied Gamma operator",
+                          "grid": shape, "decomposition": "none" if not slab else f"slab x{world}, library-owned exchange (mrl_comm)",
+                          "newton_iterations_per_substep": newton, "cg_iterations": tot_its,
+                          "transport": api.TRANSPORT_NAMES.get(comm.transport) if comm is not None else None},
+               "algorithmic_bytes_per_point_per_cg_iteration": bpi,
+               "model_GBps_per_gpu": bpi * npts * tot_its / tot_t / 1e9 / world,
+               "model_frac_of_hbm_peak": bpi * npts * tot_its / tot_t / 1e9 / world / HBM_PEAK_GBPS,
+               "model_frac_of_copy_ceiling": bpi * npts * tot_its / tot_t / 1e9 / world / HBM_COPY_GBPS}
+    finish(out, rank, slab, dist, comm, [ctx])
 
 
 if __name__ == "__main__":

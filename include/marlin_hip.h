@@ -209,7 +209,13 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
  *                 the next substep (TensorBuffer<T>::advanceState; pass 0 while timeStep() <= 1, TensorProblem.C:455).
  *                 On return the newest Nhat is in slot (*head + 1) % ring_size -- the caller's own advanceState makes it the head.
  *   d_mu        : optional, f'(c) of the last substep's input field (what the mu buffer holds after the call).
- * c_in and c_out must not alias when count > 1 on unplanned shapes. */
+ * c_in and c_out must not alias when count > 1 on unplanned shapes.
+ *   advance     : bit mask.  MRL_SUBSTEPS_ADVANCE (1): rotate the history between the substeps (see above).
+ *                 MRL_SUBSTEPS_DT_CHANGED (2): the time step size differs from the previous step's (_dt != _dt_old): the first
+ *                 predictor_order - 1 substeps of the call run at first order whatever the history holds, the history itself keeps
+ *                 advancing (AdamsBashforthMoulton.C:75, 88-91: order = min(_substep < _predictor_order && dt_changed ? 0 : n_old, ...)). */
+#define MRL_SUBSTEPS_ADVANCE 1
+#define MRL_SUBSTEPS_DT_CHANGED 2
 int mrl_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_c_out, double *const *d_Nhat_ring,
                     int ring_size, int *head, int *n_old, int predictor_order, int count, int advance, double sub_dt,
                     double *d_mu);

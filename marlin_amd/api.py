@@ -258,13 +258,13 @@ class Context:
                                             sub_dt, _ptr(cbar), _ptr(mu), carry))
 
     def ch_substeps(self, p: MrlChParams, c_in, c_out, ring: Sequence[torch.Tensor], head: int, n_old: int, predictor_order: int,
-                    count: int, advance: bool, sub_dt: float, mu=None):
+                    count: int, advance: bool, sub_dt: float, mu=None, dt_changed: bool = False):
         """`count` substeps in one call (TensorSolver::computeBuffer's loop) -> (head, n_old) after the call; the newest Nhat is
         in ring[(head + 1) % len(ring)]"""
         arr = (C.c_void_p * len(ring))(*[t.data_ptr() for t in ring])
         h, n = C.c_int32(head), C.c_int32(n_old)
         self._check(self.lib.mrl_ch_substeps(self.h, C.byref(p), _ptr(c_in), _ptr(c_out), arr, len(ring), C.byref(h), C.byref(n),
-                                             predictor_order, count, 1 if advance else 0, sub_dt, _ptr(mu)))
+                                             predictor_order, count, (1 if advance else 0) | (2 if dt_changed else 0), sub_dt, _ptr(mu)))
         return h.value, n.value
 
     def kspace_abm(self, out, ubar0, N: Sequence[torch.Tensor], coef: Sequence[float], L, dt: float):

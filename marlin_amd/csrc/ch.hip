@@ -295,13 +295,13 @@ int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const doub
 }
 
 int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *const *ring, int ring_size,
-                      int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu);
+                      int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu, bool dt_changed);
 // fast fused path (ch_fused.hip); returns MRL_ERR_UNSUPPORTED when the shape has no fast kernels
 int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new,
                      const double *const *Nhat_old, int order, double sub_dt, double *cbar, double *mu, int carry);
 // slab contexts with a communicator (slab_driver.hip)
 int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, double *c_out, double *const *ring, int ring_size,
-                     int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu);
+                     int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu, bool dt_changed);
 
 }  // namespace mrl
 
@@ -334,13 +334,13 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
     if (order == 0) {
       double *ring0[1] = {d_Nhat_new};
       int head = 0, n_old = 0;
-      return slab_ch_substeps(ctx, p, d_c_in, d_c_out, ring0, 1, &head, &n_old, 0, 1, 0, sub_dt, d_mu);
+      return slab_ch_substeps(ctx, p, d_c_in, d_c_out, ring0, 1, &head, &n_old, 0, 1, 0, sub_dt, d_mu, false);
     }
     double *ring[5];
     for (int i = 0; i < order; ++i) ring[order - 1 - i] = const_cast<double *>(d_Nhat_old[i]);
     ring[order] = d_Nhat_new;
     int head = order - 1, n_old = order;
-    return slab_ch_substeps(ctx, p, d_c_in, d_c_out, ring, order + 1, &head, &n_old, order, 1, 0, sub_dt, d_mu);
+    return slab_ch_substeps(ctx, p, d_c_in, d_c_out, ring, order + 1, &head, &n_old, order, 1, 0, sub_dt, d_mu, false);
   }
 
   if (carry != MRL_CARRY_NONE && carry != MRL_CARRY_OUT && carry != MRL_CARRY_IN)
@@ -452,6 +452,8 @@ int mrl_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, 
   ChP cp;
   MRL_TRY(ch_check_params(ctx, p, cp));
   const int pred = predictor_order - 1;
+  const bool dt_changed = (advance & MRL_SUBSTEPS_DT_CHANGED) != 0;
+  advance &= MRL_SUBSTEPS_ADVANCE;
   if (!d_c_in || !d_c_out || !d_Nhat_ring || !head || !n_old || count < 1)
     return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substeps: bad argument");
   if (predictor_order < 1 || predictor_order > 5) return set_error(ctx, MRL_ERR_INVALID, "predictor order %d out of range", predictor_order);
@@ -460,8 +462,8 @@ int mrl_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, 
   for (int i = 0; i < ring_size; ++i)
     if (!d_Nhat_ring[i]) return set_error(ctx, MRL_ERR_INVALID, "history ring entry %d missing", i);
   if (ctx->slab)  // the library owns the exchanges (communicator attached with mrl_ctx_attach_comm)
-    return slab_ch_substeps(ctx, p, d_c_in, d_c_out, d_Nhat_ring, ring_size, head, n_old, pred, count, advance, sub_dt, d_mu);
-  int rc = ch_substeps_fused(ctx, cp, d_c_in, d_c_out, d_Nhat_ring, ring_size, head, n_old, pred, count, advance, sub_dt, d_mu);
+    return slab_ch_substeps(ctx, p, d_c_in, d_c_out, d_Nhat_ring, ring_size, head, n_old, pred, count, advance, sub_dt, d_mu, dt_changed);
+  int rc = ch_substeps_fused(ctx, cp, d_c_in, d_c_out, d_Nhat_ring, ring_size, head, n_old, pred, count, advance, sub_dt, d_mu, dt_changed);
   if (rc != MRL_ERR_UNSUPPORTED) return rc;
   // generic shapes: one mrl_ch_substep per substep, the intermediate fields ping-pong between d_c_out and a scratch array
   const long long nreal = real_count_local(ctx);
@@ -470,7 +472,7 @@ int mrl_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, 
   const double *src = d_c_in;
   for (int k = 0; k < count; ++k) {
     double *dst = ((count - 1 - k) % 2 == 0) ? d_c_out : tmp;   // the last substep lands in d_c_out
-    const int order = *n_old < pred ? *n_old : pred;
+    const int order = (dt_changed && k < pred) ? 0 : (*n_old < pred ? *n_old : pred);   // AdamsBashforthMoulton.C:90-91
     const int slot_new = (*head + 1) % ring_size;
     const double *old[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < order; ++i) old[i] = d_Nhat_ring[((*head - i) % ring_size + ring_size) % ring_size];

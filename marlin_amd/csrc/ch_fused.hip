@@ -317,7 +317,7 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
 // the substep writes its Nhat into slot (*head + 1) % ring_size and, if `advance`, that slot becomes the head before the next
 // substep (TensorBuffer<T>::advanceState between substeps).  After the call the newest Nhat is in slot (*head + 1) % ring_size.
 int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *const *ring, int ring_size,
-                      int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu) {
+                      int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu, bool dt_changed) {
   if (!fast_path_ok(ctx)) return MRL_ERR_UNSUPPORTED;
   const Geo g = geo_of(ctx);
   const long long nx = g.nx, ny = g.ny, nz = g.nz, nzc = g.nzc;
@@ -355,7 +355,7 @@ int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c
       ProfScope ps(ctx, "ch_B_y_fwd", 4.0 * h);
       MRL_TRY(pass_axis(ctx, 1, false, 2, w_c, w_mu, w_c, w_mu, true));
     }
-    const int order = *n_old < pred ? *n_old : pred;
+    const int order = (dt_changed && k < pred) ? 0 : (*n_old < pred ? *n_old : pred);   // AdamsBashforthMoulton.C:90-91
     const int slot_new = (*head + 1) % ring_size;
     {
       ProfScope ps(ctx, "ch_C_x_fused", (4.0 + order) * h);

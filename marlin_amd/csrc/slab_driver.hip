@@ -28,6 +28,7 @@ struct ChPipe {
   bool built = false;
   int nsub = 0, transport = -1;
   bool carry = false, fast = false;
+  bool local_only = false;            // MRL_OPT_EXPERIMENT bit 64: no exchange at all (timing of the rank-local kernels)
   std::vector<Xchg> fwd2, fwd1, inv;  // two-field forward, one-field forward (carry-over), inverse; one per sub-block
   double *cbar = nullptr;             // carried spectrum [x_me][ny][pitch]
 };
@@ -124,7 +125,8 @@ static int ch_pipe_build(mrl_ctx *ctx) {
   int nsub = ctx->opt_nsub < 1 ? 1 : ctx->opt_nsub;
   if (nsub > nzc) nsub = (int)nzc;
   const bool carry = ctx->opt_carry != 0;
-  if (P.built && P.nsub == nsub && P.carry == carry && P.transport == c->transport) return MRL_OK;
+  const bool local_only = (ctx->exp & 64) != 0;
+  if (P.built && P.nsub == nsub && P.carry == carry && P.transport == c->transport && P.local_only == local_only) return MRL_OK;
   if (P.built && (P.nsub != nsub || P.carry != carry)) {
     MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ch_pipe_destroy(ctx, P);
@@ -160,10 +162,11 @@ static int ch_pipe_build(mrl_ctx *ctx) {
     MRL_COMM(ctx, comm_barrier(c));
   }
   for (int s = 0; s < nsub; ++s) {
-    MRL_TRY(prepare_table(ctx, &P.fwd2[s], P.fast));
-    MRL_TRY(prepare_table(ctx, &P.inv[s], P.fast));
-    if (carry) MRL_TRY(prepare_table(ctx, &P.fwd1[s], P.fast));
+    MRL_TRY(prepare_table(ctx, &P.fwd2[s], P.fast && !local_only));
+    MRL_TRY(prepare_table(ctx, &P.inv[s], P.fast && !local_only));
+    if (carry) MRL_TRY(prepare_table(ctx, &P.fwd1[s], P.fast && !local_only));
   }
+  P.local_only = local_only;
   P.nsub = nsub;
   P.carry = carry;
   P.transport = c->transport;
@@ -171,9 +174,23 @@ static int ch_pipe_build(mrl_ctx *ctx) {
   return MRL_OK;
 }
 
+// post / wait with their stream time visible to the profiler (the wait is where an exposed exchange shows up)
+static int post(mrl_ctx *ctx, Xchg *x, bool kernel_signalled, bool local_only) {
+  if (local_only) return MRL_OK;
+  ProfScope ps(ctx, "slab_exchange_post");
+  MRL_COMM(ctx, xchg_post(ctx->comm, x, ctx->stream, kernel_signalled));
+  return MRL_OK;
+}
+static int wait(mrl_ctx *ctx, Xchg *x, bool local_only) {
+  if (local_only) return MRL_OK;
+  ProfScope ps(ctx, "slab_exchange_wait");
+  MRL_COMM(ctx, xchg_wait(ctx->comm, x, ctx->stream));
+  return MRL_OK;
+}
+
 // the substep loop of TensorSolver::computeBuffer (TensorSolver.C:93-109) over slab transforms; ring semantics as mrl_ch_substeps
 int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, double *c_out, double *const *ring, int ring_size,
-                     int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu) {
+                     int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu, bool dt_changed) {
   MRL_TRY(need_comm(ctx, "mrl_ch_substeps"));
   ChP cp;
   MRL_TRY(ch_check_params(ctx, p, cp));
@@ -182,6 +199,7 @@ int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, d
   mrl_comm *c = ctx->comm;
   hipStream_t st = ctx->stream;
   const int nsub = P.nsub;
+  const bool lo = P.local_only;
   for (int k = 0; k < count; ++k) {
     const int mode = !P.carry ? MRL_CARRY_NONE : (k == 0 ? MRL_CARRY_OUT : MRL_CARRY_IN);
     double *mu_k = (k == count - 1) ? mu : nullptr;
@@ -190,7 +208,7 @@ int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, d
     } else {
       MRL_TRY(mrl_slab_ch_z_inv_fwd(ctx, p, mu_k, mode));
     }
-    const int order = *n_old < pred ? *n_old : pred;
+    const int order = (dt_changed && k < pred) ? 0 : (*n_old < pred ? *n_old : pred);   // AdamsBashforthMoulton.C:90-91
     const int slot_new = (*head + 1) % ring_size;
     const double *old[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < order; ++i) old[i] = ring[((*head - i) % ring_size + ring_size) % ring_size];
@@ -202,30 +220,30 @@ int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, d
       if (P.fast) {
         const SignalArgs sig = xchg_signal_args(c, &F[s], 0);
         MRL_TRY(slab_ch_x_fwd_fast(ctx, (int)k0, (int)ks, reinterpret_cast<cplx *const *>(F[s].d_tab), sig, mode));
-        MRL_COMM(ctx, xchg_post(c, &F[s], st, sig.counter != nullptr));
+        MRL_TRY(post(ctx, &F[s], sig.counter != nullptr, lo));
       } else {
         MRL_TRY(gen_x_fwd(ctx, k0, ks, F[s].send, mode));
-        MRL_COMM(ctx, xchg_post(c, &F[s], st));
+        MRL_TRY(post(ctx, &F[s], false, lo));
       }
     }
     for (int s = 0; s < nsub; ++s) {
       long long k0, ks;
       MRL_TRY(slab_sub_range(ctx, s, nsub, &k0, &ks));
-      MRL_COMM(ctx, xchg_wait(c, &F[s], st));
+      MRL_TRY(wait(ctx, &F[s], lo));
       MRL_COMM(ctx, xchg_begin(c, &P.inv[s], st));
       const double *recv = static_cast<const double *>(F[s].recv.local);
       if (P.fast) {
         const SignalArgs sig = xchg_signal_args(c, &P.inv[s], 0);
         MRL_TRY(slab_ch_kspace_fast(ctx, cp, (int)k0, (int)ks, recv, reinterpret_cast<cplx *const *>(P.inv[s].d_tab), sig, ring[slot_new], old,
                                     order, sub_dt, P.cbar, mode));
-        MRL_COMM(ctx, xchg_post(c, &P.inv[s], st, sig.counter != nullptr));
+        MRL_TRY(post(ctx, &P.inv[s], sig.counter != nullptr, lo));
       } else {
         MRL_TRY(gen_kspace(ctx, cp, k0, ks, recv, P.inv[s].send, ring[slot_new], old, order, sub_dt, P.cbar, mode));
-        MRL_COMM(ctx, xchg_post(c, &P.inv[s], st));
+        MRL_TRY(post(ctx, &P.inv[s], false, lo));
       }
     }
     for (int s = 0; s < nsub; ++s) {
-      MRL_COMM(ctx, xchg_wait(c, &P.inv[s], st));
+      MRL_TRY(wait(ctx, &P.inv[s], lo));
       MRL_TRY(mrl_slab_ch_x_inv(ctx, s, nsub, static_cast<const double *>(P.inv[s].recv.local)));
     }
     if (advance && k < count - 1) {  // TensorSolver.C:105-106

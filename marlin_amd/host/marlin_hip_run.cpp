@@ -17,10 +17,20 @@
 //        (test/tests/kks/KKS_no_flux_bc.i: ReciprocalMatDiffusion, ReciprocalAllenCahn, ParsedCompute derivatives, ABM order 3)
 //   marlin-hip-run problem=mechanics dim=3 nx=16 ny=16 nz=16 substeps=10 num_steps=3 dt=0.01 l_tol=1e-2 nl_rel_tol=2e-2
 //        nl_abs_tol=2e-2 out=dir          (test/tests/mechanics/mech3d.i)
+//
+// parallel_mode=FFT_SLAB nranks=P  (test/tests/cahnhilliard/tests:58-70 runs cahnhilliard.i this way under `mpiexec -n 2`):
+//   one process per rank / GPU.  Without rank=..., this process is only the launcher: it starts P copies of itself (rank=0..P-1,
+//   one job name) BEFORE anything touches the GPU and waits for them, the way mpiexec would.  Every rank reads the initial
+//   condition of the GLOBAL grid and keeps its y-slab, and writes <out>/<buffer>.<frame>.rank<r>.bin = its slab (the reference's
+//   rankNNNN files).  device=r (default: rank modulo the visible GPUs; device=0 puts all ranks on one GPU, which the library's
+//   IPC transport supports), transport=1|2|3 (peer stores, copy engines, RCCL).
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "marlin_host.h"
 
@@ -35,10 +45,12 @@ static std::string arg(const std::string & k, const std::string & dflt = "")
 static double argd(const std::string & k, double dflt) { return g_args.count(k) ? std::atof(g_args[k].c_str()) : dflt; }
 static long argi(const std::string & k, long dflt) { return g_args.count(k) ? std::atol(g_args[k].c_str()) : dflt; }
 
+static std::string g_rank_suffix;  // ".rank<r>" in FFT_SLAB runs
+
 static void dump(const std::string & dir, const std::string & name, int frame, const DeviceTensor & t)
 {
   const auto h = t.toHost();
-  const std::string path = dir + "/" + name + "." + std::to_string(frame) + ".bin";
+  const std::string path = dir + "/" + name + "." + std::to_string(frame) + g_rank_suffix + ".bin";
   std::ofstream f(path, std::ios::binary);
   if (!f)
     mooseError("cannot write " + path);
@@ -54,11 +66,29 @@ static std::vector<double> read_bin(const std::string & path, std::size_t count)
   return v;
 }
 
+// the rank's block [nx][y_begin .. y_begin + ny_local)[nz] of a global row-major field (parallel_mode NONE: the field itself)
+static std::vector<double> local_block(const DomainAction & domain, const std::vector<double> & global, int ncomp = 1)
+{
+  if (!domain.isSlab())
+    return global;
+  const auto & g = domain.getShape();
+  const auto & l = domain.getLocalShape();
+  const auto & b = domain.getLocalBegin();
+  const int dim = domain.getDim();
+  const int64_t nx = g[0], ny = g[1], nz = dim == 3 ? g[2] : 1, nyl = l[1];
+  std::vector<double> out((std::size_t)(nx * nyl * nz * ncomp));
+  for (int64_t i = 0; i < nx; ++i)
+    for (int64_t j = 0; j < nyl; ++j)
+      std::copy(global.begin() + ((i * ny + b[1] + j) * nz) * ncomp, global.begin() + ((i * ny + b[1] + j + 1) * nz) * ncomp,
+                out.begin() + ((i * nyl + j) * nz) * ncomp);
+  return out;
+}
+
 static int run_cahnhilliard(DomainAction & domain, const std::string & out)
 {
   TensorProblem problem(domain);
   const std::size_t n = domain.getNumberOfCells();
-  problem.getBuffer("c") = DeviceTensor::fromHost(read_bin(arg("ic"), n));  // RandomTensor IC (seed-0 torch stream)
+  problem.getBuffer("c") = DeviceTensor::fromHost(local_block(domain, read_bin(arg("ic"), domain.getGlobalNumberOfCells())));  // RandomTensor IC
   problem.getBuffer("mu") = DeviceTensor::zeros(n);                        // ConstantTensor
   AdamsBashforthMoulton::Params p;
   p.substeps = (unsigned int)argi("substeps", 1);
@@ -113,6 +143,19 @@ static int run_cahnhilliard(DomainAction & domain, const std::string & out)
   else
     solver = std::make_unique<AdamsBashforthMoulton>(problem, "solver", p);
   Transient ex(problem, *solver, argd("dt", 1e-3));
+  // dt_sequence=a,b,c,...: a [TimeStepper] that hands out these step sizes in turn (the last one repeats)
+  std::vector<double> dts;
+  {
+    std::string seq = arg("dt_sequence");
+    while (!seq.empty())
+    {
+      const auto comma = seq.find(',');
+      dts.push_back(std::atof(seq.substr(0, comma).c_str()));
+      seq = comma == std::string::npos ? "" : seq.substr(comma + 1);
+    }
+  }
+  if (!dts.empty())
+    ex.setTimeStepper([dts](int t_step) { return dts[std::min<std::size_t>((std::size_t)t_step - 1, dts.size() - 1)]; });
   dump(out, "c", 0, problem.getBuffer("c"));
   ex.execute((int)argi("num_steps", 1), [&](int step) {
     dump(out, "c", step, problem.getBuffer("c"));
@@ -174,7 +217,7 @@ static int run_mechanics(DomainAction & domain, const std::string & out)
   TensorProblem problem(domain);
   const int dim = domain.getDim();
   const auto & shape = domain.getShape();
-  const std::size_t n = domain.getNumberOfCells();
+  const std::size_t n = domain.getGlobalNumberOfCells();
   // phase = prod_d (cos(x_d)/2 + 0.5); K = (1-phase)*Ka + phase*Kb; mu likewise   (mech3d.i:14-35)
   std::vector<std::vector<double>> ax;
   for (int d = 0; d < dim; ++d)
@@ -201,9 +244,9 @@ static int run_mechanics(DomainAction & domain, const std::string & out)
     for (int i = 0; i < dim; ++i)
       F[e * dim * dim + i * dim + i] = 1.0;  // RankTwoIdentity
   }
-  problem.getBuffer("K") = DeviceTensor::fromHost(K);
-  problem.getBuffer("mu") = DeviceTensor::fromHost(mu);
-  problem.getBuffer("F") = DeviceTensor::fromHost(F);
+  problem.getBuffer("K") = DeviceTensor::fromHost(local_block(domain, K));
+  problem.getBuffer("mu") = DeviceTensor::fromHost(local_block(domain, mu));
+  problem.getBuffer("F") = DeviceTensor::fromHost(local_block(domain, F, dim * dim));
 
   auto root = std::make_shared<ComputeGroup>(problem, "root");
   root->add(std::make_shared<MacroscopicShearTensor>(problem, "applied_strain", "applied_strain", "F"));
@@ -223,9 +266,12 @@ static int run_mechanics(DomainAction & domain, const std::string & out)
   ComputeDisplacements displacements(problem, "displacements", "disp", "F");
   ComputeVonMisesStress vonmises(problem, "vonmises", "sV");
   ex.execute((int)argi("num_steps", 1), [&](int step) {
-    displacements.computeBuffer();
+    if (!domain.isSlab())  // (ComputeDisplacements interpolates over the global grid: serial domains only)
+    {
+      displacements.computeBuffer();
+      dump(out, "disp", step - 1, problem.getBuffer("disp"));
+    }
     vonmises.computeBuffer();
-    dump(out, "disp", step - 1, problem.getBuffer("disp"));
     dump(out, "sV", step - 1, problem.getBuffer("sV"));
     dump(out, "F", step - 1, problem.getBuffer("F"));  // frame 0 = end of step 1 (output on TIMESTEP_END only)
     const auto & st = mech->stats();
@@ -672,6 +718,42 @@ static int run_gradient(DomainAction & domain, const std::string & out)
   return 0;
 }
 
+// parallel_mode=FFT_SLAB without rank=: start one child per rank (fork + exec of this binary; the parent has made no HIP call) and
+// return the worst exit code.  The job name carries the parent's pid, so concurrent runs do not share a bootstrap segment.
+static int launch_ranks(int argc, char ** argv, int nranks)
+{
+  if (nranks < 1 || nranks > 64)
+    paramError("nranks", "1 <= nranks <= 64");
+  const std::string job = "job=mrlrun_" + std::to_string((long)getpid());
+  std::vector<pid_t> kids;
+  for (int r = 0; r < nranks; ++r)
+  {
+    const pid_t pid = fork();
+    if (pid < 0)
+      mooseError("fork failed");
+    if (pid == 0)
+    {
+      const std::string rk = "rank=" + std::to_string(r);
+      std::vector<char *> av(argv, argv + argc);
+      av.push_back(const_cast<char *>(rk.c_str()));
+      av.push_back(const_cast<char *>(job.c_str()));
+      av.push_back(nullptr);
+      execv("/proc/self/exe", av.data());
+      std::perror("execv");
+      _exit(127);
+    }
+    kids.push_back(pid);
+  }
+  int rc = 0;
+  for (const pid_t k : kids)
+  {
+    int st = 0;
+    if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0)
+      rc = 1;
+  }
+  return rc;
+}
+
 int main(int argc, char ** argv)
 {
   for (int i = 1; i < argc; ++i)
@@ -702,7 +784,27 @@ int main(int argc, char ** argv)
       const std::string m = arg(mx[d]);  // "2pi", "4pi", "6pi" or a number
       hi.push_back(m.size() > 2 && m.substr(m.size() - 2) == "pi" ? std::atof(m.c_str()) * M_PI : argd(mx[d], 1.0));
     }
-    DomainAction domain(dim, n, hi, lo);
+    DomainAction::Parallel par;
+    if (arg("parallel_mode", "NONE") == "FFT_SLAB")
+    {
+      par.mode = DomainAction::ParallelMode::FFT_SLAB;
+      par.nranks = (int)argi("nranks", 1);
+      if (!g_args.count("rank"))
+        return launch_ranks(argc, argv, par.nranks);  // nothing has touched the GPU yet
+      par.rank = (int)argi("rank", 0);
+      par.job = arg("job", "marlin_hip_run");
+      par.transport = (int)argi("transport", MRL_TRANSPORT_AUTO);
+      int ndev = 0;
+      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        mooseError("no HIP device available");
+      par.device = g_args.count("device") ? (int)argi("device", 0) : par.rank % ndev;
+      g_rank_suffix = ".rank" + std::to_string(par.rank);
+    }
+    else if (arg("parallel_mode", "NONE") != "NONE")
+      paramError("parallel_mode", "NONE or FFT_SLAB (FFT_PENCIL is multi-node: not built)");
+    DomainAction domain(dim, n, hi, lo, par);
+    if (domain.isSlab() && g_args.count("nsub"))
+      domain.check(mrl_ctx_set_option(domain.ctx(), MRL_OPT_SLAB_NSUB, argi("nsub", 1)));
     const std::string out = arg("out", ".");
     const std::string problem = arg("problem");
     if (problem == "cahnhilliard")

@@ -123,13 +123,33 @@ private:
   std::size_t _max_states = 0;
 };
 
-/// DomainAction as a math service
+/// [Domain] parallel_mode and the placement of this process in the job
+enum class DomainParallelMode
+{
+  NONE,
+  FFT_SLAB
+};
+struct DomainParallel
+{
+  DomainParallelMode mode = DomainParallelMode::NONE;
+  int nranks = 1, rank = 0;
+  std::string job;  ///< identifies the job on the node (the MOOSE shim broadcasts one string over MPI)
+  int transport = MRL_TRANSPORT_AUTO;
+  int device = -1;  ///< HIP device of this rank (-1: the current one)
+};
+
+/// DomainAction as a math service.  parallel_mode = FFT_SLAB (DomainAction.C:510-566): this process is rank `rank` of `nranks`
+/// (one process per GPU); the domain owns the library's communicator (mrl_comm_*: HIP IPC peer stores / copy engines / RCCL in
+/// place of the reference's host-staged MPI transposes, DomainAction.C:869-1019) and every buffer is the rank's LOCAL block:
+/// real space split along y, reciprocal space along x.
 class DomainAction
 {
 public:
+  using ParallelMode = DomainParallelMode;
+  using Parallel = DomainParallel;
   DomainAction(int dim, const std::vector<int64_t> & n, const std::vector<double> & max,
-               const std::vector<double> & min = {0, 0, 0})
-    : _dim(dim), _n(n)
+               const std::vector<double> & min = {0, 0, 0}, const Parallel & par = Parallel())
+    : _dim(dim), _n(n), _par(par)
   {
     mrl_domain d{};
     d.dim = dim;
@@ -142,32 +162,74 @@ public:
       _min.push_back(d.min[i]);
       _max.push_back(d.max[i]);
     }
-    d.device = -1;
+    d.device = par.device;
     d.nranks = 1;
     d.rank = 0;
     d.spectrum = MRL_SPECTRUM_HALF;
     d.stream = nullptr;  // the HIP null stream: hipMemcpy/hipMemset of this layer are ordered with the kernels
     d.flags = 0;
+    const bool slab = par.mode == ParallelMode::FFT_SLAB;
+    if (slab)
+    {
+      if (dim < 2)
+        mooseError("Dimension must be 2 or 3 for slab decomposition.");  // DomainAction.C:514-515
+      d.nranks = par.nranks;
+      d.rank = par.rank;
+      d.flags = MRL_FLAG_SLAB;
+      // 3-D keeps the r2c transform along z (half the exchange volume of the reference's c2c, identical fields);
+      // 2-D uses the reference's full c2c layout (DomainAction.C:279-281)
+      d.spectrum = dim == 3 ? MRL_SPECTRUM_HALF : MRL_SPECTRUM_FULL;
+      if (mrl_comm_create(&_comm, par.job.c_str(), par.nranks, par.rank, par.device, par.transport) != MRL_OK)
+        mooseError(std::string("DomainAction: ") + mrl_comm_last_error(nullptr));
+    }
     if (mrl_ctx_create(&_ctx, &d) != MRL_OK)
       mooseError(std::string("DomainAction: ") + mrl_last_error(nullptr));
+    if (slab)
+      check(mrl_ctx_attach_comm(_ctx, _comm));
+    int64_t rn[3], rb[3], kn[3], kb[3];
+    check(mrl_local_shape(_ctx, rn, rb, kn, kb));
+    _n_global = 1;
     _n_real = 1;
     _n_recip = 1;
     for (int i = 0; i < dim; ++i)
     {
-      _n_real *= n[i];
-      _n_recip *= (i == dim - 1) ? n[i] / 2 + 1 : n[i];
+      _n_global *= n[i];
+      _n_real *= rn[i];
+      _n_recip *= kn[i];
+      _local_shape.push_back(rn[i]);
+      _local_begin.push_back(rb[i]);
+      _recip_shape.push_back(kn[i]);
+      _recip_begin.push_back(kb[i]);
     }
+    // the Cahn-Hilliard solver's own spectral arrays (history ring) may carry a padded last-axis pitch on slab contexts
+    _n_recip_solver = slab && dim == 3 ? _n_recip / kn[dim - 1] * mrl_slab_ch_spec_pitch(_ctx) : _n_recip;
   }
-  ~DomainAction() { mrl_ctx_destroy(_ctx); }
+  ~DomainAction()
+  {
+    mrl_ctx_destroy(_ctx);
+    mrl_comm_destroy(_comm);
+  }
   DomainAction(const DomainAction &) = delete;
 
   mrl_ctx * ctx() const { return _ctx; }
+  mrl_comm * comm() const { return _comm; }
+  bool isSlab() const { return _par.mode == ParallelMode::FFT_SLAB; }
+  int rank() const { return _par.rank; }
+  int nranks() const { return _par.nranks; }
   int getDim() const { return _dim; }
-  const std::vector<int64_t> & getShape() const { return _n; }
+  const std::vector<int64_t> & getShape() const { return _n; }                 ///< global grid
+  const std::vector<int64_t> & getLocalShape() const { return _local_shape; }  ///< DomainAction::getLocalShape
+  const std::vector<int64_t> & getLocalBegin() const { return _local_begin; }
+  const std::vector<int64_t> & getReciprocalShape() const { return _recip_shape; }
+  /// cells of this rank's real-space block (= the global count in parallel_mode NONE): the size of every real buffer
   int64_t getNumberOfCells() const { return _n_real; }
+  int64_t getGlobalNumberOfCells() const { return _n_global; }
   double getExtent(int d) const { return _max[d] - _min[d]; }
+  /// points of this rank's reciprocal block: the size (in complex values) of every reciprocal buffer
   int64_t getReciprocalSize() const { return _n_recip; }
-  /// real-space axis: linspace(min + dx/2, max - dx/2, n)  (DomainAction.C:246-251)
+  /// ... of the arrays private to the fused Cahn-Hilliard solver (mrl_slab_ch_spec_pitch)
+  int64_t getSolverReciprocalSize() const { return _n_recip_solver; }
+  /// real-space axis: linspace(min + dx/2, max - dx/2, n)  (DomainAction.C:246-251), global
   std::vector<double> getAxis(int d) const
   {
     std::vector<double> a(_n[d]);
@@ -178,10 +240,10 @@ public:
       a[i] = (i < _n[d] / 2) ? lo + step * (double)i : hi - step * (double)(_n[d] - 1 - i);
     return a;
   }
-  /// reciprocal axis d (2 pi fftfreq / rfftfreq, DomainAction.C:259-303) as the library holds it
+  /// reciprocal axis d (2 pi fftfreq / rfftfreq, DomainAction.C:259-303) as the library holds it (the local part)
   std::vector<double> getReciprocalAxis(int d) const
   {
-    const int64_t n = (d == _dim - 1) ? _n[d] / 2 + 1 : _n[d];
+    const int64_t n = _recip_shape[d];
     std::vector<double> k((std::size_t)n);
     check(mrl_ctx_reciprocal_axis(_ctx, d, k.data(), n));
     return k;
@@ -213,9 +275,12 @@ public:
 private:
   const int _dim;
   std::vector<int64_t> _n;
+  const Parallel _par;
   std::vector<double> _dx, _min, _max;
   mrl_ctx * _ctx = nullptr;
-  int64_t _n_real, _n_recip;
+  mrl_comm * _comm = nullptr;
+  std::vector<int64_t> _local_shape, _local_begin, _recip_shape, _recip_begin;
+  int64_t _n_real, _n_recip, _n_recip_solver, _n_global;
 };
 
 /// the part of TensorProblem the solvers talk to: buffer registry, time bookkeeping, history advance
@@ -250,6 +315,7 @@ public:
   double & time() { return _time; }
   double & timeOld() { return _time_old; }
   double & dt() { return _dt; }
+  double & dtOld() { return _dt_old; }  ///< FEProblem::dtOld(): the previous time step's dt (TensorSolver.C:48)
   double & subDt() { return _sub_dt; }
   double & subTime() { return _sub_time; }
 
@@ -257,7 +323,7 @@ private:
   DomainAction & _domain;
   std::map<std::string, TensorBuffer> _tensor_buffer;
   int _t_step = 0;
-  double _time = 0.0, _time_old = 0.0, _dt = 0.0, _sub_dt = 0.0, _sub_time = 0.0;
+  double _time = 0.0, _time_old = 0.0, _dt = 0.0, _dt_old = 0.0, _sub_dt = 0.0, _sub_time = 0.0;
 };
 
 class TensorOperatorBase
@@ -317,7 +383,7 @@ public:
   TensorSolver(TensorProblem & problem, std::string name, unsigned int substeps,
                std::shared_ptr<TensorOperatorBase> root_compute)
     : TensorOperatorBase(problem, std::move(name)), _substeps(substeps), _sub_dt(problem.subDt()),
-      _sub_time(problem.subTime()), _dt(problem.dt()), _compute(std::move(root_compute))
+      _sub_time(problem.subTime()), _dt(problem.dt()), _dt_old(problem.dtOld()), _compute(std::move(root_compute))
   {
   }
   /// TensorSolver::computeBuffer (TensorSolver.C:93-109)
@@ -349,6 +415,9 @@ protected:
   double & _sub_dt;
   double & _sub_time;
   const double & _dt;
+  const double & _dt_old;
+  /// "If dt changes between steps, we start at first order again" (AdamsBashforthMoulton.C:75, AdamsBashforthMoultonCoupled.C:110)
+  bool dtChanged() const { return _dt != _dt_old; }
   std::shared_ptr<TensorOperatorBase> _compute;
   std::vector<std::pair<std::string, std::string>> _forwarded;
 };
@@ -380,6 +449,13 @@ public:
       paramError("predictor_order", "predictor_order > 0 & predictor_order <= 5");
     if (p.spectral_carry && p.publish_cbar)
       paramError("spectral_carry", "cbar is not materialised separately when it is carried over");
+    if (_domain.isSlab())
+    {
+      if (p.publish_cbar)
+        paramError("publish_cbar", "not available with parallel_mode = FFT_SLAB");
+      // the carried spectrum lives inside the library's slab pipeline (one mrl_ch_substeps call = one computeBuffer)
+      _domain.check(mrl_ctx_set_option(_domain.ctx(), MRL_OPT_SLAB_CARRY, p.spectral_carry ? 1 : 0));
+    }
   }
 
   /// TensorSolver::computeBuffer (TensorSolver.C:93-109).  When nothing else in the problem keeps a history and no per-substep
@@ -387,10 +463,12 @@ public:
   /// back to the TensorBuffer afterwards, so that the next advanceState sees exactly the reference's handles.
   void computeBuffer() override
   {
-    if (_substeps < 2 || _p.spectral_carry || _p.publish_cbar || _p.substep_calls || !_tensor_problem.onlyHistoryOf(_p.nonlinear_reciprocal))
+    const bool slab = _domain.isSlab();
+    if ((!slab && (_substeps < 2 || _p.spectral_carry)) || _p.publish_cbar || _p.substep_calls ||
+        !_tensor_problem.onlyHistoryOf(_p.nonlinear_reciprocal))
       return TensorSolver::computeBuffer();
     _sub_dt = _dt / _substeps;
-    const std::size_t nreal = _domain.getNumberOfCells(), nspec = 2 * _domain.getReciprocalSize();
+    const std::size_t nreal = _domain.getNumberOfCells(), nspec = 2 * _domain.getSolverReciprocalSize();
     const int size = (int)_predictor_order + 1;   // history depth + the array being written
     // ring slot (size-1-i) = Nhat_old[i]; the remaining slots are scratch arrays that hold no live state
     std::vector<DeviceTensor> ring(size);
@@ -425,7 +503,8 @@ public:
     DeviceTensor mu;
     if (_p.publish_mu)
       mu = DeviceTensor::empty(nreal);
-    const int advance = _tensor_problem.timeStep() > 1 ? 1 : 0;   // TensorProblem::advanceState is a no-op while timeStep() <= 1
+    // TensorProblem::advanceState is a no-op while timeStep() <= 1; a changed dt restarts the order (AdamsBashforthMoulton.C:75,88-91)
+    const int advance = (_tensor_problem.timeStep() > 1 ? MRL_SUBSTEPS_ADVANCE : 0) | (dtChanged() ? MRL_SUBSTEPS_DT_CHANGED : 0);
     _domain.check(mrl_ch_substeps(_domain.ctx(), &_p.ch, _u.data(), c_out.data(), ptr.data(), size, &head, &n_old,
                                   (int)_predictor_order + 1, (int)_substeps, advance, _sub_dt, mu.defined() ? mu.data() : nullptr));
     std::vector<DeviceTensor> old;
@@ -442,8 +521,8 @@ protected:
   void substep() override
   {
     const std::size_t n_old = _old_nonlinear.size();
-    const int order = (int)std::min(n_old, _predictor_order);  // AdamsBashforthMoulton.C:90-91 (dt constant)
-    const std::size_t nreal = _domain.getNumberOfCells(), nspec = 2 * _domain.getReciprocalSize();
+    const int order = (int)std::min(_substep < _predictor_order && dtChanged() ? (std::size_t)0 : n_old, _predictor_order);  // AdamsBashforthMoulton.C:88-91
+    const std::size_t nreal = _domain.getNumberOfCells(), nspec = 2 * _domain.getSolverReciprocalSize();
     auto c_out = DeviceTensor::empty(nreal);
     auto Nnew = DeviceTensor::empty(nspec);
     DeviceTensor mu, cbar;
@@ -455,7 +534,7 @@ protected:
     for (int i = 0; i < order; ++i)
       old[i] = _old_nonlinear[i].data();
     int carry = MRL_CARRY_NONE;
-    if (_p.spectral_carry)
+    if (_p.spectral_carry && !_domain.isSlab())
     {
       // the carried spectrum belongs to the tensor this solver published last; any other writer rebinds the handle
       const bool valid = _carry.defined() && _u.data() == _last_c;
@@ -985,7 +1064,7 @@ protected:
     for (auto & v : _variables)
     {
       const std::size_t n_old = v._old_nonlinear_reciprocal.size();
-      const std::size_t order = std::min(n_old, _predictor_order);
+      const std::size_t order = std::min(_substep < _predictor_order && dtChanged() ? (std::size_t)0 : n_old, _predictor_order);
       std::vector<const double *> N{v._nonlinear_reciprocal.data()};
       std::vector<double> coef{_sub_dt * abBeta(order, 0)};
       for (std::size_t i = 0; i < order; ++i)
@@ -1012,7 +1091,7 @@ protected:
         {
           auto & v = _variables[k];
           const std::size_t n_old = v._old_nonlinear_reciprocal.size();
-          const std::size_t order = std::min(n_old + 1, _corrector_order);
+          const std::size_t order = std::min(_substep < _corrector_order && dtChanged() ? (std::size_t)1 : n_old + 1, _corrector_order);
           if (order == 0)
             continue;
           std::vector<const double *> N{v._nonlinear_reciprocal.data(), N_n[k].data()};
@@ -1109,7 +1188,8 @@ protected:
     for (std::size_t k = 0; k < nv; ++k)                                              // :118-138
     {
       auto & v = _variables[k];
-      const std::size_t order = std::min(v._old_nonlinear_reciprocal.size(), _predictor_order);
+      const std::size_t order =
+          std::min(_substep < _predictor_order && dtChanged() ? (std::size_t)0 : v._old_nonlinear_reciprocal.size(), _predictor_order);
       u0[k] = v._reciprocal_buffer.data();
       N[k] = {v._nonlinear_reciprocal.data()};
       coef[k] = {_sub_dt * abBeta(order, 0)};
@@ -1135,7 +1215,8 @@ protected:
       for (std::size_t k = 0; k < nv; ++k)
       {
         auto & v = _variables[k];
-        const std::size_t order = std::min(v._old_nonlinear_reciprocal.size() + 1, _corrector_order);
+        const std::size_t order =
+            std::min(_substep < _corrector_order && dtChanged() ? (std::size_t)1 : v._old_nonlinear_reciprocal.size() + 1, _corrector_order);
         u0[k] = ubar_n[k].data();
         N[k].clear();
         coef[k].clear();
@@ -1872,8 +1953,8 @@ struct TensorPostprocessors
   static double average(DomainAction & d, const DeviceTensor & t)
   {
     double s = 0.0;
-    d.check(mrl_sum(d.ctx(), t.data(), (int64_t)t.numel(), &s));
-    return s / (double)t.numel();
+    d.check(mrl_sum(d.ctx(), t.data(), (int64_t)t.numel(), &s));  // (the sum over all ranks on a slab domain)
+    return s / (double)d.getGlobalNumberOfCells();
   }
   /// ReciprocalIntegral.C:28-47: Re(ubar[0,...,0]) / (number of cells) * volume (rank owning k = 0)
   static double reciprocalIntegral(DomainAction & d, const DeviceTensor & tbar, double volume)
@@ -1882,14 +1963,14 @@ struct TensorPostprocessors
     d.check(mrl_sync(d.ctx()));
     if (hipMemcpy(&re, tbar.data(), sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
       mooseError("ReciprocalIntegral: hipMemcpy failed");
-    return re / (double)d.getNumberOfCells() * volume;
+    return re / (double)d.getGlobalNumberOfCells() * volume;
   }
   /// integral = average * domain volume   (TensorIntegralPostprocessor.C:29-38)
   static double integral(DomainAction & d, const DeviceTensor & t, double volume)
   {
     double s = 0.0;
     d.check(mrl_sum(d.ctx(), t.data(), (int64_t)t.numel(), &s));
-    return s / (double)t.numel() * volume;
+    return s / (double)d.getGlobalNumberOfCells() * volume;
   }
 };
 
@@ -1966,9 +2047,11 @@ public:
     {
       _problem.timeOld() = _problem.time();
       _problem.timeStep() += 1;
+      const double dt_prev = _problem.dt();              // TransientBase::takeStep: _dt_old = _dt
       if (_stepper)
         _dt = _stepper(_problem.timeStep());
       _problem.dt() = _dt;
+      _problem.dtOld() = _problem.timeStep() > 1 ? dt_prev : _dt;  // (nothing has changed before the first step)
       _problem.time() = _problem.timeOld() + _dt;
       _problem.advanceState();                         // incrementStepOrReject -> advanceState
       _problem.subTime() = _problem.timeOld();         // TensorProblem.C:179

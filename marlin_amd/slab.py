@@ -232,6 +232,9 @@ class SlabCahnHilliard:
         self.hist: List[torch.Tensor] = []                         # N-hat_old[0..] (handles into the ring)
         self.cur: Optional[torch.Tensor] = None                    # N-hat of the last substep
         self.time_step = 0
+        self.dt_old: Optional[float] = None                        # the previous time step's dt (TensorSolver.C:48)
+        self.dt_changed = False
+        self._substep_index = 0
 
     # ---- state ---------------------------------------------------------------------------------
     def set_initial(self, gen: Callable[[int, int], "object"]):
@@ -296,8 +299,12 @@ class SlabCahnHilliard:
     def phase_z(self):
         self.mode = CARRY_NONE if not self.carry else (CARRY_IN if self._carry_valid else CARRY_OUT)
         self.st.ch_z_fwd(self.p, self.c, carry=self.mode)
-        self._order = min(len(self.hist), self.pred)       # AdamsBashforthMoulton.C:90-91 (constant dt)
+        self._order = self._ab_order()
         self._new = self._free_Nhat()
+
+    def _ab_order(self):
+        """AdamsBashforthMoulton.C:75,88-91: the order the history allows, restarted at first order when dt changed"""
+        return min(0 if (self._substep_index < self.pred and self.dt_changed) else len(self.hist), self.pred)
 
     def phase_a(self, s):
         self.st.ch_x_fwd(s, self.nsub, self.send_f[s], carry=self.mode)
@@ -334,7 +341,8 @@ class SlabCahnHilliard:
             self.advance_state()
         self.mode = CARRY_NONE if not self.carry else CARRY_IN
         self.st.ch_z_inv_fwd(self.p, carry=self.mode)
-        self._order = min(len(self.hist), self.pred)
+        self._substep_index += 1
+        self._order = self._ab_order()
         self._new = self._free_Nhat()
 
     def substep(self, advance: bool = True):
@@ -368,6 +376,7 @@ class SlabCahnHilliard:
         """`count` substeps as one unit (the substep loop of TensorSolver::computeBuffer): between two substeps the two z passes
         are one kernel.  `advance`: rotate the history between substeps (False while timeStep() <= 1); `advance_after`: also
         after the last one (what a following run() / substep() of the same time step needs)."""
+        self._substep_index = 0
         for k in range(count):
             if k == 0:
                 self.phase_z()
@@ -382,6 +391,8 @@ class SlabCahnHilliard:
         """One MOOSE time step: advanceState is a no-op while timeStep() <= 1 (TensorProblem.C:451-472),
         so every substep of the first step is AB1."""
         self.time_step += 1
+        self.dt_changed = self.dt_old is not None and dt != self.dt_old
+        self.dt_old = dt
         if self.time_step > 1:
             self.advance_state()
         self.sub_dt = dt / substeps

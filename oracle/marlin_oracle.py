@@ -241,6 +241,9 @@ class CahnHilliardABM:
         self.cbar: Optional[torch.Tensor] = None
         self.time_step = 0
         self.order_log: List[int] = []
+        self.dt_old: Optional[float] = None                 # FEProblem::dtOld(): the previous time step's dt
+        self.dt_changed = False
+        self._substep = 0
 
     def _advance_state(self) -> None:
         if self.time_step <= 1:                             # TensorProblem.C:455
@@ -255,7 +258,8 @@ class CahnHilliardABM:
         self.Nhat = self.Mbar * mubar                       # Mbarmubar = Mbar*mubar
         self.cbar = self.dom.fft(self.c)
         n_old = len(self.hist.old)
-        order = min(n_old, self.pred)                       # AdamsBashforthMoulton.C:90-91 (dt constant)
+        # AdamsBashforthMoulton.C:75,88-91: "If dt changes between steps, we start at first order again"
+        order = min(0 if (self._substep < self.pred and self.dt_changed) else n_old, self.pred)
         self.order_log.append(order)
         ubar = self.cbar + (sub_dt * AB_BETA[order][0]) * self.Nhat            # :94
         for i in range(order):
@@ -266,9 +270,12 @@ class CahnHilliardABM:
     def step(self, dt: float) -> None:
         """One MOOSE time step: incrementStepOrReject -> advanceState, then TensorSolver::computeBuffer."""
         self.time_step += 1
+        self.dt_changed = self.dt_old is not None and dt != self.dt_old     # _dt != _dt_old (TensorSolver.C:48)
+        self.dt_old = dt
         self._advance_state()
         sub_dt = dt / self.substeps                         # TensorSolver.C:96
         for s in range(self.substeps):
+            self._substep = s
             self.substep(sub_dt)
             if s < self.substeps - 1:                       # :104-105
                 self._advance_state()
@@ -621,6 +628,9 @@ class SplitOperatorABM:
         depth = max(self.pred, self.corr)                    # :55-56
         self.hist = {v[3]: History(max_states=depth) for v in variables}
         self.time_step = 0
+        self.dt_old: Optional[float] = None
+        self.dt_changed = False
+        self._substep = 0
 
     def _advance_state(self):
         if self.time_step <= 1:
@@ -634,7 +644,7 @@ class SplitOperatorABM:
         self.compute(s)                                      # :63
         for (u, rb, L, N) in self.vars:
             old = self.hist[N].old
-            order = min(len(old), self.pred)                 # :90-91 (dt constant)
+            order = min(0 if (self._substep < self.pred and self.dt_changed) else len(old), self.pred)    # :75,88-91
             ubar = s[rb] + (sub_dt * AB_BETA[order][0]) * s[N]
             for i in range(order):
                 ubar += (sub_dt * AB_BETA[order][i + 1]) * old[i]
@@ -648,7 +658,7 @@ class SplitOperatorABM:
                 self.compute(s)
                 for k, (u, rb, L, N) in enumerate(self.vars):
                     old = self.hist[N].old
-                    order = min(len(old) + 1, self.corr)
+                    order = min(1 if (self._substep < self.corr and self.dt_changed) else len(old) + 1, self.corr)    # :153-154
                     if order == 0:
                         continue
                     ubar = ubar_n[k] + (sub_dt * AM_ALPHA[order][0]) * s[N]
@@ -661,9 +671,12 @@ class SplitOperatorABM:
 
     def step(self, dt: float):
         self.time_step += 1
+        self.dt_changed = self.dt_old is not None and dt != self.dt_old
+        self.dt_old = dt
         self._advance_state()
         sub_dt = dt / self.substeps
         for k in range(self.substeps):
+            self._substep = k
             self.substep(sub_dt)
             if k < self.substeps - 1:
                 self._advance_state()
@@ -709,6 +722,9 @@ class CoupledABM:
         self.real_rhs, self.transposed = real_rhs, transposed
         self.hist = {v[3]: History(max_states=max(self.pred, self.corr)) for v in variables}
         self.time_step = 0
+        self.dt_old: Optional[float] = None
+        self.dt_changed = False
+        self._substep = 0
 
     _advance_state = SplitOperatorABM._advance_state
     step = SplitOperatorABM.step
@@ -738,7 +754,7 @@ class CoupledABM:
         rhs = []
         for (u, rb, _, N) in self.vars:
             old = self.hist[N].old
-            order = min(len(old), self.pred)
+            order = min(0 if (self._substep < self.pred and self.dt_changed) else len(old), self.pred)   # AdamsBashforthMoultonCoupled.C:110,134
             r = s[rb] + (sub_dt * AB_BETA[order][0]) * s[N]
             for i in range(order):
                 r += (sub_dt * AB_BETA[order][i + 1]) * old[i]
@@ -752,7 +768,7 @@ class CoupledABM:
                 rhs = []
                 for k, (u, rb, _, N) in enumerate(self.vars):
                     old = self.hist[N].old
-                    order = min(len(old) + 1, self.corr)
+                    order = min(1 if (self._substep < self.corr and self.dt_changed) else len(old) + 1, self.corr)   # :222
                     if order == 0:
                         rhs.append(ubar_n[k])
                         continue

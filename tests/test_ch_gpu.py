@@ -177,3 +177,34 @@ def test_ch_multi_substep_call(shape, pred):
         diff = (c.cpu() - states[step]).abs().max().item()
         assert diff <= 1e-15, diff
     assert (mu.cpu() - mu_ref).abs().max().item() <= 1e-16
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (12, 10, 9), (64, 128)])
+def test_ch_adaptive_dt_restarts_the_order(shape):
+    """a changed time step size restarts the Adams-Bashforth order for the first predictor_order - 1 substeps of the step while the
+    history keeps advancing (AdamsBashforthMoulton.C:75,88-91; MRL_SUBSTEPS_DT_CHANGED): AB3, 4 substeps per step, dt 1e-3, 1e-3,
+    2e-3, 2e-3, 5e-4 -- fused and generic paths against the oracle"""
+    from marlin_amd.api import Context, ch_params
+    dim = len(shape)
+    L = [2.0 + d for d in range(dim)]
+    ctx = Context(dim, list(shape), L)
+    p = ch_params()
+    torch.manual_seed(9)
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    dts, substeps, pred = [1e-3, 1e-3, 2e-3, 2e-3, 5e-4], 4, 3
+    dom = mo.Domain(dim, list(shape), L)
+    ref = mo.CahnHilliardABM(dom, c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=substeps, predictor_order=pred)
+    ring = [ctx.empty_spec() for _ in range(pred)]
+    head, n_old, dt_old = 0, 0, None
+    c = c0.cuda()
+    for step, dt in enumerate(dts):
+        ref.step(dt)
+        if step > 0:           # TensorProblem::advanceState at the start of the time step
+            head, n_old = (head + 1) % pred, min(n_old + 1, pred - 1)
+        out = torch.empty_like(c)
+        head, n_old = ctx.ch_substeps(p, c, out, ring, head, n_old, pred, substeps, step > 0, dt / substeps,
+                                      dt_changed=dt_old is not None and dt != dt_old)
+        dt_old = dt
+        c = out
+        assert (c.cpu() - ref.c).abs().max().item() <= 1e-13
+    assert ref.order_log[8:12] == [0, 0, 2, 2] and ref.order_log[16:] == [0, 0, 2, 2]

@@ -68,6 +68,73 @@ def test_mechanics_case(case, tmp_path):
     assert worst <= 1e-10, worst
 
 
+@pytest.mark.parametrize("P,extra", [(2, []), (2, ["transport=2"]), (4, ["spectral_carry=1"]), (2, ["substep_calls=1"])])
+def test_cahnhilliard_case_fft_slab(P, extra, tmp_path):
+    """test/tests/cahnhilliard/tests:58-70: cahnhilliard.i with parallel_mode = FFT_SLAB on P rank PROCESSES started by the C++
+    driver itself (`marlin-hip-run ... parallel_mode=FFT_SLAB nranks=P`, all on GPU 0): the C++ AdamsBashforthMoulton object over
+    mrl_ch_substeps with the library-owned exchange; c.1 .. c.10 of cahnhilliard.rank0001.h5 to 1e-13"""
+    import torch
+    g = load_golden("cahnhilliard_rank0001_gold.npz")
+    torch.manual_seed(0)
+    blk = (torch.rand(20, 10, dtype=torch.float64) * (0.56 - 0.44) + 0.44).numpy()
+    ic = tmp_path / "c0.bin"
+    np.concatenate([blk, blk], axis=1).astype("<f8").tofile(ic)    # both reference ranks draw the same seed-0 block
+    _run(["problem=cahnhilliard", "dim=2", "nx=20", "ny=20", "xmax=3", "ymax=3", f"ic={ic}", "substeps=10", "num_steps=10", "dt=1e-3",
+          "predictor_order=2", "mobility=0.2", "kappa=-0.001", "parallel_mode=FFT_SLAB", f"nranks={P}", "device=0"] + extra, tmp_path)
+    nyl = 20 // P
+    worst = 0.0
+    for k in range(1, 11):
+        slabs = [np.fromfile(tmp_path / f"c.{k}.rank{r}.bin", dtype="<f8").reshape(20, nyl) for r in range(P)]
+        c = np.concatenate(slabs, axis=1)
+        worst = max(worst, np.abs(g[f"c.{k}"] - c[:, 10:]).max())
+    assert worst <= 1e-13, worst
+
+
+@pytest.mark.parametrize("extra", [[], ["substep_calls=1"], ["parallel_mode=FFT_SLAB", "nranks=2", "device=0"]])
+def test_cahnhilliard_adaptive_dt(extra, tmp_path):
+    """a [TimeStepper] that changes dt between steps: the C++ AdamsBashforthMoulton object restarts the order for the first
+    predictor_order - 1 substeps of such a step (AdamsBashforthMoulton.C:75,88-91) -- one library call per computeBuffer, one per
+    substep, and on two FFT_SLAB ranks -- against the oracle"""
+    import torch
+    from oracle import marlin_oracle as mo
+    torch.manual_seed(3)
+    shape, L = [20, 20], [3.0, 3.0]
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    ic = tmp_path / "c0.bin"
+    c0.numpy().astype("<f8").tofile(ic)
+    dts, substeps, pred = [1e-3, 1e-3, 2e-3, 2e-3, 5e-4], 4, 3
+    _run(["problem=cahnhilliard", "dim=2", "nx=20", "ny=20", "xmax=3", "ymax=3", f"ic={ic}", f"substeps={substeps}", f"num_steps={len(dts)}",
+          "dt_sequence=" + ",".join(repr(d) for d in dts), f"predictor_order={pred}", "mobility=0.2", "kappa=-0.001"] + extra, tmp_path)
+    slab = any(e.startswith("parallel_mode") for e in extra)
+    dom = mo.Domain(2, shape, L, slab_c2c=slab)
+    ref = mo.CahnHilliardABM(dom, c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=substeps, predictor_order=pred)
+    for k, dt in enumerate(dts):
+        ref.step(dt)
+        if slab:
+            c = np.concatenate([np.fromfile(tmp_path / f"c.{k + 1}.rank{r}.bin", dtype="<f8").reshape(20, 10) for r in range(2)], axis=1)
+        else:
+            c = np.fromfile(tmp_path / f"c.{k + 1}.bin", dtype="<f8").reshape(20, 20)
+        assert np.abs(ref.c.numpy() - c).max() <= 1e-13
+
+
+def test_mechanics_case_fft_slab(tmp_path):
+    """mech3d.i (test/tests/mechanics/tests:2-21) on 2 rank processes: the C++ FFTMechanics object over mrl_mech_newton_cg on slab
+    contexts; F_k.frame and sV of mech3d.h5 to 1e-10"""
+    g = load_golden("mech3d_gold.npz")
+    n, P = 16, 2
+    _run(["problem=mechanics", "dim=3", "num_steps=3", "nx=16", "ny=16", "nz=16", "xmax=2pi", "ymax=2pi", "zmax=2pi", "substeps=10",
+          "dt=0.01", "l_tol=1e-2", "nl_rel_tol=2e-2", "nl_abs_tol=2e-2", "parallel_mode=FFT_SLAB", f"nranks={P}", "device=0"], tmp_path)
+    worst = 0.0
+    for frame in range(3):
+        F = np.concatenate([np.fromfile(tmp_path / f"F.{frame}.rank{r}.bin", dtype="<f8").reshape(n, n // P, n, 9) for r in range(P)], axis=1)
+        for k in range(9):
+            worst = max(worst, np.abs(g[f"F_{k}.{frame}"] - np.transpose(F[..., k], (2, 1, 0))).max())
+        if f"sV.{frame}" in g:
+            sv = np.concatenate([np.fromfile(tmp_path / f"sV.{frame}.rank{r}.bin", dtype="<f8").reshape(n, n // P, n) for r in range(P)], axis=1)
+            worst = max(worst, np.abs(g[f"sV.{frame}"] - np.transpose(sv, (2, 1, 0))).max())
+    assert worst <= 1e-10, worst
+
+
 def test_error_behaviour(tmp_path):
     """mooseError-style failures: bad dimension, unreadable IC"""
     out = subprocess.run([RUN, "problem=cahnhilliard", "dim=4"], capture_output=True, text=True)

@@ -35,12 +35,12 @@ def _worker(rank, world, port, case, q):
         dim, shape, L, c0 = case["dim"], case["shape"], case["L"], case["c0"]
         st = OracleSlabStages(dim, shape, L, world, rank)
         s = SlabCahnHilliard(dim, shape, L, ch_params(), world, rank, stages=st, nsub=case["nsub"],
-                             carry=case.get("carry", False))
+                             carry=case.get("carry", False), predictor_order=case.get("pred", 2))
         yb, nyl = st.real_begin[1], st.real_shape[1]
         s.set_local(c0[:, yb:yb + nyl].contiguous())
         out = []
-        for _ in range(case["nsteps"]):
-            s.step(case["dt"], case["substeps"])
+        for k in range(case["nsteps"]):
+            s.step(case["dts"][k] if "dts" in case else case["dt"], case["substeps"])
             out.append(s.current().clone().numpy())
         q.put((rank, yb, nyl, out))
     finally:
@@ -92,3 +92,23 @@ def test_slab_3d_matches_serial_oracle(world, shape, nsub, carry):
         for rank, yb, nyl, states in res:
             assert np.abs(ref.c[:, yb:yb + nyl].numpy() - states[k]).max() <= 1e-13
     assert ref.order_log == [0, 0, 0, 1, 1, 1]
+
+
+def test_slab_adaptive_dt_restarts_the_order():
+    """a time step size that changes between steps restarts the Adams-Bashforth order for the first predictor_order - 1 substeps
+    of the step (AdamsBashforthMoulton.C:75,88-91) while the history keeps advancing: AB3, 4 substeps, dt 1e-3, 1e-3, 2e-3, 2e-3,
+    5e-4 on two gloo ranks == the serial oracle"""
+    torch.manual_seed(8)
+    shape, L = [8, 6, 10], [3.0, 2.0, 2.5]
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    dts = [1e-3, 1e-3, 2e-3, 2e-3, 5e-4]
+    case = dict(dim=3, shape=shape, L=L, c0=c0, nsteps=len(dts), dts=dts, substeps=4, nsub=2, pred=3)
+    res = _run(2, case)
+    dom = mo.Domain(3, shape, L)
+    ref = mo.CahnHilliardABM(dom, c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=4, predictor_order=3)
+    for k, dt in enumerate(dts):
+        ref.step(dt)
+        for rank, yb, nyl, states in res:
+            assert np.abs(ref.c[:, yb:yb + nyl].numpy() - states[k]).max() <= 1e-13
+    # step 1: no history (AB1); step 2: history grows 1, 2, 2, 2; steps 3 and 5: dt changed -> two first-order substeps, then AB3
+    assert ref.order_log == [0, 0, 0, 0, 1, 2, 2, 2, 0, 0, 2, 2, 2, 2, 2, 2, 0, 0, 2, 2]
