@@ -455,6 +455,10 @@ def main():
     kernels = prof_ctx.get_profile()
     prof_ctx.set_profiling(False)
 
+    # the global field checksum (all ranks take part): lets two drivers / transports be compared from their JSON lines
+    cur = current()
+    cs = host_sum(float((cur * cur).sum(dtype=torch.float64).item()))
+
     variants = {}
     if not args.no_variants and slab and args.driver == "native":
         # (a) the spectral carry-over variant of the same job; (b) the rank-local kernels alone (exchanges switched off: the
@@ -562,10 +566,9 @@ def main():
                 ex["bytes_sent_to_peers_per_step_rank0"] = (stats1["bytes_sent"] - stats0["bytes_sent"]) / args.steps
                 ex["link_GBps_out_rank0"] = ex["bytes_sent_to_peers_per_step_rank0"] / (elapsed / args.steps) / 1e9
             out["exchange"] = ex
-    # the global field checksum (all ranks take part): lets two drivers / transports be compared from their JSON lines
-    cs = host_sum(float((current() * current()).sum(dtype=torch.float64).item())) if slab else float((cur * cur).sum(dtype=torch.float64).item())
     if rank == 0:
-        out["field_checksum"] = {"sum_c_squared": cs, "after_substeps": "all of this run (fixed for fixed flags)"}
+        out["field_checksum"] = {"sum_c_squared": cs, "after_substeps": args.warmup + args.steps + (0 if per_call == 1 else 1 + min(args.steps, 50))
+                                 + args.profile_steps}
 
     if rank == 0 and not slab:
         if args.cpu_steps > 0:

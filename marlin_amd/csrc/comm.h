@@ -50,6 +50,7 @@ struct Xchg {
   bool tab_direct = false;                 // d_tab points into the peers' receive buffers (PEER_STORE) or into `send`
   std::vector<hipEvent_t> copy_done;       // PEER_COPY: per side stream, the last push out of `send`
   hipEvent_t rccl_done = nullptr;
+  hipEvent_t release_ev = nullptr;         // PEER_STORE: system-scope release between the producing kernel and the flag kernel
   bool pending_send_guard = false;
 };
 
@@ -59,6 +60,10 @@ struct mrl_comm {
   int nranks = 1, rank = 0, device = 0;
   int transport = MRL_TRANSPORT_PEER_STORE;
   bool ipc_ok = true;
+  // PEER_STORE: the producing kernels raise the arrival flags themselves (every workgroup fences at system scope and counts itself,
+  // comm_dev.h) instead of an event-ordered flag kernel after them.  Saves a launch per exchange but costs one L2 write-back per
+  // workgroup -- measured 2x slower on one GPU, so off by default (MRL_OPT_EXPERIMENT bit 128 of an attached context turns it on)
+  bool kernel_signals = false;
   double timeout_s = 60.0;
   mrl::ShmSeg *shm = nullptr;
   std::string shm_name;

@@ -406,6 +406,7 @@ int xchg_create(mrl_comm *c, Xchg *x, const size_t *send_cnt, const size_t *recv
   COMM_HIP(c, hipMalloc(reinterpret_cast<void **>(&x->d_counter), 64));
   COMM_HIP(c, hipMemset(x->d_counter, 0, 64));
   COMM_HIP(c, hipEventCreateWithFlags(&x->rccl_done, hipEventDisableTiming));
+  COMM_HIP(c, hipEventCreateWithFlags(&x->release_ev, hipEventDisableTiming | hipEventReleaseToSystem));
   x->copy_done.resize(c->side.size());
   for (auto &e : x->copy_done) COMM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return MRL_OK;
@@ -419,6 +420,7 @@ void xchg_destroy(mrl_comm *c, Xchg *x) {
   if (x->d_tab) (void)hipFree(x->d_tab);
   if (x->d_counter) (void)hipFree(x->d_counter);
   if (x->rccl_done) (void)hipEventDestroy(x->rccl_done);
+  if (x->release_ev) (void)hipEventDestroy(x->release_ev);
   for (auto &e : x->copy_done) (void)hipEventDestroy(e);
   *x = Xchg();
 }
@@ -454,7 +456,7 @@ int xchg_begin(mrl_comm *c, Xchg *x, hipStream_t stream) {
 
 SignalArgs xchg_signal_args(const mrl_comm *c, const Xchg *x, unsigned int nblocks) {
   SignalArgs s{};
-  if (!x->tab_direct) return s;  // counter == nullptr: the host posts the exchange
+  if (!x->tab_direct || !c->kernel_signals) return s;  // counter == nullptr: the host posts the exchange
   s.counter = x->d_counter;
   s.flag_tab = c->d_flag_tab;
   s.epoch = x->epoch + 1;
@@ -473,8 +475,11 @@ int xchg_post(mrl_comm *c, Xchg *x, hipStream_t stream, bool kernel_signalled) {
     if (p != me) c->bytes_sent += (double)x->send_cnt[p];
   const int row = x->channel * kFlagRow;
   if (x->tab_direct) {
-    // the producer scattered into the peers' buffers: only the flags are left (unless the kernel raised them itself)
+    // the producer scattered into the peers' buffers: only the flags are left (unless the kernel raised them itself).
+    // An event record between the producer and the flag kernel makes the command processor release the producer's stores at SYSTEM
+    // scope (every XCD's L2 written back), which a fence inside the one-workgroup flag kernel could not do for the other XCDs.
     if (kernel_signalled) return MRL_OK;
+    COMM_HIP(c, hipEventRecord(x->release_ev, stream));
     hipLaunchKernelGGL(k_comm_signal, dim3(1), dim3(64), 0, stream, c->d_flag_tab, P, me,
                        row, (unsigned long long)x->epoch, -1);
     COMM_HIP(c, hipGetLastError());

@@ -197,6 +197,7 @@ int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, d
   MRL_TRY(ch_pipe_build(ctx));
   ChPipe &P = ctx->pipes->ch;
   mrl_comm *c = ctx->comm;
+  c->kernel_signals = (ctx->exp & 128) != 0;
   hipStream_t st = ctx->stream;
   const int nsub = P.nsub;
   const bool lo = P.local_only;

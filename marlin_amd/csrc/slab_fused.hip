@@ -131,15 +131,17 @@ static int ilog2(long long v) {
   return s;
 }
 
-// work arrays of the pipeline: slots 13, 14 = c-hat_z, mu-hat_z [nx][nyl][nzc]; slot 11 = inverse x output
+// work arrays of the pipeline: slots 13, 14 = c-hat_z, mu-hat_z [nx][nyl][nzc].  The inverse x pass writes into the c-hat_z array
+// again: its kz range s is dead once the forward x pass of sub-block s has run (which always precedes the inverse pass of s), and
+// the fused z passes between two substeps then run in place (a workgroup reads its rows before it writes them) -- one array
+// less to stream through the Infinity Cache.
 static int slab_work(mrl_ctx *ctx, cplx **w_c, cplx **w_mu, cplx **w_inv) {
   const size_t bytes = sizeof(cplx) * (size_t)(ctx->n[0] * ctx->nloc[1] * ctx->nrec[2]);
   MRL_TRY(ensure_work(ctx, 13, bytes));
   MRL_TRY(ensure_work(ctx, 14, bytes));
-  MRL_TRY(ensure_work(ctx, 11, bytes));
   *w_c = reinterpret_cast<cplx *>(ctx->d_work[13]);
   *w_mu = reinterpret_cast<cplx *>(ctx->d_work[14]);
-  *w_inv = reinterpret_cast<cplx *>(ctx->d_work[11]);
+  *w_inv = *w_c;
   return MRL_OK;
 }
 

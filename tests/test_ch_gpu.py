@@ -208,3 +208,44 @@ def test_ch_adaptive_dt_restarts_the_order(shape):
         c = out
         assert (c.cpu() - ref.c).abs().max().item() <= 1e-13
     assert ref.order_log[8:12] == [0, 0, 2, 2] and ref.order_log[16:] == [0, 0, 2, 2]
+
+
+def test_config_a_pfhub_1a_128():
+    """BASELINE configs[0] as SURVEY 8(d) specifies it: PFHub benchmark 1a (benchmarks/01_spinodal_decomposition/1a_solver.i:45-86)
+    on 128^2, L = 200 x 200: f = rho (c - c_alpha)^2 (c_beta - c)^2 with rho 5, c_alpha 0.3, c_beta 0.7, Mbar = -5 k^2,
+    Lbar = -10 k^4, the benchmark's three-mode initial condition, AB2, 10 time steps of dt = 1 with 1000 substeps each
+    (spectral_solve_substeps = 1000): the HIP path (one library call per time step) against the oracle after every step to
+    1e-13, and the total free energy F = int f + |grad c|^2 (the input's [Postprocess] block, FFTGradientSquare factor 1) falls
+    monotonically"""
+    from marlin_amd.api import Context, ch_params, FE_PFHUB
+    n, Ld = 128, 200.0
+    shape = [n, n]
+    ctx = Context(2, shape, [Ld, Ld])
+    dom = mo.Domain(2, shape, [Ld, Ld])
+    x, y = dom.axis[0], dom.axis[1]
+    c0 = (0.5 + 0.01 * (torch.cos(0.105 * x) * torch.cos(0.11 * y) + torch.pow(torch.cos(0.13 * x) * torch.cos(0.087 * y), 2)
+                        + torch.cos(0.025 * x - 0.15 * y) * torch.cos(0.07 * x - 0.02 * y))).expand(shape).contiguous()
+    substeps, pred = 1000, 2
+    ref = mo.CahnHilliardABM(dom, c0, 5.0, -10.0, lambda c: mo.mu_pfhub(c, 5.0, 0.3, 0.7), substeps=substeps, predictor_order=pred)
+    p = ch_params(FE_PFHUB, (5.0, 0.3, 0.7), mobility=5.0, kappa=-10.0)
+    ring = [ctx.empty_spec() for _ in range(pred)]
+    head, n_old = 0, 0
+    c = c0.cuda()
+
+    def free_energy(field):
+        ch = dom.fft(field)
+        g2 = sum(dom.ifft(1j * dom.kaxis[d] * ch) ** 2 for d in range(2))
+        f = 5.0 * (field - 0.3) ** 2 * (0.7 - field) ** 2 + g2
+        return float(f.sum() * (Ld / n) ** 2)
+
+    energies = [free_energy(c0)]
+    for step in range(10):
+        ref.step(1.0)
+        if step > 0:
+            head, n_old = (head + 1) % pred, min(n_old + 1, pred - 1)
+        out = torch.empty_like(c)
+        head, n_old = ctx.ch_substeps(p, c, out, ring, head, n_old, pred, substeps, step > 0, 1.0 / substeps)
+        c = out
+        assert (c.cpu() - ref.c).abs().max().item() <= 1e-13
+        energies.append(free_energy(c.cpu()))
+    assert all(b < a for a, b in zip(energies, energies[1:])), energies

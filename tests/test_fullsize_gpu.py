@@ -149,3 +149,65 @@ def test_gamma_operator_properties_128():
     grad[..., 1, 2] = -3 * torch.sin(3 * Z) * torch.cos(X)     # u_1 = cos(3z) cos(x)
     grad[..., 1, 0] = -torch.cos(3 * Z) * torch.sin(X)
     assert (ctx.gamma_apply(grad) - grad).abs().max().item() <= 1e-12
+
+
+def test_headline_256_two_ab_substeps_vs_oracle():
+    """BASELINE configs[1] at full size against the ORACLE (not HIP vs HIP): 256^3, the bench's initial condition, AB1 then AB2
+    substep through mrl_ch_substeps (one call, z passes fused between the substeps) and through two mrl_ch_substep calls;
+    abs 1e-13 (test/tests/cahnhilliard/tests:46-57)"""
+    from bench import splitmix64_uniform
+    from marlin_amd.api import Context, ch_params
+    from oracle import marlin_oracle as mo
+    n = 256
+    dx = 8.0 * math.pi / 200.0
+    shape, L = [n, n, n], [n * dx] * 3
+    c0 = torch.from_numpy(splitmix64_uniform(n ** 3).reshape(shape))
+    dom = mo.Domain(3, shape, L)
+    Mbar = mo.reciprocal_laplacian_factor(dom, 0.2)
+    Lbar = mo.reciprocal_laplacian_square_factor(dom, -0.001)
+    r1, N1, _, _ = mo.ch_substep_ops(c0, Mbar, Lbar, [], 1e-3, 0, mo.mu_double_well, dom)
+    r2, _, _, _ = mo.ch_substep_ops(r1, Mbar, Lbar, [N1], 1e-3, 1, mo.mu_double_well, dom)
+    del Mbar, Lbar, N1
+    ctx = Context(3, shape, L)
+    p = ch_params()
+    c = c0.cuda()
+    ring = [ctx.empty_spec(), ctx.empty_spec()]
+    out = torch.empty_like(c)
+    ctx.ch_substeps(p, c, out, ring, 1, 0, 2, 2, True, 1e-3)
+    assert (out.cpu() - r2).abs().max().item() <= 1e-13
+    a, b = torch.empty_like(c), torch.empty_like(c)
+    ctx.ch_substep(p, c, a, ring[0], [], 0, 1e-3)
+    assert (a.cpu() - r1).abs().max().item() <= 1e-13
+    ctx.ch_substep(p, a, b, ring[1], [ring[0]], 1, 1e-3)
+    assert (b.cpu() - r2).abs().max().item() <= 1e-13
+
+
+def test_config_c_128_newton_cg_vs_oracle():
+    """BASELINE configs[2] at full size against the oracle: 128^3 de Geus RVE (cubic inclusion, examples/degeus_mechanics/mech.i
+    parameters), one Newton-CG solve.  The oracle applies G through its closed form (pinned against the stored Ghat4 operator in
+    tests/test_oracle_golden.py::test_gamma_closed_form_matches_stored_operator: 1296 B per k-point would be 1.4 GB here) and the
+    tangent through the stored K4 exactly as FFTMechanics.C:107-108.  Same Newton / CG iteration counts, F to 1e-10."""
+    from marlin_amd.api import Context
+    from oracle import marlin_oracle as mo
+    n = 128
+    shape, L = [n, n, n], [2 * math.pi] * 3
+    dom = mo.Domain(3, shape, L)
+    s = 9 * n // 32
+    phase = torch.zeros(shape, dtype=torch.float64)
+    phase[-s:, :s, -s:] = 1.0
+    K = (1.0 - phase) * 0.833 + phase * 8.33
+    mu = (1.0 - phase) * 0.386 + phase * 3.86
+    ref = mo.FFTMechanicsOracle.__new__(mo.FFTMechanicsOracle)
+    ref.dom, ref.ids, ref.K, ref.mu = dom, mo.MechIdentities(3), K, mu
+    ref.l_tol, ref.nl_rel_tol, ref.nl_abs_tol, ref.l_max_its, ref.nl_max_its = 1e-2, 2e-2, 2e-2, n ** 3, 100
+    ref.r2_shape, ref.P, ref.K4 = dom.value_shape([3, 3]), None, None
+    ref.G = lambda A2: mo.gamma_closed_form(dom, A2.reshape(ref.r2_shape)).reshape(-1)
+    F0 = torch.eye(3, dtype=torch.float64).expand(dom.value_shape([3, 3])).contiguous()
+    applied = torch.eye(3, dtype=torch.float64)
+    applied[0, 1] += 0.001
+    applied = applied - dom.average(F0)
+    Fref, rst = ref.compute(F0, applied)
+    ctx = Context(3, shape, L)
+    Fg, P, st = ctx.mech_newton_cg(F0.cuda(), K.cuda(), mu.cuda(), applied.cuda(), l_tol=1e-2, nl_rel_tol=2e-2, nl_abs_tol=2e-2)
+    assert st["newton_its"] == rst.newton_its and list(st["cg_its"]) == list(rst.cg_its)
+    assert (Fg.cpu() - Fref).abs().max().item() <= 1e-10

@@ -342,3 +342,21 @@ def test_ch_gold_3d():
         assert np.abs(g[f"c.{k}"] - s.c.numpy()).max() <= 1e-13
         assert np.abs(g[f"mu.{k}"] - s.mu.numpy()).max() <= 1e-13
 
+
+
+def test_complex_over_real_division_is_a_reciprocal_multiply():
+    """AdamsBashforthMoulton.C:99 `ubar /= (1.0 - _sub_dt * *linear_reciprocal)` divides a complex tensor by a real one.  libTorch
+    promotes the divisor to complex and its complex division then evaluates (re, im) * (1 / d) -- one reciprocal and two multiplies,
+    bit for bit -- not two divisions.  The HIP kernels (ch_fused_body.h) therefore multiply by 1.0 / (1.0 - dt * Lbar): that IS the
+    reference's rounding; true component-wise division differs from it in the last bit for a part of the elements."""
+    torch.manual_seed(1)
+    u = torch.randn(200000, dtype=torch.complex128)
+    d = 1.0 + 3.0 * torch.rand(200000, dtype=torch.float64)
+    ref = u / d
+    inplace = u.clone()
+    inplace /= d
+    recip = u * (1.0 / d)
+    true_div = torch.view_as_complex(torch.view_as_real(u) / d[:, None])
+    assert torch.equal(torch.view_as_real(ref), torch.view_as_real(recip))
+    assert torch.equal(torch.view_as_real(inplace), torch.view_as_real(recip))
+    assert not torch.equal(torch.view_as_real(ref), torch.view_as_real(true_div))
