@@ -24,6 +24,7 @@
 //   condition of the GLOBAL grid and keeps its y-slab, and writes <out>/<buffer>.<frame>.rank<r>.bin = its slab (the reference's
 //   rankNNNN files).  device=r (default: rank modulo the visible GPUs; device=0 puts all ranks on one GPU, which the library's
 //   IPC transport supports), transport=1|2|3 (peer stores, copy engines, RCCL).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -88,7 +89,23 @@ static int run_cahnhilliard(DomainAction & domain, const std::string & out)
 {
   TensorProblem problem(domain);
   const std::size_t n = domain.getNumberOfCells();
-  problem.getBuffer("c") = DeviceTensor::fromHost(local_block(domain, read_bin(arg("ic"), domain.getGlobalNumberOfCells())));  // RandomTensor IC
+  // RandomTensor IC: a file holding the global field, or ic=splitmix64 (the counter-based generator of bench.py: uniform [0.44, 0.56])
+  std::vector<double> ic;
+  if (arg("ic") == "splitmix64")
+  {
+    ic.resize((std::size_t)domain.getGlobalNumberOfCells());
+    for (std::size_t i = 0; i < ic.size(); ++i)
+    {
+      uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z = z ^ (z >> 31);
+      ic[i] = 0.44 + (0.56 - 0.44) * ((double)(z >> 11) * (1.0 / 9007199254740992.0));
+    }
+  }
+  else
+    ic = read_bin(arg("ic"), domain.getGlobalNumberOfCells());
+  problem.getBuffer("c") = DeviceTensor::fromHost(local_block(domain, ic));
   problem.getBuffer("mu") = DeviceTensor::zeros(n);                        // ConstantTensor
   AdamsBashforthMoulton::Params p;
   p.substeps = (unsigned int)argi("substeps", 1);
@@ -156,6 +173,35 @@ static int run_cahnhilliard(DomainAction & domain, const std::string & out)
   }
   if (!dts.empty())
     ex.setTimeStepper([dts](int t_step) { return dts[std::min<std::size_t>((std::size_t)t_step - 1, dts.size() - 1)]; });
+  if (arg("output") == "xdmf" || arg("output") == "none")
+  {
+    // [TensorOutputs] XDMFTensorOutput buffer = 'c mu' (examples/cahn_hilliard/cahnhilliard2.i:41-51) in its raw-binary mode: the
+    // fields leave the GPU asynchronously and are written by a thread while the next time step computes; `output=none` runs the
+    // same steps without any output.  Prints the whole-run wall time (what doc/content/installation.md:36-42 tabulates).
+    std::unique_ptr<XDMFTensorOutput> xdmf;
+    if (arg("output") == "xdmf")
+    {
+      XDMFTensorOutput::Params op;
+      op.buffer = {"c", "mu"};
+      op.file_base = out + "/" + arg("file_base", "cahnhilliard_out");
+      xdmf = std::make_unique<XDMFTensorOutput>(problem, op);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    ex.execute((int)argi("num_steps", 1), [&](int) {
+      if (xdmf)
+        xdmf->startOutput();
+    });
+    if (xdmf)
+      xdmf->waitForCompletion();
+    domain.check(mrl_sync(domain.ctx()));
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double updates = (double)domain.getGlobalNumberOfCells() * (double)p.substeps * (double)argi("num_steps", 1);
+    if (domain.rank() == 0)
+      std::printf("{\"wall_s\": %.3f, \"grid_point_updates_per_s\": %.6e, \"frames\": %d, \"seconds_in_writer_thread\": %.3f, \"time\": %.17g}\n",
+                  wall, updates / wall, xdmf ? xdmf->frames() : 0, xdmf ? xdmf->secondsWriting() : 0.0, problem.time());
+    mrl_parsed_destroy(parsed);
+    return 0;
+  }
   dump(out, "c", 0, problem.getBuffer("c"));
   ex.execute((int)argi("num_steps", 1), [&](int step) {
     dump(out, "c", step, problem.getBuffer("c"));

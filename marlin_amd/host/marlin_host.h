@@ -21,10 +21,15 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <fstream>
 #include <functional>
 #include <map>
+#include <sstream>
+#include <thread>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -2034,6 +2039,269 @@ private:
 };
 
 /// MOOSE Transient as far as the path sees it: advanceState, then the solver at EXEC_TIMESTEP_BEGIN
+/// XDMFTensorOutput (src/tensor_outputs/XDMFTensorOutput.C:58-470, threading model of TensorOutput.C:66-81) in its raw-binary mode
+/// (enable_hdf5 = false): one little-endian file per buffer component and frame, `<file_base>[.rankNNNN].<name>[_<comp>].<frame>.bin`
+/// (:742-760), described by `<file_base>.xmf` (XDMF 2.2, temporal collection; in FFT_SLAB runs every time step is a spatial
+/// collection of the ranks' blocks, :420-470).  CELL data; `transpose` (default true) swaps x <-> y (2-D) or x <-> z (3-D) as the
+/// reference does for Paraview (:128-131, 278-292).
+/// Device-speed path: startOutput() enqueues ASYNCHRONOUS device-to-host copies of the registered buffers into pinned staging memory
+/// (two sets, used alternately) on a side stream that is ordered behind the solver's work, and hands the frame to a writer thread;
+/// the solver's next time step starts at once.  Only the next startOutput() waits for the writer (TensorOutput::waitForCompletion).
+class XDMFTensorOutput
+{
+public:
+  struct Params
+  {
+    std::vector<std::string> buffer;       ///< names of the (real-space) buffers to write
+    std::vector<int> components;           ///< values per grid point of each buffer (1 = scalar); empty = all scalar
+    std::string file_base = "out";
+    bool transpose = true;
+  };
+  XDMFTensorOutput(TensorProblem & problem, const Params & p) : _problem(problem), _domain(problem.domain()), _p(p)
+  {
+    if (_p.components.empty())
+      _p.components.assign(_p.buffer.size(), 1);
+    if (_p.components.size() != _p.buffer.size())
+      paramError("components", "one entry per buffer");
+    if (hipStreamCreateWithFlags(&_copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&_ready[0]) != hipSuccess ||
+        hipEventCreate(&_ready[1]) != hipSuccess || hipEventCreate(&_solver_done) != hipSuccess)
+      mooseError("XDMFTensorOutput: creating the copy stream failed");
+    std::size_t total = 0;
+    for (const int c : _p.components)
+      total += (std::size_t)_domain.getNumberOfCells() * c;
+    for (auto & st : _staging)
+      if (hipHostMalloc(reinterpret_cast<void **>(&st), sizeof(double) * total) != hipSuccess)
+        mooseError("XDMFTensorOutput: pinned staging allocation failed");
+    if (_domain.rank() == 0)
+      writeXMF();   // skeleton (valid XDMF with zero frames)
+  }
+  ~XDMFTensorOutput()
+  {
+    waitForCompletion();
+    for (auto & st : _staging)
+      (void)hipHostFree(st);
+    (void)hipEventDestroy(_ready[0]);
+    (void)hipEventDestroy(_ready[1]);
+    (void)hipEventDestroy(_solver_done);
+    (void)hipStreamDestroy(_copy_stream);
+  }
+  /// TensorOutput::startOutput: snapshot (asynchronously) and write in the background
+  void startOutput()
+  {
+    // the staging set of this frame was last used two frames ago, whose writer was joined when the previous frame started: the
+    // copies of this frame can go out while the previous frame is still being written
+    double * stage = _staging[_frame % 2];
+    // order the copies behind everything the solver has enqueued (it works on the context's stream = the HIP null stream here)
+    if (hipEventRecord(_solver_done, nullptr) != hipSuccess || hipStreamWaitEvent(_copy_stream, _solver_done, 0) != hipSuccess)
+      mooseError("XDMFTensorOutput: ordering the copy stream failed");
+    std::size_t off = 0;
+    auto & held = _held[_frame % 2];
+    held.clear();
+    for (std::size_t b = 0; b < _p.buffer.size(); ++b)
+    {
+      const DeviceTensor t = _problem.getBuffer(_p.buffer[b]);   // a handle: keeps the array alive while it is being copied
+      const std::size_t n = (std::size_t)_domain.getNumberOfCells() * _p.components[b];
+      if (!t.defined() || t.numel() != n)
+        mooseError("XDMFTensorOutput: buffer '" + _p.buffer[b] + "' is undefined or has an unexpected size");
+      if (hipMemcpyAsync(stage + off, t.data(), sizeof(double) * n, hipMemcpyDeviceToHost, _copy_stream) != hipSuccess)
+        mooseError("XDMFTensorOutput: hipMemcpyAsync failed");
+      held.push_back(t);
+      off += n;
+    }
+    if (hipEventRecord(_ready[_frame % 2], _copy_stream) != hipSuccess)
+      mooseError("XDMFTensorOutput: hipEventRecord failed");
+    waitForCompletion();   // "Output thread is already running. Must call waitForCompletion() first."
+    const double time = _problem.time();   // a dedicated output time, not changed while the output runs
+    const int frame = _frame++;
+    _times.push_back(time);
+    _thread = std::thread([this, stage, frame]() { this->output(stage, frame); });
+  }
+  void waitForCompletion()
+  {
+    if (_thread.joinable())
+      _thread.join();
+    if (!_error.empty())
+      mooseError(_error);
+  }
+  int frames() const { return _frame; }
+  double secondsWriting() const { return _seconds_writing; }
+
+private:
+  std::string rankTag() const
+  {
+    if (!_domain.isSlab())
+      return "";
+    char buf[32];
+    std::snprintf(buf, sizeof buf, ".rank%04d", _domain.rank());
+    return buf;
+  }
+  std::string binaryFileName(const std::string & setname, int rank) const
+  {
+    char buf[32] = "";
+    if (_domain.isSlab())
+      std::snprintf(buf, sizeof buf, ".rank%04d", rank);
+    return _p.file_base + buf + "." + setname + ".bin";
+  }
+  static std::string componentName(const std::string & name, int comps, int c)
+  {
+    return comps == 1 ? name : name + "_" + std::to_string(c);   // buildAttributeNames
+  }
+  /// the writer thread: wait for the copies of this frame, transpose on the host, write the files, update the .xmf
+  void output(const double * stage, int frame)
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (hipEventSynchronize(_ready[frame % 2]) != hipSuccess)
+    {
+      _error = "XDMFTensorOutput: waiting for the device-to-host copies failed";
+      return;
+    }
+    const auto & ls = _domain.getLocalShape();
+    const int dim = _domain.getDim();
+    const int64_t n0 = ls[0], n1 = dim > 1 ? ls[1] : 1, n2 = dim > 2 ? ls[2] : 1;
+    const std::size_t cells = (std::size_t)(n0 * n1 * n2);
+    std::vector<double> slice(cells);
+    std::size_t off = 0;
+    for (std::size_t b = 0; b < _p.buffer.size(); ++b)
+    {
+      const int comps = _p.components[b];
+      for (int c = 0; c < comps; ++c)
+      {
+        const double * src = stage + off;
+        // component c of a value-major field, transposed x <-> last axis if requested
+        if (dim == 3 && _p.transpose)
+        {
+          for (int64_t k = 0; k < n2; ++k)
+            for (int64_t j = 0; j < n1; ++j)
+              for (int64_t i = 0; i < n0; ++i)
+                slice[(std::size_t)((k * n1 + j) * n0 + i)] = src[(std::size_t)(((i * n1 + j) * n2 + k)) * comps + c];
+        }
+        else if (dim == 2 && _p.transpose)
+        {
+          for (int64_t j = 0; j < n1; ++j)
+            for (int64_t i = 0; i < n0; ++i)
+              slice[(std::size_t)(j * n0 + i)] = src[(std::size_t)(i * n1 + j) * comps + c];
+        }
+        else
+          for (std::size_t e = 0; e < cells; ++e)
+            slice[e] = src[e * comps + c];
+        const std::string setname = componentName(_p.buffer[b], comps, c) + "." + std::to_string(frame);
+        std::ofstream f(binaryFileName(setname, _domain.rank()), std::ios::binary);
+        if (!f || !f.write(reinterpret_cast<const char *>(slice.data()), sizeof(double) * cells))
+        {
+          _error = "XDMFTensorOutput: cannot write " + binaryFileName(setname, _domain.rank());
+          return;
+        }
+      }
+      off += cells * comps;
+    }
+    if (_domain.rank() == 0)
+      writeXMF();
+    _seconds_writing += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  /// the whole .xmf file for the frames written so far (rank 0; small, rewritten every frame as the reference's _doc.save_file)
+  void writeXMF()
+  {
+    const int dim = _domain.getDim();
+    const auto & g = _domain.getShape();
+    auto axis = [&](int i) { return _p.transpose ? dim - 1 - i : i; };   // mappedAxis
+    std::ostringstream x;
+    x.precision(17);
+    x << "<?xml version=\"1.0\"?>\n<Xdmf xmlns:xi=\"http://www.w3.org/2003/XInclude\" Version=\"2.2\">\n <Domain>\n";
+    std::string nodes, cellsdim, origin, spacing, geo = "ORIGIN_";
+    const char * dxyz[] = {"DX", "DY", "DZ"};
+    for (int i = 0; i < dim; ++i)
+    {
+      const int j = axis(i);
+      nodes += (i ? " " : "") + std::to_string(g[j] + 1);
+      cellsdim += (i ? " " : "") + std::to_string(g[j]);
+      std::ostringstream o, d;
+      o.precision(17);
+      d.precision(17);
+      o << 0.0;
+      d << _domain.getExtent(j) / (double)g[j];
+      origin += (i ? " " : "") + o.str();
+      spacing += (i ? " " : "") + d.str();
+      geo += dxyz[i];
+    }
+    if (!_domain.isSlab())
+    {
+      x << "  <Topology TopologyType=\"" << dim << "DCoRectMesh\" Dimensions=\"" << nodes << "\"/>\n";
+      x << "  <Geometry Type=\"" << geo << "\">\n   <DataItem Format=\"XML\" Dimensions=\"" << dim << "\">" << origin
+        << "</DataItem>\n   <DataItem Format=\"XML\" Dimensions=\"" << dim << "\">" << spacing << "</DataItem>\n  </Geometry>\n";
+    }
+    x << "  <Grid Name=\"TimeSeries\" GridType=\"Collection\" CollectionType=\"Temporal\">\n";
+    for (int f = 0; f < (int)_times.size(); ++f)
+    {
+      if (!_domain.isSlab())
+      {
+        x << "   <Grid Name=\"T" << f << "\" GridType=\"Uniform\">\n    <Time Value=\"" << _times[f] << "\"/>\n"
+          << "    <xi:include xpointer=\"xpointer(//Xdmf/Domain/Topology)\"/>\n    <xi:include xpointer=\"xpointer(//Xdmf/Domain/Geometry)\"/>\n";
+        attributes(x, f, 0, cellsdim);
+        x << "   </Grid>\n";
+        continue;
+      }
+      // FFT_SLAB: a spatial collection of the ranks' y-slabs (writeParallelXMF, XDMFTensorOutput.C:420-470)
+      x << "   <Grid Name=\"T" << f << "\" GridType=\"Collection\" CollectionType=\"Spatial\">\n    <Time Value=\"" << _times[f] << "\"/>\n";
+      int64_t ybeg = 0;
+      for (int r = 0; r < _domain.nranks(); ++r)
+      {
+        std::vector<int64_t> counts(_domain.nranks());
+        if (mrl_partition(g[1], _domain.nranks(), nullptr, counts.data()) != MRL_OK)
+          mooseError("XDMFTensorOutput: partition failed");
+        std::string rn, rc, ro;
+        for (int i = 0; i < dim; ++i)
+        {
+          const int j = axis(i);
+          const int64_t cnt = j == 1 ? counts[r] : g[j];
+          rn += (i ? " " : "") + std::to_string(cnt + 1);
+          rc += (i ? " " : "") + std::to_string(cnt);
+          std::ostringstream o;
+          o.precision(17);
+          o << (j == 1 ? (double)ybeg * _domain.getExtent(1) / (double)g[1] : 0.0);
+          ro += (i ? " " : "") + o.str();
+        }
+        x << "    <Grid Name=\"Rank" << r << "\" GridType=\"Uniform\">\n     <Topology TopologyType=\"" << dim << "DCoRectMesh\" Dimensions=\"" << rn
+          << "\"/>\n     <Geometry Type=\"" << geo << "\">\n      <DataItem Format=\"XML\" Dimensions=\"" << dim << "\">" << ro
+          << "</DataItem>\n      <DataItem Format=\"XML\" Dimensions=\"" << dim << "\">" << spacing << "</DataItem>\n     </Geometry>\n";
+        attributes(x, f, r, rc);
+        x << "    </Grid>\n";
+        ybeg += counts[r];
+      }
+      x << "   </Grid>\n";
+    }
+    x << "  </Grid>\n </Domain>\n</Xdmf>\n";
+    std::ofstream f(_p.file_base + ".xmf");
+    f << x.str();
+  }
+  void attributes(std::ostringstream & x, int frame, int rank, const std::string & dims) const
+  {
+    for (std::size_t b = 0; b < _p.buffer.size(); ++b)
+      for (int c = 0; c < _p.components[b]; ++c)
+      {
+        const std::string name = componentName(_p.buffer[b], _p.components[b], c);
+        std::string file = binaryFileName(name + "." + std::to_string(frame), rank);
+        const auto slash = file.find_last_of('/');
+        if (slash != std::string::npos)
+          file = file.substr(slash + 1);   // relative to the .xmf file
+        x << "     <Attribute Name=\"" << name << "\" Center=\"Cell\">\n      <DataItem DataType=\"Float\" Dimensions=\"" << dims
+          << "\" Format=\"Binary\" Endian=\"Little\" Precision=\"8\">" << file << "</DataItem>\n     </Attribute>\n";
+      }
+  }
+
+  TensorProblem & _problem;
+  DomainAction & _domain;
+  Params _p;
+  hipStream_t _copy_stream = nullptr;
+  hipEvent_t _ready[2] = {nullptr, nullptr}, _solver_done = nullptr;
+  double * _staging[2] = {nullptr, nullptr};
+  std::vector<DeviceTensor> _held[2];
+  std::vector<double> _times;
+  std::thread _thread;
+  std::string _error;
+  int _frame = 0;
+  double _seconds_writing = 0.0;
+};
+
 class Transient
 {
 public:

@@ -117,6 +117,48 @@ def test_cahnhilliard_adaptive_dt(extra, tmp_path):
         assert np.abs(ref.c.numpy() - c).max() <= 1e-13
 
 
+@pytest.mark.parametrize("slab", [False, True])
+def test_xdmf_tensor_output_async(slab, tmp_path):
+    """[TensorOutputs] XDMFTensorOutput (XDMFTensorOutput.C:278-343, 742-760; TensorOutput.C:66-81) in raw-binary mode through the
+    asynchronous path: device-to-host copies on a side stream into pinned staging + a writer thread while the next time step
+    computes.  cahnhilliard.i, 10 steps: file <base>[.rankNNNN].c.<frame>.bin holds c (transposed, as the reference writes it for
+    Paraview) of time step frame + 1 == gold c.(frame + 1) to 1e-13; the .xmf is well-formed and lists every frame"""
+    import xml.etree.ElementTree as ET
+    if slab:
+        import torch
+        g = load_golden("cahnhilliard_rank0001_gold.npz")
+        torch.manual_seed(0)
+        blk = (torch.rand(20, 10, dtype=torch.float64) * (0.56 - 0.44) + 0.44).numpy()
+        c0 = np.concatenate([blk, blk], axis=1)
+        extra = ["parallel_mode=FFT_SLAB", "nranks=2", "device=0"]
+    else:
+        g = load_golden("cahnhilliard_gold.npz")
+        c0 = g["c.0"][:20, :20]
+        extra = []
+    ic = tmp_path / "c0.bin"
+    c0.astype("<f8").tofile(ic)
+    out = _run(["problem=cahnhilliard", "dim=2", "nx=20", "ny=20", "xmax=3", "ymax=3", f"ic={ic}", "substeps=10", "num_steps=10", "dt=1e-3",
+                "predictor_order=2", "mobility=0.2", "kappa=-0.001", "output=xdmf", "file_base=ch"] + extra, tmp_path)
+    assert '"frames": 10' in out
+    worst = 0.0
+    for frame in range(10):
+        if slab:
+            c = np.fromfile(tmp_path / f"ch.rank0001.c.{frame}.bin", dtype="<f8").reshape(10, 20).T     # stored transposed: [y_local][x]
+            worst = max(worst, np.abs(g[f"c.{frame + 1}"] - c).max())
+        else:
+            c = np.fromfile(tmp_path / f"ch.c.{frame}.bin", dtype="<f8").reshape(20, 20).T
+            worst = max(worst, np.abs(g[f"c.{frame + 1}"][:20, :20] - c).max())
+    assert worst <= 1e-13, worst
+    if not slab:
+        mu = np.fromfile(tmp_path / "ch.mu.9.bin", dtype="<f8").reshape(20, 20).T
+        assert np.abs(g["mu.10"] - mu).max() <= 1e-13
+    root = ET.parse(tmp_path / "ch.xmf").getroot()
+    series = root.find("Domain").find("Grid")
+    assert series.get("CollectionType") == "Temporal" and len(series.findall("Grid")) == 10
+    items = [d.text for d in root.iter("DataItem") if d.get("Format") == "Binary"]
+    assert len(items) == 10 * 2 * (2 if slab else 1) and all((tmp_path / t).exists() for t in items)
+
+
 def test_mechanics_case_fft_slab(tmp_path):
     """mech3d.i (test/tests/mechanics/tests:2-21) on 2 rank processes: the C++ FFTMechanics object over mrl_mech_newton_cg on slab
     contexts; F_k.frame and sV of mech3d.h5 to 1e-10"""
