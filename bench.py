@@ -90,7 +90,7 @@ def measured_traffic(slot, n, order_tag):
     with open(path) as f:
         t = json.load(f)
     pref = KERNEL_OF_SLOT[slot]
-    cands = [k for k in t if k.startswith(pref) and (order_tag is None or order_tag in k)]
+    cands = [k for k in t if not k.startswith("_") and k.startswith(pref) and (order_tag is None or order_tag in k)]
     if slot == "ch_B_y_fwd":
         cands = [k for k in cands if "false, 2" in k]
     if slot == "ch_D_y_inv":
@@ -100,7 +100,10 @@ def measured_traffic(slot, n, order_tag):
     v = t[cands[0]]
     if v.get("fetch_bytes") is None or v.get("write_bytes") is None:
         return None, None
-    return v["fetch_bytes"] + v["write_bytes"], os.path.relpath(path, ROOT)
+    from tools.summarize_prof import kernel_sources_sha256
+    same = t.get("_kernel_sources_sha256") == kernel_sources_sha256()
+    return v["fetch_bytes"] + v["write_bytes"], os.path.relpath(path, ROOT) + (" (counters taken on these kernel sources)" if same else
+                                                                           " (counters taken on OLDER kernel sources)")
 
 
 def cpu_baseline(shape, dx, sample_steps, keep=()):

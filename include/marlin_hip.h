@@ -296,6 +296,8 @@ int mrl_broyden_update(mrl_ctx *ctx, int nvar, double *d_M, double *d_R, const d
  *   forward send  [p][field c, mu][x_p ][y_me][K_s]      forward recv  [p][field c, mu][x_me][y_p ][K_s]
  *   inverse send  [p][x_me][y_p ][K_s]                   inverse recv  [p][x_p ][y_me][K_s]
  * d_Nhat_new / d_Nhat_old / d_cbar are the dense reciprocal arrays [x_me][ny][nzc] of the reference.
+ * The last index of the exchange layouts has the pitch mrl_slab_ch_k_pitch(ctx, s, nsub) >= |K_s| (planned shapes pad the rows to
+ * 128-byte lines; the padding is never read); mrl_slab_ch_counts returns the sizes that follow from it.
  *
  * Spectral carry-over (`carry`).  The reference recomputes cbar = fft(c) in every substep although c = ifft(ubar) of
  * the previous one; fft(ifft(.)) is the identity up to rounding (1e-16 relative), so a rank can keep ubar -- it is produced
@@ -314,6 +316,7 @@ int mrl_broyden_update(mrl_ctx *ctx, int nvar, double *d_M, double *d_R, const d
  * row segments: with the odd natural pitch each of them straddles two lines and the pass moves 1.5x its algorithmic bytes, measured
  * with the FETCH_SIZE / WRITE_SIZE counters).  Allocate x_me*ny*pitch complex values per array; the padding is never read. */
 int64_t mrl_slab_ch_spec_pitch(const mrl_ctx *ctx);
+int64_t mrl_slab_ch_k_pitch(const mrl_ctx *ctx, int sub, int nsub);
 int mrl_slab_ch_counts(const mrl_ctx *ctx, int sub, int nsub, int forward, int carry, int64_t *h_send_counts,
                        int64_t *h_recv_counts);
 int mrl_slab_ch_z_fwd(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_mu /* optional out */, int carry);

@@ -109,6 +109,7 @@ SIGNATURES = {
     "mrl_secant_begin": (_i32, [_vp, _vp, _vp, _vp, _dbl, _dbl, _vp, _vp, C.POINTER(_dbl), _i64]),
     "mrl_secant_iterate": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, C.POINTER(_dbl), _i64]),
     "mrl_slab_ch_spec_pitch": (_i64, [_vp]),
+    "mrl_slab_ch_k_pitch": (_i64, [_vp, _i32, _i32]),
     "mrl_slab_ch_counts": (_i32, [_vp, _i32, _i32, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
     "mrl_slab_ch_z_fwd": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _i32]),
     "mrl_slab_ch_x_fwd": (_i32, [_vp, _i32, _i32, _vp, _i32]),

@@ -1,4 +1,5 @@
 // Context, planning and the host-only helpers of the C ABI (mirrors DomainAction's set-up work).
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -9,6 +10,9 @@
 namespace mrl {
 
 thread_local std::string g_create_error;
+// one DEVICE per process (include/marlin_hip.h): the per-kernel attributes (dynamic LDS sizes) are set once per process on the
+// device of the first context; a context on another device is refused instead of launching with unset attributes
+static std::atomic<int> g_process_device{-1};
 
 int set_error(const mrl_ctx *ctx, int code, const char *fmt, ...) {
   char buf[1024];
@@ -230,6 +234,13 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
   } else if (hipGetDevice(&c->device) != hipSuccess) {
     set_error(c, MRL_ERR_HIP, "no HIP device available (the HIP path has no CPU fallback)");
     return fail(MRL_ERR_HIP);
+  }
+  {
+    int expected = -1;
+    if (!g_process_device.compare_exchange_strong(expected, c->device) && expected != c->device) {
+      set_error(c, MRL_ERR_UNSUPPORTED, "this process already runs contexts on device %d: one device per process (one MPI rank <-> one device, DomainAction.C:197-198)", expected);
+      return fail(MRL_ERR_UNSUPPORTED);
+    }
   }
   if (!(dom->flags & MRL_FLAG_OWN_STREAM)) {
     c->stream = static_cast<hipStream_t>(dom->stream);

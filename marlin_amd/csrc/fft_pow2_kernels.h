@@ -402,6 +402,7 @@ struct SubPassArgs {
   int sh_in, sh_out;
   unsigned cs_in;
   unsigned fs_out, fo_out;   // !INV: element offset of field f within a chunk = fo_out + f * fs_out
+  int nt_out;                // !INV: non-temporal stores (experiment)
   SignalArgs sig;
 };
 
@@ -448,7 +449,11 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub(SubPassArgs a, cons
           a.out[f][bo + (n & mo) * a.sn_out] = cswap(v[f][m]);
         } else {
           cplx *base = a.otab[n >> a.sh_out];
-          base[a.fo_out + (unsigned)f * a.fs_out + bo + (n & mo) * a.sn_out] = v[f][m];
+          cplx *dst = base + (a.fo_out + (unsigned)f * a.fs_out + bo + (n & mo) * a.sn_out);
+          if (a.nt_out)
+            st_nt(dst, v[f][m]);
+          else
+            *dst = v[f][m];
         }
       }
     }

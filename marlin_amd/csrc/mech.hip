@@ -531,8 +531,13 @@ int mrl_mech_tangent_apply_fm(mrl_ctx *ctx, const double *d_F, const double *d_K
 // CG building blocks for callers that own the iteration (slab contexts: the scalars are all-reduced between the calls)
 static int put_scalars(mrl_ctx *ctx, double a, double b, double **S) {
   *S = ctx->d_red + kScalarBase + 8;
-  const double hs[2] = {a, b};  // pageable source: staged by the runtime before the call returns
-  MRL_HIP(ctx, hipMemcpyAsync(*S, hs, sizeof(hs), hipMemcpyHostToDevice, ctx->stream));
+  // source in PINNED host memory (a ring of eight pairs in the context's scratch: every caller synchronises at least once per CG
+  // iteration, so a pair is never overwritten before its copy has run) -- no reliance on how the runtime stages pageable copies
+  static_assert(32 + 2 * 8 <= 64, "pinned scratch too small");
+  double *hs = ctx->h_red + 32 + 2 * (ctx->scalar_ring++ & 7);
+  hs[0] = a;
+  hs[1] = b;
+  MRL_HIP(ctx, hipMemcpyAsync(*S, hs, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   return MRL_OK;
 }
 

@@ -91,7 +91,8 @@ struct mrl_ctx {
   double *d_work[mrl::kWorkSlots] = {};
   size_t work_bytes[mrl::kWorkSlots] = {};
   double *d_red = nullptr;      // reduction scratch
-  double *h_red = nullptr;      // pinned host scratch
+  double *h_red = nullptr;      // pinned host scratch: [0,32) reduction results, [32,48) / [48,64) rings of host scalars on their way to the device
+  unsigned scalar_ring = 0;
   double *d_h_red = nullptr;    // its device-side address (kernels may write results there), nullptr if not mappable
 
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;

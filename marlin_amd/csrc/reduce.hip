@@ -316,6 +316,8 @@ extern "C" int mrl_histogram(mrl_ctx *ctx, const double *d_a, int64_t n, const d
   if (n > 0) {
     long long nb = (n + 255) / 256;
     if (nb > 1024) nb = 1024;
+    if (cb + eb > 64 * 1024)  // 4096 bins need 65 544 bytes of dynamic LDS: above the 64 KiB default
+      MRL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_histogram), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(cb + eb)));
     hipLaunchKernelGGL(k_histogram, dim3((unsigned)nb), dim3(256), cb + eb, ctx->stream, d_a, (long long)n, d_edges, nbins, d_counts);
     MRL_HIP(ctx, hipGetLastError());
   }

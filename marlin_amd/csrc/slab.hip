@@ -364,8 +364,9 @@ int mrl_slab_ch_counts(const mrl_ctx *ctx, int sub, int nsub, int forward, int c
   long long k0, ksub;
   MRL_TRY(slab_sub_range(const_cast<mrl_ctx *>(ctx), sub, nsub, &k0, &ksub));
   const long long nf = (forward && carry != MRL_CARRY_IN) ? 2 : 1;  // the forward messages carry both fields (mu-hat only with the carry-over)
+  const long long kp = slab_kpitch(ctx, ksub);  // planned shapes: rows of the exchange layouts are padded to 128-byte lines
   for (int p = 0; p < ctx->nranks; ++p) {
-    const long long x_p_y_me = ctx->part_recip[p] * ctx->nloc[1] * ksub, x_me_y_p = ctx->nrec[0] * ctx->part_real[p] * ksub;
+    const long long x_p_y_me = ctx->part_recip[p] * ctx->nloc[1] * kp, x_me_y_p = ctx->nrec[0] * ctx->part_real[p] * kp;
     if (h_send_counts) h_send_counts[p] = nf * (forward ? x_p_y_me : x_me_y_p);
     if (h_recv_counts) h_recv_counts[p] = nf * (forward ? x_me_y_p : x_p_y_me);
   }
@@ -400,7 +401,7 @@ int mrl_slab_ch_x_fwd(mrl_ctx *ctx, int sub, int nsub, double *d_send, int carry
     // the pass scatters through a destination table: here every chunk goes to the caller's contiguous send buffer
     const size_t nf = carry == MRL_CARRY_IN ? 1 : 2;
     cplx *const *tab;
-    MRL_TRY(local_tab(ctx, 0, d_send, sizeof(cplx) * nf * (size_t)(ctx->nrec[0] * ctx->nloc[1] * ksub), &tab));
+    MRL_TRY(local_tab(ctx, 0, d_send, sizeof(cplx) * nf * (size_t)(ctx->nrec[0] * ctx->nloc[1] * slab_kpitch(ctx, ksub)), &tab));
     return slab_ch_x_fwd_fast(ctx, (int)k0, (int)ksub, tab, SignalArgs{}, carry);
   }
   return gen_x_fwd(ctx, k0, ksub, d_send, carry);
@@ -410,6 +411,13 @@ int64_t mrl_slab_ch_spec_pitch(const mrl_ctx *ctx) {
   if (!ctx) return 0;
   const long long nzc = ctx->nrec[ctx->dim - 1];
   return (ctx->slab && slab_fast_ok(ctx)) ? ((nzc + 7) & ~7LL) : nzc;
+}
+
+int64_t mrl_slab_ch_k_pitch(const mrl_ctx *ctx, int sub, int nsub) {
+  if (!ctx || !ctx->slab) return 0;
+  long long k0, ksub;
+  if (slab_sub_range(const_cast<mrl_ctx *>(ctx), sub, nsub, &k0, &ksub) != MRL_OK) return 0;
+  return slab_kpitch(ctx, ksub);
 }
 
 int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, int sub, int nsub, const double *d_recv, double *d_send,
@@ -429,7 +437,7 @@ int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, int sub, int nsub, 
   MRL_TRY(slab_sub_range(ctx, sub, nsub, &k0, &ksub));
   if (slab_fast_ok(ctx)) {
     cplx *const *tab;
-    MRL_TRY(local_tab(ctx, 1, d_send, sizeof(cplx) * (size_t)(ctx->nrec[0] * (ctx->n[1] / ctx->nranks) * ksub), &tab));
+    MRL_TRY(local_tab(ctx, 1, d_send, sizeof(cplx) * (size_t)(ctx->nrec[0] * (ctx->n[1] / ctx->nranks) * slab_kpitch(ctx, ksub)), &tab));
     return slab_ch_kspace_fast(ctx, cp, (int)k0, (int)ksub, d_recv, tab, SignalArgs{}, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, carry);
   }
   return gen_kspace(ctx, cp, k0, ksub, d_recv, d_send, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, carry);

@@ -31,8 +31,9 @@ struct YFusedArgs {
   FusedCommon c;      // chat: received chunks (field 0 of each chunk; field 1 = mu-hat follows at +chunk)
   int nxl, nzc;       // local x extent, kz pitch of the rank-local spectral arrays (Nhat, cbar): mrl_slab_ch_spec_pitch
   int k0, ksub;       // kz sub-block
+  int kp;             // row pitch of the exchange layouts (>= ksub: rows start on 128-byte lines)
   int nyl_shift;      // log2(ny / P)
-  unsigned chunk;     // nxl * nyl * ksub: elements of one field of one chunk
+  unsigned chunk;     // nxl * nyl * kp: elements of one field of one chunk
   int tiles_per_x;
   const double *kx, *ky, *kz;  // local reciprocal axes
   cplx *const *utab;  // ubar output: chunk p of the inverse exchange layout starts at utab[p] (a peer's receive buffer or the local send buffer)
@@ -54,11 +55,11 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
   const bool valid = kl0 < a.ksub;
   const int kl = valid ? kl0 : 0;
   // element (ix, j, k0+kl), p = j >> nyl_shift, jl = j & (nyl-1)       [byte offsets]
-  //   forward exchange layout  (p*2 + field)*chunk + (ix*nyl + jl)*ksub + kl
-  //   inverse exchange layout   p*chunk            + (ix*nyl + jl)*ksub + kl
+  //   forward exchange layout  (p*2 + field)*chunk + (ix*nyl + jl)*kp + kl
+  //   inverse exchange layout   p*chunk            + (ix*nyl + jl)*kp + kl
   //   dense layout              (ix*N + j)*nzc + k0 + kl
   const int sh = a.nyl_shift, msk = (1 << sh) - 1;
-  const unsigned ksB = (unsigned)a.ksub * 16u, chB = a.chunk * 16u, klB = (unsigned)kl * 16u;
+  const unsigned ksB = (unsigned)a.kp * 16u, chB = a.chunk * 16u, klB = (unsigned)kl * 16u;
   // (with the carry-over only mu-hat is received: one field per chunk)
   // ALIGNED (ny/P is a multiple of the TPL threads of a line, the usual case): the chunk index and the row within the chunk of
   // element j = q + m TPL split into a wave-uniform part that depends on m only and the per-thread constant q ksB + klB, so the
@@ -116,7 +117,7 @@ int slab_fast_ok(const mrl_ctx *ctx) {
         pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2])))
     return 0;
   // 32-bit byte offsets within an exchange buffer (two fields in the CH pipeline, the three of a tensor row in the mechanics one)
-  if (48.0 * (double)ctx->n[0] * (double)ctx->nloc[1] * (double)ctx->nrec[2] >= 4294967296.0) return 0;
+  if (48.0 * (double)ctx->n[0] * (double)ctx->nloc[1] * (double)(ctx->nrec[2] + 8) >= 4294967296.0) return 0;
   // equal power-of-two partitions: chunk addressing by shifts
   const long long nyl = ctx->n[1] / ctx->nranks, nxl = ctx->n[0] / ctx->nranks;
   if (nyl * ctx->nranks != ctx->n[1] || nxl * ctx->nranks != ctx->n[0] || (nyl & (nyl - 1)) || (nxl & (nxl - 1))) return 0;
@@ -124,6 +125,11 @@ int slab_fast_ok(const mrl_ctx *ctx) {
     if (ctx->part_real[p] != nyl || ctx->part_recip[p] != nxl) return 0;
   return 1;
 }
+
+// Row pitch (complex elements) of the exchange layouts of a kz sub-block of width ksub: rows start on 128-byte lines, so the x
+// passes write (and the y pass gathers) whole lines instead of pieces that straddle two (the spectral extent nz/2+1 is odd).  With
+// direct peer stores the padding never crosses a link; contiguous chunk pushes carry it (+2.7 % at 257 -> 264).
+long long slab_kpitch(const mrl_ctx *ctx, long long ksub) { return slab_fast_ok(ctx) ? ((ksub + 7) & ~7LL) : ksub; }
 
 static int ilog2(long long v) {
   int s = 0;
@@ -177,7 +183,8 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const 
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
   cplx *w_c, *w_mu, *w_inv;
   MRL_TRY(slab_work(ctx, &w_c, &w_mu, &w_inv));
-  const unsigned chunk = (unsigned)(nxl * nyl * ksub);
+  const long long kp = slab_kpitch(ctx, ksub);
+  const unsigned chunk = (unsigned)(nxl * nyl * kp);
   const bool one = carry == MRL_CARRY_IN;  // mu-hat only
   p2::SubPassArgs a{};
   a.in[0] = (one ? w_mu : w_c) + k0;
@@ -188,13 +195,24 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const 
   a.rows = (int)nyl;
   a.cols = ksub;
   a.pitch_in = (unsigned)nzc;
-  a.pitch_out = (unsigned)ksub;
+  a.pitch_out = (unsigned)kp;
   a.sn_in = (unsigned)(nyl * nzc);
-  a.sn_out = (unsigned)(nyl * ksub);
+  a.sn_out = (unsigned)(nyl * kp);
   a.sh_in = 31;
   a.sh_out = ilog2(nxl);
   ProfScope ps(ctx, "slab_A_x_fwd", (one ? 2.0 : 4.0) * 16.0 * nx * nyl * ksub);
+  // non-temporal stores of the exchange layout: A/B at 512^3 / 8 on one box -- rows of the natural odd pitch 182 / 162 -> 156 / 149 us,
+  // rows padded to 128-byte lines (what is used) 171 -> 211 / 220 us: off
+  a.nt_out = (ctx->exp & 512) ? 1 : 0;
   if (one) {
+    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 1>(ctx, a, ctx->ax[0].d_tw))));
+  } else if (ctx->exp & 256) {   // experiment: one field per launch (the two launches count towards one arrival flag)
+    unsigned nb = 0;
+    MRL_SWITCH_N(nx, nb = pass_sub_blocks<NN>(a.rows, a.cols));
+    a.sig.expected = 2u * nb;
+    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 1>(ctx, a, ctx->ax[0].d_tw))));
+    a.in[0] = a.in[1];
+    a.fo_out = chunk;
     MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 1>(ctx, a, ctx->ax[0].d_tw))));
   } else {
     MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 2>(ctx, a, ctx->ax[0].d_tw))));
@@ -208,7 +226,8 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const dou
   const long long nyl = ny / ctx->nranks;
   const bool spec = carry == MRL_CARRY_IN;
   p2::YFusedArgs a{};
-  a.chunk = (unsigned)(nxl * nyl * ksub);
+  a.kp = (int)slab_kpitch(ctx, ksub);
+  a.chunk = (unsigned)(nxl * nyl * a.kp);
   a.c.chat = reinterpret_cast<const cplx *>(recv);
   a.c.muhat = spec ? a.c.chat : a.c.chat + a.chunk;
   a.c.ubar = nullptr;  // scattered through utab
@@ -261,12 +280,13 @@ int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv) {
   a.out[0] = w_inv + k0;
   a.rows = (int)nyl;
   a.cols = ksub;
-  a.pitch_in = (unsigned)ksub;
+  const long long kp = slab_kpitch(ctx, ksub);
+  a.pitch_in = (unsigned)kp;
   a.pitch_out = (unsigned)nzc;
-  a.sn_in = (unsigned)(nyl * ksub);
+  a.sn_in = (unsigned)(nyl * kp);
   a.sn_out = (unsigned)(nyl * nzc);
   a.sh_in = ilog2(nxl);
-  a.cs_in = (unsigned)(nxl * nyl * ksub);
+  a.cs_in = (unsigned)(nxl * nyl * kp);
   a.sh_out = 31;
   ProfScope ps(ctx, "slab_C_x_inv", 32.0 * nx * nyl * ksub);
   MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, true, 1>(ctx, a, ctx->ax[0].d_tw))));

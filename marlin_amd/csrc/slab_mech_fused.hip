@@ -327,8 +327,12 @@ int mrl_slab_gamma_tangent_z_fwd(mrl_ctx *ctx, const double *d_F, const double *
   const long long npts = nx * nyl * nz, nspec = nx * nyl * nzc;
   MRL_TRY(ensure_work(ctx, 18, sizeof(cplx) * (size_t)(9 * nspec)));
   double *S = ctx->d_red + kScalarBase + 8;
-  const double hs[4] = {beta, 1.0, alpha_prev, 1.0};  // pageable source: staged by the runtime before the call returns
-  MRL_HIP(ctx, hipMemcpyAsync(S, hs, sizeof(hs), hipMemcpyHostToDevice, ctx->stream));
+  double *hs = ctx->h_red + 48 + 4 * (ctx->scalar_ring++ & 3);  // pinned source (ring of four quadruples, see put_scalars in mech.hip)
+  hs[0] = beta;
+  hs[1] = 1.0;
+  hs[2] = alpha_prev;
+  hs[3] = 1.0;
+  MRL_HIP(ctx, hipMemcpyAsync(S, hs, 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   ProfScope ps(ctx, "slab_gamma_z_fwd_tangent_dir", 8.0 * npts * ((d_x ? 6 : 4) * 9 + 2) + 16.0 * nspec * 9);
   MRL_TRY(gamma_z_fwd_tangent_launch(ctx, d_F, d_K, d_mu, d_p, d_r, S, 0, 1, reinterpret_cast<cplx *>(ctx->d_work[18]), npts,
                                      nx * nyl, (int)nz, 72.0 * (double)npts >= 96.0e6, d_x, 2, 3));

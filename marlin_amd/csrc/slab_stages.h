@@ -8,6 +8,7 @@ namespace mrl {
 
 int slab_fast_ok(const mrl_ctx *ctx);
 int slab_sub_range(mrl_ctx *ctx, int sub, int nsub, long long *k0, long long *ksub);
+long long slab_kpitch(const mrl_ctx *ctx, long long ksub);  // row pitch of the Cahn-Hilliard exchange layouts (slab_fused.hip)
 
 // Cahn-Hilliard, planned shapes (slab_fused.hip).  otab / utab: destination of chunk p (one entry per rank) in the forward /
 // inverse exchange layout; sig: arrival flags raised by the last workgroup of the launch (or none).

@@ -2,7 +2,7 @@
 """Time the LOCAL stages of one rank of a P-rank slab decomposition on a single GPU (the exchange is
 replaced by a device copy of the rank's own send buffer, same byte count as the receive buffer), to
 size the compute side of the 512^3 / 8-GPU configuration without an 8-GPU node.
-usage: slab_local_bench.py [P] [n] [steps] [nsub] [carry 0|1] [fused-run 0|1]"""
+usage: slab_local_bench.py [P] [n] [steps] [nsub] [carry 0|1] [fused-run 0|1] [experiment mask]"""
 import json
 import os
 import sys
@@ -33,10 +33,12 @@ def main():
     nsub = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     carry = bool(int(sys.argv[5])) if len(sys.argv) > 5 else True
     fused = bool(int(sys.argv[6])) if len(sys.argv) > 6 else True
+    exp = int(sys.argv[7]) if len(sys.argv) > 7 else 0
     shape = grid_for(P, n)
     dx = 8.0 * np.pi / 200.0
     s = SlabCahnHilliard(3, shape, [x * dx for x in shape], ch_params(), P, 0, exchange_factory=lambda a, b: _Copy(a, b), nsub=nsub,
                          carry=carry)
+    s.ctx.set_option(0, exp)
     s.set_initial(lambda count, offset: splitmix64_uniform(count, offset=offset))
     for _ in range(5):
         s.substep()
@@ -60,7 +62,7 @@ def main():
     for k in prof:
         k["avg_ms"] = k["ms"] / k["launches"]
         k["GBps"] = k["bytes_per_launch"] / k["avg_ms"] / 1e6
-    print(json.dumps({"P": P, "nsub": nsub, "carry": carry, "fused_run": fused, "global_grid": shape, "local_real": s.st.real_shape, "ms_per_substep_local_incl_copies": ms,
+    print(json.dumps({"P": P, "exp": exp, "nsub": nsub, "carry": carry, "fused_run": fused, "global_grid": shape, "local_real": s.st.real_shape, "ms_per_substep_local_incl_copies": ms,
                       "kernels": [{k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in k.items()} for k in prof]}))
 
 

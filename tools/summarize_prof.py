@@ -9,6 +9,19 @@ import sys
 from collections import defaultdict
 
 
+def kernel_sources_sha256():
+    """hash of every kernel source of the library (marlin_amd/csrc/*.hip, *.h): bench.py recomputes it and reports whether the
+    committed counter file still describes the kernels it is timing"""
+    import hashlib
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "marlin_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(here)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(here, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def short(name):
     name = name.split("(")[0]
     return name.replace("mrl::p2::", "").replace("mrl::", "").replace("void ", "")[:60]
@@ -49,6 +62,7 @@ def main(root):
         # per-launch HBM bytes (FETCH_SIZE x2 + WRITE_SIZE) per kernel: read back by bench.py as roofline.traffic
         out = {k: {"fetch_bytes": v.get("FETCH_SIZE"), "write_bytes": v.get("WRITE_SIZE")} for k, v in traffic.items()
                if k.startswith("k_")}
+        out["_kernel_sources_sha256"] = kernel_sources_sha256()   # ties the counters to the kernels they were measured on
         with open(os.path.join(root, "traffic.json"), "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)
 
