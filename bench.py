@@ -287,6 +287,7 @@ def main():
         if slab:
             dist.barrier()
 
+    native_failed = False
     if slab and args.driver == "native":
         nsub = args.nsub or 1
         job = f"mrlbench_{os.environ.get('MASTER_PORT', '0')}"
@@ -312,41 +313,81 @@ def main():
 
         if args.transport == "tune":
             # every transport this node supports runs the same substeps from the same initial condition: the fields must agree,
-            # and the fastest (max over ranks) carries the timed region
+            # and the fastest (max over ranks) carries the timed region.  A transport that fails or times out on ANY rank is dropped
+            # by all of them (the verdict is all-reduced), and the pipeline is rebuilt before the next candidate.
+            def host_min(x):
+                t = torch.tensor([x], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return float(t.item())
+
             cands, tried = [], {}
+            comm.set_timeout(20.0)
             for t in (api.TRANSPORT_PEER_STORE, api.TRANSPORT_PEER_COPY, api.TRANSPORT_RCCL):
                 name = api.TRANSPORT_NAMES[t]
+                ok, why, ms = 1.0, "", 0.0
                 try:
                     comm.set_transport(t)
+                except api.MarlinHipError as e:     # (the verdict of an unavailable transport is collective: every rank lands here)
+                    tried[name] = {"unavailable": e.message[:160]}
+                    continue
+                try:
                     solver.reset()
                     steps(3)
-                    torch.cuda.synchronize()
+                    solver.ctx.sync()
                     barrier()
                     t0 = time.perf_counter()
                     steps(6)
                     solver.ctx.sync()
-                    ms = host_max((time.perf_counter() - t0) / 6 * 1e3)
-                    tried[name] = {"ms_per_step": round(ms, 4), "checksum": checksum()}
-                    cands.append((ms, t))
-                except api.MarlinHipError as e:     # (the verdict of an unavailable transport is collective: every rank lands here)
-                    tried[name] = {"unavailable": e.message[:160]}
+                    ms = (time.perf_counter() - t0) / 6 * 1e3
+                except api.MarlinHipError as e:
+                    ok, why = 0.0, e.message[:160]
+                if host_min(ok) == 0.0:
+                    tried[name] = {"failed": why or "on another rank"}
+                    # tear the pipeline down on every rank, clear the condition, start over with fresh exchange buffers
+                    torch.cuda.synchronize()
+                    solver.ctx.close()
+                    comm.reset_error()
+                    barrier()
+                    solver = NativeSlabCH(api, shape, L, p, world, rank, dev, comm, nsub, carry)
+                    if args.exp:
+                        solver.ctx.set_option(api.OPT_EXPERIMENT, args.exp)
+                    continue
+                tried[name] = {"ms_per_step": round(host_max(ms), 4), "checksum": checksum()}
+                cands.append((tried[name]["ms_per_step"], t))
+            comm.set_timeout(120.0)
             sums = [v["checksum"] for v in tried.values() if "checksum" in v]
             ref_sum = sorted(sums)[len(sums) // 2] if sums else 0.0
             good = [(ms, t) for ms, t in cands if abs(tried[api.TRANSPORT_NAMES[t]]["checksum"] - ref_sum) <= 1e-12 * abs(ref_sum)]
-            assert good, f"no transport produced a consistent field: {tried}"
-            best = min(good)[1]
-            comm.set_transport(best)
-            transport_report = {"selected": api.TRANSPORT_NAMES[best], "tuned": tried}
+            transport_report = {"tuned": tried}
+            if good:
+                best = min(good)[1]
+                comm.set_transport(best)
+                transport_report["selected"] = api.TRANSPORT_NAMES[best]
+            else:
+                # no library transport works on this node: the torch.distributed driver over the same kernels (RCCL all-to-all)
+                transport_report["selected"] = "none: falling back to the torch.distributed driver"
+                native_failed = True
         else:
             transport_report = {"selected": api.TRANSPORT_NAMES.get(comm.transport, str(comm.transport))}
-        solver.reset()
-        prof_ctx = solver.ctx
-    elif slab:
-        from marlin_amd.slab import SlabCahnHilliard
+        if not native_failed:
+            solver.reset()
+            prof_ctx = solver.ctx
+        else:
+            torch.cuda.synchronize()
+            solver.ctx.close()
+            comm.close()
+            comm = None
+    if slab and (args.driver == "python" or native_failed):
+        from marlin_amd.slab import SlabCahnHilliard, SlabExchange
         nsub = args.nsub or 2
         if args.compute_stream == "high":
             torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
-        solver = SlabCahnHilliard(3, shape, L, p, world, rank, nsub=nsub, carry=carry)
+        # the data path uses RCCL; when the control group is gloo (native driver tried first) a second, RCCL group carries it
+        data_group = None
+        if dist.get_backend() != args.backend and args.backend == "nccl":
+            data_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", dev))
+        solver = SlabCahnHilliard(3, shape, L, p, world, rank, nsub=nsub, carry=carry,
+                                  exchange_factory=(lambda sc, rc: SlabExchange(sc, rc, group=data_group)) if data_group is not None else None)
         step = solver.substep
 
         def steps(count):   # `count` substeps per solver call: the z passes between two substeps are one kernel
@@ -354,8 +395,8 @@ def main():
 
         solver.set_initial(lambda count, offset: splitmix64_uniform(count, offset=offset))
         prof_ctx = solver.ctx
-        transport_report = {"selected": f"torch.distributed {args.backend} all_to_all_single"}
-    else:
+        transport_report = dict(transport_report or {}, selected=f"torch.distributed {args.backend} all_to_all_single")
+    if not slab:
         nsub = 0
         ctx = api.Context(3, shape, L)
         if args.exp:
@@ -463,7 +504,7 @@ def main():
     cs = host_sum(float((cur * cur).sum(dtype=torch.float64).item()))
 
     variants = {}
-    if not args.no_variants and slab and args.driver == "native":
+    if not args.no_variants and slab and comm is not None:
         # (a) the spectral carry-over variant of the same job; (b) the rank-local kernels alone (exchanges switched off: the
         # fields are meaningless afterwards, so this comes last)
         k = min(args.steps, 40)
@@ -519,7 +560,7 @@ def main():
                                 "variants.local_kernels_only has the rank-local cost")
         decomposition = "none"
         if slab:
-            how = "library-owned exchange (mrl_comm)" if args.driver == "native" else f"torch.distributed {args.backend}"
+            how = "library-owned exchange (mrl_comm)" if comm is not None else f"torch.distributed {args.backend}"
             decomposition = f"slab x{world}, {how}, {nsub} kz sub-block(s) in flight"
         out = {
             "metric": "grid-point-updates/sec, 3-D Cahn-Hilliard semi-implicit spectral substep (AB2, fp64)",
@@ -539,7 +580,7 @@ def main():
                             f"f=0.1c^2(c-1)^2, M=0.2, kappa=-0.001, sub_dt=1e-3",
                 "grid": shape,
                 "decomposition": decomposition,
-                "driver": (args.driver if slab else "serial"),
+                "driver": (("native" if comm is not None else "python") if slab else "serial"),
                 "spectral_carry_over": carry,
                 "substeps_per_library_call": per_call,
                 "ms_per_step_with_one_call_per_substep": single_ms,

@@ -117,6 +117,10 @@ int mrl_comm_transport(const mrl_comm *comm);
 /* collective; contexts attached to the communicator rebuild their exchange buffers on the next call */
 int mrl_comm_set_transport(mrl_comm *comm, int32_t transport);
 int mrl_comm_set_timeout(mrl_comm *comm, double seconds); /* bound of every host barrier and device-side wait (default 60 s) */
+/* after MRL_ERR_COMM from a device-side wait (a peer's data never arrived) every later wait returns at once; once the caller has
+ * destroyed the contexts whose exchanges were in flight (all ranks), this clears the condition so that the communicator can be
+ * used again, e.g. with another transport */
+int mrl_comm_reset_error(mrl_comm *comm);
 int mrl_comm_barrier(mrl_comm *comm);                     /* host barrier over the ranks */
 /* in-place all-reduce of n <= 16 host values: op 0 sum (rank order: identical bits on every rank), 1 min, 2 max */
 int mrl_comm_allreduce(mrl_comm *comm, double *h_values, int32_t n, int32_t op);

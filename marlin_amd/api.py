@@ -101,6 +101,12 @@ class Comm:
     def set_transport(self, transport: int):
         self._check(self.lib.mrl_comm_set_transport(self.h, transport))
 
+    def set_timeout(self, seconds: float):
+        self._check(self.lib.mrl_comm_set_timeout(self.h, float(seconds)))
+
+    def reset_error(self):
+        self._check(self.lib.mrl_comm_reset_error(self.h))
+
     def barrier(self):
         self._check(self.lib.mrl_comm_barrier(self.h))
 

@@ -213,6 +213,8 @@ __global__ void k_comm_signal(unsigned long long *const *tab, int nranks, int me
 __global__ void k_comm_wait(const unsigned long long *row, int nranks, unsigned long long epoch, int *status, long long max_ticks) {
   const int p = threadIdx.x;
   if (p >= nranks) return;
+  // after one timeout the job is lost anyway: every later wait returns at once instead of costing another full timeout
+  if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
   const long long t0 = wall_clock64();
   while (__hip_atomic_load(row + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
     if (wall_clock64() - t0 > max_ticks) {
@@ -261,8 +263,8 @@ static long long max_ticks(const mrl_comm *c) { return (long long)(c->timeout_s 
 int comm_check(mrl_comm *c) {
   if (c->h_status && *c->h_status != 0) {
     const int who = *c->h_status - 1;
-    *c->h_status = 0;
-    if (c->shm) c->shm->abort_flag.store(1);
+    // (the status word stays set: later device-side waits return at once; mrl_comm_reset_error clears it once the caller has
+    // torn down whatever was in flight)
     return comm_error(c, MRL_ERR_COMM, "rank %d: the data of rank %d did not arrive within %.0f s (device-side wait timed out)", c->rank,
                       who, c->timeout_s);
   }
@@ -699,6 +701,14 @@ int mrl_comm_set_transport(mrl_comm *c, int32_t transport) {
   COMM_TRY(comm_barrier(c));
   if (transport == MRL_TRANSPORT_RCCL) COMM_TRY(rccl_init(c));
   c->transport = transport;
+  return MRL_OK;
+}
+
+int mrl_comm_reset_error(mrl_comm *c) {
+  if (!c) return MRL_ERR_INVALID;
+  (void)hipDeviceSynchronize();
+  if (c->h_status) *c->h_status = 0;
+  c->err.clear();
   return MRL_OK;
 }
 

@@ -263,6 +263,7 @@ __global__ void k_ack_signal(unsigned long long *const *tab, int nranks, int me,
 __global__ void k_ack_wait(const unsigned long long *row, int nranks, unsigned long long epoch, int *status, long long max_ticks) {
   const int p = threadIdx.x;
   if (p >= nranks) return;
+  if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;  // (an earlier wait already timed out)
   const long long t0 = wall_clock64();
   while (__hip_atomic_load(row + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
     if (wall_clock64() - t0 > max_ticks) {

@@ -271,6 +271,35 @@ def test_rotating_grain_secant_with_predictor(scale, tmp_path):
     assert plain <= 1e-7      # the predictor only moves the starting guess: the converged fields agree with the plain run's
 
 
+def test_rotating_grain_secant_failed_solve_restores_old_solution(tmp_path):
+    """SecantSolver.C:152-159,175-184: a solve that runs out of iterations (max_iterations = 2 here) is declared not converged and
+    the old solution is restored (`_buffer = ifft(u_old)`); the next substep starts from it.  Host mirror against the oracle's
+    restatement of the same control flow (the reference's gold run never rejects a solve)"""
+    import math
+
+    import torch
+
+    from oracle import marlin_oracle as mo
+    from tests.test_oracle_golden import rotating_grain_problem
+    g = load_golden("rotating_grain_secant_gold.npz")
+    ic = tmp_path / "psi0.bin"
+    g["psi.0"].astype("<f8").tofile(ic)
+    ymax = 6 * math.pi * 2 / math.sin(math.pi / 3)
+    log = _run(["problem=rotating_grain_secant", "dim=2", "nx=40", "ny=40", "xmax=12pi", f"ymax={ymax!r}", f"ic={ic}",
+                "substeps=3", "num_steps=3", "dt=1", "max_iterations=2"], tmp_path)
+    assert log.count("converged=0") == 3 and "Solve not converged." in log
+    dom, state, compute, variables = rotating_grain_problem(torch.from_numpy(g["psi.0"]))
+    solver = mo.SecantSolver(dom, state, compute, variables, substeps=3, max_iterations=2)
+    ts = mo.IterationAdaptiveDT(1.0, min_iterations=100, max_iterations=400, growth_factor=1.4, cutback_factor=0.9, dtmax=500.0)
+    for step in range(1, 4):
+        solver.step(ts.next_dt(step, solver.iterations))
+        assert not solver.converged
+        psi = np.fromfile(tmp_path / f"psi.{step}.bin", dtype="<f8").reshape(40, 40)
+        assert np.abs(state["psi"].numpy() - psi).max() <= 1e-12
+        # restored: the field is the initial condition up to one fft / ifft round trip per substep
+        assert np.abs(g["psi.0"] - psi).max() <= 1e-13
+
+
 def test_etdrk4_case(tmp_path):
     """test/tests/solvers/tests (etdrk4_diffusion.i): ETDRK4Solver built from fused parsed kernels vs gold mse / rmse"""
     g = load_golden("solvers_gold.npz")["etdrk4_diffusion_rmse"]
