@@ -299,6 +299,9 @@ int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c
 // fast fused path (ch_fused.hip); returns MRL_ERR_UNSUPPORTED when the shape has no fast kernels
 int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new,
                      const double *const *Nhat_old, int order, double sub_dt, double *cbar, double *mu, int carry);
+// extents with plans for the plain transforms only (ch_planned.hip)
+int ch_substep_planned(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new, const double *const *Nhat_old,
+                       int order, double sub_dt, double *cbar, double *mu, int carry);
 // slab contexts with a communicator (slab_driver.hip)
 int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, double *c_out, double *const *ring, int ring_size,
                      int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu, bool dt_changed);
@@ -349,6 +352,8 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
     return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substep: the carry-over needs the d_cbar array");
 
   int rc = ch_substep_fused(ctx, cp, d_c_in, d_c_out, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, d_mu, carry);
+  if (rc != MRL_ERR_UNSUPPORTED) return rc;
+  rc = ch_substep_planned(ctx, cp, d_c_in, d_c_out, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, d_mu, carry);
   if (rc != MRL_ERR_UNSUPPORTED) return rc;
 
   // generic sequence: separate pointwise kernels around the generic transforms

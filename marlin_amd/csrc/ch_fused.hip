@@ -158,6 +158,39 @@ static int pass_axis(mrl_ctx *ctx, int axis, bool inv, int nf, const cplx *in0, 
   return MRL_OK;
 }
 
+// launchers by run-time length for the planned-unfused path (ch_planned.hip), which mixes these lengths with the radix-30 ones
+int pass_launch_std(mrl_ctx *ctx, long long n, bool inv, int nf, const p2::PassArgs &a, const cplx *tw) {
+  if (nf == 2) {
+    if (inv) {
+      MRL_SWITCH_N(n, MRL_TRY((p2::launch_pass_t<NN, true, 2>(ctx, a, tw))));
+    } else {
+      MRL_SWITCH_N(n, MRL_TRY((p2::launch_pass_t<NN, false, 2>(ctx, a, tw))));
+    }
+  } else {
+    if (inv) {
+      MRL_SWITCH_N(n, MRL_TRY((p2::launch_pass_t<NN, true, 1>(ctx, a, tw))));
+    } else {
+      MRL_SWITCH_N(n, MRL_TRY((p2::launch_pass_t<NN, false, 1>(ctx, a, tw))));
+    }
+  }
+  return MRL_OK;
+}
+int z_fwd_launch_std(mrl_ctx *ctx, long long n, int mode, int fam, const double *in, cplx *o0, cplx *o1, double *mu, const p2::ChDev &chp,
+                     long long nlines) {
+  if (mode == 0) {
+    MRL_SWITCH_N(n, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, in, o0, o1, mu, chp, nlines))));
+  } else if (fam == MRL_FE_DOUBLE_WELL) {
+    MRL_SWITCH_N(n, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, in, o0, o1, mu, chp, nlines))));
+  } else {
+    MRL_SWITCH_N(n, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, in, o0, o1, mu, chp, nlines))));
+  }
+  return MRL_OK;
+}
+int z_inv_launch_std(mrl_ctx *ctx, long long n, const cplx *in, double *out, double scale, long long nlines) {
+  MRL_SWITCH_N(n, MRL_TRY((p2::launch_z_inv<NN>(ctx, in, out, scale, nlines))));
+  return MRL_OK;
+}
+
 // plain transforms (field-major batch), used by mrl_fft_r2c / mrl_fft_c2r on fast-path shapes
 int fft_forward_fast(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch) {
   const Geo g = geo_of(ctx);

@@ -1,0 +1,412 @@
+// Planned but UNFUSED path for grids whose extents have register-radix plans for the plain transforms but not for the fused
+// Cahn-Hilliard kernels: every axis length in {60, 90, 120, 150, 180, 240, 270, 300, 360, 450, 600} (radix 30 first, 30 points
+// per thread: fft_pow2.h) mixed freely with the lengths of the fused path.  The reference's own solver tests run 150^2
+// (test/tests/solvers/diagonal.i:5-95); such sizes used to take the any-length path (fft_generic.hip), 3x slower per point.
+//   plain transforms        z pass (two real lines per complex transform) -> y pass -> x pass, each reading and writing its array once
+//   Cahn-Hilliard substep   k_z_fwd<CH> (mu = f'(c) in the loader, c and mu in one complex transform) -> y and x passes on both
+//                           fields -> k_ch_kspace (Nhat = Mbar mu-hat, ABM predictor, 1/(1 - dt Lbar); AdamsBashforthMoulton.C:94-99)
+//                           -> inverse x, y passes -> k_z_inv.  7 launches, 20 h of traffic against the fused path's 14 h (h = one
+//                           half-spectrum array), same operations in the same order on the pointwise side: results equal the fused
+//                           and the generic path to rounding of the transforms.
+#include "fft_pow2_launch.h"
+
+namespace mrl {
+
+// the same launchers for the lengths of the fused path (ch_fused.hip)
+int pass_launch_std(mrl_ctx *ctx, long long n, bool inv, int nf, const p2::PassArgs &a, const cplx *tw);
+int z_fwd_launch_std(mrl_ctx *ctx, long long n, int mode, int fam, const double *in, cplx *o0, cplx *o1, double *mu, const p2::ChDev &chp,
+                     long long nlines);
+int z_inv_launch_std(mrl_ctx *ctx, long long n, const cplx *in, double *out, double scale, long long nlines);
+int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const double *mubar, double *Nhat, double *ubar,
+                     const double *const *Nold, int order, double sub_dt);
+
+#define MRL_SWITCH_N30(n, CALL)                          \
+  switch (n) {                                           \
+    case 60: { constexpr int NN = 60; CALL; } break;     \
+    case 90: { constexpr int NN = 90; CALL; } break;     \
+    case 120: { constexpr int NN = 120; CALL; } break;   \
+    case 150: { constexpr int NN = 150; CALL; } break;   \
+    case 180: { constexpr int NN = 180; CALL; } break;   \
+    case 240: { constexpr int NN = 240; CALL; } break;   \
+    case 270: { constexpr int NN = 270; CALL; } break;   \
+    case 300: { constexpr int NN = 300; CALL; } break;   \
+    case 360: { constexpr int NN = 360; CALL; } break;   \
+    case 450: { constexpr int NN = 450; CALL; } break;   \
+    case 600: { constexpr int NN = 600; CALL; } break;   \
+    default: return MRL_ERR_UNSUPPORTED;                 \
+  }
+
+static int pass_launch(mrl_ctx *ctx, long long n, bool inv, int nf, const p2::PassArgs &a, const cplx *tw) {
+  if (!plain30_ok(n)) return pass_launch_std(ctx, n, inv, nf, a, tw);
+  // 30 points per thread: one field per launch (two fields would need 240 of the 256 vector registers for the data alone)
+  for (int f = 0; f < nf; ++f) {
+    p2::PassArgs b = a;
+    b.in[0] = a.in[f];
+    b.out[0] = a.out[f];
+    if (inv) {
+      MRL_SWITCH_N30(n, MRL_TRY((p2::launch_pass_t<NN, true, 1>(ctx, b, tw))));
+    } else {
+      MRL_SWITCH_N30(n, MRL_TRY((p2::launch_pass_t<NN, false, 1>(ctx, b, tw))));
+    }
+  }
+  return MRL_OK;
+}
+
+static int z_fwd_launch(mrl_ctx *ctx, long long n, int mode, int fam, const double *in, cplx *o0, cplx *o1, double *mu, const p2::ChDev &chp,
+                        long long nlines) {
+  if (!plain30_ok(n)) return z_fwd_launch_std(ctx, n, mode, fam, in, o0, o1, mu, chp, nlines);
+  if (mode == 0) {
+    MRL_SWITCH_N30(n, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, in, o0, o1, mu, chp, nlines))));
+  } else if (fam == MRL_FE_DOUBLE_WELL) {
+    MRL_SWITCH_N30(n, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, in, o0, o1, mu, chp, nlines))));
+  } else {
+    MRL_SWITCH_N30(n, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, in, o0, o1, mu, chp, nlines))));
+  }
+  return MRL_OK;
+}
+
+static int z_inv_launch(mrl_ctx *ctx, long long n, const cplx *in, double *out, double scale, long long nlines) {
+  if (!plain30_ok(n)) return z_inv_launch_std(ctx, n, in, out, scale, nlines);
+  MRL_SWITCH_N30(n, MRL_TRY((p2::launch_z_inv<NN>(ctx, in, out, scale, nlines))));
+  return MRL_OK;
+}
+
+
+namespace p2 {
+
+// ---- the k-space update folded into the x passes (what k_ch_xfused does in one kernel on the fused path, here in two so that one
+//      30-point array per thread suffices) -------------------------------------------------------------------------------------
+struct XKArgs {
+  const cplx *in;      // [nx][inner] work array, line along x (stride inner)
+  cplx *out;           // k_x_mbar: Nhat_new (dense, same layout) ; k_x_update: ubar, x-inverted (may alias in)
+  const cplx *Nnew;    // k_x_update
+  const cplx *Nold[4];
+  cplx *cbar;          // k_x_update: optional c-hat output
+  double coef[5];      // sub_dt * beta[order][i]
+  double M, kappa, dt;
+  long long inner;
+  int nzc;
+  const double *kx, *ky, *kz;
+};
+
+// Nhat = Mbar * fft_x(mu-hat), Mbar = -k^2 M  (ReciprocalLaplacianFactor.C:28-31; k^2 = (kx^2 + ky^2) + kz^2 as DomainAction.C:1503-1509)
+template <int N>
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_x_mbar(XKArgs a, const cplx *__restrict__ tw) {
+#pragma clang fp contract(off)
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T, NT = Plan<N>::NT, CNT = (N + NT - 1) / NT;
+  using Map = MapStrided<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  double *KX = reinterpret_cast<double *>(X + Map::size);
+  const int l = threadIdx.x % T, q = threadIdx.x / T;
+  const long long i = (long long)xcd_remap(blockIdx.x, gridDim.x) * T + l;
+  const bool valid = i < a.inner;
+  const long long ic = valid ? i : 0;
+  cplx twv[CNT];
+  double kxv[CNT];
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const int idx = threadIdx.x + j * NT;
+    twv[j] = idx < N ? tw[idx] : make_double2(0.0, 0.0);
+    kxv[j] = idx < N ? a.kx[idx] : 0.0;
+  }
+  const double ky = a.ky[ic / a.nzc], kz = a.kz[ic % a.nzc];
+  cplx v[P];
+  const cplx *src = a.in + ic + (long long)q * a.inner;
+#pragma unroll
+  for (int m = 0; m < P; ++m) v[m] = src[(long long)m * TPL * a.inner];
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const int idx = threadIdx.x + j * NT;
+    if (idx < N) {
+      W[idx] = twv[j];
+      KX[idx] = kxv[j];
+    }
+  }
+  fft_line<N, Map>(v, q, l, X, W);
+  if (!valid) return;
+  const double ky2 = ky * ky, kz2 = kz * kz;
+  cplx *dst = a.out + i + (long long)q * a.inner;
+#pragma unroll
+  for (int m = 0; m < P; ++m) {
+    const double kl = KX[q + m * TPL];
+    const double Mbar = -((kl * kl + ky2) + kz2) * a.M;
+    dst[(long long)m * TPL * a.inner] = make_double2(Mbar * v[m].x, Mbar * v[m].y);
+  }
+}
+
+// c-hat = fft_x(.) ; ubar = (c-hat + (dt b0) Nhat + sum (dt b_i) Nhat_old_i) / (1 - dt Lbar) ; inverse x transform
+// (AdamsBashforthMoulton.C:94-101; Lbar = k^2 k^2 kappa, ReciprocalLaplacianSquareFactor.C:28-32; the divide as libTorch evaluates it)
+template <int N, int ORDER>
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_x_update(XKArgs a, const cplx *__restrict__ tw) {
+#pragma clang fp contract(off)
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T, NT = Plan<N>::NT, CNT = (N + NT - 1) / NT;
+  using Map = MapStrided<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  double *KX = reinterpret_cast<double *>(X + Map::size);
+  const int l = threadIdx.x % T, q = threadIdx.x / T;
+  const long long i = (long long)xcd_remap(blockIdx.x, gridDim.x) * T + l;
+  const bool valid = i < a.inner;
+  const long long ic = valid ? i : 0;
+  cplx twv[CNT];
+  double kxv[CNT];
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const int idx = threadIdx.x + j * NT;
+    twv[j] = idx < N ? tw[idx] : make_double2(0.0, 0.0);
+    kxv[j] = idx < N ? a.kx[idx] : 0.0;
+  }
+  const double ky = a.ky[ic / a.nzc], kz = a.kz[ic % a.nzc];
+  cplx v[P];
+  const long long e0 = ic + (long long)q * a.inner, step = (long long)TPL * a.inner;
+#pragma unroll
+  for (int m = 0; m < P; ++m) v[m] = a.in[e0 + m * step];
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const int idx = threadIdx.x + j * NT;
+    if (idx < N) {
+      W[idx] = twv[j];
+      KX[idx] = kxv[j];
+    }
+  }
+  fft_line<N, Map>(v, q, l, X, W);
+  if (a.cbar && valid) {
+#pragma unroll
+    for (int m = 0; m < P; ++m) a.cbar[e0 + m * step] = v[m];
+  }
+  const double ky2 = ky * ky, kz2 = kz * kz;
+  // the history streams through in thirds of the line: 10 x (1 + ORDER) values in flight instead of 30 x (1 + ORDER)
+  constexpr int H = P / 3;
+#pragma unroll
+  for (int part = 0; part < 3; ++part) {
+    cplx nn[H], no[ORDER > 0 ? ORDER : 1][H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) nn[j] = a.Nnew[e0 + (part * H + j) * step];
+#pragma unroll
+    for (int hh = 0; hh < ORDER; ++hh) {
+#pragma unroll
+      for (int j = 0; j < H; ++j) no[hh][j] = a.Nold[hh][e0 + (part * H + j) * step];
+    }
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const int m = part * H + j;
+      cplx u = v[m];
+      u.x = u.x + a.coef[0] * nn[j].x;
+      u.y = u.y + a.coef[0] * nn[j].y;
+#pragma unroll
+      for (int hh = 0; hh < ORDER; ++hh) {
+        u.x += a.coef[hh + 1] * no[hh][j].x;
+        u.y += a.coef[hh + 1] * no[hh][j].y;
+      }
+      const double kl = KX[q + m * TPL];
+      const double k2 = (kl * kl + ky2) + kz2;
+      const double scl = 1.0 / (1.0 - a.dt * (k2 * k2 * a.kappa));
+      v[m] = make_double2(u.y * scl, u.x * scl);  // swapped for the inverse transform
+    }
+  }
+  fft_line<N, Map>(v, q, l, X, W);
+  if (!valid) return;
+#pragma unroll
+  for (int m = 0; m < P; ++m) a.out[e0 + m * step] = cswap(v[m]);
+}
+
+template <int N>
+static int launch_x_mbar(mrl_ctx *ctx, const XKArgs &a, const cplx *tw) {
+  static bool attr = false;
+  constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
+  if (!attr) {
+    MRL_TRY(set_lds_attr(ctx, k_x_mbar<N>, lds));
+    attr = true;
+  }
+  const long long nb = (a.inner + Plan<N>::T - 1) / Plan<N>::T;
+  hipLaunchKernelGGL((k_x_mbar<N>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+template <int N, int ORDER>
+static int launch_x_update(mrl_ctx *ctx, const XKArgs &a, const cplx *tw) {
+  static bool attr = false;
+  constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
+  if (!attr) {
+    MRL_TRY((set_lds_attr(ctx, k_x_update<N, ORDER>, lds)));
+    attr = true;
+  }
+  const long long nb = (a.inner + Plan<N>::T - 1) / Plan<N>::T;
+  hipLaunchKernelGGL((k_x_update<N, ORDER>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+}  // namespace p2
+
+struct PGeo {
+  long long nx, ny, nz, nzc;
+  const cplx *tw_x, *tw_y;
+};
+static PGeo pgeo(const mrl_ctx *ctx) {
+  PGeo g;
+  const int ax = ctx->dim == 3 ? 0 : 1;  // 2-D grids run as [nx][1][ny'] (serial contexts right-align the user axes)
+  g.nx = ctx->n[ax];
+  g.ny = ctx->dim == 3 ? ctx->n[1] : 1;
+  g.nz = ctx->n[2];
+  g.nzc = ctx->nrec[2];
+  g.tw_x = ctx->ax[ax].d_tw;
+  g.tw_y = ctx->ax[1].d_tw;
+  return g;
+}
+
+// serial half-spectrum contexts whose extents all have plans for the plain transforms and at least one of which needs this path
+bool planned_unfused_ok(const mrl_ctx *ctx) {
+  if (ctx->slab || ctx->spectrum != MRL_SPECTRUM_HALF || (ctx->dim != 2 && ctx->dim != 3)) return false;
+  const PGeo g = pgeo(ctx);
+  if ((g.nx * g.ny) % 2) return false;  // the z passes carry two lines per complex transform
+  const bool all = plain_ok(g.nx) && (g.ny == 1 || plain_ok(g.ny)) && plain_ok(g.nz);
+  const bool any30 = plain30_ok(g.nx) || plain30_ok(g.ny) || plain30_ok(g.nz);
+  return all && any30;
+}
+
+static int pass_axis(mrl_ctx *ctx, const PGeo &g, int axis, bool inv, int nf, cplx *a0, cplx *a1) {
+  if (axis == 1 && g.ny == 1) return MRL_OK;
+  p2::PassArgs a{};
+  a.in[0] = a0;
+  a.in[1] = a1;
+  a.out[0] = a0;
+  a.out[1] = a1;
+  a.scale = 1.0;
+  if (axis == 1) {
+    a.inner = g.nzc;
+    a.outer = g.nx;
+    a.so_in = a.so_out = g.ny * g.nzc;
+    a.sn_in = a.sn_out = g.nzc;
+  } else {
+    a.inner = g.ny * g.nzc;
+    a.outer = 1;
+    a.sn_in = a.sn_out = g.ny * g.nzc;
+  }
+  return pass_launch(ctx, axis == 1 ? g.ny : g.nx, inv, nf, a, axis == 1 ? g.tw_y : g.tw_x);
+}
+
+int fft_forward_planned(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch) {
+  const PGeo g = pgeo(ctx);
+  const long long nreal = g.nx * g.ny * g.nz, nspec = g.nx * g.ny * g.nzc;
+  p2::ChDev none{};
+  for (long long b = 0; b < batch; ++b) {
+    cplx *out = reinterpret_cast<cplx *>(d_out) + b * nspec;
+    {
+      ProfScope ps(ctx, "z_fwd_pair", 8.0 * nreal + 16.0 * nspec);
+      MRL_TRY(z_fwd_launch(ctx, g.nz, 0, 0, d_in + b * nreal, out, nullptr, nullptr, none, g.nx * g.ny / 2));
+    }
+    {
+      ProfScope ps(ctx, "pass_y", 32.0 * nspec);
+      MRL_TRY(pass_axis(ctx, g, 1, false, 1, out, nullptr));
+    }
+    ProfScope ps(ctx, "pass_x", 32.0 * nspec);
+    MRL_TRY(pass_axis(ctx, g, 0, false, 1, out, nullptr));
+  }
+  return MRL_OK;
+}
+
+int fft_inverse_planned(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch) {
+  const PGeo g = pgeo(ctx);
+  const long long nreal = g.nx * g.ny * g.nz, nspec = g.nx * g.ny * g.nzc;
+  const double scale = 1.0 / ((double)g.nx * (double)g.ny * (double)g.nz);
+  MRL_TRY(ensure_work(ctx, 0, sizeof(cplx) * nspec));
+  cplx *w = reinterpret_cast<cplx *>(ctx->d_work[0]);
+  for (long long b = 0; b < batch; ++b) {
+    MRL_HIP(ctx, hipMemcpyAsync(w, reinterpret_cast<const cplx *>(d_in) + b * nspec, sizeof(cplx) * nspec, hipMemcpyDeviceToDevice, ctx->stream));
+    {
+      ProfScope ps(ctx, "pass_x", 32.0 * nspec);
+      MRL_TRY(pass_axis(ctx, g, 0, true, 1, w, nullptr));
+    }
+    {
+      ProfScope ps(ctx, "pass_y", 32.0 * nspec);
+      MRL_TRY(pass_axis(ctx, g, 1, true, 1, w, nullptr));
+    }
+    ProfScope ps(ctx, "z_inv_pair", 8.0 * nreal + 16.0 * nspec);
+    MRL_TRY(z_inv_launch(ctx, g.nz, w, d_out + b * nreal, scale, g.nx * g.ny / 2));
+  }
+  return MRL_OK;
+}
+
+// one AdamsBashforthMoulton::substep with its compute group (AdamsBashforthMoulton.C:60-101); built-in free-energy families only
+// (a parsed free energy takes the any-length path), no spectral carry-over
+int ch_substep_planned(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new, const double *const *Nhat_old,
+                       int order, double sub_dt, double *cbar, double *mu, int carry) {
+  if (!planned_unfused_ok(ctx) || carry != MRL_CARRY_NONE || cp.family == MRL_FE_PARSED) return MRL_ERR_UNSUPPORTED;
+  const PGeo g = pgeo(ctx);
+  const long long nreal = g.nx * g.ny * g.nz, nspec = g.nx * g.ny * g.nzc;
+  MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nspec));
+  MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nspec));
+  cplx *w_c = reinterpret_cast<cplx *>(ctx->d_work[1]);
+  cplx *w_mu = reinterpret_cast<cplx *>(ctx->d_work[2]);
+  p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
+  const double h = 16.0 * nspec;
+  {
+    ProfScope ps(ctx, "chp_A_z_fwd", 8.0 * nreal + 2.0 * h + (mu ? 8.0 * nreal : 0.0));
+    MRL_TRY(z_fwd_launch(ctx, g.nz, 1, cp.family, c_in, w_c, w_mu, mu, chp, g.nx * g.ny));
+  }
+  {
+    ProfScope ps(ctx, "chp_B_y_fwd", 4.0 * h);
+    MRL_TRY(pass_axis(ctx, g, 1, false, 2, w_c, w_mu));
+  }
+  if (plain30_ok(g.nx)) {
+    // the k-space update rides on the x passes: mu-hat -> Nhat in one pass, c-hat -> ubar -> inverse x in a second one (6 h
+    // instead of 11 h for the three x passes + the k-space kernel)
+    const int ax = ctx->dim == 3 ? 0 : 1;
+    p2::XKArgs a{};
+    a.inner = g.ny * g.nzc;
+    a.nzc = (int)g.nzc;
+    a.kx = ctx->d_k[ax];
+    a.ky = ctx->dim == 3 ? ctx->d_k[1] : ctx->d_k[0];  // 2-D: the unused axis {0}
+    a.kz = ctx->d_k[2];
+    a.M = cp.M;
+    a.kappa = cp.kappa;
+    a.dt = sub_dt;
+    for (int i = 0; i <= order; ++i) a.coef[i] = sub_dt * kBetaAB[order][i];
+    {
+      ProfScope ps(ctx, "chp_C_x_mbar", 2.0 * h);
+      a.in = w_mu;
+      a.out = reinterpret_cast<cplx *>(Nhat_new);
+      MRL_SWITCH_N30(g.nx, MRL_TRY((p2::launch_x_mbar<NN>(ctx, a, g.tw_x))));
+    }
+    ProfScope ps(ctx, "chp_D_x_update", (3.0 + order + (cbar ? 1.0 : 0.0)) * h);
+    a.in = w_c;
+    a.out = w_c;
+    a.Nnew = reinterpret_cast<const cplx *>(Nhat_new);
+    for (int i = 0; i < order; ++i) a.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
+    a.cbar = reinterpret_cast<cplx *>(cbar);
+    switch (order) {
+      case 0: MRL_SWITCH_N30(g.nx, MRL_TRY((p2::launch_x_update<NN, 0>(ctx, a, g.tw_x)))); break;
+      case 1: MRL_SWITCH_N30(g.nx, MRL_TRY((p2::launch_x_update<NN, 1>(ctx, a, g.tw_x)))); break;
+      case 2: MRL_SWITCH_N30(g.nx, MRL_TRY((p2::launch_x_update<NN, 2>(ctx, a, g.tw_x)))); break;
+      case 3: MRL_SWITCH_N30(g.nx, MRL_TRY((p2::launch_x_update<NN, 3>(ctx, a, g.tw_x)))); break;
+      default: MRL_SWITCH_N30(g.nx, MRL_TRY((p2::launch_x_update<NN, 4>(ctx, a, g.tw_x)))); break;
+    }
+  } else {
+    {
+      ProfScope ps(ctx, "chp_C_x_fwd", 4.0 * h);
+      MRL_TRY(pass_axis(ctx, g, 0, false, 2, w_c, w_mu));
+    }
+    if (cbar) MRL_HIP(ctx, hipMemcpyAsync(cbar, w_c, sizeof(cplx) * nspec, hipMemcpyDeviceToDevice, ctx->stream));
+    {
+      ProfScope ps(ctx, "chp_K_kspace", (4.0 + order) * h);
+      MRL_TRY(ch_kspace_launch(ctx, cp, reinterpret_cast<const double *>(w_c), reinterpret_cast<const double *>(w_mu), Nhat_new,
+                               reinterpret_cast<double *>(w_c), Nhat_old, order, sub_dt));  // elementwise: ubar overwrites c-hat
+    }
+    ProfScope ps(ctx, "chp_D_x_inv", 2.0 * h);
+    MRL_TRY(pass_axis(ctx, g, 0, true, 1, w_c, nullptr));
+  }
+  {
+    ProfScope ps(ctx, "chp_E_y_inv", 2.0 * h);
+    MRL_TRY(pass_axis(ctx, g, 1, true, 1, w_c, nullptr));
+  }
+  ProfScope ps(ctx, "chp_F_z_inv", h + 8.0 * nreal);
+  const double scale = 1.0 / ((double)g.nx * (double)g.ny * (double)g.nz);
+  return z_inv_launch(ctx, g.nz, w_c, c_out, scale, g.nx * g.ny / 2);
+}
+
+}  // namespace mrl

@@ -165,6 +165,9 @@ int fft_inverse_serial(mrl_ctx *ctx, const double *d_in, double *d_out, long lon
   return pass_z_inverse(ctx, cur, d_out, A0, A1, batch, layout, scale);
 }
 
+bool planned_unfused_ok(const mrl_ctx *ctx);                                               // ch_planned.hip
+int fft_forward_planned(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
+int fft_inverse_planned(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
 int slab_fft_forward(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);   // slab_driver.hip
 int slab_fft_inverse(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
 
@@ -183,6 +186,7 @@ int mrl_fft_r2c(mrl_ctx *ctx, const double *d_in, double *d_out, int64_t batch, 
     return slab_fft_forward(ctx, d_in, d_out, batch);
   }
   if (fast_path_ok(ctx) && (layout == 0 || batch == 1)) return fft_forward_fast(ctx, d_in, d_out, batch);
+  if (planned_unfused_ok(ctx) && (layout == 0 || batch == 1)) return fft_forward_planned(ctx, d_in, d_out, batch);
   return fft_forward_serial(ctx, d_in, d_out, batch, layout);
 }
 
@@ -195,6 +199,7 @@ int mrl_fft_c2r(mrl_ctx *ctx, const double *d_in, double *d_out, int64_t batch, 
     return slab_fft_inverse(ctx, d_in, d_out, batch);
   }
   if (fast_path_ok(ctx) && (layout == 0 || batch == 1)) return fft_inverse_fast(ctx, d_in, d_out, batch);
+  if (planned_unfused_ok(ctx) && (layout == 0 || batch == 1)) return fft_inverse_planned(ctx, d_in, d_out, batch);
   return fft_inverse_serial(ctx, d_in, d_out, batch, layout);
 }
 

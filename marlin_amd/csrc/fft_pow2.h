@@ -61,6 +61,20 @@ MRL_PLAN(144, 12, 12, 12, 1, 1, 21)
 MRL_PLAN(192, 12, 12, 4, 4, 1, 16)
 MRL_PLAN(384, 12, 12, 4, 4, 2, 8)
 MRL_PLAN(768, 12, 12, 4, 4, 4, 4)
+// sizes 2^a 3^b 5^c with all three primes (120, 150, 240, 270 ... of the reference's own inputs, test/tests/solvers/diagonal.i): radix
+// 30 first, then 2 / 3 / 5 / 10; 30 points per thread.  120 complex registers per array: plain transforms only (z passes, strided
+// passes); the fused Cahn-Hilliard kernels, which hold three to four arrays, are not instantiated for them (ch_planned.hip)
+MRL_PLAN(60, 30, 30, 2, 1, 1, 64)
+MRL_PLAN(90, 30, 30, 3, 1, 1, 42)
+MRL_PLAN(120, 30, 30, 2, 2, 1, 32)
+MRL_PLAN(150, 30, 30, 5, 1, 1, 25)
+MRL_PLAN(180, 30, 30, 3, 2, 1, 21)
+MRL_PLAN(240, 30, 30, 2, 2, 2, 16)
+MRL_PLAN(270, 30, 30, 3, 3, 1, 14)
+MRL_PLAN(300, 30, 30, 10, 1, 1, 12)
+MRL_PLAN(360, 30, 30, 3, 2, 2, 10)
+MRL_PLAN(450, 30, 30, 5, 3, 1, 8)
+MRL_PLAN(600, 30, 30, 10, 2, 1, 6)
 
 // Lines per workgroup of the z kernels (k_z_fwd / k_z_inv / k_z_inv_fwd): their lines are contiguous in memory, so the tile
 // width T of the strided passes (T adjacent lines = one coalesced segment) buys them nothing, while smaller workgroups mean more
@@ -232,6 +246,52 @@ __device__ __forceinline__ void bfly<10>(cplx (&a)[10]) {
     a[2 * k2] = e[k2];
     a[2 * k2 + 1] = o[k2];
   }
+}
+
+// radix 30 = 3 x 10 (Cooley-Tukey): n = 10 n1 + n2, k = k1 + 3 k2
+template <>
+__device__ __forceinline__ void bfly<30>(cplx (&a)[30]) {
+  // radix 3 over n1 for each n2: (a[n2], a[n2+10], a[n2+20]) -> A[n2][k1] left in the same slots (k1 = slot / 10)
+#pragma unroll
+  for (int n2 = 0; n2 < 10; ++n2) {
+    cplx b[3] = {a[n2], a[n2 + 10], a[n2 + 20]};
+    bfly<3>(b);
+    a[n2] = b[0];
+    a[n2 + 10] = b[1];
+    a[n2 + 20] = b[2];
+  }
+  // twiddles W30^(n2 * k1), k1 = 1, 2
+  a[11] = cmul(a[11], make_double2(0.978147600733805637929, -0.207911690817759337102));  // W30^1
+  a[12] = cmul(a[12], make_double2(0.913545457642600895502, -0.406736643075800207754));  // W30^2
+  a[13] = cmul(a[13], make_double2(0.809016994374947424102, -0.587785252292473129169));  // W30^3
+  a[14] = cmul(a[14], make_double2(0.669130606358858213826, -0.743144825477394235015));  // W30^4
+  a[15] = cmul(a[15], make_double2(0.5, -0.866025403784438646764));  // W30^5
+  a[16] = cmul(a[16], make_double2(0.309016994374947424102, -0.951056516295153572116));  // W30^6
+  a[17] = cmul(a[17], make_double2(0.1045284632676534714, -0.994521895368273336923));  // W30^7
+  a[18] = cmul(a[18], make_double2(-0.1045284632676534714, -0.994521895368273336923));  // W30^8
+  a[19] = cmul(a[19], make_double2(-0.309016994374947424102, -0.951056516295153572116));  // W30^9
+  a[21] = cmul(a[21], make_double2(0.913545457642600895502, -0.406736643075800207754));  // W30^2
+  a[22] = cmul(a[22], make_double2(0.669130606358858213826, -0.743144825477394235015));  // W30^4
+  a[23] = cmul(a[23], make_double2(0.309016994374947424102, -0.951056516295153572116));  // W30^6
+  a[24] = cmul(a[24], make_double2(-0.1045284632676534714, -0.994521895368273336923));  // W30^8
+  a[25] = cmul(a[25], make_double2(-0.5, -0.866025403784438646764));  // W30^10
+  a[26] = cmul(a[26], make_double2(-0.809016994374947424102, -0.587785252292473129169));  // W30^12
+  a[27] = cmul(a[27], make_double2(-0.978147600733805637929, -0.207911690817759337102));  // W30^14
+  a[28] = cmul(a[28], make_double2(-0.978147600733805637929, 0.207911690817759337102));  // W30^16
+  a[29] = cmul(a[29], make_double2(-0.809016994374947424102, 0.587785252292473129169));  // W30^18
+  // radix 10 over n2 for each k1: X[k1 + 3 k2]
+  cplx r[30];
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    cplx b[10];
+#pragma unroll
+    for (int n2 = 0; n2 < 10; ++n2) b[n2] = a[10 * k1 + n2];
+    bfly<10>(b);
+#pragma unroll
+    for (int k2 = 0; k2 < 10; ++k2) r[k1 + 3 * k2] = b[k2];
+  }
+#pragma unroll
+  for (int i = 0; i < 30; ++i) a[i] = r[i];
 }
 
 // LDS index maps: p = position within the line, l = line within the workgroup

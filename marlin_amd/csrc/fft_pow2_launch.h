@@ -155,6 +155,30 @@ inline unsigned pass_sub_blocks(long long rows, long long cols) {
   return (unsigned)((rows * cols + T - 1) / T);
 }
 
+// ... plus the lengths whose plans exist for the PLAIN transforms only (30 points per thread: see fft_pow2.h)
+#define MRL_SWITCH_N_PLAIN(n, CALL)                      \
+  switch (n) {                                           \
+    case 60: { constexpr int NN = 60; CALL; } break;     \
+    case 90: { constexpr int NN = 90; CALL; } break;     \
+    case 120: { constexpr int NN = 120; CALL; } break;   \
+    case 150: { constexpr int NN = 150; CALL; } break;   \
+    case 180: { constexpr int NN = 180; CALL; } break;   \
+    case 240: { constexpr int NN = 240; CALL; } break;   \
+    case 270: { constexpr int NN = 270; CALL; } break;   \
+    case 300: { constexpr int NN = 300; CALL; } break;   \
+    case 360: { constexpr int NN = 360; CALL; } break;   \
+    case 450: { constexpr int NN = 450; CALL; } break;   \
+    case 600: { constexpr int NN = 600; CALL; } break;   \
+    default: MRL_SWITCH_N(n, CALL)                       \
+  }
+
+inline bool plain30_ok(long long n) {
+  switch (n) {
+    case 60: case 90: case 120: case 150: case 180: case 240: case 270: case 300: case 360: case 450: case 600: return true;
+    default: return false;
+  }
+}
+
 inline bool pow2_ok(long long n) {
   switch (n) {
     case 32: case 64: case 128: case 256: case 512: case 1024: case 2048: case 4096:  // 2^a
@@ -166,6 +190,8 @@ inline bool pow2_ok(long long n) {
   }
 }
 inline bool is_pow2(long long n) { return n > 0 && (n & (n - 1)) == 0; }
+// every length with a plan for the plain transforms
+inline bool plain_ok(long long n) { return pow2_ok(n) || plain30_ok(n); }
 
 // Adams-Bashforth coefficients (src/tensor_solver/AdamsBashforthMoulton.C:67-73, incl. the AB5 190/720 entry)
 static const double kBetaAB[5][5] = {

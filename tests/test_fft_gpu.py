@@ -15,6 +15,8 @@ SHAPES = [
     (50, 50, 50), (250, 48, 40), (500, 32, 80), (144, 768, 48), (80, 40, 32), (1000, 32), (48, 144), (32, 1000, 40),
     (768, 50, 250),                                                        # the remaining planned lengths
     (2048, 64), (32, 4096), (2048, 32, 40), (4096, 2048),                  # long lines of 2-D problems (planned lengths only)
+    (120, 90, 60), (150, 150), (240, 120, 150), (64, 60, 256), (270, 300, 60), (180, 360), (450, 64, 90), (600, 40),
+    (100, 240, 96),                                                        # radix-30 plans (2 x 3 x 5 lengths), mixed with the others
 ]
 
 
