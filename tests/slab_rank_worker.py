@@ -97,6 +97,74 @@ def run_ch(job, P, r, kv, gold=False):
     return out
 
 
+def run_chbench(job, P, r, kv):
+    """exactly what `bench.py --gpus P` runs per rank with the native driver -- grid_for(P, n) with the bench's initial condition,
+    mrl_ch_substeps on a slab context -- against the serial fused path (mrl_ch_substeps on a one-GPU context of the same GLOBAL grid)
+    in this process: `steps` substeps in one call, this rank's slab to 1e-13"""
+    from bench import grid_for, splitmix64_uniform
+    from marlin_amd import api
+    n = int(kv.get("n", 256))
+    steps = int(kv.get("steps", 4))
+    shape = grid_for(P, n)
+    dx = 8.0 * math.pi / 200.0
+    L = [s * dx for s in shape]
+    npts = shape[0] * shape[1] * shape[2]
+    c0 = torch.from_numpy(splitmix64_uniform(npts).reshape(shape))
+    p = api.ch_params()
+    serial = api.Context(3, shape, L, device=0)
+    want = torch.empty(shape, dtype=torch.float64, device="cuda")
+    ring = [serial.empty_spec(), serial.empty_spec()]
+    serial.ch_substeps(p, c0.cuda(), want, ring, 1, 0, 2, steps, True, 1e-3)
+    serial.sync()
+    del ring
+    serial.close()
+    comm = api.Comm(job, P, r, device=0, transport=int(kv.get("transport", 0)), timeout=60.0)
+    ctx = api.Context(3, shape, L, nranks=P, rank=r, slab=True, device=0)
+    ctx.attach_comm(comm)
+    ctx.set_option(api.OPT_SLAB_NSUB, int(kv.get("nsub", 1)))
+    ctx.set_option(api.OPT_SLAB_CARRY, int(kv.get("carry", 0)))
+    yb, nyl = ctx.real_begin[1], ctx.real_shape[1]
+    want = want[:, yb:yb + nyl].contiguous()
+    torch.cuda.empty_cache()
+    c = c0[:, yb:yb + nyl].contiguous().cuda()
+    out = torch.empty_like(c)
+    ctx.ch_substeps(p, c, out, ring_arrays(ctx, 2), 1, 0, 2, steps, True, 1e-3)
+    ctx.sync()
+    err = (out - want).abs().max().item()
+    mass = comm.allreduce([float(out.sum(dtype=torch.float64).item())])[0]
+    ctx.close()
+    comm.close()
+    return {"max_err": err, "mass_err": abs(mass - float(c0.sum(dtype=torch.float64).item())) / npts, "grid": shape}
+
+
+def run_lost_peer(job, P, r, kv):
+    """a peer that stops taking part must end in MRL_ERR_COMM on the others within the time-out, not in a hung GPU: every rank runs one
+    solver call (the exchange pipeline is built collectively), then the last rank leaves while the others start a second call"""
+    from marlin_amd import api
+    shape = [64, 64, 64]
+    comm = api.Comm(job, P, r, device=0, timeout=float(kv.get("timeout", 4.0)))
+    ctx = api.Context(3, shape, [3.0, 3.0, 3.0], nranks=P, rank=r, slab=True, device=0)
+    ctx.attach_comm(comm)
+    yb, nyl = ctx.real_begin[1], ctx.real_shape[1]
+    torch.manual_seed(1)
+    c = (0.44 + 0.12 * torch.rand(shape, dtype=torch.float64))[:, yb:yb + nyl].contiguous().cuda()
+    out = torch.empty_like(c)
+    ring = ring_arrays(ctx, 2)
+    ctx.ch_substeps(api.ch_params(), c, out, ring, 1, 0, 2, 2, True, 1e-3)
+    ctx.sync()
+    if r == P - 1:
+        return {"left": True}       # (its buffers stay mapped in the peers; the process simply ends)
+    import time
+    t0 = time.perf_counter()
+    code, msg = 0, ""
+    try:
+        ctx.ch_substeps(api.ch_params(), out, c, ring, 0, 1, 2, 2, True, 1e-3)
+        ctx.sync()
+    except api.MarlinHipError as e:
+        code, msg = e.code, e.message
+    return {"left": False, "code": code, "message": msg, "seconds": time.perf_counter() - t0}
+
+
 def run_fft(job, P, r, kv):
     from marlin_amd import api
     shape = [int(x) for x in kv.get("shape", "16,12,10").split(",")]
@@ -209,6 +277,10 @@ def main():
         out = run_ch(job, P, r, kv, gold=True)
     elif case == "fft":
         out = run_fft(job, P, r, kv)
+    elif case == "chbench":
+        out = run_chbench(job, P, r, kv)
+    elif case == "lost_peer":
+        out = run_lost_peer(job, P, r, kv)
     elif case == "mech":
         out = run_mech(job, P, r, kv)
     else:

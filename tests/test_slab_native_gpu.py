@@ -101,3 +101,24 @@ def test_native_slab_mechanics_fused_vs_oracle(P, shape, transport):
     res = run_job(P, "mech", f"shape={shape}", f"transport={transport}", timeout=600)
     assert all(r["traces_ok"] for r in res), res
     assert max(r["max_err"] for r in res) <= 1e-10, res
+
+
+@pytest.mark.parametrize("P,carry", [(4, 0), (2, 1)])
+def test_native_bench_configuration_equals_serial(P, carry):
+    """the configuration `bench.py --gpus P` runs per rank with the native driver (grid_for(P, 256): 512 x 512 x 256 on 4 ranks, the
+    bench's initial condition, one mrl_ch_substeps call) on P rank processes against the serial fused path on the same global grid:
+    4 substeps, every rank's slab to 1e-13, total mass conserved"""
+    res = run_job(P, "chbench", f"carry={carry}", timeout=600)
+    assert max(r["max_err"] for r in res) <= 1e-13, res
+    assert max(r["mass_err"] for r in res) <= 1e-12, res
+
+
+def test_native_lost_peer_times_out_cleanly():
+    """a rank that leaves the job: the others' next solver call returns MRL_ERR_COMM (-6) once the bounded device-side wait gives up
+    (4 s here), and later waits return at once -- no hung GPU, no hung host"""
+    res = run_job(3, "lost_peer", "timeout=4", timeout=180)
+    stayed = [r for r in res if not r["left"]]
+    assert len(stayed) == 2
+    for r in stayed:
+        assert r["code"] == -6 and "did not arrive" in r["message"], r
+        assert 3.0 <= r["seconds"] <= 30.0, r
