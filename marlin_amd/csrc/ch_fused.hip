@@ -10,6 +10,7 @@
 //   contiguous in (y,kz) jointly, so the user-visible Nhat arrays are accessed in aligned 256-B pieces.
 #include "ch_fused_body.h"
 #include "fft_pow2_launch.h"
+#include "fft_pow2_wide.h"
 
 namespace mrl {
 
@@ -142,6 +143,21 @@ static int pass_axis(mrl_ctx *ctx, int axis, bool inv, int nf, const cplx *in0, 
   }
   const cplx *tw = axis == 1 ? g.tw_y : g.tw_x;
   const long long n = axis == 1 ? g.ny : g.nx;
+  // experiment bit 1024: the wide plan (fft_pow2_wide.h) for 512-point lines.  Measured on plain transforms: +18 % on a 135 MB
+  // array (Infinity-Cache resident), -3 ... -4 % on 1 GB arrays -- not the default on one GPU; the slab x passes use it (-12 %)
+  if (n == 512 && (ctx->exp & 1024)) {
+    for (int f = 0; f < nf; ++f) {
+      p2::PassArgs b = a;
+      b.in[0] = a.in[f];
+      b.out[0] = a.out[f];
+      if (inv) {
+        MRL_TRY((p2::launch_pass_w<p2::Wide512, true>(ctx, b, tw)));
+      } else {
+        MRL_TRY((p2::launch_pass_w<p2::Wide512, false>(ctx, b, tw)));
+      }
+    }
+    return MRL_OK;
+  }
   if (nf == 2) {
     if (inv) {
       MRL_SWITCH_N(n, MRL_TRY((p2::launch_pass_t<NN, true, 2>(ctx, a, tw))));

@@ -22,6 +22,7 @@
 #include "ch_fused_body.h"
 
 #include "fft_pow2_launch.h"
+#include "fft_pow2_wide.h"
 
 namespace mrl {
 
@@ -204,6 +205,19 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const 
   // non-temporal stores of the exchange layout: A/B at 512^3 / 8 on one box -- rows of the natural odd pitch 182 / 162 -> 156 / 149 us,
   // rows padded to 128-byte lines (what is used) 171 -> 211 / 220 us: off
   a.nt_out = (ctx->exp & 512) ? 1 : 0;
+  // 512-point lines: the wide plan (fft_pow2_wide.h: 32 points per thread, two stages, 256-byte segments), one field per launch, all
+  // launches counting towards one arrival flag.  A/B at 512^3 / 8, same box, interleaved: forward pass 205-215 -> 182 us, inverse
+  // pass 66-68 -> 59 us (experiment bit 1024 switches back to the 16-point plan)
+  if (nx == 512 && !(ctx->exp & 1024)) {
+    const int nf = one ? 1 : 2;
+    a.sig.expected = (unsigned)nf * (unsigned)(((long long)a.rows * a.cols + p2::Wide512::T - 1) / p2::Wide512::T);
+    for (int f = 0; f < nf; ++f) {
+      a.in[0] = f == 0 ? a.in[0] : a.in[1];
+      a.fo_out = (unsigned)f * chunk;
+      MRL_TRY((p2::launch_pass_sub_w<p2::Wide512, false>(ctx, a, ctx->ax[0].d_tw)));
+    }
+    return MRL_OK;
+  }
   if (one) {
     MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 1>(ctx, a, ctx->ax[0].d_tw))));
   } else if (ctx->exp & 256) {   // experiment: one field per launch (the two launches count towards one arrival flag)
@@ -289,6 +303,7 @@ int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv) {
   a.cs_in = (unsigned)(nxl * nyl * kp);
   a.sh_out = 31;
   ProfScope ps(ctx, "slab_C_x_inv", 32.0 * nx * nyl * ksub);
+  if (nx == 512 && !(ctx->exp & 1024)) return p2::launch_pass_sub_w<p2::Wide512, true>(ctx, a, ctx->ax[0].d_tw);
   MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, true, 1>(ctx, a, ctx->ax[0].d_tw))));
   return MRL_OK;
 }
