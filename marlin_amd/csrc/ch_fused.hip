@@ -24,7 +24,7 @@ struct FusedArgs {
 };
 
 // NT: stream the arrays that are not re-read within the substep past the Infinity Cache (ch_fused_body.h); chosen per launch
-template <int N, int ORDER, int PRE, bool SPEC_C, bool NT>
+template <int N, int ORDER, int PRE, bool SPEC_C, bool NT, bool BIG = false>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const cplx *__restrict__ tw) {
   constexpr int TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
@@ -38,11 +38,25 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const
   const bool valid = i < a.inner;
   const long long iv = valid ? i : 0;
   // byte offset of line element m: (i + (q + m*TPL)*inner) * 16, the same in the work and the dense layout
-  const unsigned off0 = (unsigned)(iv + (long long)q * a.inner) * 16u, step = (unsigned)(TPL * a.inner) * 16u;
-  auto off = [=](int m) { return off0 + (unsigned)m * step; };
   cplx *const ubar = a.c.ubar;
-  auto stu = [=](int m, cplx val) { stc(ubar, off0 + (unsigned)m * step, val); };
-  ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT, NT, NT>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, stu, W, X, KX);
+  if constexpr (BIG) {  // arrays >= 4 GiB: m * (line stride) is wave-uniform and 64-bit, the rest fits 32 bits (checked by the launcher)
+    const unsigned off0 = (unsigned)((iv + (long long)q * a.inner) * 16);
+    const unsigned long long step = (unsigned long long)(TPL * a.inner) * 16ull;
+    auto off = [=](int m) { return BigOff{(unsigned long long)m * step, off0}; };
+    auto stu = [=](int m, cplx val) { stc(ubar, BigOff{(unsigned long long)m * step, off0}, val); };
+    ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT, NT, NT>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, stu, W, X, KX);
+  } else {
+    const unsigned off0 = (unsigned)(iv + (long long)q * a.inner) * 16u, step = (unsigned)(TPL * a.inner) * 16u;
+    auto off = [=](int m) { return off0 + (unsigned)m * step; };
+    auto stu = [=](int m, cplx val) { stc(ubar, off0 + (unsigned)m * step, val); };
+    ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT, NT, NT>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, stu, W, X, KX);
+  }
+}
+
+// lengths for which the 64-bit-offset variant is instantiated (x axes long enough for a >= 4 GiB half-spectrum array)
+template <int N>
+constexpr bool big_capable() {
+  return N == 512 || N == 768 || N == 1000 || N == 1024;
 }
 
 // The non-temporal variant pays off when the arrays are large against the 256 MB Infinity Cache (a resident old Nhat is a hit
@@ -53,23 +67,30 @@ constexpr bool nt_capable() {
   return (N == 256 || N == 384 || N == 512) && (Plan<N>::T * 16) % 128 == 0;
 }
 
-template <int N, int ORDER, bool SPEC_C, bool NT, int PRE>
+template <int N, int ORDER, bool SPEC_C, bool NT, int PRE, bool BIG = false>
 static int launch_xfused_v(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
   if (!attr) {
-    MRL_TRY((set_lds_attr(ctx, k_ch_xfused<N, ORDER, PRE, SPEC_C, NT>, lds)));
+    MRL_TRY((set_lds_attr(ctx, k_ch_xfused<N, ORDER, PRE, SPEC_C, NT, BIG>, lds)));
     attr = true;
   }
   constexpr int T = Plan<N>::T;
   const long long nb = (a.inner + T - 1) / T;
-  hipLaunchKernelGGL((k_ch_xfused<N, ORDER, PRE, SPEC_C, NT>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
+  hipLaunchKernelGGL((k_ch_xfused<N, ORDER, PRE, SPEC_C, NT, BIG>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
 
 template <int N, int ORDER, bool SPEC_C, int PRE = Plan<N>::P / 2>
 static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
+  if (16.0 * (double)N * (double)a.inner >= 4294967296.0) {   // one array is 4 GiB or more: 64-bit uniform part of the offsets
+    if constexpr (big_capable<N>() && !SPEC_C) {
+      return launch_xfused_v<N, ORDER, SPEC_C, nt_capable<N>(), PRE, true>(ctx, a, tw);
+    } else {
+      return MRL_ERR_UNSUPPORTED;
+    }
+  }
   if constexpr (nt_capable<N>()) {
     const double array_bytes = 16.0 * (double)N * (double)a.inner;
     if (array_bytes >= 96.0e6) return launch_xfused_v<N, ORDER, SPEC_C, true, PRE>(ctx, a, tw);
@@ -83,8 +104,15 @@ static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
 // (1, nx, ny_user): the user's y is the contiguous r2c axis; the absent middle axis contributes k = 0 exactly)
 bool fast_path_ok(const mrl_ctx *ctx) {
   if (ctx->slab || ctx->spectrum != MRL_SPECTRUM_HALF) return false;
-  // the fused kernels address one spectral array with 32-bit byte offsets from its base (ch_fused_body.h)
-  if (16.0 * (double)ctx->nrec[0] * (double)ctx->nrec[1] * (double)ctx->nrec[2] >= 4294967296.0) return false;
+  if (ctx->exp & 2048) return false;  // experiment: planned shapes through the any-length path (A/B and parity at sizes the oracle cannot reach)
+  // the fused kernels address one spectral array with 32-bit byte offsets from its base (ch_fused_body.h); arrays of 4 GiB and
+  // more need the 64-bit variant (x lengths 512 / 768 / 1000 / 1024) and a per-lane part (one line stride) below 4 GiB
+  if (16.0 * (double)ctx->nrec[0] * (double)ctx->nrec[1] * (double)ctx->nrec[2] >= 4294967296.0) {
+    const long long nx = ctx->n[ctx->dim == 3 ? 0 : 1];
+    if (!(nx == 512 || nx == 768 || nx == 1000 || nx == 1024)) return false;
+    const double P = nx == 1000 ? 10.0 : (nx == 768 ? 12.0 : 16.0);
+    if (16.0 * ((double)nx / P) * (double)(ctx->dim == 3 ? ctx->n[1] : 1) * (double)ctx->nrec[2] >= 4294967296.0) return false;
+  }
   if (ctx->dim == 3) return pow2_ok(ctx->n[0]) && pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]);
   if (ctx->dim == 2) return pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]);
   return false;
@@ -262,6 +290,8 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
                      const double *const *Nhat_old, int order, double sub_dt, double *cbar, double *mu, int carry) {
   if (!fast_path_ok(ctx)) return MRL_ERR_UNSUPPORTED;
   const bool spec = carry == MRL_CARRY_IN;  // spectral carry-over: c-hat is `cbar` (= ubar of the previous substep)
+  if (spec && 16.0 * (double)ctx->nrec[0] * (double)ctx->nrec[1] * (double)ctx->nrec[2] >= 4294967296.0)
+    return MRL_ERR_UNSUPPORTED;  // (the 64-bit-offset variant of the fused pass exists for the reference's data flow only)
   const Geo g = geo_of(ctx);
   const long long nx = g.nx, ny = g.ny, nz = g.nz, nzc = g.nzc;
   const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;

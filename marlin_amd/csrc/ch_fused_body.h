@@ -52,6 +52,29 @@ __device__ __forceinline__ void stc_nt(cplx *base, unsigned boff, cplx v) {
   __builtin_nontemporal_store(w, reinterpret_cast<nt_v2 *>(reinterpret_cast<char *>(base) + boff));
 }
 
+// Arrays of 4 GiB and more (1024^3 on one 288 GB GPU): an offset is a WAVE-UNIFORM 64-bit part (m * line stride: folded into the
+// scalar base address) plus a 32-bit per-lane part, so the accesses keep the "SGPR base + 32-bit VGPR offset" form
+struct BigOff {
+  unsigned long long uni;
+  unsigned lane;
+};
+__device__ __forceinline__ cplx ldc(const cplx *base, BigOff o) {
+  return *reinterpret_cast<const cplx *>(reinterpret_cast<const char *>(base) + o.uni + o.lane);
+}
+__device__ __forceinline__ void stc(cplx *base, BigOff o, cplx v) {
+  *reinterpret_cast<cplx *>(reinterpret_cast<char *>(base) + o.uni + o.lane) = v;
+}
+__device__ __forceinline__ cplx ldc_nt(const cplx *base, BigOff o) {
+  const nt_v2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_v2 *>(reinterpret_cast<const char *>(base) + o.uni + o.lane));
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void stc_nt(cplx *base, BigOff o, cplx v) {
+  nt_v2 w;
+  w.x = v.x;
+  w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<nt_v2 *>(reinterpret_cast<char *>(base) + o.uni + o.lane));
+}
+
 // OffW / OffD: callables m -> byte offset of the thread's m-th line element in the work layout / the dense
 // reference layout (computed from a few live values instead of 2 x 16 held registers).
 // StU: callable (m, value) that stores the thread's m-th element of the ubar output (work layout on one GPU; on the slab path
