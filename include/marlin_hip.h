@@ -126,6 +126,9 @@ int mrl_comm_barrier(mrl_comm *comm);                     /* host barrier over t
 int mrl_comm_allreduce(mrl_comm *comm, double *h_values, int32_t n, int32_t op);
 /* cumulative count of exchanges posted and payload bytes sent to OTHER ranks by this rank */
 int mrl_comm_stats(const mrl_comm *comm, int64_t *n_exchanges, double *bytes_sent);
+/* host half of the transport alone, no GPU needed: `rounds` x { barrier, all-gather, sum / min / max all-reduce } over the bootstrap
+ * segment "/name", each checked against its closed form; MRL_OK on every rank if all of them agree (CPU test tier) */
+int mrl_comm_bootstrap_selftest(const char *name, int32_t nranks, int32_t rank, int32_t rounds);
 /* slab contexts only; nranks / rank must match; the context does not own the communicator */
 int mrl_ctx_attach_comm(mrl_ctx *ctx, mrl_comm *comm);
 

@@ -146,6 +146,7 @@ SIGNATURES = {
     "mrl_comm_set_transport": (_i32, [_vp, C.c_int32]),
     "mrl_comm_set_timeout": (_i32, [_vp, _dbl]),
     "mrl_comm_reset_error": (_i32, [_vp]),
+    "mrl_comm_bootstrap_selftest": (_i32, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32]),
     "mrl_comm_barrier": (_i32, [_vp]),
     "mrl_comm_allreduce": (_i32, [_vp, C.POINTER(_dbl), C.c_int32, C.c_int32]),
     "mrl_comm_stats": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_dbl)]),

@@ -690,6 +690,51 @@ int mrl_comm_create(mrl_comm **out, const char *name, int32_t nranks, int32_t ra
   return MRL_OK;
 }
 
+// The host half of the transport alone (no HIP call): attach to the bootstrap segment, then `rounds` times a barrier, an
+// all-gather of a rank-stamped blob and a sum / min / max all-reduce, each checked against its closed form.  Lets the CPU test tier
+// exercise the multi-process bootstrap (tests/test_comm_bootstrap_cpu.py).
+int mrl_comm_bootstrap_selftest(const char *name, int32_t nranks, int32_t rank, int32_t rounds) {
+  if (!name || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return MRL_ERR_INVALID;
+  mrl_comm c;
+  c.nranks = nranks;
+  c.rank = rank;
+  c.timeout_s = 30.0;
+  int rc = MRL_OK;
+  if (nranks > 1) {
+    c.shm_name = std::string("/") + name;
+    const int fd = shm_open(c.shm_name.c_str(), O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, sizeof(ShmSeg)) != 0) return MRL_ERR_COMM;
+    void *m = mmap(nullptr, sizeof(ShmSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return MRL_ERR_COMM;
+    c.shm = static_cast<ShmSeg *>(m);
+    c.shm->attached.fetch_add(1);
+    const double t0 = now_s();
+    while (c.shm->attached.load() < (uint32_t)nranks && now_s() - t0 < c.timeout_s) usleep(100);
+    if (c.shm->attached.load() != (uint32_t)nranks) rc = MRL_ERR_COMM;
+  }
+  for (int it = 0; it < rounds && rc == MRL_OK; ++it) {
+    rc = comm_barrier(&c);
+    int64_t mine[4] = {rank, it, (int64_t)rank * 1000 + it, -rank}, all[4 * kMaxRanks];
+    if (rc == MRL_OK) rc = comm_allgather(&c, mine, sizeof(mine), all);
+    for (int p = 0; p < nranks && rc == MRL_OK; ++p)
+      if (all[4 * p] != p || all[4 * p + 1] != it || all[4 * p + 2] != (int64_t)p * 1000 + it || all[4 * p + 3] != -p) rc = MRL_ERR_COMM;
+    double v[3] = {(double)(rank + 1) * (it + 1), (double)(rank + it), (double)(rank + it)};
+    double s = v[0], lo = v[1], hi = v[2];
+    if (rc == MRL_OK) rc = comm_allreduce_host(&c, &s, 1, 0);
+    if (rc == MRL_OK) rc = comm_allreduce_host(&c, &lo, 1, 1);
+    if (rc == MRL_OK) rc = comm_allreduce_host(&c, &hi, 1, 2);
+    if (rc == MRL_OK && (s != (double)(it + 1) * nranks * (nranks + 1) / 2.0 || lo != (double)it || hi != (double)(nranks - 1 + it))) rc = MRL_ERR_COMM;
+  }
+  if (c.shm) {
+    if (rc == MRL_OK) rc = comm_barrier(&c);
+    if (rank == 0) shm_unlink(c.shm_name.c_str());
+    munmap(c.shm, sizeof(ShmSeg));
+    c.shm = nullptr;
+  }
+  return rc;
+}
+
 int mrl_comm_transport(const mrl_comm *c) { return c ? c->transport : MRL_ERR_INVALID; }
 
 int mrl_comm_set_transport(mrl_comm *c, int32_t transport) {

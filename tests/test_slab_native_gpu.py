@@ -122,3 +122,36 @@ def test_native_lost_peer_times_out_cleanly():
     for r in stayed:
         assert r["code"] == -6 and "did not arrive" in r["message"], r
         assert 3.0 <= r["seconds"] <= 30.0, r
+
+
+def test_bench_drivers_agree_on_two_ranks():
+    """`bench.py --gpus 2` with the native driver (library-owned exchange, transports tuned in the warm-up) and with the
+    torch.distributed driver (marlin_amd/slab.py; gloo here, because two ranks share this box's GPU) evolve the same field: the
+    global checksum sum(c^2) of their JSON lines agrees to 1e-13 relative, and the native line shows that bytes crossed ranks"""
+    import socket
+
+    def free_port():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        return port
+
+    def run(extra):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "64", "--steps", "6", "--warmup",
+               "2", "--profile-steps", "2", "--no-variants"] + extra
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert line, out.stdout[-1000:]
+        return json.loads(line[-1])
+
+    native = run([])
+    python = run(["--driver", "python", "--backend", "gloo"])
+    a, b = native["field_checksum"]["sum_c_squared"], python["field_checksum"]["sum_c_squared"]
+    assert abs(a - b) <= 1e-13 * abs(a), (a, b)
+    assert native["config"]["driver"] == "native" and python["config"]["driver"] == "python"
+    assert native["exchange"]["bytes_sent_to_peers_per_step_rank0"] > 0
+    assert native["exchange"]["transport"]["selected"] in ("peer_store", "peer_copy")
+    assert native["n_gpus"] == 2 and native["config"]["grid"] == [64, 128, 64]
