@@ -397,12 +397,16 @@ struct SubPassArgs {
   cplx *out[2];              // INV only (dense output)
   cplx *const *otab;         // !INV: destination of chunk c (device table, one entry per rank)
   int rows, cols;
+  int tcols;                 // tiles run over rows x tcols (0 = cols).  !INV with tcols = pitch_out: a tile is T consecutive elements
+                             // of the padded OUTPUT rows, i.e. every store of a wave is whole 128-byte lines (columns >= cols repeat
+                             // the last line and land in the padding); the loads straddle lines instead, which costs nothing
   unsigned pitch_in, pitch_out;
   unsigned sn_in, sn_out;
   int sh_in, sh_out;
   unsigned cs_in;
   unsigned fs_out, fo_out;   // !INV: element offset of field f within a chunk = fo_out + f * fs_out
   int nt_out;                // !INV: non-temporal stores (experiment)
+  unsigned nb;               // k_pass_sub_w: workgroups per field (set by the launcher)
   SignalArgs sig;
 };
 
@@ -416,10 +420,10 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub(SubPassArgs a, cons
   const int l = threadIdx.x % T, q = threadIdx.x / T;
   const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned i = logical * T + l;
-  const bool valid = i < (unsigned)(a.rows * a.cols);
+  const bool valid = i < (unsigned)(a.rows * a.tcols);
   const unsigned ic = valid ? i : 0u;
-  const unsigned row = ic / (unsigned)a.cols, col = ic - row * (unsigned)a.cols;
-  const unsigned bi = row * a.pitch_in + col, bo = row * a.pitch_out + col;
+  const unsigned row = ic / (unsigned)a.tcols, col = ic - row * (unsigned)a.tcols;
+  const unsigned bi = row * a.pitch_in + min(col, (unsigned)a.cols - 1u), bo = row * a.pitch_out + col;
   const unsigned mi = (a.sh_in < 31) ? ((1u << a.sh_in) - 1u) : 0xffffffffu;
   const unsigned mo = (a.sh_out < 31) ? ((1u << a.sh_out) - 1u) : 0xffffffffu;
   TwRegs<N> twr;

@@ -110,7 +110,8 @@ inline int launch_pass_sub(mrl_ctx *ctx, SubPassArgs a, const cplx *tw) {
     attr = true;
   }
   constexpr int T = Plan<N>::T;
-  const long long nb = ((long long)a.rows * a.cols + T - 1) / T;
+  if (a.tcols == 0) a.tcols = a.cols;
+  const long long nb = ((long long)a.rows * a.tcols + T - 1) / T;
   if (a.sig.expected == 0) a.sig.expected = (unsigned)nb;  // (a caller that spreads one exchange over several launches sets the total)
   hipLaunchKernelGGL((k_pass_sub<N, INV, NF>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
   MRL_HIP(ctx, hipGetLastError());

@@ -135,20 +135,27 @@ __global__ void __launch_bounds__(PL::NT, 2) k_pass_w(PassArgs a, const cplx *__
   }
 }
 
-// ... and of k_pass_sub (kz sub-block of the slab pipeline, scatter through the destination table), one field per launch
-template <class PL, bool INV>
+// ... and of k_pass_sub (kz sub-block of the slab pipeline, scatter through the destination table), one field per launch.
+// UTAB: the chunk length 2^sh_out is a multiple of TPL, so the chunk index of element n = q + m TPL depends on m only and the table
+// entry is a scalar load instead of one vector load per element in front of every store
+template <class PL, bool INV, bool UTAB = false>
 __global__ void __launch_bounds__(PL::NT, 2) k_pass_sub_w(SubPassArgs a, const cplx *__restrict__ tw) {
   constexpr int P = PL::P, TPL = PL::TPL, T = PL::T, N = PL::N, NT = PL::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
   double *X = reinterpret_cast<double *>(W + N);
   const int l = threadIdx.x % T, q = threadIdx.x / T;
-  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  // fields back to back in ONE launch (a.nb workgroups each): twice the workgroups between two launch boundaries
+  const unsigned f = logical >= a.nb ? 1u : 0u;
+  logical -= f * a.nb;
+  const cplx *__restrict__ src = a.in[f];
+  const unsigned fo = a.fo_out + f * a.fs_out;
   const unsigned i = logical * T + l;
-  const bool valid = i < (unsigned)(a.rows * a.cols);
+  const bool valid = i < (unsigned)(a.rows * a.tcols);
   const unsigned ic = valid ? i : 0u;
-  const unsigned row = ic / (unsigned)a.cols, col = ic - row * (unsigned)a.cols;
-  const unsigned bi = row * a.pitch_in + col, bo = row * a.pitch_out + col;
+  const unsigned row = ic / (unsigned)a.tcols, col = ic - row * (unsigned)a.tcols;
+  const unsigned bi = row * a.pitch_in + min(col, (unsigned)a.cols - 1u), bo = row * a.pitch_out + col;
   const unsigned mi = (a.sh_in < 31) ? ((1u << a.sh_in) - 1u) : 0xffffffffu;
   const unsigned mo = (a.sh_out < 31) ? ((1u << a.sh_out) - 1u) : 0xffffffffu;
   TwRegs<N, NT> twr;
@@ -157,7 +164,7 @@ __global__ void __launch_bounds__(PL::NT, 2) k_pass_sub_w(SubPassArgs a, const c
 #pragma unroll
   for (int m = 0; m < P; ++m) {
     const unsigned n = q + m * TPL;
-    v[m] = a.in[0][bi + (a.sh_in < 31 ? (n >> a.sh_in) * a.cs_in : 0u) + (n & mi) * a.sn_in];
+    v[m] = src[bi + (a.sh_in < 31 ? (n >> a.sh_in) * a.cs_in : 0u) + (n & mi) * a.sn_in];
   }
   tw_commit<N, NT>(twr, W);
   if (INV) {
@@ -172,8 +179,8 @@ __global__ void __launch_bounds__(PL::NT, 2) k_pass_sub_w(SubPassArgs a, const c
       if (INV) {
         a.out[0][bo + (n & mo) * a.sn_out] = cswap(v[m]);
       } else {
-        cplx *base = a.otab[n >> a.sh_out];
-        base[a.fo_out + bo + (n & mo) * a.sn_out] = v[m];
+        cplx *base = UTAB ? a.otab[(unsigned)(m * TPL) >> a.sh_out] : a.otab[n >> a.sh_out];
+        base[fo + bo + (n & mo) * a.sn_out] = v[m];
       }
     }
   }
@@ -195,19 +202,30 @@ inline int launch_pass_w(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
   return MRL_OK;
 }
 
-template <class PL, bool INV>
-inline int launch_pass_sub_w(mrl_ctx *ctx, SubPassArgs a, const cplx *tw) {
+template <class PL, bool INV, bool UTAB>
+inline int launch_pass_sub_w_v(mrl_ctx *ctx, const SubPassArgs &a, const cplx *tw, long long nb) {  // nb = all workgroups
   static bool attr = false;
   constexpr size_t lds = lds_wide<PL>();
   if (!attr) {
-    MRL_TRY((set_lds_attr(ctx, k_pass_sub_w<PL, INV>, lds)));
+    MRL_TRY((set_lds_attr(ctx, k_pass_sub_w<PL, INV, UTAB>, lds)));
     attr = true;
   }
-  const long long nb = ((long long)a.rows * a.cols + PL::T - 1) / PL::T;
-  if (a.sig.expected == 0) a.sig.expected = (unsigned)nb;
-  hipLaunchKernelGGL((k_pass_sub_w<PL, INV>), dim3((unsigned)nb), dim3(PL::NT), lds, ctx->stream, a, tw);
+  hipLaunchKernelGGL((k_pass_sub_w<PL, INV, UTAB>), dim3((unsigned)nb), dim3(PL::NT), lds, ctx->stream, a, tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
+}
+
+// nf = 1 or 2 fields (a.in[f] -> chunk offset fo_out + f * fs_out), INV: one field
+template <class PL, bool INV>
+inline int launch_pass_sub_w(mrl_ctx *ctx, SubPassArgs a, const cplx *tw, int nf = 1) {
+  if (a.tcols == 0) a.tcols = a.cols;
+  a.nb = (unsigned)(((long long)a.rows * a.tcols + PL::T - 1) / PL::T);
+  const long long nb = (long long)nf * a.nb;
+  if (a.sig.expected == 0) a.sig.expected = (unsigned)nb;
+  if constexpr (!INV) {
+    if (a.sh_out < 31 && (1 << a.sh_out) % PL::TPL == 0) return launch_pass_sub_w_v<PL, INV, true>(ctx, a, tw, nb);
+  }
+  return launch_pass_sub_w_v<PL, INV, false>(ctx, a, tw, nb);
 }
 
 }  // namespace p2

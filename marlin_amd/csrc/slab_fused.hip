@@ -201,6 +201,10 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const 
   a.sn_out = (unsigned)(nyl * kp);
   a.sh_in = 31;
   a.sh_out = ilog2(nxl);
+  // tiles over the padded rows of the exchange layout: every wave stores whole 128-byte lines (the dense tiling stored 256-byte pieces
+  // at 16-byte offsets, and the partial lines at their ends cost the memory a read-modify-write: 7 % of the write requests were short and
+  // the read side stalled on DRAM credits 9 x as often as in the inverse pass).  Experiment bit 4096 = the dense tiling
+  a.tcols = (ctx->exp & 4096) ? ksub : (int)kp;
   ProfScope ps(ctx, "slab_A_x_fwd", (one ? 2.0 : 4.0) * 16.0 * nx * nyl * ksub);
   // non-temporal stores of the exchange layout: A/B at 512^3 / 8 on one box -- rows of the natural odd pitch 182 / 162 -> 156 / 149 us,
   // rows padded to 128-byte lines (what is used) 171 -> 211 / 220 us: off
@@ -210,8 +214,9 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const 
   // pass 66-68 -> 59 us (experiment bit 1024 switches back to the 16-point plan)
   if (nx == 512 && !(ctx->exp & 1024)) {
     const int nf = one ? 1 : 2;
-    a.sig.expected = (unsigned)nf * (unsigned)(((long long)a.rows * a.cols + p2::Wide512::T - 1) / p2::Wide512::T);
-    for (int f = 0; f < nf; ++f) {
+    if (!(ctx->exp & 8192)) return p2::launch_pass_sub_w<p2::Wide512, false>(ctx, a, ctx->ax[0].d_tw, nf);  // both fields in one launch
+    a.sig.expected = (unsigned)nf * (unsigned)(((long long)a.rows * a.tcols + p2::Wide512::T - 1) / p2::Wide512::T);
+    for (int f = 0; f < nf; ++f) {  // experiment bit 8192: one launch per field, all counting towards one arrival flag
       a.in[0] = f == 0 ? a.in[0] : a.in[1];
       a.fo_out = (unsigned)f * chunk;
       MRL_TRY((p2::launch_pass_sub_w<p2::Wide512, false>(ctx, a, ctx->ax[0].d_tw)));
@@ -222,7 +227,7 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const 
     MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 1>(ctx, a, ctx->ax[0].d_tw))));
   } else if (ctx->exp & 256) {   // experiment: one field per launch (the two launches count towards one arrival flag)
     unsigned nb = 0;
-    MRL_SWITCH_N(nx, nb = pass_sub_blocks<NN>(a.rows, a.cols));
+    MRL_SWITCH_N(nx, nb = pass_sub_blocks<NN>(a.rows, a.tcols));
     a.sig.expected = 2u * nb;
     MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, false, 1>(ctx, a, ctx->ax[0].d_tw))));
     a.in[0] = a.in[1];
