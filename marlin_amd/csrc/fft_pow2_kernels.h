@@ -406,7 +406,8 @@ struct SubPassArgs {
   unsigned cs_in;
   unsigned fs_out, fo_out;   // !INV: element offset of field f within a chunk = fo_out + f * fs_out
   int nt_out;                // !INV: non-temporal stores (experiment)
-  unsigned nb;               // k_pass_sub_w: workgroups per field (set by the launcher)
+  unsigned nb;               // k_pass_sub_w / k_pass_sub_mf: workgroups per field (set by the launcher)
+  unsigned fdense;           // k_pass_sub_mf: elements between two fields of the dense (rank-local) array
   SignalArgs sig;
 };
 
@@ -459,6 +460,58 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub(SubPassArgs a, cons
           else
             *dst = v[f][m];
         }
+      }
+    }
+  }
+  if (!INV) signal_tail(a.sig);
+}
+
+// k_pass_sub over SEVERAL fields in one launch (the nine fields of the slab Gamma operator): gridDim = nf * a.nb, the field is the
+// slow block index.  Field f is a.in[0] + f * fdense (dense side) and chunk offset f * fs_out (exchange-layout side); the chunk of
+// one peer holds all nf fields (cs_in = nf * fs_out on the inverse side).
+template <int N, bool INV>
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_mf(SubPassArgs a, const cplx *__restrict__ tw) {
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T;
+  using Map = MapStrided<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  const int l = threadIdx.x % T, q = threadIdx.x / T;
+  unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned f = logical / a.nb;
+  logical -= f * a.nb;
+  const unsigned i = logical * T + l;
+  const bool valid = i < (unsigned)(a.rows * a.tcols);
+  const unsigned ic = valid ? i : 0u;
+  const unsigned row = ic / (unsigned)a.tcols, col = ic - row * (unsigned)a.tcols;
+  const unsigned bi = row * a.pitch_in + min(col, (unsigned)a.cols - 1u), bo = row * a.pitch_out + col;
+  const unsigned mi = (a.sh_in < 31) ? ((1u << a.sh_in) - 1u) : 0xffffffffu;
+  const unsigned mo = (a.sh_out < 31) ? ((1u << a.sh_out) - 1u) : 0xffffffffu;
+  const cplx *__restrict__ src = a.in[0] + (size_t)f * (INV ? a.fs_out : a.fdense);
+  TwRegs<N> twr;
+  tw_issue<N>(twr, tw);
+  cplx v[P];
+#pragma unroll
+  for (int m = 0; m < P; ++m) {
+    const unsigned n = q + m * TPL;
+    v[m] = src[bi + (a.sh_in < 31 ? (n >> a.sh_in) * a.cs_in : 0u) + (n & mi) * a.sn_in];
+  }
+  tw_commit<N>(twr, W);
+  if (INV) {
+#pragma unroll
+    for (int m = 0; m < P; ++m) v[m] = cswap(v[m]);
+  }
+  fft_line<N, Map>(v, q, l, X, W);
+  if (valid) {
+    cplx *dense = INV ? a.out[0] + (size_t)f * a.fdense : nullptr;
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      const unsigned n = q + m * TPL;
+      if (INV) {
+        dense[bo + (n & mo) * a.sn_out] = cswap(v[m]);
+      } else {
+        cplx *base = a.otab[n >> a.sh_out];
+        base[f * a.fs_out + bo + (n & mo) * a.sn_out] = v[m];
       }
     }
   }

@@ -118,6 +118,24 @@ inline int launch_pass_sub(mrl_ctx *ctx, SubPassArgs a, const cplx *tw) {
   return MRL_OK;
 }
 
+template <int N, bool INV>
+inline int launch_pass_sub_mf(mrl_ctx *ctx, SubPassArgs a, const cplx *tw, int nf) {
+  static bool attr = false;
+  constexpr size_t lds = lds_strided<N>();
+  if (!attr) {
+    MRL_TRY(set_lds_attr(ctx, k_pass_sub_mf<N, INV>, lds));
+    attr = true;
+  }
+  constexpr int T = Plan<N>::T;
+  if (a.tcols == 0) a.tcols = a.cols;
+  a.nb = (unsigned)(((long long)a.rows * a.tcols + T - 1) / T);
+  const long long nb = (long long)nf * a.nb;
+  if (a.sig.expected == 0) a.sig.expected = (unsigned)nb;
+  hipLaunchKernelGGL((k_pass_sub_mf<N, INV>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
 }  // namespace p2
 
 // every length with a Plan<N> that the fast paths are instantiated for

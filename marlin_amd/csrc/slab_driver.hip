@@ -42,9 +42,10 @@ struct FftPipe {
 };
 
 struct MechPipe {
-  bool built = false;
-  int transport = -1;
-  Xchg fwd[3], inv[3];  // one pair per tensor row
+  bool built = false, built_all = false;
+  int transport = -1, transport_all = -1;
+  Xchg fwd[3], inv[3];     // row pipeline: one pair per tensor row
+  Xchg fwd_all, inv_all;   // all rows per launch: one pair of nine-field exchanges
 };
 
 struct SlabPipes {
@@ -91,6 +92,8 @@ void slab_pipes_destroy(mrl_ctx *ctx) {
       xchg_destroy(ctx->comm, &ctx->pipes->mech.fwd[r]);
       xchg_destroy(ctx->comm, &ctx->pipes->mech.inv[r]);
     }
+    xchg_destroy(ctx->comm, &ctx->pipes->mech.fwd_all);
+    xchg_destroy(ctx->comm, &ctx->pipes->mech.inv_all);
   }
   delete ctx->pipes;
   ctx->pipes = nullptr;
@@ -364,6 +367,42 @@ int gamma_z_fwd_tangent_launch(mrl_ctx *ctx, const double *F, const double *K, c
                                const double *S, int i_num, int i_den, cplx *spec, long long npts, long long rows, int nz, bool nt,
                                double *x, int i_arz, int i_apAp);
 
+// peer stores: the producing kernels are the exchange, so nothing is gained by splitting them per row and much is lost (launches of
+// half a wave of workgroups at the rank-local sizes of BASELINE configs[4]); copies (copy engines, RCCL) overlap with the next
+// row's transforms in the row pipeline.  MRL_OPT_EXPERIMENT bits 16384 / 32768 force the row pipeline / the batched form.
+static bool mech_batched(const mrl_ctx *ctx) {
+  if (!slab_gamma_batched_ok(ctx) || (ctx->exp & 16384) || ctx->comm->kernel_signals) return false;
+  if (ctx->exp & 32768) return true;
+  return xchg_direct(ctx->comm) && (ctx->comm->ipc_ok || ctx->comm->nranks == 1);
+}
+
+static int mech_pipe_build_all(mrl_ctx *ctx) {
+  MechPipe &P = ctx->pipes->mech;
+  mrl_comm *c = ctx->comm;
+  const int R = ctx->nranks;
+  if (!P.built_all) {
+    std::vector<int64_t> sc(R), rc(R);
+    std::vector<size_t> sb(R), rb(R);
+    MRL_TRY(mrl_slab_gamma_counts(ctx, 1, sc.data(), rc.data()));
+    for (int p = 0; p < R; ++p) {
+      sb[p] = 3 * sizeof(cplx) * (size_t)sc[p];
+      rb[p] = 3 * sizeof(cplx) * (size_t)rc[p];
+    }
+    MRL_COMM(ctx, xchg_create(c, &P.fwd_all, sb.data(), rb.data(), false));
+    MRL_COMM(ctx, xchg_create(c, &P.inv_all, rb.data(), sb.data(), false));
+    P.built_all = true;
+  } else if (P.transport_all != c->transport) {
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MRL_COMM(ctx, comm_barrier(c));
+  }
+  if (P.transport_all != c->transport) {
+    MRL_TRY(prepare_table(ctx, &P.fwd_all, true));
+    MRL_TRY(prepare_table(ctx, &P.inv_all, true));
+    P.transport_all = c->transport;
+  }
+  return MRL_OK;
+}
+
 static int mech_pipe_build(mrl_ctx *ctx) {
   MechPipe &P = ctx->pipes->mech;
   mrl_comm *c = ctx->comm;
@@ -403,10 +442,31 @@ static int mech_pipe_build(mrl_ctx *ctx) {
 // the previous application, which the peer sent after its y pass had read the forward buffer (and symmetrically).
 int slab_gamma_fm(mrl_ctx *ctx, const double *A_fm, double *out_fm, double scale, const double *dotv_fm, double *d_dot) {
   MRL_TRY(need_comm(ctx, "slab Gamma operator"));
-  MRL_TRY(mech_pipe_build(ctx));
-  MechPipe &P = ctx->pipes->mech;
   mrl_comm *c = ctx->comm;
   hipStream_t st = ctx->stream;
+  c->kernel_signals = (ctx->exp & 128) != 0;
+  if (mech_batched(ctx)) {  // one launch per stage over all nine fields
+    MRL_TRY(mech_pipe_build_all(ctx));
+    MechPipe &P = ctx->pipes->mech;
+    MRL_COMM(ctx, xchg_begin(c, &P.fwd_all, st));
+    MRL_TRY(slab_gamma_rows_fwd(ctx, A_fm, reinterpret_cast<cplx *const *>(P.fwd_all.d_tab), SignalArgs{}));
+    MRL_COMM(ctx, xchg_post(c, &P.fwd_all, st, false));
+    MRL_COMM(ctx, xchg_wait(c, &P.fwd_all, st));
+    MRL_COMM(ctx, xchg_begin(c, &P.inv_all, st));
+    MRL_TRY(slab_gamma_rows_mid(ctx, static_cast<const double *>(P.fwd_all.recv.local), reinterpret_cast<cplx *const *>(P.inv_all.d_tab), SignalArgs{},
+                                scale));
+    MRL_COMM(ctx, xchg_post(c, &P.inv_all, st, false));
+    MRL_COMM(ctx, xchg_wait(c, &P.inv_all, st));
+    ctx->gamma_dot_nb = 0;
+    MRL_TRY(slab_gamma_rows_inv(ctx, static_cast<const double *>(P.inv_all.recv.local), out_fm, dotv_fm));
+    if (dotv_fm) {
+      MRL_TRY(reduce_finalize_from(ctx, ctx->d_work[3], ctx->gamma_dot_nb, d_dot));
+      ctx->gamma_dot_nb = 0;
+    }
+    return MRL_OK;
+  }
+  MRL_TRY(mech_pipe_build(ctx));
+  MechPipe &P = ctx->pipes->mech;
   for (int r = 0; r < 3; ++r) {
     MRL_COMM(ctx, xchg_begin(c, &P.fwd[r], st));
     const SignalArgs sig = xchg_signal_args(c, &P.fwd[r], 0);

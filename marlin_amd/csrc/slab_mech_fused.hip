@@ -47,12 +47,16 @@ struct GammaYArgs {
   int nxl, nzc;
   int nyl_shift;      // log2(ny / P)
   unsigned chunk;     // nxl * nyl * nzc: elements of one field of one chunk
-  int tiles_per_x;
+  int nf;             // fields per chunk: 3 (one tensor row per exchange) or 9 (all rows in one exchange, f = 3 row + component)
+  unsigned rowblk;    // workgroups per tensor row (gridDim = rows * rowblk)
   const double *kx, *ky, *kz;  // local reciprocal axes (kx already offset to this rank's x range)
   double scale;
 };
 
-template <int N>
+// AL: TPL | ny/P (the usual case), so the chunk index and the row within the chunk of point j = q + m TPL split into a wave-uniform
+// part that depends on m only and q: every load / store is "uniform 64-bit base + one per-thread 32-bit offset" (the general form keeps
+// 16 per-thread offsets and a per-element table load alive across the six transforms and spilled 47-96 VGPRs)
+template <int N, bool AL>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_yfused(GammaYArgs a, const cplx *__restrict__ tw) {
 #pragma clang fp contract(off)
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T, NT = Plan<N>::NT, CNT = (N + NT - 1) / NT;
@@ -63,11 +67,15 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_yfused(GammaYArgs a, c
   cplx *X = W + N;
   double *KY = reinterpret_cast<double *>(X + Map::size);
   const int l = threadIdx.x % T, q = threadIdx.x / T;
-  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int ix = logical / a.tiles_per_x;
-  const int kl0 = (logical % a.tiles_per_x) * T + l;
-  const bool valid = kl0 < a.nzc;
-  const int kl = valid ? kl0 : 0;
+  unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned trow = logical / a.rowblk;  // tensor row of this workgroup (0 when every row has its own exchange)
+  logical -= trow * a.rowblk;
+  // tiles run over the flattened (x, kz) index: with one tile row per x, the last tile of a row held nzc mod T lines (1 of 32 at
+  // 128^3, 1 of 16 at 256^3 -- 10 to 30 % of the lanes idle)
+  const unsigned li = logical * T + l;
+  const bool valid = li < (unsigned)(a.nxl * a.nzc);
+  const int ix = valid ? (int)(li / (unsigned)a.nzc) : 0;
+  const int kl = valid ? (int)(li - (unsigned)ix * (unsigned)a.nzc) : 0;
   cplx twv[CNT];
   double kyv[CNT];
 #pragma unroll
@@ -79,14 +87,17 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_yfused(GammaYArgs a, c
   const double kx = a.kx[ix], kz = a.kz[kl];
   // element (f, ix, j, kl): (j >> sh) * 3*chunk + f*chunk + ((ix << sh) + (j & msk)) * nzc + kl     [byte offsets]
   const int sh = a.nyl_shift, msk = (1 << sh) - 1;
-  const unsigned chB = a.chunk * 16u, rowB = (unsigned)a.nzc * 16u, klB = (unsigned)kl * 16u;
+  const unsigned chB = a.chunk * 16u, rowB = (unsigned)a.nzc * 16u, klB = (unsigned)kl * 16u + 3u * trow * chB;
+  const unsigned peerB = (unsigned)a.nf * chB;
+  const unsigned tb = (unsigned)((ix << sh) + (AL ? q : 0)) * rowB + klB;  // per-thread part
   auto off = [=](int m) {
+    if (AL) return (unsigned)((m * TPL) >> sh) * peerB + (unsigned)((m * TPL) & msk) * rowB;  // wave-uniform
     const int j = q + m * TPL;
-    return (unsigned)(j >> sh) * (3u * chB) + (unsigned)((ix << sh) + (j & msk)) * rowB + klB;
+    return (unsigned)(j >> sh) * peerB + (unsigned)(j & msk) * rowB;
   };
   cplx *const *otab = a.otab;
   auto ld = [=](unsigned f, int m) {
-    return *reinterpret_cast<const cplx *>(reinterpret_cast<const char *>(a.buf) + f * chB + off(m));
+    return *reinterpret_cast<const cplx *>(reinterpret_cast<const char *>(a.buf) + (size_t)(f * chB + off(m)) + tb);
   };
   cplx v0[P], v1[P];
 #pragma unroll
@@ -138,9 +149,8 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_yfused(GammaYArgs a, c
     if (valid) {
 #pragma unroll
       for (int m = 0; m < P; ++m) {
-        const int jj = q + m * TPL;
-        *reinterpret_cast<cplx *>(reinterpret_cast<char *>(otab[jj >> sh]) + (unsigned)j * chB + (unsigned)((ix << sh) + (jj & msk)) * rowB + klB) =
-            cswap(v0[m]);
+        const int jj = AL ? m * TPL : q + m * TPL;
+        *reinterpret_cast<cplx *>(reinterpret_cast<char *>(otab[jj >> sh]) + (size_t)((unsigned)j * chB + (unsigned)(jj & msk) * rowB) + tb) = cswap(v0[m]);
       }
     }
   }
@@ -152,14 +162,18 @@ static int launch_gamma_yfused(mrl_ctx *ctx, GammaYArgs a) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
   if (!attr) {
-    MRL_TRY(set_lds_attr(ctx, k_gamma_yfused<N>, lds));
+    MRL_TRY((set_lds_attr(ctx, k_gamma_yfused<N, true>, lds)));
+    MRL_TRY((set_lds_attr(ctx, k_gamma_yfused<N, false>, lds)));
     attr = true;
   }
   constexpr int T = Plan<N>::T;
-  a.tiles_per_x = (a.nzc + T - 1) / T;
-  const long long nb = (long long)a.nxl * a.tiles_per_x;
+  a.rowblk = (unsigned)(((long long)a.nxl * a.nzc + T - 1) / T);
+  const long long nb = (long long)(a.nf / 3) * a.rowblk;
   a.sig.expected = (unsigned)nb;
-  hipLaunchKernelGGL((k_gamma_yfused<N>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[1].d_tw);
+  if ((1 << a.nyl_shift) % Plan<N>::TPL == 0)
+    hipLaunchKernelGGL((k_gamma_yfused<N, true>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[1].d_tw);
+  else
+    hipLaunchKernelGGL((k_gamma_yfused<N, false>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[1].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
@@ -237,6 +251,7 @@ int slab_gamma_row_mid(mrl_ctx *ctx, const double *recv, cplx *const *otab, cons
   a.sig = sig;
   a.nxl = (int)nxl;
   a.nzc = (int)nzc;
+  a.nf = 3;
   a.nyl_shift = ilog2(nyl);
   a.chunk = (unsigned)(nxl * nyl * nzc);
   a.kx = ctx->d_k[0];
@@ -286,6 +301,111 @@ int slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *d_recv, double *d_ou
   MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_dot<NN>(ctx, w, d_out_fm + 3 * row * nreal, scale, 3 * nx * nyl / 2,
                                                        d_dotv_fm + 3 * row * nreal, ctx->d_work[3] + at, &nb))));
   ctx->gamma_dot_nb = nb;
+  return MRL_OK;
+}
+
+// ---- all three tensor rows per launch (one exchange of nine fields per direction) ---------------------------------------------
+// The row pipeline above overlaps the exchange of row r with the transforms of row r + 1, which pays when the exchange is a copy
+// (copy engines, RCCL).  With peer stores the producing kernels ARE the exchange, and at the rank-local sizes of BASELINE
+// configs[4] (256^3 over 8 GPUs: 17 MB per field) a one-row launch is half a wave of workgroups (258 on 512 slots): the
+// one-rank 128^3 job spent 541 us per CG iteration in 33 such launches where the serial solver needs 274 us in 4.  Here the
+// nine fields go through ONE launch per stage; chunk layout [p][9 fields][x][y][nzc], f = 3 row + component.
+bool slab_gamma_batched_ok(const mrl_ctx *ctx) {
+  const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2];
+  return 9.0 * 16.0 * (double)(nxl * ny * nzc) < 4294967296.0;  // 32-bit byte offsets within the nine-field exchange buffers
+}
+
+static int rows_work(mrl_ctx *ctx, int slot, cplx **w) {
+  const size_t bytes = sizeof(cplx) * (size_t)(9 * ctx->n[0] * ctx->nloc[1] * ctx->nrec[2]);
+  MRL_TRY(ensure_work(ctx, slot, bytes));
+  *w = reinterpret_cast<cplx *>(ctx->d_work[slot]);
+  return MRL_OK;
+}
+
+int slab_gamma_rows_fwd(mrl_ctx *ctx, const double *d_A_fm, cplx *const *otab, const SignalArgs &sig) {
+  if (!d_A_fm && !ctx->gamma_z_ready)
+    return set_error(ctx, MRL_ERR_INVALID, "slab Gamma operator: no input field and no spectra from the fused tangent / z pass");
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
+  const long long nreal = nx * nyl * nz, nspec = nx * nyl * nzc;
+  cplx *w;
+  if (d_A_fm) {
+    MRL_TRY(rows_work(ctx, 16, &w));
+    ProfScope ps(ctx, "slab_gamma_z_fwd", 9.0 * (8.0 * nreal + 16.0 * nspec));
+    p2::ChDev none{};
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, d_A_fm, w, nullptr, nullptr, none, 9 * nx * nyl / 2))));
+  } else {
+    w = reinterpret_cast<cplx *>(ctx->d_work[18]);  // z spectra of the nine fields left by slab_gamma_tangent_z
+    ctx->gamma_z_ready = false;
+  }
+  p2::SubPassArgs a{};
+  a.rows = (int)nyl;
+  a.cols = (int)nzc;
+  a.pitch_in = a.pitch_out = (unsigned)nzc;
+  a.sn_in = a.sn_out = (unsigned)(nyl * nzc);
+  a.sh_in = 31;
+  a.sh_out = ilog2(nxl);
+  a.otab = otab;
+  a.fs_out = (unsigned)(nxl * nyl * nzc);
+  a.fdense = (unsigned)nspec;
+  a.sig = sig;
+  a.in[0] = w;
+  ProfScope ps(ctx, "slab_gamma_x_fwd", 9.0 * 32.0 * nspec);
+  MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub_mf<NN, false>(ctx, a, ctx->ax[0].d_tw, 9))));
+  return MRL_OK;
+}
+
+int slab_gamma_rows_mid(mrl_ctx *ctx, const double *recv, cplx *const *otab, const SignalArgs &sig, double scale) {
+  const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2], nyl = ny / ctx->nranks;
+  p2::GammaYArgs a{};
+  a.buf = reinterpret_cast<const cplx *>(recv);
+  a.otab = otab;
+  a.sig = sig;
+  a.nxl = (int)nxl;
+  a.nzc = (int)nzc;
+  a.nf = 9;
+  a.nyl_shift = ilog2(nyl);
+  a.chunk = (unsigned)(nxl * nyl * nzc);
+  a.kx = ctx->d_k[0];
+  a.ky = ctx->d_k[1];
+  a.kz = ctx->d_k[2];
+  a.scale = scale;
+  ProfScope ps(ctx, "slab_gamma_y_fused", 9.0 * 32.0 * nxl * ny * nzc);
+  MRL_SWITCH_N(ny, MRL_TRY((p2::launch_gamma_yfused<NN>(ctx, a))));
+  return MRL_OK;
+}
+
+int slab_gamma_rows_inv(mrl_ctx *ctx, const double *d_recv, double *d_out_fm, const double *d_dotv_fm) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nz = ctx->n[2], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
+  const long long nreal = nx * nyl * nz, nspec = nx * nyl * nzc;
+  cplx *w;
+  MRL_TRY(rows_work(ctx, 17, &w));
+  {
+    p2::SubPassArgs a{};
+    a.rows = (int)nyl;
+    a.cols = (int)nzc;
+    a.pitch_in = a.pitch_out = (unsigned)nzc;
+    a.sn_in = a.sn_out = (unsigned)(nyl * nzc);
+    a.sh_in = ilog2(nxl);
+    a.fs_out = (unsigned)(nxl * nyl * nzc);
+    a.cs_in = 9u * a.fs_out;
+    a.sh_out = 31;
+    a.fdense = (unsigned)nspec;
+    a.in[0] = reinterpret_cast<const cplx *>(d_recv);
+    a.out[0] = w;
+    ProfScope ps(ctx, "slab_gamma_x_inv", 9.0 * 32.0 * nspec);
+    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub_mf<NN, true>(ctx, a, ctx->ax[0].d_tw, 9))));
+  }
+  ProfScope ps(ctx, "slab_gamma_z_inv", 9.0 * (16.0 * nspec + 8.0 * nreal) + (d_dotv_fm ? 9.0 * 8.0 * nreal : 0.0));
+  const double scale = 1.0 / ((double)nx * (double)ctx->n[1] * (double)nz);
+  if (!d_dotv_fm) {
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w, d_out_fm, scale, 9 * nx * nyl / 2))));
+    return MRL_OK;
+  }
+  const long long max_blocks = 9 * nx * nyl / 2;
+  MRL_TRY(ensure_work(ctx, 3, sizeof(double) * (size_t)max_blocks));
+  int nb = 0;
+  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_dot<NN>(ctx, w, d_out_fm, scale, 9 * nx * nyl / 2, d_dotv_fm, ctx->d_work[3], &nb))));
+  ctx->gamma_dot_nb = nb;  // all rows: the caller finalises nb partials
   return MRL_OK;
 }
 

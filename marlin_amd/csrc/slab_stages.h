@@ -38,6 +38,11 @@ int slab_inv_finish(mrl_ctx *ctx, const double *recv, double *real_out);
 int slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *A_fm, cplx *const *otab, const SignalArgs &sig);
 int slab_gamma_row_mid(mrl_ctx *ctx, const double *recv, cplx *const *otab, const SignalArgs &sig, double scale);
 int slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *recv, double *out_fm, const double *dotv_fm);
+// all three rows per launch, nine-field exchange layout [p][9][x][y][nzc] (slab_mech_fused.hip)
+bool slab_gamma_batched_ok(const mrl_ctx *ctx);
+int slab_gamma_rows_fwd(mrl_ctx *ctx, const double *A_fm, cplx *const *otab, const SignalArgs &sig);
+int slab_gamma_rows_mid(mrl_ctx *ctx, const double *recv, cplx *const *otab, const SignalArgs &sig, double scale);
+int slab_gamma_rows_inv(mrl_ctx *ctx, const double *recv, double *out_fm, const double *dotv_fm);
 
 
 // library-owned exchanges (slab_driver.hip; need an attached communicator)

@@ -2,7 +2,8 @@
 """de Geus RVE benchmark (BASELINE.json configs[2]): 3-D n^3, cubic inclusion
 phase[-s:, :s, -s:] = 1 with s = 9n/32 (test/src/tensor_computes/PhaseMechanicsTest.C:36-45), K = 0.833/8.33,
 mu = 0.386/3.86 (examples/degeus_mechanics/mech.i:23-38), shear ramp, l_tol = 1e-2, nl tolerances 2e-2.
-Reports time per CG iteration and the per-kernel device times.   usage: mech_bench.py [n] [substeps]"""
+Reports time per CG iteration and the per-kernel device times.   usage: mech_bench.py [n] [substeps] [slab 0|1] [experiment mask]
+slab = 1: the same solve as a ONE-rank slab job through the library's row pipeline (communicator, flags, exchange tables)."""
 import json
 import os
 import sys
@@ -11,12 +12,19 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from marlin_amd.api import Context  # noqa: E402
+from marlin_amd.api import Comm, Context  # noqa: E402
 
 
-def run(n=128, substeps=2, profile=True):
+def run(n=128, substeps=2, profile=True, slab=False, exp=0):
     L = 2.0 * torch.pi
-    ctx = Context(3, [n, n, n], [L, L, L])
+    if slab:
+        comm = Comm(f"mrl_mechbench_{os.getpid()}", 1, 0, device=0)
+        ctx = Context(3, [n, n, n], [L, L, L], nranks=1, rank=0, slab=True)
+        ctx.attach_comm(comm)
+    else:
+        ctx = Context(3, [n, n, n], [L, L, L])
+    if exp:
+        ctx.set_option(0, exp)
     s = 9 * n // 32
     phase = torch.zeros(n, n, n, dtype=torch.float64)
     phase[-s:, :s, -s:] = 1.0
@@ -47,7 +55,7 @@ def run(n=128, substeps=2, profile=True):
     # 2*9*B_fft(n) + 232 + 504 bytes per point per CG iteration
     h = 8.0 * (1.0 + 2.0 / n)
     bpi = 2 * 9 * (8.0 + 5.0 * h) + 232 + 504
-    out = {"n": n, "substeps": substeps, "newton_its": [r[2] for r in res], "cg_its": [r[1] for r in res],
+    out = {"n": n, "substeps": substeps, "slab_one_rank": slab, "exp": exp, "newton_its": [r[2] for r in res], "cg_its": [r[1] for r in res],
            "ms_per_cg_iteration": tot_t / max(tot_its, 1) * 1e3,
            "algorithmic_bytes_per_point_per_cg_iteration": bpi,
            "achieved_GBps": bpi * npts * tot_its / tot_t / 1e9,
@@ -61,7 +69,9 @@ def run(n=128, substeps=2, profile=True):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     substeps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    print(json.dumps(run(n, substeps)))
+    slab = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
+    exp = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    print(json.dumps(run(n, substeps, slab=slab, exp=exp)))
 
 
 if __name__ == "__main__":
