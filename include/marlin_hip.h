@@ -40,7 +40,8 @@ enum mrl_status {
   MRL_ERR_HIP = -3,          /* HIP runtime failure */
   MRL_ERR_NOMEM = -4,
   MRL_ERR_NOT_CONVERGED = -5, /* nl_max_its exceeded (FFTMechanics.C:159-161) */
-  MRL_ERR_COMM = -6           /* multi-GPU transport failure (a peer did not arrive in time, bootstrap / IPC / RCCL error) */
+  MRL_ERR_COMM = -6,          /* multi-GPU transport failure (a peer did not arrive in time, bootstrap / IPC / RCCL error) */
+  MRL_ERR_IO = -7             /* file output failed (mrl_h5_*) */
 };
 
 enum mrl_spectrum {
@@ -480,6 +481,22 @@ int mrl_timer_stop(mrl_ctx *ctx, float *h_ms); /* records, synchronises, returns
 int mrl_set_profiling(mrl_ctx *ctx, int on);
 int mrl_get_profile(mrl_ctx *ctx, int slot, const char **name, double *total_ms, int64_t *launches,
                     double *bytes_per_launch /* algorithmic HBM bytes of one launch */);
+
+/* ---- HDF5 container of XDMFTensorOutput (src/tensor_outputs/XDMFTensorOutput.C with enable_hdf5 = true) -- host code, no GPU ----
+ * The reference stores every output component as a dataset "<name>.<frame>" in the root group of "<file_base>[.rankNNNN].h5"
+ * through libhdf5: H5Fcreate (XDMFTensorOutput.C:152-160), addDataToHDF5 = H5Screate_simple + H5Dcreate + H5Dwrite
+ * (:578-650, called from :323-343), H5Fflush per output step (:244-246), H5Fclose (:113-115).  The image has no libhdf5, so
+ * these four entry points write the same container directly from the HDF5 file format specification (h5write.hip); the files
+ * are ordinary HDF5 (h5dump / h5py / the reference's HDF5Diff tester read them).  dims are the dataset's dimensions, slowest
+ * first, as H5Screate_simple takes them; host_data is dense row-major.  A dataset name that already exists is an error, as
+ * in the reference (:593-594). */
+typedef struct mrl_h5 mrl_h5;
+enum { MRL_H5_F64 = 0, MRL_H5_F32 = 1, MRL_H5_I32 = 2, MRL_H5_I64 = 3 };   /* the types XDMFTensorOutput.C:331-341 accepts */
+int mrl_h5_create(const char *path, mrl_h5 **out);   /* truncates; the empty file is already a valid HDF5 file */
+int mrl_h5_write(mrl_h5 *file, const char *name, int dtype, int rank, const int64_t *dims, const void *host_data);
+int mrl_h5_flush(mrl_h5 *file);                      /* the file on disk is valid and complete up to the last dataset */
+int mrl_h5_close(mrl_h5 *file);
+const char *mrl_h5_last_error(const mrl_h5 *file);
 
 #ifdef __cplusplus
 }

@@ -520,3 +520,44 @@ class ParsedCompute:
                 self.h = None
         except Exception:
             pass
+
+
+class H5File:
+    """HDF5 container of XDMFTensorOutput (mrl_h5_*: host code, no GPU needed): datasets "<name>.<frame>" in the root group."""
+
+    _DTYPES = {"float64": 0, "float32": 1, "int32": 2, "int64": 3}
+
+    def __init__(self, path: str):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        rc = self._lib.mrl_h5_create(str(path).encode(), C.byref(self._h))
+        if rc != 0:
+            raise MarlinHipError(rc, f"cannot create {path}")
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MarlinHipError(rc, self._lib.mrl_h5_last_error(self._h).decode())
+
+    def write(self, name: str, array):
+        import numpy as np
+        a = np.ascontiguousarray(array)
+        if a.dtype.name not in self._DTYPES:
+            raise ValueError(f"unsupported dtype {a.dtype}")
+        dims = (C.c_int64 * a.ndim)(*a.shape)
+        self._check(self._lib.mrl_h5_write(self._h, name.encode(), self._DTYPES[a.dtype.name], a.ndim, dims, a.ctypes.data_as(C.c_void_p)))
+
+    def flush(self):
+        self._check(self._lib.mrl_h5_flush(self._h))
+
+    def close(self):
+        if self._h:
+            rc = self._lib.mrl_h5_close(self._h)
+            self._h = C.c_void_p()
+            if rc != 0:
+                raise MarlinHipError(rc, "closing the HDF5 file failed")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

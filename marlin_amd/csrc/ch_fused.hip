@@ -82,7 +82,12 @@ static int launch_xfused_v(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
   return MRL_OK;
 }
 
-template <int N, int ORDER, bool SPEC_C, int PRE = Plan<N>::P / 2>
+// prefetch depth of the first-order history: half a line for the two-stage plans; the three-stage plans (512 points and more) hold
+// more twiddle / index state across the transforms and spill 7-14 VGPRs with that (tools/spill_census.sh)
+#ifndef MRL_XFUSED_PRE3_DIV
+#define MRL_XFUSED_PRE3_DIV 4
+#endif
+template <int N, int ORDER, bool SPEC_C, int PRE = (Plan<N>::ns >= 3 ? Plan<N>::P / MRL_XFUSED_PRE3_DIV : Plan<N>::P / 2)>
 static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
   if (16.0 * (double)N * (double)a.inner >= 4294967296.0) {   // one array is 4 GiB or more: 64-bit uniform part of the offsets
     if constexpr (big_capable<N>() && !SPEC_C) {

@@ -18,6 +18,9 @@
 #ifndef MRL_GAMMA_PRE
 #define MRL_GAMMA_PRE 8
 #endif
+#ifndef MRL_GAMMA_PRE_BIG  // lines of 256 points and more (12-44 spilled VGPRs with 8)
+#define MRL_GAMMA_PRE_BIG 4
+#endif
 #ifndef MRL_GAMMA_JUNROLL
 #define MRL_GAMMA_JUNROLL 1
 #endif
@@ -40,7 +43,7 @@ template <int N>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_xfused(GammaArgs a, const cplx *__restrict__ tw) {
 #pragma clang fp contract(off)
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T;
-  constexpr int GPRE = MRL_GAMMA_PRE < P ? MRL_GAMMA_PRE : P;
+  constexpr int GPRE0 = N >= 256 ? MRL_GAMMA_PRE_BIG : MRL_GAMMA_PRE, GPRE = GPRE0 < P ? GPRE0 : P;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);

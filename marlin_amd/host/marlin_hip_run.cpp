@@ -184,6 +184,7 @@ static int run_cahnhilliard(DomainAction & domain, const std::string & out)
       XDMFTensorOutput::Params op;
       op.buffer = {"c", "mu"};
       op.file_base = out + "/" + arg("file_base", "cahnhilliard_out");
+      op.enable_hdf5 = arg("enable_hdf5", "false") == "true";   // XDMFTensorOutput.C:39
       xdmf = std::make_unique<XDMFTensorOutput>(problem, op);
     }
     const auto t0 = std::chrono::steady_clock::now();

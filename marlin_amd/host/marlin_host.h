@@ -2056,6 +2056,7 @@ public:
     std::vector<int> components;           ///< values per grid point of each buffer (1 = scalar); empty = all scalar
     std::string file_base = "out";
     bool transpose = true;
+    bool enable_hdf5 = false;              ///< one "<file_base>[.rankNNNN].h5" with datasets "<name>.<frame>" instead of raw files
   };
   XDMFTensorOutput(TensorProblem & problem, const Params & p) : _problem(problem), _domain(problem.domain()), _p(p)
   {
@@ -2072,12 +2073,16 @@ public:
     for (auto & st : _staging)
       if (hipHostMalloc(reinterpret_cast<void **>(&st), sizeof(double) * total) != hipSuccess)
         mooseError("XDMFTensorOutput: pinned staging allocation failed");
+    if (_p.enable_hdf5 && mrl_h5_create(hdf5FileName(_domain.rank()).c_str(), &_h5) != MRL_OK)   // XDMFTensorOutput.C:152-160
+      mooseError("Error opening HDF5 file '" + hdf5FileName(_domain.rank()) + "'.");
     if (_domain.rank() == 0)
       writeXMF();   // skeleton (valid XDMF with zero frames)
   }
   ~XDMFTensorOutput()
   {
     waitForCompletion();
+    if (_h5)
+      (void)mrl_h5_close(_h5);                                                                      // XDMFTensorOutput.C:113-115
     for (auto & st : _staging)
       (void)hipHostFree(st);
     (void)hipEventDestroy(_ready[0]);
@@ -2135,6 +2140,13 @@ private:
     std::snprintf(buf, sizeof buf, ".rank%04d", _domain.rank());
     return buf;
   }
+  std::string hdf5FileName(int rank) const
+  {
+    char buf[32] = "";
+    if (_domain.isSlab())
+      std::snprintf(buf, sizeof buf, ".rank%04d", rank);
+    return _p.file_base + buf + ".h5";
+  }
   std::string binaryFileName(const std::string & setname, int rank) const
   {
     char buf[32] = "";
@@ -2185,6 +2197,19 @@ private:
           for (std::size_t e = 0; e < cells; ++e)
             slice[e] = src[e * comps + c];
         const std::string setname = componentName(_p.buffer[b], comps, c) + "." + std::to_string(frame);
+        if (_h5)
+        {
+          // addDataToHDF5 (XDMFTensorOutput.C:323-343): dims = the spatial sizes of the (transposed) buffer
+          int64_t dims[3];
+          for (int i = 0; i < dim; ++i)
+            dims[i] = _p.transpose ? ls[dim - 1 - i] : ls[i];
+          if (mrl_h5_write(_h5, setname.c_str(), MRL_H5_F64, dim, dims, slice.data()) != MRL_OK)
+          {
+            _error = std::string("XDMFTensorOutput: ") + mrl_h5_last_error(_h5);
+            return;
+          }
+          continue;
+        }
         std::ofstream f(binaryFileName(setname, _domain.rank()), std::ios::binary);
         if (!f || !f.write(reinterpret_cast<const char *>(slice.data()), sizeof(double) * cells))
         {
@@ -2193,6 +2218,11 @@ private:
         }
       }
       off += cells * comps;
+    }
+    if (_h5 && mrl_h5_flush(_h5) != MRL_OK)                                                        // XDMFTensorOutput.C:244-246
+    {
+      _error = std::string("XDMFTensorOutput: ") + mrl_h5_last_error(_h5);
+      return;
     }
     if (_domain.rank() == 0)
       writeXMF();
@@ -2279,12 +2309,16 @@ private:
       for (int c = 0; c < _p.components[b]; ++c)
       {
         const std::string name = componentName(_p.buffer[b], _p.components[b], c);
-        std::string file = binaryFileName(name + "." + std::to_string(frame), rank);
+        std::string file = _p.enable_hdf5 ? hdf5FileName(rank) : binaryFileName(name + "." + std::to_string(frame), rank);
         const auto slash = file.find_last_of('/');
         if (slash != std::string::npos)
           file = file.substr(slash + 1);   // relative to the .xmf file
-        x << "     <Attribute Name=\"" << name << "\" Center=\"Cell\">\n      <DataItem DataType=\"Float\" Dimensions=\"" << dims
-          << "\" Format=\"Binary\" Endian=\"Little\" Precision=\"8\">" << file << "</DataItem>\n     </Attribute>\n";
+        if (_p.enable_hdf5)   // XDMFTensorOutput.C:408-412
+          x << "     <Attribute Name=\"" << name << "\" Center=\"Cell\">\n      <DataItem DataType=\"Float\" Dimensions=\"" << dims
+            << "\" Format=\"HDF\">" << file << ":/" << name << "." << frame << "</DataItem>\n     </Attribute>\n";
+        else
+          x << "     <Attribute Name=\"" << name << "\" Center=\"Cell\">\n      <DataItem DataType=\"Float\" Dimensions=\"" << dims
+            << "\" Format=\"Binary\" Endian=\"Little\" Precision=\"8\">" << file << "</DataItem>\n     </Attribute>\n";
       }
   }
 
@@ -2300,6 +2334,7 @@ private:
   std::string _error;
   int _frame = 0;
   double _seconds_writing = 0.0;
+  mrl_h5 * _h5 = nullptr;
 };
 
 class Transient

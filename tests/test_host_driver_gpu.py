@@ -159,6 +159,58 @@ def test_xdmf_tensor_output_async(slab, tmp_path):
     assert len(items) == 10 * 2 * (2 if slab else 1) and all((tmp_path / t).exists() for t in items)
 
 
+@pytest.mark.parametrize("slab", [False, True])
+def test_xdmf_tensor_output_hdf5(slab, tmp_path):
+    """the same run with enable_hdf5 = true (XDMFTensorOutput.C:39, 152-160, 323-343, 244-246): one <base>[.rankNNNN].h5 per rank with
+    the datasets "c.<frame>" / "mu.<frame>" in its root group, written by the library's own HDF5 container writer (mrl_h5_*; the image
+    has no libhdf5) from the asynchronous output thread.  Read back with an independent reader of the file format
+    (tests/h5_subset_reader.py) and, where the image has it, with h5dump: dataset names, shapes ([y][x]: transposed, as the reference
+    writes for Paraview) and values == gold c.(frame + 1) to 1e-13 -- what the reference's HDF5Diff tester checks"""
+    import shutil
+    import subprocess
+    import xml.etree.ElementTree as ET
+
+    from tests.h5_subset_reader import read_h5
+    if slab:
+        import torch
+        g = load_golden("cahnhilliard_rank0001_gold.npz")
+        torch.manual_seed(0)
+        blk = (torch.rand(20, 10, dtype=torch.float64) * (0.56 - 0.44) + 0.44).numpy()
+        c0 = np.concatenate([blk, blk], axis=1)
+        extra = ["parallel_mode=FFT_SLAB", "nranks=2", "device=0"]
+    else:
+        g = load_golden("cahnhilliard_gold.npz")
+        c0 = g["c.0"][:20, :20]
+        extra = []
+    ic = tmp_path / "c0.bin"
+    c0.astype("<f8").tofile(ic)
+    out = _run(["problem=cahnhilliard", "dim=2", "nx=20", "ny=20", "xmax=3", "ymax=3", f"ic={ic}", "substeps=10", "num_steps=10", "dt=1e-3",
+                "predictor_order=2", "mobility=0.2", "kappa=-0.001", "output=xdmf", "enable_hdf5=true", "file_base=ch"] + extra, tmp_path)
+    assert '"frames": 10' in out
+    name = "ch.rank0001.h5" if slab else "ch.h5"
+    sets = read_h5(tmp_path / name)
+    assert sorted(sets) == sorted([f"c.{k}" for k in range(10)] + [f"mu.{k}" for k in range(10)])
+    h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if os.path.exists("/opt/conda/bin/h5dump") else None)
+    worst = 0.0
+    for frame in range(10):
+        c = sets[f"c.{frame}"]
+        assert c.shape == ((10, 20) if slab else (20, 20)) and c.dtype == np.dtype("<f8")
+        ref = g[f"c.{frame + 1}"] if slab else g[f"c.{frame + 1}"][:20, :20]
+        worst = max(worst, np.abs(ref - c.T).max())
+        if h5dump:
+            raw = tmp_path / f"c.{frame}.raw"
+            subprocess.run([h5dump, "-d", f"/c.{frame}", "-b", "LE", "-o", str(raw), str(tmp_path / name)], check=True, capture_output=True)
+            assert np.array_equal(np.fromfile(raw, dtype="<f8").reshape(c.shape), c)
+    assert worst <= 1e-13, worst
+    if not slab:
+        assert np.abs(g["mu.10"] - sets["mu.9"].T).max() <= 1e-13
+    root = ET.parse(tmp_path / "ch.xmf").getroot()
+    items = [d.text for d in root.iter("DataItem") if d.get("Format") == "HDF"]
+    assert len(items) == 10 * 2 * (2 if slab else 1)
+    assert all(t.split(":/")[0] in ("ch.h5", "ch.rank0000.h5", "ch.rank0001.h5") and (tmp_path / t.split(":/")[0]).exists() for t in items)
+    assert not list(tmp_path.glob("ch*.bin"))
+
+
 def test_mechanics_case_fft_slab(tmp_path):
     """mech3d.i (test/tests/mechanics/tests:2-21) on 2 rank processes: the C++ FFTMechanics object over mrl_mech_newton_cg on slab
     contexts; F_k.frame and sV of mech3d.h5 to 1e-10"""
