@@ -103,6 +103,17 @@ def test_native_slab_mechanics_fused_vs_oracle(P, shape, transport):
     assert max(r["max_err"] for r in res) <= 1e-10, res
 
 
+def test_native_slab_mechanics_config_e_at_size():
+    """BASELINE configs[4] at its size: the de Geus RVE on 256^3 (inclusion of bench.py --workload mech) over 4 rank processes -- 256 x
+    64 x 256 per rank, the all-rows-per-launch Gamma pipeline over one nine-field exchange (peer stores), CG scalars all-reduced on the
+    device -- against the serial HIP solver on the whole grid (oracle-checked at 128^3 in tests/test_fullsize_gpu.py; the oracle needs
+    minutes per solve here): identical Newton / CG iteration counts on every rank, F to 1e-10"""
+    res = run_job(4, "mech", "shape=256,256,256", "transport=1", "ref=hip", timeout=900)
+    assert all(r["traces_ok"] for r in res), res
+    assert max(r["max_err"] for r in res) <= 1e-10, res
+    assert sum(res[0]["cg_its_last"]) >= 20, res
+
+
 @pytest.mark.parametrize("P,carry", [(4, 0), (2, 1)])
 def test_native_bench_configuration_equals_serial(P, carry):
     """the configuration `bench.py --gpus P` runs per rank with the native driver (grid_for(P, 256): 512 x 512 x 256 on 4 ranks, the
