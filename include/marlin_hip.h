@@ -365,7 +365,7 @@ int mrl_slab_gamma_project(mrl_ctx *ctx, double *d_spec, double scale);
  *   [exchange, inverse: send = that buffer]                                             -> recv2 [p][3][x_p ][y_me][nzc]
  *   mrl_slab_gamma_row_inv(r, recv2, out_fm) inverse x + z passes, 1/N                -> fields 3r..3r+2 of out_fm
  * mrl_slab_gamma_counts: complex elements per peer of one row's message (forward / inverse direction). */
-int mrl_slab_fast_path(const mrl_ctx *ctx); /* 1 if the fused slab kernels (CH pipeline fast path, mrl_slab_gamma_row_*) apply to this context */
+int mrl_slab_fast_path(const mrl_ctx *ctx); /* 1 if the fused slab mechanics kernels (mrl_slab_gamma_row_*, 32-bit byte offsets per row buffer) apply to this context */
 int mrl_slab_gamma_counts(const mrl_ctx *ctx, int forward, int64_t *h_send_counts, int64_t *h_recv_counts);
 int mrl_slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *d_A_fm, double *d_send);
 int mrl_slab_gamma_row_mid(mrl_ctx *ctx, double *d_recv_inout, double scale);

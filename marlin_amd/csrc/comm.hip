@@ -1,6 +1,11 @@
 // Multi-GPU transport: one process per GPU on one node (see comm.h for the design).
 // Replaces the host-staged MPI transposes of DomainAction::fftSlab / ifftSlab (src/actions/DomainAction.C:869-1019).
 #include "comm.h"
+#include <thread>
+#include <mutex>
+#include <memory>
+#include <condition_variable>
+#include "mrl_trace.h"
 
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -118,6 +123,43 @@ int comm_allreduce_host(mrl_comm *c, double *v, int n, int op) {
 }
 
 // ---- symmetric device memory ------------------------------------------------------------------------------------------
+// hipIpcOpenMemHandle under a watchdog.  With two rank processes on one GPU and exchange buffers of 4.4 + 2.2 GB the call was seen
+// never to return for the second buffer (reproducibly inside this library, not in tools/ipc_probe.hip with the same sizes; cause not
+// found).  A transport must not hang its caller: the mapping runs in a helper thread, and a call that outlives the communicator's
+// time-out is reported as a failed mapping (the helper thread is abandoned; the verdict is collective like every other).
+static bool ipc_open_bounded(mrl_comm *c, hipIpcMemHandle_t handle, void **mapped) {
+  struct Job {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    hipError_t err = hipSuccess;
+    void *ptr = nullptr;
+  };
+  auto job = std::make_shared<Job>();
+  const int device = c->device;
+  std::thread([job, handle, device]() {
+    void *m = nullptr;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipIpcOpenMemHandle(&m, handle, hipIpcMemLazyEnablePeerAccess);
+    std::lock_guard<std::mutex> lk(job->mu);
+    job->err = e;
+    job->ptr = m;
+    job->done = true;
+    job->cv.notify_all();
+  }).detach();
+  std::unique_lock<std::mutex> lk(job->mu);
+  if (!job->cv.wait_for(lk, std::chrono::duration<double>(c->timeout_s), [&] { return job->done; })) {
+    comm_error(c, MRL_ERR_COMM, "hipIpcOpenMemHandle did not return within %.0f s (rank %d)", c->timeout_s, c->rank);
+    return false;
+  }
+  if (job->err != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  *mapped = job->ptr;
+  return true;
+}
+
 int sym_alloc(mrl_comm *c, size_t bytes, SymBuf *out, bool uncached) {
   out->bytes = bytes;
   // attempt 0: uncached (fine-grained) device memory for flag words; attempt 1: plain hipMalloc.  The verdict of an attempt is
@@ -125,13 +167,16 @@ int sym_alloc(mrl_comm *c, size_t bytes, SymBuf *out, bool uncached) {
   for (int attempt = uncached ? 0 : 1; attempt < 2; ++attempt) {
     out->peer.assign(c->nranks, nullptr);
     void *p = nullptr;
+    MRL_TRACE("sym_alloc: %zu bytes, attempt %d", bytes, attempt);
     hipError_t e = attempt == 0 ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) : hipMalloc(&p, bytes);
     int ok = e == hipSuccess ? 1 : 0;
     if (!ok) {
       (void)hipGetLastError();
       p = nullptr;
     }
+    MRL_TRACE("sym_alloc: allocated (%d), clearing", ok);
     if (ok && (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) ok = 0;
+    MRL_TRACE("sym_alloc: cleared (%d)", ok);
     out->local = p;
     out->peer[c->rank] = p;
     if (c->nranks == 1) {
@@ -159,16 +204,25 @@ int sym_alloc(mrl_comm *c, size_t bytes, SymBuf *out, bool uncached) {
     COMM_TRY(comm_allreduce_host(c, &v, 1, 1));
     if (v != 0.0) {
       COMM_TRY(comm_allgather(c, &mine, sizeof(mine), all));
-      for (int q = 0; q < c->nranks && ok; ++q) {
-        if (q == c->rank) continue;
-        void *m = nullptr;
-        if (hipIpcOpenMemHandle(&m, all[q], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
-          (void)hipGetLastError();
-          ok = 0;
-          break;
+      MRL_TRACE("sym_alloc: handles exchanged, mapping the peers");
+      // one rank at a time: with dmabuf IPC the importer obtains the buffer from the exporting PROCESS, and two ranks that map each
+      // other's multi-GB buffers at the same moment were seen to block each other for good inside hipIpcOpenMemHandle (512 x 1024 x
+      // 1024 on two ranks: the second exchange buffer never came back); small buffers never showed it.  P barriers per buffer, once.
+      for (int turn = 0; turn < c->nranks; ++turn) {
+        if (turn == c->rank) {
+          for (int q = 0; q < c->nranks && ok; ++q) {
+            if (q == c->rank) continue;
+            void *m = nullptr;
+            if (!ipc_open_bounded(c, all[q], &m)) {
+              ok = 0;
+              break;
+            }
+            out->peer[q] = m;
+          }
         }
-        out->peer[q] = m;
+        COMM_TRY(comm_barrier(c));
       }
+      MRL_TRACE("sym_alloc: mapped (%d)", ok);
       v = ok ? 1.0 : 0.0;  // every rank must agree on whether the mapping worked
       COMM_TRY(comm_allreduce_host(c, &v, 1, 1));
       if (v != 0.0) return MRL_OK;

@@ -7,6 +7,8 @@
 
 #include "mrl_internal.h"
 
+int g_mrl_trace = 0;
+
 namespace mrl {
 
 thread_local std::string g_create_error;
@@ -378,7 +380,10 @@ int mrl_sync(mrl_ctx *ctx) {
 int mrl_ctx_set_option(mrl_ctx *ctx, int option, int64_t value) {
   if (!ctx) return MRL_ERR_INVALID;
   switch (option) {
-    case MRL_OPT_EXPERIMENT: ctx->exp = (int)value; return MRL_OK;
+    case MRL_OPT_EXPERIMENT:
+      ctx->exp = (int)value;
+      g_mrl_trace = (value & (1 << 20)) ? 1 : 0;
+      return MRL_OK;
     case MRL_OPT_SLAB_NSUB:
       if (value < 1 || value > 64) return set_error(ctx, MRL_ERR_INVALID, "MRL_OPT_SLAB_NSUB must be in 1..64");
       ctx->opt_nsub = (int)value;

@@ -1,5 +1,6 @@
 // Internal declarations shared by the host planner and the HIP kernels (gfx950 only).
 #pragma once
+#include "mrl_trace.h"
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>

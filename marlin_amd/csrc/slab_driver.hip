@@ -152,8 +152,11 @@ static int ch_pipe_build(mrl_ctx *ctx) {
       return MRL_OK;
     };
     for (int s = 0; s < nsub; ++s) {
+      MRL_TRACE("ch_pipe_build: creating the forward exchange of sub-block %d", s);
       MRL_TRY(make(&P.fwd2[s], s, 1, MRL_CARRY_NONE));
+      MRL_TRACE("ch_pipe_build: creating the inverse exchange of sub-block %d", s);
       MRL_TRY(make(&P.inv[s], s, 0, MRL_CARRY_NONE));
+      MRL_TRACE("ch_pipe_build: exchanges of sub-block %d created", s);
       if (carry) MRL_TRY(make(&P.fwd1[s], s, 1, MRL_CARRY_IN));
     }
     if (carry) {
@@ -169,6 +172,7 @@ static int ch_pipe_build(mrl_ctx *ctx) {
     MRL_TRY(prepare_table(ctx, &P.inv[s], P.fast && !local_only));
     if (carry) MRL_TRY(prepare_table(ctx, &P.fwd1[s], P.fast && !local_only));
   }
+  MRL_TRACE("ch_pipe_build: tables ready");
   P.local_only = local_only;
   P.nsub = nsub;
   P.carry = carry;
@@ -207,6 +211,7 @@ int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, d
   for (int k = 0; k < count; ++k) {
     const int mode = !P.carry ? MRL_CARRY_NONE : (k == 0 ? MRL_CARRY_OUT : MRL_CARRY_IN);
     double *mu_k = (k == count - 1) ? mu : nullptr;
+    MRL_TRACE("substep %d: z pass", k);
     if (k == 0) {
       MRL_TRY(mrl_slab_ch_z_fwd(ctx, p, c_in, mu_k, mode));
     } else {
@@ -221,6 +226,7 @@ int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, d
       long long k0, ks;
       MRL_TRY(slab_sub_range(ctx, s, nsub, &k0, &ks));
       MRL_COMM(ctx, xchg_begin(c, &F[s], st));
+      MRL_TRACE("substep %d: forward x pass (fast %d)", k, (int)P.fast);
       if (P.fast) {
         const SignalArgs sig = xchg_signal_args(c, &F[s], 0);
         MRL_TRY(slab_ch_x_fwd_fast(ctx, (int)k0, (int)ks, reinterpret_cast<cplx *const *>(F[s].d_tab), sig, mode));
@@ -233,6 +239,7 @@ int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, d
     for (int s = 0; s < nsub; ++s) {
       long long k0, ks;
       MRL_TRY(slab_sub_range(ctx, s, nsub, &k0, &ks));
+      MRL_TRACE("substep %d: wait F, y pass", k);
       MRL_TRY(wait(ctx, &F[s], lo));
       MRL_COMM(ctx, xchg_begin(c, &P.inv[s], st));
       const double *recv = static_cast<const double *>(F[s].recv.local);
@@ -247,6 +254,7 @@ int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, d
       }
     }
     for (int s = 0; s < nsub; ++s) {
+      MRL_TRACE("substep %d: wait I, inverse x pass", k);
       MRL_TRY(wait(ctx, &P.inv[s], lo));
       MRL_TRY(mrl_slab_ch_x_inv(ctx, s, nsub, static_cast<const double *>(P.inv[s].recv.local)));
     }

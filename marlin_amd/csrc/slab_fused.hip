@@ -41,8 +41,12 @@ struct YFusedArgs {
   SignalArgs sig;     // arrival flags raised by the last workgroup (direct peer stores), or none
 };
 
-template <int N, int ORDER, bool SPEC_C, bool ALIGNED>
+// BIG (with ALIGNED): exchange buffers or rank-local spectral arrays of 4 GiB and more (1024^3 on 2 or 4 GPUs: 4.3 / 2.2 GB per array,
+// two fields per forward buffer).  The chunk index, the x plane and the row group of element j = q + m TPL are wave-uniform: they
+// go into a 64-bit scalar part of the offset, the per-thread part (q rows + kz) stays 32-bit -- same access form, same registers.
+template <int N, int ORDER, bool SPEC_C, bool ALIGNED, bool BIG = false>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, const cplx *__restrict__ tw) {
+  static_assert(!BIG || ALIGNED, "the 64-bit variant needs wave-uniform chunk offsets");
   constexpr int TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,38 +80,74 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
     const int j = q0 + m * TPL;
     stc(utab[j >> sh], (unsigned)((ix << sh) + (j & msk)) * ksB + tq, val);
   };
-  const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + a.k0 + kl) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
-  auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
   // default cache policy for every stream: on the sub-block-sized working sets of the slab pipeline the non-temporal accesses of
   // the serial kernel cost 8-30 % (measured per variant with tools/slab_local_bench.py 8 256)
-  ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, stu, W, X, KY);
+  if constexpr (BIG) {
+    const unsigned long long ks64 = (unsigned long long)a.kp * 16ull, ch64 = (unsigned long long)a.chunk * 16ull;
+    const unsigned long long x64 = ((unsigned long long)ix << sh) * ks64;
+    auto offf64 = [=](int m) {
+      const int j = m * TPL;
+      return BigOff{(unsigned long long)(j >> sh) * (SPEC_C ? ch64 : 2ull * ch64) + x64 + (unsigned long long)(j & msk) * ks64, tq};
+    };
+    auto stu64 = [=](int m, cplx val) {
+      const int j = m * TPL;
+      stc(utab[j >> sh], BigOff{x64 + (unsigned long long)(j & msk) * ks64, tq}, val);
+    };
+    const unsigned long long dx64 = (unsigned long long)ix * N * (unsigned long long)a.nzc * 16ull, dstep64 = (unsigned long long)(TPL * a.nzc) * 16ull;
+    const unsigned dl = (unsigned)(q * a.nzc + a.k0 + kl) * 16u;
+    auto offd64 = [=](int m) { return BigOff{dx64 + (unsigned long long)m * dstep64, dl}; };
+    ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf64, offd64, stu64, W, X, KY);
+  } else {
+    const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + a.k0 + kl) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
+    auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
+    ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, stu, W, X, KY);
+  }
   signal_tail(a.sig);
 }
 
-template <int N, int ORDER, bool SPEC_C, bool ALIGNED>
+template <int N, int ORDER, bool SPEC_C, bool ALIGNED, bool BIG = false>
 static int launch_yfused_v(mrl_ctx *ctx, YFusedArgs a) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
   if (!attr) {
-    MRL_TRY((set_lds_attr(ctx, k_ch_yfused<N, ORDER, SPEC_C, ALIGNED>, lds)));
+    MRL_TRY((set_lds_attr(ctx, k_ch_yfused<N, ORDER, SPEC_C, ALIGNED, BIG>, lds)));
     attr = true;
   }
   constexpr int T = Plan<N>::T;
   a.tiles_per_x = (a.ksub + T - 1) / T;
   const long long nb = (long long)a.nxl * a.tiles_per_x;
   a.sig.expected = (unsigned)nb;
-  hipLaunchKernelGGL((k_ch_yfused<N, ORDER, SPEC_C, ALIGNED>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a,
+  hipLaunchKernelGGL((k_ch_yfused<N, ORDER, SPEC_C, ALIGNED, BIG>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a,
                      ctx->ax[1].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
 
+// y lengths for which the 64-bit variant is instantiated (long enough for >= 4 GiB exchange buffers at realistic shapes)
+template <int N>
+constexpr bool ybig_capable() {
+  return N == 512 || N == 1024 || N == 2048;
+}
+
+// true when the byte offsets inside the forward exchange buffer (two fields) or a rank-local spectral array exceed 32 bits
+static bool yfused_needs_big(const YFusedArgs &a, int nranks) {
+  const double fwd = 2.0 * 16.0 * (double)a.chunk * nranks, dense = 16.0 * (double)a.nxl * (double)((1LL << a.nyl_shift) * nranks) * (double)a.nzc;
+  return fwd >= 4294967296.0 || dense >= 4294967296.0;
+}
+
 template <int N, int ORDER, bool SPEC_C>
 static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
   constexpr int TPL = Plan<N>::TPL;
+  const bool big = yfused_needs_big(a, ctx->nranks);
   if constexpr ((TPL & (TPL - 1)) == 0) {  // (ny/P is a power of two: a multiple of TPL iff TPL is one and not larger)
-    if ((1 << a.nyl_shift) % TPL == 0) return launch_yfused_v<N, ORDER, SPEC_C, true>(ctx, a);
+    if ((1 << a.nyl_shift) % TPL == 0) {
+      if constexpr (ybig_capable<N>()) {
+        if (big) return launch_yfused_v<N, ORDER, SPEC_C, true, true>(ctx, a);
+      }
+      if (!big) return launch_yfused_v<N, ORDER, SPEC_C, true>(ctx, a);
+    }
   }
+  if (big) return set_error(ctx, MRL_ERR_UNSUPPORTED, "slab y pass: arrays of 4 GiB and more need ny in {512, 1024, 2048} and ny/P a multiple of %d", TPL);
   return launch_yfused_v<N, ORDER, SPEC_C, false>(ctx, a);
 }
 
@@ -117,14 +157,26 @@ int slab_fast_ok(const mrl_ctx *ctx) {
   if (!(ctx->dim == 3 && ctx->slab && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
         pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2])))
     return 0;
-  // 32-bit byte offsets within an exchange buffer (two fields in the CH pipeline, the three of a tensor row in the mechanics one)
-  if (48.0 * (double)ctx->n[0] * (double)ctx->nloc[1] * (double)(ctx->nrec[2] + 8) >= 4294967296.0) return 0;
   // equal power-of-two partitions: chunk addressing by shifts
   const long long nyl = ctx->n[1] / ctx->nranks, nxl = ctx->n[0] / ctx->nranks;
   if (nyl * ctx->nranks != ctx->n[1] || nxl * ctx->nranks != ctx->n[0] || (nyl & (nyl - 1)) || (nxl & (nxl - 1))) return 0;
   for (int p = 0; p < ctx->nranks; ++p)
     if (ctx->part_real[p] != nyl || ctx->part_recip[p] != nxl) return 0;
+  // the x passes index with 32-bit ELEMENT offsets inside a two-field exchange buffer: arrays below 32 GiB
+  const double count = (double)ctx->n[0] * (double)ctx->nloc[1] * (double)(ctx->nrec[2] + 8);
+  if (2.0 * count >= 4294967296.0) return 0;
+  // the y pass uses 32-bit BYTE offsets up to 4 GiB per two-field buffer; beyond that its 64-bit variant, which exists for
+  // ny in {512, 1024, 2048} with ny/P a multiple of the threads per line
+  if (32.0 * count >= 4294967296.0) {
+    const long long ny = ctx->n[1];
+    if (!(ny == 512 || ny == 1024 || ny == 2048) || nyl % (ny / 16) != 0) return 0;
+  }
   return 1;
+}
+
+// the mechanics row pipelines keep 32-bit byte offsets throughout (three fields of a tensor row per exchange buffer)
+int slab_mech_fast_ok(const mrl_ctx *ctx) {
+  return slab_fast_ok(ctx) && 48.0 * (double)ctx->n[0] * (double)ctx->nloc[1] * (double)(ctx->nrec[2] + 8) < 4294967296.0;
 }
 
 // Row pitch (complex elements) of the exchange layouts of a kz sub-block of width ksub: rows start on 128-byte lines, so the x

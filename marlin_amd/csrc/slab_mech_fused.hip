@@ -34,7 +34,7 @@ int gamma_z_fwd_tangent_launch(mrl_ctx *ctx, const double *F, const double *K, c
 
 namespace mrl {
 
-int slab_fast_ok(const mrl_ctx *ctx);
+int slab_mech_fast_ok(const mrl_ctx *ctx);
 int reduce_finalize_from(mrl_ctx *ctx, const double *partial, int nb, double *d_scalar);
 
 namespace p2 {
@@ -196,7 +196,7 @@ static int row_work(mrl_ctx *ctx, int slot, cplx **w) {
 }
 
 static int check_fast(mrl_ctx *ctx, const char *what, int row) {
-  if (!slab_fast_ok(ctx))
+  if (!slab_mech_fast_ok(ctx))
     return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: needs a 3-D slab context with planned extents and equal power-of-two partitions", what);
   if (ctx->nloc[1] % 2) return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: needs an even number of local y planes", what);
   if (row < 0 || row > 2) return set_error(ctx, MRL_ERR_INVALID, "%s: row %d out of range", what, row);
@@ -415,7 +415,7 @@ using namespace mrl;
 
 extern "C" {
 
-int mrl_slab_fast_path(const mrl_ctx *ctx) { return ctx && slab_fast_ok(ctx) && ctx->nloc[1] % 2 == 0 ? 1 : 0; }
+int mrl_slab_fast_path(const mrl_ctx *ctx) { return ctx && slab_mech_fast_ok(ctx) && ctx->nloc[1] % 2 == 0 ? 1 : 0; }
 
 int mrl_slab_gamma_counts(const mrl_ctx *ctx, int forward, int64_t *h_send_counts, int64_t *h_recv_counts) {
   if (!ctx) return MRL_ERR_INVALID;

@@ -103,38 +103,57 @@ def run_chbench(job, P, r, kv):
     in this process: `steps` substeps in one call, this rank's slab to 1e-13"""
     from bench import grid_for, splitmix64_uniform
     from marlin_amd import api
+    import time
+    t_start = time.time()
+
+    def mark(what):
+        print(f"[rank {r} +{time.time() - t_start:6.1f}s] {what}", file=sys.stderr, flush=True)
+
     n = int(kv.get("n", 256))
     steps = int(kv.get("steps", 4))
-    shape = grid_for(P, n)
+    shape = [int(x) for x in kv["shape"].split(",")] if "shape" in kv else grid_for(P, n)
     dx = 8.0 * math.pi / 200.0
     L = [s * dx for s in shape]
     npts = shape[0] * shape[1] * shape[2]
-    c0 = torch.from_numpy(splitmix64_uniform(npts).reshape(shape))
+    if kv.get("ic", "splitmix") == "rand":   # big grids: the same seeded device generator in every rank process (same device, same stream of numbers)
+        torch.manual_seed(1234)
+        c0 = torch.rand(shape, dtype=torch.float64, device="cuda") * 0.12 + 0.44
+    else:
+        c0 = torch.from_numpy(splitmix64_uniform(npts).reshape(shape))
+    mass0 = float(c0.sum(dtype=torch.float64).item())
     p = api.ch_params()
     serial = api.Context(3, shape, L, device=0)
     want = torch.empty(shape, dtype=torch.float64, device="cuda")
     ring = [serial.empty_spec(), serial.empty_spec()]
     serial.ch_substeps(p, c0.cuda(), want, ring, 1, 0, 2, steps, True, 1e-3)
     serial.sync()
+    mark("serial reference done")
     del ring
     serial.close()
     comm = api.Comm(job, P, r, device=0, transport=int(kv.get("transport", 0)), timeout=60.0)
+    mark("communicator up")
     ctx = api.Context(3, shape, L, nranks=P, rank=r, slab=True, device=0)
     ctx.attach_comm(comm)
     ctx.set_option(api.OPT_SLAB_NSUB, int(kv.get("nsub", 1)))
     ctx.set_option(api.OPT_SLAB_CARRY, int(kv.get("carry", 0)))
+    if "exp" in kv:
+        ctx.set_option(api.OPT_EXPERIMENT, int(kv["exp"]))
     yb, nyl = ctx.real_begin[1], ctx.real_shape[1]
     want = want[:, yb:yb + nyl].contiguous()
-    torch.cuda.empty_cache()
     c = c0[:, yb:yb + nyl].contiguous().cuda()
+    del c0
+    torch.cuda.empty_cache()
     out = torch.empty_like(c)
+    mark("slab solve enqueue")
     ctx.ch_substeps(p, c, out, ring_arrays(ctx, 2), 1, 0, 2, steps, True, 1e-3)
+    mark("slab solve enqueued")
     ctx.sync()
+    mark("slab solve done")
     err = (out - want).abs().max().item()
     mass = comm.allreduce([float(out.sum(dtype=torch.float64).item())])[0]
     ctx.close()
     comm.close()
-    return {"max_err": err, "mass_err": abs(mass - float(c0.sum(dtype=torch.float64).item())) / npts, "grid": shape}
+    return {"max_err": err, "mass_err": abs(mass - mass0) / npts, "grid": shape}
 
 
 def run_lost_peer(job, P, r, kv):

@@ -16,12 +16,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "slab_rank_worker.py")
 _counter = itertools.count()
+EXTRA_KV = [x for x in os.environ.get("MRL_TEST_EXTRA_KV", "").split() if x]   # debugging aid, e.g. exp=1048576 (host-side trace)
 
 
 def run_job(P, case, *kv, timeout=240):
     """start P rank processes, return their RESULT records in rank order; any failure shows every rank's stderr"""
     job = f"mrltest_{os.getpid()}_{next(_counter)}"
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if os.environ.get("MRL_TEST_HIP_LOG"):   # debugging aid: the HIP runtime's own call log in every rank's stderr
+        env["AMD_LOG_LEVEL"] = os.environ["MRL_TEST_HIP_LOG"]
     procs = [subprocess.Popen([sys.executable, WORKER, job, str(P), str(r), case, *kv], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                               text=True, env=env, cwd=ROOT) for r in range(P)]
     outs = []
@@ -32,7 +35,11 @@ def run_job(P, case, *kv, timeout=240):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-        raise
+        tails = []
+        for r, p in enumerate(procs):   # what every rank had printed when the job was stopped
+            so, se = p.communicate()
+            tails.append(f"--- rank {r} (rc {p.returncode}) ---\n{(se or '')[-1500:]}\n{(so or '')[-300:]}")
+        raise AssertionError(f"job {case} {kv} timed out after {timeout} s\n" + "\n".join(tails))
     finally:
         shm = f"/dev/shm/{job}"
         if os.path.exists(shm):
@@ -120,6 +127,18 @@ def test_native_bench_configuration_equals_serial(P, carry):
     bench's initial condition, one mrl_ch_substeps call) on P rank processes against the serial fused path on the same global grid:
     4 substeps, every rank's slab to 1e-13, total mass conserved"""
     res = run_job(P, "chbench", f"carry={carry}", timeout=600)
+    assert max(r["max_err"] for r in res) <= 1e-13, res
+    assert max(r["mass_err"] for r in res) <= 1e-12, res
+
+
+def test_native_slab_exchange_buffers_beyond_4_gib():
+    """rank-local arrays of 2.2 GB: the two-field forward exchange buffer (4.36 GB) is beyond 32-bit byte offsets, which sent such
+    grids (1024^3 on 2 or 4 GPUs) to the any-size stages.  The y pass's 64-bit variant keeps them on the fused pipeline: a one-rank
+    slab job (communicator, flags, exchange tables, peer-store kernels) against the serial fused path on the same grid (itself
+    oracle-checked at the sizes the oracle reaches), 2 substeps, to 1e-13, mass conserved.  (Two rank PROCESSES on one GPU with
+    buffers of this size: hipIpcOpenMemHandle of the second multi-GB buffer does not return on this pool -- DESIGN 4.1; the library
+    turns that into MRL_ERR_COMM after the communicator's time-out.)"""
+    res = run_job(1, "chbench", "shape=512,512,1024", "steps=2", "ic=rand", *EXTRA_KV, timeout=300)
     assert max(r["max_err"] for r in res) <= 1e-13, res
     assert max(r["mass_err"] for r in res) <= 1e-12, res
 

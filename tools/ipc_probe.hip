@@ -29,9 +29,10 @@
 static int g_rank = -1;
 
 struct Shared {
-  std::atomic<int> arrived[4];
+  std::atomic<int> arrived[8];
   hipIpcMemHandle_t buf[16];
   hipIpcMemHandle_t flag[16];
+  hipIpcMemHandle_t buf2[16];
 };
 
 __global__ void k_fill(double *dst, long long n, double base) {
@@ -68,6 +69,9 @@ static void barrier(Shared *sh, int slot, int n) {
   }
 }
 
+static long long g_second_mib = 0;  // argv[4]: a second symmetric buffer of this many MiB, mapped after the first
+static long long g_slot_doubles = 4 << 20;  // doubles per peer slot (32 MiB; argv[3] = MiB per slot)
+
 static int child(int rank, int nranks, int same_device, const char *shm_name) {
   g_rank = rank;
   int fd = shm_open(shm_name, O_RDWR, 0600);
@@ -77,7 +81,7 @@ static int child(int rank, int nranks, int same_device, const char *shm_name) {
   CK(hipGetDeviceCount(&ndev));
   const int dev = same_device ? 0 : rank % ndev;
   CK(hipSetDevice(dev));
-  const long long n = 4 << 20;  // doubles per peer slot (32 MiB)
+  const long long n = g_slot_doubles;
   double *buf = nullptr;
   unsigned long long *flag = nullptr;
   CK(hipMalloc(&buf, sizeof(double) * n * nranks));
@@ -88,12 +92,30 @@ static int child(int rank, int nranks, int same_device, const char *shm_name) {
   CK(hipIpcGetMemHandle(&sh->buf[rank], buf));
   CK(hipIpcGetMemHandle(&sh->flag[rank], flag));
   barrier(sh, 0, nranks);
+  fprintf(stderr, "[rank %d] buffer of %.2f GiB allocated, handles published\n", rank, sizeof(double) * (double)n * nranks / 1073741824.0);
   std::vector<double *> pbuf(nranks);
   std::vector<unsigned long long *> pflag(nranks);
   for (int p = 0; p < nranks; ++p) {
     if (p == rank) { pbuf[p] = buf; pflag[p] = flag; continue; }
     CK(hipIpcOpenMemHandle((void **)&pbuf[p], sh->buf[p], hipIpcMemLazyEnablePeerAccess));
     CK(hipIpcOpenMemHandle((void **)&pflag[p], sh->flag[p], hipIpcMemLazyEnablePeerAccess));
+  }
+  fprintf(stderr, "[rank %d] peer buffers mapped\n", rank);
+  if (g_second_mib > 0) {
+    void *b2 = nullptr;
+    CK(hipMalloc(&b2, (size_t)g_second_mib << 20));
+    CK(hipMemset(b2, 0, (size_t)g_second_mib << 20));
+    CK(hipDeviceSynchronize());
+    CK(hipIpcGetMemHandle(&sh->buf2[rank], b2));
+    barrier(sh, 4, nranks);
+    fprintf(stderr, "[rank %d] second buffer of %lld MiB published\n", rank, g_second_mib);
+    for (int p = 0; p < nranks; ++p) {
+      if (p == rank) continue;
+      void *m = nullptr;
+      CK(hipIpcOpenMemHandle(&m, sh->buf2[p], hipIpcMemLazyEnablePeerAccess));
+    }
+    fprintf(stderr, "[rank %d] second buffer mapped\n", rank);
+    barrier(sh, 5, nranks);
   }
   hipStream_t st;
   CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -171,6 +193,8 @@ int main(int argc, char **argv) {
   const char *r = getenv("MRL_PROBE_RANK");
   const int nranks = argc > 1 ? atoi(argv[1]) : 2;
   const int same = argc > 2 ? atoi(argv[2]) : 1;
+  if (argc > 3) g_slot_doubles = (long long)atoi(argv[3]) * (1 << 17);
+  if (argc > 4) g_second_mib = atoi(argv[4]);
   if (!r || !getenv("MRL_PROBE_SHM")) {
     fprintf(stderr, "run through tools/ipc_probe.sh\n");
     return 1;
