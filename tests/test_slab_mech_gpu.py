@@ -189,10 +189,11 @@ def _gamma_rank(r, P, comm, A, fast):
     return yb, nyl, out.cpu().reshape(list(st.real_shape) + [3, 3])
 
 
-@pytest.mark.parametrize("P", [2, 4, 8])
+@pytest.mark.parametrize("P", [2, 4, 8, 32])
 def test_slab_gamma_fused_rows(P):
     """the fused row pipeline (z+x passes -> exchange -> y pass with the projection in place -> exchange -> x+z passes) ==
-    the oracle's closed-form Gamma operator on the global field == the per-component generic stages"""
+    the oracle's closed-form Gamma operator on the global field == the per-component generic stages.  P = 32: two y planes per
+    rank, fewer than the four threads of a line -- the y pass without wave-uniform chunk offsets (k_gamma_yfused<64, false>)"""
     from oracle import marlin_oracle as mo
     torch.manual_seed(21)
     A = torch.rand(_FAST_SHAPE + [3, 3], dtype=torch.float64) - 0.5
