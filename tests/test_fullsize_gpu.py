@@ -2,6 +2,7 @@
 checker: size-independent properties (round trip, Parseval, linearity, conservation, self-adjointness) and cross-checks
 between independent HIP paths (fused substep vs the operator-by-operator sequence; slab pipeline vs the serial kernels)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -180,6 +181,48 @@ def test_headline_256_two_ab_substeps_vs_oracle():
     assert (a.cpu() - r1).abs().max().item() <= 1e-13
     ctx.ch_substep(p, a, b, ring[1], [ring[0]], 1, 1e-3)
     assert (b.cpu() - r2).abs().max().item() <= 1e-13
+
+
+def test_512_two_ab_substeps_vs_oracle_serial_and_slab_pipeline():
+    """the grid of BASELINE configs[3] (512^3) against the ORACLE: AB1 then AB2 substep from a seeded random field through (a) the
+    serial fused path (`k_ch_xfused<512>` and the other N = 512 kernels) and (b) the library's slab pipeline as a one-rank job
+    (communicator, flags, peer-store tables; the wide-plan x passes with both fields per launch and the fused 512-point y pass -- the
+    kernels every rank of the 8-GPU configuration runs); abs 1e-13"""
+    from marlin_amd.api import Comm, Context, ch_params
+    from oracle import marlin_oracle as mo
+    n = 512
+    dx = 8.0 * math.pi / 200.0
+    shape, L = [n, n, n], [n * dx] * 3
+    torch.manual_seed(512)
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    dom = mo.Domain(3, shape, L)
+    Mbar = mo.reciprocal_laplacian_factor(dom, 0.2)
+    Lbar = mo.reciprocal_laplacian_square_factor(dom, -0.001)
+    r1, N1, _, _ = mo.ch_substep_ops(c0, Mbar, Lbar, [], 1e-3, 0, mo.mu_double_well, dom)
+    r2, _, _, _ = mo.ch_substep_ops(r1, Mbar, Lbar, [N1], 1e-3, 1, mo.mu_double_well, dom)
+    del Mbar, Lbar, N1, r1
+    p = ch_params()
+    c = c0.cuda()
+    out = torch.empty_like(c)
+    ctx = Context(3, shape, L)
+    ring = [ctx.empty_spec(), ctx.empty_spec()]
+    ctx.ch_substeps(p, c, out, ring, 1, 0, 2, 2, True, 1e-3)
+    err_serial = (out.cpu() - r2).abs().max().item()
+    del ring
+    ctx.close()
+    torch.cuda.empty_cache()
+    comm = Comm(f"mrl_full512_{os.getpid()}", 1, 0, device=0)
+    sctx = Context(3, shape, L, nranks=1, rank=0, slab=True)
+    sctx.attach_comm(comm)
+    pitch = sctx.spec_pitch
+    sring = [torch.zeros(2 * n * n * pitch, dtype=torch.float64, device="cuda") for _ in range(2)]
+    out.zero_()
+    sctx.ch_substeps(p, c, out, sring, 1, 0, 2, 2, True, 1e-3)
+    sctx.sync()
+    err_slab = (out.cpu() - r2).abs().max().item()
+    sctx.close()
+    comm.close()
+    assert err_serial <= 1e-13 and err_slab <= 1e-13, (err_serial, err_slab)
 
 
 def test_config_c_128_newton_cg_vs_oracle():
