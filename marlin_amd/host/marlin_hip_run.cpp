@@ -185,6 +185,16 @@ static int run_cahnhilliard(DomainAction & domain, const std::string & out)
       op.buffer = {"c", "mu"};
       op.file_base = out + "/" + arg("file_base", "cahnhilliard_out");
       op.enable_hdf5 = arg("enable_hdf5", "false") == "true";   // XDMFTensorOutput.C:39
+      if (!arg("output_mode").empty())                             // e.g. output_mode=NODE,CELL (one entry per buffer: c, mu)
+      {
+        std::string m = arg("output_mode");
+        while (!m.empty())
+        {
+          const auto comma = m.find(',');
+          op.output_mode.push_back(m.substr(0, comma));
+          m = comma == std::string::npos ? "" : m.substr(comma + 1);
+        }
+      }
       xdmf = std::make_unique<XDMFTensorOutput>(problem, op);
     }
     const auto t0 = std::chrono::steady_clock::now();

@@ -2057,6 +2057,8 @@ public:
     std::string file_base = "out";
     bool transpose = true;
     bool enable_hdf5 = false;              ///< one "<file_base>[.rankNNNN].h5" with datasets "<name>.<frame>" instead of raw files
+    std::vector<std::string> output_mode;  ///< per buffer "CELL" (default) or "NODE" (XDMFTensorOutput.C:41-51): nodal data, every
+                                           ///< dimension extended by one with a copy of the slice at 0 (extendTensor, :530-557)
   };
   XDMFTensorOutput(TensorProblem & problem, const Params & p) : _problem(problem), _domain(problem.domain()), _p(p)
   {
@@ -2064,6 +2066,13 @@ public:
       _p.components.assign(_p.buffer.size(), 1);
     if (_p.components.size() != _p.buffer.size())
       paramError("components", "one entry per buffer");
+    if (_p.output_mode.empty())
+      _p.output_mode.assign(_p.buffer.size(), "CELL");
+    if (_p.output_mode.size() != _p.buffer.size())
+      paramError("output_mode", "Specify one output mode per buffer.");                             // XDMFTensorOutput.C:80-82
+    for (const auto & m : _p.output_mode)
+      if (m != "CELL" && m != "NODE")
+        paramError("output_mode", "CELL or NODE (OVERSIZED_NODAL is not supported by this mirror)");
     if (hipStreamCreateWithFlags(&_copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&_ready[0]) != hipSuccess ||
         hipEventCreate(&_ready[1]) != hipSuccess || hipEventCreate(&_solver_done) != hipSuccess)
       mooseError("XDMFTensorOutput: creating the copy stream failed");
@@ -2171,38 +2180,45 @@ private:
     const int dim = _domain.getDim();
     const int64_t n0 = ls[0], n1 = dim > 1 ? ls[1] : 1, n2 = dim > 2 ? ls[2] : 1;
     const std::size_t cells = (std::size_t)(n0 * n1 * n2);
-    std::vector<double> slice(cells);
+    std::vector<double> slice;
     std::size_t off = 0;
     for (std::size_t b = 0; b < _p.buffer.size(); ++b)
     {
       const int comps = _p.components[b];
+      // NODE: every dimension one longer, the extra slice is a copy of slice 0 (extendTensor); e = extents of what is written
+      const int64_t ex = _p.output_mode[b] == "NODE" ? 1 : 0;
+      const int64_t e0 = n0 + ex, e1 = dim > 1 ? n1 + ex : 1, e2 = dim > 2 ? n2 + ex : 1;
+      slice.resize((std::size_t)(e0 * e1 * e2));
       for (int c = 0; c < comps; ++c)
       {
         const double * src = stage + off;
+        auto at = [&](int64_t i, int64_t j, int64_t k) { return src[(std::size_t)((((i % n0) * n1 + (j % n1)) * n2 + (k % n2))) * comps + c]; };
         // component c of a value-major field, transposed x <-> last axis if requested
         if (dim == 3 && _p.transpose)
         {
-          for (int64_t k = 0; k < n2; ++k)
-            for (int64_t j = 0; j < n1; ++j)
-              for (int64_t i = 0; i < n0; ++i)
-                slice[(std::size_t)((k * n1 + j) * n0 + i)] = src[(std::size_t)(((i * n1 + j) * n2 + k)) * comps + c];
+          for (int64_t k = 0; k < e2; ++k)
+            for (int64_t j = 0; j < e1; ++j)
+              for (int64_t i = 0; i < e0; ++i)
+                slice[(std::size_t)((k * e1 + j) * e0 + i)] = at(i, j, k);
         }
         else if (dim == 2 && _p.transpose)
         {
-          for (int64_t j = 0; j < n1; ++j)
-            for (int64_t i = 0; i < n0; ++i)
-              slice[(std::size_t)(j * n0 + i)] = src[(std::size_t)(i * n1 + j) * comps + c];
+          for (int64_t j = 0; j < e1; ++j)
+            for (int64_t i = 0; i < e0; ++i)
+              slice[(std::size_t)(j * e0 + i)] = at(i, j, 0);
         }
         else
-          for (std::size_t e = 0; e < cells; ++e)
-            slice[e] = src[e * comps + c];
+          for (int64_t i = 0; i < e0; ++i)
+            for (int64_t j = 0; j < e1; ++j)
+              for (int64_t k = 0; k < e2; ++k)
+                slice[(std::size_t)((i * e1 + j) * e2 + k)] = at(i, j, k);
         const std::string setname = componentName(_p.buffer[b], comps, c) + "." + std::to_string(frame);
         if (_h5)
         {
           // addDataToHDF5 (XDMFTensorOutput.C:323-343): dims = the spatial sizes of the (transposed) buffer
           int64_t dims[3];
           for (int i = 0; i < dim; ++i)
-            dims[i] = _p.transpose ? ls[dim - 1 - i] : ls[i];
+            dims[i] = (_p.transpose ? ls[dim - 1 - i] : ls[i]) + ex;
           if (mrl_h5_write(_h5, setname.c_str(), MRL_H5_F64, dim, dims, slice.data()) != MRL_OK)
           {
             _error = std::string("XDMFTensorOutput: ") + mrl_h5_last_error(_h5);
@@ -2211,7 +2227,7 @@ private:
           continue;
         }
         std::ofstream f(binaryFileName(setname, _domain.rank()), std::ios::binary);
-        if (!f || !f.write(reinterpret_cast<const char *>(slice.data()), sizeof(double) * cells))
+        if (!f || !f.write(reinterpret_cast<const char *>(slice.data()), sizeof(double) * slice.size()))
         {
           _error = "XDMFTensorOutput: cannot write " + binaryFileName(setname, _domain.rank());
           return;
@@ -2266,7 +2282,7 @@ private:
       {
         x << "   <Grid Name=\"T" << f << "\" GridType=\"Uniform\">\n    <Time Value=\"" << _times[f] << "\"/>\n"
           << "    <xi:include xpointer=\"xpointer(//Xdmf/Domain/Topology)\"/>\n    <xi:include xpointer=\"xpointer(//Xdmf/Domain/Geometry)\"/>\n";
-        attributes(x, f, 0, cellsdim);
+        attributes(x, f, 0, cellsdim, nodes);
         x << "   </Grid>\n";
         continue;
       }
@@ -2293,7 +2309,7 @@ private:
         x << "    <Grid Name=\"Rank" << r << "\" GridType=\"Uniform\">\n     <Topology TopologyType=\"" << dim << "DCoRectMesh\" Dimensions=\"" << rn
           << "\"/>\n     <Geometry Type=\"" << geo << "\">\n      <DataItem Format=\"XML\" Dimensions=\"" << dim << "\">" << ro
           << "</DataItem>\n      <DataItem Format=\"XML\" Dimensions=\"" << dim << "\">" << spacing << "</DataItem>\n     </Geometry>\n";
-        attributes(x, f, r, rc);
+        attributes(x, f, r, rc, rn);
         x << "    </Grid>\n";
         ybeg += counts[r];
       }
@@ -2303,21 +2319,24 @@ private:
     std::ofstream f(_p.file_base + ".xmf");
     f << x.str();
   }
-  void attributes(std::ostringstream & x, int frame, int rank, const std::string & dims) const
+  void attributes(std::ostringstream & x, int frame, int rank, const std::string & celldims, const std::string & nodedims) const
   {
     for (std::size_t b = 0; b < _p.buffer.size(); ++b)
       for (int c = 0; c < _p.components[b]; ++c)
       {
+        const bool node = _p.output_mode[b] == "NODE";                      // XDMFTensorOutput.C:375-394
+        const std::string & dims = node ? nodedims : celldims;
+        const char * center = node ? "Node" : "Cell";
         const std::string name = componentName(_p.buffer[b], _p.components[b], c);
         std::string file = _p.enable_hdf5 ? hdf5FileName(rank) : binaryFileName(name + "." + std::to_string(frame), rank);
         const auto slash = file.find_last_of('/');
         if (slash != std::string::npos)
           file = file.substr(slash + 1);   // relative to the .xmf file
         if (_p.enable_hdf5)   // XDMFTensorOutput.C:408-412
-          x << "     <Attribute Name=\"" << name << "\" Center=\"Cell\">\n      <DataItem DataType=\"Float\" Dimensions=\"" << dims
+          x << "     <Attribute Name=\"" << name << "\" Center=\"" << center << "\">\n      <DataItem DataType=\"Float\" Dimensions=\"" << dims
             << "\" Format=\"HDF\">" << file << ":/" << name << "." << frame << "</DataItem>\n     </Attribute>\n";
         else
-          x << "     <Attribute Name=\"" << name << "\" Center=\"Cell\">\n      <DataItem DataType=\"Float\" Dimensions=\"" << dims
+          x << "     <Attribute Name=\"" << name << "\" Center=\"" << center << "\">\n      <DataItem DataType=\"Float\" Dimensions=\"" << dims
             << "\" Format=\"Binary\" Endian=\"Little\" Precision=\"8\">" << file << "</DataItem>\n     </Attribute>\n";
       }
   }

@@ -165,7 +165,9 @@ def test_xdmf_tensor_output_hdf5(slab, tmp_path):
     the datasets "c.<frame>" / "mu.<frame>" in its root group, written by the library's own HDF5 container writer (mrl_h5_*; the image
     has no libhdf5) from the asynchronous output thread.  Read back with an independent reader of the file format
     (tests/h5_subset_reader.py) and, where the image has it, with h5dump: dataset names, shapes ([y][x]: transposed, as the reference
-    writes for Paraview) and values == gold c.(frame + 1) to 1e-13 -- what the reference's HDF5Diff tester checks"""
+    writes for Paraview) and values == gold c.(frame + 1) to 1e-13 -- what the reference's HDF5Diff tester checks.  The serial case
+    writes c in NODE mode as cahnhilliard.i does (output_mode, extendTensor: XDMFTensorOutput.C:41-51, 530-557), so its datasets have
+    the gold file's own 21 x 21 shape and are compared whole"""
     import shutil
     import subprocess
     import xml.etree.ElementTree as ET
@@ -181,7 +183,7 @@ def test_xdmf_tensor_output_hdf5(slab, tmp_path):
     else:
         g = load_golden("cahnhilliard_gold.npz")
         c0 = g["c.0"][:20, :20]
-        extra = []
+        extra = ["output_mode=NODE,CELL"]     # cahnhilliard.i writes c as nodal data (21 x 21 with the periodic wrap), mu per cell
     ic = tmp_path / "c0.bin"
     c0.astype("<f8").tofile(ic)
     out = _run(["problem=cahnhilliard", "dim=2", "nx=20", "ny=20", "xmax=3", "ymax=3", f"ic={ic}", "substeps=10", "num_steps=10", "dt=1e-3",
@@ -194,8 +196,8 @@ def test_xdmf_tensor_output_hdf5(slab, tmp_path):
     worst = 0.0
     for frame in range(10):
         c = sets[f"c.{frame}"]
-        assert c.shape == ((10, 20) if slab else (20, 20)) and c.dtype == np.dtype("<f8")
-        ref = g[f"c.{frame + 1}"] if slab else g[f"c.{frame + 1}"][:20, :20]
+        assert c.shape == ((10, 20) if slab else (21, 21)) and c.dtype == np.dtype("<f8")
+        ref = g[f"c.{frame + 1}"]               # serial: the gold dataset as it is, including the wrapped row and column (NODE mode)
         worst = max(worst, np.abs(ref - c.T).max())
         if h5dump:
             raw = tmp_path / f"c.{frame}.raw"
@@ -207,6 +209,9 @@ def test_xdmf_tensor_output_hdf5(slab, tmp_path):
     root = ET.parse(tmp_path / "ch.xmf").getroot()
     items = [d.text for d in root.iter("DataItem") if d.get("Format") == "HDF"]
     assert len(items) == 10 * 2 * (2 if slab else 1)
+    if not slab:
+        centers = {a.get("Name"): a.get("Center") for a in root.iter("Attribute")}
+        assert centers == {"c": "Node", "mu": "Cell"}
     assert all(t.split(":/")[0] in ("ch.h5", "ch.rank0000.h5", "ch.rank0001.h5") and (tmp_path / t.split(":/")[0]).exists() for t in items)
     assert not list(tmp_path.glob("ch*.bin"))
 
