@@ -754,9 +754,13 @@ static int run_gradient(DomainAction & domain, const std::string & out)
     double vol = 1.0;
     for (int d = 0; d < domain.getDim(); ++d)
       vol *= domain.getExtent(d);
-    std::ofstream csv2(out + "/gradient_square.csv");
-    csv2.precision(17);
-    csv2 << "time,diff\n0,0\n1," << TensorPostprocessors::integral(domain, problem.getBuffer("diff"), vol) << "\n";
+    const double diff2 = TensorPostprocessors::integral(domain, problem.getBuffer("diff"), vol);   // (global on slab contexts)
+    if (domain.rank() == 0)
+    {
+      std::ofstream csv2(out + "/gradient_square.csv");
+      csv2.precision(17);
+      csv2 << "time,diff\n0,0\n1," << diff2 << "\n";
+    }
     return 0;
   }
   parsed("cx", "cos(x)", {}, true);
@@ -769,9 +773,13 @@ static int run_gradient(DomainAction & domain, const std::string & out)
   double volume = 1.0;
   for (int d = 0; d < domain.getDim(); ++d)
     volume *= domain.getExtent(d);
-  std::ofstream csv(out + "/gradient.csv");
-  csv.precision(17);
-  csv << "time,diff\n0,0\n1," << TensorPostprocessors::integral(domain, problem.getBuffer("diff"), volume) << "\n";
+  const double diff = TensorPostprocessors::integral(domain, problem.getBuffer("diff"), volume);      // (global on slab contexts)
+  if (domain.rank() == 0)
+  {
+    std::ofstream csv(out + "/gradient.csv");
+    csv.precision(17);
+    csv << "time,diff\n0,0\n1," << diff << "\n";
+  }
   return 0;
 }
 

@@ -75,7 +75,8 @@ def test_native_slab_ch_vs_oracle(P, shape, transport, nsub, carry):
         assert all(r["stats"]["exchanges"] > 0 and r["stats"]["bytes_sent"] > 0 for r in res)
 
 
-@pytest.mark.parametrize("P,shape,transport", [(2, "16,12,10", 1), (3, "9,7,5", 2), (4, "64,64,64", 1), (2, "16,12", 2)])
+@pytest.mark.parametrize("P,shape,transport", [(2, "16,12,10", 1), (3, "9,7,5", 2), (4, "64,64,64", 1), (2, "16,12", 2),
+                                               (3, "64,64,64", 1)])   # (test/tests/tensor_compute/parallel_roundtrip_3d.i: 64^3 on 3 ranks, 22 / 21 / 21 planes)
 def test_native_slab_fft(P, shape, transport):
     """DomainAction::fft / ifft in FFT_SLAB mode through mrl_fft_r2c / mrl_fft_c2r with the library-owned exchange (repeated
     forward transforms: the acknowledgement flags), and a global reduction"""
