@@ -198,6 +198,8 @@ static int run_cahnhilliard(DomainAction & domain, const std::string & out)
       xdmf = std::make_unique<XDMFTensorOutput>(problem, op);
     }
     const auto t0 = std::chrono::steady_clock::now();
+    if (xdmf && arg("output_initial", "false") == "true")   // execute_on = 'INITIAL TIMESTEP_END' (cahnhilliard.i): frame 0 = the initial condition
+      xdmf->startOutput();
     ex.execute((int)argi("num_steps", 1), [&](int) {
       if (xdmf)
         xdmf->startOutput();

@@ -9,6 +9,7 @@ IEEE f64 dumped by `h5dump -b LE`), plus the CSV gold tables of the solver tests
 Sources (relative to /root/reference):
   test/tests/cahnhilliard/gold/cahnhilliard.h5           spec test/tests/cahnhilliard/tests:46-57  (abs_tol 1e-13)
   test/tests/cahnhilliard/gold/cahnhilliard.rank0001.h5  spec test/tests/cahnhilliard/tests:58-70  (2-rank FFT_SLAB, rank 1)
+  test/tests/cahnhilliard/gold/cahnhilliard.xmf          spec test/tests/cahnhilliard/tests:35-45  (XMLDiff of the XDMF description; stored as a JSON tree)
   test/tests/mechanics/gold/mech3d.h5, mech.h5           spec test/tests/mechanics/tests:2-21      (abs_tol 1e-10)
   test/tests/tensor_compute/gold/rotating_grain_secant.h5 spec test/tests/tensor_compute/tests:90-100 (abs_tol 1e-10)
   test/tests/cahnhilliard/gold/map_to_aux_3d.e            spec test/tests/cahnhilliard/tests:13-22 (3-D 5^3 Cahn-Hilliard; Exodus)
@@ -29,6 +30,22 @@ import numpy as np
 REF = "/root/reference"
 H5DUMP = "/opt/conda/bin/h5dump"
 OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def xml_tree(path):
+    """an XML file as nested [tag, attributes, text, children] lists (what XMLDiff compares: structure, attributes, text)"""
+    import xml.etree.ElementTree as ET
+
+    def walk(e):
+        return [e.tag, dict(sorted(e.attrib.items())), (e.text or "").strip(), [walk(c) for c in e]]
+    return walk(ET.parse(path).getroot())
+
+
+def convert_xmf(rel, out):
+    import json
+    with open(os.path.join(OUT, out), "w") as f:
+        json.dump(xml_tree(os.path.join(REF, rel)), f, indent=0)
+    print("wrote", out)
 
 
 def h5_names(path):
@@ -103,6 +120,7 @@ def convert_csv(rels, out_name):
 
 def main():
     convert_h5("test/tests/cahnhilliard/gold/cahnhilliard.h5", "cahnhilliard_gold.npz")
+    convert_xmf("test/tests/cahnhilliard/gold/cahnhilliard.xmf", "cahnhilliard_xmf_gold.json")   # spec tests:35-45 (XMLDiff)
     convert_h5("test/tests/cahnhilliard/gold/cahnhilliard.rank0001.h5", "cahnhilliard_rank0001_gold.npz")
     convert_h5("test/tests/mechanics/gold/mech3d.h5", "mech3d_gold.npz")
     convert_h5("test/tests/mechanics/gold/mech.h5", "mech2d_gold.npz")

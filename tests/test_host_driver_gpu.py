@@ -159,6 +159,59 @@ def test_xdmf_tensor_output_async(slab, tmp_path):
     assert len(items) == 10 * 2 * (2 if slab else 1) and all((tmp_path / t).exists() for t in items)
 
 
+def _xml_tree(path):
+    import xml.etree.ElementTree as ET
+
+    def walk(e):
+        return [e.tag, dict(sorted(e.attrib.items())), (e.text or "").strip(), [walk(c) for c in e]]
+    return walk(ET.parse(path).getroot())
+
+
+def _xml_same(a, b, where="/"):
+    """XMLDiff: same structure, attribute names and text; numbers (in attributes or text) equal to 1e-12 relative"""
+    def same_text(x, y):
+        if x == y:
+            return True
+        xs, ys = x.split(), y.split()
+        try:
+            return len(xs) == len(ys) and all(abs(float(p) - float(q)) <= 1e-12 * max(1.0, abs(float(q))) for p, q in zip(xs, ys))
+        except ValueError:
+            return False
+    assert a[0] == b[0], (where, a[0], b[0])
+    assert sorted(a[1]) == sorted(b[1]), (where, a[1], b[1])
+    for k in a[1]:
+        assert same_text(a[1][k], b[1][k]), (where, k, a[1][k], b[1][k])
+    assert same_text(a[2], b[2]), (where, a[2], b[2])
+    assert len(a[3]) == len(b[3]), (where, len(a[3]), len(b[3]))
+    for i, (x, y) in enumerate(zip(a[3], b[3])):
+        _xml_same(x, y, f"{where}{a[0].split('}')[-1]}[{i}]/")
+
+
+def test_xdmf_output_xml_and_hdf5_specs(tmp_path):
+    """test/tests/cahnhilliard/tests:35-57 (xdmf_output_xml: XMLDiff against gold/cahnhilliard.xmf; xdmf_output_hdf5: HDF5Diff against
+    gold/cahnhilliard.h5, abs_tol 1e-13): cahnhilliard.i as the reference runs it -- output on INITIAL and TIMESTEP_END, c as nodal
+    data, mu per cell, one HDF5 container -- through the C++ mirror.  The XDMF description must be the gold file's tree (elements,
+    attributes, HDF5 paths, times to 1e-12), and all eleven c.k datasets the gold container's (21 x 21, to 1e-13)"""
+    import json
+
+    from tests.h5_subset_reader import read_h5
+    g = load_golden("cahnhilliard_gold.npz")
+    ic = tmp_path / "c0.bin"
+    g["c.0"][:20, :20].astype("<f8").tofile(ic)
+    out = _run(["problem=cahnhilliard", "dim=2", "nx=20", "ny=20", "xmax=3", "ymax=3", f"ic={ic}", "substeps=10", "num_steps=10", "dt=1e-3",
+                "predictor_order=2", "mobility=0.2", "kappa=-0.001", "output=xdmf", "enable_hdf5=true", "output_mode=NODE,CELL",
+                "output_initial=true", "file_base=cahnhilliard"], tmp_path)
+    assert '"frames": 11' in out
+    sets = read_h5(tmp_path / "cahnhilliard.h5")
+    assert sorted(sets) == sorted([f"c.{k}" for k in range(11)] + [f"mu.{k}" for k in range(11)])
+    for k in range(11):
+        assert np.abs(g[f"c.{k}"] - sets[f"c.{k}"].T).max() <= 1e-13, k
+    assert np.abs(g["mu.10"] - sets["mu.10"].T).max() <= 1e-13
+    with open(os.path.join(ROOT, "tests", "golden", "cahnhilliard_xmf_gold.json")) as f:
+        gold_tree = json.load(f)
+    _xml_same(_xml_tree(tmp_path / "cahnhilliard.xmf"), gold_tree)
+
+
 @pytest.mark.parametrize("slab", [False, True])
 def test_xdmf_tensor_output_hdf5(slab, tmp_path):
     """the same run with enable_hdf5 = true (XDMFTensorOutput.C:39, 152-160, 323-343, 244-246): one <base>[.rankNNNN].h5 per rank with
