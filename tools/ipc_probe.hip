@@ -29,7 +29,7 @@
 static int g_rank = -1;
 
 struct Shared {
-  std::atomic<int> arrived[8];
+  std::atomic<int> arrived[16];
   hipIpcMemHandle_t buf[16];
   hipIpcMemHandle_t flag[16];
   hipIpcMemHandle_t buf2[16];
@@ -82,6 +82,23 @@ static int child(int rank, int nranks, int same_device, const char *shm_name) {
   const int dev = same_device ? 0 : rank % ndev;
   CK(hipSetDevice(dev));
   const long long n = g_slot_doubles;
+  if (g_second_mib > 0) {  // as the library does before its exchange buffers: two small symmetric buffers first, one of them uncached
+    for (int k = 0; k < 2; ++k) {
+      void *sm = nullptr;
+      if (k == 0) CK(hipExtMallocWithFlags(&sm, 1 << 19, hipDeviceMallocUncached)); else CK(hipMalloc(&sm, 1 << 17));
+      CK(hipMemset(sm, 0, 1 << 17));
+      CK(hipDeviceSynchronize());
+      CK(hipIpcGetMemHandle(&sh->buf2[rank], sm));
+      barrier(sh, 6 + k, nranks);
+      for (int p = 0; p < nranks; ++p) {
+        if (p == rank) continue;
+        void *m = nullptr;
+        CK(hipIpcOpenMemHandle(&m, sh->buf2[p], hipIpcMemLazyEnablePeerAccess));
+      }
+      barrier(sh, 8 + k, nranks);
+    }
+    fprintf(stderr, "[rank %d] two small symmetric buffers mapped first\n", rank);
+  }
   double *buf = nullptr;
   unsigned long long *flag = nullptr;
   CK(hipMalloc(&buf, sizeof(double) * n * nranks));
