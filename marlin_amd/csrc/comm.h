@@ -122,6 +122,8 @@ int xchg_post(mrl_comm *c, Xchg *x, hipStream_t stream, bool kernel_signalled = 
 SignalArgs xchg_signal_args(const mrl_comm *c, const Xchg *x, unsigned int nblocks);
 // consumer side: orders `stream` behind the arrival of every peer's chunk of the current epoch
 int xchg_wait(mrl_comm *c, Xchg *x, hipStream_t stream);
+// xchg_post + xchg_wait back to back; fuse: one flag kernel for both when the table is direct (peer stores)
+int xchg_post_wait(mrl_comm *c, Xchg *x, hipStream_t stream, bool fuse);
 // true when producers should scatter through the table straight into the peers' buffers
 inline bool xchg_direct(const mrl_comm *c) { return c->transport == MRL_TRANSPORT_PEER_STORE; }
 

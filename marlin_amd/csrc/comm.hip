@@ -279,6 +279,25 @@ __global__ void k_comm_wait(const unsigned long long *row, int nranks, unsigned 
   }
 }
 
+// k_comm_signal followed by k_comm_wait in one launch (an exchange whose post and wait are adjacent in the stream: one kernel boundary
+// less between the producing and the consuming pass).  Every lane raises its peer's flag BEFORE any lane starts to spin.
+__global__ void k_comm_signal_wait(unsigned long long *const *tab, const unsigned long long *my_row, int nranks, int me, int row,
+                                   unsigned long long epoch, int *status, long long max_ticks) {
+  const int p = threadIdx.x;
+  if (p >= nranks) return;
+  __threadfence_system();
+  __hip_atomic_store(tab[p] + row + me, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(my_row + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+    if (wall_clock64() - t0 > max_ticks) {
+      atomicMax(status, 1 + p);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
 // sum over ranks of n scalars: every rank stores its values into every peer's mailbox, raises a flag, waits for all flags and
 // adds the P contributions in rank order (identical bits everywhere).  One workgroup of 64 threads.
 __global__ void k_comm_allreduce(double *const *mbox_tab, unsigned long long *const *flag_tab, const unsigned long long *my_row,
@@ -577,6 +596,26 @@ int xchg_post(mrl_comm *c, Xchg *x, hipStream_t stream, bool kernel_signalled) {
   }
   for (int i = 0; i < ns && i < P; ++i) COMM_HIP(c, hipEventRecord(x->copy_done[i], c->side[i]));
   x->pending_send_guard = true;
+  return MRL_OK;
+}
+
+// xchg_post immediately followed by xchg_wait.  Direct tables (peer stores): the release event, then ONE kernel that raises the peers'
+// flags and waits for this rank's; other transports: the two calls.
+int xchg_post_wait(mrl_comm *c, Xchg *x, hipStream_t stream, bool fuse) {
+  if (!fuse || !x->tab_direct || c->kernel_signals) {
+    COMM_TRY(xchg_post(c, x, stream, false));
+    return xchg_wait(c, x, stream);
+  }
+  const int P = c->nranks, me = c->rank;
+  x->epoch += 1;
+  c->n_exchanges += 1;
+  for (int p = 0; p < P; ++p)
+    if (p != me) c->bytes_sent += (double)x->send_cnt[p];
+  COMM_HIP(c, hipEventRecord(x->release_ev, stream));
+  hipLaunchKernelGGL(k_comm_signal_wait, dim3(1), dim3(64), 0, stream, c->d_flag_tab,
+                     static_cast<const unsigned long long *>(c->flags.local) + (size_t)x->channel * kFlagRow, P, me, x->channel * kFlagRow,
+                     (unsigned long long)x->epoch, c->d_status, max_ticks(c));
+  COMM_HIP(c, hipGetLastError());
   return MRL_OK;
 }
 

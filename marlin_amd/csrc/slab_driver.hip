@@ -188,6 +188,13 @@ static int post(mrl_ctx *ctx, Xchg *x, bool kernel_signalled, bool local_only) {
   MRL_COMM(ctx, xchg_post(ctx->comm, x, ctx->stream, kernel_signalled));
   return MRL_OK;
 }
+// post and wait of one exchange back to back (one kz sub-block in flight: nothing is enqueued between them)
+static int post_wait(mrl_ctx *ctx, Xchg *x, bool local_only) {
+  if (local_only) return MRL_OK;
+  ProfScope ps(ctx, "slab_exchange_wait");
+  MRL_COMM(ctx, xchg_post_wait(ctx->comm, x, ctx->stream, !(ctx->exp & 262144)));
+  return MRL_OK;
+}
 static int wait(mrl_ctx *ctx, Xchg *x, bool local_only) {
   if (local_only) return MRL_OK;
   ProfScope ps(ctx, "slab_exchange_wait");
@@ -230,7 +237,11 @@ int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, d
       if (P.fast) {
         const SignalArgs sig = xchg_signal_args(c, &F[s], 0);
         MRL_TRY(slab_ch_x_fwd_fast(ctx, (int)k0, (int)ks, reinterpret_cast<cplx *const *>(F[s].d_tab), sig, mode));
-        MRL_TRY(post(ctx, &F[s], sig.counter != nullptr, lo));
+        if (nsub == 1 && !sig.counter) {
+          MRL_TRY(post_wait(ctx, &F[s], lo));
+        } else {
+          MRL_TRY(post(ctx, &F[s], sig.counter != nullptr, lo));
+        }
       } else {
         MRL_TRY(gen_x_fwd(ctx, k0, ks, F[s].send, mode));
         MRL_TRY(post(ctx, &F[s], false, lo));
@@ -240,14 +251,18 @@ int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, d
       long long k0, ks;
       MRL_TRY(slab_sub_range(ctx, s, nsub, &k0, &ks));
       MRL_TRACE("substep %d: wait F, y pass", k);
-      MRL_TRY(wait(ctx, &F[s], lo));
+      if (!(P.fast && nsub == 1 && !c->kernel_signals)) MRL_TRY(wait(ctx, &F[s], lo));   // (else: waited for by post_wait above)
       MRL_COMM(ctx, xchg_begin(c, &P.inv[s], st));
       const double *recv = static_cast<const double *>(F[s].recv.local);
       if (P.fast) {
         const SignalArgs sig = xchg_signal_args(c, &P.inv[s], 0);
         MRL_TRY(slab_ch_kspace_fast(ctx, cp, (int)k0, (int)ks, recv, reinterpret_cast<cplx *const *>(P.inv[s].d_tab), sig, ring[slot_new], old,
                                     order, sub_dt, P.cbar, mode));
-        MRL_TRY(post(ctx, &P.inv[s], sig.counter != nullptr, lo));
+        if (nsub == 1 && !sig.counter) {
+          MRL_TRY(post_wait(ctx, &P.inv[s], lo));
+        } else {
+          MRL_TRY(post(ctx, &P.inv[s], sig.counter != nullptr, lo));
+        }
       } else {
         MRL_TRY(gen_kspace(ctx, cp, k0, ks, recv, P.inv[s].send, ring[slot_new], old, order, sub_dt, P.cbar, mode));
         MRL_TRY(post(ctx, &P.inv[s], false, lo));
@@ -255,7 +270,7 @@ int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, d
     }
     for (int s = 0; s < nsub; ++s) {
       MRL_TRACE("substep %d: wait I, inverse x pass", k);
-      MRL_TRY(wait(ctx, &P.inv[s], lo));
+      if (!(P.fast && nsub == 1 && !c->kernel_signals)) MRL_TRY(wait(ctx, &P.inv[s], lo));
       MRL_TRY(mrl_slab_ch_x_inv(ctx, s, nsub, static_cast<const double *>(P.inv[s].recv.local)));
     }
     if (advance && k < count - 1) {  // TensorSolver.C:105-106
@@ -458,13 +473,11 @@ int slab_gamma_fm(mrl_ctx *ctx, const double *A_fm, double *out_fm, double scale
     MechPipe &P = ctx->pipes->mech;
     MRL_COMM(ctx, xchg_begin(c, &P.fwd_all, st));
     MRL_TRY(slab_gamma_rows_fwd(ctx, A_fm, reinterpret_cast<cplx *const *>(P.fwd_all.d_tab), SignalArgs{}));
-    MRL_COMM(ctx, xchg_post(c, &P.fwd_all, st, false));
-    MRL_COMM(ctx, xchg_wait(c, &P.fwd_all, st));
+    MRL_COMM(ctx, xchg_post_wait(c, &P.fwd_all, st, !(ctx->exp & 262144)));
     MRL_COMM(ctx, xchg_begin(c, &P.inv_all, st));
     MRL_TRY(slab_gamma_rows_mid(ctx, static_cast<const double *>(P.fwd_all.recv.local), reinterpret_cast<cplx *const *>(P.inv_all.d_tab), SignalArgs{},
                                 scale));
-    MRL_COMM(ctx, xchg_post(c, &P.inv_all, st, false));
-    MRL_COMM(ctx, xchg_wait(c, &P.inv_all, st));
+    MRL_COMM(ctx, xchg_post_wait(c, &P.inv_all, st, !(ctx->exp & 262144)));
     ctx->gamma_dot_nb = 0;
     MRL_TRY(slab_gamma_rows_inv(ctx, static_cast<const double *>(P.inv_all.recv.local), out_fm, dotv_fm));
     if (dotv_fm) {
