@@ -1,13 +1,14 @@
 #!/bin/bash
 # Run on the GPU box: PMC passes over tools/slab_local_bench.py that compare the forward and the inverse slab x pass
 # (write-request sizes and stalls, read-request sizes and stalls, L2 hit rate, address-unit stalls).  -> gpurun_out/pmc_<tag>/summary.txt
+# Budget ≈ 3-5 min per pass, four passes: give gpurun --timeout 1500.
 set -u
 TAG=${1:-slabpass}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="8 256 10 1 0 1"
+ARGS="8 256 4 1 0 1"   # few substeps: every launch is serialised and replayed under --pmc (the 10-substep version needed > 5 min per pass)
 i=0
 for set in "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum"; do
   i=$((i+1))
