@@ -122,14 +122,16 @@ def run_chbench(job, P, r, kv):
         c0 = torch.from_numpy(splitmix64_uniform(npts).reshape(shape))
     mass0 = float(c0.sum(dtype=torch.float64).item())
     p = api.ch_params()
-    serial = api.Context(3, shape, L, device=0)
+    noref = kv.get("noref", "0") == "1"   # debugging aid: no serial reference (nothing but the slab job touches the device)
     want = torch.empty(shape, dtype=torch.float64, device="cuda")
-    ring = [serial.empty_spec(), serial.empty_spec()]
-    serial.ch_substeps(p, c0.cuda(), want, ring, 1, 0, 2, steps, True, 1e-3)
-    serial.sync()
-    mark("serial reference done")
-    del ring
-    serial.close()
+    if not noref:
+        serial = api.Context(3, shape, L, device=0)
+        ring = [serial.empty_spec(), serial.empty_spec()]
+        serial.ch_substeps(p, c0.cuda(), want, ring, 1, 0, 2, steps, True, 1e-3)
+        serial.sync()
+        mark("serial reference done")
+        del ring
+        serial.close()
     comm = api.Comm(job, P, r, device=0, transport=int(kv.get("transport", 0)), timeout=60.0)
     mark("communicator up")
     ctx = api.Context(3, shape, L, nranks=P, rank=r, slab=True, device=0)
@@ -149,7 +151,7 @@ def run_chbench(job, P, r, kv):
     mark("slab solve enqueued")
     ctx.sync()
     mark("slab solve done")
-    err = (out - want).abs().max().item()
+    err = 0.0 if noref else (out - want).abs().max().item()
     mass = comm.allreduce([float(out.sum(dtype=torch.float64).item())])[0]
     ctx.close()
     comm.close()
