@@ -69,6 +69,7 @@ static void barrier(Shared *sh, int slot, int n) {
   }
 }
 
+static long long g_extra_gib = 0;
 static long long g_second_mib = 0;  // argv[4]: a second symmetric buffer of this many MiB, mapped after the first
 static long long g_slot_doubles = 4 << 20;  // doubles per peer slot (32 MiB; argv[3] = MiB per slot)
 
@@ -82,6 +83,15 @@ static int child(int rank, int nranks, int same_device, const char *shm_name) {
   const int dev = same_device ? 0 : rank % ndev;
   CK(hipSetDevice(dev));
   const long long n = g_slot_doubles;
+  if (g_extra_gib > 0) {  // ballast: other device memory the process holds (argv[5] GiB in 1 GiB pieces, touched)
+    for (long long k = 0; k < g_extra_gib; ++k) {
+      void *b = nullptr;
+      CK(hipMalloc(&b, 1ull << 30));
+      CK(hipMemset(b, 0, 1ull << 30));
+    }
+    CK(hipDeviceSynchronize());
+    fprintf(stderr, "[rank %d] %lld GiB of ballast allocated\n", rank, g_extra_gib);
+  }
   if (g_second_mib > 0) {  // as the library does before its exchange buffers: two small symmetric buffers first, one of them uncached
     for (int k = 0; k < 2; ++k) {
       void *sm = nullptr;
@@ -212,6 +222,7 @@ int main(int argc, char **argv) {
   const int same = argc > 2 ? atoi(argv[2]) : 1;
   if (argc > 3) g_slot_doubles = (long long)atoi(argv[3]) * (1 << 17);
   if (argc > 4) g_second_mib = atoi(argv[4]);
+  if (argc > 5) g_extra_gib = atoi(argv[5]);
   if (!r || !getenv("MRL_PROBE_SHM")) {
     fprintf(stderr, "run through tools/ipc_probe.sh\n");
     return 1;
