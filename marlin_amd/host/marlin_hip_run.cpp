@@ -209,9 +209,17 @@ static int run_cahnhilliard(DomainAction & domain, const std::string & out)
     domain.check(mrl_sync(domain.ctx()));
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double updates = (double)domain.getGlobalNumberOfCells() * (double)p.substeps * (double)argi("num_steps", 1);
+    // global checksums of the final field (sum c, sum c^2 over all ranks): lets two runs be compared without writing the field
+    double sum_c = 0.0, sum_c2 = 0.0;
+    {
+      const DeviceTensor c_end = problem.getBuffer("c");
+      domain.check(mrl_sum(domain.ctx(), c_end.data(), (int64_t)c_end.numel(), &sum_c));
+      domain.check(mrl_dot(domain.ctx(), c_end.data(), c_end.data(), (int64_t)c_end.numel(), &sum_c2));
+    }
     if (domain.rank() == 0)
-      std::printf("{\"wall_s\": %.3f, \"grid_point_updates_per_s\": %.6e, \"frames\": %d, \"seconds_in_writer_thread\": %.3f, \"time\": %.17g}\n",
-                  wall, updates / wall, xdmf ? xdmf->frames() : 0, xdmf ? xdmf->secondsWriting() : 0.0, problem.time());
+      std::printf("{\"wall_s\": %.3f, \"grid_point_updates_per_s\": %.6e, \"frames\": %d, \"seconds_in_writer_thread\": %.3f, \"time\": %.17g, "
+                  "\"sum_c\": %.17g, \"sum_c2\": %.17g}\n",
+                  wall, updates / wall, xdmf ? xdmf->frames() : 0, xdmf ? xdmf->secondsWriting() : 0.0, problem.time(), sum_c, sum_c2);
     mrl_parsed_destroy(parsed);
     return 0;
   }

@@ -269,6 +269,22 @@ def test_xdmf_tensor_output_hdf5(slab, tmp_path):
     assert not list(tmp_path.glob("ch*.bin"))
 
 
+def test_cahnhilliard_fft_slab_exchange_buffers_beyond_4_gib(tmp_path):
+    """512 x 1024 x 1024 on TWO rank processes of the C++ driver (all-native processes: the system HIP runtime): rank-local spectral
+    arrays of 2.2 GB, a 4.36 GB two-field forward exchange buffer and a 2.18 GB inverse one, mapped between the processes through HIP
+    IPC; the fused slab pipeline with the 64-bit y pass.  Two AB substeps against the serial fused path on the same grid through the
+    global checksums sum(c) and sum(c^2) (1e-13 relative; the fields themselves are compared at this size in
+    tests/test_slab_native_gpu.py::test_native_slab_exchange_buffers_beyond_4_gib on one rank)"""
+    import json
+    common = ["problem=cahnhilliard", "dim=3", "nx=512", "ny=1024", "nz=1024", "xmax=8pi", "ymax=16pi", "zmax=16pi", "ic=splitmix64",
+              "substeps=2", "num_steps=1", "dt=2e-3", "predictor_order=2", "mobility=0.2", "kappa=-0.001", "output=none"]
+    par = json.loads(_run(common + ["parallel_mode=FFT_SLAB", "nranks=2", "device=0"], tmp_path).strip().splitlines()[-1])
+    ser = json.loads(_run(common, tmp_path).strip().splitlines()[-1])
+    assert abs(par["sum_c"] - ser["sum_c"]) <= 1e-13 * abs(ser["sum_c"]), (par, ser)
+    assert abs(par["sum_c2"] - ser["sum_c2"]) <= 1e-13 * abs(ser["sum_c2"]), (par, ser)
+    assert abs(ser["sum_c"] / (512 * 1024 * 1024) - 0.5) < 1e-3       # (mass of the uniform [0.44, 0.56] initial condition, conserved)
+
+
 def test_mechanics_case_fft_slab(tmp_path):
     """mech3d.i (test/tests/mechanics/tests:2-21) on 2 rank processes: the C++ FFTMechanics object over mrl_mech_newton_cg on slab
     contexts; F_k.frame and sV of mech3d.h5 to 1e-10"""

@@ -136,9 +136,9 @@ def test_native_slab_exchange_buffers_beyond_4_gib():
     """rank-local arrays of 2.2 GB: the two-field forward exchange buffer (4.36 GB) is beyond 32-bit byte offsets, which sent such
     grids (1024^3 on 2 or 4 GPUs) to the any-size stages.  The y pass's 64-bit variant keeps them on the fused pipeline: a one-rank
     slab job (communicator, flags, exchange tables, peer-store kernels) against the serial fused path on the same grid (itself
-    oracle-checked at the sizes the oracle reaches), 2 substeps, to 1e-13, mass conserved.  (Two rank PROCESSES on one GPU with
-    buffers of this size: hipIpcOpenMemHandle of the second multi-GB buffer does not return on this pool -- DESIGN 4.1; the library
-    turns that into MRL_ERR_COMM after the communicator's time-out.)"""
+    oracle-checked at the sizes the oracle reaches), 2 substeps, to 1e-13, mass conserved.  (Two rank processes with buffers of this size: covered through the C++ driver,
+    tests/test_host_driver_gpu.py::test_cahnhilliard_fft_slab_exchange_buffers_beyond_4_gib -- inside a PyTorch process the HIP runtime
+    bundled with the wheel does not return from hipIpcOpenMemHandle for multi-GB buffers)"""
     res = run_job(1, "chbench", "shape=512,512,1024", "steps=2", "ic=rand", *EXTRA_KV, timeout=300)
     assert max(r["max_err"] for r in res) <= 1e-13, res
     assert max(r["mass_err"] for r in res) <= 1e-12, res
