@@ -33,6 +33,10 @@ int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const doub
     case 360: { constexpr int NN = 360; CALL; } break;   \
     case 450: { constexpr int NN = 450; CALL; } break;   \
     case 600: { constexpr int NN = 600; CALL; } break;   \
+    case 160: { constexpr int NN = 160; CALL; } break;   \
+    case 320: { constexpr int NN = 320; CALL; } break;   \
+    case 640: { constexpr int NN = 640; CALL; } break;   \
+    case 1280: { constexpr int NN = 1280; CALL; } break; \
     default: return MRL_ERR_UNSUPPORTED;                 \
   }
 
@@ -179,9 +183,11 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_x_update(XKArgs a, const cpl
   }
   const double ky2 = ky * ky, kz2 = kz * kz;
   // the history streams through in thirds of the line: 10 x (1 + ORDER) values in flight instead of 30 x (1 + ORDER)
-  constexpr int H = P / 3;
+  // (quarters for the 20-point plans)
+  constexpr int NPART = P % 3 == 0 ? 3 : 4, H = P / NPART;
+  static_assert(NPART * H == P, "the history parts must cover the line");
 #pragma unroll
-  for (int part = 0; part < 3; ++part) {
+  for (int part = 0; part < NPART; ++part) {
     cplx nn[H], no[ORDER > 0 ? ORDER : 1][H];
 #pragma unroll
     for (int j = 0; j < H; ++j) nn[j] = a.Nnew[e0 + (part * H + j) * step];

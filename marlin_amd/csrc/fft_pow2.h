@@ -75,6 +75,13 @@ MRL_PLAN(300, 30, 30, 10, 1, 1, 12)
 MRL_PLAN(360, 30, 30, 3, 2, 2, 10)
 MRL_PLAN(450, 30, 30, 5, 3, 1, 8)
 MRL_PLAN(600, 30, 30, 10, 2, 1, 6)
+// sizes 2^a 5 with a >= 5 (160, 320, 640, 1280: 2^a 5 needs too many radix-2 stages behind a radix-10 one): radix 20 first, then 4 / 2;
+// 20 points per thread = 80 registers per array: like the radix-30 lengths, plain transforms only (ch_planned.hip)
+// (128-thread workgroups: the LDS tile of T lines stays at 40 KB as for the other plans)
+MRL_PLAN(160, 20, 20, 4, 2, 1, 16)
+MRL_PLAN(320, 20, 20, 4, 4, 1, 8)
+MRL_PLAN(640, 20, 20, 4, 4, 2, 4)
+MRL_PLAN(1280, 20, 20, 4, 4, 4, 2)
 
 // Lines per workgroup of the z kernels (k_z_fwd / k_z_inv / k_z_inv_fwd): their lines are contiguous in memory, so the tile
 // width T of the strided passes (T adjacent lines = one coalesced segment) buys them nothing, while smaller workgroups mean more
@@ -246,6 +253,37 @@ __device__ __forceinline__ void bfly<10>(cplx (&a)[10]) {
     a[2 * k2] = e[k2];
     a[2 * k2 + 1] = o[k2];
   }
+}
+
+// radix 20 = 4 x 5 (Cooley-Tukey): n = 5 n1 + n2, k = k1 + 4 k2 -- first stage of the lengths 2^a 5 with a >= 5 (160, 320, 640, 1280)
+template <>
+__device__ __forceinline__ void bfly<20>(cplx (&a)[20]) {
+  // radix 4 over n1 for each n2: (a[n2], a[n2+5], a[n2+10], a[n2+15]) -> A[n2][k1] left in slot 5 k1 + n2
+#pragma unroll
+  for (int n2 = 0; n2 < 5; ++n2) bfly4(a[n2], a[n2 + 5], a[n2 + 10], a[n2 + 15]);
+  // twiddles W20^(n2 k1)
+  a[6] = cmul(a[6], make_double2(0.951056516295153531182, -0.309016994374947395752));  // W20^1
+  a[7] = cmul(a[7], make_double2(0.809016994374947451263, -0.587785252292473137103));  // W20^2
+  a[8] = cmul(a[8], make_double2(0.587785252292473137103, -0.809016994374947451263));  // W20^3
+  a[9] = cmul(a[9], make_double2(0.309016994374947451263, -0.951056516295153531182));  // W20^4
+  a[11] = cmul(a[11], make_double2(0.809016994374947451263, -0.587785252292473137103));  // W20^2
+  a[12] = cmul(a[12], make_double2(0.309016994374947451263, -0.951056516295153531182));  // W20^4
+  a[13] = cmul(a[13], make_double2(-0.309016994374947340241, -0.951056516295153642204));  // W20^6
+  a[14] = cmul(a[14], make_double2(-0.809016994374947340241, -0.587785252292473248126));  // W20^8
+  a[16] = cmul(a[16], make_double2(0.587785252292473137103, -0.809016994374947451263));  // W20^3
+  a[17] = cmul(a[17], make_double2(-0.309016994374947340241, -0.951056516295153642204));  // W20^6
+  a[18] = cmul(a[18], make_double2(-0.951056516295153531182, -0.309016994374947506774));  // W20^9
+  a[19] = cmul(a[19], make_double2(-0.809016994374947562285, 0.587785252292473026081));  // W20^12
+  // radix 5 over n2 for each k1: X[k1 + 4 k2]
+  cplx r[20];
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    bfly5(a[5 * k1], a[5 * k1 + 1], a[5 * k1 + 2], a[5 * k1 + 3], a[5 * k1 + 4]);
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) r[k1 + 4 * k2] = a[5 * k1 + k2];
+  }
+#pragma unroll
+  for (int i = 0; i < 20; ++i) a[i] = r[i];
 }
 
 // radix 30 = 3 x 10 (Cooley-Tukey): n = 10 n1 + n2, k = k1 + 3 k2

@@ -188,12 +188,17 @@ inline unsigned pass_sub_blocks(long long rows, long long cols) {
     case 360: { constexpr int NN = 360; CALL; } break;   \
     case 450: { constexpr int NN = 450; CALL; } break;   \
     case 600: { constexpr int NN = 600; CALL; } break;   \
+    case 160: { constexpr int NN = 160; CALL; } break;   \
+    case 320: { constexpr int NN = 320; CALL; } break;   \
+    case 640: { constexpr int NN = 640; CALL; } break;   \
+    case 1280: { constexpr int NN = 1280; CALL; } break; \
     default: MRL_SWITCH_N(n, CALL)                       \
   }
 
 inline bool plain30_ok(long long n) {
   switch (n) {
     case 60: case 90: case 120: case 150: case 180: case 240: case 270: case 300: case 360: case 450: case 600: return true;
+    case 160: case 320: case 640: case 1280: return true;   // (radix-20 plans: plain kernels only, as the radix-30 ones)
     default: return false;
   }
 }

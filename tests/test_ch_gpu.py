@@ -78,7 +78,8 @@ def test_ch_gold_file_3d():
                                    (200, 64, 100), (128, 128), (200, 100), (64, 400), (96, 192, 64), (384, 96),
                                    (40, 40, 40), (50, 80, 32), (48, 144, 250), (500, 32), (1000, 48), (768, 40, 32),
                                    (2048, 64), (32, 4096), (2048, 32, 40),
-                                   (150, 150), (120, 90, 60), (240, 64, 150), (64, 270, 100), (300, 180), (360, 60, 48)])   # planned-unfused path
+                                   (150, 150), (120, 90, 60), (240, 64, 150), (64, 270, 100), (300, 180), (360, 60, 48),   # planned-unfused path
+                                   (160, 64, 40), (64, 320, 32), (640, 160), (32, 40, 1280)])                              # ... radix-20 lengths
 def test_ch_vs_oracle(shape):
     from marlin_amd.api import Context, ch_params
     dim = len(shape)

@@ -17,6 +17,7 @@ SHAPES = [
     (2048, 64), (32, 4096), (2048, 32, 40), (4096, 2048),                  # long lines of 2-D problems (planned lengths only)
     (120, 90, 60), (150, 150), (240, 120, 150), (64, 60, 256), (270, 300, 60), (180, 360), (450, 64, 90), (600, 40),
     (100, 240, 96),                                                        # radix-30 plans (2 x 3 x 5 lengths), mixed with the others
+    (160, 40, 64), (64, 320, 32), (32, 48, 640), (640, 160), (1280, 64), (320, 160, 60),   # radix-20 plans (2^a 5, a >= 5)
 ]
 
 
