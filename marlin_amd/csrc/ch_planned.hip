@@ -37,6 +37,14 @@ int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const doub
     case 320: { constexpr int NN = 320; CALL; } break;   \
     case 640: { constexpr int NN = 640; CALL; } break;   \
     case 1280: { constexpr int NN = 1280; CALL; } break; \
+    case 800: { constexpr int NN = 800; CALL; } break;   \
+    case 72: { constexpr int NN = 72; CALL; } break;   \
+    case 216: { constexpr int NN = 216; CALL; } break;   \
+    case 288: { constexpr int NN = 288; CALL; } break;   \
+    case 432: { constexpr int NN = 432; CALL; } break;   \
+    case 576: { constexpr int NN = 576; CALL; } break;   \
+    case 864: { constexpr int NN = 864; CALL; } break;   \
+    case 1152: { constexpr int NN = 1152; CALL; } break;   \
     default: return MRL_ERR_UNSUPPORTED;                 \
   }
 

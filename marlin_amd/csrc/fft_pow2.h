@@ -82,6 +82,16 @@ MRL_PLAN(160, 20, 20, 4, 2, 1, 16)
 MRL_PLAN(320, 20, 20, 4, 4, 1, 8)
 MRL_PLAN(640, 20, 20, 4, 4, 2, 4)
 MRL_PLAN(1280, 20, 20, 4, 4, 4, 2)
+MRL_PLAN(800, 20, 20, 10, 4, 1, 3)
+// 2^a 3^b with b >= 2 (72 ... 1152): the 12-point plans of the fused family, here for the plain kernels only (instantiating the fused
+// kernels for every further length is what costs build time and binary size)
+MRL_PLAN(72, 12, 12, 3, 2, 1, 32)
+MRL_PLAN(216, 12, 12, 3, 3, 2, 12)
+MRL_PLAN(288, 12, 12, 12, 2, 1, 8)
+MRL_PLAN(432, 12, 12, 12, 3, 1, 6)
+MRL_PLAN(576, 12, 12, 12, 4, 1, 4)
+MRL_PLAN(864, 12, 12, 12, 3, 2, 3)
+MRL_PLAN(1152, 12, 12, 12, 4, 2, 2)
 
 // Lines per workgroup of the z kernels (k_z_fwd / k_z_inv / k_z_inv_fwd): their lines are contiguous in memory, so the tile
 // width T of the strided passes (T adjacent lines = one coalesced segment) buys them nothing, while smaller workgroups mean more

@@ -192,6 +192,14 @@ inline unsigned pass_sub_blocks(long long rows, long long cols) {
     case 320: { constexpr int NN = 320; CALL; } break;   \
     case 640: { constexpr int NN = 640; CALL; } break;   \
     case 1280: { constexpr int NN = 1280; CALL; } break; \
+    case 800: { constexpr int NN = 800; CALL; } break;   \
+    case 72: { constexpr int NN = 72; CALL; } break;   \
+    case 216: { constexpr int NN = 216; CALL; } break;   \
+    case 288: { constexpr int NN = 288; CALL; } break;   \
+    case 432: { constexpr int NN = 432; CALL; } break;   \
+    case 576: { constexpr int NN = 576; CALL; } break;   \
+    case 864: { constexpr int NN = 864; CALL; } break;   \
+    case 1152: { constexpr int NN = 1152; CALL; } break;   \
     default: MRL_SWITCH_N(n, CALL)                       \
   }
 
@@ -199,6 +207,7 @@ inline bool plain30_ok(long long n) {
   switch (n) {
     case 60: case 90: case 120: case 150: case 180: case 240: case 270: case 300: case 360: case 450: case 600: return true;
     case 160: case 320: case 640: case 1280: return true;   // (radix-20 plans: plain kernels only, as the radix-30 ones)
+    case 800: case 72: case 216: case 288: case 432: case 576: case 864: case 1152: return true;   // (further 2^a 5^2 / 2^a 3^b lengths)
     default: return false;
   }
 }

@@ -79,7 +79,8 @@ def test_ch_gold_file_3d():
                                    (40, 40, 40), (50, 80, 32), (48, 144, 250), (500, 32), (1000, 48), (768, 40, 32),
                                    (2048, 64), (32, 4096), (2048, 32, 40),
                                    (150, 150), (120, 90, 60), (240, 64, 150), (64, 270, 100), (300, 180), (360, 60, 48),   # planned-unfused path
-                                   (160, 64, 40), (64, 320, 32), (640, 160), (32, 40, 1280)])                              # ... radix-20 lengths
+                                   (160, 64, 40), (64, 320, 32), (640, 160), (32, 40, 1280),                               # ... radix-20 lengths
+                                   (288, 64, 40), (72, 216), (576, 64), (800, 32), (48, 432, 72), (864, 1152)])            # ... further plain plans
 def test_ch_vs_oracle(shape):
     from marlin_amd.api import Context, ch_params
     dim = len(shape)

@@ -18,6 +18,7 @@ SHAPES = [
     (120, 90, 60), (150, 150), (240, 120, 150), (64, 60, 256), (270, 300, 60), (180, 360), (450, 64, 90), (600, 40),
     (100, 240, 96),                                                        # radix-30 plans (2 x 3 x 5 lengths), mixed with the others
     (160, 40, 64), (64, 320, 32), (32, 48, 640), (640, 160), (1280, 64), (320, 160, 60),   # radix-20 plans (2^a 5, a >= 5)
+    (72, 216, 40), (288, 64), (64, 432, 32), (576, 96), (864, 32), (1152, 48), (800, 40), (40, 800, 32), (288, 72, 216),   # further plain plans
 ]
 
 
