@@ -296,10 +296,30 @@ def main():
         barrier()
         want = {"tune": api.TRANSPORT_AUTO, "auto": api.TRANSPORT_AUTO, "peer_store": api.TRANSPORT_PEER_STORE,
                 "peer_copy": api.TRANSPORT_PEER_COPY, "rccl": api.TRANSPORT_RCCL}[args.transport]
-        comm = api.Comm(job, world, rank, device=dev, transport=want, timeout=120.0)
-        solver = NativeSlabCH(api, shape, L, p, world, rank, dev, comm, nsub, carry)
-        if args.exp:
-            solver.ctx.set_option(api.OPT_EXPERIMENT, args.exp)
+        # a communicator or pipeline that cannot be set up on this node (no IPC and no RCCL, ...) must not end the benchmark: the verdict
+        # is collective (all-reduced over the control group) and the torch.distributed driver over the same kernels takes over
+        setup_ok, setup_why, solver = 1.0, "", None
+        try:
+            comm = api.Comm(job, world, rank, device=dev, transport=want, timeout=120.0)
+            solver = NativeSlabCH(api, shape, L, p, world, rank, dev, comm, nsub, carry)
+            if args.exp:
+                solver.ctx.set_option(api.OPT_EXPERIMENT, args.exp)
+        except api.MarlinHipError as e:
+            setup_ok, setup_why = 0.0, e.message[:200]
+        t_ok = torch.tensor([setup_ok], dtype=torch.float64)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if float(t_ok.item()) == 0.0:
+            native_failed = True
+            transport_report = {"selected": "none: falling back to the torch.distributed driver",
+                                "native_setup_error": setup_why or "on another rank"}
+            if solver is not None:
+                solver.ctx.close()
+            if comm is not None:
+                try:
+                    comm.close()
+                except api.MarlinHipError:
+                    pass
+            comm = None
 
         def steps(count):
             solver.run(count, sub_dt)
@@ -311,7 +331,9 @@ def main():
             cur = solver.current()
             return host_sum(float((cur * cur).sum(dtype=torch.float64).item()))
 
-        if args.transport == "tune":
+        if native_failed:
+            pass
+        elif args.transport == "tune":
             # every transport this node supports runs the same substeps from the same initial condition: the fields must agree,
             # and the fastest (max over ranks) carries the timed region.  A transport that fails or times out on ANY rank is dropped
             # by all of them (the verdict is all-reduced), and the pipeline is rebuilt before the next candidate.
@@ -372,7 +394,7 @@ def main():
         if not native_failed:
             solver.reset()
             prof_ctx = solver.ctx
-        else:
+        elif comm is not None:      # (a failed setup has closed its objects already)
             torch.cuda.synchronize()
             solver.ctx.close()
             comm.close()
