@@ -6,10 +6,15 @@ A "step" is one solver substep (AdamsBashforthMoulton::substep + its compute gro
   N = 1   256^3 on one GPU (BASELINE configs[1]).
   N > 1   slab decomposition, one process per GPU; per-GPU work is held at 256^3 points (weak scaling: N = 8 is the 512^3
           configuration of north_star, configs[3]); `--global-grid G` fixes the GLOBAL grid instead (strong scaling).
+          `python bench.py --gpus N` starts its own ranks: this process never touches the GPU, it runs marlin_amd/lib/marlin-hip-bench
+          (C++ rank processes over the C ABI and the system HIP runtime, forked before any HIP call -- the reference picks its device
+          from the host-local rank inside the program, DomainAction.C:163-199) and wraps the JSON line it prints.  Under
+          `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` rank 0 does exactly that and the other launcher ranks
+          wait for its verdict.  Fallback chain, each stage in fresh child processes: native C++ ranks -> torch.distributed.run children
+          with the native driver (--inner) -> the same with `--driver python` (marlin_amd/slab.py over RCCL all_to_all_single).
           The exchange is owned by the library (include/marlin_hip.h: mrl_comm_*): kernels storing straight into the peers'
-          receive buffers over xGMI, copy-engine pushes, or RCCL grouped send/recv -- `--transport tune` (default) times each of them
-          on the real links during the untimed warm-up and keeps the fastest.  `--driver python` runs the torch.distributed driver
-          (marlin_amd/slab.py: RCCL all_to_all_single) over the same kernels instead.
+          receive buffers over xGMI, copy-engine pushes, or RCCL grouped send/recv -- the warm-up times {transport} x {kz sub-blocks
+          in flight} x {event-ordered / in-kernel arrival flags} on the real links (identical checksums required) and keeps the fastest.
   --workload mech   de Geus finite-strain RVE (configs[2] at N = 1: 128^3; configs[4] at N = 8: 256^3), time per CG iteration.
 
 The same data flow runs at every N: the reference's (three transforms per substep, `--carry off`).  The spectral carry-over
@@ -29,7 +34,8 @@ import time
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
+
+torch = None  # imported by main() once this process is known to be a rank (the launcher of a multi-GPU run never needs it)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -197,6 +203,114 @@ class NativeSlabCH:
         return self.c[self.i]
 
 
+
+# ---- multi-GPU launcher: this process starts the ranks and never touches the GPU ----------------------------------------------
+NATIVE_BENCH = os.path.join(ROOT, "marlin_amd", "lib", "marlin-hip-bench")
+_LAUNCH_ENV_DROP = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "MASTER_ADDR",
+                    "MASTER_PORT", "GROUP_WORLD_SIZE", "ROLE_NAME", "OMP_NUM_THREADS")
+
+
+def _child_env():
+    env = {k: v for k, v in os.environ.items() if k not in _LAUNCH_ENV_DROP and not k.startswith("TORCHELASTIC_")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+def _run_child(cmd, timeout_s):
+    """Run one stage of the chain as a fresh child (its own process group, so that exactly what was started can be ended on a
+    time-out); returns (rc, parsed JSON line or None, tail of the output)."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_child_env(), cwd=ROOT, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout_s)
+        rc = p.returncode
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        rc = -9
+    line = None
+    for ln in reversed(out.strip().splitlines()):
+        if ln.startswith("{"):
+            try:
+                line = json.loads(ln)
+                break
+            except ValueError:
+                pass
+    return rc, line, (err or "")[-600:] + (out or "")[-300:]
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_multi(args, argv):
+    """--gpus N > 1 without --inner.  Stand-alone: run the chain.  Under torch.distributed.run (the driver's launch form): rank 0 runs
+    the chain, the other launcher ranks wait for its verdict file; none of them initialises the GPU."""
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    verdict = None
+    if world_env > 1:
+        verdict = f"/tmp/mrlbench_verdict_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}_{os.getppid()}"
+        if rank != 0:
+            t0 = time.time()
+            while not os.path.exists(verdict):
+                time.sleep(0.2)
+                if time.time() - t0 > 3600:
+                    sys.exit("bench.py: no verdict from rank 0 within an hour")
+            with open(verdict) as f:
+                sys.exit(0 if f.read().strip() == "ok" else 1)
+    stages, tried, result = [], [], None
+    if args.driver == "native":
+        n = args.n or (256 if args.workload == "ch" else 128)
+        cmd = [NATIVE_BENCH, f"workload={args.workload}", f"gpus={args.gpus}", f"steps={args.steps}", f"warmup={args.warmup}", f"grid={n}",
+               f"global_grid={args.global_grid}", f"nsub={args.nsub}", f"carry={1 if args.carry == 'on' else 0}", f"exp={args.exp}",
+               f"variants={0 if args.no_variants else 1}", f"profile_steps={args.profile_steps}",
+               f"substeps_per_call={args.substeps_per_call}",
+               "transport=" + {"tune": "tune", "auto": "auto", "peer_store": "1", "peer_copy": "2", "rccl": "3"}[args.transport]]
+        if args.device >= 0:
+            cmd.append(f"device={args.device}")
+        stages.append(("native C++ rank processes (marlin-hip-bench)", cmd))
+    passthrough = [a for a in argv if a != "--inner"]
+    for drv in (["native", "python"] if args.driver == "native" else ["python"]):
+        rest, skip = [], False
+        for a in passthrough:       # replace any --driver the caller gave
+            if skip:
+                skip = False
+                continue
+            if a == "--driver":
+                skip = True
+                continue
+            if a.startswith("--driver="):
+                continue
+            rest.append(a)
+        stages.append((f"torch.distributed.run children, --driver {drv}",
+                       [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.abspath(__file__)] + rest + ["--inner", "--driver", drv]))
+    for name, cmd in stages:
+        if not os.path.exists(cmd[0]):
+            tried.append({"stage": name, "skipped": f"{cmd[0]} has not been built"})
+            continue
+        rc, line, tail = _run_child(cmd, args.stage_timeout)
+        if rc == 0 and line is not None:
+            result = line
+            result["launcher"] = {"started_by": "bench.py (this process made no GPU call)" + (", rank 0 of torch.distributed.run" if world_env > 1 else ""),
+                                  "ranks_run_as": name, "earlier_stages": tried}
+            break
+        tried.append({"stage": name, "rc": rc, "tail": tail[-400:]})
+    if verdict:
+        with open(verdict + ".tmp", "w") as f:
+            f.write("ok" if result is not None else "failed")
+        os.replace(verdict + ".tmp", verdict)
+    if result is None:
+        print(json.dumps({"error": "no stage of the multi-GPU launch chain produced a result", "stages": tried}), file=sys.stderr, flush=True)
+        sys.exit(1)
+    print(json.dumps(result), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,16 +340,26 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the carry-over variant and the local-only timing")
     ap.add_argument("--exp", type=int, default=0, help="MRL_OPT_EXPERIMENT mask (A/B runs)")
     ap.add_argument("--force-slab", action="store_true", help="run the slab pipeline with one rank: a single-GPU check of the N > 1 code path")
+    ap.add_argument("--inner", action="store_true",
+                    help="this process IS one rank of a torch.distributed.run job (set by the launcher for its fallback stages)")
+    ap.add_argument("--device", type=int, default=-1, help="put every rank on this GPU (functional runs on a one-GPU box); default: local rank")
+    ap.add_argument("--stage-timeout", type=float, default=1500.0, help="launcher: seconds before a stage of the chain is given up")
     args = ap.parse_args()
+
+    if args.gpus > 1 and not args.inner:
+        return launch_multi(args, sys.argv[1:])
+
+    global torch
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        sys.exit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if world != args.gpus:
+        sys.exit(f"--inner: WORLD_SIZE = {world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    dev = local_rank % torch.cuda.device_count()   # (several ranks on one GPU only in single-GPU smoke runs)
+    dev = args.device if args.device >= 0 else local_rank % torch.cuda.device_count()   # (several ranks on one GPU only in single-GPU smoke runs)
     torch.cuda.set_device(dev)
 
     from marlin_amd import api
@@ -394,12 +518,20 @@ def main():
         if not native_failed:
             solver.reset()
             prof_ctx = solver.ctx
-        elif comm is not None:      # (a failed setup has closed its objects already)
-            torch.cuda.synchronize()
-            solver.ctx.close()
-            comm.close()
-            comm = None
-    if slab and (args.driver == "python" or native_failed):
+        else:
+            # the library's transports do not work in these processes.  The torch.distributed driver (marlin_amd/slab.py) is only
+            # ever entered through an explicit --driver python, and in FRESH processes (a communicator whose IPC mapping was abandoned
+            # may hold runtime locks): every rank leaves with the same code and the launcher starts the next stage of its chain.
+            if comm is not None:      # (a failed setup has closed its objects already)
+                torch.cuda.synchronize()
+                solver.ctx.close()
+                comm.close()
+            dist.destroy_process_group()
+            if rank == 0:
+                print(json.dumps({"error": "native driver unusable in torch.distributed.run children", "transport": transport_report}),
+                      file=sys.stderr, flush=True)
+            sys.exit(3)
+    if slab and args.driver == "python":
         from marlin_amd.slab import SlabCahnHilliard, SlabExchange
         nsub = args.nsub or 2
         if args.compute_stream == "high":

@@ -82,8 +82,13 @@ int mrl_set_stream(mrl_ctx *ctx, void *stream);
 enum mrl_option {
   MRL_OPT_EXPERIMENT = 0,  /* bit mask of A/B switches for kernel variants (tools/ only; 0 = product defaults) */
   MRL_OPT_SLAB_NSUB = 1,   /* kz sub-blocks the slab Cahn-Hilliard substep is pipelined over (default 1) */
-  MRL_OPT_SLAB_CARRY = 2   /* 1: spectral carry-over inside mrl_ch_substeps on slab contexts (see mrl_slab_ch_*; default 0 =
+  MRL_OPT_SLAB_CARRY = 2,  /* 1: spectral carry-over inside mrl_ch_substeps on slab contexts (see mrl_slab_ch_*; default 0 =
                               the reference's data flow, three slab transposes per substep) */
+  MRL_OPT_VERIFY_EXCHANGE = 3,   /* debug, slab contexts with a communicator: after every arrival wait the receive buffer is re-read
+                                    once with plain loads and once with system-scope loads behind a system-scope acquire; 64-bit
+                                    words that differ (a stale cache line on the consumer's GPU: the memory-model argument of the
+                                    peer-store transport, DESIGN.md 4.1, does not hold on this node) are counted */
+  MRL_OPT_VERIFY_MISMATCHES = 4  /* get: that count for the communicator of this context (synchronises); set 0: reset */
 };
 int mrl_ctx_set_option(mrl_ctx *ctx, int option, int64_t value);
 int64_t mrl_ctx_get_option(const mrl_ctx *ctx, int option);
@@ -121,16 +126,23 @@ int mrl_comm_set_timeout(mrl_comm *comm, double seconds); /* bound of every host
 /* after MRL_ERR_COMM from a device-side wait (a peer's data never arrived) every later wait returns at once; once the caller has
  * destroyed the contexts whose exchanges were in flight (all ranks), this clears the condition so that the communicator can be
  * used again, e.g. with another transport */
-int mrl_comm_reset_error(mrl_comm *comm);
+int mrl_comm_reset_error(mrl_comm *comm); /* COLLECTIVE: also repairs the host barrier a timed-out rank left behind */
 int mrl_comm_barrier(mrl_comm *comm);                     /* host barrier over the ranks */
 /* in-place all-reduce of n <= 16 host values: op 0 sum (rank order: identical bits on every rank), 1 min, 2 max */
 int mrl_comm_allreduce(mrl_comm *comm, double *h_values, int32_t n, int32_t op);
+/* one JSON object describing what the communicator runs on: HIP runtime version and the libamdhip64 actually mapped into the
+ * process, whether HIP IPC is usable, the RCCL library loaded (it is looked up beside that libamdhip64 first), its version and the
+ * rank count RCCL itself reports for the communicator (-1: not initialised), exchange channels in use */
+int mrl_comm_describe(const mrl_comm *comm, char *buf, size_t cap);
 /* cumulative count of exchanges posted and payload bytes sent to OTHER ranks by this rank */
 int mrl_comm_stats(const mrl_comm *comm, int64_t *n_exchanges, double *bytes_sent);
 /* host half of the transport alone, no GPU needed: `rounds` x { barrier, all-gather, sum / min / max all-reduce } over the bootstrap
  * segment "/name", each checked against its closed form; MRL_OK on every rank if all of them agree (CPU test tier) */
 int mrl_comm_bootstrap_selftest(const char *name, int32_t nranks, int32_t rank, int32_t rounds);
-/* slab contexts only; nranks / rank must match; the context does not own the communicator */
+/* slab contexts only; nranks / rank must match; the context does not own the communicator.  Lifetime: destroy the contexts first
+ * (mrl_ctx_destroy tears their exchange pipelines down: collective over the ranks), then the communicator.  If the communicator is
+ * destroyed first, mrl_comm_destroy tears the pipelines of every attached context down itself and detaches them; those contexts
+ * stay valid for rank-local work and for mrl_ctx_destroy. */
 int mrl_ctx_attach_comm(mrl_ctx *ctx, mrl_comm *comm);
 
 /* Local extents: DomainAction::getLocalShape / getReciprocalShape and the partition getters
@@ -466,7 +478,9 @@ int mrl_sum(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_out);
 /* TensorExtremeValuePostprocessor (src/postprocessors/TensorExtremeValuePostprocessor.C:30-44) */
 int mrl_minmax(mrl_ctx *ctx, const double *d_a, int64_t n, double *h_min, double *h_max);
 /* DomainAction::average over the grid of a value-major field [grid][ncomp] -> h_out[ncomp]; on a slab context the
- * local sum divided by the GLOBAL point count (the sum over ranks is the average) */
+ * local sum divided by the GLOBAL point count (the sum over ranks is the average).
+ * With a communicator attached to a slab context, mrl_dot / mrl_norm2 / mrl_sum / mrl_minmax / mrl_average return GLOBAL values
+ * (any ncomp); mrl_histogram stays rank-local (the reference gathers its vector postprocessors itself). */
 int mrl_average(mrl_ctx *ctx, const double *d_a, int64_t ncomp, double *h_out);
 /* TensorHistogram (src/vectorpostprocessors/TensorHistogram.C:48-79, at::native::histogramdd with explicit edges): counts of the
  * values of d_a per bin [edge_i, edge_i+1) -- the last bin closed on the right, values outside the edges ignored.  h_edges has

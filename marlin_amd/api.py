@@ -69,7 +69,7 @@ def ch_params(family=FE_DOUBLE_WELL, coef=(0.1,), mobility=0.2, kappa=-0.001, pa
 
 TRANSPORT_AUTO, TRANSPORT_PEER_STORE, TRANSPORT_PEER_COPY, TRANSPORT_RCCL = 0, 1, 2, 3
 TRANSPORT_NAMES = {1: "peer_store", 2: "peer_copy", 3: "rccl"}
-OPT_EXPERIMENT, OPT_SLAB_NSUB, OPT_SLAB_CARRY = 0, 1, 2
+OPT_EXPERIMENT, OPT_SLAB_NSUB, OPT_SLAB_CARRY, OPT_VERIFY_EXCHANGE, OPT_VERIFY_MISMATCHES = 0, 1, 2, 3, 4
 
 
 class Comm:
@@ -121,7 +121,16 @@ class Comm:
         self._check(self.lib.mrl_comm_stats(self.h, C.byref(n), C.byref(b)))
         return {"exchanges": n.value, "bytes_sent": b.value}
 
+    def describe(self) -> dict:
+        """what the communicator runs on (HIP runtime / library actually mapped, RCCL library and the rank count it reports, ...)"""
+        import json
+        buf = C.create_string_buffer(4096)
+        self._check(self.lib.mrl_comm_describe(self.h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
     def close(self):
+        """collective.  Contexts still attached lose their exchange pipelines here (mrl_comm_destroy tears them down and detaches
+        them); they stay valid for rank-local work and for Context.close()."""
         if getattr(self, "h", None):
             self.lib.mrl_comm_destroy(self.h)
             self.h = None
@@ -183,10 +192,14 @@ class Context:
     def attach_comm(self, comm: Optional["Comm"]):
         """slab contexts: hand the exchanges to the library (mrl_ch_substeps, mrl_fft_*, mrl_mech_newton_cg, reductions become global)"""
         self._check(self.lib.mrl_ctx_attach_comm(self.h, comm.h if comm is not None else None))
+        self._comm = comm   # (keeps the communicator object alive as long as this context refers to it)
         self._comm = comm
 
     def set_option(self, option: int, value: int):
         self._check(self.lib.mrl_ctx_set_option(self.h, option, int(value)))
+
+    def get_option(self, option: int) -> int:
+        return int(self.lib.mrl_ctx_get_option(self.h, option))
 
     @property
     def spec_pitch(self) -> int:

@@ -75,6 +75,15 @@ struct mrl_comm {
   int *d_status = nullptr;
   long long wall_khz = 100000;
   int next_channel = 0;
+  // channels returned by destroyed exchanges (every rank creates and destroys exchanges in the same order, so the lists agree);
+  // a reused channel continues from the epoch its previous owner reached: flags left in the row can never satisfy a new wait
+  std::vector<int> free_channels;
+  std::vector<uint64_t> chan_epoch = std::vector<uint64_t>(mrl::kMaxChannels, 0);
+  // contexts whose exchange pipelines live on this communicator (mrl_ctx_attach_comm): torn down by mrl_comm_destroy if the
+  // caller destroys the communicator first
+  std::vector<mrl_ctx *> attached;
+  // MRL_OPT_VERIFY_EXCHANGE: mismatches between plain and system-scope re-reads of the receive buffers (device counter)
+  unsigned long long *d_verify = nullptr;
   std::vector<hipStream_t> side;    // side streams (copy engines / RCCL)
   hipEvent_t ev_prod = nullptr;
   // device mailbox for scalar all-reduces: [2][kMaxRanks][16] doubles, symmetric
@@ -124,6 +133,11 @@ SignalArgs xchg_signal_args(const mrl_comm *c, const Xchg *x, unsigned int nbloc
 int xchg_wait(mrl_comm *c, Xchg *x, hipStream_t stream);
 // xchg_post + xchg_wait back to back; fuse: one flag kernel for both when the table is direct (peer stores)
 int xchg_post_wait(mrl_comm *c, Xchg *x, hipStream_t stream, bool fuse);
+// debug (MRL_OPT_VERIFY_EXCHANGE): after xchg_wait, re-read the whole receive buffer with plain loads and with system-scope loads
+// behind a system-scope acquire; differing 64-bit words are counted in c->d_verify (a stale cache line on the consumer's side)
+int xchg_verify(mrl_comm *c, Xchg *x, hipStream_t stream);
+int comm_alloc_channel(mrl_comm *c);
+void comm_free_channel(mrl_comm *c, int channel, uint64_t epoch);
 // true when producers should scatter through the table straight into the peers' buffers
 inline bool xchg_direct(const mrl_comm *c) { return c->transport == MRL_TRANSPORT_PEER_STORE; }
 

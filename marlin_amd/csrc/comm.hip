@@ -22,6 +22,7 @@
 #include <new>
 
 #include "comm_dev.h"
+#include "mrl_internal.h"
 
 namespace mrl {
 
@@ -57,7 +58,8 @@ struct ShmSeg {
   std::atomic<uint32_t> attached;
   std::atomic<uint32_t> bar_count, bar_gen;
   std::atomic<int32_t> abort_flag;
-  unsigned char pad[48];
+  std::atomic<uint32_t> reset_count, reset_gen;  // rendezvous of mrl_comm_reset_error (independent of the barrier words it repairs)
+  unsigned char pad[40];
   unsigned char blob[kMaxRanks][256];
   double red[2][kMaxRanks][16];
 };
@@ -148,8 +150,10 @@ static bool ipc_open_bounded(mrl_comm *c, hipIpcMemHandle_t handle, void **mappe
     job->cv.notify_all();
   }).detach();
   std::unique_lock<std::mutex> lk(job->mu);
-  if (!job->cv.wait_for(lk, std::chrono::duration<double>(c->timeout_s), [&] { return job->done; })) {
-    comm_error(c, MRL_ERR_COMM, "hipIpcOpenMemHandle did not return within %.0f s (rank %d)", c->timeout_s, c->rank);
+  // half the communicator's time-out: the peers wait for this rank's verdict in a host barrier bounded by the whole of it, so the
+  // verdict "mapping failed" always arrives before their barrier gives up and poisons the bootstrap segment
+  if (!job->cv.wait_for(lk, std::chrono::duration<double>(0.5 * c->timeout_s), [&] { return job->done; })) {
+    comm_error(c, MRL_ERR_COMM, "hipIpcOpenMemHandle did not return within %.0f s (rank %d)", 0.5 * c->timeout_s, c->rank);
     return false;
   }
   if (job->err != hipSuccess) {
@@ -371,6 +375,24 @@ int comm_allreduce_device(mrl_comm *c, hipStream_t stream, const double *d_in, i
   return MRL_OK;
 }
 
+// path of the shared object mapped into this process whose file name contains `needle` (/proc/self/maps)
+static std::string mapped_library(const char *needle) {
+  std::string found;
+  if (FILE *f = std::fopen("/proc/self/maps", "r")) {
+    char line[4096];
+    while (std::fgets(line, sizeof line, f)) {
+      const char *p = std::strchr(line, '/');
+      if (p && std::strstr(p, needle)) {
+        found = p;
+        while (!found.empty() && (found.back() == '\n' || found.back() == ' ')) found.pop_back();
+        break;
+      }
+    }
+    std::fclose(f);
+  }
+  return found;
+}
+
 // ---- RCCL (loaded at run time) ------------------------------------------------------------------------------------------
 struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *);
@@ -381,15 +403,27 @@ struct RcclApi {
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
   const char *(*GetErrorString)(ncclResult_t);
+  ncclResult_t (*GetVersion)(int *) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
 };
 
 static int rccl_init(mrl_comm *c) {
   if (c->rccl_comm) return MRL_OK;
   int ok = 1;
   if (!c->rccl_lib) {
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) {
-      c->rccl_lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    // RCCL must match the HIP runtime this process has actually loaded: inside a PyTorch process that is the runtime bundled with the
+    // wheel (torch/lib/libamdhip64.so, with its own librccl.so next to it), in a native process the system ROCm.  Look beside the
+    // mapped libamdhip64 first, then along the default search path.
+    std::vector<std::string> names;
+    const std::string hip = mapped_library("libamdhip64.so");
+    if (!hip.empty()) {
+      const std::string dir = hip.substr(0, hip.rfind('/') + 1);
+      names.push_back(dir + "librccl.so.1");
+      names.push_back(dir + "librccl.so");
+    }
+    names.insert(names.end(), {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"});
+    for (const std::string &n : names) {
+      c->rccl_lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (c->rccl_lib) break;
     }
     if (c->rccl_lib) {
@@ -404,6 +438,9 @@ static int rccl_init(mrl_comm *c) {
       MRL_SYM(Recv, "ncclRecv");
       MRL_SYM(GetErrorString, "ncclGetErrorString");
 #undef MRL_SYM
+      // optional (reporting only)
+      *reinterpret_cast<void **>(&c->rccl->GetVersion) = dlsym(c->rccl_lib, "ncclGetVersion");
+      *reinterpret_cast<void **>(&c->rccl->CommCount) = dlsym(c->rccl_lib, "ncclCommCount");
     } else {
       ok = 0;
     }
@@ -429,11 +466,26 @@ static int rccl_init(mrl_comm *c) {
 }
 
 // ---- exchange endpoints -------------------------------------------------------------------------------------------------
+int comm_alloc_channel(mrl_comm *c) {
+  if (!c->free_channels.empty()) {
+    const int ch = c->free_channels.back();
+    c->free_channels.pop_back();
+    return ch;
+  }
+  if (c->next_channel >= kMaxChannels) return -1;
+  return c->next_channel++;
+}
+void comm_free_channel(mrl_comm *c, int channel, uint64_t epoch) {
+  if (channel < 0 || channel >= kMaxChannels) return;
+  if (epoch > c->chan_epoch[channel]) c->chan_epoch[channel] = epoch;
+  c->free_channels.push_back(channel);
+}
+
 int xchg_create(mrl_comm *c, Xchg *x, const size_t *send_cnt, const size_t *recv_cnt, bool want_send_buffer) {
   const int P = c->nranks;
-  if (c->next_channel >= kMaxChannels) return comm_error(c, MRL_ERR_UNSUPPORTED, "out of exchange channels");
-  x->channel = c->next_channel++;
-  x->epoch = 0;
+  x->channel = comm_alloc_channel(c);
+  if (x->channel < 0) return comm_error(c, MRL_ERR_UNSUPPORTED, "out of exchange channels");
+  x->epoch = c->chan_epoch[x->channel];  // (a reused channel: flags of its previous owner are <= this epoch)
   x->send_cnt.assign(send_cnt, send_cnt + P);
   x->recv_cnt.assign(recv_cnt, recv_cnt + P);
   x->send_off.assign(P, 0);
@@ -497,6 +549,7 @@ void xchg_destroy(mrl_comm *c, Xchg *x) {
   if (x->rccl_done) (void)hipEventDestroy(x->rccl_done);
   if (x->release_ev) (void)hipEventDestroy(x->release_ev);
   for (auto &e : x->copy_done) (void)hipEventDestroy(e);
+  comm_free_channel(c, x->channel, x->epoch);
   *x = Xchg();
 }
 
@@ -631,6 +684,32 @@ int xchg_wait(mrl_comm *c, Xchg *x, hipStream_t stream) {
   return MRL_OK;
 }
 
+// MRL_OPT_VERIFY_EXCHANGE: what this kernel's plain loads see (it sits where the consuming pass sits: behind the arrival wait, so its
+// launch performs the same acquire) against what system-scope loads see after an explicit system-scope acquire inside the kernel.
+// On one GPU, and wherever the release / acquire chain of DESIGN 4.1 holds, the two agree word for word.
+__global__ void __launch_bounds__(256) k_comm_verify(const unsigned long long *buf, size_t nwords, unsigned long long *bad) {
+  unsigned long long mine = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned long long plain = buf[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: invalidates what this CU / XCD may hold of non-coherent lines
+    const unsigned long long sys = __hip_atomic_load(buf + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    mine += plain != sys;
+  }
+  if (mine) atomicAdd(bad, mine);
+}
+
+int xchg_verify(mrl_comm *c, Xchg *x, hipStream_t stream) {
+  if (!x->recv.local || !x->recv.bytes) return MRL_OK;
+  if (!c->d_verify) {
+    COMM_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_verify), sizeof(unsigned long long)));
+    COMM_HIP(c, hipMemset(c->d_verify, 0, sizeof(unsigned long long)));
+  }
+  hipLaunchKernelGGL(k_comm_verify, dim3(1024), dim3(256), 0, stream, static_cast<const unsigned long long *>(x->recv.local), x->recv.bytes / 8,
+                     c->d_verify);
+  COMM_HIP(c, hipGetLastError());
+  return MRL_OK;
+}
+
 }  // namespace mrl
 
 using namespace mrl;
@@ -642,6 +721,17 @@ const char *mrl_comm_last_error(const mrl_comm *c) { return c ? c->err.c_str() :
 void mrl_comm_destroy(mrl_comm *c) {
   if (!c) return;
   (void)hipDeviceSynchronize();
+  // contexts still attached: their exchange pipelines live in this communicator's symmetric memory.  Tear them down here (collective,
+  // like this call) and detach, so that a context destroyed AFTER its communicator finds nothing left to free.
+  {
+    const std::vector<mrl_ctx *> att = c->attached;
+    for (mrl_ctx *ctx : att) {
+      slab_pipes_destroy(ctx);
+      ctx->comm = nullptr;
+    }
+    c->attached.clear();
+  }
+  if (c->d_verify) (void)hipFree(c->d_verify);
   if (c->rccl_comm && c->rccl) c->rccl->CommDestroy(static_cast<ncclComm_t>(c->rccl_comm));
   delete c->rccl;
   // (the RCCL library stays loaded: unloading it under a live HIP runtime is not safe)
@@ -757,7 +847,10 @@ int mrl_comm_create(mrl_comm **out, const char *name, int32_t nranks, int32_t ra
   // flags + mailboxes.  If HIP IPC is unusable every rank agrees to fall back to RCCL (sym_alloc's verdict is collective).
   c->transport = MRL_TRANSPORT_PEER_STORE;
   int rc = sym_alloc(c, sizeof(unsigned long long) * kMaxChannels * kFlagRow, &c->flags, true);
-  if (rc == MRL_ERR_COMM && nranks > 1 && (transport == MRL_TRANSPORT_AUTO || transport == MRL_TRANSPORT_RCCL)) {
+  // "IPC unusable on this node" (every rank agreed on it: fall back to RCCL) is not "the bootstrap died" (a rank timed out in a host
+  // barrier and raised the abort flag: nothing collective can follow)
+  const bool bootstrap_dead = c->shm && c->shm->abort_flag.load() != 0;
+  if (rc == MRL_ERR_COMM && !bootstrap_dead && nranks > 1 && (transport == MRL_TRANSPORT_AUTO || transport == MRL_TRANSPORT_RCCL)) {
     c->ipc_ok = false;
     c->transport = MRL_TRANSPORT_RCCL;
     rc = MRL_OK;
@@ -774,7 +867,7 @@ int mrl_comm_create(mrl_comm **out, const char *name, int32_t nranks, int32_t ra
       return fail(MRL_ERR_HIP);
     }
   }
-  c->mbox_channel = c->next_channel++;
+  c->mbox_channel = comm_alloc_channel(c);
   if (transport != MRL_TRANSPORT_AUTO && c->ipc_ok) {
     c->transport = transport;
     if (transport == MRL_TRANSPORT_RCCL && (rc = rccl_init(c)) != MRL_OK) return fail(rc);
@@ -847,6 +940,47 @@ int mrl_comm_reset_error(mrl_comm *c) {
   (void)hipDeviceSynchronize();
   if (c->h_status) *c->h_status = 0;
   c->err.clear();
+  if (c->nranks > 1 && c->shm) {
+    // collective: a host barrier that timed out has left the abort flag raised and the barrier count short of a generation.  Every rank
+    // has returned from its failed call by now (that is the contract of this function), so the LAST rank to arrive here repairs the
+    // barrier words and releases the others; the rendezvous uses its own two words.
+    ShmSeg *s = c->shm;
+    const uint32_t gen = s->reset_gen.load(std::memory_order_acquire);
+    if (s->reset_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)c->nranks) {
+      s->reset_count.store(0, std::memory_order_relaxed);
+      s->bar_count.store(0, std::memory_order_relaxed);
+      s->abort_flag.store(0, std::memory_order_relaxed);
+      s->reset_gen.fetch_add(1, std::memory_order_release);
+    } else {
+      const double t0 = now_s();
+      while (s->reset_gen.load(std::memory_order_acquire) == gen) {
+        usleep(50);
+        if (now_s() - t0 > c->timeout_s)
+          return comm_error(c, MRL_ERR_COMM, "mrl_comm_reset_error is collective: only some ranks called it within %.0f s", c->timeout_s);
+      }
+    }
+    c->red_parity = 0;  // (every rank restarts the double-buffered host all-reduce at the same parity)
+  }
+  return MRL_OK;
+}
+
+int mrl_comm_describe(const mrl_comm *c, char *buf, size_t cap) {
+  if (!c || !buf || cap < 2) return MRL_ERR_INVALID;
+  int hip_rt = 0, rccl_v = 0, rccl_n = -1;
+  (void)hipRuntimeGetVersion(&hip_rt);
+  std::string rccl_path;
+  if (c->rccl_lib && c->rccl) {
+    if (c->rccl->GetVersion) c->rccl->GetVersion(&rccl_v);
+    if (c->rccl->CommCount && c->rccl_comm) c->rccl->CommCount(static_cast<ncclComm_t>(c->rccl_comm), &rccl_n);
+    Dl_info info;
+    if (c->rccl->GetUniqueId && dladdr(reinterpret_cast<void *>(c->rccl->GetUniqueId), &info) && info.dli_fname) rccl_path = info.dli_fname;
+  }
+  const std::string hip_lib = mapped_library("libamdhip64.so");
+  std::snprintf(buf, cap,
+                "{\"hip_runtime_version\": %d, \"hip_library\": \"%s\", \"ipc_usable\": %s, \"rccl_loaded\": %s, \"rccl_library\": \"%s\", "
+                "\"rccl_version\": %d, \"rccl_comm_nranks\": %d, \"exchange_channels_in_use\": %d}",
+                hip_rt, hip_lib.c_str(), c->ipc_ok ? "true" : "false", c->rccl_lib ? "true" : "false", rccl_path.c_str(), rccl_v, rccl_n,
+                c->next_channel - (int)c->free_channels.size());
   return MRL_OK;
 }
 

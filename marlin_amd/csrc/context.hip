@@ -350,7 +350,8 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
 void mrl_ctx_destroy(mrl_ctx *c) {
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
-  slab_pipes_destroy(c);
+  slab_pipes_destroy(c);  // (collective on a communicator with several ranks; a communicator destroyed first has done it already)
+  slab_detach_comm(c);
   if (c->d_tabs) hipFree(c->d_tabs);
   for (int a = 0; a < 3; ++a) {
     if (c->ax[a].d_tw) hipFree(c->ax[a].d_tw);
@@ -389,6 +390,10 @@ int mrl_ctx_set_option(mrl_ctx *ctx, int option, int64_t value) {
       ctx->opt_nsub = (int)value;
       return MRL_OK;
     case MRL_OPT_SLAB_CARRY: ctx->opt_carry = value != 0; return MRL_OK;
+    case MRL_OPT_VERIFY_EXCHANGE: ctx->opt_verify = value != 0; return MRL_OK;
+    case MRL_OPT_VERIFY_MISMATCHES:  // (only 0 may be stored: resets the counter)
+      if (value != 0) return set_error(ctx, MRL_ERR_INVALID, "MRL_OPT_VERIFY_MISMATCHES can only be reset to 0");
+      return slab_verify_count(ctx, true) < 0 ? MRL_ERR_HIP : MRL_OK;
     default: return set_error(ctx, MRL_ERR_INVALID, "unknown option %d", option);
   }
 }
@@ -399,6 +404,8 @@ int64_t mrl_ctx_get_option(const mrl_ctx *ctx, int option) {
     case MRL_OPT_EXPERIMENT: return ctx->exp;
     case MRL_OPT_SLAB_NSUB: return ctx->opt_nsub;
     case MRL_OPT_SLAB_CARRY: return ctx->opt_carry;
+    case MRL_OPT_VERIFY_EXCHANGE: return ctx->opt_verify;
+    case MRL_OPT_VERIFY_MISMATCHES: return slab_verify_count(const_cast<mrl_ctx *>(ctx), false);
     default: return 0;
   }
 }

@@ -234,9 +234,14 @@ int write_metadata(mrl_h5 *h) {
     const unsigned char z[8] = {0};
     MRL_TRY(write_at(h, h->eod, z, (size_t)(meta0 - h->eod)));
   }
+  // order: the new metadata block reaches the file before the superblock that points at it
   MRL_TRY(write_at(h, meta0, m.b.data(), m.size()));
+  if (fflush(h->f) != 0) return fail(h, MRL_ERR_IO, "flush of " + h->path + " failed");
   MRL_TRY(write_at(h, 0, sb.b.data(), sb.size()));
   if (fflush(h->f) != 0) return fail(h, MRL_ERR_IO, "flush of " + h->path + " failed");
+  // the block just written is LIVE (the superblock on disk points at it): the next dataset goes behind it, so the file stays valid
+  // and complete up to the last flush at every moment in between (H5Fflush semantics, XDMFTensorOutput.C:244-246)
+  h->eod = eof;
   h->dirty = false;
   return MRL_OK;
 }

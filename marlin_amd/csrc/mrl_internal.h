@@ -105,6 +105,7 @@ struct mrl_ctx {
   int exp = 0;  // experiment switches (MRL_OPT_EXPERIMENT, bit mask): A/B testing of kernel variants inside one process
   int opt_nsub = 1;    // MRL_OPT_SLAB_NSUB
   int opt_carry = 0;   // MRL_OPT_SLAB_CARRY
+  int opt_verify = 0;  // MRL_OPT_VERIFY_EXCHANGE
 
   // multi-GPU (slab contexts): the attached communicator (not owned) and the exchange pipelines built on it (slab_driver.hip)
   mrl_comm *comm = nullptr;
@@ -171,6 +172,8 @@ int ensure_work(mrl_ctx *ctx, int slot, size_t bytes);
 // destination table of a scatter-capable kernel when the chunks go to one contiguous local buffer
 int local_tab(mrl_ctx *ctx, int slot, void *base, size_t stride_bytes, cplx *const **out);
 void slab_pipes_destroy(mrl_ctx *ctx);
+void slab_detach_comm(mrl_ctx *ctx);
+long long slab_verify_count(mrl_ctx *ctx, bool reset);  // MRL_OPT_VERIFY_MISMATCHES: synchronises the stream; -1 on a HIP error
 int slab_comm_check(mrl_ctx *ctx);  // MRL_ERR_COMM if a device-side wait of the attached communicator timed out
 
 // generic pass launcher (fft_generic.hip)

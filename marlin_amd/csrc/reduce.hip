@@ -15,7 +15,9 @@ namespace mrl {
 // DomainAction.C:1564-1567).  op 0 sum, 1 min, 2 max.
 static int global_values(mrl_ctx *ctx, double *h, int n, int op) {
   if (!ctx->comm || ctx->comm->nranks == 1) return MRL_OK;
-  const int rc = comm_allreduce_host(ctx->comm, h, n, op);
+  int rc = MRL_OK;
+  for (int base = 0; base < n && rc == MRL_OK; base += 16)  // (the bootstrap all-reduce carries 16 values per call)
+    rc = comm_allreduce_host(ctx->comm, h + base, n - base < 16 ? n - base : 16, op);
   if (rc != MRL_OK) set_error(ctx, rc, "%s", ctx->comm->err.c_str());
   return rc;
 }

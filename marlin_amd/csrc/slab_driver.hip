@@ -16,6 +16,8 @@
 //
 //   Plain transforms (DomainAction::fft / ifft in FFT_SLAB mode) have no such request / response structure, so their
 //   exchanges use an explicit acknowledgement flag per receive buffer.
+#include <algorithm>
+
 #include "comm.h"
 #include "slab_stages.h"
 
@@ -39,6 +41,7 @@ struct FftPipe {
   Xchg fwd, inv;
   int ack_fwd = -1, ack_inv = -1;  // acknowledgement channels
   unsigned long long ack_fwd_epoch = 0, ack_inv_epoch = 0;
+  unsigned long long ack_fwd_base = 0, ack_inv_base = 0;  // epochs the channels were taken over at (nothing to acquire yet)
 };
 
 struct MechPipe {
@@ -64,6 +67,16 @@ static int comm_fail(mrl_ctx *ctx, int rc) {
     if (rc__ != MRL_OK) return comm_fail(ctx, rc__); \
   } while (0)
 
+long long slab_verify_count(mrl_ctx *ctx, bool reset) {
+  if (!ctx->comm || !ctx->comm->d_verify) return 0;
+  unsigned long long v = 0;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+      hipMemcpy(&v, ctx->comm->d_verify, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  if (reset && hipMemset(ctx->comm->d_verify, 0, sizeof(v)) != hipSuccess) return -1;
+  return (long long)v;
+}
+
 int slab_comm_check(mrl_ctx *ctx) {
   if (!ctx->comm) return MRL_OK;
   return comm_fail(ctx, comm_check(ctx->comm));
@@ -88,6 +101,8 @@ void slab_pipes_destroy(mrl_ctx *ctx) {
   if (ctx->comm) {
     xchg_destroy(ctx->comm, &ctx->pipes->fft.fwd);
     xchg_destroy(ctx->comm, &ctx->pipes->fft.inv);
+    if (ctx->pipes->fft.ack_fwd >= 0) comm_free_channel(ctx->comm, ctx->pipes->fft.ack_fwd, ctx->pipes->fft.ack_fwd_epoch);
+    if (ctx->pipes->fft.ack_inv >= 0) comm_free_channel(ctx->comm, ctx->pipes->fft.ack_inv, ctx->pipes->fft.ack_inv_epoch);
     for (int r = 0; r < 3; ++r) {
       xchg_destroy(ctx->comm, &ctx->pipes->mech.fwd[r]);
       xchg_destroy(ctx->comm, &ctx->pipes->mech.inv[r]);
@@ -97,6 +112,14 @@ void slab_pipes_destroy(mrl_ctx *ctx) {
   }
   delete ctx->pipes;
   ctx->pipes = nullptr;
+}
+
+// the context leaves its communicator's list (mrl_ctx_destroy, re-attachment); the pipes are gone by then
+void slab_detach_comm(mrl_ctx *ctx) {
+  if (!ctx->comm) return;
+  auto &v = ctx->comm->attached;
+  v.erase(std::remove(v.begin(), v.end(), ctx), v.end());
+  ctx->comm = nullptr;
 }
 
 static int need_comm(mrl_ctx *ctx, const char *what) {
@@ -189,17 +212,27 @@ static int post(mrl_ctx *ctx, Xchg *x, bool kernel_signalled, bool local_only) {
   return MRL_OK;
 }
 // post and wait of one exchange back to back (one kz sub-block in flight: nothing is enqueued between them)
+static int verify(mrl_ctx *ctx, Xchg *x) {  // MRL_OPT_VERIFY_EXCHANGE (debug): see xchg_verify
+  if (!ctx->opt_verify) return MRL_OK;
+  ProfScope ps(ctx, "slab_exchange_verify");
+  MRL_COMM(ctx, xchg_verify(ctx->comm, x, ctx->stream));
+  return MRL_OK;
+}
 static int post_wait(mrl_ctx *ctx, Xchg *x, bool local_only) {
   if (local_only) return MRL_OK;
-  ProfScope ps(ctx, "slab_exchange_wait");
-  MRL_COMM(ctx, xchg_post_wait(ctx->comm, x, ctx->stream, !(ctx->exp & 262144)));
-  return MRL_OK;
+  {
+    ProfScope ps(ctx, "slab_exchange_wait");
+    MRL_COMM(ctx, xchg_post_wait(ctx->comm, x, ctx->stream, !(ctx->exp & 262144)));
+  }
+  return verify(ctx, x);
 }
 static int wait(mrl_ctx *ctx, Xchg *x, bool local_only) {
   if (local_only) return MRL_OK;
-  ProfScope ps(ctx, "slab_exchange_wait");
-  MRL_COMM(ctx, xchg_wait(ctx->comm, x, ctx->stream));
-  return MRL_OK;
+  {
+    ProfScope ps(ctx, "slab_exchange_wait");
+    MRL_COMM(ctx, xchg_wait(ctx->comm, x, ctx->stream));
+  }
+  return verify(ctx, x);
 }
 
 // the substep loop of TensorSolver::computeBuffer (TensorSolver.C:93-109) over slab transforms; ring semantics as mrl_ch_substeps
@@ -315,9 +348,11 @@ static int fft_pipe_build(mrl_ctx *ctx) {
       }
       MRL_COMM(ctx, xchg_create(c, dir ? &P.fwd : &P.inv, sb.data(), rb.data(), true));
     }
-    if (c->next_channel + 2 > kMaxChannels) return set_error(ctx, MRL_ERR_UNSUPPORTED, "out of exchange channels");
-    P.ack_fwd = c->next_channel++;
-    P.ack_inv = c->next_channel++;
+    P.ack_fwd = comm_alloc_channel(c);
+    P.ack_inv = comm_alloc_channel(c);
+    if (P.ack_fwd < 0 || P.ack_inv < 0) return set_error(ctx, MRL_ERR_UNSUPPORTED, "out of exchange channels");
+    P.ack_fwd_epoch = P.ack_fwd_base = c->chan_epoch[P.ack_fwd];  // (reused channels continue from their previous owner's epoch)
+    P.ack_inv_epoch = P.ack_inv_base = c->chan_epoch[P.ack_inv];
     P.built = true;
   }
   if (P.transport != c->transport) {
@@ -338,9 +373,9 @@ static int ack_release(mrl_ctx *ctx, int ack_channel, unsigned long long *epoch)
   return MRL_OK;
 }
 // before pushing into the peers' buffers: all of them have released the previous contents
-static int ack_acquire(mrl_ctx *ctx, int ack_channel, unsigned long long epoch) {
+static int ack_acquire(mrl_ctx *ctx, int ack_channel, unsigned long long epoch, unsigned long long base) {
   mrl_comm *c = ctx->comm;
-  if (epoch == 0 || (!c->ipc_ok && c->nranks > 1) || c->transport == MRL_TRANSPORT_RCCL) return MRL_OK;
+  if (epoch == base || (!c->ipc_ok && c->nranks > 1) || c->transport == MRL_TRANSPORT_RCCL) return MRL_OK;
   hipLaunchKernelGGL(k_ack_wait, dim3(1), dim3(64), 0, ctx->stream,
                      static_cast<const unsigned long long *>(c->flags.local) + (size_t)ack_channel * kFlagRow, c->nranks, epoch,
                      c->d_status, (long long)(c->timeout_s * (double)c->wall_khz * 1000.0));
@@ -357,7 +392,7 @@ int slab_fft_forward(mrl_ctx *ctx, const double *d_in, double *d_out, long long 
   for (long long b = 0; b < batch; ++b) {
     MRL_COMM(ctx, xchg_begin(c, &P.fwd, ctx->stream));
     MRL_TRY(slab_fwd_local(ctx, d_in + b * nreal, P.fwd.send));
-    MRL_TRY(ack_acquire(ctx, P.ack_fwd, P.ack_fwd_epoch));
+    MRL_TRY(ack_acquire(ctx, P.ack_fwd, P.ack_fwd_epoch, P.ack_fwd_base));
     MRL_COMM(ctx, xchg_post(c, &P.fwd, ctx->stream));
     MRL_COMM(ctx, xchg_wait(c, &P.fwd, ctx->stream));
     MRL_TRY(slab_fwd_finish(ctx, static_cast<const double *>(P.fwd.recv.local), d_out + 2 * b * nspec));
@@ -375,7 +410,7 @@ int slab_fft_inverse(mrl_ctx *ctx, const double *d_in, double *d_out, long long 
   for (long long b = 0; b < batch; ++b) {
     MRL_COMM(ctx, xchg_begin(c, &P.inv, ctx->stream));
     MRL_TRY(slab_inv_local(ctx, d_in + 2 * b * nspec, P.inv.send));
-    MRL_TRY(ack_acquire(ctx, P.ack_inv, P.ack_inv_epoch));
+    MRL_TRY(ack_acquire(ctx, P.ack_inv, P.ack_inv_epoch, P.ack_inv_base));
     MRL_COMM(ctx, xchg_post(c, &P.inv, ctx->stream));
     MRL_COMM(ctx, xchg_wait(c, &P.inv, ctx->stream));
     MRL_TRY(slab_inv_finish(ctx, static_cast<const double *>(P.inv.recv.local), d_out + b * nreal));
@@ -474,10 +509,12 @@ int slab_gamma_fm(mrl_ctx *ctx, const double *A_fm, double *out_fm, double scale
     MRL_COMM(ctx, xchg_begin(c, &P.fwd_all, st));
     MRL_TRY(slab_gamma_rows_fwd(ctx, A_fm, reinterpret_cast<cplx *const *>(P.fwd_all.d_tab), SignalArgs{}));
     MRL_COMM(ctx, xchg_post_wait(c, &P.fwd_all, st, !(ctx->exp & 262144)));
+    MRL_TRY(verify(ctx, &P.fwd_all));
     MRL_COMM(ctx, xchg_begin(c, &P.inv_all, st));
     MRL_TRY(slab_gamma_rows_mid(ctx, static_cast<const double *>(P.fwd_all.recv.local), reinterpret_cast<cplx *const *>(P.inv_all.d_tab), SignalArgs{},
                                 scale));
     MRL_COMM(ctx, xchg_post_wait(c, &P.inv_all, st, !(ctx->exp & 262144)));
+    MRL_TRY(verify(ctx, &P.inv_all));
     ctx->gamma_dot_nb = 0;
     MRL_TRY(slab_gamma_rows_inv(ctx, static_cast<const double *>(P.inv_all.recv.local), out_fm, dotv_fm));
     if (dotv_fm) {
@@ -496,6 +533,7 @@ int slab_gamma_fm(mrl_ctx *ctx, const double *A_fm, double *out_fm, double scale
   }
   for (int r = 0; r < 3; ++r) {
     MRL_COMM(ctx, xchg_wait(c, &P.fwd[r], st));
+    MRL_TRY(verify(ctx, &P.fwd[r]));
     MRL_COMM(ctx, xchg_begin(c, &P.inv[r], st));
     const SignalArgs sig = xchg_signal_args(c, &P.inv[r], 0);
     MRL_TRY(slab_gamma_row_mid(ctx, static_cast<const double *>(P.fwd[r].recv.local), reinterpret_cast<cplx *const *>(P.inv[r].d_tab), sig, scale));
@@ -504,6 +542,7 @@ int slab_gamma_fm(mrl_ctx *ctx, const double *A_fm, double *out_fm, double scale
   ctx->gamma_dot_nb = 0;
   for (int r = 0; r < 3; ++r) {
     MRL_COMM(ctx, xchg_wait(c, &P.inv[r], st));
+    MRL_TRY(verify(ctx, &P.inv[r]));
     MRL_TRY(slab_gamma_row_inv(ctx, r, static_cast<const double *>(P.inv[r].recv.local), out_fm, dotv_fm));
   }
   if (dotv_fm) {
@@ -566,8 +605,10 @@ int mrl_ctx_attach_comm(mrl_ctx *ctx, mrl_comm *comm) {
   if (ctx->comm && ctx->comm != comm) {
     MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     slab_pipes_destroy(ctx);
+    slab_detach_comm(ctx);
   }
   ctx->comm = comm;
+  if (comm && std::find(comm->attached.begin(), comm->attached.end(), ctx) == comm->attached.end()) comm->attached.push_back(ctx);
   return MRL_OK;
 }
 

@@ -70,7 +70,7 @@ def read_h5(path):
     sb_ver, _, root_ver, _, _, so, sl, _, leaf_k, int_k, flags = struct.unpack_from("<BBBBBBBBHHI", buf, 8)
     _need((sb_ver, root_ver, so, sl, flags) == (0, 0, 8, 8, 0), "superblock fields")
     base, freesp, eof, drv = struct.unpack_from("<QQQQ", buf, 24)
-    _need(base == 0 and freesp == UNDEF and drv == UNDEF and eof == len(buf), f"superblock addresses (eof {eof}, file {len(buf)})")
+    _need(base == 0 and freesp == UNDEF and drv == UNDEF and eof <= len(buf), f"superblock addresses (eof {eof}, file {len(buf)})")  # (data appended since the last flush lies beyond the end-of-file address: libhdf5 accepts that too)
     name_off, root, cache, _, btree, heap = struct.unpack_from("<QQIIQQ", buf, 56)
     _need(name_off == 0 and cache == 1, "root symbol table entry")
     msgs = _messages(buf, root)

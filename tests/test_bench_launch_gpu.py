@@ -1,0 +1,69 @@
+"""bench.py --gpus N starts its own rank processes: the launcher never touches the GPU, the ranks are native
+C++ processes (marlin_amd/lib/marlin-hip-bench) that pick their device from the host-local rank as the reference does
+(src/actions/DomainAction.C:163-199).  On a one-GPU box both ranks share device 0 over HIP IPC: a functional check of the whole
+chain (launch, communicator, tuning phase, timed region, JSON), not a rate."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _last_json(out):
+    for ln in reversed(out.strip().splitlines()):
+        if ln.startswith("{"):
+            return json.loads(ln)
+    raise AssertionError("no JSON line in:\n" + out[-2000:])
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+def test_bench_two_ranks_without_a_launcher():
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--grid", "64", "--steps", "6", "--warmup", "2", "--profile-steps", "2"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["warmup"] == 2 and j["value"] > 0
+    assert j["config"]["grid"] == [64, 128, 64] and j["dtype"] == "f64"
+    ex = j["exchange"]
+    assert ex["ranks"] == 2 and len(ex["devices_per_rank"]) == 2
+    assert ex["bytes_sent_to_peers_per_step_rank0"] > 0 and ex["exchanges_per_step"] >= 3
+    assert ex["transport"]["selected"] in ("peer_store", "peer_copy", "rccl") and ex["transport"]["nsub"] in (1, 2, 4)
+    # every tuned candidate that ran agrees on the field checksum, and the consumers' system-scope re-reads found nothing stale
+    ran = [c for c in ex["transport"]["tuned"] if "ms_per_step" in c]
+    assert len(ran) >= 2 and all(c["checksum_agrees"] for c in ran)
+    assert all(c.get("receive_buffer_reread_mismatches", 0) == 0 for c in ran)
+    assert "exposed_wait_ms_per_step" in ex and "local_kernels_only" in j["variants"]
+    assert j["launcher"]["ranks_run_as"].startswith("native C++ rank processes")
+    assert ex["runtime"]["hip_runtime_version"] > 0 and "libamdhip64" in ex["runtime"]["hip_library"]
+
+
+def test_bench_two_ranks_under_torch_distributed_run():
+    """the driver's launch form: rank 0 of the launcher job starts the native ranks, the other launcher rank waits for its verdict"""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29611", "bench.py", "--gpus", "2", "--grid", "64", "--steps", "4", "--warmup", "1", "--no-variants",
+                        "--transport", "peer_store", "--profile-steps", "2"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 2 and j["exchange"]["transport"]["selected"] == "peer_store"
+    assert "rank 0 of torch.distributed.run" in j["launcher"]["started_by"]
+
+
+def test_bench_mech_two_ranks_without_a_launcher():
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "mech", "--gpus", "2", "--grid", "32", "--steps", "2"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["grid"] == [32, 64, 32] and j["steps"] > 0
+    assert j["exchange"]["ranks"] == 2 and j["exchange"]["bytes_sent_to_peers_per_step_rank0"] > 0
+    ran = [c for c in j["exchange"]["transport"]["tuned"] if "ms_per_cg_iteration" in c]
+    assert ran and max(c["norm_F"] for c in ran) - min(c["norm_F"] for c in ran) <= 1e-9 * ran[0]["norm_F"]

@@ -110,3 +110,33 @@ def test_errors(tmp_path):
     assert sorted(read_h5(tmp_path / "e.h5")) == ["c.0"]
     with pytest.raises(MarlinHipError):
         H5File(tmp_path / "no_such_dir" / "x.h5")
+
+
+def test_file_stays_valid_between_a_write_and_the_next_flush(tmp_path):
+    """a dataset written after a flush used to overwrite the metadata block the on-disk superblock points at, so the
+    file (and every frame flushed before) was unreadable until the next flush.  The reference flushes once per output step
+    (XDMFTensorOutput.C:244-246) precisely so that a crash, or a reader, in mid-frame finds the earlier frames."""
+    p = tmp_path / "midframe.h5"
+    rng = np.random.default_rng(3)
+    a0, a1, a2 = rng.standard_normal((4, 5)), rng.standard_normal((4, 5)), rng.standard_normal((300,))
+    f = H5File(p)
+    f.write("a.0", a0)
+    f.flush()
+    assert np.array_equal(read_h5(p)["a.0"], a0)
+    f.write("a.1", a1)                         # no flush yet: the file on disk still describes exactly {a.0}
+    got = read_h5(p)
+    assert sorted(got) == ["a.0"] and np.array_equal(got["a.0"], a0)
+    if H5DUMP:
+        assert np.array_equal(_h5dump(p, "a.0", a0.dtype, a0.shape), a0)
+    f.write("big.1", a2)
+    got = read_h5(p)
+    assert sorted(got) == ["a.0"]
+    f.flush()
+    got = read_h5(p)
+    assert sorted(got) == ["a.0", "a.1", "big.1"] and np.array_equal(got["a.1"], a1) and np.array_equal(got["big.1"], a2)
+    f.close()
+    got = read_h5(p)
+    assert sorted(got) == ["a.0", "a.1", "big.1"] and np.array_equal(got["a.0"], a0)
+    if H5DUMP:
+        for k, a in (("a.0", a0), ("a.1", a1), ("big.1", a2)):
+            assert np.array_equal(_h5dump(p, k, a.dtype, a.shape), a), k
