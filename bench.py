@@ -340,6 +340,8 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the carry-over variant and the local-only timing")
     ap.add_argument("--exp", type=int, default=0, help="MRL_OPT_EXPERIMENT mask (A/B runs)")
     ap.add_argument("--force-slab", action="store_true", help="run the slab pipeline with one rank: a single-GPU check of the N > 1 code path")
+    ap.add_argument("--dense-spectra", action="store_true",
+                    help="A/B: keep the solver's spectral arrays dense (MRL_FLAG_DENSE_SPECTRA) instead of the padded x planes")
     ap.add_argument("--inner", action="store_true",
                     help="this process IS one rank of a torch.distributed.run job (set by the launcher for its fallback stages)")
     ap.add_argument("--device", type=int, default=-1, help="put every rank on this GPU (functional runs on a one-GPU box); default: local rank")
@@ -552,15 +554,15 @@ def main():
         transport_report = dict(transport_report or {}, selected=f"torch.distributed {args.backend} all_to_all_single")
     if not slab:
         nsub = 0
-        ctx = api.Context(3, shape, L)
+        ctx = api.Context(3, shape, L, dense_spectra=args.dense_spectra)
         if args.exp:
             ctx.set_option(api.OPT_EXPERIMENT, args.exp)
         ic = torch.from_numpy(splitmix64_uniform(npts).reshape(shape))
         c = [ic.cuda(), None]
         c[1] = torch.empty_like(c[0])
-        Nh = [ctx.empty_spec(), ctx.empty_spec()]
+        Nh = [ctx.empty_hist(), ctx.empty_hist()]
         state = {"i": 0, "have_old": False}
-        carried = ctx.empty_spec() if carry else None
+        carried = ctx.empty_hist() if carry else None
         # Nh is the history ring of the AB2 scheme (two arrays): ring["head"] = slot of Nhat_old[0], the substep writes the other
         # slot; TensorBuffer::advanceState between substeps = the written slot becomes the head
         ring = {"head": 1, "n_old": 0}
@@ -676,7 +678,7 @@ def main():
     elif not args.no_variants and not slab and not carry:
         k = min(args.steps, 40)
         reset_serial()
-        carried = ctx.empty_spec()
+        carried = ctx.empty_hist()
         step()
         variants["spectral_carry_over_on"] = {"ms_per_step": timed(k, 1) / k * 1e3, "substeps_per_library_call": 1}
         carried = None

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MRL_ABI_VERSION 2
+#define MRL_ABI_VERSION 3
 
 enum mrl_status {
   MRL_OK = 0,
@@ -66,6 +66,7 @@ typedef struct mrl_domain {
 
 #define MRL_FLAG_OWN_STREAM 1 /* the context creates (and owns) a non-blocking stream; `stream` is ignored */
 #define MRL_FLAG_SLAB 2       /* slab context even with nranks = 1 (the staged mrl_slab_* pipeline on one rank; exchanges are self-copies) */
+#define MRL_FLAG_DENSE_SPECTRA 4 /* the Cahn-Hilliard history arrays of this context are dense [nx][ny][nzc] (see mrl_ch_spec_elems) */
 
 /* ---- context ------------------------------------------------------------------------ */
 int mrl_abi_version(void);
@@ -197,6 +198,19 @@ typedef struct mrl_ch_params {
 
 /* ParsedCompute f'(c) (src/tensor_computes/ParsedCompute.C:184-265) for the built-in families */
 int mrl_ch_mu(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c, double *d_mu, int64_t count);
+
+/* Layout of the spectral arrays that belong to the Cahn-Hilliard solver (d_Nhat_new, d_Nhat_old[], d_Nhat_ring[], d_cbar): they are
+ * produced and consumed by mrl_ch_substep / mrl_ch_substeps only -- the Nhat history (the reference's Mbarmubar states) and the
+ * carried / exported cbar -- and live in a solver-private layout:
+ *   element (ix, iy, kz) at ix * plane_pitch + iy * row_pitch + kz           (complex elements)
+ * mrl_ch_spec_elems = complex elements to allocate per array, mrl_ch_spec_layout = the two pitches.  Generic shapes: dense
+ * (plane_pitch = ny * nzc, row_pitch = nzc).  Serial 3-D contexts on the fused fast path pad the x planes so that the plane pitch is
+ * an odd number of 256-byte pieces: the fused x pass gathers 256-byte pieces one plane apart, and the natural pitch of the
+ * power-of-two grids puts them on a few memory channels only (256^3: 8 of 128; measured -17 % time for the same bytes with one piece
+ * of padding per plane).  Slab contexts: row_pitch = mrl_slab_ch_spec_pitch, plane_pitch = ny * row_pitch.  The padding is never
+ * read.  MRL_FLAG_DENSE_SPECTRA at context creation keeps every context dense (mrl_fft_r2c output can then be used as cbar). */
+int64_t mrl_ch_spec_elems(const mrl_ctx *ctx);
+int mrl_ch_spec_layout(const mrl_ctx *ctx, int64_t *plane_pitch, int64_t *row_pitch);
 
 /* One AdamsBashforthMoulton::substep for the CH system including its root compute group
  * (src/tensor_solver/AdamsBashforthMoulton.C:60-101, src/tensor_computes/ComputeGroup.C:61-84):

@@ -78,6 +78,8 @@ SIGNATURES = {
     "mrl_slab_fwd_finish": (_i32, [_vp, _vp, _vp]),
     "mrl_slab_inv_local": (_i32, [_vp, _vp, _vp]),
     "mrl_slab_inv_finish": (_i32, [_vp, _vp, _vp]),
+    "mrl_ch_spec_elems": (_i64, [_vp]),
+    "mrl_ch_spec_layout": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "mrl_ch_mu": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _i64]),
     "mrl_ch_substep": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _vp, _pp, _i32, _dbl, _vp, _vp, _i32]),
     "mrl_ch_substeps": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _pp, _i32, C.POINTER(_i32), C.POINTER(_i32), _i32, _i32, _i32,
@@ -181,7 +183,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.mrl_abi_version() != 2:
+    if lib.mrl_abi_version() != 3:
         raise RuntimeError("libmarlin_hip.so ABI version mismatch")
     _lib = lib
     return lib

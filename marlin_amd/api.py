@@ -142,7 +142,7 @@ class Context:
     def __init__(self, dim: int, n: Sequence[int], mx: Sequence[float], mn: Sequence[float] = (0.0, 0.0, 0.0),
                  nranks: int = 1, rank: int = 0, weights: Optional[Sequence[int]] = None,
                  spectrum: int = SPECTRUM_HALF, device: Optional[int] = None, use_torch_stream: bool = True,
-                 slab: bool = False):
+                 slab: bool = False, dense_spectra: bool = False):
         self.lib = _lib.load()
         d = MrlDomain()
         d.dim = dim
@@ -158,7 +158,7 @@ class Context:
         d.weights = self._weights
         d.spectrum = spectrum
         d.stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if use_torch_stream else None
-        d.flags = (0 if use_torch_stream else 1) | (2 if slab else 0)  # MRL_FLAG_OWN_STREAM | MRL_FLAG_SLAB
+        d.flags = (0 if use_torch_stream else 1) | (2 if slab else 0) | (4 if dense_spectra else 0)  # MRL_FLAG_OWN_STREAM | _SLAB | _DENSE_SPECTRA
         h = C.c_void_p()
         rc = self.lib.mrl_ctx_create(C.byref(h), C.byref(d))
         if rc != 0:
@@ -214,6 +214,34 @@ class Context:
     def empty_spec(self, *value_dims, batch_first: Optional[int] = None):
         shape = ([batch_first] if batch_first else []) + list(self.recip_shape) + list(value_dims)
         return torch.empty(shape, dtype=torch.complex128, device=self.device)
+
+    @property
+    def spec_elems(self) -> int:
+        """complex elements of one solver-private spectral array (Nhat history, cbar): mrl_ch_spec_elems"""
+        return int(self.lib.mrl_ch_spec_elems(self.h))
+
+    def spec_layout(self):
+        """(plane_pitch, row_pitch) of the solver-private spectral arrays: element (ix, iy, kz) at ix*plane + iy*row + kz"""
+        pl, rw = C.c_int64(), C.c_int64()
+        self._check(self.lib.mrl_ch_spec_layout(self.h, C.byref(pl), C.byref(rw)))
+        return pl.value, rw.value
+
+    def empty_hist(self, zero: bool = False) -> torch.Tensor:
+        """One array of the Cahn-Hilliard solver (an Nhat history entry, cbar / the carried spectrum) in its private layout
+        (mrl_ch_spec_elems / mrl_ch_spec_layout: x planes padded on fused fast-path shapes), returned as a strided VIEW of the
+        reciprocal shape -- its data pointer is what the library takes, `.cpu()` / `.contiguous()` give the dense values."""
+        n = self.spec_elems
+        buf = (torch.zeros if zero else torch.empty)(n, dtype=torch.complex128, device=self.device)
+        return self.hist_view(buf)
+
+    def hist_view(self, buf: torch.Tensor) -> torch.Tensor:
+        plane, row = self.spec_layout()
+        shp = list(self.recip_shape)
+        if self.dim == 3:
+            return torch.as_strided(buf, shp, (plane, row, 1))
+        if self.dim == 2:   # serial 2-D contexts are [1][nx][ny']: one plane
+            return torch.as_strided(buf, shp, (row, 1))
+        return torch.as_strided(buf, shp, (1,))
 
     def reciprocal_axis(self, axis: int) -> torch.Tensor:
         n = self.recip_shape[axis]
@@ -272,15 +300,28 @@ class Context:
                    sub_dt: float, cbar=None, mu=None, carry: int = 0):
         """carry: 0 = the reference's data flow; 1 = same, ubar kept in `cbar`; 2 = `cbar` holds c-hat (the previous ubar) on
         entry and receives the new ubar (spectral carry-over, include/marlin_hip.h)"""
-        arr = (C.c_void_p * max(1, len(Nhat_old)))(*[t.data_ptr() for t in Nhat_old])
-        self._check(self.lib.mrl_ch_substep(self.h, C.byref(p), _ptr(c_in), _ptr(c_out), _ptr(Nhat_new), arr, order,
-                                            sub_dt, _ptr(cbar), _ptr(mu), carry))
+        arr = (C.c_void_p * max(1, len(Nhat_old)))(*[self._hist_ptr(t).value for t in Nhat_old])
+        self._check(self.lib.mrl_ch_substep(self.h, C.byref(p), _ptr(c_in), _ptr(c_out), self._hist_ptr(Nhat_new), arr, order,
+                                            sub_dt, self._hist_ptr(cbar), _ptr(mu), carry))
+
+    def _hist_ptr(self, t):
+        """device pointer of a solver-private spectral array (empty_hist); refuses arrays that are too small for the layout --
+        the kernels would write past their end"""
+        if t is None:
+            return None
+        if not t.is_cuda:
+            raise ValueError("device tensor required (the HIP path has no CPU fallback)")
+        have = t.untyped_storage().nbytes() - t.storage_offset() * t.element_size()
+        if have < 16 * self.spec_elems:
+            raise ValueError(f"history / cbar arrays need mrl_ch_spec_elems = {self.spec_elems} complex values (Context.empty_hist), "
+                             f"this one holds {have // 16}")
+        return C.c_void_p(t.data_ptr())
 
     def ch_substeps(self, p: MrlChParams, c_in, c_out, ring: Sequence[torch.Tensor], head: int, n_old: int, predictor_order: int,
                     count: int, advance: bool, sub_dt: float, mu=None, dt_changed: bool = False):
         """`count` substeps in one call (TensorSolver::computeBuffer's loop) -> (head, n_old) after the call; the newest Nhat is
         in ring[(head + 1) % len(ring)]"""
-        arr = (C.c_void_p * len(ring))(*[t.data_ptr() for t in ring])
+        arr = (C.c_void_p * len(ring))(*[self._hist_ptr(t).value for t in ring])
         h, n = C.c_int32(head), C.c_int32(n_old)
         self._check(self.lib.mrl_ch_substeps(self.h, C.byref(p), _ptr(c_in), _ptr(c_out), arr, len(ring), C.byref(h), C.byref(n),
                                              predictor_order, count, (1 if advance else 0) | (2 if dt_changed else 0), sub_dt, _ptr(mu)))

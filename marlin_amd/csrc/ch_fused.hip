@@ -17,8 +17,9 @@ namespace mrl {
 namespace p2 {
 
 struct FusedArgs {
-  FusedCommon c;      // chat/muhat/ubar in the work layout [x][inner]; Nnew/cbar/Nold dense [x][y][kz]
-  long long inner;    // ny*nzc
+  FusedCommon c;      // chat/muhat/ubar, Nnew/cbar/Nold: all in the solver-private layout [x][plane], rows [y][kz] inside a plane
+  long long inner;    // ny*nzc: valid elements of a plane
+  long long plane;    // elements between two x planes (>= inner; mrl_ctx::spec_plane)
   int nzc;
   const double *kx, *ky, *kz;
 };
@@ -37,16 +38,16 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const
   const long long i = (long long)logical * T + l;
   const bool valid = i < a.inner;
   const long long iv = valid ? i : 0;
-  // byte offset of line element m: (i + (q + m*TPL)*inner) * 16, the same in the work and the dense layout
+  // byte offset of line element m: (i + (q + m*TPL)*plane) * 16, the same for every array of the pass
   cplx *const ubar = a.c.ubar;
   if constexpr (BIG) {  // arrays >= 4 GiB: m * (line stride) is wave-uniform and 64-bit, the rest fits 32 bits (checked by the launcher)
-    const unsigned off0 = (unsigned)((iv + (long long)q * a.inner) * 16);
-    const unsigned long long step = (unsigned long long)(TPL * a.inner) * 16ull;
+    const unsigned off0 = (unsigned)((iv + (long long)q * a.plane) * 16);
+    const unsigned long long step = (unsigned long long)(TPL * a.plane) * 16ull;
     auto off = [=](int m) { return BigOff{(unsigned long long)m * step, off0}; };
     auto stu = [=](int m, cplx val) { stc(ubar, BigOff{(unsigned long long)m * step, off0}, val); };
     ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT, NT, NT>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, stu, W, X, KX);
   } else {
-    const unsigned off0 = (unsigned)(iv + (long long)q * a.inner) * 16u, step = (unsigned)(TPL * a.inner) * 16u;
+    const unsigned off0 = (unsigned)(iv + (long long)q * a.plane) * 16u, step = (unsigned)(TPL * a.plane) * 16u;
     auto off = [=](int m) { return off0 + (unsigned)m * step; };
     auto stu = [=](int m, cplx val) { stc(ubar, off0 + (unsigned)m * step, val); };
     ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT, NT, NT>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, stu, W, X, KX);
@@ -89,7 +90,7 @@ static int launch_xfused_v(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
 #endif
 template <int N, int ORDER, bool SPEC_C, int PRE = (Plan<N>::ns >= 3 ? Plan<N>::P / MRL_XFUSED_PRE3_DIV : Plan<N>::P / 2)>
 static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
-  if (16.0 * (double)N * (double)a.inner >= 4294967296.0) {   // one array is 4 GiB or more: 64-bit uniform part of the offsets
+  if (16.0 * (double)N * (double)a.plane >= 4294967296.0) {   // one array is 4 GiB or more: 64-bit uniform part of the offsets
     if constexpr (big_capable<N>() && !SPEC_C) {
       return launch_xfused_v<N, ORDER, SPEC_C, nt_capable<N>(), PRE, true>(ctx, a, tw);
     } else {
@@ -97,7 +98,7 @@ static int launch_xfused(mrl_ctx *ctx, const FusedArgs &a, const cplx *tw) {
     }
   }
   if constexpr (nt_capable<N>()) {
-    const double array_bytes = 16.0 * (double)N * (double)a.inner;
+    const double array_bytes = 16.0 * (double)N * (double)a.plane;
     if (array_bytes >= 96.0e6) return launch_xfused_v<N, ORDER, SPEC_C, true, PRE>(ctx, a, tw);
   }
   return launch_xfused_v<N, ORDER, SPEC_C, false, PRE>(ctx, a, tw);
@@ -125,6 +126,8 @@ bool fast_path_ok(const mrl_ctx *ctx) {
 
 struct Geo {
   long long nx, ny, nz, nzc;
+  long long plane;   // elements between two x planes of the solver-private spectral arrays (= ny * nzc when dense)
+  p2::ZLay zl;       // the same for the z kernels (rows per plane, extra elements per plane)
   const cplx *tw_x, *tw_y;
   const double *kx, *ky, *kz;
 };
@@ -135,6 +138,8 @@ static Geo geo_of(const mrl_ctx *ctx) {
   g.ny = ctx->dim == 3 ? ctx->n[1] : 1;
   g.nz = ctx->n[2];
   g.nzc = ctx->nrec[2];
+  g.plane = ctx->spec_plane ? ctx->spec_plane : g.ny * g.nzc;
+  g.zl = p2::ZLay{(unsigned)g.ny, (unsigned)(g.plane - g.ny * g.nzc)};
   g.tw_x = ctx->ax[ax].d_tw;
   g.tw_y = ctx->ax[1].d_tw;
   g.kx = ctx->d_k[ax];
@@ -144,17 +149,19 @@ static Geo geo_of(const mrl_ctx *ctx) {
 }
 
 // strided pass along internal axis `a` (0 = x, 1 = y) of NF complex [nx][ny][nzc] arrays
+// plane: elements between two x planes of the arrays (0 = dense: the plain transforms on caller arrays)
 static int pass_axis(mrl_ctx *ctx, int axis, bool inv, int nf, const cplx *in0, const cplx *in1, cplx *out0,
-                     cplx *out1, bool reverse = false, long long x0 = 0, long long x1 = -1) {
+                     cplx *out1, bool reverse = false, long long x0 = 0, long long x1 = -1, long long plane = 0) {
   const Geo g = geo_of(ctx);
   if (axis == 1 && g.ny == 1) return MRL_OK;  // 2-D: there is no middle axis
   const long long ny = g.ny, nzc = g.nzc;
+  if (plane == 0) plane = ny * nzc;
   const long long nx = (x1 < 0 ? g.nx : x1) - x0;  // y pass only: restrict to the x planes [x0, x1)
   if (x0 > 0) {
-    in0 += x0 * ny * nzc;
-    out0 += x0 * ny * nzc;
-    if (in1) in1 += x0 * ny * nzc;
-    if (out1) out1 += x0 * ny * nzc;
+    in0 += x0 * plane;
+    out0 += x0 * plane;
+    if (in1) in1 += x0 * plane;
+    if (out1) out1 += x0 * plane;
   }
   p2::PassArgs a{};
   a.in[0] = in0;
@@ -166,13 +173,13 @@ static int pass_axis(mrl_ctx *ctx, int axis, bool inv, int nf, const cplx *in0, 
   if (axis == 1) {
     a.inner = nzc;
     a.outer = nx;
-    a.so_in = a.so_out = ny * nzc;
+    a.so_in = a.so_out = plane;
     a.sn_in = a.sn_out = nzc;
   } else {
     a.inner = ny * nzc;
     a.outer = 1;
     a.so_in = a.so_out = 0;
-    a.sn_in = a.sn_out = ny * nzc;
+    a.sn_in = a.sn_out = plane;
   }
   const cplx *tw = axis == 1 ? g.tw_y : g.tw_x;
   const long long n = axis == 1 ? g.ny : g.nx;
@@ -298,13 +305,14 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
   if (spec && 16.0 * (double)ctx->nrec[0] * (double)ctx->nrec[1] * (double)ctx->nrec[2] >= 4294967296.0)
     return MRL_ERR_UNSUPPORTED;  // (the 64-bit-offset variant of the fused pass exists for the reference's data flow only)
   const Geo g = geo_of(ctx);
-  const long long nx = g.nx, ny = g.ny, nz = g.nz, nzc = g.nzc;
+  const long long nx = g.nx, ny = g.ny, nz = g.nz, nzc = g.nzc, plane = g.plane;
   const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
-  MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nspec));
-  MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nspec));
+  MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nx * plane));
+  MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nx * plane));
   cplx *w_c = reinterpret_cast<cplx *>(ctx->d_work[1]);
   cplx *w_mu = reinterpret_cast<cplx *>(ctx->d_work[2]);
   p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
+  const unsigned lpp = g.zl.lpp, lpad = g.zl.pad;
   const double h = 16.0 * nspec;  // bytes of one complex half-spectrum array
   // A (z pass) and B (y pass) are both local to an x plane and can run chunk by chunk over x, so that B reads what A
   // has just written while it is still in the 256 MB Infinity Cache (B walks its tiles in reverse, starting where A ended)
@@ -314,36 +322,36 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
     const long long x0 = nx * ch / nchunk, x1 = nx * (ch + 1) / nchunk;
     const long long l0 = x0 * ny, nl = (x1 - x0) * ny;
     const double *cin = c_in + l0 * nz;
-    cplx *wc = w_c + l0 * nzc, *wm = w_mu + l0 * nzc;
+    cplx *wc = w_c + x0 * plane, *wm = w_mu + x0 * plane;
     double *muc = mu ? mu + l0 * nz : nullptr;
     if (spec) {  // mu only: two lines per complex transform, one field through the y pass
       {
         ProfScope ps(ctx, "ch_A_z_fwd", (8.0 * nreal + h + (mu ? 8.0 * nreal : 0.0)) / nchunk);
         if (cp.family == MRL_FE_PARSED) {
-          MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 2, cin, wm, nullptr, muc, nl / 2));
+          MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 2, cin, wm, nullptr, muc, nl / 2, lpp, lpad));
         } else if (cp.family == MRL_FE_DOUBLE_WELL) {
-          MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 2, MRL_FE_DOUBLE_WELL>(ctx, cin, wm, nullptr, muc, chp, nl / 2))));
+          MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 2, MRL_FE_DOUBLE_WELL>(ctx, cin, wm, nullptr, muc, chp, nl / 2, g.zl))));
         } else {
-          MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 2, MRL_FE_PFHUB>(ctx, cin, wm, nullptr, muc, chp, nl / 2))));
+          MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 2, MRL_FE_PFHUB>(ctx, cin, wm, nullptr, muc, chp, nl / 2, g.zl))));
         }
       }
       ProfScope ps(ctx, "ch_B_y_fwd", 2.0 * h / nchunk);
-      MRL_TRY(pass_axis(ctx, 1, false, 1, w_mu, nullptr, w_mu, nullptr, true, x0, x1));
+      MRL_TRY(pass_axis(ctx, 1, false, 1, w_mu, nullptr, w_mu, nullptr, true, x0, x1, plane));
       continue;
     }
     {
       ProfScope ps(ctx, "ch_A_z_fwd", (8.0 * nreal + 2.0 * h + (mu ? 8.0 * nreal : 0.0)) / nchunk);
       if (cp.family == MRL_FE_PARSED) {
-        MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 1, cin, wc, wm, muc, nl));
+        MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 1, cin, wc, wm, muc, nl, lpp, lpad));
       } else if (cp.family == MRL_FE_DOUBLE_WELL) {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, cin, wc, wm, muc, chp, nl))));
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, cin, wc, wm, muc, chp, nl, g.zl))));
       } else {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, cin, wc, wm, muc, chp, nl))));
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, cin, wc, wm, muc, chp, nl, g.zl))));
       }
     }
     {
       ProfScope ps(ctx, "ch_B_y_fwd", 4.0 * h / nchunk);
-      MRL_TRY(pass_axis(ctx, 1, false, 2, w_c, w_mu, w_c, w_mu, true, x0, x1));
+      MRL_TRY(pass_axis(ctx, 1, false, 2, w_c, w_mu, w_c, w_mu, true, x0, x1, plane));
     }
   }
   {
@@ -358,6 +366,7 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
     for (int i = 0; i < order; ++i) a.c.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
     for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaAB[order][i];
     a.inner = ny * nzc;
+    a.plane = plane;
     a.nzc = (int)nzc;
     a.kx = g.kx;
     a.ky = g.ky;
@@ -385,12 +394,12 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
   }
   {
     ProfScope ps(ctx, "ch_D_y_inv", 2.0 * h);
-    MRL_TRY(pass_axis(ctx, 1, true, 1, w_c, nullptr, w_c, nullptr));
+    MRL_TRY(pass_axis(ctx, 1, true, 1, w_c, nullptr, w_c, nullptr, false, 0, -1, plane));
   }
   {
     ProfScope ps(ctx, "ch_E_z_inv", h + 8.0 * nreal);
     const double scale = 1.0 / ((double)nx * (double)ny * (double)nz);
-    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w_c, c_out, scale, nx * ny / 2))));
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w_c, c_out, scale, nx * ny / 2, g.zl))));
   }
   return MRL_OK;
 }
@@ -404,11 +413,12 @@ int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c
                       int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu, bool dt_changed) {
   if (!fast_path_ok(ctx)) return MRL_ERR_UNSUPPORTED;
   const Geo g = geo_of(ctx);
-  const long long nx = g.nx, ny = g.ny, nz = g.nz, nzc = g.nzc;
+  const long long nx = g.nx, ny = g.ny, nz = g.nz, nzc = g.nzc, plane = g.plane;
   if ((nx * ny) % 2) return MRL_ERR_UNSUPPORTED;
   const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
-  MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nspec));
-  MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nspec));
+  const unsigned lpp = g.zl.lpp, lpad = g.zl.pad;
+  MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nx * plane));
+  MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nx * plane));
   cplx *w_c = reinterpret_cast<cplx *>(ctx->d_work[1]);
   cplx *w_mu = reinterpret_cast<cplx *>(ctx->d_work[2]);
   p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
@@ -419,25 +429,25 @@ int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c
     if (k == 0) {
       ProfScope ps(ctx, "ch_A_z_fwd", 8.0 * nreal + 2.0 * h + (mu_k ? 8.0 * nreal : 0.0));
       if (cp.family == MRL_FE_PARSED) {
-        MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 1, c_in, w_c, w_mu, mu_k, nx * ny));
+        MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 1, c_in, w_c, w_mu, mu_k, nx * ny, lpp, lpad));
       } else if (cp.family == MRL_FE_DOUBLE_WELL) {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_c, w_mu, mu_k, chp, nx * ny))));
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_c, w_mu, mu_k, chp, nx * ny, g.zl))));
       } else {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, w_c, w_mu, mu_k, chp, nx * ny))));
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, w_c, w_mu, mu_k, chp, nx * ny, g.zl))));
       }
     } else {
       ProfScope ps(ctx, "ch_EA_z_inv_fwd", 3.0 * h + (mu_k ? 8.0 * nreal : 0.0));
       if (cp.family == MRL_FE_PARSED) {
-        MRL_TRY(parsed_z_inv_fwd_launch(ctx, cp.parsed, (int)nz, w_c, w_c, w_mu, mu_k, scale, nx * ny / 2));
+        MRL_TRY(parsed_z_inv_fwd_launch(ctx, cp.parsed, (int)nz, w_c, w_c, w_mu, mu_k, scale, nx * ny / 2, false, lpp, lpad));
       } else if (cp.family == MRL_FE_DOUBLE_WELL) {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_DOUBLE_WELL>(ctx, w_c, w_c, w_mu, mu_k, chp, scale, nx * ny / 2))));
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_DOUBLE_WELL>(ctx, w_c, w_c, w_mu, mu_k, chp, scale, nx * ny / 2, g.zl))));
       } else {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_PFHUB>(ctx, w_c, w_c, w_mu, mu_k, chp, scale, nx * ny / 2))));
+        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_PFHUB>(ctx, w_c, w_c, w_mu, mu_k, chp, scale, nx * ny / 2, g.zl))));
       }
     }
     {
       ProfScope ps(ctx, "ch_B_y_fwd", 4.0 * h);
-      MRL_TRY(pass_axis(ctx, 1, false, 2, w_c, w_mu, w_c, w_mu, true));
+      MRL_TRY(pass_axis(ctx, 1, false, 2, w_c, w_mu, w_c, w_mu, true, 0, -1, plane));
     }
     const int order = (dt_changed && k < pred) ? 0 : (*n_old < pred ? *n_old : pred);   // AdamsBashforthMoulton.C:90-91
     const int slot_new = (*head + 1) % ring_size;
@@ -451,6 +461,7 @@ int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c
       for (int i = 0; i < order; ++i) a.c.Nold[i] = reinterpret_cast<const cplx *>(ring[((*head - i) % ring_size + ring_size) % ring_size]);
       for (int i = 0; i <= order; ++i) a.c.coef[i] = sub_dt * kBetaAB[order][i];
       a.inner = ny * nzc;
+      a.plane = plane;
       a.nzc = (int)nzc;
       a.kx = g.kx;
       a.ky = g.ky;
@@ -468,7 +479,7 @@ int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c
     }
     {
       ProfScope ps(ctx, "ch_D_y_inv", 2.0 * h);
-      MRL_TRY(pass_axis(ctx, 1, true, 1, w_c, nullptr, w_c, nullptr));
+      MRL_TRY(pass_axis(ctx, 1, true, 1, w_c, nullptr, w_c, nullptr, false, 0, -1, plane));
     }
     if (advance && k < count - 1) {   // TensorSolver.C:105-106
       *head = slot_new;
@@ -476,7 +487,7 @@ int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c
     }
   }
   ProfScope ps(ctx, "ch_E_z_inv", h + 8.0 * nreal);
-  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w_c, c_out, scale, nx * ny / 2))));
+  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w_c, c_out, scale, nx * ny / 2, g.zl))));
   return MRL_OK;
 }
 

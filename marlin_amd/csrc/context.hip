@@ -332,6 +332,15 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
   }
   if (rc != MRL_OK) return fail(rc);
 
+  // solver-private spectral layout of the fused serial path (mrl_ch_spec_elems): x planes padded to an odd number of 256-byte pieces
+  if (!c->slab && c->dim == 3 && !(dom->flags & MRL_FLAG_DENSE_SPECTRA) && fast_path_ok(c) && (c->n[0] * c->n[1]) % 2 == 0) {
+    const long long inner = c->n[1] * c->nrec[2];
+    long long plane = (inner + 15) / 16 * 16;
+    if ((plane / 16) % 2 == 0) plane += 16;
+    // (arrays of 4 GiB and more keep the dense layout: their 64-bit offset variants are rare enough not to be doubled)
+    if (16.0 * (double)c->n[0] * (double)plane < 4294967296.0) c->spec_plane = plane;
+  }
+
   if (hipMalloc(reinterpret_cast<void **>(&c->d_red), sizeof(double) * 4096) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void **>(&c->h_red), sizeof(double) * 64) != hipSuccess ||
       hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
@@ -382,6 +391,8 @@ int mrl_ctx_set_option(mrl_ctx *ctx, int option, int64_t value) {
   if (!ctx) return MRL_ERR_INVALID;
   switch (option) {
     case MRL_OPT_EXPERIMENT:
+      if ((value & 2048) && ctx->spec_plane)
+        return set_error(ctx, MRL_ERR_UNSUPPORTED, "experiment 2048 (any-length path on a planned shape) needs a context created with MRL_FLAG_DENSE_SPECTRA");
       ctx->exp = (int)value;
       g_mrl_trace = (value & (1 << 20)) ? 1 : 0;
       return MRL_OK;
@@ -408,6 +419,23 @@ int64_t mrl_ctx_get_option(const mrl_ctx *ctx, int option) {
     case MRL_OPT_VERIFY_MISMATCHES: return slab_verify_count(const_cast<mrl_ctx *>(ctx), false);
     default: return 0;
   }
+}
+
+int64_t mrl_ch_spec_elems(const mrl_ctx *ctx) {
+  if (!ctx) return 0;
+  if (ctx->slab && ctx->dim == 3) return ctx->nrec[0] * ctx->nrec[1] * mrl_slab_ch_spec_pitch(ctx);
+  if (ctx->spec_plane) return ctx->n[0] * ctx->spec_plane;
+  return ctx->nrec[0] * ctx->nrec[1] * ctx->nrec[2];
+}
+
+int mrl_ch_spec_layout(const mrl_ctx *ctx, int64_t *plane_pitch, int64_t *row_pitch) {
+  if (!ctx) return MRL_ERR_INVALID;
+  // (internal axes: serial contexts right-align the user axes, so the last two internal axes are always the rows of a plane)
+  int64_t row = ctx->nrec[2];
+  if (ctx->slab && ctx->dim == 3) row = mrl_slab_ch_spec_pitch(ctx);
+  if (row_pitch) *row_pitch = row;
+  if (plane_pitch) *plane_pitch = ctx->spec_plane ? ctx->spec_plane : ctx->nrec[1] * row;
+  return MRL_OK;
 }
 
 int mrl_set_stream(mrl_ctx *ctx, void *stream) {

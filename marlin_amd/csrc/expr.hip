@@ -863,16 +863,17 @@ static ChDevHost parsed_chdev(const mrl_parsed *p) {
 }
 
 int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const double *in, cplx *out0, cplx *out1, double *mu_out,
-                        long long nlines) {
+                        long long nlines, unsigned lay_lpp, unsigned lay_pad) {
   int T = 0, NT = 0;
   MRL_TRY(plan_shape(ctx, N, &T, &NT));
   if (mode != 1 && mode != 2) return set_error(ctx, MRL_ERR_INVALID, "parsed z pass: mode %d", mode);
   hipFunction_t fn;
   MRL_TRY(parsed_z_kernel(ctx, p, N, mode, &fn));
-  // the argument block of k_z_fwd(const double*, cplx*, cplx*, double*, ChDev, long long, const cplx*)
+  // the argument block of k_z_fwd(const double*, cplx*, cplx*, double*, ChDev, long long, const cplx*, ZLay)
   ChDevHost chp = parsed_chdev(p);
   const cplx *tw = ctx->ax[2].d_tw;
-  void *params[] = {&in, &out0, &out1, &mu_out, &chp, &nlines, &tw};
+  struct { unsigned lpp, pad; } zl = {lay_lpp, lay_pad};  // = p2::ZLay
+  void *params[] = {&in, &out0, &out1, &mu_out, &chp, &nlines, &tw, &zl};
   const int LP = N + N / 16;
   const size_t lds = sizeof(cplx) * (size_t)(N + T * LP);
   const long long nb = (nlines + T - 1) / T;
@@ -880,16 +881,17 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const doub
   return MRL_OK;
 }
 
-// k_z_inv_fwd<N, PARSED>(const cplx*, cplx*, cplx*, double*, ChDev, double, long long, const cplx*); nlines = line pairs
+// k_z_inv_fwd<N, PARSED>(const cplx*, cplx*, cplx*, double*, ChDev, double, long long, const cplx*, ZLay); nlines = line pairs
 int parsed_z_inv_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const cplx *in, cplx *out0, cplx *out1, double *mu_out,
-                            double scale, long long nlines, bool mu_only) {
+                            double scale, long long nlines, bool mu_only, unsigned lay_lpp, unsigned lay_pad) {
   int T = 0, NT = 0;
   MRL_TRY(plan_shape(ctx, N, &T, &NT));
   hipFunction_t fn;
   MRL_TRY(parsed_z_kernel(ctx, p, N, mu_only ? 4 : 3, &fn));
   ChDevHost chp = parsed_chdev(p);
   const cplx *tw = ctx->ax[2].d_tw;
-  void *params[] = {&in, &out0, &out1, &mu_out, &chp, &scale, &nlines, &tw};
+  struct { unsigned lpp, pad; } zl = {lay_lpp, lay_pad};  // = p2::ZLay
+  void *params[] = {&in, &out0, &out1, &mu_out, &chp, &scale, &nlines, &tw, &zl};
   const int LP = N + N / 16;
   const size_t lds = sizeof(cplx) * (size_t)(N + T * LP);
   const long long nb = (nlines + T - 1) / T;

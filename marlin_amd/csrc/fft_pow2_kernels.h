@@ -17,6 +17,18 @@ struct ChDev {
   double k[8];  // named constants of a parsed free energy (MRL_FE_PARSED)
 };
 
+// Solver-private spectral layout of the fused serial path: rows of NZC complex values, `lpp` rows per x plane, and every plane `pad`
+// elements longer than lpp * NZC.  The pad makes the stride between consecutive x planes an ODD number of 256-byte pieces: the x
+// passes gather 256-byte pieces one plane apart, and with the natural pitch of the power-of-two grids (256^3: 2064 pieces) they fall
+// on 8 of the memory channels only (tools/ldsdma_probe.hip: the same bytes move in 67 us with the dense pitch and in 56 us with one
+// piece of padding per plane).  pad = 0: dense.
+struct ZLay {
+  unsigned lpp, pad;
+};
+__device__ __forceinline__ long long zrow(long long row, int nzc, ZLay z) {
+  return row * nzc + (z.pad ? (long long)((unsigned)row / z.lpp) * z.pad : 0ll);
+}
+
 // MRL_FE_PARSED: the chemical potential generated from the user's expression (expr.hip); it only exists in the
 // run-time compiled (hiprtc) instance of k_z_fwd, where its definition is appended to these headers
 __device__ double mrl_user_mu(double c, const double *k);
@@ -49,7 +61,7 @@ __device__ __forceinline__ double mu_eval(const ChDev &p, double c) {
 template <int N, int MODE, int FAM>
 __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_fwd(const double *__restrict__ in, cplx *__restrict__ out0,
                                                cplx *__restrict__ out1, double *__restrict__ mu_out, ChDev chp,
-                                               long long nlines, const cplx *__restrict__ tw) {
+                                               long long nlines, const cplx *__restrict__ tw, ZLay zl) {
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = ZPlan<N>::T, NZC = N / 2 + 1;
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -108,8 +120,8 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_fwd(const double *__restr
   for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
   __syncthreads();
   if (!valid) return;
-  cplx *o0 = (MODE != 1) ? out0 + (2 * L) * NZC : out0 + L * NZC;
-  cplx *o1 = (MODE != 1) ? out0 + (2 * L + 1) * NZC : out1 + L * NZC;
+  cplx *o0 = (MODE != 1) ? out0 + zrow(2 * L, NZC, zl) : out0 + zrow(L, NZC, zl);
+  cplx *o1 = (MODE != 1) ? out0 + zrow(2 * L + 1, NZC, zl) : out1 + zrow(L, NZC, zl);
 #pragma unroll
   for (int m = 0; m <= P / 2; ++m) {
     const int k = q + m * TPL;
@@ -128,7 +140,8 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_fwd(const double *__restr
 template <int N, bool DOT = false>
 __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const cplx *__restrict__ in, double *__restrict__ out, double scale,
                                                long long nlines, const cplx *__restrict__ tw,
-                                               const double *__restrict__ dotv = nullptr, double *__restrict__ partial = nullptr) {
+                                               const double *__restrict__ dotv = nullptr, double *__restrict__ partial = nullptr,
+                                               ZLay zl = ZLay{0u, 0u}) {
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = ZPlan<N>::T, NZC = N / 2 + 1;
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,8 +154,8 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const cplx *__restric
   tw_issue<N>(twr, tw);
   cplx v[P];
   {
-    const cplx *A = in + (2 * (valid ? L : 0)) * NZC;
-    const cplx *B = A + NZC;
+    const cplx *A = in + zrow(2 * (valid ? L : 0), NZC, zl);
+    const cplx *B = in + zrow(2 * (valid ? L : 0) + 1, NZC, zl);
     cplx av[P], bv[P];
 #pragma unroll
     for (int m = 0; m < P; ++m) {
@@ -219,7 +232,7 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const cplx *__restric
 template <int N, int FAM, bool MU_ONLY = false>
 __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const cplx *__restrict__ in, cplx *__restrict__ out0,
                                                                 cplx *__restrict__ out1, double *__restrict__ mu_out, ChDev chp,
-                                                                double scale, long long nlines, const cplx *__restrict__ tw) {
+                                                                double scale, long long nlines, const cplx *__restrict__ tw, ZLay zl) {
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = ZPlan<N>::T, NZC = N / 2 + 1;
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -232,8 +245,8 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const cplx *__res
   tw_issue<N>(twr, tw);
   cplx v[P];
   {
-    const cplx *A = in + (2 * (valid ? L : 0)) * NZC;
-    const cplx *B = A + NZC;
+    const cplx *A = in + zrow(2 * (valid ? L : 0), NZC, zl);
+    const cplx *B = in + zrow(2 * (valid ? L : 0) + 1, NZC, zl);
     cplx av[P], bv[P];
 #pragma unroll
     for (int m = 0; m < P; ++m) {
@@ -275,7 +288,7 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const cplx *__res
     for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
     __syncthreads();
     if (valid) {
-      cplx *o0 = out0 + (2 * L) * NZC, *o1 = o0 + NZC;
+      cplx *o0 = out0 + zrow(2 * L, NZC, zl), *o1 = out0 + zrow(2 * L + 1, NZC, zl);
 #pragma unroll
       for (int m = 0; m <= P / 2; ++m) {
         const int k = q + m * TPL;
@@ -314,7 +327,7 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const cplx *__res
     for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
     __syncthreads();
     if (valid) {
-      cplx *o0 = out0 + (2 * L + half) * NZC, *o1 = out1 + (2 * L + half) * NZC;
+      cplx *o0 = out0 + zrow(2 * L + half, NZC, zl), *o1 = out1 + zrow(2 * L + half, NZC, zl);
 #pragma unroll
       for (int m = 0; m <= P / 2; ++m) {
         const int k = q + m * TPL;

@@ -17,7 +17,7 @@ inline int set_lds_attr(mrl_ctx *ctx, K kernel, size_t lds) {
 // nlines = number of complex transforms (MODE 0: pairs of real lines; MODE 1: one CH line each)
 template <int N, int MODE, int FAM>
 inline int launch_z_fwd(mrl_ctx *ctx, const double *in, cplx *o0, cplx *o1, double *mu, const ChDev &chp,
-                        long long nlines) {
+                        long long nlines, ZLay zl = ZLay{0u, 0u}) {
   static bool attr = false;
   constexpr size_t lds = lds_line<N>();
   if (!attr) {
@@ -27,13 +27,13 @@ inline int launch_z_fwd(mrl_ctx *ctx, const double *in, cplx *o0, cplx *o1, doub
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
   hipLaunchKernelGGL((k_z_fwd<N, MODE, FAM>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, nlines,
-                     ctx->ax[2].d_tw);
+                     ctx->ax[2].d_tw, zl);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
 
 template <int N>
-inline int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale, long long nlines) {
+inline int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale, long long nlines, ZLay zl = ZLay{0u, 0u}) {
   static bool attr = false;
   constexpr size_t lds = lds_line<N>();
   if (!attr) {
@@ -43,7 +43,7 @@ inline int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale,
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
   hipLaunchKernelGGL((k_z_inv<N, false>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
-                     ctx->ax[2].d_tw, nullptr, nullptr);
+                     ctx->ax[2].d_tw, nullptr, nullptr, zl);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
@@ -51,7 +51,7 @@ inline int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale,
 // nlines = number of line PAIRS (= complex inverse transforms)
 template <int N, int FAM, bool MU_ONLY = false>
 inline int launch_z_inv_fwd(mrl_ctx *ctx, const cplx *in, cplx *o0, cplx *o1, double *mu, const ChDev &chp, double scale,
-                            long long nlines) {
+                            long long nlines, ZLay zl = ZLay{0u, 0u}) {
   static bool attr = false;
   constexpr size_t lds = lds_line<N>();
   if (!attr) {
@@ -61,7 +61,7 @@ inline int launch_z_inv_fwd(mrl_ctx *ctx, const cplx *in, cplx *o0, cplx *o1, do
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
   hipLaunchKernelGGL((k_z_inv_fwd<N, FAM, MU_ONLY>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, scale,
-                     nlines, ctx->ax[2].d_tw);
+                     nlines, ctx->ax[2].d_tw, zl);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
@@ -79,7 +79,7 @@ inline int launch_z_inv_dot(mrl_ctx *ctx, const cplx *in, double *out, double sc
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
   hipLaunchKernelGGL((k_z_inv<N, true>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
-                     ctx->ax[2].d_tw, dotv, partial);
+                     ctx->ax[2].d_tw, dotv, partial, ZLay{0u, 0u});
   MRL_HIP(ctx, hipGetLastError());
   *nblocks = (int)nb;
   return MRL_OK;

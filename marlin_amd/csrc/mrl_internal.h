@@ -106,6 +106,10 @@ struct mrl_ctx {
   int opt_nsub = 1;    // MRL_OPT_SLAB_NSUB
   int opt_carry = 0;   // MRL_OPT_SLAB_CARRY
   int opt_verify = 0;  // MRL_OPT_VERIFY_EXCHANGE
+  // serial contexts on the fused fast path: elements between two x planes of the solver-private spectral arrays (work arrays, Nhat
+  // history, cbar).  ny * nzc rounded up so that the plane pitch is an ODD number of 256-byte pieces (fft_pow2_kernels.h: ZLay);
+  // 0 = dense (every other context, and MRL_FLAG_DENSE_SPECTRA)
+  long long spec_plane = 0;
 
   // multi-GPU (slab contexts): the attached communicator (not owned) and the exchange pipelines built on it (slab_driver.hip)
   mrl_comm *comm = nullptr;
@@ -204,10 +208,11 @@ struct ChP {
 int parsed_check_mu(mrl_ctx *ctx, const mrl_parsed *p);                     // one real input, real output, same context
 int parsed_eval1(mrl_parsed *p, const double *c, double *mu, long long n);  // mu = expression(c), pointwise
 // k_z_fwd<N, mode, PARSED> (mode 1: c and mu per line, 2: mu of two lines) with the generated chemical potential compiled in (hiprtc)
+// lay_lpp / lay_pad: p2::ZLay of the spectral side (rows per x plane, extra elements per plane; 0, 0 = dense)
 int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const double *in, cplx *out0, cplx *out1, double *mu_out,
-                        long long nlines);
+                        long long nlines, unsigned lay_lpp = 0, unsigned lay_pad = 0);
 int parsed_z_inv_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const cplx *in, cplx *out0, cplx *out1, double *mu_out, double scale,
-                            long long nlines, bool mu_only = false);
+                            long long nlines, bool mu_only = false, unsigned lay_lpp = 0, unsigned lay_pad = 0);
 
 // power-of-two fast path (ch_fused.hip)
 bool fast_path_ok(const mrl_ctx *ctx);

@@ -860,6 +860,7 @@ int main(int argc, char ** argv)
       hi.push_back(m.size() > 2 && m.substr(m.size() - 2) == "pi" ? std::atof(m.c_str()) * M_PI : argd(mx[d], 1.0));
     }
     DomainAction::Parallel par;
+    par.dense_spectra = arg("dense_spectra", "false") == "true";
     if (arg("parallel_mode", "NONE") == "FFT_SLAB")
     {
       par.mode = DomainAction::ParallelMode::FFT_SLAB;

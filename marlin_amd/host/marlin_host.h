@@ -141,6 +141,9 @@ struct DomainParallel
   std::string job;  ///< identifies the job on the node (the MOOSE shim broadcasts one string over MPI)
   int transport = MRL_TRANSPORT_AUTO;
   int device = -1;  ///< HIP device of this rank (-1: the current one)
+  /// the Cahn-Hilliard solver's spectral arrays (Mbarmubar states, cbar) dense [nx][ny][nzc] instead of the library's private layout
+  /// (mrl_ch_spec_elems: x planes padded on fused fast-path grids): needed when another object reads them
+  bool dense_spectra = false;
 };
 
 /// DomainAction as a math service.  parallel_mode = FFT_SLAB (DomainAction.C:510-566): this process is rank `rank` of `nranks`
@@ -172,7 +175,7 @@ public:
     d.rank = 0;
     d.spectrum = MRL_SPECTRUM_HALF;
     d.stream = nullptr;  // the HIP null stream: hipMemcpy/hipMemset of this layer are ordered with the kernels
-    d.flags = 0;
+    d.flags = par.dense_spectra ? MRL_FLAG_DENSE_SPECTRA : 0;
     const bool slab = par.mode == ParallelMode::FFT_SLAB;
     if (slab)
     {
@@ -180,7 +183,7 @@ public:
         mooseError("Dimension must be 2 or 3 for slab decomposition.");  // DomainAction.C:514-515
       d.nranks = par.nranks;
       d.rank = par.rank;
-      d.flags = MRL_FLAG_SLAB;
+      d.flags |= MRL_FLAG_SLAB;
       // 3-D keeps the r2c transform along z (half the exchange volume of the reference's c2c, identical fields);
       // 2-D uses the reference's full c2c layout (DomainAction.C:279-281)
       d.spectrum = dim == 3 ? MRL_SPECTRUM_HALF : MRL_SPECTRUM_FULL;
@@ -207,7 +210,7 @@ public:
       _recip_begin.push_back(kb[i]);
     }
     // the Cahn-Hilliard solver's own spectral arrays (history ring) may carry a padded last-axis pitch on slab contexts
-    _n_recip_solver = slab && dim == 3 ? _n_recip / kn[dim - 1] * mrl_slab_ch_spec_pitch(_ctx) : _n_recip;
+    _n_recip_solver = mrl_ch_spec_elems(_ctx);
   }
   ~DomainAction()
   {
@@ -454,6 +457,8 @@ public:
       paramError("predictor_order", "predictor_order > 0 & predictor_order <= 5");
     if (p.spectral_carry && p.publish_cbar)
       paramError("spectral_carry", "cbar is not materialised separately when it is carried over");
+    if (p.publish_cbar && _domain.getSolverReciprocalSize() != _domain.getReciprocalSize())
+      paramError("publish_cbar", "cbar would be published in the solver's private (padded) layout: create the Domain with dense_spectra = true");
     if (_domain.isSlab())
     {
       if (p.publish_cbar)

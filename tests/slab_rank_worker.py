@@ -126,7 +126,7 @@ def run_chbench(job, P, r, kv):
     want = torch.empty(shape, dtype=torch.float64, device="cuda")
     if not noref:
         serial = api.Context(3, shape, L, device=0)
-        ring = [serial.empty_spec(), serial.empty_spec()]
+        ring = [serial.empty_hist(), serial.empty_hist()]
         serial.ch_substeps(p, c0.cuda(), want, ring, 1, 0, 2, steps, True, 1e-3)
         serial.sync()
         mark("serial reference done")

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in marlin_hip.h but not exported"
     assert set(_lib.SIGNATURES) == declared
-    assert lib.mrl_abi_version() == 2
+    assert lib.mrl_abi_version() == 3
 
 
 def test_partition_matches_reference_helper():

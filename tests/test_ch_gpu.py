@@ -13,7 +13,7 @@ def _run_hip_ch(ctx, p, c0, nsteps, substeps, dt, pred=1, want_mu=False, carry=F
     """TensorSolver::computeBuffer loop with the history rules of TensorProblem::advanceState (host logic only).
     carry: spectral carry-over (first substep MRL_CARRY_OUT, then MRL_CARRY_IN on the same array)"""
     c = c0.cuda()
-    carried = ctx.empty_spec() if carry else None
+    carried = ctx.empty_hist() if carry else None
     nsub_done = 0
     hist = []
     Nhat = None
@@ -38,7 +38,7 @@ def _run_hip_ch(ctx, p, c0, nsteps, substeps, dt, pred=1, want_mu=False, carry=F
         sub_dt = dt / substeps
         for s in range(substeps):
             order = min(len(hist), pred)
-            Nnew = ctx.empty_spec()
+            Nnew = ctx.empty_hist()
             cn = torch.empty_like(c)
             ctx.ch_substep(p, c, cn, Nnew, hist[:order], order, sub_dt, mu=mu, cbar=carried,
                            carry=0 if not carry else (1 if nsub_done == 0 else 2))
@@ -133,8 +133,8 @@ def test_ch_fused_fast_path_outputs(shape):
     r3, N3, _, _ = mo.ch_substep_ops(r2, Mbar, Lbar, [N2, N1], 2e-3, 2, mo.mu_double_well, dom)
     p = ch_params()
     c = c0.cuda()
-    Na, Nb, Nc = ctx.empty_spec(), ctx.empty_spec(), ctx.empty_spec()
-    cbar, mu = ctx.empty_spec(), torch.empty_like(c)
+    Na, Nb, Nc = ctx.empty_hist(), ctx.empty_hist(), ctx.empty_hist()
+    cbar, mu = ctx.empty_hist(), torch.empty_like(c)
     c1, c2, c3 = torch.empty_like(c), torch.empty_like(c), torch.empty_like(c)
     ctx.ch_substep(p, c, c1, Na, [], 0, 2e-3, cbar=cbar, mu=mu)
     sc = cb1.abs().max().item()
@@ -167,7 +167,7 @@ def test_ch_multi_substep_call(shape, pred):
     sub_dt, substeps = 2e-3, 7
     # reference: one mrl_ch_substep per substep with the host-side history logic (two time steps: the first never advances)
     states, mu_ref = _run_hip_ch(ctx, p, c0.cpu(), 2, substeps, sub_dt * substeps, pred=pred - 1, want_mu=True)
-    ring = [ctx.empty_spec() for _ in range(pred)]
+    ring = [ctx.empty_hist() for _ in range(pred)]
     head, n_old = 0, 0
     c, mu = c0.clone(), torch.empty_like(c0)
     for step in range(2):
@@ -197,7 +197,7 @@ def test_ch_adaptive_dt_restarts_the_order(shape):
     dts, substeps, pred = [1e-3, 1e-3, 2e-3, 2e-3, 5e-4], 4, 3
     dom = mo.Domain(dim, list(shape), L)
     ref = mo.CahnHilliardABM(dom, c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=substeps, predictor_order=pred)
-    ring = [ctx.empty_spec() for _ in range(pred)]
+    ring = [ctx.empty_hist() for _ in range(pred)]
     head, n_old, dt_old = 0, 0, None
     c = c0.cuda()
     for step, dt in enumerate(dts):
@@ -234,7 +234,7 @@ def test_config_a_pfhub_1a_128():
     substeps, pred = 1000, 2
     ref = mo.CahnHilliardABM(dom, c0, 5.0, -10.0, lambda c: mo.mu_pfhub(c, 5.0, 0.3, 0.7), substeps=substeps, predictor_order=pred)
     p = ch_params(FE_PFHUB, (5.0, 0.3, 0.7), mobility=5.0, kappa=-10.0)
-    ring = [ctx.empty_spec() for _ in range(pred)]
+    ring = [ctx.empty_hist() for _ in range(pred)]
     head, n_old = 0, 0
     c = c0.cuda()
 

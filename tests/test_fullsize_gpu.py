@@ -45,7 +45,7 @@ def test_ch_substep_fused_vs_operator_sequence_and_conservation(ctx256):
     p = ch_params()
     dt = 1e-3
     c0 = _field(3)
-    N0, N1, cbar = ctx256.empty_spec(), ctx256.empty_spec(), ctx256.empty_spec()
+    N0, N1, cbar = ctx256.empty_hist(), ctx256.empty_hist(), ctx256.empty_hist()
     c1, c2, mu = torch.empty_like(c0), torch.empty_like(c0), torch.empty_like(c0)
     ctx256.ch_substep(p, c0, c1, N0, [], 0, dt)
     ctx256.ch_substep(p, c1, c2, N1, [N0], 1, dt, cbar=cbar, mu=mu)
@@ -60,7 +60,7 @@ def test_ch_substep_fused_vs_operator_sequence_and_conservation(ctx256):
     assert (N1 - Nhat).abs().max().item() <= 1e-13 * max(1.0, Nhat.abs().max().item())
     Lbar = (k2 * k2 * (-0.001)).contiguous()
     ubar = ctx256.empty_spec()
-    ctx256.kspace_abm(ubar, cbar_ref, [Nhat.contiguous(), N0], [dt * 1.5, dt * -0.5], Lbar, dt)
+    ctx256.kspace_abm(ubar, cbar_ref, [Nhat.contiguous(), N0.contiguous()], [dt * 1.5, dt * -0.5], Lbar, dt)   # (N0: solver layout -> dense)
     c2_ref = ctx256.ifft(ubar)
     assert (c2 - c2_ref).abs().max().item() <= 1e-13
     # conservation of mass (the k = 0 mode has Mbar = Lbar = 0) and boundedness
@@ -84,7 +84,7 @@ def test_slab_pipeline_equals_serial_at_full_size(ctx256):
     for s in solvers:
         s.advance_state()
     _substep_all(solvers)
-    N0, N1 = ctx256.empty_spec(), ctx256.empty_spec()
+    N0, N1 = ctx256.empty_hist(), ctx256.empty_hist()
     c1, c2 = torch.empty_like(c0), torch.empty_like(c0)
     ctx256.ch_substep(p, c0, c1, N0, [], 0, 1e-3)
     ctx256.ch_substep(p, c1, c2, N1, [N0], 1, 1e-3)
@@ -117,7 +117,7 @@ def test_slab_bench_configuration_equals_serial(P):
     del solvers
     torch.cuda.empty_cache()
     ctx = Context(3, list(shape), L)
-    ring = [ctx.empty_spec(), ctx.empty_spec()]
+    ring = [ctx.empty_hist(), ctx.empty_hist()]
     want = torch.empty_like(c0)
     ctx.ch_substeps(ch_params(), c0, want, ring, 1, 0, 2, 4, True, 1e-3)
     assert (got - want).abs().max().item() <= 1e-13
@@ -172,7 +172,7 @@ def test_headline_256_two_ab_substeps_vs_oracle():
     ctx = Context(3, shape, L)
     p = ch_params()
     c = c0.cuda()
-    ring = [ctx.empty_spec(), ctx.empty_spec()]
+    ring = [ctx.empty_hist(), ctx.empty_hist()]
     out = torch.empty_like(c)
     ctx.ch_substeps(p, c, out, ring, 1, 0, 2, 2, True, 1e-3)
     assert (out.cpu() - r2).abs().max().item() <= 1e-13
@@ -205,7 +205,7 @@ def test_512_two_ab_substeps_vs_oracle_serial_and_slab_pipeline():
     c = c0.cuda()
     out = torch.empty_like(c)
     ctx = Context(3, shape, L)
-    ring = [ctx.empty_spec(), ctx.empty_spec()]
+    ring = [ctx.empty_hist(), ctx.empty_hist()]
     ctx.ch_substeps(p, c, out, ring, 1, 0, 2, 2, True, 1e-3)
     err_serial = (out.cpu() - r2).abs().max().item()
     del ring
@@ -273,7 +273,7 @@ def test_arrays_beyond_4_gib_stay_on_the_fused_path():
     for exp in (0, 2048):
         ctx = Context(3, shape, L)
         ctx.set_option(0, exp)
-        N0, N1 = ctx.empty_spec(), ctx.empty_spec()
+        N0, N1 = ctx.empty_hist(), ctx.empty_hist()
         a, b = torch.empty_like(c0), torch.empty_like(c0)
         ctx.ch_substep(p, c0, a, N0, [], 0, 1e-3)
         ctx.ch_substep(p, a, b, N1, [N0], 1, 1e-3)
@@ -288,7 +288,7 @@ def test_arrays_beyond_4_gib_stay_on_the_fused_path():
     # and it really was the fused path: its profile slots exist
     ctx = Context(3, shape, L)
     ctx.set_profiling(True)
-    out, N0 = torch.empty_like(c0), ctx.empty_spec()
+    out, N0 = torch.empty_like(c0), ctx.empty_hist()
     ctx.ch_substep(p, c0, out, N0, [], 0, 1e-3)
     ctx.sync()
     names = {k["kernel"] for k in ctx.get_profile() if k["launches"]}

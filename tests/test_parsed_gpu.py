@@ -130,7 +130,7 @@ def test_parsed_free_energy_in_ch_substep(shape):
         pp = ch_params(mobility=builtin.mobility, kappa=builtin.kappa, parsed=parsed)
         res = []
         for prm in (builtin, pp):
-            c, N0, N1 = c0.clone(), ctx.empty_spec(), ctx.empty_spec()
+            c, N0, N1 = c0.clone(), ctx.empty_hist(), ctx.empty_hist()
             c1, c2, mu = torch.empty_like(c), torch.empty_like(c), torch.empty_like(c)
             ctx.ch_substep(prm, c, c1, N0, [], 0, 1e-3)
             ctx.ch_substep(prm, c1, c2, N1, [N0], 1, 1e-3, mu=mu)
@@ -140,7 +140,7 @@ def test_parsed_free_energy_in_ch_substep(shape):
         # the multi-substep call (run-time compiled k_z_inv_fwd with the generated chemical potential between two substeps)
         multi = []
         for prm in (builtin, pp):
-            ring = [ctx.empty_spec(), ctx.empty_spec()]
+            ring = [ctx.empty_hist(), ctx.empty_hist()]
             out, mu = torch.empty_like(c0), torch.empty_like(c0)
             ctx.ch_substeps(prm, c0.clone(), out, ring, 1, 0, 2, 4, True, 1e-3, mu=mu)
             multi.append((out.cpu(), mu.cpu()))

@@ -314,7 +314,7 @@ def test_slab_pipeline_over_rccl_single_rank(carry, nsub):
     c0 = (torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44).cuda()
     p = ch_params()
     ctx = Context(3, shape, L)
-    want, Nh = [c0.clone(), torch.empty_like(c0)], [ctx.empty_spec(), ctx.empty_spec()]
+    want, Nh = [c0.clone(), torch.empty_like(c0)], [ctx.empty_hist(), ctx.empty_hist()]
     for k in range(6):
         ctx.ch_substep(p, want[k % 2], want[1 - k % 2], Nh[k % 2], [Nh[1 - k % 2]] if k else [], 1 if k else 0, 1e-3)
     want = want[0].clone()

@@ -18,7 +18,7 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(1)
     c = [torch.rand(shape, dtype=torch.float64, device="cuda", generator=g) * 0.12 + 0.44, None]
     c[1] = torch.empty_like(c[0])
-    Nh = [ctx.empty_spec(), ctx.empty_spec()]
+    Nh = [ctx.empty_hist(), ctx.empty_hist()]
     for k in range(steps + 5):
         if k == 5:
             torch.cuda.synchronize()

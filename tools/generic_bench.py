@@ -20,7 +20,7 @@ def main():
     torch.manual_seed(0)
     c = [(torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44).cuda(), None]
     c[1] = torch.empty_like(c[0])
-    Nh = [ctx.empty_spec(), ctx.empty_spec()]
+    Nh = [ctx.empty_hist(), ctx.empty_hist()]
     ctx.ch_substep(p, c[0], c[1], Nh[0], [], 0, 1e-3)
     i = 1
     steps = 50

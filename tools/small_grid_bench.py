@@ -12,7 +12,7 @@ from marlin_amd.api import Context, ch_params
 for shape in ([128,128],[200,200],[512,512],[64,64,64]):
     ctx = Context(len(shape), shape, [3.0]*len(shape)); p = ch_params()
     c = [torch.rand(shape, dtype=torch.float64, device='cuda')*0.12+0.44, None]; c[1]=torch.empty_like(c[0])
-    Nh=[ctx.empty_spec(), ctx.empty_spec()]
+    Nh=[ctx.empty_hist(), ctx.empty_hist()]
     head,n_old = 1,0
     head,n_old = ctx.ch_substeps(p, c[0], c[1], Nh, head, n_old, 2, 10, True, 1e-3)
     torch.cuda.synchronize(); t0=time.perf_counter()
