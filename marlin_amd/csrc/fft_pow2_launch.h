@@ -69,7 +69,7 @@ inline int launch_z_inv_fwd(mrl_ctx *ctx, const cplx *in, cplx *o0, cplx *o1, do
 // z inverse that also leaves sum(out * dotv) as one partial per workgroup in `partial`; *nblocks = their number
 template <int N>
 inline int launch_z_inv_dot(mrl_ctx *ctx, const cplx *in, double *out, double scale, long long nlines, const double *dotv,
-                            double *partial, int *nblocks) {
+                            double *partial, int *nblocks, ZLay zl = ZLay{0u, 0u}) {
   static bool attr = false;
   constexpr size_t lds = lds_line<N>();
   if (!attr) {
@@ -79,7 +79,7 @@ inline int launch_z_inv_dot(mrl_ctx *ctx, const cplx *in, double *out, double sc
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
   hipLaunchKernelGGL((k_z_inv<N, true>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
-                     ctx->ax[2].d_tw, dotv, partial, ZLay{0u, 0u});
+                     ctx->ax[2].d_tw, dotv, partial, zl);
   MRL_HIP(ctx, hipGetLastError());
   *nblocks = (int)nb;
   return MRL_OK;

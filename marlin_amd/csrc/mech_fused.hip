@@ -31,9 +31,10 @@ namespace mrl {
 namespace p2 {
 
 struct GammaArgs {
-  cplx *spec;        // [9][nx][inner], transformed along z and y; projected in place
-  long long field;   // elements per field = nx * inner
-  long long inner;   // ny * nzc
+  cplx *spec;        // [9][nx][plane], transformed along z and y; projected in place
+  long long field;   // elements per field = nx * plane
+  long long inner;   // ny * nzc: valid elements of an x plane
+  long long plane;   // elements between two x planes (padded to an odd number of 256-byte pieces: fft_pow2_kernels.h ZLay)
   int nzc;
   const double *kx, *ky, *kz;
   double scale;
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_xfused(GammaArgs a, co
   // stores take the "SGPR base + VGPR offset" form instead of 3 x 16 64-bit addresses held in registers
   char *b0 = reinterpret_cast<char *>(a.spec + (long long)(row * 3 + 0) * a.field);
   char *b1 = b0 + a.field * 16, *b2 = b1 + a.field * 16;
-  const unsigned boff0 = (unsigned)((iv + (long long)q * a.inner) * 16), stepB = (unsigned)((long long)TPL * a.inner * 16);
+  const unsigned boff0 = (unsigned)((iv + (long long)q * a.plane) * 16), stepB = (unsigned)((long long)TPL * a.plane * 16);
   auto ldf = [=](const char *b, int m) { return *reinterpret_cast<const cplx *>(b + (boff0 + (unsigned)m * stepB)); };
   cplx v0[P], v1[P];
 #pragma unroll
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_z_fwd_tangent(const do
                                                                         int i_num, int i_den, cplx *__restrict__ spec,
                                                                         long long npts, long long rows_total,
                                                                         const cplx *__restrict__ tw, double *__restrict__ xsol,
-                                                                        int i_arz, int i_apAp) {
+                                                                        int i_arz, int i_apAp, ZLay zl) {
 #pragma clang fp contract(off)
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, NZC = N / 2 + 1, R = 512 / N, NL = 9 * R / 2;
   static_assert(Plan<N>::NT == 256 && R >= 2 && R % 2 == 0 && NL <= Plan<N>::T, "tile shape");
@@ -241,8 +242,9 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_z_fwd_tangent(const do
   __syncthreads();
   if (!valid) return;
   const int c = l / (R / 2), pr = l % (R / 2);
-  cplx *o0 = spec + ((long long)c * rows_total + tile * R + 2 * pr) * NZC;
-  cplx *o1 = o0 + NZC;
+  const long long row0 = (long long)c * rows_total + tile * R + 2 * pr;  // (rows of all nine fields are numbered through: plane = row / ny)
+  cplx *o0 = spec + zrow(row0, NZC, zl);
+  cplx *o1 = spec + zrow(row0 + 1, NZC, zl);
 #pragma unroll
   for (int m = 0; m <= P / 2; ++m) {
     const int k = q + m * TPL;
@@ -257,7 +259,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_z_fwd_tangent(const do
 template <int N>
 static int launch_gamma_z_fwd_tangent(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
                                       const double *S, int i_num, int i_den, cplx *spec, long long npts, long long rows, bool nt,
-                                      double *x, int i_arz, int i_apAp) {
+                                      double *x, int i_arz, int i_apAp, ZLay zl) {
   static bool attr = false;
   constexpr size_t lds = lds_line_full<N>();
   if (!attr) {
@@ -270,7 +272,7 @@ static int launch_gamma_z_fwd_tangent(mrl_ctx *ctx, const double *F, const doubl
   const unsigned nb = (unsigned)(npts / 512);
 #define MRL_GZT(NTV_, XU_)                                                                                                        \
   hipLaunchKernelGGL((k_gamma_z_fwd_tangent<N, NTV_, XU_>), dim3(nb), dim3(256), lds, ctx->stream, F, K, mu, p, r, S, i_num, i_den, \
-                     spec, npts, rows, ctx->ax[2].d_tw, x, i_arz, i_apAp)
+                     spec, npts, rows, ctx->ax[2].d_tw, x, i_arz, i_apAp, zl)
   if (nt) {
     if (x) MRL_GZT(true, true); else MRL_GZT(true, false);
   } else {
@@ -283,10 +285,19 @@ static int launch_gamma_z_fwd_tangent(mrl_ctx *ctx, const double *F, const doubl
 
 }  // namespace p2
 
+// x-plane pitch of the spectral scratch [9][nx][plane] of the Gamma operator: ny * nzc padded to an odd number of 256-byte pieces (the
+// fused x pass gathers 256-byte pieces one plane apart; the natural pitch of a power-of-two grid -- 128^3: 520 pieces -- puts them on
+// 16 of the memory channels).  Internal scratch: no interface sees it.
+static long long mech_plane(const mrl_ctx *ctx) {
+  long long plane = (ctx->n[1] * ctx->nrec[2] + 15) / 16 * 16;
+  if ((plane / 16) % 2 == 0) plane += 16;
+  return (ctx->exp & (1 << 22)) ? ctx->n[1] * ctx->nrec[2] : plane;   // experiment bit 1 << 22: dense planes (A/B)
+}
+
 bool mech_fast_ok(const mrl_ctx *ctx) {
   // (one spectral field < 4 GiB: k_gamma_xfused addresses it with 32-bit byte offsets)
   return ctx->dim == 3 && !ctx->slab && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
-         pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]) && 16.0 * (double)(ctx->n[0] * ctx->n[1] * ctx->nrec[2]) < 4294967296.0;
+         pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]) && 16.0 * (double)(ctx->n[0] * (ctx->n[1] * ctx->nrec[2] + 32)) < 4294967296.0;
 }
 
 // out = scale * G(A), A and out field-major real [9][nx][ny][nz] (out may alias A).  dotv != nullptr: the last pass
@@ -295,7 +306,8 @@ int reduce_finalize_from(mrl_ctx *ctx, const double *partial, int nb, double *d_
 // the passes after the forward z pass: y forward, x + projection, y inverse, z inverse (+ optional dot product)
 static int gamma_fast_rest(mrl_ctx *ctx, cplx *spec, double *out, double scale, const double *dotv, double *d_dot) {
   const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
-  const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
+  const long long nreal = nx * ny * nz, nspec = nx * ny * nzc, plane = mech_plane(ctx);
+  const p2::ZLay zl{(unsigned)ny, (unsigned)(plane - ny * nzc)};
   const double r = 8.0 * nreal * 9, h = 16.0 * nspec * 9;
   p2::PassArgs pa{};
   pa.in[0] = spec;
@@ -303,7 +315,7 @@ static int gamma_fast_rest(mrl_ctx *ctx, cplx *spec, double *out, double scale, 
   pa.scale = 1.0;
   pa.inner = nzc;
   pa.outer = 9 * nx;
-  pa.so_in = pa.so_out = ny * nzc;
+  pa.so_in = pa.so_out = plane;
   pa.sn_in = pa.sn_out = nzc;
   {
     ProfScope ps(ctx, "gamma_y_fwd", 2.0 * h);
@@ -314,8 +326,9 @@ static int gamma_fast_rest(mrl_ctx *ctx, cplx *spec, double *out, double scale, 
     ProfScope ps(ctx, "gamma_x_fused", 2.0 * h);
     p2::GammaArgs g{};
     g.spec = spec;
-    g.field = nspec;
+    g.field = nx * plane;
     g.inner = ny * nzc;
+    g.plane = plane;
     g.nzc = (int)nzc;
     g.kx = ctx->d_k[0];
     g.ky = ctx->d_k[1];
@@ -331,27 +344,28 @@ static int gamma_fast_rest(mrl_ctx *ctx, cplx *spec, double *out, double scale, 
   const double norm = 1.0 / ((double)nx * (double)ny * (double)nz);
   if (!dotv) {
     ProfScope ps(ctx, "gamma_z_inv", r + h);
-    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, spec, out, norm, 9 * nx * ny / 2))));
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, spec, out, norm, 9 * nx * ny / 2, zl))));
     return MRL_OK;
   }
   ProfScope ps(ctx, "gamma_z_inv_dot", 2.0 * r + h);
   const long long max_blocks = 9 * nx * ny / 2;  // >= the number of workgroups for every plan
   MRL_TRY(ensure_work(ctx, 3, sizeof(double) * (size_t)max_blocks));
   int nb = 0;
-  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_dot<NN>(ctx, spec, out, norm, 9 * nx * ny / 2, dotv, ctx->d_work[3], &nb))));
+  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_dot<NN>(ctx, spec, out, norm, 9 * nx * ny / 2, dotv, ctx->d_work[3], &nb, zl))));
   return reduce_finalize_from(ctx, ctx->d_work[3], nb, d_dot);
 }
 
 int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale, const double *dotv, double *d_dot) {
   const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
-  const long long nreal = nx * ny * nz, nspec = nx * ny * nzc;
-  MRL_TRY(ensure_work(ctx, 4, sizeof(cplx) * nspec * 9));
+  const long long nreal = nx * ny * nz, nspec = nx * ny * nzc, plane = mech_plane(ctx);
+  const p2::ZLay zl{(unsigned)ny, (unsigned)(plane - ny * nzc)};
+  MRL_TRY(ensure_work(ctx, 4, sizeof(cplx) * nx * plane * 9));
   cplx *spec = reinterpret_cast<cplx *>(ctx->d_work[4]);
   const double r = 8.0 * nreal * 9, h = 16.0 * nspec * 9;
   {
     ProfScope ps(ctx, "gamma_z_fwd", r + h);
     p2::ChDev none{};
-    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, A, spec, nullptr, nullptr, none, 9 * nx * ny / 2))));
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, A, spec, nullptr, nullptr, none, 9 * nx * ny / 2, zl))));
   }
   return gamma_fast_rest(ctx, spec, out, scale, dotv, d_dot);
 }
@@ -360,11 +374,12 @@ int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale, const d
 int gamma_z_fwd_tangent_launch(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
                                const double *S, int i_num, int i_den, cplx *spec, long long npts, long long rows, int nz, bool nt,
                                double *x, int i_arz, int i_apAp) {
+  const p2::ZLay zl{0u, 0u};  // (the slab work arrays are dense)
   switch (nz) {
-    case 32: return p2::launch_gamma_z_fwd_tangent<32>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, rows, nt, x, i_arz, i_apAp);
-    case 64: return p2::launch_gamma_z_fwd_tangent<64>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, rows, nt, x, i_arz, i_apAp);
-    case 128: return p2::launch_gamma_z_fwd_tangent<128>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, rows, nt, x, i_arz, i_apAp);
-    case 256: return p2::launch_gamma_z_fwd_tangent<256>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, rows, nt, x, i_arz, i_apAp);
+    case 32: return p2::launch_gamma_z_fwd_tangent<32>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, rows, nt, x, i_arz, i_apAp, zl);
+    case 64: return p2::launch_gamma_z_fwd_tangent<64>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, rows, nt, x, i_arz, i_apAp, zl);
+    case 128: return p2::launch_gamma_z_fwd_tangent<128>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, rows, nt, x, i_arz, i_apAp, zl);
+    case 256: return p2::launch_gamma_z_fwd_tangent<256>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, rows, nt, x, i_arz, i_apAp, zl);
     default: return set_error(ctx, MRL_ERR_UNSUPPORTED, "fused tangent + z pass: unplanned z length %d", nz);
   }
 }
@@ -383,16 +398,17 @@ int gamma_fast_tangent_dir(mrl_ctx *ctx, const double *F, const double *K, const
                            const double *S, int i_num, int i_den, double *out, double *d_dot, bool nt, double *x, int i_arz,
                            int i_apAp) {
   const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
-  const long long npts = nx * ny * nz, nspec = nx * ny * nzc;
-  MRL_TRY(ensure_work(ctx, 4, sizeof(cplx) * nspec * 9));
+  const long long npts = nx * ny * nz, nspec = nx * ny * nzc, plane = mech_plane(ctx);
+  const p2::ZLay zl{(unsigned)ny, (unsigned)(plane - ny * nzc)};
+  MRL_TRY(ensure_work(ctx, 4, sizeof(cplx) * nx * plane * 9));
   cplx *spec = reinterpret_cast<cplx *>(ctx->d_work[4]);
   {
     ProfScope ps(ctx, "gamma_z_fwd_tangent_dir", 8.0 * npts * ((x ? 6 : 4) * 9 + 2) + 16.0 * nspec * 9);
     switch (nz) {
-      case 32: MRL_TRY((p2::launch_gamma_z_fwd_tangent<32>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp))); break;
-      case 64: MRL_TRY((p2::launch_gamma_z_fwd_tangent<64>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp))); break;
-      case 128: MRL_TRY((p2::launch_gamma_z_fwd_tangent<128>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp))); break;
-      case 256: MRL_TRY((p2::launch_gamma_z_fwd_tangent<256>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp))); break;
+      case 32: MRL_TRY((p2::launch_gamma_z_fwd_tangent<32>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp, zl))); break;
+      case 64: MRL_TRY((p2::launch_gamma_z_fwd_tangent<64>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp, zl))); break;
+      case 128: MRL_TRY((p2::launch_gamma_z_fwd_tangent<128>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp, zl))); break;
+      case 256: MRL_TRY((p2::launch_gamma_z_fwd_tangent<256>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp, zl))); break;
       default: return set_error(ctx, MRL_ERR_UNSUPPORTED, "gamma_fast_tangent_dir: unplanned z length");
     }
   }
