@@ -331,7 +331,10 @@ int mrl_broyden_update(mrl_ctx *ctx, int nvar, double *d_M, double *d_R, const d
  *   inverse send  [p][x_me][y_p ][K_s]                   inverse recv  [p][x_p ][y_me][K_s]
  * d_Nhat_new / d_Nhat_old / d_cbar are the dense reciprocal arrays [x_me][ny][nzc] of the reference.
  * The last index of the exchange layouts has the pitch mrl_slab_ch_k_pitch(ctx, s, nsub) >= |K_s| (planned shapes pad the rows to
- * 128-byte lines; the padding is never read); mrl_slab_ch_counts returns the sizes that follow from it.
+ * 128-byte lines), and on planned shapes the x planes of a chunk lie an ODD number of 256-byte pieces apart (>= y extent x pitch:
+ * the x passes gather / scatter 256-byte pieces one plane apart, and the natural pitch of the power-of-two grids puts them on a few
+ * memory channels only); the padding is never read.  The buffers are opaque to the caller: mrl_slab_ch_counts returns the message
+ * sizes that follow from the layout, chunks back to back in rank order.
  *
  * Spectral carry-over (`carry`).  The reference recomputes cbar = fft(c) in every substep although c = ifft(ubar) of
  * the previous one; fft(ifft(.)) is the identity up to rounding (1e-16 relative), so a rank can keep ubar -- it is produced

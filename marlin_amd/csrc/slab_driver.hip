@@ -31,6 +31,7 @@ struct ChPipe {
   int nsub = 0, transport = -1;
   bool carry = false, fast = false;
   bool local_only = false;            // MRL_OPT_EXPERIMENT bit 64: no exchange at all (timing of the rank-local kernels)
+  int dense_planes = -1;              // MRL_OPT_EXPERIMENT bit 1 << 23 at build time (it changes the message sizes)
   std::vector<Xchg> fwd2, fwd1, inv;  // two-field forward, one-field forward (carry-over), inverse; one per sub-block
   double *cbar = nullptr;             // carried spectrum [x_me][ny][pitch]
 };
@@ -152,8 +153,10 @@ static int ch_pipe_build(mrl_ctx *ctx) {
   if (nsub > nzc) nsub = (int)nzc;
   const bool carry = ctx->opt_carry != 0;
   const bool local_only = (ctx->exp & 64) != 0;
-  if (P.built && P.nsub == nsub && P.carry == carry && P.transport == c->transport && P.local_only == local_only) return MRL_OK;
-  if (P.built && (P.nsub != nsub || P.carry != carry)) {
+  const int dense_planes = (ctx->exp >> 23) & 1;
+  if (P.built && P.nsub == nsub && P.carry == carry && P.transport == c->transport && P.local_only == local_only && P.dense_planes == dense_planes)
+    return MRL_OK;
+  if (P.built && (P.nsub != nsub || P.carry != carry || P.dense_planes != dense_planes)) {
     MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ch_pipe_destroy(ctx, P);
   }
@@ -197,6 +200,7 @@ static int ch_pipe_build(mrl_ctx *ctx) {
   }
   MRL_TRACE("ch_pipe_build: tables ready");
   P.local_only = local_only;
+  P.dense_planes = dense_planes;
   P.nsub = nsub;
   P.carry = carry;
   P.transport = c->transport;

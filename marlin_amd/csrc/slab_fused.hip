@@ -34,7 +34,8 @@ struct YFusedArgs {
   int k0, ksub;       // kz sub-block
   int kp;             // row pitch of the exchange layouts (>= ksub: rows start on 128-byte lines)
   int nyl_shift;      // log2(ny / P)
-  unsigned chunk;     // nxl * nyl * kp: elements of one field of one chunk
+  unsigned xp;        // elements between two x planes of a chunk (>= nyl * kp: slab_xplane)
+  unsigned chunk;     // nxl * xp: elements of one field of one chunk
   int tiles_per_x;
   const double *kx, *ky, *kz;  // local reciprocal axes
   cplx *const *utab;  // ubar output: chunk p of the inverse exchange layout starts at utab[p] (a peer's receive buffer or the local send buffer)
@@ -60,11 +61,11 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
   const bool valid = kl0 < a.ksub;
   const int kl = valid ? kl0 : 0;
   // element (ix, j, k0+kl), p = j >> nyl_shift, jl = j & (nyl-1)       [byte offsets]
-  //   forward exchange layout  (p*2 + field)*chunk + (ix*nyl + jl)*kp + kl
-  //   inverse exchange layout   p*chunk            + (ix*nyl + jl)*kp + kl
+  //   forward exchange layout  (p*2 + field)*chunk + ix*xp + jl*kp + kl
+  //   inverse exchange layout   p*chunk            + ix*xp + jl*kp + kl
   //   dense layout              (ix*N + j)*nzc + k0 + kl
   const int sh = a.nyl_shift, msk = (1 << sh) - 1;
-  const unsigned ksB = (unsigned)a.kp * 16u, chB = a.chunk * 16u, klB = (unsigned)kl * 16u;
+  const unsigned ksB = (unsigned)a.kp * 16u, chB = a.chunk * 16u, klB = (unsigned)kl * 16u, xB = (unsigned)ix * a.xp * 16u;
   // (with the carry-over only mu-hat is received: one field per chunk)
   // ALIGNED (ny/P is a multiple of the TPL threads of a line, the usual case): the chunk index and the row within the chunk of
   // element j = q + m TPL split into a wave-uniform part that depends on m only and the per-thread constant q ksB + klB, so the
@@ -73,18 +74,18 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
   const int q0 = ALIGNED ? 0 : q;
   auto offf = [=](int m) {
     const int j = q0 + m * TPL;
-    return (unsigned)(j >> sh) * (SPEC_C ? chB : 2u * chB) + (unsigned)((ix << sh) + (j & msk)) * ksB + tq;
+    return (unsigned)(j >> sh) * (SPEC_C ? chB : 2u * chB) + xB + (unsigned)(j & msk) * ksB + tq;
   };
   cplx *const *utab = a.utab;
   auto stu = [=](int m, cplx val) {  // (ALIGNED: the chunk index depends on m only -> the table entry is a scalar load)
     const int j = q0 + m * TPL;
-    stc(utab[j >> sh], (unsigned)((ix << sh) + (j & msk)) * ksB + tq, val);
+    stc(utab[j >> sh], xB + (unsigned)(j & msk) * ksB + tq, val);
   };
   // default cache policy for every stream: on the sub-block-sized working sets of the slab pipeline the non-temporal accesses of
   // the serial kernel cost 8-30 % (measured per variant with tools/slab_local_bench.py 8 256)
   if constexpr (BIG) {
     const unsigned long long ks64 = (unsigned long long)a.kp * 16ull, ch64 = (unsigned long long)a.chunk * 16ull;
-    const unsigned long long x64 = ((unsigned long long)ix << sh) * ks64;
+    const unsigned long long x64 = (unsigned long long)ix * (unsigned long long)a.xp * 16ull;
     auto offf64 = [=](int m) {
       const int j = m * TPL;
       return BigOff{(unsigned long long)(j >> sh) * (SPEC_C ? ch64 : 2ull * ch64) + x64 + (unsigned long long)(j & msk) * ks64, tq};
@@ -163,7 +164,7 @@ int slab_fast_ok(const mrl_ctx *ctx) {
   for (int p = 0; p < ctx->nranks; ++p)
     if (ctx->part_real[p] != nyl || ctx->part_recip[p] != nxl) return 0;
   // the x passes index with 32-bit ELEMENT offsets inside a two-field exchange buffer: arrays below 32 GiB
-  const double count = (double)ctx->n[0] * (double)ctx->nloc[1] * (double)(ctx->nrec[2] + 8);
+  const double count = (double)ctx->n[0] * ((double)ctx->nloc[1] * (double)(ctx->nrec[2] + 8) + 32.0);
   if (2.0 * count >= 4294967296.0) return 0;
   // the y pass uses 32-bit BYTE offsets up to 4 GiB per two-field buffer; beyond that its 64-bit variant, which exists for
   // ny in {512, 1024, 2048} with ny/P a multiple of the threads per line
@@ -176,13 +177,31 @@ int slab_fast_ok(const mrl_ctx *ctx) {
 
 // the mechanics row pipelines keep 32-bit byte offsets throughout (three fields of a tensor row per exchange buffer)
 int slab_mech_fast_ok(const mrl_ctx *ctx) {
-  return slab_fast_ok(ctx) && 48.0 * (double)ctx->n[0] * (double)ctx->nloc[1] * (double)(ctx->nrec[2] + 8) < 4294967296.0;
+  return slab_fast_ok(ctx) && 48.0 * (double)ctx->n[0] * ((double)ctx->nloc[1] * (double)(ctx->nrec[2] + 8) + 32.0) < 4294967296.0;
 }
 
 // Row pitch (complex elements) of the exchange layouts of a kz sub-block of width ksub: rows start on 128-byte lines, so the x
 // passes write (and the y pass gathers) whole lines instead of pieces that straddle two (the spectral extent nz/2+1 is odd).  With
 // direct peer stores the padding never crosses a link; contiguous chunk pushes carry it (+2.7 % at 257 -> 264).
 long long slab_kpitch(const mrl_ctx *ctx, long long ksub) { return slab_fast_ok(ctx) ? ((ksub + 7) & ~7LL) : ksub; }
+
+// Pitch between two x planes (complex elements): [nyl][pitch] rows padded so that the plane pitch is an ODD number of 256-byte pieces.
+// The x passes gather / scatter 256-byte pieces one plane apart; with the natural pitches of the power-of-two grids (512^3 / 8:
+// 64 x 257 = 1028 pieces in the work arrays, 64 x 264 = 1056 pieces in the exchange layout) they fall on 32 resp. 4 of the 128
+// memory channels (tools/ldsdma_probe.hip: -14 % time for the pass's bytes with both strides padded).  Experiment bit 1 << 23: dense.
+static long long odd_plane(const mrl_ctx *ctx, long long elems) {
+  if (ctx->exp & (1 << 23)) return elems;
+  long long plane = (elems + 15) / 16 * 16;
+  if ((plane / 16) % 2 == 0) plane += 16;
+  return plane;
+}
+// x planes inside a chunk of the exchange layouts [p][field][x][y][kp]: what mrl_slab_ch_counts sizes the messages with
+long long slab_xplane(const mrl_ctx *ctx, long long kp) { return slab_fast_ok(ctx) ? odd_plane(ctx, ctx->nloc[1] * kp) : ctx->nloc[1] * kp; }
+// x planes of the rank-local work arrays [nx][nyl][nzc]
+static long long slab_wplane(const mrl_ctx *ctx) { return odd_plane(ctx, ctx->nloc[1] * ctx->nrec[2]); }
+static p2::ZLay slab_zlay(const mrl_ctx *ctx) {
+  return p2::ZLay{(unsigned)ctx->nloc[1], (unsigned)(slab_wplane(ctx) - ctx->nloc[1] * ctx->nrec[2])};
+}
 
 static int ilog2(long long v) {
   int s = 0;
@@ -195,7 +214,7 @@ static int ilog2(long long v) {
 // the fused z passes between two substeps then run in place (a workgroup reads its rows before it writes them) -- one array
 // less to stream through the Infinity Cache.
 static int slab_work(mrl_ctx *ctx, cplx **w_c, cplx **w_mu, cplx **w_inv) {
-  const size_t bytes = sizeof(cplx) * (size_t)(ctx->n[0] * ctx->nloc[1] * ctx->nrec[2]);
+  const size_t bytes = sizeof(cplx) * (size_t)(ctx->n[0] * slab_wplane(ctx));
   MRL_TRY(ensure_work(ctx, 13, bytes));
   MRL_TRY(ensure_work(ctx, 14, bytes));
   *w_c = reinterpret_cast<cplx *>(ctx->d_work[13]);
@@ -209,25 +228,26 @@ int slab_ch_z_fwd_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *
   cplx *w_c, *w_mu, *w_inv;
   MRL_TRY(slab_work(ctx, &w_c, &w_mu, &w_inv));
   p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
+  const p2::ZLay zl = slab_zlay(ctx);
   if (carry == MRL_CARRY_IN) {  // mu = f'(c) only, two lines per transform
     if (nyl % 2) return set_error(ctx, MRL_ERR_UNSUPPORTED, "carry-over z pass needs an even number of local lines");
     ProfScope ps(ctx, "slab_Z_z_fwd", 8.0 * nx * nyl * nz + 16.0 * nx * nyl * nzc + (mu ? 8.0 * nx * nyl * nz : 0.0));
     if (cp.family == MRL_FE_PARSED) {
-      MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 2, c_in, w_mu, nullptr, mu, nx * nyl / 2));
+      MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 2, c_in, w_mu, nullptr, mu, nx * nyl / 2, zl.lpp, zl.pad));
     } else if (cp.family == MRL_FE_DOUBLE_WELL) {
-      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 2, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_mu, nullptr, mu, chp, nx * nyl / 2))));
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 2, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_mu, nullptr, mu, chp, nx * nyl / 2, zl))));
     } else {
-      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 2, MRL_FE_PFHUB>(ctx, c_in, w_mu, nullptr, mu, chp, nx * nyl / 2))));
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 2, MRL_FE_PFHUB>(ctx, c_in, w_mu, nullptr, mu, chp, nx * nyl / 2, zl))));
     }
     return MRL_OK;
   }
   ProfScope ps(ctx, "slab_Z_z_fwd", 8.0 * nx * nyl * nz + 32.0 * nx * nyl * nzc + (mu ? 8.0 * nx * nyl * nz : 0.0));
   if (cp.family == MRL_FE_PARSED) {
-    MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 1, c_in, w_c, w_mu, mu, nx * nyl));
+    MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 1, c_in, w_c, w_mu, mu, nx * nyl, zl.lpp, zl.pad));
   } else if (cp.family == MRL_FE_DOUBLE_WELL) {
-    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_c, w_mu, mu, chp, nx * nyl))));
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_c, w_mu, mu, chp, nx * nyl, zl))));
   } else {
-    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, w_c, w_mu, mu, chp, nx * nyl))));
+    MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, w_c, w_mu, mu, chp, nx * nyl, zl))));
   }
   return MRL_OK;
 }
@@ -236,8 +256,8 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const 
   const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2], nxl = ctx->nrec[0];
   cplx *w_c, *w_mu, *w_inv;
   MRL_TRY(slab_work(ctx, &w_c, &w_mu, &w_inv));
-  const long long kp = slab_kpitch(ctx, ksub);
-  const unsigned chunk = (unsigned)(nxl * nyl * kp);
+  const long long kp = slab_kpitch(ctx, ksub), xp = slab_xplane(ctx, kp), wp = slab_wplane(ctx);
+  const unsigned chunk = (unsigned)(nxl * xp);
   const bool one = carry == MRL_CARRY_IN;  // mu-hat only
   p2::SubPassArgs a{};
   a.in[0] = (one ? w_mu : w_c) + k0;
@@ -249,8 +269,8 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const 
   a.cols = ksub;
   a.pitch_in = (unsigned)nzc;
   a.pitch_out = (unsigned)kp;
-  a.sn_in = (unsigned)(nyl * nzc);
-  a.sn_out = (unsigned)(nyl * kp);
+  a.sn_in = (unsigned)wp;
+  a.sn_out = (unsigned)xp;
   a.sh_in = 31;
   a.sh_out = ilog2(nxl);
   // tiles over the padded rows of the exchange layout: every wave stores whole 128-byte lines (the dense tiling stored 256-byte pieces
@@ -298,7 +318,8 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const dou
   const bool spec = carry == MRL_CARRY_IN;
   p2::YFusedArgs a{};
   a.kp = (int)slab_kpitch(ctx, ksub);
-  a.chunk = (unsigned)(nxl * nyl * a.kp);
+  a.xp = (unsigned)slab_xplane(ctx, a.kp);
+  a.chunk = (unsigned)(nxl * a.xp);
   a.c.chat = reinterpret_cast<const cplx *>(recv);
   a.c.muhat = spec ? a.c.chat : a.c.chat + a.chunk;
   a.c.ubar = nullptr;  // scattered through utab
@@ -351,13 +372,13 @@ int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv) {
   a.out[0] = w_inv + k0;
   a.rows = (int)nyl;
   a.cols = ksub;
-  const long long kp = slab_kpitch(ctx, ksub);
+  const long long kp = slab_kpitch(ctx, ksub), xp = slab_xplane(ctx, kp);
   a.pitch_in = (unsigned)kp;
   a.pitch_out = (unsigned)nzc;
-  a.sn_in = (unsigned)(nyl * kp);
-  a.sn_out = (unsigned)(nyl * nzc);
+  a.sn_in = (unsigned)xp;
+  a.sn_out = (unsigned)slab_wplane(ctx);
   a.sh_in = ilog2(nxl);
-  a.cs_in = (unsigned)(nxl * nyl * kp);
+  a.cs_in = (unsigned)(nxl * xp);
   a.sh_out = 31;
   ProfScope ps(ctx, "slab_C_x_inv", 32.0 * nx * nyl * ksub);
   if (nx == 512 && !(ctx->exp & 1024)) return p2::launch_pass_sub_w<p2::Wide512, true>(ctx, a, ctx->ax[0].d_tw);
@@ -377,19 +398,20 @@ int slab_ch_z_inv_fwd_fast(mrl_ctx *ctx, const ChP &cp, double *mu, int carry) {
   const double scale = 1.0 / ((double)nx * (double)ctx->n[1] * (double)nz);
   p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
   const long long np = nx * nyl / 2;
+  const p2::ZLay zl = slab_zlay(ctx);
   if (cp.family == MRL_FE_PARSED) {
-    MRL_TRY(parsed_z_inv_fwd_launch(ctx, cp.parsed, (int)nz, w_inv, mu_only ? w_mu : w_c, w_mu, mu, scale, np, mu_only));
+    MRL_TRY(parsed_z_inv_fwd_launch(ctx, cp.parsed, (int)nz, w_inv, mu_only ? w_mu : w_c, w_mu, mu, scale, np, mu_only, zl.lpp, zl.pad));
   } else if (cp.family == MRL_FE_DOUBLE_WELL) {
     if (mu_only) {
-      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_DOUBLE_WELL, true>(ctx, w_inv, w_mu, nullptr, mu, chp, scale, np))));
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_DOUBLE_WELL, true>(ctx, w_inv, w_mu, nullptr, mu, chp, scale, np, zl))));
     } else {
-      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_DOUBLE_WELL, false>(ctx, w_inv, w_c, w_mu, mu, chp, scale, np))));
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_DOUBLE_WELL, false>(ctx, w_inv, w_c, w_mu, mu, chp, scale, np, zl))));
     }
   } else {
     if (mu_only) {
-      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_PFHUB, true>(ctx, w_inv, w_mu, nullptr, mu, chp, scale, np))));
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_PFHUB, true>(ctx, w_inv, w_mu, nullptr, mu, chp, scale, np, zl))));
     } else {
-      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_PFHUB, false>(ctx, w_inv, w_c, w_mu, mu, chp, scale, np))));
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_PFHUB, false>(ctx, w_inv, w_c, w_mu, mu, chp, scale, np, zl))));
     }
   }
   return MRL_OK;
@@ -401,7 +423,7 @@ int slab_ch_z_inv_fast(mrl_ctx *ctx, double *real_out) {
   MRL_TRY(slab_work(ctx, &w_c, &w_mu, &w_inv));
   ProfScope ps(ctx, "slab_E_z_inv", 16.0 * nx * nyl * nzc + 8.0 * nx * nyl * nz);
   const double scale = 1.0 / ((double)nx * (double)ctx->n[1] * (double)nz);
-  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w_inv, real_out, scale, nx * nyl / 2))));
+  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w_inv, real_out, scale, nx * nyl / 2, slab_zlay(ctx)))));
   return MRL_OK;
 }
 

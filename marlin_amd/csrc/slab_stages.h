@@ -9,6 +9,7 @@ namespace mrl {
 int slab_fast_ok(const mrl_ctx *ctx);
 int slab_mech_fast_ok(const mrl_ctx *ctx);  // ... and the exchange buffers of the mechanics row pipelines fit 32-bit byte offsets
 int slab_sub_range(mrl_ctx *ctx, int sub, int nsub, long long *k0, long long *ksub);
+long long slab_xplane(const mrl_ctx *ctx, long long kp);    // elements between two x planes of a chunk of those layouts (padded: odd number of 256-byte pieces)
 long long slab_kpitch(const mrl_ctx *ctx, long long ksub);  // row pitch of the Cahn-Hilliard exchange layouts (slab_fused.hip)
 
 // Cahn-Hilliard, planned shapes (slab_fused.hip).  otab / utab: destination of chunk p (one entry per rank) in the forward /

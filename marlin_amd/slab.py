@@ -188,7 +188,7 @@ class SlabCahnHilliard:
     set_initial / invalidate_carry()."""
 
     def __init__(self, dim, shape, L, params, nranks, rank, predictor_order: int = 2, sub_dt: float = 1e-3,
-                 stages=None, exchange_factory: Optional[Callable] = None, nsub: int = 2, carry: bool = False):
+                 stages=None, exchange_factory: Optional[Callable] = None, nsub: int = 2, carry: bool = False, exp: int = 0):
         self.p = params
         self.carry = carry
         self._carry_valid = False
@@ -196,6 +196,8 @@ class SlabCahnHilliard:
         self.nranks, self.rank = nranks, rank
         self.st = stages if stages is not None else HipSlabStages(dim, shape, L, nranks, rank)
         self.ctx = getattr(self.st, "ctx", None)
+        if exp and self.ctx is not None:           # experiment switches that change the exchange layouts must precede the counts below
+            self.ctx.set_option(0, exp)
         self.pred = predictor_order - 1            # AdamsBashforthMoulton.C:48
         self.sub_dt = sub_dt
         nzc = self.st.recip_shape[2] if dim == 3 else 1

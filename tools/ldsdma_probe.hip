@@ -39,6 +39,7 @@ struct Args {
   unsigned sn_in, sn_out;        // stride between consecutive points of a line (elements)
   unsigned ntiles;
   int work;                      // dependent FMAs per value between the slot read and the store
+  int clip;                      // 1: store only columns < cols (tiles that overhang a row: the fused y pass)
   int remap;                     // 1: every XCD owns a contiguous range of tiles (the product kernels' xcd_remap)
 };
 
@@ -125,9 +126,10 @@ __global__ void __launch_bounds__(320) k_dma_move(Args a) {
     }
     __syncthreads();
     const unsigned i = tile * T + l;
-    const bool valid = i < a.rows * a.tcols;
-    const unsigned ic = valid ? i : 0u;
+    const bool valid0 = i < a.rows * a.tcols;
+    const unsigned ic = valid0 ? i : 0u;
     const unsigned row = ic / a.tcols, col = ic - row * a.tcols;
+    const bool valid = valid0 && (!a.clip || col < a.cols);
     double2 *o = a.out + (size_t)row * a.pitch_out + col;
     if (valid) {
 #pragma unroll
@@ -142,9 +144,10 @@ __global__ void __launch_bounds__(256, 2) k_move(Args a) {
   constexpr int TPL = N / P;
   const unsigned l = threadIdx.x % T, q = threadIdx.x / T;
   const unsigned i = (a.remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x) * T + l;
-  const bool valid = i < a.rows * a.tcols;
-  const unsigned ic = valid ? i : 0u;
+  const bool valid0 = i < a.rows * a.tcols;
+  const unsigned ic = valid0 ? i : 0u;
   const unsigned row = ic / a.tcols, col = ic - row * a.tcols;
+  const bool valid = valid0 && (!a.clip || col < a.cols);
   const unsigned cc = min(col, a.cols - 1u);
   const size_t bi = (size_t)row * a.pitch_in + cc, bo = (size_t)row * a.pitch_out + col;
   double2 v[P];
@@ -326,6 +329,21 @@ int main(int argc, char **argv) {
       char nm[128];
       snprintf(nm, sizeof nm, "slab x pass 512 x (64 x 257 -> 264), line strides %u / %u elements", a.sn_in, a.sn_out);
       bench(nm, a, cap, (size_t)nx * nyl * nzc, k_move<512, 32, 16>, a.ntiles, k_dma_move<512, 16, 64, 5, false>, k_dma_move<512, 16, 64, 5, true>,
+            5 * 64 * 16 * 16, 5 * 64 * 16 * 16, "LDS-DMA 5 x 16 KB ring", "LDS-DMA 5 x 16 KB ring, nt loads");
+    }
+  }
+  if (which == 6) {
+    // the fused y pass of 512^3 / 8 on the rank-local arrays [64 x planes][512 y][K]: lines along y (stride K), 17 tiles of 16 kz per x plane
+    const unsigned nxl = 64, ny = 512, nzc = 257;
+    for (unsigned K : {257u, 264u, 272u, 280u}) {
+      Args a{};
+      a.rows = nxl; a.cols = nzc; a.tcols = 272; a.clip = 1;
+      a.pitch_in = a.pitch_out = ny * K; a.sn_in = a.sn_out = K;
+      a.ntiles = (a.rows * a.tcols + 15) / 16;
+      const size_t cap = (size_t)nxl * ny * K + 4096;
+      char nm[128];
+      snprintf(nm, sizeof nm, "slab y pass 512 x (64 x 257), row pitch K = %u elements (%u B)", K, K * 16);
+      bench(nm, a, cap, (size_t)nxl * ny * nzc, k_move<512, 32, 16>, a.ntiles, k_dma_move<512, 16, 64, 5, false>, k_dma_move<512, 16, 64, 5, true>,
             5 * 64 * 16 * 16, 5 * 64 * 16 * 16, "LDS-DMA 5 x 16 KB ring", "LDS-DMA 5 x 16 KB ring, nt loads");
     }
   }

@@ -37,8 +37,7 @@ def main():
     shape = grid_for(P, n)
     dx = 8.0 * np.pi / 200.0
     s = SlabCahnHilliard(3, shape, [x * dx for x in shape], ch_params(), P, 0, exchange_factory=lambda a, b: _Copy(a, b), nsub=nsub,
-                         carry=carry)
-    s.ctx.set_option(0, exp)
+                         carry=carry, exp=exp)
     s.set_initial(lambda count, offset: splitmix64_uniform(count, offset=offset))
     for _ in range(5):
         s.substep()
