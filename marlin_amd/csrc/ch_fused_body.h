@@ -86,12 +86,14 @@ __device__ __forceinline__ void stc_nt(cplx *base, BigOff o, cplx v) {
 // following y pass 54.5 -> 49 us).  NT_W: the same for the mu-hat loads, which are dead after this pass (another 2.5 % of the substep).
 // NT_CARRY: the same for the carried spectrum (read and rewritten once per substep).
 // NT_HIST: ... for the old / new Nhat arrays and the cbar output.
+// OffM: offset callable of the mu-hat loads where they differ from the c-hat ones (the table-driven slab pass: the second field of a
+// received chunk lies a chunk-dependent distance behind the first); the other callers pass `offw` twice.
 template <int N, int ORDER, bool LINE_IS_X, int PRE, bool SPEC_C, bool NT_W, bool NT_CARRY, bool NT_HIST, class OffW,
-          class OffD, class StU>
+          class OffM, class OffD, class StU>
 __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *__restrict__ tw,
                                               const double *__restrict__ kline, const double *__restrict__ ka_ptr,
                                               const double *__restrict__ kb_ptr, bool valid, int q, int l,
-                                              OffW offw, OffD offd, StU stu, cplx *W, cplx *X,
+                                              OffW offw, OffM offm, OffD offd, StU stu, cplx *W, cplx *X,
                                               double *KL) {
 #pragma clang fp contract(off)
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, NT = Plan<N>::NT, CNT = (N + NT - 1) / NT;
@@ -112,7 +114,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   const double ka = *ka_ptr, kb = *kb_ptr;
   cplx v[P], cp[P];
 #pragma unroll
-  for (int m = 0; m < P; ++m) v[m] = NT_W ? ldc_nt(a.muhat, offw(m)) : ldc(a.muhat, offw(m));
+  for (int m = 0; m < P; ++m) v[m] = NT_W ? ldc_nt(a.muhat, offm(m)) : ldc(a.muhat, offm(m));
 #pragma unroll
   for (int m = 0; m < P; ++m) cp[m] = SPEC_C ? (NT_CARRY ? ldc_nt(a.carry, offd(m)) : ldc(a.carry, offd(m))) : ldc(a.chat, offw(m));
 #pragma unroll

@@ -43,6 +43,26 @@ int local_tab(mrl_ctx *ctx, int slot, void *base, size_t stride_bytes, cplx *con
   return MRL_OK;
 }
 
+struct TabOffsets {
+  unsigned long long off[64];
+};
+__global__ void k_fill_tab_offsets(char **tab, char *base, TabOffsets o, int n) {
+  if ((int)threadIdx.x < n) tab[threadIdx.x] = base + o.off[threadIdx.x];
+}
+
+// the same with explicit byte offsets per rank (chunks of different sizes: uneven partitions)
+int local_tab_offsets(mrl_ctx *ctx, int slot, void *base, const size_t *byte_offsets, cplx *const **out) {
+  if (ctx->nranks > 64 || slot < 0 || slot > 7) return set_error(ctx, MRL_ERR_UNSUPPORTED, "pointer tables hold at most 64 ranks");
+  if (!ctx->d_tabs) MRL_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_tabs), sizeof(char *) * 64 * 8));
+  char **t = ctx->d_tabs + 64 * slot;
+  TabOffsets o{};
+  for (int p = 0; p < ctx->nranks; ++p) o.off[p] = byte_offsets[p];
+  hipLaunchKernelGGL(k_fill_tab_offsets, dim3(1), dim3(64), 0, ctx->stream, t, static_cast<char *>(base), o, ctx->nranks);
+  MRL_HIP(ctx, hipGetLastError());
+  *out = reinterpret_cast<cplx *const *>(t);
+  return MRL_OK;
+}
+
 int ensure_work(mrl_ctx *ctx, int slot, size_t bytes) {
   if (ctx->work_bytes[slot] >= bytes) return MRL_OK;
   if (ctx->d_work[slot]) {
@@ -362,6 +382,8 @@ void mrl_ctx_destroy(mrl_ctx *c) {
   slab_pipes_destroy(c);  // (collective on a communicator with several ranks; a communicator destroyed first has done it already)
   slab_detach_comm(c);
   if (c->d_tabs) hipFree(c->d_tabs);
+  for (auto &t : c->slab_tabs)
+    if (t.d) hipFree(t.d);
   for (int a = 0; a < 3; ++a) {
     if (c->ax[a].d_tw) hipFree(c->ax[a].d_tw);
     if (c->d_k[a]) hipFree(c->d_k[a]);

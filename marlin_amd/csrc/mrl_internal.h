@@ -50,6 +50,16 @@ struct AxisPlan {
   cplx *d_tw = nullptr;  // exp(-2 pi i k / n), k = 0..n-1
 };
 
+// Device tables of the table-driven slab pipeline (slab_fused.hip: partitions that are not equal powers of two), one set per row
+// pitch kp of the exchange layouts; element units, 32 bits
+struct SlabTabs {
+  long long kp = -1;
+  int dense = -1;           // MRL_OPT_EXPERIMENT bit 1 << 23 when the set was built
+  unsigned *d = nullptr;    // one allocation holding all tables
+  const unsigned *xch = nullptr, *xoff = nullptr, *fsz = nullptr, *cofi = nullptr;                            // x passes
+  const unsigned *ych = nullptr, *yD = nullptr, *yB = nullptr, *yC = nullptr, *yA2 = nullptr, *yA1 = nullptr;  // fused y pass
+};
+
 struct Profile {
   const char *name;
   double ms;
@@ -115,6 +125,7 @@ struct mrl_ctx {
   mrl_comm *comm = nullptr;
   struct mrl::SlabPipes *pipes = nullptr;
   char **d_tabs = nullptr;  // 8 device pointer tables of 64 entries for the staged entry points (caller-owned send buffers)
+  std::vector<mrl::SlabTabs> slab_tabs;
 
   mutable std::string err;
 };
@@ -175,6 +186,7 @@ int ensure_work(mrl_ctx *ctx, int slot, size_t bytes);
 // device pointer table `slot` (0..7) filled on the context's stream with base + p * stride_bytes, p = 0..nranks-1: the
 // destination table of a scatter-capable kernel when the chunks go to one contiguous local buffer
 int local_tab(mrl_ctx *ctx, int slot, void *base, size_t stride_bytes, cplx *const **out);
+int local_tab_offsets(mrl_ctx *ctx, int slot, void *base, const size_t *byte_offsets, cplx *const **out);
 void slab_pipes_destroy(mrl_ctx *ctx);
 void slab_detach_comm(mrl_ctx *ctx);
 long long slab_verify_count(mrl_ctx *ctx, bool reset);  // MRL_OPT_VERIFY_MISMATCHES: synchronises the stream; -1 on a HIP error

@@ -365,16 +365,29 @@ int mrl_slab_ch_counts(const mrl_ctx *ctx, int sub, int nsub, int forward, int c
   MRL_TRY(slab_sub_range(const_cast<mrl_ctx *>(ctx), sub, nsub, &k0, &ksub));
   const long long nf = (forward && carry != MRL_CARRY_IN) ? 2 : 1;  // the forward messages carry both fields (mu-hat only with the carry-over)
   const long long kp = slab_kpitch(ctx, ksub);  // planned shapes: rows of the exchange layouts are padded to 128-byte lines
-  // (planned pipeline: x planes of a chunk lie slab_xplane elements apart -- an odd number of 256-byte pieces; equal partitions there)
+  // (planned pipeline: x planes of a chunk lie slab_xplane_of(rows of the chunk) elements apart -- an odd number of 256-byte pieces)
   const bool fast = slab_fast_ok(ctx) != 0;
-  const long long xp = fast ? slab_xplane(ctx, kp) : 0;
   for (int p = 0; p < ctx->nranks; ++p) {
-    const long long x_p_y_me = fast ? ctx->part_recip[p] * xp : ctx->part_recip[p] * ctx->nloc[1] * kp;
-    const long long x_me_y_p = fast ? ctx->nrec[0] * xp : ctx->nrec[0] * ctx->part_real[p] * kp;
+    const long long x_p_y_me = fast ? ctx->part_recip[p] * slab_xplane_of(ctx, ctx->nloc[1], kp) : ctx->part_recip[p] * ctx->nloc[1] * kp;
+    const long long x_me_y_p = fast ? ctx->nrec[0] * slab_xplane_of(ctx, ctx->part_real[p], kp) : ctx->nrec[0] * ctx->part_real[p] * kp;
     if (h_send_counts) h_send_counts[p] = nf * (forward ? x_p_y_me : x_me_y_p);
     if (h_recv_counts) h_recv_counts[p] = nf * (forward ? x_me_y_p : x_p_y_me);
   }
   return MRL_OK;
+}
+
+// pointer table of the staged entry points: chunk p of the caller's contiguous send buffer starts where mrl_slab_ch_counts puts it
+static int staged_tab(mrl_ctx *ctx, int slot, double *d_send, int sub, int nsub, int forward, int carry, cplx *const **tab) {
+  int64_t cnt[64];
+  size_t off[64];
+  if (ctx->nranks > 64) return set_error(ctx, MRL_ERR_UNSUPPORTED, "pointer tables hold at most 64 ranks");
+  MRL_TRY(mrl_slab_ch_counts(ctx, sub, nsub, forward, carry, cnt, nullptr));
+  size_t at = 0;
+  for (int p = 0; p < ctx->nranks; ++p) {
+    off[p] = at;
+    at += sizeof(cplx) * (size_t)cnt[p];
+  }
+  return local_tab_offsets(ctx, slot, d_send, off, tab);
 }
 
 static int check_carry(mrl_ctx *ctx, const char *what, int carry) {
@@ -403,9 +416,8 @@ int mrl_slab_ch_x_fwd(mrl_ctx *ctx, int sub, int nsub, double *d_send, int carry
   MRL_TRY(check_carry(ctx, "mrl_slab_ch_x_fwd", carry));
   if (slab_fast_ok(ctx)) {
     // the pass scatters through a destination table: here every chunk goes to the caller's contiguous send buffer
-    const size_t nf = carry == MRL_CARRY_IN ? 1 : 2;
     cplx *const *tab;
-    MRL_TRY(local_tab(ctx, 0, d_send, sizeof(cplx) * nf * (size_t)(ctx->nrec[0] * slab_xplane(ctx, slab_kpitch(ctx, ksub))), &tab));
+    MRL_TRY(staged_tab(ctx, 0, d_send, sub, nsub, 1, carry, &tab));
     return slab_ch_x_fwd_fast(ctx, (int)k0, (int)ksub, tab, SignalArgs{}, carry);
   }
   return gen_x_fwd(ctx, k0, ksub, d_send, carry);
@@ -441,7 +453,7 @@ int mrl_slab_ch_kspace(mrl_ctx *ctx, const mrl_ch_params *p, int sub, int nsub, 
   MRL_TRY(slab_sub_range(ctx, sub, nsub, &k0, &ksub));
   if (slab_fast_ok(ctx)) {
     cplx *const *tab;
-    MRL_TRY(local_tab(ctx, 1, d_send, sizeof(cplx) * (size_t)(ctx->nrec[0] * slab_xplane(ctx, slab_kpitch(ctx, ksub))), &tab));
+    MRL_TRY(staged_tab(ctx, 1, d_send, sub, nsub, 0, MRL_CARRY_NONE, &tab));
     return slab_ch_kspace_fast(ctx, cp, (int)k0, (int)ksub, d_recv, tab, SignalArgs{}, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, carry);
   }
   return gen_kspace(ctx, cp, k0, ksub, d_recv, d_send, d_Nhat_new, d_Nhat_old, order, sub_dt, d_cbar, carry);

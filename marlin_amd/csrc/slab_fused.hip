@@ -97,11 +97,11 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
     const unsigned long long dx64 = (unsigned long long)ix * N * (unsigned long long)a.nzc * 16ull, dstep64 = (unsigned long long)(TPL * a.nzc) * 16ull;
     const unsigned dl = (unsigned)(q * a.nzc + a.k0 + kl) * 16u;
     auto offd64 = [=](int m) { return BigOff{dx64 + (unsigned long long)m * dstep64, dl}; };
-    ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf64, offd64, stu64, W, X, KY);
+    ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf64, offf64, offd64, stu64, W, X, KY);
   } else {
     const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + a.k0 + kl) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
     auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
-    ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offd, stu, W, X, KY);
+    ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offf, offd, stu, W, X, KY);
   }
   signal_tail(a.sig);
 }
@@ -152,12 +152,157 @@ static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
   return launch_yfused_v<N, ORDER, SPEC_C, false>(ctx, a);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Table-addressed forms of the two slab kernels that see the chunked exchange layouts, for partitions that are not equal powers of
+// two (slab_fast_table).  Same transforms, same pointwise arithmetic in the same order as the shift-addressed kernels (ch_fused_body):
+// only the address of an element differs -- the chunk index and the offset inside the chunk are looked up (tables: L1 / L2 resident,
+// <= 5 x 4 bytes per line element) instead of being split off the index by shifts.
+struct SubPassTabs {
+  const unsigned *xch;    // [nx] rank whose chunk holds x plane n
+  const unsigned *xoff;   // [nx] element offset of plane n inside a field block of that chunk: (n - first plane) * plane pitch
+  const unsigned *fsz;    // [P]  forward: elements between two fields of the chunk for rank p
+  const unsigned *cofi;   // [P]  inverse: element offset of the chunk received from rank p
+};
+
+template <int N, bool INV, int NF>
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_t(SubPassArgs a, SubPassTabs t, const cplx *__restrict__ tw) {
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T;
+  using Map = MapStrided<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  const int l = threadIdx.x % T, q = threadIdx.x / T;
+  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned i = logical * T + l;
+  const bool valid = i < (unsigned)(a.rows * a.tcols);
+  const unsigned ic = valid ? i : 0u;
+  const unsigned row = ic / (unsigned)a.tcols, col = ic - row * (unsigned)a.tcols;
+  const unsigned bi = row * a.pitch_in + min(col, (unsigned)a.cols - 1u), bo = row * a.pitch_out + col;
+  TwRegs<N> twr;
+  tw_issue<N>(twr, tw);
+  cplx v[NF][P];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      const unsigned n = q + m * TPL;
+      if (INV)
+        v[f][m] = a.in[f][bi + t.cofi[t.xch[n]] + t.xoff[n]];
+      else
+        v[f][m] = a.in[f][bi + n * a.sn_in];
+    }
+  }
+  tw_commit<N>(twr, W);
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    if (INV) {
+#pragma unroll
+      for (int m = 0; m < P; ++m) v[f][m] = cswap(v[f][m]);
+    }
+    fft_line<N, Map>(v[f], q, l, X, W);
+    if (valid) {
+#pragma unroll
+      for (int m = 0; m < P; ++m) {
+        const unsigned n = q + m * TPL;
+        if (INV) {
+          a.out[f][bo + n * a.sn_out] = cswap(v[f][m]);
+        } else {
+          const unsigned p = t.xch[n];
+          a.otab[p][(unsigned)f * t.fsz[p] + bo + t.xoff[n]] = v[f][m];
+        }
+      }
+    }
+  }
+  if (!INV) signal_tail(a.sig);
+}
+
+template <int N, bool INV, int NF>
+inline int launch_pass_sub_t(mrl_ctx *ctx, SubPassArgs a, const SubPassTabs &t, const cplx *tw) {
+  static bool attr = false;
+  constexpr size_t lds = lds_strided<N>();
+  if (!attr) {
+    MRL_TRY((set_lds_attr(ctx, k_pass_sub_t<N, INV, NF>, lds)));
+    attr = true;
+  }
+  constexpr int T = Plan<N>::T;
+  if (a.tcols == 0) a.tcols = a.cols;
+  const long long nb = ((long long)a.rows * a.tcols + T - 1) / T;
+  if (a.sig.expected == 0) a.sig.expected = (unsigned)nb;
+  hipLaunchKernelGGL((k_pass_sub_t<N, INV, NF>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, t, tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+struct YTabs {
+  const unsigned *ych;  // [ny] rank whose chunk holds y row j
+  const unsigned *yD;   // [ny] (j - first row of that chunk) * kp
+  const unsigned *yB;   // [ny] x-plane pitch of that chunk
+  const unsigned *yC;   // [ny] elements between the two fields of that chunk (forward, two fields)
+  const unsigned *yA;   // [ny] element offset of row j at x plane 0, field 0, in the received forward buffer
+};
+
+// (fields of YFusedArgs used here: c, nxl, nzc, k0, ksub, tiles_per_x, kx, ky, kz, utab, sig)
+template <int N, int ORDER, bool SPEC_C>
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused_t(YFusedArgs a, YTabs t, const cplx *__restrict__ tw) {
+  constexpr int TPL = Plan<N>::TPL, T = Plan<N>::T;
+  using Map = MapStrided<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  double *KY = reinterpret_cast<double *>(X + Map::size);
+  const int l = threadIdx.x % T, q = threadIdx.x / T;
+  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int ix = logical / a.tiles_per_x;
+  const int kl0 = (logical % a.tiles_per_x) * T + l;
+  const bool valid = kl0 < a.ksub;
+  const int kl = valid ? kl0 : 0;
+  const unsigned uix = (unsigned)ix, klB = (unsigned)kl * 16u;
+  // element (field f, ix, j, k0 + kl) of the received forward buffer: yA[j] + f * yC[j] + ix * yB[j] + kl; of the chunk for rank
+  // ych[j] in the inverse layout: ix * yB[j] + yD[j] + kl                                                        [byte offsets]
+  auto offf = [=](int m) {
+    const unsigned j = q + m * TPL;
+    return (t.yA[j] + uix * t.yB[j]) * 16u + klB;
+  };
+  auto offm = [=](int m) {
+    const unsigned j = q + m * TPL;
+    return (t.yA[j] + (SPEC_C ? 0u : t.yC[j]) + uix * t.yB[j]) * 16u + klB;
+  };
+  cplx *const *utab = a.utab;
+  auto stu = [=](int m, cplx val) {
+    const unsigned j = q + m * TPL;
+    stc(utab[t.ych[j]], (uix * t.yB[j] + t.yD[j]) * 16u + klB, val);
+  };
+  const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + a.k0 + kl) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
+  auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
+  ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offm, offd, stu, W, X, KY);
+  signal_tail(a.sig);
+}
+
+template <int N, int ORDER, bool SPEC_C>
+static int launch_yfused_t(mrl_ctx *ctx, YFusedArgs a, const YTabs &t) {
+  static bool attr = false;
+  constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
+  if (!attr) {
+    MRL_TRY((set_lds_attr(ctx, k_ch_yfused_t<N, ORDER, SPEC_C>, lds)));
+    attr = true;
+  }
+  constexpr int T = Plan<N>::T;
+  a.tiles_per_x = (a.ksub + T - 1) / T;
+  const long long nb = (long long)a.nxl * a.tiles_per_x;
+  a.sig.expected = (unsigned)nb;
+  hipLaunchKernelGGL((k_ch_yfused_t<N, ORDER, SPEC_C>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, t, ctx->ax[1].d_tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
 }  // namespace p2
 
-int slab_fast_ok(const mrl_ctx *ctx) {
+int slab_fast_shift(const mrl_ctx *ctx) {
   if (!(ctx->dim == 3 && ctx->slab && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
         pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2])))
     return 0;
+  if (ctx->exp & (1 << 24)) return 0;  // experiment: the table-addressed kernels on a shape that has the shift-addressed ones (A/B, parity)
   // equal power-of-two partitions: chunk addressing by shifts
   const long long nyl = ctx->n[1] / ctx->nranks, nxl = ctx->n[0] / ctx->nranks;
   if (nyl * ctx->nranks != ctx->n[1] || nxl * ctx->nranks != ctx->n[0] || (nyl & (nyl - 1)) || (nxl & (nxl - 1))) return 0;
@@ -175,9 +320,32 @@ int slab_fast_ok(const mrl_ctx *ctx) {
   return 1;
 }
 
+// Every other partition of a grid of planned lengths (the reference's own 200^3 example grid on 2 or 4 ranks: ny/P = 100 or 50; its
+// 3-rank 64^3 test: 22 / 21 / 21 planes; device_weights) runs the same pipeline with TABLE-addressed chunks (k_pass_sub_t,
+// k_ch_yfused_t): the chunk of an x plane / a y row and its offset inside the chunk come from small device tables instead of shifts.
+// The verdict must be the same on every rank (the message sizes depend on it): it only uses global quantities.
+static int slab_fast_table(const mrl_ctx *ctx) {
+  if (!(ctx->dim == 3 && ctx->slab && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
+        pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2])))
+    return 0;
+  if ((int)ctx->part_real.size() != ctx->nranks || (int)ctx->part_recip.size() != ctx->nranks) return 0;
+  if (ctx->n[0] % 2) return 0;  // (the pair-wise z passes: nx * nyl even on every rank)
+  long long ymax = 0, xmax = 0;
+  for (int p = 0; p < ctx->nranks; ++p) {
+    ymax = ctx->part_real[p] > ymax ? ctx->part_real[p] : ymax;
+    xmax = ctx->part_recip[p] > xmax ? ctx->part_recip[p] : xmax;
+  }
+  // 32-bit BYTE offsets everywhere: the two-field forward buffer of the rank with the most rows, a rank-local spectral array
+  const double fwd = 32.0 * (double)ctx->n[0] * ((double)ymax * (double)(ctx->nrec[2] + 8) + 32.0);
+  const double dense = 16.0 * (double)xmax * (double)ctx->n[1] * (double)(ctx->nrec[2] + 8);
+  return fwd < 4294967296.0 && dense < 4294967296.0;
+}
+
+int slab_fast_ok(const mrl_ctx *ctx) { return slab_fast_shift(ctx) || slab_fast_table(ctx); }
+
 // the mechanics row pipelines keep 32-bit byte offsets throughout (three fields of a tensor row per exchange buffer)
 int slab_mech_fast_ok(const mrl_ctx *ctx) {
-  return slab_fast_ok(ctx) && 48.0 * (double)ctx->n[0] * ((double)ctx->nloc[1] * (double)(ctx->nrec[2] + 8) + 32.0) < 4294967296.0;
+  return slab_fast_shift(ctx) && 48.0 * (double)ctx->n[0] * ((double)ctx->nloc[1] * (double)(ctx->nrec[2] + 8) + 32.0) < 4294967296.0;
 }
 
 // Row pitch (complex elements) of the exchange layouts of a kz sub-block of width ksub: rows start on 128-byte lines, so the x
@@ -196,7 +364,8 @@ static long long odd_plane(const mrl_ctx *ctx, long long elems) {
   return plane;
 }
 // x planes inside a chunk of the exchange layouts [p][field][x][y][kp]: what mrl_slab_ch_counts sizes the messages with
-long long slab_xplane(const mrl_ctx *ctx, long long kp) { return slab_fast_ok(ctx) ? odd_plane(ctx, ctx->nloc[1] * kp) : ctx->nloc[1] * kp; }
+long long slab_xplane_of(const mrl_ctx *ctx, long long rows, long long kp) { return slab_fast_ok(ctx) ? odd_plane(ctx, rows * kp) : rows * kp; }
+long long slab_xplane(const mrl_ctx *ctx, long long kp) { return slab_xplane_of(ctx, ctx->nloc[1], kp); }
 // x planes of the rank-local work arrays [nx][nyl][nzc]
 static long long slab_wplane(const mrl_ctx *ctx) { return odd_plane(ctx, ctx->nloc[1] * ctx->nrec[2]); }
 static p2::ZLay slab_zlay(const mrl_ctx *ctx) {
@@ -207,6 +376,70 @@ static int ilog2(long long v) {
   int s = 0;
   while ((1LL << s) < v) ++s;
   return s;
+}
+
+// the device tables of the table-addressed kernels for exchange rows of pitch kp (built once per pitch, kept by the context)
+static int slab_tabs_get(mrl_ctx *ctx, long long kp, const SlabTabs **out) {
+  const int dense = (ctx->exp >> 23) & 1;
+  for (const SlabTabs &t : ctx->slab_tabs)
+    if (t.kp == kp && t.dense == dense) {
+      *out = &t;
+      return MRL_OK;
+    }
+  const int P = ctx->nranks;
+  const long long nx = ctx->n[0], ny = ctx->n[1], nxl = ctx->nrec[0], nyl = ctx->nloc[1];
+  std::vector<unsigned> h((size_t)(2 * nx + 2 * P + 6 * ny));
+  unsigned *xch = h.data(), *xoff = xch + nx, *fsz = xoff + nx, *cofi = fsz + P, *ych = cofi + P, *yD = ych + ny, *yB = yD + ny,
+           *yC = yB + ny, *yA2 = yC + ny, *yA1 = yA2 + ny;
+  const long long xp_me = slab_xplane_of(ctx, nyl, kp);
+  long long xb = 0, off = 0;
+  for (int p = 0; p < P; ++p) {
+    for (long long i = 0; i < ctx->part_recip[p]; ++i) {
+      xch[xb + i] = (unsigned)p;
+      xoff[xb + i] = (unsigned)(i * xp_me);
+    }
+    fsz[p] = (unsigned)(ctx->part_recip[p] * xp_me);
+    cofi[p] = (unsigned)off;
+    off += ctx->part_recip[p] * xp_me;
+    xb += ctx->part_recip[p];
+  }
+  long long yb = 0, off2 = 0, off1 = 0;
+  for (int p = 0; p < P; ++p) {
+    const long long xp_p = slab_xplane_of(ctx, ctx->part_real[p], kp);
+    for (long long i = 0; i < ctx->part_real[p]; ++i) {
+      const long long j = yb + i;
+      ych[j] = (unsigned)p;
+      yD[j] = (unsigned)(i * kp);
+      yB[j] = (unsigned)xp_p;
+      yC[j] = (unsigned)(nxl * xp_p);
+      yA2[j] = (unsigned)(off2 + i * kp);
+      yA1[j] = (unsigned)(off1 + i * kp);
+    }
+    off2 += 2 * nxl * xp_p;
+    off1 += nxl * xp_p;
+    yb += ctx->part_real[p];
+  }
+  if (xb != nx || yb != ny) return set_error(ctx, MRL_ERR_INVALID, "slab tables: the partitions do not cover the grid");
+  if (16.0 * (double)off2 >= 4294967296.0 || 16.0 * (double)off >= 4294967296.0)
+    return set_error(ctx, MRL_ERR_UNSUPPORTED, "slab tables: exchange buffers of 4 GiB and more");
+  SlabTabs t;
+  t.kp = kp;
+  t.dense = dense;
+  MRL_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&t.d), sizeof(unsigned) * h.size()));
+  MRL_HIP(ctx, hipMemcpy(t.d, h.data(), sizeof(unsigned) * h.size(), hipMemcpyHostToDevice));
+  t.xch = t.d;
+  t.xoff = t.xch + nx;
+  t.fsz = t.xoff + nx;
+  t.cofi = t.fsz + P;
+  t.ych = t.cofi + P;
+  t.yD = t.ych + ny;
+  t.yB = t.yD + ny;
+  t.yC = t.yB + ny;
+  t.yA2 = t.yC + ny;
+  t.yA1 = t.yA2 + ny;
+  ctx->slab_tabs.push_back(t);
+  *out = &ctx->slab_tabs.back();
+  return MRL_OK;
 }
 
 // work arrays of the pipeline: slots 13, 14 = c-hat_z, mu-hat_z [nx][nyl][nzc].  The inverse x pass writes into the c-hat_z array
@@ -230,7 +463,7 @@ int slab_ch_z_fwd_fast(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *
   p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
   const p2::ZLay zl = slab_zlay(ctx);
   if (carry == MRL_CARRY_IN) {  // mu = f'(c) only, two lines per transform
-    if (nyl % 2) return set_error(ctx, MRL_ERR_UNSUPPORTED, "carry-over z pass needs an even number of local lines");
+    if ((nx * nyl) % 2) return set_error(ctx, MRL_ERR_UNSUPPORTED, "carry-over z pass needs an even number of local lines");
     ProfScope ps(ctx, "slab_Z_z_fwd", 8.0 * nx * nyl * nz + 16.0 * nx * nyl * nzc + (mu ? 8.0 * nx * nyl * nz : 0.0));
     if (cp.family == MRL_FE_PARSED) {
       MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 2, c_in, w_mu, nullptr, mu, nx * nyl / 2, zl.lpp, zl.pad));
@@ -259,6 +492,29 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const 
   const long long kp = slab_kpitch(ctx, ksub), xp = slab_xplane(ctx, kp), wp = slab_wplane(ctx);
   const unsigned chunk = (unsigned)(nxl * xp);
   const bool one = carry == MRL_CARRY_IN;  // mu-hat only
+  if (!slab_fast_shift(ctx)) {  // table-addressed chunks (partitions that are not equal powers of two)
+    const SlabTabs *tb;
+    MRL_TRY(slab_tabs_get(ctx, kp, &tb));
+    p2::SubPassArgs a{};
+    a.in[0] = (one ? w_mu : w_c) + k0;
+    a.in[1] = w_mu + k0;
+    a.otab = otab;
+    a.sig = sig;
+    a.rows = (int)nyl;
+    a.cols = ksub;
+    a.tcols = (int)kp;
+    a.pitch_in = (unsigned)nzc;
+    a.pitch_out = (unsigned)kp;
+    a.sn_in = (unsigned)wp;
+    const p2::SubPassTabs t{tb->xch, tb->xoff, tb->fsz, tb->cofi};
+    ProfScope ps(ctx, "slab_A_x_fwd", (one ? 2.0 : 4.0) * 16.0 * nx * nyl * ksub);
+    if (one) {
+      MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub_t<NN, false, 1>(ctx, a, t, ctx->ax[0].d_tw))));
+    } else {
+      MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub_t<NN, false, 2>(ctx, a, t, ctx->ax[0].d_tw))));
+    }
+    return MRL_OK;
+  }
   p2::SubPassArgs a{};
   a.in[0] = (one ? w_mu : w_c) + k0;
   a.in[1] = w_mu + k0;
@@ -343,6 +599,30 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const dou
   a.c.dt = sub_dt;
   // NONE: recv 2, Nnew, send (+ cbar) ; OUT: + carry write ; IN: recv 1, carry read + write, Nnew, send
   ProfScope ps(ctx, "slab_B_y_fused", ((spec ? 5.0 : 4.0) + order + (cbar && !spec ? 1.0 : 0.0)) * 16.0 * nxl * ny * ksub);
+  if (!slab_fast_shift(ctx)) {  // table-addressed chunks
+    const SlabTabs *tb;
+    MRL_TRY(slab_tabs_get(ctx, a.kp, &tb));
+    a.c.muhat = a.c.chat;  // (the field offset comes from the table: chunk-dependent)
+    const p2::YTabs t{tb->ych, tb->yD, tb->yB, tb->yC, spec ? tb->yA1 : tb->yA2};
+    if (spec) {
+      switch (order) {
+        case 0: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused_t<NN, 0, true>(ctx, a, t)))); break;
+        case 1: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused_t<NN, 1, true>(ctx, a, t)))); break;
+        case 2: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused_t<NN, 2, true>(ctx, a, t)))); break;
+        case 3: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused_t<NN, 3, true>(ctx, a, t)))); break;
+        default: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused_t<NN, 4, true>(ctx, a, t)))); break;
+      }
+      return MRL_OK;
+    }
+    switch (order) {
+      case 0: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused_t<NN, 0, false>(ctx, a, t)))); break;
+      case 1: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused_t<NN, 1, false>(ctx, a, t)))); break;
+      case 2: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused_t<NN, 2, false>(ctx, a, t)))); break;
+      case 3: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused_t<NN, 3, false>(ctx, a, t)))); break;
+      default: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused_t<NN, 4, false>(ctx, a, t)))); break;
+    }
+    return MRL_OK;
+  }
   if (spec) {
     switch (order) {
       case 0: MRL_SWITCH_N(ny, MRL_TRY((p2::launch_yfused<NN, 0, true>(ctx, a)))); break;
@@ -381,6 +661,13 @@ int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv) {
   a.cs_in = (unsigned)(nxl * xp);
   a.sh_out = 31;
   ProfScope ps(ctx, "slab_C_x_inv", 32.0 * nx * nyl * ksub);
+  if (!slab_fast_shift(ctx)) {  // table-addressed chunks
+    const SlabTabs *tb;
+    MRL_TRY(slab_tabs_get(ctx, kp, &tb));
+    const p2::SubPassTabs t{tb->xch, tb->xoff, tb->fsz, tb->cofi};
+    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub_t<NN, true, 1>(ctx, a, t, ctx->ax[0].d_tw))));
+    return MRL_OK;
+  }
   if (nx == 512 && !(ctx->exp & 1024)) return p2::launch_pass_sub_w<p2::Wide512, true>(ctx, a, ctx->ax[0].d_tw);
   MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub<NN, true, 1>(ctx, a, ctx->ax[0].d_tw))));
   return MRL_OK;

@@ -6,7 +6,9 @@
 
 namespace mrl {
 
-int slab_fast_ok(const mrl_ctx *ctx);
+int slab_fast_ok(const mrl_ctx *ctx);      // the fused slab pipeline applies (shift- or table-addressed chunks)
+int slab_fast_shift(const mrl_ctx *ctx);   // ... with equal power-of-two partitions: chunk addressing by shifts (the tuned kernels)
+long long slab_xplane_of(const mrl_ctx *ctx, long long rows, long long kp);   // x-plane pitch of a chunk with `rows` y rows
 int slab_mech_fast_ok(const mrl_ctx *ctx);  // ... and the exchange buffers of the mechanics row pipelines fit 32-bit byte offsets
 int slab_sub_range(mrl_ctx *ctx, int sub, int nsub, long long *k0, long long *ksub);
 long long slab_xplane(const mrl_ctx *ctx, long long kp);    // elements between two x planes of a chunk of those layouts (padded: odd number of 256-byte pieces)

@@ -66,6 +66,9 @@ def run_ch(job, P, r, kv, gold=False):
     ctx.attach_comm(comm)
     ctx.set_option(api.OPT_SLAB_NSUB, int(kv.get("nsub", 1)))
     ctx.set_option(api.OPT_SLAB_CARRY, int(kv.get("carry", 0)))
+    if "exp" in kv:
+        ctx.set_option(api.OPT_EXPERIMENT, int(kv["exp"]))
+    ctx.set_profiling(True)
     p = api.ch_params()
     yb, nyl = ctx.real_begin[1], ctx.real_shape[1]
     c = c0[:, yb:yb + nyl].contiguous().cuda()
@@ -89,9 +92,10 @@ def run_ch(job, P, r, kv, gold=False):
             gk = torch.from_numpy(g[f"c.{step}"].copy())
             gold_errs.append((c.cpu() - gk[:, yb - 10:yb - 10 + nyl]).abs().max().item())
     st, tr = comm.stats(), comm.transport
+    kernels = sorted(k["kernel"] for k in ctx.get_profile() if k["launches"])
     ctx.close()
     comm.close()
-    out = {"max_err": max(errs), "transport": tr, "stats": st}
+    out = {"max_err": max(errs), "transport": tr, "stats": st, "kernels": kernels}
     if gold_errs:
         out["max_gold_err"] = max(gold_errs)
     return out

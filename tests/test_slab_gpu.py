@@ -199,6 +199,38 @@ def test_slab_ch_matches_serial_oracle(shape, P, nsub):
     assert [s.last_order for s in solvers] == [1] * P
 
 
+@pytest.mark.parametrize("shape,P,nsub,exp", [((64, 64, 64), 3, 2, 0),       # the reference's 3-rank 64^3 test: 22 / 21 / 21 planes
+                                              ((100, 200, 50), 4, 1, 0),     # radix-10 family, ny / P = 50, nx / P = 25
+                                              ((200, 100, 40), 2, 3, 0),
+                                              ((96, 48, 64), 5, 1, 0),       # uneven on both axes: 20/19/19/19/19 and 10/10/10/9/9
+                                              ((64, 128, 64), 4, 2, 1 << 24)])   # a shift-addressable shape through the table kernels
+def test_slab_table_addressed_pipeline(shape, P, nsub, exp):
+    """partitions that are not equal powers of two (the reference's 200^3 example grid on 2 / 4 ranks, its 3-rank
+    64^3 test, device_weights) run the FUSED slab pipeline with table-addressed chunks (k_pass_sub_t, k_ch_yfused_t) instead of the
+    generic stages: fields vs the serial oracle to 1e-13 with and without the spectral carry-over, and the profile shows the fused
+    y pass"""
+    torch.manual_seed(4)
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    L = [3.0, 2.0, 2.5]
+    plain = _make(3, list(shape), L, P, nsub=nsub, exp=exp)
+    carry = _make(3, list(shape), L, P, nsub=nsub, carry=True, exp=exp)
+    assert int(plain[0].ctx.lib.mrl_slab_ch_spec_pitch(plain[0].ctx.h)) % 8 == 0     # the planned pipeline's padded rows
+    for s in plain + carry:
+        yb, nyl = s.st.real_begin[1], s.st.real_shape[1]
+        s.set_local(c0[:, yb:yb + nyl].contiguous().cuda())
+    plain[0].ctx.set_profiling(True)
+    dom = mo.Domain(3, list(shape), L)
+    ref = mo.CahnHilliardABM(dom, c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=3)
+    for k in range(2):
+        ref.step(1e-3)
+        _step_all(plain, 1e-3, 3)
+        _step_all(carry, 1e-3, 3)
+        assert (_gather(plain) - ref.c).abs().max().item() <= 1e-13
+        assert (_gather(carry) - ref.c).abs().max().item() <= 1e-13
+    names = {k["kernel"] for k in plain[0].ctx.get_profile() if k["launches"]}
+    assert {"slab_A_x_fwd", "slab_B_y_fused", "slab_C_x_inv"} <= names, names
+
+
 @pytest.mark.parametrize("shape,P,nsub", [((8, 6, 10), 2, 2), ((9, 7, 5), 3, 1), ((64, 64, 64), 2, 4), ((64, 128, 64), 8, 3),
                                           ((128, 64, 64), 4, 2), ((32, 64, 32), 32, 2)])
 def test_slab_ch_carry_over(shape, P, nsub):

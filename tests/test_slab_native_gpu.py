@@ -75,6 +75,24 @@ def test_native_slab_ch_vs_oracle(P, shape, transport, nsub, carry):
         assert all(r["stats"]["exchanges"] > 0 and r["stats"]["bytes_sent"] > 0 for r in res)
 
 
+@pytest.mark.parametrize("P,shape,transport,nsub,carry,exp", [
+    (3, "64,64,64", 1, 1, 0, 0),        # test/tests/tensor_compute/parallel_roundtrip_3d.i's grid on 3 ranks: 22 / 21 / 21 planes
+    (3, "64,64,64", 2, 2, 1, 0),        # ... copy-engine pushes, two kz sub-blocks, spectral carry-over
+    (2, "200,200,200", 1, 1, 0, 0),     # examples/cahn_hilliard/cahnhilliard2.i:7-13 (200^3) on 2 and 4 ranks: ny / P = 100, 50
+    (4, "200,200,200", 1, 2, 0, 0),
+    (2, "64,128,64", 1, 1, 0, 1 << 24)])   # a shift-addressable shape through the table-addressed kernels
+def test_native_slab_table_addressed_pipeline(P, shape, transport, nsub, carry, exp):
+    """partitions that are not equal powers of two take the FUSED slab pipeline (table-addressed chunks:
+    k_pass_sub_t, k_ch_yfused_t scattering into the peers' buffers), not the generic stages: the profile slots of the fused passes
+    are present on every rank, fields vs the serial oracle to 1e-13"""
+    res = run_job(P, "ch", f"shape={shape}", f"transport={transport}", f"nsub={nsub}", f"carry={carry}", f"exp={exp}", timeout=600)
+    assert max(r["max_err"] for r in res) <= 1e-13, res
+    for r in res:
+        assert {"slab_A_x_fwd", "slab_B_y_fused", "slab_C_x_inv"} <= set(r["kernels"]), r["kernels"]
+        assert not {"slab_x_fwd", "slab_y_fwd", "slab_pack"} & set(r["kernels"]), r["kernels"]
+        assert r["stats"]["exchanges"] > 0 and r["stats"]["bytes_sent"] > 0
+
+
 @pytest.mark.parametrize("P,shape,transport", [(2, "16,12,10", 1), (3, "9,7,5", 2), (4, "64,64,64", 1), (2, "16,12", 2),
                                                (3, "64,64,64", 1)])   # (test/tests/tensor_compute/parallel_roundtrip_3d.i: 64^3 on 3 ranks, 22 / 21 / 21 planes)
 def test_native_slab_fft(P, shape, transport):

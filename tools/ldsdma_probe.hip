@@ -347,5 +347,32 @@ int main(int argc, char **argv) {
             5 * 64 * 16 * 16, 5 * 64 * 16 * 16, "LDS-DMA 5 x 16 KB ring", "LDS-DMA 5 x 16 KB ring, nt loads");
     }
   }
+  if (which == 7) {
+    // light run for rocprofv3 --pmc (tools/pmc_probe.sh): the 256^3 x pass with plane pitch + argv[2] elements, four launches of the
+    // register-staged form and four of the LDS-DMA form, nothing else
+    const unsigned nx = 256, ncol = 256 * 129, pad = argc > 2 ? atoi(argv[2]) : 0, sn = ncol + pad;
+    Args a{};
+    a.rows = 1; a.cols = ncol; a.tcols = ncol; a.pitch_in = sn; a.pitch_out = sn; a.sn_in = sn; a.sn_out = sn;
+    a.ntiles = (ncol + 15) / 16; a.work = 4; a.remap = 1;
+    const size_t cap = (size_t)nx * sn + 4096;
+    double2 *in[2], *out[2];
+    for (int b = 0; b < 2; ++b) {
+      CK(hipMalloc(&in[b], cap * sizeof(double2)));
+      CK(hipMalloc(&out[b], cap * sizeof(double2)));
+      k_fill<<<2048, 256>>>(in[b], cap, 1.0 + b);
+    }
+    auto kd = k_dma_move<256, 16, 64, 5, false>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 64 * 16 * 16));
+    for (int r = 0; r < 4; ++r) {
+      a.in = in[r % 2]; a.out = out[r % 2];
+      hipLaunchKernelGGL((k_move<256, 16, 16>), dim3(a.ntiles), dim3(256), 0, 0, a);
+    }
+    for (int r = 0; r < 4; ++r) {
+      a.in = in[r % 2]; a.out = out[r % 2];
+      hipLaunchKernelGGL(kd, dim3(512), dim3(320), 5 * 64 * 16 * 16, 0, a);
+    }
+    CK(hipDeviceSynchronize());
+    printf("pad %u done\n", pad);
+  }
   return 0;
 }
