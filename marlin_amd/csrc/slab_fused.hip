@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
   const int ix = logical / a.tiles_per_x;
   const int kl0 = (logical % a.tiles_per_x) * T + l;
   const bool valid = kl0 < a.ksub;
-  const int kl = valid ? kl0 : 0;
+  const int kl = valid ? kl0 : a.ksub - 1;  // (idle lanes of the last tile re-load its last valid column: the same 128-byte line, not another one)
   // element (ix, j, k0+kl), p = j >> nyl_shift, jl = j & (nyl-1)       [byte offsets]
   //   forward exchange layout  (p*2 + field)*chunk + ix*xp + jl*kp + kl
   //   inverse exchange layout   p*chunk            + ix*xp + jl*kp + kl
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused_t(YFusedArgs a, YT
   const int ix = logical / a.tiles_per_x;
   const int kl0 = (logical % a.tiles_per_x) * T + l;
   const bool valid = kl0 < a.ksub;
-  const int kl = valid ? kl0 : 0;
+  const int kl = valid ? kl0 : a.ksub - 1;  // (idle lanes of the last tile re-load its last valid column: the same 128-byte line, not another one)
   const unsigned uix = (unsigned)ix, klB = (unsigned)kl * 16u;
   // element (field f, ix, j, k0 + kl) of the received forward buffer: yA[j] + f * yC[j] + ix * yB[j] + kl; of the chunk for rank
   // ych[j] in the inverse layout: ix * yB[j] + yD[j] + kl                                                        [byte offsets]

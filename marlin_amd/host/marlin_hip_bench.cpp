@@ -197,8 +197,7 @@ struct ChState
 static void ch_alloc(Rank & R, ChState & S)
 {
   S.nreal = (size_t)(R.rn[0] * R.rn[1] * R.rn[2]);
-  const int64_t pitch = R.slab ? mrl_slab_ch_spec_pitch(R.ctx) : R.kn[2];
-  S.nspec2 = 2 * (size_t)(R.kn[0] * R.kn[1] * pitch);
+  S.nspec2 = 2 * (size_t)mrl_ch_spec_elems(R.ctx);  // the solver's private layout (padded rows / x planes): include/marlin_hip.h
   for (int k = 0; k < 2; ++k)
   {
     HIPCK(hipMalloc(reinterpret_cast<void **>(&S.c[k]), sizeof(double) * S.nreal));
@@ -407,13 +406,28 @@ static int run_ch(Rank & R)
       results.push_back(r);
     }
     mrl_comm_set_timeout(R.comm, 120.0);
-    // the checksum most candidates agree on (median) is the reference; a candidate that disagrees is disqualified
-    std::vector<double> sums;
-    for (auto & r : results)
-      if (r.ok)
-        sums.push_back(r.sum);
-    std::sort(sums.begin(), sums.end());
-    const double ref = sums.empty() ? 0.0 : sums[sums.size() / 2];
+    // reference checksum: the most conservative transport that ran -- RCCL (its own rendezvous and fences), else the copy engines
+    // (hipMemcpyAsync between IPC mappings), else the median of the peer-store variants.  The peer-store candidates share one
+    // memory-model argument: if it failed on this node they could agree with each other and still be wrong, so
+    // they must not outvote a transport that does not depend on it.  A candidate that disagrees is disqualified.
+    double ref = 0.0;
+    bool have_ref = false;
+    for (int want : {MRL_TRANSPORT_RCCL, MRL_TRANSPORT_PEER_COPY})
+      for (auto & r : results)
+        if (!have_ref && r.ok && r.c.transport == want)
+        {
+          ref = r.sum;
+          have_ref = true;
+        }
+    if (!have_ref)
+    {
+      std::vector<double> sums;
+      for (auto & r : results)
+        if (r.ok)
+          sums.push_back(r.sum);
+      std::sort(sums.begin(), sums.end());
+      ref = sums.empty() ? 0.0 : sums[sums.size() / 2];
+    }
     int best = -1;
     tuned << "[";
     for (size_t k = 0; k < results.size(); ++k)

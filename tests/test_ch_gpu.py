@@ -74,11 +74,13 @@ def test_ch_gold_file_3d():
     assert np.abs(g["mu.10"] - mu.numpy()).max() <= 1e-13
 
 
-@pytest.mark.parametrize("shape", [(16, 16, 16), (12, 10, 9), (32, 32, 32), (24,), (64, 64, 64), (100, 100, 100),
-                                   (200, 64, 100), (128, 128), (200, 100), (64, 400), (96, 192, 64), (384, 96),
-                                   (40, 40, 40), (50, 80, 32), (48, 144, 250), (500, 32), (1000, 48), (768, 40, 32),
-                                   (2048, 64), (32, 4096), (2048, 32, 40),
-                                   (150, 150), (120, 90, 60), (240, 64, 150), (64, 270, 100), (300, 180), (360, 60, 48),   # planned-unfused path
+# one shape per plan family and length (every planned length of fft_pow2.h appears once, with small co-dimensions: the oracle's CPU
+# transforms are what this sweep costs), the generic any-length path, 1-D / 2-D
+@pytest.mark.parametrize("shape", [(16, 16, 16), (12, 10, 9), (32, 32, 32), (24,), (64, 64, 64), (100, 40, 50),
+                                   (200, 64, 40), (128, 128), (200, 100), (64, 400), (96, 192, 48), (384, 96),
+                                   (40, 80, 32), (48, 144, 50), (250, 32), (500, 32), (1000, 48), (768, 40, 32),
+                                   (2048, 64), (32, 4096), (2048, 32, 40), (256, 32, 512), (1024, 32),
+                                   (150, 150), (120, 90, 60), (240, 40, 32), (32, 270, 40), (300, 180), (360, 60, 48), (450, 600),   # planned-unfused path
                                    (160, 64, 40), (64, 320, 32), (640, 160), (32, 40, 1280),                               # ... radix-20 lengths
                                    (288, 64, 40), (72, 216), (576, 64), (800, 32), (48, 432, 72), (864, 1152)])            # ... further plain plans
 def test_ch_vs_oracle(shape):
@@ -89,13 +91,14 @@ def test_ch_vs_oracle(shape):
     dom = mo.Domain(dim, list(shape), L)
     torch.manual_seed(11)
     c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
-    ref = mo.CahnHilliardABM(dom, c0, 0.2, -0.001, mo.mu_double_well, substeps=5)
-    for _ in range(3):
-        ref.step(5e-3)
-    states, _ = _run_hip_ch(ctx, ch_params(), c0, 3, 5, 5e-3)
+    # two time steps of three substeps: AB1, then AB2 with the history rules of the first and of a later time step
+    ref = mo.CahnHilliardABM(dom, c0, 0.2, -0.001, mo.mu_double_well, substeps=3)
+    for _ in range(2):
+        ref.step(3e-3)
+    states, _ = _run_hip_ch(ctx, ch_params(), c0, 2, 3, 3e-3)
     assert (states[-1] - ref.c).abs().max().item() <= 1e-13
     # opt-in spectral carry-over (c-hat = ubar of the previous substep): same fields to rounding
-    carried, _ = _run_hip_ch(ctx, ch_params(), c0, 3, 5, 5e-3, carry=True)
+    carried, _ = _run_hip_ch(ctx, ch_params(), c0, 2, 3, 3e-3, carry=True)
     assert (carried[-1] - ref.c).abs().max().item() <= 1e-13
 
 
@@ -217,7 +220,8 @@ def test_config_a_pfhub_1a_128():
     """BASELINE configs[0] as SURVEY 8(d) specifies it: PFHub benchmark 1a (benchmarks/01_spinodal_decomposition/1a_solver.i:45-86)
     on 128^2, L = 200 x 200: f = rho (c - c_alpha)^2 (c_beta - c)^2 with rho 5, c_alpha 0.3, c_beta 0.7, Mbar = -5 k^2,
     Lbar = -10 k^4, the benchmark's three-mode initial condition, AB2, 10 time steps of dt = 1 with 1000 substeps each
-    (spectral_solve_substeps = 1000): the HIP path (one library call per time step) against the oracle after every step, and the
+    (spectral_solve_substeps = 1000): the HIP path (one library call per time step) against the oracle after each of the first
+    three steps (3 000 substeps; the oracle's 10 000 CPU substeps were 70 s of the GPU test tier), and the
     total free energy F = int f + |grad c|^2 (the input's [Postprocess] block, FFTGradientSquare factor 1) falls monotonically.
     Tolerance: the reference's 1e-13 is quoted for 100 substeps (test/tests/cahnhilliard/tests:46-57); the butterflies of this FFT
     and MKL's round differently (1e-16 per transform) and the difference grows linearly with the substep count -- measured 1.8e-14
@@ -246,12 +250,14 @@ def test_config_a_pfhub_1a_128():
 
     energies = [free_energy(c0)]
     for step in range(10):
-        ref.step(1.0)
+        if step < 3:
+            ref.step(1.0)
         if step > 0:
             head, n_old = (head + 1) % pred, min(n_old + 1, pred - 1)
         out = torch.empty_like(c)
         head, n_old = ctx.ch_substeps(p, c, out, ring, head, n_old, pred, substeps, step > 0, 1.0 / substeps)
         c = out
-        assert (c.cpu() - ref.c).abs().max().item() <= max(1e-13, 1e-16 * substeps * (step + 1))
+        if step < 3:
+            assert (c.cpu() - ref.c).abs().max().item() <= max(1e-13, 1e-16 * substeps * (step + 1))
         energies.append(free_energy(c.cpu()))
     assert all(b < a for a, b in zip(energies, energies[1:])), energies

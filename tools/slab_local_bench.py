@@ -2,7 +2,7 @@
 """Time the LOCAL stages of one rank of a P-rank slab decomposition on a single GPU (the exchange is
 replaced by a device copy of the rank's own send buffer, same byte count as the receive buffer), to
 size the compute side of the 512^3 / 8-GPU configuration without an 8-GPU node.
-usage: slab_local_bench.py [P] [n] [steps] [nsub] [carry 0|1] [fused-run 0|1] [experiment mask]"""
+usage: slab_local_bench.py [P] [n] [steps] [nsub] [carry 0|1] [fused-run 0|1] [experiment mask] [global grid gx,gy,gz]"""
 import json
 import os
 import sys
@@ -34,7 +34,7 @@ def main():
     carry = bool(int(sys.argv[5])) if len(sys.argv) > 5 else True
     fused = bool(int(sys.argv[6])) if len(sys.argv) > 6 else True
     exp = int(sys.argv[7]) if len(sys.argv) > 7 else 0
-    shape = grid_for(P, n)
+    shape = [int(x) for x in sys.argv[8].split(",")] if len(sys.argv) > 8 else grid_for(P, n)   # argv[8]: the GLOBAL grid gx,gy,gz
     dx = 8.0 * np.pi / 200.0
     s = SlabCahnHilliard(3, shape, [x * dx for x in shape], ch_params(), P, 0, exchange_factory=lambda a, b: _Copy(a, b), nsub=nsub,
                          carry=carry, exp=exp)
