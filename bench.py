@@ -683,6 +683,23 @@ def main():
         variants["spectral_carry_over_on"] = {"ms_per_step": timed(k, 1) / k * 1e3, "substeps_per_library_call": 1}
         carried = None
 
+    if not args.no_variants and not slab and ctx.spec_elems_f32 > 0:
+        # fp32 form of the same substep (mrl_ch_substeps_f32: the same kernel templates instantiated for float).  NEVER the headline:
+        # the like-for-like number against the reference's only published GPU figures, which are fp32 (doc/content/installation.md:36-43)
+        k = min(args.steps, 40)
+        ring32 = [ctx.empty_hist_f32(zero=True), ctx.empty_hist_f32(zero=True)]
+        a32, b32 = ic.float().cuda(), torch.empty(shape, dtype=torch.float32, device="cuda")
+        h32, n32 = ctx.ch_substeps_f32(p, a32, b32, ring32, 1, 0, 2, 3, True, sub_dt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.ch_substeps_f32(p, b32, a32, ring32, (h32 + 1) % 2, 1, 2, k, True, sub_dt)
+        torch.cuda.synchronize()
+        ms32 = (time.perf_counter() - t0) / k * 1e3
+        variants["fp32"] = {"ms_per_step": ms32, "dtype": "f32", "substeps_per_library_call": k,
+                            "note": "mrl_ch_substeps_f32: the kernels of the fp64 path instantiated for float; parity vs the oracle run in "
+                                    "float32: tests/test_ch_f32_gpu.py (2e-6); never the headline"}
+        del ring32, a32, b32
+
     out = None
     if rank == 0:
         value = npts * args.steps / elapsed

@@ -254,6 +254,18 @@ int mrl_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, 
                     int ring_size, int *head, int *n_old, int predictor_order, int count, int advance, double sub_dt,
                     double *d_mu);
 
+/* fp32 form of mrl_ch_substeps.  The reference selects its floating-point precision per run (src/utils/MarlinUtils.C:39-44,
+ * DomainAction.C:81,201), and its only published GPU numbers are fp32 (doc/content/installation.md:36-43).  Same kernels as the fp64
+ * path instantiated for float (same butterflies, same pointwise expressions in the same association), on an ordinary context: the
+ * shim calls this entry point when the run's float tensor options are float32.  All arrays are float / complex64:
+ * d_c_in, d_c_out real [nx][ny][nz]; d_Nhat_ring arrays of mrl_ch_spec_elems_f32(ctx) complex64 values in the solver-private layout
+ * mrl_ch_spec_layout_f32 (x planes padded as for fp64).  Scope: serial 3-D contexts with extents in {64, 100, 128, 200, 256, 400, 512},
+ * built-in free-energy families, predictor_order <= 3; MRL_ERR_UNSUPPORTED otherwise (mrl_ch_spec_elems_f32 returns 0 then). */
+int64_t mrl_ch_spec_elems_f32(const mrl_ctx *ctx);
+int mrl_ch_spec_layout_f32(const mrl_ctx *ctx, int64_t *plane_pitch, int64_t *row_pitch);
+int mrl_ch_substeps_f32(mrl_ctx *ctx, const mrl_ch_params *p, const float *d_c_in, float *d_c_out, float *const *d_Nhat_ring,
+                        int ring_size, int *head, int *n_old, int predictor_order, int count, int advance, double sub_dt);
+
 /* ReciprocalLaplacianFactor (power = 1: -k^2 * factor, ReciprocalLaplacianFactor.C:28-31) and
  * ReciprocalLaplacianSquareFactor (power = 2: k^2 * k^2 * factor, ReciprocalLaplacianSquareFactor.C:28-32) as real
  * arrays on the local reciprocal grid, for solvers that take their linear operator as a buffer. */

@@ -84,6 +84,9 @@ SIGNATURES = {
     "mrl_ch_substep": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _vp, _pp, _i32, _dbl, _vp, _vp, _i32]),
     "mrl_ch_substeps": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _pp, _i32, C.POINTER(_i32), C.POINTER(_i32), _i32, _i32, _i32,
                         _dbl, _vp]),
+    "mrl_ch_spec_elems_f32": (_i64, [_vp]),
+    "mrl_ch_spec_layout_f32": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "mrl_ch_substeps_f32": (_i32, [_vp, C.POINTER(MrlChParams), _vp, _vp, _pp, _i32, C.POINTER(_i32), C.POINTER(_i32), _i32, _i32, _i32, _dbl]),
     "mrl_kspace_abm": (_i32, [_vp, _vp, _vp, _pp, C.POINTER(_dbl), _i32, _vp, _dbl, _i64]),
     "mrl_kspace_coupled": (_i32, [_vp, _i32, _pp, _pp, _pp, C.POINTER(_dbl), C.POINTER(_i32), _pp, _dbl, _i32, _i64]),
     "mrl_slab_fast_path": (_i32, [_vp]),

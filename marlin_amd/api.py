@@ -327,6 +327,34 @@ class Context:
                                              predictor_order, count, (1 if advance else 0) | (2 if dt_changed else 0), sub_dt, _ptr(mu)))
         return h.value, n.value
 
+    # ---- fp32 form of the fused Cahn-Hilliard solver (mrl_ch_substeps_f32; serial 3-D contexts of a few planned extents)
+    @property
+    def spec_elems_f32(self) -> int:
+        return int(self.lib.mrl_ch_spec_elems_f32(self.h))
+
+    def empty_hist_f32(self, zero: bool = False) -> torch.Tensor:
+        """a history array of the fp32 solver (complex64, solver-private layout) as a strided view of the reciprocal shape"""
+        n = self.spec_elems_f32
+        if n == 0:
+            raise MarlinHipError(-2, "mrl_ch_substeps_f32 does not cover this context (mrl_ch_spec_elems_f32 = 0)")
+        pl, rw = C.c_int64(), C.c_int64()
+        self._check(self.lib.mrl_ch_spec_layout_f32(self.h, C.byref(pl), C.byref(rw)))
+        buf = (torch.zeros if zero else torch.empty)(n, dtype=torch.complex64, device=self.device)
+        return torch.as_strided(buf, list(self.recip_shape), (pl.value, rw.value, 1))
+
+    def ch_substeps_f32(self, p: MrlChParams, c_in, c_out, ring: Sequence[torch.Tensor], head: int, n_old: int, predictor_order: int,
+                        count: int, advance: bool, sub_dt: float, dt_changed: bool = False):
+        assert c_in.dtype == torch.float32 and c_out.dtype == torch.float32 and all(t.dtype == torch.complex64 for t in ring)
+        need = 8 * self.spec_elems_f32
+        for t in ring:
+            if t.untyped_storage().nbytes() - t.storage_offset() * t.element_size() < need:
+                raise ValueError("history arrays of the fp32 solver need mrl_ch_spec_elems_f32 complex64 values (Context.empty_hist_f32)")
+        arr = (C.c_void_p * len(ring))(*[t.data_ptr() for t in ring])
+        h, n = C.c_int32(head), C.c_int32(n_old)
+        self._check(self.lib.mrl_ch_substeps_f32(self.h, C.byref(p), _ptr(c_in), _ptr(c_out), arr, len(ring), C.byref(h), C.byref(n),
+                                                 predictor_order, count, (1 if advance else 0) | (2 if dt_changed else 0), sub_dt))
+        return h.value, n.value
+
     def kspace_abm(self, out, ubar0, N: Sequence[torch.Tensor], coef: Sequence[float], L, dt: float):
         n = len(N)
         arr = (C.c_void_p * max(1, n))(*[t.data_ptr() for t in N])

@@ -13,39 +13,39 @@
 
 
 namespace mrl {
-namespace p2 {
+namespace MRL_P2NS {
 
 struct FusedCommon {
-  const cplx *chat;   // c-hat, work layout
-  const cplx *muhat;  // mu-hat, work layout
-  cplx *ubar;         // out, work layout (may alias chat)
-  cplx *Nnew;         // out, dense reference layout
-  cplx *cbar;         // optional out, dense: c-hat of this substep (the reference's cbar buffer)
-  cplx *carry;        // spectral carry-over (dense): SPEC_C -> in: c-hat of this substep, out: ubar = c-hat of the next one;
+  const kcplx *chat;   // c-hat, work layout
+  const kcplx *muhat;  // mu-hat, work layout
+  kcplx *ubar;         // out, work layout (may alias chat)
+  kcplx *Nnew;         // out, dense reference layout
+  kcplx *cbar;         // optional out, dense: c-hat of this substep (the reference's cbar buffer)
+  kcplx *carry;        // spectral carry-over (dense): SPEC_C -> in: c-hat of this substep, out: ubar = c-hat of the next one;
                       // otherwise optional out (ubar), which bootstraps the carry-over
-  const cplx *Nold[4];
-  double coef[5];     // sub_dt * beta[order][i]
-  double M, kappa, dt;
+  const kcplx *Nold[4];
+  kreal coef[5];     // sub_dt * beta[order][i]
+  kreal M, kappa, dt;
 };
 
 // LINE_IS_X: the line axis is x (k^2 = (kl^2 + ka^2) + kb^2 with ka = ky, kb = kz); otherwise the line
 // axis is y (k^2 = (ka^2 + kl^2) + kb^2 with ka = kx, kb = kz) -- the reference's association kx*kx + ky*ky + kz*kz.
 // 32-bit BYTE offsets from a wave-uniform base pointer: the loads / stores take the "SGPR base + 32-bit VGPR
 // offset" form, which halves the address registers of the 5 x 16 accesses (arrays of the fast path are < 4 GiB).
-__device__ __forceinline__ cplx ldc(const cplx *base, unsigned boff) {
-  return *reinterpret_cast<const cplx *>(reinterpret_cast<const char *>(base) + boff);
+__device__ __forceinline__ kcplx ldc(const kcplx *base, unsigned boff) {
+  return *reinterpret_cast<const kcplx *>(reinterpret_cast<const char *>(base) + boff);
 }
-__device__ __forceinline__ void stc(cplx *base, unsigned boff, cplx v) {
-  *reinterpret_cast<cplx *>(reinterpret_cast<char *>(base) + boff) = v;
+__device__ __forceinline__ void stc(kcplx *base, unsigned boff, kcplx v) {
+  *reinterpret_cast<kcplx *>(reinterpret_cast<char *>(base) + boff) = v;
 }
 // streaming (non-temporal) forms for the arrays that are not touched again within the substep (old / new Nhat): they
 // should not displace the work arrays, which the next pass re-reads, from the 256 MB Infinity Cache
-typedef double nt_v2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ cplx ldc_nt(const cplx *base, unsigned boff) {
+typedef kreal nt_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ kcplx ldc_nt(const kcplx *base, unsigned boff) {
   const nt_v2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_v2 *>(reinterpret_cast<const char *>(base) + boff));
-  return make_double2(v.x, v.y);
+  return mkc(v.x, v.y);
 }
-__device__ __forceinline__ void stc_nt(cplx *base, unsigned boff, cplx v) {
+__device__ __forceinline__ void stc_nt(kcplx *base, unsigned boff, kcplx v) {
   nt_v2 w;
   w.x = v.x;
   w.y = v.y;
@@ -58,17 +58,17 @@ struct BigOff {
   unsigned long long uni;
   unsigned lane;
 };
-__device__ __forceinline__ cplx ldc(const cplx *base, BigOff o) {
-  return *reinterpret_cast<const cplx *>(reinterpret_cast<const char *>(base) + o.uni + o.lane);
+__device__ __forceinline__ kcplx ldc(const kcplx *base, BigOff o) {
+  return *reinterpret_cast<const kcplx *>(reinterpret_cast<const char *>(base) + o.uni + o.lane);
 }
-__device__ __forceinline__ void stc(cplx *base, BigOff o, cplx v) {
-  *reinterpret_cast<cplx *>(reinterpret_cast<char *>(base) + o.uni + o.lane) = v;
+__device__ __forceinline__ void stc(kcplx *base, BigOff o, kcplx v) {
+  *reinterpret_cast<kcplx *>(reinterpret_cast<char *>(base) + o.uni + o.lane) = v;
 }
-__device__ __forceinline__ cplx ldc_nt(const cplx *base, BigOff o) {
+__device__ __forceinline__ kcplx ldc_nt(const kcplx *base, BigOff o) {
   const nt_v2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_v2 *>(reinterpret_cast<const char *>(base) + o.uni + o.lane));
-  return make_double2(v.x, v.y);
+  return mkc(v.x, v.y);
 }
-__device__ __forceinline__ void stc_nt(cplx *base, BigOff o, cplx v) {
+__device__ __forceinline__ void stc_nt(kcplx *base, BigOff o, kcplx v) {
   nt_v2 w;
   w.x = v.x;
   w.y = v.y;
@@ -90,29 +90,29 @@ __device__ __forceinline__ void stc_nt(cplx *base, BigOff o, cplx v) {
 // received chunk lies a chunk-dependent distance behind the first); the other callers pass `offw` twice.
 template <int N, int ORDER, bool LINE_IS_X, int PRE, bool SPEC_C, bool NT_W, bool NT_CARRY, bool NT_HIST, class OffW,
           class OffM, class OffD, class StU>
-__device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *__restrict__ tw,
-                                              const double *__restrict__ kline, const double *__restrict__ ka_ptr,
-                                              const double *__restrict__ kb_ptr, bool valid, int q, int l,
-                                              OffW offw, OffM offm, OffD offd, StU stu, cplx *W, cplx *X,
-                                              double *KL) {
+__device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const kcplx *__restrict__ tw,
+                                              const kreal *__restrict__ kline, const kreal *__restrict__ ka_ptr,
+                                              const kreal *__restrict__ kb_ptr, bool valid, int q, int l,
+                                              OffW offw, OffM offm, OffD offd, StU stu, kcplx *W, kcplx *X,
+                                              kreal *KL) {
 #pragma clang fp contract(off)
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, NT = Plan<N>::NT, CNT = (N + NT - 1) / NT;
   static_assert(PRE <= P, "prefetch depth");
   using Map = MapStrided<N>;
 
   // ---- issue every early load: small ones first
-  cplx twv[CNT];
-  double klv[CNT];
+  kcplx twv[CNT];
+  kreal klv[CNT];
 #pragma unroll
   for (int j = 0; j < CNT; ++j) {
     const int idx = threadIdx.x + j * NT;
-    twv[j] = idx < N ? tw[idx] : make_double2(0.0, 0.0);
+    twv[j] = idx < N ? tw[idx] : mkc(0.0, 0.0);
     klv[j] = idx < N ? kline[idx] : 0.0;
   }
   // Loads are unconditional (the caller clamps the offsets of out-of-range lanes to a valid element; their
   // results are never stored): a branch around them would make hipcc's vmcnt bookkeeping fall back to vmcnt(0).
-  const double ka = *ka_ptr, kb = *kb_ptr;
-  cplx v[P], cp[P];
+  const kreal ka = *ka_ptr, kb = *kb_ptr;
+  kcplx v[P], cp[P];
 #pragma unroll
   for (int m = 0; m < P; ++m) v[m] = NT_W ? ldc_nt(a.muhat, offm(m)) : ldc(a.muhat, offm(m));
 #pragma unroll
@@ -125,19 +125,19 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
       KL[idx] = klv[j];
     }
   }
-  const double ka2 = ka * ka, kb2 = kb * kb;
+  const kreal ka2 = ka * ka, kb2 = kb * kb;
 
   // ---- 1. mu-hat: forward transform (its first exchange publishes W and KL to the workgroup)
   fft_line<N, Map>(v, q, l, X, W);
 
   // ---- 2. Nhat = Mbar * mu-hat, Mbar = -k^2 * M
-  cplx Nv[P];
+  kcplx Nv[P];
 #pragma unroll
   for (int m = 0; m < P; ++m) {
-    const double kl = KL[q + m * TPL];
-    const double k2 = LINE_IS_X ? (kl * kl + ka2) + kb2 : (ka2 + kl * kl) + kb2;
-    const double Mbar = -k2 * a.M;
-    Nv[m] = make_double2(Mbar * v[m].x, Mbar * v[m].y);
+    const kreal kl = KL[q + m * TPL];
+    const kreal k2 = LINE_IS_X ? (kl * kl + ka2) + kb2 : (ka2 + kl * kl) + kb2;
+    const kreal Mbar = -k2 * a.M;
+    Nv[m] = mkc(Mbar * v[m].x, Mbar * v[m].y);
   }
   if (valid) {
 #pragma unroll
@@ -160,7 +160,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
 
   // ---- first-order history: PRE of the 16 old Nhat values are requested before the c-hat transform and are in flight
   //      during it, the rest right after it (PRE is tuned per kernel against the 256-VGPR / two-waves-per-SIMD limit)
-  cplx o1[ORDER == 1 ? P : 1];
+  kcplx o1[ORDER == 1 ? P : 1];
   if (ORDER == 1) {
 #pragma unroll
     for (int m = 0; m < PRE; ++m) o1[ORDER == 1 ? m : 0] = NT_HIST ? ldc_nt(a.Nold[0], offd(m)) : ldc(a.Nold[0], offd(m));
@@ -179,18 +179,18 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
     for (int m = PRE; m < P; ++m) o1[ORDER == 1 ? m : 0] = NT_HIST ? ldc_nt(a.Nold[0], offd(m)) : ldc(a.Nold[0], offd(m));
 #pragma unroll
     for (int m = 0; m < P; ++m) {
-      cplx u = cp[m];
+      kcplx u = cp[m];
       if (!SPEC_C) {
         u.x = u.x + a.coef[0] * Nv[m].x;
         u.y = u.y + a.coef[0] * Nv[m].y;
       }
       u.x += a.coef[1] * o1[ORDER == 1 ? m : 0].x;
       u.y += a.coef[1] * o1[ORDER == 1 ? m : 0].y;
-      const double kl = KL[q + m * TPL];
-      const double k2 = LINE_IS_X ? (kl * kl + ka2) + kb2 : (ka2 + kl * kl) + kb2;
-      const double Lb = k2 * k2 * a.kappa;
-      const double scl = 1.0 / (1.0 - a.dt * Lb);
-      v[m] = make_double2(u.y * scl, u.x * scl);  // swapped for the inverse transform
+      const kreal kl = KL[q + m * TPL];
+      const kreal k2 = LINE_IS_X ? (kl * kl + ka2) + kb2 : (ka2 + kl * kl) + kb2;
+      const kreal Lb = k2 * k2 * a.kappa;
+      const kreal scl = kreal(1.0) / (kreal(1.0) - a.dt * Lb);
+      v[m] = mkc(u.y * scl, u.x * scl);  // swapped for the inverse transform
     }
   } else {
     //    (deeper histories: half of the points at a time; a run-time trip count here would make hipcc wait vmcnt(0) per element)
@@ -198,7 +198,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
     constexpr int H = (ORDER >= 3 && P % 4 == 0) ? P / 4 : P / 2;
 #pragma unroll
     for (int half = 0; half < P / H; ++half) {
-      cplx o[ORDER > 0 ? ORDER : 1][H];
+      kcplx o[ORDER > 0 ? ORDER : 1][H];
 #pragma unroll
       for (int h = 0; h < ORDER; ++h) {
 #pragma unroll
@@ -207,7 +207,7 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
 #pragma unroll
       for (int j = 0; j < H; ++j) {
         const int m = half * H + j;
-        cplx u = cp[m];
+        kcplx u = cp[m];
         if (!SPEC_C) {
           u.x = u.x + a.coef[0] * Nv[m].x;
           u.y = u.y + a.coef[0] * Nv[m].y;
@@ -217,11 +217,11 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
           u.x += a.coef[h + 1] * o[h][j].x;
           u.y += a.coef[h + 1] * o[h][j].y;
         }
-        const double kl = KL[q + m * TPL];
-        const double k2 = LINE_IS_X ? (kl * kl + ka2) + kb2 : (ka2 + kl * kl) + kb2;
-        const double Lb = k2 * k2 * a.kappa;
-        const double scl = 1.0 / (1.0 - a.dt * Lb);
-        v[m] = make_double2(u.y * scl, u.x * scl);
+        const kreal kl = KL[q + m * TPL];
+        const kreal k2 = LINE_IS_X ? (kl * kl + ka2) + kb2 : (ka2 + kl * kl) + kb2;
+        const kreal Lb = k2 * k2 * a.kappa;
+        const kreal scl = kreal(1.0) / (kreal(1.0) - a.dt * Lb);
+        v[m] = mkc(u.y * scl, u.x * scl);
       }
     }
   }
@@ -244,5 +244,5 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const cplx *
   }
 }
 
-}  // namespace p2
+}  // namespace MRL_P2NS
 }  // namespace mrl

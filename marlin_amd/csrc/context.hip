@@ -136,6 +136,43 @@ static int build_axis(mrl_ctx *ctx, AxisPlan &ax, long long n) {
   return MRL_OK;
 }
 
+// fp32 copies for the fp32 instantiation of the fused Cahn-Hilliard path (ch_fused_f32.hip), built on first use.
+// Twiddles: the long-double table rounded once to float.  Reciprocal axis: the reference's sequence evaluated in float32 as libTorch
+// does for a float32 run (MarlinUtils.C:39-44): fftfreq = arange * float(1 / (n d)), then * 2.0f, then * float(pi).
+int axis_tw32(mrl_ctx *ctx, int axis) {
+  AxisPlan &ax = ctx->ax[axis];
+  if (ax.d_tw32) return MRL_OK;
+  const long long n = ax.n;
+  std::vector<float2> tw((size_t)n);
+  const long double two_pi = 6.283185307179586476925286766559005768L;
+  for (long long k = 0; k < n; ++k) {
+    const long double a = two_pi * (long double)k / (long double)n;
+    tw[k] = make_float2((float)cosl(a), (float)(-sinl(a)));
+  }
+  MRL_HIP(ctx, hipMalloc(&ax.d_tw32, sizeof(float2) * n));
+  MRL_HIP(ctx, hipMemcpy(ax.d_tw32, tw.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+  return MRL_OK;
+}
+
+int axis_k32(mrl_ctx *ctx, int axis) {
+  AxisPlan &ax = ctx->ax[axis];
+  if (ax.d_k32) return MRL_OK;
+  const long long n = ctx->n[axis], cnt = ctx->nrec[axis];
+  const bool rfft = (axis == 2) && ctx->spectrum == MRL_SPECTRUM_HALF;
+  std::vector<float> k((size_t)cnt);
+  const float scale = (float)(1.0 / ((double)n * ctx->dx[axis]));
+  for (long long i = 0; i < cnt; ++i) {
+    long long idx = i + ctx->kbeg[axis];
+    if (!rfft && idx >= (n + 1) / 2) idx -= n;
+    if (n == 1) idx = 0;
+    const float f = (float)idx * scale;
+    k[i] = f * 2.0f * (float)M_PI;
+  }
+  MRL_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ax.d_k32), sizeof(float) * cnt));
+  MRL_HIP(ctx, hipMemcpy(ax.d_k32, k.data(), sizeof(float) * cnt, hipMemcpyHostToDevice));
+  return MRL_OK;
+}
+
 // torch::fft::fftfreq / rfftfreq followed by `* 2.0 * pi` (DomainAction.C:284-293):
 //   arange values times the scalar 1.0/(n*d), then *2.0, then *pi  -- same rounding sequence.
 static void reciprocal_axis(long long n, double dx, bool rfft, std::vector<double> &out) {
@@ -386,6 +423,8 @@ void mrl_ctx_destroy(mrl_ctx *c) {
     if (t.d) hipFree(t.d);
   for (int a = 0; a < 3; ++a) {
     if (c->ax[a].d_tw) hipFree(c->ax[a].d_tw);
+    if (c->ax[a].d_tw32) hipFree(c->ax[a].d_tw32);
+    if (c->ax[a].d_k32) hipFree(c->ax[a].d_k32);
     if (c->d_k[a]) hipFree(c->d_k[a]);
     if (c->d_x[a]) hipFree(c->d_x[a]);
   }

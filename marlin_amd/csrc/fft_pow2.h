@@ -11,16 +11,45 @@
 #pragma once
 #include "mrl_internal.h"
 
-namespace mrl {
-namespace p2 {
+// Scalar type of the kernels built from these headers: double (the product path) unless a translation unit defines MRL_KREAL = float
+// and MRL_P2NS before including them (ch_fused_f32.hip: the fp32 instantiation of the fused Cahn-Hilliard path, its own namespace).
+#ifndef MRL_KREAL
+#define MRL_KREAL double
+#endif
+#ifndef MRL_P2NS
+#define MRL_P2NS p2
+#endif
 
-__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
-  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+namespace mrl {
+namespace MRL_P2NS {
+
+typedef MRL_KREAL kreal;
+template <class T>
+struct Complex2;
+template <>
+struct Complex2<double> {
+  typedef double2 type;
+};
+template <>
+struct Complex2<float> {
+  typedef float2 type;
+};
+typedef Complex2<kreal>::type kcplx;  // interleaved (re, im)
+__device__ __forceinline__ kcplx mkc(kreal x, kreal y) {
+  kcplx r;
+  r.x = x;
+  r.y = y;
+  return r;
 }
-__device__ __forceinline__ cplx mul_mi(cplx a) { return make_double2(a.y, -a.x); }  // * (-i)
-__device__ __forceinline__ cplx cswap(cplx a) { return make_double2(a.y, a.x); }
+
+
+__device__ __forceinline__ kcplx cadd(kcplx a, kcplx b) { return mkc(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ kcplx csub(kcplx a, kcplx b) { return mkc(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ kcplx cmul(kcplx a, kcplx b) {
+  return mkc(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ kcplx mul_mi(kcplx a) { return mkc(a.y, -a.x); }  // * (-i)
+__device__ __forceinline__ kcplx cswap(kcplx a) { return mkc(a.y, a.x); }
 
 // Plan<N>: P = points per thread, up to four radix stages r0..r3 (1 = unused; every radix divides P), T = lines per
 // workgroup.  TPL = N/P threads own one line, a workgroup is NT = T*TPL threads (256 for the power-of-two sizes,
@@ -108,8 +137,8 @@ struct ZPlan<256> {
 };
 #undef MRL_PLAN
 
-__device__ __forceinline__ void bfly4(cplx &a0, cplx &a1, cplx &a2, cplx &a3) {
-  const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
+__device__ __forceinline__ void bfly4(kcplx &a0, kcplx &a1, kcplx &a2, kcplx &a3) {
+  const kcplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
   a0 = cadd(t0, t2);
   a1 = cadd(t1, t3);
   a2 = csub(t0, t2);
@@ -118,23 +147,23 @@ __device__ __forceinline__ void bfly4(cplx &a0, cplx &a1, cplx &a2, cplx &a3) {
 
 // natural-order DFT of R register values a[0..R-1]
 template <int R>
-__device__ __forceinline__ void bfly(cplx (&a)[R]);
+__device__ __forceinline__ void bfly(kcplx (&a)[R]);
 
 template <>
-__device__ __forceinline__ void bfly<4>(cplx (&a)[4]) {
+__device__ __forceinline__ void bfly<4>(kcplx (&a)[4]) {
   bfly4(a[0], a[1], a[2], a[3]);
 }
 
 template <>
-__device__ __forceinline__ void bfly<8>(cplx (&a)[8]) {
-  const double h = 0.70710678118654752440;
-  cplx e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
-  cplx o0 = a[1], o1 = a[3], o2 = a[5], o3 = a[7];
+__device__ __forceinline__ void bfly<8>(kcplx (&a)[8]) {
+  const kreal h = 0.70710678118654752440;
+  kcplx e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
+  kcplx o0 = a[1], o1 = a[3], o2 = a[5], o3 = a[7];
   bfly4(e0, e1, e2, e3);
   bfly4(o0, o1, o2, o3);
-  o1 = make_double2(h * (o1.x + o1.y), h * (o1.y - o1.x));    // * W8^1 = (h, -h)
+  o1 = mkc(h * (o1.x + o1.y), h * (o1.y - o1.x));    // * W8^1 = (h, -h)
   o2 = mul_mi(o2);                                            // * W8^2 = -i
-  o3 = make_double2(h * (o3.y - o3.x), -h * (o3.x + o3.y));   // * W8^3 = (-h, -h)
+  o3 = mkc(h * (o3.y - o3.x), -h * (o3.x + o3.y));   // * W8^3 = (-h, -h)
   a[0] = cadd(e0, o0);
   a[4] = csub(e0, o0);
   a[1] = cadd(e1, o1);
@@ -146,26 +175,26 @@ __device__ __forceinline__ void bfly<8>(cplx (&a)[8]) {
 }
 
 template <>
-__device__ __forceinline__ void bfly<16>(cplx (&a)[16]) {
-  const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
+__device__ __forceinline__ void bfly<16>(kcplx (&a)[16]) {
+  const kreal c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
   // inner DFT-4 over n1 for each n2: (a[n2], a[n2+4], a[n2+8], a[n2+12]) -> A[n2][k1] at a[n2+4*k1]
 #pragma unroll
   for (int n2 = 0; n2 < 4; ++n2) bfly4(a[n2], a[n2 + 4], a[n2 + 8], a[n2 + 12]);
   // twiddles W16^(n2*k1)
-  a[5] = cmul(a[5], make_double2(c1, -s1));                      // 1*1
-  a[9] = make_double2(h * (a[9].x + a[9].y), h * (a[9].y - a[9].x));  // 1*2 -> W16^2
-  a[13] = cmul(a[13], make_double2(s1, -c1));                    // 1*3
-  a[6] = make_double2(h * (a[6].x + a[6].y), h * (a[6].y - a[6].x));  // 2*1 -> W16^2
+  a[5] = cmul(a[5], mkc(c1, -s1));                      // 1*1
+  a[9] = mkc(h * (a[9].x + a[9].y), h * (a[9].y - a[9].x));  // 1*2 -> W16^2
+  a[13] = cmul(a[13], mkc(s1, -c1));                    // 1*3
+  a[6] = mkc(h * (a[6].x + a[6].y), h * (a[6].y - a[6].x));  // 2*1 -> W16^2
   a[10] = mul_mi(a[10]);                                         // 2*2 -> W16^4
-  a[14] = make_double2(h * (a[14].y - a[14].x), -h * (a[14].x + a[14].y));  // 2*3 -> W16^6
-  a[7] = cmul(a[7], make_double2(s1, -c1));                      // 3*1 -> W16^3
-  a[11] = make_double2(h * (a[11].y - a[11].x), -h * (a[11].x + a[11].y));  // 3*2 -> W16^6
-  a[15] = cmul(a[15], make_double2(-c1, s1));                    // 3*3 -> W16^9
+  a[14] = mkc(h * (a[14].y - a[14].x), -h * (a[14].x + a[14].y));  // 2*3 -> W16^6
+  a[7] = cmul(a[7], mkc(s1, -c1));                      // 3*1 -> W16^3
+  a[11] = mkc(h * (a[11].y - a[11].x), -h * (a[11].x + a[11].y));  // 3*2 -> W16^6
+  a[15] = cmul(a[15], mkc(-c1, s1));                    // 3*3 -> W16^9
   // outer DFT-4 over n2 for each k1: X[k1 + 4*k2] lands at a[4*k1 + k2]
 #pragma unroll
   for (int k1 = 0; k1 < 4; ++k1) bfly4(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);
   // transpose to natural order
-  cplx t;
+  kcplx t;
 #define MRL_SWAP(i, j) \
   t = a[i];            \
   a[i] = a[j];         \
@@ -175,35 +204,36 @@ __device__ __forceinline__ void bfly<16>(cplx (&a)[16]) {
 }
 
 template <>
-__device__ __forceinline__ void bfly<3>(cplx (&a)[3]) {
-  const double s = 0.86602540378443864676;  // sin(pi/3)
-  const cplx t = cadd(a[1], a[2]);
-  const cplx m = make_double2(a[0].x - 0.5 * t.x, a[0].y - 0.5 * t.y);
-  const cplx n = make_double2(s * (a[1].x - a[2].x), s * (a[1].y - a[2].y));
+__device__ __forceinline__ void bfly<3>(kcplx (&a)[3]) {
+  const kreal s = 0.86602540378443864676;  // sin(pi/3)
+  const kcplx t = cadd(a[1], a[2]);
+  const kreal hf = 0.5;
+  const kcplx m = mkc(a[0].x - hf * t.x, a[0].y - hf * t.y);
+  const kcplx n = mkc(s * (a[1].x - a[2].x), s * (a[1].y - a[2].y));
   a[0] = cadd(a[0], t);
-  a[1] = make_double2(m.x + n.y, m.y - n.x);  // m - i n
-  a[2] = make_double2(m.x - n.y, m.y + n.x);  // m + i n
+  a[1] = mkc(m.x + n.y, m.y - n.x);  // m - i n
+  a[2] = mkc(m.x - n.y, m.y + n.x);  // m + i n
 }
 
 // radix 12 = 4 x 3 (Cooley-Tukey): n = 3 n1 + n2, k = k1 + 4 k2
 template <>
-__device__ __forceinline__ void bfly<12>(cplx (&a)[12]) {
-  const double h = 0.5, s = 0.86602540378443864676;
+__device__ __forceinline__ void bfly<12>(kcplx (&a)[12]) {
+  const kreal h = 0.5, s = 0.86602540378443864676;
   // radix 4 over n1 for each n2: (a[n2], a[n2+3], a[n2+6], a[n2+9]) -> A[n2][k1] left in the same slots (k1 = slot/3)
 #pragma unroll
   for (int n2 = 0; n2 < 3; ++n2) bfly4(a[n2], a[n2 + 3], a[n2 + 6], a[n2 + 9]);
   // twiddles W12^(n2*k1): slot n2 + 3*k1
-  a[4] = cmul(a[4], make_double2(s, -h));     // 1*1 -> W12^1
-  a[7] = cmul(a[7], make_double2(h, -s));     // 1*2 -> W12^2
+  a[4] = cmul(a[4], mkc(s, -h));     // 1*1 -> W12^1
+  a[7] = cmul(a[7], mkc(h, -s));     // 1*2 -> W12^2
   a[10] = mul_mi(a[10]);                      // 1*3 -> W12^3 = -i
-  a[5] = cmul(a[5], make_double2(h, -s));     // 2*1 -> W12^2
-  a[8] = cmul(a[8], make_double2(-h, -s));    // 2*2 -> W12^4
-  a[11] = make_double2(-a[11].x, -a[11].y);   // 2*3 -> W12^6 = -1
+  a[5] = cmul(a[5], mkc(h, -s));     // 2*1 -> W12^2
+  a[8] = cmul(a[8], mkc(-h, -s));    // 2*2 -> W12^4
+  a[11] = mkc(-a[11].x, -a[11].y);   // 2*3 -> W12^6 = -1
   // radix 3 over n2 for each k1: X[k1 + 4 k2]
-  cplx r[12];
+  kcplx r[12];
 #pragma unroll
   for (int k1 = 0; k1 < 4; ++k1) {
-    cplx b[3] = {a[3 * k1], a[3 * k1 + 1], a[3 * k1 + 2]};
+    kcplx b[3] = {a[3 * k1], a[3 * k1 + 1], a[3 * k1 + 2]};
     bfly<3>(b);
 #pragma unroll
     for (int k2 = 0; k2 < 3; ++k2) r[k1 + 4 * k2] = b[k2];
@@ -213,49 +243,49 @@ __device__ __forceinline__ void bfly<12>(cplx (&a)[12]) {
 }
 
 template <>
-__device__ __forceinline__ void bfly<2>(cplx (&a)[2]) {
-  const cplx t = a[0];
+__device__ __forceinline__ void bfly<2>(kcplx (&a)[2]) {
+  const kcplx t = a[0];
   a[0] = cadd(t, a[1]);
   a[1] = csub(t, a[1]);
 }
 
 // radix 5: X1,4 = m1 -+ i n1, X2,3 = m2 -+ i n2 (forward sign)
-__device__ __forceinline__ void bfly5(cplx &a0, cplx &a1, cplx &a2, cplx &a3, cplx &a4) {
-  const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;  // cos(2 pi/5), cos(4 pi/5)
-  const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;   // sin(2 pi/5), sin(4 pi/5)
-  const cplx t1 = cadd(a1, a4), t2 = cadd(a2, a3), t3 = csub(a1, a4), t4 = csub(a2, a3);
-  const cplx m1 = make_double2(a0.x + c1 * t1.x + c2 * t2.x, a0.y + c1 * t1.y + c2 * t2.y);
-  const cplx m2 = make_double2(a0.x + c2 * t1.x + c1 * t2.x, a0.y + c2 * t1.y + c1 * t2.y);
-  const cplx n1 = make_double2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
-  const cplx n2 = make_double2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
-  a0 = make_double2(a0.x + t1.x + t2.x, a0.y + t1.y + t2.y);
-  a1 = make_double2(m1.x + n1.y, m1.y - n1.x);  // m1 - i n1
-  a4 = make_double2(m1.x - n1.y, m1.y + n1.x);  // m1 + i n1
-  a2 = make_double2(m2.x + n2.y, m2.y - n2.x);
-  a3 = make_double2(m2.x - n2.y, m2.y + n2.x);
+__device__ __forceinline__ void bfly5(kcplx &a0, kcplx &a1, kcplx &a2, kcplx &a3, kcplx &a4) {
+  const kreal c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;  // cos(2 pi/5), cos(4 pi/5)
+  const kreal s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;   // sin(2 pi/5), sin(4 pi/5)
+  const kcplx t1 = cadd(a1, a4), t2 = cadd(a2, a3), t3 = csub(a1, a4), t4 = csub(a2, a3);
+  const kcplx m1 = mkc(a0.x + c1 * t1.x + c2 * t2.x, a0.y + c1 * t1.y + c2 * t2.y);
+  const kcplx m2 = mkc(a0.x + c2 * t1.x + c1 * t2.x, a0.y + c2 * t1.y + c1 * t2.y);
+  const kcplx n1 = mkc(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+  const kcplx n2 = mkc(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+  a0 = mkc(a0.x + t1.x + t2.x, a0.y + t1.y + t2.y);
+  a1 = mkc(m1.x + n1.y, m1.y - n1.x);  // m1 - i n1
+  a4 = mkc(m1.x - n1.y, m1.y + n1.x);  // m1 + i n1
+  a2 = mkc(m2.x + n2.y, m2.y - n2.x);
+  a3 = mkc(m2.x - n2.y, m2.y + n2.x);
 }
 
 template <>
-__device__ __forceinline__ void bfly<5>(cplx (&a)[5]) {
+__device__ __forceinline__ void bfly<5>(kcplx (&a)[5]) {
   bfly5(a[0], a[1], a[2], a[3], a[4]);
 }
 
 // radix 10 = 2 x 5 (Cooley-Tukey): n = 5 n1 + n2, k = k1 + 2 k2
 template <>
-__device__ __forceinline__ void bfly<10>(cplx (&a)[10]) {
+__device__ __forceinline__ void bfly<10>(kcplx (&a)[10]) {
   // W10^j = exp(-2 pi i j / 10), j = 1..4
-  const double c1 = 0.80901699437494742410, s1 = 0.58778525229247312917;  // cos, sin(pi/5)
-  const double c2 = 0.30901699437494742410, s2 = 0.95105651629515357212;  // cos, sin(2 pi/5)
-  cplx e[5], o[5];
+  const kreal c1 = 0.80901699437494742410, s1 = 0.58778525229247312917;  // cos, sin(pi/5)
+  const kreal c2 = 0.30901699437494742410, s2 = 0.95105651629515357212;  // cos, sin(2 pi/5)
+  kcplx e[5], o[5];
 #pragma unroll
   for (int n2 = 0; n2 < 5; ++n2) {
     e[n2] = cadd(a[n2], a[n2 + 5]);  // k1 = 0
     o[n2] = csub(a[n2], a[n2 + 5]);  // k1 = 1
   }
-  o[1] = cmul(o[1], make_double2(c1, -s1));
-  o[2] = cmul(o[2], make_double2(c2, -s2));
-  o[3] = cmul(o[3], make_double2(-c2, -s2));
-  o[4] = cmul(o[4], make_double2(-c1, -s1));
+  o[1] = cmul(o[1], mkc(c1, -s1));
+  o[2] = cmul(o[2], mkc(c2, -s2));
+  o[3] = cmul(o[3], mkc(-c2, -s2));
+  o[4] = cmul(o[4], mkc(-c1, -s1));
   bfly5(e[0], e[1], e[2], e[3], e[4]);  // X[2 k2]
   bfly5(o[0], o[1], o[2], o[3], o[4]);  // X[1 + 2 k2]
 #pragma unroll
@@ -267,25 +297,25 @@ __device__ __forceinline__ void bfly<10>(cplx (&a)[10]) {
 
 // radix 20 = 4 x 5 (Cooley-Tukey): n = 5 n1 + n2, k = k1 + 4 k2 -- first stage of the lengths 2^a 5 with a >= 5 (160, 320, 640, 1280)
 template <>
-__device__ __forceinline__ void bfly<20>(cplx (&a)[20]) {
+__device__ __forceinline__ void bfly<20>(kcplx (&a)[20]) {
   // radix 4 over n1 for each n2: (a[n2], a[n2+5], a[n2+10], a[n2+15]) -> A[n2][k1] left in slot 5 k1 + n2
 #pragma unroll
   for (int n2 = 0; n2 < 5; ++n2) bfly4(a[n2], a[n2 + 5], a[n2 + 10], a[n2 + 15]);
   // twiddles W20^(n2 k1)
-  a[6] = cmul(a[6], make_double2(0.951056516295153531182, -0.309016994374947395752));  // W20^1
-  a[7] = cmul(a[7], make_double2(0.809016994374947451263, -0.587785252292473137103));  // W20^2
-  a[8] = cmul(a[8], make_double2(0.587785252292473137103, -0.809016994374947451263));  // W20^3
-  a[9] = cmul(a[9], make_double2(0.309016994374947451263, -0.951056516295153531182));  // W20^4
-  a[11] = cmul(a[11], make_double2(0.809016994374947451263, -0.587785252292473137103));  // W20^2
-  a[12] = cmul(a[12], make_double2(0.309016994374947451263, -0.951056516295153531182));  // W20^4
-  a[13] = cmul(a[13], make_double2(-0.309016994374947340241, -0.951056516295153642204));  // W20^6
-  a[14] = cmul(a[14], make_double2(-0.809016994374947340241, -0.587785252292473248126));  // W20^8
-  a[16] = cmul(a[16], make_double2(0.587785252292473137103, -0.809016994374947451263));  // W20^3
-  a[17] = cmul(a[17], make_double2(-0.309016994374947340241, -0.951056516295153642204));  // W20^6
-  a[18] = cmul(a[18], make_double2(-0.951056516295153531182, -0.309016994374947506774));  // W20^9
-  a[19] = cmul(a[19], make_double2(-0.809016994374947562285, 0.587785252292473026081));  // W20^12
+  a[6] = cmul(a[6], mkc(0.951056516295153531182, -0.309016994374947395752));  // W20^1
+  a[7] = cmul(a[7], mkc(0.809016994374947451263, -0.587785252292473137103));  // W20^2
+  a[8] = cmul(a[8], mkc(0.587785252292473137103, -0.809016994374947451263));  // W20^3
+  a[9] = cmul(a[9], mkc(0.309016994374947451263, -0.951056516295153531182));  // W20^4
+  a[11] = cmul(a[11], mkc(0.809016994374947451263, -0.587785252292473137103));  // W20^2
+  a[12] = cmul(a[12], mkc(0.309016994374947451263, -0.951056516295153531182));  // W20^4
+  a[13] = cmul(a[13], mkc(-0.309016994374947340241, -0.951056516295153642204));  // W20^6
+  a[14] = cmul(a[14], mkc(-0.809016994374947340241, -0.587785252292473248126));  // W20^8
+  a[16] = cmul(a[16], mkc(0.587785252292473137103, -0.809016994374947451263));  // W20^3
+  a[17] = cmul(a[17], mkc(-0.309016994374947340241, -0.951056516295153642204));  // W20^6
+  a[18] = cmul(a[18], mkc(-0.951056516295153531182, -0.309016994374947506774));  // W20^9
+  a[19] = cmul(a[19], mkc(-0.809016994374947562285, 0.587785252292473026081));  // W20^12
   // radix 5 over n2 for each k1: X[k1 + 4 k2]
-  cplx r[20];
+  kcplx r[20];
 #pragma unroll
   for (int k1 = 0; k1 < 4; ++k1) {
     bfly5(a[5 * k1], a[5 * k1 + 1], a[5 * k1 + 2], a[5 * k1 + 3], a[5 * k1 + 4]);
@@ -298,40 +328,40 @@ __device__ __forceinline__ void bfly<20>(cplx (&a)[20]) {
 
 // radix 30 = 3 x 10 (Cooley-Tukey): n = 10 n1 + n2, k = k1 + 3 k2
 template <>
-__device__ __forceinline__ void bfly<30>(cplx (&a)[30]) {
+__device__ __forceinline__ void bfly<30>(kcplx (&a)[30]) {
   // radix 3 over n1 for each n2: (a[n2], a[n2+10], a[n2+20]) -> A[n2][k1] left in the same slots (k1 = slot / 10)
 #pragma unroll
   for (int n2 = 0; n2 < 10; ++n2) {
-    cplx b[3] = {a[n2], a[n2 + 10], a[n2 + 20]};
+    kcplx b[3] = {a[n2], a[n2 + 10], a[n2 + 20]};
     bfly<3>(b);
     a[n2] = b[0];
     a[n2 + 10] = b[1];
     a[n2 + 20] = b[2];
   }
   // twiddles W30^(n2 * k1), k1 = 1, 2
-  a[11] = cmul(a[11], make_double2(0.978147600733805637929, -0.207911690817759337102));  // W30^1
-  a[12] = cmul(a[12], make_double2(0.913545457642600895502, -0.406736643075800207754));  // W30^2
-  a[13] = cmul(a[13], make_double2(0.809016994374947424102, -0.587785252292473129169));  // W30^3
-  a[14] = cmul(a[14], make_double2(0.669130606358858213826, -0.743144825477394235015));  // W30^4
-  a[15] = cmul(a[15], make_double2(0.5, -0.866025403784438646764));  // W30^5
-  a[16] = cmul(a[16], make_double2(0.309016994374947424102, -0.951056516295153572116));  // W30^6
-  a[17] = cmul(a[17], make_double2(0.1045284632676534714, -0.994521895368273336923));  // W30^7
-  a[18] = cmul(a[18], make_double2(-0.1045284632676534714, -0.994521895368273336923));  // W30^8
-  a[19] = cmul(a[19], make_double2(-0.309016994374947424102, -0.951056516295153572116));  // W30^9
-  a[21] = cmul(a[21], make_double2(0.913545457642600895502, -0.406736643075800207754));  // W30^2
-  a[22] = cmul(a[22], make_double2(0.669130606358858213826, -0.743144825477394235015));  // W30^4
-  a[23] = cmul(a[23], make_double2(0.309016994374947424102, -0.951056516295153572116));  // W30^6
-  a[24] = cmul(a[24], make_double2(-0.1045284632676534714, -0.994521895368273336923));  // W30^8
-  a[25] = cmul(a[25], make_double2(-0.5, -0.866025403784438646764));  // W30^10
-  a[26] = cmul(a[26], make_double2(-0.809016994374947424102, -0.587785252292473129169));  // W30^12
-  a[27] = cmul(a[27], make_double2(-0.978147600733805637929, -0.207911690817759337102));  // W30^14
-  a[28] = cmul(a[28], make_double2(-0.978147600733805637929, 0.207911690817759337102));  // W30^16
-  a[29] = cmul(a[29], make_double2(-0.809016994374947424102, 0.587785252292473129169));  // W30^18
+  a[11] = cmul(a[11], mkc(0.978147600733805637929, -0.207911690817759337102));  // W30^1
+  a[12] = cmul(a[12], mkc(0.913545457642600895502, -0.406736643075800207754));  // W30^2
+  a[13] = cmul(a[13], mkc(0.809016994374947424102, -0.587785252292473129169));  // W30^3
+  a[14] = cmul(a[14], mkc(0.669130606358858213826, -0.743144825477394235015));  // W30^4
+  a[15] = cmul(a[15], mkc(0.5, -0.866025403784438646764));  // W30^5
+  a[16] = cmul(a[16], mkc(0.309016994374947424102, -0.951056516295153572116));  // W30^6
+  a[17] = cmul(a[17], mkc(0.1045284632676534714, -0.994521895368273336923));  // W30^7
+  a[18] = cmul(a[18], mkc(-0.1045284632676534714, -0.994521895368273336923));  // W30^8
+  a[19] = cmul(a[19], mkc(-0.309016994374947424102, -0.951056516295153572116));  // W30^9
+  a[21] = cmul(a[21], mkc(0.913545457642600895502, -0.406736643075800207754));  // W30^2
+  a[22] = cmul(a[22], mkc(0.669130606358858213826, -0.743144825477394235015));  // W30^4
+  a[23] = cmul(a[23], mkc(0.309016994374947424102, -0.951056516295153572116));  // W30^6
+  a[24] = cmul(a[24], mkc(-0.1045284632676534714, -0.994521895368273336923));  // W30^8
+  a[25] = cmul(a[25], mkc(-0.5, -0.866025403784438646764));  // W30^10
+  a[26] = cmul(a[26], mkc(-0.809016994374947424102, -0.587785252292473129169));  // W30^12
+  a[27] = cmul(a[27], mkc(-0.978147600733805637929, -0.207911690817759337102));  // W30^14
+  a[28] = cmul(a[28], mkc(-0.978147600733805637929, 0.207911690817759337102));  // W30^16
+  a[29] = cmul(a[29], mkc(-0.809016994374947424102, 0.587785252292473129169));  // W30^18
   // radix 10 over n2 for each k1: X[k1 + 3 k2]
-  cplx r[30];
+  kcplx r[30];
 #pragma unroll
   for (int k1 = 0; k1 < 3; ++k1) {
-    cplx b[10];
+    kcplx b[10];
 #pragma unroll
     for (int n2 = 0; n2 < 10; ++n2) b[n2] = a[10 * k1 + n2];
     bfly<10>(b);
@@ -359,12 +389,12 @@ struct MapLine {  // position fastest (lanes vary q): one pad element per 16 pos
 
 // radix-R stage on the P register values (v[i + S*t] = element t of butterfly i, S = P/R butterflies per thread)
 template <int N, int R, int NS>
-__device__ __forceinline__ void stage(cplx (&v)[Plan<N>::P], int q, const cplx *W) {
+__device__ __forceinline__ void stage(kcplx (&v)[Plan<N>::P], int q, const kcplx *W) {
   constexpr int P = Plan<N>::P, S = P / R, TPL = N / P;
   static_assert(P % R == 0, "radix must divide the points per thread");
 #pragma unroll
   for (int i = 0; i < S; ++i) {
-    cplx a[R];
+    kcplx a[R];
 #pragma unroll
     for (int t = 0; t < R; ++t) a[t] = v[i + S * t];
     if (NS > 1) {
@@ -382,7 +412,7 @@ __device__ __forceinline__ void stage(cplx (&v)[Plan<N>::P], int q, const cplx *
 
 // write the outputs of a radix-R stage (Ns = NS) in Stockham order, then re-own q + m*TPL
 template <int N, int R, int NS, class Map>
-__device__ __forceinline__ void exchange(cplx (&v)[Plan<N>::P], int q, int l, cplx *X) {
+__device__ __forceinline__ void exchange(kcplx (&v)[Plan<N>::P], int q, int l, kcplx *X) {
   constexpr int P = Plan<N>::P, S = P / R, TPL = N / P;
   __syncthreads();  // previous readers of X are done
 #pragma unroll
@@ -399,7 +429,7 @@ __device__ __forceinline__ void exchange(cplx (&v)[Plan<N>::P], int q, int l, cp
 
 // full forward transform of the line owned by (q, l); v in: x[q + m*TPL], out: X[q + m*TPL]
 template <int N, class Map>
-__device__ __forceinline__ void fft_line(cplx (&v)[Plan<N>::P], int q, int l, cplx *X, const cplx *W) {
+__device__ __forceinline__ void fft_line(kcplx (&v)[Plan<N>::P], int q, int l, kcplx *X, const kcplx *W) {
   using Pl = Plan<N>;
   stage<N, Pl::r0, 1>(v, q, W);
   exchange<N, Pl::r0, 1, Map>(v, q, l, X);
@@ -436,18 +466,18 @@ __device__ __forceinline__ unsigned xcd_remap_rev(unsigned b, unsigned nb) {
 template <int N, int NTH = Plan<N>::NT>
 struct TwRegs {
   static constexpr int NT = NTH, CNT = (N + NT - 1) / NT;
-  cplx v[CNT];
+  kcplx v[CNT];
 };
 template <int N, int NTH>
-__device__ __forceinline__ void tw_issue(TwRegs<N, NTH> &r, const cplx *__restrict__ tw) {
+__device__ __forceinline__ void tw_issue(TwRegs<N, NTH> &r, const kcplx *__restrict__ tw) {
 #pragma unroll
   for (int j = 0; j < TwRegs<N, NTH>::CNT; ++j) {
     const int idx = threadIdx.x + j * NTH;
-    r.v[j] = idx < N ? tw[idx] : make_double2(0.0, 0.0);
+    r.v[j] = idx < N ? tw[idx] : mkc(0.0, 0.0);
   }
 }
 template <int N, int NTH>
-__device__ __forceinline__ void tw_commit(const TwRegs<N, NTH> &r, cplx *W) {
+__device__ __forceinline__ void tw_commit(const TwRegs<N, NTH> &r, kcplx *W) {
 #pragma unroll
   for (int j = 0; j < TwRegs<N, NTH>::CNT; ++j) {
     const int idx = threadIdx.x + j * NTH;
@@ -455,5 +485,5 @@ __device__ __forceinline__ void tw_commit(const TwRegs<N, NTH> &r, cplx *W) {
   }
 }
 
-}  // namespace p2
+}  // namespace MRL_P2NS
 }  // namespace mrl

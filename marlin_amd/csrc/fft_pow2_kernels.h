@@ -9,12 +9,12 @@
 #include "fft_pow2.h"
 
 namespace mrl {
-namespace p2 {
+namespace MRL_P2NS {
 
 struct ChDev {
   int family;
-  double c0, c1, c2;
-  double k[8];  // named constants of a parsed free energy (MRL_FE_PARSED)
+  kreal c0, c1, c2;
+  kreal k[8];  // named constants of a parsed free energy (MRL_FE_PARSED)
 };
 
 // Solver-private spectral layout of the fused serial path: rows of NZC complex values, `lpp` rows per x plane, and every plane `pad`
@@ -31,20 +31,22 @@ __device__ __forceinline__ long long zrow(long long row, int nzc, ZLay z) {
 
 // MRL_FE_PARSED: the chemical potential generated from the user's expression (expr.hip); it only exists in the
 // run-time compiled (hiprtc) instance of k_z_fwd, where its definition is appended to these headers
-__device__ double mrl_user_mu(double c, const double *k);
+__device__ kreal mrl_user_mu(kreal c, const kreal *k);
 
 // FAM is a compile-time constant: a run-time family test inside the unrolled load loop makes hipcc
 // branch around every element and wait vmcnt(0) per load (16 dependent HBM round trips).
 template <int FAM>
-__device__ __forceinline__ double mu_eval(const ChDev &p, double c) {
+__device__ __forceinline__ kreal mu_eval(const ChDev &p, kreal c) {
 #pragma clang fp contract(off)
   if constexpr (FAM == MRL_FE_DOUBLE_WELL) {
-    const double cm1 = c - 1.0;
-    return (p.c0 * (2.0 * c)) * (cm1 * cm1) + (p.c0 * (c * c)) * (2.0 * cm1);
+    const kreal one = 1.0, two = 2.0;
+    const kreal cm1 = c - one;
+    return (p.c0 * (two * c)) * (cm1 * cm1) + (p.c0 * (c * c)) * (two * cm1);
   } else if constexpr (FAM == MRL_FE_PFHUB) {
-    const double a = c - p.c1;
-    const double b = p.c2 - c;
-    return (p.c0 * (2.0 * a)) * (b * b) + (p.c0 * (a * a)) * ((2.0 * b) * -1.0);
+    const kreal a = c - p.c1;
+    const kreal b = p.c2 - c;
+    const kreal two = 2.0, mone = -1.0;
+    return (p.c0 * (two * a)) * (b * b) + (p.c0 * (a * a)) * ((two * b) * mone);
   } else {
     return mrl_user_mu(c, p.k);
   }
@@ -59,26 +61,26 @@ __device__ __forceinline__ double mu_eval(const ChDev &p, double c) {
 //                            (the spectral carry-over pipeline, where c-hat is not recomputed); optional mu_out.
 // nlines = number of complex transforms.
 template <int N, int MODE, int FAM>
-__global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_fwd(const double *__restrict__ in, cplx *__restrict__ out0,
-                                               cplx *__restrict__ out1, double *__restrict__ mu_out, ChDev chp,
-                                               long long nlines, const cplx *__restrict__ tw, ZLay zl) {
+__global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_fwd(const kreal *__restrict__ in, kcplx *__restrict__ out0,
+                                               kcplx *__restrict__ out1, kreal *__restrict__ mu_out, ChDev chp,
+                                               long long nlines, const kcplx *__restrict__ tw, ZLay zl) {
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = ZPlan<N>::T, NZC = N / 2 + 1;
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cplx *W = reinterpret_cast<cplx *>(smem);
-  cplx *X = W + N;
+  kcplx *W = reinterpret_cast<kcplx *>(smem);
+  kcplx *X = W + N;
   const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
   const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
   const bool valid = L < nlines;
   TwRegs<N, ZPlan<N>::NT> twr;
   tw_issue<N>(twr, tw);
 
-  cplx v[P];
+  kcplx v[P];
   const long long Lc = valid ? L : 0;  // out-of-range lanes transform line 0 again and store nothing
   const long long r0 = (MODE == 1) ? Lc : 2 * Lc;
   {
-    const double *p0 = in + r0 * N + q;
-    double a[P], b[P];
+    const kreal *p0 = in + r0 * N + q;
+    kreal a[P], b[P];
 #pragma unroll
     for (int m = 0; m < P; ++m) a[m] = p0[m * TPL];
     if (MODE != 1) {
@@ -98,14 +100,14 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_fwd(const double *__restr
       }
     }
 #pragma unroll
-    for (int m = 0; m < P; ++m) v[m] = make_double2(a[m], b[m]);
+    for (int m = 0; m < P; ++m) v[m] = mkc(a[m], b[m]);
     if (MODE == 1 && mu_out && valid) {
-      double *pm = mu_out + r0 * N + q;
+      kreal *pm = mu_out + r0 * N + q;
 #pragma unroll
       for (int m = 0; m < P; ++m) pm[m * TPL] = v[m].y;
     }
     if (MODE == 2 && mu_out && valid) {
-      double *pm = mu_out + r0 * N + q;
+      kreal *pm = mu_out + r0 * N + q;
 #pragma unroll
       for (int m = 0; m < P; ++m) {
         pm[m * TPL] = v[m].x;
@@ -120,16 +122,16 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_fwd(const double *__restr
   for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
   __syncthreads();
   if (!valid) return;
-  cplx *o0 = (MODE != 1) ? out0 + zrow(2 * L, NZC, zl) : out0 + zrow(L, NZC, zl);
-  cplx *o1 = (MODE != 1) ? out0 + zrow(2 * L + 1, NZC, zl) : out1 + zrow(L, NZC, zl);
+  kcplx *o0 = (MODE != 1) ? out0 + zrow(2 * L, NZC, zl) : out0 + zrow(L, NZC, zl);
+  kcplx *o1 = (MODE != 1) ? out0 + zrow(2 * L + 1, NZC, zl) : out1 + zrow(L, NZC, zl);
 #pragma unroll
   for (int m = 0; m <= P / 2; ++m) {
     const int k = q + m * TPL;
     if (k > N / 2) break;  // (only q = 0 owns the Nyquist bin)
-    const cplx xk = v[m];
-    const cplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
-    o0[k] = make_double2(0.5 * (xk.x + xn.x), 0.5 * (xk.y - xn.y));
-    o1[k] = make_double2(0.5 * (xk.y + xn.y), -0.5 * (xk.x - xn.x));
+    const kcplx xk = v[m];
+    const kcplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
+    o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
+    o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
   }
 }
 
@@ -138,25 +140,25 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_fwd(const double *__restr
 // DOT: additionally accumulates sum(out * dotv) over the rows written (one partial per workgroup, deterministic): the
 // p.Ap of the conjugate-gradient iteration, taken while Ap is still in registers instead of re-reading it from HBM.
 template <int N, bool DOT = false>
-__global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const cplx *__restrict__ in, double *__restrict__ out, double scale,
-                                               long long nlines, const cplx *__restrict__ tw,
-                                               const double *__restrict__ dotv = nullptr, double *__restrict__ partial = nullptr,
+__global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const kcplx *__restrict__ in, kreal *__restrict__ out, kreal scale,
+                                               long long nlines, const kcplx *__restrict__ tw,
+                                               const kreal *__restrict__ dotv = nullptr, kreal *__restrict__ partial = nullptr,
                                                ZLay zl = ZLay{0u, 0u}) {
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = ZPlan<N>::T, NZC = N / 2 + 1;
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cplx *W = reinterpret_cast<cplx *>(smem);
-  cplx *X = W + N;
+  kcplx *W = reinterpret_cast<kcplx *>(smem);
+  kcplx *X = W + N;
   const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
   const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
   const bool valid = L < nlines;
   TwRegs<N, ZPlan<N>::NT> twr;
   tw_issue<N>(twr, tw);
-  cplx v[P];
+  kcplx v[P];
   {
-    const cplx *A = in + zrow(2 * (valid ? L : 0), NZC, zl);
-    const cplx *B = in + zrow(2 * (valid ? L : 0) + 1, NZC, zl);
-    cplx av[P], bv[P];
+    const kcplx *A = in + zrow(2 * (valid ? L : 0), NZC, zl);
+    const kcplx *B = in + zrow(2 * (valid ? L : 0) + 1, NZC, zl);
+    kcplx av[P], bv[P];
 #pragma unroll
     for (int m = 0; m < P; ++m) {
       const int p = q + m * TPL;
@@ -170,23 +172,23 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const cplx *__restric
       const int p = q + m * TPL;
       const bool lo = p <= N / 2;
       const int k = lo ? p : N - p;
-      cplx a = av[m], b = bv[m];
+      kcplx a = av[m], b = bv[m];
       if (k == 0 || k == N / 2) {  // c2r ignores the imaginary part of the self-conjugate bins
         a.y = 0.0;
         b.y = 0.0;
       }
       // X[p] = A + iB (p <= N/2), conj(A[k]) + i conj(B[k]) otherwise ; then swap for the inverse
-      const cplx x = lo ? make_double2(a.x - b.y, a.y + b.x) : make_double2(a.x + b.y, b.x - a.y);
+      const kcplx x = lo ? mkc(a.x - b.y, a.y + b.x) : mkc(a.x + b.y, b.x - a.y);
       v[m] = cswap(x);
     }
   }
   fft_line<N, Map>(v, q, l, X, W);
-  double acc = 0.0;
+  kreal acc = 0.0;
   if (valid) {
-    double *o0 = out + (2 * L) * N + q;
-    double pa[DOT ? P : 1], pb[DOT ? P : 1];
+    kreal *o0 = out + (2 * L) * N + q;
+    kreal pa[DOT ? P : 1], pb[DOT ? P : 1];
     if (DOT) {
-      const double *d0 = dotv + (2 * L) * N + q;
+      const kreal *d0 = dotv + (2 * L) * N + q;
 #pragma unroll
       for (int m = 0; m < P; ++m) {
         pa[DOT ? m : 0] = d0[m * TPL];
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const cplx *__restric
 #pragma unroll
     for (int m = 0; m < P; ++m) {
       // swap back: real part (row 2L) = v.y, imaginary part (row 2L+1) = v.x
-      const double ra = v[m].y * scale, rb = v[m].x * scale;
+      const kreal ra = v[m].y * scale, rb = v[m].x * scale;
       o0[m * TPL] = ra;
       o0[N + m * TPL] = rb;
       if (DOT) acc += ra * pa[DOT ? m : 0] + rb * pb[DOT ? m : 0];
@@ -205,12 +207,12 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const cplx *__restric
   if (DOT) {
     // workgroup sum through LDS (the exchange tile is free again); NT need not be a multiple of 64
     constexpr int NT = ZPlan<N>::NT;
-    double *S = reinterpret_cast<double *>(X);
+    kreal *S = reinterpret_cast<kreal *>(X);
     __syncthreads();
     S[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x < 64) {
-      double s = 0.0;
+      kreal s = 0.0;
       for (int i = threadIdx.x; i < NT; i += 64) s += S[i];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -230,24 +232,24 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const cplx *__restric
 // MU_ONLY (the spectral carry-over of the slab pipeline, where c-hat is not recomputed): the two lines of mu are packed into
 // ONE forward transform -> rows 2L, 2L+1 of out0 = mu-hat_z; out1 unused.
 template <int N, int FAM, bool MU_ONLY = false>
-__global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const cplx *__restrict__ in, cplx *__restrict__ out0,
-                                                                cplx *__restrict__ out1, double *__restrict__ mu_out, ChDev chp,
-                                                                double scale, long long nlines, const cplx *__restrict__ tw, ZLay zl) {
+__global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const kcplx *__restrict__ in, kcplx *__restrict__ out0,
+                                                                kcplx *__restrict__ out1, kreal *__restrict__ mu_out, ChDev chp,
+                                                                kreal scale, long long nlines, const kcplx *__restrict__ tw, ZLay zl) {
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = ZPlan<N>::T, NZC = N / 2 + 1;
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cplx *W = reinterpret_cast<cplx *>(smem);
-  cplx *X = W + N;
+  kcplx *W = reinterpret_cast<kcplx *>(smem);
+  kcplx *X = W + N;
   const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
   const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
   const bool valid = L < nlines;
   TwRegs<N, ZPlan<N>::NT> twr;
   tw_issue<N>(twr, tw);
-  cplx v[P];
+  kcplx v[P];
   {
-    const cplx *A = in + zrow(2 * (valid ? L : 0), NZC, zl);
-    const cplx *B = in + zrow(2 * (valid ? L : 0) + 1, NZC, zl);
-    cplx av[P], bv[P];
+    const kcplx *A = in + zrow(2 * (valid ? L : 0), NZC, zl);
+    const kcplx *B = in + zrow(2 * (valid ? L : 0) + 1, NZC, zl);
+    kcplx av[P], bv[P];
 #pragma unroll
     for (int m = 0; m < P; ++m) {
       const int p = q + m * TPL;
@@ -261,21 +263,21 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const cplx *__res
       const int p = q + m * TPL;
       const bool lo = p <= N / 2;
       const int k = lo ? p : N - p;
-      cplx a = av[m], b = bv[m];
+      kcplx a = av[m], b = bv[m];
       if (k == 0 || k == N / 2) {
         a.y = 0.0;
         b.y = 0.0;
       }
-      const cplx x = lo ? make_double2(a.x - b.y, a.y + b.x) : make_double2(a.x + b.y, b.x - a.y);
+      const kcplx x = lo ? mkc(a.x - b.y, a.y + b.x) : mkc(a.x + b.y, b.x - a.y);
       v[m] = cswap(x);
     }
   }
   fft_line<N, Map>(v, q, l, X, W);
   if constexpr (MU_ONLY) {
 #pragma unroll
-    for (int m = 0; m < P; ++m) v[m] = make_double2(mu_eval<FAM>(chp, v[m].y * scale), mu_eval<FAM>(chp, v[m].x * scale));
+    for (int m = 0; m < P; ++m) v[m] = mkc(mu_eval<FAM>(chp, v[m].y * scale), mu_eval<FAM>(chp, v[m].x * scale));
     if (mu_out && valid) {
-      double *pm = mu_out + (2 * L) * N + q;
+      kreal *pm = mu_out + (2 * L) * N + q;
 #pragma unroll
       for (int m = 0; m < P; ++m) {
         pm[m * TPL] = v[m].x;
@@ -288,36 +290,36 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const cplx *__res
     for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
     __syncthreads();
     if (valid) {
-      cplx *o0 = out0 + zrow(2 * L, NZC, zl), *o1 = out0 + zrow(2 * L + 1, NZC, zl);
+      kcplx *o0 = out0 + zrow(2 * L, NZC, zl), *o1 = out0 + zrow(2 * L + 1, NZC, zl);
 #pragma unroll
       for (int m = 0; m <= P / 2; ++m) {
         const int k = q + m * TPL;
         if (k > N / 2) break;
-        const cplx xk = v[m];
-        const cplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
-        o0[k] = make_double2(0.5 * (xk.x + xn.x), 0.5 * (xk.y - xn.y));
-        o1[k] = make_double2(0.5 * (xk.y + xn.y), -0.5 * (xk.x - xn.x));
+        const kcplx xk = v[m];
+        const kcplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
+        o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
+        o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
       }
     }
     return;
   }
-  double cb[P];  // second line (row 2L+1), kept while the first one is transformed
+  kreal cb[P];  // second line (row 2L+1), kept while the first one is transformed
   {
 #pragma unroll
     for (int m = 0; m < P; ++m) {
-      const double ca = v[m].y * scale;
+      const kreal ca = v[m].y * scale;
       cb[m] = v[m].x * scale;
-      v[m] = make_double2(ca, mu_eval<FAM>(chp, ca));
+      v[m] = mkc(ca, mu_eval<FAM>(chp, ca));
     }
   }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     if (half == 1) {
 #pragma unroll
-      for (int m = 0; m < P; ++m) v[m] = make_double2(cb[m], mu_eval<FAM>(chp, cb[m]));
+      for (int m = 0; m < P; ++m) v[m] = mkc(cb[m], mu_eval<FAM>(chp, cb[m]));
     }
     if (mu_out && valid) {
-      double *pm = mu_out + (2 * L + half) * N + q;
+      kreal *pm = mu_out + (2 * L + half) * N + q;
 #pragma unroll
       for (int m = 0; m < P; ++m) pm[m * TPL] = v[m].y;
     }
@@ -327,15 +329,15 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const cplx *__res
     for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
     __syncthreads();
     if (valid) {
-      cplx *o0 = out0 + zrow(2 * L + half, NZC, zl), *o1 = out1 + zrow(2 * L + half, NZC, zl);
+      kcplx *o0 = out0 + zrow(2 * L + half, NZC, zl), *o1 = out1 + zrow(2 * L + half, NZC, zl);
 #pragma unroll
       for (int m = 0; m <= P / 2; ++m) {
         const int k = q + m * TPL;
         if (k > N / 2) break;
-        const cplx xk = v[m];
-        const cplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
-        o0[k] = make_double2(0.5 * (xk.x + xn.x), 0.5 * (xk.y - xn.y));
-        o1[k] = make_double2(0.5 * (xk.y + xn.y), -0.5 * (xk.x - xn.x));
+        const kcplx xk = v[m];
+        const kcplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
+        o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
+        o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
       }
     }
   }
@@ -345,24 +347,24 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const cplx *__res
 // strided c2c pass.  Arrays are [outer][N][inner] complex (inner contiguous); a workgroup owns
 // T = 4096/N consecutive `inner` positions of one `outer` slice for all N points of the axis.
 struct PassArgs {
-  const cplx *in[2];
-  cplx *out[2];
+  const kcplx *in[2];
+  kcplx *out[2];
   long long inner;           // contiguous extent
   long long outer;           // number of outer slices
   long long so_in, so_out;   // outer strides (elements)
   long long sn_in, sn_out;   // stride between successive points of the axis
   int tiles_per_outer;
-  double scale;
+  kreal scale;
   int reverse;  // traverse tiles in descending order: start where the producer kernel ended (Infinity Cache reuse)
 };
 
 template <int N, bool INV, int NF>
-__global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass(PassArgs a, const cplx *__restrict__ tw) {
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass(PassArgs a, const kcplx *__restrict__ tw) {
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cplx *W = reinterpret_cast<cplx *>(smem);
-  cplx *X = W + N;
+  kcplx *W = reinterpret_cast<kcplx *>(smem);
+  kcplx *X = W + N;
   const int l = threadIdx.x % T, q = threadIdx.x / T;
   const unsigned logical = a.reverse ? xcd_remap_rev(blockIdx.x, gridDim.x) : xcd_remap(blockIdx.x, gridDim.x);
   const long long o = logical / a.tiles_per_outer;
@@ -373,10 +375,10 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass(PassArgs a, const cplx 
   // all fields' operands are requested up front: field 1 is in flight while field 0 is transformed
   // (unconditional loads from a clamped position: a branch here degrades hipcc's vmcnt counting to vmcnt(0))
   const long long ic = valid ? i : 0;
-  cplx v[NF][P];
+  kcplx v[NF][P];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
-    const cplx *p = a.in[f] + o * a.so_in + ic + (long long)q * a.sn_in;
+    const kcplx *p = a.in[f] + o * a.so_in + ic + (long long)q * a.sn_in;
 #pragma unroll
     for (int m = 0; m < P; ++m) v[f][m] = p[(long long)m * TPL * a.sn_in];
   }
@@ -389,7 +391,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass(PassArgs a, const cplx 
     }
     fft_line<N, Map>(v[f], q, l, X, W);
     if (valid) {
-      cplx *p = a.out[f] + o * a.so_out + i + (long long)q * a.sn_out;
+      kcplx *p = a.out[f] + o * a.so_out + i + (long long)q * a.sn_out;
 #pragma unroll
       for (int m = 0; m < P; ++m) p[(long long)m * TPL * a.sn_out] = INV ? cswap(v[f][m]) : v[f][m];
     }
@@ -406,9 +408,9 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass(PassArgs a, const cplx 
 // send buffer; field f of a chunk lies fs_out elements further.  After its last store every workgroup counts itself and the
 // last one raises the arrival flags (comm_dev.h) when `sig` asks for it.
 struct SubPassArgs {
-  const cplx *in[2];
-  cplx *out[2];              // INV only (dense output)
-  cplx *const *otab;         // !INV: destination of chunk c (device table, one entry per rank)
+  const kcplx *in[2];
+  kcplx *out[2];              // INV only (dense output)
+  kcplx *const *otab;         // !INV: destination of chunk c (device table, one entry per rank)
   int rows, cols;
   int tcols;                 // tiles run over rows x tcols (0 = cols).  !INV with tcols = pitch_out: a tile is T consecutive elements
                              // of the padded OUTPUT rows, i.e. every store of a wave is whole 128-byte lines (columns >= cols repeat
@@ -425,12 +427,12 @@ struct SubPassArgs {
 };
 
 template <int N, bool INV, int NF>
-__global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub(SubPassArgs a, const cplx *__restrict__ tw) {
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub(SubPassArgs a, const kcplx *__restrict__ tw) {
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cplx *W = reinterpret_cast<cplx *>(smem);
-  cplx *X = W + N;
+  kcplx *W = reinterpret_cast<kcplx *>(smem);
+  kcplx *X = W + N;
   const int l = threadIdx.x % T, q = threadIdx.x / T;
   const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned i = logical * T + l;
@@ -442,7 +444,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub(SubPassArgs a, cons
   const unsigned mo = (a.sh_out < 31) ? ((1u << a.sh_out) - 1u) : 0xffffffffu;
   TwRegs<N> twr;
   tw_issue<N>(twr, tw);
-  cplx v[NF][P];
+  kcplx v[NF][P];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
 #pragma unroll
@@ -466,8 +468,8 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub(SubPassArgs a, cons
         if (INV) {
           a.out[f][bo + (n & mo) * a.sn_out] = cswap(v[f][m]);
         } else {
-          cplx *base = a.otab[n >> a.sh_out];
-          cplx *dst = base + (a.fo_out + (unsigned)f * a.fs_out + bo + (n & mo) * a.sn_out);
+          kcplx *base = a.otab[n >> a.sh_out];
+          kcplx *dst = base + (a.fo_out + (unsigned)f * a.fs_out + bo + (n & mo) * a.sn_out);
           if (a.nt_out)
             st_nt(dst, v[f][m]);
           else
@@ -483,12 +485,12 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub(SubPassArgs a, cons
 // slow block index.  Field f is a.in[0] + f * fdense (dense side) and chunk offset f * fs_out (exchange-layout side); the chunk of
 // one peer holds all nf fields (cs_in = nf * fs_out on the inverse side).
 template <int N, bool INV>
-__global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_mf(SubPassArgs a, const cplx *__restrict__ tw) {
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_mf(SubPassArgs a, const kcplx *__restrict__ tw) {
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cplx *W = reinterpret_cast<cplx *>(smem);
-  cplx *X = W + N;
+  kcplx *W = reinterpret_cast<kcplx *>(smem);
+  kcplx *X = W + N;
   const int l = threadIdx.x % T, q = threadIdx.x / T;
   unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned f = logical / a.nb;
@@ -500,10 +502,10 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_mf(SubPassArgs a, c
   const unsigned bi = row * a.pitch_in + min(col, (unsigned)a.cols - 1u), bo = row * a.pitch_out + col;
   const unsigned mi = (a.sh_in < 31) ? ((1u << a.sh_in) - 1u) : 0xffffffffu;
   const unsigned mo = (a.sh_out < 31) ? ((1u << a.sh_out) - 1u) : 0xffffffffu;
-  const cplx *__restrict__ src = a.in[0] + (size_t)f * (INV ? a.fs_out : a.fdense);
+  const kcplx *__restrict__ src = a.in[0] + (size_t)f * (INV ? a.fs_out : a.fdense);
   TwRegs<N> twr;
   tw_issue<N>(twr, tw);
-  cplx v[P];
+  kcplx v[P];
 #pragma unroll
   for (int m = 0; m < P; ++m) {
     const unsigned n = q + m * TPL;
@@ -516,14 +518,14 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_mf(SubPassArgs a, c
   }
   fft_line<N, Map>(v, q, l, X, W);
   if (valid) {
-    cplx *dense = INV ? a.out[0] + (size_t)f * a.fdense : nullptr;
+    kcplx *dense = INV ? a.out[0] + (size_t)f * a.fdense : nullptr;
 #pragma unroll
     for (int m = 0; m < P; ++m) {
       const unsigned n = q + m * TPL;
       if (INV) {
         dense[bo + (n & mo) * a.sn_out] = cswap(v[m]);
       } else {
-        cplx *base = a.otab[n >> a.sh_out];
+        kcplx *base = a.otab[n >> a.sh_out];
         base[f * a.fs_out + bo + (n & mo) * a.sn_out] = v[m];
       }
     }
@@ -533,16 +535,16 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_mf(SubPassArgs a, c
 
 template <int N>
 constexpr size_t lds_line() {  // the z kernels: ZPlan<N>::T lines
-  return sizeof(cplx) * (N + MapLine<N>::zsize);
+  return sizeof(kcplx) * (N + MapLine<N>::zsize);
 }
 template <int N>
 constexpr size_t lds_line_full() {  // MapLine tiles of Plan<N>::T lines (k_gamma_z_fwd_tangent)
-  return sizeof(cplx) * (N + MapLine<N>::size);
+  return sizeof(kcplx) * (N + MapLine<N>::size);
 }
 template <int N>
 constexpr size_t lds_strided() {
-  return sizeof(cplx) * (N + MapStrided<N>::size);
+  return sizeof(kcplx) * (N + MapStrided<N>::size);
 }
 
-}  // namespace p2
+}  // namespace MRL_P2NS
 }  // namespace mrl

@@ -3,7 +3,17 @@
 #include "fft_pow2_kernels.h"
 
 namespace mrl {
-namespace p2 {
+namespace MRL_P2NS {
+
+// twiddle table exp(-2 pi i k / n) of an axis in the scalar type of this translation unit (the fp32 copy is built on first use)
+inline const kcplx *tw_table(mrl_ctx *ctx, int axis) {
+  if constexpr (sizeof(kreal) == 8) {
+    return reinterpret_cast<const kcplx *>(ctx->ax[axis].d_tw);
+  } else {
+    if (!ctx->ax[axis].d_tw32 && axis_tw32(ctx, axis) != MRL_OK) return nullptr;
+    return reinterpret_cast<const kcplx *>(ctx->ax[axis].d_tw32);
+  }
+}
 
 template <class K>
 inline int set_lds_attr(mrl_ctx *ctx, K kernel, size_t lds) {
@@ -16,7 +26,7 @@ inline int set_lds_attr(mrl_ctx *ctx, K kernel, size_t lds) {
 
 // nlines = number of complex transforms (MODE 0: pairs of real lines; MODE 1: one CH line each)
 template <int N, int MODE, int FAM>
-inline int launch_z_fwd(mrl_ctx *ctx, const double *in, cplx *o0, cplx *o1, double *mu, const ChDev &chp,
+inline int launch_z_fwd(mrl_ctx *ctx, const kreal *in, kcplx *o0, kcplx *o1, kreal *mu, const ChDev &chp,
                         long long nlines, ZLay zl = ZLay{0u, 0u}) {
   static bool attr = false;
   constexpr size_t lds = lds_line<N>();
@@ -27,13 +37,13 @@ inline int launch_z_fwd(mrl_ctx *ctx, const double *in, cplx *o0, cplx *o1, doub
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
   hipLaunchKernelGGL((k_z_fwd<N, MODE, FAM>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, nlines,
-                     ctx->ax[2].d_tw, zl);
+                     tw_table(ctx, 2), zl);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
 
 template <int N>
-inline int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale, long long nlines, ZLay zl = ZLay{0u, 0u}) {
+inline int launch_z_inv(mrl_ctx *ctx, const kcplx *in, kreal *out, kreal scale, long long nlines, ZLay zl = ZLay{0u, 0u}) {
   static bool attr = false;
   constexpr size_t lds = lds_line<N>();
   if (!attr) {
@@ -43,14 +53,14 @@ inline int launch_z_inv(mrl_ctx *ctx, const cplx *in, double *out, double scale,
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
   hipLaunchKernelGGL((k_z_inv<N, false>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
-                     ctx->ax[2].d_tw, nullptr, nullptr, zl);
+                     tw_table(ctx, 2), nullptr, nullptr, zl);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
 
 // nlines = number of line PAIRS (= complex inverse transforms)
 template <int N, int FAM, bool MU_ONLY = false>
-inline int launch_z_inv_fwd(mrl_ctx *ctx, const cplx *in, cplx *o0, cplx *o1, double *mu, const ChDev &chp, double scale,
+inline int launch_z_inv_fwd(mrl_ctx *ctx, const kcplx *in, kcplx *o0, kcplx *o1, kreal *mu, const ChDev &chp, kreal scale,
                             long long nlines, ZLay zl = ZLay{0u, 0u}) {
   static bool attr = false;
   constexpr size_t lds = lds_line<N>();
@@ -61,15 +71,15 @@ inline int launch_z_inv_fwd(mrl_ctx *ctx, const cplx *in, cplx *o0, cplx *o1, do
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
   hipLaunchKernelGGL((k_z_inv_fwd<N, FAM, MU_ONLY>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, scale,
-                     nlines, ctx->ax[2].d_tw, zl);
+                     nlines, tw_table(ctx, 2), zl);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
 
 // z inverse that also leaves sum(out * dotv) as one partial per workgroup in `partial`; *nblocks = their number
 template <int N>
-inline int launch_z_inv_dot(mrl_ctx *ctx, const cplx *in, double *out, double scale, long long nlines, const double *dotv,
-                            double *partial, int *nblocks, ZLay zl = ZLay{0u, 0u}) {
+inline int launch_z_inv_dot(mrl_ctx *ctx, const kcplx *in, kreal *out, kreal scale, long long nlines, const kreal *dotv,
+                            kreal *partial, int *nblocks, ZLay zl = ZLay{0u, 0u}) {
   static bool attr = false;
   constexpr size_t lds = lds_line<N>();
   if (!attr) {
@@ -79,14 +89,14 @@ inline int launch_z_inv_dot(mrl_ctx *ctx, const cplx *in, double *out, double sc
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
   hipLaunchKernelGGL((k_z_inv<N, true>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
-                     ctx->ax[2].d_tw, dotv, partial, zl);
+                     tw_table(ctx, 2), dotv, partial, zl);
   MRL_HIP(ctx, hipGetLastError());
   *nblocks = (int)nb;
   return MRL_OK;
 }
 
 template <int N, bool INV, int NF>
-inline int launch_pass_t(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
+inline int launch_pass_t(mrl_ctx *ctx, PassArgs a, const kcplx *tw) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>();
   if (!attr) {
@@ -102,7 +112,7 @@ inline int launch_pass_t(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
 }
 
 template <int N, bool INV, int NF>
-inline int launch_pass_sub(mrl_ctx *ctx, SubPassArgs a, const cplx *tw) {
+inline int launch_pass_sub(mrl_ctx *ctx, SubPassArgs a, const kcplx *tw) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>();
   if (!attr) {
@@ -119,7 +129,7 @@ inline int launch_pass_sub(mrl_ctx *ctx, SubPassArgs a, const cplx *tw) {
 }
 
 template <int N, bool INV>
-inline int launch_pass_sub_mf(mrl_ctx *ctx, SubPassArgs a, const cplx *tw, int nf) {
+inline int launch_pass_sub_mf(mrl_ctx *ctx, SubPassArgs a, const kcplx *tw, int nf) {
   static bool attr = false;
   constexpr size_t lds = lds_strided<N>();
   if (!attr) {
@@ -136,7 +146,7 @@ inline int launch_pass_sub_mf(mrl_ctx *ctx, SubPassArgs a, const cplx *tw, int n
   return MRL_OK;
 }
 
-}  // namespace p2
+}  // namespace MRL_P2NS
 
 // every length with a Plan<N> that the fast paths are instantiated for
 #define MRL_SWITCH_N(n, CALL)  \
@@ -170,7 +180,7 @@ inline int launch_pass_sub_mf(mrl_ctx *ctx, SubPassArgs a, const cplx *tw, int n
 // workgroups of one k_pass_sub launch over rows x cols lines
 template <int N>
 inline unsigned pass_sub_blocks(long long rows, long long cols) {
-  constexpr int T = p2::Plan<N>::T;
+  constexpr int T = MRL_P2NS::Plan<N>::T;
   return (unsigned)((rows * cols + T - 1) / T);
 }
 

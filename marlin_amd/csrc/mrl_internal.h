@@ -48,6 +48,8 @@ struct AxisPlan {
   int n = 1;
   std::vector<int> radix;
   cplx *d_tw = nullptr;  // exp(-2 pi i k / n), k = 0..n-1
+  void *d_tw32 = nullptr;  // the same as float2 (fp32 instantiation of the fused Cahn-Hilliard path), built on first use
+  float *d_k32 = nullptr;  // LOCAL reciprocal axis as float, likewise
 };
 
 // Device tables of the table-driven slab pipeline (slab_fused.hip: partitions that are not equal powers of two), one set per row
@@ -180,11 +182,24 @@ __device__ __forceinline__ void st_nt(double2 *p, double2 v) {
   w.y = v.y;
   __builtin_nontemporal_store(w, reinterpret_cast<mrl_ntv2 *>(p));
 }
+typedef float mrl_ntv2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 ld_nt(const float2 *p) {
+  const mrl_ntv2f v = __builtin_nontemporal_load(reinterpret_cast<const mrl_ntv2f *>(p));
+  return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void st_nt(float2 *p, float2 v) {
+  mrl_ntv2f w;
+  w.x = v.x;
+  w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<mrl_ntv2f *>(p));
+}
 
 // scratch management
 int ensure_work(mrl_ctx *ctx, int slot, size_t bytes);
 // device pointer table `slot` (0..7) filled on the context's stream with base + p * stride_bytes, p = 0..nranks-1: the
 // destination table of a scatter-capable kernel when the chunks go to one contiguous local buffer
+int axis_tw32(mrl_ctx *ctx, int axis);  // fp32 twiddle table / local reciprocal axis of an internal axis, built on first use
+int axis_k32(mrl_ctx *ctx, int axis);
 int local_tab(mrl_ctx *ctx, int slot, void *base, size_t stride_bytes, cplx *const **out);
 int local_tab_offsets(mrl_ctx *ctx, int slot, void *base, const size_t *byte_offsets, cplx *const **out);
 void slab_pipes_destroy(mrl_ctx *ctx);

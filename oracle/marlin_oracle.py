@@ -161,6 +161,20 @@ def reciprocal_laplacian_square_factor(dom: Domain, factor: float) -> torch.Tens
     return k2 * k2 * factor
 
 
+def float32_operators(dom: "Domain", mobility: float, kappa_factor: float):
+    """Mbar = -k^2 M and Lbar = k^2 k^2 f as a float32 run of the reference builds them: every tensor of the run is created with
+    MooseTensor::floatTensorOptions() (src/utils/MarlinUtils.C:39-44, selected in src/actions/DomainAction.C:81,201), so the
+    reciprocal axes are fftfreq / rfftfreq in float32 times 2.0 times pi (DomainAction.C:284-293) and k^2 = kx*kx + ky*ky + kz*kz is
+    accumulated in float32 (ReciprocalLaplacianFactor.C:28-31, ReciprocalLaplacianSquareFactor.C:28-32).  Returns (Mbar, Lbar)."""
+    assert dom.dim == 3
+    n, dx = dom.n, dom.dx
+    kx = torch.fft.fftfreq(n[0], d=dx[0], dtype=torch.float32) * 2.0 * math.pi
+    ky = torch.fft.fftfreq(n[1], d=dx[1], dtype=torch.float32) * 2.0 * math.pi
+    kz = torch.fft.rfftfreq(n[2], d=dx[2], dtype=torch.float32) * 2.0 * math.pi
+    k2 = kx.reshape(-1, 1, 1) * kx.reshape(-1, 1, 1) + ky.reshape(1, -1, 1) * ky.reshape(1, -1, 1) + kz.reshape(1, 1, -1) * kz.reshape(1, 1, -1)
+    return -k2 * mobility, k2 * k2 * kappa_factor
+
+
 def mu_double_well(c: torch.Tensor, A: float = 0.1) -> torch.Tensor:
     """d/dc [A*c^2*(c-1)^2] exactly as the reference's parser derives and evaluates it.
 
