@@ -9,6 +9,7 @@
 //                           half-spectrum array), same operations in the same order on the pointwise side: results equal the fused
 //                           and the generic path to rounding of the transforms.
 #include "fft_pow2_launch.h"
+#include <atomic>
 
 namespace mrl {
 
@@ -229,11 +230,11 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_x_update(XKArgs a, const cpl
 
 template <int N>
 static int launch_x_mbar(mrl_ctx *ctx, const XKArgs &a, const cplx *tw) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY(set_lds_attr(ctx, k_x_mbar<N>, lds));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   const long long nb = (a.inner + Plan<N>::T - 1) / Plan<N>::T;
   hipLaunchKernelGGL((k_x_mbar<N>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);
@@ -243,11 +244,11 @@ static int launch_x_mbar(mrl_ctx *ctx, const XKArgs &a, const cplx *tw) {
 
 template <int N, int ORDER>
 static int launch_x_update(mrl_ctx *ctx, const XKArgs &a, const cplx *tw) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY((set_lds_attr(ctx, k_x_update<N, ORDER>, lds)));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   const long long nb = (a.inner + Plan<N>::T - 1) / Plan<N>::T;
   hipLaunchKernelGGL((k_x_update<N, ORDER>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, tw);

@@ -1,6 +1,7 @@
 // The fused Cahn-Hilliard x pass (forward x on mu-hat and c-hat, Nhat = Mbar mu-hat, ABM predictor, 1/(1 - dt Lbar), inverse x) and its
 // launchers: shared by ch_fused.hip (fp64, the product path) and ch_fused_f32.hip (the fp32 instantiation: MRL_KREAL = float).
 #pragma once
+#include <atomic>
 #include "ch_fused_body.h"
 #include "fft_pow2_launch.h"
 
@@ -62,11 +63,11 @@ constexpr bool nt_capable() {
 
 template <int N, int ORDER, bool SPEC_C, bool NT, int PRE, bool BIG = false>
 static int launch_xfused_v(mrl_ctx *ctx, const FusedArgs &a, const kcplx *tw) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_strided<N>() + sizeof(kreal) * N;
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY((set_lds_attr(ctx, k_ch_xfused<N, ORDER, PRE, SPEC_C, NT, BIG>, lds)));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   constexpr int T = Plan<N>::T;
   const long long nb = (a.inner + T - 1) / T;

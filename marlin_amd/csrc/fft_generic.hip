@@ -9,6 +9,7 @@
 // "one thread per output element": y[o] = sum_t x[j + t n/r] W_n^{t (k n/(Ns r) + u n/r)},
 // which needs no register arrays and works for any (also large prime) radix.
 #include "mrl_internal.h"
+#include <atomic>
 
 namespace mrl {
 
@@ -323,11 +324,11 @@ int launch_pass(mrl_ctx *ctx, const PassDesc &d0, const double *in, double *out,
   d.tile = tile;
   const size_t lds = tw_bytes + per_line * tile;
   if (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load(std::memory_order_acquire)) {
       MRL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_generic),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
+      attr_set.store(true, std::memory_order_release);
     }
   }
   const long long nblocks = (nlines + tile - 1) / tile;

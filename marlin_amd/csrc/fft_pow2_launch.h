@@ -1,5 +1,6 @@
 // Host-side launchers of the power-of-two kernels, shared by ch_fused.hip, slab_fused.hip and mech_fused.hip.
 #pragma once
+#include <atomic>
 #include "fft_pow2_kernels.h"
 
 namespace mrl {
@@ -28,11 +29,11 @@ inline int set_lds_attr(mrl_ctx *ctx, K kernel, size_t lds) {
 template <int N, int MODE, int FAM>
 inline int launch_z_fwd(mrl_ctx *ctx, const kreal *in, kcplx *o0, kcplx *o1, kreal *mu, const ChDev &chp,
                         long long nlines, ZLay zl = ZLay{0u, 0u}) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_line<N>();
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY(set_lds_attr(ctx, k_z_fwd<N, MODE, FAM>, lds));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
@@ -44,11 +45,11 @@ inline int launch_z_fwd(mrl_ctx *ctx, const kreal *in, kcplx *o0, kcplx *o1, kre
 
 template <int N>
 inline int launch_z_inv(mrl_ctx *ctx, const kcplx *in, kreal *out, kreal scale, long long nlines, ZLay zl = ZLay{0u, 0u}) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_line<N>();
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY(set_lds_attr(ctx, k_z_inv<N, false>, lds));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
@@ -62,11 +63,11 @@ inline int launch_z_inv(mrl_ctx *ctx, const kcplx *in, kreal *out, kreal scale, 
 template <int N, int FAM, bool MU_ONLY = false>
 inline int launch_z_inv_fwd(mrl_ctx *ctx, const kcplx *in, kcplx *o0, kcplx *o1, kreal *mu, const ChDev &chp, kreal scale,
                             long long nlines, ZLay zl = ZLay{0u, 0u}) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_line<N>();
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY((set_lds_attr(ctx, k_z_inv_fwd<N, FAM, MU_ONLY>, lds)));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
@@ -80,11 +81,11 @@ inline int launch_z_inv_fwd(mrl_ctx *ctx, const kcplx *in, kcplx *o0, kcplx *o1,
 template <int N>
 inline int launch_z_inv_dot(mrl_ctx *ctx, const kcplx *in, kreal *out, kreal scale, long long nlines, const kreal *dotv,
                             kreal *partial, int *nblocks, ZLay zl = ZLay{0u, 0u}) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_line<N>();
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY(set_lds_attr(ctx, k_z_inv<N, true>, lds));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
@@ -97,11 +98,11 @@ inline int launch_z_inv_dot(mrl_ctx *ctx, const kcplx *in, kreal *out, kreal sca
 
 template <int N, bool INV, int NF>
 inline int launch_pass_t(mrl_ctx *ctx, PassArgs a, const kcplx *tw) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_strided<N>();
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY(set_lds_attr(ctx, k_pass<N, INV, NF>, lds));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   constexpr int T = Plan<N>::T;
   a.tiles_per_outer = (int)((a.inner + T - 1) / T);
@@ -113,11 +114,11 @@ inline int launch_pass_t(mrl_ctx *ctx, PassArgs a, const kcplx *tw) {
 
 template <int N, bool INV, int NF>
 inline int launch_pass_sub(mrl_ctx *ctx, SubPassArgs a, const kcplx *tw) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_strided<N>();
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY(set_lds_attr(ctx, k_pass_sub<N, INV, NF>, lds));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   constexpr int T = Plan<N>::T;
   if (a.tcols == 0) a.tcols = a.cols;
@@ -130,11 +131,11 @@ inline int launch_pass_sub(mrl_ctx *ctx, SubPassArgs a, const kcplx *tw) {
 
 template <int N, bool INV>
 inline int launch_pass_sub_mf(mrl_ctx *ctx, SubPassArgs a, const kcplx *tw, int nf) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_strided<N>();
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY(set_lds_attr(ctx, k_pass_sub_mf<N, INV>, lds));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   constexpr int T = Plan<N>::T;
   if (a.tcols == 0) a.tcols = a.cols;

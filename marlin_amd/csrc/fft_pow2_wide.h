@@ -3,6 +3,7 @@
 // for the real and the imaginary parts separately so that the LDS tile stays at 64 KB (two workgroups per CU).  One array is 128
 // vector registers: plain one-field passes only (the fused kernels hold three to four arrays and keep the 16-point plans).
 #pragma once
+#include <atomic>
 #include "fft_pow2_launch.h"
 
 namespace mrl {
@@ -189,11 +190,11 @@ __global__ void __launch_bounds__(PL::NT, 2) k_pass_sub_w(SubPassArgs a, const c
 
 template <class PL, bool INV>
 inline int launch_pass_w(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_wide<PL>();
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY((set_lds_attr(ctx, k_pass_w<PL, INV>, lds)));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   a.tiles_per_outer = (int)((a.inner + PL::T - 1) / PL::T);
   const long long nb = a.outer * a.tiles_per_outer;
@@ -204,11 +205,11 @@ inline int launch_pass_w(mrl_ctx *ctx, PassArgs a, const cplx *tw) {
 
 template <class PL, bool INV, bool UTAB>
 inline int launch_pass_sub_w_v(mrl_ctx *ctx, const SubPassArgs &a, const cplx *tw, long long nb) {  // nb = all workgroups
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_wide<PL>();
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY((set_lds_attr(ctx, k_pass_sub_w<PL, INV, UTAB>, lds)));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL((k_pass_sub_w<PL, INV, UTAB>), dim3((unsigned)nb), dim3(PL::NT), lds, ctx->stream, a, tw);
   MRL_HIP(ctx, hipGetLastError());

@@ -10,6 +10,7 @@
 //   z inverse   k_z_inv, x scale/N                                h + r
 // = 9 * (2r + 8h) bytes per application (r = 8 B, h = 8(1+2/n) B per grid point): 724.5 B/pt at n = 128.
 #include "fft_pow2_launch.h"
+#include <atomic>
 
 // Register budget of k_gamma_xfused (16 points per thread: s, v0, v1 = 192 VGPRs of the 256 that two workgroups per CU allow):
 // the three output transforms must NOT be unrolled into each other (the scheduler then overlaps them and spills 50-90 VGPRs: 128^3
@@ -135,11 +136,11 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_xfused(GammaArgs a, co
 
 template <int N>
 static int launch_gamma_xfused(mrl_ctx *ctx, const GammaArgs &a) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY(set_lds_attr(ctx, k_gamma_xfused<N>, lds));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   constexpr int T = Plan<N>::T;
   const long long nb = (a.inner + T - 1) / T;
@@ -260,14 +261,14 @@ template <int N>
 static int launch_gamma_z_fwd_tangent(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
                                       const double *S, int i_num, int i_den, cplx *spec, long long npts, long long rows, bool nt,
                                       double *x, int i_arz, int i_apAp, ZLay zl) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_line_full<N>();
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY(set_lds_attr(ctx, k_gamma_z_fwd_tangent<N, true, true>, lds));
     MRL_TRY(set_lds_attr(ctx, k_gamma_z_fwd_tangent<N, false, true>, lds));
     MRL_TRY(set_lds_attr(ctx, k_gamma_z_fwd_tangent<N, true, false>, lds));
     MRL_TRY(set_lds_attr(ctx, k_gamma_z_fwd_tangent<N, false, false>, lds));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   const unsigned nb = (unsigned)(npts / 512);
 #define MRL_GZT(NTV_, XU_)                                                                                                        \

@@ -20,6 +20,7 @@
 // forward all-to-all carry ONE field instead of two: the exchange volume of a substep drops from 3 to 2 slab transposes,
 // which is what bounds the multi-GPU rate on point-to-point xGMI links.
 #include "ch_fused_body.h"
+#include <atomic>
 
 #include "fft_pow2_launch.h"
 #include "fft_pow2_wide.h"
@@ -108,11 +109,11 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
 
 template <int N, int ORDER, bool SPEC_C, bool ALIGNED, bool BIG = false>
 static int launch_yfused_v(mrl_ctx *ctx, YFusedArgs a) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY((set_lds_attr(ctx, k_ch_yfused<N, ORDER, SPEC_C, ALIGNED, BIG>, lds)));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   constexpr int T = Plan<N>::T;
   a.tiles_per_x = (a.ksub + T - 1) / T;
@@ -219,11 +220,11 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_t(SubPassArgs a, Su
 
 template <int N, bool INV, int NF>
 inline int launch_pass_sub_t(mrl_ctx *ctx, SubPassArgs a, const SubPassTabs &t, const cplx *tw) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_strided<N>();
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY((set_lds_attr(ctx, k_pass_sub_t<N, INV, NF>, lds)));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   constexpr int T = Plan<N>::T;
   if (a.tcols == 0) a.tcols = a.cols;
@@ -281,11 +282,11 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused_t(YFusedArgs a, YT
 
 template <int N, int ORDER, bool SPEC_C>
 static int launch_yfused_t(mrl_ctx *ctx, YFusedArgs a, const YTabs &t) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY((set_lds_attr(ctx, k_ch_yfused_t<N, ORDER, SPEC_C>, lds)));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   constexpr int T = Plan<N>::T;
   a.tiles_per_x = (a.ksub + T - 1) / T;

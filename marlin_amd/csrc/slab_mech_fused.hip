@@ -15,6 +15,7 @@
 //   -- all-to-all --
 //   inv   inverse x pass from [p][3][x_p][y_me][nzc] into the work arrays, k_z_inv<PAIR> * 1/N into the row's 3 output fields
 #include "fft_pow2_launch.h"
+#include <atomic>
 #include "slab_stages.h"
 
 // register budget of k_gamma_yfused: see k_gamma_xfused (mech_fused.hip); here the full prefetch of the third component measured
@@ -159,12 +160,12 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_yfused(GammaYArgs a, c
 
 template <int N>
 static int launch_gamma_yfused(mrl_ctx *ctx, GammaYArgs a) {
-  static bool attr = false;
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
-  if (!attr) {
+  if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY((set_lds_attr(ctx, k_gamma_yfused<N, true>, lds)));
     MRL_TRY((set_lds_attr(ctx, k_gamma_yfused<N, false>, lds)));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   constexpr int T = Plan<N>::T;
   a.rowblk = (unsigned)(((long long)a.nxl * a.nzc + T - 1) / T);

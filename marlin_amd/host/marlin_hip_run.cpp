@@ -290,7 +290,7 @@ static int run_mechanics(DomainAction & domain, const std::string & out)
   for (int d = 0; d < dim; ++d)
     ax.push_back(domain.getAxis(d));
   const double Ka = argd("Ka", 1.0), Kb = argd("Kb", 10.0), mua = argd("mua", 0.5), mub = argd("mub", 5.0);
-  std::vector<double> K(n), mu(n), F(n * dim * dim, 0.0);
+  std::vector<double> K(n), mu(n), F(n * dim * dim, 0.0), phase_field(n);
   for (std::size_t e = 0; e < n; ++e)
   {
     std::size_t r = e;
@@ -308,9 +308,11 @@ static int run_mechanics(DomainAction & domain, const std::string & out)
     }
     K[e] = (1.0 - phase) * Ka + phase * Kb;
     mu[e] = (1.0 - phase) * mua + phase * mub;
+    phase_field[e] = phase;
     for (int i = 0; i < dim; ++i)
       F[e * dim * dim + i * dim + i] = 1.0;  // RankTwoIdentity
   }
+  problem.getBuffer("phase") = DeviceTensor::fromHost(local_block(domain, phase_field));
   problem.getBuffer("K") = DeviceTensor::fromHost(local_block(domain, K));
   problem.getBuffer("mu") = DeviceTensor::fromHost(local_block(domain, mu));
   problem.getBuffer("F") = DeviceTensor::fromHost(local_block(domain, F, dim * dim));
@@ -332,6 +334,21 @@ static int run_mechanics(DomainAction & domain, const std::string & out)
   // [Postprocess] group: evaluated before the outputs of a time step
   ComputeDisplacements displacements(problem, "displacements", "disp", "F");
   ComputeVonMisesStress vonmises(problem, "vonmises", "sV");
+  // output=xdmf: the [TensorOutputs] block of mech3d.i:95-103 -- buffer = 'disp sV F phase', output_mode = 'OVERSIZED_NODAL CELL CELL
+  // NODE', enable_hdf5 = true, execute_on TIMESTEP_END (serial domains: disp is a global field)
+  std::unique_ptr<XDMFTensorOutput> xdmf;
+  if (arg("output") == "xdmf")
+  {
+    XDMFTensorOutput::Params op;
+    op.buffer = {"disp", "sV", "F", "phase"};
+    op.components = {dim, 1, dim * dim, 1};
+    op.output_mode = {"OVERSIZED_NODAL", "CELL", "CELL", "NODE"};
+    op.file_base = out + "/" + arg("file_base", "mech_out");
+    op.enable_hdf5 = arg("enable_hdf5", "true") == "true";
+    // (the displacement buffer has to exist with its final size before the output object sizes its staging area)
+    displacements.computeBuffer();
+    xdmf = std::make_unique<XDMFTensorOutput>(problem, op);
+  }
   ex.execute((int)argi("num_steps", 1), [&](int step) {
     if (!domain.isSlab())  // (ComputeDisplacements interpolates over the global grid: serial domains only)
     {
@@ -341,9 +358,13 @@ static int run_mechanics(DomainAction & domain, const std::string & out)
     vonmises.computeBuffer();
     dump(out, "sV", step - 1, problem.getBuffer("sV"));
     dump(out, "F", step - 1, problem.getBuffer("F"));  // frame 0 = end of step 1 (output on TIMESTEP_END only)
+    if (xdmf)
+      xdmf->startOutput();
     const auto & st = mech->stats();
     std::printf("step %d: newton_its=%d cg_its_total=%d |R|=%.6e\n", step, st.newton_its, st.cg_its_total, st.last_anorm);
   });
+  if (xdmf)
+    xdmf->waitForCompletion();
   return 0;
 }
 

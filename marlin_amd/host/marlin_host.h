@@ -2062,8 +2062,10 @@ public:
     std::string file_base = "out";
     bool transpose = true;
     bool enable_hdf5 = false;              ///< one "<file_base>[.rankNNNN].h5" with datasets "<name>.<frame>" instead of raw files
-    std::vector<std::string> output_mode;  ///< per buffer "CELL" (default) or "NODE" (XDMFTensorOutput.C:41-51): nodal data, every
-                                           ///< dimension extended by one with a copy of the slice at 0 (extendTensor, :530-557)
+    std::vector<std::string> output_mode;  ///< per buffer "CELL" (default), "NODE" (XDMFTensorOutput.C:41-51: nodal data, every
+                                           ///< dimension extended by one with a copy of the slice at 0, extendTensor :530-557) or
+                                           ///< "OVERSIZED_NODAL" (:47-49,287: the buffer already holds n + 1 points per dimension --
+                                           ///< displacement fields -- and is written as it is, as nodal data; serial domains)
   };
   XDMFTensorOutput(TensorProblem & problem, const Params & p) : _problem(problem), _domain(problem.domain()), _p(p)
   {
@@ -2076,14 +2078,18 @@ public:
     if (_p.output_mode.size() != _p.buffer.size())
       paramError("output_mode", "Specify one output mode per buffer.");                             // XDMFTensorOutput.C:80-82
     for (const auto & m : _p.output_mode)
-      if (m != "CELL" && m != "NODE")
-        paramError("output_mode", "CELL or NODE (OVERSIZED_NODAL is not supported by this mirror)");
+    {
+      if (m != "CELL" && m != "NODE" && m != "OVERSIZED_NODAL")
+        paramError("output_mode", "CELL, NODE or OVERSIZED_NODAL");
+      if (m == "OVERSIZED_NODAL" && _domain.isSlab())
+        paramError("output_mode", "OVERSIZED_NODAL buffers are global fields (ComputeDisplacements): serial domains only");
+    }
     if (hipStreamCreateWithFlags(&_copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&_ready[0]) != hipSuccess ||
         hipEventCreate(&_ready[1]) != hipSuccess || hipEventCreate(&_solver_done) != hipSuccess)
       mooseError("XDMFTensorOutput: creating the copy stream failed");
     std::size_t total = 0;
-    for (const int c : _p.components)
-      total += (std::size_t)_domain.getNumberOfCells() * c;
+    for (std::size_t b = 0; b < _p.buffer.size(); ++b)
+      total += pointsOf(b) * (std::size_t)_p.components[b];
     for (auto & st : _staging)
       if (hipHostMalloc(reinterpret_cast<void **>(&st), sizeof(double) * total) != hipSuccess)
         mooseError("XDMFTensorOutput: pinned staging allocation failed");
@@ -2119,7 +2125,7 @@ public:
     for (std::size_t b = 0; b < _p.buffer.size(); ++b)
     {
       const DeviceTensor t = _problem.getBuffer(_p.buffer[b]);   // a handle: keeps the array alive while it is being copied
-      const std::size_t n = (std::size_t)_domain.getNumberOfCells() * _p.components[b];
+      const std::size_t n = pointsOf(b) * (std::size_t)_p.components[b];
       if (!t.defined() || t.numel() != n)
         mooseError("XDMFTensorOutput: buffer '" + _p.buffer[b] + "' is undefined or has an unexpected size");
       if (hipMemcpyAsync(stage + off, t.data(), sizeof(double) * n, hipMemcpyDeviceToHost, _copy_stream) != hipSuccess)
@@ -2170,7 +2176,18 @@ private:
   }
   static std::string componentName(const std::string & name, int comps, int c)
   {
-    return comps == 1 ? name : name + "_" + std::to_string(c);   // buildAttributeNames
+    static const char * xyz[3] = {"x", "y", "z"};   // buildAttributeNames (XDMFTensorOutput.C:654-670): vectors _x _y _z, tensors _0 ...
+    return comps == 1 ? name : name + "_" + (comps <= 3 ? std::string(xyz[c]) : std::to_string(c));
+  }
+  /// grid points of buffer b as it is stored: the cells of the domain, or n + 1 points per dimension for an OVERSIZED_NODAL buffer
+  std::size_t pointsOf(std::size_t b) const
+  {
+    if (_p.output_mode[b] != "OVERSIZED_NODAL")
+      return (std::size_t)_domain.getNumberOfCells();
+    std::size_t n = 1;
+    for (const auto v : _domain.getLocalShape())
+      n *= (std::size_t)(v + 1);
+    return n;
   }
   /// the writer thread: wait for the copies of this frame, transpose on the host, write the files, update the .xmf
   void output(const double * stage, int frame)
@@ -2184,20 +2201,22 @@ private:
     const auto & ls = _domain.getLocalShape();
     const int dim = _domain.getDim();
     const int64_t n0 = ls[0], n1 = dim > 1 ? ls[1] : 1, n2 = dim > 2 ? ls[2] : 1;
-    const std::size_t cells = (std::size_t)(n0 * n1 * n2);
     std::vector<double> slice;
     std::size_t off = 0;
     for (std::size_t b = 0; b < _p.buffer.size(); ++b)
     {
       const int comps = _p.components[b];
-      // NODE: every dimension one longer, the extra slice is a copy of slice 0 (extendTensor); e = extents of what is written
-      const int64_t ex = _p.output_mode[b] == "NODE" ? 1 : 0;
+      // NODE: every dimension one longer, the extra slice is a copy of slice 0 (extendTensor); OVERSIZED_NODAL: the stored field already
+      // has the extra points (no periodic copy); e = extents of what is written, s = extents of what is stored
+      const bool oversized = _p.output_mode[b] == "OVERSIZED_NODAL";
+      const int64_t ex = (_p.output_mode[b] == "NODE" || oversized) ? 1 : 0;
       const int64_t e0 = n0 + ex, e1 = dim > 1 ? n1 + ex : 1, e2 = dim > 2 ? n2 + ex : 1;
+      const int64_t s0 = oversized ? e0 : n0, s1 = oversized ? e1 : n1, s2 = oversized ? e2 : n2;
       slice.resize((std::size_t)(e0 * e1 * e2));
       for (int c = 0; c < comps; ++c)
       {
         const double * src = stage + off;
-        auto at = [&](int64_t i, int64_t j, int64_t k) { return src[(std::size_t)((((i % n0) * n1 + (j % n1)) * n2 + (k % n2))) * comps + c]; };
+        auto at = [&](int64_t i, int64_t j, int64_t k) { return src[(std::size_t)((((i % s0) * s1 + (j % s1)) * s2 + (k % s2))) * comps + c]; };
         // component c of a value-major field, transposed x <-> last axis if requested
         if (dim == 3 && _p.transpose)
         {
@@ -2238,7 +2257,7 @@ private:
           return;
         }
       }
-      off += cells * comps;
+      off += pointsOf(b) * (std::size_t)comps;
     }
     if (_h5 && mrl_h5_flush(_h5) != MRL_OK)                                                        // XDMFTensorOutput.C:244-246
     {
@@ -2329,7 +2348,7 @@ private:
     for (std::size_t b = 0; b < _p.buffer.size(); ++b)
       for (int c = 0; c < _p.components[b]; ++c)
       {
-        const bool node = _p.output_mode[b] == "NODE";                      // XDMFTensorOutput.C:375-394
+        const bool node = _p.output_mode[b] != "CELL";                      // XDMFTensorOutput.C:375-394 (NODE and OVERSIZED_NODAL)
         const std::string & dims = node ? nodedims : celldims;
         const char * center = node ? "Node" : "Cell";
         const std::string name = componentName(_p.buffer[b], _p.components[b], c);

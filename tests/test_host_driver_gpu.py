@@ -303,6 +303,28 @@ def test_mechanics_case_fft_slab(tmp_path):
     assert worst <= 1e-10, worst
 
 
+def test_mechanics_tensor_output_block_of_mech3d(tmp_path):
+    """The [TensorOutputs] block of test/tests/mechanics/mech3d.i:95-103 reproduced as written -- buffer = 'disp sV F phase',
+    output_mode = 'OVERSIZED_NODAL CELL CELL NODE' (XDMFTensorOutput.C:41-51,287), enable_hdf5 = true, TIMESTEP_END -- through the
+    mirror's XDMFTensorOutput and the library's HDF5 writer: EVERY dataset of the gold file mech3d.h5 (disp_x/y/z on 17^3 nodes,
+    phase extended periodically to 17^3, sV and F_0..F_8 on 16^3 cells, frames 0..2) by name, shape and value (1e-10)"""
+    from tests.h5_subset_reader import read_h5
+    g = load_golden("mech3d_gold.npz")
+    _run(["problem=mechanics", "dim=3", "num_steps=3", "nx=16", "ny=16", "nz=16", "xmax=2pi", "ymax=2pi", "zmax=2pi", "substeps=10",
+          "dt=0.01", "l_tol=1e-2", "nl_rel_tol=2e-2", "nl_abs_tol=2e-2", "output=xdmf", "enable_hdf5=true"], tmp_path)
+    got = read_h5(tmp_path / "mech_out.h5")
+    want = [k for k in g.files if "." in k]
+    assert set(want) <= set(got), sorted(set(want) - set(got))
+    worst = 0.0
+    for k in want:
+        assert got[k].shape == g[k].shape, (k, got[k].shape, g[k].shape)
+        worst = max(worst, np.abs(got[k] - g[k]).max())
+    assert worst <= 1e-10, worst
+    assert got["disp_x.0"].shape == (17, 17, 17) and got["phase.2"].shape == (17, 17, 17) and got["F_8.1"].shape == (16, 16, 16)
+    xmf = (tmp_path / "mech_out.xmf").read_text()
+    assert 'Name="disp_x" Center="Node"' in xmf and 'Name="sV" Center="Cell"' in xmf and 'Name="phase" Center="Node"' in xmf
+
+
 def test_error_behaviour(tmp_path):
     """mooseError-style failures: bad dimension, unreadable IC"""
     out = subprocess.run([RUN, "problem=cahnhilliard", "dim=4"], capture_output=True, text=True)
