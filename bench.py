@@ -345,7 +345,7 @@ def main():
     ap.add_argument("--inner", action="store_true",
                     help="this process IS one rank of a torch.distributed.run job (set by the launcher for its fallback stages)")
     ap.add_argument("--device", type=int, default=-1, help="put every rank on this GPU (functional runs on a one-GPU box); default: local rank")
-    ap.add_argument("--stage-timeout", type=float, default=1500.0, help="launcher: seconds before a stage of the chain is given up")
+    ap.add_argument("--stage-timeout", type=float, default=420.0, help="launcher: seconds before a stage of the chain is given up")
     args = ap.parse_args()
 
     if args.gpus > 1 and not args.inner:

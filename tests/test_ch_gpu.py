@@ -79,7 +79,7 @@ def test_ch_gold_file_3d():
 @pytest.mark.parametrize("shape", [(16, 16, 16), (12, 10, 9), (32, 32, 32), (24,), (64, 64, 64), (100, 40, 50),
                                    (200, 64, 40), (128, 128), (200, 100), (64, 400), (96, 192, 48), (384, 96),
                                    (40, 80, 32), (48, 144, 50), (250, 32), (500, 32), (1000, 48), (768, 40, 32),
-                                   (2048, 64), (32, 4096), (2048, 32, 40), (256, 32, 512), (1024, 32),
+                                   (2048, 64), (32, 4096), (2048, 32, 40), (256, 32, 64), (32, 64, 512), (1024, 32),
                                    (150, 150), (120, 90, 60), (240, 40, 32), (32, 270, 40), (300, 180), (360, 60, 48), (450, 600),   # planned-unfused path
                                    (160, 64, 40), (64, 320, 32), (640, 160), (32, 40, 1280),                               # ... radix-20 lengths
                                    (288, 64, 40), (72, 216), (576, 64), (800, 32), (48, 432, 72), (864, 1152)])            # ... further plain plans
@@ -221,7 +221,7 @@ def test_config_a_pfhub_1a_128():
     on 128^2, L = 200 x 200: f = rho (c - c_alpha)^2 (c_beta - c)^2 with rho 5, c_alpha 0.3, c_beta 0.7, Mbar = -5 k^2,
     Lbar = -10 k^4, the benchmark's three-mode initial condition, AB2, 10 time steps of dt = 1 with 1000 substeps each
     (spectral_solve_substeps = 1000): the HIP path (one library call per time step) against the oracle after each of the first
-    three steps (3 000 substeps; the oracle's 10 000 CPU substeps were 70 s of the GPU test tier), and the
+    two steps (2 000 substeps; the oracle's 10 000 CPU substeps were 70 s of the GPU test tier), and the
     total free energy F = int f + |grad c|^2 (the input's [Postprocess] block, FFTGradientSquare factor 1) falls monotonically.
     Tolerance: the reference's 1e-13 is quoted for 100 substeps (test/tests/cahnhilliard/tests:46-57); the butterflies of this FFT
     and MKL's round differently (1e-16 per transform) and the difference grows linearly with the substep count -- measured 1.8e-14
@@ -250,14 +250,14 @@ def test_config_a_pfhub_1a_128():
 
     energies = [free_energy(c0)]
     for step in range(10):
-        if step < 3:
+        if step < 2:
             ref.step(1.0)
         if step > 0:
             head, n_old = (head + 1) % pred, min(n_old + 1, pred - 1)
         out = torch.empty_like(c)
         head, n_old = ctx.ch_substeps(p, c, out, ring, head, n_old, pred, substeps, step > 0, 1.0 / substeps)
         c = out
-        if step < 3:
+        if step < 2:
             assert (c.cpu() - ref.c).abs().max().item() <= max(1e-13, 1e-16 * substeps * (step + 1))
         energies.append(free_energy(c.cpu()))
     assert all(b < a for a, b in zip(energies, energies[1:])), energies
