@@ -9,6 +9,8 @@
 // values of the thread, and the old Nhat values right after the Nhat stores -- so the three transforms run
 // while the next operands are in flight instead of paying one full HBM latency per phase.
 #pragma once
+#include <type_traits>
+
 #include "fft_pow2.h"
 
 
@@ -87,7 +89,9 @@ __device__ __forceinline__ void stc_nt(kcplx *base, BigOff o, kcplx v) {
 // NT_CARRY: the same for the carried spectrum (read and rewritten once per substep).
 // NT_HIST: ... for the old / new Nhat arrays and the cbar output.
 // OffM: offset callable of the mu-hat loads where they differ from the c-hat ones (the table-driven slab pass: the second field of a
-// received chunk lies a chunk-dependent distance behind the first); the other callers pass `offw` twice.
+// received chunk lies a chunk-dependent distance behind the first); the other callers pass OffSame{} and the body uses `offw` (a
+// second copy of the same callable cost the 512-point slab kernel 33 spilled VGPRs: 80 MB of scratch traffic per launch).
+struct OffSame {};
 template <int N, int ORDER, bool LINE_IS_X, int PRE, bool SPEC_C, bool NT_W, bool NT_CARRY, bool NT_HIST, class OffW,
           class OffM, class OffD, class StU>
 __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const kcplx *__restrict__ tw,
@@ -114,7 +118,12 @@ __device__ __forceinline__ void ch_fused_body(const FusedCommon &a, const kcplx 
   const kreal ka = *ka_ptr, kb = *kb_ptr;
   kcplx v[P], cp[P];
 #pragma unroll
-  for (int m = 0; m < P; ++m) v[m] = NT_W ? ldc_nt(a.muhat, offm(m)) : ldc(a.muhat, offm(m));
+  for (int m = 0; m < P; ++m) {
+    if constexpr (std::is_same<OffM, OffSame>::value)
+      v[m] = NT_W ? ldc_nt(a.muhat, offw(m)) : ldc(a.muhat, offw(m));
+    else
+      v[m] = NT_W ? ldc_nt(a.muhat, offm(m)) : ldc(a.muhat, offm(m));
+  }
 #pragma unroll
   for (int m = 0; m < P; ++m) cp[m] = SPEC_C ? (NT_CARRY ? ldc_nt(a.carry, offd(m)) : ldc(a.carry, offd(m))) : ldc(a.chat, offw(m));
 #pragma unroll

@@ -38,12 +38,12 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_xfused(FusedArgs a, const
     const unsigned long long step = (unsigned long long)(TPL * a.plane) * (unsigned long long)sizeof(kcplx);
     auto off = [=](int m) { return BigOff{(unsigned long long)m * step, off0}; };
     auto stu = [=](int m, kcplx val) { stc(ubar, BigOff{(unsigned long long)m * step, off0}, val); };
-    ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT, NT, NT>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, stu, W, X, KX);
+    ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT, NT, NT>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, OffSame{}, off, stu, W, X, KX);
   } else {
     const unsigned off0 = (unsigned)(iv + (long long)q * a.plane) * (unsigned)sizeof(kcplx), step = (unsigned)(TPL * a.plane) * (unsigned)sizeof(kcplx);
     auto off = [=](int m) { return off0 + (unsigned)m * step; };
     auto stu = [=](int m, kcplx val) { stc(ubar, off0 + (unsigned)m * step, val); };
-    ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT, NT, NT>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, off, off, stu, W, X, KX);
+    ch_fused_body<N, ORDER, true, PRE, SPEC_C, NT, NT, NT>(a.c, tw, a.kx, a.ky + iv / a.nzc, a.kz + iv % a.nzc, valid, q, l, off, OffSame{}, off, stu, W, X, KX);
   }
 }
 

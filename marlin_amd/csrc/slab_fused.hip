@@ -38,6 +38,7 @@ struct YFusedArgs {
   unsigned xp;        // elements between two x planes of a chunk (>= nyl * kp: slab_xplane)
   unsigned chunk;     // nxl * xp: elements of one field of one chunk
   int tiles_per_x;
+  int idle_kl;        // column that the idle lanes of a row's last tile load (ksub - 1; experiment bit 1 << 25: 0, the round-2 behaviour)
   const double *kx, *ky, *kz;  // local reciprocal axes
   cplx *const *utab;  // ubar output: chunk p of the inverse exchange layout starts at utab[p] (a peer's receive buffer or the local send buffer)
   SignalArgs sig;     // arrival flags raised by the last workgroup (direct peer stores), or none
@@ -60,13 +61,19 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
   const int ix = logical / a.tiles_per_x;
   const int kl0 = (logical % a.tiles_per_x) * T + l;
   const bool valid = kl0 < a.ksub;
-  const int kl = valid ? kl0 : a.ksub - 1;  // (idle lanes of the last tile re-load its last valid column: the same 128-byte line, not another one)
+  const int kl = valid ? kl0 : a.idle_kl;  // (idle lanes of the last tile re-load its last valid column: the same 128-byte line, not another one)
   // element (ix, j, k0+kl), p = j >> nyl_shift, jl = j & (nyl-1)       [byte offsets]
   //   forward exchange layout  (p*2 + field)*chunk + ix*xp + jl*kp + kl
   //   inverse exchange layout   p*chunk            + ix*xp + jl*kp + kl
   //   dense layout              (ix*N + j)*nzc + k0 + kl
   const int sh = a.nyl_shift, msk = (1 << sh) - 1;
-  const unsigned ksB = (unsigned)a.kp * 16u, chB = a.chunk * 16u, klB = (unsigned)kl * 16u, xB = (unsigned)ix * a.xp * 16u;
+  const unsigned ksB = (unsigned)a.kp * 16u, chB = a.chunk * 16u, klB = (unsigned)kl * 16u;
+  // the x plane of this workgroup is folded into the (wave-uniform) base pointers: the per-element offsets keep the shape they had
+  // without padded planes (an extra uniform term in each of them cost 30 spilled VGPRs)
+  const size_t xE = (size_t)ix * a.xp;
+  FusedCommon fc = a.c;
+  fc.chat += xE;
+  fc.muhat += xE;
   // (with the carry-over only mu-hat is received: one field per chunk)
   // ALIGNED (ny/P is a multiple of the TPL threads of a line, the usual case): the chunk index and the row within the chunk of
   // element j = q + m TPL split into a wave-uniform part that depends on m only and the per-thread constant q ksB + klB, so the
@@ -75,34 +82,33 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
   const int q0 = ALIGNED ? 0 : q;
   auto offf = [=](int m) {
     const int j = q0 + m * TPL;
-    return (unsigned)(j >> sh) * (SPEC_C ? chB : 2u * chB) + xB + (unsigned)(j & msk) * ksB + tq;
+    return (unsigned)(j >> sh) * (SPEC_C ? chB : 2u * chB) + (unsigned)(j & msk) * ksB + tq;
   };
   cplx *const *utab = a.utab;
   auto stu = [=](int m, cplx val) {  // (ALIGNED: the chunk index depends on m only -> the table entry is a scalar load)
     const int j = q0 + m * TPL;
-    stc(utab[j >> sh], xB + (unsigned)(j & msk) * ksB + tq, val);
+    stc(utab[j >> sh] + xE, (unsigned)(j & msk) * ksB + tq, val);
   };
   // default cache policy for every stream: on the sub-block-sized working sets of the slab pipeline the non-temporal accesses of
   // the serial kernel cost 8-30 % (measured per variant with tools/slab_local_bench.py 8 256)
   if constexpr (BIG) {
     const unsigned long long ks64 = (unsigned long long)a.kp * 16ull, ch64 = (unsigned long long)a.chunk * 16ull;
-    const unsigned long long x64 = (unsigned long long)ix * (unsigned long long)a.xp * 16ull;
     auto offf64 = [=](int m) {
       const int j = m * TPL;
-      return BigOff{(unsigned long long)(j >> sh) * (SPEC_C ? ch64 : 2ull * ch64) + x64 + (unsigned long long)(j & msk) * ks64, tq};
+      return BigOff{(unsigned long long)(j >> sh) * (SPEC_C ? ch64 : 2ull * ch64) + (unsigned long long)(j & msk) * ks64, tq};
     };
     auto stu64 = [=](int m, cplx val) {
       const int j = m * TPL;
-      stc(utab[j >> sh], BigOff{x64 + (unsigned long long)(j & msk) * ks64, tq}, val);
+      stc(utab[j >> sh] + xE, BigOff{(unsigned long long)(j & msk) * ks64, tq}, val);
     };
     const unsigned long long dx64 = (unsigned long long)ix * N * (unsigned long long)a.nzc * 16ull, dstep64 = (unsigned long long)(TPL * a.nzc) * 16ull;
     const unsigned dl = (unsigned)(q * a.nzc + a.k0 + kl) * 16u;
     auto offd64 = [=](int m) { return BigOff{dx64 + (unsigned long long)m * dstep64, dl}; };
-    ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf64, offf64, offd64, stu64, W, X, KY);
+    ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(fc, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf64, OffSame{}, offd64, stu64, W, X, KY);
   } else {
     const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + a.k0 + kl) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
     auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
-    ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(a.c, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, offf, offd, stu, W, X, KY);
+    ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(fc, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, OffSame{}, offd, stu, W, X, KY);
   }
   signal_tail(a.sig);
 }
@@ -257,7 +263,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused_t(YFusedArgs a, YT
   const int ix = logical / a.tiles_per_x;
   const int kl0 = (logical % a.tiles_per_x) * T + l;
   const bool valid = kl0 < a.ksub;
-  const int kl = valid ? kl0 : a.ksub - 1;  // (idle lanes of the last tile re-load its last valid column: the same 128-byte line, not another one)
+  const int kl = valid ? kl0 : a.idle_kl;  // (idle lanes of the last tile re-load its last valid column: the same 128-byte line, not another one)
   const unsigned uix = (unsigned)ix, klB = (unsigned)kl * 16u;
   // element (field f, ix, j, k0 + kl) of the received forward buffer: yA[j] + f * yC[j] + ix * yB[j] + kl; of the chunk for rank
   // ych[j] in the inverse layout: ix * yB[j] + yD[j] + kl                                                        [byte offsets]
@@ -591,6 +597,7 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const dou
   a.nzc = (int)((nzc + 7) & ~7LL);  // mrl_slab_ch_spec_pitch: rows of the rank-local spectral arrays start on 128-byte lines
   a.k0 = k0;
   a.ksub = ksub;
+  a.idle_kl = (ctx->exp & (1 << 25)) ? 0 : ksub - 1;
   a.nyl_shift = ilog2(nyl);
   a.kx = ctx->d_k[0];
   a.ky = ctx->d_k[1];

@@ -129,7 +129,7 @@ def test_native_slab_mechanics_fused_vs_oracle(P, shape, transport):
     assert max(r["max_err"] for r in res) <= 1e-10, res
 
 
-def test_native_slab_mechanics_config_e_at_size():
+def test_native_slab_mechanics_config_e_at_size_vs_the_serial_hip_solver():
     """BASELINE configs[4] at its size: the de Geus RVE on 256^3 (inclusion of bench.py --workload mech) over 4 rank processes -- 256 x
     64 x 256 per rank, the all-rows-per-launch Gamma pipeline over one nine-field exchange (peer stores), CG scalars all-reduced on the
     device -- against the serial HIP solver on the whole grid (oracle-checked at 128^3 in tests/test_fullsize_gpu.py; the oracle needs
