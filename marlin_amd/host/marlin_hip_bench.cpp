@@ -358,16 +358,21 @@ static int run_ch(Rank & R)
         continue;
       }
       Res r{c, 0.0, 0.0, true, "", -1};
-      set_opts(c.nsub, exp_user | c.exp | (verify ? (1l << 21) : 0), carry);
+      set_opts(c.nsub, exp_user | c.exp, carry);
+      if (verify)
+      {  // the first three substeps of every candidate: consumers re-read their receive buffers with system-scope loads
+        R.ck(mrl_ctx_set_option(R.ctx, MRL_OPT_VERIFY_MISMATCHES, 0), "MRL_OPT_VERIFY_MISMATCHES");
+        R.ck(mrl_ctx_set_option(R.ctx, MRL_OPT_VERIFY_EXCHANGE, 1), "MRL_OPT_VERIFY_EXCHANGE");
+      }
       ch_reset(S);
       int rc = ch_run(R, S, p, 3, sub_dt);
       if (rc == MRL_OK)
         rc = mrl_sync(R.ctx);
-      if (rc == MRL_OK && verify)
-      {
-        int64_t bad = mrl_ctx_get_option(R.ctx, MRL_OPT_VERIFY_MISMATCHES);
-        r.bad = (long long)R.reduce((double)bad, 0);
-        set_opts(c.nsub, exp_user | c.exp, carry);  // the timed candidate runs without the re-reads
+      if (verify)
+      {  // (collective on every rank, whatever its own return code was)
+        const int64_t bad = rc == MRL_OK ? mrl_ctx_get_option(R.ctx, MRL_OPT_VERIFY_MISMATCHES) : 0;
+        r.bad = (long long)R.reduce((double)(bad < 0 ? 0 : bad), 0);
+        (void)mrl_ctx_set_option(R.ctx, MRL_OPT_VERIFY_EXCHANGE, 0);  // the timed substeps run without the re-reads
       }
       if (rc == MRL_OK)
       {

@@ -69,6 +69,8 @@ def run_ch(job, P, r, kv, gold=False):
     if "exp" in kv:
         ctx.set_option(api.OPT_EXPERIMENT, int(kv["exp"]))
     ctx.set_profiling(True)
+    if kv.get("verify", "0") == "1":   # consumers re-read their receive buffers with system-scope loads (MRL_OPT_VERIFY_EXCHANGE)
+        ctx.set_option(api.OPT_VERIFY_EXCHANGE, 1)
     p = api.ch_params()
     yb, nyl = ctx.real_begin[1], ctx.real_shape[1]
     c = c0[:, yb:yb + nyl].contiguous().cuda()
@@ -93,9 +95,10 @@ def run_ch(job, P, r, kv, gold=False):
             gold_errs.append((c.cpu() - gk[:, yb - 10:yb - 10 + nyl]).abs().max().item())
     st, tr = comm.stats(), comm.transport
     kernels = sorted(k["kernel"] for k in ctx.get_profile() if k["launches"])
+    mismatches = ctx.get_option(api.OPT_VERIFY_MISMATCHES)
     ctx.close()
     comm.close()
-    out = {"max_err": max(errs), "transport": tr, "stats": st, "kernels": kernels}
+    out = {"max_err": max(errs), "transport": tr, "stats": st, "kernels": kernels, "verify_mismatches": mismatches}
     if gold_errs:
         out["max_gold_err"] = max(gold_errs)
     return out

@@ -85,9 +85,12 @@ def test_native_slab_table_addressed_pipeline(P, shape, transport, nsub, carry, 
     """partitions that are not equal powers of two take the FUSED slab pipeline (table-addressed chunks:
     k_pass_sub_t, k_ch_yfused_t scattering into the peers' buffers), not the generic stages: the profile slots of the fused passes
     are present on every rank, fields vs the serial oracle to 1e-13"""
-    res = run_job(P, "ch", f"shape={shape}", f"transport={transport}", f"nsub={nsub}", f"carry={carry}", f"exp={exp}", timeout=600)
+    res = run_job(P, "ch", f"shape={shape}", f"transport={transport}", f"nsub={nsub}", f"carry={carry}", f"exp={exp}", "verify=1", timeout=600)
     assert max(r["max_err"] for r in res) <= 1e-13, res
     for r in res:
+        # MRL_OPT_VERIFY_EXCHANGE was on: the re-read kernel ran behind every arrival wait and found no word that a system-scope load
+        # sees differently from a plain one
+        assert "slab_exchange_verify" in r["kernels"] and r["verify_mismatches"] == 0, r
         assert {"slab_A_x_fwd", "slab_B_y_fused", "slab_C_x_inv"} <= set(r["kernels"]), r["kernels"]
         assert not {"slab_x_fwd", "slab_y_fwd", "slab_pack"} & set(r["kernels"]), r["kernels"]
         assert r["stats"]["exchanges"] > 0 and r["stats"]["bytes_sent"] > 0
