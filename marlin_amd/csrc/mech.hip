@@ -611,7 +611,7 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
          *x = ctx->d_work[10];
   // Fast-path shapes run the whole solve on field-major vectors [9][grid] (coalesced streams for every kernel);
   // the caller's value-major F is converted once on entry, Fnew and P once on exit.
-  const bool soa = dist ? (ctx->dim == 3 && mrl_slab_fast_path(ctx) && npts % 2 == 0) : mech_fast_ok(ctx);
+  const bool soa = dist ? (ctx->dim == 3 && slab_mech_soa(ctx)) : mech_fast_ok(ctx);
   double *Fin = nullptr, *Fwork = d_Fnew, *Pwork = d_P;
   if (soa) {
     for (int s = 11; s <= 13; ++s) MRL_TRY(ensure_work(ctx, s, vb));
@@ -658,7 +658,7 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
     return gamma(tmp, out, 1.0);
   };
 
-  const bool fuse_dir = soa && (dist ? mrl_slab_gamma_tangent_fusable(ctx) != 0 : gamma_tangent_fusable(ctx)) && !(ctx->exp & 32);
+  const bool fuse_dir = soa && (dist ? slab_gamma_tangent_fusable(ctx) != 0 : gamma_tangent_fusable(ctx)) && !(ctx->exp & 32);
   int iiter = 0;
   while (true) {
     // ---- conjugateGradientSolve(G_K_dF, b, dFm, l_tol, l_max_its)        MarlinUtils.h:55-123

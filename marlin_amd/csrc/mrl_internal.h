@@ -57,6 +57,8 @@ struct AxisPlan {
 struct SlabTabs {
   long long kp = -1;
   int dense = -1;           // MRL_OPT_EXPERIMENT bit 1 << 23 when the set was built
+  int nf = 0;               // 0: Cahn-Hilliard layouts (padded x planes; yA2 / yA1 = two / one field per forward chunk);
+                            // 3 / 9: Gamma-operator layouts (dense planes, nf fields per chunk in both directions; yA2 only)
   unsigned *d = nullptr;    // one allocation holding all tables
   const unsigned *xch = nullptr, *xoff = nullptr, *fsz = nullptr, *cofi = nullptr;                            // x passes
   const unsigned *ych = nullptr, *yD = nullptr, *yB = nullptr, *yC = nullptr, *yA2 = nullptr, *yA1 = nullptr;  // fused y pass

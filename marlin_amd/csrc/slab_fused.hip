@@ -24,6 +24,7 @@
 
 #include "fft_pow2_launch.h"
 #include "fft_pow2_wide.h"
+#include "slab_tables.h"
 
 namespace mrl {
 
@@ -160,95 +161,6 @@ static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Table-addressed forms of the two slab kernels that see the chunked exchange layouts, for partitions that are not equal powers of
-// two (slab_fast_table).  Same transforms, same pointwise arithmetic in the same order as the shift-addressed kernels (ch_fused_body):
-// only the address of an element differs -- the chunk index and the offset inside the chunk are looked up (tables: L1 / L2 resident,
-// <= 5 x 4 bytes per line element) instead of being split off the index by shifts.
-struct SubPassTabs {
-  const unsigned *xch;    // [nx] rank whose chunk holds x plane n
-  const unsigned *xoff;   // [nx] element offset of plane n inside a field block of that chunk: (n - first plane) * plane pitch
-  const unsigned *fsz;    // [P]  forward: elements between two fields of the chunk for rank p
-  const unsigned *cofi;   // [P]  inverse: element offset of the chunk received from rank p
-};
-
-template <int N, bool INV, int NF>
-__global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_t(SubPassArgs a, SubPassTabs t, const cplx *__restrict__ tw) {
-  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T;
-  using Map = MapStrided<N>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  cplx *W = reinterpret_cast<cplx *>(smem);
-  cplx *X = W + N;
-  const int l = threadIdx.x % T, q = threadIdx.x / T;
-  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned i = logical * T + l;
-  const bool valid = i < (unsigned)(a.rows * a.tcols);
-  const unsigned ic = valid ? i : 0u;
-  const unsigned row = ic / (unsigned)a.tcols, col = ic - row * (unsigned)a.tcols;
-  const unsigned bi = row * a.pitch_in + min(col, (unsigned)a.cols - 1u), bo = row * a.pitch_out + col;
-  TwRegs<N> twr;
-  tw_issue<N>(twr, tw);
-  cplx v[NF][P];
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-#pragma unroll
-    for (int m = 0; m < P; ++m) {
-      const unsigned n = q + m * TPL;
-      if (INV)
-        v[f][m] = a.in[f][bi + t.cofi[t.xch[n]] + t.xoff[n]];
-      else
-        v[f][m] = a.in[f][bi + n * a.sn_in];
-    }
-  }
-  tw_commit<N>(twr, W);
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    if (INV) {
-#pragma unroll
-      for (int m = 0; m < P; ++m) v[f][m] = cswap(v[f][m]);
-    }
-    fft_line<N, Map>(v[f], q, l, X, W);
-    if (valid) {
-#pragma unroll
-      for (int m = 0; m < P; ++m) {
-        const unsigned n = q + m * TPL;
-        if (INV) {
-          a.out[f][bo + n * a.sn_out] = cswap(v[f][m]);
-        } else {
-          const unsigned p = t.xch[n];
-          a.otab[p][(unsigned)f * t.fsz[p] + bo + t.xoff[n]] = v[f][m];
-        }
-      }
-    }
-  }
-  if (!INV) signal_tail(a.sig);
-}
-
-template <int N, bool INV, int NF>
-inline int launch_pass_sub_t(mrl_ctx *ctx, SubPassArgs a, const SubPassTabs &t, const cplx *tw) {
-  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
-  constexpr size_t lds = lds_strided<N>();
-  if (!attr.load(std::memory_order_acquire)) {
-    MRL_TRY((set_lds_attr(ctx, k_pass_sub_t<N, INV, NF>, lds)));
-    attr.store(true, std::memory_order_release);
-  }
-  constexpr int T = Plan<N>::T;
-  if (a.tcols == 0) a.tcols = a.cols;
-  const long long nb = ((long long)a.rows * a.tcols + T - 1) / T;
-  if (a.sig.expected == 0) a.sig.expected = (unsigned)nb;
-  hipLaunchKernelGGL((k_pass_sub_t<N, INV, NF>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, t, tw);
-  MRL_HIP(ctx, hipGetLastError());
-  return MRL_OK;
-}
-
-struct YTabs {
-  const unsigned *ych;  // [ny] rank whose chunk holds y row j
-  const unsigned *yD;   // [ny] (j - first row of that chunk) * kp
-  const unsigned *yB;   // [ny] x-plane pitch of that chunk
-  const unsigned *yC;   // [ny] elements between the two fields of that chunk (forward, two fields)
-  const unsigned *yA;   // [ny] element offset of row j at x plane 0, field 0, in the received forward buffer
-};
-
 // (fields of YFusedArgs used here: c, nxl, nzc, k0, ksub, tiles_per_x, kx, ky, kz, utab, sig)
 template <int N, int ORDER, bool SPEC_C>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused_t(YFusedArgs a, YTabs t, const cplx *__restrict__ tw) {
@@ -354,6 +266,20 @@ int slab_fast_ok(const mrl_ctx *ctx) { return slab_fast_shift(ctx) || slab_fast_
 int slab_mech_fast_ok(const mrl_ctx *ctx) {
   return slab_fast_shift(ctx) && 48.0 * (double)ctx->n[0] * ((double)ctx->nloc[1] * (double)(ctx->nrec[2] + 8) + 32.0) < 4294967296.0;
 }
+// ... the same pipelines with table-addressed chunks (k_pass_sub_mft, k_gamma_yfused_t): every other partition of planned extents whose
+// nine-field exchange buffers fit 32-bit byte offsets.  Global quantities only: the same verdict on every rank.
+int slab_mech_table_ok(const mrl_ctx *ctx) {
+  if (slab_fast_shift(ctx) || !slab_fast_table(ctx)) return 0;
+  long long ymax = 0, xmax = 0;
+  for (int p = 0; p < ctx->nranks; ++p) {
+    if ((ctx->n[0] * ctx->part_real[p]) % 2) return 0;  // pair-wise z passes on every rank
+    ymax = ctx->part_real[p] > ymax ? ctx->part_real[p] : ymax;
+    xmax = ctx->part_recip[p] > xmax ? ctx->part_recip[p] : xmax;
+  }
+  const double fwd = 9.0 * 16.0 * (double)ctx->n[0] * (double)ymax * (double)ctx->nrec[2];
+  const double inv = 9.0 * 16.0 * (double)xmax * (double)ctx->n[1] * (double)ctx->nrec[2];
+  return fwd < 4294967296.0 && inv < 4294967296.0;
+}
 
 // Row pitch (complex elements) of the exchange layouts of a kz sub-block of width ksub: rows start on 128-byte lines, so the x
 // passes write (and the y pass gathers) whole lines instead of pieces that straddle two (the spectral extent nz/2+1 is odd).  With
@@ -386,10 +312,10 @@ static int ilog2(long long v) {
 }
 
 // the device tables of the table-addressed kernels for exchange rows of pitch kp (built once per pitch, kept by the context)
-static int slab_tabs_get(mrl_ctx *ctx, long long kp, const SlabTabs **out) {
-  const int dense = (ctx->exp >> 23) & 1;
+int slab_tabs_get(mrl_ctx *ctx, long long kp, int nf, const SlabTabs **out) {
+  const int dense = nf ? 1 : (ctx->exp >> 23) & 1;
   for (const SlabTabs &t : ctx->slab_tabs)
-    if (t.kp == kp && t.dense == dense) {
+    if (t.kp == kp && t.dense == dense && t.nf == nf) {
       *out = &t;
       return MRL_OK;
     }
@@ -398,7 +324,10 @@ static int slab_tabs_get(mrl_ctx *ctx, long long kp, const SlabTabs **out) {
   std::vector<unsigned> h((size_t)(2 * nx + 2 * P + 6 * ny));
   unsigned *xch = h.data(), *xoff = xch + nx, *fsz = xoff + nx, *cofi = fsz + P, *ych = cofi + P, *yD = ych + ny, *yB = yD + ny,
            *yC = yB + ny, *yA2 = yC + ny, *yA1 = yA2 + ny;
-  const long long xp_me = slab_xplane_of(ctx, nyl, kp);
+  // x-plane pitch of a chunk with `rows` y rows, fields per chunk (forward / inverse)
+  auto plane = [&](long long rows) { return nf ? rows * kp : slab_xplane_of(ctx, rows, kp); };
+  const long long nff = nf ? nf : 2, nfi = nf ? nf : 1;
+  const long long xp_me = plane(nyl);
   long long xb = 0, off = 0;
   for (int p = 0; p < P; ++p) {
     for (long long i = 0; i < ctx->part_recip[p]; ++i) {
@@ -407,12 +336,12 @@ static int slab_tabs_get(mrl_ctx *ctx, long long kp, const SlabTabs **out) {
     }
     fsz[p] = (unsigned)(ctx->part_recip[p] * xp_me);
     cofi[p] = (unsigned)off;
-    off += ctx->part_recip[p] * xp_me;
+    off += nfi * ctx->part_recip[p] * xp_me;
     xb += ctx->part_recip[p];
   }
   long long yb = 0, off2 = 0, off1 = 0;
   for (int p = 0; p < P; ++p) {
-    const long long xp_p = slab_xplane_of(ctx, ctx->part_real[p], kp);
+    const long long xp_p = plane(ctx->part_real[p]);
     for (long long i = 0; i < ctx->part_real[p]; ++i) {
       const long long j = yb + i;
       ych[j] = (unsigned)p;
@@ -422,7 +351,7 @@ static int slab_tabs_get(mrl_ctx *ctx, long long kp, const SlabTabs **out) {
       yA2[j] = (unsigned)(off2 + i * kp);
       yA1[j] = (unsigned)(off1 + i * kp);
     }
-    off2 += 2 * nxl * xp_p;
+    off2 += nff * nxl * xp_p;
     off1 += nxl * xp_p;
     yb += ctx->part_real[p];
   }
@@ -432,6 +361,7 @@ static int slab_tabs_get(mrl_ctx *ctx, long long kp, const SlabTabs **out) {
   SlabTabs t;
   t.kp = kp;
   t.dense = dense;
+  t.nf = nf;
   MRL_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&t.d), sizeof(unsigned) * h.size()));
   MRL_HIP(ctx, hipMemcpy(t.d, h.data(), sizeof(unsigned) * h.size(), hipMemcpyHostToDevice));
   t.xch = t.d;
@@ -501,7 +431,7 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const 
   const bool one = carry == MRL_CARRY_IN;  // mu-hat only
   if (!slab_fast_shift(ctx)) {  // table-addressed chunks (partitions that are not equal powers of two)
     const SlabTabs *tb;
-    MRL_TRY(slab_tabs_get(ctx, kp, &tb));
+    MRL_TRY(slab_tabs_get(ctx, kp, 0, &tb));
     p2::SubPassArgs a{};
     a.in[0] = (one ? w_mu : w_c) + k0;
     a.in[1] = w_mu + k0;
@@ -609,7 +539,7 @@ int slab_ch_kspace_fast(mrl_ctx *ctx, const ChP &cp, int k0, int ksub, const dou
   ProfScope ps(ctx, "slab_B_y_fused", ((spec ? 5.0 : 4.0) + order + (cbar && !spec ? 1.0 : 0.0)) * 16.0 * nxl * ny * ksub);
   if (!slab_fast_shift(ctx)) {  // table-addressed chunks
     const SlabTabs *tb;
-    MRL_TRY(slab_tabs_get(ctx, a.kp, &tb));
+    MRL_TRY(slab_tabs_get(ctx, a.kp, 0, &tb));
     a.c.muhat = a.c.chat;  // (the field offset comes from the table: chunk-dependent)
     const p2::YTabs t{tb->ych, tb->yD, tb->yB, tb->yC, spec ? tb->yA1 : tb->yA2};
     if (spec) {
@@ -671,7 +601,7 @@ int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv) {
   ProfScope ps(ctx, "slab_C_x_inv", 32.0 * nx * nyl * ksub);
   if (!slab_fast_shift(ctx)) {  // table-addressed chunks
     const SlabTabs *tb;
-    MRL_TRY(slab_tabs_get(ctx, kp, &tb));
+    MRL_TRY(slab_tabs_get(ctx, kp, 0, &tb));
     const p2::SubPassTabs t{tb->xch, tb->xoff, tb->fsz, tb->cofi};
     MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub_t<NN, true, 1>(ctx, a, t, ctx->ax[0].d_tw))));
     return MRL_OK;

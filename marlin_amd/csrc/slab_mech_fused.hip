@@ -17,6 +17,7 @@
 #include "fft_pow2_launch.h"
 #include <atomic>
 #include "slab_stages.h"
+#include "slab_tables.h"
 
 // register budget of k_gamma_yfused: see k_gamma_xfused (mech_fused.hip); here the full prefetch of the third component measured
 // best once the output transforms are no longer unrolled into each other (rank-local 256^3 / 8: 60 -> 45 us per row)
@@ -179,12 +180,156 @@ static int launch_gamma_yfused(mrl_ctx *ctx, GammaYArgs a) {
   return MRL_OK;
 }
 
+// Table-addressed form of k_gamma_yfused (slab_mech_table_ok): the same transforms and the same projection arithmetic in the same order;
+// the chunk of y row j and its offsets come from the tables (built for nf fields per chunk, dense planes: slab_tabs_get(ctx, nzc, nf)).
+//   received element (f, ix, j, kl): yA[j] + f yC[j] + ix yB[j] + kl ;   in the chunk for rank ych[j]: f yC[j] + ix yB[j] + yD[j] + kl
+template <int N>
+__global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_yfused_t(GammaYArgs a, YTabs t, const cplx *__restrict__ tw) {
+#pragma clang fp contract(off)
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T, NT = Plan<N>::NT, CNT = (N + NT - 1) / NT;
+  using Map = MapStrided<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  cplx *X = W + N;
+  double *KY = reinterpret_cast<double *>(X + Map::size);
+  const int l = threadIdx.x % T, q = threadIdx.x / T;
+  unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned trow = logical / a.rowblk;
+  logical -= trow * a.rowblk;
+  const unsigned li = logical * T + l;
+  const bool valid = li < (unsigned)(a.nxl * a.nzc);
+  const unsigned ix = valid ? li / (unsigned)a.nzc : 0u;
+  const unsigned kl = valid ? li - ix * (unsigned)a.nzc : 0u;
+#pragma unroll
+  for (int j = 0; j < CNT; ++j) {
+    const int idx = threadIdx.x + j * NT;
+    if (idx < N) {
+      W[idx] = tw[idx];
+      KY[idx] = a.ky[idx];
+    }
+  }
+  const double kx = a.kx[ix], kz = a.kz[kl];
+  const unsigned f0 = 3u * trow;
+  auto ld = [=](unsigned f, int m) {
+    const unsigned j = q + m * TPL;
+    return a.buf[t.yA[j] + (f0 + f) * t.yC[j] + ix * t.yB[j] + kl];
+  };
+  cplx v0[P], v1[P];
+#pragma unroll
+  for (int m = 0; m < P; ++m) v0[m] = ld(0u, m);
+#pragma unroll
+  for (int m = 0; m < P; ++m) v1[m] = ld(1u, m);
+  // (fft_line starts with a barrier-protected exchange through X only; W / KY are read after its first __syncthreads)
+  __syncthreads();
+  cplx s[P];
+  fft_line<N, Map>(v0, q, l, X, W);
+#pragma unroll
+  for (int m = 0; m < P; ++m) s[m] = make_double2(v0[m].x * kx, v0[m].y * kx);
+#pragma unroll
+  for (int m = 0; m < P; ++m) v0[m] = ld(2u, m);
+  fft_line<N, Map>(v1, q, l, X, W);
+#pragma unroll
+  for (int m = 0; m < P; ++m) {
+    const double ky = KY[q + m * TPL];
+    s[m].x += v1[m].x * ky;
+    s[m].y += v1[m].y * ky;
+  }
+  fft_line<N, Map>(v0, q, l, X, W);
+#pragma unroll
+  for (int m = 0; m < P; ++m) {
+    const double ky = KY[q + m * TPL];
+    const double Q = kx * kx + (ky * ky + kz * kz);
+    const double inv = (Q == 0.0) ? 0.0 : a.scale / Q;
+    s[m].x = (s[m].x + v0[m].x * kz) * inv;
+    s[m].y = (s[m].y + v0[m].y * kz) * inv;
+  }
+#pragma unroll 1
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      const double qj = (j == 0) ? kx : (j == 1 ? KY[q + m * TPL] : kz);
+      v0[m] = make_double2(s[m].y * qj, s[m].x * qj);
+    }
+    fft_line<N, Map>(v0, q, l, X, W);
+    if (valid) {
+#pragma unroll
+      for (int m = 0; m < P; ++m) {
+        const unsigned jj = q + m * TPL;
+        a.otab[t.ych[jj]][(f0 + (unsigned)j) * t.yC[jj] + ix * t.yB[jj] + t.yD[jj] + kl] = cswap(v0[m]);
+      }
+    }
+  }
+  signal_tail(a.sig);
+}
+
+template <int N>
+static int launch_gamma_yfused_t(mrl_ctx *ctx, GammaYArgs a, const YTabs &t) {
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
+  constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
+  if (!attr.load(std::memory_order_acquire)) {
+    MRL_TRY((set_lds_attr(ctx, k_gamma_yfused_t<N>, lds)));
+    attr.store(true, std::memory_order_release);
+  }
+  constexpr int T = Plan<N>::T;
+  a.rowblk = (unsigned)(((long long)a.nxl * a.nzc + T - 1) / T);
+  const long long nb = (long long)(a.nf / 3) * a.rowblk;
+  a.sig.expected = (unsigned)nb;
+  hipLaunchKernelGGL((k_gamma_yfused_t<N>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, t, ctx->ax[1].d_tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
 }  // namespace p2
 
 static int ilog2(long long v) {
   int s = 0;
   while ((1LL << s) < v) ++s;
   return s;
+}
+
+// table-addressed x passes of nf fields (k_pass_sub_mft): forward from the dense work array w into the exchange layout through otab,
+// inverse from the received chunks into w
+static int x_pass_tab(mrl_ctx *ctx, bool inverse, int nf, const cplx *src, cplx *dst, cplx *const *otab, const SignalArgs &sig) {
+  const long long nx = ctx->n[0], nyl = ctx->nloc[1], nzc = ctx->nrec[2];
+  const SlabTabs *tb;
+  MRL_TRY(slab_tabs_get(ctx, nzc, nf, &tb));
+  p2::SubPassArgs a{};
+  a.rows = (int)nyl;
+  a.cols = (int)nzc;
+  a.pitch_in = a.pitch_out = (unsigned)nzc;
+  a.sn_in = a.sn_out = (unsigned)(nyl * nzc);
+  a.fdense = (unsigned)(nx * nyl * nzc);
+  a.in[0] = src;
+  a.out[0] = dst;
+  a.otab = otab;
+  a.sig = sig;
+  const p2::SubPassTabs t{tb->xch, tb->xoff, tb->fsz, tb->cofi};
+  if (inverse) {
+    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub_mft<NN, true>(ctx, a, t, ctx->ax[0].d_tw, nf))));
+  } else {
+    MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub_mft<NN, false>(ctx, a, t, ctx->ax[0].d_tw, nf))));
+  }
+  return MRL_OK;
+}
+
+static int y_fused_tab(mrl_ctx *ctx, int nf, const double *recv, cplx *const *otab, const SignalArgs &sig, double scale) {
+  const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2];
+  const SlabTabs *tb;
+  MRL_TRY(slab_tabs_get(ctx, nzc, nf, &tb));
+  p2::GammaYArgs a{};
+  a.buf = reinterpret_cast<const cplx *>(recv);
+  a.otab = otab;
+  a.sig = sig;
+  a.nxl = (int)nxl;
+  a.nzc = (int)nzc;
+  a.nf = nf;
+  a.kx = ctx->d_k[0];
+  a.ky = ctx->d_k[1];
+  a.kz = ctx->d_k[2];
+  a.scale = scale;
+  const p2::YTabs t{tb->ych, tb->yD, tb->yB, tb->yC, tb->yA2};
+  MRL_SWITCH_N(ny, MRL_TRY((p2::launch_gamma_yfused_t<NN>(ctx, a, t))));
+  return MRL_OK;
 }
 
 // work arrays: slot 16 = the three z/x-transformed fields of a row [3][nx][nyl][nzc] (one row at a time per direction:
@@ -219,6 +364,10 @@ int slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *d_A_fm, cplx *const 
     w = reinterpret_cast<cplx *>(ctx->d_work[18]) + 3 * row * nspec;  // z spectra left by mrl_slab_gamma_tangent_z_fwd
     if (row == 2) ctx->gamma_z_ready = false;                         // consumed: a later call needs a new fused z pass
   }
+  if (!slab_fast_shift(ctx)) {
+    ProfScope ps(ctx, "slab_gamma_x_fwd", 3.0 * 32.0 * nspec);
+    return x_pass_tab(ctx, false, 3, w, nullptr, otab, sig);
+  }
   const unsigned chunk = (unsigned)(nxl * nyl * nzc);
   p2::SubPassArgs a{};
   a.rows = (int)nyl;
@@ -246,6 +395,10 @@ int slab_gamma_row_fwd(mrl_ctx *ctx, int row, const double *d_A_fm, cplx *const 
 
 int slab_gamma_row_mid(mrl_ctx *ctx, const double *recv, cplx *const *otab, const SignalArgs &sig, double scale) {
   const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2], nyl = ny / ctx->nranks;
+  if (!slab_fast_shift(ctx)) {
+    ProfScope ps(ctx, "slab_gamma_y_fused", 3.0 * 32.0 * nxl * ny * nzc);
+    return y_fused_tab(ctx, 3, recv, otab, sig, scale);
+  }
   p2::GammaYArgs a{};
   a.buf = reinterpret_cast<const cplx *>(recv);
   a.otab = otab;
@@ -270,7 +423,10 @@ int slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *d_recv, double *d_ou
   cplx *w;
   MRL_TRY(row_work(ctx, 17, &w));
   const unsigned chunk = (unsigned)(nxl * nyl * nzc);
-  {
+  if (!slab_fast_shift(ctx)) {
+    ProfScope ps(ctx, "slab_gamma_x_inv", 3.0 * 32.0 * nspec);
+    MRL_TRY(x_pass_tab(ctx, true, 3, reinterpret_cast<const cplx *>(d_recv), w, nullptr, SignalArgs{}));
+  } else {
     p2::SubPassArgs a{};
     a.rows = (int)nyl;
     a.cols = (int)nzc;
@@ -312,7 +468,9 @@ int slab_gamma_row_inv(mrl_ctx *ctx, int row, const double *d_recv, double *d_ou
 // one-rank 128^3 job spent 541 us per CG iteration in 33 such launches where the serial solver needs 274 us in 4.  Here the
 // nine fields go through ONE launch per stage; chunk layout [p][9 fields][x][y][nzc], f = 3 row + component.
 bool slab_gamma_batched_ok(const mrl_ctx *ctx) {
-  const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2];
+  long long nxl = ctx->nrec[0];
+  for (long long v : ctx->part_recip) nxl = v > nxl ? v : nxl;  // (the same verdict on every rank)
+  const long long ny = ctx->n[1], nzc = ctx->nrec[2];
   return 9.0 * 16.0 * (double)(nxl * ny * nzc) < 4294967296.0;  // 32-bit byte offsets within the nine-field exchange buffers
 }
 
@@ -338,6 +496,10 @@ int slab_gamma_rows_fwd(mrl_ctx *ctx, const double *d_A_fm, cplx *const *otab, c
     w = reinterpret_cast<cplx *>(ctx->d_work[18]);  // z spectra of the nine fields left by slab_gamma_tangent_z
     ctx->gamma_z_ready = false;
   }
+  if (!slab_fast_shift(ctx)) {
+    ProfScope ps(ctx, "slab_gamma_x_fwd", 9.0 * 32.0 * nspec);
+    return x_pass_tab(ctx, false, 9, w, nullptr, otab, sig);
+  }
   p2::SubPassArgs a{};
   a.rows = (int)nyl;
   a.cols = (int)nzc;
@@ -357,6 +519,10 @@ int slab_gamma_rows_fwd(mrl_ctx *ctx, const double *d_A_fm, cplx *const *otab, c
 
 int slab_gamma_rows_mid(mrl_ctx *ctx, const double *recv, cplx *const *otab, const SignalArgs &sig, double scale) {
   const long long nxl = ctx->nrec[0], ny = ctx->n[1], nzc = ctx->nrec[2], nyl = ny / ctx->nranks;
+  if (!slab_fast_shift(ctx)) {
+    ProfScope ps(ctx, "slab_gamma_y_fused", 9.0 * 32.0 * nxl * ny * nzc);
+    return y_fused_tab(ctx, 9, recv, otab, sig, scale);
+  }
   p2::GammaYArgs a{};
   a.buf = reinterpret_cast<const cplx *>(recv);
   a.otab = otab;
@@ -380,7 +546,10 @@ int slab_gamma_rows_inv(mrl_ctx *ctx, const double *d_recv, double *d_out_fm, co
   const long long nreal = nx * nyl * nz, nspec = nx * nyl * nzc;
   cplx *w;
   MRL_TRY(rows_work(ctx, 17, &w));
-  {
+  if (!slab_fast_shift(ctx)) {
+    ProfScope ps(ctx, "slab_gamma_x_inv", 9.0 * 32.0 * nspec);
+    MRL_TRY(x_pass_tab(ctx, true, 9, reinterpret_cast<const cplx *>(d_recv), w, nullptr, SignalArgs{}));
+  } else {
     p2::SubPassArgs a{};
     a.rows = (int)nyl;
     a.cols = (int)nzc;
@@ -410,6 +579,17 @@ int slab_gamma_rows_inv(mrl_ctx *ctx, const double *d_recv, double *d_out_fm, co
   return MRL_OK;
 }
 
+// the fused CG direction + tangent + forward z pass: z lines of 32 ... 256 points in whole 512-point tiles, on EVERY rank (the ranks must
+// agree on the pipeline: with the fused form the forward exchange starts from the spectra the z pass left in the context)
+int slab_gamma_tangent_fusable(const mrl_ctx *ctx) {
+  if (!ctx->slab || ctx->dim != 3 || !slab_mech_any_ok(ctx)) return 0;
+  const long long nz = ctx->n[2];
+  if (!(nz == 32 || nz == 64 || nz == 128 || nz == 256)) return 0;
+  for (int p = 0; p < ctx->nranks; ++p)
+    if ((ctx->n[0] * ctx->part_real[p]) % (512 / nz)) return 0;
+  return 1;
+}
+
 }  // namespace mrl
 
 using namespace mrl;
@@ -432,9 +612,7 @@ int mrl_slab_gamma_counts(const mrl_ctx *ctx, int forward, int64_t *h_send_count
 
 int mrl_slab_gamma_tangent_fusable(const mrl_ctx *ctx) {
   if (!ctx || !ctx->slab || !mrl_slab_fast_path(ctx)) return 0;
-  const long long nz = ctx->n[2], rows = ctx->n[0] * ctx->nloc[1];
-  if (!(nz == 32 || nz == 64 || nz == 128 || nz == 256)) return 0;
-  return rows % (512 / nz) == 0 ? 1 : 0;
+  return slab_gamma_tangent_fusable(ctx);
 }
 
 int mrl_slab_gamma_tangent_z_fwd(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu, double *d_p,

@@ -10,6 +10,12 @@ int slab_fast_ok(const mrl_ctx *ctx);      // the fused slab pipeline applies (s
 int slab_fast_shift(const mrl_ctx *ctx);   // ... with equal power-of-two partitions: chunk addressing by shifts (the tuned kernels)
 long long slab_xplane_of(const mrl_ctx *ctx, long long rows, long long kp);   // x-plane pitch of a chunk with `rows` y rows
 int slab_mech_fast_ok(const mrl_ctx *ctx);  // ... and the exchange buffers of the mechanics row pipelines fit 32-bit byte offsets
+int slab_mech_table_ok(const mrl_ctx *ctx); // the mechanics pipelines with table-addressed chunks (partitions that are not equal powers of two)
+inline int slab_mech_any_ok(const mrl_ctx *ctx) { return slab_mech_fast_ok(ctx) || slab_mech_table_ok(ctx); }
+// the slab Newton-CG solve runs on field-major vectors through slab_gamma_fm (the same verdict on every rank)
+inline int slab_mech_soa(const mrl_ctx *ctx) { return slab_mech_table_ok(ctx) || (slab_mech_fast_ok(ctx) && ctx->nloc[1] % 2 == 0); }
+int slab_gamma_tangent_fusable(const mrl_ctx *ctx);  // fused CG direction + tangent + forward z pass available on this slab context
+int slab_tabs_get(mrl_ctx *ctx, long long kp, int nf, const SlabTabs **out);  // device tables of the table-addressed kernels (nf: SlabTabs)
 int slab_sub_range(mrl_ctx *ctx, int sub, int nsub, long long *k0, long long *ksub);
 long long slab_xplane(const mrl_ctx *ctx, long long kp);    // elements between two x planes of a chunk of those layouts (padded: odd number of 256-byte pieces)
 long long slab_kpitch(const mrl_ctx *ctx, long long ksub);  // row pitch of the Cahn-Hilliard exchange layouts (slab_fused.hip)

@@ -252,6 +252,9 @@ def run_mech(job, P, r, kv):
     comm = api.Comm(job, P, r, device=0, transport=int(kv.get("transport", 0)), timeout=60.0)
     ctx = api.Context(dim, shape, [2 * math.pi] * dim, nranks=P, rank=r, slab=True, device=0)
     ctx.attach_comm(comm)
+    ctx.set_profiling(True)
+    if kv.get("exp"):
+        ctx.set_option(api.OPT_EXPERIMENT, int(kv["exp"]))
     yb, nyl = ctx.real_begin[1], ctx.real_shape[1]
     Kl, mul = K[:, yb:yb + nyl].contiguous().cuda(), mu[:, yb:yb + nyl].contiguous().cuda()
     F = torch.eye(dim, dtype=torch.float64).expand(list(ctx.real_shape) + [dim, dim]).contiguous().cuda()
@@ -301,11 +304,12 @@ def run_mech(job, P, r, kv):
                 gk = torch.from_numpy(np.ascontiguousarray(g[f"F_{k}.{step}"])).permute(*perm)   # XDMF default transpose
                 gold_errs.append((Fl[..., k] - gk[:, yb:yb + nyl]).abs().max().item())
     tr = comm.transport
+    kernels = sorted(k["kernel"] for k in ctx.get_profile() if k["launches"])
     ctx.close()
     comm.close()
     if hip_ref:
         sctx.close()
-    out = {"max_err": max(errs), "traces_ok": bool(traces_ok), "transport": tr, "seconds_library": round(t_lib, 2),
+    out = {"max_err": max(errs), "traces_ok": bool(traces_ok), "transport": tr, "seconds_library": round(t_lib, 2), "kernels": kernels,
            "seconds_oracle": round(t_ref, 2), "cg_its_last": list(st["cg_its"])}
     if gold_errs:
         out["max_gold_err"] = max(gold_errs)
