@@ -139,9 +139,10 @@ def test_displacements_and_von_mises_vs_oracle(shape, L):
 
 
 def test_mech_fast_path_vs_oracle():
-    """64^3 (power-of-two fast path: field-major vectors, Gamma fused into the x pass) against the oracle's
-    FFTMechanics::computeBuffer with the stored Ghat4 / K4: same Newton and CG iteration counts, F to 1e-10"""
-    dim, n = 3, 64
+    """32^3 (power-of-two fast path: field-major vectors, Gamma fused into the x pass) against the oracle's
+    FFTMechanics::computeBuffer with the stored Ghat4 / K4 (1296 B per k-point: the reason for the size; 128^3 against the oracle's
+    closed form in tests/test_fullsize_gpu.py): same Newton and CG iteration counts, F to 1e-10"""
+    dim, n = 3, 32
     dom, phase, K, mu = _mech_setup(dim, n)
     ctx = _ctx(dim, dom.shape, [2 * math.pi] * dim)
     oracle = mo.FFTMechanicsOracle(dom, K, mu, l_tol=1e-2, nl_rel_tol=2e-2, nl_abs_tol=2e-2)

@@ -146,7 +146,7 @@ def test_native_slab_mechanics_table_addressed(P, shape, transport, exp):
     assert max(r["max_err"] for r in res) <= 1e-10, res
     for r in res:
         assert {"slab_gamma_x_fwd", "slab_gamma_y_fused", "slab_gamma_x_inv"} <= set(r["kernels"]), r["kernels"]
-        assert not {"slab_x_fwd", "slab_y_fwd", "slab_pack", "gamma_project"} & set(r["kernels"]), r["kernels"]
+        assert not {"slab_x_fwd", "slab_y_fwd", "slab_pack", "gamma_project_fm", "mech_gamma_project"} & set(r["kernels"]), r["kernels"]
 
 
 def test_native_slab_mechanics_config_e_at_size_vs_the_serial_hip_solver():
