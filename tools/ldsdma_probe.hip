@@ -179,6 +179,50 @@ __global__ void k_diff(const double2 *a, const double2 *b, size_t n, unsigned lo
     if (a[i].x != b[i].x || a[i].y != b[i].y) atomicAdd(bad, 1ull);
 }
 
+// mode 8: the register-staged mover with the workgroup shape as template parameters (threads = T N / P), occupancy set through the
+// dynamic LDS size as in the product kernels (their Stockham tile): which tile shape suits 512-point lines of a 512^3 grid on one GPU
+template <int N, int P, int T, int MINB>
+__global__ void __launch_bounds__(T * (N / P), MINB) k_move_g(Args a) {
+  constexpr int TPL = N / P;
+  extern __shared__ double2 dyn_lds[];
+  const unsigned l = threadIdx.x % T, q = threadIdx.x / T;
+  const unsigned i = (a.remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x) * T + l;
+  const bool valid = i < a.rows * a.tcols;
+  const unsigned ic = valid ? i : 0u;
+  const unsigned row = ic / a.tcols, col = ic - row * a.tcols;
+  const size_t bi = (size_t)row * a.pitch_in + col, bo = (size_t)row * a.pitch_out + col;
+  double2 v[P];
+#pragma unroll
+  for (int m = 0; m < P; ++m) v[m] = a.in[bi + (size_t)(q + m * TPL) * a.sn_in];
+  if (a.work < 0) dyn_lds[threadIdx.x] = v[0];  // (keeps the allocation alive)
+  __syncthreads();
+  for (int w = 0; w < a.work; ++w) {
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      v[m].x = v[m].x * 1.0000001 + v[(m + 1) % P].y;
+      v[m].y = v[m].y * 0.9999999 - v[(m + 1) % P].x;
+    }
+  }
+  __syncthreads();
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < P; ++m) a.out[bo + (size_t)(q + m * TPL) * a.sn_out] = v[m];
+  }
+}
+__global__ void __launch_bounds__(256) k_copy12(const double2 *__restrict__ in, double2 *__restrict__ o1, double2 *__restrict__ o2, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double2 v = in[i];
+    o1[i] = v;
+    o2[i] = make_double2(v.y, v.x);
+  }
+}
+__global__ void __launch_bounds__(256) k_copy21(const double2 *__restrict__ i1, const double2 *__restrict__ i2, double2 *__restrict__ o, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double2 v = i1[i], w = i2[i];
+    o[i] = make_double2(v.y + w.x, v.x - w.y);
+  }
+}
+
 int main(int argc, char **argv) {
   const int which = argc > 1 ? atoi(argv[1]) : 0;  // 0 both, 1 slab geometry, 2 serial geometry
   const int NBUF = 3;
@@ -373,6 +417,71 @@ int main(int argc, char **argv) {
     }
     CK(hipDeviceSynchronize());
     printf("pad %u done\n", pad);
+  }
+  if (which == 8) {
+    // 512^3 on one GPU: x pass over [512][512 x 257 (+ pad)] and y pass over [512 planes][512][257]; 1.08 GB per array (no cache holds it)
+    const unsigned n = 512, nzc = 257;
+    const size_t plane = (size_t)n * nzc;
+    double2 *in[2], *out[2];
+    const size_t cap = (size_t)n * (plane + 64) + 4096;
+    for (int b = 0; b < 2; ++b) {
+      CK(hipMalloc(&in[b], cap * sizeof(double2)));
+      CK(hipMalloc(&out[b], cap * sizeof(double2)));
+      k_fill<<<2048, 256>>>(in[b], cap, 1.0 + b);
+      CK(hipMemset(out[b], 0, cap * sizeof(double2)));
+    }
+    CK(hipDeviceSynchronize());
+    const size_t payload = (size_t)n * plane;
+    for (int r = 0; r < 100; ++r) k_copy<<<4096, 256>>>(in[r % 2], out[r % 2], payload);
+    auto time_it = [&](auto launch, int reps) {
+      for (int w = 0; w < 2; ++w) launch(w);
+      CK(hipEventRecord(e0));
+      for (int r = 0; r < reps; ++r) launch(r);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      return ms * 1e3 / reps;
+    };
+    double us = time_it([&](int r) { k_copy<<<4096, 256>>>(in[r % 2], out[r % 2], payload); }, 20);
+    printf("%-72s %8.1f us %6.0f GB/s\n", "grid-stride copy 1 read : 1 write, 1.08 GB arrays", us, 32.0 * payload / us * 1e-3);
+    us = time_it([&](int r) { k_copy<<<16384, 256>>>(in[r % 2], out[r % 2], payload); }, 20);
+    printf("%-72s %8.1f us %6.0f GB/s\n", "  ... 16384 workgroups", us, 32.0 * payload / us * 1e-3);
+    us = time_it([&](int r) { k_copy12<<<4096, 256>>>(in[r % 2], out[0], out[1], payload); }, 20);
+    printf("%-72s %8.1f us %6.0f GB/s\n", "copy 1 read : 2 writes (the fused z passes' ratio)", us, 48.0 * payload / us * 1e-3);
+    us = time_it([&](int r) { k_copy21<<<4096, 256>>>(in[0], in[1], out[r % 2], payload); }, 20);
+    printf("%-72s %8.1f us %6.0f GB/s\n", "copy 2 reads : 1 write", us, 48.0 * payload / us * 1e-3);
+    auto run = [&](const char *nm, auto kern, unsigned T, unsigned threads, size_t lds, Args a) {
+      CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      a.ntiles = (unsigned)(((size_t)a.rows * a.tcols + T - 1) / T);
+      for (int work : {0, 4, 12}) {
+        a.work = work;
+        const double t = time_it([&](int r) { a.in = in[r % 2]; a.out = out[r % 2]; hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(threads), lds, 0, a); }, 12);
+        printf("%-60s work %2d  %8.1f us %6.0f GB/s\n", nm, work, t, 32.0 * payload / t * 1e-3);
+      }
+    };
+    for (unsigned pad : {0u, 16u}) {
+      for (int pass = 0; pass < 2; ++pass) {
+        Args a{};
+        a.remap = 1;
+        if (pass == 0) {  // x pass: lines across planes, tiles over the flattened (y, kz) index of a plane
+          const unsigned sn = (unsigned)plane + pad;
+          a.rows = 1; a.cols = (unsigned)plane; a.tcols = (unsigned)plane; a.pitch_in = a.pitch_out = sn; a.sn_in = a.sn_out = sn;
+          printf("== x pass 512 x (512 x 257), plane pitch + %u elements\n", pad);
+        } else {          // y pass: lines along y inside an x plane (stride nzc), tiles over (x, kz)
+          if (pad) continue;
+          a.rows = n; a.cols = nzc; a.tcols = nzc; a.pitch_in = a.pitch_out = (unsigned)plane; a.sn_in = a.sn_out = nzc;
+          printf("== y pass 512 x (512 planes x 257)\n");
+        }
+        run("16 pts/thread,  8 lines (128-B pieces), 256 thr, 2 WG/CU", k_move_g<512, 16, 8, 2>, 8, 256, 64 * 1024, a);
+        run("16 pts/thread,  8 lines (128-B pieces), 256 thr, 4 WG/CU", k_move_g<512, 16, 8, 4>, 8, 256, 32 * 1024, a);
+        run("16 pts/thread, 16 lines (256-B pieces), 512 thr, 1 WG/CU", k_move_g<512, 16, 16, 1>, 16, 512, 128 * 1024, a);
+        run("16 pts/thread, 16 lines (256-B pieces), 512 thr, 2 WG/CU", k_move_g<512, 16, 16, 2>, 16, 512, 64 * 1024, a);
+        run("32 pts/thread, 16 lines (256-B pieces), 256 thr, 2 WG/CU", k_move_g<512, 32, 16, 2>, 16, 256, 64 * 1024, a);
+        run("32 pts/thread, 32 lines (512-B pieces), 512 thr, 1 WG/CU", k_move_g<512, 32, 32, 1>, 32, 512, 128 * 1024, a);
+        run("8 pts/thread,   8 lines (128-B pieces), 512 thr, 2 WG/CU", k_move_g<512, 8, 8, 2>, 8, 512, 64 * 1024, a);
+      }
+    }
   }
   return 0;
 }
