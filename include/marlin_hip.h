@@ -278,7 +278,7 @@ int mrl_kspace_abm(mrl_ctx *ctx, double *d_ubar_out, const double *d_ubar0, cons
                    const double *h_coef, int nterms, const double *d_L, double dt, int64_t n_spec);
 
 /* Coupled k-space update of AdamsBashforthMoultonCoupled::substep (AdamsBashforthMoultonCoupled.C:118-186, corrector
- * :214-270): for nvar <= 4 variables, at every reciprocal grid point
+ * :214-270): for nvar <= 8 variables (the reference solves any N; its inputs couple 2 or 3), at every reciprocal grid point
  *   rhs_i = ubar0_i + sum_t coef[i][t] * N[i][t]          (h_nterms[i] <= 6 terms; d_N / h_coef are the rows concatenated)
  *   solve (I - dt * Lhat) ubar = rhs                       (dense nvar x nvar, LU with partial pivoting, one thread per k)
  * d_L[i*nvar + j] = real array of the linear operator entry the input file names (row i, column j), NULL = zero.
@@ -458,6 +458,14 @@ typedef struct mrl_mech_stats {
 int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *p, const double *d_F, const double *d_K,
                        const double *d_mu, const double *d_applied, double *d_Fnew, double *d_P,
                        mrl_mech_stats *stats);
+/* Small-strain linear-elastic RVE, the wording of BASELINE configs[2] (de Geus's Gamma-operator scheme with a constant tangent).  The
+ * reference itself has only the finite-strain solve above; this is that solve's FIRST linear system taken at F = I, where the second
+ * Piola-Kirchhoff stress vanishes and the tangent of HyperElasticIsotropic.C:42-52 reduces to C4 = K II + 2 mu (I4s - II/3):
+ *   CG (MarlinUtils.h:55-123, l_tol / l_max_its of p) on  G(C4 : d_eps) = -G(C4 : E),   eps = E + d_eps,   sigma = C4 : eps
+ * with the same kernels (tangent at the identity field, Gamma operator, fused CG vectors).  d_E: [dim][dim] device array (the applied
+ * macroscopic strain); d_eps, d_sigma: [grid...][dim][dim].  stats: newton_its = 1, cg_its[0].  Serial and slab contexts. */
+int mrl_mech_small_strain(mrl_ctx *ctx, const mrl_mech_params *p, const double *d_K, const double *d_mu, const double *d_E,
+                          double *d_eps, double *d_sigma, mrl_mech_stats *stats);
 
 /* ComputeDisplacements::computeBuffer (src/tensor_computes/ComputeDisplacements.C:53-107): displacement field of a deformation
  * gradient F [grid..., D, D]:  u = (<F> - I) X + ifft( fft(F - <F>) . (-i q) / |q|^2 )  (zero at q = 0), linearly interpolated

@@ -129,6 +129,7 @@ SIGNATURES = {
     "mrl_relayout": (_i32, [_vp, _i32, _vp, _vp, _i64, C.c_int32]),
     "mrl_axpby": (_i32, [_vp, _dbl, _vp, _dbl, _vp, _vp, _i64]),
     "mrl_mech_newton_cg": (_i32, [_vp, C.POINTER(MrlMechParams), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(MrlMechStats)]),
+    "mrl_mech_small_strain": (_i32, [_vp, C.POINTER(MrlMechParams), _vp, _vp, _vp, _vp, _vp, C.POINTER(MrlMechStats)]),
     "mrl_parsed_create": (_i32, [_vp, C.POINTER(_vp), C.c_char_p, _i32, C.POINTER(C.c_char_p), C.POINTER(_i32), _i32,
                                  C.POINTER(C.c_char_p), C.POINTER(_dbl), _i32, C.POINTER(C.c_char_p), _i32, _i32]),
     "mrl_parsed_destroy": (None, [_vp]),

@@ -494,6 +494,18 @@ class Context:
                  "cg_its_total": st.cg_its_total, "anorm": st.last_anorm, "rnorm": st.last_rnorm, "Fn": st.Fn}
         return Fnew, P, stats
 
+    def mech_small_strain(self, K, mu, E, l_tol=1e-2, l_max_its=0):
+        """small-strain linear-elastic RVE (mrl_mech_small_strain): returns (eps, sigma, stats dict); E = [dim, dim] device tensor"""
+        prm = MrlMechParams()
+        prm.l_tol, prm.l_max_its = l_tol, l_max_its
+        prm.nl_rel_tol, prm.nl_abs_tol, prm.nl_max_its = 0.0, 0.0, 1
+        shape = list(K.shape) + [self.dim, self.dim]
+        eps = torch.empty(shape, dtype=torch.float64, device=K.device)
+        sigma = torch.empty_like(eps)
+        st = MrlMechStats()
+        self._check(self.lib.mrl_mech_small_strain(self.h, C.byref(prm), _ptr(K), _ptr(mu), _ptr(E), _ptr(eps), _ptr(sigma), C.byref(st)))
+        return eps, sigma, {"cg_its": st.cg_its[0], "anorm": st.last_anorm, "Fn": st.Fn}
+
     # ---- reductions (synchronous)
     def _scalar(self, fn, *args):
         out = C.c_double()

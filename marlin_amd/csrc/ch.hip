@@ -132,13 +132,14 @@ __global__ void __launch_bounds__(256) k_kspace_abm(AbmArgs a, double2 *__restri
 // matrix it hands to the solver is A[a][b] = delta_ab - dt * L_ba (the transpose of the operator table of the input file),
 // and it casts the complex right-hand side to the real dtype of L (:183), i.e. only Re(rhs) enters the solve; both are
 // reproduced unless the corresponding flag asks for the operator as written / the full complex solve.
+constexpr int kCoupledMax = 8;  // variables of one coupled solve (the reference: any N; none of its inputs has more than 3)
 struct CoupledArgs {
-  int nterms[4];
-  double coef[4][6];
-  const double *N[4][6];
-  const double *u0[4];
-  const double *L[16];
-  double *out[4];
+  int nterms[kCoupledMax];
+  double coef[kCoupledMax][6];
+  const double *N[kCoupledMax][6];
+  const double *u0[kCoupledMax];
+  const double *L[kCoupledMax * kCoupledMax];
+  double *out[kCoupledMax];
   double dt;
   int flags;
 };
@@ -419,8 +420,8 @@ int mrl_kspace_coupled(mrl_ctx *ctx, int nvar, double *const *d_ubar_out, const 
                        const double *const *d_N, const double *h_coef, const int *h_nterms, const double *const *d_L,
                        double dt, int flags, int64_t n_spec) {
   if (!ctx) return MRL_ERR_INVALID;
-  if (nvar < 1 || nvar > 4 || !d_ubar_out || !d_ubar0 || !d_L || !h_nterms || n_spec < 0)
-    return set_error(ctx, MRL_ERR_INVALID, "mrl_kspace_coupled: bad argument (1 <= nvar <= 4)");
+  if (nvar < 1 || nvar > kCoupledMax || !d_ubar_out || !d_ubar0 || !d_L || !h_nterms || n_spec < 0)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_kspace_coupled: bad argument (1 <= nvar <= %d)", kCoupledMax);
   if (n_spec == 0) return MRL_OK;
   CoupledArgs a{};
   a.dt = dt;
@@ -444,7 +445,11 @@ int mrl_kspace_coupled(mrl_ctx *ctx, int nvar, double *const *d_ubar_out, const 
     case 1: hipLaunchKernelGGL(k_kspace_coupled<1>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
     case 2: hipLaunchKernelGGL(k_kspace_coupled<2>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
     case 3: hipLaunchKernelGGL(k_kspace_coupled<3>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
-    default: hipLaunchKernelGGL(k_kspace_coupled<4>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
+    case 4: hipLaunchKernelGGL(k_kspace_coupled<4>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
+    case 5: hipLaunchKernelGGL(k_kspace_coupled<5>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
+    case 6: hipLaunchKernelGGL(k_kspace_coupled<6>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
+    case 7: hipLaunchKernelGGL(k_kspace_coupled<7>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
+    default: hipLaunchKernelGGL(k_kspace_coupled<8>, grid, block, 0, ctx->stream, a, (long long)n_spec); break;
   }
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;

@@ -589,10 +589,21 @@ int mrl_mech_tangent_dir_fm(mrl_ctx *ctx, const double *d_F, const double *d_K, 
   return tangent_dir_launch(ctx, d_F, d_K, d_mu, d_p, d_r, S, 0, 1, d_out, true);
 }
 
-int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d_F, const double *d_K,
-                       const double *d_mu, const double *d_applied, double *d_Fnew, double *d_P,
-                       mrl_mech_stats *stats) {
-  if (!ctx) return MRL_ERR_INVALID;
+}  // extern "C"
+
+// value-major identity field [npts][dim][dim]
+__global__ void k_fill_identity(double *out, long long n, int dim) {
+  const int dd = dim * dim;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % dd);
+    out[e] = (c / dim == c % dim) ? 1.0 : 0.0;
+  }
+}
+
+// FFTMechanics::computeBuffer.  small: stop after the first linear solve and report sigma = C4 : (F - I) = K_dF(I; F - I) instead of
+// P(F) (mrl_mech_small_strain; the caller passes the identity field as d_F)
+static int newton_cg_impl(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d_F, const double *d_K, const double *d_mu,
+                          const double *d_applied, double *d_Fnew, double *d_P, mrl_mech_stats *stats, bool small) {
   // slab contexts: the same solve on the rank's y-slab, the Gamma operator over the library-owned exchanges and every norm / dot
   // product summed over the ranks on the device (the reference's norms are serial-only, DomainAction.C:1564-1567)
   const bool dist = ctx->slab;
@@ -739,6 +750,15 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
 
     // _u = _u + dFm ; constitutive ; b = -G(P)                              FFTMechanics.C:137-143
     hipLaunchKernelGGL(k_add, dim3(nb), dim3(256), 0, ctx->stream, Fwork, x, n, 0LL, 0LL);
+    if (small) {  // linear problem: eps = F - I is the solution, sigma = C4 : eps (the tangent at F = I applied to eps)
+      MRL_TRY(mrl_axpby(ctx, 1.0, Fwork, -1.0, lin, tmp, n));
+      MRL_TRY(tangent_launch(ctx, lin, d_K, d_mu, tmp, false, Pwork, soa));
+      MRL_TRY(reduce_async(ctx, 2, x, x, n, S + 3));
+      MRL_TRY(global(S + 3, h));
+      st.last_anorm = sqrt(h[0]);
+      st.last_rnorm = Fn > 0.0 ? st.last_anorm / Fn : 0.0;
+      break;
+    }
     lin = Fwork;
     MRL_TRY(stress_launch(ctx, Fwork, d_K, d_mu, Pwork, soa));
     MRL_TRY(gamma(Pwork, b, -1.0));
@@ -766,6 +786,30 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
   }
   if (stats) *stats = st;
   return MRL_OK;
+}
+
+extern "C" {
+
+int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d_F, const double *d_K,
+                       const double *d_mu, const double *d_applied, double *d_Fnew, double *d_P,
+                       mrl_mech_stats *stats) {
+  if (!ctx) return MRL_ERR_INVALID;
+  return newton_cg_impl(ctx, prm, d_F, d_K, d_mu, d_applied, d_Fnew, d_P, stats, false);
+}
+
+int mrl_mech_small_strain(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d_K, const double *d_mu, const double *d_E,
+                          double *d_eps, double *d_sigma, mrl_mech_stats *stats) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!prm || !d_K || !d_mu || !d_E || !d_eps || !d_sigma) return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_small_strain: null argument");
+  MRL_TRY(check_dim(ctx, "mrl_mech_small_strain", !ctx->slab));
+  const long long n = real_count_local(ctx) * ctx->dim * ctx->dim;
+  MRL_TRY(ensure_work(ctx, 23, sizeof(double) * (size_t)(n + 2)));
+  double *ident = ctx->d_work[23];
+  hipLaunchKernelGGL(k_fill_identity, dim3(grid_for(n)), dim3(256), 0, ctx->stream, ident, n, ctx->dim);
+  MRL_HIP(ctx, hipGetLastError());
+  // d_eps receives I + eps first (the impl's Fnew), then eps
+  MRL_TRY(newton_cg_impl(ctx, prm, ident, d_K, d_mu, d_E, d_eps, d_sigma, stats, true));
+  return mrl_axpby(ctx, 1.0, d_eps, -1.0, ident, d_eps, n);
 }
 
 }  // extern "C"

@@ -1142,8 +1142,8 @@ public:
       _flags(flags)
   {
     const std::size_t N = _variables.size();
-    if (N > 4)
-      paramError("buffer", "at most 4 coupled variables");
+    if (N > 8)
+      paramError("buffer", "at most 8 coupled variables");
     _L.assign(N * N, nullptr);
     for (std::size_t i = 0; i < N; ++i)
       _L[i * N + i] = _variables[i]._linear_reciprocal;

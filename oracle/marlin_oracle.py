@@ -515,6 +515,29 @@ class FFTMechanicsOracle:
         return u, stats
 
 
+def small_strain_linear_elastic(dom: Domain, K, mu, E: torch.Tensor, l_tol: float, l_max_its: Optional[int] = None, closed_form: bool = False):
+    """The 'small-strain linear-elastic RVE, Gamma-operator fixed point' of BASELINE configs[2].  PARITY UNPINNED: the reference has no
+    small-strain solve (only FFTMechanics.C:96-163, finite strain); this is that routine's first linear system at F = I -- where
+    HyperElasticIsotropic.C:42-52 gives S = 0 and K4 = C4 = K II + 2 mu (I4s - II/3) -- with sigma = C4 : eps in place of P(F):
+    b = -G(C4 : E) (FFTMechanics.C:116-117), conjugateGradientSolve (MarlinUtils.h:55-123), eps = E + d_eps.
+    Returns (eps, sigma, cg iterations).  closed_form: apply G through gamma_closed_form (sizes where Ghat4 does not fit)."""
+    dim = dom.dim
+    r2 = dom.value_shape([dim, dim])
+    ident = torch.eye(dim, dtype=F64).expand(r2).contiguous()
+    _, K4 = hyper_elastic_isotropic(dom, MechIdentities(dim), ident, K, mu)
+    if closed_form:
+        G = lambda A2: gamma_closed_form(dom, A2.reshape(r2)).reshape(-1)
+    else:
+        Gh = ghat4(dom)
+        G = lambda A2: dom.ifft_batched(ddot42(Gh, dom.fft_batched(A2.reshape(r2)))).reshape(-1)
+    K_d = lambda v: trans2(ddot42(K4, trans2(v.reshape(r2))))
+    n_max = l_max_its if l_max_its is not None else int(torch.tensor(dom.shape).prod().item())
+    b = -G(K_d(E.expand(r2)))
+    x, its, _ = conjugate_gradient_solve(lambda v: G(K_d(v)), b, torch.zeros_like(b), l_tol, n_max)
+    eps = E.expand(r2) + x.reshape(r2)
+    return eps, K_d(eps), its
+
+
 # batched transforms: trailing value dims are batch (SURVEY A.2; DomainAction.C:859-863 applies
 # rfftn over the leading `dim` axes of a [..., 3, 3] tensor)
 def _fft_batched(self: Domain, t):

@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle runs on libTorch's CPU kernels: keep its thread pool within the CPU share this process really has (a GPU box hands out
+    # 16 cores of a much larger host; the default pool of one thread per host core spends its time in contention)
+    import torch
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
 
 
 def load_golden(name):

@@ -38,7 +38,7 @@ def _oracle(dom, u0, N, coef, L, dt, real_rhs, transposed):
     return s.solve(rhs, dt)
 
 
-@pytest.mark.parametrize("nv,shape", [(1, (24,)), (2, (20, 18)), (3, (12, 10, 9)), (4, (16, 15))])
+@pytest.mark.parametrize("nv,shape", [(1, (24,)), (2, (20, 18)), (3, (12, 10, 9)), (4, (16, 15)), (6, (10, 9)), (8, (12, 7))])
 @pytest.mark.parametrize("flags", [0, 1, 2, 3])
 def test_kspace_coupled_matches_linalg_solve(nv, shape, flags):
     dom, ctx, u0, N, coef, L = _problem(nv, shape, 11 * nv + flags)
@@ -77,4 +77,4 @@ def test_kspace_coupled_rejects_bad_arguments():
     ctx = Context(1, [16], [1.0])
     t = torch.zeros(9, dtype=torch.complex128, device="cuda")
     with pytest.raises(MarlinHipError):
-        ctx.kspace_coupled([t] * 5, [t] * 5, [[]] * 5, [[]] * 5, [[None] * 5] * 5, 1.0)
+        ctx.kspace_coupled([t] * 9, [t] * 9, [[]] * 9, [[]] * 9, [[None] * 9] * 9, 1.0)

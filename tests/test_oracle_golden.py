@@ -360,3 +360,24 @@ def test_complex_over_real_division_is_a_reciprocal_multiply():
     assert torch.equal(torch.view_as_real(ref), torch.view_as_real(recip))
     assert torch.equal(torch.view_as_real(inplace), torch.view_as_real(recip))
     assert not torch.equal(torch.view_as_real(ref), torch.view_as_real(true_div))
+
+
+def test_small_strain_restatement_properties():
+    """oracle/marlin_oracle.py::small_strain_linear_elastic (parity unpinned: no reference counterpart) -- the properties the solution of
+    the Lippmann-Schwinger problem must have: mean strain = applied strain, sigma symmetric and in equilibrium (G(sigma) = 0 to the CG
+    tolerance), homogeneous material -> eps = E exactly and zero iterations of correction; closed-form G == stored Ghat4"""
+    dom, phase, K, mu = _mech_setup(3, 8)
+    E = torch.tensor([[0.0, 0.01, 0.0], [0.01, 0.0, 0.0], [0.0, 0.0, 0.002]], dtype=torch.float64)
+    eps, sig, its = mo.small_strain_linear_elastic(dom, K, mu, E, 1e-10)
+    eps2, sig2, its2 = mo.small_strain_linear_elastic(dom, K, mu, E, 1e-10, closed_form=True)
+    assert its == its2 and its > 0
+    assert (eps - eps2).abs().max().item() <= 1e-13 and (sig - sig2).abs().max().item() <= 1e-12
+    assert (eps.mean(dim=(0, 1, 2)) - E).abs().max().item() <= 1e-15
+    assert (sig - sig.transpose(-1, -2)).abs().max().item() <= 1e-13
+    div = mo.gamma_closed_form(dom, sig)
+    assert div.abs().max().item() <= 1e-8 * sig.abs().max().item()
+    Kh, muh = torch.full_like(K, 2.0), torch.full_like(mu, 0.7)
+    eps_h, sig_h, its_h = mo.small_strain_linear_elastic(dom, Kh, muh, E, 1e-10)
+    assert (eps_h - E).abs().max().item() <= 1e-15
+    want = 2.0 * E.trace() * torch.eye(3, dtype=torch.float64) + 2 * 0.7 * (0.5 * (E + E.T) - E.trace() / 3 * torch.eye(3, dtype=torch.float64))
+    assert (sig_h - want).abs().max().item() <= 1e-14
