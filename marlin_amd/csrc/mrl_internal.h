@@ -129,6 +129,9 @@ struct mrl_ctx {
   mrl_comm *comm = nullptr;
   struct mrl::SlabPipes *pipes = nullptr;
   char **d_tabs = nullptr;  // 8 device pointer tables of 64 entries for the staged entry points (caller-owned send buffers)
+  const void *tab_base[8] = {};          // what each table was last filled from: the same buffer and offsets need no new fill
+  unsigned long long tab_off[8][64] = {};
+  bool tab_valid[8] = {};
   std::vector<mrl::SlabTabs> slab_tabs;
 
   mutable std::string err;
