@@ -810,7 +810,8 @@ def main():
             out["mechanics"] = {"workload": f"de Geus finite-strain RVE {args.mech_grid}^3, Newton-CG (l_tol 1e-2)",
                                 "ms_per_cg_iteration": m["ms_per_cg_iteration"], "cg_iterations_per_substep": m["cg_its"],
                                 "algorithmic_bytes_per_point_per_cg_iteration": m["algorithmic_bytes_per_point_per_cg_iteration"],
-                                "achieved_GBps": m["achieved_GBps"], "frac_of_hbm_peak": m["achieved_GBps"] / HBM_PEAK_GBPS}
+                                "achieved_GBps": m["achieved_GBps"], "frac_of_hbm_peak": m["achieved_GBps"] / HBM_PEAK_GBPS,
+                                "small_strain_linear_elastic": m.get("small_strain_linear_elastic")}
     finish(out, rank, slab, dist, comm, [prof_ctx])
 
 
@@ -885,6 +886,23 @@ def bench_mech(args, api, world, rank, dev, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tot_t = float(t.item())
     npts = nx * ny * nz
+    # the wording of BASELINE configs[2] ("small-strain linear-elastic RVE, Gamma-operator fixed point"): the same kernels with the
+    # constant tangent (mrl_mech_small_strain: one CG solve), reported beside the finite-strain number, never in its place
+    small = None
+    if not slab:
+        E = torch.zeros(3, 3, dtype=torch.float64)
+        E[0, 1] = E[1, 0] = 0.005
+        E = E.cuda()
+        ctx.mech_small_strain(K, mu, E, l_tol=1e-6)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, _, sst = ctx.mech_small_strain(K, mu, E, l_tol=1e-6)
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        small = {"cg_iterations": sst["cg_its"], "l_tol": 1e-6, "ms_per_cg_iteration": dt_s / max(sst["cg_its"], 1) * 1e3,
+                 "value": npts * sst["cg_its"] / dt_s,
+                 "note": "mrl_mech_small_strain: C4 = K II + 2 mu (I4s - II/3), the finite-strain solve's first linear system at F = I; "
+                         "parity vs the oracle's restatement in tests/test_mech_gpu.py (the reference has no small-strain solve)"}
     out = None
     if rank == 0:
         bpi = mech_bytes_per_point(nz)
@@ -901,6 +919,8 @@ def bench_mech(args, api, world, rank, dev, dist):
                "model_GBps_per_gpu": bpi * npts * tot_its / tot_t / 1e9 / world,
                "model_frac_of_hbm_peak": bpi * npts * tot_its / tot_t / 1e9 / world / HBM_PEAK_GBPS,
                "model_frac_of_copy_ceiling": bpi * npts * tot_its / tot_t / 1e9 / world / HBM_COPY_GBPS}
+        if small is not None:
+            out["variants"] = {"small_strain_linear_elastic": small}
     finish(out, rank, slab, dist, comm, [ctx])
 
 

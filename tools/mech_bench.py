@@ -49,6 +49,19 @@ def run(n=128, substeps=2, profile=True, slab=False, exp=0):
         if 1 <= it <= substeps:
             res.append((dt, st["cg_its_total"], st["newton_its"]))
     prof = [k for k in ctx.get_profile() if k["launches"]]
+    ctx.set_profiling(False)
+    # the small-strain linear-elastic form of the same RVE (mrl_mech_small_strain: constant tangent, one CG solve), serial contexts
+    small = None
+    if not slab:
+        E = torch.zeros(3, 3, dtype=torch.float64)
+        E[0, 1] = E[1, 0] = 0.005
+        E = E.cuda()
+        ctx.mech_small_strain(K, mu, E, l_tol=1e-6)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, _, sst = ctx.mech_small_strain(K, mu, E, l_tol=1e-6)
+        torch.cuda.synchronize()
+        small = {"l_tol": 1e-6, "cg_iterations": sst["cg_its"], "ms_per_cg_iteration": (time.perf_counter() - t0) / max(sst["cg_its"], 1) * 1e3}
     tot_its = sum(r[1] for r in res)
     tot_t = sum(r[0] for r in res)
     npts = n ** 3
@@ -58,7 +71,7 @@ def run(n=128, substeps=2, profile=True, slab=False, exp=0):
     out = {"n": n, "substeps": substeps, "slab_one_rank": slab, "exp": exp, "newton_its": [r[2] for r in res], "cg_its": [r[1] for r in res],
            "ms_per_cg_iteration": tot_t / max(tot_its, 1) * 1e3,
            "algorithmic_bytes_per_point_per_cg_iteration": bpi,
-           "achieved_GBps": bpi * npts * tot_its / tot_t / 1e9,
+           "achieved_GBps": bpi * npts * tot_its / tot_t / 1e9, "small_strain_linear_elastic": small,
            "kernels": sorted([{"kernel": k["kernel"], "total_ms": round(k["ms"], 3), "launches": k["launches"],
                                "avg_ms": round(k["ms"] / k["launches"], 4),
                                "GBps": round(k["bytes_per_launch"] / (k["ms"] / k["launches"]) / 1e6, 1)} for k in prof],
