@@ -17,16 +17,21 @@
 // path then shows up as a count of differing elements, not as wrong physics.
 // Rank 0 prints ONE JSON line; bench.py wraps it (adds nothing that was not measured here).
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -341,6 +346,7 @@ static int run_ch(Rank & R)
     };
     std::vector<Res> results;
     std::map<int, std::string> unavailable;
+    std::set<std::pair<int, long>> failed_variants;
     const double t_tune0 = now_s();
     mrl_comm_set_timeout(R.comm, 20.0);
     const bool verify = argi("verify", 1) != 0;
@@ -350,8 +356,8 @@ static int run_ch(Rank & R)
       double over = (R.rank == 0 && now_s() - t_tune0 > tune_budget && !results.empty()) ? 1.0 : 0.0;
       if (R.reduce(over, 2) != 0.0)
         break;
-      if (unavailable.count(c.transport))
-        continue;
+      if (unavailable.count(c.transport) || failed_variants.count({c.transport, c.exp}))
+        continue;  // (a variant that failed once is not tried again with another sub-block count: each failure costs a time-out)
       if (mrl_comm_transport(R.comm) != c.transport && mrl_comm_set_transport(R.comm, c.transport) != MRL_OK)
       {  // (collective verdict: every rank lands here)
         unavailable[c.transport] = mrl_comm_last_error(R.comm);
@@ -395,6 +401,7 @@ static int run_ch(Rank & R)
         if (r.ok)
           r.why = "failed on another rank";
         r.ok = false;
+        failed_variants.insert({c.transport, c.exp});
         // tear the pipeline down on every rank, clear the condition, start over with fresh exchange buffers
         (void)hipDeviceSynchronize();
         mrl_ctx_destroy(R.ctx);
@@ -821,13 +828,45 @@ static int launch_ranks(int argc, char ** argv, int nranks)
     }
     kids.push_back(pid);
   }
+  // reap in any order; once a rank has failed the others can only run into their communicator time-outs (120 s): give them a grace
+  // period, then end exactly the processes started here (by pid) so that the caller's fallback starts without that wait
+  const double grace_s = (double)argi("launch_grace_s", 20);
   int rc = 0;
-  for (const pid_t k : kids)
+  double first_fail = -1.0;
+  bool killed = false;
+  std::vector<pid_t> left = kids;
+  while (!left.empty())
   {
     int st = 0;
-    if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0)
+    const pid_t p = waitpid(-1, &st, WNOHANG);
+    if (p > 0)
+    {
+      const auto it = std::find(left.begin(), left.end(), p);
+      if (it == left.end())
+        continue;
+      left.erase(it);
+      if (!WIFEXITED(st) || WEXITSTATUS(st) != 0)
+      {
+        rc = 1;
+        if (first_fail < 0)
+          first_fail = now_s();
+      }
+      continue;
+    }
+    if (p < 0 && errno != EINTR)
+    {
       rc = 1;
+      break;
+    }
+    if (first_fail >= 0 && !killed && now_s() - first_fail > grace_s)
+    {
+      for (const pid_t k : left)
+        kill(k, SIGKILL);
+      killed = true;
+    }
+    usleep(20000);
   }
+  shm_unlink(("/mrlbench_" + std::to_string((long)getpid())).c_str());  // (left behind only if the ranks died before the bootstrap)
   return rc;
 }
 
@@ -870,6 +909,8 @@ int main(int argc, char ** argv)
     if (mrl_comm_create(&R.comm, arg("job", "mrlbench").c_str(), R.world, R.rank, R.device, want) != MRL_OK)
       die(R.rank, std::string("mrl_comm_create: ") + mrl_comm_last_error(nullptr));
     mrl_comm_set_timeout(R.comm, 120.0);
+    if (g_args.count("test_die_rank") && argi("test_die_rank", -1) == R.rank)
+      _exit(3);  // (test hook: a rank lost after the bootstrap -- the launcher must not wait for the survivors' time-outs)
   }
   const std::string workload = arg("workload", "ch");
   int rc = 2;

@@ -67,3 +67,17 @@ def test_bench_mech_two_ranks_without_a_launcher():
     assert j["exchange"]["ranks"] == 2 and j["exchange"]["bytes_sent_to_peers_per_step_rank0"] > 0
     ran = [c for c in j["exchange"]["transport"]["tuned"] if "ms_per_cg_iteration" in c]
     assert ran and max(c["norm_F"] for c in ran) - min(c["norm_F"] for c in ran) <= 1e-9 * ran[0]["norm_F"]
+
+
+def test_native_launcher_does_not_wait_for_the_survivors_of_a_lost_rank():
+    """a rank that dies after the bootstrap leaves its peers in a collective (communicator time-out: 120 s): the launcher reaps in any
+    order, gives the others a grace period, then ends exactly the processes it started and returns non-zero -- bench.py's fallback
+    chain starts seconds later, not minutes"""
+    import time
+    exe = os.path.join(ROOT, "marlin_amd", "lib", "marlin-hip-bench")
+    t0 = time.perf_counter()
+    r = subprocess.run([exe, "workload=ch", "gpus=2", "device=0", "grid=64", "steps=2", "warmup=1", "test_die_rank=1", "launch_grace_s=3"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1, (r.returncode, r.stderr[-2000:])
+    assert time.perf_counter() - t0 < 60.0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
