@@ -148,16 +148,13 @@ template <int N, int ORDER, bool SPEC_C>
 static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
   constexpr int TPL = Plan<N>::TPL;
   const bool big = yfused_needs_big(a, ctx->nranks);
-  if constexpr ((TPL & (TPL - 1)) == 0) {  // (ny/P is a power of two: a multiple of TPL iff TPL is one and not larger)
-    if ((1 << a.nyl_shift) % TPL == 0) {
-      if constexpr (ybig_capable<N>()) {
-        if (big) return launch_yfused_v<N, ORDER, SPEC_C, true, true>(ctx, a);
-      }
-      if (!big) return launch_yfused_v<N, ORDER, SPEC_C, true>(ctx, a);
-    }
+  if ((1 << a.nyl_shift) % TPL)  // (slab_fast_shift sends such partitions to the table-addressed kernel)
+    return set_error(ctx, MRL_ERR_UNSUPPORTED, "slab y pass: %d rows per chunk are not a multiple of the %d threads of a line", 1 << a.nyl_shift, TPL);
+  if constexpr (ybig_capable<N>()) {
+    if (big) return launch_yfused_v<N, ORDER, SPEC_C, true, true>(ctx, a);
   }
-  if (big) return set_error(ctx, MRL_ERR_UNSUPPORTED, "slab y pass: arrays of 4 GiB and more need ny in {512, 1024, 2048} and ny/P a multiple of %d", TPL);
-  return launch_yfused_v<N, ORDER, SPEC_C, false>(ctx, a);
+  if (big) return set_error(ctx, MRL_ERR_UNSUPPORTED, "slab y pass: arrays of 4 GiB and more need ny in {512, 1024, 2048}");
+  return launch_yfused_v<N, ORDER, SPEC_C, true>(ctx, a);
 }
 
 
@@ -217,6 +214,12 @@ static int launch_yfused_t(mrl_ctx *ctx, YFusedArgs a, const YTabs &t) {
 
 }  // namespace p2
 
+// threads per line of the plan of a fused-capable length
+static int plan_tpl(long long n) {
+  MRL_SWITCH_N(n, return p2::Plan<NN>::TPL);
+  return 0;
+}
+
 int slab_fast_shift(const mrl_ctx *ctx) {
   if (!(ctx->dim == 3 && ctx->slab && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
         pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2])))
@@ -227,6 +230,9 @@ int slab_fast_shift(const mrl_ctx *ctx) {
   if (nyl * ctx->nranks != ctx->n[1] || nxl * ctx->nranks != ctx->n[0] || (nyl & (nyl - 1)) || (nxl & (nxl - 1))) return 0;
   for (int p = 0; p < ctx->nranks; ++p)
     if (ctx->part_real[p] != nyl || ctx->part_recip[p] != nxl) return 0;
+  // the y kernels want the rows of a chunk to be a multiple of the threads that share a line (chunk index and row offset of an element
+  // then split into a wave-uniform and a per-thread part); chunks of fewer rows take the table-addressed kernels
+  if (nyl % plan_tpl(ctx->n[1])) return 0;
   // the x passes index with 32-bit ELEMENT offsets inside a two-field exchange buffer: arrays below 32 GiB
   const double count = (double)ctx->n[0] * ((double)ctx->nloc[1] * (double)(ctx->nrec[2] + 8) + 32.0);
   if (2.0 * count >= 4294967296.0) return 0;

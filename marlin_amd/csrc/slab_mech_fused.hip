@@ -165,17 +165,15 @@ static int launch_gamma_yfused(mrl_ctx *ctx, GammaYArgs a) {
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
   if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY((set_lds_attr(ctx, k_gamma_yfused<N, true>, lds)));
-    MRL_TRY((set_lds_attr(ctx, k_gamma_yfused<N, false>, lds)));
     attr.store(true, std::memory_order_release);
   }
   constexpr int T = Plan<N>::T;
   a.rowblk = (unsigned)(((long long)a.nxl * a.nzc + T - 1) / T);
   const long long nb = (long long)(a.nf / 3) * a.rowblk;
   a.sig.expected = (unsigned)nb;
-  if ((1 << a.nyl_shift) % Plan<N>::TPL == 0)
-    hipLaunchKernelGGL((k_gamma_yfused<N, true>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[1].d_tw);
-  else
-    hipLaunchKernelGGL((k_gamma_yfused<N, false>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[1].d_tw);
+  if ((1 << a.nyl_shift) % Plan<N>::TPL)  // (slab_fast_shift sends such partitions to k_gamma_yfused_t)
+    return set_error(ctx, MRL_ERR_UNSUPPORTED, "slab Gamma y pass: %d rows per chunk are not a multiple of the %d threads of a line", 1 << a.nyl_shift, Plan<N>::TPL);
+  hipLaunchKernelGGL((k_gamma_yfused<N, true>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, ctx->ax[1].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
@@ -341,10 +339,19 @@ static int row_work(mrl_ctx *ctx, int slot, cplx **w) {
   return MRL_OK;
 }
 
+// the staged entry points (caller-owned exchange: chunks of one size at a uniform stride in the caller's buffers): the shift-addressed
+// pipeline, or the table-addressed one on EQUAL partitions (e.g. fewer rows per chunk than the threads of a line)
+static bool staged_ok(const mrl_ctx *ctx) {
+  if (slab_mech_fast_ok(ctx)) return ctx->nloc[1] % 2 == 0;
+  if (!slab_mech_table_ok(ctx)) return false;
+  for (int p = 0; p < ctx->nranks; ++p)
+    if (ctx->part_real[p] != ctx->part_real[0] || ctx->part_recip[p] != ctx->part_recip[0]) return false;
+  return true;
+}
+
 static int check_fast(mrl_ctx *ctx, const char *what, int row) {
-  if (!slab_mech_fast_ok(ctx))
-    return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: needs a 3-D slab context with planned extents and equal power-of-two partitions", what);
-  if (ctx->nloc[1] % 2) return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: needs an even number of local y planes", what);
+  if (!staged_ok(ctx))
+    return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: needs a 3-D slab context with planned extents, equal partitions and an even number of local z lines", what);
   if (row < 0 || row > 2) return set_error(ctx, MRL_ERR_INVALID, "%s: row %d out of range", what, row);
   return MRL_OK;
 }
@@ -596,7 +603,7 @@ using namespace mrl;
 
 extern "C" {
 
-int mrl_slab_fast_path(const mrl_ctx *ctx) { return ctx && slab_mech_fast_ok(ctx) && ctx->nloc[1] % 2 == 0 ? 1 : 0; }
+int mrl_slab_fast_path(const mrl_ctx *ctx) { return ctx && ctx->slab && ctx->dim == 3 && staged_ok(ctx) ? 1 : 0; }
 
 int mrl_slab_gamma_counts(const mrl_ctx *ctx, int forward, int64_t *h_send_counts, int64_t *h_recv_counts) {
   if (!ctx) return MRL_ERR_INVALID;

@@ -193,7 +193,7 @@ def _gamma_rank(r, P, comm, A, fast):
 def test_slab_gamma_fused_rows(P):
     """the fused row pipeline (z+x passes -> exchange -> y pass with the projection in place -> exchange -> x+z passes) ==
     the oracle's closed-form Gamma operator on the global field == the per-component generic stages.  P = 32: two y planes per
-    rank, fewer than the four threads of a line -- the y pass without wave-uniform chunk offsets (k_gamma_yfused<64, false>)"""
+    rank, fewer than the four threads of a line -- the table-addressed y pass (k_gamma_yfused_t) behind the same staged entry points"""
     from oracle import marlin_oracle as mo
     torch.manual_seed(21)
     A = torch.rand(_FAST_SHAPE + [3, 3], dtype=torch.float64) - 0.5
