@@ -60,7 +60,7 @@ struct SlabTabs {
   int nf = 0;               // 0: Cahn-Hilliard layouts (padded x planes; yA2 / yA1 = two / one field per forward chunk);
                             // 3 / 9: Gamma-operator layouts (dense planes, nf fields per chunk in both directions; yA2 only)
   unsigned *d = nullptr;    // one allocation holding all tables
-  const unsigned *xch = nullptr, *xoff = nullptr, *fsz = nullptr, *cofi = nullptr;                            // x passes
+  const unsigned *xch = nullptr, *xoff = nullptr, *fsz = nullptr, *cofi = nullptr, *xin = nullptr, *xfs = nullptr;  // x passes
   const unsigned *ych = nullptr, *yD = nullptr, *yB = nullptr, *yC = nullptr, *yA2 = nullptr, *yA1 = nullptr;  // fused y pass
 };
 

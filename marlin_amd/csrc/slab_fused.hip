@@ -327,9 +327,9 @@ int slab_tabs_get(mrl_ctx *ctx, long long kp, int nf, const SlabTabs **out) {
     }
   const int P = ctx->nranks;
   const long long nx = ctx->n[0], ny = ctx->n[1], nxl = ctx->nrec[0], nyl = ctx->nloc[1];
-  std::vector<unsigned> h((size_t)(2 * nx + 2 * P + 6 * ny));
+  std::vector<unsigned> h((size_t)(4 * nx + 2 * P + 6 * ny));
   unsigned *xch = h.data(), *xoff = xch + nx, *fsz = xoff + nx, *cofi = fsz + P, *ych = cofi + P, *yD = ych + ny, *yB = yD + ny,
-           *yC = yB + ny, *yA2 = yC + ny, *yA1 = yA2 + ny;
+           *yC = yB + ny, *yA2 = yC + ny, *yA1 = yA2 + ny, *xin = yA1 + ny, *xfs = xin + nx;
   // x-plane pitch of a chunk with `rows` y rows, fields per chunk (forward / inverse)
   auto plane = [&](long long rows) { return nf ? rows * kp : slab_xplane_of(ctx, rows, kp); };
   const long long nff = nf ? nf : 2, nfi = nf ? nf : 1;
@@ -362,6 +362,10 @@ int slab_tabs_get(mrl_ctx *ctx, long long kp, int nf, const SlabTabs **out) {
     yb += ctx->part_real[p];
   }
   if (xb != nx || yb != ny) return set_error(ctx, MRL_ERR_INVALID, "slab tables: the partitions do not cover the grid");
+  for (long long n = 0; n < nx; ++n) {  // inverse x pass: ONE look-up between the plane index and the address (not chunk -> offset -> address)
+    xin[n] = cofi[xch[n]] + xoff[n];
+    xfs[n] = fsz[xch[n]];
+  }
   if (16.0 * (double)off2 >= 4294967296.0 || 16.0 * (double)off >= 4294967296.0)
     return set_error(ctx, MRL_ERR_UNSUPPORTED, "slab tables: exchange buffers of 4 GiB and more");
   SlabTabs t;
@@ -380,6 +384,8 @@ int slab_tabs_get(mrl_ctx *ctx, long long kp, int nf, const SlabTabs **out) {
   t.yC = t.yB + ny;
   t.yA2 = t.yC + ny;
   t.yA1 = t.yA2 + ny;
+  t.xin = t.yA1 + ny;
+  t.xfs = t.xin + nx;
   ctx->slab_tabs.push_back(t);
   *out = &ctx->slab_tabs.back();
   return MRL_OK;
@@ -449,7 +455,7 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const 
     a.pitch_in = (unsigned)nzc;
     a.pitch_out = (unsigned)kp;
     a.sn_in = (unsigned)wp;
-    const p2::SubPassTabs t{tb->xch, tb->xoff, tb->fsz, tb->cofi};
+    const p2::SubPassTabs t{tb->xch, tb->xoff, tb->fsz, tb->xin, tb->xfs};
     ProfScope ps(ctx, "slab_A_x_fwd", (one ? 2.0 : 4.0) * 16.0 * nx * nyl * ksub);
     if (one) {
       MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub_t<NN, false, 1>(ctx, a, t, ctx->ax[0].d_tw))));
@@ -608,7 +614,7 @@ int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv) {
   if (!slab_fast_shift(ctx)) {  // table-addressed chunks
     const SlabTabs *tb;
     MRL_TRY(slab_tabs_get(ctx, kp, 0, &tb));
-    const p2::SubPassTabs t{tb->xch, tb->xoff, tb->fsz, tb->cofi};
+    const p2::SubPassTabs t{tb->xch, tb->xoff, tb->fsz, tb->xin, tb->xfs};
     MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub_t<NN, true, 1>(ctx, a, t, ctx->ax[0].d_tw))));
     return MRL_OK;
   }

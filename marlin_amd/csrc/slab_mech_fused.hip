@@ -301,7 +301,7 @@ static int x_pass_tab(mrl_ctx *ctx, bool inverse, int nf, const cplx *src, cplx 
   a.out[0] = dst;
   a.otab = otab;
   a.sig = sig;
-  const p2::SubPassTabs t{tb->xch, tb->xoff, tb->fsz, tb->cofi};
+  const p2::SubPassTabs t{tb->xch, tb->xoff, tb->fsz, tb->xin, tb->xfs};
   if (inverse) {
     MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub_mft<NN, true>(ctx, a, t, ctx->ax[0].d_tw, nf))));
   } else {

@@ -16,8 +16,9 @@ namespace p2 {
 struct SubPassTabs {
   const unsigned *xch;    // [nx] rank whose chunk holds x plane n
   const unsigned *xoff;   // [nx] element offset of plane n inside a field block of that chunk: (n - first plane) * plane pitch
-  const unsigned *fsz;    // [P]  forward: elements between two fields of the chunk for rank p
-  const unsigned *cofi;   // [P]  inverse: element offset of the chunk received from rank p
+  const unsigned *fsz;    // [P]  elements between two fields of the chunk for rank p (host side; the kernels use xfs)
+  const unsigned *xin;    // [nx] inverse: element offset of plane n, field 0, in the received buffer (chunk offset + plane offset)
+  const unsigned *xfs;    // [nx] inverse: elements between two fields of the chunk that holds plane n
 };
 
 template <int N, bool INV, int NF>
@@ -43,7 +44,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_t(SubPassArgs a, Su
     for (int m = 0; m < P; ++m) {
       const unsigned n = q + m * TPL;
       if (INV)
-        v[f][m] = a.in[f][bi + t.cofi[t.xch[n]] + t.xoff[n]];
+        v[f][m] = a.in[f][bi + t.xin[n]];
       else
         v[f][m] = a.in[f][bi + n * a.sn_in];
     }
@@ -63,8 +64,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_t(SubPassArgs a, Su
         if (INV) {
           a.out[f][bo + n * a.sn_out] = cswap(v[f][m]);
         } else {
-          const unsigned p = t.xch[n];
-          a.otab[p][(unsigned)f * t.fsz[p] + bo + t.xoff[n]] = v[f][m];
+          a.otab[t.xch[n]][(unsigned)f * t.xfs[n] + bo + t.xoff[n]] = v[f][m];
         }
       }
     }
@@ -115,8 +115,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_mft(SubPassArgs a, 
   for (int m = 0; m < P; ++m) {
     const unsigned n = q + m * TPL;
     if (INV) {
-      const unsigned p = t.xch[n];
-      v[m] = a.in[0][bi + t.cofi[p] + f * t.fsz[p] + t.xoff[n]];
+      v[m] = a.in[0][bi + t.xin[n] + f * t.xfs[n]];
     } else {
       v[m] = a.in[0][(size_t)f * a.fdense + bi + n * a.sn_in];
     }
@@ -134,8 +133,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_mft(SubPassArgs a, 
       if (INV) {
         a.out[0][(size_t)f * a.fdense + bo + n * a.sn_out] = cswap(v[m]);
       } else {
-        const unsigned p = t.xch[n];
-        a.otab[p][f * t.fsz[p] + bo + t.xoff[n]] = v[m];
+        a.otab[t.xch[n]][f * t.xfs[n] + bo + t.xoff[n]] = v[m];
       }
     }
   }
