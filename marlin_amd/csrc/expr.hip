@@ -788,10 +788,10 @@ static int build_mu_function(mrl_parsed *p, std::string &out) {
 }
 
 // lines per workgroup / threads per workgroup of the z kernels (ZPlan<N>, fft_pow2.h)
-static int plan_shape(mrl_ctx *ctx, int N, int *T, int *NT) {
+static int plan_shape(mrl_ctx *ctx, int N, int *T, int *NT, size_t *lds) {
   *T = 0;
   if (!pow2_ok(N)) return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
-  MRL_SWITCH_N(N, (*T = p2::ZPlan<NN>::T, *NT = p2::ZPlan<NN>::NT));
+  MRL_SWITCH_N(N, (*T = p2::ZPlan<NN>::T, *NT = p2::ZPlan<NN>::NT, *lds = p2::lds_line<NN>()));
   if (*T == 0) return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
   return MRL_OK;
 }
@@ -865,7 +865,8 @@ static ChDevHost parsed_chdev(const mrl_parsed *p) {
 int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const double *in, cplx *out0, cplx *out1, double *mu_out,
                         long long nlines, unsigned lay_lpp, unsigned lay_pad) {
   int T = 0, NT = 0;
-  MRL_TRY(plan_shape(ctx, N, &T, &NT));
+  size_t lds = 0;  // twiddle table + the line tile of the z kernels (MapLine<N>)
+  MRL_TRY(plan_shape(ctx, N, &T, &NT, &lds));
   if (mode != 1 && mode != 2) return set_error(ctx, MRL_ERR_INVALID, "parsed z pass: mode %d", mode);
   hipFunction_t fn;
   MRL_TRY(parsed_z_kernel(ctx, p, N, mode, &fn));
@@ -874,8 +875,6 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const doub
   const cplx *tw = ctx->ax[2].d_tw;
   struct { unsigned lpp, pad; } zl = {lay_lpp, lay_pad};  // = p2::ZLay
   void *params[] = {&in, &out0, &out1, &mu_out, &chp, &nlines, &tw, &zl};
-  const int LP = N + N / 16;
-  const size_t lds = sizeof(cplx) * (size_t)(N + T * LP);
   const long long nb = (nlines + T - 1) / T;
   MRL_HIP(ctx, hipModuleLaunchKernel(fn, (unsigned)nb, 1, 1, (unsigned)NT, 1, 1, (unsigned)lds, ctx->stream, params, nullptr));
   return MRL_OK;
@@ -885,15 +884,14 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const doub
 int parsed_z_inv_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const cplx *in, cplx *out0, cplx *out1, double *mu_out,
                             double scale, long long nlines, bool mu_only, unsigned lay_lpp, unsigned lay_pad) {
   int T = 0, NT = 0;
-  MRL_TRY(plan_shape(ctx, N, &T, &NT));
+  size_t lds = 0;  // twiddle table + the line tile of the z kernels (MapLine<N>)
+  MRL_TRY(plan_shape(ctx, N, &T, &NT, &lds));
   hipFunction_t fn;
   MRL_TRY(parsed_z_kernel(ctx, p, N, mu_only ? 4 : 3, &fn));
   ChDevHost chp = parsed_chdev(p);
   const cplx *tw = ctx->ax[2].d_tw;
   struct { unsigned lpp, pad; } zl = {lay_lpp, lay_pad};  // = p2::ZLay
   void *params[] = {&in, &out0, &out1, &mu_out, &chp, &scale, &nlines, &tw, &zl};
-  const int LP = N + N / 16;
-  const size_t lds = sizeof(cplx) * (size_t)(N + T * LP);
   const long long nb = (nlines + T - 1) / T;
   MRL_HIP(ctx, hipModuleLaunchKernel(fn, (unsigned)nb, 1, 1, (unsigned)NT, 1, 1, (unsigned)lds, ctx->stream, params, nullptr));
   return MRL_OK;

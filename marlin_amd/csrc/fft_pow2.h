@@ -378,17 +378,89 @@ struct MapStrided {  // lines fastest (lanes of a wave vary l): conflict-free wi
   static constexpr int T = Plan<N>::T;
   __device__ __forceinline__ static int at(int p, int l) { return p * T + l; }
   static constexpr int size = N * T;
+  static constexpr bool staged_tw = false;  // all lanes of a 16-lane group read the same twiddle (broadcast): the natural table
 };
+// Position-fastest map of the z kernels (lanes of a wave vary q): index = l * LP + (p ^ ((p >> XS) & XM)) + (PA ? p >> PA : 0),
+// LP = N + C + (PA ? N >> PA : 0).  The parameters per length come from tools/lds_conflict_model.py, which applies the
+// per-instruction banking of the LDS (ds_write_b128: 8 lanes on 32 banks, ds_read_b128: 4 groups of 16 lanes on 64 banks) to the
+// Stockham exchanges of each plan; the default (one pad element per 16 positions) is conflict-free for the 16 x 16 / 16 x 8 / 16 x 2
+// plans only.  Measured before (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE): 41-47 % of the LDS cycles of the 512-point z kernels.
+// XM < 2^XS and the lengths are multiples of XM + 1: the swizzle permutes positions inside aligned blocks of the line.
 template <int N>
-struct MapLine {  // position fastest (lanes vary q): one pad element per 16 positions
-  static constexpr int LP = N + N / 16;
-  __device__ __forceinline__ static int at(int p, int l) { return l * LP + p + (p >> 4); }
+struct LineMapParams {
+  static constexpr int C = 0, XS = 0, XM = 0, PA = 4;
+};
+#define MRL_LINEMAP(N_, C_, XS_, XM_, PA_)                      \
+  template <>                                                   \
+  struct LineMapParams<N_> {                                    \
+    static constexpr int C = C_, XS = XS_, XM = XM_, PA = PA_;  \
+  };
+//           N    C XS XM PA     LDS cycles of the exchanges of one tile: before -> now (ideal)
+MRL_LINEMAP(40, 4, 2, 1, 0)      // 2016 -> 1024 (960)
+MRL_LINEMAP(48, 4, 2, 3, 0)      // 1344 -> 576 (576)
+MRL_LINEMAP(50, 3, 0, 0, 0)      // 1169 -> 760 (480)
+MRL_LINEMAP(60, 2, 1, 1, 0)      // 1440 -> 720 (720)
+MRL_LINEMAP(64, 0, 2, 3, 4)      // 1280 -> 768 (768)
+MRL_LINEMAP(72, 5, 4, 1, 3)      // 1792 -> 1424 (864)
+MRL_LINEMAP(80, 8, 3, 1, 0)      // 3424 -> 1696 (1440)
+MRL_LINEMAP(90, 1, 0, 0, 5)      // 1938 -> 1053 (720)
+MRL_LINEMAP(96, 8, 3, 3, 0)      // 2496 -> 1280 (1152)
+MRL_LINEMAP(100, 2, 3, 1, 0)     // 1175 -> 808 (480)
+MRL_LINEMAP(120, 4, 2, 1, 0)     // 4320 -> 1472 (1440)
+MRL_LINEMAP(144, 4, 3, 3, 0)     // 1212 -> 812 (576)
+MRL_LINEMAP(150, 1, 0, 0, 5)     // 3072 -> 1123 (720)
+MRL_LINEMAP(160, 8, 3, 3, 0)     // 2176 -> 1024 (960)
+MRL_LINEMAP(180, 2, 1, 1, 0)     // 4734 -> 1860 (1440)
+MRL_LINEMAP(192, 0, 3, 3, 0)     // 2112 -> 1280 (1152)
+MRL_LINEMAP(200, 4, 3, 1, 0)     // 1896 -> 1428 (960)
+MRL_LINEMAP(216, 2, 3, 1, 0)     // 3114 -> 2448 (1728)
+MRL_LINEMAP(240, 8, 3, 1, 0)     // 6256 -> 2288 (2160)
+MRL_LINEMAP(250, 8, 3, 1, 0)     // 2125 -> 1434 (960)
+MRL_LINEMAP(270, 3, 0, 0, 5)     // 4563 -> 2243 (1440)
+MRL_LINEMAP(288, 8, 3, 3, 0)     // 1632 -> 960 (864)
+MRL_LINEMAP(300, 5, 0, 0, 5)     // 2952 -> 1178 (720)
+MRL_LINEMAP(320, 0, 3, 3, 0)     // 1856 -> 1024 (960)
+MRL_LINEMAP(360, 4, 3, 1, 0)     // 5340 -> 2570 (2160)
+MRL_LINEMAP(384, 0, 3, 3, 0)     // 2880 -> 1856 (1728)
+MRL_LINEMAP(400, 8, 3, 1, 0)     // 2685 -> 1662 (1440)
+MRL_LINEMAP(432, 4, 3, 3, 0)     // 2124 -> 1272 (1152)
+MRL_LINEMAP(450, 8, 0, 0, 5)     // 4522 -> 2330 (1440)
+MRL_LINEMAP(500, 2, 3, 1, 0)     // 2015 -> 1328 (960)
+MRL_LINEMAP(512, 0, 3, 7, 0)     // 2560 -> 1536 (1536)
+MRL_LINEMAP(576, 0, 3, 3, 0)     // 1584 -> 960 (864)
+MRL_LINEMAP(600, 4, 3, 1, 0)     // 4321 -> 1956 (1440)
+MRL_LINEMAP(640, 0, 3, 3, 0)     // 2496 -> 1504 (1440)
+MRL_LINEMAP(768, 0, 3, 3, 0)     // 2880 -> 1856 (1728)
+MRL_LINEMAP(800, 8, 3, 3, 0)     // 1896 -> 1100 (960)
+MRL_LINEMAP(864, 8, 3, 3, 0)     // 2736 -> 1872 (1728)
+MRL_LINEMAP(1000, 2, 3, 1, 0)    // 1774 -> 1136 (960)
+MRL_LINEMAP(1024, 0, 4, 7, 0)    // 2048 -> 1536 (1536)
+MRL_LINEMAP(1152, 0, 3, 3, 0)    // 2160 -> 1392 (1296)
+MRL_LINEMAP(1280, 0, 3, 3, 0)    // 2496 -> 1504 (1440)
+MRL_LINEMAP(2048, 0, 4, 7, 0)    // 2048 -> 1536 (1536)
+MRL_LINEMAP(4096, 0, 4, 7, 0)    // 2048 -> 1536 (1536)
+#undef MRL_LINEMAP
+
+template <int N>
+struct MapLine {
+  using Pm = LineMapParams<N>;
+  static_assert(Pm::XM < (1 << Pm::XS) || Pm::XM == 0, "the swizzle may only touch bits below its source bits");
+  static_assert(N % (Pm::XM + 1) == 0, "the swizzle permutes inside aligned blocks: the length must be a multiple of the block");
+  static constexpr int LP = N + Pm::C + (Pm::PA ? (N >> Pm::PA) : 0);
+  // twiddles of a stage laid out [t - 1][k] (k = the lane-dependent index): see stage()
+  static constexpr bool staged_tw = true;
+  __device__ __forceinline__ static int at(int p, int l) {
+    return l * LP + (Pm::XM ? (p ^ ((p >> Pm::XS) & Pm::XM)) : p) + (Pm::PA ? (p >> Pm::PA) : 0);
+  }
   static constexpr int size = Plan<N>::T * LP;    // for Plan<N>::T lines
   static constexpr int zsize = ZPlan<N>::T * LP;  // for the z kernels' ZPlan<N>::T lines
 };
 
 // radix-R stage on the P register values (v[i + S*t] = element t of butterfly i, S = P/R butterflies per thread)
-template <int N, int R, int NS>
+// ST (staged twiddle table, the z kernels): W holds, stage after stage, the factors [t - 1][k] = w_N^(t k N / (Ns R)) with k fastest
+// -- the lanes of a wave differ in k, so a plain W[t k N / (Ns R)] is a strided LDS read (8-way conflicts in the 512-point plan:
+// 1664 LDS cycles per tile where 448 suffice); the table of stage Ns starts at Ns - r0 (the stages before it hold that many entries).
+template <int N, int R, int NS, bool ST = false>
 __device__ __forceinline__ void stage(kcplx (&v)[Plan<N>::P], int q, const kcplx *W) {
   constexpr int P = Plan<N>::P, S = P / R, TPL = N / P;
   static_assert(P % R == 0, "radix must divide the points per thread");
@@ -400,9 +472,15 @@ __device__ __forceinline__ void stage(kcplx (&v)[Plan<N>::P], int q, const kcplx
     if (NS > 1) {
       const int b = q + i * TPL;
       const int k = b % NS;
-      const int step = k * (N / (NS * R));
+      if (ST) {
+        const kcplx *Ws = W + (NS - Plan<N>::r0) + k;
 #pragma unroll
-      for (int t = 1; t < R; ++t) a[t] = cmul(a[t], W[t * step]);
+        for (int t = 1; t < R; ++t) a[t] = cmul(a[t], Ws[(t - 1) * NS]);
+      } else {
+        const int step = k * (N / (NS * R));
+#pragma unroll
+        for (int t = 1; t < R; ++t) a[t] = cmul(a[t], W[t * step]);
+      }
     }
     bfly<R>(a);
 #pragma unroll
@@ -431,16 +509,17 @@ __device__ __forceinline__ void exchange(kcplx (&v)[Plan<N>::P], int q, int l, k
 template <int N, class Map>
 __device__ __forceinline__ void fft_line(kcplx (&v)[Plan<N>::P], int q, int l, kcplx *X, const kcplx *W) {
   using Pl = Plan<N>;
-  stage<N, Pl::r0, 1>(v, q, W);
+  constexpr bool ST = Map::staged_tw;
+  stage<N, Pl::r0, 1, ST>(v, q, W);
   exchange<N, Pl::r0, 1, Map>(v, q, l, X);
-  stage<N, Pl::r1, Pl::r0>(v, q, W);
+  stage<N, Pl::r1, Pl::r0, ST>(v, q, W);
   if constexpr (Pl::ns >= 3) {
     exchange<N, Pl::r1, Pl::r0, Map>(v, q, l, X);
-    stage<N, Pl::r2, Pl::r0 * Pl::r1>(v, q, W);
+    stage<N, Pl::r2, Pl::r0 * Pl::r1, ST>(v, q, W);
   }
   if constexpr (Pl::ns >= 4) {
     exchange<N, Pl::r2, Pl::r0 * Pl::r1, Map>(v, q, l, X);
-    stage<N, Pl::r3, Pl::r0 * Pl::r1 * Pl::r2>(v, q, W);
+    stage<N, Pl::r3, Pl::r0 * Pl::r1 * Pl::r2, ST>(v, q, W);
   }
 }
 
@@ -474,6 +553,28 @@ __device__ __forceinline__ void tw_issue(TwRegs<N, NTH> &r, const kcplx *__restr
   for (int j = 0; j < TwRegs<N, NTH>::CNT; ++j) {
     const int idx = threadIdx.x + j * NTH;
     r.v[j] = idx < N ? tw[idx] : mkc(0.0, 0.0);
+  }
+}
+// the staged table of the z kernels (stage(): ST): entry s of stage Ns is w_N^(t k N / (Ns R)), t = s / Ns + 1, k = s % Ns, gathered
+// from the natural table (L1 / L2 resident); N - r0 entries in all
+template <int N>
+__device__ __forceinline__ int tw_staged_src(int s) {
+  using Pl = Plan<N>;
+  constexpr int n1 = Pl::r0, c1 = (Pl::r1 - 1) * n1;        // first twiddled stage: Ns = r0, radix r1
+  constexpr int n2 = n1 * Pl::r1, c2 = (Pl::r2 - 1) * n2;   // second
+  constexpr int n3 = n2 * Pl::r2;                            // third
+  if (s < c1) return (s / n1 + 1) * (s % n1) * (N / (n1 * Pl::r1));
+  s -= c1;
+  if (c2 > 0 && s < c2) return (s / n2 + 1) * (s % n2) * (N / (n2 * Pl::r2));
+  s -= c2;
+  return (s / n3 + 1) * (s % n3) * (N / (n3 * Pl::r3));
+}
+template <int N, int NTH>
+__device__ __forceinline__ void tw_issue_staged(TwRegs<N, NTH> &r, const kcplx *__restrict__ tw) {
+#pragma unroll
+  for (int j = 0; j < TwRegs<N, NTH>::CNT; ++j) {
+    const int idx = threadIdx.x + j * NTH;
+    r.v[j] = idx < N - Plan<N>::r0 ? tw[tw_staged_src<N>(idx)] : mkc(0.0, 0.0);
   }
 }
 template <int N, int NTH>

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_fwd(const kreal *__restri
   const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
   const bool valid = L < nlines;
   TwRegs<N, ZPlan<N>::NT> twr;
-  tw_issue<N>(twr, tw);
+  tw_issue_staged<N>(twr, tw);
 
   kcplx v[P];
   const long long Lc = valid ? L : 0;  // out-of-range lanes transform line 0 again and store nothing
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const kcplx *__restri
   const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
   const bool valid = L < nlines;
   TwRegs<N, ZPlan<N>::NT> twr;
-  tw_issue<N>(twr, tw);
+  tw_issue_staged<N>(twr, tw);
   kcplx v[P];
   {
     const kcplx *A = in + zrow(2 * (valid ? L : 0), NZC, zl);
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const kcplx *__re
   const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
   const bool valid = L < nlines;
   TwRegs<N, ZPlan<N>::NT> twr;
-  tw_issue<N>(twr, tw);
+  tw_issue_staged<N>(twr, tw);
   kcplx v[P];
   {
     const kcplx *A = in + zrow(2 * (valid ? L : 0), NZC, zl);

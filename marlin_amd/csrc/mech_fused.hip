@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_z_fwd_tangent(const do
   const int t = threadIdx.x;
   const long long tile = xcd_remap(blockIdx.x, gridDim.x);
   TwRegs<N> twr;
-  tw_issue<N>(twr, tw);
+  tw_issue_staged<N>(twr, tw);
 
   // ---- phase 1: two grid points per thread
   const double beta = S[i_num] / S[i_den];
