@@ -23,7 +23,6 @@
 #include <atomic>
 
 #include "fft_pow2_launch.h"
-#include "fft_pow2_wide.h"
 #include "slab_tables.h"
 
 namespace mrl {
@@ -457,6 +456,8 @@ int slab_ch_x_fwd_fast(mrl_ctx *ctx, int k0, int ksub, cplx *const *otab, const 
     a.sn_in = (unsigned)wp;
     const p2::SubPassTabs t{tb->xch, tb->xoff, tb->fsz, tb->xin, tb->xfs};
     ProfScope ps(ctx, "slab_A_x_fwd", (one ? 2.0 : 4.0) * 16.0 * nx * nyl * ksub);
+    if (nx == 512 && !(ctx->exp & 1024))  // the wide plan, as on the shift-addressed path
+      return p2::launch_pass_sub_wt<p2::Wide512, false>(ctx, a, t, ctx->ax[0].d_tw, one ? 1 : 2);
     if (one) {
       MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub_t<NN, false, 1>(ctx, a, t, ctx->ax[0].d_tw))));
     } else {
@@ -615,6 +616,7 @@ int slab_ch_x_inv_fast(mrl_ctx *ctx, int k0, int ksub, const double *recv) {
     const SlabTabs *tb;
     MRL_TRY(slab_tabs_get(ctx, kp, 0, &tb));
     const p2::SubPassTabs t{tb->xch, tb->xoff, tb->fsz, tb->xin, tb->xfs};
+    if (nx == 512 && !(ctx->exp & 1024)) return p2::launch_pass_sub_wt<p2::Wide512, true>(ctx, a, t, ctx->ax[0].d_tw);
     MRL_SWITCH_N(nx, MRL_TRY((p2::launch_pass_sub_t<NN, true, 1>(ctx, a, t, ctx->ax[0].d_tw))));
     return MRL_OK;
   }

@@ -5,6 +5,7 @@
 #include <atomic>
 
 #include "fft_pow2_launch.h"
+#include "fft_pow2_wide.h"
 
 namespace mrl {
 namespace p2 {
@@ -154,6 +155,68 @@ inline int launch_pass_sub_mft(mrl_ctx *ctx, SubPassArgs a, const SubPassTabs &t
   const long long nb = (long long)nf * a.nb;
   if (a.sig.expected == 0) a.sig.expected = (unsigned)nb;
   hipLaunchKernelGGL((k_pass_sub_mft<N, INV>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a, t, tw);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+// The wide 512-point plan (fft_pow2_wide.h: 32 points per thread, two stages, 256-byte segments) with table-addressed chunks: nf = 1 or 2
+// fields back to back in one launch (forward), one field (inverse).  Same transform as k_pass_sub_w, same addressing as k_pass_sub_t.
+template <class PL, bool INV>
+__global__ void __launch_bounds__(PL::NT, 2) k_pass_sub_wt(SubPassArgs a, SubPassTabs t, const cplx *__restrict__ tw) {
+  constexpr int P = PL::P, TPL = PL::TPL, T = PL::T, N = PL::N, NT = PL::NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx *W = reinterpret_cast<cplx *>(smem);
+  double *X = reinterpret_cast<double *>(W + N);
+  const int l = threadIdx.x % T, q = threadIdx.x / T;
+  unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned f = logical >= a.nb ? 1u : 0u;
+  logical -= f * a.nb;
+  const cplx *__restrict__ src = a.in[f];
+  const unsigned i = logical * T + l;
+  const bool valid = i < (unsigned)(a.rows * a.tcols);
+  const unsigned ic = valid ? i : 0u;
+  const unsigned row = ic / (unsigned)a.tcols, col = ic - row * (unsigned)a.tcols;
+  const unsigned bi = row * a.pitch_in + min(col, (unsigned)a.cols - 1u), bo = row * a.pitch_out + col;
+  TwRegs<N, NT> twr;
+  tw_issue<N, NT>(twr, tw);
+  cplx v[P];
+#pragma unroll
+  for (int m = 0; m < P; ++m) {
+    const unsigned n = q + m * TPL;
+    v[m] = INV ? src[bi + t.xin[n]] : src[bi + n * a.sn_in];
+  }
+  tw_commit<N, NT>(twr, W);
+  if (INV) {
+#pragma unroll
+    for (int m = 0; m < P; ++m) v[m] = cswap(v[m]);
+  }
+  fft_line_w<PL>(v, q, l, X, W);
+  if (valid) {
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      const unsigned n = q + m * TPL;
+      if (INV)
+        a.out[0][bo + n * a.sn_out] = cswap(v[m]);
+      else
+        a.otab[t.xch[n]][f * t.xfs[n] + bo + t.xoff[n]] = v[m];
+    }
+  }
+  if (!INV) signal_tail(a.sig);
+}
+
+template <class PL, bool INV>
+inline int launch_pass_sub_wt(mrl_ctx *ctx, SubPassArgs a, const SubPassTabs &t, const cplx *tw, int nf = 1) {
+  static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
+  constexpr size_t lds = lds_wide<PL>();
+  if (!attr.load(std::memory_order_acquire)) {
+    MRL_TRY((set_lds_attr(ctx, k_pass_sub_wt<PL, INV>, lds)));
+    attr.store(true, std::memory_order_release);
+  }
+  if (a.tcols == 0) a.tcols = a.cols;
+  a.nb = (unsigned)(((long long)a.rows * a.tcols + PL::T - 1) / PL::T);
+  const long long nb = (long long)nf * a.nb;
+  if (a.sig.expected == 0) a.sig.expected = (unsigned)nb;
+  hipLaunchKernelGGL((k_pass_sub_wt<PL, INV>), dim3((unsigned)nb), dim3(PL::NT), lds, ctx->stream, a, t, tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }

@@ -203,7 +203,8 @@ def test_slab_ch_matches_serial_oracle(shape, P, nsub):
                                               ((100, 200, 50), 4, 1, 0),     # radix-10 family, ny / P = 50, nx / P = 25
                                               ((200, 100, 40), 2, 3, 0),
                                               ((96, 48, 64), 5, 1, 0),       # uneven on both axes: 20/19/19/19/19 and 10/10/10/9/9
-                                              ((64, 128, 64), 4, 2, 1 << 24)])   # a shift-addressable shape through the table kernels
+                                              ((64, 128, 64), 4, 2, 1 << 24),  # a shift-addressable shape through the table kernels
+                                              ((512, 48, 32), 3, 2, 0)])     # 512-point x lines on 171 / 171 / 170 planes: the wide plan, table-addressed
 def test_slab_table_addressed_pipeline(shape, P, nsub, exp):
     """partitions that are not equal powers of two (the reference's 200^3 example grid on 2 / 4 ranks, its 3-rank
     64^3 test, device_weights) run the FUSED slab pipeline with table-addressed chunks (k_pass_sub_t, k_ch_yfused_t) instead of the
