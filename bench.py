@@ -264,6 +264,19 @@ def launch_multi(args, argv):
             with open(verdict) as f:
                 sys.exit(0 if f.read().strip() == "ok" else 1)
     stages, tried, result = [], [], None
+    # more than four rank processes per card is refused here (a box allows few processes on a card at once): one rank per GPU is the
+    # configuration; several ranks sharing a card over HIP IPC are for functional runs on a one-GPU box (N = 2 ... 4)
+    import torch as _t
+    ndev = _t.cuda.device_count()     # (counts the devices without initialising the GPU)
+    per_card = args.gpus if args.device >= 0 else -(-args.gpus // max(ndev, 1))
+    if ndev < 1 or per_card > 4:
+        msg = f"bench.py --gpus {args.gpus}: {ndev} GPU(s) visible -> {per_card} rank processes per card (at most 4 are started)"
+        if verdict:
+            with open(verdict + ".tmp", "w") as f:
+                f.write("failed")
+            os.replace(verdict + ".tmp", verdict)
+        print(json.dumps({"error": msg}), file=sys.stderr, flush=True)
+        sys.exit(2)
     if args.driver == "native":
         n = args.n or (256 if args.workload == "ch" else 128)
         cmd = [NATIVE_BENCH, f"workload={args.workload}", f"gpus={args.gpus}", f"steps={args.steps}", f"warmup={args.warmup}", f"grid={n}",

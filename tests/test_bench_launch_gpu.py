@@ -81,3 +81,13 @@ def test_native_launcher_does_not_wait_for_the_survivors_of_a_lost_rank():
     assert r.returncode == 1, (r.returncode, r.stderr[-2000:])
     assert time.perf_counter() - t0 < 60.0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_refuses_more_than_four_ranks_per_card():
+    """--gpus 8 on a one-GPU box would put eight rank processes on one card: refused before anything is started (rc 2, no GPU call)"""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a one-GPU box")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "2"], cwd=ROOT, env=_env(), capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 2 and "rank processes per card" in r.stderr, (r.returncode, r.stderr[-500:])
