@@ -85,6 +85,81 @@ static std::vector<double> local_block(const DomainAction & domain, const std::v
   return out;
 }
 
+// precision=float32: the reference's per-run precision switch (src/utils/MarlinUtils.C:39-44, DomainAction.C:81,201; its published GPU
+// numbers are float32 runs, doc/content/installation.md:36-43).  The same time loop -- num_steps steps of `substeps` substeps, AB2 by
+// default, first step at first order (TensorProblem.C:455), history ring rotated per substep -- straight over mrl_ch_substeps_f32 with
+// float buffers; no output (the wall time of the whole run is what is reported).  Serial contexts, built-in free-energy families.
+static int run_cahnhilliard_f32(DomainAction & domain, const std::vector<double> & ic)
+{
+  if (domain.nranks() > 1)
+    mooseError("precision=float32: serial runs only");
+  mrl_ctx * ctx = domain.ctx();
+  const int64_t nspec = mrl_ch_spec_elems_f32(ctx);
+  if (nspec <= 0)
+    mooseError("precision=float32: extents must be of {64, 100, 128, 200, 256, 400, 512} in three dimensions");
+  const std::size_t n = ic.size();
+  std::vector<float> icf(n);
+  for (std::size_t i = 0; i < n; ++i)
+    icf[i] = (float)ic[i];
+  float *c[2] = {nullptr, nullptr}, *ring[3] = {nullptr, nullptr, nullptr};
+  const int pred = (int)argi("predictor_order", 2);
+  if (pred < 1 || pred > 3)
+    paramError("predictor_order", "precision=float32: predictor_order 1 ... 3");
+  for (int i = 0; i < 2; ++i)
+    if (hipMalloc(reinterpret_cast<void **>(&c[i]), sizeof(float) * n) != hipSuccess)
+      mooseError("hipMalloc failed");
+  for (int i = 0; i < pred; ++i)
+    if (hipMalloc(reinterpret_cast<void **>(&ring[i]), 2 * sizeof(float) * (std::size_t)nspec) != hipSuccess ||
+        hipMemset(ring[i], 0, 2 * sizeof(float) * (std::size_t)nspec) != hipSuccess)
+      mooseError("hipMalloc failed");
+  if (hipMemcpy(c[0], icf.data(), sizeof(float) * n, hipMemcpyHostToDevice) != hipSuccess)
+    mooseError("hipMemcpy (host to device) failed");
+  mrl_ch_params p{};
+  p.family = arg("free_energy", "DOUBLE_WELL") == "PFHUB" ? MRL_FE_PFHUB : MRL_FE_DOUBLE_WELL;
+  p.coef[0] = argd("A", 0.1);
+  p.coef[1] = argd("c_alpha", 0.3);
+  p.coef[2] = argd("c_beta", 0.7);
+  p.mobility = argd("mobility", 0.2);
+  p.kappa = argd("kappa", -0.001);
+  const int substeps = (int)argi("substeps", 1), num_steps = (int)argi("num_steps", 1);
+  const double sub_dt = argd("dt", 1e-3) / substeps;
+  int head = 0, n_old = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int step = 0; step < num_steps; ++step)
+  {
+    // the history advances between time steps only from the second step on (TensorProblem.C:455: the whole first step is AB1 of the
+    // ring's point of view: n_old grows inside the call)
+    if (step > 0)
+    {
+      head = (head + 1) % pred;
+      if (n_old < pred - 1)
+        n_old += 1;
+    }
+    domain.check(mrl_ch_substeps_f32(ctx, &p, c[step % 2], c[1 - step % 2], ring, pred, &head, &n_old, pred, substeps, step > 0 ? 1 : 0, sub_dt));
+  }
+  domain.check(mrl_sync(ctx));
+  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::vector<float> end(n);
+  if (hipMemcpy(end.data(), c[num_steps % 2], sizeof(float) * n, hipMemcpyDeviceToHost) != hipSuccess)
+    mooseError("hipMemcpy (device to host) failed");
+  double sum_c = 0.0, sum_c2 = 0.0;
+  for (const float v : end)
+  {
+    sum_c += v;
+    sum_c2 += (double)v * v;
+  }
+  const double updates = (double)n * substeps * num_steps;
+  std::printf("{\"precision\": \"float32\", \"wall_s\": %.3f, \"grid_point_updates_per_s\": %.6e, \"frames\": 0, \"time\": %.17g, "
+              "\"sum_c\": %.17g, \"sum_c2\": %.17g}\n",
+              wall, updates / wall, argd("dt", 1e-3) * num_steps, sum_c, sum_c2);
+  for (float * q : c)
+    (void)hipFree(q);
+  for (float * q : ring)
+    if (q)
+      (void)hipFree(q);
+  return 0;
+}
+
 static int run_cahnhilliard(DomainAction & domain, const std::string & out)
 {
   TensorProblem problem(domain);
@@ -105,6 +180,8 @@ static int run_cahnhilliard(DomainAction & domain, const std::string & out)
   }
   else
     ic = read_bin(arg("ic"), domain.getGlobalNumberOfCells());
+  if (arg("precision", "float64") == "float32")
+    return run_cahnhilliard_f32(domain, local_block(domain, ic));
   problem.getBuffer("c") = DeviceTensor::fromHost(local_block(domain, ic));
   problem.getBuffer("mu") = DeviceTensor::zeros(n);                        // ConstantTensor
   AdamsBashforthMoulton::Params p;

@@ -604,3 +604,25 @@ def test_coupled_pf_mech_case(tmp_path):
             u = np.fromfile(tmp_path / f"{nm}.{k}.bin", dtype="<f8").reshape(n, n, n)
             assert np.abs(u - ref.disp[d].numpy()).max() <= 1e-12 * np.abs(ref.disp[d].numpy()).max()
     assert np.abs(ref.c.numpy() - c0.numpy()).max() > 1e-4      # the fields did evolve
+
+
+def test_cahnhilliard_precision_float32_whole_run(tmp_path):
+    """precision=float32 (the reference's per-run precision switch, MarlinUtils.C:39-44): the same time loop straight over
+    mrl_ch_substeps_f32 -- 3 steps of 20 substeps on 64^3 from the splitmix64 initial condition -- ends at the float64 run's checksums to
+    float32 accuracy (sum c: the scheme conserves mass; sum c^2 measures the field itself)"""
+    import json
+    base = ["problem=cahnhilliard", "dim=3", "nx=64", "ny=64", "nz=64", "xmax=8.04", "ymax=8.04", "zmax=8.04", "ic=splitmix64", "substeps=20",
+            "num_steps=3", "dt=0.02", "predictor_order=2", "mobility=0.2", "kappa=-0.001", "output=none"]
+    res = {}
+    for prec in ("float64", "float32"):
+        out = subprocess.run([RUN] + base + [f"precision={prec}", f"out={tmp_path}"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[prec] = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    a, b = res["float64"], res["float32"]
+    assert b["precision"] == "float32"
+    assert abs(b["sum_c"] - a["sum_c"]) <= 2e-6 * abs(a["sum_c"])
+    assert abs(b["sum_c2"] - a["sum_c2"]) <= 2e-6 * abs(a["sum_c2"])
+    # a length outside the fp32 instantiations is refused with the reason
+    bad = subprocess.run([RUN] + [x if not x.startswith("nx=") else "nx=96" for x in base] + ["precision=float32", f"out={tmp_path}"],
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "float32" in (bad.stderr + bad.stdout)
