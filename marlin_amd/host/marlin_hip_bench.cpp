@@ -16,6 +16,12 @@
 // the consumers re-read their receive buffers with system-scope loads (MRL_OPT_VERIFY_EXCHANGE): a stale-line bug of the peer-store
 // path then shows up as a count of differing elements, not as wrong physics.
 // Rank 0 prints ONE JSON line; bench.py wraps it (adds nothing that was not measured here).
+//
+// PROFILERS.  The launcher starts its ranks with fork + exec, which is only safe while the launching process has not initialised the
+// GPU.  A profiler preload (rocprofv3: LD_PRELOAD / ROCP_TOOL_LIBRARIES / HSA_TOOLS_LIB) initialises it before main(), so with
+// gpus > 1 the launcher REFUSES to start under one (exit 2): profile ONE rank process directly, `rocprofv3 ... -- marlin-hip-bench
+// gpus=N rank=r job=<name> ...` (the other ranks started unprofiled with the same job name), or a single-process run.  gpus=1 never
+// forks or execs: the one rank runs in this process, so `rocprofv3 -- marlin-hip-bench gpus=1 ...` is fine.
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <signal.h>
@@ -802,9 +808,32 @@ static int run_mech(Rank & R)
   return 0;
 }
 
+// a profiler (or any tool library) that is loaded into this process before main() and initialises the GPU there
+static const char * profiler_preload()
+{
+  static const char * vars[] = {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD", nullptr};
+  for (int i = 0; vars[i]; ++i)
+  {
+    const char * v = std::getenv(vars[i]);
+    if (v && (std::strstr(v, "rocprof") || std::strstr(v, "roctracer") || std::strstr(v, "rocprofiler")))
+      return vars[i];
+  }
+  return nullptr;
+}
+
 // start one child per rank (fork + exec of this binary; the parent has made no HIP call) and return the worst exit code
 static int launch_ranks(int argc, char ** argv, int nranks)
 {
+  if (const char * why = profiler_preload())
+  {
+    // the tool library has initialised the GPU before main(): an exec from here takes the machine down on this pool
+    std::fprintf(stderr,
+                 "marlin-hip-bench: refusing to fork + exec %d rank processes under a profiler preload (%s is set): the preloaded tool "
+                 "has initialised the GPU in this process.  Profile ONE rank directly: rocprofv3 ... -- marlin-hip-bench gpus=%d rank=r "
+                 "job=<name> ... (start the other ranks unprofiled with the same job=), or run gpus=1.\n",
+                 nranks, why, nranks);
+    return 2;
+  }
   const std::string job = "job=mrlbench_" + std::to_string((long)getpid());
   std::vector<pid_t> kids;
   for (int r = 0; r < nranks; ++r)
@@ -889,8 +918,12 @@ int main(int argc, char ** argv)
     std::fprintf(stderr, "1 <= gpus <= 64\n");
     return 2;
   }
-  if (!g_args.count("rank"))
+  if (!g_args.count("rank") && gpus > 1)
     return launch_ranks(argc, argv, gpus);  // nothing has touched the GPU yet
+  // gpus == 1 without rank=: this process IS the rank -- no fork, no exec (safe under rocprofv3, whose preload initialises the GPU
+  // before main)
+  if (!g_args.count("job"))
+    g_args["job"] = "mrlbench_" + std::to_string((long)getpid());
 
   Rank R;
   R.world = gpus;

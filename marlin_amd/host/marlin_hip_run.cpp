@@ -27,6 +27,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 
@@ -897,6 +898,15 @@ static int launch_ranks(int argc, char ** argv, int nranks)
 {
   if (nranks < 1 || nranks > 64)
     paramError("nranks", "1 <= nranks <= 64");
+  // a profiler preload (rocprofv3) initialises the GPU before main(): an exec from such a process takes the machine down on this
+  // pool.  Profile one `rank=r job=<name>` process directly instead (the other ranks started unprofiled with the same job name).
+  for (const char * var : {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD"})
+  {
+    const char * v = std::getenv(var);
+    if (v && (std::strstr(v, "rocprof") || std::strstr(v, "roctracer")))
+      mooseError(std::string("refusing to fork + exec rank processes under a profiler preload (") + var +
+                 " is set): profile one rank=r job=<name> process directly");
+  }
   const std::string job = "job=mrlrun_" + std::to_string((long)getpid());
   std::vector<pid_t> kids;
   for (int r = 0; r < nranks; ++r)

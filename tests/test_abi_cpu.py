@@ -78,6 +78,27 @@ def test_bench_launch_chain_refuses_without_touching_a_gpu():
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_launchers_refuse_to_exec_rank_processes_under_a_profiler_preload():
+    """a profiler preload (rocprofv3) initialises the GPU before main(); the fork + exec of rank processes from such a
+    process takes the machine down on this pool.  bench.py --gpus N, marlin-hip-bench gpus=N and marlin-hip-run nranks=N all refuse
+    (rc != 0, a message that says what to profile instead) BEFORE anything is started -- checked with the variables a preload sets,
+    no profiler involved."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ROCP_TOOL_LIBRARIES"] = "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 2 and "profiler preload" in r.stderr, (r.returncode, r.stderr[-400:])
+    for exe, argv in (("marlin-hip-bench", ["gpus=2", "steps=1", "warmup=0"]),
+                      ("marlin-hip-run", ["problem=cahnhilliard", "dim=2", "nx=20", "ny=20", "parallel_mode=FFT_SLAB", "nranks=2"])):
+        path = os.path.join(ROOT, "marlin_amd", "lib", exe)
+        if not os.path.exists(path):
+            pytest.skip(f"{exe} has not been built")
+        r = subprocess.run([path] + argv, capture_output=True, text=True, timeout=60, env=env, cwd=ROOT)
+        assert r.returncode != 0 and "profiler preload" in r.stderr, (exe, r.returncode, r.stderr[-400:])
+
+
 def test_lds_conflict_model_reproduces_the_measured_shares():
     """tools/lds_conflict_model.py (the bank model behind LineMapParams): the old line map of the 512-point z kernels costs
     40 % conflict cycles (measured: 41-47 %), the adopted xor swizzle none; the 256-point plan was and stays conflict-free"""
