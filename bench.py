@@ -554,6 +554,9 @@ def main():
         if not native_failed:
             solver.reset()
             prof_ctx = solver.ctx
+
+            def reset_state():
+                solver.reset()
         else:
             # the library's transports do not work in these processes.  The torch.distributed driver (marlin_amd/slab.py) is only
             # ever entered through an explicit --driver python, and in FRESH processes (a communicator whose IPC mapping was abandoned
@@ -586,6 +589,9 @@ def main():
         solver.set_initial(lambda count, offset: splitmix64_uniform(count, offset=offset))
         prof_ctx = solver.ctx
         transport_report = dict(transport_report or {}, selected=f"torch.distributed {args.backend} all_to_all_single")
+
+        def reset_state():
+            solver.reset(lambda count, offset: splitmix64_uniform(count, offset=offset))
     if not slab:
         nsub = 0
         ctx = api.Context(3, shape, L, dense_spectra=args.dense_spectra)
@@ -605,6 +611,8 @@ def main():
             c[0].copy_(ic)
             state.update({"i": 0, "have_old": False})
             ring.update({"head": 1, "n_old": 0})
+
+        reset_state = reset_serial
 
         def step():
             i = state["i"]
@@ -704,10 +712,15 @@ def main():
     kernels = prof_ctx.get_profile()
     prof_ctx.set_profiling(False)
 
-    # the global field checksum (all ranks take part): lets two drivers / transports be compared from their JSON lines
+    # the global field checksum (all ranks take part): lets two drivers / transports be compared from their JSON lines.  Taken after a
+    # DETERMINISTIC number of substeps from the initial condition (the timed protocol above runs a box-dependent number of warm-up
+    # regions): warmup + steps substeps, in calls of `per_call`, exactly as marlin-hip-bench does
+    reset_state()
+    cs_after = args.warmup + args.steps
+    run(cs_after)
+    torch.cuda.synchronize()
     cur = current()
     cs = host_sum(float((cur * cur).sum(dtype=torch.float64).item()))
-    cs_after = substeps_done["n"]
 
     variants = {}
     if not args.no_variants and slab and comm is not None:

@@ -67,12 +67,26 @@ typedef struct mrl_domain {
 #define MRL_FLAG_OWN_STREAM 1 /* the context creates (and owns) a non-blocking stream; `stream` is ignored */
 #define MRL_FLAG_SLAB 2       /* slab context even with nranks = 1 (the staged mrl_slab_* pipeline on one rank; exchanges are self-copies) */
 #define MRL_FLAG_DENSE_SPECTRA 4 /* the Cahn-Hilliard history arrays of this context are dense [nx][ny][nzc] (see mrl_ch_spec_elems) */
+#define MRL_FLAG_PENCIL 8        /* parallel_mode = FFT_PENCIL (DomainAction::partitionPencils, DomainAction.C:568-742): 3-D only,
+                                    nranks = py * pz with both factors >= 2 (the reference's choice: mrl_pencil_factors).  Real space
+                                    [nx][ny / py][nz / pz] (rank r: y block r % py, z block r / py); reciprocal space
+                                    [(nx/2+1) / py][ny / pz][nz]: the r2c transform runs along X (DomainAction.C:282-284), kx is split
+                                    over py, ky over pz, kz is complete.  mrl_fft_r2c / mrl_fft_c2r are DomainAction::fftPencil /
+                                    ifftPencil (:1021-1047) with their four staged exchanges (:1105-1404) owned by the library;
+                                    reductions are global, pointwise entry points (mrl_parsed_*, mrl_axpby, ...) work on the local
+                                    blocks; the fused solver entry points (mrl_ch_substep(s), mrl_mech_*) return MRL_ERR_UNSUPPORTED */
 
 /* ---- context ------------------------------------------------------------------------ */
 int mrl_abi_version(void);
 /* DomainAction::DomainAction + gridChanged + partitionSlabs */
 int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom);
 void mrl_ctx_destroy(mrl_ctx *ctx);
+/* DomainAction::partitionPencils' choice of the process grid (DomainAction.C:574-618): among the factorisations nranks = py * pz with
+ * py, pz >= 2, py <= min(ny, nx/2+1), pz <= min(nz, ny), the one with the smallest |py - pz| (first found wins).  Host only.
+ * MRL_ERR_INVALID with the reference's message when no factorisation fits. */
+int mrl_pencil_factors(int32_t nranks, const int64_t n[3], int32_t *py, int32_t *pz);
+/* the process grid of a pencil context (MRL_ERR_INVALID on other contexts) */
+int mrl_pencil_grid(const mrl_ctx *ctx, int32_t *py, int32_t *pz);
 /* message of the last failing call on ctx (ctx may be NULL: failure of mrl_ctx_create) */
 const char *mrl_last_error(const mrl_ctx *ctx);
 /* hipStreamSynchronize on the context stream */

@@ -42,6 +42,18 @@ def reciprocal_axis(n: int, dx: float, rfft: bool) -> List[float]:
     return list(out)
 
 
+def pencil_factors(nranks: int, n: Sequence[int]):
+    """DomainAction::partitionPencils' process grid (py, pz) for `nranks` ranks on an nx x ny x nz grid (host only); raises
+    MarlinHipError with the reference's message when no factorisation fits"""
+    lib = _lib.load()
+    nn = (C.c_int64 * 3)(*[int(v) for v in n])
+    py, pz = C.c_int32(), C.c_int32()
+    rc = lib.mrl_pencil_factors(nranks, nn, C.byref(py), C.byref(pz))
+    if rc != 0:
+        raise MarlinHipError(rc, lib.mrl_last_error(None).decode())
+    return py.value, pz.value
+
+
 def partition(total: int, nranks: int, weights: Optional[Sequence[int]] = None) -> List[int]:
     lib = _lib.load()
     out = (C.c_int64 * nranks)()
@@ -142,7 +154,7 @@ class Context:
     def __init__(self, dim: int, n: Sequence[int], mx: Sequence[float], mn: Sequence[float] = (0.0, 0.0, 0.0),
                  nranks: int = 1, rank: int = 0, weights: Optional[Sequence[int]] = None,
                  spectrum: int = SPECTRUM_HALF, device: Optional[int] = None, use_torch_stream: bool = True,
-                 slab: bool = False, dense_spectra: bool = False):
+                 slab: bool = False, dense_spectra: bool = False, pencil: bool = False):
         self.lib = _lib.load()
         d = MrlDomain()
         d.dim = dim
@@ -158,7 +170,8 @@ class Context:
         d.weights = self._weights
         d.spectrum = spectrum
         d.stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if use_torch_stream else None
-        d.flags = (0 if use_torch_stream else 1) | (2 if slab else 0) | (4 if dense_spectra else 0)  # MRL_FLAG_OWN_STREAM | _SLAB | _DENSE_SPECTRA
+        # MRL_FLAG_OWN_STREAM | _SLAB | _DENSE_SPECTRA | _PENCIL
+        d.flags = (0 if use_torch_stream else 1) | (2 if slab else 0) | (4 if dense_spectra else 0) | (8 if pencil else 0)
         h = C.c_void_p()
         rc = self.lib.mrl_ctx_create(C.byref(h), C.byref(d))
         if rc != 0:
@@ -173,6 +186,11 @@ class Context:
         self.recip_shape = [kn[i] for i in range(dim)]
         self.recip_begin = [kb[i] for i in range(dim)]
         self.nranks, self.rank = nranks, rank
+        self.pencil_grid = None
+        if pencil:   # (py, pz) of DomainAction::partitionPencils
+            py, pz = C.c_int32(), C.c_int32()
+            self._check(self.lib.mrl_pencil_grid(h, C.byref(py), C.byref(pz)))
+            self.pencil_grid = (py.value, pz.value)
 
     def close(self):
         if getattr(self, "h", None):

@@ -324,6 +324,7 @@ int mrl_ch_mu(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c, double *d
 int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_c_out, double *d_Nhat_new,
                    const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar, double *d_mu, int carry) {
   if (!ctx) return MRL_ERR_INVALID;
+  MRL_NO_PENCIL(ctx, "mrl_ch_substep");
   ChP cp;
   MRL_TRY(ch_check_params(ctx, p, cp));
   if (!d_c_in || !d_c_out || !d_Nhat_new) return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substep: null buffer");
@@ -459,6 +460,7 @@ int mrl_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, 
                     int ring_size, int *head, int *n_old, int predictor_order, int count, int advance, double sub_dt,
                     double *d_mu) {
   if (!ctx) return MRL_ERR_INVALID;
+  MRL_NO_PENCIL(ctx, "mrl_ch_substeps");
   ChP cp;
   MRL_TRY(ch_check_params(ctx, p, cp));
   const int pred = predictor_order - 1;

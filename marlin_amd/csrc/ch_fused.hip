@@ -17,7 +17,7 @@ namespace mrl {
 // 3-D grids [nx][ny][nz], and 2-D grids [nx][nz'] run as [nx][1][nz'] (serial contexts hold them as internal axes
 // (1, nx, ny_user): the user's y is the contiguous r2c axis; the absent middle axis contributes k = 0 exactly)
 bool fast_path_ok(const mrl_ctx *ctx) {
-  if (ctx->slab || ctx->spectrum != MRL_SPECTRUM_HALF) return false;
+  if (ctx->slab || ctx->pencil || ctx->spectrum != MRL_SPECTRUM_HALF) return false;
   if (ctx->exp & 2048) return false;  // experiment: planned shapes through the any-length path (A/B and parity at sizes the oracle cannot reach)
   // the fused kernels address one spectral array with 32-bit byte offsets from its base (ch_fused_body.h); arrays of 4 GiB and
   // more need the 64-bit variant (x lengths 512 / 768 / 1000 / 1024) and a per-lane part (one line stride) below 4 GiB

@@ -38,7 +38,7 @@ static long long f32_plane(const mrl_ctx *ctx) {
 }
 
 static bool f32_ok(const mrl_ctx *ctx) {
-  return !ctx->slab && ctx->dim == 3 && ctx->spectrum == MRL_SPECTRUM_HALF && f32_len_ok(ctx->n[0]) && f32_len_ok(ctx->n[1]) &&
+  return !ctx->slab && !ctx->pencil && ctx->dim == 3 && ctx->spectrum == MRL_SPECTRUM_HALF && f32_len_ok(ctx->n[0]) && f32_len_ok(ctx->n[1]) &&
          f32_len_ok(ctx->n[2]) && 8.0 * (double)ctx->n[0] * (double)f32_plane(ctx) < 4294967296.0;
 }
 

@@ -209,6 +209,40 @@ static int partition(long long total, int nranks, const int64_t *weights, std::v
   return MRL_OK;
 }
 
+// DomainAction::partitionPencils, the choice of the process grid (DomainAction.C:574-618)
+static bool pencil_factors(int nranks, long long nx, long long ny, long long nz, int *py_out, int *pz_out) {
+  const long long nxc = nx / 2 + 1;
+  auto can_use = [&](long long px, long long pz) {
+    if (px < 2 || pz < 2) return false;
+    if (px > ny || px > nxc) return false;
+    if (pz > nz || pz > ny) return false;
+    return true;
+  };
+  bool found = false;
+  long long best_px = 0, best_pz = 0, best_cost = 0;
+  auto consider = [&](long long px, long long pz) {
+    if (!can_use(px, pz)) return;
+    const long long cost = px > pz ? px - pz : pz - px;
+    if (!found || cost < best_cost) {
+      best_px = px;
+      best_pz = pz;
+      best_cost = cost;
+      found = true;
+    }
+  };
+  long long max_divisor = (long long)std::sqrt((double)nranks);
+  if (max_divisor < 2) max_divisor = 2;
+  for (long long d = 2; d <= max_divisor; ++d)
+    if (nranks % d == 0) {
+      consider(d, nranks / d);
+      consider(nranks / d, d);
+    }
+  if (!found) return false;
+  *py_out = (int)best_px;
+  *pz_out = (int)best_pz;
+  return true;
+}
+
 }  // namespace mrl
 
 using namespace mrl;
@@ -216,6 +250,26 @@ using namespace mrl;
 extern "C" {
 
 int mrl_abi_version(void) { return MRL_ABI_VERSION; }
+
+int mrl_pencil_factors(int32_t nranks, const int64_t n[3], int32_t *py, int32_t *pz) {
+  if (!n || !py || !pz || nranks < 1) return set_error(nullptr, MRL_ERR_INVALID, "mrl_pencil_factors: bad argument");
+  int a = 0, b = 0;
+  if (!pencil_factors(nranks, n[0], n[1], n[2], &a, &b))
+    return set_error(nullptr, MRL_ERR_INVALID,
+                     "FFT_PENCIL requires factoring the number of MPI ranks into two integers greater than one that fit the domain "
+                     "(ranks = %d). Use FFT_SLAB or adjust the rank count.", nranks);
+  *py = a;
+  *pz = b;
+  return MRL_OK;
+}
+
+int mrl_pencil_grid(const mrl_ctx *ctx, int32_t *py, int32_t *pz) {
+  if (!ctx) return MRL_ERR_INVALID;
+  if (!ctx->pencil) return set_error(ctx, MRL_ERR_INVALID, "mrl_pencil_grid: not a pencil context");
+  if (py) *py = ctx->pen_py;
+  if (pz) *pz = ctx->pen_pz;
+  return MRL_OK;
+}
 
 const char *mrl_last_error(const mrl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -243,7 +297,19 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
   if (dom->dim < 1 || dom->dim > 3) return set_error(nullptr, MRL_ERR_INVALID, "Unsupported mesh dimension %d", dom->dim);
   if (dom->nranks < 1 || dom->rank < 0 || dom->rank >= dom->nranks)
     return set_error(nullptr, MRL_ERR_INVALID, "invalid rank %d of %d", dom->rank, dom->nranks);
-  const bool slab = dom->nranks > 1 || (dom->flags & MRL_FLAG_SLAB);
+  const bool pencil = (dom->flags & MRL_FLAG_PENCIL) != 0;
+  int pen_py = 1, pen_pz = 1;
+  if (pencil) {
+    if (dom->dim < 3) return set_error(nullptr, MRL_ERR_INVALID, "Dimension must be 3 for pencil decomposition.");  // DomainAction.C:571-572
+    if (dom->spectrum != MRL_SPECTRUM_HALF) return set_error(nullptr, MRL_ERR_UNSUPPORTED, "FFT_PENCIL needs spectrum = MRL_SPECTRUM_HALF (r2c along x)");
+    if (dom->weights) return set_error(nullptr, MRL_ERR_UNSUPPORTED, "FFT_PENCIL partitions with equal weights (DomainAction.C:633-637)");
+    if (dom->nranks > 64) return set_error(nullptr, MRL_ERR_UNSUPPORTED, "at most 64 ranks");
+    if (!pencil_factors(dom->nranks, dom->n[0], dom->n[1], dom->n[2], &pen_py, &pen_pz))
+      return set_error(nullptr, MRL_ERR_INVALID,
+                       "FFT_PENCIL requires factoring the number of MPI ranks into two integers greater than one that fit the domain "
+                       "(ranks = %d). Use FFT_SLAB or adjust the rank count.", dom->nranks);
+  }
+  const bool slab = !pencil && (dom->nranks > 1 || (dom->flags & MRL_FLAG_SLAB));
   if (slab && dom->dim < 2)
     return set_error(nullptr, MRL_ERR_INVALID, "Dimension must be 2 or 3 for slab decomposition.");
   if (slab && dom->dim == 2 && dom->spectrum != MRL_SPECTRUM_FULL)
@@ -268,10 +334,13 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
   c->nranks = dom->nranks;
   c->rank = dom->rank;
   c->slab = slab;
+  c->pencil = pencil;
+  c->pen_py = pen_py;
+  c->pen_pz = pen_pz;
   // internal axes: serial contexts right-align the user axes (the r2c axis is always A2); slab
   // contexts left-align them so that x = A0 is the reciprocal split axis and y = A1 the real-space
   // split axis in 2-D and 3-D alike (a 2-D slab domain is [nx][ny][1]).
-  c->off = c->slab ? 0 : 3 - c->dim;
+  c->off = (c->slab || c->pencil) ? 0 : 3 - c->dim;
   const int off = c->off;
   for (int a = 0; a < 3; ++a) {
     c->n[a] = 1;
@@ -325,7 +394,8 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
       c->h_k[a] = {0.0};  // DomainAction.C:295-296
       c->nrec_glob[a] = 1;
     } else {
-      const bool rfft = (a == 2) && c->spectrum == MRL_SPECTRUM_HALF;
+      // r2c axis: the last one (parallel_mode NONE, and this library's slab mode); FFT_PENCIL: x (DomainAction.C:282-284)
+      const bool rfft = c->pencil ? (a == 0) : ((a == 2) && c->spectrum == MRL_SPECTRUM_HALF);
       reciprocal_axis(c->n[a], c->dx[a], rfft, c->h_k[a]);
       c->nrec_glob[a] = (long long)c->h_k[a].size();
     }
@@ -374,6 +444,28 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
     c->nrec[c->split_recip_axis] = c->part_recip[c->rank];
   }
 
+  if (c->pencil) {  // DomainAction::partitionPencils (DomainAction.C:620-698)
+    const int py = c->rank % c->pen_py, pz = c->rank / c->pen_py;
+    if (partition(c->n[1], c->pen_py, nullptr, c->pen_y) != MRL_OK || partition(c->n[2], c->pen_pz, nullptr, c->pen_z) != MRL_OK ||
+        partition(c->nrec_glob[0], c->pen_py, nullptr, c->pen_kx) != MRL_OK || partition(c->nrec_glob[1], c->pen_pz, nullptr, c->pen_ky) != MRL_OK) {
+      set_error(c, MRL_ERR_INVALID, "Internal partitioning error.");
+      return fail(MRL_ERR_INVALID);
+    }
+    auto begin_of = [](const std::vector<long long> &v, int i) {
+      long long b = 0;
+      for (int r = 0; r < i; ++r) b += v[r];
+      return b;
+    };
+    c->nloc[1] = c->pen_y[py];
+    c->rbeg[1] = begin_of(c->pen_y, py);
+    c->nloc[2] = c->pen_z[pz];
+    c->rbeg[2] = begin_of(c->pen_z, pz);
+    c->nrec[0] = c->pen_kx[py];   // (px = rank % py partitions, :689-693)
+    c->kbeg[0] = begin_of(c->pen_kx, py);
+    c->nrec[1] = c->pen_ky[pz];   // (py_final = rank / py partitions, :690-697)
+    c->kbeg[1] = begin_of(c->pen_ky, pz);
+  }
+
   for (int a = 0; a < 3 && rc == MRL_OK; ++a) {
     rc = build_axis(c, c->ax[a], c->n[a]);
     if (rc != MRL_OK) break;
@@ -393,7 +485,7 @@ int mrl_ctx_create(mrl_ctx **out, const mrl_domain *dom) {
   if (rc != MRL_OK) return fail(rc);
 
   // solver-private spectral layout of the fused serial path (mrl_ch_spec_elems): x planes padded to an odd number of 256-byte pieces
-  if (!c->slab && c->dim == 3 && !(dom->flags & MRL_FLAG_DENSE_SPECTRA) && fast_path_ok(c) && (c->n[0] * c->n[1]) % 2 == 0) {
+  if (!c->slab && !c->pencil && c->dim == 3 && !(dom->flags & MRL_FLAG_DENSE_SPECTRA) && fast_path_ok(c) && (c->n[0] * c->n[1]) % 2 == 0) {
     const long long inner = c->n[1] * c->nrec[2];
     long long plane = (inner + 15) / 16 * 16;
     if ((plane / 16) % 2 == 0) plane += 16;
@@ -436,6 +528,8 @@ void mrl_ctx_destroy(mrl_ctx *c) {
   if (c->d_red) hipFree(c->d_red);
   if (c->h_red) hipHostFree(c->h_red);
   if (c->ev_start) hipEventDestroy(c->ev_start);
+  for (int e = 0; e < 2; ++e)
+    if (c->cg_ev[e]) hipEventDestroy(c->cg_ev[e]);
   if (c->ev_stop) hipEventDestroy(c->ev_stop);
   for (auto &p : c->prof_events) {
     hipEventDestroy(p.first);

@@ -788,10 +788,15 @@ static int build_mu_function(mrl_parsed *p, std::string &out) {
 }
 
 // lines per workgroup / threads per workgroup of the z kernels (ZPlan<N>, fft_pow2.h)
-static int plan_shape(mrl_ctx *ctx, int N, int *T, int *NT, size_t *lds) {
+// (ea: the fused inverse + forward kernel, ZPlanEA<N>)
+static int plan_shape(mrl_ctx *ctx, int N, int *T, int *NT, size_t *lds, bool ea = false) {
   *T = 0;
   if (!pow2_ok(N)) return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
-  MRL_SWITCH_N(N, (*T = p2::ZPlan<NN>::T, *NT = p2::ZPlan<NN>::NT, *lds = p2::lds_line<NN>()));
+  if (ea) {
+    MRL_SWITCH_N(N, (*T = p2::ZPlanEA<NN>::T, *NT = p2::ZPlanEA<NN>::NT, *lds = p2::lds_line_ea<NN>()));
+  } else {
+    MRL_SWITCH_N(N, (*T = p2::ZPlan<NN>::T, *NT = p2::ZPlan<NN>::NT, *lds = p2::lds_line<NN>()));
+  }
   if (*T == 0) return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
   return MRL_OK;
 }
@@ -885,7 +890,7 @@ int parsed_z_inv_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const cplx *in, 
                             double scale, long long nlines, bool mu_only, unsigned lay_lpp, unsigned lay_pad) {
   int T = 0, NT = 0;
   size_t lds = 0;  // twiddle table + the line tile of the z kernels (MapLine<N>)
-  MRL_TRY(plan_shape(ctx, N, &T, &NT, &lds));
+  MRL_TRY(plan_shape(ctx, N, &T, &NT, &lds, true));
   hipFunction_t fn;
   MRL_TRY(parsed_z_kernel(ctx, p, N, mu_only ? 4 : 3, &fn));
   ChDevHost chp = parsed_chdev(p);

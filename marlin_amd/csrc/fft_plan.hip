@@ -87,7 +87,7 @@ int pass_strided(mrl_ctx *ctx, int a, int sign, const double *d_in, double *d_ou
 // c2c pass along `axis` over an explicit set of lines: line (o, i), o < outer, i < inner, starts at o*so + i*si,
 // successive points are sn apart (complex elements); used on kz sub-ranges by the slab pipeline
 int pass_lines(mrl_ctx *ctx, int axis, int sign, const double *in, double *out, long long outer, long long inner,
-               long long so, long long si, long long sn) {
+               long long so, long long si, long long sn, int lines_fastest) {
   PassDesc d{};
   fill_radix(d, ctx->ax[axis], sign);
   d.inner = inner;
@@ -96,7 +96,7 @@ int pass_lines(mrl_ctx *ctx, int axis, int sign, const double *in, double *out, 
   d.in_si = d.out_si = si;
   d.in_sn = d.out_sn = sn;
   d.in_sb = d.out_sb = 0;
-  d.lines_fastest = 1;
+  d.lines_fastest = lines_fastest;
   return launch_pass(ctx, d, in, out, ctx->ax[axis].d_tw, 1);
 }
 
@@ -170,6 +170,8 @@ int fft_forward_planned(mrl_ctx *ctx, const double *d_in, double *d_out, long lo
 int fft_inverse_planned(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
 int slab_fft_forward(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);   // slab_driver.hip
 int slab_fft_inverse(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
+int pencil_fft_forward(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
+int pencil_fft_inverse(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
 
 }  // namespace mrl
 
@@ -181,6 +183,10 @@ int mrl_fft_r2c(mrl_ctx *ctx, const double *d_in, double *d_out, int64_t batch, 
   if (!ctx) return MRL_ERR_INVALID;
   if (!d_in || !d_out || batch < 1 || (layout != 0 && layout != 1))
     return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_r2c: bad argument");
+  if (ctx->pencil) {  // DomainAction::fftPencil (DomainAction.C:1021-1034)
+    if (layout == 1 && batch > 1) return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_fft_r2c on a pencil context: field-major batches only");
+    return pencil_fft_forward(ctx, d_in, d_out, batch);
+  }
   if (ctx->slab) {  // DomainAction::fftSlab with the library-owned exchange (communicator attached)
     if (layout == 1 && batch > 1) return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_fft_r2c on a slab context: field-major batches only");
     return slab_fft_forward(ctx, d_in, d_out, batch);
@@ -194,6 +200,10 @@ int mrl_fft_c2r(mrl_ctx *ctx, const double *d_in, double *d_out, int64_t batch, 
   if (!ctx) return MRL_ERR_INVALID;
   if (!d_in || !d_out || batch < 1 || (layout != 0 && layout != 1))
     return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_c2r: bad argument");
+  if (ctx->pencil) {  // DomainAction::ifftPencil (DomainAction.C:1036-1047)
+    if (layout == 1 && batch > 1) return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_fft_c2r on a pencil context: field-major batches only");
+    return pencil_fft_inverse(ctx, d_in, d_out, batch);
+  }
   if (ctx->slab) {  // DomainAction::ifftSlab
     if (layout == 1 && batch > 1) return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_fft_c2r on a slab context: field-major batches only");
     return slab_fft_inverse(ctx, d_in, d_out, batch);

@@ -135,6 +135,17 @@ template <>
 struct ZPlan<256> {
   static constexpr int T = 8, NT = 8 * Plan<256>::TPL;
 };
+// ... and of the fused inverse + forward z kernel (k_z_inv_fwd): three transforms between one burst of loads and the stores, so more,
+// smaller workgroups in different phases pay at 512 points (tools/zpass_probe.hip, same box: 8 -> 4 lines 84.7 -> 82.1 us on the
+// slab-local 512^3 / 8 arrays; 256 points: 72.2 vs 71.2 us, within the noise: unchanged)
+template <int N>
+struct ZPlanEA {
+  static constexpr int T = ZPlan<N>::T, NT = ZPlan<N>::NT;
+};
+template <>
+struct ZPlanEA<512> {
+  static constexpr int T = 4, NT = 4 * Plan<512>::TPL;
+};
 #undef MRL_PLAN
 
 __device__ __forceinline__ void bfly4(kcplx &a0, kcplx &a1, kcplx &a2, kcplx &a3) {

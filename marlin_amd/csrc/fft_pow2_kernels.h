@@ -53,6 +53,149 @@ __device__ __forceinline__ kreal mu_eval(const ChDev &p, kreal c) {
 }
 
 
+
+// ---------------------------------------------------------------------------------------------
+// Lane exchange for the k <-> N - k pairing of the z kernels (round 4).  A line is owned by TPL consecutive lanes (register m of
+// lane q = position q + m TPL), so position N - k of the line lives in lane (TPL - q) % TPL of the SAME wave, register P - 1 - m (lane
+// 0: its own register P - m).  ds_bpermute moves it there without touching LDS memory: the forward kernels lose their natural-order
+// copy (one of two LDS round trips per transform at 256 points, one of three at 512), the inverse kernels load every spectral element
+// once instead of twice (the mirrored half came through L1 again and cost 64 VGPRs of landing space).  Same operands, same
+// operations: bit-identical results.  tools/zpass_probe.hip, same box: k_z_inv_fwd<256> 77.5 -> 72.2 us, <512> 88 -> 85 us.
+template <int N>
+constexpr bool lane_pair_ok() {
+  constexpr int TPL = Plan<N>::TPL;
+  return TPL <= 64 && (TPL & (TPL - 1)) == 0 && Plan<N>::P % 2 == 0;   // (power of two <= 64: a line never straddles two waves)
+}
+__device__ __forceinline__ double lane_get(double x, int src) {
+  union {
+    double d;
+    int i[2];
+  } u;
+  u.d = x;
+  u.i[0] = __builtin_amdgcn_ds_bpermute(src << 2, u.i[0]);
+  u.i[1] = __builtin_amdgcn_ds_bpermute(src << 2, u.i[1]);
+  return u.d;
+}
+__device__ __forceinline__ float lane_get(float x, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ kcplx lane_get(kcplx x, int src) { return mkc(lane_get(x.x, src), lane_get(x.y, src)); }
+// lane (of the wave) that holds positions N - k of the line of lane-in-line q
+template <int N>
+__device__ __forceinline__ int lane_partner(int q) {
+  constexpr int TPL = Plan<N>::TPL;
+  return (int)(threadIdx.x & 63u) - q + ((TPL - q) & (TPL - 1));
+}
+
+// v = transform of the packed line x = a + i b (registers q + m TPL): store the half spectra of a (o0) and b (o1), k = 0 .. N/2.
+// Every lane of the line must call it (the exchange is wave-wide); `X`, `l` are only used by the LDS fallback (other lengths).
+template <int N, class Map>
+__device__ __forceinline__ void store_half_spectra(const kcplx (&v)[Plan<N>::P], int q, int l, kcplx *X, bool valid, kcplx *o0, kcplx *o1) {
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL;
+  if constexpr (lane_pair_ok<N>()) {
+    const int partner = lane_partner<N>(q);
+#pragma unroll
+    for (int m = 0; m < P / 2; ++m) {
+      const int k = q + m * TPL;
+      const kcplx s = lane_get(v[P - 1 - m], partner);
+      const kcplx own = v[(P - m) % P];
+      const kcplx xk = v[m];
+      const kcplx xn = mkc(q == 0 ? own.x : s.x, q == 0 ? own.y : s.y);
+      if (valid) {
+        o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
+        o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
+      }
+    }
+    if (q == 0 && valid) {  // the Nyquist bin pairs with itself
+      const kcplx xk = v[P / 2];
+      o0[N / 2] = mkc(kreal(0.5) * (xk.x + xk.x), kreal(0.5) * (xk.y - xk.y));
+      o1[N / 2] = mkc(kreal(0.5) * (xk.y + xk.y), kreal(-0.5) * (xk.x - xk.x));
+    }
+  } else {
+    // natural-order copy in LDS for the k <-> N-k pairing
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
+    __syncthreads();
+    if (!valid) return;
+#pragma unroll
+    for (int m = 0; m <= P / 2; ++m) {
+      const int k = q + m * TPL;
+      if (k > N / 2) break;  // (only q = 0 owns the Nyquist bin)
+      const kcplx xk = v[m];
+      const kcplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
+      o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
+      o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
+    }
+  }
+}
+
+// The inverse of it on the load side: half spectra A, B of two real lines -> v = swap(X), X[p] = A[p] + i B[p] for p <= N/2 and
+// conj(A[N-p]) + i conj(B[N-p]) beyond (the swap turns the forward transform that follows into the inverse one); the twiddle table
+// is committed to LDS while the loads are in flight.
+template <int N, int NTH>
+__device__ __forceinline__ void load_half_spectra(kcplx (&v)[Plan<N>::P], int q, const kcplx *A, const kcplx *B, const TwRegs<N, NTH> &twr,
+                                                  kcplx *W) {
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL;
+  if constexpr (lane_pair_ok<N>()) {
+    const int partner = lane_partner<N>(q);
+    kcplx av[P / 2], bv[P / 2];
+#pragma unroll
+    for (int m = 0; m < P / 2; ++m) {
+      av[m] = A[q + m * TPL];
+      bv[m] = B[q + m * TPL];
+    }
+    kcplx aN = A[q == 0 ? N / 2 : q], bN = B[q == 0 ? N / 2 : q];  // Nyquist bin: lane 0 (the others re-read an element they hold)
+    tw_commit<N>(twr, W);
+    kcplx yh[P / 2];
+#pragma unroll
+    for (int m = 0; m < P / 2; ++m) {
+      kcplx a = av[m], b = bv[m];
+      // for position N - k (k = q + m TPL, never 0 or N/2 in the lanes that use it): conj(A[k]) + i conj(B[k])
+      yh[m] = cswap(mkc(a.x + b.y, b.x - a.y));
+      if (m == 0) {  // k = 0 (lane 0): c2r ignores the imaginary part of the self-conjugate bins
+        a.y = q == 0 ? kreal(0.0) : a.y;
+        b.y = q == 0 ? kreal(0.0) : b.y;
+      }
+      v[m] = cswap(mkc(a.x - b.y, a.y + b.x));
+    }
+    aN.y = 0.0;
+    bN.y = 0.0;
+    const kcplx vN = cswap(mkc(aN.x - bN.y, aN.y + bN.x));
+#pragma unroll
+    for (int m = P / 2; m < P; ++m) {
+      // position p = q + m TPL > N/2 is held by the partner lane as yh[P - 1 - m]; lane 0: p = m TPL, its own yh[P - m] (m = P/2: Nyquist)
+      const kcplx s = lane_get(yh[P - 1 - m], partner);
+      const kcplx own = (m == P / 2) ? vN : yh[(P - m) % (P / 2)];
+      v[m] = mkc(q == 0 ? own.x : s.x, q == 0 ? own.y : s.y);
+    }
+  } else {
+    kcplx av[P], bv[P];
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      const int p = q + m * TPL;
+      const int k = (p <= N / 2) ? p : N - p;
+      av[m] = A[k];
+      bv[m] = B[k];
+    }
+    tw_commit<N>(twr, W);
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      const int p = q + m * TPL;
+      const bool lo = p <= N / 2;
+      const int k = lo ? p : N - p;
+      kcplx a = av[m], b = bv[m];
+      if (k == 0 || k == N / 2) {  // c2r ignores the imaginary part of the self-conjugate bins
+        a.y = 0.0;
+        b.y = 0.0;
+      }
+      // X[p] = A + iB (p <= N/2), conj(A[k]) + i conj(B[k]) otherwise ; then swap for the inverse
+      const kcplx x = lo ? mkc(a.x - b.y, a.y + b.x) : mkc(a.x + b.y, b.x - a.y);
+      v[m] = cswap(x);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // z forward.  MODE 0 (PAIR): rows 2L, 2L+1 of `in` -> rows 2L, 2L+1 of out0.
 //             MODE 1 (CH)  : row L of `in` (=c) -> row L of out0 (c-hat_z) and out1 (mu-hat_z);
@@ -116,23 +259,9 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_fwd(const kreal *__restri
     }
   }
   fft_line<N, Map>(v, q, l, X, W);
-  // natural-order copy in LDS for the k <-> N-k pairing
-  __syncthreads();
-#pragma unroll
-  for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
-  __syncthreads();
-  if (!valid) return;
-  kcplx *o0 = (MODE != 1) ? out0 + zrow(2 * L, NZC, zl) : out0 + zrow(L, NZC, zl);
-  kcplx *o1 = (MODE != 1) ? out0 + zrow(2 * L + 1, NZC, zl) : out1 + zrow(L, NZC, zl);
-#pragma unroll
-  for (int m = 0; m <= P / 2; ++m) {
-    const int k = q + m * TPL;
-    if (k > N / 2) break;  // (only q = 0 owns the Nyquist bin)
-    const kcplx xk = v[m];
-    const kcplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
-    o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
-    o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
-  }
+  kcplx *o0 = (MODE != 1) ? out0 + zrow(2 * Lc, NZC, zl) : out0 + zrow(Lc, NZC, zl);
+  kcplx *o1 = (MODE != 1) ? out0 + zrow(2 * Lc + 1, NZC, zl) : out1 + zrow(Lc, NZC, zl);
+  store_half_spectra<N, Map>(v, q, l, X, valid, o0, o1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -143,8 +272,9 @@ template <int N, bool DOT = false>
 __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const kcplx *__restrict__ in, kreal *__restrict__ out, kreal scale,
                                                long long nlines, const kcplx *__restrict__ tw,
                                                const kreal *__restrict__ dotv = nullptr, kreal *__restrict__ partial = nullptr,
-                                               ZLay zl = ZLay{0u, 0u}) {
+                                               ZLay zl = ZLay{0u, 0u}, const int *__restrict__ stop = nullptr) {
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = ZPlan<N>::T, NZC = N / 2 + 1;
+  if (stop && *stop) return;  // see PassArgs::stop
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   kcplx *W = reinterpret_cast<kcplx *>(smem);
@@ -155,33 +285,7 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const kcplx *__restri
   TwRegs<N, ZPlan<N>::NT> twr;
   tw_issue_staged<N>(twr, tw);
   kcplx v[P];
-  {
-    const kcplx *A = in + zrow(2 * (valid ? L : 0), NZC, zl);
-    const kcplx *B = in + zrow(2 * (valid ? L : 0) + 1, NZC, zl);
-    kcplx av[P], bv[P];
-#pragma unroll
-    for (int m = 0; m < P; ++m) {
-      const int p = q + m * TPL;
-      const int k = (p <= N / 2) ? p : N - p;
-      av[m] = A[k];
-      bv[m] = B[k];
-    }
-    tw_commit<N>(twr, W);
-#pragma unroll
-    for (int m = 0; m < P; ++m) {
-      const int p = q + m * TPL;
-      const bool lo = p <= N / 2;
-      const int k = lo ? p : N - p;
-      kcplx a = av[m], b = bv[m];
-      if (k == 0 || k == N / 2) {  // c2r ignores the imaginary part of the self-conjugate bins
-        a.y = 0.0;
-        b.y = 0.0;
-      }
-      // X[p] = A + iB (p <= N/2), conj(A[k]) + i conj(B[k]) otherwise ; then swap for the inverse
-      const kcplx x = lo ? mkc(a.x - b.y, a.y + b.x) : mkc(a.x + b.y, b.x - a.y);
-      v[m] = cswap(x);
-    }
-  }
+  load_half_spectra<N>(v, q, in + zrow(2 * (valid ? L : 0), NZC, zl), in + zrow(2 * (valid ? L : 0) + 1, NZC, zl), twr, W);
   fft_line<N, Map>(v, q, l, X, W);
   kreal acc = 0.0;
   if (valid) {
@@ -232,10 +336,10 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv(const kcplx *__restri
 // MU_ONLY (the spectral carry-over of the slab pipeline, where c-hat is not recomputed): the two lines of mu are packed into
 // ONE forward transform -> rows 2L, 2L+1 of out0 = mu-hat_z; out1 unused.
 template <int N, int FAM, bool MU_ONLY = false>
-__global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const kcplx *__restrict__ in, kcplx *__restrict__ out0,
-                                                                kcplx *__restrict__ out1, kreal *__restrict__ mu_out, ChDev chp,
-                                                                kreal scale, long long nlines, const kcplx *__restrict__ tw, ZLay zl) {
-  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = ZPlan<N>::T, NZC = N / 2 + 1;
+__global__ void __launch_bounds__(ZPlanEA<N>::NT, 2) k_z_inv_fwd(const kcplx *__restrict__ in, kcplx *__restrict__ out0,
+                                                                  kcplx *__restrict__ out1, kreal *__restrict__ mu_out, ChDev chp,
+                                                                  kreal scale, long long nlines, const kcplx *__restrict__ tw, ZLay zl) {
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = ZPlanEA<N>::T, NZC = N / 2 + 1;
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   kcplx *W = reinterpret_cast<kcplx *>(smem);
@@ -243,35 +347,11 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const kcplx *__re
   const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
   const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
   const bool valid = L < nlines;
-  TwRegs<N, ZPlan<N>::NT> twr;
+  TwRegs<N, ZPlanEA<N>::NT> twr;
   tw_issue_staged<N>(twr, tw);
+  const long long Lc = valid ? L : 0;  // out-of-range lanes transform line pair 0 again and store nothing
   kcplx v[P];
-  {
-    const kcplx *A = in + zrow(2 * (valid ? L : 0), NZC, zl);
-    const kcplx *B = in + zrow(2 * (valid ? L : 0) + 1, NZC, zl);
-    kcplx av[P], bv[P];
-#pragma unroll
-    for (int m = 0; m < P; ++m) {
-      const int p = q + m * TPL;
-      const int k = (p <= N / 2) ? p : N - p;
-      av[m] = A[k];
-      bv[m] = B[k];
-    }
-    tw_commit<N>(twr, W);
-#pragma unroll
-    for (int m = 0; m < P; ++m) {
-      const int p = q + m * TPL;
-      const bool lo = p <= N / 2;
-      const int k = lo ? p : N - p;
-      kcplx a = av[m], b = bv[m];
-      if (k == 0 || k == N / 2) {
-        a.y = 0.0;
-        b.y = 0.0;
-      }
-      const kcplx x = lo ? mkc(a.x - b.y, a.y + b.x) : mkc(a.x + b.y, b.x - a.y);
-      v[m] = cswap(x);
-    }
-  }
+  load_half_spectra<N>(v, q, in + zrow(2 * Lc, NZC, zl), in + zrow(2 * Lc + 1, NZC, zl), twr, W);
   fft_line<N, Map>(v, q, l, X, W);
   if constexpr (MU_ONLY) {
 #pragma unroll
@@ -285,22 +365,7 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const kcplx *__re
       }
     }
     fft_line<N, Map>(v, q, l, X, W);
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
-    __syncthreads();
-    if (valid) {
-      kcplx *o0 = out0 + zrow(2 * L, NZC, zl), *o1 = out0 + zrow(2 * L + 1, NZC, zl);
-#pragma unroll
-      for (int m = 0; m <= P / 2; ++m) {
-        const int k = q + m * TPL;
-        if (k > N / 2) break;
-        const kcplx xk = v[m];
-        const kcplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
-        o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
-        o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
-      }
-    }
+    store_half_spectra<N, Map>(v, q, l, X, valid, out0 + zrow(2 * Lc, NZC, zl), out0 + zrow(2 * Lc + 1, NZC, zl));
     return;
   }
   kreal cb[P];  // second line (row 2L+1), kept while the first one is transformed
@@ -324,22 +389,7 @@ __global__ void __launch_bounds__(ZPlan<N>::NT, 2) k_z_inv_fwd(const kcplx *__re
       for (int m = 0; m < P; ++m) pm[m * TPL] = v[m].y;
     }
     fft_line<N, Map>(v, q, l, X, W);
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
-    __syncthreads();
-    if (valid) {
-      kcplx *o0 = out0 + zrow(2 * L + half, NZC, zl), *o1 = out1 + zrow(2 * L + half, NZC, zl);
-#pragma unroll
-      for (int m = 0; m <= P / 2; ++m) {
-        const int k = q + m * TPL;
-        if (k > N / 2) break;
-        const kcplx xk = v[m];
-        const kcplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
-        o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
-        o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
-      }
-    }
+    store_half_spectra<N, Map>(v, q, l, X, valid, out0 + zrow(2 * Lc + half, NZC, zl), out1 + zrow(2 * Lc + half, NZC, zl));
   }
 }
 
@@ -356,6 +406,8 @@ struct PassArgs {
   int tiles_per_outer;
   kreal scale;
   int reverse;  // traverse tiles in descending order: start where the producer kernel ended (Infinity Cache reuse)
+  const int *stop;  // optional device word: non-zero = this launch has nothing to do (a conjugate-gradient solve that converged while
+                    // the next iteration was already enqueued, mech.hip); nullptr everywhere else
 };
 
 template <int N, bool INV, int NF>
@@ -365,6 +417,7 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass(PassArgs a, const kcplx
   extern __shared__ __attribute__((aligned(16))) char smem[];
   kcplx *W = reinterpret_cast<kcplx *>(smem);
   kcplx *X = W + N;
+  if (a.stop && *a.stop) return;  // (wave-uniform scalar load; nullptr on the Cahn-Hilliard path)
   const int l = threadIdx.x % T, q = threadIdx.x / T;
   const unsigned logical = a.reverse ? xcd_remap_rev(blockIdx.x, gridDim.x) : xcd_remap(blockIdx.x, gridDim.x);
   const long long o = logical / a.tiles_per_outer;
@@ -536,6 +589,10 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_pass_sub_mf(SubPassArgs a, c
 template <int N>
 constexpr size_t lds_line() {  // the z kernels: ZPlan<N>::T lines
   return sizeof(kcplx) * (N + MapLine<N>::zsize);
+}
+template <int N>
+constexpr size_t lds_line_ea() {  // k_z_inv_fwd: ZPlanEA<N>::T lines
+  return sizeof(kcplx) * (N + ZPlanEA<N>::T * MapLine<N>::LP);
 }
 template <int N>
 constexpr size_t lds_line_full() {  // MapLine tiles of Plan<N>::T lines (k_gamma_z_fwd_tangent)

@@ -64,14 +64,14 @@ template <int N, int FAM, bool MU_ONLY = false>
 inline int launch_z_inv_fwd(mrl_ctx *ctx, const kcplx *in, kcplx *o0, kcplx *o1, kreal *mu, const ChDev &chp, kreal scale,
                             long long nlines, ZLay zl = ZLay{0u, 0u}) {
   static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
-  constexpr size_t lds = lds_line<N>();
+  constexpr size_t lds = lds_line_ea<N>();
   if (!attr.load(std::memory_order_acquire)) {
     MRL_TRY((set_lds_attr(ctx, k_z_inv_fwd<N, FAM, MU_ONLY>, lds)));
     attr.store(true, std::memory_order_release);
   }
-  constexpr int LPB = ZPlan<N>::T;
+  constexpr int LPB = ZPlanEA<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_inv_fwd<N, FAM, MU_ONLY>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, scale,
+  hipLaunchKernelGGL((k_z_inv_fwd<N, FAM, MU_ONLY>), dim3((unsigned)nb), dim3(ZPlanEA<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, scale,
                      nlines, tw_table(ctx, 2), zl);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
@@ -80,7 +80,7 @@ inline int launch_z_inv_fwd(mrl_ctx *ctx, const kcplx *in, kcplx *o0, kcplx *o1,
 // z inverse that also leaves sum(out * dotv) as one partial per workgroup in `partial`; *nblocks = their number
 template <int N>
 inline int launch_z_inv_dot(mrl_ctx *ctx, const kcplx *in, kreal *out, kreal scale, long long nlines, const kreal *dotv,
-                            kreal *partial, int *nblocks, ZLay zl = ZLay{0u, 0u}) {
+                            kreal *partial, int *nblocks, ZLay zl = ZLay{0u, 0u}, const int *stop = nullptr) {
   static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_line<N>();
   if (!attr.load(std::memory_order_acquire)) {
@@ -90,7 +90,7 @@ inline int launch_z_inv_dot(mrl_ctx *ctx, const kcplx *in, kreal *out, kreal sca
   constexpr int LPB = ZPlan<N>::T;
   const long long nb = (nlines + LPB - 1) / LPB;
   hipLaunchKernelGGL((k_z_inv<N, true>), dim3((unsigned)nb), dim3(ZPlan<N>::NT), lds, ctx->stream, in, out, scale, nlines,
-                     tw_table(ctx, 2), dotv, partial, zl);
+                     tw_table(ctx, 2), dotv, partial, zl, stop);
   MRL_HIP(ctx, hipGetLastError());
   *nblocks = (int)nb;
   return MRL_OK;

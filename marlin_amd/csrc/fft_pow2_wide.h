@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(PL::NT, 2) k_pass_w(PassArgs a, const cplx *__
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx *W = reinterpret_cast<cplx *>(smem);
   double *X = reinterpret_cast<double *>(W + N);
+  if (a.stop && *a.stop) return;
   const int l = threadIdx.x % T, q = threadIdx.x / T;
   const unsigned logical = a.reverse ? xcd_remap_rev(blockIdx.x, gridDim.x) : xcd_remap(blockIdx.x, gridDim.x);
   const long long o = logical / a.tiles_per_outer;

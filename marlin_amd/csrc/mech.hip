@@ -220,9 +220,10 @@ template <bool NT, bool SKIP_X = false>
 __global__ void __launch_bounds__(256) k_cg_update(const double *__restrict__ S, int i_rz, int i_pAp,
                                                     double *__restrict__ x, double *__restrict__ r,
                                                     const double *__restrict__ p, const double *__restrict__ Ap,
-                                                    long long n, double *__restrict__ partial) {
+                                                    long long n, double *__restrict__ partial, const int *__restrict__ stop = nullptr) {
 #pragma clang fp contract(off)
   __shared__ double sh[4];
+  if (stop && *stop) return;  // a solve that converged while this iteration was already enqueued (k_reduce_final_cg)
   const double alpha = S[i_rz] / S[i_pAp];
   double acc = 0.0;
   const long long n2 = n >> 1;
@@ -321,7 +322,8 @@ bool mech_fast_ok(const mrl_ctx *ctx);
 bool gamma_tangent_fusable(const mrl_ctx *ctx);
 int gamma_fast_tangent_dir(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
                            const double *S, int i_num, int i_den, double *out, double *d_dot, bool nt, double *x, int i_arz,
-                           int i_apAp);
+                           int i_apAp, const int *stop);
+int reduce_finalize_cg(mrl_ctx *ctx, int nb, double *d_scalar, int slot, double thr, int *stop);
 int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale, const double *dotv = nullptr,
                double *d_dot = nullptr);
 
@@ -446,6 +448,7 @@ extern "C" {
 
 int mrl_gamma_apply(mrl_ctx *ctx, const double *d_A, double *d_out) {
   if (!ctx) return MRL_ERR_INVALID;
+  MRL_NO_PENCIL(ctx, "mrl_gamma_apply");
   MRL_TRY(check_dim(ctx, "mrl_gamma_apply"));
   if (!d_A || !d_out) return set_error(ctx, MRL_ERR_INVALID, "mrl_gamma_apply: null buffer");
   if (mech_fast_ok(ctx)) {
@@ -663,6 +666,8 @@ static int newton_cg_impl(mrl_ctx *ctx, const mrl_mech_params *prm, const double
   const double Fn = sqrt(h[0]);  // :123-124
   st.Fn = Fn;
   MRL_HIP(ctx, hipMemsetAsync(x, 0, sizeof(double) * n, ctx->stream));  // dFm = zeros_like(b)
+  bool x_is_zero = true;  // until the first solve has run: G_K_dF(0) is exactly 0 (tangent, transforms and projection of zeros), so the
+                          // initial residual b - A x0 of that solve is b itself -- no operator application needed for it
 
   auto apply_A = [&](const double *v, double *out) -> int {  // G_K_dF
     MRL_TRY(tangent_launch(ctx, lin, d_K, d_mu, v, false, tmp, soa));
@@ -670,6 +675,17 @@ static int newton_cg_impl(mrl_ctx *ctx, const mrl_mech_params *prm, const double
   };
 
   const bool fuse_dir = soa && (dist ? slab_gamma_tangent_fusable(ctx) != 0 : gamma_tangent_fusable(ctx)) && !(ctx->exp & 32);
+  // Look-ahead (round 4, one GPU, fused direction kernel): iteration k + 1 is enqueued BEFORE the host reads the residual norm of
+  // iteration k, so the GPU never idles behind the per-iteration read (128^3: the kernels of an iteration sum to 0.49 ms, the loop ran
+  // at 0.61 ms).  The convergence test of MarlinUtils.h:118-121 is taken on the device (k_reduce_final_cg); once it holds, every kernel
+  // of the iterations enqueued ahead returns at once, so x, p, r and the scalars are exactly those of the converged iteration: same
+  // iteration count, same solution as with the blocking read (experiment bit 1 << 26 restores it, A/B).
+  const bool look = fuse_dir && !dist && ctx->d_h_red != nullptr && !(ctx->exp & (1 << 26));
+  int *stop = reinterpret_cast<int *>(S + 8);
+  if (look) {
+    for (int e = 0; e < 2; ++e)
+      if (!ctx->cg_ev[e]) MRL_HIP(ctx, hipEventCreateWithFlags(&ctx->cg_ev[e], hipEventDisableTiming));
+  }
   int iiter = 0;
   while (true) {
     // ---- conjugateGradientSolve(G_K_dF, b, dFm, l_tol, l_max_its)        MarlinUtils.h:55-123
@@ -679,14 +695,24 @@ static int newton_cg_impl(mrl_ctx *ctx, const mrl_mech_params *prm, const double
     MRL_TRY(global(S + 3, h));
     const double b_norm = sqrt(h[0]);
     if (b_norm != 0.0) {
-      MRL_TRY(apply_A(x, Ap));
+      if (x_is_zero && !(ctx->exp & (1 << 27))) {
+        MRL_HIP(ctx, hipMemsetAsync(Ap, 0, sizeof(double) * n, ctx->stream));  // = A x0 for x0 = 0, bit for bit
+      } else {
+        MRL_TRY(apply_A(x, Ap));
+      }
+      x_is_zero = false;
       hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(256), 0, ctx->stream, b, Ap, r, p, n, ctx->d_red);
       MRL_TRY(reduce_finalize(ctx, nb, 1, S + 0));
       MRL_TRY(global(S + 0, nullptr));
       int i_old = 0, i_new = 2;
       int pend_rz = -1;  // slot of r.r of the iteration whose x update is still pending (deferred updates, fuse_dir)
       its = (int)l_max_its;
+      const double thr = prm->l_tol * b_norm;
+      const int *stop_k = look ? stop : nullptr;
+      if (look) MRL_HIP(ctx, hipMemsetAsync(stop, 0, sizeof(double), ctx->stream));
+      bool seen = false;  // look-ahead: the verdict of the last enqueued iteration has been read
       for (long long k = 0; k < l_max_its; ++k) {
+        const int pend_before = pend_rz;   // (look-ahead) what is pending if this iteration turns out to be a no-op
         if (k == 0) {
           MRL_TRY(apply_A(p, Ap));
         } else {
@@ -697,7 +723,7 @@ static int newton_cg_impl(mrl_ctx *ctx, const mrl_mech_params *prm, const double
               MRL_TRY(slab_gamma_fm(ctx, nullptr, Ap, 1.0, p, S + 1));
             } else {
               MRL_TRY(gamma_fast_tangent_dir(ctx, lin, d_K, d_mu, p, r, S, i_old, i_new, Ap, S + 1, mech_stream_vectors(npts), x,
-                                             pend_rz, 1));
+                                             pend_rz, 1, stop_k));
             }
             pend_rz = -1;
           } else {
@@ -717,27 +743,57 @@ static int newton_cg_impl(mrl_ctx *ctx, const mrl_mech_params *prm, const double
         {
           ProfScope ps(ctx, "cg_update_x_r", (fuse_dir ? 24.0 : 48.0) * n);
           if (fuse_dir) {  // x += alpha p is deferred into the next direction kernel (or the k_axpy_ratio after the loop)
-            hipLaunchKernelGGL((k_cg_update<false, true>), dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
+            hipLaunchKernelGGL((k_cg_update<false, true>), dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red,
+                               stop_k);
             pend_rz = i_old;
           } else if (mech_stream_vectors(npts))
             hipLaunchKernelGGL(k_cg_update<true>, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
           else
             hipLaunchKernelGGL(k_cg_update<false>, dim3(nb), dim3(256), 0, ctx->stream, S, i_old, 1, x, r, p, Ap, n, ctx->d_red);
-          if (dist) {  // the one host sync of the iteration
+          if (look) {
+            // r.r and the verdict of iteration k go to the pinned pair k & 1; the host reads the pair of iteration k - 1 now, with
+            // iteration k already in the queue
+            MRL_TRY(reduce_finalize_cg(ctx, nb, S + i_new, (int)(k & 1), thr, stop));
+            MRL_HIP(ctx, hipEventRecord(ctx->cg_ev[k & 1], ctx->stream));
+          } else if (dist) {  // the one host sync of the iteration
             MRL_TRY(reduce_finalize(ctx, nb, 1, S + i_new));
             MRL_TRY(global(S + i_new, h));
           } else {
             MRL_TRY(reduce_finalize_to_host(ctx, nb, 1, S + i_new, h));  // (no copy command)
           }
         }
+        if (look) {
+          if (k == 0) {
+            const int t0 = i_old;
+            i_old = i_new;
+            i_new = t0;
+            continue;
+          }
+          MRL_HIP(ctx, hipEventSynchronize(ctx->cg_ev[(k - 1) & 1]));
+          res_norm = sqrt(ctx->h_red[8 + 2 * ((k - 1) & 1)]);
+          if (ctx->h_red[9 + 2 * ((k - 1) & 1)] != 0.0) {  // iteration k - 1 converged: iteration k (enqueued) does nothing on the device
+            its = (int)k;
+            pend_rz = pend_before;
+            seen = true;
+            break;
+          }
+          const int t1 = i_old;
+          i_old = i_new;
+          i_new = t1;
+          continue;
+        }
         res_norm = sqrt(h[0]);
-        if (res_norm <= prm->l_tol * b_norm) {
+        if (res_norm <= thr) {
           its = (int)k + 1;
           break;
         }
         const int t = i_old;  // rr_new becomes rr_old; the next iteration's beta = S[i_old] / S[i_new]
         i_old = i_new;
         i_new = t;
+      }
+      if (look && !seen) {  // the loop ran to l_max_its: the last iteration's residual has not been looked at yet
+        MRL_HIP(ctx, hipEventSynchronize(ctx->cg_ev[(l_max_its - 1) & 1]));
+        res_norm = sqrt(ctx->h_red[8 + 2 * ((l_max_its - 1) & 1)]);
       }
       if (pend_rz >= 0) {
         hipLaunchKernelGGL(k_axpy_ratio, dim3(nb), dim3(256), 0, ctx->stream, S, pend_rz, 1, x, p, n);
@@ -794,12 +850,14 @@ int mrl_mech_newton_cg(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d
                        const double *d_mu, const double *d_applied, double *d_Fnew, double *d_P,
                        mrl_mech_stats *stats) {
   if (!ctx) return MRL_ERR_INVALID;
+  MRL_NO_PENCIL(ctx, "mrl_mech_newton_cg");
   return newton_cg_impl(ctx, prm, d_F, d_K, d_mu, d_applied, d_Fnew, d_P, stats, false);
 }
 
 int mrl_mech_small_strain(mrl_ctx *ctx, const mrl_mech_params *prm, const double *d_K, const double *d_mu, const double *d_E,
                           double *d_eps, double *d_sigma, mrl_mech_stats *stats) {
   if (!ctx) return MRL_ERR_INVALID;
+  MRL_NO_PENCIL(ctx, "mrl_mech_small_strain");
   if (!prm || !d_K || !d_mu || !d_E || !d_eps || !d_sigma) return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_small_strain: null argument");
   MRL_TRY(check_dim(ctx, "mrl_mech_small_strain", !ctx->slab));
   const long long n = real_count_local(ctx) * ctx->dim * ctx->dim;

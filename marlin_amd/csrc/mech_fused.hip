@@ -39,12 +39,14 @@ struct GammaArgs {
   int nzc;
   const double *kx, *ky, *kz;
   double scale;
+  const int *stop;   // optional: non-zero = nothing to do (PassArgs::stop)
 };
 
 template <int N>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_xfused(GammaArgs a, const cplx *__restrict__ tw) {
 #pragma clang fp contract(off)
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, T = Plan<N>::T;
+  if (a.stop && *a.stop) return;
   constexpr int GPRE0 = N >= 256 ? MRL_GAMMA_PRE_BIG : MRL_GAMMA_PRE, GPRE = GPRE0 < P ? GPRE0 : P;
   using Map = MapStrided<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -166,9 +168,10 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_z_fwd_tangent(const do
                                                                         int i_num, int i_den, cplx *__restrict__ spec,
                                                                         long long npts, long long rows_total,
                                                                         const cplx *__restrict__ tw, double *__restrict__ xsol,
-                                                                        int i_arz, int i_apAp, ZLay zl) {
+                                                                        int i_arz, int i_apAp, ZLay zl, const int *__restrict__ stop) {
 #pragma clang fp contract(off)
   constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, NZC = N / 2 + 1, R = 512 / N, NL = 9 * R / 2;
+  if (stop && *stop) return;  // the solve converged while this iteration was already enqueued: p and x stay as they are
   static_assert(Plan<N>::NT == 256 && R >= 2 && R % 2 == 0 && NL <= Plan<N>::T, "tile shape");
   using Map = MapLine<N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -237,30 +240,16 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_gamma_z_fwd_tangent(const do
   for (int m = 0; m < P; ++m) v[m] = X[Map::at(q + m * TPL, lr)];
   __syncthreads();
   fft_line<N, Map>(v, q, l, X, W);
-  __syncthreads();
-#pragma unroll
-  for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
-  __syncthreads();
-  if (!valid) return;
-  const int c = l / (R / 2), pr = l % (R / 2);
+  const int c = lr / (R / 2), pr = lr % (R / 2);
   const long long row0 = (long long)c * rows_total + tile * R + 2 * pr;  // (rows of all nine fields are numbered through: plane = row / ny)
-  cplx *o0 = spec + zrow(row0, NZC, zl);
-  cplx *o1 = spec + zrow(row0 + 1, NZC, zl);
-#pragma unroll
-  for (int m = 0; m <= P / 2; ++m) {
-    const int k = q + m * TPL;
-    if (k > N / 2) break;
-    const cplx xk = v[m];
-    const cplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
-    o0[k] = make_double2(0.5 * (xk.x + xn.x), 0.5 * (xk.y - xn.y));
-    o1[k] = make_double2(0.5 * (xk.y + xn.y), -0.5 * (xk.x - xn.x));
-  }
+  // the k <-> N - k pairing by lane exchange where the plan allows it (fft_pow2_kernels.h: store_half_spectra), through LDS otherwise
+  store_half_spectra<N, Map>(v, q, l, X, valid, spec + zrow(row0, NZC, zl), spec + zrow(row0 + 1, NZC, zl));
 }
 
 template <int N>
 static int launch_gamma_z_fwd_tangent(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
                                       const double *S, int i_num, int i_den, cplx *spec, long long npts, long long rows, bool nt,
-                                      double *x, int i_arz, int i_apAp, ZLay zl) {
+                                      double *x, int i_arz, int i_apAp, ZLay zl, const int *stop = nullptr) {
   static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_line_full<N>();
   if (!attr.load(std::memory_order_acquire)) {
@@ -273,7 +262,7 @@ static int launch_gamma_z_fwd_tangent(mrl_ctx *ctx, const double *F, const doubl
   const unsigned nb = (unsigned)(npts / 512);
 #define MRL_GZT(NTV_, XU_)                                                                                                        \
   hipLaunchKernelGGL((k_gamma_z_fwd_tangent<N, NTV_, XU_>), dim3(nb), dim3(256), lds, ctx->stream, F, K, mu, p, r, S, i_num, i_den, \
-                     spec, npts, rows, ctx->ax[2].d_tw, x, i_arz, i_apAp, zl)
+                     spec, npts, rows, ctx->ax[2].d_tw, x, i_arz, i_apAp, zl, stop)
   if (nt) {
     if (x) MRL_GZT(true, true); else MRL_GZT(true, false);
   } else {
@@ -297,15 +286,18 @@ static long long mech_plane(const mrl_ctx *ctx) {
 
 bool mech_fast_ok(const mrl_ctx *ctx) {
   // (one spectral field < 4 GiB: k_gamma_xfused addresses it with 32-bit byte offsets)
-  return ctx->dim == 3 && !ctx->slab && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
+  return ctx->dim == 3 && !ctx->slab && !ctx->pencil && ctx->spectrum == MRL_SPECTRUM_HALF && pow2_ok(ctx->n[0]) &&
          pow2_ok(ctx->n[1]) && pow2_ok(ctx->n[2]) && 16.0 * (double)(ctx->n[0] * (ctx->n[1] * ctx->nrec[2] + 32)) < 4294967296.0;
 }
 
 // out = scale * G(A), A and out field-major real [9][nx][ny][nz] (out may alias A).  dotv != nullptr: the last pass
 // also accumulates sum(out * dotv) into the device scalar d_dot (deterministic two-stage sum)
 int reduce_finalize_from(mrl_ctx *ctx, const double *partial, int nb, double *d_scalar);
+int reduce_finalize_from_guarded(mrl_ctx *ctx, const double *partial, int nb, double *d_scalar, const int *stop);
 // the passes after the forward z pass: y forward, x + projection, y inverse, z inverse (+ optional dot product)
-static int gamma_fast_rest(mrl_ctx *ctx, cplx *spec, double *out, double scale, const double *dotv, double *d_dot) {
+// stop (optional): device word checked by every launch (a CG iteration enqueued ahead of the host's convergence test, mech.hip)
+static int gamma_fast_rest(mrl_ctx *ctx, cplx *spec, double *out, double scale, const double *dotv, double *d_dot,
+                           const int *stop = nullptr) {
   const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
   const long long nreal = nx * ny * nz, nspec = nx * ny * nzc, plane = mech_plane(ctx);
   const p2::ZLay zl{(unsigned)ny, (unsigned)(plane - ny * nzc)};
@@ -318,6 +310,7 @@ static int gamma_fast_rest(mrl_ctx *ctx, cplx *spec, double *out, double scale, 
   pa.outer = 9 * nx;
   pa.so_in = pa.so_out = plane;
   pa.sn_in = pa.sn_out = nzc;
+  pa.stop = stop;
   {
     ProfScope ps(ctx, "gamma_y_fwd", 2.0 * h);
     pa.reverse = 1;
@@ -335,6 +328,7 @@ static int gamma_fast_rest(mrl_ctx *ctx, cplx *spec, double *out, double scale, 
     g.ky = ctx->d_k[1];
     g.kz = ctx->d_k[2];
     g.scale = scale;
+    g.stop = stop;
     MRL_SWITCH_N(nx, MRL_TRY((p2::launch_gamma_xfused<NN>(ctx, g))));
   }
   {
@@ -352,8 +346,8 @@ static int gamma_fast_rest(mrl_ctx *ctx, cplx *spec, double *out, double scale, 
   const long long max_blocks = 9 * nx * ny / 2;  // >= the number of workgroups for every plan
   MRL_TRY(ensure_work(ctx, 3, sizeof(double) * (size_t)max_blocks));
   int nb = 0;
-  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_dot<NN>(ctx, spec, out, norm, 9 * nx * ny / 2, dotv, ctx->d_work[3], &nb, zl))));
-  return reduce_finalize_from(ctx, ctx->d_work[3], nb, d_dot);
+  MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_dot<NN>(ctx, spec, out, norm, 9 * nx * ny / 2, dotv, ctx->d_work[3], &nb, zl, stop))));
+  return reduce_finalize_from_guarded(ctx, ctx->d_work[3], nb, d_dot, stop);
 }
 
 int gamma_fast(mrl_ctx *ctx, const double *A, double *out, double scale, const double *dotv, double *d_dot) {
@@ -397,7 +391,7 @@ bool gamma_tangent_fusable(const mrl_ctx *ctx) {
 // p <- r + (S[i_num]/S[i_den]) p ; out = G(K4 : p) ; *d_dot = p . out     (one CG iteration's operator application)
 int gamma_fast_tangent_dir(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
                            const double *S, int i_num, int i_den, double *out, double *d_dot, bool nt, double *x, int i_arz,
-                           int i_apAp) {
+                           int i_apAp, const int *stop) {
   const long long nx = ctx->n[0], ny = ctx->n[1], nz = ctx->n[2], nzc = ctx->nrec[2];
   const long long npts = nx * ny * nz, nspec = nx * ny * nzc, plane = mech_plane(ctx);
   const p2::ZLay zl{(unsigned)ny, (unsigned)(plane - ny * nzc)};
@@ -406,14 +400,14 @@ int gamma_fast_tangent_dir(mrl_ctx *ctx, const double *F, const double *K, const
   {
     ProfScope ps(ctx, "gamma_z_fwd_tangent_dir", 8.0 * npts * ((x ? 6 : 4) * 9 + 2) + 16.0 * nspec * 9);
     switch (nz) {
-      case 32: MRL_TRY((p2::launch_gamma_z_fwd_tangent<32>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp, zl))); break;
-      case 64: MRL_TRY((p2::launch_gamma_z_fwd_tangent<64>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp, zl))); break;
-      case 128: MRL_TRY((p2::launch_gamma_z_fwd_tangent<128>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp, zl))); break;
-      case 256: MRL_TRY((p2::launch_gamma_z_fwd_tangent<256>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp, zl))); break;
+      case 32: MRL_TRY((p2::launch_gamma_z_fwd_tangent<32>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp, zl, stop))); break;
+      case 64: MRL_TRY((p2::launch_gamma_z_fwd_tangent<64>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp, zl, stop))); break;
+      case 128: MRL_TRY((p2::launch_gamma_z_fwd_tangent<128>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp, zl, stop))); break;
+      case 256: MRL_TRY((p2::launch_gamma_z_fwd_tangent<256>(ctx, F, K, mu, p, r, S, i_num, i_den, spec, npts, nx * ny, nt, x, i_arz, i_apAp, zl, stop))); break;
       default: return set_error(ctx, MRL_ERR_UNSUPPORTED, "gamma_fast_tangent_dir: unplanned z length");
     }
   }
-  return gamma_fast_rest(ctx, spec, out, 1.0, p, d_dot);
+  return gamma_fast_rest(ctx, spec, out, 1.0, p, d_dot, stop);
 }
 
 }  // namespace mrl

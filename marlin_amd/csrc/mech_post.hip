@@ -158,7 +158,7 @@ extern "C" {
 int mrl_mech_displacements(mrl_ctx *ctx, const double *d_F, double *d_disp) {
   if (!ctx) return MRL_ERR_INVALID;
   if (ctx->dim != 2 && ctx->dim != 3) return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_mech_displacements: 2-D or 3-D domains");
-  if (ctx->slab || ctx->spectrum != MRL_SPECTRUM_HALF)
+  if (ctx->slab || ctx->pencil || ctx->spectrum != MRL_SPECTRUM_HALF)
     return set_error(ctx, MRL_ERR_UNSUPPORTED, "mrl_mech_displacements: serial half-spectrum contexts only");
   if (!d_F || !d_disp) return set_error(ctx, MRL_ERR_INVALID, "mrl_mech_displacements: null buffer");
   const int D = ctx->dim, dd = D * D;

@@ -81,6 +81,10 @@ struct mrl_ctx {
   int spectrum = MRL_SPECTRUM_HALF;
   int nranks = 1, rank = 0;
   bool slab = false;            // FFT_SLAB layout and staged entry points (nranks > 1, or MRL_FLAG_SLAB)
+  bool pencil = false;          // FFT_PENCIL (MRL_FLAG_PENCIL): y / z split in real space, kx / ky split in reciprocal space (pencil.hip)
+  int pen_py = 1, pen_pz = 1;   // process grid: rank r = (r % pen_py, r / pen_py)
+  std::vector<long long> pen_y, pen_z;    // real-space counts of the py y blocks / the pz z blocks (partitionHepler, equal weights)
+  std::vector<long long> pen_kx, pen_ky;  // reciprocal counts: kx = nx/2+1 over py, ky = ny over pz
   bool gamma_z_ready = false;   // d_work[18] holds the 9 z spectra written by mrl_slab_gamma_tangent_z_fwd
   int gamma_dot_nb = 0;         // workgroups per row of the fused slab Gamma z pass that left dot-product partials (d_work[3])
   int device = 0;
@@ -111,6 +115,7 @@ struct mrl_ctx {
   double *d_h_red = nullptr;    // its device-side address (kernels may write results there), nullptr if not mappable
 
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  hipEvent_t cg_ev[2] = {nullptr, nullptr};   // look-ahead conjugate-gradient loop (mech.hip): end of iteration k, k & 1
   bool profiling = false;
   std::vector<mrl::Profile> prof;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -216,6 +221,14 @@ int slab_comm_check(mrl_ctx *ctx);  // MRL_ERR_COMM if a device-side wait of the
 int launch_pass(mrl_ctx *ctx, const PassDesc &d, const double *in, double *out, const cplx *d_tw, long long nbatch);
 
 // spectral sizes
+// entry points that run their own (serial or slab) transform pipelines refuse FFT_PENCIL contexts: those offer the transforms
+// (mrl_fft_r2c / mrl_fft_c2r), the reductions and the pointwise entry points
+#define MRL_NO_PENCIL(ctx, what)                                                                                                  \
+  do {                                                                                                                            \
+    if ((ctx)->pencil)                                                                                                            \
+      return mrl::set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: not available on FFT_PENCIL contexts (use mrl_fft_r2c / mrl_fft_c2r and " \
+                                                      "the pointwise entry points, or FFT_SLAB)", what);                         \
+  } while (0)
 inline long long spec_count_local(const mrl_ctx *c) { return c->nrec[0] * c->nrec[1] * c->nrec[2]; }
 inline long long real_count_local(const mrl_ctx *c) { return c->nloc[0] * c->nloc[1] * c->nloc[2]; }
 

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) k_elastic_mu(const double2 *__restrict__ 
 
 static int check_pf(mrl_ctx *ctx, const char *what) {
   if (ctx->dim != 3) return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: 3-D domains only (one displacement per dimension, k = 0 at index {0,0,0})", what);
-  if (ctx->slab || ctx->spectrum != MRL_SPECTRUM_HALF)
+  if (ctx->slab || ctx->pencil || ctx->spectrum != MRL_SPECTRUM_HALF)
     return set_error(ctx, MRL_ERR_UNSUPPORTED, "%s: serial half-spectrum contexts only", what);
   return MRL_OK;
 }

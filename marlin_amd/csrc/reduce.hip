@@ -52,9 +52,12 @@ __global__ void __launch_bounds__(256) k_reduce_partial(const double *__restrict
 // fold `nb` partials of `nslots` interleaved quantities (partial[b*nslots + s]) into out[s]
 // `mirror` (optional): the same values also go to pinned host memory, so that a host that needs them only has to wait for the
 // stream -- no device-to-host copy command (one per CG iteration otherwise)
+// `stop` (optional): non-zero = leave everything as it is (see k_reduce_final_cg)
 __global__ void __launch_bounds__(256) k_reduce_final(const double *__restrict__ partial, int nb, int nslots,
-                                                       double *__restrict__ out, double *__restrict__ mirror = nullptr) {
+                                                       double *__restrict__ out, double *__restrict__ mirror = nullptr,
+                                                       const int *__restrict__ stop = nullptr) {
   __shared__ double sh[4];
+  if (stop && *stop) return;
   for (int s = 0; s < nslots; ++s) {
     double acc = 0.0;
     for (int i = threadIdx.x; i < nb; i += 256) acc += partial[(long long)i * nslots + s];
@@ -63,6 +66,27 @@ __global__ void __launch_bounds__(256) k_reduce_final(const double *__restrict__
       out[s] = r;
       if (mirror) mirror[s] = r;
     }
+  }
+}
+
+// The r.r of a conjugate-gradient iteration whose successor is enqueued BEFORE the host has seen this value (mech.hip: the host reads
+// one iteration late, so the GPU never waits for it).  out[0] = r.r ; mirror[0] = r.r and mirror[1] = 1.0 / 0.0 = converged or not, in
+// pinned host memory ; converged: sqrt(r.r) <= thr, the test of MarlinUtils.h:118-121 with the host's thr = l_tol * |b| (IEEE sqrt on
+// both sides) -- then *stop = 1, and every kernel of the iterations already enqueued returns at once (k_pass, k_gamma_xfused, k_z_inv,
+// k_gamma_z_fwd_tangent, k_cg_update, k_reduce_final): r, p, x and the scalars stay those of the converged iteration.
+__global__ void __launch_bounds__(256) k_reduce_final_cg(const double *__restrict__ partial, int nb, double *__restrict__ out,
+                                                          double *__restrict__ mirror, double thr, int *__restrict__ stop) {
+  __shared__ double sh[4];
+  if (*stop) return;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += partial[i];
+  const double r = block_sum256(acc, sh);
+  if (threadIdx.x == 0) {
+    const bool conv = sqrt(r) <= thr;
+    out[0] = r;
+    mirror[0] = r;
+    mirror[1] = conv ? 1.0 : 0.0;
+    if (conv) *stop = 1;
   }
 }
 
@@ -162,6 +186,21 @@ int reduce_finalize(mrl_ctx *ctx, int nb, int nslots, double *d_scalar) {
 // the same for partials in a caller-supplied buffer (any number of workgroups)
 int reduce_finalize_from(mrl_ctx *ctx, const double *partial, int nb, double *d_scalar) {
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, partial, nb, 1, d_scalar);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+// ... that leaves d_scalar alone once *stop is set (a CG solve that has converged: k_reduce_final_cg)
+int reduce_finalize_from_guarded(mrl_ctx *ctx, const double *partial, int nb, double *d_scalar, const int *stop) {
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, partial, nb, 1, d_scalar, nullptr, stop);
+  MRL_HIP(ctx, hipGetLastError());
+  return MRL_OK;
+}
+
+// r.r of a CG iteration with the convergence verdict taken on the device (k_reduce_final_cg); `slot` 0 / 1: which pair of the pinned
+// mirror (ctx->h_red[8 + 2 slot], [9 + 2 slot]) receives {r.r, verdict}.  Nothing is waited for here.
+int reduce_finalize_cg(mrl_ctx *ctx, int nb, double *d_scalar, int slot, double thr, int *stop) {
+  if (!ctx->d_h_red) return set_error(ctx, MRL_ERR_UNSUPPORTED, "reduce_finalize_cg: the pinned scratch is not device-mapped");
+  hipLaunchKernelGGL(k_reduce_final_cg, dim3(1), dim3(256), 0, ctx->stream, ctx->d_red, nb, d_scalar, ctx->d_h_red + 8 + 2 * slot, thr, stop);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }

@@ -133,7 +133,7 @@ int slab_inv_finish(mrl_ctx *ctx, const double *recv, double *real_out) {
 // ---- Cahn-Hilliard substep pipelined over kz sub-blocks -------------------------------------------------
 // generic passes on a sub-range (fft_plan.hip), k-space update on a kz sub-range (ch.hip)
 int pass_lines(mrl_ctx *ctx, int axis, int sign, const double *in, double *out, long long outer, long long inner,
-               long long so, long long si, long long sn);
+               long long so, long long si, long long sn, int lines_fastest = 1);
 int ch_kspace_sub_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const double *mubar, double *Nhat, double *ubar,
                          const double *const *Nold, int order, double sub_dt, long long k0, long long ksub);
 

@@ -52,10 +52,21 @@ struct MechPipe {
   Xchg fwd_all, inv_all;   // all rows per launch: one pair of nine-field exchanges
 };
 
+// FFT_PENCIL: the four staged exchanges of DomainAction::fftPencil / ifftPencil (DomainAction.C:1105-1404), each with its own
+// acknowledgement channel (a receive buffer is only overwritten once every peer has consumed its previous contents)
+struct PencilPipe {
+  bool built = false;
+  int transport = -1;
+  Xchg x[4];                       // 0: stage 1 forward, 1: stage 2 forward, 2: stage 2 inverse, 3: stage 1 inverse
+  int ack[4] = {-1, -1, -1, -1};
+  unsigned long long ack_epoch[4] = {0, 0, 0, 0}, ack_base[4] = {0, 0, 0, 0};
+};
+
 struct SlabPipes {
   ChPipe ch;
   FftPipe fft;
   MechPipe mech;
+  PencilPipe pencil;
 };
 
 static int comm_fail(mrl_ctx *ctx, int rc) {
@@ -110,6 +121,10 @@ void slab_pipes_destroy(mrl_ctx *ctx) {
     }
     xchg_destroy(ctx->comm, &ctx->pipes->mech.fwd_all);
     xchg_destroy(ctx->comm, &ctx->pipes->mech.inv_all);
+    for (int i = 0; i < 4; ++i) {
+      xchg_destroy(ctx->comm, &ctx->pipes->pencil.x[i]);
+      if (ctx->pipes->pencil.ack[i] >= 0) comm_free_channel(ctx->comm, ctx->pipes->pencil.ack[i], ctx->pipes->pencil.ack_epoch[i]);
+    }
   }
   delete ctx->pipes;
   ctx->pipes = nullptr;
@@ -124,7 +139,7 @@ void slab_detach_comm(mrl_ctx *ctx) {
 }
 
 static int need_comm(mrl_ctx *ctx, const char *what) {
-  if (!ctx->slab) return set_error(ctx, MRL_ERR_INVALID, "%s: not a slab context", what);
+  if (!ctx->slab && !ctx->pencil) return set_error(ctx, MRL_ERR_INVALID, "%s: not a slab context", what);
   if (!ctx->comm)
     return set_error(ctx, MRL_ERR_INVALID, "%s on a slab context needs a communicator (mrl_ctx_attach_comm), or use the staged mrl_slab_* entry points", what);
   if (!ctx->pipes) ctx->pipes = new SlabPipes();
@@ -423,6 +438,97 @@ int slab_fft_inverse(mrl_ctx *ctx, const double *d_in, double *d_out, long long 
   return MRL_OK;
 }
 
+// ---- FFT_PENCIL: DomainAction::fftPencil / ifftPencil with library-owned exchanges -------------------------------------------------
+int pencil_counts(const mrl_ctx *ctx, int stage, int forward, long long *send, long long *recv);   // pencil.hip
+int pencil_fwd_x(mrl_ctx *ctx, const double *real_in, double *send1);
+int pencil_fwd_y(mrl_ctx *ctx, const double *recv1, double *send2);
+int pencil_fwd_z(mrl_ctx *ctx, const double *recv2, double *spec_out);
+int pencil_inv_z(mrl_ctx *ctx, const double *spec_in, double *send2);
+int pencil_inv_y(mrl_ctx *ctx, const double *recv2, double *send1);
+int pencil_inv_x(mrl_ctx *ctx, const double *recv1, double *real_out);
+
+static int pencil_pipe_build(mrl_ctx *ctx) {
+  PencilPipe &P = ctx->pipes->pencil;
+  mrl_comm *c = ctx->comm;
+  const int R = ctx->nranks;
+  if (!P.built) {
+    std::vector<long long> sc(R), rc(R);
+    std::vector<size_t> sb(R), rb(R);
+    const int stage_of[4] = {1, 2, 2, 1}, fwd_of[4] = {1, 1, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+      MRL_TRY(pencil_counts(ctx, stage_of[i], fwd_of[i], sc.data(), rc.data()));
+      for (int p = 0; p < R; ++p) {
+        sb[p] = sizeof(cplx) * (size_t)sc[p];
+        rb[p] = sizeof(cplx) * (size_t)rc[p];
+      }
+      MRL_COMM(ctx, xchg_create(c, &P.x[i], sb.data(), rb.data(), true));
+      P.ack[i] = comm_alloc_channel(c);
+      if (P.ack[i] < 0) return set_error(ctx, MRL_ERR_UNSUPPORTED, "out of exchange channels");
+      P.ack_epoch[i] = P.ack_base[i] = c->chan_epoch[P.ack[i]];
+    }
+    P.built = true;
+  }
+  if (P.transport != c->transport) {
+    for (int i = 0; i < 4; ++i) MRL_TRY(prepare_table(ctx, &P.x[i], false));
+    P.transport = c->transport;
+  }
+  return MRL_OK;
+}
+
+// one staged exchange: `produce` fills the send buffer, `consume` reads the receive buffer
+template <class Produce, class Consume>
+static int pencil_exchange(mrl_ctx *ctx, int i, Produce produce, Consume consume) {
+  PencilPipe &P = ctx->pipes->pencil;
+  mrl_comm *c = ctx->comm;
+  MRL_COMM(ctx, xchg_begin(c, &P.x[i], ctx->stream));
+  MRL_TRY(produce(P.x[i].send));
+  MRL_TRY(ack_acquire(ctx, P.ack[i], P.ack_epoch[i], P.ack_base[i]));
+  MRL_COMM(ctx, xchg_post(c, &P.x[i], ctx->stream));
+  MRL_COMM(ctx, xchg_wait(c, &P.x[i], ctx->stream));
+  MRL_TRY(consume(static_cast<const double *>(P.x[i].recv.local)));
+  return ack_release(ctx, P.ack[i], &P.ack_epoch[i]);
+}
+
+int pencil_fft_forward(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch) {
+  if (!ctx->comm) return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_r2c on a pencil context needs a communicator (mrl_ctx_attach_comm)");
+  MRL_TRY(need_comm(ctx, "mrl_fft_r2c"));
+  MRL_TRY(pencil_pipe_build(ctx));
+  PencilPipe &P = ctx->pipes->pencil;
+  const long long nreal = real_count_local(ctx), nspec = spec_count_local(ctx);
+  for (long long b = 0; b < batch; ++b) {
+    const double *in = d_in + b * nreal;
+    double *out = d_out + 2 * b * nspec;
+    // stage 1: the x-transformed block leaves, my kx chunk of every y block of the group arrives -> y transform -> stage 2 leaves
+    MRL_TRY(pencil_exchange(ctx, 0, [&](double *send) { return pencil_fwd_x(ctx, in, send); },
+                            [&](const double *recv) {
+                              MRL_COMM(ctx, xchg_begin(ctx->comm, &P.x[1], ctx->stream));
+                              return pencil_fwd_y(ctx, recv, P.x[1].send);
+                            }));
+    // stage 2 (its send buffer was filled by the consumer above)
+    MRL_TRY(pencil_exchange(ctx, 1, [&](double *) { return (int)MRL_OK; }, [&](const double *recv) { return pencil_fwd_z(ctx, recv, out); }));
+  }
+  return MRL_OK;
+}
+
+int pencil_fft_inverse(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch) {
+  if (!ctx->comm) return set_error(ctx, MRL_ERR_INVALID, "mrl_fft_c2r on a pencil context needs a communicator (mrl_ctx_attach_comm)");
+  MRL_TRY(need_comm(ctx, "mrl_fft_c2r"));
+  MRL_TRY(pencil_pipe_build(ctx));
+  PencilPipe &P = ctx->pipes->pencil;
+  const long long nreal = real_count_local(ctx), nspec = spec_count_local(ctx);
+  for (long long b = 0; b < batch; ++b) {
+    const double *in = d_in + 2 * b * nspec;
+    double *out = d_out + b * nreal;
+    MRL_TRY(pencil_exchange(ctx, 2, [&](double *send) { return pencil_inv_z(ctx, in, send); },
+                            [&](const double *recv) {
+                              MRL_COMM(ctx, xchg_begin(ctx->comm, &P.x[3], ctx->stream));
+                              return pencil_inv_y(ctx, recv, P.x[3].send);
+                            }));
+    MRL_TRY(pencil_exchange(ctx, 3, [&](double *) { return (int)MRL_OK; }, [&](const double *recv) { return pencil_inv_x(ctx, recv, out); }));
+  }
+  return MRL_OK;
+}
+
 // ---- Gamma operator on a slab-decomposed grid (FFTMechanics.C:74-84,105-106 over fftSlab / ifftSlab) ------------------------
 int reduce_finalize_from(mrl_ctx *ctx, const double *partial, int nb, double *d_scalar);
 int gamma_z_fwd_tangent_launch(mrl_ctx *ctx, const double *F, const double *K, const double *mu, double *p, const double *r,
@@ -600,7 +706,7 @@ extern "C" {
 
 int mrl_ctx_attach_comm(mrl_ctx *ctx, mrl_comm *comm) {
   if (!ctx) return MRL_ERR_INVALID;
-  if (!ctx->slab) return set_error(ctx, MRL_ERR_INVALID, "mrl_ctx_attach_comm: not a slab context");
+  if (!ctx->slab && !ctx->pencil) return set_error(ctx, MRL_ERR_INVALID, "mrl_ctx_attach_comm: not a slab or pencil context");
   if (comm && (comm->nranks != ctx->nranks || comm->rank != ctx->rank))
     return set_error(ctx, MRL_ERR_INVALID, "mrl_ctx_attach_comm: communicator is rank %d of %d, context rank %d of %d", comm->rank,
                      comm->nranks, ctx->rank, ctx->nranks);

@@ -984,8 +984,24 @@ int main(int argc, char ** argv)
       par.device = g_args.count("device") ? (int)argi("device", 0) : par.rank % ndev;
       g_rank_suffix = ".rank" + std::to_string(par.rank);
     }
+    else if (arg("parallel_mode", "NONE") == "FFT_PENCIL")
+    {
+      // DomainAction::partitionPencils (DomainAction.C:568-742): nranks = py * pz rank processes, here on the GPUs of one node
+      par.mode = DomainAction::ParallelMode::FFT_PENCIL;
+      par.nranks = (int)argi("nranks", 4);
+      if (!g_args.count("rank"))
+        return launch_ranks(argc, argv, par.nranks);  // nothing has touched the GPU yet
+      par.rank = (int)argi("rank", 0);
+      par.job = arg("job", "marlin_hip_run");
+      par.transport = (int)argi("transport", MRL_TRANSPORT_AUTO);
+      int ndev = 0;
+      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        mooseError("no HIP device available");
+      par.device = g_args.count("device") ? (int)argi("device", 0) : par.rank % ndev;
+      g_rank_suffix = ".rank" + std::to_string(par.rank);
+    }
     else if (arg("parallel_mode", "NONE") != "NONE")
-      paramError("parallel_mode", "NONE or FFT_SLAB (FFT_PENCIL is multi-node: not built)");
+      paramError("parallel_mode", "NONE, FFT_SLAB or FFT_PENCIL");
     DomainAction domain(dim, n, hi, lo, par);
     if (domain.isSlab() && g_args.count("nsub"))
       domain.check(mrl_ctx_set_option(domain.ctx(), MRL_OPT_SLAB_NSUB, argi("nsub", 1)));

@@ -132,7 +132,8 @@ private:
 enum class DomainParallelMode
 {
   NONE,
-  FFT_SLAB
+  FFT_SLAB,
+  FFT_PENCIL  ///< 3-D, nranks = py * pz (DomainAction::partitionPencils): transforms, reductions and pointwise computes
 };
 struct DomainParallel
 {
@@ -190,9 +191,23 @@ public:
       if (mrl_comm_create(&_comm, par.job.c_str(), par.nranks, par.rank, par.device, par.transport) != MRL_OK)
         mooseError(std::string("DomainAction: ") + mrl_comm_last_error(nullptr));
     }
+    const bool pencil = par.mode == ParallelMode::FFT_PENCIL;
+    if (pencil)
+    {
+      if (dim < 3)
+        mooseError("Dimension must be 3 for pencil decomposition.");  // DomainAction.C:571-572
+      d.nranks = par.nranks;
+      d.rank = par.rank;
+      d.flags |= MRL_FLAG_PENCIL;  // r2c along x, kx split over py, ky over pz (DomainAction.C:282-284, 620-698)
+      int32_t py = 0, pz = 0;
+      if (mrl_pencil_factors(par.nranks, d.n, &py, &pz) != MRL_OK)
+        paramError("parallel_mode", mrl_last_error(nullptr));  // DomainAction.C:611-616
+      if (mrl_comm_create(&_comm, par.job.c_str(), par.nranks, par.rank, par.device, par.transport) != MRL_OK)
+        mooseError(std::string("DomainAction: ") + mrl_comm_last_error(nullptr));
+    }
     if (mrl_ctx_create(&_ctx, &d) != MRL_OK)
       mooseError(std::string("DomainAction: ") + mrl_last_error(nullptr));
-    if (slab)
+    if (slab || pencil)
       check(mrl_ctx_attach_comm(_ctx, _comm));
     int64_t rn[3], rb[3], kn[3], kb[3];
     check(mrl_local_shape(_ctx, rn, rb, kn, kb));
@@ -222,6 +237,7 @@ public:
   mrl_ctx * ctx() const { return _ctx; }
   mrl_comm * comm() const { return _comm; }
   bool isSlab() const { return _par.mode == ParallelMode::FFT_SLAB; }
+  bool isPencil() const { return _par.mode == ParallelMode::FFT_PENCIL; }
   int rank() const { return _par.rank; }
   int nranks() const { return _par.nranks; }
   int getDim() const { return _dim; }

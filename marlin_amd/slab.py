@@ -257,6 +257,16 @@ class SlabCahnHilliard:
         self.c.copy_(host.reshape(-1))
         self._carry_valid = False
 
+    def reset(self, gen: Callable[[int, int], "object"]):
+        """back to the initial condition with an empty history (the state right after construction + set_initial)"""
+        self.set_initial(gen)
+        self.hist = []
+        self.cur = None
+        self.time_step = 0
+        self.dt_old = None
+        self.dt_changed = False
+        self._substep_index = 0
+
     def set_local(self, c_local: torch.Tensor):
         self.c.copy_(c_local.reshape(-1))
         self._carry_valid = False

@@ -148,6 +148,123 @@ def partition_helper(total: int, weights: Sequence[int]) -> List[int]:
 
 
 # --------------------------------------------------------------------------------------
+# FFT_PENCIL (src/actions/DomainAction.C:568-742 partitionPencils, :1021-1047 fftPencil / ifftPencil, :1105-1404 the staged
+# exchanges).  The reference runs one MPI rank per block; here every rank's block is an entry of a Python list and an MPI
+# message is an assignment between entries -- the arithmetic (torch rfft / fft / ifft / irfft per block, in the reference's
+# order) and the data placement (who sends which slice to whom, where it lands) are the reference's.
+# --------------------------------------------------------------------------------------
+def pencil_factors(nranks: int, n: Sequence[int]):
+    """:574-618 -- (pencil_y_partitions, pencil_z_partitions): py, pz >= 2, py <= min(ny, nx/2+1), pz <= min(nz, ny), smallest
+    |py - pz|, first found wins; None when nothing fits (the reference's paramError)."""
+    nxc = n[0] // 2 + 1
+    best = None
+    best_cost = None
+
+    def consider(px, pz):
+        nonlocal best, best_cost
+        if px < 2 or pz < 2 or px > n[1] or px > nxc or pz > n[2] or pz > n[1]:
+            return
+        cost = abs(px - pz)
+        if best is None or cost < best_cost:
+            best, best_cost = (px, pz), cost
+
+    max_divisor = max(2, int(math.sqrt(nranks)))
+    for d in range(2, max_divisor + 1):
+        if nranks % d == 0:
+            consider(d, nranks // d)
+            consider(nranks // d, d)
+    return best
+
+
+class PencilDomain:
+    """The blocks of every rank of an FFT_PENCIL job on an nx x ny x nz grid (:620-698): rank r = (py, pz) = (r % Py, r // Py)
+    holds real [nx][y block py][z block pz] and reciprocal [kx block py][ky block pz][nz]; kx = rfftfreq (the r2c transform runs
+    along x, :282-284), ky, kz = fftfreq."""
+
+    def __init__(self, n: Sequence[int], mx: Sequence[float], nranks: int, mn: Sequence[float] = (0.0, 0.0, 0.0)):
+        self.n = [int(v) for v in n]
+        self.nranks = nranks
+        f = pencil_factors(nranks, self.n)
+        if f is None:
+            raise RuntimeError("FFT_PENCIL requires factoring the number of MPI ranks into two integers greater than one that fit the domain")
+        self.Py, self.Pz = f
+        self.dx = [(float(mx[d]) - float(mn[d])) / self.n[d] for d in range(3)]
+        ones = lambda k: [1] * k
+        self.y_counts = partition_helper(self.n[1], ones(self.Py))
+        self.z_counts = partition_helper(self.n[2], ones(self.Pz))
+        self.x_sizes = partition_helper(self.n[0] // 2 + 1, ones(self.Py))      # _pencil_x_sizes
+        self.y2_sizes = partition_helper(self.n[1], ones(self.Pz))              # _pencil_stage2_y_sizes
+        off = lambda c: [sum(c[:i]) for i in range(len(c))]
+        self.y_off, self.z_off, self.x_off, self.y2_off = off(self.y_counts), off(self.z_counts), off(self.x_sizes), off(self.y2_sizes)
+        self.kaxis = [torch.fft.rfftfreq(self.n[0], self.dx[0], dtype=F64) * 2.0 * math.pi,
+                      torch.fft.fftfreq(self.n[1], self.dx[1], dtype=F64) * 2.0 * math.pi,
+                      torch.fft.fftfreq(self.n[2], self.dx[2], dtype=F64) * 2.0 * math.pi]
+
+    def real_slices(self, r):
+        py, pz = r % self.Py, r // self.Py
+        return (slice(0, self.n[0]), slice(self.y_off[py], self.y_off[py] + self.y_counts[py]),
+                slice(self.z_off[pz], self.z_off[pz] + self.z_counts[pz]))
+
+    def recip_slices(self, r):
+        px, pyf = r % self.Py, r // self.Py
+        return (slice(self.x_off[px], self.x_off[px] + self.x_sizes[px]), slice(self.y2_off[pyf], self.y2_off[pyf] + self.y2_sizes[pyf]),
+                slice(0, self.n[2]))
+
+    def split(self, g: torch.Tensor) -> List[torch.Tensor]:
+        return [g[self.real_slices(r)].contiguous() for r in range(self.nranks)]
+
+    # :1021-1034 with pencilStage1Forward (:1105-1180) and pencilStage2Forward (:1182-1256)
+    def fft(self, blocks: List[torch.Tensor]) -> List[torch.Tensor]:
+        Py, Pz = self.Py, self.Pz
+        after_x = [torch.fft.rfft(b, dim=0) for b in blocks]
+        stage1 = []
+        for r in range(self.nranks):
+            px, base = r % Py, (r // Py) * Py
+            res = torch.empty((self.x_sizes[px], self.n[1], blocks[r].shape[2]), dtype=after_x[r].dtype)
+            for py_src in range(Py):           # message from rank base + py_src: its slice [x_off[px] : +x_sizes[px]]
+                src = base + py_src
+                chunk = after_x[src][self.x_off[px]:self.x_off[px] + self.x_sizes[px]].contiguous()
+                res[:, self.y_off[py_src]:self.y_off[py_src] + self.y_counts[py_src], :] = chunk
+            stage1.append(res)
+        after_y = [torch.fft.fft(t, dim=1) for t in stage1]
+        out = []
+        for r in range(self.nranks):
+            px, yf = r % Py, r // Py
+            res = torch.empty((self.x_sizes[px], self.y2_sizes[yf], self.n[2]), dtype=after_y[r].dtype)
+            for z_src in range(Pz):            # message from rank z_src * Py + px: its slice [:, y2_off[yf] : +y2_sizes[yf]]
+                src = z_src * Py + px
+                chunk = after_y[src][:, self.y2_off[yf]:self.y2_off[yf] + self.y2_sizes[yf]].contiguous()
+                res[:, :, self.z_off[z_src]:self.z_off[z_src] + self.z_counts[z_src]] = chunk
+            out.append(torch.fft.fft(res, dim=2))
+        return out
+
+    # :1036-1047 with pencilStage2Inverse (:1258-1329) and pencilStage1Inverse (:1331-1404)
+    def ifft(self, spec: List[torch.Tensor]) -> List[torch.Tensor]:
+        Py, Pz = self.Py, self.Pz
+        after_z = [torch.fft.ifft(t, dim=2) for t in spec]
+        stage2 = []
+        for r in range(self.nranks):
+            px, zi = r % Py, r // Py
+            res = torch.empty((self.x_sizes[px], self.n[1], self.z_counts[zi]), dtype=after_z[r].dtype)
+            for py_src in range(Pz):           # message from rank py_src * Py + px: its z slice of THIS rank
+                src = py_src * Py + px
+                chunk = after_z[src][:, :, self.z_off[zi]:self.z_off[zi] + self.z_counts[zi]].contiguous()
+                res[:, self.y2_off[py_src]:self.y2_off[py_src] + self.y2_sizes[py_src], :] = chunk
+            stage2.append(res)
+        after_y = [torch.fft.ifft(t, dim=1) for t in stage2]
+        out = []
+        for r in range(self.nranks):
+            py, base = r % Py, (r // Py) * Py
+            res = torch.empty((self.n[0] // 2 + 1, self.y_counts[py], after_y[r].shape[2]), dtype=after_y[r].dtype)
+            for px_src in range(Py):           # message from rank base + px_src: its y slice of THIS rank
+                src = base + px_src
+                chunk = after_y[src][:, self.y_off[py]:self.y_off[py] + self.y_counts[py], :].contiguous()
+                res[self.x_off[px_src]:self.x_off[px_src] + self.x_sizes[px_src]] = chunk
+            out.append(torch.fft.irfft(res, n=self.n[0], dim=0))
+        return out
+
+
+# --------------------------------------------------------------------------------------
 # Cahn-Hilliard operators
 # --------------------------------------------------------------------------------------
 def reciprocal_laplacian_factor(dom: Domain, factor: float) -> torch.Tensor:

@@ -222,6 +222,67 @@ def run_fft(job, P, r, kv):
     return {"max_err": max(errs), "errs": errs}
 
 
+def run_pencil(job, P, r, kv):
+    """parallel_mode = FFT_PENCIL (DomainAction.C:568-742, 1021-1047, 1105-1404): mrl_fft_r2c / mrl_fft_c2r on a pencil context with the
+    library-owned staged exchanges, against the oracle's restatement of the reference's stages (oracle.PencilDomain) and the serial
+    torch transform of the global array; local shapes, begins and reciprocal axes against partitionPencils"""
+    import math
+    from marlin_amd import api
+    from oracle import marlin_oracle as mo
+    shape = [int(x) for x in kv.get("shape", "16,12,10").split(",")]
+    L = [2.0 * math.pi, 4.0 * math.pi, 6.0 * math.pi]
+    comm = api.Comm(job, P, r, device=0, transport=int(kv.get("transport", 0)), timeout=40.0)
+    ctx = api.Context(3, shape, L, nranks=P, rank=r, pencil=True, device=0)
+    ctx.attach_comm(comm)
+    dom = mo.PencilDomain(shape, L, P)
+    rs, ks = dom.real_slices(r), dom.recip_slices(r)
+    layout_ok = (ctx.pencil_grid == (dom.Py, dom.Pz)
+                 and ctx.real_shape == [s.stop - s.start for s in rs] and ctx.real_begin == [s.start for s in rs]
+                 and ctx.recip_shape == [s.stop - s.start for s in ks] and ctx.recip_begin == [s.start for s in ks])
+    axes_ok = all(bool((ctx.reciprocal_axis(d).cpu() == dom.kaxis[d][ks[d]]).all()) for d in range(3))
+    torch.manual_seed(11)
+    g = torch.rand(shape, dtype=torch.float64)
+    blocks = dom.split(g)
+    ref = dom.fft(blocks)[r]
+    serial = torch.fft.fftn(torch.fft.rfft(g, dim=0), dim=(1, 2))[ks]
+    loc = blocks[r].cuda()
+    errs = []
+    scale = serial.abs().max().item()
+    for rep in range(3):   # repeated transforms reuse the receive buffers: the acknowledgement flags are exercised
+        spec = ctx.fft(loc)
+        ctx.sync()
+        errs.append((spec.cpu() - ref).abs().max().item() / scale)
+        errs.append((spec.cpu() - serial).abs().max().item() / scale)
+    back = ctx.ifft(spec)
+    ctx.sync()
+    errs.append((back.cpu() - blocks[r]).abs().max().item())
+    # an inverse transform of a spectrum that is NOT the image of a real field in its self-conjugate x bins (irfft ignores their
+    # imaginary parts): against the oracle's irfft-based stages
+    torch.manual_seed(12 + r)
+    junk = torch.randn(ctx.recip_shape, dtype=torch.complex128)
+    junk_all = []
+    for q in range(P):
+        torch.manual_seed(12 + q)
+        junk_all.append(torch.randn([s.stop - s.start for s in dom.recip_slices(q)], dtype=torch.complex128))
+    back2 = ctx.ifft(junk.cuda())
+    ctx.sync()
+    ref2 = dom.ifft(junk_all)[r]
+    errs.append((back2.cpu() - ref2).abs().max().item() / max(ref2.abs().max().item(), 1e-300))
+    tot = ctx.sum(loc)
+    errs.append(abs(tot - g.sum().item()) / g.sum().item())
+    # the fused solver entry points refuse pencil contexts
+    refused = False
+    try:
+        ctx.ch_substep(api.ch_params(), loc, torch.empty_like(loc), torch.zeros(2 * spec.numel(), dtype=torch.float64, device="cuda"), [], 0, 1e-3)
+    except api.MarlinHipError as e:
+        refused = e.code == -2
+    st = comm.stats()
+    ctx.close()
+    comm.close()
+    return {"max_err": max(errs), "errs": errs, "layout_ok": layout_ok, "axes_ok": axes_ok, "refused": refused, "stats": st,
+            "grid": [dom.Py, dom.Pz]}
+
+
 def run_mech(job, P, r, kv):
     """FFTMechanics::computeBuffer through mrl_mech_newton_cg on a slab context (library-owned exchanges, device-side all-reduce of the
     CG scalars).  case=gold: test/tests/mechanics/mech3d.i against mech3d.h5 (abs 1e-10); otherwise an n^3 two-phase RVE (planned
@@ -325,6 +386,8 @@ def main():
         out = run_ch(job, P, r, kv)
     elif case == "chgold":
         out = run_ch(job, P, r, kv, gold=True)
+    elif case == "pencil":
+        out = run_pencil(job, P, r, kv)
     elif case == "fft":
         out = run_fft(job, P, r, kv)
     elif case == "chbench":

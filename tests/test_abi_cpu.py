@@ -99,6 +99,28 @@ def test_launchers_refuse_to_exec_rank_processes_under_a_profiler_preload():
         assert r.returncode != 0 and "profiler preload" in r.stderr, (exe, r.returncode, r.stderr[-400:])
 
 
+def test_moose_shim_sources_only_call_what_the_abi_declares():
+    """marlin_plugin/ (the MOOSE-side classes a Marlin maintainer compiles; INTEGRATION.md quotes them): every mrl_* function, MRL_*
+    constant and mrl_ch_params / mrl_mech_params member they use is declared in include/marlin_hip.h -- the shim cannot be compiled
+    here (no MOOSE), so this is the check that it has not drifted from the ABI"""
+    hdr = open(os.path.join(ROOT, "include", "marlin_hip.h")).read()
+    plug = os.path.join(ROOT, "marlin_plugin")
+    files = [os.path.join(d, f) for d, _, fs in os.walk(plug) for f in fs if f.endswith((".h", ".C"))]
+    assert len(files) >= 5
+    for path in files:
+        src = open(path).read()
+        code = re.sub(r"//[^\n]*", "", src)
+        for fn in set(re.findall(r"\b(mrl_[a-z0-9_]+)\s*\(", code)):
+            assert re.search(r"\b%s\s*\(" % fn, hdr), (os.path.basename(path), fn)
+        for const in set(re.findall(r"\b(MRL_[A-Z0-9_]+)\b", code)):
+            assert re.search(r"\b%s\b" % const, hdr), (os.path.basename(path), const)
+        for member in set(re.findall(r"\b_p\.([a-z_]+)\b", code)) | set(re.findall(r"\b_prm\.([a-z_]+)\b", code)):
+            assert re.search(r"\b%s\b[^;]*;" % member, hdr), (os.path.basename(path), member)
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for f in ("HipDomain.h", "HipAdamsBashforthMoulton.C", "HipFFTMechanics.C", "marlin_plugin.mk"):
+        assert f in integ, f
+
+
 def test_lds_conflict_model_reproduces_the_measured_shares():
     """tools/lds_conflict_model.py (the bank model behind LineMapParams): the old line map of the 512-point z kernels costs
     40 % conflict cycles (measured: 41-47 %), the adopted xor swizzle none; the 256-point plan was and stays conflict-free"""

@@ -256,6 +256,60 @@ def test_config_c_128_newton_cg_vs_oracle():
     assert (Fg.cpu() - Fref).abs().max().item() <= 1e-10
 
 
+def test_config_e_256_operator_applications_vs_oracle():
+    """BASELINE configs[4] at its size, pinned to the ORACLE (the 256^3 mechanics test compared the slab path with the
+    serial HIP solver only).  A seeded finite-strain state on the 256^3 two-phase RVE: one HyperElasticIsotropic stress
+    (HyperElasticIsotropic.C:42-52) and one operator application G(K_dF(dF)) (FFTMechanics.C:105-108).  The oracle evaluates the
+    constitutive model in x-slabs of 8 planes -- its K4 is 648 B per point, 10.9 GB at once -- and G through its closed form
+    (pinned against the stored Ghat4 operator in tests/test_oracle_golden.py).  1e-10, the tolerance of the reference's mechanics
+    tests; the 4-rank slab solve at this size is tied to this serial path by test_slab_native_gpu.py."""
+    from marlin_amd.api import Context
+    from oracle import marlin_oracle as mo
+    n = 256
+    shape, L = [n, n, n], [2 * math.pi] * 3
+    dom = mo.Domain(3, shape, L)
+    s = 9 * n // 32
+    phase = torch.zeros(shape, dtype=torch.float64)
+    phase[-s:, :s, -s:] = 1.0
+    K = (1.0 - phase) * 0.833 + phase * 8.33
+    mu = (1.0 - phase) * 0.386 + phase * 3.86
+    del phase
+    g = torch.Generator().manual_seed(1234)
+    F = torch.eye(3, dtype=torch.float64) + 0.02 * torch.randn(shape + [3, 3], dtype=torch.float64, generator=g)
+    dF = torch.randn(shape + [3, 3], dtype=torch.float64, generator=g)
+    ids = mo.MechIdentities(3)
+
+    class _Slab:                      # what hyper_elastic_isotropic needs of a Domain: the shape of a block of x planes
+        def __init__(self, nxs):
+            self.dim, self.nxs = 3, nxs
+
+        def value_shape(self, extra):
+            return [self.nxs, n, n] + list(extra)
+
+    P_ref = torch.empty_like(F)
+    KdF_ref = torch.empty_like(F)
+    step = 8
+    for x0 in range(0, n, step):
+        sl = slice(x0, x0 + step)
+        Ps, K4s = mo.hyper_elastic_isotropic(_Slab(step), ids, F[sl], K[sl], mu[sl])
+        P_ref[sl] = Ps
+        KdF_ref[sl] = mo.trans2(mo.ddot42(K4s, mo.trans2(dF[sl])))       # FFTMechanics.C:107-108
+        del Ps, K4s
+    G_ref = mo.gamma_closed_form(dom, KdF_ref)
+
+    ctx = Context(3, shape, L)
+    Fd, Kd, mud = F.cuda(), K.cuda(), mu.cuda()
+    Pg = ctx.mech_stress(Fd, Kd, mud)
+    tg = ctx.mech_tangent_apply(Fd, Kd, mud, dF.cuda())
+    ctx.sync()
+    assert (Pg.cpu() - P_ref).abs().max().item() <= 1e-10
+    assert (tg.cpu() - KdF_ref).abs().max().item() <= 1e-10 * max(1.0, KdF_ref.abs().max().item())
+    Gg = ctx.gamma_apply(tg)
+    ctx.sync()
+    assert (Gg.cpu() - G_ref).abs().max().item() <= 1e-10 * max(1.0, G_ref.abs().max().item())
+    ctx.close()
+
+
 def test_arrays_beyond_4_gib_stay_on_the_fused_path():
     """1024 x 512 x 1024 (4.3 GB per half-spectrum array): the fused x pass takes its 64-bit-offset variant instead of falling to the
     any-length path (round 1: silently 3x slower).  The oracle cannot reach this size in test time, so parity is against the

@@ -482,6 +482,22 @@ def test_gradient_case_fft_slab(tmp_path):
     assert 0.0 <= got2[1, 1] <= 1e-10
 
 
+def test_gradient_case_fft_pencil(tmp_path):
+    """test/tests/gradient/tests:21-29 (gradient_cpu_pencil): the same input with parallel_mode = FFT_PENCIL on FOUR ranks (2 x 2
+    pencils of the 40^3 box), here four rank processes on one GPU through the C++ driver -- FFTGradient over the library's pencil
+    transforms (r2c along x, two staged exchanges each way, owned by the library), the integral all-reduced; against the serial gold
+    CSV as in the reference"""
+    g = load_golden("fft_gold.npz")["gradient_out"]
+    _run(["problem=gradient", "dim=3", "nx=40", "ny=40", "nz=40", "xmax=2pi", "ymax=4pi", "zmax=6pi", "parallel_mode=FFT_PENCIL", "nranks=4",
+          "device=0"], tmp_path)
+    got = np.loadtxt(tmp_path / "gradient.csv", delimiter=",", skiprows=1)
+    assert 0.0 <= got[1, 1] <= 10.0 * g[1, 1]
+    _run(["problem=gradient_square", "dim=3", "nx=40", "ny=40", "nz=40", "xmax=2pi", "ymax=4pi", "zmax=6pi", "parallel_mode=FFT_PENCIL",
+          "nranks=4", "device=0"], tmp_path)
+    got2 = np.loadtxt(tmp_path / "gradient_square.csv", delimiter=",", skiprows=1)
+    assert 0.0 <= got2[1, 1] <= 1e-10
+
+
 def test_gradient_square_case(tmp_path):
     """test/tests/gradient/tests (gradient_square.i): FFTGradientSquare of sin(x)+sin(y)+sin(z) vs cos^2 sums; the gold
     value is integrated round-off (6.9e-12)"""

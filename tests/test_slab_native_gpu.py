@@ -224,3 +224,17 @@ def test_bench_drivers_agree_on_two_ranks():
     assert native["exchange"]["bytes_sent_to_peers_per_step_rank0"] > 0
     assert native["exchange"]["transport"]["selected"] in ("peer_store", "peer_copy")
     assert native["n_gpus"] == 2 and native["config"]["grid"] == [64, 128, 64]
+
+
+@pytest.mark.parametrize("P,shape,transport", [(4, "16,12,10", 1), (4, "40,40,40", 2), (4, "64,64,64", 1), (6, "9,8,7", 1), (4, "7,9,11", 2)])
+def test_native_pencil_transforms_vs_oracle(P, shape, transport):
+    """parallel_mode = FFT_PENCIL (the last SURVEY 8(f) item; DomainAction.C:568-742, 1021-1047, 1105-1404) on P = py x pz rank
+    PROCESSES sharing this box's GPU: mrl_fft_r2c / mrl_fft_c2r with the four staged exchanges owned by the library against the oracle's
+    restatement of the reference's stages and the serial transform of the global array (2e-15 x n relative), the round trip (1e-14,
+    64^3 included), an inverse transform of a non-Hermitian spectrum (irfft semantics), block shapes / begins / reciprocal axes of
+    partitionPencils bit for bit, global reductions, and MRL_ERR_UNSUPPORTED from the fused solver entry points"""
+    res = run_job(P, "pencil", f"shape={shape}", f"transport={transport}")
+    n = max(int(x) for x in shape.split(","))
+    assert all(r["layout_ok"] and r["axes_ok"] and r["refused"] for r in res), res
+    assert max(r["max_err"] for r in res) <= 2e-15 * n, res
+    assert all(r["stats"]["exchanges"] > 0 and r["stats"]["bytes_sent"] > 0 for r in res)

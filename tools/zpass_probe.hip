@@ -1,0 +1,459 @@
+// Where does the fused z pass (k_z_inv_fwd: half spectra -> c -> mu = f'(c) -> half spectra of c and mu) spend its time?
+// Ablations of the product kernel on the product geometry, all in one process so that one gpurun compares them on one box:
+//   ABL 0  the kernel as it is (loads, three transforms, stores)
+//   ABL 1  memory only: the same loads and stores in the same order, no transform (what the access pattern + occupancy allow)
+//   ABL 2  compute only: the three transforms on register data, one never-taken store (what the ALU / LDS side costs alone)
+// with the lines per workgroup T and the waves-per-SIMD bound as template knobs.  Before every timed launch a copy kernel
+// re-writes the input array in place (the inverse y pass that precedes the kernel in the substep leaves it partly in the
+// Infinity Cache in the same way).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -Imarlin_amd/csrc tools/zpass_probe.hip -o marlin_amd/lib/zpass_probe
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "fft_pow2_kernels.h"
+
+using namespace mrl;
+using namespace mrl::p2;
+
+#define CK(x)                                                                   \
+  do {                                                                          \
+    hipError_t e_ = (x);                                                        \
+    if (e_ != hipSuccess) {                                                     \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      exit(1);                                                                  \
+    }                                                                           \
+  } while (0)
+
+template <int N, int T, int WPS, int ABL>
+__global__ void __launch_bounds__(T *Plan<N>::TPL, WPS) k_ea(const kcplx *__restrict__ in, kcplx *__restrict__ out0, kcplx *__restrict__ out1,
+                                                              ChDev chp, kreal scale, long long nlines, const kcplx *__restrict__ tw, ZLay zl) {
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = T, NZC = N / 2 + 1, NT = T * TPL;
+  constexpr int FAM = MRL_FE_DOUBLE_WELL;
+  using Map = MapLine<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  kcplx *W = reinterpret_cast<kcplx *>(smem);
+  kcplx *X = W + N;
+  const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
+  const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
+  const bool valid = L < nlines;
+  TwRegs<N, NT> twr;
+  tw_issue_staged<N>(twr, tw);
+  kcplx v[P];
+  if (ABL != 2) {
+    const kcplx *A = in + zrow(2 * (valid ? L : 0), NZC, zl);
+    const kcplx *B = in + zrow(2 * (valid ? L : 0) + 1, NZC, zl);
+    kcplx av[P], bv[P];
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      const int p = q + m * TPL;
+      const int k = (p <= N / 2) ? p : N - p;
+      av[m] = A[k];
+      bv[m] = B[k];
+    }
+    tw_commit<N>(twr, W);
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      const int p = q + m * TPL;
+      const bool lo = p <= N / 2;
+      const int k = lo ? p : N - p;
+      kcplx a = av[m], b = bv[m];
+      if (k == 0 || k == N / 2) {
+        a.y = 0.0;
+        b.y = 0.0;
+      }
+      const kcplx x = lo ? mkc(a.x - b.y, a.y + b.x) : mkc(a.x + b.y, b.x - a.y);
+      v[m] = cswap(x);
+    }
+  } else {
+    tw_commit<N>(twr, W);
+#pragma unroll
+    for (int m = 0; m < P; ++m) v[m] = mkc(0.5 + 1e-3 * (q + m), 0.25 - 1e-3 * l);
+  }
+  if (ABL != 1) fft_line<N, Map>(v, q, l, X, W);
+  kreal cb[P];
+#pragma unroll
+  for (int m = 0; m < P; ++m) {
+    const kreal ca = v[m].y * scale;
+    cb[m] = v[m].x * scale;
+    v[m] = mkc(ca, mu_eval<FAM>(chp, ca));
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half == 1) {
+#pragma unroll
+      for (int m = 0; m < P; ++m) v[m] = mkc(cb[m], mu_eval<FAM>(chp, cb[m]));
+    }
+    if (ABL != 1) fft_line<N, Map>(v, q, l, X, W);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
+    __syncthreads();
+    if (valid && (ABL != 2 || v[0].x == 123.456)) {
+      kcplx *o0 = out0 + zrow(2 * L + half, NZC, zl), *o1 = out1 + zrow(2 * L + half, NZC, zl);
+#pragma unroll
+      for (int m = 0; m <= P / 2; ++m) {
+        const int k = q + m * TPL;
+        if (k > N / 2) break;
+        const kcplx xk = v[m];
+        const kcplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
+        o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
+        o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
+      }
+    }
+  }
+}
+
+
+// value of `x` held by lane `src` (absolute lane index in the wave)
+__device__ __forceinline__ double shfl_d(double x, int src) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_ds_bpermute(src << 2, lo);
+  hi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ kcplx shfl_c(kcplx x, int src) { return mkc(shfl_d(x.x, src), shfl_d(x.y, src)); }
+
+// k <-> N - k pairing of a transformed line without the natural-order copy through LDS: element N - k of the line lives in lane
+// (TPL - q) % TPL of the same line (register P - 1 - m), for q = 0 in the lane itself (register P - m)
+template <int N>
+__device__ __forceinline__ void store_pair_shfl(const kcplx (&v)[Plan<N>::P], int q, int partner, kcplx *o0, kcplx *o1) {
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL;
+#pragma unroll
+  for (int m = 0; m < P / 2; ++m) {
+    const int k = q + m * TPL;
+    const kcplx s = shfl_c(v[P - 1 - m], partner);
+    const kcplx own = v[(P - m) % P];
+    const kcplx xk = v[m];
+    const kcplx xn = q == 0 ? own : s;
+    o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
+    o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
+  }
+  if (q == 0) {
+    const kcplx xk = v[P / 2];
+    o0[N / 2] = mkc(kreal(0.5) * (xk.x + xk.x), kreal(0.5) * (xk.y - xk.y));
+    o1[N / 2] = mkc(kreal(0.5) * (xk.y + xk.y), kreal(-0.5) * (xk.x - xk.x));
+  }
+}
+
+template <int N, int T, int WPS, bool SHIN, bool SHOUT>
+__global__ void __launch_bounds__(T *Plan<N>::TPL, WPS) k_ea2(const kcplx *__restrict__ in, kcplx *__restrict__ out0, kcplx *__restrict__ out1,
+                                                               ChDev chp, kreal scale, long long nlines, const kcplx *__restrict__ tw, ZLay zl) {
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, LPB = T, NZC = N / 2 + 1, NT = T * TPL;
+  constexpr int FAM = MRL_FE_DOUBLE_WELL;
+  static_assert(64 % TPL == 0, "a line must not straddle waves");
+  using Map = MapLine<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  kcplx *W = reinterpret_cast<kcplx *>(smem);
+  kcplx *X = W + N;
+  const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
+  const int lane = threadIdx.x & 63;
+  const int partner = lane - q + ((TPL - q) % TPL);
+  const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * LPB + l;
+  const bool valid = L < nlines;
+  TwRegs<N, NT> twr;
+  tw_issue_staged<N>(twr, tw);
+  kcplx v[P];
+  {
+    const kcplx *A = in + zrow(2 * (valid ? L : 0), NZC, zl);
+    const kcplx *B = in + zrow(2 * (valid ? L : 0) + 1, NZC, zl);
+    if (SHIN) {
+      kcplx av[P / 2], bv[P / 2];
+#pragma unroll
+      for (int m = 0; m < P / 2; ++m) {
+        av[m] = A[q + m * TPL];
+        bv[m] = B[q + m * TPL];
+      }
+      kcplx aN = A[q == 0 ? N / 2 : q], bN = B[q == 0 ? N / 2 : q];  // Nyquist bin: lane 0 only (the others re-read an element they hold)
+      tw_commit<N>(twr, W);
+      kcplx yh[P / 2];
+#pragma unroll
+      for (int m = 0; m < P / 2; ++m) {
+        kcplx a = av[m], b = bv[m];
+        // position N - k (k = q + m TPL, never 0 or N/2 for the lanes that use it): conj(A[k]) + i conj(B[k])
+        yh[m] = cswap(mkc(a.x + b.y, b.x - a.y));
+        if (m == 0) {  // k = 0 (lane 0): c2r ignores the imaginary part of the self-conjugate bins
+          a.y = q == 0 ? 0.0 : a.y;
+          b.y = q == 0 ? 0.0 : b.y;
+        }
+        v[m] = cswap(mkc(a.x - b.y, a.y + b.x));
+      }
+      aN.y = 0.0;
+      bN.y = 0.0;
+      const kcplx vN = cswap(mkc(aN.x - bN.y, aN.y + bN.x));
+#pragma unroll
+      for (int m = P / 2; m < P; ++m) {
+        // position p = q + m TPL > N/2: held by the partner lane as yh[P - 1 - m]; lane 0: p = m TPL, its own yh[P - m] (m = P/2: the Nyquist bin)
+        const kcplx s = shfl_c(yh[P - 1 - m], partner);
+        const kcplx own = (m == P / 2) ? vN : yh[(P - m) % (P / 2)];
+        v[m] = mkc(q == 0 ? own.x : s.x, q == 0 ? own.y : s.y);
+      }
+    } else {
+      kcplx av[P], bv[P];
+#pragma unroll
+      for (int m = 0; m < P; ++m) {
+        const int p = q + m * TPL;
+        const int k = (p <= N / 2) ? p : N - p;
+        av[m] = A[k];
+        bv[m] = B[k];
+      }
+      tw_commit<N>(twr, W);
+#pragma unroll
+      for (int m = 0; m < P; ++m) {
+        const int p = q + m * TPL;
+        const bool lo = p <= N / 2;
+        const int k = lo ? p : N - p;
+        kcplx a = av[m], b = bv[m];
+        if (k == 0 || k == N / 2) {
+          a.y = 0.0;
+          b.y = 0.0;
+        }
+        const kcplx x = lo ? mkc(a.x - b.y, a.y + b.x) : mkc(a.x + b.y, b.x - a.y);
+        v[m] = cswap(x);
+      }
+    }
+  }
+  fft_line<N, Map>(v, q, l, X, W);
+  kreal cb[P];
+#pragma unroll
+  for (int m = 0; m < P; ++m) {
+    const kreal ca = v[m].y * scale;
+    cb[m] = v[m].x * scale;
+    v[m] = mkc(ca, mu_eval<FAM>(chp, ca));
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half == 1) {
+#pragma unroll
+      for (int m = 0; m < P; ++m) v[m] = mkc(cb[m], mu_eval<FAM>(chp, cb[m]));
+    }
+    fft_line<N, Map>(v, q, l, X, W);
+    kcplx *o0 = out0 + zrow(2 * L + half, NZC, zl), *o1 = out1 + zrow(2 * L + half, NZC, zl);
+    if (SHOUT) {
+      if (valid) store_pair_shfl<N>(v, q, partner, o0, o1);   // (`valid` is uniform over a line, hence over the lanes that exchange)
+    } else {
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < P; ++m) X[Map::at(q + m * TPL, l)] = v[m];
+      __syncthreads();
+      if (valid) {
+#pragma unroll
+        for (int m = 0; m <= P / 2; ++m) {
+          const int k = q + m * TPL;
+          if (k > N / 2) break;
+          const kcplx xk = v[m];
+          const kcplx xn = X[Map::at(k == 0 ? 0 : N - k, l)];
+          o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
+          o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_touch(double2 *p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double2 v = p[i];
+    v.x += 1e-300;
+    p[i] = v;
+  }
+}
+__global__ void k_fill(double2 *p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = make_double2(0.5 + 1e-3 * (double)(i % 977), 0.1);
+}
+
+struct Bufs {
+  double2 *a, *b, *tw;
+  size_t nspec;
+  long long rows;
+};
+
+template <int N, int T, int WPS, int ABL>
+static void run(const char *name, const Bufs &B, bool padded) {
+  constexpr int NZC = N / 2 + 1;
+  const size_t lds = sizeof(kcplx) * (N + T * MapLine<N>::LP);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ea<N, T, WPS, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int occ = 0;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ea<N, T, WPS, ABL>, T * Plan<N>::TPL, lds));
+  const long long nlines = B.rows / 2;
+  const unsigned nb = (unsigned)((nlines + T - 1) / T);
+  ChDev chp{MRL_FE_DOUBLE_WELL, 0.1, 0.0, 0.0, {}};
+  // rows per plane as in the product layout (N rows per x plane, pad to an odd number of 256-byte pieces)
+  ZLay zl{0u, 0u};
+  if (padded) {
+    const unsigned lpp = (unsigned)N;
+    size_t plane = (size_t)lpp * NZC;
+    plane = (plane + 15) / 16 * 16;
+    if (((plane / 16) & 1) == 0) plane += 16;
+    zl = ZLay{lpp, (unsigned)(plane - (size_t)lpp * NZC)};
+  }
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  float tot = 0.f, best = 1e9f;
+  const int reps = 24;
+  for (int r = -4; r < reps; ++r) {
+    k_touch<<<4096, 256>>>(B.a, B.nspec);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_ea<N, T, WPS, ABL>), dim3(nb), dim3(T * Plan<N>::TPL), lds, 0, B.a, B.a, B.b, chp, 1.0 / N, nlines, B.tw, zl);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r >= 0) {
+      tot += ms;
+      best = ms < best ? ms : best;
+    }
+  }
+  CK(hipGetLastError());
+  const double bytes = 3.0 * 16.0 * (double)B.rows * NZC;
+  const double us = tot / reps * 1e3;
+  printf("%-44s N=%d T=%d wps=%d abl=%d  blocks/CU %d  lds %6zu  avg %7.1f us  best %7.1f us  %6.0f GB/s (3h model)\n", name, N, T, WPS, ABL, occ, lds, us,
+         best * 1e3, bytes / us * 1e-3);
+  fflush(stdout);
+  CK(hipEventDestroy(e0));
+  CK(hipEventDestroy(e1));
+}
+
+typedef void (*EaKernel)(const kcplx *, kcplx *, kcplx *, ChDev, kreal, long long, const kcplx *, ZLay);
+
+template <int N>
+static ZLay lay(bool padded) {
+  constexpr int NZC = N / 2 + 1;
+  ZLay zl{0u, 0u};
+  if (padded) {
+    const unsigned lpp = (unsigned)N;
+    size_t plane = (size_t)lpp * NZC;
+    plane = (plane + 15) / 16 * 16;
+    if (((plane / 16) & 1) == 0) plane += 16;
+    zl = ZLay{lpp, (unsigned)(plane - (size_t)lpp * NZC)};
+  }
+  return zl;
+}
+
+static std::vector<double2> g_ref0, g_ref1;
+
+// time kernel K (T lines per workgroup) like run(); check = 1: keep its outputs as the reference, 2: compare with the reference bit for bit
+template <int N, int T>
+static void run2(const char *name, EaKernel K, const Bufs &B, bool padded, int check = 0) {
+  constexpr int NZC = N / 2 + 1;
+  const size_t lds = sizeof(kcplx) * (N + T * MapLine<N>::LP);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int occ = 0;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, K, T * Plan<N>::TPL, lds));
+  const long long nlines = B.rows / 2;
+  const unsigned nb = (unsigned)((nlines + T - 1) / T);
+  ChDev chp{MRL_FE_DOUBLE_WELL, 0.1, 0.0, 0.0, {}};
+  const ZLay zl = lay<N>(padded);
+  char verdict[64] = "";
+  if (check) {
+    double2 *c, *d;
+    CK(hipMalloc(&c, B.nspec * sizeof(double2)));
+    CK(hipMalloc(&d, B.nspec * sizeof(double2)));
+    CK(hipMemset(c, 0, B.nspec * sizeof(double2)));
+    CK(hipMemset(d, 0, B.nspec * sizeof(double2)));
+    k_fill<<<2048, 256>>>(B.a, B.nspec);
+    hipLaunchKernelGGL(K, dim3(nb), dim3(T * Plan<N>::TPL), lds, 0, B.a, c, d, chp, 1.0 / N, nlines, B.tw, zl);
+    CK(hipDeviceSynchronize());
+    std::vector<double2> h0(B.nspec), h1(B.nspec);
+    CK(hipMemcpy(h0.data(), c, B.nspec * sizeof(double2), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h1.data(), d, B.nspec * sizeof(double2), hipMemcpyDeviceToHost));
+    if (check == 1) {
+      g_ref0 = h0;
+      g_ref1 = h1;
+      snprintf(verdict, sizeof verdict, "  [reference]");
+    } else {
+      size_t bad = 0;
+      for (size_t i = 0; i < B.nspec; ++i)
+        bad += (memcmp(&h0[i], &g_ref0[i], 16) != 0) + (memcmp(&h1[i], &g_ref1[i], 16) != 0);
+      snprintf(verdict, sizeof verdict, "  [%zu elements differ from the reference]", bad);
+    }
+    CK(hipFree(c));
+    CK(hipFree(d));
+  }
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  float tot = 0.f, best = 1e9f;
+  const int reps = 24;
+  for (int r = -4; r < reps; ++r) {
+    k_touch<<<4096, 256>>>(B.a, B.nspec);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(K, dim3(nb), dim3(T * Plan<N>::TPL), lds, 0, B.a, B.a, B.b, chp, 1.0 / N, nlines, B.tw, zl);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r >= 0) {
+      tot += ms;
+      best = ms < best ? ms : best;
+    }
+  }
+  CK(hipGetLastError());
+  const double bytes = 3.0 * 16.0 * (double)B.rows * NZC;
+  const double us = tot / reps * 1e3;
+  printf("%-44s N=%d T=%d blocks/CU %d  lds %6zu  avg %7.1f us  best %7.1f us  %6.0f GB/s (3h model)%s\n", name, N, T, occ, lds, us, best * 1e3,
+         bytes / us * 1e-3, verdict);
+  fflush(stdout);
+  CK(hipEventDestroy(e0));
+  CK(hipEventDestroy(e1));
+}
+
+template <int N>
+static Bufs make(long long rows) {
+  constexpr int NZC = N / 2 + 1;
+  Bufs B;
+  B.rows = rows;
+  B.nspec = (size_t)rows * NZC + (size_t)(rows / N + 2) * 64;
+  CK(hipMalloc(&B.a, B.nspec * sizeof(double2)));
+  CK(hipMalloc(&B.b, B.nspec * sizeof(double2)));
+  k_fill<<<2048, 256>>>(B.a, B.nspec);
+  k_fill<<<2048, 256>>>(B.b, B.nspec);
+  std::vector<double2> tw(N);
+  for (int k = 0; k < N; ++k) {
+    const long double ang = -2.0L * M_PIl * k / N;
+    tw[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+  }
+  CK(hipMalloc(&B.tw, N * sizeof(double2)));
+  CK(hipMemcpy(B.tw, tw.data(), N * sizeof(double2), hipMemcpyHostToDevice));
+  CK(hipDeviceSynchronize());
+  return B;
+}
+
+int main(int argc, char **argv) {
+  {  // clock warm-up
+    Bufs B = make<256>(65536);
+    for (int r = 0; r < 2000; ++r) k_touch<<<4096, 256>>>(B.a, B.nspec);
+    CK(hipDeviceSynchronize());
+    printf("== 256^3 (65536 rows of 129)\n");
+    run2<256, 8>("product", k_ea<256, 8, 2, 0>, B, true, 1);
+    run2<256, 8>("memory only", k_ea<256, 8, 2, 1>, B, true);
+    run2<256, 8>("compute only", k_ea<256, 8, 2, 2>, B, true);
+    run2<256, 8>("pairing by lane shuffle (out)", k_ea2<256, 8, 2, false, true>, B, true, 2);
+    run2<256, 8>("mirror loads by lane shuffle (in)", k_ea2<256, 8, 2, true, false>, B, true, 2);
+    run2<256, 8>("both", k_ea2<256, 8, 2, true, true>, B, true, 2);
+    run2<256, 4>("both, 4 lines", k_ea2<256, 4, 2, true, true>, B, true, 2);
+    run2<256, 4>("both, 4 lines, <= 168 VGPR", k_ea2<256, 4, 3, true, true>, B, true, 2);
+    run2<256, 8>("both, 8 lines, <= 168 VGPR", k_ea2<256, 8, 3, true, true>, B, true, 2);
+    run2<256, 8>("product (again)", k_ea<256, 8, 2, 0>, B, true, 2);
+  }
+  {
+    Bufs B = make<512>(32768);
+    printf("== 512^3 / 8 slab-local (32768 rows of 257)\n");
+    run2<512, 8>("product", k_ea<512, 8, 2, 0>, B, false, 1);
+    run2<512, 8>("memory only", k_ea<512, 8, 2, 1>, B, false);
+    run2<512, 8>("compute only", k_ea<512, 8, 2, 2>, B, false);
+    run2<512, 8>("pairing by lane shuffle (out)", k_ea2<512, 8, 2, false, true>, B, false, 2);
+    run2<512, 8>("mirror loads by lane shuffle (in)", k_ea2<512, 8, 2, true, false>, B, false, 2);
+    run2<512, 8>("both", k_ea2<512, 8, 2, true, true>, B, false, 2);
+    run2<512, 4>("both, 4 lines", k_ea2<512, 4, 2, true, true>, B, false, 2);
+    run2<512, 2>("both, 2 lines", k_ea2<512, 2, 2, true, true>, B, false, 2);
+    run2<512, 8>("product (again)", k_ea<512, 8, 2, 0>, B, false, 2);
+  }
+  return 0;
+}
