@@ -114,6 +114,39 @@ def measured_traffic(slot, n, order_tag):
                                                                            " (counters taken on OLDER kernel sources)")
 
 
+# mechanics profile slot -> kernel name prefix in the rocprofv3 traces (tools/profile_mech.sh -> profiles/traffic_mech<n>.json)
+MECH_KERNEL_OF_SLOT = {"gamma_z_fwd_tangent_dir": "k_gamma_z_fwd_tangent<", "gamma_x_fused": "k_gamma_xfused<",
+                       "gamma_z_inv_dot": "k_z_inv<{n}, true", "cg_update_x_r": "k_cg_update<false, true"}
+
+
+def mech_roofline(kernels, n):
+    """roofline object of the dominant kernel of the Newton-CG solve (per-launch HIP-event time from the library's profile, algorithmic
+    bytes from its ProfScope, counter traffic from the committed PMC passes of tools/profile_mech.sh)"""
+    compute = [k for k in kernels if k.get("GBps", 0) > 0]
+    if not compute:
+        return None
+    dom = max(compute, key=lambda k: k["total_ms"])
+    traffic, src = None, None
+    path = os.path.join(ROOT, "profiles", f"traffic_mech{n}.json")
+    pref = MECH_KERNEL_OF_SLOT.get(dom["kernel"])
+    if pref and os.path.exists(path):
+        with open(path) as f:
+            t = json.load(f)
+        cands = [k for k in t if not k.startswith("_") and k.startswith(pref.format(n=n))]
+        if cands:
+            # (the XUPD / streaming template variants of one kernel: the one with the most launches is the CG loop's)
+            v = t[cands[0]] if len(cands) == 1 else max((t[c] for c in cands), key=lambda e: e.get("fetch_bytes") or 0)
+            if v.get("fetch_bytes") is not None and v.get("write_bytes") is not None:
+                from tools.summarize_prof import kernel_sources_sha256
+                same = t.get("_kernel_sources_sha256") == kernel_sources_sha256()
+                traffic = v["fetch_bytes"] + v["write_bytes"]
+                src = os.path.relpath(path, ROOT) + (" (counters taken on these kernel sources)" if same else " (counters taken on OLDER kernel sources)")
+    return {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(dom["GBps"] / HBM_PEAK_GBPS, 4), "frac_of_measured_copy_ceiling": round(dom["GBps"] / HBM_COPY_GBPS, 4),
+            "traffic": traffic, "traffic_source": src, "avg_launch_ms": dom["avg_ms"],
+            "algorithmic_bytes_per_launch": round(dom["GBps"] * dom["avg_ms"] * 1e6)}
+
+
 def cpu_baseline(shape, dx, sample_steps, keep=()):
     """The oracle (libTorch CPU ops in the reference's order) timed on this box's host cores.  `keep`: substep counts k after
     which the oracle's field is kept (the parity check of the headline configuration: the GPU runs the same k substeps from the
@@ -221,9 +254,24 @@ def _child_env():
 def _run_child(cmd, timeout_s):
     """Run one stage of the chain as a fresh child (its own process group, so that exactly what was started can be ended on a
     time-out); returns (rc, parsed JSON line or None, tail of the output)."""
+    import atexit
     import signal
     import subprocess
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_child_env(), cwd=ROOT, start_new_session=True)
+
+    # the stage lives in its own session: if THIS process is ended (driver time-out, SIGTERM, Ctrl-C) nothing else would signal it and
+    # the ranks would keep the GPUs until their communicator time-outs (ADVICE r03) -- end exactly the process group started here
+    def _end_child(*_sig):
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+        if _sig:
+            sys.exit(128 + _sig[0])
+
+    atexit.register(_end_child)
+    old_handlers = {sg: signal.signal(sg, _end_child) for sg in (signal.SIGTERM, signal.SIGINT)}
     try:
         out, err = p.communicate(timeout=timeout_s)
         rc = p.returncode
@@ -231,6 +279,10 @@ def _run_child(cmd, timeout_s):
         os.killpg(p.pid, signal.SIGKILL)
         out, err = p.communicate()
         rc = -9
+    finally:
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
+        atexit.unregister(_end_child)
     line = None
     for ln in reversed(out.strip().splitlines()):
         if ln.startswith("{"):
@@ -247,6 +299,29 @@ def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def _count_gpus_without_hip():
+    """GPU count from the KFD topology in sysfs (nodes with SIMDs are GPUs): no HIP / torch call, so the launcher really makes no GPU
+    call (torch.cuda.device_count can fall back to hipGetDeviceCount).  Respects HIP_/ROCR_VISIBLE_DEVICES lists."""
+    n = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(root):
+            try:
+                with open(os.path.join(root, node, "properties")) as f:
+                    props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        n = 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""])) if n else len([x for x in v.split(",") if x.strip() != ""])
+    return n
 
 
 def launch_multi(args, argv):
@@ -281,8 +356,10 @@ def launch_multi(args, argv):
             sys.exit(2)
     # more than four rank processes per card is refused here (a box allows few processes on a card at once): one rank per GPU is the
     # configuration; several ranks sharing a card over HIP IPC are for functional runs on a one-GPU box (N = 2 ... 4)
-    import torch as _t
-    ndev = _t.cuda.device_count()     # (counts the devices without initialising the GPU)
+    ndev, counted_by = _count_gpus_without_hip(), "KFD topology in sysfs (no HIP call)"
+    if ndev < 1:   # no KFD topology visible (some containers): torch's count -- amdsmi where present, else hipGetDeviceCount
+        import torch as _t
+        ndev, counted_by = _t.cuda.device_count(), "torch.cuda.device_count (may call hipGetDeviceCount in this launcher process)"
     per_card = args.gpus if args.device >= 0 else -(-args.gpus // max(ndev, 1))
     if ndev < 1 or per_card > 4:
         msg = f"bench.py --gpus {args.gpus}: {ndev} GPU(s) visible -> {per_card} rank processes per card (at most 4 are started)"
@@ -325,7 +402,8 @@ def launch_multi(args, argv):
         rc, line, tail = _run_child(cmd, args.stage_timeout)
         if rc == 0 and line is not None:
             result = line
-            result["launcher"] = {"started_by": "bench.py (this process made no GPU call)" + (", rank 0 of torch.distributed.run" if world_env > 1 else ""),
+            result["launcher"] = {"started_by": "bench.py" + (", rank 0 of torch.distributed.run" if world_env > 1 else ""),
+                                  "devices_counted_by": counted_by,
                                   "ranks_run_as": name, "earlier_stages": tried}
             break
         tried.append({"stage": name, "rc": rc, "tail": tail[-400:]})
@@ -333,6 +411,17 @@ def launch_multi(args, argv):
         with open(verdict + ".tmp", "w") as f:
             f.write("ok" if result is not None else "failed")
         os.replace(verdict + ".tmp", verdict)
+        # the other launcher ranks poll every 0.2 s; the file is removed once they have had ample time to read it, so that a later
+        # job whose port / run id / parent pid coincide cannot read a stale verdict
+        import atexit
+
+        def _drop_verdict(path=verdict):
+            time.sleep(3.0)
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        atexit.register(_drop_verdict)
     if result is None:
         print(json.dumps({"error": "no stage of the multi-GPU launch chain produced a result", "stages": tried}), file=sys.stderr, flush=True)
         sys.exit(1)
@@ -889,8 +978,13 @@ def main():
             from tools.mech_bench import run as mech_run
             del c, Nh
             torch.cuda.empty_cache()
-            m = mech_run(args.mech_grid, 2, profile=False)
+            m = mech_run(args.mech_grid, 2, profile=True)
             out["mechanics"] = {"workload": f"de Geus finite-strain RVE {args.mech_grid}^3, Newton-CG (l_tol 1e-2)",
+                                "roofline": mech_roofline(m["kernels"], args.mech_grid),
+                                "note": "ms_per_cg_iteration = whole mrl_mech_newton_cg calls / CG iterations: it carries the Newton-level "
+                                        "work (stress, residual, two operator applications per Newton step, layout conversion at the ABI) of "
+                                        "2 Newton steps per ~28 iterations; the pure CG loop is small_strain_linear_elastic (197 iterations in "
+                                        "one solve), which runs at the sum of its kernels (look-ahead loop, DESIGN 3b)",
                                 "ms_per_cg_iteration": m["ms_per_cg_iteration"], "cg_iterations_per_substep": m["cg_its"],
                                 "algorithmic_bytes_per_point_per_cg_iteration": m["algorithmic_bytes_per_point_per_cg_iteration"],
                                 "achieved_GBps": m["achieved_GBps"], "frac_of_hbm_peak": m["achieved_GBps"] / HBM_PEAK_GBPS,
@@ -986,6 +1080,14 @@ def bench_mech(args, api, world, rank, dev, dist):
                  "value": npts * sst["cg_its"] / dt_s,
                  "note": "mrl_mech_small_strain: C4 = K II + 2 mu (I4s - II/3), the finite-strain solve's first linear system at F = I; "
                          "parity vs the oracle's restatement in tests/test_mech_gpu.py (the reference has no small-strain solve)"}
+    roof = None
+    if not slab:   # per-kernel HIP-event times of one more solve -> the dominant kernel against the roofline, with counter traffic
+        ctx.set_profiling(True)
+        solve(substeps + 1, F)
+        prof = [k for k in ctx.get_profile() if k["launches"]]
+        ctx.set_profiling(False)
+        roof = mech_roofline([{"kernel": k["kernel"], "total_ms": k["ms"], "avg_ms": k["ms"] / k["launches"],
+                               "GBps": round(k["bytes_per_launch"] / (k["ms"] / k["launches"]) / 1e6, 1)} for k in prof], nz)
     out = None
     if rank == 0:
         bpi = mech_bytes_per_point(nz)
@@ -1001,7 +1103,8 @@ def bench_mech(args, api, world, rank, dev, dist):
                "algorithmic_bytes_per_point_per_cg_iteration": bpi,
                "model_GBps_per_gpu": bpi * npts * tot_its / tot_t / 1e9 / world,
                "model_frac_of_hbm_peak": bpi * npts * tot_its / tot_t / 1e9 / world / HBM_PEAK_GBPS,
-               "model_frac_of_copy_ceiling": bpi * npts * tot_its / tot_t / 1e9 / world / HBM_COPY_GBPS}
+               "model_frac_of_copy_ceiling": bpi * npts * tot_its / tot_t / 1e9 / world / HBM_COPY_GBPS,
+               "roofline": roof}
         if small is not None:
             out["variants"] = {"small_strain_linear_elastic": small}
     finish(out, rank, slab, dist, comm, [ctx])

@@ -149,6 +149,15 @@ int mrl_comm_allreduce(mrl_comm *comm, double *h_values, int32_t n, int32_t op);
  * process, whether HIP IPC is usable, the RCCL library loaded (it is looked up beside that libamdhip64 first), its version and the
  * rank count RCCL itself reports for the communicator (-1: not initialised), exchange channels in use */
 int mrl_comm_describe(const mrl_comm *comm, char *buf, size_t cap);
+/* COLLECTIVE.  The RCCL bring-up alone, stage by stage with a collective verdict after each: load librccl beside the mapped HIP
+ * runtime, draw the ncclUniqueId on rank 0 and broadcast it over the bootstrap segment, check the placement (one device per rank --
+ * PCI bus ids gathered at creation), ncclCommInitRank, ncclCommCount == nranks.  MRL_OK: RCCL is ready (mrl_comm_set_transport(RCCL)
+ * will not initialise anything further); MRL_ERR_UNSUPPORTED: it cannot work on this placement ("unavailable": several ranks share a
+ * device, or no library) -- not an error of the job; MRL_ERR_COMM: a stage that should have worked failed.  mrl_comm_describe reports
+ * rccl_status, rccl_unique_id_hash (equal on every rank once stage 2 ran), devices_per_rank, distinct_devices, rccl_comm_nranks.
+ * Replaces nothing in the reference (its transposes are MPI, DomainAction.C:889-927); this is what lets N rank processes on one GPU
+ * test everything up to the call that needs N GPUs. */
+int mrl_comm_rccl_preflight(mrl_comm *comm);
 /* cumulative count of exchanges posted and payload bytes sent to OTHER ranks by this rank */
 int mrl_comm_stats(const mrl_comm *comm, int64_t *n_exchanges, double *bytes_sent);
 /* host half of the transport alone, no GPU needed: `rounds` x { barrier, all-gather, sum / min / max all-reduce } over the bootstrap

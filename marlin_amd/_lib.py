@@ -159,6 +159,7 @@ SIGNATURES = {
     "mrl_comm_allreduce": (_i32, [_vp, C.POINTER(_dbl), C.c_int32, C.c_int32]),
     "mrl_comm_stats": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_dbl)]),
     "mrl_comm_describe": (_i32, [_vp, C.c_char_p, C.c_size_t]),
+    "mrl_comm_rccl_preflight": (_i32, [_vp]),
     "mrl_ctx_attach_comm": (_i32, [_vp, _vp]),
     "mrl_h5_create": (_i32, [C.c_char_p, C.POINTER(_vp)]),
     "mrl_h5_write": (_i32, [_vp, C.c_char_p, _i32, _i32, C.POINTER(_i64), _vp]),

@@ -133,6 +133,11 @@ class Comm:
         self._check(self.lib.mrl_comm_stats(self.h, C.byref(n), C.byref(b)))
         return {"exchanges": n.value, "bytes_sent": b.value}
 
+    def rccl_preflight(self) -> int:
+        """COLLECTIVE: the RCCL bring-up stage by stage (library, unique-id broadcast, placement, ncclCommInitRank); returns the
+        status code (0 ready, -2 unavailable on this placement, -6 failed) instead of raising: describe() has the details"""
+        return int(self.lib.mrl_comm_rccl_preflight(self.h))
+
     def describe(self) -> dict:
         """what the communicator runs on (HIP runtime / library actually mapped, RCCL library and the rank count it reports, ...)"""
         import json

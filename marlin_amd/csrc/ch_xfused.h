@@ -77,7 +77,9 @@ static int launch_xfused_v(mrl_ctx *ctx, const FusedArgs &a, const kcplx *tw) {
 }
 
 // prefetch depth of the first-order history: half a line for the two-stage plans; the three-stage plans (512 points and more) hold
-// more twiddle / index state across the transforms and spill 7-14 VGPRs with that (tools/spill_census.sh)
+// more twiddle / index state across the transforms and spill 7-14 VGPRs with that (tools/spill_census.sh).  Round 4, 512^3 on one
+// GPU, same box, interleaved: depth 8 instead of 4 changes nothing (fused x pass 1141 / 1141 vs 1144 / 1157 us) -- the pass runs at
+// the rate of its memory pattern (tools/xfused_probe.hip: with the three transforms removed it takes the same 1.06-1.10 ms)
 #ifndef MRL_XFUSED_PRE3_DIV
 #define MRL_XFUSED_PRE3_DIV 4
 #endif

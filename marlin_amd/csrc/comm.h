@@ -93,6 +93,13 @@ struct mrl_comm {
   uint64_t mbox_epoch = 0;
   double *h_mbox = nullptr;  // pinned result [16]
   double *d_h_mbox = nullptr;
+  // which physical GPU every rank runs on (PCI bus ids gathered at creation): RCCL needs one device per rank, HIP IPC does not
+  std::vector<std::string> pci;        // [nranks]
+  int distinct_devices = 1;
+  // RCCL bring-up, stage by stage (rccl_init): "not tried" | "ready" | "unavailable: ..." (cannot work on this placement: several
+  // ranks on one device, no library) | "failed: ..." (it should have worked)
+  std::string rccl_status = "not tried";
+  unsigned long long rccl_id_hash = 0;  // FNV-1a of the ncclUniqueId this rank holds after the bootstrap broadcast (0: none yet)
   // RCCL (dlopen)
   void *rccl_lib = nullptr;
   void *rccl_comm = nullptr;

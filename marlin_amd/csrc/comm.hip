@@ -9,6 +9,7 @@
 
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <set>
 #include <rccl/rccl.h>  // types only: the library is loaded at run time (dlopen) when the RCCL transport is selected
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -407,6 +408,34 @@ struct RcclApi {
   ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
 };
 
+// PCI bus id of every rank's device -> c->pci, c->distinct_devices (collective)
+static int device_census(mrl_comm *c) {
+  char mine[32] = {0}, all[kMaxRanks * 32];
+  if (hipDeviceGetPCIBusId(mine, sizeof(mine), c->device) != hipSuccess) {
+    (void)hipGetLastError();
+    std::snprintf(mine, sizeof(mine), "device%d", c->device);
+  }
+  if (c->nranks > 1) {
+    COMM_TRY(comm_allgather(c, mine, sizeof(mine), all));
+  } else {
+    std::memcpy(all, mine, sizeof(mine));
+  }
+  c->pci.clear();
+  std::set<std::string> distinct;
+  for (int p = 0; p < c->nranks; ++p) {
+    all[p * 32 + 31] = 0;
+    c->pci.emplace_back(all + p * 32);
+    distinct.insert(c->pci.back());
+  }
+  c->distinct_devices = (int)distinct.size();
+  return MRL_OK;
+}
+
+// RCCL bring-up in stages, each with a collective verdict, so that everything up to ncclCommInitRank can be exercised with N rank
+// processes on ONE GPU (where the last stage cannot work: RCCL refuses two ranks on one device):
+//   1 load librccl beside the mapped HIP runtime      2 rank 0 draws the unique id, the bootstrap segment broadcasts it
+//   3 placement: one device per rank?  otherwise "unavailable" (MRL_ERR_UNSUPPORTED), ncclCommInitRank is not called
+//   4 ncclCommInitRank; ncclCommCount must report nranks
 static int rccl_init(mrl_comm *c) {
   if (c->rccl_comm) return MRL_OK;
   int ok = 1;
@@ -447,21 +476,55 @@ static int rccl_init(mrl_comm *c) {
   }
   double v = ok ? 1.0 : 0.0;
   COMM_TRY(comm_allreduce_host(c, &v, 1, 1));
-  if (v == 0.0) return comm_error(c, MRL_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded on every rank (%s)", ok ? "another rank" : dlerror());
+  if (v == 0.0) {
+    c->rccl_status = std::string("unavailable: librccl.so.1 could not be loaded on every rank (") + (ok ? "another rank" : "this rank") + ")";
+    return comm_error(c, MRL_ERR_UNSUPPORTED, "RCCL %s", c->rccl_status.c_str());
+  }
   ncclUniqueId id, all[kMaxRanks];
   std::memset(&id, 0, sizeof(id));
   static_assert(sizeof(ncclUniqueId) <= 256, "unique id does not fit a bootstrap blob");
   if (c->rank == 0 && c->rccl->GetUniqueId(&id) != ncclSuccess) ok = 0;
   COMM_TRY(comm_allgather(c, &id, sizeof(id), all));
-  ncclComm_t nc = nullptr;
-  const ncclResult_t r = ok ? c->rccl->CommInitRank(&nc, c->nranks, all[0], c->rank) : ncclInternalError;
-  v = (r == ncclSuccess) ? 1.0 : 0.0;
+  {  // what this rank now holds (rank 0's id): the same hash on every rank, or the bootstrap broadcast is broken
+    unsigned long long h = 1469598103934665603ull;
+    const unsigned char *b = reinterpret_cast<const unsigned char *>(&all[0]);
+    for (size_t i = 0; i < sizeof(ncclUniqueId); ++i) h = (h ^ b[i]) * 1099511628211ull;
+    c->rccl_id_hash = h ? h : 1ull;
+  }
+  v = ok ? 1.0 : 0.0;
   COMM_TRY(comm_allreduce_host(c, &v, 1, 1));
   if (v == 0.0) {
+    c->rccl_status = "failed: ncclGetUniqueId on rank 0";
+    return comm_error(c, MRL_ERR_COMM, "RCCL %s", c->rccl_status.c_str());
+  }
+  if (c->pci.empty()) COMM_TRY(device_census(c));
+  if (c->distinct_devices < c->nranks) {
+    // RCCL needs one device per rank ("invalid usage" from ncclCommInitRank otherwise): a property of the placement, not a failure
+    std::string shared;
+    for (int p = 0; p < c->nranks && shared.empty(); ++p)
+      for (int q = p + 1; q < c->nranks; ++q)
+        if (c->pci[p] == c->pci[q]) {
+          shared = "ranks " + std::to_string(p) + " and " + std::to_string(q) + " share device " + c->pci[p];
+          break;
+        }
+    c->rccl_status = "unavailable: " + std::to_string(c->nranks) + " ranks on " + std::to_string(c->distinct_devices) +
+                     " device(s), " + shared + " (RCCL needs one device per rank; the unique id was broadcast, ncclCommInitRank not called)";
+    return comm_error(c, MRL_ERR_UNSUPPORTED, "RCCL %s", c->rccl_status.c_str());
+  }
+  ncclComm_t nc = nullptr;
+  const ncclResult_t r = c->rccl->CommInitRank(&nc, c->nranks, all[0], c->rank);
+  int counted = -1;
+  if (r == ncclSuccess && c->rccl->CommCount) c->rccl->CommCount(nc, &counted);
+  v = (r == ncclSuccess && (counted < 0 || counted == c->nranks)) ? 1.0 : 0.0;
+  COMM_TRY(comm_allreduce_host(c, &v, 1, 1));
+  if (v == 0.0) {
+    c->rccl_status = std::string("failed: ncclCommInitRank (") +
+                     (r != ncclSuccess ? c->rccl->GetErrorString(r) : (counted >= 0 && counted != c->nranks ? "ncclCommCount disagrees" : "on another rank")) + ")";
     if (nc) c->rccl->CommDestroy(nc);
-    return comm_error(c, MRL_ERR_COMM, "ncclCommInitRank failed (%s)", r == ncclSuccess ? "on another rank" : c->rccl->GetErrorString(r));
+    return comm_error(c, MRL_ERR_COMM, "RCCL %s", c->rccl_status.c_str());
   }
   c->rccl_comm = nc;
+  c->rccl_status = "ready";
   return MRL_OK;
 }
 
@@ -815,6 +878,8 @@ int mrl_comm_create(mrl_comm **out, const char *name, int32_t nranks, int32_t ra
     if (rank == 0) shm_unlink(c->shm_name.c_str());  // the mappings stay; the name is free again
   }
 
+  if (device_census(c) != MRL_OK) return fail(MRL_ERR_COMM);
+
   // side streams: one per peer offset (copy engines) / the RCCL stream
   const int ns = nranks < 8 ? nranks : 8;
   for (int i = 0; i < ns; ++i) {
@@ -955,13 +1020,25 @@ int mrl_comm_reset_error(mrl_comm *c) {
       const double t0 = now_s();
       while (s->reset_gen.load(std::memory_order_acquire) == gen) {
         usleep(50);
-        if (now_s() - t0 > c->timeout_s)
+        if (now_s() - t0 > c->timeout_s) {
+          // take the arrival back, or every later rendezvous would count one rank too many.  If the generation moved
+          // between the check above and here, the last rank has already zeroed the count: do not drive it below zero
+          uint32_t cur = s->reset_count.load(std::memory_order_acquire);
+          while (cur > 0 && s->reset_gen.load(std::memory_order_acquire) == gen &&
+                 !s->reset_count.compare_exchange_weak(cur, cur - 1, std::memory_order_acq_rel)) {
+          }
           return comm_error(c, MRL_ERR_COMM, "mrl_comm_reset_error is collective: only some ranks called it within %.0f s", c->timeout_s);
+        }
       }
     }
     c->red_parity = 0;  // (every rank restarts the double-buffered host all-reduce at the same parity)
   }
   return MRL_OK;
+}
+
+int mrl_comm_rccl_preflight(mrl_comm *c) {
+  if (!c) return MRL_ERR_INVALID;
+  return rccl_init(c);
 }
 
 int mrl_comm_describe(const mrl_comm *c, char *buf, size_t cap) {
@@ -976,11 +1053,20 @@ int mrl_comm_describe(const mrl_comm *c, char *buf, size_t cap) {
     if (c->rccl->GetUniqueId && dladdr(reinterpret_cast<void *>(c->rccl->GetUniqueId), &info) && info.dli_fname) rccl_path = info.dli_fname;
   }
   const std::string hip_lib = mapped_library("libamdhip64.so");
+  std::string devs = "[";
+  for (size_t p = 0; p < c->pci.size(); ++p) devs += (p ? ", \"" : "\"") + c->pci[p] + "\"";
+  devs += "]";
+  std::string status = c->rccl_status;
+  for (char &ch : status)
+    if (ch == '"' || ch == '\\') ch = '\'';
+  char idh[32];
+  std::snprintf(idh, sizeof(idh), "%016llx", c->rccl_id_hash);
   std::snprintf(buf, cap,
                 "{\"hip_runtime_version\": %d, \"hip_library\": \"%s\", \"ipc_usable\": %s, \"rccl_loaded\": %s, \"rccl_library\": \"%s\", "
-                "\"rccl_version\": %d, \"rccl_comm_nranks\": %d, \"exchange_channels_in_use\": %d}",
+                "\"rccl_version\": %d, \"rccl_comm_nranks\": %d, \"rccl_status\": \"%s\", \"rccl_unique_id_hash\": \"%s\", "
+                "\"devices_per_rank\": %s, \"distinct_devices\": %d, \"exchange_channels_in_use\": %d}",
                 hip_rt, hip_lib.c_str(), c->ipc_ok ? "true" : "false", c->rccl_lib ? "true" : "false", rccl_path.c_str(), rccl_v, rccl_n,
-                c->next_channel - (int)c->free_channels.size());
+                status.c_str(), c->rccl_id_hash ? idh : "", devs.c_str(), c->distinct_devices, c->next_channel - (int)c->free_channels.size());
   return MRL_OK;
 }
 

@@ -35,6 +35,7 @@ struct Dataset {
   int dtype, rank;
   uint64_t dims[4];
   uint64_t addr, bytes;
+  uint64_t oh = 0;   // address of the dataset's object header: written ONCE, right behind its data (it never changes)
 };
 
 struct Buf {
@@ -157,14 +158,11 @@ int write_metadata(mrl_h5 *h) {
   uint64_t at = (h->eod + 7) & ~7ULL;
   const uint64_t meta0 = at;
   Buf m;
-  // dataset object headers
+  // dataset object headers: each was written once, behind its data, by mrl_h5_write.  A flush re-appends only what DOES change with
+  // every new dataset -- the name heap, the symbol-table nodes, the B-tree node and the root header -- so the dead metadata a flush per
+  // output step leaves behind is ~50 B per dataset and flush plus 8 KB per flush instead of ~400 B per dataset and flush
   std::vector<uint64_t> oh(n);
-  for (size_t i = 0; i < n; ++i) {
-    oh[i] = meta0 + m.size();
-    Buf d = dataset_header(h->sets[order[i]]);
-    m.raw(d.b.data(), d.size());
-    m.pad8();
-  }
+  for (size_t i = 0; i < n; ++i) oh[i] = h->sets[order[i]].oh;
   // local heap: header + data segment (offset 0 = the empty name of the root group)
   Buf names;
   names.zeros(8);
@@ -292,6 +290,17 @@ int mrl_h5_write(mrl_h5 *h, const char *name, int dtype, int rank, const int64_t
   }
   MRL_TRY(write_at(h, d.addr, data, (size_t)d.bytes));
   h->eod = d.addr + d.bytes;
+  {  // its object header, once and for all (nothing points at it until the next flush publishes a symbol-table entry)
+    d.oh = (h->eod + 7) & ~7ULL;
+    if (d.oh > h->eod) {
+      const unsigned char z[8] = {0};
+      MRL_TRY(write_at(h, h->eod, z, (size_t)(d.oh - h->eod)));
+    }
+    Buf hd = dataset_header(d);
+    hd.pad8();
+    MRL_TRY(write_at(h, d.oh, hd.b.data(), hd.size()));
+    h->eod = d.oh + hd.size();
+  }
   h->sets.push_back(d);
   h->dirty = true;
   return MRL_OK;

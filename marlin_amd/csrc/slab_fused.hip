@@ -47,7 +47,8 @@ struct YFusedArgs {
 // BIG (with ALIGNED): exchange buffers or rank-local spectral arrays of 4 GiB and more (1024^3 on 2 or 4 GPUs: 4.3 / 2.2 GB per array,
 // two fields per forward buffer).  The chunk index, the x plane and the row group of element j = q + m TPL are wave-uniform: they
 // go into a 64-bit scalar part of the offset, the per-thread part (q rows + kz) stays 32-bit -- same access form, same registers.
-template <int N, int ORDER, bool SPEC_C, bool ALIGNED, bool BIG = false>
+// NTH (experiment bit 1 << 28, 512 points): stream the old / new Nhat arrays past the Infinity Cache as the serial x pass does
+template <int N, int ORDER, bool SPEC_C, bool ALIGNED, bool BIG = false, bool NTH = false>
 __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, const cplx *__restrict__ tw) {
   static_assert(!BIG || ALIGNED, "the 64-bit variant needs wave-uniform chunk offsets");
   constexpr int TPL = Plan<N>::TPL, T = Plan<N>::T;
@@ -108,24 +109,24 @@ __global__ void __launch_bounds__(Plan<N>::NT, 2) k_ch_yfused(YFusedArgs a, cons
   } else {
     const unsigned d0 = (unsigned)(((long long)ix * N + q) * a.nzc + a.k0 + kl) * 16u, dstep = (unsigned)(TPL * a.nzc) * 16u;
     auto offd = [=](int m) { return d0 + (unsigned)m * dstep; };
-    ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, false>(fc, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, OffSame{}, offd, stu, W, X, KY);
+    ch_fused_body<N, ORDER, false, Plan<N>::P / 2, SPEC_C, false, false, NTH>(fc, tw, a.ky, a.kx + ix, a.kz + a.k0 + kl, valid, q, l, offf, OffSame{}, offd, stu, W, X, KY);
   }
   signal_tail(a.sig);
 }
 
-template <int N, int ORDER, bool SPEC_C, bool ALIGNED, bool BIG = false>
+template <int N, int ORDER, bool SPEC_C, bool ALIGNED, bool BIG = false, bool NTH = false>
 static int launch_yfused_v(mrl_ctx *ctx, YFusedArgs a) {
   static std::atomic<bool> attr{false};  // (two host threads may both set the attribute: harmless, and no torn flag)
   constexpr size_t lds = lds_strided<N>() + sizeof(double) * N;
   if (!attr.load(std::memory_order_acquire)) {
-    MRL_TRY((set_lds_attr(ctx, k_ch_yfused<N, ORDER, SPEC_C, ALIGNED, BIG>, lds)));
+    MRL_TRY((set_lds_attr(ctx, k_ch_yfused<N, ORDER, SPEC_C, ALIGNED, BIG, NTH>, lds)));
     attr.store(true, std::memory_order_release);
   }
   constexpr int T = Plan<N>::T;
   a.tiles_per_x = (a.ksub + T - 1) / T;
   const long long nb = (long long)a.nxl * a.tiles_per_x;
   a.sig.expected = (unsigned)nb;
-  hipLaunchKernelGGL((k_ch_yfused<N, ORDER, SPEC_C, ALIGNED, BIG>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a,
+  hipLaunchKernelGGL((k_ch_yfused<N, ORDER, SPEC_C, ALIGNED, BIG, NTH>), dim3((unsigned)nb), dim3(Plan<N>::NT), lds, ctx->stream, a,
                      ctx->ax[1].d_tw);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
@@ -153,6 +154,16 @@ static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
     if (big) return launch_yfused_v<N, ORDER, SPEC_C, true, true>(ctx, a);
   }
   if (big) return set_error(ctx, MRL_ERR_UNSUPPORTED, "slab y pass: arrays of 4 GiB and more need ny in {512, 1024, 2048}");
+  if constexpr (N == 512 && !SPEC_C) {
+    // 512-point lines, the whole kz range in one sub-block, history arrays of 96 MB and more (512^3 on 8 GPUs: 138 MB): the old / new
+    // Nhat arrays are streamed past the Infinity Cache as in the serial x pass, which leaves it to the exchange buffers the next pass
+    // re-reads.  Same-box A/B (tools/ab_r04.sh, slab-local 512^3 / 8): y pass 160 -> 153-155 us, forward z pass 84 -> 79 us, sum of
+    // the rank-local kernels 0.611 -> 0.599 ms; experiment bit 1 << 28 switches it off.  (Sub-block-sized working sets lose with
+    // streaming accesses, DESIGN 3: hence only for nsub = 1.)
+    const double hist_bytes = 16.0 * (double)a.nxl * (double)N * (double)a.nzc;
+    if (a.k0 == 0 && a.ksub == ctx->nrec[2] && hist_bytes >= 96.0e6 && !(ctx->exp & (1 << 28)))
+      return launch_yfused_v<N, ORDER, SPEC_C, true, false, true>(ctx, a);
+  }
   return launch_yfused_v<N, ORDER, SPEC_C, true>(ctx, a);
 }
 

@@ -255,6 +255,30 @@ struct Cand
   std::string label;
 };
 
+// physical devices of the job as the communicator sees them (PCI bus ids gathered at its creation): mrl_comm_describe
+static int comm_distinct_devices(mrl_comm * comm)
+{
+  if (!comm)
+    return 1;
+  char buf[2048] = "";
+  if (mrl_comm_describe(comm, buf, sizeof buf) != MRL_OK)
+    return 1;
+  const char * p = std::strstr(buf, "\"distinct_devices\": ");
+  return p ? std::max(1, std::atoi(p + 20)) : 1;
+}
+static std::string comm_devices_json(mrl_comm * comm)
+{
+  char buf[2048] = "";
+  if (!comm || mrl_comm_describe(comm, buf, sizeof buf) != MRL_OK)
+    return "[]";
+  const char * p = std::strstr(buf, "\"devices_per_rank\": ");
+  if (!p)
+    return "[]";
+  p += 20;
+  const char * e = std::strchr(p, ']');
+  return e ? std::string(p, e + 1) : "[]";
+}
+
 static int run_ch(Rank & R)
 {
   const int steps = (int)argi("steps", 100), warmup = (int)argi("warmup", 10);
@@ -262,7 +286,8 @@ static int run_ch(Rank & R)
   const bool carry = argi("carry", 0) != 0;
   const long exp_user = argi("exp", 0);
   const int profile_steps = (int)argi("profile_steps", 10);
-  const double tune_budget = (double)argi("tune_budget_s", 60);
+  const double tune_budget = (double)argi("tune_budget_s", 45);
+  double tuning_s = 0.0;
   const bool variants = argi("variants", 1) != 0;
   if (G)
     R.shape[0] = R.shape[1] = R.shape[2] = G;
@@ -324,6 +349,7 @@ static int run_ch(Rank & R)
   {
     const std::string tr = arg("transport", "tune");
     const int nsub_user = (int)argi("nsub", 0);
+    const int distinct_devices = comm_distinct_devices(R.comm);
     std::vector<Cand> cands;
     if (tr == "tune")
     {
@@ -332,7 +358,10 @@ static int run_ch(Rank & R)
         if (nsub_user && ns != nsub_user)
           continue;
         cands.push_back({MRL_TRANSPORT_PEER_STORE, ns, 0, "event-ordered flags"});
-        cands.push_back({MRL_TRANSPORT_PEER_STORE, ns, 128, "in-kernel flags"});
+        // in-kernel arrival flags: 3 x slower than event-ordered ones in every run on one device (one L2 write-back per workgroup);
+        // only worth a slot where the stores really cross a link
+        if (distinct_devices > 1 || argi("tune_in_kernel_flags", 0) != 0)
+          cands.push_back({MRL_TRANSPORT_PEER_STORE, ns, 128, "in-kernel flags"});
         cands.push_back({MRL_TRANSPORT_PEER_COPY, ns, 0, ""});
         cands.push_back({MRL_TRANSPORT_RCCL, ns, 0, ""});
       }
@@ -424,6 +453,7 @@ static int run_ch(Rank & R)
       results.push_back(r);
     }
     mrl_comm_set_timeout(R.comm, 120.0);
+    tuning_s = R.reduce(now_s() - t_tune0, 2);
     // reference checksum: the most conservative transport that ran -- RCCL (its own rendezvous and fences), else the copy engines
     // (hipMemcpyAsync between IPC mappings), else the median of the peer-store variants.  The peer-store candidates share one
     // memory-model argument: if it failed on this node they could agree with each other and still be wrong, so
@@ -658,7 +688,8 @@ static int run_ch(Rank & R)
         ndistinct = (int)(std::unique(d.begin(), d.end()) - d.begin());
       }
       o << "], \"distinct_devices\": " << ndistinct << ", \"transport\": {\"selected\": " << jstr(selected) << ", \"nsub\": " << sel_nsub
-        << ", \"arrival_flags\": " << jstr(flag_variant) << ", \"tuned\": " << (tuned.str().empty() ? "[]" : tuned.str()) << "}";
+        << ", \"arrival_flags\": " << jstr(flag_variant) << ", \"tuning_s\": " << jnum(tuning_s) << ", \"tune_budget_s\": " << jnum(tune_budget)
+        << ", \"tuned\": " << (tuned.str().empty() ? "[]" : tuned.str()) << "}, \"physical_devices_per_rank\": " << comm_devices_json(R.comm);
       if (verify_mismatches >= 0)
         o << ", \"receive_buffer_reread_mismatches\": " << verify_mismatches;
       o << ", \"kernel_ms_per_step_incl_peer_stores\": " << jnum(loc) << ", \"exposed_wait_ms_per_step\": " << jnum(waits)
@@ -812,6 +843,20 @@ static int run_mech(Rank & R)
   tot_t = R.reduce(tot_t, 2);
   double fn = 0.0;
   R.ck(mrl_norm2(R.ctx, dF[cur], (int64_t)(9 * npl), &fn), "mrl_norm2");
+  // one more solve with per-kernel event timing: the exposed arrival waits per CG iteration (after the checksum: not part of it)
+  double waits_ms = 0.0;
+  long prof_its = 0;
+  if (R.slab)
+  {
+    R.ck(mrl_set_profiling(R.ctx, 1), "mrl_set_profiling");
+    mrl_mech_stats pst{};
+    solve(substeps + 1, pst);
+    prof_its = pst.cg_its_total;
+    for (const KernelRow & k : read_profile(R.ctx))
+      if (k.name == "slab_exchange_wait")
+        waits_ms += k.ms;
+    R.ck(mrl_set_profiling(R.ctx, 0), "mrl_set_profiling");
+  }
   char describe[2048] = "{}";
   if (R.comm)
     mrl_comm_describe(R.comm, describe, sizeof describe);
@@ -835,9 +880,11 @@ static int run_mech(Rank & R)
       << ", \"roofline\": {\"bound\": \"hbm\", \"kernel\": \"one CG iteration (all kernels; SURVEY 8(d) byte model)\", \"achieved\": " << jnum(gbps) << ", \"peak\": " << HBM_PEAK
       << ", \"unit\": \"GB/s\", \"frac\": " << jnum(gbps / HBM_PEAK) << ", \"traffic\": null}";
     if (R.slab)
-      o << ", \"exchange\": {\"ranks\": " << R.world << ", \"transport\": {\"selected\": " << jstr(selected) << ", \"tuned\": " << tuned.str()
+      o << ", \"exchange\": {\"ranks\": " << R.world << ", \"devices_per_rank\": " << comm_devices_json(R.comm) << ", \"distinct_devices\": "
+        << comm_distinct_devices(R.comm) << ", \"transport\": {\"selected\": " << jstr(selected) << ", \"tuned\": " << tuned.str()
         << "}, \"exchanges_per_step\": " << jnum((double)(ex1 - ex0) / std::max(1l, tot_its)) << ", \"bytes_sent_to_peers_per_step_rank0\": "
-        << jnum((by1 - by0) / std::max(1l, tot_its)) << ", \"runtime\": " << describe << "}";
+        << jnum((by1 - by0) / std::max(1l, tot_its)) << ", \"link_GBps_out_rank0\": " << jnum((by1 - by0) / tot_t / 1e9)
+        << ", \"exposed_wait_ms_per_step\": " << jnum(prof_its ? waits_ms / prof_its : 0.0) << ", \"runtime\": " << describe << "}";
     o << ", \"field_checksum\": {\"norm_F\": " << jnum(fn) << "}}";
     std::printf("%s\n", o.str().c_str());
     std::fflush(stdout);

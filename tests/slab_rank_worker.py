@@ -222,6 +222,27 @@ def run_fft(job, P, r, kv):
     return {"max_err": max(errs), "errs": errs}
 
 
+def run_rccl_preflight(job, P, r, kv):
+    """everything of the RCCL bring-up that P rank processes on ONE GPU can exercise (mrl_comm_rccl_preflight): the library loads, rank
+    0's unique id reaches every rank through the bootstrap segment, the placement check sees the shared device and reports RCCL as
+    unavailable (MRL_ERR_UNSUPPORTED) instead of calling ncclCommInitRank into its 'invalid usage' failure; the communicator stays usable"""
+    from marlin_amd import api
+    comm = api.Comm(job, P, r, device=0, transport=0, timeout=40.0)
+    rc = comm.rccl_preflight()
+    d = comm.describe()
+    # the transport switch reports the same verdict, and the communicator still works afterwards
+    switched = True
+    try:
+        comm.set_transport(api.TRANSPORT_RCCL)
+    except api.MarlinHipError as e:
+        switched = False
+        switch_code = e.code
+    v = [float(r + 1)]
+    tot = comm.allreduce(v, 0)
+    comm.close()
+    return {"rc": rc, "describe": d, "switched": switched, "switch_code": None if switched else switch_code, "allreduce": tot}
+
+
 def run_pencil(job, P, r, kv):
     """parallel_mode = FFT_PENCIL (DomainAction.C:568-742, 1021-1047, 1105-1404): mrl_fft_r2c / mrl_fft_c2r on a pencil context with the
     library-owned staged exchanges, against the oracle's restatement of the reference's stages (oracle.PencilDomain) and the serial
@@ -386,6 +407,8 @@ def main():
         out = run_ch(job, P, r, kv)
     elif case == "chgold":
         out = run_ch(job, P, r, kv, gold=True)
+    elif case == "rccl_preflight":
+        out = run_rccl_preflight(job, P, r, kv)
     elif case == "pencil":
         out = run_pencil(job, P, r, kv)
     elif case == "fft":

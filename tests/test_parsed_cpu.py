@@ -82,3 +82,53 @@ def test_complex_typing():
     assert p.is_complex and "cscale(" in p.source
     assert not ParsedCompute(None, "Mbar*2", inputs=["Mbar"]).is_complex
     assert ParsedCompute(None, "i*kx*a", inputs=["a"], extra_symbols=True, reciprocal=True).is_complex
+
+
+# ---- unit/src/ParsedTensorTest.C, the sections not mirrored above -----------------------------------------
+@pytest.mark.parametrize("expr,expected", [
+    # TEST(ParsedTensorTest, Simplify) :411-545 -- constant folding, the algebraic identities, nesting (our printer writes 5 for the
+    # reference's "5.000000": std::to_string vs shortest round-trip; the trees are the same)
+    ("2 + 3", "5"), ("4 * 5", "20"), ("2 ^ 3", "8"), ("x * 0", "0"), ("x * 1", "x"), ("x + 0", "x"), ("x - 0", "x"), ("x / 1", "x"),
+    ("x ^ 0", "1"), ("x ^ 1", "x"), ("sin(0)", "0"), ("(x + 0) * 1 + 0", "x"),
+    # ... ErrorHandling :396-409: let bindings are simplified, function calls on constants are folded
+    ("a := 2 + 3; a * x", "(5 * x)"), ("sqrt(4) + log(1) + exp(0)", "3"),
+])
+def test_reference_unit_test_simplify_section(expr, expected):
+    assert tree(expr, inputs=["x", "y"]) == expected
+
+
+@pytest.mark.parametrize("expr,expected", [
+    # TEST(ParsedTensorTest, Substitute) :206-310.  The reference substitutes into let expressions and keeps the bindings in its
+    # tree; this front end resolves a binding by substituting it into the body at parse time, so the SAME cases read as: every use of
+    # a bound name is the bound expression (evaluation order inside it unchanged), a later binding sees the earlier ones, and a
+    # bound name shadows an input of the same name
+    ("a := x + 1; a * x", "((x + 1) * x)"),
+    ("a := x; b := a + 1; b * x", "((x + 1) * x)"),
+    ("r := x^2 + y^2; sqrt(r) + r", "(sqrt(((x ^ 2) + (y ^ 2))) + ((x ^ 2) + (y ^ 2)))"),
+    ("y := 2*x; x + y", "(x + (2 * x))"),            # the binding shadows the input y
+    ("s := sin(x); s + cos(x) * s", "(sin(x) + (cos(x) * sin(x)))"),
+])
+def test_reference_unit_test_substitute_section_through_let_bindings(expr, expected):
+    assert tree(expr, inputs=["x", "y"]) == expected
+
+
+@pytest.mark.parametrize("expr,column", [
+    # TEST(ParsedTensorTest, ErrorHandling) :312-394: the same inputs are rejected at the same column ("Line 1:<column>" in the
+    # reference's message; ours reports the 0-based position)
+    ("x + ", 5), ("(x + y", 7), ("x + y)", 6), ("sin(x", 6), ("a := ; x + a", 6), ("x + * y", 5), ("", 1), ("1.2.3 + x", 4),
+])
+def test_reference_unit_test_error_handling_section(expr, column):
+    with pytest.raises(MarlinHipError) as e:
+        tree(expr, inputs=["x", "y"])
+    assert e.value.code == -1 and "Invalid function" in e.value.message
+    assert f"at position {column - 1} of" in e.value.message
+
+
+def test_reference_unit_test_undefined_names_and_constants():
+    """:356-394 (a name that is neither an input nor a constant), :397-402 (derivative with respect to a name the expression does not
+    contain is 0), TEST(ParsedTensorTest, Constants) :663-676 (a constant is not a variable: d/dx[x + pi] = 1)"""
+    with pytest.raises(MarlinHipError, match="unknown variable 'q'"):
+        tree("x + q", inputs=["x"])
+    assert tree("x + y", inputs=["x", "y", "z"], derivatives=["z"]) == "0"
+    assert tree("x + pi", inputs=["x"], constants={"pi": 3.141592653589793}, derivatives=["x"]) == "1"
+    assert tree("x * pi", inputs=["x"], constants={"pi": 3.141592653589793}, derivatives=["x"]) == "pi"

@@ -192,3 +192,27 @@ def test_histogram_gold_gpu():
     want = torch.histogramdd(v[~torch.isnan(v)].reshape(-1, 1), [edges]).hist
     assert ctx.histogram(v.cuda(), edges.tolist()) == [int(x) for x in want]
 
+
+
+@pytest.mark.parametrize("expr", ["x^2", "x^3", "sin(x)", "cos(x)", "exp(x)", "log(x)", "1/x", "sqrt(x)", "a := x^2; a * x"])
+def test_reference_unit_test_second_derivatives(ctx, expr):
+    """TEST(ParsedTensorTest, SecondDerivatives), unit/src/ParsedTensorTest.C:546-609: the symbolic second derivative against central
+    differences of the compiled expression, x = linspace(0.1, 2.01, 11), h = 1e-4, relative 1e-3 -- the reference's numbers"""
+    x = torch.linspace(0.1, 2.01, 11, dtype=torch.float64).cuda()
+    h = 1e-4
+    f = _pc(ctx, expr, inputs=["x"])
+    d2 = _pc(ctx, expr, inputs=["x"], derivatives=["x", "x"])(x)
+    fd = (f(x + h) - 2.0 * f(x) + f(x - h)) / (h * h)
+    rel = ((d2 - fd).abs() / (fd.abs() + h)).max().item()
+    assert rel < 1e-3, (expr, rel)
+
+
+def test_reference_unit_test_constants(ctx):
+    """TEST(ParsedTensorTest, Constants), unit/src/ParsedTensorTest.C:611-700: named constants in expressions, in let bindings and
+    under differentiation (1e-12, the reference's fp64 epsilon)"""
+    x = torch.linspace(0.1, 2.01, 11, dtype=torch.float64).cuda()
+    K = {"pi": math.pi, "e": math.e}
+    assert (_pc(ctx, "x * pi", inputs=["x"], constants={"pi": math.pi})(x) - x * math.pi).abs().max().item() <= 1e-12
+    assert (_pc(ctx, "sin(x) + pi * e", inputs=["x"], constants=K)(x) - (torch.sin(x) + math.pi * math.e)).abs().max().item() <= 1e-12
+    assert (_pc(ctx, "x * pi", inputs=["x"], constants={"pi": math.pi}, derivatives=["x"])(x) - math.pi).abs().max().item() <= 1e-12
+    assert (_pc(ctx, "a := x * pi; a + a", inputs=["x"], constants={"pi": math.pi})(x) - 2.0 * x * math.pi).abs().max().item() <= 1e-12

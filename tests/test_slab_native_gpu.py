@@ -226,15 +226,36 @@ def test_bench_drivers_agree_on_two_ranks():
     assert native["n_gpus"] == 2 and native["config"]["grid"] == [64, 128, 64]
 
 
-@pytest.mark.parametrize("P,shape,transport", [(4, "16,12,10", 1), (4, "40,40,40", 2), (4, "64,64,64", 1), (6, "9,8,7", 1), (4, "7,9,11", 2)])
+@pytest.mark.parametrize("P,shape,transport", [(4, "16,12,10", 1), (4, "40,40,40", 2), (4, "64,64,64", 1), (4, "9,8,7", 1), (4, "7,9,11", 2)])
 def test_native_pencil_transforms_vs_oracle(P, shape, transport):
     """parallel_mode = FFT_PENCIL (the last SURVEY 8(f) item; DomainAction.C:568-742, 1021-1047, 1105-1404) on P = py x pz rank
     PROCESSES sharing this box's GPU: mrl_fft_r2c / mrl_fft_c2r with the four staged exchanges owned by the library against the oracle's
     restatement of the reference's stages and the serial transform of the global array (2e-15 x n relative), the round trip (1e-14,
     64^3 included), an inverse transform of a non-Hermitian spectrum (irfft semantics), block shapes / begins / reciprocal axes of
-    partitionPencils bit for bit, global reductions, and MRL_ERR_UNSUPPORTED from the fused solver entry points"""
+    partitionPencils bit for bit, global reductions, and MRL_ERR_UNSUPPORTED from the fused solver entry points.  (At most four rank
+    processes: this process holds the GPU too and a box admits six; the 2 x 3 and 2 x 4 process grids are covered by the oracle-level
+    CPU tests, tests/test_pencil_cpu.py.)"""
     res = run_job(P, "pencil", f"shape={shape}", f"transport={transport}")
     n = max(int(x) for x in shape.split(","))
     assert all(r["layout_ok"] and r["axes_ok"] and r["refused"] for r in res), res
     assert max(r["max_err"] for r in res) <= 2e-15 * n, res
     assert all(r["stats"]["exchanges"] > 0 and r["stats"]["bytes_sent"] > 0 for r in res)
+
+
+def test_rccl_bring_up_is_exercised_up_to_comm_init_on_one_gpu():
+    """RCCL with N > 1 ranks cannot run on a one-GPU box (it refuses two ranks on one device), but everything up
+    to ncclCommInitRank can: 2 and 4 rank processes load the library, hold the SAME unique id after the bootstrap broadcast (hash in
+    mrl_comm_describe), see the shared device in the placement census, and report RCCL as *unavailable* (MRL_ERR_UNSUPPORTED, status
+    text) -- not as a failed ncclCommInitRank; the host collectives keep working afterwards.  src/actions/DomainAction.C:163-199
+    (one rank <-> one device) is the placement rule RCCL insists on."""
+    for P in (2, 4):
+        res = run_job(P, "rccl_preflight")
+        ids = {r["describe"]["rccl_unique_id_hash"] for r in res}
+        assert len(ids) == 1 and ids != {""}, res
+        for r in res:
+            d = r["describe"]
+            assert r["rc"] == -2 and not r["switched"] and r["switch_code"] == -2, r
+            assert d["rccl_loaded"] and d["rccl_status"].startswith("unavailable:") and "share device" in d["rccl_status"], d
+            assert d["distinct_devices"] == 1 and len(d["devices_per_rank"]) == P and len(set(d["devices_per_rank"])) == 1, d
+            assert d["rccl_comm_nranks"] == -1
+            assert r["allreduce"] == [P * (P + 1) / 2.0]
