@@ -85,6 +85,14 @@ void mrl_ctx_destroy(mrl_ctx *ctx);
  * py, pz >= 2, py <= min(ny, nx/2+1), pz <= min(nz, ny), the one with the smallest |py - pz| (first found wins).  Host only.
  * MRL_ERR_INVALID with the reference's message when no factorisation fits. */
 int mrl_pencil_factors(int32_t nranks, const int64_t n[3], int32_t *py, int32_t *pz);
+/* Host only (no GPU, no context): the block layout and the message sizes of the four staged exchanges of an FFT_PENCIL job for rank
+ * `rank` of `nranks` on an n[0] x n[1] x n[2] grid -- what a caller that keeps its own exchange (MPI, torch.distributed) needs, and what
+ * the library's own pipeline uses.  real_n / real_begin / recip_n / recip_begin: as mrl_local_shape.  stage 1 = inside the group of
+ * equal z block (DomainAction.C:1105-1180 forward, :1331-1404 inverse), stage 2 = inside the group of equal kx block (:1182-1256,
+ * :1258-1329); counts in COMPLEX elements per peer rank (zero outside the group), nranks entries each; any output may be NULL. */
+int mrl_pencil_layout(int32_t nranks, int32_t rank, const int64_t n[3], int64_t real_n[3], int64_t real_begin[3], int64_t recip_n[3],
+                      int64_t recip_begin[3], int64_t *stage1_fwd_send, int64_t *stage1_fwd_recv, int64_t *stage2_fwd_send,
+                      int64_t *stage2_fwd_recv);
 /* the process grid of a pencil context (MRL_ERR_INVALID on other contexts) */
 int mrl_pencil_grid(const mrl_ctx *ctx, int32_t *py, int32_t *pz);
 /* message of the last failing call on ctx (ctx may be NULL: failure of mrl_ctx_create) */

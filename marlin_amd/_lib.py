@@ -72,6 +72,7 @@ SIGNATURES = {
     "mrl_partition": (_i32, [_i64, C.c_int32, C.POINTER(_i64), C.POINTER(_i64)]),
     "mrl_pencil_factors": (_i32, [C.c_int32, C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mrl_pencil_grid": (_i32, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mrl_pencil_layout": (_i32, [C.c_int32, C.c_int32, C.POINTER(_i64)] + [C.POINTER(_i64)] * 8),
     "mrl_ctx_reciprocal_axis": (_i32, [_vp, _i32, C.POINTER(_dbl), _i64]),
     "mrl_fft_r2c": (_i32, [_vp, _vp, _vp, _i64, _i32]),
     "mrl_fft_c2r": (_i32, [_vp, _vp, _vp, _i64, _i32]),

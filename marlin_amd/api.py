@@ -54,6 +54,19 @@ def pencil_factors(nranks: int, n: Sequence[int]):
     return py.value, pz.value
 
 
+def pencil_layout(nranks: int, rank: int, n: Sequence[int]) -> dict:
+    """host only: blocks and message sizes (complex elements per peer) of the staged exchanges of an FFT_PENCIL job (mrl_pencil_layout)"""
+    lib = _lib.load()
+    nn = (C.c_int64 * 3)(*[int(v) for v in n])
+    rn, rb, kn, kb = ((C.c_int64 * 3)() for _ in range(4))
+    cnt = [(C.c_int64 * nranks)() for _ in range(4)]
+    rc = lib.mrl_pencil_layout(nranks, rank, nn, rn, rb, kn, kb, *cnt)
+    if rc != 0:
+        raise MarlinHipError(rc, lib.mrl_last_error(None).decode())
+    return {"real_shape": list(rn), "real_begin": list(rb), "recip_shape": list(kn), "recip_begin": list(kb),
+            "stage1_send": list(cnt[0]), "stage1_recv": list(cnt[1]), "stage2_send": list(cnt[2]), "stage2_recv": list(cnt[3])}
+
+
 def partition(total: int, nranks: int, weights: Optional[Sequence[int]] = None) -> List[int]:
     lib = _lib.load()
     out = (C.c_int64 * nranks)()

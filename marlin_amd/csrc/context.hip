@@ -263,6 +263,48 @@ int mrl_pencil_factors(int32_t nranks, const int64_t n[3], int32_t *py, int32_t 
   return MRL_OK;
 }
 
+int mrl_pencil_layout(int32_t nranks, int32_t rank, const int64_t n[3], int64_t real_n[3], int64_t real_begin[3], int64_t recip_n[3],
+                      int64_t recip_begin[3], int64_t *s1s, int64_t *s1r, int64_t *s2s, int64_t *s2r) {
+  if (!n || nranks < 1 || rank < 0 || rank >= nranks) return set_error(nullptr, MRL_ERR_INVALID, "mrl_pencil_layout: bad argument");
+  int Py = 0, Pz = 0;
+  if (!pencil_factors(nranks, n[0], n[1], n[2], &Py, &Pz))
+    return set_error(nullptr, MRL_ERR_INVALID,
+                     "FFT_PENCIL requires factoring the number of MPI ranks into two integers greater than one that fit the domain "
+                     "(ranks = %d). Use FFT_SLAB or adjust the rank count.", nranks);
+  std::vector<long long> y, z, kx, ky;
+  if (partition(n[1], Py, nullptr, y) != MRL_OK || partition(n[2], Pz, nullptr, z) != MRL_OK ||
+      partition(n[0] / 2 + 1, Py, nullptr, kx) != MRL_OK || partition(n[1], Pz, nullptr, ky) != MRL_OK)
+    return set_error(nullptr, MRL_ERR_INVALID, "Internal partitioning error.");
+  auto begin_of = [](const std::vector<long long> &v, int i) {
+    long long b = 0;
+    for (int r = 0; r < i; ++r) b += v[r];
+    return b;
+  };
+  const int px = rank % Py, pz = rank / Py;
+  const long long nyl = y[px], nzl = z[pz], kxl = kx[px], kyl = ky[pz];
+  if (real_n) { real_n[0] = n[0]; real_n[1] = nyl; real_n[2] = nzl; }
+  if (real_begin) { real_begin[0] = 0; real_begin[1] = begin_of(y, px); real_begin[2] = begin_of(z, pz); }
+  if (recip_n) { recip_n[0] = kxl; recip_n[1] = kyl; recip_n[2] = n[2]; }
+  if (recip_begin) { recip_begin[0] = begin_of(kx, px); recip_begin[1] = begin_of(ky, pz); recip_begin[2] = 0; }
+  for (int p = 0; p < nranks; ++p) {
+    if (s1s) s1s[p] = 0;
+    if (s1r) s1r[p] = 0;
+    if (s2s) s2s[p] = 0;
+    if (s2r) s2r[p] = 0;
+  }
+  for (int q = 0; q < Py; ++q) {   // stage 1: my kx chunk for px' = q  <->  their y blocks
+    const int peer = pz * Py + q;
+    if (s1s) s1s[peer] = kx[q] * nyl * nzl;
+    if (s1r) s1r[peer] = kxl * y[q] * nzl;
+  }
+  for (int q = 0; q < Pz; ++q) {   // stage 2: my ky chunk for pz' = q  <->  their z blocks
+    const int peer = q * Py + px;
+    if (s2s) s2s[peer] = kxl * ky[q] * nzl;
+    if (s2r) s2r[peer] = kxl * kyl * z[q];
+  }
+  return MRL_OK;
+}
+
 int mrl_pencil_grid(const mrl_ctx *ctx, int32_t *py, int32_t *pz) {
   if (!ctx) return MRL_ERR_INVALID;
   if (!ctx->pencil) return set_error(ctx, MRL_ERR_INVALID, "mrl_pencil_grid: not a pencil context");

@@ -66,25 +66,19 @@ static long long begin_of(const std::vector<long long> &v, int i) {
 //   stage 1: the Py ranks of equal pz      forward: my kx chunk for px' <-> their y blocks          (:1105-1180)  inverse (:1331-1404)
 //   stage 2: the Pz ranks of equal px      forward: my ky chunk for pz' <-> their z blocks          (:1182-1256)  inverse (:1258-1329)
 int pencil_counts(const mrl_ctx *ctx, int stage, int forward, long long *send, long long *recv) {
-  const int Py = ctx->pen_py, Pz = ctx->pen_pz, px = ctx->rank % Py, pz = ctx->rank / Py;
-  const long long nyl = ctx->nloc[1], nzl = ctx->nloc[2], kxl = ctx->nrec[0], kyl = ctx->nrec[1];
-  for (int p = 0; p < ctx->nranks; ++p) send[p] = recv[p] = 0;
-  if (stage == 1) {
-    for (int q = 0; q < Py; ++q) {
-      const int peer = pz * Py + q;
-      const long long a = ctx->pen_kx[q] * nyl * nzl;     // kx chunk of peer q, my y block
-      const long long b = kxl * ctx->pen_y[q] * nzl;      // my kx chunk, peer q's y block
-      send[peer] = forward ? a : b;
-      recv[peer] = forward ? b : a;
-    }
-  } else {
-    for (int q = 0; q < Pz; ++q) {
-      const int peer = q * Py + px;
-      const long long a = kxl * ctx->pen_ky[q] * nzl;     // ky chunk of peer q, my z block
-      const long long b = kxl * kyl * ctx->pen_z[q];      // my ky chunk, peer q's z block
-      send[peer] = forward ? a : b;
-      recv[peer] = forward ? b : a;
-    }
+  // ONE implementation of the message sizes: the host-only ABI entry point (context.hip), which the CPU tests drive with real
+  // gloo messages (tests/test_pencil_gloo.py); the inverse stages swap send and receive
+  const int64_t n[3] = {ctx->n[0], ctx->n[1], ctx->n[2]};
+  std::vector<int64_t> a(ctx->nranks), b(ctx->nranks);
+  int rc;
+  if (stage == 1)
+    rc = mrl_pencil_layout(ctx->nranks, ctx->rank, n, nullptr, nullptr, nullptr, nullptr, a.data(), b.data(), nullptr, nullptr);
+  else
+    rc = mrl_pencil_layout(ctx->nranks, ctx->rank, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, a.data(), b.data());
+  if (rc != MRL_OK) return set_error(ctx, rc, "%s", mrl_last_error(nullptr));
+  for (int p = 0; p < ctx->nranks; ++p) {
+    send[p] = forward ? a[p] : b[p];
+    recv[p] = forward ? b[p] : a[p];
   }
   return MRL_OK;
 }
