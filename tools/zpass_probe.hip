@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "fft_pow2_kernels.h"
+#include "fft_pow2_wide.h"   // bfly<32>
 
 using namespace mrl;
 using namespace mrl::p2;
@@ -255,6 +256,134 @@ __global__ void __launch_bounds__(T *Plan<N>::TPL, WPS) k_ea2(const kcplx *__res
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The two-stage 32 x 16 plan for 512-point z lines: 32 points per thread, 16 threads per line, ONE LDS
+// exchange per transform, lane-exchange pairing.  v (128 VGPRs) + the second real line (64) + the loads do not fit 256 registers:
+// launch bound 1 wave per SIMD.
+struct W512z {
+  static constexpr int N = 512, P = 32, r0 = 32, r1 = 16, TPL = 16;
+};
+template <int PAD>
+struct MapW {   // position-fastest line map: PAD = 0: the xor swizzle of the product's 512-point map; 1: one pad element per 16
+  static constexpr int LP = PAD ? 512 + 32 : 512;
+  __device__ __forceinline__ static int at(int p, int l) { return PAD ? l * LP + p + (p >> 4) : l * LP + (p ^ ((p >> 3) & 7)); }
+};
+template <int R, int NS>
+__device__ __forceinline__ void stage_w512(kcplx (&v)[32], int q, const kcplx *W) {
+  constexpr int P = 32, S = P / R, TPL = 16, N = 512;
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    kcplx a[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) a[t] = v[i + S * t];
+    if (NS > 1) {
+      const int k = (q + i * TPL) % NS;
+      const kcplx *Ws = W + k;   // staged table [t - 1][k], k fastest (N - r0 entries)
+#pragma unroll
+      for (int t = 1; t < R; ++t) a[t] = cmul(a[t], Ws[(t - 1) * NS]);
+    }
+    bfly<R>(a);
+#pragma unroll
+    for (int t = 0; t < R; ++t) v[i + S * t] = a[t];
+  }
+}
+template <class Map>
+__device__ __forceinline__ void fft_line_w512(kcplx (&v)[32], int q, int l, kcplx *X, const kcplx *W) {
+  constexpr int TPL = 16;
+  stage_w512<32, 1>(v, q, W);
+  __syncthreads();
+  {  // Stockham exchange after the radix-32 stage (Ns = 1): butterfly b = q writes its outputs t at b * 32 + t
+#pragma unroll
+    for (int t = 0; t < 32; ++t) X[Map::at(q * 32 + t, l)] = v[t];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 32; ++m) v[m] = X[Map::at(q + m * TPL, l)];
+  stage_w512<16, 32>(v, q, W);
+}
+
+template <int T, class Map>
+__global__ void __launch_bounds__(T * 16, 1) k_ea_w512(const kcplx *__restrict__ in, kcplx *__restrict__ out0, kcplx *__restrict__ out1, ChDev chp,
+                                                       kreal scale, long long nlines, const kcplx *__restrict__ tw, ZLay zl) {
+  constexpr int N = 512, P = 32, TPL = 16, NZC = N / 2 + 1, NT = T * TPL, FAM = MRL_FE_DOUBLE_WELL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  kcplx *W = reinterpret_cast<kcplx *>(smem);
+  kcplx *X = W + N;
+  const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
+  const int partner = (int)(threadIdx.x & 63u) - q + ((TPL - q) & (TPL - 1));
+  const long long L = (long long)xcd_remap(blockIdx.x, gridDim.x) * T + l;
+  const bool valid = L < nlines;
+  const long long Lc = valid ? L : 0;
+  // staged twiddle table of the radix-16 stage: entry (t - 1) * 32 + k = w^(t k), 480 entries
+  for (int s = threadIdx.x; s < 480; s += NT) W[s] = tw[((s / 32) + 1) * (s % 32)];
+  kcplx v[P];
+  {
+    const kcplx *A = in + zrow(2 * Lc, NZC, zl), *B = in + zrow(2 * Lc + 1, NZC, zl);
+    kcplx av[P / 2], bv[P / 2];
+#pragma unroll
+    for (int m = 0; m < P / 2; ++m) {
+      av[m] = A[q + m * TPL];
+      bv[m] = B[q + m * TPL];
+    }
+    kcplx aN = A[q == 0 ? N / 2 : q], bN = B[q == 0 ? N / 2 : q];
+    kcplx yh[P / 2];
+#pragma unroll
+    for (int m = 0; m < P / 2; ++m) {
+      kcplx a = av[m], b = bv[m];
+      yh[m] = cswap(mkc(a.x + b.y, b.x - a.y));
+      if (m == 0) {
+        a.y = q == 0 ? 0.0 : a.y;
+        b.y = q == 0 ? 0.0 : b.y;
+      }
+      v[m] = cswap(mkc(a.x - b.y, a.y + b.x));
+    }
+    aN.y = 0.0;
+    bN.y = 0.0;
+    const kcplx vN = cswap(mkc(aN.x - bN.y, aN.y + bN.x));
+#pragma unroll
+    for (int m = P / 2; m < P; ++m) {
+      const kcplx s = shfl_c(yh[P - 1 - m], partner);
+      const kcplx own = (m == P / 2) ? vN : yh[(P - m) % (P / 2)];
+      v[m] = mkc(q == 0 ? own.x : s.x, q == 0 ? own.y : s.y);
+    }
+  }
+  fft_line_w512<Map>(v, q, l, X, W);
+  kreal cb[P];
+#pragma unroll
+  for (int m = 0; m < P; ++m) {
+    const kreal ca = v[m].y * scale;
+    cb[m] = v[m].x * scale;
+    v[m] = mkc(ca, mu_eval<FAM>(chp, ca));
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half == 1) {
+#pragma unroll
+      for (int m = 0; m < P; ++m) v[m] = mkc(cb[m], mu_eval<FAM>(chp, cb[m]));
+    }
+    fft_line_w512<Map>(v, q, l, X, W);
+    kcplx *o0 = out0 + zrow(2 * Lc + half, NZC, zl), *o1 = out1 + zrow(2 * Lc + half, NZC, zl);
+#pragma unroll
+    for (int m = 0; m < P / 2; ++m) {
+      const int k = q + m * TPL;
+      const kcplx s = shfl_c(v[P - 1 - m], partner);
+      const kcplx own = v[(P - m) % P];
+      const kcplx xk = v[m];
+      const kcplx xn = mkc(q == 0 ? own.x : s.x, q == 0 ? own.y : s.y);
+      if (valid) {
+        o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
+        o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
+      }
+    }
+    if (q == 0 && valid) {
+      const kcplx xk = v[P / 2];
+      o0[N / 2] = mkc(kreal(0.5) * (xk.x + xk.x), kreal(0.5) * (xk.y - xk.y));
+      o1[N / 2] = mkc(kreal(0.5) * (xk.y + xk.y), kreal(-0.5) * (xk.x - xk.x));
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_touch(double2 *p, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     double2 v = p[i];
@@ -404,6 +533,68 @@ static void run2(const char *name, EaKernel K, const Bufs &B, bool padded, int c
   CK(hipEventDestroy(e1));
 }
 
+
+template <int T, class Map>
+static void run_w512(const char *name, const Bufs &B, int check) {
+  constexpr int N = 512, NZC = 257;
+  const size_t lds = sizeof(kcplx) * (N + T * Map::LP);
+  auto K = k_ea_w512<T, Map>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int occ = 0;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, K, T * 16, lds));
+  const long long nlines = B.rows / 2;
+  const unsigned nb = (unsigned)((nlines + T - 1) / T);
+  ChDev chp{MRL_FE_DOUBLE_WELL, 0.1, 0.0, 0.0, {}};
+  const ZLay zl{0u, 0u};
+  char verdict[96] = "";
+  if (check) {
+    double2 *c, *d;
+    CK(hipMalloc(&c, B.nspec * sizeof(double2)));
+    CK(hipMalloc(&d, B.nspec * sizeof(double2)));
+    CK(hipMemset(c, 0, B.nspec * sizeof(double2)));
+    CK(hipMemset(d, 0, B.nspec * sizeof(double2)));
+    k_fill<<<2048, 256>>>(B.a, B.nspec);
+    hipLaunchKernelGGL(K, dim3(nb), dim3(T * 16), lds, 0, B.a, c, d, chp, 1.0 / N, nlines, B.tw, zl);
+    CK(hipDeviceSynchronize());
+    std::vector<double2> h0(B.nspec), h1(B.nspec);
+    CK(hipMemcpy(h0.data(), c, B.nspec * sizeof(double2), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h1.data(), d, B.nspec * sizeof(double2), hipMemcpyDeviceToHost));
+    double worst = 0.0, scale = 0.0;   // (another butterfly order: equal to rounding, not bit for bit)
+    for (size_t i = 0; i < B.nspec; ++i) {
+      worst = fmax(worst, fmax(fabs(h0[i].x - g_ref0[i].x), fabs(h0[i].y - g_ref0[i].y)));
+      worst = fmax(worst, fmax(fabs(h1[i].x - g_ref1[i].x), fabs(h1[i].y - g_ref1[i].y)));
+      scale = fmax(scale, fmax(fabs(g_ref0[i].x), fabs(g_ref1[i].x)));
+    }
+    snprintf(verdict, sizeof verdict, "  [max |diff| vs the reference %.2e of %.2e]", worst, scale);
+    CK(hipFree(c));
+    CK(hipFree(d));
+  }
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  float tot = 0.f, best = 1e9f;
+  const int reps = 24;
+  for (int r = -4; r < reps; ++r) {
+    k_touch<<<4096, 256>>>(B.a, B.nspec);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(K, dim3(nb), dim3(T * 16), lds, 0, B.a, B.a, B.b, chp, 1.0 / N, nlines, B.tw, zl);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r >= 0) {
+      tot += ms;
+      best = ms < best ? ms : best;
+    }
+  }
+  CK(hipGetLastError());
+  const double bytes = 3.0 * 16.0 * (double)B.rows * NZC;
+  const double us = tot / reps * 1e3;
+  printf("%-44s N=512 T=%d blocks/CU %d  lds %6zu  avg %7.1f us  best %7.1f us  %6.0f GB/s (3h model)%s\n", name, T, occ, lds, us, best * 1e3,
+         bytes / us * 1e-3, verdict);
+  fflush(stdout);
+}
+
 template <int N>
 static Bufs make(long long rows) {
   constexpr int NZC = N / 2 + 1;
@@ -453,6 +644,9 @@ int main(int argc, char **argv) {
     run2<512, 8>("both", k_ea2<512, 8, 2, true, true>, B, false, 2);
     run2<512, 4>("both, 4 lines", k_ea2<512, 4, 2, true, true>, B, false, 2);
     run2<512, 2>("both, 2 lines", k_ea2<512, 2, 2, true, true>, B, false, 2);
+    run_w512<4, MapW<0>>("two-stage 32 x 16, 4 lines, xor map", B, 1);
+    run_w512<4, MapW<1>>("two-stage 32 x 16, 4 lines, padded map", B, 1);
+    run_w512<8, MapW<1>>("two-stage 32 x 16, 8 lines, padded map", B, 1);
     run2<512, 8>("product (again)", k_ea<512, 8, 2, 0>, B, false, 2);
   }
   return 0;
