@@ -140,7 +140,8 @@ struct ZPlan<256> {
 };
 // ... and of the fused inverse + forward z kernel (k_z_inv_fwd): three transforms between one burst of loads and the stores, so more,
 // smaller workgroups in different phases pay at 512 points (tools/zpass_probe.hip, same box: 8 -> 4 lines 84.7 -> 82.1 us on the
-// slab-local 512^3 / 8 arrays; 256 points: 72.2 vs 71.2 us, within the noise: unchanged)
+// slab-local 512^3 / 8 arrays; 256 points: 72.2 vs 71.2 us in the probe, and 0.3052 / 0.3051 vs 0.3039 / 0.3053 ms per substep in two
+// interleaved bench.py runs of each build on one box: within the noise, unchanged)
 template <int N>
 struct ZPlanEA {
   static constexpr int T = ZPlan<N>::T, NT = ZPlan<N>::NT;

@@ -8,6 +8,7 @@
 // Infinity Cache in the same way).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -Imarlin_amd/csrc tools/zpass_probe.hip -o marlin_amd/lib/zpass_probe
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include <cmath>
 #include <cstdio>
@@ -257,6 +258,90 @@ __global__ void __launch_bounds__(T *Plan<N>::TPL, WPS) k_ea2(const kcplx *__res
 }
 
 
+// persistent workgroups that request the spectral elements of line pair t + 1 before transforming pair t
+// (the operands of the next tile wait in 72 VGPRs at 16 points per thread while this tile's three transforms run).
+template <int N, int T, int WHEN>
+__global__ void __launch_bounds__(T *Plan<N>::TPL, 2) k_ea3(const kcplx *__restrict__ in, kcplx *__restrict__ out0, kcplx *__restrict__ out1,
+                                                            ChDev chp, kreal scale, long long nlines, const kcplx *__restrict__ tw, ZLay zl) {
+  constexpr int P = Plan<N>::P, TPL = Plan<N>::TPL, NZC = N / 2 + 1, NT = T * TPL;
+  constexpr int FAM = MRL_FE_DOUBLE_WELL;
+  using Map = MapLine<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  kcplx *W = reinterpret_cast<kcplx *>(smem);
+  kcplx *X = W + N;
+  const int q = threadIdx.x % TPL, l = threadIdx.x / TPL;
+  const int lane = threadIdx.x & 63;
+  const int partner = lane - q + ((TPL - q) % TPL);
+  const long long ntiles = (nlines + T - 1) / T;
+  TwRegs<N, NT> twr;
+  tw_issue_staged<N>(twr, tw);
+  kcplx av[P / 2], bv[P / 2], aN, bN;
+  auto request = [&](long long tile) {
+    long long L = tile * T + l;
+    L = L < nlines ? L : 0;
+    const kcplx *A = in + zrow(2 * L, NZC, zl), *B = in + zrow(2 * L + 1, NZC, zl);
+#pragma unroll
+    for (int m = 0; m < P / 2; ++m) {
+      av[m] = A[q + m * TPL];
+      bv[m] = B[q + m * TPL];
+    }
+    aN = A[q == 0 ? N / 2 : q];
+    bN = B[q == 0 ? N / 2 : q];
+  };
+  long long tile = blockIdx.x;
+  if (tile < ntiles) request(tile);
+  tw_commit<N>(twr, W);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long long L = tile * T + l;
+    const bool valid = L < nlines;
+    if (WHEN == 2 && tile != (long long)blockIdx.x) request(tile);
+    kcplx v[P];
+    {
+      kcplx yh[P / 2];
+#pragma unroll
+      for (int m = 0; m < P / 2; ++m) {
+        kcplx a = av[m], b = bv[m];
+        yh[m] = cswap(mkc(a.x + b.y, b.x - a.y));
+        if (m == 0) {
+          a.y = q == 0 ? 0.0 : a.y;
+          b.y = q == 0 ? 0.0 : b.y;
+        }
+        v[m] = cswap(mkc(a.x - b.y, a.y + b.x));
+      }
+      aN.y = 0.0;
+      bN.y = 0.0;
+      const kcplx vN = cswap(mkc(aN.x - bN.y, aN.y + bN.x));
+#pragma unroll
+      for (int m = P / 2; m < P; ++m) {
+        const kcplx s = shfl_c(yh[P - 1 - m], partner);
+        const kcplx own = (m == P / 2) ? vN : yh[(P - m) % (P / 2)];
+        v[m] = mkc(q == 0 ? own.x : s.x, q == 0 ? own.y : s.y);
+      }
+    }
+    if (WHEN == 0 && tile + gridDim.x < ntiles) request(tile + gridDim.x);   // in flight during the three transforms below
+    fft_line<N, Map>(v, q, l, X, W);
+    kreal cb[P];
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      const kreal ca = v[m].y * scale;
+      cb[m] = v[m].x * scale;
+      v[m] = mkc(ca, mu_eval<FAM>(chp, ca));
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (half == 1) {
+#pragma unroll
+        for (int m = 0; m < P; ++m) v[m] = mkc(cb[m], mu_eval<FAM>(chp, cb[m]));
+        if (WHEN == 1 && tile + gridDim.x < ntiles) request(tile + gridDim.x);   // the second real line is consumed: 32 registers free
+      }
+      fft_line<N, Map>(v, q, l, X, W);
+      kcplx *o0 = out0 + zrow(2 * (valid ? L : 0) + half, NZC, zl), *o1 = out1 + zrow(2 * (valid ? L : 0) + half, NZC, zl);
+      if (valid) store_pair_shfl<N>(v, q, partner, o0, o1);
+    }
+    __syncthreads();   // (the next tile's first exchange reuses X)
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The two-stage 32 x 16 plan for 512-point z lines: 32 points per thread, 16 threads per line, ONE LDS
 // exchange per transform, lane-exchange pairing.  v (128 VGPRs) + the second real line (64) + the loads do not fit 256 registers:
@@ -469,14 +554,15 @@ static std::vector<double2> g_ref0, g_ref1;
 
 // time kernel K (T lines per workgroup) like run(); check = 1: keep its outputs as the reference, 2: compare with the reference bit for bit
 template <int N, int T>
-static void run2(const char *name, EaKernel K, const Bufs &B, bool padded, int check = 0) {
+static void run2(const char *name, EaKernel K, const Bufs &B, bool padded, int check = 0, int persist = 0) {
   constexpr int NZC = N / 2 + 1;
   const size_t lds = sizeof(kcplx) * (N + T * MapLine<N>::LP);
   CK(hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int occ = 0;
   CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, K, T * Plan<N>::TPL, lds));
   const long long nlines = B.rows / 2;
-  const unsigned nb = (unsigned)((nlines + T - 1) / T);
+  unsigned nb = (unsigned)((nlines + T - 1) / T);
+  if (persist) nb = std::min(nb, (unsigned)(persist * 256));   // persistent form: `persist` workgroups per CU walk the tiles
   ChDev chp{MRL_FE_DOUBLE_WELL, 0.1, 0.0, 0.0, {}};
   const ZLay zl = lay<N>(padded);
   char verdict[64] = "";
@@ -631,6 +717,11 @@ int main(int argc, char **argv) {
     run2<256, 4>("both, 4 lines", k_ea2<256, 4, 2, true, true>, B, true, 2);
     run2<256, 4>("both, 4 lines, <= 168 VGPR", k_ea2<256, 4, 3, true, true>, B, true, 2);
     run2<256, 8>("both, 8 lines, <= 168 VGPR", k_ea2<256, 8, 3, true, true>, B, true, 2);
+    run2<256, 8>("persistent, next pair at once (spills), 4/CU", k_ea3<256, 8, 0>, B, true, 2, 4);
+    run2<256, 8>("persistent, next pair before transform 3, 4/CU", k_ea3<256, 8, 1>, B, true, 2, 4);
+    run2<256, 8>("persistent, no early request, 4/CU", k_ea3<256, 8, 2>, B, true, 2, 4);
+    run2<256, 4>("persistent, 4 lines, before transform 3, 7/CU", k_ea3<256, 4, 1>, B, true, 2, 7);
+    run2<256, 4>("persistent, 4 lines, before transform 3, 4/CU", k_ea3<256, 4, 1>, B, true, 2, 4);
     run2<256, 8>("product (again)", k_ea<256, 8, 2, 0>, B, true, 2);
   }
   {
@@ -644,6 +735,10 @@ int main(int argc, char **argv) {
     run2<512, 8>("both", k_ea2<512, 8, 2, true, true>, B, false, 2);
     run2<512, 4>("both, 4 lines", k_ea2<512, 4, 2, true, true>, B, false, 2);
     run2<512, 2>("both, 2 lines", k_ea2<512, 2, 2, true, true>, B, false, 2);
+    run2<512, 4>("persistent, next pair at once (spills), 4/CU", k_ea3<512, 4, 0>, B, false, 2, 4);
+    run2<512, 4>("persistent, next pair before transform 3, 4/CU", k_ea3<512, 4, 1>, B, false, 2, 4);
+    run2<512, 4>("persistent, no early request, 4/CU", k_ea3<512, 4, 2>, B, false, 2, 4);
+    run2<512, 8>("persistent, 8 lines, before transform 3, 2/CU", k_ea3<512, 8, 1>, B, false, 2, 2);
     run_w512<4, MapW<0>>("two-stage 32 x 16, 4 lines, xor map", B, 1);
     run_w512<4, MapW<1>>("two-stage 32 x 16, 4 lines, padded map", B, 1);
     run_w512<8, MapW<1>>("two-stage 32 x 16, 8 lines, padded map", B, 1);
