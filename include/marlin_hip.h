@@ -309,16 +309,19 @@ int mrl_kspace_abm(mrl_ctx *ctx, double *d_ubar_out, const double *d_ubar0, cons
                    const double *h_coef, int nterms, const double *d_L, double dt, int64_t n_spec);
 
 /* Coupled k-space update of AdamsBashforthMoultonCoupled::substep (AdamsBashforthMoultonCoupled.C:118-186, corrector
- * :214-270): for nvar <= 8 variables (the reference solves any N; its inputs couple 2 or 3), at every reciprocal grid point
+ * :214-270): for nvar <= 32 variables (the reference solves any N; its inputs couple 2 or 3), at every reciprocal grid point
  *   rhs_i = ubar0_i + sum_t coef[i][t] * N[i][t]          (h_nterms[i] <= 6 terms; d_N / h_coef are the rows concatenated)
  *   solve (I - dt * Lhat) ubar = rhs                       (dense nvar x nvar, LU with partial pivoting, one thread per k)
  * d_L[i*nvar + j] = real array of the linear operator entry the input file names (row i, column j), NULL = zero.
  * Default flags (0) reproduce the reference bit for bit in structure, including two of its quirks that its gold files
  * (test/tests/solvers/gold/coupled_*.csv) pin: the matrix is assembled transposed (A_ab = delta_ab - dt*L_ba, :160-178)
  * and the complex right-hand side is cast to the real dtype of L, dropping Im(rhs) (:183; outputs then have Im = 0).
- * MRL_COUPLED_L_AS_WRITTEN uses A_ab = delta_ab - dt*L_ab; MRL_COUPLED_COMPLEX_RHS solves for the full complex rhs. */
+ * MRL_COUPLED_L_AS_WRITTEN uses A_ab = delta_ab - dt*L_ab; MRL_COUPLED_COMPLEX_RHS solves for the full complex rhs.
+ * Up to 8 variables the matrix of a k-point lives in registers; 9 ... 32 (or MRL_COUPLED_GENERAL at any size) run the same
+ * elimination, operation for operation, on a device workspace of (nvar^2 + 2 nvar) x 65536 doubles owned by the context. */
 #define MRL_COUPLED_L_AS_WRITTEN 1
 #define MRL_COUPLED_COMPLEX_RHS 2
+#define MRL_COUPLED_GENERAL 4
 int mrl_kspace_coupled(mrl_ctx *ctx, int nvar, double *const *d_ubar_out, const double *const *d_ubar0,
                        const double *const *d_N, const double *h_coef, const int *h_nterms, const double *const *d_L,
                        double dt, int flags, int64_t n_spec);
@@ -338,7 +341,7 @@ int mrl_secant_iterate(mrl_ctx *ctx, const double *d_u, const double *d_N, const
                        const double *d_u_prev, double *d_R_prev, double sub_dt, double damping, double *d_u_new,
                        double *h_sumsq, int64_t n_spec);
 
-/* BroydenSolver::substep (src/tensor_solver/BroydenSolver.C:63-176) for nvar <= 8 coupled variables: per reciprocal grid point
+/* BroydenSolver::substep (src/tensor_solver/BroydenSolver.C:63-176) for nvar <= 32 coupled variables: per reciprocal grid point
  * a Broyden iteration on R(u) = (N + L u) sub_dt + u_old - u with a persistent complex nvar x nvar approximation M of the inverse
  * Jacobian.  The caller keeps the reference's control flow (compute group, inverse transforms, convergence tests); per iteration:
  *   mrl_broyden_predict: S = -M R ; u_out_i = u_i + step * S_i                    (:124-133; the reference hard-wires step = 0.5)

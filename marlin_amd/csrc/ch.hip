@@ -3,6 +3,8 @@
 //   k-space : Mbar*mubar + ABM predictor     (src/tensor_solver/AdamsBashforthMoulton.C:94-99)
 // k, Mbar = -k^2 M and Lbar = k^2 k^2 f are recomputed from the 1-D reciprocal axes (no full arrays).
 #include "mrl_internal.h"
+#include <cstring>
+#include <vector>
 
 namespace mrl {
 
@@ -219,6 +221,97 @@ __global__ void __launch_bounds__(256) k_kspace_coupled(CoupledArgs a, long long
   }
 }
 
+// The same solve for more variables than a register file holds (9 ... kCoupledAnyMax; the reference: any N): the matrix and the
+// right-hand side of a thread live in a workspace [(nv * nv + 2 nv)][lanes] doubles -- entry-major, so that the lanes of a wave touch
+// consecutive addresses -- and the pointer tables in device memory.  Same operations in the same order as k_kspace_coupled (row swaps
+// are real swaps here): equal results bit for bit where both apply (tests/test_coupled_gpu.py).
+constexpr int kCoupledAnyMax = 32;
+struct CoupledAnyArgs {
+  int nv, flags;
+  double dt;
+  const int *nterms;        // [nv]
+  const double *coef;       // [nv][6]
+  const double *const *N;   // [nv][6]
+  const double *const *u0;  // [nv]
+  const double *const *L;   // [nv][nv] as the caller names them (row = equation, column = variable)
+  double *const *out;       // [nv]
+  double *ws;
+  long long lanes;
+};
+
+__global__ void __launch_bounds__(256) k_kspace_coupled_any(CoupledAnyArgs a, long long n) {
+#pragma clang fp contract(off)
+  const int nv = a.nv;
+  const bool real_rhs = !(a.flags & MRL_COUPLED_COMPLEX_RHS), transposed = !(a.flags & MRL_COUPLED_L_AS_WRITTEN);
+  const long long lane = (long long)blockIdx.x * blockDim.x + threadIdx.x, W = a.lanes;
+  double *A = a.ws + lane;                       // A(i, j) = A[(i * nv + j) * W]
+  double *br = A + (long long)nv * nv * W, *bi = br + (long long)nv * W;
+  for (long long e = lane; e < n; e += W) {
+    for (int i = 0; i < nv; ++i) {
+      double2 u = reinterpret_cast<const double2 *>(a.u0[i])[e];
+      for (int t = 0; t < a.nterms[i]; ++t) {
+        const double2 o = reinterpret_cast<const double2 *>(a.N[i * 6 + t])[e];
+        const double c = a.coef[i * 6 + t];
+        u.x += c * o.x;
+        u.y += c * o.y;
+      }
+      br[i * W] = u.x;
+      bi[i * W] = real_rhs ? 0.0 : u.y;
+      for (int j = 0; j < nv; ++j) {
+        const double *Lp = transposed ? a.L[j * nv + i] : a.L[i * nv + j];
+        const double l = Lp ? Lp[e] : 0.0;
+        A[(long long)(i * nv + j) * W] = (i == j ? 1.0 : 0.0) - a.dt * l;
+      }
+    }
+    for (int c = 0; c < nv; ++c) {
+      int piv = c;
+      double best = fabs(A[(long long)(c * nv + c) * W]);
+      for (int r = c + 1; r < nv; ++r) {
+        const double v = fabs(A[(long long)(r * nv + c) * W]);
+        if (v > best) {
+          best = v;
+          piv = r;
+        }
+      }
+      if (piv != c) {
+        for (int j = 0; j < nv; ++j) {
+          const double t = A[(long long)(c * nv + j) * W];
+          A[(long long)(c * nv + j) * W] = A[(long long)(piv * nv + j) * W];
+          A[(long long)(piv * nv + j) * W] = t;
+        }
+        double t = br[c * W];
+        br[c * W] = br[piv * W];
+        br[piv * W] = t;
+        t = bi[c * W];
+        bi[c * W] = bi[piv * W];
+        bi[piv * W] = t;
+      }
+      const double inv = 1.0 / A[(long long)(c * nv + c) * W];
+      const double brc = br[c * W], bic = bi[c * W];
+      for (int r = c + 1; r < nv; ++r) {
+        const double f = A[(long long)(r * nv + c) * W] * inv;
+        for (int j = c + 1; j < nv; ++j) A[(long long)(r * nv + j) * W] -= f * A[(long long)(c * nv + j) * W];
+        br[r * W] -= f * brc;
+        bi[r * W] -= f * bic;
+      }
+    }
+    for (int c = nv - 1; c >= 0; --c) {
+      double xr = br[c * W], xi = bi[c * W];
+      for (int j = c + 1; j < nv; ++j) {
+        const double m = A[(long long)(c * nv + j) * W];
+        xr -= m * br[j * W];
+        xi -= m * bi[j * W];
+      }
+      const double d = A[(long long)(c * nv + c) * W];
+      xr /= d;
+      xi /= d;
+      br[c * W] = xr;
+      bi[c * W] = xi;
+    }
+    for (int i = 0; i < nv; ++i) reinterpret_cast<double2 *>(a.out[i])[e] = make_double2(br[i * W], bi[i * W]);
+  }
+}
+
 // Adams-Bashforth coefficients (src/tensor_solver/AdamsBashforthMoulton.C:67-73, incl. the AB5 190/720 entry)
 static const double kBeta[5][5] = {
     {1.0, 0.0, 0.0, 0.0, 0.0},
@@ -421,9 +514,63 @@ int mrl_kspace_coupled(mrl_ctx *ctx, int nvar, double *const *d_ubar_out, const 
                        const double *const *d_N, const double *h_coef, const int *h_nterms, const double *const *d_L,
                        double dt, int flags, int64_t n_spec) {
   if (!ctx) return MRL_ERR_INVALID;
-  if (nvar < 1 || nvar > kCoupledMax || !d_ubar_out || !d_ubar0 || !d_L || !h_nterms || n_spec < 0)
-    return set_error(ctx, MRL_ERR_INVALID, "mrl_kspace_coupled: bad argument (1 <= nvar <= %d)", kCoupledMax);
+  if (nvar < 1 || nvar > kCoupledAnyMax || !d_ubar_out || !d_ubar0 || !d_L || !h_nterms || n_spec < 0)
+    return set_error(ctx, MRL_ERR_INVALID, "mrl_kspace_coupled: bad argument (1 <= nvar <= %d)", kCoupledAnyMax);
   if (n_spec == 0) return MRL_OK;
+  if (nvar > kCoupledMax || (flags & MRL_COUPLED_GENERAL)) {
+    // pointer tables and the per-thread matrices in device memory (slots 16 / 17 belong to this entry point)
+    std::vector<unsigned char> tab;
+    auto put = [&tab](const void *src, size_t bytes) {
+      const size_t at = (tab.size() + 15) & ~size_t(15);
+      tab.resize(at + bytes);
+      std::memcpy(tab.data() + at, src, bytes);
+      return at;
+    };
+    std::vector<int> nt(nvar);
+    std::vector<double> coef((size_t)nvar * 6, 0.0);
+    std::vector<const double *> Np((size_t)nvar * 6, nullptr), u0(nvar), Lp((size_t)nvar * nvar);
+    std::vector<double *> outp(nvar);
+    int at = 0;
+    for (int i = 0; i < nvar; ++i) {
+      if (!d_ubar_out[i] || !d_ubar0[i] || h_nterms[i] < 0 || h_nterms[i] > 6 || (h_nterms[i] > 0 && (!d_N || !h_coef)))
+        return set_error(ctx, MRL_ERR_INVALID, "mrl_kspace_coupled: bad variable %d (at most 6 terms each)", i);
+      nt[i] = h_nterms[i];
+      u0[i] = d_ubar0[i];
+      outp[i] = d_ubar_out[i];
+      for (int t = 0; t < h_nterms[i]; ++t, ++at) {
+        coef[(size_t)i * 6 + t] = h_coef[at];
+        Np[(size_t)i * 6 + t] = d_N[at];
+      }
+      for (int j = 0; j < nvar; ++j) Lp[(size_t)i * nvar + j] = d_L[i * nvar + j];
+    }
+    const size_t o_nt = put(nt.data(), sizeof(int) * nvar), o_cf = put(coef.data(), sizeof(double) * coef.size()),
+                 o_N = put(Np.data(), sizeof(void *) * Np.size()), o_u = put(u0.data(), sizeof(void *) * nvar),
+                 o_L = put(Lp.data(), sizeof(void *) * Lp.size()), o_o = put(outp.data(), sizeof(void *) * nvar);
+    long long nb = (n_spec + 255) / 256;
+    if (nb > 256) nb = 256;
+    const long long lanes = nb * 256;
+    MRL_TRY(ensure_work(ctx, 16, sizeof(double) * (size_t)(nvar * nvar + 2 * nvar) * (size_t)lanes));
+    MRL_TRY(ensure_work(ctx, 17, tab.size()));
+    unsigned char *dt_ = reinterpret_cast<unsigned char *>(ctx->d_work[17]);
+    MRL_HIP(ctx, hipMemcpyAsync(dt_, tab.data(), tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (`tab` is pageable host memory that dies with this scope)
+    CoupledAnyArgs g{};
+    g.nv = nvar;
+    g.flags = flags;
+    g.dt = dt;
+    g.nterms = reinterpret_cast<const int *>(dt_ + o_nt);
+    g.coef = reinterpret_cast<const double *>(dt_ + o_cf);
+    g.N = reinterpret_cast<const double *const *>(dt_ + o_N);
+    g.u0 = reinterpret_cast<const double *const *>(dt_ + o_u);
+    g.L = reinterpret_cast<const double *const *>(dt_ + o_L);
+    g.out = reinterpret_cast<double *const *>(dt_ + o_o);
+    g.ws = ctx->d_work[16];
+    g.lanes = lanes;
+    ProfScope ps(ctx, "kspace_coupled_general");
+    hipLaunchKernelGGL(k_kspace_coupled_any, dim3((unsigned)nb), dim3(256), 0, ctx->stream, g, (long long)n_spec);
+    MRL_HIP(ctx, hipGetLastError());
+    return MRL_OK;
+  }
   CoupledArgs a{};
   a.dt = dt;
   a.flags = flags;

@@ -158,7 +158,7 @@ int mrl_secant_iterate(mrl_ctx *ctx, const double *d_u, const double *d_N, const
 // M, R, s are field-major ([nvar*nvar][n], [nvar][n] complex) so that every access is coalesced.
 namespace mrl {
 
-constexpr int kBroydenMax = 8;
+constexpr int kBroydenMax = 32;   // (the reference: any N; per-thread vectors are sized 8 or 32: kernels below are instantiated for both)
 struct BroydenPtrs {
   const double2 *u[kBroydenMax], *N[kBroydenMax], *uold[kBroydenMax];
   const double *L[kBroydenMax];
@@ -196,12 +196,13 @@ __global__ void __launch_bounds__(256) k_broyden_residual(int nv, BroydenPtrs p,
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+template <int MAXV>
 __global__ void __launch_bounds__(256) k_broyden_predict(int nv, BroydenPtrs p, const double2 *__restrict__ M,
                                                           const double2 *__restrict__ R, double2 *__restrict__ S, double step,
                                                           long long n) {
 #pragma clang fp contract(off)
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
-    double2 r[kBroydenMax];
+    double2 r[MAXV];
     for (int j = 0; j < nv; ++j) r[j] = R[(long long)j * n + e];
     for (int i = 0; i < nv; ++i) {
       double2 s = make_double2(0.0, 0.0);
@@ -218,6 +219,7 @@ __global__ void __launch_bounds__(256) k_broyden_predict(int nv, BroydenPtrs p, 
   }
 }
 
+template <int MAXV>
 __global__ void __launch_bounds__(256) k_broyden_update(int nv, BroydenPtrs p, double2 *__restrict__ M, double2 *__restrict__ R,
                                                          const double2 *__restrict__ S, double dt, long long n,
                                                          double *__restrict__ partial) {
@@ -225,7 +227,7 @@ __global__ void __launch_bounds__(256) k_broyden_update(int nv, BroydenPtrs p, d
   __shared__ double sh[4];
   double acc = 0.0;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
-    double2 y[kBroydenMax], s[kBroydenMax];
+    double2 y[MAXV], s[MAXV];
     double2 d = make_double2(0.0, 0.0);
     for (int i = 0; i < nv; ++i) {
       const double2 u = p.u[i][e], Nn = p.N[i][e], uo = p.uold[i][e];
@@ -319,9 +321,9 @@ int mrl_broyden_predict(mrl_ctx *ctx, int nvar, const double *d_M, const double 
   MRL_TRY(broyden_ptrs(ctx, nvar, d_u, nullptr, nullptr, nullptr, d_u_out, p));
   if (n_spec == 0) return MRL_OK;
   ProfScope ps(ctx, "broyden_predict");
-  hipLaunchKernelGGL(k_broyden_predict, dim3(blocks_for(n_spec)), dim3(256), 0, ctx->stream, nvar, p,
-                     reinterpret_cast<const double2 *>(d_M), reinterpret_cast<const double2 *>(d_R), reinterpret_cast<double2 *>(d_S),
-                     step, (long long)n_spec);
+  hipLaunchKernelGGL(nvar <= 8 ? k_broyden_predict<8> : k_broyden_predict<kBroydenMax>, dim3(blocks_for(n_spec)), dim3(256), 0,
+                     ctx->stream, nvar, p, reinterpret_cast<const double2 *>(d_M), reinterpret_cast<const double2 *>(d_R),
+                     reinterpret_cast<double2 *>(d_S), step, (long long)n_spec);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
@@ -340,8 +342,9 @@ int mrl_broyden_update(mrl_ctx *ctx, int nvar, double *d_M, double *d_R, const d
   double *slot = ctx->d_red + kScalarBase;
   {
     ProfScope ps(ctx, "broyden_update");
-    hipLaunchKernelGGL(k_broyden_update, dim3(nb), dim3(256), 0, ctx->stream, nvar, p, reinterpret_cast<double2 *>(d_M),
-                       reinterpret_cast<double2 *>(d_R), reinterpret_cast<const double2 *>(d_S), sub_dt, (long long)n_spec, ctx->d_red);
+    hipLaunchKernelGGL(nvar <= 8 ? k_broyden_update<8> : k_broyden_update<kBroydenMax>, dim3(nb), dim3(256), 0, ctx->stream, nvar, p,
+                       reinterpret_cast<double2 *>(d_M), reinterpret_cast<double2 *>(d_R), reinterpret_cast<const double2 *>(d_S), sub_dt,
+                       (long long)n_spec, ctx->d_red);
     MRL_HIP(ctx, hipGetLastError());
   }
   MRL_TRY(reduce_finalize(ctx, nb, 1, slot));

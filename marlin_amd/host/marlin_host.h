@@ -1158,8 +1158,8 @@ public:
       _flags(flags)
   {
     const std::size_t N = _variables.size();
-    if (N > 8)
-      paramError("buffer", "at most 8 coupled variables");
+    if (N > 32)
+      paramError("buffer", "at most 32 coupled variables");
     _L.assign(N * N, nullptr);
     for (std::size_t i = 0; i < N; ++i)
       _L[i * N + i] = _variables[i]._linear_reciprocal;
@@ -1557,8 +1557,8 @@ public:
     : SplitOperatorABM(problem, name, p.substeps, std::move(root_compute), vars, 1, 1, 0), _p(p)
   {
     const int n = (int)_variables.size();
-    if (n > 8)
-      paramError("buffer", "at most 8 coupled variables");
+    if (n > 32)
+      paramError("buffer", "at most 32 coupled variables");
     const int64_t ns = _domain.getReciprocalSize();
     _M = DeviceTensor::empty((std::size_t)(2 * n * n * ns));   // persists over substeps (:57-63)
     _domain.check(mrl_broyden_init(_domain.ctx(), n, _p.initial_jacobian_guess, _M.data(), ns));

@@ -75,3 +75,39 @@ def test_broyden_matches_oracle(n):
     assert trace_gpu == trace_ref                       # same iteration counts and convergence flags in every substep
     assert errs[0] <= 1e-11 and max(errs) <= 1e-6
     assert any(conv and it > 0 for it, conv in trace_ref)
+
+
+@pytest.mark.parametrize("nv", [3, 8, 9, 20])
+def test_broyden_kernels_for_any_variable_count(nv):
+    """one predict + update of nv coupled variables on random data against BroydenSolver.C:124-165 written with torch.matmul
+    (the restatement's expressions, oracle/marlin_oracle.py BroydenSolver.substep); nv > 8 takes the kernels' 32-wide instance"""
+    from marlin_amd.api import Context
+    n = 37
+    ctx = Context(1, [2 * (n - 1)], [2.0 * math.pi])
+    g = torch.Generator().manual_seed(nv)
+    rc = lambda *sh: torch.randn(*sh, dtype=torch.complex128, generator=g)
+    u, Nn, u_old, R = rc(n, nv), rc(n, nv), rc(n, nv), rc(n, nv)
+    L = -torch.rand(n, nv, dtype=torch.float64, generator=g)
+    M = torch.eye(nv, dtype=torch.complex128).expand(n, nv, nv) + 0.1 * rc(n, nv, nv)
+    sub_dt = 0.03
+    # reference expressions
+    sk = -torch.matmul(M, R.unsqueeze(-1))
+    skT = sk.squeeze(-1).unsqueeze(-2)
+    u_half = u + sk.squeeze(-1) * 0.5
+    u2 = u_half * (1.0 + 0.01)            # stands for ifft -> compute group -> fft: any new iterate will do for the update
+    Rnew = (Nn + L * u2) * sub_dt + u_old - u2
+    yk = (Rnew - R).unsqueeze(-1)
+    denom = torch.matmul(skT, yk)
+    M_new = M + torch.where(torch.abs(denom) > 1e-12, torch.matmul((sk - torch.matmul(M, yk)), skT) / denom, 0.0)
+    # device
+    fm = lambda t: [t[:, i].contiguous().cuda() for i in range(nv)]
+    Md = M.permute(1, 2, 0).reshape(nv * nv, n).contiguous().cuda()
+    Rd = R.t().contiguous().cuda()
+    S, out = ctx.broyden_predict(Md, Rd, fm(u), 0.5)
+    assert (torch.stack([o.cpu() for o in out], -1) - u_half).abs().max().item() <= 1e-12
+    assert (S.cpu().t() - sk.squeeze(-1)).abs().max().item() <= 1e-12
+    rn = ctx.broyden_update(Md, Rd, S, fm(u2), fm(Nn), [L[:, i].contiguous().cuda() for i in range(nv)], fm(u_old), sub_dt)
+    assert abs(rn - torch.norm(Rnew).item()) <= 1e-11 * rn
+    assert (Rd.cpu().t() - Rnew).abs().max().item() <= 1e-12
+    got = Md.cpu().reshape(nv, nv, n).permute(2, 0, 1)
+    assert (got - M_new).abs().max().item() <= 1e-9 * M_new.abs().max().item()

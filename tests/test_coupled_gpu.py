@@ -72,9 +72,40 @@ def test_kspace_coupled_pivots():
         assert (out[i].cpu() - want[i]).abs().max().item() <= 1e-13
 
 
+@pytest.mark.parametrize("nv,shape", [(9, (12, 10)), (12, (9, 8, 7)), (16, (40,)), (32, (6, 5))])
+@pytest.mark.parametrize("flags", [0, 3])
+def test_kspace_coupled_beyond_the_register_kernel(nv, shape, flags):
+    """9 ... 32 variables (the reference solves any N, AdamsBashforthMoultonCoupled.C:183): the workspace form against linalg_solve"""
+    dom, ctx, u0, N, coef, L = _problem(nv, shape, 5 * nv + flags)
+    dt = 0.21
+    want = _oracle(dom, u0, N, coef, L, dt, real_rhs=not (flags & 2), transposed=not (flags & 1))
+    dev = lambda t: None if t is None else t.cuda().contiguous()
+    out = [torch.empty(dom.rshape, dtype=torch.complex128, device="cuda") for _ in range(nv)]
+    ctx.kspace_coupled(out, [dev(t) for t in u0], [[dev(t) for t in row] for row in N], coef,
+                       [[dev(t) for t in row] for row in L], dt, flags)
+    for i in range(nv):
+        w = want[i] if want[i].is_complex() else want[i].to(torch.complex128)
+        assert (out[i].cpu() - w).abs().max().item() <= 1e-12 * max(1.0, w.abs().max().item())
+
+
+@pytest.mark.parametrize("nv,shape", [(2, (300, 290)), (5, (33, 31)), (8, (20, 19))])
+def test_kspace_coupled_workspace_form_equals_the_register_kernel_bit_for_bit(nv, shape):
+    """same elimination, operation for operation: flag 4 (MRL_COUPLED_GENERAL) forces the workspace form at any size; the first shape
+    has more k-points than workspace lanes (65536), so lanes are reused"""
+    dom, ctx, u0, N, coef, L = _problem(nv, shape, 100 + nv)
+    dev = lambda t: None if t is None else t.cuda().contiguous()
+    args = ([dev(t) for t in u0], [[dev(t) for t in row] for row in N], coef, [[dev(t) for t in row] for row in L], 0.4)
+    a = [torch.empty(dom.rshape, dtype=torch.complex128, device="cuda") for _ in range(nv)]
+    b = [torch.empty(dom.rshape, dtype=torch.complex128, device="cuda") for _ in range(nv)]
+    ctx.kspace_coupled(a, *args, 2)
+    ctx.kspace_coupled(b, *args, 2 | 4)
+    for x, y in zip(a, b):
+        assert torch.equal(torch.view_as_real(x), torch.view_as_real(y))
+
+
 def test_kspace_coupled_rejects_bad_arguments():
     from marlin_amd.api import Context, MarlinHipError
     ctx = Context(1, [16], [1.0])
     t = torch.zeros(9, dtype=torch.complex128, device="cuda")
     with pytest.raises(MarlinHipError):
-        ctx.kspace_coupled([t] * 9, [t] * 9, [[]] * 9, [[]] * 9, [[None] * 9] * 9, 1.0)
+        ctx.kspace_coupled([t] * 33, [t] * 33, [[]] * 33, [[]] * 33, [[None] * 33] * 33, 1.0)

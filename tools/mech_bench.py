@@ -2,7 +2,7 @@
 """de Geus RVE benchmark (BASELINE.json configs[2]): 3-D n^3, cubic inclusion
 phase[-s:, :s, -s:] = 1 with s = 9n/32 (test/src/tensor_computes/PhaseMechanicsTest.C:36-45), K = 0.833/8.33,
 mu = 0.386/3.86 (examples/degeus_mechanics/mech.i:23-38), shear ramp, l_tol = 1e-2, nl tolerances 2e-2.
-Reports time per CG iteration and the per-kernel device times.   usage: mech_bench.py [n] [substeps] [slab 0|1] [experiment mask]
+Reports time per CG iteration and the per-kernel device times.   usage: mech_bench.py [n] [substeps] [slab 0|1] [experiment mask] [profile 0|1]
 slab = 1: the same solve as a ONE-rank slab job through the library's row pipeline (communicator, flags, exchange tables)."""
 import json
 import os
@@ -84,7 +84,8 @@ def main():
     substeps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     slab = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
     exp = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-    print(json.dumps(run(n, substeps, slab=slab, exp=exp)))
+    profile = bool(int(sys.argv[5])) if len(sys.argv) > 5 else True   # 0: no event-timed second half (for timeline traces)
+    print(json.dumps(run(n, substeps, profile=profile, slab=slab, exp=exp)))
 
 
 if __name__ == "__main__":
