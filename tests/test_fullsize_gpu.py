@@ -310,6 +310,50 @@ def test_config_e_256_operator_applications_vs_oracle():
     ctx.close()
 
 
+def test_config_e_256_newton_cg_vs_oracle_through_periodicity():
+    """BASELINE configs[4]'s grid (256^3 mechanics) through a whole Newton-CG solve against the ORACLE: the RVE is 4 x 4 x 4 copies of a
+    64^3 cell (same dx), so the solution is the oracle's 64^3 solution tiled, with the same Newton / CG iteration counts (every norm of
+    the big problem is 8 x the cell's on both sides of each relative test; the absolute Newton tolerance is switched off because it is
+    not scale-free).  F and P to 1e-10."""
+    from marlin_amd.api import Context
+    from oracle import marlin_oracle as mo
+    cell, reps = 64, 4
+    n = cell * reps
+    dx = 2 * math.pi / cell
+    dom = mo.Domain(3, [cell] * 3, [cell * dx] * 3)
+    s = 9 * cell // 32
+    phase = torch.zeros([cell] * 3, dtype=torch.float64)
+    phase[-s:, :s, -s:] = 1.0
+    K = (1.0 - phase) * 0.833 + phase * 8.33
+    mu = (1.0 - phase) * 0.386 + phase * 3.86
+    ref = mo.FFTMechanicsOracle.__new__(mo.FFTMechanicsOracle)
+    ref.dom, ref.ids, ref.K, ref.mu = dom, mo.MechIdentities(3), K, mu
+    ref.l_tol, ref.nl_rel_tol, ref.nl_abs_tol, ref.l_max_its, ref.nl_max_its = 1e-2, 2e-2, 0.0, cell ** 3, 100
+    ref.r2_shape, ref.P, ref.K4 = dom.value_shape([3, 3]), None, None
+    ref.G = lambda A2: mo.gamma_closed_form(dom, A2.reshape(ref.r2_shape)).reshape(-1)
+    F0 = torch.eye(3, dtype=torch.float64).expand(dom.value_shape([3, 3])).contiguous()
+    applied = torch.eye(3, dtype=torch.float64)
+    applied[0, 1] += 0.001
+    applied = applied - dom.average(F0)
+    Fref, rst = ref.compute(F0, applied)
+    Pref = ref.P
+    ctx = Context(3, [n] * 3, [n * dx] * 3)
+    tile = lambda t: t.cuda().repeat(reps, reps, reps, *([1] * (t.dim() - 3)))
+    Fg, Pg, st = ctx.mech_newton_cg(tile(F0), tile(K), tile(mu), applied.cuda(), l_tol=1e-2, nl_rel_tol=2e-2, nl_abs_tol=0.0)
+    assert st["newton_its"] == rst.newton_its and list(st["cg_its"]) == list(rst.cg_its)
+    Fw, Pw = Fref.cuda(), Pref.reshape(Fref.shape).cuda()
+    worst_F = worst_P = 0.0
+    for i in range(reps):
+        for j in range(reps):
+            for k in range(reps):
+                blk = (slice(i * cell, (i + 1) * cell), slice(j * cell, (j + 1) * cell), slice(k * cell, (k + 1) * cell))
+                worst_F = max(worst_F, (Fg[blk] - Fw).abs().max().item())
+                worst_P = max(worst_P, (Pg[blk] - Pw).abs().max().item())
+    assert worst_F <= 1e-10 and worst_P <= 1e-10 * max(1.0, Pw.abs().max().item()), (worst_F, worst_P)
+    assert (Fg[..., 0, 1] - 0.001).abs().max().item() > 1e-5      # the inclusion really deforms the field
+    ctx.close()
+
+
 def test_arrays_beyond_4_gib_stay_on_the_fused_path():
     """1024 x 512 x 1024 (4.3 GB per half-spectrum array): the fused x pass takes its 64-bit-offset variant instead of falling to the
     any-length path (round 1: silently 3x slower).  The oracle cannot reach this size in test time, so parity is against the
@@ -347,3 +391,41 @@ def test_arrays_beyond_4_gib_stay_on_the_fused_path():
     ctx.sync()
     names = {k["kernel"] for k in ctx.get_profile() if k["launches"]}
     assert "ch_C_x_fused" in names, names
+
+def test_arrays_beyond_4_gib_vs_oracle_through_periodicity():
+    """The same 1024 x 512 x 1024 grid against the ORACLE (not only against the library's own other path): the initial
+    field repeats 32 times along x, so the solution of the big grid IS the oracle's solution of one 32 x 512 x 1024 period (same dx, every
+    wave number of the small grid is one of the big grid's, powers of two in every scale factor), tiled.  A 32-bit offset that wrapped
+    inside the 4.3 GB spectral arrays would land 2^28 complex elements = 1021.99 x planes away -- on another (y, kz) -- and break the
+    tiling.  AB1 + AB2, fields to 1e-13."""
+    from bench import splitmix64_uniform
+    from marlin_amd.api import Context, ch_params
+    import oracle.marlin_oracle as mo
+    period, reps = 32, 32
+    small = [period, 512, 1024]
+    shape = [period * reps, 512, 1024]
+    dx = 8.0 * math.pi / 200.0
+    s0 = torch.from_numpy(splitmix64_uniform(small[0] * small[1] * small[2], seed=5).reshape(small))
+    dom = mo.Domain(3, small, [n * dx for n in small])
+    Mbar = mo.reciprocal_laplacian_factor(dom, 0.2)
+    Lbar = mo.reciprocal_laplacian_square_factor(dom, -0.001)
+    r1, N1, _, _ = mo.ch_substep_ops(s0, Mbar, Lbar, [], 1e-3, 0, mo.mu_double_well, dom)
+    r2, _, _, _ = mo.ch_substep_ops(r1, Mbar, Lbar, [N1], 1e-3, 1, mo.mu_double_well, dom)
+    del Mbar, Lbar, N1
+    c0 = s0.cuda().repeat(reps, 1, 1)
+    ctx = Context(3, shape, [n * dx for n in shape])
+    p = ch_params()
+    N0, Nn = ctx.empty_hist(), ctx.empty_hist()
+    a, b = torch.empty_like(c0), torch.empty_like(c0)
+    ctx.ch_substep(p, c0, a, N0, [], 0, 1e-3)
+    ctx.ch_substep(p, a, b, Nn, [N0], 1, 1e-3)
+    ctx.sync()
+    del N0, Nn, c0
+    for got, want in ((a, r1), (b, r2)):
+        w = want.cuda()
+        worst = max((got[i * period:(i + 1) * period] - w).abs().max().item() for i in range(reps))
+        assert worst <= 1e-13, worst
+    # the result is not trivially the input
+    assert (b[:period] - s0.cuda()).abs().max().item() > 1e-6
+    ctx.close()
+
