@@ -843,11 +843,16 @@ def main():
         a32, b32 = ic.float().cuda(), torch.empty(shape, dtype=torch.float32, device="cuda")
         h32, n32 = ctx.ch_substeps_f32(p, a32, b32, ring32, 1, 0, 2, 3, True, sub_dt)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ctx.ch_substeps_f32(p, b32, a32, ring32, (h32 + 1) % 2, 1, 2, k, True, sub_dt)
-        torch.cuda.synchronize()
-        ms32 = (time.perf_counter() - t0) / k * 1e3
-        variants["fp32"] = {"ms_per_step": ms32, "dtype": "f32", "substeps_per_library_call": k,
+        # the headline's timing protocol (median of repeated regions): the first region over freshly allocated arrays reads 10 % slow
+        reps32 = []
+        for _ in range(max(1, min(args.repeats, 5))):
+            t0 = time.perf_counter()
+            h32, n32 = ctx.ch_substeps_f32(p, b32, a32, ring32, (h32 + 1) % 2, 1, 2, k, True, sub_dt)
+            torch.cuda.synchronize()
+            reps32.append((time.perf_counter() - t0) / k * 1e3)
+        ms32 = sorted(reps32)[len(reps32) // 2]
+        variants["fp32"] = {"ms_per_step": ms32, "repeats_ms": [round(x, 5) for x in reps32], "dtype": "f32", "substeps_per_library_call": k,
+                            "algorithmic_GBps": 14 * 8.0 * (shape[0] * shape[1] * (shape[2] // 2 + 1)) / ms32 * 1e-6,
                             "note": "mrl_ch_substeps_f32: the kernels of the fp64 path instantiated for float; parity vs the oracle run in "
                                     "float32: tests/test_ch_f32_gpu.py (2e-6); never the headline"}
         del ring32, a32, b32

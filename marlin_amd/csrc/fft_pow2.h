@@ -67,7 +67,9 @@ struct Plan;
 MRL_PLAN(32, 16, 16, 2, 1, 1, 128)
 // (fp32 instantiation, ch_fused_f32.hip: the same plans.  Round 4 tried the two ways to 256-byte pieces per line element for 8-byte
 // complex values -- 32 points per thread: the fused kernels spill 50-110 VGPRs; twice the lines per tile with 512-thread workgroups: no
-// spills, but one workgroup per CU in lockstep: 0.205-0.209 ms per 256^3 substep against 0.193-0.198 ms with these plans.  Kept as is.)
+// spills, but one workgroup per CU in lockstep: 0.205-0.209 ms per 256^3 substep against 0.193-0.198 ms with these plans (first-region
+// figures; steady state 0.174-0.176 ms).  A register budget of three waves per SIMD for the float x-fused kernel (176 -> 168 VGPRs, 11-25
+// spilled): 0.186 against 0.174-0.176 ms in interleaved runs.  Kept as is.)
 MRL_PLAN(64, 16, 8, 8, 1, 1, 64)
 MRL_PLAN(128, 16, 16, 8, 1, 1, 32)
 MRL_PLAN(256, 16, 16, 16, 1, 1, 16)
