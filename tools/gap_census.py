@@ -39,6 +39,14 @@ def main():
             small += g
     print(f"{len(rows)} dispatches, span {span * 1e-6:.2f} ms, kernels busy {busy * 1e-6:.2f} ms ({busy / span:.1%}); "
           f"gaps below {min_gap:g} us: {small * 1e-3:.2f} ms in all")
+    per = collections.defaultdict(lambda: [0, 0.0])
+    for s0, e0, k0 in rows:
+        per[k0][0] += 1
+        per[k0][1] += (e0 - s0) * 1e-3
+    print(f"{'kernel':60s} {'count':>6s} {'total ms':>9s} {'avg us':>8s}")
+    for k0, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:30]:
+        print(f"{k0:60s} {c:6d} {t * 1e-3:9.3f} {t / c:8.1f}")
+    print()
     print(f"{'previous kernel -> next kernel':100s} {'count':>6s} {'total ms':>9s} {'avg us':>8s}")
     for (k0, k1), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"{(k0 + ' -> ' + k1):100s} {c:6d} {t * 1e-3:9.3f} {t / c:8.1f}")
