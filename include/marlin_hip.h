@@ -74,7 +74,8 @@ typedef struct mrl_domain {
                                     over py, ky over pz, kz is complete.  mrl_fft_r2c / mrl_fft_c2r are DomainAction::fftPencil /
                                     ifftPencil (:1021-1047) with their four staged exchanges (:1105-1404) owned by the library;
                                     reductions are global, pointwise entry points (mrl_parsed_*, mrl_axpby, ...) work on the local
-                                    blocks; the fused solver entry points (mrl_ch_substep(s), mrl_mech_*) return MRL_ERR_UNSUPPORTED */
+                                    blocks; mrl_ch_substep(s) run as the reference's operator sequence over these transforms
+                                    (unfused); the mechanics entry points (mrl_mech_*, mrl_gamma_apply) return MRL_ERR_UNSUPPORTED */
 
 /* ---- context ------------------------------------------------------------------------ */
 int mrl_abi_version(void);

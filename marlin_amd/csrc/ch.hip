@@ -417,7 +417,6 @@ int mrl_ch_mu(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c, double *d
 int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, double *d_c_out, double *d_Nhat_new,
                    const double *const *d_Nhat_old, int order, double sub_dt, double *d_cbar, double *d_mu, int carry) {
   if (!ctx) return MRL_ERR_INVALID;
-  MRL_NO_PENCIL(ctx, "mrl_ch_substep");
   ChP cp;
   MRL_TRY(ch_check_params(ctx, p, cp));
   if (!d_c_in || !d_c_out || !d_Nhat_new) return set_error(ctx, MRL_ERR_INVALID, "mrl_ch_substep: null buffer");
@@ -465,16 +464,25 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
   // carry-over: MRL_CARRY_IN reads c-hat from d_cbar (no transform of c) and both carry modes leave ubar there
   double *cbar = (d_cbar && carry != MRL_CARRY_OUT) ? d_cbar : ctx->d_work[2];
   double *ubar = carry == MRL_CARRY_NONE ? ctx->d_work[2] : d_cbar;
-  MRL_TRY(fft_forward_serial(ctx, mu, mubar, 1, 0));
-  if (carry != MRL_CARRY_IN) MRL_TRY(fft_forward_serial(ctx, d_c_in, cbar, 1, 0));
+  // pencil contexts (parallel_mode = FFT_PENCIL): the same operator sequence over the staged pencil transforms -- in the reference
+  // every solver reaches the decomposition only through DomainAction::fft / ifft (AdamsBashforthMoulton.C:88-101); the k-space
+  // kernel works on this rank's reciprocal block with its own slices of the reciprocal axes (ctx->nrec, ctx->d_k)
+  auto forward = [ctx](const double *in, double *out) {
+    return ctx->pencil ? pencil_fft_forward(ctx, in, out, 1) : fft_forward_serial(ctx, in, out, 1, 0);
+  };
+  auto inverse = [ctx](const double *in, double *out) {
+    return ctx->pencil ? pencil_fft_inverse(ctx, in, out, 1) : fft_inverse_serial(ctx, in, out, 1, 0);
+  };
+  MRL_TRY(forward(mu, mubar));
+  if (carry != MRL_CARRY_IN) MRL_TRY(forward(d_c_in, cbar));
   {
     ProfScope ps(ctx, "ch_kspace", 16.0 * (double)nspec * (4 + order));
     MRL_TRY(ch_kspace_launch(ctx, cp, cbar, mubar, d_Nhat_new, ubar, d_Nhat_old, order, sub_dt));  // elementwise: ubar may alias cbar
   }
-  if (carry == MRL_CARRY_NONE) return fft_inverse_serial(ctx, ubar, d_c_out, 1, 0);
+  if (carry == MRL_CARRY_NONE) return inverse(ubar, d_c_out);
   // the inverse transform may overwrite its input: run it on a copy so that d_cbar keeps ubar
   MRL_HIP(ctx, hipMemcpyAsync(mubar, ubar, sizeof(cplx) * nspec, hipMemcpyDeviceToDevice, ctx->stream));
-  return fft_inverse_serial(ctx, mubar, d_c_out, 1, 0);
+  return inverse(mubar, d_c_out);
 }
 
 int mrl_reciprocal_laplacian(mrl_ctx *ctx, int power, double factor, double *d_out) {
@@ -607,7 +615,6 @@ int mrl_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, 
                     int ring_size, int *head, int *n_old, int predictor_order, int count, int advance, double sub_dt,
                     double *d_mu) {
   if (!ctx) return MRL_ERR_INVALID;
-  MRL_NO_PENCIL(ctx, "mrl_ch_substeps");
   ChP cp;
   MRL_TRY(ch_check_params(ctx, p, cp));
   const int pred = predictor_order - 1;

@@ -274,5 +274,7 @@ int component_sums_async(mrl_ctx *ctx, const double *a, long long npts, int ncom
 // serial transforms (fft_plan.hip)
 int fft_forward_serial(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch, int layout);
 int fft_inverse_serial(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch, int layout);
+int pencil_fft_forward(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);   // slab_driver.hip (pencil contexts)
+int pencil_fft_inverse(mrl_ctx *ctx, const double *d_in, double *d_out, long long batch);
 
 }  // namespace mrl

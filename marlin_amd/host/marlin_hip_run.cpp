@@ -68,21 +68,25 @@ static std::vector<double> read_bin(const std::string & path, std::size_t count)
   return v;
 }
 
-// the rank's block [nx][y_begin .. y_begin + ny_local)[nz] of a global row-major field (parallel_mode NONE: the field itself)
+// the rank's block of a global row-major field: [nx][y_begin .. y_end)[nz] in FFT_SLAB mode, [nx][y_begin .. y_end)[z_begin .. z_end) in
+// FFT_PENCIL mode (parallel_mode NONE: the field itself)
 static std::vector<double> local_block(const DomainAction & domain, const std::vector<double> & global, int ncomp = 1)
 {
-  if (!domain.isSlab())
+  if (!domain.isSlab() && !domain.isPencil())
     return global;
   const auto & g = domain.getShape();
   const auto & l = domain.getLocalShape();
   const auto & b = domain.getLocalBegin();
   const int dim = domain.getDim();
-  const int64_t nx = g[0], ny = g[1], nz = dim == 3 ? g[2] : 1, nyl = l[1];
-  std::vector<double> out((std::size_t)(nx * nyl * nz * ncomp));
-  for (int64_t i = 0; i < nx; ++i)
-    for (int64_t j = 0; j < nyl; ++j)
-      std::copy(global.begin() + ((i * ny + b[1] + j) * nz) * ncomp, global.begin() + ((i * ny + b[1] + j + 1) * nz) * ncomp,
-                out.begin() + ((i * nyl + j) * nz) * ncomp);
+  const int64_t ny = g[1], nz = dim == 3 ? g[2] : 1;
+  const int64_t lx = l[0], ly = l[1], lz = dim == 3 ? l[2] : 1, b0 = b[0], b1 = b[1], b2 = dim == 3 ? b[2] : 0;
+  std::vector<double> out((std::size_t)(lx * ly * lz * ncomp));
+  for (int64_t i = 0; i < lx; ++i)
+    for (int64_t j = 0; j < ly; ++j)
+    {
+      const auto first = global.begin() + (((b0 + i) * ny + b1 + j) * nz + b2) * ncomp;
+      std::copy(first, first + lz * ncomp, out.begin() + ((i * ly + j) * lz) * ncomp);
+    }
   return out;
 }
 

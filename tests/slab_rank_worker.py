@@ -291,17 +291,41 @@ def run_pencil(job, P, r, kv):
     errs.append((back2.cpu() - ref2).abs().max().item() / max(ref2.abs().max().item(), 1e-300))
     tot = ctx.sum(loc)
     errs.append(abs(tot - g.sum().item()) / g.sum().item())
-    # the fused solver entry points refuse pencil contexts
+    # the mechanics entry points refuse pencil contexts (the reference's mechanics norms are serial-only, DomainAction.C:1564-1567)
     refused = False
     try:
-        ctx.ch_substep(api.ch_params(), loc, torch.empty_like(loc), torch.zeros(2 * spec.numel(), dtype=torch.float64, device="cuda"), [], 0, 1e-3)
+        ctx.gamma_apply(torch.zeros(ctx.real_shape + [3, 3], dtype=torch.float64, device="cuda"))
     except api.MarlinHipError as e:
         refused = e.code == -2
+    # Cahn-Hilliard substeps on the pencil context (the operator sequence of AdamsBashforthMoulton.C:88-101 over the staged transforms)
+    # against the oracle's serial solution of the global field: AB1 + AB2 + AB2 through mrl_ch_substeps, then one mrl_ch_substep
+    dser = mo.Domain(3, shape, L)
+    c0 = 0.44 + 0.12 * g
+    Mbar = mo.reciprocal_laplacian_factor(dser, 0.2)
+    Lbar = mo.reciprocal_laplacian_square_factor(dser, -0.001)
+    want, hist = c0, []
+    for k in range(4):
+        want, Nn, _, _ = mo.ch_substep_ops(want, Mbar, Lbar, hist[:1], 1e-3, min(k, 1), mo.mu_double_well, dser)
+        hist = [Nn]
+        if k == 2:
+            want3 = want
+    p = api.ch_params()
+    ring = [torch.zeros(2 * spec.numel(), dtype=torch.float64, device="cuda") for _ in range(2)]
+    cl = dom.split(c0)[r].cuda()
+    out3 = torch.empty_like(cl)
+    head, n_old = ctx.ch_substeps(p, cl, out3, ring, 1, 0, 2, 3, True, 1e-3)
+    ctx.sync()
+    ch_err = (out3.cpu() - dom.split(want3)[r]).abs().max().item()
+    head = (head + 1) % 2                       # advance_state: the newest N-hat becomes old[0]
+    out4 = torch.empty_like(cl)
+    ctx.ch_substep(p, out3, out4, ring[(head + 1) % 2], [ring[head]], 1, 1e-3)
+    ctx.sync()
+    ch_err = max(ch_err, (out4.cpu() - dom.split(want)[r]).abs().max().item())
     st = comm.stats()
     ctx.close()
     comm.close()
     return {"max_err": max(errs), "errs": errs, "layout_ok": layout_ok, "axes_ok": axes_ok, "refused": refused, "stats": st,
-            "grid": [dom.Py, dom.Pz]}
+            "grid": [dom.Py, dom.Pz], "ch_err": ch_err}
 
 
 def run_mech(job, P, r, kv):

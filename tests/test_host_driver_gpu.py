@@ -498,6 +498,21 @@ def test_gradient_case_fft_pencil(tmp_path):
     assert 0.0 <= got2[1, 1] <= 1e-10
 
 
+def test_cahnhilliard_case_fft_pencil(tmp_path):
+    """cahnhilliard.i's solver block with parallel_mode = FFT_PENCIL (every solver of the reference reaches the decomposition only
+    through DomainAction::fft / ifft): 3 steps of 4 AB2 substeps on a 40 x 36 x 30 box on FOUR rank processes (2 x 2 pencils) through the
+    C++ driver -- AdamsBashforthMoulton over mrl_ch_substeps on pencil contexts, the operator sequence over the staged transforms --
+    against the serial run of the same input through the global checksums sum(c), sum(c^2) (1e-12 relative)"""
+    import json
+    common = ["problem=cahnhilliard", "dim=3", "nx=40", "ny=36", "nz=30", "xmax=5.0", "ymax=4.5", "zmax=3.75", "ic=splitmix64",
+              "substeps=4", "num_steps=3", "dt=4e-3", "predictor_order=2", "mobility=0.2", "kappa=-0.001", "output=none"]
+    par = json.loads(_run(common + ["parallel_mode=FFT_PENCIL", "nranks=4", "device=0"], tmp_path).strip().splitlines()[-1])
+    ser = json.loads(_run(common, tmp_path).strip().splitlines()[-1])
+    assert abs(par["sum_c"] - ser["sum_c"]) <= 1e-12 * abs(ser["sum_c"]), (par, ser)
+    assert abs(par["sum_c2"] - ser["sum_c2"]) <= 1e-12 * abs(ser["sum_c2"]), (par, ser)
+    assert abs(ser["sum_c2"] / (40 * 36 * 30) - 0.25) < 5e-3 and par["time"] == ser["time"]
+
+
 def test_gradient_square_case(tmp_path):
     """test/tests/gradient/tests (gradient_square.i): FFTGradientSquare of sin(x)+sin(y)+sin(z) vs cos^2 sums; the gold
     value is integrated round-off (6.9e-12)"""

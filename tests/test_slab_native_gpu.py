@@ -232,13 +232,16 @@ def test_native_pencil_transforms_vs_oracle(P, shape, transport):
     PROCESSES sharing this box's GPU: mrl_fft_r2c / mrl_fft_c2r with the four staged exchanges owned by the library against the oracle's
     restatement of the reference's stages and the serial transform of the global array (2e-15 x n relative), the round trip (1e-14,
     64^3 included), an inverse transform of a non-Hermitian spectrum (irfft semantics), block shapes / begins / reciprocal axes of
-    partitionPencils bit for bit, global reductions, and MRL_ERR_UNSUPPORTED from the fused solver entry points.  (At most four rank
+    partitionPencils bit for bit, global reductions, MRL_ERR_UNSUPPORTED from the mechanics entry points, and four Cahn-Hilliard
+    substeps (mrl_ch_substeps x 3 + mrl_ch_substep: the operator sequence over the staged transforms) against the oracle's serial
+    solution of the global field, 1e-13.  (At most four rank
     processes: this process holds the GPU too and a box admits six; the 2 x 3 and 2 x 4 process grids are covered by the oracle-level
     CPU tests, tests/test_pencil_cpu.py.)"""
     res = run_job(P, "pencil", f"shape={shape}", f"transport={transport}")
     n = max(int(x) for x in shape.split(","))
     assert all(r["layout_ok"] and r["axes_ok"] and r["refused"] for r in res), res
     assert max(r["max_err"] for r in res) <= 2e-15 * n, res
+    assert max(r["ch_err"] for r in res) <= 1e-13, res
     assert all(r["stats"]["exchanges"] > 0 and r["stats"]["bytes_sent"] > 0 for r in res)
 
 
