@@ -94,7 +94,7 @@ def ch_params(family=FE_DOUBLE_WELL, coef=(0.1,), mobility=0.2, kappa=-0.001, pa
 
 TRANSPORT_AUTO, TRANSPORT_PEER_STORE, TRANSPORT_PEER_COPY, TRANSPORT_RCCL = 0, 1, 2, 3
 TRANSPORT_NAMES = {1: "peer_store", 2: "peer_copy", 3: "rccl"}
-OPT_EXPERIMENT, OPT_SLAB_NSUB, OPT_SLAB_CARRY, OPT_VERIFY_EXCHANGE, OPT_VERIFY_MISMATCHES = 0, 1, 2, 3, 4
+OPT_EXPERIMENT, OPT_SLAB_NSUB, OPT_SLAB_CARRY, OPT_VERIFY_EXCHANGE, OPT_VERIFY_MISMATCHES, OPT_CACHE_CHUNK_MB = 0, 1, 2, 3, 4, 5
 
 
 class Comm:

@@ -332,30 +332,67 @@ int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c
   p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
   const double h = 16.0 * nspec;
   const double scale = 1.0 / ((double)nx * (double)ny * (double)nz);
+  // Infinity-Cache-sized chunks of x planes (round 4, MRL_OPT_CACHE_CHUNK_MB; OFF by default).  Between the x-fused pass of one substep
+  // and that of the next every pass works plane by plane -- inverse y, fused inverse + forward z, forward y -- so they can run chunk
+  // after chunk, a chunk's c-hat and mu-hat planes being written by one pass and read by the next while they are still in the 256 MiB
+  // cache (DRAM traffic per substep 14 h -> 8 h for arrays beyond the cache).  Same kernels on the same data in another order:
+  // bit-identical fields.  Measured (tools/chunk_sweep.py, 512^3, one box): unchunked 2.885 ms, chunks of 32 / 64 / 96 / 128 / 160 /
+  // 192 MB: 4.14 / 3.10 / 3.30 / 2.98 / 3.02 / 2.86 ms -- an in-cache stream is only ~25 % faster than a DRAM one (6.8 against 5.3-5.5
+  // TB/s, tools/mall_probe.hip) and launches of 700-1400 workgroups on 512-1024 slots lose more than that in their last partial wave;
+  // 256^3: 0.305 -> 0.34-0.43 ms.  Kept as an option for A/B runs on other parts, not used by default.
+  long long xchunk = 0;
+  if (ctx->opt_chunk_mb > 0 && ny > 1) {
+    xchunk = (long long)((double)ctx->opt_chunk_mb * 1048576.0 / (2.0 * 16.0 * (double)plane));
+    if (xchunk < 1) xchunk = 1;
+    if ((xchunk * ny) % 2) xchunk += 1;   // the z kernels take line PAIRS
+    if (xchunk >= nx) xchunk = 0;
+  }
+  auto launch_ea = [&](long long x0, long long x1, double *mu_k) -> int {   // fused inverse + forward z pass of the x planes [x0, x1)
+    cplx *c = w_c + x0 * plane, *m = w_mu + x0 * plane;
+    double *mk = mu_k ? mu_k + x0 * ny * nz : nullptr;
+    const long long pairs = (x1 - x0) * ny / 2;
+    ProfScope ps(ctx, "ch_EA_z_inv_fwd", (3.0 * h + (mu_k ? 8.0 * nreal : 0.0)) * (double)(x1 - x0) / (double)nx);
+    if (cp.family == MRL_FE_PARSED) {
+      MRL_TRY(parsed_z_inv_fwd_launch(ctx, cp.parsed, (int)nz, c, c, m, mk, scale, pairs, false, lpp, lpad));
+    } else if (cp.family == MRL_FE_DOUBLE_WELL) {
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_DOUBLE_WELL>(ctx, c, c, m, mk, chp, scale, pairs, g.zl))));
+    } else {
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_PFHUB>(ctx, c, c, m, mk, chp, scale, pairs, g.zl))));
+    }
+    return MRL_OK;
+  };
+  auto launch_b = [&](long long x0, long long x1) -> int {
+    ProfScope ps(ctx, "ch_B_y_fwd", 4.0 * h * (double)(x1 - x0) / (double)nx);
+    return pass_axis(ctx, 1, false, 2, w_c, w_mu, w_c, w_mu, true, x0, x1, plane);
+  };
+  auto launch_d = [&](long long x0, long long x1) -> int {
+    ProfScope ps(ctx, "ch_D_y_inv", 2.0 * h * (double)(x1 - x0) / (double)nx);
+    return pass_axis(ctx, 1, true, 1, w_c, nullptr, w_c, nullptr, false, x0, x1, plane);
+  };
   for (int k = 0; k < count; ++k) {
     double *mu_k = (k == count - 1) ? mu : nullptr;   // the buffer `mu` holds f'(c) of the last substep's input field
     if (k == 0) {
-      ProfScope ps(ctx, "ch_A_z_fwd", 8.0 * nreal + 2.0 * h + (mu_k ? 8.0 * nreal : 0.0));
-      if (cp.family == MRL_FE_PARSED) {
-        MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 1, c_in, w_c, w_mu, mu_k, nx * ny, lpp, lpad));
-      } else if (cp.family == MRL_FE_DOUBLE_WELL) {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_c, w_mu, mu_k, chp, nx * ny, g.zl))));
-      } else {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, w_c, w_mu, mu_k, chp, nx * ny, g.zl))));
+      {
+        ProfScope ps(ctx, "ch_A_z_fwd", 8.0 * nreal + 2.0 * h + (mu_k ? 8.0 * nreal : 0.0));
+        if (cp.family == MRL_FE_PARSED) {
+          MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)nz, 1, c_in, w_c, w_mu, mu_k, nx * ny, lpp, lpad));
+        } else if (cp.family == MRL_FE_DOUBLE_WELL) {
+          MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, c_in, w_c, w_mu, mu_k, chp, nx * ny, g.zl))));
+        } else {
+          MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_fwd<NN, 1, MRL_FE_PFHUB>(ctx, c_in, w_c, w_mu, mu_k, chp, nx * ny, g.zl))));
+        }
+      }
+      MRL_TRY(launch_b(0, nx));
+    } else if (xchunk) {
+      for (long long x0 = 0; x0 < nx; x0 += xchunk) {   // D of substep k - 1, then EA and B of substep k, chunk after chunk
+        const long long x1 = x0 + xchunk < nx ? x0 + xchunk : nx;
+        MRL_TRY(launch_d(x0, x1));
+        MRL_TRY(launch_ea(x0, x1, mu_k));
+        MRL_TRY(launch_b(x0, x1));
       }
     } else {
-      ProfScope ps(ctx, "ch_EA_z_inv_fwd", 3.0 * h + (mu_k ? 8.0 * nreal : 0.0));
-      if (cp.family == MRL_FE_PARSED) {
-        MRL_TRY(parsed_z_inv_fwd_launch(ctx, cp.parsed, (int)nz, w_c, w_c, w_mu, mu_k, scale, nx * ny / 2, false, lpp, lpad));
-      } else if (cp.family == MRL_FE_DOUBLE_WELL) {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_DOUBLE_WELL>(ctx, w_c, w_c, w_mu, mu_k, chp, scale, nx * ny / 2, g.zl))));
-      } else {
-        MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_PFHUB>(ctx, w_c, w_c, w_mu, mu_k, chp, scale, nx * ny / 2, g.zl))));
-      }
-    }
-    {
-      ProfScope ps(ctx, "ch_B_y_fwd", 4.0 * h);
-      MRL_TRY(pass_axis(ctx, 1, false, 2, w_c, w_mu, w_c, w_mu, true, 0, -1, plane));
+      MRL_TRY(launch_ea(0, nx, mu_k));
+      MRL_TRY(launch_b(0, nx));
     }
     const int order = (dt_changed && k < pred) ? 0 : (*n_old < pred ? *n_old : pred);   // AdamsBashforthMoulton.C:90-91
     const int slot_new = (*head + 1) % ring_size;
@@ -385,14 +422,20 @@ int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c
         default: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 4, false>(ctx, a, g.tw_x)))); break;
       }
     }
-    {
-      ProfScope ps(ctx, "ch_D_y_inv", 2.0 * h);
-      MRL_TRY(pass_axis(ctx, 1, true, 1, w_c, nullptr, w_c, nullptr, false, 0, -1, plane));
-    }
+    if (!xchunk) MRL_TRY(launch_d(0, nx));   // (chunked schedule: it runs in front of the next substep's z pass, or of the final one below)
     if (advance && k < count - 1) {   // TensorSolver.C:105-106
       *head = slot_new;
       if (*n_old < pred) *n_old += 1;
     }
+  }
+  if (xchunk) {   // the last substep's inverse y pass and the final inverse z pass, chunk after chunk
+    for (long long x0 = 0; x0 < nx; x0 += xchunk) {
+      const long long x1 = x0 + xchunk < nx ? x0 + xchunk : nx;
+      MRL_TRY(launch_d(x0, x1));
+      ProfScope ps(ctx, "ch_E_z_inv", (h + 8.0 * nreal) * (double)(x1 - x0) / (double)nx);
+      MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w_c + x0 * plane, c_out + x0 * ny * nz, scale, (x1 - x0) * ny / 2, g.zl))));
+    }
+    return MRL_OK;
   }
   ProfScope ps(ctx, "ch_E_z_inv", h + 8.0 * nreal);
   MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv<NN>(ctx, w_c, c_out, scale, nx * ny / 2, g.zl))));

@@ -601,6 +601,10 @@ int mrl_ctx_set_option(mrl_ctx *ctx, int option, int64_t value) {
       ctx->opt_nsub = (int)value;
       return MRL_OK;
     case MRL_OPT_SLAB_CARRY: ctx->opt_carry = value != 0; return MRL_OK;
+    case MRL_OPT_CACHE_CHUNK_MB:
+      if (value < 0 || value > 1024) return set_error(ctx, MRL_ERR_INVALID, "MRL_OPT_CACHE_CHUNK_MB must be 0 (off) or 1..1024");
+      ctx->opt_chunk_mb = (int)value;
+      return MRL_OK;
     case MRL_OPT_VERIFY_EXCHANGE: ctx->opt_verify = value != 0; return MRL_OK;
     case MRL_OPT_VERIFY_MISMATCHES:  // (only 0 may be stored: resets the counter)
       if (value != 0) return set_error(ctx, MRL_ERR_INVALID, "MRL_OPT_VERIFY_MISMATCHES can only be reset to 0");
@@ -615,6 +619,7 @@ int64_t mrl_ctx_get_option(const mrl_ctx *ctx, int option) {
     case MRL_OPT_EXPERIMENT: return ctx->exp;
     case MRL_OPT_SLAB_NSUB: return ctx->opt_nsub;
     case MRL_OPT_SLAB_CARRY: return ctx->opt_carry;
+    case MRL_OPT_CACHE_CHUNK_MB: return ctx->opt_chunk_mb;
     case MRL_OPT_VERIFY_EXCHANGE: return ctx->opt_verify;
     case MRL_OPT_VERIFY_MISMATCHES: return slab_verify_count(const_cast<mrl_ctx *>(ctx), false);
     default: return 0;

@@ -123,6 +123,7 @@ struct mrl_ctx {
 
   int exp = 0;  // experiment switches (MRL_OPT_EXPERIMENT, bit mask): A/B testing of kernel variants inside one process
   int opt_nsub = 1;    // MRL_OPT_SLAB_NSUB
+  int opt_chunk_mb = 0;   // MRL_OPT_CACHE_CHUNK_MB: 0 = off, > 0 = MB of c-hat + mu-hat planes per chunk
   int opt_carry = 0;   // MRL_OPT_SLAB_CARRY
   int opt_verify = 0;  // MRL_OPT_VERIFY_EXCHANGE
   // serial contexts on the fused fast path: elements between two x planes of the solver-private spectral arrays (work arrays, Nhat

@@ -261,3 +261,29 @@ def test_config_a_pfhub_1a_128():
             assert (c.cpu() - ref.c).abs().max().item() <= max(1e-13, 1e-16 * substeps * (step + 1))
         energies.append(free_energy(c.cpu()))
     assert all(b < a for a, b in zip(energies, energies[1:])), energies
+
+
+@pytest.mark.parametrize("shape,mb", [((64, 64, 64), 1), ((100, 64, 128), 2), ((128, 128, 128), 7)])
+def test_cache_chunked_schedule_is_bit_identical(shape, mb):
+    """MRL_OPT_CACHE_CHUNK_MB (A/B switch, off by default): the plane-wise passes between two x passes run chunk after chunk over x --
+    the same kernels on the same data in another order -- so a multi-substep call ends on the same bits, field and chemical
+    potential, incl. a last chunk of another size (100 planes in chunks of 30)"""
+    from marlin_amd import api
+    ctx = api.Context(3, list(shape), [3.0, 2.5, 4.0])
+    p = api.ch_params()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    c0 = torch.rand(*shape, dtype=torch.float64, device="cuda", generator=g) * 0.12 + 0.44
+    res = []
+    for budget in (0, mb):
+        ctx.set_option(api.OPT_CACHE_CHUNK_MB, budget)
+        ring = [ctx.empty_hist(), ctx.empty_hist(), ctx.empty_hist()]
+        for r in ring:
+            r.zero_()
+        out, mu = torch.empty_like(c0), torch.empty_like(c0)
+        ctx.ch_substeps(p, c0, out, ring, 2, 0, 3, 7, True, 1e-3, mu=mu)
+        ctx.sync()
+        res.append((out, mu))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert (res[0][0] - c0).abs().max().item() > 1e-6
+    with pytest.raises(api.MarlinHipError):
+        ctx.set_option(api.OPT_CACHE_CHUNK_MB, -3)
