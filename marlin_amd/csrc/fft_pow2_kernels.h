@@ -64,7 +64,10 @@ __device__ __forceinline__ kreal mu_eval(const ChDev &p, kreal c) {
 template <int N>
 constexpr bool lane_pair_ok() {
   constexpr int TPL = Plan<N>::TPL;
-  return TPL <= 64 && (TPL & (TPL - 1)) == 0 && Plan<N>::P % 2 == 0;   // (power of two <= 64: a line never straddles two waves)
+  // power of two <= 64: a line never straddles two waves.  (Round 4 also laid the 100- / 200-point lines out wave by wave -- 6 / 3 whole
+  // lines per wave and 4 spare lanes shadowing the first ones -- to give them the lane exchange: bit-identical, and 200^3 0.167-0.169 ms
+  // with and without it, 100^3 0.0393 against 0.0402 ms; not kept.)
+  return TPL <= 64 && (TPL & (TPL - 1)) == 0 && Plan<N>::P % 2 == 0;
 }
 __device__ __forceinline__ double lane_get(double x, int src) {
   union {
