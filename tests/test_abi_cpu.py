@@ -141,3 +141,23 @@ def test_lds_conflict_model_reproduces_the_measured_shares():
     # the parameters in fft_pow2.h are the ones the model was run with
     hdr = open(os.path.join(ROOT, "marlin_amd", "csrc", "fft_pow2.h")).read()
     assert re.search(r"MRL_LINEMAP\(512, 0, 3, 7, 0\)", hdr) and re.search(r"MRL_LINEMAP\(200, 4, 3, 1, 0\)", hdr)
+
+
+def test_python_constants_match_the_header():
+    """the ctypes plumbing (marlin_amd/api.py) names options, flags and transports by value: every one of them against the #define /
+    enum of include/marlin_hip.h, so that a renumbering in the header cannot silently change what a test or bench.py asks for"""
+    import re
+    from marlin_amd import api
+    text = open(os.path.join(ROOT, "include", "marlin_hip.h")).read()
+    values = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(MRL_[A-Z0-9_]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\b", text)}
+    values.update({m.group(1): int(m.group(2)) for m in re.finditer(r"\b(MRL_[A-Z0-9_]+)\s*=\s*(-?\d+)", text)})
+    pairs = {"OPT_EXPERIMENT": "MRL_OPT_EXPERIMENT", "OPT_SLAB_NSUB": "MRL_OPT_SLAB_NSUB", "OPT_SLAB_CARRY": "MRL_OPT_SLAB_CARRY",
+             "OPT_VERIFY_EXCHANGE": "MRL_OPT_VERIFY_EXCHANGE", "OPT_VERIFY_MISMATCHES": "MRL_OPT_VERIFY_MISMATCHES",
+             "OPT_CACHE_CHUNK_MB": "MRL_OPT_CACHE_CHUNK_MB", "TRANSPORT_PEER_STORE": "MRL_TRANSPORT_PEER_STORE",
+             "TRANSPORT_PEER_COPY": "MRL_TRANSPORT_PEER_COPY", "TRANSPORT_RCCL": "MRL_TRANSPORT_RCCL"}
+    for py, c in pairs.items():
+        assert c in values, c
+        assert getattr(api, py) == values[c], (py, getattr(api, py), values[c])
+    assert api.Context.COUPLED_L_AS_WRITTEN == values["MRL_COUPLED_L_AS_WRITTEN"]
+    assert api.Context.COUPLED_COMPLEX_RHS == values["MRL_COUPLED_COMPLEX_RHS"]
+    assert values["MRL_COUPLED_GENERAL"] == 4 and values["MRL_FLAG_PENCIL"] == 8
