@@ -263,14 +263,20 @@ def test_config_a_pfhub_1a_128():
     assert all(b < a for a, b in zip(energies, energies[1:])), energies
 
 
+@pytest.mark.parametrize("family", ["double_well", "pfhub", "parsed"])
 @pytest.mark.parametrize("shape,mb", [((64, 64, 64), 1), ((100, 64, 128), 2), ((128, 128, 128), 7)])
-def test_cache_chunked_schedule_is_bit_identical(shape, mb):
+def test_cache_chunked_schedule_is_bit_identical(shape, mb, family):
     """MRL_OPT_CACHE_CHUNK_MB (A/B switch, off by default): the plane-wise passes between two x passes run chunk after chunk over x --
     the same kernels on the same data in another order -- so a multi-substep call ends on the same bits, field and chemical
     potential, incl. a last chunk of another size (100 planes in chunks of 30)"""
     from marlin_amd import api
     ctx = api.Context(3, list(shape), [3.0, 2.5, 4.0])
-    p = api.ch_params()
+    if family == "double_well":
+        p = api.ch_params()
+    elif family == "pfhub":
+        p = api.ch_params(family=api.FE_PFHUB, coef=(5.0, 0.3, 0.7), mobility=5.0, kappa=-10.0)
+    else:   # the user's expression compiled into the z passes (hiprtc): its launcher takes the same chunk offsets
+        p = api.ch_params(parsed=api.ParsedCompute(ctx, "0.1*c^2*(c-1)^2+0.01*c^4", inputs=["c"], derivatives=["c"]))
     g = torch.Generator(device="cuda").manual_seed(3)
     c0 = torch.rand(*shape, dtype=torch.float64, device="cuda", generator=g) * 0.12 + 0.44
     res = []
