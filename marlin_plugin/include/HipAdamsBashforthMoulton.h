@@ -1,5 +1,12 @@
-// HipAdamsBashforthMoulton -- replaces AdamsBashforthMoulton for the scalar Cahn-Hilliard system
-// (include/tensor_solver/AdamsBashforthMoulton.h, SplitOperatorBase.h:27-34, TensorSolver.h).
+// HipAdamsBashforthMoulton -- replaces AdamsBashforthMoulton (include/tensor_solver/AdamsBashforthMoulton.h, SplitOperatorBase.h:27-34,
+// TensorSolver.h): predictor orders 1-5, Adams-Moulton corrector, any number of variables.
+//
+// Two ways to run, selected by the input file:
+//  * `expression = <free energy f(c)>` + `mobility` + `kappa_factor`: the scalar Cahn-Hilliard system INCLUDING its compute group
+//    (ParsedCompute mu = f'(c), ForwardFFT x 2, Mbar * mubar) as one library call per substep (mrl_ch_substep) or per solver call
+//    (mrl_ch_substeps, `fuse_substeps = true`, the default) -- the headline path;
+//  * no `expression`: the reference's structure -- `root_compute` is evaluated (any mix of Marlin's own and Hip* compute objects), the
+//    k-space update of every variable is mrl_kspace_abm and the inverse transform mrl_fft_c2r.
 #pragma once
 
 #include "SplitOperatorBase.h"
@@ -12,11 +19,7 @@ class HipAdamsBashforthMoulton : public SplitOperatorBase
 public:
   static InputParameters validParams();
   HipAdamsBashforthMoulton(const InputParameters & parameters);
-  ~HipAdamsBashforthMoulton()
-  {
-    if (_parsed)
-      mrl_parsed_destroy(_parsed);
-  }
+  ~HipAdamsBashforthMoulton();
 
   /// the whole substep loop of TensorSolver::computeBuffer (TensorSolver.C:93-109) in one library call when nothing can observe
   /// the intermediate fields, the inherited loop over substep() otherwise
@@ -25,15 +28,29 @@ public:
 protected:
   virtual void substep() override;
 
+  void substepCahnHilliard();
+  void substepGeneric();
+  /// ubar = (ubar0 + sum coef_i N_i) / (1 - sub_dt L);  u = ifft(ubar)            (AdamsBashforthMoulton.C:94-101, 158-172)
+  void update(Variable & v, const torch::Tensor & ubar0, const std::vector<torch::Tensor> & N, const std::vector<double> & coef);
+  /// a fresh array in the solver-private spectral layout
+  torch::Tensor newSpectral() const;
   /// the buffers the compute group of the reference would have assigned
-  void publish(const torch::Tensor & Nnew);
+  void publish(const torch::Tensor & Nnew, const torch::Tensor & mu);
 
-  std::unique_ptr<HipDomain> _hip;
+  static constexpr std::size_t max_order = 5;
+
+  std::shared_ptr<HipDomain> _hip;
+  const std::size_t _predictor_order; ///< user value - 1, as AdamsBashforthMoulton.C:48
+  const std::size_t _corrector_order; ///< user value - 1, :49
+  const std::size_t _corrector_steps;
+  const bool _cahn_hilliard;
+  const bool _fuse_substeps;
+  const bool _verbose;
   mrl_ch_params _p;
   mrl_parsed * _parsed = nullptr;
-  const std::size_t _predictor_order;
-  const bool _fuse_substeps;
-  /// ring of predictor_order + 1 spectral arrays in the library's private layout (mrl_ch_spec_elems complex values each)
+  torch::Tensor * const _mu_out;
+  /// fused loop: ring of predictor_order spectral arrays in the library's private layout (mrl_ch_spec_elems complex values each)
   std::vector<torch::Tensor> _ring;
   int _head = 0, _n_old = 0;
+  bool _have_new = false; ///< slot (_head + 1) holds an Nhat that the next advanceState turns into history
 };

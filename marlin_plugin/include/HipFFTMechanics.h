@@ -18,7 +18,7 @@ public:
   virtual bool supportsJIT() const override { return false; }
 
 protected:
-  std::unique_ptr<HipDomain> _hip;
+  std::shared_ptr<HipDomain> _hip;
   const torch::Tensor & _tF;
   const torch::Tensor & _tK;
   const torch::Tensor & _tmu;

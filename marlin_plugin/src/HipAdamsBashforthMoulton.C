@@ -1,9 +1,9 @@
-// HipAdamsBashforthMoulton: AdamsBashforthMoulton::substep (src/tensor_solver/AdamsBashforthMoulton.C:60-101) and the compute group it
-// re-evaluates (ParsedCompute mu = f'(c), PerformFFT, ReciprocalLaplacianFactor Mbar, ReciprocalLaplacianSquareFactor kappabarbar)
-// as ONE library call per substep -- or one per solver call -- on the tensors Marlin owns.
+// HipAdamsBashforthMoulton: AdamsBashforthMoulton::substep (src/tensor_solver/AdamsBashforthMoulton.C:60-177) on libmarlin_hip.
 #include "HipAdamsBashforthMoulton.h"
 #include "TensorProblem.h"
 #include "DomainAction.h"
+
+#include <algorithm>
 
 registerMooseObject("MarlinApp", HipAdamsBashforthMoulton);
 
@@ -11,43 +11,65 @@ InputParameters
 HipAdamsBashforthMoulton::validParams()
 {
   InputParameters params = SplitOperatorBase::validParams();
-  params.addClassDescription("Adams-Bashforth semi-implicit Cahn-Hilliard solver on libmarlin_hip (MI355X).");
+  params.addClassDescription("Adams-Bashforth-Moulton semi-implicit solver on libmarlin_hip (MI355X).");
   params.addParam<unsigned int>("substeps", 1, "semi-implicit substeps per time step.");
   params.addRangeCheckedParam<std::size_t>(
       "predictor_order", 2, "predictor_order > 0 & predictor_order <= 5", "Order of the Adams-Bashforth predictor.");
-  // copied verbatim from the [mu] ParsedCompute block of the input (cahnhilliard.i:61-69)
-  params.addRequiredParam<std::string>("expression", "Free energy density f(c); mu = df/dc is derived symbolically");
+  params.addRangeCheckedParam<std::size_t>(
+      "corrector_order", 2, "corrector_order > 0 & corrector_order <= 5", "Order of the Adams-Moulton corrector.");
+  params.addParam<std::size_t>("corrector_steps", 0, "Number the Adams-Moulton corrector steps to take.");
+  // Cahn-Hilliard form: copied verbatim from the [mu] ParsedCompute block and the two Laplacian factor blocks (cahnhilliard.i:33-69)
+  params.addParam<std::string>("expression", "Free energy density f(c); mu = df/dc is derived symbolically. Selects the fused path");
   params.addParam<std::vector<std::string>>("constant_names", {}, "Named constants of the expression");
   params.addParam<std::vector<Real>>("constant_expressions", {}, "... and their values");
-  params.addRequiredParam<Real>("mobility", "Factor of the ReciprocalLaplacianFactor block (Mbar = -k^2 M)");
-  params.addRequiredParam<Real>("kappa_factor", "Factor of the ReciprocalLaplacianSquareFactor block (Lbar = k^4 kappa)");
+  params.addParam<Real>("mobility", "Factor of the ReciprocalLaplacianFactor block (Mbar = -k^2 M)");
+  params.addParam<Real>("kappa_factor", "Factor of the ReciprocalLaplacianSquareFactor block (Lbar = k^4 kappa)");
+  params.addParam<TensorOutputBufferName>("chemical_potential", "Buffer that receives mu = f'(c) (what the [mu] block would hold)");
   params.addParam<bool>("fuse_substeps", true, "Hand the whole substep loop of a solver call to the library (mrl_ch_substeps)");
+  params.addParam<bool>("verbose", false, "Print the predictor order of every substep.");
   return params;
 }
 
 HipAdamsBashforthMoulton::HipAdamsBashforthMoulton(const InputParameters & parameters)
   : SplitOperatorBase(parameters),
-    _hip(std::make_unique<HipDomain>(_domain, comm())),
-    _predictor_order(getParam<std::size_t>("predictor_order") - 1), // AdamsBashforthMoulton.C:48
-    _fuse_substeps(getParam<bool>("fuse_substeps"))
+    _hip(HipDomain::get(_domain, comm())),
+    _predictor_order(getParam<std::size_t>("predictor_order") - 1),
+    _corrector_order(getParam<std::size_t>("corrector_order") - 1),
+    _corrector_steps(getParam<std::size_t>("corrector_steps")),
+    _cahn_hilliard(isParamValid("expression")),
+    _fuse_substeps(getParam<bool>("fuse_substeps")),
+    _verbose(getParam<bool>("verbose")),
+    _mu_out(isParamValid("chemical_potential") ? &getOutputBuffer("chemical_potential") : nullptr)
 {
-  getVariables(_predictor_order); // history depth, AdamsBashforthMoulton.C:55-56
-  if (_variables.size() != 1)
-    paramError("buffer", "HipAdamsBashforthMoulton solves one variable; use AdamsBashforthMoulton with mrl_kspace_abm otherwise");
+  if (_predictor_order >= max_order)
+    paramError("predictor_order", "predictor_order > 0 & predictor_order <= 5");
+  if (_corrector_order >= max_order)
+    paramError("corrector_order", "corrector_order > 0 & corrector_order <= 5");
+  // history consistent with the chosen orders, AdamsBashforthMoulton.C:55-56
+  getVariables(_cahn_hilliard ? _predictor_order : std::max(_predictor_order, _corrector_order));
+  if (!_cahn_hilliard)
+    return;
 
-  const auto names = getParam<std::vector<std::string>>("constant_names");
-  const auto values = getParam<std::vector<Real>>("constant_expressions");
+  if (_variables.size() != 1)
+    paramError("buffer", "`expression` selects the scalar Cahn-Hilliard path: one variable (leave it out to integrate several)");
+  if (_corrector_steps)
+    paramError("corrector_steps", "the fused Cahn-Hilliard path is predictor-only; leave `expression` out to use the corrector");
+  if (!isParamValid("mobility") || !isParamValid("kappa_factor"))
+    paramError("expression", "`mobility` and `kappa_factor` are needed with `expression`");
+  const auto & names = getParam<std::vector<std::string>>("constant_names");
+  const auto & values = getParam<std::vector<Real>>("constant_expressions");
   if (names.size() != values.size())
     paramError("constant_names", "Need one value per named constant");
   std::vector<const char *> cn;
   for (const auto & s : names)
     cn.push_back(s.c_str());
-  const char * inputs[] = {"c"};
+  // the variable's name in the expression is the name of its buffer (the `inputs = c` of the [mu] block)
+  const std::string cname = getParam<std::vector<TensorOutputBufferName>>("buffer")[0];
+  const char * inputs[] = {cname.c_str()};
   const int is_complex[] = {0};
-  const char * wrt[] = {"c"};
   // symbolic derivative with the reference's rules (MarlinExpressionParser.C:50-235), compiled into the forward z pass
   _hip->check(mrl_parsed_create(_hip->ctx(), &_parsed, getParam<std::string>("expression").c_str(), 1, inputs, is_complex,
-                                (int)cn.size(), cn.data(), values.data(), 1, wrt, /*extra_symbols=*/0, /*space=*/0),
+                                (int)cn.size(), cn.data(), values.data(), 1, inputs, /*extra_symbols=*/0, /*space=*/0),
               name());
   _p = mrl_ch_params{};
   _p.family = MRL_FE_PARSED;
@@ -55,44 +77,74 @@ HipAdamsBashforthMoulton::HipAdamsBashforthMoulton(const InputParameters & param
   _p.mobility = getParam<Real>("mobility");
   _p.kappa = getParam<Real>("kappa_factor");
 
-  const auto copt = MooseTensor::complexFloatTensorOptions();
-  for (std::size_t i = 0; i < _predictor_order + 1; ++i)
-    _ring.push_back(torch::zeros({mrl_ch_spec_elems(_hip->ctx())}, copt));
+  if (_fuse_substeps)
+    for (std::size_t i = 0; i < _predictor_order + 1; ++i)
+      _ring.push_back(newSpectral().zero_());
+}
+
+HipAdamsBashforthMoulton::~HipAdamsBashforthMoulton()
+{
+  if (_parsed)
+    mrl_parsed_destroy(_parsed);
+}
+
+torch::Tensor
+HipAdamsBashforthMoulton::newSpectral() const
+{
+  return torch::empty({mrl_ch_spec_elems(_hip->ctx())}, MooseTensor::complexFloatTensorOptions());
 }
 
 void
-HipAdamsBashforthMoulton::publish(const torch::Tensor & Nnew)
+HipAdamsBashforthMoulton::publish(const torch::Tensor & Nnew, const torch::Tensor & mu)
 {
-  // what ComputeGroup would have assigned (Mbarmubar); consumers see the dense values through a strided view
-  int64_t plane = 0, row = 0;
-  mrl_ch_spec_layout(_hip->ctx(), &plane, &row);
-  const auto shape = _domain.getReciprocalShape();
-  auto & v = _variables[0];
-  const_cast<torch::Tensor &>(v._nonlinear_reciprocal) =
-      shape.size() == 3 ? torch::as_strided(Nnew, {shape[0], shape[1], shape[2]}, {plane, row, 1}) : Nnew;
+  // what ComputeGroup would have assigned (Mbarmubar): the dense values through a strided view of the private layout; the next
+  // advanceState moves this handle into the history (TensorBuffer.h:62-79), where substepCahnHilliard() finds it again
+  const_cast<torch::Tensor &>(_variables[0]._nonlinear_reciprocal) = _hip->spectralView(Nnew);
+  if (_mu_out)
+    *_mu_out = mu;
 }
 
 void
 HipAdamsBashforthMoulton::substep()
 {
+  if (_cahn_hilliard)
+    substepCahnHilliard();
+  else
+    substepGeneric();
+}
+
+void
+HipAdamsBashforthMoulton::substepCahnHilliard()
+{
   auto & v = _variables[0];
   const auto & hist = v._old_nonlinear_reciprocal;
   // AdamsBashforthMoulton.C:75,88-91: a changed time step size restarts the predictor at first order
-  const int order = (int)std::min<std::size_t>(_substep < _predictor_order && _dt != _dt_old ? 0 : hist.size(), _predictor_order);
+  const std::size_t order = std::min(_substep < _predictor_order && _dt != _dt_old ? 0 : hist.size(), _predictor_order);
+  if (_verbose)
+    _console << name() << ": substep " << _substep << " order " << order << '\n';
   const torch::Tensor c_in = v._buffer.contiguous();
   torch::Tensor c_out = torch::empty_like(c_in);
-  torch::Tensor Nnew = torch::empty({mrl_ch_spec_elems(_hip->ctx())}, MooseTensor::complexFloatTensorOptions());
+  torch::Tensor Nnew = newSpectral();
+  torch::Tensor mu = _mu_out ? torch::empty_like(c_in) : torch::Tensor();
   std::vector<const double *> old(order);
   std::vector<torch::Tensor> keep(order);
-  for (int i = 0; i < order; ++i)
+  for (std::size_t i = 0; i < order; ++i)
   {
-    keep[i] = hist[i].contiguous();
+    // history entries are the views publish() created; a tensor that some other object assigned to the buffer is repacked
+    if (_hip->isSpectralView(hist[i]))
+      keep[i] = hist[i];
+    else
+    {
+      keep[i] = _hip->spectralView(newSpectral());
+      keep[i].copy_(hist[i]);
+    }
     old[i] = static_cast<const double *>(keep[i].data_ptr());
   }
   _hip->check(mrl_ch_substep(_hip->ctx(), &_p, c_in.data_ptr<double>(), c_out.data_ptr<double>(),
-                             static_cast<double *>(Nnew.data_ptr()), old.data(), order, _sub_dt, nullptr, nullptr, MRL_CARRY_NONE),
+                             static_cast<double *>(Nnew.data_ptr()), old.data(), (int)order, _sub_dt, nullptr,
+                             _mu_out ? mu.data_ptr<double>() : nullptr, MRL_CARRY_NONE),
               name());
-  publish(Nnew);
+  publish(Nnew, mu);
   v._buffer = c_out; // AdamsBashforthMoulton.C:101: rebinding the handle
 }
 
@@ -100,32 +152,151 @@ void
 HipAdamsBashforthMoulton::computeBuffer()
 {
   // per-substep outputs or other objects with a history need every intermediate field: keep Marlin's own loop
-  if (!_fuse_substeps || _substeps < 2)
+  if (!_cahn_hilliard || !_fuse_substeps)
   {
     TensorSolver::computeBuffer();
     return;
   }
+  _sub_time = _time;           // TensorSolver.C:95
+  _sub_dt = _dt / _substeps;   // TensorSolver.C:96
   auto & v = _variables[0];
   const torch::Tensor c_in = v._buffer.contiguous();
   torch::Tensor c_out = torch::empty_like(c_in);
+  torch::Tensor mu = _mu_out ? torch::empty_like(c_in) : torch::Tensor();
   std::vector<double *> ring;
   for (auto & t : _ring)
     ring.push_back(static_cast<double *>(t.data_ptr()));
-  // TensorSolver.C:105-106: advanceState between substeps, a no-op for the buffers while timeStep() <= 1
-  int advance = _tensor_problem.timeStep() > 1 ? 1 : 0;
-  if (_dt != _dt_old)
-    advance |= MRL_SUBSTEPS_DT_CHANGED;
-  if (_tensor_problem.timeStep() > 1 && _n_old < (int)_predictor_order) // advanceState between two solver calls
+  // MOOSE called advanceState between the previous solver call and this one; TensorSolver.C:105-106 calls it between substeps.
+  // Both are no-ops for the buffers while timeStep() <= 1 (TensorProblem.C:455): all substeps of the first step are AB1.
+  const bool advancing = _tensor_problem.timeStep() > 1;
+  if (advancing && _have_new)
   {
     _head = (_head + 1) % (int)_ring.size();
-    _n_old += 1;
+    _n_old = std::min<int>(_n_old + 1, (int)_predictor_order);
   }
-  else if (_tensor_problem.timeStep() > 1)
-    _head = (_head + 1) % (int)_ring.size();
+  int advance = advancing ? MRL_SUBSTEPS_ADVANCE : 0;
+  if (_dt != _dt_old)
+    advance |= MRL_SUBSTEPS_DT_CHANGED; // AdamsBashforthMoulton.C:75
+  if (_verbose) // what the call below is asked to do: order = min(dt_changed && k < pred ? 0 : n_old, pred), n_old growing when advancing
+    for (unsigned int k = 0, n_old = _n_old; k < _substeps; ++k)
+    {
+      _console << name() << ": substep " << k << " order "
+               << std::min<std::size_t>(_dt != _dt_old && k < _predictor_order ? 0 : n_old, _predictor_order) << '\n';
+      if (advancing && n_old < _predictor_order)
+        ++n_old;
+    }
+  // the ABI takes the user-facing order (1 = AB1); _predictor_order holds it minus one
   _hip->check(mrl_ch_substeps(_hip->ctx(), &_p, c_in.data_ptr<double>(), c_out.data_ptr<double>(), ring.data(), (int)_ring.size(),
-                              &_head, &_n_old, (int)_predictor_order, (int)_substeps, advance, _sub_dt, nullptr),
+                              &_head, &_n_old, (int)_predictor_order + 1, (int)_substeps, advance, _sub_dt,
+                              _mu_out ? mu.data_ptr<double>() : nullptr),
               name());
-  publish(_ring[(_head + 1) % _ring.size()]);
+  _have_new = true;
+  publish(_ring[(_head + 1) % _ring.size()], mu);
   v._buffer = c_out;
-  _sub_time += _substeps * _sub_dt;
+  _substep = _substeps;
+  _sub_time += _substeps * _sub_dt; // TensorSolver.C:108, once per substep
+}
+
+void
+HipAdamsBashforthMoulton::update(Variable & v,
+                                 const torch::Tensor & ubar0,
+                                 const std::vector<torch::Tensor> & N,
+                                 const std::vector<double> & coef)
+{
+  const int64_t n_spec = _hip->reciprocalCount();
+  const torch::Tensor u0 = ubar0.contiguous();
+  if (u0.numel() != n_spec)
+    paramError("reciprocal_buffer", "expected ", n_spec, " complex values (the local reciprocal grid), got ", u0.numel());
+  std::vector<torch::Tensor> keep;
+  std::vector<const double *> ptr;
+  for (const auto & t : N)
+  {
+    keep.push_back(t.contiguous());
+    if (keep.back().numel() != n_spec || !keep.back().is_complex())
+      paramError("nonlinear_reciprocal", "expected ", n_spec, " complex values, got ", keep.back().numel());
+    ptr.push_back(static_cast<const double *>(keep.back().data_ptr()));
+  }
+  torch::Tensor L;
+  if (v._linear_reciprocal)
+    L = v._linear_reciprocal->expand(u0.sizes()).contiguous(); // (a broadcast k-axis product is materialised here)
+  torch::Tensor ubar = torch::empty_like(u0);
+  _hip->check(mrl_kspace_abm(_hip->ctx(), static_cast<double *>(ubar.data_ptr()), static_cast<const double *>(u0.data_ptr()),
+                             ptr.data(), coef.data(), (int)ptr.size(), v._linear_reciprocal ? L.data_ptr<double>() : nullptr,
+                             _sub_dt, n_spec),
+              name());
+  torch::Tensor u = torch::empty(_hip->realShape(), MooseTensor::floatTensorOptions());
+  _hip->check(mrl_fft_c2r(_hip->ctx(), static_cast<const double *>(ubar.data_ptr()), u.data_ptr<double>(), 1, 0), name());
+  v._buffer = u; // AdamsBashforthMoulton.C:101
+}
+
+void
+HipAdamsBashforthMoulton::substepGeneric()
+{
+  // re-evaluate the solve compute                                                          AdamsBashforthMoulton.C:63-64
+  _compute->computeBuffer();
+  forwardBuffers();
+
+  // (zero-padded tables of the reference, including its first AB5 entry 190/720, AdamsBashforthMoulton.C:67-73, 108-114)
+  static const double beta[max_order][max_order] = {{1.0, 0.0, 0.0, 0.0, 0.0},
+                                                    {3.0 / 2.0, -1.0 / 2.0, 0.0, 0.0, 0.0},
+                                                    {23.0 / 12.0, -16.0 / 12.0, 5.0 / 12.0, 0.0, 0.0},
+                                                    {55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -9.0 / 24.0, 0.0},
+                                                    {190.0 / 720.0, -2774.0 / 720.0, 2616.0 / 720.0, -1274.0 / 720.0, 251.0 / 720.0}};
+  static const double alpha[max_order][max_order] = {{1.0, 0.0, 0.0, 0.0, 0.0},
+                                                     {0.5, 0.5, 0.0, 0.0, 0.0},
+                                                     {5.0 / 12.0, 8.0 / 12.0, -1.0 / 12.0, 0.0, 0.0},
+                                                     {9.0 / 24.0, 19.0 / 24.0, -5.0 / 24.0, 1.0 / 24.0, 0.0},
+                                                     {251.0 / 720.0, 646.0 / 720.0, -264.0 / 720.0, 106.0 / 720.0, -19.0 / 720.0}};
+  const bool dt_changed = (_dt != _dt_old);
+
+  // Adams-Bashforth predictor on all variables                                             :80-102
+  for (auto & v : _variables)
+  {
+    const auto & hist = v._old_nonlinear_reciprocal;
+    const std::size_t order = std::min(_substep < _predictor_order && dt_changed ? 0 : hist.size(), _predictor_order);
+    if (_verbose)
+      _console << name() << ": substep " << _substep << " order " << order << '\n';
+    std::vector<torch::Tensor> N{v._nonlinear_reciprocal};
+    std::vector<double> coef{_sub_dt * beta[order][0]};
+    for (std::size_t i = 0; i < order; ++i)
+    {
+      N.push_back(hist[i]);
+      coef.push_back(_sub_dt * beta[order][i + 1]);
+    }
+    update(v, v._reciprocal_buffer, N, coef);
+  }
+
+  if (!_corrector_steps)
+    return;
+
+  // Adams-Moulton corrector                                                                :117-177
+  _sub_time += _sub_dt;
+  std::vector<torch::Tensor> ubar_n, N_n; // handle copies keep the step-n tensors alive
+  for (auto & v : _variables)
+  {
+    ubar_n.push_back(v._reciprocal_buffer);
+    N_n.push_back(v._nonlinear_reciprocal);
+  }
+  for (std::size_t j = 0; j < _corrector_steps; ++j)
+  {
+    _compute->computeBuffer();
+    forwardBuffers();
+    for (std::size_t k = 0; k < _variables.size(); ++k)
+    {
+      auto & v = _variables[k];
+      const auto & hist = v._old_nonlinear_reciprocal;
+      const std::size_t order = std::min(_substep < _corrector_order && dt_changed ? 1 : hist.size() + 1, _corrector_order);
+      if (order == 0)
+        continue;
+      std::vector<torch::Tensor> N{v._nonlinear_reciprocal, N_n[k]};
+      std::vector<double> coef{_sub_dt * alpha[order][0], _sub_dt * alpha[order][1]};
+      for (std::size_t i = 0; i + 1 < order; ++i)
+      {
+        N.push_back(hist[i]);
+        coef.push_back(_sub_dt * alpha[order][i + 2]);
+      }
+      update(v, ubar_n[k], N, coef);
+    }
+  }
+  _sub_time -= _sub_dt;
 }

@@ -27,7 +27,7 @@ HipFFTMechanics::validParams()
 
 HipFFTMechanics::HipFFTMechanics(const InputParameters & parameters)
   : TensorOperator<>(parameters),
-    _hip(std::make_unique<HipDomain>(_domain, comm())),
+    _hip(HipDomain::get(_domain, comm())),
     _tF(getInputBuffer("F")),
     _tK(getInputBuffer("K")),
     _tmu(getInputBuffer("mu")),

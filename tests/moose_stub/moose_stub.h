@@ -1,0 +1,598 @@
+// TEST INFRASTRUCTURE, not product code and not a build of the reference: the smallest stand-ins for the MOOSE / libMesh / Marlin
+// base classes that the files of marlin_plugin/ derive from and call, so that those files -- the reference-side binding of
+// include/marlin_hip.h -- are COMPILED AS THEY ARE and EXECUTED on the GPU box (tests/test_moose_shim_gpu.py), where no MOOSE exists.
+// Nothing here evaluates a transform or a solver step; tensors are real libTorch tensors on the HIP device, as in Marlin.
+//
+// Behaviour written from (paths relative to idaholab/marlin):
+//   include/tensor_solver/TensorSolver.h:17-62, src/tensor_solver/TensorSolver.C:41-109   members, getBufferOld, the substep loop
+//   include/tensor_solver/SplitOperatorBase.h:17-37, src/tensor_solver/SplitOperatorBase.C:13-64   Variable, getVariables
+//   include/tensor_computes/TensorOperatorBase.h:26-151, TensorOperator.h:17-45            buffer getters, _time = subTime()
+//   include/tensor_buffers/TensorBuffer.h:17-118                                            advanceState of one buffer
+//   src/problems/TensorProblem.C:160-190, 451-472                                           execute(TIMESTEP_BEGIN), advanceState, timeStep() <= 1
+//   src/tensor_computes/ComputeGroup.C:61-84                                                computes of a group run in order
+//   MOOSE: InputParameters (addParam / addRequiredParam / addRangeCheckedParam / set / get), MooseObject (getParam, isParamValid,
+//   paramError, name, comm, _console), registerMooseObject, mooseError, TransientBase::incrementStepOrReject / takeStep
+//   (t_step += 1, advanceState, dt_old = dt).
+// The same-named forwarding headers next to this file (SplitOperatorBase.h, TensorOperator.h, ...) only include this one.
+#pragma once
+
+#include <torch/torch.h>
+
+#include <any>
+#include <array>
+#include <cstdint>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <typeinfo>
+#include <vector>
+
+using Real = double;
+typedef std::string TensorComputeName;
+typedef std::string TensorInputBufferName;
+typedef std::string TensorOutputBufferName;
+
+namespace moose_stub
+{
+template <typename... A>
+std::string
+cat(A &&... a)
+{
+  std::ostringstream s;
+  (s << ... << a);
+  return s.str();
+}
+/// where the tensors of a run live (the reference: MooseTensor::floatTensorOptions(), src/utils/MarlinUtils.C:100-123)
+inline torch::Device &
+device()
+{
+  static torch::Device d(torch::kCPU);
+  return d;
+}
+
+template <typename T>
+struct FromString;
+template <>
+struct FromString<std::string>
+{
+  static std::string get(const std::string & s) { return s; }
+};
+template <>
+struct FromString<bool>
+{
+  static bool get(const std::string & s) { return s == "true" || s == "1" || s == "TRUE"; }
+};
+template <>
+struct FromString<double>
+{
+  static double get(const std::string & s) { return std::stod(s); }
+};
+template <>
+struct FromString<unsigned int>
+{
+  static unsigned int get(const std::string & s) { return (unsigned int)std::stoul(s); }
+};
+template <>
+struct FromString<std::size_t>
+{
+  static std::size_t get(const std::string & s) { return std::stoull(s); }
+};
+template <typename T>
+struct FromString<std::vector<T>>
+{
+  static std::vector<T> get(const std::string & s)
+  {
+    std::vector<T> v;
+    std::istringstream in(s);
+    std::string tok;
+    while (in >> tok)
+      v.push_back(FromString<T>::get(tok));
+    return v;
+  }
+};
+} // namespace moose_stub
+
+struct MooseStubError : std::runtime_error
+{
+  using std::runtime_error::runtime_error;
+};
+
+template <typename... A>
+[[noreturn]] void
+mooseError(A &&... a)
+{
+  throw MooseStubError(moose_stub::cat(std::forward<A>(a)...));
+}
+
+namespace libMesh
+{
+namespace Parallel
+{
+/// one rank: the shim classes are exercised serially here (their multi-rank branch needs MPI)
+class Communicator
+{
+public:
+  unsigned int size() const { return 1; }
+  unsigned int rank() const { return 0; }
+  void broadcast(std::string &) const {}
+};
+}
+}
+
+class RealVectorValue
+{
+public:
+  Real operator()(unsigned int i) const { return _v[i]; }
+  Real & operator()(unsigned int i) { return _v[i]; }
+
+private:
+  std::array<Real, 3> _v{{0, 0, 0}};
+};
+
+namespace MooseTensor
+{
+inline const torch::TensorOptions
+floatTensorOptions()
+{
+  return torch::TensorOptions().dtype(torch::kFloat64).device(moose_stub::device());
+}
+inline const torch::TensorOptions
+complexFloatTensorOptions()
+{
+  return torch::TensorOptions().dtype(torch::kComplexDouble).device(moose_stub::device());
+}
+}
+
+class InputParameters
+{
+public:
+  void addClassDescription(const std::string & d) { _description = d; }
+  void registerBase(const std::string &) {}
+  template <typename T>
+  void addParam(const std::string & name, const T & value, const std::string & doc)
+  {
+    declare<T>(name, doc, false);
+    _values[name] = value;
+  }
+  template <typename T>
+  void addParam(const std::string & name, const std::string & doc)
+  {
+    declare<T>(name, doc, false);
+  }
+  template <typename T>
+  void addRequiredParam(const std::string & name, const std::string & doc)
+  {
+    declare<T>(name, doc, true);
+  }
+  template <typename T>
+  void addRangeCheckedParam(const std::string & name, const T & value, const std::string & range, const std::string & doc)
+  {
+    declare<T>(name, doc + " [" + range + "]", false);
+    _values[name] = value;
+  }
+  template <typename T>
+  T & set(const std::string & name)
+  {
+    auto & slot = _values[name];
+    if (!slot.has_value() || slot.type() != typeid(T))
+      slot = T{};
+    return *std::any_cast<T>(&slot);
+  }
+  template <typename T>
+  const T & get(const std::string & name) const
+  {
+    auto it = _values.find(name);
+    if (it == _values.end() || !it->second.has_value())
+      mooseError("parameter '", name, "' has no value");
+    const T * p = std::any_cast<T>(&it->second);
+    if (!p)
+      mooseError("parameter '", name, "' was declared with another type than the one it is read with");
+    return *p;
+  }
+  bool isParamValid(const std::string & name) const
+  {
+    auto it = _values.find(name);
+    return it != _values.end() && it->second.has_value();
+  }
+  bool declared(const std::string & name) const { return _parse.count(name) != 0; }
+  /// the input-file side: a value arrives as text and is converted to the declared type (unknown names are an error, as in MOOSE)
+  void setFromString(const std::string & name, const std::string & text)
+  {
+    auto it = _parse.find(name);
+    if (it == _parse.end())
+      mooseError("unused parameter '", name, "'");
+    it->second(_values[name], text);
+  }
+  void checkRequired(const std::string & object) const
+  {
+    for (const auto & r : _required)
+      if (!isParamValid(r))
+        mooseError(object, ": missing required parameter '", r, "'");
+  }
+
+private:
+  template <typename T>
+  void declare(const std::string & name, const std::string & doc, bool required)
+  {
+    _doc[name] = doc;
+    _parse[name] = [](std::any & slot, const std::string & text) { slot = moose_stub::FromString<T>::get(text); };
+    if (required)
+      _required.insert(name);
+  }
+  std::string _description;
+  std::map<std::string, std::any> _values;
+  std::map<std::string, std::string> _doc;
+  std::map<std::string, std::function<void(std::any &, const std::string &)>> _parse;
+  std::set<std::string> _required;
+};
+
+class MooseObject
+{
+public:
+  MooseObject(const InputParameters & parameters) : _pars(parameters), _console(std::cout) {}
+  virtual ~MooseObject() = default;
+  const std::string & name() const { return _pars.get<std::string>("_object_name"); }
+  template <typename T>
+  const T & getParam(const std::string & n) const
+  {
+    return _pars.get<T>(n);
+  }
+  bool isParamValid(const std::string & n) const { return _pars.isParamValid(n); }
+  template <typename... A>
+  [[noreturn]] void paramError(const std::string & param, A &&... a) const
+  {
+    mooseError(name(), ": parameter '", param, "': ", std::forward<A>(a)...);
+  }
+  const libMesh::Parallel::Communicator & comm() const
+  {
+    static libMesh::Parallel::Communicator c;
+    return c;
+  }
+
+protected:
+  const InputParameters _pars;
+  std::ostream & _console;
+};
+
+/// registerMooseObject: the factory of the test driver (type name -> validParams + constructor)
+struct MooseStubFactory
+{
+  struct Entry
+  {
+    std::function<InputParameters()> valid_params;
+    std::function<std::shared_ptr<MooseObject>(const InputParameters &)> build;
+  };
+  static std::map<std::string, Entry> & registry()
+  {
+    static std::map<std::string, Entry> r;
+    return r;
+  }
+  template <typename T>
+  static int add(const std::string & type)
+  {
+    registry()[type] = Entry{[]() { return T::validParams(); },
+                             [](const InputParameters & p) -> std::shared_ptr<MooseObject> { return std::make_shared<T>(p); }};
+    return 0;
+  }
+};
+#define registerMooseObject(app, classname)                                                                            \
+  static const int moose_stub_registered_##classname = MooseStubFactory::add<classname>(#classname)
+
+/// include/actions/DomainAction.h:31-69 -- the getters the shim reads; parallel_mode = NONE (DomainAction.C:268-296: r2c on the last axis)
+class DomainAction
+{
+public:
+  DomainAction(unsigned int dim, std::array<int64_t, 3> n, std::array<Real, 3> lo, std::array<Real, 3> hi) : _dim(dim), _n(n)
+  {
+    for (unsigned int d = 0; d < 3; ++d)
+    {
+      if (d >= dim)
+        _n[d] = 1;
+      _min(d) = lo[d];
+      _max(d) = hi[d];
+    }
+    _n_reciprocal = _n;
+    _n_reciprocal[dim - 1] = _n[dim - 1] / 2 + 1;
+    _shape_store.assign(_n.begin(), _n.begin() + dim);
+    _reciprocal_store.assign(_n_reciprocal.begin(), _n_reciprocal.begin() + dim);
+    _shape = _shape_store;
+    _reciprocal_shape = _reciprocal_store;
+  }
+  DomainAction(const DomainAction &) = delete; // (_shape points into this object)
+  const unsigned int & getDim() const { return _dim; }
+  bool isRealSpaceMode() const { return false; }
+  const std::array<int64_t, 3> & getGridSize() const { return _n; }
+  const std::array<int64_t, 3> & getReciprocalGridSize() const { return _n_reciprocal; }
+  const std::array<int64_t, 3> & getLocalGridSize() const { return _n; }
+  const std::array<int64_t, 3> & getLocalReciprocalGridSize() const { return _n_reciprocal; }
+  const RealVectorValue & getDomainMin() const { return _min; }
+  const RealVectorValue & getDomainMax() const { return _max; }
+  const torch::IntArrayRef & getShape() const { return _shape; }
+  const torch::IntArrayRef & getReciprocalShape() const { return _reciprocal_shape; }
+  bool isParallelFFT() const { return false; }
+  void getLocalBounds(unsigned int, std::array<int64_t, 3> & begin, std::array<int64_t, 3> & end) const
+  {
+    begin = {{0, 0, 0}};
+    end = _n;
+  }
+  int64_t getNumberOfCells() const { return _n[0] * _n[1] * _n[2]; }
+
+private:
+  unsigned int _dim;
+  std::array<int64_t, 3> _n, _n_reciprocal;
+  RealVectorValue _min, _max;
+  std::vector<int64_t> _shape_store, _reciprocal_store;
+  torch::IntArrayRef _shape, _reciprocal_shape;
+};
+
+/// include/tensor_buffers/TensorBuffer.h:17-118
+struct TensorBufferStub
+{
+  torch::Tensor u;
+  std::vector<torch::Tensor> u_old;
+  std::size_t max_states = 0;
+  std::size_t advanceState()
+  {
+    if (u_old.size() < max_states)
+      u_old.resize(u_old.size() + 1);
+    for (std::size_t i = u_old.size(); i-- > 1;)
+      u_old[i] = u_old[i - 1];
+    if (!u_old.empty())
+      u_old[0] = u;
+    return u_old.size();
+  }
+};
+
+class TensorOperatorBase;
+
+/// the slice of TensorProblem (+ FEProblemBase time bookkeeping) that solvers and computes reach
+class TensorProblem
+{
+public:
+  TensorProblem(const DomainAction & domain) : _domain(domain) {}
+  const DomainAction & domain() const { return _domain; }
+  template <typename T = torch::Tensor>
+  T & getBuffer(const std::string & buffer_name, unsigned int = 0)
+  {
+    return slot(buffer_name).u;
+  }
+  template <typename T = torch::Tensor>
+  const std::vector<T> & getBufferOld(const std::string & buffer_name, unsigned int max_states)
+  {
+    auto & b = slot(buffer_name);
+    b.max_states = std::max<std::size_t>(b.max_states, max_states);
+    return b.u_old;
+  }
+  void registerGhostLayerRequest(const std::string &, unsigned int) {}
+  Real & subDt() { return _sub_dt; }
+  Real & subTime() { return _sub_time; }
+  Real & dt() { return _dt; }
+  Real & dtOld() { return _dt_old; }
+  Real & time() { return _time; }
+  Real & timeOld() { return _time_old; }
+  int & timeStep() { return _t_step; }
+  /// src/problems/TensorProblem.C:451-472
+  void advanceState()
+  {
+    if (timeStep() <= 1)
+      return;
+    for (auto & kv : _buffers)
+      kv.second.advanceState();
+  }
+  typedef std::vector<std::shared_ptr<TensorOperatorBase>> TensorComputeList;
+  const TensorComputeList & getComputes() const { return _computes; }
+  TensorComputeList & computes() { return _computes; }
+
+private:
+  TensorBufferStub & slot(const std::string & name) { return _buffers[name]; }
+  const DomainAction & _domain;
+  std::map<std::string, TensorBufferStub> _buffers;
+  TensorComputeList _computes;
+  Real _sub_dt = 0, _sub_time = 0, _dt = 0, _dt_old = 0, _time = 0, _time_old = 0;
+  int _t_step = 0;
+};
+
+/// include/tensor_computes/TensorOperatorBase.h:26-151
+class TensorOperatorBase : public MooseObject
+{
+public:
+  static InputParameters validParams() { return InputParameters(); }
+  TensorOperatorBase(const InputParameters & parameters)
+    : MooseObject(parameters),
+      _tensor_problem(*parameters.get<TensorProblem *>("_tensor_problem")),
+      _domain(_tensor_problem.domain()),
+      _time(_tensor_problem.subTime()),
+      _dim(_domain.getDim())
+  {
+  }
+  virtual void updateDependencies() {}
+  virtual void computeBuffer() = 0;
+  virtual bool supportsJIT() const { return true; }
+  template <typename T = torch::Tensor>
+  const T & getInputBuffer(const std::string & param, unsigned int = 0)
+  {
+    return getInputBufferByName<T>(getParam<TensorInputBufferName>(param));
+  }
+  template <typename T = torch::Tensor>
+  const T & getInputBufferByName(const TensorInputBufferName & buffer_name, unsigned int = 0)
+  {
+    _requested_buffers.insert(buffer_name);
+    return _tensor_problem.getBuffer<T>(buffer_name);
+  }
+  template <typename T = torch::Tensor>
+  T & getOutputBuffer(const std::string & param)
+  {
+    return getOutputBufferByName<T>(getParam<TensorOutputBufferName>(param));
+  }
+  template <typename T = torch::Tensor>
+  T & getOutputBufferByName(const TensorOutputBufferName & buffer_name)
+  {
+    _supplied_buffers.insert(buffer_name);
+    return _tensor_problem.getBuffer<T>(buffer_name);
+  }
+  std::set<std::string> _requested_buffers, _supplied_buffers;
+  TensorProblem & _tensor_problem;
+  const DomainAction & _domain;
+  const Real & _time;
+  const unsigned int & _dim;
+};
+
+/// include/tensor_computes/TensorOperator.h:17-45
+template <typename T = torch::Tensor>
+class TensorOperator : public TensorOperatorBase
+{
+public:
+  static InputParameters validParams()
+  {
+    InputParameters params = TensorOperatorBase::validParams();
+    params.addRequiredParam<TensorOutputBufferName>("buffer", "The buffer this compute is writing to");
+    return params;
+  }
+  TensorOperator(const InputParameters & parameters) : TensorOperatorBase(parameters), _u(getOutputBuffer<T>("buffer")) {}
+
+protected:
+  T & _u;
+};
+
+/// src/tensor_computes/ComputeGroup.C:61-84 (members run in the order given: the driver lists them in dependency order)
+class ComputeGroup : public TensorOperatorBase
+{
+public:
+  ComputeGroup(const InputParameters & parameters) : TensorOperatorBase(parameters) {}
+  void add(std::shared_ptr<TensorOperatorBase> c) { _members.push_back(std::move(c)); }
+  virtual void computeBuffer() override
+  {
+    for (auto & m : _members)
+      m->computeBuffer();
+  }
+
+private:
+  std::vector<std::shared_ptr<TensorOperatorBase>> _members;
+};
+
+/// include/tensor_solver/TensorSolver.h:17-62, src/tensor_solver/TensorSolver.C:14-109
+class TensorSolver : public TensorOperatorBase
+{
+public:
+  static InputParameters validParams()
+  {
+    InputParameters params = TensorOperatorBase::validParams();
+    params.addParam<TensorComputeName>("root_compute", "Primary compute object that updates the buffers");
+    params.addParam<unsigned int>("substeps", 1, "Solver substeps per time step.");
+    params.addParam<std::vector<TensorOutputBufferName>>("forward_buffer", {}, "Buffers updated from forward_buffer_new");
+    params.addParam<std::vector<TensorInputBufferName>>("forward_buffer_new", {}, "New values to update `forward_buffer` with.");
+    return params;
+  }
+  TensorSolver(const InputParameters & parameters)
+    : TensorOperatorBase(parameters),
+      _substeps(getParam<unsigned int>("substeps")),
+      _substep(0),
+      _sub_dt(_tensor_problem.subDt()),
+      _sub_time(_tensor_problem.subTime()),
+      _dt(_tensor_problem.dt()),
+      _dt_old(_tensor_problem.dtOld())
+  {
+    const auto & to = getParam<std::vector<TensorOutputBufferName>>("forward_buffer");
+    const auto & from = getParam<std::vector<TensorInputBufferName>>("forward_buffer_new");
+    if (to.size() != from.size())
+      paramError("forward_buffer", "needs one forward_buffer_new per entry");
+    for (std::size_t i = 0; i < to.size(); ++i)
+      _forwarded_buffers.emplace_back(getOutputBufferByName(to[i]), getInputBufferByName(from[i]));
+  }
+  virtual void computeBuffer() override
+  {
+    _sub_time = _time;
+    _sub_dt = _dt / _substeps;
+    for (_substep = 0; _substep < _substeps; _substep++)
+    {
+      substep();
+      if (_substep < _substeps - 1)
+        _tensor_problem.advanceState();
+      _sub_time += _sub_dt;
+    }
+  }
+  virtual void updateDependencies() override
+  {
+    if (!isParamValid("root_compute"))
+      return;
+    for (const auto & cmp : _tensor_problem.getComputes())
+      if (cmp->name() == getParam<TensorComputeName>("root_compute"))
+      {
+        _compute = cmp;
+        return;
+      }
+    paramError("root_compute", "Compute object not found.");
+  }
+  virtual bool supportsJIT() const override { return false; }
+
+protected:
+  const std::vector<torch::Tensor> & getBufferOldByName(const TensorInputBufferName & buffer_name, unsigned int max_states)
+  {
+    return _tensor_problem.getBufferOld(buffer_name, max_states);
+  }
+  void forwardBuffers()
+  {
+    for (const auto & fb : _forwarded_buffers)
+      fb.first = fb.second;
+  }
+  virtual void substep() = 0;
+
+  const unsigned int _substeps;
+  unsigned int _substep;
+  Real & _sub_dt;
+  Real & _sub_time;
+  const Real & _dt;
+  const Real & _dt_old;
+  std::shared_ptr<TensorOperatorBase> _compute;
+  std::vector<std::pair<torch::Tensor &, const torch::Tensor &>> _forwarded_buffers;
+};
+
+/// include/tensor_solver/SplitOperatorBase.h:17-37, src/tensor_solver/SplitOperatorBase.C:13-64
+class SplitOperatorBase : public TensorSolver
+{
+public:
+  static InputParameters validParams()
+  {
+    InputParameters params = TensorSolver::validParams();
+    params.addRequiredParam<std::vector<TensorOutputBufferName>>("buffer", "The buffer this solver is writing to");
+    params.addRequiredParam<std::vector<TensorInputBufferName>>("reciprocal_buffer", "Reciprocal of the integrated buffer");
+    params.addRequiredParam<std::vector<TensorInputBufferName>>("linear_reciprocal", "Reciprocal of the linear prefactor");
+    params.addRequiredParam<std::vector<TensorInputBufferName>>("nonlinear_reciprocal", "Reciprocal of the non-linear contribution");
+    return params;
+  }
+  SplitOperatorBase(const InputParameters & parameters) : TensorSolver(parameters) {}
+
+protected:
+  struct Variable
+  {
+    torch::Tensor & _buffer;
+    const torch::Tensor & _reciprocal_buffer;
+    const torch::Tensor * _linear_reciprocal;
+    const torch::Tensor & _nonlinear_reciprocal;
+    const std::vector<torch::Tensor> & _old_nonlinear_reciprocal;
+  };
+  void getVariables(unsigned int history_size)
+  {
+    const auto buffers = getParam<std::vector<TensorOutputBufferName>>("buffer");
+    const auto ubar = getParam<std::vector<TensorInputBufferName>>("reciprocal_buffer");
+    auto lin = getParam<std::vector<TensorInputBufferName>>("linear_reciprocal");
+    const auto nonlin = getParam<std::vector<TensorInputBufferName>>("nonlinear_reciprocal");
+    const auto n = buffers.size();
+    if (lin.empty())
+      lin.assign(n, "0");
+    if (ubar.size() != n || lin.size() != n || nonlin.size() != n)
+      paramError("buffer", "Must have the same number of entries as 'reciprocal_buffer', 'linear_reciprocal' and 'nonlinear_reciprocal'.");
+    for (std::size_t i = 0; i < n; ++i)
+      _variables.push_back(Variable{getOutputBufferByName(buffers[i]),
+                                    getInputBufferByName(ubar[i]),
+                                    lin[i] == "0" ? nullptr : &getInputBufferByName(lin[i]),
+                                    getInputBufferByName(nonlin[i]),
+                                    getBufferOldByName(nonlin[i], history_size)});
+  }
+  std::vector<Variable> _variables;
+};

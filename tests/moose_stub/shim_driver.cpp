@@ -1,0 +1,362 @@
+// TEST INFRASTRUCTURE: runs the reference's regression inputs through the marlin_plugin/ classes (compiled unchanged against
+// moose_stub.h) the way MOOSE's Transient executioner + TensorProblem would: objects are created by type name from parameter blocks,
+// TensorProblem::execute(TIMESTEP_BEGIN) calls the solver, advanceState runs between the time steps.
+//
+//   shim-driver case=cahnhilliard nx=20 ny=20 xmax=3 ymax=3 ic=c0.bin substeps=10 num_steps=10 dt=1e-3 [fuse_substeps=false]
+//               [predictor_order=2] [dt_sequence=a,b,c] out=dir          (test/tests/cahnhilliard/cahnhilliard.i, [TensorSolver] type =
+//               HipAdamsBashforthMoulton with expression / mobility / kappa_factor): writes c.<step>.bin, mu.<step>.bin, Nhat.<step>.bin
+//   shim-driver case=brusselator nx=150 ny=150 xmax=2pi ymax=2pi ss=10 cs=0 order=2 num_steps=25 dt=0.5 out=dir
+//               (test/tests/solvers/diagonal.i: two variables, HipForwardFFT / HipParsedCompute / HipReciprocalLaplacianFactor in the
+//               compute group, HipAdamsBashforthMoulton without `expression`): writes brusselator.csv
+//   shim-driver case=mechanics nx=16 ny=16 nz=16 substeps=10 num_steps=3 dt=0.01 l_tol=1e-2 nl_rel_tol=2e-2 nl_abs_tol=2e-2 out=dir
+//               (test/tests/mechanics/mech3d.i with [mech] type = HipFFTMechanics): writes F.<frame>.bin, stress.<frame>.bin
+// Raw little-endian f64 files, dense row-major, as marlin-hip-run writes them.
+#include "moose_stub.h"
+
+#include <cmath>
+#include <fstream>
+
+static std::map<std::string, std::string> g_args;
+static std::string
+arg(const std::string & k, const std::string & dflt = "")
+{
+  auto it = g_args.find(k);
+  return it == g_args.end() ? dflt : it->second;
+}
+static double
+argd(const std::string & k, double dflt)
+{
+  if (!g_args.count(k))
+    return dflt;
+  const std::string & s = g_args[k];
+  if (s.size() > 2 && s.substr(s.size() - 2) == "pi")
+    return std::atof(s.substr(0, s.size() - 2).c_str()) * M_PI;
+  return std::atof(s.c_str());
+}
+static long
+argi(const std::string & k, long dflt)
+{
+  return g_args.count(k) ? std::atol(g_args[k].c_str()) : dflt;
+}
+
+static void
+dump(const std::string & dir, const std::string & name, int frame, const torch::Tensor & t)
+{
+  torch::Tensor h = t.is_complex() ? torch::view_as_real(t.resolve_conj()) : t;
+  h = h.contiguous().cpu();
+  const std::string path = dir + "/" + name + "." + std::to_string(frame) + ".bin";
+  std::ofstream f(path, std::ios::binary);
+  if (!f)
+    mooseError("cannot write ", path);
+  f.write(reinterpret_cast<const char *>(h.data_ptr<double>()), sizeof(double) * h.numel());
+}
+
+static torch::Tensor
+read_bin(const std::string & path, std::vector<int64_t> shape)
+{
+  torch::Tensor h = torch::empty(shape, torch::kFloat64);
+  std::ifstream f(path, std::ios::binary);
+  if (!f || !f.read(reinterpret_cast<char *>(h.data_ptr<double>()), sizeof(double) * h.numel()))
+    mooseError("cannot read ", h.numel(), " doubles from ", path);
+  return h.to(moose_stub::device());
+}
+
+/// an [object] block of an input file: type + parameters as text
+template <typename T>
+static std::shared_ptr<T>
+create(TensorProblem & problem, const std::string & type, const std::string & name,
+       const std::vector<std::pair<std::string, std::string>> & block)
+{
+  auto it = MooseStubFactory::registry().find(type);
+  if (it == MooseStubFactory::registry().end())
+    mooseError("A '", type, "' is not a registered object");
+  InputParameters params = it->second.valid_params();
+  for (const auto & kv : block)
+    params.setFromString(kv.first, kv.second);
+  params.set<std::string>("_object_name") = name;
+  params.set<TensorProblem *>("_tensor_problem") = &problem;
+  params.checkRequired(name);
+  auto obj = std::dynamic_pointer_cast<T>(it->second.build(params));
+  if (!obj)
+    mooseError(name, ": a '", type, "' is not of the requested base class");
+  return obj;
+}
+
+/// the reference's ForwardEulerSolver with no variables (src/tensor_solver/ForwardEulerSolver.C:28-38; mech3d.i:81-89 uses it that way)
+class StubForwardEulerSolver : public TensorSolver
+{
+public:
+  static InputParameters validParams() { return TensorSolver::validParams(); }
+  StubForwardEulerSolver(const InputParameters & p) : TensorSolver(p) {}
+
+protected:
+  virtual void substep() override
+  {
+    _compute->computeBuffer();
+    forwardBuffers();
+  }
+};
+registerMooseObject("MarlinApp", StubForwardEulerSolver);
+
+/// test/src/tensor_computes/MacroscopicShearTensor.C:31-43
+class StubMacroscopicShearTensor : public TensorOperator<>
+{
+public:
+  static InputParameters validParams()
+  {
+    InputParameters params = TensorOperator<>::validParams();
+    params.addParam<TensorInputBufferName>("F", "F", "Deformation gradient tensor.");
+    return params;
+  }
+  StubMacroscopicShearTensor(const InputParameters & p) : TensorOperator<>(p), _tF(getInputBuffer("F")) {}
+  virtual void computeBuffer() override
+  {
+    std::vector<int64_t> grid_dims;
+    for (unsigned int d = 0; d < _dim; ++d)
+      grid_dims.push_back(d);
+    const auto avg = _tF.sum(grid_dims) / double(_domain.getNumberOfCells());
+    auto applied = torch::eye(_dim, MooseTensor::floatTensorOptions());
+    applied.index_put_({0, 1}, applied.index({0, 1}) + _time);
+    _u = applied - avg;
+  }
+
+private:
+  const torch::Tensor & _tF;
+};
+registerMooseObject("MarlinApp", StubMacroscopicShearTensor);
+
+/// Transient executioner: TransientBase::incrementStepOrReject (t_step += 1, advanceState), takeStep (dt_old = dt), then
+/// TensorProblem::execute(EXEC_TIMESTEP_BEGIN) (TensorProblem.C:176-186: _sub_time = timeOld(), solver->computeBuffer())
+template <typename F>
+static void
+transient(TensorProblem & problem, TensorSolver & solver, const std::vector<double> & dts, F && on_timestep_end)
+{
+  for (std::size_t s = 0; s < dts.size(); ++s)
+  {
+    problem.timeOld() = problem.time();
+    problem.timeStep() += 1;
+    const double dt_prev = problem.dt();
+    problem.dt() = dts[s];
+    problem.dtOld() = problem.timeStep() > 1 ? dt_prev : dts[s];
+    problem.time() = problem.timeOld() + dts[s];
+    problem.advanceState();
+    problem.subTime() = problem.timeOld();
+    solver.computeBuffer();
+    on_timestep_end(problem.timeStep());
+  }
+}
+
+static std::vector<double>
+time_steps()
+{
+  std::vector<double> dts;
+  if (g_args.count("dt_sequence"))
+  {
+    std::istringstream in(g_args["dt_sequence"]);
+    std::string tok;
+    while (std::getline(in, tok, ','))
+      dts.push_back(std::atof(tok.c_str()));
+  }
+  else
+    dts.assign((std::size_t)argi("num_steps", 1), argd("dt", 1.0));
+  return dts;
+}
+
+static DomainAction
+make_domain(unsigned int dim)
+{
+  return DomainAction(dim, {{argi("nx", 1), argi("ny", 1), argi("nz", 1)}}, {{argd("xmin", 0), argd("ymin", 0), argd("zmin", 0)}},
+                      {{argd("xmax", 1), argd("ymax", 1), argd("zmax", 1)}});
+}
+
+static int
+run_cahnhilliard(const std::string & out)
+{
+  const unsigned int dim = g_args.count("nz") ? 3 : 2;
+  DomainAction domain = make_domain(dim);
+  TensorProblem problem(domain);
+  problem.getBuffer("c") = read_bin(arg("ic"), std::vector<int64_t>(domain.getShape().begin(), domain.getShape().end()));
+  // the buffers of cahnhilliard.i's [TensorSolver] block; the compute group's work is the solver's (expression = the [mu] block's)
+  auto solver = create<TensorSolver>(problem, "HipAdamsBashforthMoulton", "solver",
+                                     {{"buffer", "c"},
+                                      {"reciprocal_buffer", "cbar"},
+                                      {"linear_reciprocal", "kappabarbar"},
+                                      {"nonlinear_reciprocal", "Mbarmubar"},
+                                      {"substeps", arg("substeps", "10")},
+                                      {"predictor_order", arg("predictor_order", "2")},
+                                      {"expression", arg("expression", "0.1*c^2*(c-1)^2")},
+                                      {"mobility", arg("mobility", "0.2")},
+                                      {"kappa_factor", arg("kappa_factor", "-0.001")},
+                                      {"chemical_potential", "mu"},
+                                      {"fuse_substeps", arg("fuse_substeps", "true")},
+                                      {"verbose", "true"}});
+  solver->updateDependencies();
+  transient(problem, *solver, time_steps(), [&](int step) {
+    dump(out, "c", step, problem.getBuffer("c"));
+    dump(out, "mu", step, problem.getBuffer("mu"));
+    dump(out, "Nhat", step, problem.getBuffer("Mbarmubar")); // (read through the published view: dense values)
+    std::cout << "step " << step << " time " << problem.time() << " sub_time " << problem.subTime() << " sub_dt " << problem.subDt()
+              << "\n";
+  });
+  return 0;
+}
+
+static int
+run_brusselator(const std::string & out)
+{
+  DomainAction domain = make_domain(2);
+  TensorProblem problem(domain);
+  const std::string cn = "A B", cv = arg("A", "1") + " " + arg("B", "3.5");
+  // [Initialize]
+  create<TensorOperatorBase>(problem, "HipParsedCompute", "u",
+                             {{"buffer", "u"}, {"expression", "sin(x)*sin(y)"}, {"extra_symbols", "true"}, {"expand", "REAL"}})
+      ->computeBuffer();
+  problem.getBuffer("v") = torch::zeros(domain.getShape(), MooseTensor::floatTensorOptions());
+  create<TensorOperatorBase>(problem, "HipReciprocalLaplacianFactor", "Du", {{"buffer", "Du"}, {"factor", arg("Du", "1e-2")}})->computeBuffer();
+  create<TensorOperatorBase>(problem, "HipReciprocalLaplacianFactor", "Dv", {{"buffer", "Dv"}, {"factor", arg("Dv", "1e-3")}})->computeBuffer();
+  // [Solve], in dependency order
+  InputParameters gp;
+  gp.set<std::string>("_object_name") = "root";
+  gp.set<TensorProblem *>("_tensor_problem") = &problem;
+  auto root = std::make_shared<ComputeGroup>(gp);
+  auto fft = [&](const std::string & to, const std::string & from)
+  { root->add(create<TensorOperatorBase>(problem, "HipForwardFFT", to, {{"buffer", to}, {"input", from}})); };
+  auto parsed = [&](const std::string & to, const std::string & expression)
+  {
+    root->add(create<TensorOperatorBase>(problem, "HipParsedCompute", to,
+                                         {{"buffer", to}, {"expression", expression}, {"inputs", "u v"}, {"constant_names", cn},
+                                          {"constant_expressions", cv}}));
+  };
+  fft("u_bar", "u");
+  fft("v_bar", "v");
+  parsed("source_u", "A - (B+1)*u +u^2*v");
+  fft("source_u_bar", "source_u");
+  parsed("source_v", "B*u - u^2*v");
+  fft("source_v_bar", "source_v");
+  problem.computes().push_back(root);
+  auto solver = create<TensorSolver>(problem, "HipAdamsBashforthMoulton", "solver",
+                                     {{"root_compute", "root"},
+                                      {"buffer", "u v"},
+                                      {"reciprocal_buffer", "u_bar v_bar"},
+                                      {"linear_reciprocal", "Du Dv"},
+                                      {"nonlinear_reciprocal", "source_u_bar source_v_bar"},
+                                      {"substeps", arg("ss", "10")},
+                                      {"corrector_steps", arg("cs", "0")},
+                                      {"predictor_order", arg("order", "2")},
+                                      {"corrector_order", arg("order", "2")}});
+  solver->updateDependencies();
+  const double volume = (argd("xmax", 1) - argd("xmin", 0)) * (argd("ymax", 1) - argd("ymin", 0));
+  std::ofstream csv(out + "/brusselator.csv");
+  csv.precision(17);
+  csv << "time,U,V,u_max,u_min,v_max,v_min\n0,0,0,0,0,0,0\n";
+  // TensorIntegralPostprocessor.C:29-38 (average * volume), TensorExtremeValuePostprocessor
+  auto integral = [&](const torch::Tensor & t) { return t.sum().item<double>() / double(domain.getNumberOfCells()) * volume; };
+  transient(problem, *solver, time_steps(), [&](int) {
+    const auto & u = problem.getBuffer("u");
+    const auto & v = problem.getBuffer("v");
+    csv << problem.time() << ',' << integral(u) << ',' << integral(v) << ',' << u.max().item<double>() << ',' << u.min().item<double>()
+        << ',' << v.max().item<double>() << ',' << v.min().item<double>() << "\n";
+  });
+  return 0;
+}
+
+static int
+run_mechanics(const std::string & out)
+{
+  const unsigned int dim = g_args.count("nz") ? 3 : 2;
+  DomainAction domain = make_domain(dim);
+  TensorProblem problem(domain);
+  // [Initialize] of mech3d.i:14-41
+  std::string phase = "(cos(x)/2+0.5)^1*(cos(y)/2+0.5)^1";
+  if (dim == 3)
+    phase += "*(cos(z)/2+0.5)^1";
+  create<TensorOperatorBase>(problem, "HipParsedCompute", "phase",
+                             {{"buffer", "phase"}, {"expression", phase}, {"extra_symbols", "true"}, {"expand", "REAL"}})
+      ->computeBuffer();
+  create<TensorOperatorBase>(problem, "HipParsedCompute", "K",
+                             {{"buffer", "K"}, {"expression", "(1-phase)*Ka + phase*Kb"}, {"inputs", "phase"}, {"constant_names", "Ka Kb"},
+                              {"constant_expressions", arg("Ka", "1") + " " + arg("Kb", "10")}})
+      ->computeBuffer();
+  create<TensorOperatorBase>(problem, "HipParsedCompute", "mu",
+                             {{"buffer", "mu"}, {"expression", "(1-phase)*mua + phase*mub"}, {"inputs", "phase"},
+                              {"constant_names", "mua mub"}, {"constant_expressions", arg("mua", "0.5") + " " + arg("mub", "5")}})
+      ->computeBuffer();
+  {
+    // RankTwoIdentity.C:31-32: an expanded view of eye(dim), not a dense array
+    std::vector<int64_t> shape(domain.getShape().begin(), domain.getShape().end());
+    shape.push_back(dim);
+    shape.push_back(dim);
+    problem.getBuffer("F") = torch::eye(dim, MooseTensor::floatTensorOptions()).expand(shape);
+  }
+  // [Solve] root group of mech3d.i:53-71 with type = HipFFTMechanics (which is FFTMechanics + HyperElasticIsotropic)
+  InputParameters gp;
+  gp.set<std::string>("_object_name") = "root";
+  gp.set<TensorProblem *>("_tensor_problem") = &problem;
+  auto root = std::make_shared<ComputeGroup>(gp);
+  root->add(create<TensorOperatorBase>(problem, "StubMacroscopicShearTensor", "applied_strain", {{"buffer", "applied_strain"}}));
+  std::vector<std::pair<std::string, std::string>> mech = {{"buffer", "Fnew"},
+                                                           {"F", "F"},
+                                                           {"K", "K"},
+                                                           {"mu", "mu"},
+                                                           {"l_tol", arg("l_tol", "1e-2")},
+                                                           {"nl_rel_tol", arg("nl_rel_tol", "1e-5")},
+                                                           {"nl_abs_tol", arg("nl_abs_tol", "1e-8")},
+                                                           {"stress", "stress"},
+                                                           {"applied_macroscopic_strain", "applied_strain"},
+                                                           {"verbose", "true"}};
+  if (g_args.count("l_max_its"))
+    mech.push_back({"l_max_its", arg("l_max_its")});
+  root->add(create<TensorOperatorBase>(problem, "HipFFTMechanics", "mech", mech));
+  problem.computes().push_back(root);
+  auto solver = create<TensorSolver>(problem, "StubForwardEulerSolver", "solver",
+                                     {{"root_compute", "root"}, {"forward_buffer", "F"}, {"forward_buffer_new", "Fnew"},
+                                      {"substeps", arg("substeps", "1")}});
+  solver->updateDependencies();
+  transient(problem, *solver, time_steps(), [&](int step) {
+    dump(out, "F", step - 1, problem.getBuffer("F"));
+    dump(out, "stress", step - 1, problem.getBuffer("stress"));
+  });
+  return 0;
+}
+
+int
+main(int argc, char ** argv)
+{
+  for (int i = 1; i < argc; ++i)
+  {
+    const std::string a = argv[i];
+    const auto eq = a.find('=');
+    if (eq == std::string::npos)
+    {
+      std::cerr << "arguments are key=value\n";
+      return 2;
+    }
+    g_args[a.substr(0, eq)] = a.substr(eq + 1);
+  }
+  try
+  {
+    if (arg("case") == "types") // (no GPU needed: what registerMooseObject has registered)
+    {
+      for (const auto & kv : MooseStubFactory::registry())
+        std::cout << kv.first << "\n";
+      return 0;
+    }
+    if (!torch::cuda::is_available())
+      mooseError("shim-driver needs a GPU (libTorch sees no HIP device)");
+    moose_stub::device() = torch::Device(torch::kCUDA, (c10::DeviceIndex)argi("device", 0));
+    const std::string out = arg("out", ".");
+    const std::string which = arg("case");
+    if (which == "cahnhilliard")
+      return run_cahnhilliard(out);
+    if (which == "brusselator")
+      return run_brusselator(out);
+    if (which == "mechanics")
+      return run_mechanics(out);
+    mooseError("unknown case '", which, "'");
+  }
+  catch (const std::exception & e)
+  {
+    std::cerr << "*** ERROR ***\n" << e.what() << "\n";
+    return 1;
+  }
+}

@@ -101,8 +101,8 @@ def test_launchers_refuse_to_exec_rank_processes_under_a_profiler_preload():
 
 def test_moose_shim_sources_only_call_what_the_abi_declares():
     """marlin_plugin/ (the MOOSE-side classes a Marlin maintainer compiles; INTEGRATION.md quotes them): every mrl_* function, MRL_*
-    constant and mrl_ch_params / mrl_mech_params member they use is declared in include/marlin_hip.h -- the shim cannot be compiled
-    here (no MOOSE), so this is the check that it has not drifted from the ABI"""
+    constant and mrl_ch_params / mrl_mech_params member they use is declared in include/marlin_hip.h (a static check beside
+    the compiled one: tests/moose_stub builds these files, tests/test_moose_shim_gpu.py runs them)"""
     hdr = open(os.path.join(ROOT, "include", "marlin_hip.h")).read()
     plug = os.path.join(ROOT, "marlin_plugin")
     files = [os.path.join(d, f) for d, _, fs in os.walk(plug) for f in fs if f.endswith((".h", ".C"))]
@@ -117,8 +117,30 @@ def test_moose_shim_sources_only_call_what_the_abi_declares():
         for member in set(re.findall(r"\b_p\.([a-z_]+)\b", code)) | set(re.findall(r"\b_prm\.([a-z_]+)\b", code)):
             assert re.search(r"\b%s\b[^;]*;" % member, hdr), (os.path.basename(path), member)
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    for f in ("HipDomain.h", "HipAdamsBashforthMoulton.C", "HipFFTMechanics.C", "marlin_plugin.mk"):
+    for f in ("HipDomain.h", "HipAdamsBashforthMoulton.C", "HipFFTMechanics.C", "HipSpectralComputes.C", "marlin_plugin.mk"):
         assert f in integ, f
+
+
+def test_moose_shim_compiles_against_the_stub_and_registers_its_classes():
+    """tests/moose_stub: the files of marlin_plugin/ compile unchanged against the MOOSE stand-ins + libTorch and link with
+    libmarlin_hip.so (build() makes marlin_amd/lib/shim-driver); registerMooseObject has registered every class INTEGRATION.md names.
+    Without a GPU the driver refuses to run a case (no CPU path behind the shim either)."""
+    import subprocess
+    exe = os.path.join(ROOT, "marlin_amd", "lib", "shim-driver")
+    assert os.path.exists(exe), "shim-driver has not been built (python -c 'import __graft_entry__ as g; g.build()')"
+    r = subprocess.run([exe, "case=types"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    types = set(r.stdout.split())
+    want = {"HipAdamsBashforthMoulton", "HipFFTMechanics", "HipForwardFFT", "HipInverseFFT", "HipParsedCompute",
+            "HipReciprocalLaplacianFactor", "HipReciprocalLaplacianSquareFactor"}
+    assert want <= types, want - types
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for t in want:
+        assert t in integ, t
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "case=cahnhilliard"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "needs a GPU" in r.stderr
 
 
 def test_lds_conflict_model_reproduces_the_measured_shares():

@@ -1,0 +1,136 @@
+"""The MOOSE-side binding (marlin_plugin/*.C, *.h) EXECUTED: its files are compiled unchanged against the stand-ins of
+tests/moose_stub/ (MooseObject / InputParameters / TensorProblem / TensorSolver / SplitOperatorBase / TensorOperator with the
+reference's semantics, real libTorch tensors on the HIP device) and driven by `shim-driver` the way the Transient executioner drives
+the objects of an input file.  The reference's regression inputs then run through `type = HipAdamsBashforthMoulton`,
+`type = HipFFTMechanics`, `type = HipForwardFFT` ... and are diffed against its gold files as its HDF5Diff / CSVDiff testers do."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+RUN = os.path.join(ROOT, "marlin_amd", "lib", "shim-driver")
+
+
+def _run(args, tmp_path):
+    assert os.path.exists(RUN), "shim-driver has not been built (python -c 'import __graft_entry__ as g; g.build()')"
+    out = subprocess.run([RUN] + args + [f"out={tmp_path}"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr + out.stdout
+    return out.stdout
+
+
+def _orders(log):
+    return [int(m) for m in re.findall(r"substep \d+ order (\d+)", log)]
+
+
+@pytest.mark.parametrize("fuse", ["true", "false"])
+def test_cahnhilliard_gold_through_the_shim(fuse, tmp_path):
+    """test/tests/cahnhilliard/tests:46-57 (cahnhilliard.i) with [TensorSolver] type = HipAdamsBashforthMoulton: c.1 .. c.10 and
+    mu.10 of gold cahnhilliard.h5 to 1e-13, with the whole substep loop in one library call (default) and with the inherited
+    TensorSolver::computeBuffer loop over substep().  Default predictor_order = 2: the ten substeps of the first time step are AB1
+    (advanceState is a no-op while timeStep() <= 1), every later one AB2; _sub_dt = _dt / substeps and _sub_time ends at the step's
+    time (TensorSolver.C:95-96,108)."""
+    g = load_golden("cahnhilliard_gold.npz")
+    ic = tmp_path / "c0.bin"
+    g["c.0"][:20, :20].astype("<f8").tofile(ic)
+    log = _run(["case=cahnhilliard", "nx=20", "ny=20", "xmax=3", "ymax=3", f"ic={ic}", "substeps=10", "num_steps=10", "dt=1e-3",
+                f"fuse_substeps={fuse}"], tmp_path)
+    assert _orders(log) == [0] * 10 + [1] * 90
+    steps = re.findall(r"step (\d+) time (\S+) sub_time (\S+) sub_dt (\S+)", log)
+    assert len(steps) == 10
+    for k, t, st, sdt in steps:
+        assert abs(float(sdt) - 1e-4) <= 1e-19 and abs(float(st) - float(t)) <= 1e-15 and abs(float(t) - int(k) * 1e-3) <= 1e-15
+    worst = 0.0
+    for k in range(1, 11):
+        c = np.fromfile(tmp_path / f"c.{k}.bin", dtype="<f8").reshape(20, 20)
+        worst = max(worst, np.abs(g[f"c.{k}"][:20, :20] - c).max())
+    assert worst <= 1e-13, worst
+    mu = np.fromfile(tmp_path / "mu.10.bin", dtype="<f8").reshape(20, 20)
+    assert np.abs(g["mu.10"] - mu).max() <= 1e-13
+
+
+@pytest.mark.parametrize("fuse", ["true", "false"])
+@pytest.mark.parametrize("pred", [1, 3])
+def test_cahnhilliard_adaptive_dt_through_the_shim(fuse, pred, tmp_path):
+    """a time step size that changes between steps (AdamsBashforthMoulton.C:75,88-91: the first predictor_order - 1 substeps of such a
+    step run at first order), predictor_order = 1 (which the round-4 shim turned into an invalid-argument error) and 3, against the
+    oracle: fields 1e-13, the order of every substep equal to the oracle's log"""
+    import torch
+    from oracle import marlin_oracle as mo
+    torch.manual_seed(3)
+    shape, L = [20, 20], [3.0, 3.0]
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    ic = tmp_path / "c0.bin"
+    c0.numpy().astype("<f8").tofile(ic)
+    dts, substeps = [1e-3, 1e-3, 2e-3, 2e-3, 5e-4], 4
+    log = _run(["case=cahnhilliard", "nx=20", "ny=20", "xmax=3", "ymax=3", f"ic={ic}", f"substeps={substeps}",
+                "dt_sequence=" + ",".join(repr(d) for d in dts), f"predictor_order={pred}", f"fuse_substeps={fuse}"], tmp_path)
+    ref = mo.CahnHilliardABM(mo.Domain(2, shape, L), c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=substeps,
+                             predictor_order=pred)
+    for k, dt in enumerate(dts):
+        ref.step(dt)
+        c = np.fromfile(tmp_path / f"c.{k + 1}.bin", dtype="<f8").reshape(20, 20)
+        assert np.abs(ref.c.numpy() - c).max() <= 1e-13
+    assert _orders(log) == ref.order_log
+
+
+@pytest.mark.parametrize("fuse", ["true", "false"])
+def test_cahnhilliard_3d_private_spectral_layout_through_the_shim(fuse, tmp_path):
+    """64^3 is a fast-path shape: the Nhat history lives in the solver-private layout (x planes padded to an odd number of 256-byte
+    pieces).  The shim publishes it as a strided view, TensorBuffer::advanceState moves those handles into the history, and the
+    substep finds them again -- AB3 over three time steps against the oracle, and the published Mbarmubar values == the oracle's"""
+    import torch
+    from oracle import marlin_oracle as mo
+    torch.manual_seed(5)
+    n, L = 64, 3.0
+    c0 = torch.rand([n] * 3, dtype=torch.float64) * 0.12 + 0.44
+    ic = tmp_path / "c0.bin"
+    c0.numpy().astype("<f8").tofile(ic)
+    log = _run(["case=cahnhilliard", f"nx={n}", f"ny={n}", f"nz={n}", f"xmax={L}", f"ymax={L}", f"zmax={L}", f"ic={ic}", "substeps=3",
+                "num_steps=3", "dt=1e-3", "predictor_order=3", f"fuse_substeps={fuse}"], tmp_path)
+    ref = mo.CahnHilliardABM(mo.Domain(3, [n] * 3, [L] * 3), c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=3,
+                             predictor_order=3)
+    for k in range(3):
+        ref.step(1e-3)
+        c = np.fromfile(tmp_path / f"c.{k + 1}.bin", dtype="<f8").reshape(n, n, n)
+        assert np.abs(ref.c.numpy() - c).max() <= 1e-13
+        nh = np.fromfile(tmp_path / f"Nhat.{k + 1}.bin", dtype="<f8").reshape(n, n, n // 2 + 1, 2)
+        want = torch.view_as_real(ref.Nhat).numpy()
+        assert np.abs(want - nh).max() <= 2e-15 * np.abs(want).max() * n ** 3      # (the spectra tolerance of tests/test_fft_gpu.py)
+    assert _orders(log) == ref.order_log == [0, 0, 0, 1, 2, 2, 2, 2, 2]
+
+
+@pytest.mark.parametrize("ss,cs,order", [(10, 0, 1), (10, 0, 2), (10, 0, 3), (20, 0, 4), (10, 1, 1), (10, 2, 1), (10, 2, 2)])
+def test_brusselator_gold_through_the_shim(ss, cs, order, tmp_path):
+    """test/tests/solvers/tests (diagonal.i, CSVDiff): two variables, the compute group made of HipForwardFFT / HipParsedCompute,
+    the linear operators from HipReciprocalLaplacianFactor, [TensorSolver] type = HipAdamsBashforthMoulton without `expression`
+    (mrl_kspace_abm per variable, AdamsBashforthMoulton.C:80-101, corrector :117-177) against diagonal_<ss>_<cs>_<order>.csv"""
+    g = load_golden("solvers_gold.npz")[f"diagonal_{ss}_{cs}_{order}"]
+    _run(["case=brusselator", "nx=150", "ny=150", "xmax=2pi", "ymax=2pi", f"ss={ss}", f"cs={cs}", f"order={order}", "num_steps=25",
+          "dt=0.5"], tmp_path)
+    got = np.loadtxt(tmp_path / "brusselator.csv", delimiter=",", skiprows=1)
+    assert got.shape == g.shape
+    assert np.allclose(got[:, 0], g[:, 0])
+    err = np.abs(got[1:, 1:] - g[1:, 1:]) / np.maximum(1.0, np.abs(g[1:, 1:]))
+    assert err.max() <= 5e-11, err.max()
+
+
+def test_mech3d_gold_through_the_shim(tmp_path):
+    """test/tests/mechanics/tests:2-11 (mech3d.i) with [mech] type = HipFFTMechanics inside the root group of a ForwardEulerSolver
+    that forwards Fnew -> F: F_k.frame of gold mech3d.h5 to 1e-10, two Newton iterations per substep as the reference"""
+    g = load_golden("mech3d_gold.npz")
+    n = 16
+    log = _run(["case=mechanics", "nx=16", "ny=16", "nz=16", "xmax=2pi", "ymax=2pi", "zmax=2pi", "substeps=10", "num_steps=3", "dt=0.01",
+                "l_tol=1e-2", "nl_rel_tol=2e-2", "nl_abs_tol=2e-2"], tmp_path)
+    its = [int(m) for m in re.findall(r"(\d+) Newton iterations", log)]
+    assert len(its) == 30 and set(its) == {2}
+    worst = 0.0
+    for frame in range(3):
+        F = np.fromfile(tmp_path / f"F.{frame}.bin", dtype="<f8").reshape(n, n, n, 9)
+        for k in range(9):
+            worst = max(worst, np.abs(g[f"F_{k}.{frame}"] - np.transpose(F[..., k], (2, 1, 0))).max())   # XDMF default transpose
+    assert worst <= 1e-10, worst
