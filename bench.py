@@ -303,7 +303,7 @@ def _free_port():
 
 def _count_gpus_without_hip():
     """GPU count from the KFD topology in sysfs (nodes with SIMDs are GPUs): no HIP / torch call, so the launcher really makes no GPU
-    call (torch.cuda.device_count can fall back to hipGetDeviceCount).  Respects HIP_/ROCR_VISIBLE_DEVICES lists."""
+    call (torch.cuda.device_count can fall back to hipGetDeviceCount).  Respects HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES lists."""
     n = 0
     root = "/sys/class/kfd/kfd/topology/nodes"
     try:
@@ -317,7 +317,7 @@ def _count_gpus_without_hip():
                 pass
     except OSError:
         n = 0
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):   # (HIP honours all three)
         v = os.environ.get(var)
         if v is not None and v.strip() != "":
             n = min(n, len([x for x in v.split(",") if x.strip() != ""])) if n else len([x for x in v.split(",") if x.strip() != ""])

@@ -33,6 +33,7 @@ struct SymBuf {  // a device allocation of the same size on every rank, mapped b
   void *local = nullptr;
   size_t bytes = 0;
   std::vector<void *> peer;  // peer[p] = address of rank p's allocation in THIS process (peer[rank] = local)
+  std::vector<char> ipc_mapped;  // peer[p] came from hipIpcOpenMemHandle (to be closed); 0: rank p lives in this process (a thread), peer[p] is its pointer
 };
 
 // One exchange endpoint: a symmetric receive buffer, an optional local send buffer, one arrival channel.

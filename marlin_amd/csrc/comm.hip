@@ -125,6 +125,8 @@ int comm_allreduce_host(mrl_comm *c, double *v, int n, int op) {
   return MRL_OK;
 }
 
+static inline int side_stream_count(int nranks) { return nranks < 8 ? nranks : 8; }
+
 // ---- symmetric device memory ------------------------------------------------------------------------------------------
 // hipIpcOpenMemHandle under a watchdog.  With two rank processes on one GPU and exchange buffers of 4.4 + 2.2 GB the call was seen
 // never to return for the second buffer (reproducibly inside this library, not in tools/ipc_probe.hip with the same sizes; cause not
@@ -209,6 +211,15 @@ int sym_alloc(mrl_comm *c, size_t bytes, SymBuf *out, bool uncached) {
     COMM_TRY(comm_allreduce_host(c, &v, 1, 1));
     if (v != 0.0) {
       COMM_TRY(comm_allgather(c, &mine, sizeof(mine), all));
+      // ranks that are THREADS of one process (the in-process jobs of tests/test_slab_native_gpu.py: eight ranks on one GPU, where
+      // the box admits six processes; any host application that drives several contexts itself): HIP IPC cannot import a handle
+      // into the process that exported it, and does not need to -- the peer's pointer is valid here as it stands
+      struct Where {
+        long long pid;
+        void *ptr;
+      } here{(long long)getpid(), p}, where[kMaxRanks];
+      COMM_TRY(comm_allgather(c, &here, sizeof(here), where));
+      out->ipc_mapped.assign(c->nranks, 0);
       MRL_TRACE("sym_alloc: handles exchanged, mapping the peers");
       // one rank at a time: with dmabuf IPC the importer obtains the buffer from the exporting PROCESS, and two ranks that map each
       // other's multi-GB buffers at the same moment were seen to block each other for good inside hipIpcOpenMemHandle (512 x 1024 x
@@ -217,12 +228,17 @@ int sym_alloc(mrl_comm *c, size_t bytes, SymBuf *out, bool uncached) {
         if (turn == c->rank) {
           for (int q = 0; q < c->nranks && ok; ++q) {
             if (q == c->rank) continue;
+            if (where[q].pid == here.pid) {
+              out->peer[q] = where[q].ptr;
+              continue;
+            }
             void *m = nullptr;
             if (!ipc_open_bounded(c, all[q], &m)) {
               ok = 0;
               break;
             }
             out->peer[q] = m;
+            out->ipc_mapped[q] = 1;
           }
         }
         COMM_TRY(comm_barrier(c));
@@ -234,7 +250,7 @@ int sym_alloc(mrl_comm *c, size_t bytes, SymBuf *out, bool uncached) {
     }
     // undo this attempt on every rank
     for (int q = 0; q < c->nranks; ++q)
-      if (q != c->rank && out->peer[q]) (void)hipIpcCloseMemHandle(out->peer[q]);
+      if (q != c->rank && out->peer[q] && q < (int)out->ipc_mapped.size() && out->ipc_mapped[q]) (void)hipIpcCloseMemHandle(out->peer[q]);
     COMM_TRY(comm_barrier(c));
     if (p) (void)hipFree(p);
     out->local = nullptr;
@@ -250,7 +266,7 @@ int sym_free(mrl_comm *c, SymBuf *b) {
   int rc = MRL_OK;
   if (c->nranks > 1) rc = comm_barrier(c);  // nobody is still writing into it
   for (int q = 0; q < (int)b->peer.size(); ++q)
-    if (q != c->rank && b->peer[q]) (void)hipIpcCloseMemHandle(b->peer[q]);
+    if (q != c->rank && b->peer[q] && q < (int)b->ipc_mapped.size() && b->ipc_mapped[q]) (void)hipIpcCloseMemHandle(b->peer[q]);
   if (c->nranks > 1 && rc == MRL_OK) rc = comm_barrier(c);  // every mapping is closed before the owner frees
   (void)hipFree(b->local);
   b->local = nullptr;
@@ -597,7 +613,7 @@ int xchg_create(mrl_comm *c, Xchg *x, const size_t *send_cnt, const size_t *recv
   COMM_HIP(c, hipMemset(x->d_counter, 0, 64));
   COMM_HIP(c, hipEventCreateWithFlags(&x->rccl_done, hipEventDisableTiming));
   COMM_HIP(c, hipEventCreateWithFlags(&x->release_ev, hipEventDisableTiming | hipEventReleaseToSystem));
-  x->copy_done.resize(c->side.size());
+  x->copy_done.resize(side_stream_count(c->nranks));
   for (auto &e : x->copy_done) COMM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return MRL_OK;
 }
@@ -658,6 +674,21 @@ SignalArgs xchg_signal_args(const mrl_comm *c, const Xchg *x, unsigned int nbloc
   return s;
 }
 
+// Side streams: one per peer offset (copy-engine pushes) / the RCCL stream.  Created on first use: a communicator whose exchanges are
+// peer stores needs none, and every stream of a process takes a slot in the round-robin over its hardware queues -- with several
+// ranks as THREADS of one process (tests) 8 idle side streams per rank put the ranks' main streams, whose wait kernels spin, on
+// shared queues.
+static int ensure_side_streams(mrl_comm *c) {
+  if (!c->side.empty()) return MRL_OK;
+  const int ns = side_stream_count(c->nranks);
+  for (int i = 0; i < ns; ++i) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return comm_error(c, MRL_ERR_HIP, "hipStreamCreate failed");
+    c->side.push_back(s);
+  }
+  return MRL_OK;
+}
+
 int xchg_post(mrl_comm *c, Xchg *x, hipStream_t stream, bool kernel_signalled) {
   const int P = c->nranks, me = c->rank;
   x->epoch += 1;
@@ -677,6 +708,7 @@ int xchg_post(mrl_comm *c, Xchg *x, hipStream_t stream, bool kernel_signalled) {
     return MRL_OK;
   }
   if (!x->send && x->send_bytes) return comm_error(c, MRL_ERR_INVALID, "exchange posted without a send buffer");
+  COMM_TRY(ensure_side_streams(c));
   if (c->transport == MRL_TRANSPORT_RCCL) {
     COMM_TRY(rccl_init(c));
     hipStream_t rs = c->side[0];
@@ -880,16 +912,7 @@ int mrl_comm_create(mrl_comm **out, const char *name, int32_t nranks, int32_t ra
 
   if (device_census(c) != MRL_OK) return fail(MRL_ERR_COMM);
 
-  // side streams: one per peer offset (copy engines) / the RCCL stream
-  const int ns = nranks < 8 ? nranks : 8;
-  for (int i = 0; i < ns; ++i) {
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
-      comm_error(c, MRL_ERR_HIP, "hipStreamCreate failed");
-      return fail(MRL_ERR_HIP);
-    }
-    c->side.push_back(s);
-  }
+  // (side streams: created by the first exchange that pushes or uses RCCL, ensure_side_streams)
   if (hipEventCreateWithFlags(&c->ev_prod, hipEventDisableTiming) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void **>(&c->h_status), sizeof(int)) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void **>(&c->h_mbox), sizeof(double) * 16) != hipSuccess) {

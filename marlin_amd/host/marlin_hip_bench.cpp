@@ -279,6 +279,122 @@ static std::string comm_devices_json(mrl_comm * comm)
   return e ? std::string(p, e + 1) : "[]";
 }
 
+// The denominators of the parallel efficiency, measured IN THE SAME JOB: rank 0 runs the serial path (one
+// context without a communicator, the N = 1 code) of grid g on its own GPU while the other ranks wait at a host barrier.  Soft
+// failure: a grid that does not fit the free memory of the card is reported as such, never fatal.
+struct SerialRef
+{
+  bool ok = false;
+  double ms = 0.0;
+  int64_t g[3] = {0, 0, 0};
+  std::string why;
+};
+static SerialRef serial_reference(int device, const int64_t g[3], const mrl_ch_params & p, double sub_dt, int steps)
+{
+  SerialRef out;
+  for (int i = 0; i < 3; ++i)
+    out.g[i] = g[i];
+  const double nreal = (double)g[0] * (double)g[1] * (double)g[2];
+  const double hspec = 16.0 * (double)g[0] * (double)g[1] * (double)(g[2] / 2 + 1);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    out.why = "hipMemGetInfo failed";
+    return out;
+  }
+  // two real fields, two history arrays, the context's work arrays (four spectra) + slack
+  const double need = 2.0 * 8.0 * nreal + 6.5 * hspec;
+  if (need > 0.9 * (double)free_b)
+  {
+    out.why = "needs " + jnum(need / 1e9) + " GB of device memory, " + jnum((double)free_b / 1e9) + " GB free on rank 0's card";
+    return out;
+  }
+  mrl_domain d{};
+  d.dim = 3;
+  const double dx = 8.0 * M_PI / 200.0;
+  for (int i = 0; i < 3; ++i)
+  {
+    d.n[i] = g[i];
+    d.min[i] = 0.0;
+    d.max[i] = (double)g[i] * dx;
+  }
+  d.device = device;
+  d.nranks = 1;
+  d.spectrum = MRL_SPECTRUM_HALF;
+  mrl_ctx * ctx = nullptr;
+  if (mrl_ctx_create(&ctx, &d) != MRL_OK)
+  {
+    out.why = std::string("mrl_ctx_create: ") + mrl_last_error(nullptr);
+    return out;
+  }
+  double * c[2] = {nullptr, nullptr};
+  double * ring[2] = {nullptr, nullptr};
+  const size_t nr = (size_t)nreal, ns2 = 2 * (size_t)mrl_ch_spec_elems(ctx);
+  bool alloc = true;
+  for (int k = 0; k < 2; ++k)
+  {
+    alloc = alloc && hipMalloc(reinterpret_cast<void **>(&c[k]), sizeof(double) * nr) == hipSuccess;
+    alloc = alloc && hipMalloc(reinterpret_cast<void **>(&ring[k]), sizeof(double) * ns2) == hipSuccess;
+    if (alloc)
+      alloc = hipMemset(ring[k], 0, sizeof(double) * ns2) == hipSuccess;
+  }
+  if (alloc)
+  {
+    std::vector<double> ic(nr);
+    for (size_t i = 0; i < nr; ++i)
+      ic[i] = splitmix((uint64_t)i);
+    alloc = hipMemcpy(c[0], ic.data(), sizeof(double) * nr, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (!alloc)
+  {
+    (void)hipGetLastError();
+    out.why = "device allocation failed";
+  }
+  else
+  {
+    int head = 1, n_old = 0, cur = 0, rc = MRL_OK;
+    auto run = [&](int count) {
+      rc = mrl_ch_substeps(ctx, &p, c[cur], c[1 - cur], ring, 2, &head, &n_old, 2, count, MRL_SUBSTEPS_ADVANCE, sub_dt, nullptr);
+      cur = 1 - cur;
+      head = (head + 1) % 2;
+      n_old = 1;
+    };
+    run(5);
+    std::vector<double> t;
+    const double t_warm = now_s();
+    while (rc == MRL_OK && now_s() - t_warm < 0.15)  // clocks
+      run(steps);
+    (void)mrl_sync(ctx);
+    for (int r = 0; r < 5 && rc == MRL_OK; ++r)
+    {
+      (void)hipDeviceSynchronize();
+      const double t0 = now_s();
+      run(steps);
+      if (rc == MRL_OK)
+        rc = mrl_sync(ctx);
+      t.push_back((now_s() - t0) / steps * 1e3);
+    }
+    if (rc != MRL_OK)
+      out.why = std::string("mrl_ch_substeps: ") + mrl_last_error(ctx);
+    else
+    {
+      std::sort(t.begin(), t.end());
+      out.ms = t[t.size() / 2];
+      out.ok = true;
+    }
+  }
+  for (int k = 0; k < 2; ++k)
+  {
+    if (c[k])
+      (void)hipFree(c[k]);
+    if (ring[k])
+      (void)hipFree(ring[k]);
+  }
+  mrl_ctx_destroy(ctx);
+  return out;
+}
+
 static int run_ch(Rank & R)
 {
   const int steps = (int)argi("steps", 100), warmup = (int)argi("warmup", 10);
@@ -358,12 +474,14 @@ static int run_ch(Rank & R)
         if (nsub_user && ns != nsub_user)
           continue;
         cands.push_back({MRL_TRANSPORT_PEER_STORE, ns, 0, "event-ordered flags"});
+        cands.push_back({MRL_TRANSPORT_PEER_COPY, ns, 0, ""});
+        // (RCCL before the in-kernel-flag variant: every multi-device job times the RCCL candidate at least once inside the budget
+        // and reports runtime.rccl_comm_nranks, whichever transport wins)
+        cands.push_back({MRL_TRANSPORT_RCCL, ns, 0, ""});
         // in-kernel arrival flags: 3 x slower than event-ordered ones in every run on one device (one L2 write-back per workgroup);
         // only worth a slot where the stores really cross a link
         if (distinct_devices > 1 || argi("tune_in_kernel_flags", 0) != 0)
           cands.push_back({MRL_TRANSPORT_PEER_STORE, ns, 128, "in-kernel flags"});
-        cands.push_back({MRL_TRANSPORT_PEER_COPY, ns, 0, ""});
-        cands.push_back({MRL_TRANSPORT_RCCL, ns, 0, ""});
       }
     }
     else
@@ -583,6 +701,7 @@ static int run_ch(Rank & R)
 
   // ---- variants --------------------------------------------------------------------------------------------------------------
   std::ostringstream var;
+  double local_only_ms = NAN;
   if (variants && R.slab)
   {
     const int k = std::min(steps, 40);
@@ -594,10 +713,30 @@ static int run_ch(Rank & R)
     ch_reset(S);
     R.ck(ch_run(R, S, p, 3, sub_dt), "local-only variant");
     const double ms_l = timed(k, k) / k * 1e3;
+    local_only_ms = ms_l;
     set_opts(sel_nsub, sel_exp, carry);
     var << "{\"spectral_carry_over_" << (carry ? "off" : "on") << "\": {\"ms_per_step\": " << jnum(ms_c) << ", \"value\": " << jnum(npts / (ms_c * 1e-3))
         << "}, \"local_kernels_only\": {\"ms_per_step\": " << jnum(ms_l) << ", \"value\": " << jnum(npts / (ms_l * 1e-3))
         << ", \"note\": \"the same launches without any exchange or wait: what the rank-local work costs\"}}";
+  }
+
+  // ---- parallel efficiency: both denominators from this job ------------------------------------------------------------------
+  SerialRef ref_weak, ref_strong;
+  if (R.slab && R.world > 1 && argi("efficiency", 1) != 0)
+  {
+    HIPCK(hipDeviceSynchronize());
+    R.barrier();
+    if (R.rank == 0)
+    {
+      const int k = std::min(std::max(steps, 4), 20);
+      const int64_t base[3] = {n, n, n};
+      if (!G)
+        ref_weak = serial_reference(R.device, base, p, sub_dt, k);  // what ONE GPU does with one rank's share of the points
+      ref_strong = serial_reference(R.device, R.shape, p, sub_dt, k);  // what ONE GPU does with the whole grid of this job
+    }
+    mrl_comm_set_timeout(R.comm, 600.0);
+    R.barrier();
+    mrl_comm_set_timeout(R.comm, 120.0);
   }
 
   // devices per rank (all-gathered through the 16-value host all-reduce: sums of one-hot rows)
@@ -698,6 +837,30 @@ static int run_ch(Rank & R)
     }
     if (!var.str().empty())
       o << ", \"variants\": " << var.str();
+    if (R.slab)
+    {
+      // the two readings of north_star's "parallel efficiency on 512^3": WEAK = against one GPU doing one rank's share (grid^3
+      // points), STRONG = against one GPU doing this job's whole grid.  efficiency = value(N) / (N * value(1)); both value(1)
+      // were measured by rank 0 in this job (serial context, same kernels as the N = 1 line), nothing is taken from a file.
+      auto side = [&](const char * name, const SerialRef & r) {
+        o << "\"" << name << "\": ";
+        if (r.ok)
+        {
+          const double pts = (double)r.g[0] * (double)r.g[1] * (double)r.g[2], v1 = pts / (r.ms * 1e-3);
+          o << "{\"efficiency\": " << jnum(value / ((double)R.world * v1)) << ", \"one_gpu\": {\"grid\": [" << r.g[0] << ", " << r.g[1] << ", "
+            << r.g[2] << "], \"ms_per_step\": " << jnum(r.ms) << ", \"value\": " << jnum(v1) << "}}";
+        }
+        else
+          o << "{\"efficiency\": null, \"why\": " << jstr(r.why.empty() ? (R.world > 1 ? "not measured" : "one rank") : r.why) << "}";
+      };
+      o << ", \"parallel_efficiency\": {";
+      side("weak", ref_weak);
+      o << ", ";
+      side("strong", ref_strong);
+      o << ", \"definition\": \"value(N) / (N * value(1)); value(1) measured by rank 0 of this job on its own GPU with the serial path while the "
+           "other ranks waited: weak = one GPU on one rank's share of the points (grid^3), strong = one GPU on this job's whole grid\"}";
+      o << ", \"local_kernels_only_ms\": " << jnum(local_only_ms) << ", \"exposed_wait_ms_per_step\": " << jnum(waits);
+    }
     o << ", \"field_checksum\": {\"sum_c_squared\": " << jnum(cs) << "}}";
     std::printf("%s\n", o.str().c_str());
     std::fflush(stdout);

@@ -36,8 +36,10 @@ def test_bench_two_ranks_without_a_launcher():
     ex = j["exchange"]
     assert ex["ranks"] == 2 and len(ex["devices_per_rank"]) == 2
     # (two exchanges per substep and kz sub-block: the two-field forward one and the inverse one; the tuning picks 1, 2 or 4 sub-blocks)
-    assert ex["bytes_sent_to_peers_per_step_rank0"] > 0 and ex["exchanges_per_step"] >= 2
     assert ex["transport"]["selected"] in ("peer_store", "peer_copy", "rccl") and ex["transport"]["nsub"] in (1, 2, 4)
+    # exactly two exchanges per substep and kz sub-block (reference data flow: the two-field forward one and the inverse one) over the
+    # timed regions: a window that dropped or double-counted an exchange would not give the integer
+    assert ex["bytes_sent_to_peers_per_step_rank0"] > 0 and abs(ex["exchanges_per_step"] - 2 * ex["transport"]["nsub"]) <= 1e-9
     # every tuned candidate that ran agrees on the field checksum, and the consumers' system-scope re-reads found nothing stale
     ran = [c for c in ex["transport"]["tuned"] if "ms_per_step" in c]
     assert len(ran) >= 2 and all(c["checksum_agrees"] for c in ran)
@@ -55,6 +57,15 @@ def test_bench_two_ranks_without_a_launcher():
     assert ex["runtime"]["rccl_status"].startswith("unavailable:") and ex["runtime"]["rccl_unique_id_hash"]
     assert 0.0 < ex["transport"]["tuning_s"] <= ex["transport"]["tune_budget_s"] + 30.0
     assert len(j["repeats_ms"]) == 7 and "MEDIAN" in j["timing_protocol"]
+    # both denominators of the parallel efficiency measured inside the job, the rank-local cost and the exposed
+    # waits at the top level (two ranks sharing ONE card: the numbers are a functional record, not a scaling result)
+    pe = j["parallel_efficiency"]
+    assert pe["weak"]["one_gpu"]["grid"] == [64, 64, 64] and pe["strong"]["one_gpu"]["grid"] == [64, 128, 64]
+    for side in ("weak", "strong"):
+        one = pe[side]["one_gpu"]
+        assert one["ms_per_step"] > 0 and abs(pe[side]["efficiency"] - j["value"] / (2 * one["value"])) <= 1e-9 * pe[side]["efficiency"]
+    assert j["local_kernels_only_ms"] > 0 and j["exposed_wait_ms_per_step"] >= 0
+    assert "rccl_comm_nranks" in ex["runtime"]
 
 
 def test_bench_two_ranks_under_torch_distributed_run():

@@ -262,3 +262,5 @@ def test_rccl_bring_up_is_exercised_up_to_comm_init_on_one_gpu():
             assert d["distinct_devices"] == 1 and len(d["devices_per_rank"]) == P and len(set(d["devices_per_rank"])) == 1, d
             assert d["rccl_comm_nranks"] == -1
             assert r["allreduce"] == [P * (P + 1) / 2.0]
+
+
