@@ -680,7 +680,10 @@ static int newton_cg_impl(mrl_ctx *ctx, const mrl_mech_params *prm, const double
   // at 0.61 ms).  The convergence test of MarlinUtils.h:118-121 is taken on the device (k_reduce_final_cg); once it holds, every kernel
   // of the iterations enqueued ahead returns at once, so x, p, r and the scalars are exactly those of the converged iteration: same
   // iteration count, same solution as with the blocking read (experiment bit 1 << 26 restores it, A/B).
-  const bool look = fuse_dir && !dist && ctx->d_h_red != nullptr && !(ctx->exp & (1 << 26));
+  // (not while the per-kernel profile is being taken: the iteration enqueued past convergence launches kernels that return at once,
+  // and their microsecond launches would be averaged into the profile slots as if they had moved their algorithmic bytes -- ADVICE r04;
+  // the timed solves run with the look-ahead, the profile pass with the blocking read, same iteration counts and fields)
+  const bool look = fuse_dir && !dist && ctx->d_h_red != nullptr && !(ctx->exp & (1 << 26)) && !ctx->profiling;
   int *stop = reinterpret_cast<int *>(S + 8);
   if (look) {
     for (int e = 0; e < 2; ++e)

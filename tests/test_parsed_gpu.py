@@ -216,3 +216,96 @@ def test_reference_unit_test_constants(ctx):
     assert (_pc(ctx, "sin(x) + pi * e", inputs=["x"], constants=K)(x) - (torch.sin(x) + math.pi * math.e)).abs().max().item() <= 1e-12
     assert (_pc(ctx, "x * pi", inputs=["x"], constants={"pi": math.pi}, derivatives=["x"])(x) - math.pi).abs().max().item() <= 1e-12
     assert (_pc(ctx, "a := x * pi; a + a", inputs=["x"], constants={"pi": math.pi})(x) - 2.0 * x * math.pi).abs().max().item() <= 1e-12
+
+
+# ---- TEST(ParsedTensorTest, Parse), unit/src/ParsedTensorTest.C:19-205, case by case ---------------------------------------------
+# (expression, gold as the reference writes it in libTorch, derivative_check) -- x = linspace(0.1, 2.01, 11)[:, None],
+# y = linspace(0.11, 3.02, 15)[None, :], n = max(x*y)*1.01, broadcast to the 11 x 15 grid (the library evaluates full-size arrays)
+_PARSE_CASES = [
+    ("hypot(x,y)", lambda x, y, n: torch.hypot(x, y), True),
+    ("sqrt(x^2+y^2+n)", lambda x, y, n: torch.sqrt(x * x + y * y + n), True),
+    ("sqrt(x*x+y*y+n)", lambda x, y, n: torch.sqrt(x * x + y * y + n), True),
+    ("sqrt(x^2+y^2)", lambda x, y, n: torch.sqrt(x * x + y * y), True),
+    ("sqrt(x*x+y*y)", lambda x, y, n: torch.sqrt(x * x + y * y), True),
+    ("tan((x-y)/2)", lambda x, y, n: torch.tan((x - y) / 2.0), True),
+    ("tanh(x-y)", lambda x, y, n: torch.tanh(x - y), True),
+    ("cos(y)", lambda x, y, n: torch.cos(y) + 0 * x, True),
+    ("sin(y)", lambda x, y, n: torch.sin(y) + 0 * x, True),
+    ("cosh(y)", lambda x, y, n: torch.cosh(y) + 0 * x, True),
+    ("sinh(y)", lambda x, y, n: torch.sinh(y) + 0 * x, True),
+    ("atan(x + y)", lambda x, y, n: torch.atan(x + y), True),
+    ("asin((x * y / 2) / n)", lambda x, y, n: torch.asin((x * y / 2.0) / n), True),
+    ("acos((x * y / 2) / n)", lambda x, y, n: torch.acos((x * y / 2.0) / n), True),
+    ("acosh(x+y+1)", lambda x, y, n: torch.acosh(x + y + 1), True),
+    ("asinh(x-y)", lambda x, y, n: torch.asinh(x - y), True),
+    ("atan2(x,y)", lambda x, y, n: torch.atan2(x, y), True),
+    ("1/sqrt(x+y)", lambda x, y, n: 1.0 / torch.sqrt(x + y), True),
+    ("sin(y)-cos(y)", lambda x, y, n: torch.sin(y) - torch.cos(y) + 0 * x, True),
+    ("(x * y) / n", lambda x, y, n: (x * y) / n, True),
+    ("y/x", lambda x, y, n: y / x, False),
+    ("-x", lambda x, y, n: -x + 0 * y, True),
+    ("rsqrt(x*y)", lambda x, y, n: 1.0 / torch.sqrt(x * y), True),
+    ("exp(x*y)", lambda x, y, n: torch.exp(x * y), True),
+    ("exp2(x*y)", lambda x, y, n: torch.pow(2.0, x * y), True),
+    ("(x*y) % 1.5", lambda x, y, n: torch.remainder(x * y, 1.5), True),
+    ("log(x)", lambda x, y, n: torch.log(x) + 0 * y, True),
+    ("log10(x)", lambda x, y, n: torch.log10(x) + 0 * y, True),
+    ("log2(x)", lambda x, y, n: torch.log2(x) + 0 * y, True),
+    ("pow(y, x)", lambda x, y, n: torch.pow(y, x), True),
+    ("abs(y-x)", lambda x, y, n: torch.abs(y - x), False),
+    ("floor(x-y)", lambda x, y, n: torch.floor(x - y), False),
+    ("ceil(x-y)", lambda x, y, n: torch.ceil(x - y), False),
+    ("round(x-y)", lambda x, y, n: torch.round(x - y), False),
+    ("trunc(x-y)", lambda x, y, n: torch.trunc(x - y), True),
+    ("min(x^3,y^2)", lambda x, y, n: torch.minimum(x * x * x, y * y), True),
+    ("max(x^2,sin(4*y))", lambda x, y, n: torch.maximum(x * x, torch.sin(y * 4.0)), False),
+    ("pow(2, x)", lambda x, y, n: torch.pow(2, x) + 0 * y, True),
+    ("pow(x, 1.0/3.0)", lambda x, y, n: torch.pow(x, 1.0 / 3.0) + 0 * y, True),
+    ("if(x<1 | y>=2, x, y)", lambda x, y, n: torch.where(torch.logical_or(x < 1, y >= 2), x + 0 * y, y + 0 * x), True),
+    ("if(x<=1 & y>2, x*x, 3*y)", lambda x, y, n: torch.where(torch.logical_and(x <= 1, y > 2), x * x + 0 * y, y * 3 + 0 * x), True),
+    ("r2:=x^2+y^2; sqrt(r2)", lambda x, y, n: torch.sqrt(x * x + y * y), True),
+]
+
+
+def _parse_inputs():
+    x = torch.linspace(0.1, 2.01, 11, dtype=torch.float64).unsqueeze(1)
+    y = torch.linspace(0.11, 3.02, 15, dtype=torch.float64).unsqueeze(0)
+    n = torch.max(x * y) * 1.01
+    shape = (11, 15)
+    return x.expand(shape).contiguous(), y.expand(shape).contiguous(), n.expand(shape).contiguous()
+
+
+@pytest.mark.parametrize("expr,gold,derivative_check", _PARSE_CASES, ids=[c[0] for c in _PARSE_CASES])
+def test_reference_unit_test_parse_section(ctx, expr, gold, derivative_check):
+    """`check(expression, gold)` of TEST(ParsedTensorTest, Parse): the compiled expression == the libTorch gold to epsilon = 1e-12, and
+    (where the reference checks it) the symbolic derivative w.r.t. x, y and n against a forward difference with the reference's
+    step 1e-6 and its acceptance: relative error < 1e-5 or absolute difference < sqrt(epsilon)"""
+    x, y, n = _parse_inputs()
+    eps, eps_fd, rel_tol, abs_tol = 1e-12, 1e-6, 1e-5, 1e-6
+    f = _pc(ctx, expr, inputs=["x", "y", "n"])
+    xs = [t.cuda() for t in (x, y, n)]
+    r = f(*xs)
+    assert (r.cpu() - gold(x, y, n)).abs().max().item() <= eps
+    if not derivative_check:
+        return
+    for k, var in enumerate("xyn"):
+        pert = [t + eps_fd if i == k else t for i, t in enumerate(xs)]
+        dr1 = (f(*pert) - r) / eps_fd
+        dr2 = _pc(ctx, expr, inputs=["x", "y", "n"], derivatives=[var])(*xs)
+        abs_diff = (dr2 - dr1).abs()
+        rel = (abs_diff / (dr1.abs() + eps_fd)).max().item()
+        assert rel < rel_tol or abs_diff.max().item() < abs_tol, (expr, var, rel, abs_diff.max().item())
+
+
+@pytest.mark.parametrize("expr,var,derivative", [
+    ("y/x", "x", "-y/x^2"), ("y/x", "y", "1/x"),
+    ("max(x^2,sin(4*y))", "x", "if(x^2>=sin(4*y),2*x,0)"), ("max(x^2,sin(4*y))", "y", "if(x^2>=sin(4*y),0,4*cos(4*y))"),
+    ("x2:=x^2; sinx2:=sin(x2); 4*sinx2", "x", "8*x*cos(x*x)"), ("a:=sin(x^2); a + 2*a + 3*a", "x", "12*x*cos(x^2)")])
+def test_reference_unit_test_parse_section_check2(ctx, expr, var, derivative):
+    """`check2(expression, dvar, derivative, compile)` of the same test: the symbolic derivative == the hand-written one,
+    relative 1e-5 (the library always compiles: the reference's compile = true / false pair is one case here)"""
+    x, y, n = (t.cuda() for t in _parse_inputs())
+    r1 = _pc(ctx, expr, inputs=["x", "y", "n"], derivatives=[var])(x, y, n)
+    r2 = _pc(ctx, derivative, inputs=["x", "y", "n"])(x, y, n)
+    rel = ((r1 - r2).abs() / (r1.abs() + 1e-12)).max().item()
+    assert rel <= 1e-5, (expr, var, rel)
