@@ -989,7 +989,7 @@ def main():
                                 "note": "ms_per_cg_iteration = whole mrl_mech_newton_cg calls / CG iterations: it carries the Newton-level "
                                         "work (stress, residual, two operator applications per Newton step, layout conversion at the ABI) of "
                                         "2 Newton steps per ~28 iterations; the pure CG loop is small_strain_linear_elastic (197 iterations in "
-                                        "one solve), which runs at the sum of its kernels (look-ahead loop, DESIGN 3b)",
+                                        "one solve), which runs at the sum of its kernels (look-ahead loop, DESIGN 3.3)",
                                 "ms_per_cg_iteration": m["ms_per_cg_iteration"], "cg_iterations_per_substep": m["cg_its"],
                                 "algorithmic_bytes_per_point_per_cg_iteration": m["algorithmic_bytes_per_point_per_cg_iteration"],
                                 "achieved_GBps": m["achieved_GBps"], "frac_of_hbm_peak": m["achieved_GBps"] / HBM_PEAK_GBPS,

@@ -111,12 +111,12 @@ enum mrl_option {
   MRL_OPT_VERIFY_EXCHANGE = 3,   /* debug, slab contexts with a communicator: after every arrival wait the receive buffer is re-read
                                     once with plain loads and once with system-scope loads behind a system-scope acquire; 64-bit
                                     words that differ (a stale cache line on the consumer's GPU: the memory-model argument of the
-                                    peer-store transport, DESIGN.md 4.1, does not hold on this node) are counted */
+                                    peer-store transport, profiles/HISTORY.md 4.1a, does not hold on this node) are counted */
   MRL_OPT_VERIFY_MISMATCHES = 4, /* get: that count for the communicator of this context (synchronises); set 0: reset */
   MRL_OPT_CACHE_CHUNK_MB = 5     /* serial fused Cahn-Hilliard path, A/B switch (0 = off, the default): the plane-wise passes between
                                     two x passes (inverse y, fused z, forward y) run over chunks of x planes whose c-hat + mu-hat
                                     planes take this many MB, to meet in the 256 MiB Infinity Cache; results are bit-identical
-                                    (measured slower on MI355X: DESIGN.md section 5) */
+                                    (measured slower on MI355X: profiles/HISTORY.md section 5) */
 };
 int mrl_ctx_set_option(mrl_ctx *ctx, int option, int64_t value);
 int64_t mrl_ctx_get_option(const mrl_ctx *ctx, int option);

@@ -781,7 +781,7 @@ int xchg_wait(mrl_comm *c, Xchg *x, hipStream_t stream) {
 
 // MRL_OPT_VERIFY_EXCHANGE: what this kernel's plain loads see (it sits where the consuming pass sits: behind the arrival wait, so its
 // launch performs the same acquire) against what system-scope loads see after an explicit system-scope acquire inside the kernel.
-// On one GPU, and wherever the release / acquire chain of DESIGN 4.1 holds, the two agree word for word.
+// On one GPU, and wherever the release / acquire chain of profiles/HISTORY.md 4.1a holds, the two agree word for word.
 __global__ void __launch_bounds__(256) k_comm_verify(const unsigned long long *buf, size_t nwords, unsigned long long *bad) {
   unsigned long long mine = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) {

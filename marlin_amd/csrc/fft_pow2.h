@@ -542,6 +542,9 @@ __device__ __forceinline__ void fft_line(kcplx (&v)[Plan<N>::P], int q, int l, k
 
 // bijective XCD-aware remap: hardware deals block b to XCD b % 8; give each XCD a contiguous
 // range of logical tiles so neighbouring tiles (which share partial 128-B lines) share an L2.
+// (Round 5 A/B against the identity map -- consecutive tiles round-robin over the XCDs, the shape that wins in a plain mover:
+// serial y passes 92 -> 122 us at 256^3 and 860 -> 1465 us at 512^3, 256^3 substep 0.305 -> 0.368 ms; the slab-local kernels,
+// whose pieces are whole lines, do not care (+-1 %): profiles/r05_ab_xcd_remap_vs_identity.txt.)
 __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nb) {
   const unsigned q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, idx = b >> 3;
   return (xcd < r8) ? xcd * (q8 + 1) + idx : r8 * (q8 + 1) + (xcd - r8) * q8 + idx;

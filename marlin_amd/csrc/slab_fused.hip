@@ -159,7 +159,7 @@ static int launch_yfused(mrl_ctx *ctx, YFusedArgs a) {
     // Nhat arrays are streamed past the Infinity Cache as in the serial x pass, which leaves it to the exchange buffers the next pass
     // re-reads.  Same-box A/B (tools/ab_r04.sh, slab-local 512^3 / 8): y pass 160 -> 153-155 us, forward z pass 84 -> 79 us, sum of
     // the rank-local kernels 0.611 -> 0.599 ms; experiment bit 1 << 28 switches it off.  (Sub-block-sized working sets lose with
-    // streaming accesses, DESIGN 3: hence only for nsub = 1.)
+    // streaming accesses, profiles/HISTORY.md 3: hence only for nsub = 1.)
     const double hist_bytes = 16.0 * (double)a.nxl * (double)N * (double)a.nzc;
     if (a.k0 == 0 && a.ksub == ctx->nrec[2] && hist_bytes >= 96.0e6 && !(ctx->exp & (1 << 28)))
       return launch_yfused_v<N, ORDER, SPEC_C, true, false, true>(ctx, a);

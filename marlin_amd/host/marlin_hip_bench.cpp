@@ -574,7 +574,7 @@ static int run_ch(Rank & R)
     tuning_s = R.reduce(now_s() - t_tune0, 2);
     // reference checksum: the most conservative transport that ran -- RCCL (its own rendezvous and fences), else the copy engines
     // (hipMemcpyAsync between IPC mappings), else the median of the peer-store variants.  The peer-store candidates share one
-    // memory-model argument: if it failed on this node they could agree with each other and still be wrong, so
+    // memory-model argument (profiles/HISTORY.md 4.1a): if it failed on this node they could agree with each other and still be wrong, so
     // they must not outvote a transport that does not depend on it.  A candidate that disagrees is disqualified.
     double ref = 0.0;
     bool have_ref = false;

@@ -95,6 +95,13 @@ struct FromString<std::vector<T>>
     return v;
   }
 };
+/// how a declared parameter takes a value from text (MooseEnum keeps its list of names: see below)
+template <typename T>
+void
+assign(T & v, const std::string & text)
+{
+  v = FromString<T>::get(text);
+}
 } // namespace moose_stub
 
 struct MooseStubError : std::runtime_error
@@ -148,6 +155,55 @@ complexFloatTensorOptions()
 }
 }
 
+/// MooseEnum("X=0 Y=1 Z=2"[, "default"]): a named choice that converts to its integer
+class MooseEnum
+{
+public:
+  MooseEnum() = default;
+  MooseEnum(const std::string & options, const std::string & selected = "")
+  {
+    std::istringstream in(options);
+    std::string tok;
+    int next = 0;
+    while (in >> tok)
+    {
+      const auto eq = tok.find('=');
+      const int id = eq == std::string::npos ? next : std::stoi(tok.substr(eq + 1));
+      _names.emplace_back(tok.substr(0, eq), id);
+      next = id + 1;
+    }
+    if (!selected.empty())
+      select(selected);
+  }
+  void select(const std::string & name)
+  {
+    for (const auto & n : _names)
+      if (n.first == name)
+      {
+        _current = n.second;
+        _valid = true;
+        return;
+      }
+    mooseError("'", name, "' is not one of the values of this MooseEnum");
+  }
+  bool isValid() const { return _valid; }
+  operator int() const { return _current; }
+
+private:
+  std::vector<std::pair<std::string, int>> _names;
+  int _current = -1;
+  bool _valid = false;
+};
+namespace moose_stub
+{
+template <>
+inline void
+assign<MooseEnum>(MooseEnum & v, const std::string & text)
+{
+  v.select(text);
+}
+}
+
 class InputParameters
 {
 public:
@@ -168,6 +224,13 @@ public:
   void addRequiredParam(const std::string & name, const std::string & doc)
   {
     declare<T>(name, doc, true);
+  }
+  /// required, but declared with a prototype value that carries the choices (MooseEnum)
+  template <typename T>
+  void addRequiredParam(const std::string & name, const T & prototype, const std::string & doc)
+  {
+    declare<T>(name, doc, true);
+    _values[name] = prototype;
   }
   template <typename T>
   void addRangeCheckedParam(const std::string & name, const T & value, const std::string & range, const std::string & doc)
@@ -207,11 +270,12 @@ public:
     if (it == _parse.end())
       mooseError("unused parameter '", name, "'");
     it->second(_values[name], text);
+    _set_by_user.insert(name);
   }
   void checkRequired(const std::string & object) const
   {
     for (const auto & r : _required)
-      if (!isParamValid(r))
+      if (!_set_by_user.count(r))
         mooseError(object, ": missing required parameter '", r, "'");
   }
 
@@ -220,7 +284,12 @@ private:
   void declare(const std::string & name, const std::string & doc, bool required)
   {
     _doc[name] = doc;
-    _parse[name] = [](std::any & slot, const std::string & text) { slot = moose_stub::FromString<T>::get(text); };
+    _parse[name] = [](std::any & slot, const std::string & text)
+    {
+      T v = (slot.has_value() && slot.type() == typeid(T)) ? *std::any_cast<T>(&slot) : T{};
+      moose_stub::assign(v, text);
+      slot = v;
+    };
     if (required)
       _required.insert(name);
   }
@@ -228,7 +297,7 @@ private:
   std::map<std::string, std::any> _values;
   std::map<std::string, std::string> _doc;
   std::map<std::string, std::function<void(std::any &, const std::string &)>> _parse;
-  std::set<std::string> _required;
+  std::set<std::string> _required, _set_by_user;
 };
 
 class MooseObject

@@ -8,8 +8,13 @@
 //   shim-driver case=brusselator nx=150 ny=150 xmax=2pi ymax=2pi ss=10 cs=0 order=2 num_steps=25 dt=0.5 out=dir
 //               (test/tests/solvers/diagonal.i: two variables, HipForwardFFT / HipParsedCompute / HipReciprocalLaplacianFactor in the
 //               compute group, HipAdamsBashforthMoulton without `expression`): writes brusselator.csv
+//   shim-driver case=coupled nx=150 ny=150 xmax=2pi ymax=2pi ss=10 cs=0 order=2 num_steps=25 dt=10 out=dir
+//               (test/tests/solvers/coupled.i: HipAdamsBashforthMoultonCoupled, dense 2 x 2 operator): writes coupled.csv
 //   shim-driver case=mechanics nx=16 ny=16 nz=16 substeps=10 num_steps=3 dt=0.01 l_tol=1e-2 nl_rel_tol=2e-2 nl_abs_tol=2e-2 out=dir
-//               (test/tests/mechanics/mech3d.i with [mech] type = HipFFTMechanics): writes F.<frame>.bin, stress.<frame>.bin
+//               (test/tests/mechanics/mech3d.i with [mech] type = HipFFTMechanics, [displacements] type = HipComputeDisplacements,
+//               [vonmises] type = HipComputeVonMisesStress): writes F / stress / disp / sV.<frame>.bin
+//   shim-driver case=gradient|gradient_square nx=40 ny=40 nz=40 xmax=2pi ymax=4pi zmax=6pi out=dir
+//               (test/tests/gradient/gradient.i, gradient_square.i with HipFFTGradient / HipFFTGradientSquare / HipParsedCompute)
 // Raw little-endian f64 files, dense row-major, as marlin-hip-run writes them.
 #include "moose_stub.h"
 
@@ -260,6 +265,58 @@ run_brusselator(const std::string & out)
   return 0;
 }
 
+// test/tests/solvers/coupled.i: AdamsBashforthMoultonCoupled with the dense operator [[D1, D2], [D2, D1]] and zero nonlinear terms
+static int
+run_coupled(const std::string & out)
+{
+  DomainAction domain = make_domain(2);
+  TensorProblem problem(domain);
+  auto ic = [&](const std::string & buffer, const std::string & expr)
+  {
+    create<TensorOperatorBase>(problem, "HipParsedCompute", buffer,
+                               {{"buffer", buffer}, {"expression", expr}, {"extra_symbols", "true"}, {"expand", "REAL"}})
+        ->computeBuffer();
+  };
+  ic("u", "sin(x)*sin(y)");
+  ic("v", "cos(x)*cos(y)");
+  problem.getBuffer("zero") = torch::zeros(domain.getReciprocalShape(), MooseTensor::complexFloatTensorOptions()); // ConstantReciprocalTensor
+  create<TensorOperatorBase>(problem, "HipReciprocalLaplacianFactor", "D1", {{"buffer", "D1"}, {"factor", arg("D1", "1e-2")}})->computeBuffer();
+  create<TensorOperatorBase>(problem, "HipReciprocalLaplacianFactor", "D2", {{"buffer", "D2"}, {"factor", arg("D2", "1e-3")}})->computeBuffer();
+  InputParameters gp;
+  gp.set<std::string>("_object_name") = "root";
+  gp.set<TensorProblem *>("_tensor_problem") = &problem;
+  auto root = std::make_shared<ComputeGroup>(gp);
+  root->add(create<TensorOperatorBase>(problem, "HipForwardFFT", "u_bar", {{"buffer", "u_bar"}, {"input", "u"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipForwardFFT", "v_bar", {{"buffer", "v_bar"}, {"input", "v"}}));
+  problem.computes().push_back(root);
+  auto solver = create<TensorSolver>(problem, "HipAdamsBashforthMoultonCoupled", "solver",
+                                     {{"root_compute", "root"},
+                                      {"buffer", "u v"},
+                                      {"reciprocal_buffer", "u_bar v_bar"},
+                                      {"linear_reciprocal", "D1 D1"},
+                                      {"linear_offdiag_cols", "0 1"},
+                                      {"linear_offdiag_rows", "1 0"},
+                                      {"linear_offdiag", "D2 D2"},
+                                      {"nonlinear_reciprocal", "zero zero"},
+                                      {"substeps", arg("ss", "10")},
+                                      {"corrector_steps", arg("cs", "0")},
+                                      {"predictor_order", arg("order", "2")},
+                                      {"corrector_order", arg("order", "2")}});
+  solver->updateDependencies();
+  const double volume = (argd("xmax", 1) - argd("xmin", 0)) * (argd("ymax", 1) - argd("ymin", 0));
+  std::ofstream csv(out + "/coupled.csv");
+  csv.precision(17);
+  csv << "time,U,V,u_max,u_min,v_max,v_min\n0,0,0,0,0,0,0\n";
+  auto integral = [&](const torch::Tensor & t) { return t.sum().item<double>() / double(domain.getNumberOfCells()) * volume; };
+  transient(problem, *solver, time_steps(), [&](int) {
+    const auto & u = problem.getBuffer("u");
+    const auto & v = problem.getBuffer("v");
+    csv << problem.time() << ',' << integral(u) << ',' << integral(v) << ',' << u.max().item<double>() << ',' << u.min().item<double>()
+        << ',' << v.max().item<double>() << ',' << v.min().item<double>() << "\n";
+  });
+  return 0;
+}
+
 static int
 run_mechanics(const std::string & out)
 {
@@ -312,10 +369,62 @@ run_mechanics(const std::string & out)
                                      {{"root_compute", "root"}, {"forward_buffer", "F"}, {"forward_buffer_new", "Fnew"},
                                       {"substeps", arg("substeps", "1")}});
   solver->updateDependencies();
+  // [Postprocess] of mech3d.i:74-85, evaluated before the outputs of a time step
+  auto displacements = create<TensorOperatorBase>(problem, "HipComputeDisplacements", "displacements", {{"buffer", "disp"}, {"F", "F"}});
+  auto vonmises = create<TensorOperatorBase>(problem, "HipComputeVonMisesStress", "vonmises", {{"buffer", "sV"}});
   transient(problem, *solver, time_steps(), [&](int step) {
+    displacements->computeBuffer();
+    vonmises->computeBuffer();
     dump(out, "F", step - 1, problem.getBuffer("F"));
     dump(out, "stress", step - 1, problem.getBuffer("stress"));
+    dump(out, "disp", step - 1, problem.getBuffer("disp"));
+    dump(out, "sV", step - 1, problem.getBuffer("sV"));
   });
+  return 0;
+}
+
+// test/tests/gradient/gradient.i and gradient_square.i: spectral derivatives of sin(x)+sin(y)+sin(z) against the analytic ones,
+// the postprocessor value = integral of the absolute difference (TensorIntegralPostprocessor.C:29-38)
+static int
+run_gradient(const std::string & out, bool square)
+{
+  DomainAction domain = make_domain(3);
+  TensorProblem problem(domain);
+  auto parsed = [&](const std::string & buffer, const std::string & expr, const std::string & inputs, bool extra)
+  {
+    std::vector<std::pair<std::string, std::string>> block = {{"buffer", buffer}, {"expression", expr}};
+    if (!inputs.empty())
+      block.push_back({"inputs", inputs});
+    if (extra)
+    {
+      block.push_back({"extra_symbols", "true"});
+      block.push_back({"expand", "REAL"});
+    }
+    create<TensorOperatorBase>(problem, "HipParsedCompute", buffer, block)->computeBuffer();
+  };
+  const double volume = (argd("xmax", 1) - argd("xmin", 0)) * (argd("ymax", 1) - argd("ymin", 0)) * (argd("zmax", 1) - argd("zmin", 0));
+  auto integral = [&](const torch::Tensor & t) { return t.sum().item<double>() / double(domain.getNumberOfCells()) * volume; };
+  parsed("s", "sin(x)+sin(y)+sin(z)", "", true);
+  std::ofstream csv(out + (square ? "/gradient_square.csv" : "/gradient.csv"));
+  csv.precision(17);
+  if (square)
+  {
+    parsed("c2", "cos(x)^2+cos(y)^2+cos(z)^2", "", true);
+    create<TensorOperatorBase>(problem, "HipFFTGradientSquare", "grad_sq", {{"buffer", "grad_sq"}, {"input", "s"}})->computeBuffer();
+    parsed("diff", "abs(grad_sq - c2)", "grad_sq c2", false);
+  }
+  else
+  {
+    parsed("cx", "cos(x)", "", true);
+    parsed("cy", "cos(y)", "", true);
+    parsed("cz", "cos(z)", "", true);
+    const char * dir[] = {"X", "Y", "Z"};
+    const char * buf[] = {"gradx_s", "grady_s", "gradz_s"};
+    for (int d = 0; d < 3; ++d)
+      create<TensorOperatorBase>(problem, "HipFFTGradient", buf[d], {{"buffer", buf[d]}, {"input", "s"}, {"direction", dir[d]}})->computeBuffer();
+    parsed("diff", "abs(gradx_s - cx)+abs(grady_s - cy)+abs(gradz_s - cz)", "gradx_s grady_s gradz_s cx cy cz", false);
+  }
+  csv << "time,diff\n0,0\n1," << integral(problem.getBuffer("diff")) << "\n";
   return 0;
 }
 
@@ -350,8 +459,12 @@ main(int argc, char ** argv)
       return run_cahnhilliard(out);
     if (which == "brusselator")
       return run_brusselator(out);
+    if (which == "coupled")
+      return run_coupled(out);
     if (which == "mechanics")
       return run_mechanics(out);
+    if (which == "gradient" || which == "gradient_square")
+      return run_gradient(out, which == "gradient_square");
     mooseError("unknown case '", which, "'");
   }
   catch (const std::exception & e)

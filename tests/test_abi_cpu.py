@@ -117,7 +117,8 @@ def test_moose_shim_sources_only_call_what_the_abi_declares():
         for member in set(re.findall(r"\b_p\.([a-z_]+)\b", code)) | set(re.findall(r"\b_prm\.([a-z_]+)\b", code)):
             assert re.search(r"\b%s\b[^;]*;" % member, hdr), (os.path.basename(path), member)
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    for f in ("HipDomain.h", "HipAdamsBashforthMoulton.C", "HipFFTMechanics.C", "HipSpectralComputes.C", "marlin_plugin.mk"):
+    for f in ("HipDomain.h", "HipAdamsBashforthMoulton.C", "HipFFTMechanics.C", "HipSpectralComputes.C", "HipSpectralOperators.C",
+              "marlin_plugin.mk"):
         assert f in integ, f
 
 
@@ -131,8 +132,9 @@ def test_moose_shim_compiles_against_the_stub_and_registers_its_classes():
     r = subprocess.run([exe, "case=types"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     types = set(r.stdout.split())
-    want = {"HipAdamsBashforthMoulton", "HipFFTMechanics", "HipForwardFFT", "HipInverseFFT", "HipParsedCompute",
-            "HipReciprocalLaplacianFactor", "HipReciprocalLaplacianSquareFactor"}
+    want = {"HipAdamsBashforthMoulton", "HipAdamsBashforthMoultonCoupled", "HipFFTMechanics", "HipForwardFFT", "HipInverseFFT",
+            "HipParsedCompute", "HipReciprocalLaplacianFactor", "HipReciprocalLaplacianSquareFactor", "HipFFTGradient",
+            "HipFFTGradientSquare", "HipComputeDisplacements", "HipComputeVonMisesStress"}
     assert want <= types, want - types
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for t in want:
@@ -144,7 +146,7 @@ def test_moose_shim_compiles_against_the_stub_and_registers_its_classes():
 
 
 def test_lds_conflict_model_reproduces_the_measured_shares():
-    """tools/lds_conflict_model.py (the bank model behind LineMapParams): the old line map of the 512-point z kernels costs
+    """tools/lds_conflict_model.py (the bank model behind LineMapParams, profiles/HISTORY.md 3.2): the old line map of the 512-point z kernels costs
     40 % conflict cycles (measured: 41-47 %), the adopted xor swizzle none; the 256-point plan was and stays conflict-free"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("ldsmodel", os.path.join(ROOT, "tools", "lds_conflict_model.py"))

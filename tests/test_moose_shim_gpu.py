@@ -119,9 +119,25 @@ def test_brusselator_gold_through_the_shim(ss, cs, order, tmp_path):
     assert err.max() <= 5e-11, err.max()
 
 
+@pytest.mark.parametrize("ss,cs,order", [(10, 0, 1), (10, 0, 2), (10, 0, 3), (20, 0, 4), (10, 1, 1), (10, 2, 1), (10, 2, 2)])
+def test_coupled_gold_through_the_shim(ss, cs, order, tmp_path):
+    """test/tests/solvers/tests (coupled.i, CSVDiff): [TensorSolver] type = HipAdamsBashforthMoultonCoupled -- the right-hand sides
+    of HipAdamsBashforthMoulton, then one dense 2 x 2 solve per k-point (mrl_kspace_coupled) with the reference's transposed
+    assembly and real cast of the right-hand side, which its gold files pin -- against coupled_<ss>_<cs>_<order>.csv"""
+    g = load_golden("solvers_gold.npz")[f"coupled_{ss}_{cs}_{order}"]
+    _run(["case=coupled", "nx=150", "ny=150", "xmax=2pi", "ymax=2pi", f"ss={ss}", f"cs={cs}", f"order={order}", "num_steps=25",
+          "dt=10"], tmp_path)
+    got = np.loadtxt(tmp_path / "coupled.csv", delimiter=",", skiprows=1)
+    assert got.shape == g.shape
+    assert np.allclose(got[:, 0], g[:, 0])
+    err = np.abs(got[1:, 1:] - g[1:, 1:]) / np.maximum(1.0, np.abs(g[1:, 1:]))
+    assert err.max() <= 5e-11, err.max()
+
+
 def test_mech3d_gold_through_the_shim(tmp_path):
     """test/tests/mechanics/tests:2-11 (mech3d.i) with [mech] type = HipFFTMechanics inside the root group of a ForwardEulerSolver
-    that forwards Fnew -> F: F_k.frame of gold mech3d.h5 to 1e-10, two Newton iterations per substep as the reference"""
+    that forwards Fnew -> F: F_k.frame, disp_* (HipComputeDisplacements) and sV (HipComputeVonMisesStress) of gold mech3d.h5 to
+    1e-10, two Newton iterations per substep as the reference"""
     g = load_golden("mech3d_gold.npz")
     n = 16
     log = _run(["case=mechanics", "nx=16", "ny=16", "nz=16", "xmax=2pi", "ymax=2pi", "zmax=2pi", "substeps=10", "num_steps=3", "dt=0.01",
@@ -133,4 +149,20 @@ def test_mech3d_gold_through_the_shim(tmp_path):
         F = np.fromfile(tmp_path / f"F.{frame}.bin", dtype="<f8").reshape(n, n, n, 9)
         for k in range(9):
             worst = max(worst, np.abs(g[f"F_{k}.{frame}"] - np.transpose(F[..., k], (2, 1, 0))).max())   # XDMF default transpose
+        disp = np.fromfile(tmp_path / f"disp.{frame}.bin", dtype="<f8").reshape(n + 1, n + 1, n + 1, 3)
+        for k, nm in enumerate(("disp_x", "disp_y", "disp_z")):      # [displacements] type = HipComputeDisplacements
+            worst = max(worst, np.abs(g[f"{nm}.{frame}"] - np.transpose(disp[..., k], (2, 1, 0))).max())
+        sv = np.fromfile(tmp_path / f"sV.{frame}.bin", dtype="<f8").reshape(n, n, n)   # [vonmises] type = HipComputeVonMisesStress
+        worst = max(worst, np.abs(g[f"sV.{frame}"] - np.transpose(sv, (2, 1, 0))).max())
     assert worst <= 1e-10, worst
+
+
+@pytest.mark.parametrize("case,bound", [("gradient", None), ("gradient_square", 1e-10)])
+def test_gradient_cases_through_the_shim(case, bound, tmp_path):
+    """test/tests/gradient/tests (gradient.i, gradient_square.i): HipFFTGradient (X, Y, Z) and HipFFTGradientSquare of
+    sin(x)+sin(y)+sin(z) on the 40^3 anisotropic box against the analytic derivatives, every expression a HipParsedCompute; the gold
+    value is integrated round-off (7.6e-12 / 6.9e-12) -- ours must be round-off too"""
+    g = load_golden("fft_gold.npz")["gradient_out" if case == "gradient" else "gradient_square_out"]
+    _run([f"case={case}", "nx=40", "ny=40", "nz=40", "xmax=2pi", "ymax=4pi", "zmax=6pi"], tmp_path)
+    got = np.loadtxt(tmp_path / f"{case}.csv", delimiter=",", skiprows=1)
+    assert 0.0 <= got[1, 1] <= (bound if bound else 10.0 * g[1, 1])

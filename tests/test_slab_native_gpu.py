@@ -176,7 +176,7 @@ def test_native_slab_exchange_buffers_beyond_4_gib():
     slab job (communicator, flags, exchange tables, peer-store kernels) against the serial fused path on the same grid (itself
     oracle-checked at the sizes the oracle reaches), 2 substeps, to 1e-13, mass conserved.  (Two rank processes with buffers of this size: covered through the C++ driver,
     tests/test_host_driver_gpu.py::test_cahnhilliard_fft_slab_exchange_buffers_beyond_4_gib -- inside a PyTorch process the HIP runtime
-    bundled with the wheel does not return from hipIpcOpenMemHandle for multi-GB buffers)"""
+    bundled with the wheel does not return from hipIpcOpenMemHandle for multi-GB buffers, profiles/HISTORY.md 4.1.)"""
     res = run_job(1, "chbench", "shape=512,512,1024", "steps=2", "ic=rand", *EXTRA_KV, timeout=300)
     assert max(r["max_err"] for r in res) <= 1e-13, res
     assert max(r["mass_err"] for r in res) <= 1e-12, res
