@@ -317,6 +317,11 @@ public:
   {
     mooseError(name(), ": parameter '", param, "': ", std::forward<A>(a)...);
   }
+  template <typename... A>
+  void paramWarning(const std::string & param, A &&... a) const
+  {
+    std::cerr << "*** Warning ***\n" << moose_stub::cat(name(), ": parameter '", param, "': ", std::forward<A>(a)...) << "\n";
+  }
   const libMesh::Parallel::Communicator & comm() const
   {
     static libMesh::Parallel::Communicator c;
@@ -664,4 +669,32 @@ protected:
                                     getBufferOldByName(nonlin[i], history_size)});
   }
   std::vector<Variable> _variables;
+};
+
+/// include/tensor_predictor/TensorPredictor.h (what IterativeTensorSolverInterface::applyPredictors calls)
+class TensorPredictor
+{
+public:
+  virtual ~TensorPredictor() = default;
+  virtual void computeBuffer() = 0;
+};
+
+/// include/tensor_solver/IterativeTensorSolverInterface.h:17-33, src/tensor_solver/IterativeTensorSolverInterface.C:13-24
+class IterativeTensorSolverInterface
+{
+public:
+  IterativeTensorSolverInterface() : _iterations(0), _is_converged(true) {}
+  const unsigned int & getIterations() const { return _iterations; }
+  const bool & isConverged() const { return _is_converged; }
+  void addPredictor(std::shared_ptr<TensorPredictor> predictor) { _predictors.push_back(std::move(predictor)); }
+
+protected:
+  void applyPredictors()
+  {
+    for (const auto & pred : _predictors)
+      pred->computeBuffer();
+  }
+  unsigned int _iterations;
+  bool _is_converged;
+  std::vector<std::shared_ptr<TensorPredictor>> _predictors;
 };

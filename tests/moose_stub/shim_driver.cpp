@@ -10,6 +10,8 @@
 //               compute group, HipAdamsBashforthMoulton without `expression`): writes brusselator.csv
 //   shim-driver case=coupled nx=150 ny=150 xmax=2pi ymax=2pi ss=10 cs=0 order=2 num_steps=25 dt=10 out=dir
 //               (test/tests/solvers/coupled.i: HipAdamsBashforthMoultonCoupled, dense 2 x 2 operator): writes coupled.csv
+//   shim-driver case=etdrk4 nx=64 xmax=2pi D=0.05 k=1.0 ss=1 dt=10 num_steps=10 out=dir
+//               (test/tests/solvers/etdrk4_diffusion.i: HipETDRK4Solver, 1-D): writes etdrk4.csv
 //   shim-driver case=mechanics nx=16 ny=16 nz=16 substeps=10 num_steps=3 dt=0.01 l_tol=1e-2 nl_rel_tol=2e-2 nl_abs_tol=2e-2 out=dir
 //               (test/tests/mechanics/mech3d.i with [mech] type = HipFFTMechanics, [displacements] type = HipComputeDisplacements,
 //               [vonmises] type = HipComputeVonMisesStress): writes F / stress / disp / sV.<frame>.bin
@@ -317,6 +319,47 @@ run_coupled(const std::string & out)
   return 0;
 }
 
+// test/tests/solvers/etdrk4_diffusion.i: 1-D periodic diffusion advanced by the ETDRK4 solver against the analytic solution
+static int
+run_etdrk4(const std::string & out)
+{
+  DomainAction domain = make_domain(1);
+  TensorProblem problem(domain);
+  const std::string D = arg("D", "0.05"), k = arg("k", "1.0");
+  create<TensorOperatorBase>(problem, "HipParsedCompute", "u0",
+                             {{"buffer", "u0"}, {"expression", "sin(kk*x)"}, {"constant_names", "kk"}, {"constant_expressions", k},
+                              {"extra_symbols", "true"}, {"expand", "REAL"}})
+      ->computeBuffer();
+  create<TensorOperatorBase>(problem, "HipParsedCompute", "u", {{"buffer", "u"}, {"expression", "u0"}, {"inputs", "u0"}})->computeBuffer();
+  create<TensorOperatorBase>(problem, "HipReciprocalLaplacianFactor", "L", {{"buffer", "L"}, {"factor", D}})->computeBuffer();
+  problem.getBuffer("zero") = torch::zeros(domain.getReciprocalShape(), MooseTensor::complexFloatTensorOptions()); // ConstantReciprocalTensor
+  InputParameters gp;
+  gp.set<std::string>("_object_name") = "root";
+  gp.set<TensorProblem *>("_tensor_problem") = &problem;
+  auto root = std::make_shared<ComputeGroup>(gp);
+  root->add(create<TensorOperatorBase>(problem, "HipForwardFFT", "u_bar", {{"buffer", "u_bar"}, {"input", "u"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipParsedCompute", "u_exact",
+                                       {{"buffer", "u_exact"}, {"expression", "u0*exp(-DD*kk^2*t)"}, {"inputs", "u0"},
+                                        {"constant_names", "DD kk"}, {"constant_expressions", D + " " + k}, {"extra_symbols", "true"},
+                                        {"expand", "REAL"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipParsedCompute", "u_diff_sq",
+                                       {{"buffer", "u_diff_sq"}, {"expression", "(u - u_exact)^2"}, {"inputs", "u u_exact"}}));
+  problem.computes().push_back(root);
+  auto solver = create<TensorSolver>(problem, "HipETDRK4Solver", "solver",
+                                     {{"root_compute", "root"}, {"buffer", "u"}, {"reciprocal_buffer", "u_bar"}, {"linear_reciprocal", "L"},
+                                      {"nonlinear_reciprocal", "zero"}, {"substeps", arg("ss", "1")}});
+  solver->updateDependencies();
+  const double length = argd("xmax", 1) - argd("xmin", 0);
+  std::ofstream csv(out + "/etdrk4.csv");
+  csv.precision(17);
+  csv << "time,mse,rmse\n0,0,0\n";
+  transient(problem, *solver, time_steps(), [&](int) {
+    const double mse = problem.getBuffer("u_diff_sq").sum().item<double>() / double(domain.getNumberOfCells()) * length;
+    csv << problem.time() << ',' << mse << ',' << std::sqrt(mse) << "\n";
+  });
+  return 0;
+}
+
 static int
 run_mechanics(const std::string & out)
 {
@@ -461,6 +504,8 @@ main(int argc, char ** argv)
       return run_brusselator(out);
     if (which == "coupled")
       return run_coupled(out);
+    if (which == "etdrk4")
+      return run_etdrk4(out);
     if (which == "mechanics")
       return run_mechanics(out);
     if (which == "gradient" || which == "gradient_square")

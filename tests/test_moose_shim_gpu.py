@@ -134,6 +134,16 @@ def test_coupled_gold_through_the_shim(ss, cs, order, tmp_path):
     assert err.max() <= 5e-11, err.max()
 
 
+def test_etdrk4_gold_through_the_shim(tmp_path):
+    """test/tests/solvers/tests:220-230 (etdrk4_diffusion.i, CSVDiff): [TensorSolver] type = HipETDRK4Solver on the 1-D 64-point
+    domain, the exact solution and the squared difference as HipParsedComputes with `t`: mse / rmse of etdrk4_diffusion_rmse.csv"""
+    g = load_golden("solvers_gold.npz")["etdrk4_diffusion_rmse"]
+    _run(["case=etdrk4", "nx=64", "xmax=2pi", "D=0.05", "k=1.0", "ss=1", "dt=10", "num_steps=10"], tmp_path)
+    got = np.loadtxt(tmp_path / "etdrk4.csv", delimiter=",", skiprows=1)
+    assert got.shape == g.shape
+    assert np.abs(got[1:, 1:] - g[1:, 1:]).max() <= 1e-12
+
+
 def test_mech3d_gold_through_the_shim(tmp_path):
     """test/tests/mechanics/tests:2-11 (mech3d.i) with [mech] type = HipFFTMechanics inside the root group of a ForwardEulerSolver
     that forwards Fnew -> F: F_k.frame, disp_* (HipComputeDisplacements) and sV (HipComputeVonMisesStress) of gold mech3d.h5 to
