@@ -12,6 +12,10 @@
 //               (test/tests/solvers/coupled.i: HipAdamsBashforthMoultonCoupled, dense 2 x 2 operator): writes coupled.csv
 //   shim-driver case=etdrk4 nx=64 xmax=2pi D=0.05 k=1.0 ss=1 dt=10 num_steps=10 out=dir
 //               (test/tests/solvers/etdrk4_diffusion.i: HipETDRK4Solver, 1-D): writes etdrk4.csv
+//   shim-driver case=secant nx=40 ny=40 xmax=12pi ymax=<..> ic=psi0.bin substeps=3 num_steps=10 dt=1 out=dir
+//               (test/tests/tensor_compute/rotating_grain_secant.i: HipSecantSolver, iteration-adaptive dt): writes psi.<step>.bin
+//   shim-driver case=broyden nx=24 ny=24 xmax=2pi ymax=2pi num_steps=3 dt=0.05 out=dir
+//               (two coupled Brusselator variables through HipBroydenSolver, one substep per step): writes u / v.<step>.bin
 //   shim-driver case=mechanics nx=16 ny=16 nz=16 substeps=10 num_steps=3 dt=0.01 l_tol=1e-2 nl_rel_tol=2e-2 nl_abs_tol=2e-2 out=dir
 //               (test/tests/mechanics/mech3d.i with [mech] type = HipFFTMechanics, [displacements] type = HipComputeDisplacements,
 //               [vonmises] type = HipComputeVonMisesStress): writes F / stress / disp / sV.<frame>.bin
@@ -360,6 +364,114 @@ run_etdrk4(const std::string & out)
   return 0;
 }
 
+// test/tests/tensor_compute/rotating_grain_secant.i: SecantSolver + SwiftHohenbergLinear + TensorSolveIterationAdaptiveDT
+// (src/timesteppers/TensorSolveIterationAdaptiveDT.C: dt grows / shrinks with the solver's iteration count of the previous step)
+static int
+run_secant(const std::string & out)
+{
+  DomainAction domain = make_domain(2);
+  TensorProblem problem(domain);
+  problem.getBuffer("psi") = read_bin(arg("ic"), std::vector<int64_t>(domain.getShape().begin(), domain.getShape().end()));
+  // SwiftHohenbergLinear.C:35-39: r - alpha^2 (1 - k^2)^2
+  create<TensorOperatorBase>(problem, "HipParsedCompute", "linear",
+                             {{"buffer", "linear"}, {"expression", "r-aa*(1-k2)*(1-k2)"}, {"constant_names", "r aa"},
+                              {"constant_expressions", arg("r", "0.025") + " " + arg("aa", "1")}, {"extra_symbols", "true"},
+                              {"expand", "RECIPROCAL"}})
+      ->computeBuffer();
+  InputParameters gp;
+  gp.set<std::string>("_object_name") = "root";
+  gp.set<TensorProblem *>("_tensor_problem") = &problem;
+  auto root = std::make_shared<ComputeGroup>(gp);
+  root->add(create<TensorOperatorBase>(problem, "HipParsedCompute", "psi3",
+                                       {{"buffer", "psi3"}, {"expression", "0.20*psi^2-psi^3"}, {"inputs", "psi"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipForwardFFT", "psibar", {{"buffer", "psibar"}, {"input", "psi"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipForwardFFT", "psi3bar", {{"buffer", "psi3bar"}, {"input", "psi3"}}));
+  problem.computes().push_back(root);
+  auto solver = create<TensorSolver>(problem, "HipSecantSolver", "solver",
+                                     {{"root_compute", "root"}, {"buffer", "psi"}, {"reciprocal_buffer", "psibar"},
+                                      {"linear_reciprocal", "linear"}, {"nonlinear_reciprocal", "psi3bar"},
+                                      {"substeps", arg("substeps", "3")}, {"max_iterations", arg("max_iterations", "30")}});
+  solver->updateDependencies();
+  auto * iterative = dynamic_cast<IterativeTensorSolverInterface *>(solver.get());
+  if (!iterative)
+    mooseError("HipSecantSolver does not implement IterativeTensorSolverInterface");
+  const double dt0 = argd("dt", 1.0), growth = argd("growth_factor", 1.4), cutback = argd("cutback_factor", 0.9), dtmax = argd("dtmax", 500.0);
+  const unsigned int ts_min = (unsigned int)argi("ts_min_iterations", 100), ts_max = (unsigned int)argi("ts_max_iterations", 400);
+  dump(out, "psi", 0, problem.getBuffer("psi"));
+  double dt_old = 0.0;
+  for (int step = 1; step <= (int)argi("num_steps", 10); ++step)
+  {
+    double dt = dt0; // computeInitialDT
+    if (step > 1)
+    {
+      dt = dt_old;
+      if (iterative->getIterations() < ts_min)
+        dt *= growth;
+      else if (iterative->getIterations() > ts_max)
+        dt *= cutback;
+    }
+    dt = std::min(dt, dtmax);
+    dt_old = dt;
+    transient(problem, *solver, {dt}, [&](int) {
+      dump(out, "psi", step, problem.getBuffer("psi"));
+      std::cout << "step " << step << ": dt=" << dt << " iterations=" << iterative->getIterations() << " converged=" << iterative->isConverged() << "\n";
+    });
+  }
+  return 0;
+}
+
+// two coupled reaction-diffusion variables (the Brusselator sources of diagonal.i) integrated implicitly by the Broyden solver: the
+// reference ships no input for BroydenSolver; this is the problem of tests/test_broyden_gpu.py
+static int
+run_broyden(const std::string & out)
+{
+  DomainAction domain = make_domain(2);
+  TensorProblem problem(domain);
+  auto ic = [&](const std::string & buffer, const std::string & expr)
+  {
+    create<TensorOperatorBase>(problem, "HipParsedCompute", buffer,
+                               {{"buffer", buffer}, {"expression", expr}, {"extra_symbols", "true"}, {"expand", "REAL"}})
+        ->computeBuffer();
+  };
+  ic("u", "1.0 + 0.1*sin(x)*sin(y)");
+  ic("v", "3.0 + 0.1*cos(x)*cos(2*y)");
+  create<TensorOperatorBase>(problem, "HipReciprocalLaplacianFactor", "Du", {{"buffer", "Du"}, {"factor", "1e-2"}})->computeBuffer();
+  create<TensorOperatorBase>(problem, "HipReciprocalLaplacianFactor", "Dv", {{"buffer", "Dv"}, {"factor", "1e-3"}})->computeBuffer();
+  InputParameters gp;
+  gp.set<std::string>("_object_name") = "root";
+  gp.set<TensorProblem *>("_tensor_problem") = &problem;
+  auto root = std::make_shared<ComputeGroup>(gp);
+  auto fft = [&](const std::string & to, const std::string & from)
+  { root->add(create<TensorOperatorBase>(problem, "HipForwardFFT", to, {{"buffer", to}, {"input", from}})); };
+  auto parsed = [&](const std::string & to, const std::string & expression)
+  {
+    root->add(create<TensorOperatorBase>(problem, "HipParsedCompute", to,
+                                         {{"buffer", to}, {"expression", expression}, {"inputs", "u v"}, {"constant_names", "A B"},
+                                          {"constant_expressions", "1 3.5"}}));
+  };
+  fft("u_bar", "u");
+  fft("v_bar", "v");
+  parsed("su", "A - (B+1)*u +u^2*v");
+  fft("su_bar", "su");
+  parsed("sv", "B*u - u^2*v");
+  fft("sv_bar", "sv");
+  problem.computes().push_back(root);
+  auto solver = create<TensorSolver>(problem, "HipBroydenSolver", "solver",
+                                     {{"root_compute", "root"}, {"buffer", "u v"}, {"reciprocal_buffer", "u_bar v_bar"},
+                                      {"linear_reciprocal", "Du Dv"}, {"nonlinear_reciprocal", "su_bar sv_bar"}, {"substeps", "1"},
+                                      {"max_iterations", arg("max_iterations", "30")},
+                                      {"relative_tolerance", arg("relative_tolerance", "1e-6")},
+                                      {"absolute_tolerance", arg("absolute_tolerance", "1e-10")}});
+  solver->updateDependencies();
+  auto * iterative = dynamic_cast<IterativeTensorSolverInterface *>(solver.get());
+  transient(problem, *solver, time_steps(), [&](int step) {
+    dump(out, "u", step, problem.getBuffer("u"));
+    dump(out, "v", step, problem.getBuffer("v"));
+    std::cout << "step " << step << ": iterations=" << iterative->getIterations() << " converged=" << iterative->isConverged() << "\n";
+  });
+  return 0;
+}
+
 static int
 run_mechanics(const std::string & out)
 {
@@ -506,6 +618,10 @@ main(int argc, char ** argv)
       return run_coupled(out);
     if (which == "etdrk4")
       return run_etdrk4(out);
+    if (which == "secant")
+      return run_secant(out);
+    if (which == "broyden")
+      return run_broyden(out);
     if (which == "mechanics")
       return run_mechanics(out);
     if (which == "gradient" || which == "gradient_square")

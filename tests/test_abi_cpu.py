@@ -134,7 +134,8 @@ def test_moose_shim_compiles_against_the_stub_and_registers_its_classes():
     types = set(r.stdout.split())
     want = {"HipAdamsBashforthMoulton", "HipAdamsBashforthMoultonCoupled", "HipFFTMechanics", "HipForwardFFT", "HipInverseFFT",
             "HipParsedCompute", "HipReciprocalLaplacianFactor", "HipReciprocalLaplacianSquareFactor", "HipFFTGradient",
-            "HipFFTGradientSquare", "HipComputeDisplacements", "HipComputeVonMisesStress"}
+            "HipFFTGradientSquare", "HipComputeDisplacements", "HipComputeVonMisesStress", "HipETDRK4Solver", "HipSecantSolver",
+            "HipBroydenSolver"}
     assert want <= types, want - types
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for t in want:

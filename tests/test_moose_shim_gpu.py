@@ -144,6 +144,59 @@ def test_etdrk4_gold_through_the_shim(tmp_path):
     assert np.abs(got[1:, 1:] - g[1:, 1:]).max() <= 1e-12
 
 
+def test_rotating_grain_secant_gold_through_the_shim(tmp_path):
+    """test/tests/tensor_compute/tests:90-100 (rotating_grain_secant.i, HDF5Diff abs_tol 1e-10): [TensorSolver] type = HipSecantSolver,
+    the Swift-Hohenberg linear operator as a HipParsedCompute on the reciprocal grid, the time stepper following the solver's
+    iteration count (IterativeTensorSolverInterface); psi.0 (a MOOSE ParsedFunction) is the IC"""
+    import math
+    g = load_golden("rotating_grain_secant_gold.npz")
+    ic = tmp_path / "psi0.bin"
+    g["psi.0"].astype("<f8").tofile(ic)
+    ymax = 6 * math.pi * 2 / math.sin(math.pi / 3)
+    log = _run(["case=secant", "nx=40", "ny=40", "xmax=12pi", f"ymax={ymax!r}", f"ic={ic}", "substeps=3", "num_steps=10", "dt=1"], tmp_path)
+    assert log.count("converged=1") == 10
+    worst = 0.0
+    for k in range(0, 11):
+        psi = np.fromfile(tmp_path / f"psi.{k}.bin", dtype="<f8").reshape(40, 40)
+        worst = max(worst, np.abs(g[f"psi.{k}"] - psi).max())
+    assert worst <= 1e-10, worst
+
+
+@pytest.mark.parametrize("n", [24, 64])
+def test_broyden_vs_oracle_through_the_shim(n, tmp_path):
+    """[TensorSolver] type = HipBroydenSolver on two coupled reaction-diffusion variables (the problem of tests/test_broyden_gpu.py;
+    the reference has neither an input nor gold data for BroydenSolver: **parity unpinned**, oracle restatement only): three substeps,
+    the oracle's iteration counts and convergence flags in every one, fields 1e-11 after the first (converging) substep and 1e-6
+    through the ill-conditioned ones (rank-one updates divided by s.y down to 1e-12)"""
+    import math
+    import torch
+    import oracle.marlin_oracle as mo
+    dom = mo.Domain(2, [n, n], [2.0 * math.pi] * 2)
+    state = {"u": (1.0 + 0.1 * torch.sin(dom.axis[0]) * torch.sin(dom.axis[1])).expand(dom.shape).contiguous(),
+             "v": (3.0 + 0.1 * torch.cos(dom.axis[0]) * torch.cos(2 * dom.axis[1])).expand(dom.shape).contiguous()}
+    Du, Dv = mo.reciprocal_laplacian_factor(dom, 1e-2), mo.reciprocal_laplacian_factor(dom, 1e-3)
+
+    def compute(s):
+        u, v = s["u"], s["v"]
+        s["u_bar"], s["v_bar"] = dom.fft(u), dom.fft(v)
+        s["su_bar"] = dom.fft((1.0 - (3.5 + 1.0) * u) + torch.pow(u, 2.0) * v)
+        s["sv_bar"] = dom.fft(3.5 * u - torch.pow(u, 2.0) * v)
+
+    ref = mo.BroydenSolver(dom, state, compute, [("u", "u_bar", Du, "su_bar"), ("v", "v_bar", Dv, "sv_bar")], substeps=3, max_iterations=30,
+                           relative_tolerance=1e-6, absolute_tolerance=1e-10)
+    log = _run(["case=broyden", f"nx={n}", f"ny={n}", "xmax=2pi", "ymax=2pi", "num_steps=3", "dt=0.05"], tmp_path)
+    got = [(int(i), bool(int(c))) for i, c in re.findall(r"iterations=(\d+) converged=(\d)", log)]
+    want, errs = [], []
+    for k in range(3):
+        ref.substep(0.05)
+        want.append((ref.iterations, ref.converged))
+        u = np.fromfile(tmp_path / f"u.{k + 1}.bin", dtype="<f8").reshape(n, n)
+        v = np.fromfile(tmp_path / f"v.{k + 1}.bin", dtype="<f8").reshape(n, n)
+        errs.append(max(np.abs(u - state["u"].numpy()).max(), np.abs(v - state["v"].numpy()).max()))
+    assert got == want, (got, want)
+    assert errs[0] <= 1e-11 and max(errs) <= 1e-6, errs
+
+
 def test_mech3d_gold_through_the_shim(tmp_path):
     """test/tests/mechanics/tests:2-11 (mech3d.i) with [mech] type = HipFFTMechanics inside the root group of a ForwardEulerSolver
     that forwards Fnew -> F: F_k.frame, disp_* (HipComputeDisplacements) and sV (HipComputeVonMisesStress) of gold mech3d.h5 to
