@@ -347,11 +347,11 @@ int fft_inverse_planned(mrl_ctx *ctx, const double *d_in, double *d_out, long lo
   return MRL_OK;
 }
 
-// one AdamsBashforthMoulton::substep with its compute group (AdamsBashforthMoulton.C:60-101); built-in free-energy families only
-// (a parsed free energy takes the any-length path), no spectral carry-over
+// one AdamsBashforthMoulton::substep with its compute group (AdamsBashforthMoulton.C:60-101); a parsed free energy is compiled into
+// the forward z pass at run time as on the fused path (expr.hip: parsed_z_fwd_launch); no spectral carry-over
 int ch_substep_planned(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new, const double *const *Nhat_old,
                        int order, double sub_dt, double *cbar, double *mu, int carry) {
-  if (!planned_unfused_ok(ctx) || carry != MRL_CARRY_NONE || cp.family == MRL_FE_PARSED) return MRL_ERR_UNSUPPORTED;
+  if (!planned_unfused_ok(ctx) || carry != MRL_CARRY_NONE) return MRL_ERR_UNSUPPORTED;
   const PGeo g = pgeo(ctx);
   const long long nreal = g.nx * g.ny * g.nz, nspec = g.nx * g.ny * g.nzc;
   MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nspec));
@@ -362,7 +362,11 @@ int ch_substep_planned(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *
   const double h = 16.0 * nspec;
   {
     ProfScope ps(ctx, "chp_A_z_fwd", 8.0 * nreal + 2.0 * h + (mu ? 8.0 * nreal : 0.0));
-    MRL_TRY(z_fwd_launch(ctx, g.nz, 1, cp.family, c_in, w_c, w_mu, mu, chp, g.nx * g.ny));
+    if (cp.family == MRL_FE_PARSED) {
+      MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)g.nz, 1, c_in, w_c, w_mu, mu, g.nx * g.ny));
+    } else {
+      MRL_TRY(z_fwd_launch(ctx, g.nz, 1, cp.family, c_in, w_c, w_mu, mu, chp, g.nx * g.ny));
+    }
   }
   {
     ProfScope ps(ctx, "chp_B_y_fwd", 4.0 * h);

@@ -791,11 +791,13 @@ static int build_mu_function(mrl_parsed *p, std::string &out) {
 // (ea: the fused inverse + forward kernel, ZPlanEA<N>)
 static int plan_shape(mrl_ctx *ctx, int N, int *T, int *NT, size_t *lds, bool ea = false) {
   *T = 0;
-  if (!pow2_ok(N)) return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
+  // the forward z pass exists for every planned length (the radix-30 / radix-20 lengths of ch_planned.hip included: their k_z_fwd is a
+  // plain kernel with one array per thread); the fused inverse + forward pass only for the lengths of the fused family
+  if (ea ? !pow2_ok(N) : !plain_ok(N)) return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
   if (ea) {
     MRL_SWITCH_N(N, (*T = p2::ZPlanEA<NN>::T, *NT = p2::ZPlanEA<NN>::NT, *lds = p2::lds_line_ea<NN>()));
   } else {
-    MRL_SWITCH_N(N, (*T = p2::ZPlan<NN>::T, *NT = p2::ZPlan<NN>::NT, *lds = p2::lds_line<NN>()));
+    MRL_SWITCH_N_PLAIN(N, (*T = p2::ZPlan<NN>::T, *NT = p2::ZPlan<NN>::NT, *lds = p2::lds_line<NN>()));
   }
   if (*T == 0) return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
   return MRL_OK;

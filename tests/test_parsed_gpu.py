@@ -113,13 +113,17 @@ def test_derivative_vs_finite_difference(ctx, expr):
         assert (d - fd).abs().max().item() <= 1e-7 * max(1.0, fd.abs().max().item())
 
 
-@pytest.mark.parametrize("shape", [(64, 64, 64), (12, 10, 9), (128, 64, 64)])
+@pytest.mark.parametrize("shape", [(64, 64, 64), (12, 10, 9), (128, 64, 64), (120, 60, 64), (64, 48, 150), (160, 40, 240)])
 def test_parsed_free_energy_in_ch_substep(shape):
     """MRL_FE_PARSED: the user's free energy, differentiated symbolically and compiled INTO the forward z pass on
-    fast-path shapes (hiprtc instance of k_z_fwd), must reproduce the built-in families bit for bit (same tree)"""
+    fast-path shapes (hiprtc instance of k_z_fwd), must reproduce the built-in families bit for bit (same tree).  Round 5: also on
+    the planned-unfused path (radix-30 / radix-20 lengths on any axis, ch_planned.hip) -- before, a parsed free energy sent those
+    grids to the any-length path"""
     from marlin_amd.api import Context, ParsedCompute, ch_params, FE_PFHUB
     L = [3.0, 2.0, 2.5]
     ctx = Context(3, list(shape), L)
+    planned_unfused = any(n in (60, 120, 150, 160, 240) for n in shape)
+    ctx.set_profiling(True)
     torch.manual_seed(9)
     c0 = (torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44).cuda()
     cases = [(ch_params(), ParsedCompute(ctx, "0.1*c^2*(c-1)^2", inputs=["c"], derivatives=["c"])),
@@ -137,6 +141,9 @@ def test_parsed_free_energy_in_ch_substep(shape):
             res.append((c2.cpu(), N1.cpu(), mu.cpu()))
         for a, b in zip(*res):
             assert torch.equal(a, b)
+        if planned_unfused:   # both parameter sets ran the planned kernels: 2 + 2 substeps, none through the any-length transforms
+            slots = {k["kernel"]: k["launches"] for k in ctx.get_profile() if k["launches"]}
+            assert slots.get("chp_A_z_fwd", 0) >= 4 and "ch_kspace" not in slots, slots
         # the multi-substep call (run-time compiled k_z_inv_fwd with the generated chemical potential between two substeps)
         multi = []
         for prm in (builtin, pp):
