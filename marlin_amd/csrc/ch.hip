@@ -554,14 +554,34 @@ int mrl_kspace_coupled(mrl_ctx *ctx, int nvar, double *const *d_ubar_out, const 
     const size_t o_nt = put(nt.data(), sizeof(int) * nvar), o_cf = put(coef.data(), sizeof(double) * coef.size()),
                  o_N = put(Np.data(), sizeof(void *) * Np.size()), o_u = put(u0.data(), sizeof(void *) * nvar),
                  o_L = put(Lp.data(), sizeof(void *) * Lp.size()), o_o = put(outp.data(), sizeof(void *) * nvar);
+    // workgroups: as many as the grid needs, at most 256, and no more than a 256 MB workspace holds (32 variables: 108 instead of 256;
+    // the kernel walks the grid with a stride of `lanes`)
+    const size_t per_lane = sizeof(double) * (size_t)(nvar * nvar + 2 * nvar);
     long long nb = (n_spec + 255) / 256;
     if (nb > 256) nb = 256;
+    const long long cap_nb = (long long)((256u << 20) / (per_lane * 256));
+    if (nb > cap_nb) nb = cap_nb < 1 ? 1 : cap_nb;
     const long long lanes = nb * 256;
-    MRL_TRY(ensure_work(ctx, 16, sizeof(double) * (size_t)(nvar * nvar + 2 * nvar) * (size_t)lanes));
-    MRL_TRY(ensure_work(ctx, 17, tab.size()));
-    unsigned char *dt_ = reinterpret_cast<unsigned char *>(ctx->d_work[17]);
-    MRL_HIP(ctx, hipMemcpyAsync(dt_, tab.data(), tab.size(), hipMemcpyHostToDevice, ctx->stream));
-    MRL_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (`tab` is pageable host memory that dies with this scope)
+    MRL_TRY(ensure_work(ctx, 16, per_lane * (size_t)lanes));
+    // the tables travel through a pinned staging slot; the slot is reused only after the launch that read its device copy has
+    // finished (an event per slot: with four slots the wait is on a launch four calls back) -- no synchronisation per call
+    auto &slot = ctx->tab_ring[ctx->tab_next];
+    ctx->tab_next = (ctx->tab_next + 1) % 4;
+    if (slot.done) MRL_HIP(ctx, hipEventSynchronize(slot.done));
+    if (slot.cap < tab.size()) {
+      if (slot.h) (void)hipHostFree(slot.h);
+      if (slot.d) (void)hipFree(slot.d);
+      slot.h = slot.d = nullptr;
+      slot.cap = 0;
+      const size_t cap = (tab.size() + 4095) & ~size_t(4095);
+      MRL_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&slot.h), cap));
+      MRL_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&slot.d), cap));
+      slot.cap = cap;
+    }
+    if (!slot.done) MRL_HIP(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    std::memcpy(slot.h, tab.data(), tab.size());
+    unsigned char *dt_ = slot.d;
+    MRL_HIP(ctx, hipMemcpyAsync(dt_, slot.h, tab.size(), hipMemcpyHostToDevice, ctx->stream));
     CoupledAnyArgs g{};
     g.nv = nvar;
     g.flags = flags;
@@ -577,6 +597,7 @@ int mrl_kspace_coupled(mrl_ctx *ctx, int nvar, double *const *d_ubar_out, const 
     ProfScope ps(ctx, "kspace_coupled_general");
     hipLaunchKernelGGL(k_kspace_coupled_any, dim3((unsigned)nb), dim3(256), 0, ctx->stream, g, (long long)n_spec);
     MRL_HIP(ctx, hipGetLastError());
+    MRL_HIP(ctx, hipEventRecord(slot.done, ctx->stream));
     return MRL_OK;
   }
   CoupledArgs a{};

@@ -572,6 +572,11 @@ void mrl_ctx_destroy(mrl_ctx *c) {
   if (c->ev_start) hipEventDestroy(c->ev_start);
   for (int e = 0; e < 2; ++e)
     if (c->cg_ev[e]) hipEventDestroy(c->cg_ev[e]);
+  for (auto &t : c->tab_ring) {
+    if (t.h) hipHostFree(t.h);
+    if (t.d) hipFree(t.d);
+    if (t.done) hipEventDestroy(t.done);
+  }
   if (c->ev_stop) hipEventDestroy(c->ev_stop);
   for (auto &p : c->prof_events) {
     hipEventDestroy(p.first);

@@ -116,6 +116,15 @@ struct mrl_ctx {
 
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   hipEvent_t cg_ev[2] = {nullptr, nullptr};   // look-ahead conjugate-gradient loop (mech.hip): end of iteration k, k & 1
+  // small argument tables that do not fit a kernel's argument block (mrl_kspace_coupled beyond 8 variables): a ring of pinned host
+  // staging slots, each with its device copy and an event that says when the launch that read it has finished -- no host
+  // synchronisation per call, capture-safe ordering
+  struct TabSlot {
+    unsigned char *h = nullptr, *d = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+  } tab_ring[4];
+  int tab_next = 0;
   bool profiling = false;
   std::vector<mrl::Profile> prof;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
