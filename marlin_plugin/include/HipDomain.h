@@ -86,6 +86,16 @@ public:
            t.sizes().vec() == reciprocalShape() && t.strides().vec() == spectralStrides();
   }
 
+  /// host copy of this rank's reciprocal axis `a` (what `_i`, `_j`, `_k` hold in a TensorOperatorBase); absent axes are {0}
+  std::vector<double> reciprocalAxis(unsigned int a) const
+  {
+    if (a >= _dim)
+      return {0.0};
+    std::vector<double> k((std::size_t)_recip_n[a]);
+    check(mrl_ctx_reciprocal_axis(_ctx, (int)a, k.data(), (int64_t)k.size()), "marlin_hip");
+    return k;
+  }
+
   /// turn a return code into a mooseError carrying the library's message
   void check(int rc, const std::string & who) const
   {

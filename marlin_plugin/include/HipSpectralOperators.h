@@ -3,6 +3,8 @@
 //   HipFFTGradientSquare       FFTGradientSquare       (src/tensor_computes/FFTGradientSquare.C:14-50:  _u = factor * sum_d ifft(fft(input) k_d i)^2)
 //   HipComputeDisplacements    ComputeDisplacements    (src/tensor_computes/ComputeDisplacements.C:53-107)
 //   HipComputeVonMisesStress   ComputeVonMisesStress   (src/tensor_computes/ComputeVonMisesStress.C:31-66)
+//   HipDeAliasingTensor        DeAliasingTensor        (src/tensor_computes/DeAliasingTensor.C:14-65: SHARP 2/3 rule, Hou-Li filter)
+//   HipSwiftHohenbergLinear    SwiftHohenbergLinear    (src/tensor_computes/SwiftHohenbergLinear.C:14-40: r - alpha^2 (1 - k^2)^2)
 #pragma once
 
 #include "TensorOperator.h"
@@ -66,4 +68,34 @@ public:
 protected:
   std::shared_ptr<HipDomain> _hip;
   const torch::Tensor & _stress;
+};
+
+/// a reciprocal-grid operator that is one generated kernel of the extra symbols (kx, ky, kz, k2) and named constants
+class HipReciprocalExpression : public TensorOperator<>
+{
+public:
+  HipReciprocalExpression(const InputParameters & parameters);
+  ~HipReciprocalExpression();
+  virtual void computeBuffer() override;
+
+protected:
+  /// derived constructors call this once their constants are known
+  void build(const std::string & expression, const std::vector<std::string> & names, const std::vector<double> & values);
+
+  std::shared_ptr<HipDomain> _hip;
+  mrl_parsed * _parsed = nullptr;
+};
+
+class HipDeAliasingTensor : public HipReciprocalExpression
+{
+public:
+  static InputParameters validParams();
+  HipDeAliasingTensor(const InputParameters & parameters);
+};
+
+class HipSwiftHohenbergLinear : public HipReciprocalExpression
+{
+public:
+  static InputParameters validParams();
+  HipSwiftHohenbergLinear(const InputParameters & parameters);
 };

@@ -2,10 +2,15 @@
 #include "HipSpectralOperators.h"
 #include "DomainAction.h"
 
+#include <algorithm>
+#include <cmath>
+
 registerMooseObject("MarlinApp", HipFFTGradient);
 registerMooseObject("MarlinApp", HipFFTGradientSquare);
 registerMooseObject("MarlinApp", HipComputeDisplacements);
 registerMooseObject("MarlinApp", HipComputeVonMisesStress);
+registerMooseObject("MarlinApp", HipDeAliasingTensor);
+registerMooseObject("MarlinApp", HipSwiftHohenbergLinear);
 
 namespace
 {
@@ -195,4 +200,76 @@ HipComputeVonMisesStress::computeBuffer()
   torch::Tensor out = torch::empty(_hip->realShape(), MooseTensor::floatTensorOptions());
   _hip->check(mrl_mech_von_mises(_hip->ctx(), s.data_ptr<double>(), out.data_ptr<double>()), name());
   _u = out;
+}
+
+HipReciprocalExpression::HipReciprocalExpression(const InputParameters & parameters)
+  : TensorOperator<>(parameters), _hip(HipDomain::get(_domain, comm()))
+{
+}
+
+HipReciprocalExpression::~HipReciprocalExpression()
+{
+  if (_parsed)
+    mrl_parsed_destroy(_parsed);
+}
+
+void
+HipReciprocalExpression::build(const std::string & expression, const std::vector<std::string> & names, const std::vector<double> & values)
+{
+  std::vector<const char *> cn;
+  for (const auto & n : names)
+    cn.push_back(n.c_str());
+  if (mrl_parsed_create(_hip->ctx(), &_parsed, expression.c_str(), 0, nullptr, nullptr, (int)cn.size(), cn.data(), values.data(), 0,
+                        nullptr, /*extra_symbols=*/1, /*reciprocal=*/1) != MRL_OK)
+    mooseError(name(), ": ", mrl_last_error(_hip->ctx()));
+}
+
+void
+HipReciprocalExpression::computeBuffer()
+{
+  torch::Tensor out = torch::empty(_hip->reciprocalShape(), MooseTensor::floatTensorOptions());
+  _hip->check(mrl_parsed_eval(_parsed, nullptr, out.data_ptr<double>(), _hip->reciprocalCount(), _time), name());
+  _u = out;
+}
+
+InputParameters
+HipDeAliasingTensor::validParams()
+{
+  InputParameters params = TensorOperator<>::validParams();
+  params.addClassDescription("Create a de-aliasing filter on libmarlin_hip (MI355X).");
+  params.addRequiredParam<MooseEnum>("method", MooseEnum("SHARP HOULI"), "Filter: SHARP (2/3 rule) or HOULI (Hou-Li exponential)");
+  params.addParam<Real>("p", 16, "Hou-Li filter exponent");
+  params.addParam<Real>("alpha", 36, "Hou-Li filter pre-factor");
+  return params;
+}
+
+HipDeAliasingTensor::HipDeAliasingTensor(const InputParameters & parameters) : HipReciprocalExpression(parameters)
+{
+  // maximum |frequency| of this rank's reciprocal axes (DeAliasingTensor.C:40-43: max(abs(_i)) ...)
+  double mx[3] = {0.0, 0.0, 0.0};
+  for (unsigned int d = 0; d < 3; ++d)
+    for (const double k : _hip->reciprocalAxis(d))
+      mx[d] = std::max(mx[d], std::fabs(k));
+  const int method = getParam<MooseEnum>("method");
+  if (method == 0) // SHARP, :47-52
+    build("if((abs(kx) > cx) | (abs(ky) > cy) | (abs(kz) > cz), 0, 1)", {"cx", "cy", "cz"}, {2 * mx[0] / 3, 2 * mx[1] / 3, 2 * mx[2] / 3});
+  else // HOULI, :54-60
+    build("exp(0-alpha*((abs(kx)/mx)^p + (abs(ky)/my)^p + (abs(kz)/mz)^p))", {"alpha", "p", "mx", "my", "mz"},
+          {getParam<Real>("alpha"), getParam<Real>("p"), mx[0] ? mx[0] : 1.0, mx[1] ? mx[1] : 1.0, mx[2] ? mx[2] : 1.0});
+}
+
+InputParameters
+HipSwiftHohenbergLinear::validParams()
+{
+  InputParameters params = TensorOperator<>::validParams();
+  params.addClassDescription("Swift-Hohenberg linear operator r - alpha^2 (1 - k^2)^2 on libmarlin_hip (MI355X).");
+  params.addRequiredParam<Real>("r", "Control parameter");
+  params.addRequiredParam<Real>("alpha", "Wave number scale");
+  return params;
+}
+
+HipSwiftHohenbergLinear::HipSwiftHohenbergLinear(const InputParameters & parameters) : HipReciprocalExpression(parameters)
+{
+  const Real alpha = getParam<Real>("alpha");
+  build("r-aa*(1-k2)*(1-k2)", {"r", "aa"}, {getParam<Real>("r"), alpha * alpha}); // SwiftHohenbergLinear.C:38
 }

@@ -16,6 +16,8 @@
 //               (test/tests/tensor_compute/rotating_grain_secant.i: HipSecantSolver, iteration-adaptive dt): writes psi.<step>.bin
 //   shim-driver case=broyden nx=24 ny=24 xmax=2pi ymax=2pi num_steps=3 dt=0.05 out=dir
 //               (two coupled Brusselator variables through HipBroydenSolver, one substep per step): writes u / v.<step>.bin
+//   shim-driver case=explicit nx=50 ny=50 xmax=3 ymax=3 ic=c0.bin method=SHARP|HOULI substeps=50 num_steps=20 dt=0.5 out=dir
+//               (test/tests/cahnhilliard/cahnhilliard_explicit_smooth.i: HipForwardEulerSolver + HipDeAliasingTensor): writes c / mu.<step>.bin
 //   shim-driver case=mechanics nx=16 ny=16 nz=16 substeps=10 num_steps=3 dt=0.01 l_tol=1e-2 nl_rel_tol=2e-2 nl_abs_tol=2e-2 out=dir
 //               (test/tests/mechanics/mech3d.i with [mech] type = HipFFTMechanics, [displacements] type = HipComputeDisplacements,
 //               [vonmises] type = HipComputeVonMisesStress): writes F / stress / disp / sV.<frame>.bin
@@ -92,22 +94,6 @@ create(TensorProblem & problem, const std::string & type, const std::string & na
     mooseError(name, ": a '", type, "' is not of the requested base class");
   return obj;
 }
-
-/// the reference's ForwardEulerSolver with no variables (src/tensor_solver/ForwardEulerSolver.C:28-38; mech3d.i:81-89 uses it that way)
-class StubForwardEulerSolver : public TensorSolver
-{
-public:
-  static InputParameters validParams() { return TensorSolver::validParams(); }
-  StubForwardEulerSolver(const InputParameters & p) : TensorSolver(p) {}
-
-protected:
-  virtual void substep() override
-  {
-    _compute->computeBuffer();
-    forwardBuffers();
-  }
-};
-registerMooseObject("MarlinApp", StubForwardEulerSolver);
 
 /// test/src/tensor_computes/MacroscopicShearTensor.C:31-43
 class StubMacroscopicShearTensor : public TensorOperator<>
@@ -372,11 +358,7 @@ run_secant(const std::string & out)
   DomainAction domain = make_domain(2);
   TensorProblem problem(domain);
   problem.getBuffer("psi") = read_bin(arg("ic"), std::vector<int64_t>(domain.getShape().begin(), domain.getShape().end()));
-  // SwiftHohenbergLinear.C:35-39: r - alpha^2 (1 - k^2)^2
-  create<TensorOperatorBase>(problem, "HipParsedCompute", "linear",
-                             {{"buffer", "linear"}, {"expression", "r-aa*(1-k2)*(1-k2)"}, {"constant_names", "r aa"},
-                              {"constant_expressions", arg("r", "0.025") + " " + arg("aa", "1")}, {"extra_symbols", "true"},
-                              {"expand", "RECIPROCAL"}})
+  create<TensorOperatorBase>(problem, "HipSwiftHohenbergLinear", "linear", {{"buffer", "linear"}, {"alpha", arg("alpha", "1")}, {"r", arg("r", "0.025")}})
       ->computeBuffer();
   InputParameters gp;
   gp.set<std::string>("_object_name") = "root";
@@ -472,6 +454,42 @@ run_broyden(const std::string & out)
   return 0;
 }
 
+// test/tests/cahnhilliard/cahnhilliard_explicit_smooth.i: explicit Euler Cahn-Hilliard with a de-aliasing filter on the rate
+static int
+run_explicit(const std::string & out)
+{
+  DomainAction domain = make_domain(2);
+  TensorProblem problem(domain);
+  problem.getBuffer("c") = read_bin(arg("ic"), std::vector<int64_t>(domain.getShape().begin(), domain.getShape().end()));
+  problem.getBuffer("mu") = torch::zeros(domain.getShape(), MooseTensor::floatTensorOptions());                       // ConstantTensor
+  problem.getBuffer("dc_dt_bar") = torch::zeros(domain.getReciprocalShape(), MooseTensor::complexFloatTensorOptions()); // ConstantReciprocalTensor
+  create<TensorOperatorBase>(problem, "HipReciprocalLaplacianFactor", "Mbar", {{"buffer", "Mbar"}, {"factor", arg("mobility", "0.2")}})->computeBuffer();
+  create<TensorOperatorBase>(problem, "HipReciprocalLaplacianSquareFactor", "Mkappabarbar", {{"buffer", "Mkappabarbar"}, {"factor", arg("Mkappa", "2e-5")}})
+      ->computeBuffer();
+  create<TensorOperatorBase>(problem, "HipDeAliasingTensor", "smooth", {{"buffer", "smooth"}, {"method", arg("method", "SHARP")}})->computeBuffer();
+  InputParameters gp;
+  gp.set<std::string>("_object_name") = "cahn_hilliard";
+  gp.set<TensorProblem *>("_tensor_problem") = &problem;
+  auto root = std::make_shared<ComputeGroup>(gp);
+  root->add(create<TensorOperatorBase>(problem, "HipParsedCompute", "mu",
+                                       {{"buffer", "mu"}, {"expression", "0.1*c^2*(c-1)^2"}, {"inputs", "c"}, {"derivatives", "c"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipForwardFFT", "mubar", {{"buffer", "mubar"}, {"input", "mu"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipForwardFFT", "cbar", {{"buffer", "cbar"}, {"input", "c"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipParsedCompute", "dc_dt_bar",
+                                       {{"buffer", "dc_dt_bar"}, {"expression", "smooth * (Mbar*mubar - Mkappabarbar*cbar)"},
+                                        {"inputs", "Mbar mubar Mkappabarbar cbar smooth"}}));
+  problem.computes().push_back(root);
+  auto solver = create<TensorSolver>(problem, "HipForwardEulerSolver", "solver",
+                                     {{"root_compute", "cahn_hilliard"}, {"buffer", "c"}, {"reciprocal_buffer", "cbar"},
+                                      {"time_derivative_reciprocal", "dc_dt_bar"}, {"substeps", arg("substeps", "50")}});
+  solver->updateDependencies();
+  transient(problem, *solver, time_steps(), [&](int step) {
+    dump(out, "c", step, problem.getBuffer("c"));
+    dump(out, "mu", step, problem.getBuffer("mu"));
+  });
+  return 0;
+}
+
 static int
 run_mechanics(const std::string & out)
 {
@@ -520,7 +538,7 @@ run_mechanics(const std::string & out)
     mech.push_back({"l_max_its", arg("l_max_its")});
   root->add(create<TensorOperatorBase>(problem, "HipFFTMechanics", "mech", mech));
   problem.computes().push_back(root);
-  auto solver = create<TensorSolver>(problem, "StubForwardEulerSolver", "solver",
+  auto solver = create<TensorSolver>(problem, "HipForwardEulerSolver", "solver",
                                      {{"root_compute", "root"}, {"forward_buffer", "F"}, {"forward_buffer_new", "Fnew"},
                                       {"substeps", arg("substeps", "1")}});
   solver->updateDependencies();
@@ -622,6 +640,8 @@ main(int argc, char ** argv)
       return run_secant(out);
     if (which == "broyden")
       return run_broyden(out);
+    if (which == "explicit")
+      return run_explicit(out);
     if (which == "mechanics")
       return run_mechanics(out);
     if (which == "gradient" || which == "gradient_square")

@@ -197,8 +197,25 @@ def test_broyden_vs_oracle_through_the_shim(n, tmp_path):
     assert errs[0] <= 1e-11 and max(errs) <= 1e-6, errs
 
 
+@pytest.mark.parametrize("method", ["SHARP", "HOULI"])
+def test_cahnhilliard_explicit_smooth_gold_through_the_shim(method, tmp_path):
+    """test/tests/cahnhilliard/tests:121-143 (cahnhilliard_explicit_smooth.i, Exodiff): [TensorSolver] type = HipForwardEulerSolver
+    (1000 explicit substeps), the rate de-aliased by a HipDeAliasingTensor inside a reciprocal-grid HipParsedCompute; nodal c and
+    elemental mu of sharp.e / houli.e mapped back onto the 50 x 50 grid"""
+    g = load_golden(f"cahnhilliard_explicit_{method.lower()}_gold.npz")
+    ic = tmp_path / "c0.bin"
+    g["c.0"].astype("<f8").tofile(ic)
+    _run(["case=explicit", "nx=50", "ny=50", "xmax=3", "ymax=3", f"ic={ic}", f"method={method}", "substeps=50", "num_steps=20", "dt=0.5"],
+         tmp_path)
+    for k in (1, 2, 5, 10, 20):
+        c = np.fromfile(tmp_path / f"c.{k}.bin", dtype="<f8").reshape(50, 50)
+        mu = np.fromfile(tmp_path / f"mu.{k}.bin", dtype="<f8").reshape(50, 50)
+        assert np.abs(g[f"c.{k}"] - c).max() <= 1e-9
+        assert np.abs(g[f"mu.{k}"] - mu).max() <= 1e-10
+
+
 def test_mech3d_gold_through_the_shim(tmp_path):
-    """test/tests/mechanics/tests:2-11 (mech3d.i) with [mech] type = HipFFTMechanics inside the root group of a ForwardEulerSolver
+    """test/tests/mechanics/tests:2-11 (mech3d.i) with [mech] type = HipFFTMechanics inside the root group of a HipForwardEulerSolver
     that forwards Fnew -> F: F_k.frame, disp_* (HipComputeDisplacements) and sV (HipComputeVonMisesStress) of gold mech3d.h5 to
     1e-10, two Newton iterations per substep as the reference"""
     g = load_golden("mech3d_gold.npz")
