@@ -135,7 +135,7 @@ def test_moose_shim_compiles_against_the_stub_and_registers_its_classes():
     want = {"HipAdamsBashforthMoulton", "HipAdamsBashforthMoultonCoupled", "HipFFTMechanics", "HipForwardFFT", "HipInverseFFT",
             "HipParsedCompute", "HipReciprocalLaplacianFactor", "HipReciprocalLaplacianSquareFactor", "HipFFTGradient",
             "HipFFTGradientSquare", "HipComputeDisplacements", "HipComputeVonMisesStress", "HipETDRK4Solver", "HipSecantSolver",
-            "HipBroydenSolver"}
+            "HipBroydenSolver", "HipForwardEulerSolver", "HipDeAliasingTensor", "HipSwiftHohenbergLinear"}
     assert want <= types, want - types
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for t in want:
