@@ -698,3 +698,24 @@ protected:
   bool _is_converged;
   std::vector<std::shared_ptr<TensorPredictor>> _predictors;
 };
+
+/// include/tensor_timeintegrators/TensorTimeIntegrator.h:17-33 (the legacy [TensorTimeIntegrators] base: a TensorOperator with access
+/// to old buffer states and the substep size)
+template <typename T = torch::Tensor>
+class TensorTimeIntegrator : public TensorOperator<T>
+{
+public:
+  static InputParameters validParams() { return TensorOperator<T>::validParams(); }
+  TensorTimeIntegrator(const InputParameters & parameters) : TensorOperator<T>(parameters), _sub_dt(this->_tensor_problem.subDt()) {}
+
+protected:
+  const std::vector<T> & getBufferOld(const std::string & param, unsigned int max_states)
+  {
+    return getBufferOldByName(this->template getParam<TensorInputBufferName>(param), max_states);
+  }
+  const std::vector<T> & getBufferOldByName(const TensorInputBufferName & buffer_name, unsigned int max_states)
+  {
+    return this->_tensor_problem.template getBufferOld<T>(buffer_name, max_states);
+  }
+  const Real & _sub_dt;
+};

@@ -18,6 +18,8 @@
 //               (two coupled Brusselator variables through HipBroydenSolver, one substep per step): writes u / v.<step>.bin
 //   shim-driver case=explicit nx=50 ny=50 xmax=3 ymax=3 ic=c0.bin method=SHARP|HOULI substeps=50 num_steps=20 dt=0.5 out=dir
 //               (test/tests/cahnhilliard/cahnhilliard_explicit_smooth.i: HipForwardEulerSolver + HipDeAliasingTensor): writes c / mu.<step>.bin
+//   shim-driver case=kks nx=20 ny=20 xmin=-50 xmax=50 ymin=-50 ymax=50 c=c0.bin eta=eta0.bin psi=psi0.bin num_steps=10 dt=0.1 out=dir
+//               (test/tests/kks/KKS_no_flux_bc.i: HipReciprocalMatDiffusion, HipReciprocalAllenCahn, two-variable HipAdamsBashforthMoulton order 3)
 //   shim-driver case=mechanics nx=16 ny=16 nz=16 substeps=10 num_steps=3 dt=0.01 l_tol=1e-2 nl_rel_tol=2e-2 nl_abs_tol=2e-2 out=dir
 //               (test/tests/mechanics/mech3d.i with [mech] type = HipFFTMechanics, [displacements] type = HipComputeDisplacements,
 //               [vonmises] type = HipComputeVonMisesStress): writes F / stress / disp / sV.<frame>.bin
@@ -94,6 +96,26 @@ create(TensorProblem & problem, const std::string & type, const std::string & na
     mooseError(name, ": a '", type, "' is not of the requested base class");
   return obj;
 }
+
+/// the pre-TensorSolver syntax ([TensorTimeIntegrators], TensorProblem.C: per substep the root compute, then every integrator)
+class StubTimeIntegratorSolver : public TensorSolver
+{
+public:
+  static InputParameters validParams() { return TensorSolver::validParams(); }
+  StubTimeIntegratorSolver(const InputParameters & p) : TensorSolver(p) {}
+  void add(std::shared_ptr<TensorOperatorBase> ti) { _integrators.push_back(std::move(ti)); }
+
+protected:
+  virtual void substep() override
+  {
+    _compute->computeBuffer();
+    forwardBuffers();
+    for (auto & ti : _integrators)
+      ti->computeBuffer();
+  }
+  std::vector<std::shared_ptr<TensorOperatorBase>> _integrators;
+};
+registerMooseObject("MarlinApp", StubTimeIntegratorSolver);
 
 /// test/src/tensor_computes/MacroscopicShearTensor.C:31-43
 class StubMacroscopicShearTensor : public TensorOperator<>
@@ -194,6 +216,87 @@ run_cahnhilliard(const std::string & out)
     dump(out, "Nhat", step, problem.getBuffer("Mbarmubar")); // (read through the published view: dense values)
     std::cout << "step " << step << " time " << problem.time() << " sub_time " << problem.subTime() << " sub_dt " << problem.subDt()
               << "\n";
+  });
+  return 0;
+}
+
+// cahnhilliard.i in the legacy [TensorTimeIntegrators] form: explicit compute group + FFTSemiImplicit (history_size 1)
+static int
+run_semi_implicit(const std::string & out)
+{
+  DomainAction domain = make_domain(2);
+  TensorProblem problem(domain);
+  problem.getBuffer("c") = read_bin(arg("ic"), std::vector<int64_t>(domain.getShape().begin(), domain.getShape().end()));
+  create<TensorOperatorBase>(problem, "HipReciprocalLaplacianFactor", "Mbar", {{"buffer", "Mbar"}, {"factor", arg("mobility", "0.2")}})->computeBuffer();
+  create<TensorOperatorBase>(problem, "HipReciprocalLaplacianSquareFactor", "kappabarbar", {{"buffer", "kappabarbar"}, {"factor", arg("kappa_factor", "-0.001")}})
+      ->computeBuffer();
+  InputParameters gp;
+  gp.set<std::string>("_object_name") = "root";
+  gp.set<TensorProblem *>("_tensor_problem") = &problem;
+  auto root = std::make_shared<ComputeGroup>(gp);
+  root->add(create<TensorOperatorBase>(problem, "HipParsedCompute", "mu",
+                                       {{"buffer", "mu"}, {"expression", "0.1*c^2*(c-1)^2"}, {"inputs", "c"}, {"derivatives", "c"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipForwardFFT", "mubar", {{"buffer", "mubar"}, {"input", "mu"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipParsedCompute", "Mbarmubar",
+                                       {{"buffer", "Mbarmubar"}, {"expression", "Mbar*mubar"}, {"inputs", "Mbar mubar"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipForwardFFT", "cbar", {{"buffer", "cbar"}, {"input", "c"}}));
+  problem.computes().push_back(root);
+  auto solver = create<StubTimeIntegratorSolver>(problem, "StubTimeIntegratorSolver", "solver",
+                                                 {{"root_compute", "root"}, {"substeps", arg("substeps", "10")}});
+  solver->add(create<TensorOperatorBase>(problem, "HipFFTSemiImplicit", "c",
+                                         {{"buffer", "c"}, {"reciprocal_buffer", "cbar"}, {"linear_reciprocal", "kappabarbar"},
+                                          {"nonlinear_reciprocal", "Mbarmubar"}, {"history_size", "1"}}));
+  solver->updateDependencies();
+  transient(problem, *solver, time_steps(), [&](int step) {
+    dump(out, "c", step, problem.getBuffer("c"));
+    dump(out, "mu", step, problem.getBuffer("mu"));
+  });
+  return 0;
+}
+
+// test/tests/tensor_compute/coupled_pf_mech.i: Cahn-Hilliard + homogeneous quasistatic elasticity with the eigenstrain e0 * c, through
+// the legacy FFTSemiImplicit integrator
+static int
+run_coupled_pf_mech(const std::string & out)
+{
+  DomainAction domain = make_domain(3);
+  TensorProblem problem(domain);
+  const std::vector<int64_t> shape(domain.getShape().begin(), domain.getShape().end());
+  problem.getBuffer("c") = read_bin(arg("ic"), shape);
+  for (const char * d : {"disp_x", "disp_y", "disp_z"})
+    problem.getBuffer(d) = torch::zeros(shape, MooseTensor::floatTensorOptions()); // RandomTensor min = max = 0
+  const std::string mu = arg("mu", "50.0"), lambda = arg("lambda", "100.0"), e0 = arg("e0", "0.02");
+  create<TensorOperatorBase>(problem, "HipReciprocalLaplacianFactor", "Mbar", {{"buffer", "Mbar"}, {"factor", arg("mobility", "0.2")}})->computeBuffer();
+  create<TensorOperatorBase>(problem, "HipReciprocalLaplacianSquareFactor", "kappabarbar", {{"buffer", "kappabarbar"}, {"factor", arg("kappa", "-0.001")}})
+      ->computeBuffer();
+  InputParameters gp;
+  gp.set<std::string>("_object_name") = "Solve";
+  gp.set<TensorProblem *>("_tensor_problem") = &problem;
+  auto root = std::make_shared<ComputeGroup>(gp);
+  root->add(create<TensorOperatorBase>(problem, "HipParsedCompute", "mu",
+                                       {{"buffer", "mu"}, {"expression", "0.1*c^2*(c-1)^2"}, {"inputs", "c"}, {"derivatives", "c"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipForwardFFT", "mubar", {{"buffer", "mubar"}, {"input", "mu"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipForwardFFT", "cbar", {{"buffer", "cbar"}, {"input", "c"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipFFTQuasistaticElasticity", "qsmech",
+                                       {{"displacements", "disp_x disp_y disp_z"}, {"cbar", "cbar"}, {"mu", mu}, {"lambda", lambda}, {"e0", e0}}));
+  root->add(create<TensorOperatorBase>(problem, "HipFFTElasticChemicalPotential", "mumechbar",
+                                       {{"buffer", "mumechbar"}, {"displacements", "disp_x disp_y disp_z"}, {"cbar", "cbar"}, {"mu", mu},
+                                        {"lambda", lambda}, {"e0", e0}}));
+  root->add(create<TensorOperatorBase>(problem, "HipInverseFFT", "mumech", {{"buffer", "mumech"}, {"input", "mumechbar"}}));
+  root->add(create<TensorOperatorBase>(problem, "HipParsedCompute", "Mbarmubar",
+                                       {{"buffer", "Mbarmubar"}, {"expression", "Mbar*(mubar+mumechbar)"}, {"inputs", "Mbar mubar mumechbar"}}));
+  problem.computes().push_back(root);
+  auto solver = create<StubTimeIntegratorSolver>(problem, "StubTimeIntegratorSolver", "solver",
+                                                 {{"root_compute", "Solve"}, {"substeps", arg("substeps", "10")}});
+  solver->add(create<TensorOperatorBase>(problem, "HipFFTSemiImplicit", "c",
+                                         {{"buffer", "c"}, {"reciprocal_buffer", "cbar"}, {"linear_reciprocal", "kappabarbar"},
+                                          {"nonlinear_reciprocal", "Mbarmubar"}, {"history_size", "1"}}));
+  solver->updateDependencies();
+  transient(problem, *solver, time_steps(), [&](int step) {
+    dump(out, "c", step, problem.getBuffer("c"));
+    dump(out, "mumech", step, problem.getBuffer("mumech"));
+    for (const char * d : {"disp_x", "disp_y", "disp_z"})
+      dump(out, d, step, problem.getBuffer(d));
   });
   return 0;
 }
@@ -490,6 +593,64 @@ run_explicit(const std::string & out)
   return 0;
 }
 
+// test/tests/kks/KKS_no_flux_bc.i: two-variable Kim-Kim-Suzuki model with the smooth boundary method; AdamsBashforthMoulton order 3
+static int
+run_kks(const std::string & out)
+{
+  DomainAction domain = make_domain(2);
+  TensorProblem problem(domain);
+  const std::vector<int64_t> shape(domain.getShape().begin(), domain.getShape().end());
+  for (const char * b : {"c", "eta", "psi"})
+    problem.getBuffer(b) = read_bin(arg(b), shape);
+  auto constant = [&](const char * b, double v) { problem.getBuffer(b) = torch::full(shape, v, MooseTensor::floatTensorOptions()); };
+  constant("M", argd("M", 5.0));
+  constant("L", argd("L", 5.0));
+  constant("L_kappa", argd("L", 5.0) * argd("kappa_eta", 5.0));
+  // ${F} after MOOSE's textual substitution of h_eta, rho_sq, w, c0_a, c0_b (KKS_no_flux_bc.i:24-25)
+  const std::string h = "eta^3*(6*eta^2-15*eta+10)";
+  const std::string F = h + "*(2*((c - (1-" + h + ")*(0.7 - 0.3))-0.3)^2) + (1-" + h + ")*(2*((c + (" + h + ")*(0.7 - 0.3))-0.7)^2 ) + 1*(eta^2)*(1-eta)^2";
+  InputParameters gp;
+  gp.set<std::string>("_object_name") = "root";
+  gp.set<TensorProblem *>("_tensor_problem") = &problem;
+  auto root = std::make_shared<ComputeGroup>(gp);
+  auto add = [&](const std::string & type, const std::string & name, std::vector<std::pair<std::string, std::string>> block)
+  {
+    block.push_back({"buffer", name});
+    root->add(create<TensorOperatorBase>(problem, type, name, block));
+  };
+  add("HipForwardFFT", "cbar", {{"input", "c"}});
+  add("HipForwardFFT", "etabar", {{"input", "eta"}});
+  add("HipParsedCompute", "mu", {{"expression", F}, {"inputs", "c eta"}, {"derivatives", "c"}});
+  add("HipReciprocalMatDiffusion", "div_J", {{"chemical_potential", "mu"}, {"mobility", "M"}, {"psi", "psi"}});
+  add("HipParsedCompute", "domega_chem_deta", {{"expression", F + " - mu*c"}, {"inputs", "mu c eta"}, {"derivatives", "eta"}});
+  add("HipReciprocalAllenCahn", "AC_bulk", {{"dF_chem_deta", "domega_chem_deta"}, {"L", "L"}, {"psi", "psi"}});
+  add("HipReciprocalMatDiffusion", "kappa_grad_eta", {{"chemical_potential", "eta"}, {"mobility", "L_kappa"}, {"psi", "psi"}});
+  add("HipParsedCompute", "AC_bar", {{"expression", "kappa_grad_eta + AC_bulk"}, {"inputs", "AC_bulk kappa_grad_eta"}});
+  problem.computes().push_back(root);
+  // linear_reciprocal = '0 0': no linear operator (dividing by 1 - dt * 0 is the identity)
+  auto solver = create<TensorSolver>(problem, "HipAdamsBashforthMoulton", "solver",
+                                     {{"root_compute", "root"}, {"buffer", "c eta"}, {"reciprocal_buffer", "cbar etabar"},
+                                      {"linear_reciprocal", "0 0"}, {"nonlinear_reciprocal", "div_J AC_bar"},
+                                      {"substeps", arg("substeps", "1000")}, {"predictor_order", arg("predictor_order", "3")},
+                                      {"corrector_order", arg("predictor_order", "3")}});
+  solver->updateDependencies();
+  const double volume = (argd("xmax", 1) - argd("xmin", 0)) * (argd("ymax", 1) - argd("ymin", 0));
+  auto integral = [&](const torch::Tensor & t) { return t.sum().item<double>() / double(domain.getNumberOfCells()) * volume; };
+  std::ofstream csv(out + "/kks.csv");
+  csv.precision(17);
+  csv << "time,total_C,total_eta\n";
+  auto row = [&](int frame)
+  {
+    csv << problem.time() << ',' << integral(problem.getBuffer("c")) << ',' << integral(problem.getBuffer("eta")) << "\n";
+    for (const char * b : {"c", "eta", "mu"})
+      if (problem.getBuffer(b).defined())
+        dump(out, b, frame, problem.getBuffer(b));
+  };
+  row(0);
+  transient(problem, *solver, time_steps(), [&](int step) { row(step); });
+  return 0;
+}
+
 static int
 run_mechanics(const std::string & out)
 {
@@ -642,6 +803,12 @@ main(int argc, char ** argv)
       return run_broyden(out);
     if (which == "explicit")
       return run_explicit(out);
+    if (which == "kks")
+      return run_kks(out);
+    if (which == "semi_implicit")
+      return run_semi_implicit(out);
+    if (which == "coupled_pf_mech")
+      return run_coupled_pf_mech(out);
     if (which == "mechanics")
       return run_mechanics(out);
     if (which == "gradient" || which == "gradient_square")

@@ -135,7 +135,8 @@ def test_moose_shim_compiles_against_the_stub_and_registers_its_classes():
     want = {"HipAdamsBashforthMoulton", "HipAdamsBashforthMoultonCoupled", "HipFFTMechanics", "HipForwardFFT", "HipInverseFFT",
             "HipParsedCompute", "HipReciprocalLaplacianFactor", "HipReciprocalLaplacianSquareFactor", "HipFFTGradient",
             "HipFFTGradientSquare", "HipComputeDisplacements", "HipComputeVonMisesStress", "HipETDRK4Solver", "HipSecantSolver",
-            "HipBroydenSolver", "HipForwardEulerSolver", "HipDeAliasingTensor", "HipSwiftHohenbergLinear"}
+            "HipBroydenSolver", "HipForwardEulerSolver", "HipDeAliasingTensor", "HipSwiftHohenbergLinear", "HipFFTSemiImplicit",
+            "HipReciprocalMatDiffusion", "HipReciprocalAllenCahn", "HipFFTQuasistaticElasticity", "HipFFTElasticChemicalPotential"}
     assert want <= types, want - types
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for t in want:

@@ -214,6 +214,74 @@ def test_cahnhilliard_explicit_smooth_gold_through_the_shim(method, tmp_path):
         assert np.abs(g[f"mu.{k}"] - mu).max() <= 1e-10
 
 
+def test_cahnhilliard_gold_through_the_legacy_time_integrator_shim(tmp_path):
+    """cahnhilliard.i in the pre-TensorSolver syntax: explicit compute group (HipParsedCompute with `derivatives = c`, HipForwardFFT x 2,
+    Mbar * mubar as a reciprocal-grid HipParsedCompute) + [TensorTimeIntegrators] type = HipFFTSemiImplicit (history_size 1: first
+    order while timeStep() <= 1, then (3 N - N_old) / 2) -- the same numbers as AdamsBashforthMoulton orders 1 / 2 to rounding: gold
+    cahnhilliard.h5 to 1e-13"""
+    g = load_golden("cahnhilliard_gold.npz")
+    ic = tmp_path / "c0.bin"
+    g["c.0"][:20, :20].astype("<f8").tofile(ic)
+    _run(["case=semi_implicit", "nx=20", "ny=20", "xmax=3", "ymax=3", f"ic={ic}", "substeps=10", "num_steps=10", "dt=1e-3"], tmp_path)
+    worst = 0.0
+    for k in range(1, 11):
+        c = np.fromfile(tmp_path / f"c.{k}.bin", dtype="<f8").reshape(20, 20)
+        worst = max(worst, np.abs(g[f"c.{k}"][:20, :20] - c).max())
+    assert worst <= 1e-13, worst
+    mu = np.fromfile(tmp_path / "mu.10.bin", dtype="<f8").reshape(20, 20)
+    assert np.abs(g["mu.10"] - mu).max() <= 1e-13
+
+
+def test_coupled_pf_mech_vs_oracle_through_the_shim(tmp_path):
+    """test/tests/tensor_compute/coupled_pf_mech.i (Cahn-Hilliard + HipFFTQuasistaticElasticity + HipFFTElasticChemicalPotential
+    + HipInverseFFT through the legacy HipFFTSemiImplicit integrator; lambda = 100, mu = 50, e0 = 0.02) on a 16^3 grid against the oracle's
+    restatement of the same input.  The reference has no gold data for this input: **parity unpinned**, see the oracle header."""
+    import math
+    import torch
+    from oracle import marlin_oracle as mo
+    n, substeps, steps, dt = 16, 5, 3, 0.05
+    torch.manual_seed(5)
+    c0 = torch.rand(n, n, n, dtype=torch.float64) * 0.12 + 0.44
+    ic = tmp_path / "c0.bin"
+    c0.numpy().astype("<f8").tofile(ic)
+    _run(["case=coupled_pf_mech", f"nx={n}", f"ny={n}", f"nz={n}", "xmax=4pi", "ymax=4pi", "zmax=4pi", f"ic={ic}", f"substeps={substeps}",
+          f"num_steps={steps}", f"dt={dt}"], tmp_path)
+    dom = mo.Domain(3, [n] * 3, [4 * math.pi] * 3)
+    ref = mo.CoupledPFMech(dom, c0, 0.2, -0.001, mo.mu_double_well, substeps, 50.0, 100.0, 0.02)
+    for k in range(1, steps + 1):
+        ref.step(dt)
+        c = np.fromfile(tmp_path / f"c.{k}.bin", dtype="<f8").reshape(n, n, n)
+        assert np.abs(c - ref.c.numpy()).max() <= 1e-13
+        mm = np.fromfile(tmp_path / f"mumech.{k}.bin", dtype="<f8").reshape(n, n, n)
+        assert np.abs(mm - ref.mumech.numpy()).max() <= 1e-12 * np.abs(ref.mumech.numpy()).max()
+        for d, nm in enumerate(("disp_x", "disp_y", "disp_z")):
+            u = np.fromfile(tmp_path / f"{nm}.{k}.bin", dtype="<f8").reshape(n, n, n)
+            assert np.abs(u - ref.disp[d].numpy()).max() <= 1e-12 * np.abs(ref.disp[d].numpy()).max()
+
+
+def test_kks_no_flux_bc_gold_through_the_shim(tmp_path):
+    """test/tests/kks/tests:13-31 (KKS_no_flux_bc.i; HDF5Diff abs_tol 1e-10, CSVDiff): two coupled variables through
+    HipAdamsBashforthMoulton order 3 (10 x 1000 substeps, no linear operator), the Gibbs-energy derivatives as HipParsedComputes,
+    HipReciprocalMatDiffusion / HipReciprocalAllenCahn with the smooth-boundary mask.  Frame 0 of the gold file is the IC."""
+    g = load_golden("kks_no_flux_bc_gold.npz")
+    files = []
+    for b in ("c", "eta", "psi"):
+        f = tmp_path / f"{b}0.bin"
+        g[f"{b}.0"].astype("<f8").tofile(f)
+        files.append(f"{b}={f}")
+    _run(["case=kks", "nx=20", "ny=20", "xmin=-50", "xmax=50", "ymin=-50", "ymax=50", "num_steps=10", "dt=0.1", "substeps=1000",
+          "predictor_order=3"] + files, tmp_path)
+    worst = {}
+    for b in ("c", "eta", "mu"):
+        worst[b] = max(np.abs(g[f"{b}.{k}"] - np.fromfile(tmp_path / f"{b}.{k}.bin", dtype="<f8").reshape(20, 20)).max()
+                       for k in range(1, 11))
+    assert max(worst.values()) <= 1e-10, worst
+    csv = np.loadtxt(tmp_path / "kks.csv", delimiter=",", skiprows=1)
+    ref = load_golden("fft_gold.npz")["KKS_no_flux_bc_out"]
+    assert csv.shape == ref.shape
+    assert np.abs(csv - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
 def test_mech3d_gold_through_the_shim(tmp_path):
     """test/tests/mechanics/tests:2-11 (mech3d.i) with [mech] type = HipFFTMechanics inside the root group of a HipForwardEulerSolver
     that forwards Fnew -> F: F_k.frame, disp_* (HipComputeDisplacements) and sV (HipComputeVonMisesStress) of gold mech3d.h5 to
