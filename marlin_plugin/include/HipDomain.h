@@ -143,7 +143,7 @@ private:
     dom.flags = pencil ? MRL_FLAG_PENCIL : 0;
     if (mrl_ctx_create(&_ctx, &dom) != MRL_OK)
       mooseError("marlin_hip: ", mrl_last_error(nullptr));
-    checkLayout(d, begin, end);
+    checkLayout(d, begin, end, pencil);
     if (_nranks > 1)
     {
       // the library owns the global transposes (HIP IPC peer stores / copy engines / RCCL) in place of the host-staged
@@ -159,10 +159,11 @@ private:
     }
   }
 
-  /// The blocks the library works on must be the blocks Marlin's tensors hold: same local real-space extents and offsets on every
-  /// axis, same reciprocal extents wherever both sides use the same transform.  A mismatch would be out-of-bounds access, so it is an
-  /// error at construction, not a surprise in the first substep.
-  void checkLayout(const DomainAction & d, const std::array<int64_t, 3> & begin, const std::array<int64_t, 3> & end)
+  /// The blocks the library works on must be the blocks Marlin's tensors hold: same local extents in real and reciprocal space on
+  /// every axis, and in FFT_SLAB mode the same offsets (getLocalBounds hands out _local_begin / _local_end: the RECIPROCAL x range on
+  /// axis 0, the real y range on axis 1, DomainAction.C:524-533).  A mismatch would be out-of-bounds access, so it is an error at
+  /// construction, not a surprise in the first substep.
+  void checkLayout(const DomainAction & d, const std::array<int64_t, 3> & begin, const std::array<int64_t, 3> & end, bool pencil)
   {
     int64_t rb[3], kb[3];
     if (mrl_local_shape(_ctx, _real_n.data(), rb, _recip_n.data(), kb) != MRL_OK)
@@ -171,14 +172,23 @@ private:
     const auto & kl = d.getLocalReciprocalGridSize();
     for (unsigned int a = 0; a < _dim; ++a)
     {
-      if (_real_n[a] != nl[a] || (_nranks > 1 && (rb[a] != begin[a] || rb[a] + _real_n[a] != end[a])))
+      if (_real_n[a] != nl[a])
         mooseError("marlin_hip: the library's real-space block differs from the DomainAction's along axis ", a, " (", _real_n[a],
-                   " entries from ", rb[a], " against ", nl[a], " from ", begin[a], "): unsupported partition (device_weights?)");
+                   " against ", nl[a], " entries): unsupported partition (device_weights?)");
       // (3-D FFT_SLAB: r2c on z here, c2c in the reference -- the one extent that differs by design, see the constructor)
-      const bool r2c_kept = _nranks > 1 && _dim == 3 && a == 2 && _recip_n[2] == nl[2] / 2 + 1;
+      const bool r2c_kept = _nranks > 1 && !pencil && _dim == 3 && a == 2 && _recip_n[2] == nl[2] / 2 + 1;
       if (_recip_n[a] != kl[a] && !r2c_kept)
         mooseError("marlin_hip: the library's reciprocal block differs from the DomainAction's along axis ", a, " (", _recip_n[a],
                    " against ", kl[a], ")");
+    }
+    if (_nranks > 1 && !pencil)
+    {
+      if (kb[0] != begin[0] || kb[0] + _recip_n[0] != end[0])
+        mooseError("marlin_hip: this rank's reciprocal x planes are [", kb[0], ", ", kb[0] + _recip_n[0], ") in the library and [", begin[0],
+                   ", ", end[0], ") in the DomainAction");
+      if (rb[1] != begin[1] || rb[1] + _real_n[1] != end[1])
+        mooseError("marlin_hip: this rank's real-space y planes are [", rb[1], ", ", rb[1] + _real_n[1], ") in the library and [", begin[1],
+                   ", ", end[1], ") in the DomainAction");
     }
     for (unsigned int a = _dim; a < 3; ++a)
       _real_n[a] = _recip_n[a] = 1;

@@ -18,8 +18,15 @@
 
 #include <torch/torch.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <algorithm>
 #include <any>
 #include <array>
+#include <atomic>
+#include <cstring>
 #include <cstdint>
 #include <functional>
 #include <iostream>
@@ -116,17 +123,92 @@ mooseError(A &&... a)
   throw MooseStubError(moose_stub::cat(std::forward<A>(a)...));
 }
 
+namespace moose_stub
+{
+/// the "MPI job" of a multi-rank run of the driver: rank processes forked by shim-driver share one POSIX shared-memory page
+struct World
+{
+  unsigned int size = 1, rank = 0;
+  struct Page
+  {
+    std::atomic<unsigned int> seq, arrived;
+    unsigned int len;
+    char text[3072];
+  } * page = nullptr;
+};
+inline World &
+world()
+{
+  static World w;
+  return w;
+}
+/// join the job `name` as rank `rank` of `size` (creates / maps the page; rank 0 clears it before the others can see it is ready)
+inline void
+joinWorld(const std::string & name, unsigned int size, unsigned int rank)
+{
+  auto & w = world();
+  w.size = size;
+  w.rank = rank;
+  if (size == 1)
+    return;
+  const int fd = shm_open(("/" + name).c_str(), O_CREAT | O_RDWR, 0600);
+  if (fd < 0 || ftruncate(fd, sizeof(World::Page)) != 0)
+    throw std::runtime_error("moose_stub: cannot create the job page");
+  void * m = mmap(nullptr, sizeof(World::Page), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED)
+    throw std::runtime_error("moose_stub: cannot map the job page");
+  w.page = static_cast<World::Page *>(m); // (a fresh segment is zero-filled: seq = arrived = 0)
+}
+}
+
 namespace libMesh
 {
 namespace Parallel
 {
-/// one rank: the shim classes are exercised serially here (their multi-rank branch needs MPI)
+/// size / rank of the job and the one collective the shim uses (the job-name broadcast of HipDomain); one rank unless the driver was
+/// started with nranks = P
 class Communicator
 {
 public:
-  unsigned int size() const { return 1; }
-  unsigned int rank() const { return 0; }
-  void broadcast(std::string &) const {}
+  unsigned int size() const { return moose_stub::world().size; }
+  unsigned int rank() const { return moose_stub::world().rank; }
+  /// broadcast from rank 0
+  void broadcast(std::string & s) const
+  {
+    auto & w = moose_stub::world();
+    if (w.size == 1)
+      return;
+    auto * p = w.page;
+    const unsigned int round = p->seq.load() / 2; // every rank has finished the previous broadcast before anyone starts the next
+    int spins = 0;
+    auto wait_for = [&](unsigned int v) {
+      while (p->seq.load() != v)
+      {
+        usleep(50);
+        if (++spins > 2400000) // two minutes: a rank has died
+          throw std::runtime_error("moose_stub: broadcast timed out (a rank is gone)");
+      }
+    };
+    if (w.rank == 0)
+    {
+      p->len = (unsigned int)std::min<std::size_t>(s.size(), sizeof(p->text));
+      std::memcpy(p->text, s.data(), p->len);
+      p->seq.store(2 * round + 1);
+    }
+    else
+    {
+      wait_for(2 * round + 1);
+      s.assign(p->text, p->len);
+    }
+    if (p->arrived.fetch_add(1) + 1 == w.size)
+    {
+      p->arrived.store(0);
+      p->seq.store(2 * round + 2);
+    }
+    else
+      wait_for(2 * round + 2);
+  }
 };
 }
 }
@@ -357,12 +439,19 @@ struct MooseStubFactory
 #define registerMooseObject(app, classname)                                                                            \
   static const int moose_stub_registered_##classname = MooseStubFactory::add<classname>(#classname)
 
-/// include/actions/DomainAction.h:31-69 -- the getters the shim reads; parallel_mode = NONE (DomainAction.C:268-296: r2c on the last axis)
+/// include/actions/DomainAction.h:31-69 -- the getters the shim reads.  parallel_mode = NONE (DomainAction.C:268-296: r2c on the last
+/// axis) with one rank; with several ranks parallel_mode = FFT_SLAB as DomainAction::partitionSlabs does it (:510-566): the real space
+/// is split along y, the reciprocal space along x, every axis transforms c2c (:278-280), equal weights through partitionHepler
+/// (DomainAction.h:247-280); getLocalBounds hands out _local_begin / _local_end, i.e. the RECIPROCAL x range on axis 0 and the real y
+/// range on axis 1 (:524-533, 1544-1556).
 class DomainAction
 {
 public:
   DomainAction(unsigned int dim, std::array<int64_t, 3> n, std::array<Real, 3> lo, std::array<Real, 3> hi) : _dim(dim), _n(n)
   {
+    const auto & w = moose_stub::world();
+    _n_rank = w.size;
+    _rank = w.rank;
     for (unsigned int d = 0; d < 3; ++d)
     {
       if (d >= dim)
@@ -371,9 +460,40 @@ public:
       _max(d) = hi[d];
     }
     _n_reciprocal = _n;
-    _n_reciprocal[dim - 1] = _n[dim - 1] / 2 + 1;
-    _shape_store.assign(_n.begin(), _n.begin() + dim);
-    _reciprocal_store.assign(_n_reciprocal.begin(), _n_reciprocal.begin() + dim);
+    if (_n_rank == 1)
+      _n_reciprocal[dim - 1] = _n[dim - 1] / 2 + 1;
+    _n_local = _n;
+    _n_reciprocal_local = _n_reciprocal;
+    for (unsigned int d = 0; d < 3; ++d)
+    {
+      _begin[d].assign(_n_rank, 0);
+      _end[d].assign(_n_rank, _n[d]);
+    }
+    if (_n_rank > 1)
+    {
+      if (dim < 2)
+        mooseError("Dimension must be 2 or 3 for slab decomposition.");
+      const int64_t totals[2] = {_n_reciprocal[0], _n[1]};
+      for (unsigned int d = 0; d < 2; ++d)
+      {
+        int64_t total = totals[d], remaining = _n_rank, b = 0;
+        for (unsigned int r = 0; r < _n_rank; ++r)
+        {
+          int64_t c = std::max<int64_t>(total / remaining, 1); // weights 1: (total * w) / remaining_total_weight
+          if (r + 1 == _n_rank)
+            c = total;
+          _begin[d][r] = b;
+          b += c;
+          _end[d][r] = b;
+          total -= c;
+          remaining -= 1;
+        }
+      }
+      _n_local[1] = _end[1][_rank] - _begin[1][_rank];
+      _n_reciprocal_local[0] = _end[0][_rank] - _begin[0][_rank];
+    }
+    _shape_store.assign(_n_local.begin(), _n_local.begin() + dim);
+    _reciprocal_store.assign(_n_reciprocal_local.begin(), _n_reciprocal_local.begin() + dim);
     _shape = _shape_store;
     _reciprocal_shape = _reciprocal_store;
   }
@@ -382,23 +502,31 @@ public:
   bool isRealSpaceMode() const { return false; }
   const std::array<int64_t, 3> & getGridSize() const { return _n; }
   const std::array<int64_t, 3> & getReciprocalGridSize() const { return _n_reciprocal; }
-  const std::array<int64_t, 3> & getLocalGridSize() const { return _n; }
-  const std::array<int64_t, 3> & getLocalReciprocalGridSize() const { return _n_reciprocal; }
+  const std::array<int64_t, 3> & getLocalGridSize() const { return _n_local; }
+  const std::array<int64_t, 3> & getLocalReciprocalGridSize() const { return _n_reciprocal_local; }
   const RealVectorValue & getDomainMin() const { return _min; }
   const RealVectorValue & getDomainMax() const { return _max; }
   const torch::IntArrayRef & getShape() const { return _shape; }
   const torch::IntArrayRef & getReciprocalShape() const { return _reciprocal_shape; }
-  bool isParallelFFT() const { return false; }
-  void getLocalBounds(unsigned int, std::array<int64_t, 3> & begin, std::array<int64_t, 3> & end) const
+  bool isParallelFFT() const { return _n_rank > 1; }
+  void getLocalBounds(unsigned int rank, std::array<int64_t, 3> & begin, std::array<int64_t, 3> & end) const
   {
-    begin = {{0, 0, 0}};
-    end = _n;
+    if (rank >= _n_rank)
+      mooseError("Requested local bounds for invalid rank ", rank, " (n_rank=", _n_rank, ").");
+    for (unsigned int d = 0; d < 3; ++d)
+    {
+      begin[d] = _begin[d][rank];
+      end[d] = _end[d][rank];
+    }
   }
-  int64_t getNumberOfCells() const { return _n[0] * _n[1] * _n[2]; }
+  /// cells of this rank's real-space block
+  int64_t getNumberOfCells() const { return _n_local[0] * _n_local[1] * _n_local[2]; }
+  int64_t getGlobalNumberOfCells() const { return _n[0] * _n[1] * _n[2]; }
 
 private:
-  unsigned int _dim;
-  std::array<int64_t, 3> _n, _n_reciprocal;
+  unsigned int _dim, _n_rank = 1, _rank = 0;
+  std::array<int64_t, 3> _n, _n_reciprocal, _n_local, _n_reciprocal_local;
+  std::array<std::vector<int64_t>, 3> _begin, _end;
   RealVectorValue _min, _max;
   std::vector<int64_t> _shape_store, _reciprocal_store;
   torch::IntArrayRef _shape, _reciprocal_shape;

@@ -25,8 +25,14 @@
 //               [vonmises] type = HipComputeVonMisesStress): writes F / stress / disp / sV.<frame>.bin
 //   shim-driver case=gradient|gradient_square nx=40 ny=40 nz=40 xmax=2pi ymax=4pi zmax=6pi out=dir
 //               (test/tests/gradient/gradient.i, gradient_square.i with HipFFTGradient / HipFFTGradientSquare / HipParsedCompute)
+//   shim-driver nranks=P case=cahnhilliard ...    (parallel_mode = FFT_SLAB on P ranks sharing device 0: the launcher starts P copies of
+//               itself with rank=r job=<name> BEFORE anything touches the GPU and waits for them; every rank reads the global initial
+//               condition, keeps its y slab and writes <name>.<frame>.rank<r>.bin -- cahnhilliard.rank0001.h5 of the reference's
+//               2-rank regression is rank 1's file)
 // Raw little-endian f64 files, dense row-major, as marlin-hip-run writes them.
 #include "moose_stub.h"
+
+#include <sys/wait.h>
 
 #include <cmath>
 #include <fstream>
@@ -59,7 +65,9 @@ dump(const std::string & dir, const std::string & name, int frame, const torch::
 {
   torch::Tensor h = t.is_complex() ? torch::view_as_real(t.resolve_conj()) : t;
   h = h.contiguous().cpu();
-  const std::string path = dir + "/" + name + "." + std::to_string(frame) + ".bin";
+  const auto & w = moose_stub::world();
+  const std::string path =
+      dir + "/" + name + "." + std::to_string(frame) + (w.size > 1 ? ".rank" + std::to_string(w.rank) : std::string()) + ".bin";
   std::ofstream f(path, std::ios::binary);
   if (!f)
     mooseError("cannot write ", path);
@@ -74,6 +82,19 @@ read_bin(const std::string & path, std::vector<int64_t> shape)
   if (!f || !f.read(reinterpret_cast<char *>(h.data_ptr<double>()), sizeof(double) * h.numel()))
     mooseError("cannot read ", h.numel(), " doubles from ", path);
   return h.to(moose_stub::device());
+}
+
+/// this rank's real-space block of an initial condition given on the global grid (FFT_SLAB: the y range of getLocalBounds)
+static torch::Tensor
+read_ic(const std::string & path, const DomainAction & domain)
+{
+  const auto & n = domain.getGridSize();
+  torch::Tensor g = read_bin(path, std::vector<int64_t>(n.begin(), n.begin() + domain.getDim()));
+  if (!domain.isParallelFFT())
+    return g;
+  std::array<int64_t, 3> b, e;
+  domain.getLocalBounds(moose_stub::world().rank, b, e);
+  return g.slice(1, b[1], e[1]).contiguous();
 }
 
 /// an [object] block of an input file: type + parameters as text
@@ -194,7 +215,7 @@ run_cahnhilliard(const std::string & out)
   const unsigned int dim = g_args.count("nz") ? 3 : 2;
   DomainAction domain = make_domain(dim);
   TensorProblem problem(domain);
-  problem.getBuffer("c") = read_bin(arg("ic"), std::vector<int64_t>(domain.getShape().begin(), domain.getShape().end()));
+  problem.getBuffer("c") = read_ic(arg("ic"), domain);
   // the buffers of cahnhilliard.i's [TensorSolver] block; the compute group's work is the solver's (expression = the [mu] block's)
   auto solver = create<TensorSolver>(problem, "HipAdamsBashforthMoulton", "solver",
                                      {{"buffer", "c"},
@@ -214,8 +235,9 @@ run_cahnhilliard(const std::string & out)
     dump(out, "c", step, problem.getBuffer("c"));
     dump(out, "mu", step, problem.getBuffer("mu"));
     dump(out, "Nhat", step, problem.getBuffer("Mbarmubar")); // (read through the published view: dense values)
-    std::cout << "step " << step << " time " << problem.time() << " sub_time " << problem.subTime() << " sub_dt " << problem.subDt()
-              << "\n";
+    if (moose_stub::world().rank == 0)
+      std::cout << "step " << step << " time " << problem.time() << " sub_time " << problem.subTime() << " sub_dt " << problem.subDt()
+                << "\n";
   });
   return 0;
 }
@@ -784,6 +806,44 @@ main(int argc, char ** argv)
         std::cout << kv.first << "\n";
       return 0;
     }
+    const long nranks = argi("nranks", 1);
+    if (nranks > 1 && !g_args.count("rank"))
+    {
+      // the "mpiexec" of the stub: P copies of this program, started before this process has made any HIP call (it never makes one)
+      const std::string job = "shimjob_" + std::to_string(getpid());
+      std::vector<pid_t> kids;
+      for (long r = 0; r < nranks; ++r)
+      {
+        const pid_t pid = fork();
+        if (pid < 0)
+          mooseError("fork failed");
+        if (pid == 0)
+        {
+          std::vector<std::string> av(argv, argv + argc);
+          av.push_back("rank=" + std::to_string(r));
+          av.push_back("job=" + job);
+          std::vector<char *> cav;
+          for (auto & a : av)
+            cav.push_back(a.data());
+          cav.push_back(nullptr);
+          execv("/proc/self/exe", cav.data());
+          _exit(127);
+        }
+        kids.push_back(pid);
+      }
+      int rc = 0;
+      for (pid_t k : kids)
+      {
+        int st = 0;
+        waitpid(k, &st, 0);
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0)
+          rc = 1;
+      }
+      shm_unlink(("/" + job).c_str());
+      return rc;
+    }
+    if (nranks > 1)
+      moose_stub::joinWorld(arg("job"), (unsigned int)nranks, (unsigned int)argi("rank", 0));
     if (!torch::cuda::is_available())
       mooseError("shim-driver needs a GPU (libTorch sees no HIP device)");
     moose_stub::device() = torch::Device(torch::kCUDA, (c10::DeviceIndex)argi("device", 0));

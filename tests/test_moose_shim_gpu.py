@@ -54,6 +54,52 @@ def test_cahnhilliard_gold_through_the_shim(fuse, tmp_path):
 
 
 @pytest.mark.parametrize("fuse", ["true", "false"])
+def test_cahnhilliard_fft_slab_gold_through_the_shim_on_two_ranks(fuse, tmp_path):
+    """test/tests/cahnhilliard/tests:58-70 (cahnhilliard.i, parallel_mode = FFT_SLAB, 2 ranks) through HipAdamsBashforthMoulton: the
+    stub's launcher starts two rank processes on GPU 0, its DomainAction partitions as partitionSlabs does (DomainAction.C:510-566),
+    and HipDomain takes its several-rank branch -- job name broadcast over the (stub) MPI communicator, mrl_comm_create,
+    mrl_ctx_attach_comm, checkLayout against getLocalBounds.  Rank 1's c.1 .. c.10 equal cahnhilliard.rank0001.h5 to 1e-13."""
+    import torch
+    g = load_golden("cahnhilliard_rank0001_gold.npz")
+    torch.manual_seed(0)
+    blk = (torch.rand(20, 10, dtype=torch.float64) * (0.56 - 0.44) + 0.44).numpy()
+    ic = tmp_path / "c0.bin"
+    np.concatenate([blk, blk], axis=1).astype("<f8").tofile(ic)    # both reference ranks draw the same seed-0 block
+    log = _run(["nranks=2", "case=cahnhilliard", "nx=20", "ny=20", "xmax=3", "ymax=3", f"ic={ic}", "substeps=10", "num_steps=10",
+                "dt=1e-3", f"fuse_substeps={fuse}"], tmp_path)
+    assert len(re.findall(r"step (\d+) time", log)) == 10
+    worst = 0.0
+    for k in range(1, 11):
+        c = np.fromfile(tmp_path / f"c.{k}.rank1.bin", dtype="<f8").reshape(20, 10)
+        worst = max(worst, np.abs(g[f"c.{k}"] - c).max())
+    assert worst <= 1e-13, worst
+    # the published spectral buffer is this rank's reciprocal block: 10 of the 20 x planes, all 20 y (c2c on both axes in 2-D FFT_SLAB)
+    assert os.path.getsize(tmp_path / "Nhat.10.rank0.bin") == 10 * 20 * 16
+
+
+@pytest.mark.parametrize("fuse", ["true", "false"])
+def test_cahnhilliard_3d_fft_slab_through_the_shim_on_two_ranks(fuse, tmp_path):
+    """a 3-D grid on two FFT_SLAB ranks through the shim (the library keeps r2c on z there, the one extent checkLayout lets differ
+    from the DomainAction's): both ranks' slabs against the oracle's serial run to 1e-13, changing dt included"""
+    import torch
+    from oracle import marlin_oracle as mo
+    torch.manual_seed(5)
+    shape, L = [16, 12, 20], [3.0, 2.0, 4.0]
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    ic = tmp_path / "c0.bin"
+    c0.numpy().astype("<f8").tofile(ic)
+    dts, substeps, pred = [1e-3, 1e-3, 2e-3], 3, 3
+    _run(["nranks=2", "case=cahnhilliard", "nx=16", "ny=12", "nz=20", "xmax=3", "ymax=2", "zmax=4", f"ic={ic}", f"substeps={substeps}",
+          "dt_sequence=" + ",".join(repr(d) for d in dts), f"predictor_order={pred}", f"fuse_substeps={fuse}"], tmp_path)
+    ref = mo.CahnHilliardABM(mo.Domain(3, shape, L), c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=substeps,
+                             predictor_order=pred)
+    for k, dt in enumerate(dts):
+        ref.step(dt)
+        c = np.concatenate([np.fromfile(tmp_path / f"c.{k + 1}.rank{r}.bin", dtype="<f8").reshape(16, 6, 20) for r in range(2)], axis=1)
+        assert np.abs(ref.c.numpy() - c).max() <= 1e-13
+
+
+@pytest.mark.parametrize("fuse", ["true", "false"])
 @pytest.mark.parametrize("pred", [1, 3])
 def test_cahnhilliard_adaptive_dt_through_the_shim(fuse, pred, tmp_path):
     """a time step size that changes between steps (AdamsBashforthMoulton.C:75,88-91: the first predictor_order - 1 substeps of such a
