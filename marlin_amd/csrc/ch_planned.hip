@@ -9,6 +9,7 @@
 //                           half-spectrum array), same operations in the same order on the pointwise side: results equal the fused
 //                           and the generic path to rounding of the transforms.
 #include "fft_pow2_launch.h"
+#include "fft_two.h"
 #include <atomic>
 
 namespace mrl {
@@ -49,8 +50,37 @@ int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const doub
     default: return MRL_ERR_UNSUPPORTED;                 \
   }
 
+#define MRL_SWITCH_N2(n, CALL)                          \
+  switch (n) {                                          \
+    case 120: { constexpr int NN = 120; CALL; } break;  \
+    case 150: { constexpr int NN = 150; CALL; } break;  \
+    case 160: { constexpr int NN = 160; CALL; } break;  \
+    case 180: { constexpr int NN = 180; CALL; } break;  \
+    case 240: { constexpr int NN = 240; CALL; } break;  \
+    default: return MRL_ERR_UNSUPPORTED;                \
+  }
+
+// experiment bit 1 << 29: the uniform 30- / 20-point plans where the two-stage plans of fft_two.h would run (A/B, tests)
+static bool two_stage(const mrl_ctx *ctx, long long n) { return p2::two_stage_len(n) && !(ctx->exp & (1 << 29)); }
+
 static int pass_launch(mrl_ctx *ctx, long long n, bool inv, int nf, const p2::PassArgs &a, const cplx *tw) {
   if (!plain30_ok(n)) return pass_launch_std(ctx, n, inv, nf, a, tw);
+  if (two_stage(ctx, n)) {  // 16 points per thread at most: both fields of the forward passes in one launch
+    if (inv) {
+      if (nf == 2) {
+        MRL_SWITCH_N2(n, MRL_TRY((p2::launch_pass2<NN, true, 2>(ctx, a, tw))));
+      } else {
+        MRL_SWITCH_N2(n, MRL_TRY((p2::launch_pass2<NN, true, 1>(ctx, a, tw))));
+      }
+    } else {
+      if (nf == 2) {
+        MRL_SWITCH_N2(n, MRL_TRY((p2::launch_pass2<NN, false, 2>(ctx, a, tw))));
+      } else {
+        MRL_SWITCH_N2(n, MRL_TRY((p2::launch_pass2<NN, false, 1>(ctx, a, tw))));
+      }
+    }
+    return MRL_OK;
+  }
   // 30 points per thread: one field per launch (two fields would need 240 of the 256 vector registers for the data alone)
   for (int f = 0; f < nf; ++f) {
     p2::PassArgs b = a;
@@ -372,7 +402,34 @@ int ch_substep_planned(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *
     ProfScope ps(ctx, "chp_B_y_fwd", 4.0 * h);
     MRL_TRY(pass_axis(ctx, g, 1, false, 2, w_c, w_mu));
   }
-  if (plain30_ok(g.nx)) {
+  if (two_stage(ctx, g.nx) && 16.0 * (double)nspec < 4294967296.0) {
+    // one kernel: forward x of both fields, the k-space update, inverse x (5 h at AB2, as k_ch_xfused on the fused path)
+    const int ax = ctx->dim == 3 ? 0 : 1;
+    p2::X2Args a{};
+    a.chat = w_c;
+    a.muhat = w_mu;
+    a.ubar = w_c;
+    a.Nnew = reinterpret_cast<cplx *>(Nhat_new);
+    a.cbar = reinterpret_cast<cplx *>(cbar);
+    for (int i = 0; i < order; ++i) a.Nold[i] = reinterpret_cast<const cplx *>(Nhat_old[i]);
+    for (int i = 0; i <= order; ++i) a.coef[i] = sub_dt * kBetaAB[order][i];
+    a.M = cp.M;
+    a.kappa = cp.kappa;
+    a.dt = sub_dt;
+    a.inner = g.ny * g.nzc;
+    a.nzc = (int)g.nzc;
+    a.kx = ctx->d_k[ax];
+    a.ky = ctx->dim == 3 ? ctx->d_k[1] : ctx->d_k[0];  // 2-D: the unused axis {0}
+    a.kz = ctx->d_k[2];
+    ProfScope ps(ctx, "chp_CD_x_fused", (4.0 + order + (cbar ? 1.0 : 0.0)) * h);
+    switch (order) {
+      case 0: MRL_SWITCH_N2(g.nx, MRL_TRY((p2::launch_xfused2<NN, 0>(ctx, a, g.tw_x)))); break;
+      case 1: MRL_SWITCH_N2(g.nx, MRL_TRY((p2::launch_xfused2<NN, 1>(ctx, a, g.tw_x)))); break;
+      case 2: MRL_SWITCH_N2(g.nx, MRL_TRY((p2::launch_xfused2<NN, 2>(ctx, a, g.tw_x)))); break;
+      case 3: MRL_SWITCH_N2(g.nx, MRL_TRY((p2::launch_xfused2<NN, 3>(ctx, a, g.tw_x)))); break;
+      default: MRL_SWITCH_N2(g.nx, MRL_TRY((p2::launch_xfused2<NN, 4>(ctx, a, g.tw_x)))); break;
+    }
+  } else if (plain30_ok(g.nx)) {
     // the k-space update rides on the x passes: mu-hat -> Nhat in one pass, c-hat -> ubar -> inverse x in a second one (6 h
     // instead of 11 h for the three x passes + the k-space kernel)
     const int ax = ctx->dim == 3 ? 0 : 1;

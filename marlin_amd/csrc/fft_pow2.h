@@ -473,6 +473,19 @@ struct MapLine {
   static constexpr int zsize = ZPlan<N>::T * LP;  // for the z kernels' ZPlan<N>::T lines
 };
 
+// (q + off) % NS and (q + off) / NS for q < TPL and an offset that is a compile-time constant after unrolling
+template <int NS, int TPL>
+__device__ __forceinline__ int mod_ns(int q, int off) {
+  const int qn = TPL <= NS ? q : q % NS;
+  const int s = qn + off % NS;
+  return s >= NS ? s - NS : s;
+}
+template <int NS, int TPL>
+__device__ __forceinline__ int div_ns(int q, int off) {
+  const int qn = TPL <= NS ? q : q % NS, qq = TPL <= NS ? 0 : q / NS;
+  return off / NS + qq + (qn + off % NS >= NS ? 1 : 0);
+}
+
 // radix-R stage on the P register values (v[i + S*t] = element t of butterfly i, S = P/R butterflies per thread)
 // ST (staged twiddle table, the z kernels): W holds, stage after stage, the factors [t - 1][k] = w_N^(t k N / (Ns R)) with k fastest
 // -- the lanes of a wave differ in k, so a plain W[t k N / (Ns R)] is a strided LDS read (8-way conflicts in the 512-point plan:
@@ -487,8 +500,11 @@ __device__ __forceinline__ void stage(kcplx (&v)[Plan<N>::P], int q, const kcplx
 #pragma unroll
     for (int t = 0; t < R; ++t) a[t] = v[i + S * t];
     if (NS > 1) {
-      const int b = q + i * TPL;
-      const int k = b % NS;
+      // k = (q + i TPL) % NS without a division: i TPL splits into a compile-time multiple of NS and a compile-time remainder.
+      // (The plain `b % NS` form is also MISCOMPILED by hipcc 7.2 for N = 240, NS = 30, TPL = 8: the 16-bit multiply-shift it
+      // emits for the modulo ends with the butterflies i = 8 and i = 12 reading the imaginary part of the staged twiddle of
+      // another butterfly -- every 240-point z transform was wrong until round 5 compared one with the oracle.)
+      const int k = mod_ns<NS, TPL>(q, i * TPL);
       if (ST) {
         const kcplx *Ws = W + (NS - Plan<N>::r0) + k;
 #pragma unroll
@@ -512,8 +528,7 @@ __device__ __forceinline__ void exchange(kcplx (&v)[Plan<N>::P], int q, int l, k
   __syncthreads();  // previous readers of X are done
 #pragma unroll
   for (int i = 0; i < S; ++i) {
-    const int b = q + i * TPL;
-    const int p0 = (b / NS) * NS * R + (b % NS);
+    const int p0 = div_ns<NS, TPL>(q, i * TPL) * NS * R + mod_ns<NS, TPL>(q, i * TPL);
 #pragma unroll
     for (int t = 0; t < R; ++t) X[Map::at(p0 + t * NS, l)] = v[i + S * t];
   }

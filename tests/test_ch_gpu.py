@@ -82,6 +82,7 @@ def test_ch_gold_file_3d():
                                    (2048, 64), (32, 4096), (2048, 32, 32), (256, 32, 32), (32, 64, 512), (1024, 32),
                                    (150, 150), (120, 90), (240, 40, 32), (32, 270, 40), (300, 180), (360, 60), (450, 600),   # planned-unfused path
                                    (160, 64), (64, 320, 32), (640, 160), (32, 40, 1280),                               # ... radix-20 lengths
+                                   (240, 120, 32), (150, 180, 32), (160, 160), (120, 240), (180, 150, 40),         # ... two-stage plans on x and y (fft_two.h)
                                    (288, 64), (72, 216), (576, 64), (800, 32), (48, 432), (864, 1152)])            # ... further plain plans
 def test_ch_vs_oracle(shape):
     from marlin_amd.api import Context, ch_params
@@ -100,6 +101,39 @@ def test_ch_vs_oracle(shape):
     # opt-in spectral carry-over (c-hat = ubar of the previous substep): same fields to rounding
     carried, _ = _run_hip_ch(ctx, ch_params(), c0, 2, 3, 3e-3, carry=True)
     assert (carried[-1] - ref.c).abs().max().item() <= 1e-13
+
+
+@pytest.mark.parametrize("shape", [(240, 60, 32), (120, 150), (160, 180, 40), (150, 32, 32), (180, 120)])
+@pytest.mark.parametrize("pred", [3, 5])
+def test_two_stage_plans_deep_histories_and_outputs(shape, pred):
+    """fft_two.h: the fused x pass of the two-stage plans (120 / 150 / 160 / 180 / 240 points) with AB3 and AB5 histories, the
+    optional cbar / mu outputs, against the oracle (1e-13) and against the uniform 30- / 20-point plans it replaces (experiment bit
+    1 << 29: the same operations on the pointwise side, so the fields agree to the rounding of the transforms); the profile must show
+    the fused x kernel, and the two x kernels of the uniform plans with the experiment bit"""
+    from marlin_amd import api
+    from marlin_amd.api import Context, ch_params
+    dim = len(shape)
+    L = [2.0 + d for d in range(dim)]
+    dom = mo.Domain(dim, list(shape), L)
+    torch.manual_seed(7)
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    ref = mo.CahnHilliardABM(dom, c0, 0.2, -0.001, mo.mu_double_well, substeps=3, predictor_order=pred)
+    for _ in range(pred + 1):
+        ref.step(3e-3)
+    got = {}
+    for name, exp in (("two_stage", 0), ("uniform", 1 << 29)):
+        ctx = Context(dim, list(shape), L)
+        ctx.set_option(api.OPT_EXPERIMENT, exp)
+        ctx.set_profiling(True)
+        states, mu = _run_hip_ch(ctx, ch_params(), c0, pred + 1, 3, 3e-3, pred=pred - 1, want_mu=True)
+        slots = {k["kernel"] for k in ctx.get_profile() if k["launches"]}
+        if name == "two_stage":
+            assert "chp_CD_x_fused" in slots and "chp_C_x_mbar" not in slots, slots
+        else:
+            assert "chp_C_x_mbar" in slots and "chp_CD_x_fused" not in slots, slots
+        assert (states[-1] - ref.c).abs().max().item() <= 1e-13
+        got[name] = states[-1]
+    assert (got["two_stage"] - got["uniform"]).abs().max().item() <= 1e-14
 
 
 def test_ch_pfhub_family_and_ab3():

@@ -1,8 +1,11 @@
 """HIP FFT service vs the oracle (DomainAction::fft / ifft), through the C ABI.  Needs a GPU."""
+import os
+
 import pytest
 import torch
 
 from oracle import marlin_oracle as mo
+from tests.conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -18,6 +21,7 @@ SHAPES = [
     (2048, 64), (32, 4096), (2048, 32, 40),                               # long lines of 2-D problems (planned lengths only)
     (120, 90, 60), (150, 150), (240, 40, 150), (270, 300, 60), (180, 360), (450, 64, 90), (600, 40),   # radix-30 plans (2 x 3 x 5 lengths)
     (160, 40, 64), (64, 320, 32), (32, 48, 640), (1280, 64),              # radix-20 plans (2^a 5, a >= 5)
+    (240, 120, 34), (150, 180, 32), (160, 240), (120, 160, 18), (180, 150),   # two-stage plans on the strided axes (fft_two.h)
     (72, 216, 40), (64, 432, 32), (576, 96), (864, 32), (1152, 48), (40, 800, 32), (288, 32, 216),   # further plain plans
 ]
 
@@ -45,6 +49,40 @@ def test_forward_inverse_match_oracle(shape):
     # round trip (test/tests/tensor_compute/backandforth.i)
     back = ctx.ifft(ctx.fft(a.cuda())).cpu()
     assert (back - a).abs().max().item() <= 1e-14
+
+
+def _planned_lengths():
+    import re
+    src = open(os.path.join(ROOT, "marlin_amd", "csrc", "fft_pow2.h")).read()
+    return sorted({int(m) for m in re.findall(r"^MRL_PLAN\((\d+),", src, flags=re.M)})
+
+
+@pytest.mark.parametrize("axis", ["z", "y", "x"])
+def test_every_planned_length_on_every_axis(axis):
+    """every length with a register-radix plan (MRL_PLAN in fft_pow2.h, 46 of them) as the contiguous axis (r2c / c2r kernels, staged
+    twiddles), as y and as x (strided passes; two-stage plans where fft_two.h has one), forward and inverse against the oracle's
+    transforms.  Round 5 found the 240-point z transform wrong (a miscompiled modulo in stage()): until then no test had that length on
+    the contiguous axis."""
+    from marlin_amd.api import Context
+    lengths = _planned_lengths()
+    assert len(lengths) >= 46 and 240 in lengths
+    worst = []
+    for n in lengths:
+        if n > 1280 and axis != "z":
+            continue                      # (the longest lines are 2-D / 1-D plans)
+        shape = {"z": (32, n), "y": (32, n, 32), "x": (n, 32)}[axis]      # (every extent planned: no generic stages)
+        L = [1.0 + 0.5 * i for i in range(len(shape))]
+        ctx = Context(len(shape), list(shape), L)
+        torch.manual_seed(n)
+        x = torch.rand(shape, dtype=torch.float64)
+        X = torch.fft.rfftn(x)
+        got = ctx.fft(x.cuda()).cpu()
+        e1 = (got - X).abs().max().item() / (X.abs().max().item() * 2e-15 * n)
+        back = ctx.ifft(X.cuda().contiguous()).cpu()
+        e2 = (back - x).abs().max().item() / 1e-14
+        worst.append((max(e1, e2), n))
+    bad = [(round(e, 2), n) for e, n in worst if e > 1.0]
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("shape", [(6, 8, 4), (16, 16, 16), (9, 10), (12, 10, 14)])
