@@ -397,6 +397,8 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
 int ch_substep_planned(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new, const double *const *Nhat_old,
                        int order, double sub_dt, double *cbar, double *mu, int carry);
 // slab contexts with a communicator (slab_driver.hip)
+int ch_substeps_planned(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *const *ring, int ring_size, int *head,
+                        int *n_old, int pred, int count, int advance, double sub_dt, double *mu, bool dt_changed);
 int slab_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *c_in, double *c_out, double *const *ring, int ring_size,
                      int *head, int *n_old, int pred, int count, int advance, double sub_dt, double *mu, bool dt_changed);
 
@@ -651,6 +653,8 @@ int mrl_ch_substeps(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, 
   if (ctx->slab)  // the library owns the exchanges (communicator attached with mrl_ctx_attach_comm)
     return slab_ch_substeps(ctx, p, d_c_in, d_c_out, d_Nhat_ring, ring_size, head, n_old, pred, count, advance, sub_dt, d_mu, dt_changed);
   int rc = ch_substeps_fused(ctx, cp, d_c_in, d_c_out, d_Nhat_ring, ring_size, head, n_old, pred, count, advance, sub_dt, d_mu, dt_changed);
+  if (rc != MRL_ERR_UNSUPPORTED) return rc;
+  rc = ch_substeps_planned(ctx, cp, d_c_in, d_c_out, d_Nhat_ring, ring_size, head, n_old, pred, count, advance, sub_dt, d_mu, dt_changed);
   if (rc != MRL_ERR_UNSUPPORTED) return rc;
   // generic shapes: one mrl_ch_substep per substep, the intermediate fields ping-pong between d_c_out and a scratch array
   const long long nreal = real_count_local(ctx);

@@ -10,6 +10,7 @@
 //                           and the generic path to rounding of the transforms.
 #include "fft_pow2_launch.h"
 #include "fft_two.h"
+#include "fft_two_z.h"
 #include <atomic>
 
 namespace mrl {
@@ -98,6 +99,16 @@ static int pass_launch(mrl_ctx *ctx, long long n, bool inv, int nf, const p2::Pa
 static int z_fwd_launch(mrl_ctx *ctx, long long n, int mode, int fam, const double *in, cplx *o0, cplx *o1, double *mu, const p2::ChDev &chp,
                         long long nlines) {
   if (!plain30_ok(n)) return z_fwd_launch_std(ctx, n, mode, fam, in, o0, o1, mu, chp, nlines);
+  if (two_stage(ctx, n)) {
+    if (mode == 0) {
+      MRL_SWITCH_N2(n, MRL_TRY((p2::launch_z_fwd2<NN, 0, 0>(ctx, in, o0, o1, mu, chp, nlines))));
+    } else if (fam == MRL_FE_DOUBLE_WELL) {
+      MRL_SWITCH_N2(n, MRL_TRY((p2::launch_z_fwd2<NN, 1, MRL_FE_DOUBLE_WELL>(ctx, in, o0, o1, mu, chp, nlines))));
+    } else {
+      MRL_SWITCH_N2(n, MRL_TRY((p2::launch_z_fwd2<NN, 1, MRL_FE_PFHUB>(ctx, in, o0, o1, mu, chp, nlines))));
+    }
+    return MRL_OK;
+  }
   if (mode == 0) {
     MRL_SWITCH_N30(n, MRL_TRY((p2::launch_z_fwd<NN, 0, 0>(ctx, in, o0, o1, mu, chp, nlines))));
   } else if (fam == MRL_FE_DOUBLE_WELL) {
@@ -110,6 +121,10 @@ static int z_fwd_launch(mrl_ctx *ctx, long long n, int mode, int fam, const doub
 
 static int z_inv_launch(mrl_ctx *ctx, long long n, const cplx *in, double *out, double scale, long long nlines) {
   if (!plain30_ok(n)) return z_inv_launch_std(ctx, n, in, out, scale, nlines);
+  if (two_stage(ctx, n)) {
+    MRL_SWITCH_N2(n, MRL_TRY((p2::launch_z_inv2<NN>(ctx, in, out, scale, nlines))));
+    return MRL_OK;
+  }
   MRL_SWITCH_N30(n, MRL_TRY((p2::launch_z_inv<NN>(ctx, in, out, scale, nlines))));
   return MRL_OK;
 }
@@ -377,27 +392,12 @@ int fft_inverse_planned(mrl_ctx *ctx, const double *d_in, double *d_out, long lo
   return MRL_OK;
 }
 
-// one AdamsBashforthMoulton::substep with its compute group (AdamsBashforthMoulton.C:60-101); a parsed free energy is compiled into
-// the forward z pass at run time as on the fused path (expr.hip: parsed_z_fwd_launch); no spectral carry-over
-int ch_substep_planned(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new, const double *const *Nhat_old,
-                       int order, double sub_dt, double *cbar, double *mu, int carry) {
-  if (!planned_unfused_ok(ctx) || carry != MRL_CARRY_NONE) return MRL_ERR_UNSUPPORTED;
-  const PGeo g = pgeo(ctx);
-  const long long nreal = g.nx * g.ny * g.nz, nspec = g.nx * g.ny * g.nzc;
-  MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nspec));
-  MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nspec));
-  cplx *w_c = reinterpret_cast<cplx *>(ctx->d_work[1]);
-  cplx *w_mu = reinterpret_cast<cplx *>(ctx->d_work[2]);
-  p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
+// forward y of both fields -> x passes with the k-space update (AdamsBashforthMoulton.C:94-101) -> inverse y: what lies between the
+// forward z pass of a substep and the inverse z pass that ends it; w_c holds ubar (x- and y-inverted) afterwards
+static int planned_kspace_passes(mrl_ctx *ctx, const PGeo &g, const ChP &cp, cplx *w_c, cplx *w_mu, double *Nhat_new,
+                                 const double *const *Nhat_old, int order, double sub_dt, double *cbar) {
+  const long long nspec = g.nx * g.ny * g.nzc;
   const double h = 16.0 * nspec;
-  {
-    ProfScope ps(ctx, "chp_A_z_fwd", 8.0 * nreal + 2.0 * h + (mu ? 8.0 * nreal : 0.0));
-    if (cp.family == MRL_FE_PARSED) {
-      MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)g.nz, 1, c_in, w_c, w_mu, mu, g.nx * g.ny));
-    } else {
-      MRL_TRY(z_fwd_launch(ctx, g.nz, 1, cp.family, c_in, w_c, w_mu, mu, chp, g.nx * g.ny));
-    }
-  }
   {
     ProfScope ps(ctx, "chp_B_y_fwd", 4.0 * h);
     MRL_TRY(pass_axis(ctx, g, 1, false, 2, w_c, w_mu));
@@ -480,8 +480,83 @@ int ch_substep_planned(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *
     ProfScope ps(ctx, "chp_E_y_inv", 2.0 * h);
     MRL_TRY(pass_axis(ctx, g, 1, true, 1, w_c, nullptr));
   }
+  return MRL_OK;
+}
+
+// one AdamsBashforthMoulton::substep with its compute group (AdamsBashforthMoulton.C:60-101); a parsed free energy is compiled into
+// the forward z pass at run time as on the fused path (expr.hip: parsed_z_fwd_launch); no spectral carry-over
+int ch_substep_planned(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *Nhat_new, const double *const *Nhat_old,
+                       int order, double sub_dt, double *cbar, double *mu, int carry) {
+  if (!planned_unfused_ok(ctx) || carry != MRL_CARRY_NONE) return MRL_ERR_UNSUPPORTED;
+  const PGeo g = pgeo(ctx);
+  const long long nreal = g.nx * g.ny * g.nz, nspec = g.nx * g.ny * g.nzc;
+  MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nspec));
+  MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nspec));
+  cplx *w_c = reinterpret_cast<cplx *>(ctx->d_work[1]);
+  cplx *w_mu = reinterpret_cast<cplx *>(ctx->d_work[2]);
+  p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
+  const double h = 16.0 * nspec;
+  {
+    ProfScope ps(ctx, "chp_A_z_fwd", 8.0 * nreal + 2.0 * h + (mu ? 8.0 * nreal : 0.0));
+    if (cp.family == MRL_FE_PARSED) {
+      MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)g.nz, 1, c_in, w_c, w_mu, mu, g.nx * g.ny));
+    } else {
+      MRL_TRY(z_fwd_launch(ctx, g.nz, 1, cp.family, c_in, w_c, w_mu, mu, chp, g.nx * g.ny));
+    }
+  }
+  MRL_TRY(planned_kspace_passes(ctx, g, cp, w_c, w_mu, Nhat_new, Nhat_old, order, sub_dt, cbar));
   ProfScope ps(ctx, "chp_F_z_inv", h + 8.0 * nreal);
   const double scale = 1.0 / ((double)g.nx * (double)g.ny * (double)g.nz);
+  return z_inv_launch(ctx, g.nz, w_c, c_out, scale, g.nx * g.ny / 2);
+}
+
+
+// The substep loop of TensorSolver::computeBuffer (TensorSolver.C:95-108) in one call for grids whose z extent has a two-stage plan
+// (fft_two_z.h) and a built-in free energy: between two substeps the inverse z pass and the next forward z pass are one kernel and
+// the real field never reaches HBM (ch_substeps_fused of ch_fused.hip, for the planned path): 14 h of traffic per AB2 substep.
+int ch_substeps_planned(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_out, double *const *ring, int ring_size, int *head,
+                        int *n_old, int pred, int count, int advance, double sub_dt, double *mu, bool dt_changed) {
+  if (!planned_unfused_ok(ctx)) return MRL_ERR_UNSUPPORTED;
+  const PGeo g = pgeo(ctx);
+  if (!two_stage(ctx, g.nz)) return MRL_ERR_UNSUPPORTED;
+  const long long nreal = g.nx * g.ny * g.nz, nspec = g.nx * g.ny * g.nzc;
+  MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nspec));
+  MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nspec));
+  cplx *w_c = reinterpret_cast<cplx *>(ctx->d_work[1]);
+  cplx *w_mu = reinterpret_cast<cplx *>(ctx->d_work[2]);
+  p2::ChDev chp{cp.family, cp.c0, cp.c1, cp.c2, {}};
+  const double h = 16.0 * nspec;
+  const double scale = 1.0 / ((double)g.nx * (double)g.ny * (double)g.nz);
+  for (int k = 0; k < count; ++k) {
+    double *mu_k = (k == count - 1) ? mu : nullptr;   // the buffer `mu` holds f'(c) of the last substep's input field
+    if (k == 0) {
+      ProfScope ps(ctx, "chp_A_z_fwd", 8.0 * nreal + 2.0 * h + (mu_k ? 8.0 * nreal : 0.0));
+      if (cp.family == MRL_FE_PARSED) {
+        MRL_TRY(parsed_z_fwd_launch(ctx, cp.parsed, (int)g.nz, 1, c_in, w_c, w_mu, mu_k, g.nx * g.ny));
+      } else {
+        MRL_TRY(z_fwd_launch(ctx, g.nz, 1, cp.family, c_in, w_c, w_mu, mu_k, chp, g.nx * g.ny));
+      }
+    } else {
+      ProfScope ps(ctx, "chp_FA_z_inv_fwd", 3.0 * h + (mu_k ? 8.0 * nreal : 0.0));
+      if (cp.family == MRL_FE_PARSED) {
+        MRL_TRY(parsed_z_inv_fwd_launch(ctx, cp.parsed, (int)g.nz, w_c, w_c, w_mu, mu_k, scale, g.nx * g.ny / 2, false));
+      } else if (cp.family == MRL_FE_DOUBLE_WELL) {
+        MRL_SWITCH_N2(g.nz, MRL_TRY((p2::launch_z_inv_fwd2<NN, MRL_FE_DOUBLE_WELL>(ctx, w_c, w_c, w_mu, mu_k, chp, scale, g.nx * g.ny / 2))));
+      } else {
+        MRL_SWITCH_N2(g.nz, MRL_TRY((p2::launch_z_inv_fwd2<NN, MRL_FE_PFHUB>(ctx, w_c, w_c, w_mu, mu_k, chp, scale, g.nx * g.ny / 2))));
+      }
+    }
+    const int order = (dt_changed && k < pred) ? 0 : (*n_old < pred ? *n_old : pred);   // AdamsBashforthMoulton.C:90-91
+    const int slot_new = (*head + 1) % ring_size;
+    const double *old[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < order; ++i) old[i] = ring[((*head - i) % ring_size + ring_size) % ring_size];
+    MRL_TRY(planned_kspace_passes(ctx, g, cp, w_c, w_mu, ring[slot_new], old, order, sub_dt, nullptr));
+    if (advance && k < count - 1) {   // TensorSolver.C:105-106
+      *head = slot_new;
+      if (*n_old < pred) *n_old += 1;
+    }
+  }
+  ProfScope ps(ctx, "chp_F_z_inv", h + 8.0 * nreal);
   return z_inv_launch(ctx, g.nz, w_c, c_out, scale, g.nx * g.ny / 2);
 }
 

@@ -26,6 +26,7 @@
 
 #include "mrl_internal.h"
 #include "fft_pow2_launch.h"
+#include "fft_two_z.h"
 
 namespace mrl {
 namespace ex {
@@ -789,8 +790,19 @@ static int build_mu_function(mrl_parsed *p, std::string &out) {
 
 // lines per workgroup / threads per workgroup of the z kernels (ZPlan<N>, fft_pow2.h)
 // (ea: the fused inverse + forward kernel, ZPlanEA<N>)
+// (experiment bit 1 << 29: the uniform 30- / 20-point plans where the two-stage plans of fft_two_z.h would run, as in ch_planned.hip)
+static bool two_stage_z(const mrl_ctx *ctx, int N) { return p2::two_stage_z_len(N) && !(ctx->exp & (1 << 29)); }
+
 static int plan_shape(mrl_ctx *ctx, int N, int *T, int *NT, size_t *lds, bool ea = false) {
   *T = 0;
+  if (two_stage_z(ctx, N)) {
+    switch (N) {
+#define MRL_Z2(NN_) case NN_: *T = p2::ZPlan2<NN_>::LPB; *NT = p2::ZPlan2<NN_>::NT; *lds = p2::lds_two_z<NN_>(ea ? 2 : 1); break;
+      MRL_Z2(120) MRL_Z2(150) MRL_Z2(160) MRL_Z2(180) MRL_Z2(240)
+#undef MRL_Z2
+    }
+    return MRL_OK;
+  }
   // the forward z pass exists for every planned length (the radix-30 / radix-20 lengths of ch_planned.hip included: their k_z_fwd is a
   // plain kernel with one array per thread); the fused inverse + forward pass only for the lengths of the fused family
   if (ea ? !pow2_ok(N) : !plain_ok(N)) return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: unsupported length %d", N);
@@ -807,7 +819,9 @@ static int plan_shape(mrl_ctx *ctx, int N, int *T, int *NT, size_t *lds, bool ea
 // 3 = k_z_inv_fwd<N, PARSED>, 4 = its MU_ONLY form; cached per (N, mode)
 static int parsed_z_kernel(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, hipFunction_t *fn_out) {
   if (mode < 1 || mode > 4) return set_error(ctx, MRL_ERR_INVALID, "parsed z pass: mode %d", mode);
-  const int key = N * 8 + mode;
+  const bool two = two_stage_z(ctx, N);
+  if (two && (mode == 2 || mode == 4)) return set_error(ctx, MRL_ERR_UNSUPPORTED, "parsed z pass: no carry-over form for length %d", N);
+  const int key = N * 16 + mode + (two ? 8 : 0);
   auto it = p->zfwd.find(key);
   if (it == p->zfwd.end()) {
     std::string mu_fn;
@@ -823,7 +837,8 @@ static int parsed_z_kernel(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, hipFunc
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "mrl_z_fwd_parsed.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
       return set_error(ctx, MRL_ERR_HIP, "hiprtcCreateProgram failed");
-    const std::string name = mode == 3   ? "mrl::p2::k_z_inv_fwd<" + std::to_string(N) + ", 2, false>"
+    const std::string name = two ? (mode == 3 ? "mrl::p2::k_z_inv_fwd2<" + std::to_string(N) + ", 2>" : "mrl::p2::k_z_fwd2<" + std::to_string(N) + ", 1, 2>")
+                             : mode == 3 ? "mrl::p2::k_z_inv_fwd<" + std::to_string(N) + ", 2, false>"
                              : mode == 4 ? "mrl::p2::k_z_inv_fwd<" + std::to_string(N) + ", 2, true>"
                                          : "mrl::p2::k_z_fwd<" + std::to_string(N) + ", " + std::to_string(mode) + ", 2>";
     hiprtcAddNameExpression(prog, name.c_str());
@@ -881,7 +896,9 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const doub
   ChDevHost chp = parsed_chdev(p);
   const cplx *tw = ctx->ax[2].d_tw;
   struct { unsigned lpp, pad; } zl = {lay_lpp, lay_pad};  // = p2::ZLay
+  // (the two-stage kernels work on dense rows: k_z_fwd2(const double*, cplx*, cplx*, double*, ChDev, long long, const cplx*))
   void *params[] = {&in, &out0, &out1, &mu_out, &chp, &nlines, &tw, &zl};
+  if (two_stage_z(ctx, N) && (lay_lpp || lay_pad)) return set_error(ctx, MRL_ERR_INVALID, "parsed z pass: padded rows with a two-stage plan");
   const long long nb = (nlines + T - 1) / T;
   MRL_HIP(ctx, hipModuleLaunchKernel(fn, (unsigned)nb, 1, 1, (unsigned)NT, 1, 1, (unsigned)lds, ctx->stream, params, nullptr));
   return MRL_OK;
@@ -899,6 +916,7 @@ int parsed_z_inv_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const cplx *in, 
   const cplx *tw = ctx->ax[2].d_tw;
   struct { unsigned lpp, pad; } zl = {lay_lpp, lay_pad};  // = p2::ZLay
   void *params[] = {&in, &out0, &out1, &mu_out, &chp, &scale, &nlines, &tw, &zl};
+  if (two_stage_z(ctx, N) && (lay_lpp || lay_pad)) return set_error(ctx, MRL_ERR_INVALID, "parsed z pass: padded rows with a two-stage plan");
   const long long nb = (nlines + T - 1) / T;
   MRL_HIP(ctx, hipModuleLaunchKernel(fn, (unsigned)nb, 1, 1, (unsigned)NT, 1, 1, (unsigned)lds, ctx->stream, params, nullptr));
   return MRL_OK;

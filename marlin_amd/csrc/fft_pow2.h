@@ -312,6 +312,39 @@ __device__ __forceinline__ void bfly<10>(kcplx (&a)[10]) {
   }
 }
 
+// radix 15 = 3 x 5 (Cooley-Tukey): n = 5 n1 + n2, k = k1 + 3 k2 -- the two-stage plans of fft_two.h / fft_two_z.h
+template <>
+__device__ __forceinline__ void bfly<15>(kcplx (&a)[15]) {
+  // radix 3 over n1 for each n2: (a[n2], a[n2+5], a[n2+10]) -> A[n2][k1] left in slot n2 + 5 k1
+#pragma unroll
+  for (int n2 = 0; n2 < 5; ++n2) {
+    kcplx b[3] = {a[n2], a[n2 + 5], a[n2 + 10]};
+    bfly<3>(b);
+    a[n2] = b[0];
+    a[n2 + 5] = b[1];
+    a[n2 + 10] = b[2];
+  }
+  // twiddles W15^(n2 k1), k1 = 1, 2
+  a[6] = cmul(a[6], mkc(0.913545457642600895493, -0.406736643075800207754));    // W15^1
+  a[7] = cmul(a[7], mkc(0.669130606358858213826, -0.743144825477394235010));    // W15^2
+  a[8] = cmul(a[8], mkc(0.309016994374947424076, -0.951056516295153572111));    // W15^3
+  a[9] = cmul(a[9], mkc(-0.104528463267653471389, -0.994521895368273336916));   // W15^4
+  a[11] = cmul(a[11], mkc(0.669130606358858213826, -0.743144825477394235010));  // W15^2
+  a[12] = cmul(a[12], mkc(-0.104528463267653471389, -0.994521895368273336916)); // W15^4
+  a[13] = cmul(a[13], mkc(-0.809016994374947424104, -0.587785252292473129135)); // W15^6
+  a[14] = cmul(a[14], mkc(-0.978147600733805637930, 0.207911690817759337087));  // W15^8
+  // radix 5 over n2 for each k1: X[k1 + 3 k2]
+  kcplx r[15];
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    bfly5(a[5 * k1], a[5 * k1 + 1], a[5 * k1 + 2], a[5 * k1 + 3], a[5 * k1 + 4]);
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) r[k1 + 3 * k2] = a[5 * k1 + k2];
+  }
+#pragma unroll
+  for (int i = 0; i < 15; ++i) a[i] = r[i];
+}
+
 // radix 20 = 4 x 5 (Cooley-Tukey): n = 5 n1 + n2, k = k1 + 4 k2 -- first stage of the lengths 2^a 5 with a >= 5 (160, 320, 640, 1280)
 template <>
 __device__ __forceinline__ void bfly<20>(kcplx (&a)[20]) {

@@ -83,6 +83,7 @@ def test_ch_gold_file_3d():
                                    (150, 150), (120, 90), (240, 40, 32), (32, 270, 40), (300, 180), (360, 60), (450, 600),   # planned-unfused path
                                    (160, 64), (64, 320, 32), (640, 160), (32, 40, 1280),                               # ... radix-20 lengths
                                    (240, 120, 32), (150, 180, 32), (160, 160), (120, 240), (180, 150, 40),         # ... two-stage plans on x and y (fft_two.h)
+                                   (32, 40, 150), (40, 32, 180), (32, 32, 120), (48, 240, 160),                       # ... and on z (fft_two_z.h)
                                    (288, 64), (72, 216), (576, 64), (800, 32), (48, 432), (864, 1152)])            # ... further plain plans
 def test_ch_vs_oracle(shape):
     from marlin_amd.api import Context, ch_params
@@ -189,7 +190,8 @@ def test_ch_fused_fast_path_outputs(shape):
     assert torch.equal(c2b, c2)
 
 
-@pytest.mark.parametrize("shape,pred", [((64, 64, 64), 2), ((128, 64, 96), 3), ((100, 40, 50), 2), ((12, 10, 9), 2), ((64, 128), 2)])
+@pytest.mark.parametrize("shape,pred", [((64, 64, 64), 2), ((128, 64, 96), 3), ((100, 40, 50), 2), ((12, 10, 9), 2), ((64, 128), 2),
+                                        ((160, 48, 240), 3), ((120, 150), 2), ((64, 180, 120), 2), ((240, 32, 160), 2), ((60, 40, 180), 4)])   # two-stage z plans
 def test_ch_multi_substep_call(shape, pred):
     """mrl_ch_substeps (the substep loop of TensorSolver::computeBuffer in one call; on planned shapes the inverse z pass of a
     substep is fused with the forward z pass of the next one) == the same substeps one call at a time, bit for bit on the fused

@@ -152,7 +152,12 @@ def test_parsed_free_energy_in_ch_substep(shape):
             ctx.ch_substeps(prm, c0.clone(), out, ring, 1, 0, 2, 4, True, 1e-3, mu=mu)
             multi.append((out.cpu(), mu.cpu()))
         for a, b in zip(*multi):
-            assert torch.equal(a, b)
+            if shape[2] in (150, 160, 180, 240):
+                # the fused inverse + forward z kernel of the two-stage plans (fft_two_z.h): its run-time compiled instance and the
+                # built-in one contract different multiply-adds in the radix-15 / radix-16 butterflies (measured 2e-16 per substep)
+                assert (a - b).abs().max().item() <= 1e-14
+            else:
+                assert torch.equal(a, b)
 
 
 def test_gradient_tensor_gold_gpu():
