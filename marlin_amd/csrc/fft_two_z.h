@@ -27,6 +27,8 @@ struct ZPlan2;
     static constexpr int NTABF = (R1_ - 1) * R0_, NTABI = (R0_ - 1) * R1_;                         \
     static_assert(R0_ * R1_ == N_ && NT <= 256 && NTABF <= N_ && NTABI <= N_, "bad plan");        \
   };
+// (lines per workgroup: 4 / 8 / 16 measured level on 150 / 160 / 180-point lines, round 5 -- those grids are short launches of 1-2 k
+// workgroups, bound by their first and last generation rather than by the tile shape)
 MRL_ZPLAN2(120, 10, 12, 16)
 MRL_ZPLAN2(150, 10, 15, 8)
 MRL_ZPLAN2(160, 16, 10, 8)

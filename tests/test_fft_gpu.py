@@ -85,6 +85,32 @@ def test_every_planned_length_on_every_axis(axis):
     assert not bad, bad
 
 
+def test_random_mixes_of_planned_lengths():
+    """60 random 3-D grids whose three extents are drawn independently from the planned lengths (every plan family next to every other:
+    uniform, radix-30 / radix-20, two-stage), forward and inverse against libTorch's transforms on the device (rocFFT: an independent
+    implementation, here only as the checker)"""
+    import random
+    from marlin_amd.api import Context
+    rng = random.Random(20261005)
+    lengths = [n for n in _planned_lengths() if n <= 640]
+    small = [n for n in lengths if n <= 100]
+    bad = []
+    for it in range(60):
+        big_axis = rng.randrange(3)
+        shape = [rng.choice(lengths) if a == big_axis else rng.choice(small) for a in range(3)]
+        if (shape[0] * shape[1]) % 2:
+            continue
+        ctx = Context(3, shape, [1.0, 1.5, 2.0])
+        g = torch.Generator(device="cuda").manual_seed(it)
+        x = torch.rand(shape, dtype=torch.float64, device="cuda", generator=g)
+        X = torch.fft.rfftn(x)
+        e1 = (ctx.fft(x) - X).abs().max().item() / (X.abs().max().item() * 2e-15 * max(shape))
+        e2 = (ctx.ifft(X.contiguous()) - x).abs().max().item() / 1e-14
+        if max(e1, e2) > 1.0:
+            bad.append((shape, e1, e2))
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("shape", [(6, 8, 4), (16, 16, 16), (9, 10), (12, 10, 14)])
 def test_value_major_batch(shape):
     """trailing value dimensions are batch (mechanics [n,n,n,3,3]); SURVEY A.2"""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Cahn-Hilliard substeps through ONE mrl_ch_substeps call per time step (the product's default) for an arbitrary grid shape:
-ch_substeps_bench.py nx ny nz [substeps per call] [calls] -> ms per substep by wall clock around the calls and the per-kernel profile"""
+ch_substeps_bench.py nx ny nz [substeps per call] [calls] [MRL_OPT_EXPERIMENT bits] -> ms per substep by wall clock around the calls and the per-kernel profile"""
 import json
 import os
 import sys
@@ -16,7 +16,11 @@ def main():
     shape = [int(v) for v in sys.argv[1:4]]
     nsub = int(sys.argv[4]) if len(sys.argv) > 4 else 20
     calls = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+    exp = int(sys.argv[6], 0) if len(sys.argv) > 6 else 0
     ctx = Context(3, shape, [float(s) * 0.1256 for s in shape])
+    if exp:
+        from marlin_amd import api
+        ctx.set_option(api.OPT_EXPERIMENT, exp)
     p = ch_params()
     g = torch.Generator(device="cuda").manual_seed(1)
     c = torch.rand(shape, dtype=torch.float64, device="cuda", generator=g) * 0.12 + 0.44
@@ -40,7 +44,7 @@ def main():
     prof = [k for k in ctx.get_profile() if k["launches"]]
     npts = shape[0] * shape[1] * shape[2]
     best = min(times[2:])
-    print(json.dumps({"shape": shape, "substeps_per_call": nsub, "ms_per_substep": round(best, 4), "G_updates_per_s": round(npts / best / 1e6, 2),
+    print(json.dumps({"shape": shape, "experiment": exp, "substeps_per_call": nsub, "ms_per_substep": round(best, 4), "G_updates_per_s": round(npts / best / 1e6, 2),
                       "kernels": {k["kernel"]: [round(k["ms"] / k["launches"] * 1e3, 1), round(k["bytes_per_launch"] / (k["ms"] / k["launches"]) / 1e9, 2)]
                                   for k in prof}}))
 
