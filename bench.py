@@ -857,6 +857,31 @@ def main():
                                     "float32: tests/test_ch_f32_gpu.py (2e-6); never the headline"}
         del ring32, a32, b32
 
+    if not args.no_variants and not slab and world == 1 and list(shape) == [256, 256, 256]:
+        # a grid of the two-stage plans (fft_two.h, round 5): 240^3 through the same entry point, one call of k substeps per region.
+        # Never the headline (another grid); recorded so that the driver's bench file shows what the 2 x 3 x 5 lengths run at
+        k = min(args.steps, 40)
+        shape2 = [240, 240, 240]
+        ctx2 = api.Context(3, shape2, [m * dx for m in shape2])
+        g2 = torch.Generator(device="cuda").manual_seed(5)
+        a2 = torch.rand(shape2, dtype=torch.float64, device="cuda", generator=g2) * 0.12 + 0.44
+        b2 = torch.empty_like(a2)
+        ring2 = [ctx2.empty_hist(), ctx2.empty_hist()]
+        h2, n2 = ctx2.ch_substeps(p, a2, b2, ring2, 1, 0, 2, 3, True, sub_dt)
+        torch.cuda.synchronize()
+        reps2 = []
+        for _ in range(max(1, min(args.repeats, 5))):
+            t0 = time.perf_counter()
+            h2, n2 = ctx2.ch_substeps(p, b2, a2, ring2, (h2 + 1) % 2, 1, 2, k, True, sub_dt)
+            torch.cuda.synchronize()
+            reps2.append((time.perf_counter() - t0) / k * 1e3)
+        ms2 = sorted(reps2)[len(reps2) // 2]
+        variants["grid_240_two_stage_plans"] = {"ms_per_step": ms2, "repeats_ms": [round(x, 5) for x in reps2], "substeps_per_library_call": k,
+                                                "grid": shape2, "value": 240.0 ** 3 / (ms2 * 1e-3),
+                                                "note": "240 = 15 x 16: two-stage plans with per-stage ownership on every axis (DESIGN 3.5); "
+                                                        "the uniform 30-point plans of round 4 ran this grid at 0.44-0.47 ms"}
+        del ctx2, a2, b2, ring2
+
     out = None
     if rank == 0:
         value = npts * args.steps / elapsed
@@ -949,7 +974,7 @@ def main():
         }
         if variants:
             for v in variants.values():
-                v["value"] = npts / (v["ms_per_step"] * 1e-3)
+                v.setdefault("value", npts / (v["ms_per_step"] * 1e-3))
             out["variants"] = variants
         if slab:
             loc = sum(k["avg_ms"] * k["launches"] / args.profile_steps for k in kernels if k["bytes_per_launch"] > 0)

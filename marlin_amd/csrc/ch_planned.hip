@@ -1,13 +1,19 @@
-// Planned but UNFUSED path for grids whose extents have register-radix plans for the plain transforms but not for the fused
-// Cahn-Hilliard kernels: every axis length in {60, 90, 120, 150, 180, 240, 270, 300, 360, 450, 600} (radix 30 first, 30 points
-// per thread: fft_pow2.h) mixed freely with the lengths of the fused path.  The reference's own solver tests run 150^2
-// (test/tests/solvers/diagonal.i:5-95); such sizes used to take the any-length path (fft_generic.hip), 3x slower per point.
+// Planned path for grids whose extents have register-radix plans for the plain transforms but are not all in the fused family of
+// ch_fused.hip: every axis length in {60, 90, 120, 150, 180, 240, 270, 300, 360, 450, 600} (radix 30 first), {160, 320, 640, 800,
+// 1280} (radix 20 first) or {72, 216, 288, 432, 576, 864, 1152}, mixed freely with the lengths of the fused path.  The reference's
+// own solver tests run 150^2 (test/tests/solvers/diagonal.i:5-95); such sizes used to take the any-length path (fft_generic.hip).
 //   plain transforms        z pass (two real lines per complex transform) -> y pass -> x pass, each reading and writing its array once
-//   Cahn-Hilliard substep   k_z_fwd<CH> (mu = f'(c) in the loader, c and mu in one complex transform) -> y and x passes on both
-//                           fields -> k_ch_kspace (Nhat = Mbar mu-hat, ABM predictor, 1/(1 - dt Lbar); AdamsBashforthMoulton.C:94-99)
-//                           -> inverse x, y passes -> k_z_inv.  7 launches, 20 h of traffic against the fused path's 14 h (h = one
-//                           half-spectrum array), same operations in the same order on the pointwise side: results equal the fused
-//                           and the generic path to rounding of the transforms.
+//   Cahn-Hilliard substep   forward z with mu = f'(c) in the loader (c and mu in one complex transform) -> forward y of both fields ->
+//                           x passes with the k-space update (Nhat = Mbar mu-hat, ABM predictor, 1/(1 - dt Lbar);
+//                           AdamsBashforthMoulton.C:94-99) -> inverse y -> inverse z
+//   120 / 150 / 160 / 180 / 240 points   two-stage plans (fft_two.h, fft_two_z.h: at most 16 points per thread): both fields per y
+//                           launch, ONE fused x kernel, and -- when the z extent is one of them -- ch_substeps_planned, the substep
+//                           loop with the inverse z pass of a substep fused into the forward z pass of the next: 14 h of traffic
+//                           per AB2 substep (h = one half-spectrum array), as on the fused path
+//   the other lengths       uniform 30- / 20- / 12-point plans: one field per y launch, the x update in two kernels (k_x_mbar,
+//                           k_x_update), separate z passes: 15 h
+// Same operations in the same order on the pointwise side everywhere: results equal the fused and the generic path to the rounding of
+// the transforms.
 #include "fft_pow2_launch.h"
 #include "fft_two.h"
 #include "fft_two_z.h"

@@ -101,29 +101,48 @@ __device__ __forceinline__ void fft2z(kcplx (&v)[ZPlan2<N>::PM], int q, int l, k
   }
 }
 
-// v (pattern B) = transform of the packed line a + i b: half spectra of a (o0) and b (o1), bins 0 .. N/2.  The k <-> N - k pairing
-// goes through a natural-order copy of the line in LDS.
+// v (pattern B) = transform of the packed line a + i b: half spectra of a (o0) and b (o1), bins 0 .. N/2.  The k <-> N - k pairing:
+// with 16 threads on the spectral side (160, 240) bin N - k of the line sits in lane (16 - q) % 16 of the same 16-lane group, register
+// R1 - 1 - t' (lane 0: its own register (R1 - t') % R1) and comes over with ds_bpermute (store_half_spectra of fft_pow2_kernels.h);
+// the other lengths go through a natural-order copy of the line in LDS.  (Measured level with the LDS form at 160 / 240 points: these
+// kernels are not bound by their LDS traffic.)  Every thread of the workgroup must call it.
 template <int N>
 __device__ __forceinline__ void store_half_spectra2(const kcplx (&v)[ZPlan2<N>::PM], int q, int l, kcplx *X, bool valid, kcplx *o0, kcplx *o1) {
   using Pl = ZPlan2<N>;
   constexpr int R0 = Pl::R0, R1 = Pl::R1;
-  kcplx *Xl = X + l * Pl::LP;
-  const bool own = R0 == Pl::TPL || q < R0;
-  __syncthreads();
-  if (own) {
+  if constexpr (R0 == 16 && Pl::TPL == 16) {
+    const int partner = (int)(threadIdx.x & 63u) - q + ((16 - q) & 15);
 #pragma unroll
-    for (int t = 0; t < R1; ++t) Xl[q + R0 * t] = v[t];
-  }
-  __syncthreads();
-  if (!valid || !own) return;
-#pragma unroll
-  for (int t = 0; t < R1; ++t) {
-    const int k = q + R0 * t;
-    if (k <= N / 2) {
+    for (int t = 0; t <= (N / 2) / R0; ++t) {   // bins beyond N/2 are somebody's mirror image only
+      const int k = q + R0 * t;
+      const kcplx s = lane_get(v[R1 - 1 - t], partner);
+      const kcplx own = v[(R1 - t) % R1];
       const kcplx xk = v[t];
-      const kcplx xn = Xl[k == 0 ? 0 : N - k];
-      o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
-      o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
+      const kcplx xn = mkc(q == 0 ? own.x : s.x, q == 0 ? own.y : s.y);
+      if (valid && k <= N / 2) {
+        o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
+        o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
+      }
+    }
+  } else {
+    kcplx *Xl = X + l * Pl::LP;
+    const bool own = R0 == Pl::TPL || q < R0;
+    __syncthreads();
+    if (own) {
+#pragma unroll
+      for (int t = 0; t < R1; ++t) Xl[q + R0 * t] = v[t];
+    }
+    __syncthreads();
+    if (!valid || !own) return;
+#pragma unroll
+    for (int t = 0; t < R1; ++t) {
+      const int k = q + R0 * t;
+      if (k <= N / 2) {
+        const kcplx xk = v[t];
+        const kcplx xn = Xl[k == 0 ? 0 : N - k];
+        o0[k] = mkc(kreal(0.5) * (xk.x + xn.x), kreal(0.5) * (xk.y - xn.y));
+        o1[k] = mkc(kreal(0.5) * (xk.y + xn.y), kreal(-0.5) * (xk.x - xn.x));
+      }
     }
   }
 }
