@@ -10,6 +10,7 @@
 //   contiguous in (y,kz) jointly, so the user-visible Nhat arrays are accessed in aligned 256-B pieces.
 #include "ch_xfused.h"
 #include "fft_pow2_wide.h"
+#include "fft_two.h"
 
 namespace mrl {
 
@@ -54,6 +55,39 @@ static Geo geo_of(const mrl_ctx *ctx) {
   g.ky = ctx->dim == 3 ? ctx->d_k[1] : ctx->d_k[0];  // 2-D: the unused axis {0}
   g.kz = ctx->d_k[2];
   return g;
+}
+
+// 400-point x axes: the fused x pass of the two-stage plan 20 x 20 (fft_two.h: k_ch_xfused2 with the re-read Nhat) instead of
+// k_ch_xfused<400> (10 x 10 x 2 x 2, 40 threads per line, tiles of 6 lines = 96-byte pieces: 3.5 TB/s; 735 -> 547 us at 400^3);
+// the reference's data flow only (no spectral carry-over); experiment bit 1 << 29 keeps the uniform kernel (A/B)
+static bool x400_two_stage(const mrl_ctx *ctx, long long nx, int carry, double array_bytes) {
+  return nx == 400 && carry == MRL_CARRY_NONE && !(ctx->exp & (1 << 29)) && array_bytes < 4294967296.0;
+}
+static int launch_x400(mrl_ctx *ctx, const p2::FusedArgs &f, int order, const cplx *tw) {
+  p2::X2Args a{};
+  a.chat = f.c.chat;
+  a.muhat = f.c.muhat;
+  a.ubar = f.c.ubar;
+  a.Nnew = f.c.Nnew;
+  a.cbar = f.c.cbar;
+  for (int i = 0; i < 4; ++i) a.Nold[i] = f.c.Nold[i];
+  for (int i = 0; i < 5; ++i) a.coef[i] = f.c.coef[i];
+  a.M = f.c.M;
+  a.kappa = f.c.kappa;
+  a.dt = f.c.dt;
+  a.inner = f.inner;
+  a.plane = f.plane;
+  a.nzc = f.nzc;
+  a.kx = f.kx;
+  a.ky = f.ky;
+  a.kz = f.kz;
+  switch (order) {
+    case 0: return p2::launch_xfused2<400, 0>(ctx, a, tw);
+    case 1: return p2::launch_xfused2<400, 1>(ctx, a, tw);
+    case 2: return p2::launch_xfused2<400, 2>(ctx, a, tw);
+    case 3: return p2::launch_xfused2<400, 3>(ctx, a, tw);
+    default: return p2::launch_xfused2<400, 4>(ctx, a, tw);
+  }
 }
 
 // strided pass along internal axis `a` (0 = x, 1 = y) of NF complex [nx][ny][nzc] arrays
@@ -290,6 +324,8 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
         case 3: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 3, true>(ctx, a, g.tw_x)))); break;
         default: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 4, true>(ctx, a, g.tw_x)))); break;
       }
+    } else if (x400_two_stage(ctx, nx, carry, 16.0 * (double)nx * (double)plane)) {
+      MRL_TRY(launch_x400(ctx, a, order, g.tw_x));
     } else {
       switch (order) {
         case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0, false>(ctx, a, g.tw_x)))); break;
@@ -414,12 +450,16 @@ int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c
       a.c.M = cp.M;
       a.c.kappa = cp.kappa;
       a.c.dt = sub_dt;
-      switch (order) {
-        case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0, false>(ctx, a, g.tw_x)))); break;
-        case 1: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 1, false>(ctx, a, g.tw_x)))); break;
-        case 2: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 2, false>(ctx, a, g.tw_x)))); break;
-        case 3: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 3, false>(ctx, a, g.tw_x)))); break;
-        default: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 4, false>(ctx, a, g.tw_x)))); break;
+      if (x400_two_stage(ctx, nx, MRL_CARRY_NONE, 16.0 * (double)nx * (double)plane)) {
+        MRL_TRY(launch_x400(ctx, a, order, g.tw_x));
+      } else {
+        switch (order) {
+          case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0, false>(ctx, a, g.tw_x)))); break;
+          case 1: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 1, false>(ctx, a, g.tw_x)))); break;
+          case 2: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 2, false>(ctx, a, g.tw_x)))); break;
+          case 3: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 3, false>(ctx, a, g.tw_x)))); break;
+          default: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 4, false>(ctx, a, g.tw_x)))); break;
+        }
       }
     }
     if (!xchunk) MRL_TRY(launch_d(0, nx));   // (chunked schedule: it runs in front of the next substep's z pass, or of the final one below)

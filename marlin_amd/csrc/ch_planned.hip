@@ -64,15 +64,24 @@ int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const doub
     case 160: { constexpr int NN = 160; CALL; } break;  \
     case 180: { constexpr int NN = 180; CALL; } break;  \
     case 240: { constexpr int NN = 240; CALL; } break;  \
+    case 300: { constexpr int NN = 300; CALL; } break;  \
+    case 320: { constexpr int NN = 320; CALL; } break;  \
     default: return MRL_ERR_UNSUPPORTED;                \
+  }
+
+#define MRL_SWITCH_N2X(n, CALL)                         \
+  switch (n) {                                          \
+    case 400: { constexpr int NN = 400; CALL; } break;  \
+    default: MRL_SWITCH_N2(n, CALL)                     \
   }
 
 // experiment bit 1 << 29: the uniform 30- / 20-point plans where the two-stage plans of fft_two.h would run (A/B, tests)
 static bool two_stage(const mrl_ctx *ctx, long long n) { return p2::two_stage_len(n) && !(ctx->exp & (1 << 29)); }
+static bool two_stage_x(const mrl_ctx *ctx, long long n) { return p2::two_stage_x_len(n) && !(ctx->exp & (1 << 29)); }
 
 static int pass_launch(mrl_ctx *ctx, long long n, bool inv, int nf, const p2::PassArgs &a, const cplx *tw) {
-  if (!plain30_ok(n)) return pass_launch_std(ctx, n, inv, nf, a, tw);
-  if (two_stage(ctx, n)) {  // 16 points per thread at most: both fields of the forward passes in one launch
+  if (!two_stage(ctx, n) && !plain30_ok(n)) return pass_launch_std(ctx, n, inv, nf, a, tw);
+  if (two_stage(ctx, n)) {  // 16 (20) points per thread at most: both fields of the forward passes in one launch
     if (inv) {
       if (nf == 2) {
         MRL_SWITCH_N2(n, MRL_TRY((p2::launch_pass2<NN, true, 2>(ctx, a, tw))));
@@ -104,7 +113,7 @@ static int pass_launch(mrl_ctx *ctx, long long n, bool inv, int nf, const p2::Pa
 
 static int z_fwd_launch(mrl_ctx *ctx, long long n, int mode, int fam, const double *in, cplx *o0, cplx *o1, double *mu, const p2::ChDev &chp,
                         long long nlines) {
-  if (!plain30_ok(n)) return z_fwd_launch_std(ctx, n, mode, fam, in, o0, o1, mu, chp, nlines);
+  if (!two_stage(ctx, n) && !plain30_ok(n)) return z_fwd_launch_std(ctx, n, mode, fam, in, o0, o1, mu, chp, nlines);
   if (two_stage(ctx, n)) {
     if (mode == 0) {
       MRL_SWITCH_N2(n, MRL_TRY((p2::launch_z_fwd2<NN, 0, 0>(ctx, in, o0, o1, mu, chp, nlines))));
@@ -126,7 +135,7 @@ static int z_fwd_launch(mrl_ctx *ctx, long long n, int mode, int fam, const doub
 }
 
 static int z_inv_launch(mrl_ctx *ctx, long long n, const cplx *in, double *out, double scale, long long nlines) {
-  if (!plain30_ok(n)) return z_inv_launch_std(ctx, n, in, out, scale, nlines);
+  if (!two_stage(ctx, n) && !plain30_ok(n)) return z_inv_launch_std(ctx, n, in, out, scale, nlines);
   if (two_stage(ctx, n)) {
     MRL_SWITCH_N2(n, MRL_TRY((p2::launch_z_inv2<NN>(ctx, in, out, scale, nlines))));
     return MRL_OK;
@@ -408,7 +417,7 @@ static int planned_kspace_passes(mrl_ctx *ctx, const PGeo &g, const ChP &cp, cpl
     ProfScope ps(ctx, "chp_B_y_fwd", 4.0 * h);
     MRL_TRY(pass_axis(ctx, g, 1, false, 2, w_c, w_mu));
   }
-  if (two_stage(ctx, g.nx) && 16.0 * (double)nspec < 4294967296.0) {
+  if (two_stage_x(ctx, g.nx) && 16.0 * (double)nspec < 4294967296.0) {
     // one kernel: forward x of both fields, the k-space update, inverse x (5 h at AB2, as k_ch_xfused on the fused path)
     const int ax = ctx->dim == 3 ? 0 : 1;
     p2::X2Args a{};
@@ -423,17 +432,18 @@ static int planned_kspace_passes(mrl_ctx *ctx, const PGeo &g, const ChP &cp, cpl
     a.kappa = cp.kappa;
     a.dt = sub_dt;
     a.inner = g.ny * g.nzc;
+    a.plane = a.inner;
     a.nzc = (int)g.nzc;
     a.kx = ctx->d_k[ax];
     a.ky = ctx->dim == 3 ? ctx->d_k[1] : ctx->d_k[0];  // 2-D: the unused axis {0}
     a.kz = ctx->d_k[2];
     ProfScope ps(ctx, "chp_CD_x_fused", (4.0 + order + (cbar ? 1.0 : 0.0)) * h);
     switch (order) {
-      case 0: MRL_SWITCH_N2(g.nx, MRL_TRY((p2::launch_xfused2<NN, 0>(ctx, a, g.tw_x)))); break;
-      case 1: MRL_SWITCH_N2(g.nx, MRL_TRY((p2::launch_xfused2<NN, 1>(ctx, a, g.tw_x)))); break;
-      case 2: MRL_SWITCH_N2(g.nx, MRL_TRY((p2::launch_xfused2<NN, 2>(ctx, a, g.tw_x)))); break;
-      case 3: MRL_SWITCH_N2(g.nx, MRL_TRY((p2::launch_xfused2<NN, 3>(ctx, a, g.tw_x)))); break;
-      default: MRL_SWITCH_N2(g.nx, MRL_TRY((p2::launch_xfused2<NN, 4>(ctx, a, g.tw_x)))); break;
+      case 0: MRL_SWITCH_N2X(g.nx, MRL_TRY((p2::launch_xfused2<NN, 0>(ctx, a, g.tw_x)))); break;
+      case 1: MRL_SWITCH_N2X(g.nx, MRL_TRY((p2::launch_xfused2<NN, 1>(ctx, a, g.tw_x)))); break;
+      case 2: MRL_SWITCH_N2X(g.nx, MRL_TRY((p2::launch_xfused2<NN, 2>(ctx, a, g.tw_x)))); break;
+      case 3: MRL_SWITCH_N2X(g.nx, MRL_TRY((p2::launch_xfused2<NN, 3>(ctx, a, g.tw_x)))); break;
+      default: MRL_SWITCH_N2X(g.nx, MRL_TRY((p2::launch_xfused2<NN, 4>(ctx, a, g.tw_x)))); break;
     }
   } else if (plain30_ok(g.nx)) {
     // the k-space update rides on the x passes: mu-hat -> Nhat in one pass, c-hat -> ubar -> inverse x in a second one (6 h

@@ -798,7 +798,7 @@ static int plan_shape(mrl_ctx *ctx, int N, int *T, int *NT, size_t *lds, bool ea
   if (two_stage_z(ctx, N)) {
     switch (N) {
 #define MRL_Z2(NN_) case NN_: *T = p2::ZPlan2<NN_>::LPB; *NT = p2::ZPlan2<NN_>::NT; *lds = p2::lds_two_z<NN_>(ea ? 2 : 1); break;
-      MRL_Z2(120) MRL_Z2(150) MRL_Z2(160) MRL_Z2(180) MRL_Z2(240)
+      MRL_Z2(120) MRL_Z2(150) MRL_Z2(160) MRL_Z2(180) MRL_Z2(240) MRL_Z2(300) MRL_Z2(320)
 #undef MRL_Z2
     }
     return MRL_OK;

@@ -25,23 +25,37 @@ template <int N>
 struct Plan2 {
   static constexpr bool ok = false;
 };
-#define MRL_PLAN2(N_, R0_, R1_)                                                        \
+#define MRL_PLAN2(N_, R0_, R1_, T_)                                                    \
   template <>                                                                          \
   struct Plan2<N_> {                                                                   \
     static constexpr bool ok = true;                                                   \
     static constexpr int R0 = R0_, R1 = R1_, PM = (R0_ > R1_ ? R0_ : R1_), TPL = PM;   \
-    static constexpr int T = 16, NT = T * TPL;   /* 16 adjacent lines: 256-byte pieces */ \
+    static constexpr int T = T_, NT = T * TPL;   /* T adjacent lines per tile */       \
     static_assert(R0_ * R1_ == N_ && NT <= 256, "bad two-stage plan");                 \
   };
-// (R1 >= R0: pattern A, which carries three of the five streams of the fused x pass, is the one with every thread busy)
-MRL_PLAN2(120, 10, 12)
-MRL_PLAN2(150, 10, 15)
-MRL_PLAN2(160, 10, 16)
-MRL_PLAN2(180, 12, 15)
-MRL_PLAN2(240, 15, 16)
+// (R1 >= R0 for the 16-point plans: pattern A, which carries three of the five streams of the fused x pass, is the one with every
+// thread busy; the 20-point plans put the 20 on the A side -- 80 registers while one array is loaded and transformed, 60-64 per array
+// in the update, where three arrays are live: no spills, against 28-270 spilled registers the other way round)
+// 16 lines per tile = 256-byte pieces
+MRL_PLAN2(120, 10, 12, 16)
+MRL_PLAN2(150, 10, 15, 16)
+MRL_PLAN2(160, 10, 16, 16)
+MRL_PLAN2(180, 12, 15, 16)
+MRL_PLAN2(240, 15, 16, 16)
+// 20 points per thread (80 registers per array): both fields of a y pass still fit one launch; the fused x pass keeps TWO arrays and
+// re-reads the Nhat it has just stored (k_ch_xfused2<REREAD>).  300 = 15 x 20, 320 = 16 x 20 replace 30- / 20-point uniform plans,
+// 400 = 20 x 20 the four-stage 10-point plan of the fused family (10 x 10 x 2 x 2, 40 threads per line, tiles of 6 lines = 96-byte
+// pieces: its fused x pass ran at 3.4 TB/s).  Tiles of 12 lines (192-byte pieces) where the LDS tile allows it, 8 at 400 points.
+MRL_PLAN2(300, 20, 15, 12)
+MRL_PLAN2(320, 20, 16, 12)
+MRL_PLAN2(400, 20, 20, 8)
 #undef MRL_PLAN2
 
-constexpr bool two_stage_len(long long n) { return n == 120 || n == 150 || n == 160 || n == 180 || n == 240; }
+// lengths whose strided passes and z kernels run two-stage plans ...
+constexpr bool two_stage_len(long long n) { return n == 120 || n == 150 || n == 160 || n == 180 || n == 240 || n == 300 || n == 320; }
+// ... and whose fused x pass does: 400 = 20 x 20 keeps the uniform 10-point plan of the fused family for its y and z passes (measured
+// faster there: 402 / 354 us against 476 / 381 us at 400^3) and takes only this kernel (735 -> 547 us)
+constexpr bool two_stage_x_len(long long n) { return two_stage_len(n) || n == 400; }
 
 // what a thread holds in a pattern: CNT points q + STRIDE t, and whether thread q holds anything
 template <int N, bool PATTERN_B>
@@ -171,7 +185,8 @@ struct X2Args {
   const kcplx *Nold[4];
   kreal coef[5];        // sub_dt * beta[order][i]
   kreal M, kappa, dt;
-  long long inner;      // ny * nzc = elements between two x planes
+  long long inner;      // ny * nzc = valid elements of an x plane
+  long long plane;      // elements between two x planes (>= inner: the solver-private layout of the fused path pads it)
   int nzc;
   const kreal *kx, *ky, *kz;
 };
@@ -197,7 +212,10 @@ constexpr int part_len(int cnt, int order) {
   return order == 0 ? cnt : best;
 }
 
-template <int N, int ORDER, bool NT_HIST>
+// REREAD (20 points per thread, and AB3 - AB5 everywhere): three arrays (of 80 registers) and deep histories do not fit, so Nhat is not
+// kept: it is stored (cached, not streamed) and read again with the history in the update -- each thread re-reads exactly what it
+// wrote, a few hundred cycles later, out of L2.  No kernel of the family spills with it (without: 35-270 VGPRs at AB3 - AB5).
+template <int N, int ORDER, bool NT_HIST, bool REREAD = (Plan2<N>::PM > 16 || ORDER >= 2)>
 __global__ void __launch_bounds__(Plan2<N>::NT, 2) k_ch_xfused2(X2Args a, const kcplx *__restrict__ tw) {
 #pragma clang fp contract(off)
   using Pl = Plan2<N>;
@@ -222,14 +240,16 @@ __global__ void __launch_bounds__(Plan2<N>::NT, 2) k_ch_xfused2(X2Args a, const 
   }
   const kreal ky = a.ky[ic / a.nzc], kz = a.kz[ic % a.nzc];
   // byte offsets of the thread's elements: pattern A (q + R1 t), pattern B (q + R0 t')
-  const unsigned plane = (unsigned)a.inner * (unsigned)sizeof(kcplx);
-  const unsigned offA0 = ((unsigned)ic + (unsigned)A::clamp(q) * (unsigned)a.inner) * (unsigned)sizeof(kcplx), stepA = A::STRIDE * plane;
-  const unsigned offB0 = ((unsigned)ic + (unsigned)B::clamp(q) * (unsigned)a.inner) * (unsigned)sizeof(kcplx), stepB = B::STRIDE * plane;
+  const unsigned plane = (unsigned)a.plane * (unsigned)sizeof(kcplx);
+  const unsigned offA0 = ((unsigned)ic + (unsigned)A::clamp(q) * (unsigned)a.plane) * (unsigned)sizeof(kcplx), stepA = A::STRIDE * plane;
+  const unsigned offB0 = ((unsigned)ic + (unsigned)B::clamp(q) * (unsigned)a.plane) * (unsigned)sizeof(kcplx), stepB = B::STRIDE * plane;
   kcplx v[PM], cp[PM];
 #pragma unroll
   for (int m = 0; m < A::CNT; ++m) v[m] = ldc(a.muhat, offA0 + m * stepA);
+  if (!REREAD) {
 #pragma unroll
-  for (int m = 0; m < A::CNT; ++m) cp[m] = ldc(a.chat, offA0 + m * stepA);
+    for (int m = 0; m < A::CNT; ++m) cp[m] = ldc(a.chat, offA0 + m * stepA);
+  }
 #pragma unroll
   for (int j = 0; j < CNT; ++j) {
     const int idx = threadIdx.x + j * NT;
@@ -246,27 +266,37 @@ __global__ void __launch_bounds__(Plan2<N>::NT, 2) k_ch_xfused2(X2Args a, const 
   fft2_a_to_b<N>(v, q, l, X, W);
 
   // ---- 2. Nhat = Mbar * mu-hat, Mbar = -k^2 M
-  kcplx Nv[PM];
+  kcplx Nv[REREAD ? 1 : PM];
 #pragma unroll
   for (int m = 0; m < B::CNT; ++m) {
     const kreal kl = KX[qb + m * B::STRIDE];
     const kreal Mbar = -((kl * kl + ky2) + kz2) * a.M;
-    Nv[m] = mkc(Mbar * v[m].x, Mbar * v[m].y);
+    const kcplx nh = mkc(Mbar * v[m].x, Mbar * v[m].y);
+    if (REREAD)
+      v[m] = nh;
+    else
+      Nv[m] = nh;
   }
   if (storeB) {
 #pragma unroll
     for (int m = 0; m < B::CNT; ++m) {
-      if (NT_HIST)
+      if (REREAD)
+        stc(a.Nnew, offB0 + m * stepB, v[m]);
+      else if (NT_HIST)
         stc_nt(a.Nnew, offB0 + m * stepB, Nv[m]);
       else
         stc(a.Nnew, offB0 + m * stepB, Nv[m]);
     }
   }
+  if (REREAD) {  // the second field, now that the first one's registers are free
+#pragma unroll
+    for (int m = 0; m < A::CNT; ++m) cp[m] = ldc(a.chat, offA0 + m * stepA);
+  }
   // ---- first-order history: half of it is requested before the c-hat transform and is in flight during it
   constexpr int PRE = B::CNT / 2;
   const unsigned offB1 = fresh(offB0);
-  kcplx o1[ORDER == 1 ? PM : 1];
-  if (ORDER == 1) {
+  kcplx o1[(ORDER == 1 && !REREAD) ? PM : 1];
+  if (ORDER == 1 && !REREAD) {
 #pragma unroll
     for (int m = 0; m < PRE; ++m) o1[ORDER == 1 ? m : 0] = NT_HIST ? ldc_nt(a.Nold[0], offB1 + m * stepB) : ldc(a.Nold[0], offB1 + m * stepB);
   }
@@ -281,12 +311,14 @@ __global__ void __launch_bounds__(Plan2<N>::NT, 2) k_ch_xfused2(X2Args a, const 
 
   // ---- 4. ubar = (cbar + (dt b0) N + sum (dt b_i) Nold_i) / (1 - dt Lbar), the reference's association.  The first term is formed
   //      at once, so that N's registers are free before the history arrives
+  if (!REREAD) {
 #pragma unroll
-  for (int m = 0; m < B::CNT; ++m) {
-    cp[m].x = cp[m].x + a.coef[0] * Nv[m].x;
-    cp[m].y = cp[m].y + a.coef[0] * Nv[m].y;
+    for (int m = 0; m < B::CNT; ++m) {
+      cp[m].x = cp[m].x + a.coef[0] * Nv[m].x;
+      cp[m].y = cp[m].y + a.coef[0] * Nv[m].y;
+    }
   }
-  if (ORDER == 1) {
+  if (ORDER == 1 && !REREAD) {
 #pragma unroll
     for (int m = PRE; m < B::CNT; ++m) o1[ORDER == 1 ? m : 0] = NT_HIST ? ldc_nt(a.Nold[0], offB2 + m * stepB) : ldc(a.Nold[0], offB2 + m * stepB);
 #pragma unroll
@@ -301,12 +333,15 @@ __global__ void __launch_bounds__(Plan2<N>::NT, 2) k_ch_xfused2(X2Args a, const 
       v[m] = mkc(u.y * scl, u.x * scl);  // swapped for the inverse transform
     }
   } else {
-    // deeper histories a part of the line at a time: at most 8 old values in flight per thread
-    constexpr int H = part_len(B::CNT, ORDER), NPART = B::CNT / H;
+    // deeper histories (and the re-read Nhat) a part of the line at a time: at most 8 old values in flight per thread
+    constexpr int NH = ORDER + (REREAD ? 1 : 0);
+    constexpr int H = part_len(B::CNT, NH);
+    constexpr int NPART = B::CNT / H;
     static_assert(NPART * H == B::CNT, "the history parts must cover the line");
 #pragma unroll
     for (int part = 0; part < NPART; ++part) {
       kcplx o[ORDER > 0 ? ORDER : 1][H];
+      kcplx nn[REREAD ? H : 1];
       // (a copy per part that depends on the last result of the part before: its loads cannot be issued, and their landing registers
       // held, before that part has been consumed -- hoisted to the top they spill 40-170 registers)
       const unsigned ob = (part == 0 ? fresh(offB0) : fresh_after(offB0, v[part * H - 1].x)) + (part * H) * stepB;
@@ -315,10 +350,18 @@ __global__ void __launch_bounds__(Plan2<N>::NT, 2) k_ch_xfused2(X2Args a, const 
 #pragma unroll
         for (int j = 0; j < H; ++j) o[h][j] = NT_HIST ? ldc_nt(a.Nold[h], ob + j * stepB) : ldc(a.Nold[h], ob + j * stepB);
       }
+      if (REREAD) {
+#pragma unroll
+        for (int j = 0; j < H; ++j) nn[j] = ldc(a.Nnew, ob + j * stepB);
+      }
 #pragma unroll
       for (int j = 0; j < H; ++j) {
         const int m = part * H + j;
         kcplx u = cp[m];
+        if (REREAD) {
+          u.x = u.x + a.coef[0] * nn[j].x;
+          u.y = u.y + a.coef[0] * nn[j].y;
+        }
 #pragma unroll
         for (int h = 0; h < ORDER; ++h) {
           u.x += a.coef[h + 1] * o[h][j].x;
@@ -349,7 +392,7 @@ inline int launch_xfused2(mrl_ctx *ctx, const X2Args &a, const kcplx *tw) {
   const long long nb = (a.inner + T - 1) / T;
   // old / new Nhat are not touched again within the substep: streamed past the Infinity Cache when the arrays are large against it
   // (the choice of ch_xfused.h: 128^3 loses 8 % with it, 256^3 gains 10 %)
-  const bool nt = (double)sizeof(kcplx) * (double)N * (double)a.inner >= 96.0e6;
+  const bool nt = (double)sizeof(kcplx) * (double)N * (double)a.plane >= 96.0e6;
   if (nt) {
     static std::atomic<bool> attr{false};
     if (!attr.load(std::memory_order_acquire)) {

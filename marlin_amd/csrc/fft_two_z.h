@@ -15,7 +15,7 @@ namespace mrl {
 namespace MRL_P2NS {
 
 // the lengths with a two-stage plan (fft_two.h has the strided passes for the same list)
-constexpr bool two_stage_z_len(long long n) { return n == 120 || n == 150 || n == 160 || n == 180 || n == 240; }
+constexpr bool two_stage_z_len(long long n) { return n == 120 || n == 150 || n == 160 || n == 180 || n == 240 || n == 300 || n == 320; }
 
 template <int N>
 struct ZPlan2;
@@ -34,6 +34,9 @@ MRL_ZPLAN2(150, 10, 15, 8)
 MRL_ZPLAN2(160, 16, 10, 8)
 MRL_ZPLAN2(180, 12, 15, 8)
 MRL_ZPLAN2(240, 16, 15, 8)
+// 20 points per thread on one side (fft_two.h): 160-thread workgroups of 8 lines
+MRL_ZPLAN2(300, 20, 15, 8)
+MRL_ZPLAN2(320, 16, 20, 8)
 #undef MRL_ZPLAN2
 
 template <int N>

@@ -84,6 +84,7 @@ def test_ch_gold_file_3d():
                                    (160, 64), (64, 320, 32), (640, 160), (32, 40, 1280),                               # ... radix-20 lengths
                                    (240, 120, 32), (150, 180, 32), (160, 160), (120, 240), (180, 150, 40),         # ... two-stage plans on x and y (fft_two.h)
                                    (32, 40, 150), (40, 32, 180), (32, 32, 120), (48, 240, 160),                       # ... and on z (fft_two_z.h)
+                                   (400, 40, 32), (32, 400, 40), (40, 32, 400), (300, 320), (320, 32, 300), (32, 300, 320),   # ... 20 points per thread
                                    (288, 64), (72, 216), (576, 64), (800, 32), (48, 432), (864, 1152)])            # ... further plain plans
 def test_ch_vs_oracle(shape):
     from marlin_amd.api import Context, ch_params
@@ -104,7 +105,7 @@ def test_ch_vs_oracle(shape):
     assert (carried[-1] - ref.c).abs().max().item() <= 1e-13
 
 
-@pytest.mark.parametrize("shape", [(240, 60, 32), (120, 150), (160, 180, 40), (150, 32, 32), (180, 120)])
+@pytest.mark.parametrize("shape", [(240, 60, 32), (120, 150), (160, 180, 40), (150, 32, 32), (180, 120), (400, 32, 40), (300, 320), (320, 40, 32)])
 @pytest.mark.parametrize("pred", [3, 5])
 def test_two_stage_plans_deep_histories_and_outputs(shape, pred):
     """fft_two.h: the fused x pass of the two-stage plans (120 / 150 / 160 / 180 / 240 points) with AB3 and AB5 histories, the
@@ -128,10 +129,12 @@ def test_two_stage_plans_deep_histories_and_outputs(shape, pred):
         ctx.set_profiling(True)
         states, mu = _run_hip_ch(ctx, ch_params(), c0, pred + 1, 3, 3e-3, pred=pred - 1, want_mu=True)
         slots = {k["kernel"] for k in ctx.get_profile() if k["launches"]}
-        if name == "two_stage":
+        if shape[0] == 400:     # a length of the fused family: same profile slot, k_ch_xfused2<400> or k_ch_xfused<400> behind it
+            assert "ch_C_x_fused" in slots, slots
+        elif name == "two_stage":
             assert "chp_CD_x_fused" in slots and "chp_C_x_mbar" not in slots, slots
         else:
-            assert "chp_C_x_mbar" in slots and "chp_CD_x_fused" not in slots, slots
+            assert ("chp_C_x_mbar" in slots or "ch_C_x_fused" in slots) and "chp_CD_x_fused" not in slots, slots   # (400: the fused family)
         assert (states[-1] - ref.c).abs().max().item() <= 1e-13
         got[name] = states[-1]
     assert (got["two_stage"] - got["uniform"]).abs().max().item() <= 1e-14
@@ -191,7 +194,8 @@ def test_ch_fused_fast_path_outputs(shape):
 
 
 @pytest.mark.parametrize("shape,pred", [((64, 64, 64), 2), ((128, 64, 96), 3), ((100, 40, 50), 2), ((12, 10, 9), 2), ((64, 128), 2),
-                                        ((160, 48, 240), 3), ((120, 150), 2), ((64, 180, 120), 2), ((240, 32, 160), 2), ((60, 40, 180), 4)])   # two-stage z plans
+                                        ((160, 48, 240), 3), ((120, 150), 2), ((64, 180, 120), 2), ((240, 32, 160), 2), ((60, 40, 180), 4),
+                                        ((400, 32, 400), 3), ((320, 40, 300), 2), ((32, 300, 320), 5)])   # two-stage z plans
 def test_ch_multi_substep_call(shape, pred):
     """mrl_ch_substeps (the substep loop of TensorSolver::computeBuffer in one call; on planned shapes the inverse z pass of a
     substep is fused with the forward z pass of the next one) == the same substeps one call at a time, bit for bit on the fused
