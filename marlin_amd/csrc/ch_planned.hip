@@ -6,7 +6,7 @@
 //   Cahn-Hilliard substep   forward z with mu = f'(c) in the loader (c and mu in one complex transform) -> forward y of both fields ->
 //                           x passes with the k-space update (Nhat = Mbar mu-hat, ABM predictor, 1/(1 - dt Lbar);
 //                           AdamsBashforthMoulton.C:94-99) -> inverse y -> inverse z
-//   120 / 150 / 160 / 180 / 240 points   two-stage plans (fft_two.h, fft_two_z.h: at most 16 points per thread): both fields per y
+//   120 / 150 / 160 / 180 / 240 / 300 / 320 points   two-stage plans (fft_two.h, fft_two_z.h: at most 16 / 20 points per thread): both fields per y
 //                           launch, ONE fused x kernel, and -- when the z extent is one of them -- ch_substeps_planned, the substep
 //                           loop with the inverse z pass of a substep fused into the forward z pass of the next: 14 h of traffic
 //                           per AB2 substep (h = one half-spectrum array), as on the fused path

@@ -1,5 +1,6 @@
 // Two-stage plans with per-stage ownership for the strided passes of the lengths 2^a 3^b 5^c that the uniform plans of fft_pow2.h
-// can only serve with 30 (or 20) points per thread: 120 = 10 x 12, 150 = 10 x 15, 160 = 10 x 16, 180 = 12 x 15, 240 = 15 x 16.
+// can only serve with 30 (or 20) points per thread: 120 = 10 x 12, 150 = 10 x 15, 160 = 10 x 16, 180 = 12 x 15, 240 = 15 x 16, and with
+// 20 points per thread 300 = 20 x 15, 320 = 20 x 16, 400 = 20 x 20 (the fused x pass only).
 //
 // A uniform plan (Plan<N>) gives every thread the same P points q + m TPL through all stages, so a length whose factors do not share
 // a common P ends at P = 30: 120 vector registers per array, one field per launch, no room for the fused Cahn-Hilliard x pass, and
@@ -49,6 +50,8 @@ MRL_PLAN2(240, 15, 16, 16)
 MRL_PLAN2(300, 20, 15, 12)
 MRL_PLAN2(320, 20, 16, 12)
 MRL_PLAN2(400, 20, 20, 8)
+// (200 = 20 x 10 was measured too: its fused x pass 67.4-68.3 us against 62.5-63.6 us of the uniform 10-point plan at 200^3 -- ten of
+// twenty lanes idle on the pattern-A side, which carries three of the five streams; not instantiated)
 #undef MRL_PLAN2
 
 // lengths whose strided passes and z kernels run two-stage plans ...
