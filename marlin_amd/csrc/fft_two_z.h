@@ -34,9 +34,10 @@ MRL_ZPLAN2(150, 10, 15, 8)
 MRL_ZPLAN2(160, 16, 10, 8)
 MRL_ZPLAN2(180, 12, 15, 8)
 MRL_ZPLAN2(240, 16, 15, 8)
-// 20 points per thread on one side (fft_two.h): 160-thread workgroups of 8 lines
-MRL_ZPLAN2(300, 20, 15, 8)
-MRL_ZPLAN2(320, 16, 20, 8)
+// 20 points per thread on the real side, 20 threads per line (fft_two.h); 12 lines per workgroup = 240 threads (8 lines = 2.5 waves:
+// fused z pass 177 -> 156 us at 300^3; 320 with the 20 on the spectral side instead: 208 -> 175 us at 320^3); 16 lines at 240 points: level
+MRL_ZPLAN2(300, 20, 15, 12)
+MRL_ZPLAN2(320, 20, 16, 12)
 #undef MRL_ZPLAN2
 
 template <int N>
