@@ -337,6 +337,7 @@ static PGeo pgeo(const mrl_ctx *ctx) {
 // serial half-spectrum contexts whose extents all have plans for the plain transforms and at least one of which needs this path
 bool planned_unfused_ok(const mrl_ctx *ctx) {
   if (ctx->slab || ctx->pencil || ctx->spectrum != MRL_SPECTRUM_HALF || (ctx->dim != 2 && ctx->dim != 3)) return false;
+  if (ctx->exp & 2048) return false;  // experiment: planned shapes through the any-length path (A/B and parity, as fast_path_ok)
   const PGeo g = pgeo(ctx);
   if ((g.nx * g.ny) % 2) return false;  // the z passes carry two lines per complex transform
   const bool all = plain_ok(g.nx) && (g.ny == 1 || plain_ok(g.ny)) && plain_ok(g.nz);

@@ -1,10 +1,12 @@
 """Cahn-Hilliard substep on the GPU vs the reference gold file and the oracle, through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import marlin_oracle as mo
-from tests.conftest import load_golden
+from tests.conftest import ROOT, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -138,6 +140,51 @@ def test_two_stage_plans_deep_histories_and_outputs(shape, pred):
         assert (states[-1] - ref.c).abs().max().item() <= 1e-13
         got[name] = states[-1]
     assert (got["two_stage"] - got["uniform"]).abs().max().item() <= 1e-14
+
+
+def test_random_mixes_of_planned_lengths_against_the_any_length_path():
+    """48 random grids (2-D and 3-D) whose extents are drawn from the planned lengths -- uniform, radix-30 / radix-20, two-stage plans
+    next to each other on every axis role -- : three substeps (AB1, AB2, AB3) through the planned / fused kernels and through the
+    any-length path (experiment bit 2048: generic transforms + separate pointwise kernels, an independent implementation of the same
+    operator sequence), fields and mu to 1e-13"""
+    import random
+    import re
+    from marlin_amd import api
+    from marlin_amd.api import Context, ch_params
+    src = open(os.path.join(ROOT, "marlin_amd", "csrc", "fft_pow2.h")).read()
+    lengths = sorted({int(m) for m in re.findall(r"^MRL_PLAN\((\d+),", src, flags=re.M)})
+    lengths = [n for n in lengths if n <= 640]
+    small = [n for n in lengths if n <= 80]
+    rng = random.Random(5)
+    bad = []
+    for it in range(48):
+        dim = 2 if it % 4 == 3 else 3
+        big_axis = rng.randrange(dim)
+        shape = [rng.choice(lengths) if a == big_axis else rng.choice(small) for a in range(dim)]
+        if dim == 3 and (shape[0] * shape[1]) % 2:
+            continue
+        L = [2.0 + d for d in range(dim)]
+        torch.manual_seed(it)
+        c0 = (torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44).cuda()
+        res = []
+        for exp in (0, 2048):
+            ctx = Context(dim, shape, L, dense_spectra=exp != 0)
+            ctx.set_option(api.OPT_EXPERIMENT, exp)
+            ctx.set_profiling(True)
+            c, hist = c0.clone(), []
+            mu = torch.empty_like(c0)
+            for k in range(3):
+                Nn, cn = ctx.empty_hist(), torch.empty_like(c)
+                ctx.ch_substep(ch_params(), c, cn, Nn, hist[:k], k, 2e-3, mu=mu)
+                hist.insert(0, Nn)
+                c = cn
+            res.append((c.cpu(), mu.cpu()))
+            slots = {k["kernel"] for k in ctx.get_profile() if k["launches"]}
+            assert ("ch_kspace" in slots) == (exp != 0), (shape, exp, slots)     # the any-length path, and only it, has this kernel
+        e = max((a - b).abs().max().item() for a, b in zip(*res))
+        if e > 1e-13:
+            bad.append((shape, e))
+    assert not bad, bad
 
 
 def test_ch_pfhub_family_and_ab3():
