@@ -351,6 +351,26 @@ def test_mech3d_gold_through_the_shim(tmp_path):
     assert worst <= 1e-10, worst
 
 
+def test_mech3d_gold_through_the_shim_on_two_ranks(tmp_path):
+    """mech3d.i with parallel_mode = FFT_SLAB on two rank processes through HipFFTMechanics (the Newton-CG solve on the library-owned
+    slab pipeline, global CG scalars through its mailbox all-reduce), HipParsedCompute with the coordinate symbols on a rank's block,
+    HipComputeVonMisesStress: both ranks' slabs of F_k and sV against gold mech3d.h5 to 1e-10, the serial run's Newton counts"""
+    g = load_golden("mech3d_gold.npz")
+    n = 16
+    log = _run(["nranks=2", "case=mechanics", "nx=16", "ny=16", "nz=16", "xmax=2pi", "ymax=2pi", "zmax=2pi", "substeps=10", "num_steps=3",
+                "dt=0.01", "l_tol=1e-2", "nl_rel_tol=2e-2", "nl_abs_tol=2e-2"], tmp_path)
+    its = [int(m) for m in re.findall(r"(\d+) Newton iterations", log)]
+    assert len(its) >= 30 and set(its) == {2}, its
+    worst = 0.0
+    for frame in range(3):
+        F = np.concatenate([np.fromfile(tmp_path / f"F.{frame}.rank{r}.bin", dtype="<f8").reshape(n, n // 2, n, 9) for r in range(2)], axis=1)
+        for k in range(9):
+            worst = max(worst, np.abs(g[f"F_{k}.{frame}"] - np.transpose(F[..., k], (2, 1, 0))).max())
+        sv = np.concatenate([np.fromfile(tmp_path / f"sV.{frame}.rank{r}.bin", dtype="<f8").reshape(n, n // 2, n) for r in range(2)], axis=1)
+        worst = max(worst, np.abs(g[f"sV.{frame}"] - np.transpose(sv, (2, 1, 0))).max())
+    assert worst <= 1e-10, worst
+
+
 @pytest.mark.parametrize("case,bound", [("gradient", None), ("gradient_square", 1e-10)])
 def test_gradient_cases_through_the_shim(case, bound, tmp_path):
     """test/tests/gradient/tests (gradient.i, gradient_square.i): HipFFTGradient (X, Y, Z) and HipFFTGradientSquare of
