@@ -233,7 +233,8 @@ def test_slab_table_addressed_pipeline(shape, P, nsub, exp):
 
 
 @pytest.mark.parametrize("shape,P,nsub", [((8, 6, 10), 2, 2), ((9, 7, 5), 3, 1), ((64, 64, 64), 2, 4), ((64, 128, 64), 8, 3),
-                                          ((128, 32, 32), 4, 2), ((32, 64, 32), 32, 2)])
+                                          ((128, 32, 32), 4, 2), ((32, 64, 32), 32, 2),
+                                          ((40, 48, 240), 2, 1), ((240, 40, 48), 2, 2), ((48, 240, 40), 3, 1), ((160, 120, 150), 2, 1)])  # 2 x 3 x 5 lengths
 def test_slab_ch_carry_over(shape, P, nsub):
     """spectral carry-over (MRL_CARRY_OUT on the first substep, MRL_CARRY_IN afterwards) vs the reference's data flow on
     the same kernels and vs the serial oracle: generic path (odd / uneven) and fused fast path, AB1 -> AB2 history"""
