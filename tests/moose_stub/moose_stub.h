@@ -23,6 +23,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cmath>
 #include <any>
 #include <array>
 #include <atomic>
@@ -129,6 +130,7 @@ namespace moose_stub
 struct World
 {
   unsigned int size = 1, rank = 0;
+  bool pencil = false;   // parallel_mode = FFT_PENCIL (FFT_SLAB otherwise)
   struct Page
   {
     std::atomic<unsigned int> seq, arrived;
@@ -439,7 +441,7 @@ struct MooseStubFactory
 #define registerMooseObject(app, classname)                                                                            \
   static const int moose_stub_registered_##classname = MooseStubFactory::add<classname>(#classname)
 
-/// include/actions/DomainAction.h:31-69 -- the getters the shim reads.  parallel_mode = NONE (DomainAction.C:268-296: r2c on the last
+/// include/actions/DomainAction.h:31-69 -- the getters the shim reads (+ partitionPencils when the job runs FFT_PENCIL, see below).  parallel_mode = NONE (DomainAction.C:268-296: r2c on the last
 /// axis) with one rank; with several ranks parallel_mode = FFT_SLAB as DomainAction::partitionSlabs does it (:510-566): the real space
 /// is split along y, the reciprocal space along x, every axis transforms c2c (:278-280), equal weights through partitionHepler
 /// (DomainAction.h:247-280); getLocalBounds hands out _local_begin / _local_end, i.e. the RECIPROCAL x range on axis 0 and the real y
@@ -469,24 +471,84 @@ public:
       _begin[d].assign(_n_rank, 0);
       _end[d].assign(_n_rank, _n[d]);
     }
-    if (_n_rank > 1)
+    auto split = [](int64_t total, unsigned int parts)   // partitionHepler with unit weights (DomainAction.h:247-280)
+    {
+      std::vector<int64_t> counts(parts);
+      int64_t remaining = parts;
+      for (unsigned int r = 0; r < parts; ++r)
+      {
+        int64_t c = std::max<int64_t>(total / remaining, 1);
+        if (r + 1 == parts)
+          c = total;
+        counts[r] = c;
+        total -= c;
+        remaining -= 1;
+      }
+      return counts;
+    };
+    auto offset = [](const std::vector<int64_t> & counts, unsigned int i)
+    {
+      int64_t o = 0;
+      for (unsigned int k = 0; k < i; ++k)
+        o += counts[k];
+      return o;
+    };
+    if (_n_rank > 1 && w.pencil)
+    {
+      // DomainAction::partitionPencils (DomainAction.C:568-698): r2c on x (:282-284), the real space split along y (rank % Py) and z
+      // (rank / Py), the reciprocal space along kx (rank % Py) and ky (rank / Py); Py x Pz = the most balanced factorisation of the ranks
+      if (dim < 3)
+        mooseError("Dimension must be 3 for pencil decomposition.");
+      _n_reciprocal = _n;
+      _n_reciprocal[0] = _n[0] / 2 + 1;
+      unsigned int Py = 0, Pz = 0, best = ~0u;
+      auto consider = [&](unsigned int px, unsigned int pz)
+      {
+        if (px < 2 || pz < 2 || px > _n[1] || px > _n_reciprocal[0] || pz > _n[2] || pz > _n[1])
+          return;
+        const unsigned int cost = px > pz ? px - pz : pz - px;
+        if (Py == 0 || cost < best)
+        {
+          Py = px;
+          Pz = pz;
+          best = cost;
+        }
+      };
+      const unsigned int max_divisor = std::max(2u, (unsigned int)std::sqrt((double)_n_rank));
+      for (unsigned int d = 2; d <= max_divisor; ++d)
+        if (_n_rank % d == 0)
+        {
+          consider(d, _n_rank / d);
+          consider(_n_rank / d, d);
+        }
+      if (Py == 0)
+        mooseError("FFT_PENCIL requires factoring the number of MPI ranks into two integers greater than one that fit the domain (ranks = ",
+                   _n_rank, "). Use FFT_SLAB or adjust the rank count.");
+      const auto yc = split(_n[1], Py), zc = split(_n[2], Pz), kxc = split(_n_reciprocal[0], Py), kyc = split(_n_reciprocal[1], Pz);
+      for (unsigned int r = 0; r < _n_rank; ++r)
+      {
+        const unsigned int py = r % Py, pz = r / Py;
+        _begin[1][r] = offset(yc, py);
+        _end[1][r] = _begin[1][r] + yc[py];
+        _begin[2][r] = offset(zc, pz);
+        _end[2][r] = _begin[2][r] + zc[pz];
+      }
+      _n_local[1] = yc[_rank % Py];
+      _n_local[2] = zc[_rank / Py];
+      _n_reciprocal_local = {{kxc[_rank % Py], kyc[_rank / Py], _n_reciprocal[2]}};
+    }
+    else if (_n_rank > 1)
     {
       if (dim < 2)
         mooseError("Dimension must be 2 or 3 for slab decomposition.");
       const int64_t totals[2] = {_n_reciprocal[0], _n[1]};
       for (unsigned int d = 0; d < 2; ++d)
       {
-        int64_t total = totals[d], remaining = _n_rank, b = 0;
+        const auto counts = split(totals[d], _n_rank);
         for (unsigned int r = 0; r < _n_rank; ++r)
         {
-          int64_t c = std::max<int64_t>(total / remaining, 1); // weights 1: (total * w) / remaining_total_weight
-          if (r + 1 == _n_rank)
-            c = total;
-          _begin[d][r] = b;
-          b += c;
-          _end[d][r] = b;
-          total -= c;
-          remaining -= 1;
+          _begin[d][r] = offset(counts, r);
+          _end[d][r] = _begin[d][r] + counts[r];
         }
       }
       _n_local[1] = _end[1][_rank] - _begin[1][_rank];

@@ -94,7 +94,10 @@ read_ic(const std::string & path, const DomainAction & domain)
     return g;
   std::array<int64_t, 3> b, e;
   domain.getLocalBounds(moose_stub::world().rank, b, e);
-  return g.slice(1, b[1], e[1]).contiguous();
+  g = g.slice(1, b[1], e[1]);
+  if (domain.getDim() == 3)   // (FFT_PENCIL also splits z; FFT_SLAB: the whole axis)
+    g = g.slice(2, b[2], e[2]);
+  return g.contiguous();
 }
 
 /// an [object] block of an input file: type + parameters as text
@@ -372,7 +375,8 @@ run_brusselator(const std::string & out)
   csv.precision(17);
   csv << "time,U,V,u_max,u_min,v_max,v_min\n0,0,0,0,0,0,0\n";
   // TensorIntegralPostprocessor.C:29-38 (average * volume), TensorExtremeValuePostprocessor
-  auto integral = [&](const torch::Tensor & t) { return t.sum().item<double>() / double(domain.getNumberOfCells()) * volume; };
+  // (on several ranks: this rank's part of the integral; the parts add up to the postprocessor's value)
+  auto integral = [&](const torch::Tensor & t) { return t.sum().item<double>() / double(domain.getGlobalNumberOfCells()) * volume; };
   transient(problem, *solver, time_steps(), [&](int) {
     const auto & u = problem.getBuffer("u");
     const auto & v = problem.getBuffer("v");
@@ -424,7 +428,8 @@ run_coupled(const std::string & out)
   std::ofstream csv(out + "/coupled.csv");
   csv.precision(17);
   csv << "time,U,V,u_max,u_min,v_max,v_min\n0,0,0,0,0,0,0\n";
-  auto integral = [&](const torch::Tensor & t) { return t.sum().item<double>() / double(domain.getNumberOfCells()) * volume; };
+  // (on several ranks: this rank's part of the integral; the parts add up to the postprocessor's value)
+  auto integral = [&](const torch::Tensor & t) { return t.sum().item<double>() / double(domain.getGlobalNumberOfCells()) * volume; };
   transient(problem, *solver, time_steps(), [&](int) {
     const auto & u = problem.getBuffer("u");
     const auto & v = problem.getBuffer("v");
@@ -657,7 +662,8 @@ run_kks(const std::string & out)
                                       {"corrector_order", arg("predictor_order", "3")}});
   solver->updateDependencies();
   const double volume = (argd("xmax", 1) - argd("xmin", 0)) * (argd("ymax", 1) - argd("ymin", 0));
-  auto integral = [&](const torch::Tensor & t) { return t.sum().item<double>() / double(domain.getNumberOfCells()) * volume; };
+  // (on several ranks: this rank's part of the integral; the parts add up to the postprocessor's value)
+  auto integral = [&](const torch::Tensor & t) { return t.sum().item<double>() / double(domain.getGlobalNumberOfCells()) * volume; };
   std::ofstream csv(out + "/kks.csv");
   csv.precision(17);
   csv << "time,total_C,total_eta\n";
@@ -764,9 +770,11 @@ run_gradient(const std::string & out, bool square)
     create<TensorOperatorBase>(problem, "HipParsedCompute", buffer, block)->computeBuffer();
   };
   const double volume = (argd("xmax", 1) - argd("xmin", 0)) * (argd("ymax", 1) - argd("ymin", 0)) * (argd("zmax", 1) - argd("zmin", 0));
-  auto integral = [&](const torch::Tensor & t) { return t.sum().item<double>() / double(domain.getNumberOfCells()) * volume; };
+  // (on several ranks: this rank's part of the integral; the parts add up to the postprocessor's value)
+  auto integral = [&](const torch::Tensor & t) { return t.sum().item<double>() / double(domain.getGlobalNumberOfCells()) * volume; };
   parsed("s", "sin(x)+sin(y)+sin(z)", "", true);
-  std::ofstream csv(out + (square ? "/gradient_square.csv" : "/gradient.csv"));
+  const auto & wld = moose_stub::world();
+  std::ofstream csv(out + (square ? "/gradient_square" : "/gradient") + (wld.size > 1 ? ".rank" + std::to_string(wld.rank) : std::string()) + ".csv");
   csv.precision(17);
   if (square)
   {
@@ -848,7 +856,10 @@ main(int argc, char ** argv)
       return rc;
     }
     if (nranks > 1)
+    {
       moose_stub::joinWorld(arg("job"), (unsigned int)nranks, (unsigned int)argi("rank", 0));
+      moose_stub::world().pencil = arg("parallel_mode", "FFT_SLAB") == "FFT_PENCIL";
+    }
     if (!torch::cuda::is_available())
       mooseError("shim-driver needs a GPU (libTorch sees no HIP device)");
     moose_stub::device() = torch::Device(torch::kCUDA, (c10::DeviceIndex)argi("device", 0));

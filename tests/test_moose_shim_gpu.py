@@ -351,6 +351,43 @@ def test_mech3d_gold_through_the_shim(tmp_path):
     assert worst <= 1e-10, worst
 
 
+@pytest.mark.parametrize("case", ["gradient", "gradient_square"])
+def test_gradient_cases_through_the_shim_on_four_pencil_ranks(case, tmp_path):
+    """test/tests/gradient/tests, the reference's 4-rank FFT_PENCIL spec: the stub's DomainAction partitions as partitionPencils does
+    (DomainAction.C:568-698: 2 x 2, r2c on x), HipDomain recognises the pencil partition (a local z extent shorter than the global one),
+    sets MRL_FLAG_PENCIL and checks the library's blocks against the DomainAction's; HipParsedCompute / HipForwardFFT / HipFFTGradient /
+    HipFFTGradientSquare work on a rank's pencil.  The four partial integrals add up to the serial run's postprocessor value."""
+    args = [f"case={case}", "nx=40", "ny=40", "nz=40", "xmax=2pi", "ymax=4pi", "zmax=6pi"]
+    _run(args, tmp_path)
+    serial = np.loadtxt(tmp_path / f"{case}.csv", delimiter=",", skiprows=1)[-1, 1]
+    _run(["nranks=4", "parallel_mode=FFT_PENCIL"] + args, tmp_path)
+    parts = [np.loadtxt(tmp_path / f"{case}.rank{r}.csv", delimiter=",", skiprows=1)[-1, 1] for r in range(4)]
+    assert abs(sum(parts) - serial) <= 1e-10 * max(1.0, abs(serial)), (parts, serial)
+    assert serial < 1e-9     # (spectral derivatives of sin(x) + sin(y) + sin(z) are exact to rounding: gradient*_out.csv)
+
+
+def test_cahnhilliard_3d_fft_pencil_through_the_shim_on_four_ranks(tmp_path):
+    """Cahn-Hilliard substeps on four FFT_PENCIL ranks through HipAdamsBashforthMoulton (the library runs the unfused operator
+    sequence over its staged pencil transforms): the four pencils against the oracle's serial run to 1e-13"""
+    import torch
+    from oracle import marlin_oracle as mo
+    torch.manual_seed(6)
+    shape, L = [16, 12, 20], [3.0, 2.0, 4.0]
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    ic = tmp_path / "c0.bin"
+    c0.numpy().astype("<f8").tofile(ic)
+    dts, substeps, pred = [1e-3, 1e-3, 2e-3], 3, 2
+    _run(["nranks=4", "parallel_mode=FFT_PENCIL", "case=cahnhilliard", "nx=16", "ny=12", "nz=20", "xmax=3", "ymax=2", "zmax=4", f"ic={ic}",
+          f"substeps={substeps}", "dt_sequence=" + ",".join(repr(d) for d in dts), f"predictor_order={pred}"], tmp_path)
+    ref = mo.CahnHilliardABM(mo.Domain(3, shape, L), c0, M=0.2, kappa_factor=-0.001, mu_fn=mo.mu_double_well, substeps=substeps,
+                             predictor_order=pred)
+    for k, dt in enumerate(dts):
+        ref.step(dt)
+        blocks = [np.fromfile(tmp_path / f"c.{k + 1}.rank{r}.bin", dtype="<f8").reshape(16, 6, 10) for r in range(4)]
+        c = np.concatenate([np.concatenate([blocks[0], blocks[1]], axis=1), np.concatenate([blocks[2], blocks[3]], axis=1)], axis=2)
+        assert np.abs(ref.c.numpy() - c).max() <= 1e-13
+
+
 def test_mech3d_gold_through_the_shim_on_two_ranks(tmp_path):
     """mech3d.i with parallel_mode = FFT_SLAB on two rank processes through HipFFTMechanics (the Newton-CG solve on the library-owned
     slab pipeline, global CG scalars through its mailbox all-reduce), HipParsedCompute with the coordinate symbols on a rank's block,
