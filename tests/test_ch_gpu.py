@@ -142,6 +142,41 @@ def test_two_stage_plans_deep_histories_and_outputs(shape, pred):
     assert (got["two_stage"] - got["uniform"]).abs().max().item() <= 1e-14
 
 
+@pytest.mark.parametrize("shape", [(240, 32, 120), (300, 40, 32), (160, 150), (400, 32, 32)])
+def test_two_stage_plans_cbar_and_history_outputs(shape):
+    """the optional outputs of a substep on the two-stage kernels (k_ch_xfused2: cbar = c-hat of the substep, Nhat = the history
+    entry; k_z_fwd2: mu) against the oracle's op sequence, AB1 and AB2"""
+    from marlin_amd.api import Context, ch_params
+    dim = len(shape)
+    L = [4.0, 5.0, 6.0][:dim]
+    ctx = Context(dim, list(shape), L)
+    dom = mo.Domain(dim, list(shape), L)
+    torch.manual_seed(3)
+    c0 = torch.rand(shape, dtype=torch.float64) * 0.12 + 0.44
+    Mbar = mo.reciprocal_laplacian_factor(dom, 0.2)
+    Lbar = mo.reciprocal_laplacian_square_factor(dom, -0.001)
+    r1, N1, cb1, mu1 = mo.ch_substep_ops(c0, Mbar, Lbar, [], 2e-3, 0, mo.mu_double_well, dom)
+    r2, N2, cb2, mu2 = mo.ch_substep_ops(r1, Mbar, Lbar, [N1], 2e-3, 1, mo.mu_double_well, dom)
+    p = ch_params()
+    c = c0.cuda()
+    Na, Nb = ctx.empty_hist(), ctx.empty_hist()
+    cbar, mu = ctx.empty_hist(), torch.empty_like(c)
+    c1, c2 = torch.empty_like(c), torch.empty_like(c)
+    ctx.ch_substep(p, c, c1, Na, [], 0, 2e-3, cbar=cbar, mu=mu)
+    assert (cbar.cpu() - cb1).abs().max().item() <= 1e-13 * cb1.abs().max().item()
+    assert (mu.cpu() - mu1).abs().max().item() <= 1e-15
+    # Nhat = Mbar mu-hat: the rounding of the transform (~ eps log2(n) max|mu-hat|, white over the spectrum) times the largest |Mbar|
+    tolN = lambda m: 4e-16 * np.log2(c0.numel()) * torch.fft.rfftn(m).abs().max().item() * Mbar.abs().max().item()
+    assert (Na.cpu() - N1).abs().max().item() <= tolN(mu1)
+    assert (c1.cpu() - r1).abs().max().item() <= 1e-14
+    # (the second substep starts from the oracle's field: Nhat amplifies the 1e-15 differences of its input by |Mbar| ~ 1e4 at high k)
+    ctx.ch_substep(p, r1.cuda(), c2, Nb, [Na], 1, 2e-3, cbar=cbar, mu=mu)
+    assert (cbar.cpu() - cb2).abs().max().item() <= 1e-13 * cb2.abs().max().item()
+    assert (Nb.cpu() - N2).abs().max().item() <= tolN(mu2)
+    assert (mu.cpu() - mu2).abs().max().item() <= 1e-15
+    assert (c2.cpu() - r2).abs().max().item() <= 1e-14
+
+
 def test_random_mixes_of_planned_lengths_against_the_any_length_path():
     """48 random grids (2-D and 3-D) whose extents are drawn from the planned lengths -- uniform, radix-30 / radix-20, two-stage plans
     next to each other on every axis role -- : three substeps (AB1, AB2, AB3) through the planned / fused kernels and through the
