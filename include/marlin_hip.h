@@ -271,8 +271,8 @@ int mrl_ch_substep(mrl_ctx *ctx, const mrl_ch_params *p, const double *d_c_in, d
  * Cahn-Hilliard system, i.e. count x { AdamsBashforthMoulton::substep ; advanceState between substeps }.  The reference's
  * examples run 1000 substeps per solver call; inside the loop the real field c of an intermediate substep is not visible to
  * anything (the buffer is rebound every substep, outputs and postprocessors run at the end of the time step), so on planned
- * shapes the inverse z pass of substep k and the forward z pass of substep k+1 are one kernel and that field never reaches HBM
- * (bit-identical results; 12 % less traffic at 256^3).
+ * shapes (the fused family, and z extents with a two-stage plan: 120 ... 320 points) the inverse z pass of substep k and the
+ * forward z pass of substep k+1 are one kernel and that field never reaches HBM (bit-identical results; 12 % less traffic at 256^3).
  *   d_Nhat_ring : ring_size >= predictor_order arrays (complex, reciprocal grid).  *head = slot of the newest history entry
  *                 (Nhat_old[0]), *n_old = number of valid history entries.  A substep uses order = min(*n_old, predictor_order-1),
  *                 writes its Nhat into slot (*head + 1) % ring_size, and with advance != 0 that slot becomes the head before
