@@ -184,6 +184,16 @@ int z_fwd_launch_std(mrl_ctx *ctx, long long n, int mode, int fam, const double 
   }
   return MRL_OK;
 }
+// fused inverse + forward z pass (built-in families) on dense rows; nlines = line pairs
+int z_inv_fwd_launch_std(mrl_ctx *ctx, long long n, int fam, const cplx *in, cplx *o0, cplx *o1, double *mu, const p2::ChDev &chp, double scale,
+                         long long nlines) {
+  if (fam == MRL_FE_DOUBLE_WELL) {
+    MRL_SWITCH_N(n, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_DOUBLE_WELL>(ctx, in, o0, o1, mu, chp, scale, nlines))));
+  } else {
+    MRL_SWITCH_N(n, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_PFHUB>(ctx, in, o0, o1, mu, chp, scale, nlines))));
+  }
+  return MRL_OK;
+}
 int z_inv_launch_std(mrl_ctx *ctx, long long n, const cplx *in, double *out, double scale, long long nlines) {
   MRL_SWITCH_N(n, MRL_TRY((p2::launch_z_inv<NN>(ctx, in, out, scale, nlines))));
   return MRL_OK;

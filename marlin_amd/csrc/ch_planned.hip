@@ -26,6 +26,8 @@ int pass_launch_std(mrl_ctx *ctx, long long n, bool inv, int nf, const p2::PassA
 int z_fwd_launch_std(mrl_ctx *ctx, long long n, int mode, int fam, const double *in, cplx *o0, cplx *o1, double *mu, const p2::ChDev &chp,
                      long long nlines);
 int z_inv_launch_std(mrl_ctx *ctx, long long n, const cplx *in, double *out, double scale, long long nlines);
+int z_inv_fwd_launch_std(mrl_ctx *ctx, long long n, int fam, const cplx *in, cplx *o0, cplx *o1, double *mu, const p2::ChDev &chp, double scale,
+                         long long nlines);
 int ch_kspace_launch(mrl_ctx *ctx, const ChP &cp, const double *cbar, const double *mubar, double *Nhat, double *ubar,
                      const double *const *Nold, int order, double sub_dt);
 
@@ -535,7 +537,10 @@ int ch_substeps_planned(mrl_ctx *ctx, const ChP &cp, const double *c_in, double 
                         int *n_old, int pred, int count, int advance, double sub_dt, double *mu, bool dt_changed) {
   if (!planned_unfused_ok(ctx)) return MRL_ERR_UNSUPPORTED;
   const PGeo g = pgeo(ctx);
-  if (!two_stage(ctx, g.nz)) return MRL_ERR_UNSUPPORTED;
+  // a fused inverse + forward z kernel exists for the two-stage lengths and for the lengths of the fused family (a grid like
+  // 240 x 240 x 256 is on this path because of its x and y extents); the uniform 30- / 20-point z plans have none
+  const bool z_two = two_stage(ctx, g.nz), z_std = !z_two && pow2_ok(g.nz);
+  if (!z_two && !z_std) return MRL_ERR_UNSUPPORTED;
   const long long nreal = g.nx * g.ny * g.nz, nspec = g.nx * g.ny * g.nzc;
   MRL_TRY(ensure_work(ctx, 1, sizeof(cplx) * nspec));
   MRL_TRY(ensure_work(ctx, 2, sizeof(cplx) * nspec));
@@ -557,6 +562,8 @@ int ch_substeps_planned(mrl_ctx *ctx, const ChP &cp, const double *c_in, double 
       ProfScope ps(ctx, "chp_FA_z_inv_fwd", 3.0 * h + (mu_k ? 8.0 * nreal : 0.0));
       if (cp.family == MRL_FE_PARSED) {
         MRL_TRY(parsed_z_inv_fwd_launch(ctx, cp.parsed, (int)g.nz, w_c, w_c, w_mu, mu_k, scale, g.nx * g.ny / 2, false));
+      } else if (z_std) {
+        MRL_TRY(z_inv_fwd_launch_std(ctx, g.nz, cp.family, w_c, w_c, w_mu, mu_k, chp, scale, g.nx * g.ny / 2));
       } else if (cp.family == MRL_FE_DOUBLE_WELL) {
         MRL_SWITCH_N2(g.nz, MRL_TRY((p2::launch_z_inv_fwd2<NN, MRL_FE_DOUBLE_WELL>(ctx, w_c, w_c, w_mu, mu_k, chp, scale, g.nx * g.ny / 2))));
       } else {

@@ -277,7 +277,8 @@ def test_ch_fused_fast_path_outputs(shape):
 
 @pytest.mark.parametrize("shape,pred", [((64, 64, 64), 2), ((128, 64, 96), 3), ((100, 40, 50), 2), ((12, 10, 9), 2), ((64, 128), 2),
                                         ((160, 48, 240), 3), ((120, 150), 2), ((64, 180, 120), 2), ((240, 32, 160), 2), ((60, 40, 180), 4),
-                                        ((400, 32, 400), 3), ((320, 40, 300), 2), ((32, 300, 320), 5)])   # two-stage z plans
+                                        ((400, 32, 400), 3), ((320, 40, 300), 2), ((32, 300, 320), 5),   # two-stage z plans
+                                        ((240, 32, 128), 2), ((120, 150, 64), 3), ((60, 90, 100), 2)])    # planned x / y, fused-family z
 def test_ch_multi_substep_call(shape, pred):
     """mrl_ch_substeps (the substep loop of TensorSolver::computeBuffer in one call; on planned shapes the inverse z pass of a
     substep is fused with the forward z pass of the next one) == the same substeps one call at a time, bit for bit on the fused
