@@ -896,9 +896,7 @@ int parsed_z_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, int mode, const doub
   ChDevHost chp = parsed_chdev(p);
   const cplx *tw = ctx->ax[2].d_tw;
   struct { unsigned lpp, pad; } zl = {lay_lpp, lay_pad};  // = p2::ZLay
-  // (the two-stage kernels work on dense rows: k_z_fwd2(const double*, cplx*, cplx*, double*, ChDev, long long, const cplx*))
   void *params[] = {&in, &out0, &out1, &mu_out, &chp, &nlines, &tw, &zl};
-  if (two_stage_z(ctx, N) && (lay_lpp || lay_pad)) return set_error(ctx, MRL_ERR_INVALID, "parsed z pass: padded rows with a two-stage plan");
   const long long nb = (nlines + T - 1) / T;
   MRL_HIP(ctx, hipModuleLaunchKernel(fn, (unsigned)nb, 1, 1, (unsigned)NT, 1, 1, (unsigned)lds, ctx->stream, params, nullptr));
   return MRL_OK;
@@ -916,7 +914,6 @@ int parsed_z_inv_fwd_launch(mrl_ctx *ctx, mrl_parsed *p, int N, const cplx *in, 
   const cplx *tw = ctx->ax[2].d_tw;
   struct { unsigned lpp, pad; } zl = {lay_lpp, lay_pad};  // = p2::ZLay
   void *params[] = {&in, &out0, &out1, &mu_out, &chp, &scale, &nlines, &tw, &zl};
-  if (two_stage_z(ctx, N) && (lay_lpp || lay_pad)) return set_error(ctx, MRL_ERR_INVALID, "parsed z pass: padded rows with a two-stage plan");
   const long long nb = (nlines + T - 1) / T;
   MRL_HIP(ctx, hipModuleLaunchKernel(fn, (unsigned)nb, 1, 1, (unsigned)NT, 1, 1, (unsigned)lds, ctx->stream, params, nullptr));
   return MRL_OK;

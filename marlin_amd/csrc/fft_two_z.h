@@ -37,6 +37,8 @@ MRL_ZPLAN2(240, 16, 15, 8)
 // 20 points per thread on the real side, 20 threads per line (fft_two.h); 12 lines per workgroup = 240 threads (8 lines = 2.5 waves:
 // fused z pass 177 -> 156 us at 300^3; 320 with the 20 on the spectral side instead: 208 -> 175 us at 320^3); 16 lines at 240 points: level
 MRL_ZPLAN2(300, 20, 15, 12)
+// (200 = 20 x 10 was measured for the fused inverse + forward z pass of the fused family: 55.7-56.3 us against 44.4-45.2 us of
+// k_z_inv_fwd<200> at 200^3 -- ten of twenty lanes carry the whole real-side work; not instantiated)
 MRL_ZPLAN2(320, 20, 16, 12)
 #undef MRL_ZPLAN2
 
@@ -186,7 +188,7 @@ __device__ __forceinline__ void load_half_spectra2(kcplx (&v)[ZPlan2<N>::PM], in
 template <int N, int MODE, int FAM>
 __global__ void __launch_bounds__(ZPlan2<N>::NT, 2) k_z_fwd2(const kreal *__restrict__ in, kcplx *__restrict__ out0, kcplx *__restrict__ out1,
                                                               kreal *__restrict__ mu_out, ChDev chp, long long nlines,
-                                                              const kcplx *__restrict__ tw) {
+                                                              const kcplx *__restrict__ tw, ZLay zl) {
   using Pl = ZPlan2<N>;
   constexpr int R0 = Pl::R0, R1 = Pl::R1, TPL = Pl::TPL, LPB = Pl::LPB, NZC = N / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -225,15 +227,15 @@ __global__ void __launch_bounds__(ZPlan2<N>::NT, 2) k_z_fwd2(const kreal *__rest
     }
   }
   fft2z<N, R0, R1>(v, q, l, X, W);
-  kcplx *o0 = (MODE != 1) ? out0 + (2 * Lc) * NZC : out0 + Lc * NZC;
-  kcplx *o1 = (MODE != 1) ? out0 + (2 * Lc + 1) * NZC : out1 + Lc * NZC;
+  kcplx *o0 = (MODE != 1) ? out0 + zrow(2 * Lc, NZC, zl) : out0 + zrow(Lc, NZC, zl);
+  kcplx *o1 = (MODE != 1) ? out0 + zrow(2 * Lc + 1, NZC, zl) : out1 + zrow(Lc, NZC, zl);
   store_half_spectra2<N>(v, q, l, X, valid, o0, o1);
 }
 
 // ---- z inverse (PAIR): rows 2L, 2L+1 of the half spectrum `in` -> real rows 2L, 2L+1 of out, * scale
 template <int N>
 __global__ void __launch_bounds__(ZPlan2<N>::NT, 2) k_z_inv2(const kcplx *__restrict__ in, kreal *__restrict__ out, kreal scale,
-                                                              long long nlines, const kcplx *__restrict__ tw) {
+                                                              long long nlines, const kcplx *__restrict__ tw, ZLay zl) {
   using Pl = ZPlan2<N>;
   constexpr int R0 = Pl::R0, R1 = Pl::R1, TPL = Pl::TPL, LPB = Pl::LPB, NZC = N / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -246,7 +248,7 @@ __global__ void __launch_bounds__(ZPlan2<N>::NT, 2) k_z_inv2(const kcplx *__rest
   tw2_issue(twr, tw);
   const long long Lc = valid ? L : 0;
   kcplx v[Pl::PM];
-  load_half_spectra2<N>(v, q, in + (2 * Lc) * NZC, in + (2 * Lc + 1) * NZC);
+  load_half_spectra2<N>(v, q, in + zrow(2 * Lc, NZC, zl), in + zrow(2 * Lc + 1, NZC, zl));
   tw2_commit(twr, W);
   fft2z<N, R1, R0>(v, q, l, X, W);
   if (valid && (R1 == TPL || q < R1)) {
@@ -276,7 +278,7 @@ __device__ __forceinline__ kreal mul_exact(kreal a, kreal b) {
 template <int N, int FAM>
 __global__ void __launch_bounds__(ZPlan2<N>::NT, 2) k_z_inv_fwd2(const kcplx *__restrict__ in, kcplx *__restrict__ out0, kcplx *__restrict__ out1,
                                                                   kreal *__restrict__ mu_out, ChDev chp, kreal scale, long long nlines,
-                                                                  const kcplx *__restrict__ tw) {
+                                                                  const kcplx *__restrict__ tw, ZLay zl) {
   using Pl = ZPlan2<N>;
   constexpr int R0 = Pl::R0, R1 = Pl::R1, TPL = Pl::TPL, LPB = Pl::LPB, NZC = N / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -292,7 +294,7 @@ __global__ void __launch_bounds__(ZPlan2<N>::NT, 2) k_z_inv_fwd2(const kcplx *__
   tw2_issue(twf, tw);
   const long long Lc = valid ? L : 0;  // out-of-range lines transform line pair 0 again and store nothing
   kcplx v[Pl::PM];
-  load_half_spectra2<N>(v, q, in + (2 * Lc) * NZC, in + (2 * Lc + 1) * NZC);
+  load_half_spectra2<N>(v, q, in + zrow(2 * Lc, NZC, zl), in + zrow(2 * Lc + 1, NZC, zl));
   tw2_commit(twi, Wi);
   tw2_commit(twf, Wf);
   fft2z<N, R1, R0>(v, q, l, X, Wi);
@@ -316,13 +318,14 @@ __global__ void __launch_bounds__(ZPlan2<N>::NT, 2) k_z_inv_fwd2(const kcplx *__
       for (int t = 0; t < R0; ++t) pm[t * R1] = v[t].y;
     }
     fft2z<N, R0, R1>(v, q, l, X, Wf);
-    store_half_spectra2<N>(v, q, l, X, valid, out0 + (2 * Lc + half) * NZC, out1 + (2 * Lc + half) * NZC);
+    store_half_spectra2<N>(v, q, l, X, valid, out0 + zrow(2 * Lc + half, NZC, zl), out1 + zrow(2 * Lc + half, NZC, zl));
   }
 }
 
 #ifndef __HIPCC_RTC__   // (the kernels above are also compiled at run time with a generated chemical potential: expr.hip)
 template <int N, int MODE, int FAM>
-inline int launch_z_fwd2(mrl_ctx *ctx, const kreal *in, kcplx *o0, kcplx *o1, kreal *mu, const ChDev &chp, long long nlines) {
+inline int launch_z_fwd2(mrl_ctx *ctx, const kreal *in, kcplx *o0, kcplx *o1, kreal *mu, const ChDev &chp, long long nlines,
+                         ZLay zl = ZLay{0u, 0u}) {
   static std::atomic<bool> attr{false};
   constexpr size_t lds = lds_two_z<N>(1);
   if (!attr.load(std::memory_order_acquire)) {
@@ -331,12 +334,12 @@ inline int launch_z_fwd2(mrl_ctx *ctx, const kreal *in, kcplx *o0, kcplx *o1, kr
   }
   constexpr int LPB = ZPlan2<N>::LPB;
   const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_fwd2<N, MODE, FAM>), dim3((unsigned)nb), dim3(ZPlan2<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, nlines, tw_table(ctx, 2));
+  hipLaunchKernelGGL((k_z_fwd2<N, MODE, FAM>), dim3((unsigned)nb), dim3(ZPlan2<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, nlines, tw_table(ctx, 2), zl);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
 template <int N>
-inline int launch_z_inv2(mrl_ctx *ctx, const kcplx *in, kreal *out, kreal scale, long long nlines) {
+inline int launch_z_inv2(mrl_ctx *ctx, const kcplx *in, kreal *out, kreal scale, long long nlines, ZLay zl = ZLay{0u, 0u}) {
   static std::atomic<bool> attr{false};
   constexpr size_t lds = lds_two_z<N>(1);
   if (!attr.load(std::memory_order_acquire)) {
@@ -345,13 +348,14 @@ inline int launch_z_inv2(mrl_ctx *ctx, const kcplx *in, kreal *out, kreal scale,
   }
   constexpr int LPB = ZPlan2<N>::LPB;
   const long long nb = (nlines + LPB - 1) / LPB;
-  hipLaunchKernelGGL((k_z_inv2<N>), dim3((unsigned)nb), dim3(ZPlan2<N>::NT), lds, ctx->stream, in, out, scale, nlines, tw_table(ctx, 2));
+  hipLaunchKernelGGL((k_z_inv2<N>), dim3((unsigned)nb), dim3(ZPlan2<N>::NT), lds, ctx->stream, in, out, scale, nlines, tw_table(ctx, 2), zl);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
 // nlines = number of line PAIRS
 template <int N, int FAM>
-inline int launch_z_inv_fwd2(mrl_ctx *ctx, const kcplx *in, kcplx *o0, kcplx *o1, kreal *mu, const ChDev &chp, kreal scale, long long nlines) {
+inline int launch_z_inv_fwd2(mrl_ctx *ctx, const kcplx *in, kcplx *o0, kcplx *o1, kreal *mu, const ChDev &chp, kreal scale, long long nlines,
+                             ZLay zl = ZLay{0u, 0u}) {
   static std::atomic<bool> attr{false};
   constexpr size_t lds = lds_two_z<N>(2);
   if (!attr.load(std::memory_order_acquire)) {
@@ -361,7 +365,7 @@ inline int launch_z_inv_fwd2(mrl_ctx *ctx, const kcplx *in, kcplx *o0, kcplx *o1
   constexpr int LPB = ZPlan2<N>::LPB;
   const long long nb = (nlines + LPB - 1) / LPB;
   hipLaunchKernelGGL((k_z_inv_fwd2<N, FAM>), dim3((unsigned)nb), dim3(ZPlan2<N>::NT), lds, ctx->stream, in, o0, o1, mu, chp, scale, nlines,
-                     tw_table(ctx, 2));
+                     tw_table(ctx, 2), zl);
   MRL_HIP(ctx, hipGetLastError());
   return MRL_OK;
 }
