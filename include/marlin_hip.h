@@ -478,6 +478,9 @@ int mrl_mech_tangent_apply_fm(mrl_ctx *ctx, const double *d_F_fm, const double *
 int mrl_relayout(mrl_ctx *ctx, int to_field_major, const double *d_in, double *d_out, int64_t npts, int32_t ncomp);
 /* out = a*x + b*y (out may alias x or y) */
 int mrl_axpby(mrl_ctx *ctx, double a, const double *d_x, double b, const double *d_y, double *d_out, int64_t n);
+/* y += a*x: the update of conjugateGradientSolve (x = x + alpha p, r = r - alpha Ap; src/utils/ConjugateGradientSolver.h) under the
+ * name the survey's boundary table uses; = mrl_axpby(a, x, 1, y, y) */
+int mrl_axpy(mrl_ctx *ctx, double a, const double *d_x, double *d_y, int64_t n);
 
 typedef struct mrl_mech_params {
   double l_tol;       /* FFTMechanics l_tol */
@@ -571,6 +574,17 @@ int mrl_timer_stop(mrl_ctx *ctx, float *h_ms); /* records, synchronises, returns
 int mrl_set_profiling(mrl_ctx *ctx, int on);
 int mrl_get_profile(mrl_ctx *ctx, int slot, const char **name, double *total_ms, int64_t *launches,
                     double *bytes_per_launch /* algorithmic HBM bytes of one launch */);
+/* the whole profile in one struct (the survey's mrl_get_timing): device time, launches and algorithmic bytes summed over the kernel
+ * classes recorded since profiling was switched on, and the class with the largest share */
+typedef struct mrl_timing {
+  int32_t kernel_classes;      /* profile slots with at least one launch */
+  int64_t launches;
+  double device_ms;            /* sum of the per-launch HIP-event times */
+  double algorithmic_bytes;    /* sum over launches of the bytes their kernels must move */
+  const char *dominant;        /* name of the class with the largest device time (owned by the context), NULL when empty */
+  double dominant_ms;
+} mrl_timing;
+int mrl_get_timing(mrl_ctx *ctx, mrl_timing *out);
 
 /* ---- HDF5 container of XDMFTensorOutput (src/tensor_outputs/XDMFTensorOutput.C with enable_hdf5 = true) -- host code, no GPU ----
  * The reference stores every output component as a dataset "<name>.<frame>" in the root group of "<file_base>[.rankNNNN].h5"

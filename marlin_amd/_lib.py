@@ -45,6 +45,17 @@ class MrlMechParams(C.Structure):
     ]
 
 
+class MrlTiming(C.Structure):
+    _fields_ = [
+        ("kernel_classes", C.c_int32),
+        ("launches", C.c_int64),
+        ("device_ms", C.c_double),
+        ("algorithmic_bytes", C.c_double),
+        ("dominant", C.c_char_p),
+        ("dominant_ms", C.c_double),
+    ]
+
+
 class MrlMechStats(C.Structure):
     _fields_ = [
         ("newton_its", C.c_int32),
@@ -131,6 +142,7 @@ SIGNATURES = {
     "mrl_slab_gamma_project": (_i32, [_vp, _vp, _dbl]),
     "mrl_relayout": (_i32, [_vp, _i32, _vp, _vp, _i64, C.c_int32]),
     "mrl_axpby": (_i32, [_vp, _dbl, _vp, _dbl, _vp, _vp, _i64]),
+    "mrl_axpy": (_i32, [_vp, _dbl, _vp, _vp, _i64]),
     "mrl_mech_newton_cg": (_i32, [_vp, C.POINTER(MrlMechParams), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(MrlMechStats)]),
     "mrl_mech_small_strain": (_i32, [_vp, C.POINTER(MrlMechParams), _vp, _vp, _vp, _vp, _vp, C.POINTER(MrlMechStats)]),
     "mrl_parsed_create": (_i32, [_vp, C.POINTER(_vp), C.c_char_p, _i32, C.POINTER(C.c_char_p), C.POINTER(_i32), _i32,
@@ -171,6 +183,7 @@ SIGNATURES = {
     "mrl_timer_stop": (_i32, [_vp, C.POINTER(C.c_float)]),
     "mrl_set_profiling": (_i32, [_vp, _i32]),
     "mrl_get_profile": (_i32, [_vp, _i32, C.POINTER(C.c_char_p), C.POINTER(_dbl), C.POINTER(_i64), C.POINTER(_dbl)]),
+    "mrl_get_timing": (_i32, [_vp, C.POINTER(MrlTiming)]),
 }
 
 _lib = None

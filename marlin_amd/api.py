@@ -579,6 +579,19 @@ class Context:
     def set_profiling(self, on: bool):
         self._check(self.lib.mrl_set_profiling(self.h, 1 if on else 0))
 
+    def get_timing(self) -> dict:
+        """mrl_get_timing: the profile summed over its kernel classes"""
+        from ._lib import MrlTiming
+        t = MrlTiming()
+        self._check(self.lib.mrl_get_timing(self.h, C.byref(t)))
+        return {"kernel_classes": t.kernel_classes, "launches": t.launches, "device_ms": t.device_ms,
+                "algorithmic_bytes": t.algorithmic_bytes, "dominant": t.dominant.decode() if t.dominant else None,
+                "dominant_ms": t.dominant_ms}
+
+    def axpy(self, a: float, x: torch.Tensor, y: torch.Tensor):
+        """y += a x (mrl_axpy)"""
+        self._check(self.lib.mrl_axpy(self.h, float(a), x.data_ptr(), y.data_ptr(), x.numel()))
+
     def get_profile(self):
         res = []
         slot = 0

@@ -733,4 +733,23 @@ int mrl_get_profile(mrl_ctx *ctx, int slot, const char **name, double *total_ms,
   return MRL_OK;
 }
 
+int mrl_get_timing(mrl_ctx *ctx, mrl_timing *out) {
+  if (!ctx || !out) return MRL_ERR_INVALID;
+  *out = mrl_timing{};
+  const int rc = mrl_get_profile(ctx, 0, nullptr, nullptr, nullptr, nullptr);  // folds the pending event pairs
+  if (rc != MRL_OK && !ctx->prof.empty()) return rc;
+  for (const auto &s : ctx->prof) {
+    if (s.launches <= 0) continue;
+    out->kernel_classes += 1;
+    out->launches += s.launches;
+    out->device_ms += s.ms;
+    out->algorithmic_bytes += s.bytes * (double)s.launches;
+    if (!out->dominant || s.ms > out->dominant_ms) {
+      out->dominant = s.name;
+      out->dominant_ms = s.ms;
+    }
+  }
+  return MRL_OK;
+}
+
 }  // extern "C"

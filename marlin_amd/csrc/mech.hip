@@ -498,6 +498,8 @@ int mrl_axpby(mrl_ctx *ctx, double a, const double *d_x, double b, const double 
   return MRL_OK;
 }
 
+int mrl_axpy(mrl_ctx *ctx, double a, const double *d_x, double *d_y, int64_t n) { return mrl_axpby(ctx, a, d_x, 1.0, d_y, d_y, n); }
+
 int mrl_mech_stress(mrl_ctx *ctx, const double *d_F, const double *d_K, const double *d_mu, double *d_P) {
   if (!ctx) return MRL_ERR_INVALID;
   MRL_TRY(check_dim(ctx, "mrl_mech_stress", false));

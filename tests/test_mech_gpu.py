@@ -257,3 +257,23 @@ def test_small_strain_linear_elastic_vs_oracle(n, closed):
     # the mean strain is the applied one (the CG correction has zero mean); sigma is symmetric
     assert (eps.mean(dim=(0, 1, 2)).cpu() - E).abs().max().item() <= 1e-13
     assert (sig - sig.transpose(-1, -2)).abs().max().item() <= 1e-12
+
+
+def test_axpy_and_timing_summary():
+    """mrl_axpy (y += a x: the vector update of conjugateGradientSolve) and mrl_get_timing (the profile summed over its kernel
+    classes) -- the two names of the survey's boundary table that round 4 served only as mrl_axpby / mrl_get_profile"""
+    from marlin_amd.api import Context
+    ctx = Context(3, [16, 16, 16], [1.0, 1.0, 1.0])
+    torch.manual_seed(0)
+    x = torch.rand(16, 16, 16, dtype=torch.float64, device="cuda")
+    y = torch.rand(16, 16, 16, dtype=torch.float64, device="cuda")
+    want = y + 0.375 * x
+    ctx.set_profiling(True)
+    ctx.axpy(0.375, x, y)
+    ctx.axpy(0.0, x, y)
+    assert torch.equal(y, want)
+    t = ctx.get_timing()
+    prof = [k for k in ctx.get_profile() if k["launches"]]
+    assert t["kernel_classes"] == len(prof) == 1 and t["launches"] == 2 and t["dominant"] == "axpby"
+    assert abs(t["device_ms"] - sum(k["ms"] for k in prof)) <= 1e-12 and t["algorithmic_bytes"] == 2 * 24.0 * x.numel()
+
