@@ -11,6 +11,7 @@
 #include "ch_xfused.h"
 #include "fft_pow2_wide.h"
 #include "fft_two.h"
+#include "fft_two_z.h"
 
 namespace mrl {
 
@@ -59,11 +60,12 @@ static Geo geo_of(const mrl_ctx *ctx) {
 
 // 400-point x axes: the fused x pass of the two-stage plan 20 x 20 (fft_two.h: k_ch_xfused2 with the re-read Nhat) instead of
 // k_ch_xfused<400> (10 x 10 x 2 x 2, 40 threads per line, tiles of 6 lines = 96-byte pieces: 3.5 TB/s; 735 -> 547 us at 400^3);
-// the reference's data flow only (no spectral carry-over); experiment bit 1 << 29 keeps the uniform kernel (A/B)
+// the reference's data flow only (no spectral carry-over); experiment bit 1 << 29 keeps the uniform kernel (A/B).  192-point x axes
+// likewise (12 x 16 instead of 12 x 4 x 4: 52.5 -> 50.0 us at 192^3)
 static bool x400_two_stage(const mrl_ctx *ctx, long long nx, int carry, double array_bytes) {
-  return nx == 400 && carry == MRL_CARRY_NONE && !(ctx->exp & (1 << 29)) && array_bytes < 4294967296.0;
+  return (nx == 400 || nx == 192) && carry == MRL_CARRY_NONE && !(ctx->exp & (1 << 29)) && array_bytes < 4294967296.0;
 }
-static int launch_x400(mrl_ctx *ctx, const p2::FusedArgs &f, int order, const cplx *tw) {
+static int launch_x400(mrl_ctx *ctx, const p2::FusedArgs &f, int order, const cplx *tw, bool nx_is_192) {
   p2::X2Args a{};
   a.chat = f.c.chat;
   a.muhat = f.c.muhat;
@@ -81,12 +83,13 @@ static int launch_x400(mrl_ctx *ctx, const p2::FusedArgs &f, int order, const cp
   a.kx = f.kx;
   a.ky = f.ky;
   a.kz = f.kz;
+  const bool n192 = nx_is_192;
   switch (order) {
-    case 0: return p2::launch_xfused2<400, 0>(ctx, a, tw);
-    case 1: return p2::launch_xfused2<400, 1>(ctx, a, tw);
-    case 2: return p2::launch_xfused2<400, 2>(ctx, a, tw);
-    case 3: return p2::launch_xfused2<400, 3>(ctx, a, tw);
-    default: return p2::launch_xfused2<400, 4>(ctx, a, tw);
+    case 0: return n192 ? p2::launch_xfused2<192, 0>(ctx, a, tw) : p2::launch_xfused2<400, 0>(ctx, a, tw);
+    case 1: return n192 ? p2::launch_xfused2<192, 1>(ctx, a, tw) : p2::launch_xfused2<400, 1>(ctx, a, tw);
+    case 2: return n192 ? p2::launch_xfused2<192, 2>(ctx, a, tw) : p2::launch_xfused2<400, 2>(ctx, a, tw);
+    case 3: return n192 ? p2::launch_xfused2<192, 3>(ctx, a, tw) : p2::launch_xfused2<400, 3>(ctx, a, tw);
+    default: return n192 ? p2::launch_xfused2<192, 4>(ctx, a, tw) : p2::launch_xfused2<400, 4>(ctx, a, tw);
   }
 }
 
@@ -335,7 +338,7 @@ int ch_substep_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c_
         default: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 4, true>(ctx, a, g.tw_x)))); break;
       }
     } else if (x400_two_stage(ctx, nx, carry, 16.0 * (double)nx * (double)plane)) {
-      MRL_TRY(launch_x400(ctx, a, order, g.tw_x));
+      MRL_TRY(launch_x400(ctx, a, order, g.tw_x, nx == 192));
     } else {
       switch (order) {
         case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0, false>(ctx, a, g.tw_x)))); break;
@@ -400,6 +403,13 @@ int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c
     ProfScope ps(ctx, "ch_EA_z_inv_fwd", (3.0 * h + (mu_k ? 8.0 * nreal : 0.0)) * (double)(x1 - x0) / (double)nx);
     if (cp.family == MRL_FE_PARSED) {
       MRL_TRY(parsed_z_inv_fwd_launch(ctx, cp.parsed, (int)nz, c, c, m, mk, scale, pairs, false, lpp, lpad));
+    } else if (nz == 192 && !(ctx->exp & (1 << 29))) {
+      // 192-point lines: the two-stage kernel 16 x 12 (fft_two_z.h) instead of k_z_inv_fwd<192> (12 x 4 x 4)
+      if (cp.family == MRL_FE_DOUBLE_WELL) {
+        MRL_TRY((p2::launch_z_inv_fwd2<192, MRL_FE_DOUBLE_WELL>(ctx, c, c, m, mk, chp, scale, pairs, g.zl)));
+      } else {
+        MRL_TRY((p2::launch_z_inv_fwd2<192, MRL_FE_PFHUB>(ctx, c, c, m, mk, chp, scale, pairs, g.zl)));
+      }
     } else if (cp.family == MRL_FE_DOUBLE_WELL) {
       MRL_SWITCH_N(nz, MRL_TRY((p2::launch_z_inv_fwd<NN, MRL_FE_DOUBLE_WELL>(ctx, c, c, m, mk, chp, scale, pairs, g.zl))));
     } else {
@@ -461,7 +471,7 @@ int ch_substeps_fused(mrl_ctx *ctx, const ChP &cp, const double *c_in, double *c
       a.c.kappa = cp.kappa;
       a.c.dt = sub_dt;
       if (x400_two_stage(ctx, nx, MRL_CARRY_NONE, 16.0 * (double)nx * (double)plane)) {
-        MRL_TRY(launch_x400(ctx, a, order, g.tw_x));
+        MRL_TRY(launch_x400(ctx, a, order, g.tw_x, nx == 192));
       } else {
         switch (order) {
           case 0: MRL_SWITCH_N(nx, MRL_TRY((p2::launch_xfused<NN, 0, false>(ctx, a, g.tw_x)))); break;

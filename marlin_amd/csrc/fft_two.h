@@ -44,12 +44,13 @@ MRL_PLAN2(160, 10, 16, 16)
 MRL_PLAN2(180, 12, 15, 16)
 MRL_PLAN2(240, 15, 16, 16)
 // 20 points per thread (80 registers per array): both fields of a y pass still fit one launch; the fused x pass keeps TWO arrays and
-// re-reads the Nhat it has just stored (k_ch_xfused2<REREAD>).  300 = 15 x 20, 320 = 16 x 20 replace 30- / 20-point uniform plans,
+// re-reads the Nhat it has just stored (k_ch_xfused2<REREAD>).  300 = 20 x 15, 320 = 20 x 16 replace 30- / 20-point uniform plans,
 // 400 = 20 x 20 the four-stage 10-point plan of the fused family (10 x 10 x 2 x 2, 40 threads per line, tiles of 6 lines = 96-byte
 // pieces: its fused x pass ran at 3.4 TB/s).  Tiles of 12 lines (192-byte pieces) where the LDS tile allows it, 8 at 400 points.
 MRL_PLAN2(300, 20, 15, 12)
 MRL_PLAN2(320, 20, 16, 12)
 MRL_PLAN2(400, 20, 20, 8)
+MRL_PLAN2(192, 12, 16, 16)   // (fused x pass of the fused family's 192-point grids: 52.5 -> 50.0 us at 192^3)
 // (200 = 20 x 10 was measured too: its fused x pass 67.4-68.3 us against 62.5-63.6 us of the uniform 10-point plan at 200^3 -- ten of
 // twenty lanes idle on the pattern-A side, which carries three of the five streams; not instantiated)
 #undef MRL_PLAN2
@@ -58,7 +59,7 @@ MRL_PLAN2(400, 20, 20, 8)
 constexpr bool two_stage_len(long long n) { return n == 120 || n == 150 || n == 160 || n == 180 || n == 240 || n == 300 || n == 320; }
 // ... and whose fused x pass does: 400 = 20 x 20 keeps the uniform 10-point plan of the fused family for its y and z passes (measured
 // faster there: 402 / 354 us against 476 / 381 us at 400^3) and takes only this kernel (735 -> 547 us)
-constexpr bool two_stage_x_len(long long n) { return two_stage_len(n) || n == 400; }
+constexpr bool two_stage_x_len(long long n) { return two_stage_len(n) || n == 400; }   // (192: ch_fused.hip only)
 
 // what a thread holds in a pattern: CNT points q + STRIDE t, and whether thread q holds anything
 template <int N, bool PATTERN_B>

@@ -34,6 +34,7 @@ MRL_ZPLAN2(150, 10, 15, 8)
 MRL_ZPLAN2(160, 16, 10, 8)
 MRL_ZPLAN2(180, 12, 15, 8)
 MRL_ZPLAN2(240, 16, 15, 8)
+MRL_ZPLAN2(192, 16, 12, 8)   // (the fused inverse + forward z pass of the fused family's 192-point grids, ch_fused.hip)
 // 20 points per thread on the real side, 20 threads per line (fft_two.h); 12 lines per workgroup = 240 threads (8 lines = 2.5 waves:
 // fused z pass 177 -> 156 us at 300^3; 320 with the 20 on the spectral side instead: 208 -> 175 us at 320^3); 16 lines at 240 points: level
 MRL_ZPLAN2(300, 20, 15, 12)

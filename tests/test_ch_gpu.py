@@ -87,6 +87,7 @@ def test_ch_gold_file_3d():
                                    (240, 120, 32), (150, 180, 32), (160, 160), (120, 240), (180, 150, 40),         # ... two-stage plans on x and y (fft_two.h)
                                    (32, 40, 150), (40, 32, 180), (32, 32, 120), (48, 240, 160),                       # ... and on z (fft_two_z.h)
                                    (400, 40, 32), (32, 400, 40), (40, 32, 400), (300, 320), (320, 32, 300), (32, 300, 320),   # ... 20 points per thread
+                                   (192, 32, 192), (192, 192),                                                         # ... fused family, two-stage x / z kernels
                                    (288, 64), (72, 216), (576, 64), (800, 32), (48, 432), (864, 1152)])            # ... further plain plans
 def test_ch_vs_oracle(shape):
     from marlin_amd.api import Context, ch_params
@@ -278,7 +279,8 @@ def test_ch_fused_fast_path_outputs(shape):
 @pytest.mark.parametrize("shape,pred", [((64, 64, 64), 2), ((128, 64, 96), 3), ((100, 40, 50), 2), ((12, 10, 9), 2), ((64, 128), 2),
                                         ((160, 48, 240), 3), ((120, 150), 2), ((64, 180, 120), 2), ((240, 32, 160), 2), ((60, 40, 180), 4),
                                         ((400, 32, 400), 3), ((320, 40, 300), 2), ((32, 300, 320), 5),   # two-stage z plans
-                                        ((240, 32, 128), 2), ((120, 150, 64), 3), ((60, 90, 100), 2)])    # planned x / y, fused-family z
+                                        ((240, 32, 128), 2), ((120, 150, 64), 3), ((60, 90, 100), 2),    # planned x / y, fused-family z
+                                        ((192, 48, 192), 3)])                                              # fused family with two-stage x / z kernels
 def test_ch_multi_substep_call(shape, pred):
     """mrl_ch_substeps (the substep loop of TensorSolver::computeBuffer in one call; on planned shapes the inverse z pass of a
     substep is fused with the forward z pass of the next one) == the same substeps one call at a time, bit for bit on the fused

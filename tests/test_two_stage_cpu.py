@@ -42,7 +42,7 @@ def test_index_scheme_of_every_two_stage_plan():
     rng = np.random.default_rng(0)
     strided = _plans(_read("fft_two.h"), "MRL_PLAN2")
     zplans = _plans(_read("fft_two_z.h"), "MRL_ZPLAN2")
-    assert set(strided) == {120, 150, 160, 180, 240, 300, 320, 400} and set(zplans) == {120, 150, 160, 180, 240, 300, 320}
+    assert set(strided) == {120, 150, 160, 180, 240, 300, 320, 400, 192} and set(zplans) == {120, 150, 160, 180, 240, 300, 320, 192}
     for plans, staged in ((strided, False), (zplans, True)):
         for n, (r0, r1, _) in plans.items():
             assert r0 * r1 == n and max(r0, r1) <= 20
@@ -89,8 +89,10 @@ def test_plan_tables_and_dispatch_lists_agree():
     zplans = _plans(twoz, "MRL_ZPLAN2")
     listed = lambda text, fn: {int(v) for v in re.findall(r"n == (\d+)", text[text.index(fn):].split("}")[0])}
     lens = listed(two, "constexpr bool two_stage_len")
-    assert lens == set(zplans) == listed(twoz, "constexpr bool two_stage_z_len")          # passes and z kernels: the same lengths
-    assert set(strided) == lens | {400}                                                    # 400: the fused x pass only
+    # passes and z kernels: the same lengths; 400 (x pass) and 192 (x pass, fused z pass) are fused-family lengths that ch_fused.hip
+    # serves with single two-stage kernels
+    assert lens == set(zplans) - {192} == listed(twoz, "constexpr bool two_stage_z_len")
+    assert set(strided) == lens | {400, 192}
     assert "two_stage_len(n) || n == 400" in two
     sw = planned[planned.index("#define MRL_SWITCH_N2(n, CALL)"):planned.index("#define MRL_SWITCH_N2X")]
     assert {int(v) for v in re.findall(r"case (\d+):", sw)} == lens                         # run-time length -> template (ch_planned.hip)
