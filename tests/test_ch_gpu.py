@@ -143,7 +143,7 @@ def test_two_stage_plans_deep_histories_and_outputs(shape, pred):
     assert (got["two_stage"] - got["uniform"]).abs().max().item() <= 1e-14
 
 
-@pytest.mark.parametrize("shape", [(240, 32, 120), (300, 40, 32), (160, 150), (400, 32, 32)])
+@pytest.mark.parametrize("shape", [(240, 32, 120), (300, 40, 32), (160, 150), (400, 32, 32), (192, 32, 192)])
 def test_two_stage_plans_cbar_and_history_outputs(shape):
     """the optional outputs of a substep on the two-stage kernels (k_ch_xfused2: cbar = c-hat of the substep, Nhat = the history
     entry; k_z_fwd2: mu) against the oracle's op sequence, AB1 and AB2"""
